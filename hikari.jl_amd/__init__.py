@@ -1,0 +1,19 @@
+"""hikari.jl_amd — MI355X-native VolPath hot path of JuliaGraphics/Hikari.jl behind a C-ABI.
+
+The package holds only what the path needs: `csrc/` (HIP kernels + the C-ABI library) and this host-side
+mirror of the reference's Integrator / Scene / Material / Film interface for the path.  The directory name
+contains a dot, so import it through the `hikari_jl_amd` shim at the repository root.
+"""
+from . import _abi, geometry, tables
+from ._lib import HikariMI355XError, LIB_PATH
+from .camera import PerspectiveCamera
+from .film import Film
+from .lights import (AmbientLight, DiffuseAreaLight, DirectionalLight, PointLight, RGBIlluminantSpectrum, SpotLight,
+                     SunLight)
+from .materials import (CoatedConductorMaterial, CoatedDiffuseMaterial, CoatedDiffuseTransmissionMaterial,
+                        ConductorMaterial, DiffuseTransmissionMaterial, Emissive, GlassMaterial, MatteMaterial,
+                        MediumInterface, MirrorMaterial, MixMaterial, PiecewiseLinearSpectrum, PlasticMaterial,
+                        RGBSpectrum, Texture, ThinDielectricMaterial)
+from .scene import Scene
+from .volpath import (BoxFilter, Context, GaussianFilter, LanczosSincFilter, MitchellFilter, TriangleFilter, VolPath,
+                      integrator_params, scene_handle)

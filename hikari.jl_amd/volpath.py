@@ -1,0 +1,185 @@
+"""VolPath integrator — host-side mirror of `Hikari.VolPath` (src/integrators/volpath/volpath.jl:29-113,
+445-670) whose per-ray work runs in the HIP library behind the C-ABI (include/hikari_mi355x.h).
+
+    vp = VolPath(max_depth=8, samples=64)      # same keywords / defaults as volpath.jl:75-84
+    vp(scene, film, camera)                    # full render: reset, `samples` x render!, return film
+    vp.render(scene, film, camera)             # render!: ONE more sample on top of the accumulators
+    vp.clear(); vp.close()
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi as A
+from . import _lib
+from . import tables
+
+
+class GaussianFilter:
+    def __init__(self, radius=(1.5, 1.5), sigma=0.5):
+        self.type, self.radius, self.p1, self.p2 = A.HK_FILTER_GAUSSIAN, radius, sigma, 0.0
+
+
+class BoxFilter:
+    def __init__(self, radius=(0.5, 0.5)):
+        self.type, self.radius, self.p1, self.p2 = A.HK_FILTER_BOX, radius, 0.0, 0.0
+
+
+class TriangleFilter:
+    def __init__(self, radius=(2.0, 2.0)):
+        self.type, self.radius, self.p1, self.p2 = A.HK_FILTER_TRIANGLE, radius, 0.0, 0.0
+
+
+class MitchellFilter:
+    def __init__(self, radius=(2.0, 2.0), B=1.0 / 3.0, C=1.0 / 3.0):
+        self.type, self.radius, self.p1, self.p2 = A.HK_FILTER_MITCHELL, radius, B, C
+
+
+class LanczosSincFilter:
+    def __init__(self, radius=(4.0, 4.0), tau=3.0):
+        self.type, self.radius, self.p1, self.p2 = A.HK_FILTER_LANCZOS, radius, tau, 0.0
+
+
+def integrator_params(max_depth=8, samples=64, russian_roulette_depth=3, regularize=True, material_coherence="none",
+                      max_component_value=10.0, filter=None, accumulation_eltype="Float32", sampler_seed=0,
+                      samples_per_pass=0):
+    if material_coherence not in ("none", "sorted", "per_type"):
+        raise AssertionError("material_coherence must be :none, :sorted, :per_type")  # volpath.jl:85
+    if accumulation_eltype not in ("Float32", "Float64"):
+        raise AssertionError("accumulation_eltype must be Float32 or Float64")  # volpath.jl:86
+    f = filter if filter is not None else GaussianFilter()
+    p = A.hk_integrator_params()
+    p.max_depth, p.samples_per_pixel, p.russian_roulette_depth = int(max_depth), int(samples), int(russian_roulette_depth)
+    p.regularize = 1 if regularize else 0
+    p.material_coherence = ("none", "sorted", "per_type").index(material_coherence)
+    p.max_component_value = float(max_component_value)
+    p.filter_type = f.type
+    p.filter_radius[:] = [float(f.radius[0]), float(f.radius[1])]
+    p.filter_param1, p.filter_param2 = float(f.p1), float(f.p2)
+    p.accumulate_f64 = 1 if accumulation_eltype == "Float64" else 0
+    p.sampler_seed = int(sampler_seed)
+    p.samples_per_pass = int(samples_per_pass)
+    return p
+
+
+class Context:
+    """One hk_ctx per GPU (tables uploaded once)."""
+    _by_device = {}
+
+    def __init__(self, device=0, stream=0):
+        L = _lib.lib()
+        self.h = C.c_void_p()
+        _lib.check(L.hk_ctx_create(int(device), C.c_void_p(stream), C.byref(self.h)), "hk_ctx_create")
+        t = tables.load()
+        _lib.check(L.hk_ctx_set_tables(self.h, C.byref(t["struct"])), "hk_ctx_set_tables")
+        self.device = device
+
+    @classmethod
+    def get(cls, device=0):
+        if device not in cls._by_device:
+            cls._by_device[device] = Context(device)
+        return cls._by_device[device]
+
+
+def scene_handle(ctx, scene):
+    d = scene.desc
+    dev = getattr(scene, "_device", None)
+    if dev is None:
+        dev = scene._device = {}
+    if id(ctx) not in dev:
+        h = C.c_void_p()
+        _lib.check(_lib.lib().hk_scene_create(ctx.h, C.byref(d), C.byref(h)), "hk_scene_create")
+        dev[id(ctx)] = h
+    return dev[id(ctx)]
+
+
+class VolPath:
+    def __init__(self, max_depth=8, samples=64, russian_roulette_depth=3, regularize=True, material_coherence="none",
+                 max_component_value=10.0, filter=None, accumulation_eltype="Float32", device=0, samples_per_pass=0):
+        self.params = integrator_params(max_depth, samples, russian_roulette_depth, regularize, material_coherence,
+                                        max_component_value, filter, accumulation_eltype, 0, samples_per_pass)
+        self.samples_per_pixel = int(samples)
+        self.max_depth = int(max_depth)
+        self.device = device
+        self._ctx = None
+        self._integ = None
+        self._film = None      # (hk_film handle, w, h)
+        self._external_accum = None
+
+    # -- lazily created device state (the reference's `vp.state`, volpath.jl:463-482) --
+    def _ensure(self, film):
+        L = _lib.lib()
+        if self._ctx is None:
+            self._ctx = Context.get(self.device)
+        if self._integ is None:
+            self._integ = C.c_void_p()
+            _lib.check(L.hk_integrator_create(self._ctx.h, C.byref(self.params), C.byref(self._integ)), "hk_integrator_create")
+        if self._film is None or self._film[1:] != (film.width, film.height):
+            if self._film is not None:
+                L.hk_film_destroy(self._film[0])
+            h = C.c_void_p()
+            ext = C.c_void_p(self._external_accum) if self._external_accum else None
+            _lib.check(L.hk_film_create(self._ctx.h, film.width, film.height, self.params.accumulate_f64, ext, C.byref(h)), "hk_film_create")
+            self._film = (h, film.width, film.height)
+
+    def use_external_accumulators(self, device_ptr):
+        """Accumulate into caller-owned device memory (a torch tensor the host reduces with torch.distributed)."""
+        self._external_accum = int(device_ptr)
+        self._film = None
+
+    def clear(self):
+        if self._film is not None:
+            _lib.check(_lib.lib().hk_film_clear(self._film[0]), "hk_film_clear")
+
+    def render_samples(self, scene, film, camera, n_samples, stride=1, first=None, readback=True):
+        """Render `n_samples` more samples (sample indices first, first+stride, ...)."""
+        self._ensure(film)
+        L = _lib.lib()
+        sh = scene_handle(self._ctx, scene)
+        cam = camera.record()
+        if first is None:
+            first = film.iteration_index + 1
+        _lib.check(L.hk_render(self._ctx.h, sh, self._integ, self._film[0], C.byref(cam), int(first), int(n_samples), int(stride)), "hk_render")
+        film.iteration_index = first + (n_samples - 1) * stride
+        if readback:
+            self.read_framebuffer(film)
+
+    def render(self, scene, film, camera):
+        """render!(vp, scene, film, camera): one sample, progressive (volpath.jl:445-450)."""
+        self.render_samples(scene, film, camera, 1)
+
+    def read_framebuffer(self, film):
+        out = np.empty((film.width, film.height, 3), dtype=np.float32)  # Julia [h,w] column-major == C [w][h]
+        _lib.check(_lib.lib().hk_film_read_rgb(self._ctx.h, self._film[0], out.ctypes.data_as(A.PF)), "hk_film_read_rgb")
+        film.framebuffer[...] = np.transpose(out, (1, 0, 2))
+
+    def read_accumulators(self, film):
+        n = film.width * film.height
+        dt = np.float64 if self.params.accumulate_f64 else np.float32
+        out = np.empty(4 * n, dtype=dt)
+        _lib.check(_lib.lib().hk_film_read_accum(self._ctx.h, self._film[0], out.ctypes.data_as(C.c_void_p)), "hk_film_read_accum")
+        return out
+
+    def __call__(self, scene, film, camera):
+        film.iteration_index = 0
+        self._ensure(film)
+        self.clear()
+        self.render_samples(scene, film, camera, self.samples_per_pixel)
+        return film
+
+    def stats(self):
+        s = A.hk_stats()
+        _lib.check(_lib.lib().hk_stats_get(self._ctx.h, C.byref(s)), "hk_stats_get")
+        return s
+
+    def sync(self):
+        _lib.check(_lib.lib().hk_sync(self._ctx.h), "hk_sync")
+
+    def close(self):
+        L = _lib.lib()
+        if self._film is not None:
+            L.hk_film_destroy(self._film[0])
+            self._film = None
+        if self._integ is not None:
+            L.hk_integrator_destroy(self._integ)
+            self._integ = None

@@ -1,0 +1,1061 @@
+// hko_render.cpp — CPU ORACLE (test infrastructure; NOT part of the product, never a fallback).
+//
+// Restatement of Hikari.jl's VolPath wavefront path for checking the HIP implementation:
+//   render! (one sample)                 src/integrators/volpath/volpath.jl:445-636
+//   K1  vp_generate_camera_rays_kernel!  src/integrators/volpath/volpath.jl:125-205
+//   K2  vp_generate_ray_samples_kernel!  src/integrators/volpath/volpath.jl:222-271
+//   K3  vp_trace_rays_kernel!            src/integrators/volpath/intersection.jl:188-269
+//   K7  vp_handle_escaped_rays_kernel!   src/integrators/volpath/intersection.jl:622-678
+//   K8  vp_process_surface_hits_kernel!  src/integrators/volpath/surface-eval.jl:147-220
+//   K9  surface_direct_lighting_inner!   src/integrators/volpath/surface-eval.jl:250-341
+//   K10 vp_trace_shadow_rays_kernel!     src/integrators/volpath/intersection.jl:302-406, 565-600
+//   K11 evaluate_material_inner!         src/integrators/volpath/surface-eval.jl:396-512
+//   K12 vp_accumulate_to_rgb_kernel!     src/integrators/volpath/volpath.jl:326-375
+//   K13 vp_finalize_film_kernel!         src/integrators/volpath/volpath.jl:384-417
+// The stage order inside a bounce is the reference's; each stage is an OpenMP loop over its queue
+// (one item per pixel per queue, so the order inside a stage cannot change any result).
+//
+// Parity status: "parity unpinned" at the Raycore boundary (see hko_accel.h) — the reference cannot
+// be executed here (Julia absent) and its tests pin no radiance values; the pieces that
+// have known answers (hashes, PCG32, Sobol, filter, Fresnel, uplift identities) are pinned by
+// tests/test_oracle_kat.py.
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "hikari_mi355x.h"
+#include "hko_bsdf.h"
+#include "hko_filter_camera.h"
+#include "hko_media.h"
+
+#if defined(_OPENMP)
+#include <omp.h>
+#endif
+
+namespace hko {
+
+struct SetKeyM {  // medium index: -1 = vacuum (has_medium = valid)
+    int32_t idx = -1;
+};
+
+struct RayItem {  // VPRayWorkItem  workitems.jl:14-41
+    V3 o, d;
+    float t_max, time;
+    int32_t depth;
+    Wavelengths lambda;
+    int32_t pixel_index;  // 1-based
+    Spec beta, r_u, r_l;
+    float eta_scale;
+    bool specular_bounce, any_non_specular;
+    int32_t medium;
+};
+struct SurfaceGeom {
+    V3 pi, n, dpdu, dpdv, ns, dpdus, dpdvs;
+    V2 uv;
+};
+struct HitItem {  // VPHitSurfaceWorkItem
+    V3 ray_o, ray_d;
+    float ray_time;
+    SurfaceGeom g;
+    int32_t material;
+    hk_medium_interface iface;
+    uint32_t face_idx;
+    float bary[3];
+    uint32_t arealight;
+    float triangle_area;
+    Wavelengths lambda;
+    int32_t pixel_index;
+    Spec beta, r_u, r_l;
+    int32_t depth;
+    float eta_scale;
+    bool specular_bounce, any_non_specular;
+    int32_t current_medium;
+    float t_hit;
+};
+struct MatItem {  // VPMaterialEvalWorkItem
+    SurfaceGeom g;
+    V3 wo;
+    int32_t material;
+    hk_medium_interface iface;
+    Wavelengths lambda;
+    int32_t pixel_index;
+    Spec beta, r_u, r_l;
+    int32_t depth;
+    float eta_scale;
+    bool specular_bounce, any_non_specular;
+    int32_t current_medium;
+};
+struct ShadowItem {  // VPShadowRayWorkItem
+    V3 o, d;
+    float t_max;
+    Wavelengths lambda;
+    Spec Ld, r_u, r_l;
+    int32_t pixel_index;
+    int32_t medium;
+};
+struct EscapedItem {
+    V3 d;
+    Wavelengths lambda;
+    int32_t pixel_index;
+    Spec beta, r_u, r_l;
+    int32_t depth;
+    bool specular_bounce;
+};
+
+struct Scene {
+    hk_scene_desc desc;
+    Accel accel;
+    LightSampler sampler;
+    RGB2SpecTable table;
+    CIETable cie;
+    const uint32_t* sobol;
+    MaterialCtx mctx;
+    TextureSet textures;
+    MediaCtx media;
+    bool any_infinite_or_env = false;
+};
+
+struct Counters {
+    uint64_t rays_closest = 0, rays_shadow = 0, nodes = 0, tris = 0, hits = 0, vertices = 0, collisions = 0;
+};
+
+// ---- geometry at a hit (intersection.jl:13-182) -------------------------------------------------
+static inline void tri_vertices(const Scene& sc, int32_t prim, V3& v0, V3& v1, V3& v2) {
+    const float* p = sc.desc.positions + 9 * (size_t)prim;
+    v0 = V3(p[0], p[1], p[2]);
+    v1 = V3(p[3], p[4], p[5]);
+    v2 = V3(p[6], p[7], p[8]);
+}
+static inline V3 geometric_normal(const Scene& sc, int32_t prim) {
+    V3 v0, v1, v2;
+    tri_vertices(sc, prim, v0, v1, v2);
+    return normalize(cross(v1 - v0, v2 - v0));
+}
+static inline void tri_uvs(const Scene& sc, int32_t prim, V2& a, V2& b, V2& c) {
+    if (sc.desc.uvs) {
+        const float* q = sc.desc.uvs + 6 * (size_t)prim;
+        a = V2(q[0], q[1]);
+        b = V2(q[2], q[3]);
+        c = V2(q[4], q[5]);
+    } else {
+        a = V2(0, 0);
+        b = V2(1, 0);
+        c = V2(1, 1);
+    }
+}
+static inline V2 uv_barycentric(const Scene& sc, int32_t prim, const float bary[3]) {
+    V2 a, b, c;
+    tri_uvs(sc, prim, a, b, c);
+    float w = bary[0], u = bary[1], v = bary[2];
+    return V2(w * a.x + u * b.x + v * c.x, w * a.y + u * b.y + v * c.y);
+}
+static inline float triangle_area(const Scene& sc, int32_t prim) {
+    V3 v0, v1, v2;
+    tri_vertices(sc, prim, v0, v1, v2);
+    return 0.5f * norm(cross(v1 - v0, v2 - v0));
+}
+static SurfaceGeom surface_geometry(const Scene& sc, int32_t prim, const float bary[3], V3 ro, V3 rd, float t_hit) {
+    SurfaceGeom g;
+    g.pi = ro + rd * t_hit;
+    V3 v0, v1, v2;
+    tri_vertices(sc, prim, v0, v1, v2);
+    V3 n = normalize(cross(v1 - v0, v2 - v0));
+    g.uv = uv_barycentric(sc, prim, bary);
+    // partial derivatives
+    V2 uv0, uv1, uv2;
+    tri_uvs(sc, prim, uv0, uv1, uv2);
+    float du10 = uv1.x - uv0.x, dv10 = uv1.y - uv0.y, du20 = uv2.x - uv0.x, dv20 = uv2.y - uv0.y;
+    V3 dp10 = v1 - v0, dp20 = v2 - v0;
+    float det = du10 * dv20 - dv10 * du20;
+    if (std::fabs(det) < 1e-8f) {
+        V3 e1 = normalize(dp10);
+        V3 nn = normalize(cross(dp10, dp20));
+        g.dpdu = e1;
+        g.dpdv = cross(nn, e1);
+    } else {
+        float inv_det = 1.0f / det;
+        g.dpdu = (dv20 * dp10 - dv10 * dp20) * inv_det;
+        g.dpdv = (-du20 * dp10 + du10 * dp20) * inv_det;
+    }
+    // shading normal
+    V3 ns = n;
+    bool has_normals = false;
+    V3 n0, n1, n2;
+    if (sc.desc.normals) {
+        const float* q = sc.desc.normals + 9 * (size_t)prim;
+        n0 = V3(q[0], q[1], q[2]);
+        n1 = V3(q[3], q[4], q[5]);
+        n2 = V3(q[6], q[7], q[8]);
+        has_normals = !(std::isnan(n0.x) || std::isnan(n1.x) || std::isnan(n2.x));
+    }
+    float w = bary[0], u = bary[1], v = bary[2];
+    if (has_normals) ns = normalize(V3(w * n0.x + u * n1.x + v * n2.x, w * n0.y + u * n1.y + v * n2.y, w * n0.z + u * n1.z + v * n2.z));
+    n = dot(n, ns) < 0.0f ? -n : n;
+    g.n = n;
+    g.ns = ns;
+    // shading tangents
+    bool has_tangents = false;
+    V3 t0, t1, t2;
+    if (sc.desc.tangents) {
+        const float* q = sc.desc.tangents + 9 * (size_t)prim;
+        t0 = V3(q[0], q[1], q[2]);
+        t1 = V3(q[3], q[4], q[5]);
+        t2 = V3(q[6], q[7], q[8]);
+        has_tangents = !std::isnan(t0.x) && !std::isnan(t1.x) && !std::isnan(t2.x);
+    }
+    V3 dpdus;
+    if (has_tangents) {
+        dpdus = normalize(V3(w * t0.x + u * t1.x + v * t2.x, w * t0.y + u * t1.y + v * t2.y, w * t0.z + u * t1.z + v * t2.z));
+    } else {
+        dpdus = g.dpdu - ns * dot(ns, g.dpdu);
+        float len_sq = dot(dpdus, dpdus);
+        if (len_sq > 1e-10f)
+            dpdus = dpdus / std::sqrt(len_sq);
+        else if (std::fabs(ns.x) > std::fabs(ns.y))
+            dpdus = V3(-ns.z, 0.0f, ns.x) / std::sqrt(ns.x * ns.x + ns.z * ns.z);
+        else
+            dpdus = V3(0.0f, ns.z, -ns.y) / std::sqrt(ns.y * ns.y + ns.z * ns.z);
+    }
+    g.dpdus = dpdus;
+    g.dpdvs = cross(ns, dpdus);
+    return g;
+}
+
+static inline bool is_medium_transition(const hk_medium_interface& mi) { return mi.inside != mi.outside; }
+static inline int32_t get_medium_index(const hk_medium_interface& mi, V3 wi, V3 n) { return dot(wi, n) > 0.0f ? mi.outside : mi.inside; }
+
+// ---- shadow transmittance (intersection.jl:302-406) ----------------------------------------------
+static bool trace_shadow_transmittance(const Scene& sc, V3 origin, V3 dir, float t_max, const Wavelengths& lambda, int32_t medium_idx, Spec& T_ray, Spec& r_u,
+                                       Spec& r_l, Counters& cnt) {
+    T_ray = Spec(1.0f);
+    r_u = Spec(1.0f);
+    r_l = Spec(1.0f);
+    int32_t current_medium = medium_idx;
+    V3 ray_o = origin;
+    float t_remaining = t_max;
+    for (int it = 0; it < 10; ++it) {
+        if (t_remaining < 1e-6f) break;
+        cnt.rays_shadow++;
+        Hit h = sc.accel.closest_hit(ray_o, dir, t_remaining, &cnt.nodes, &cnt.tris);
+        if (!h.hit) {
+            if (current_medium >= 0) {
+                Spec sT, su, sl;
+                transmittance_ratio_tracking(sc.media, current_medium, ray_o, dir, t_remaining, lambda, sT, su, sl, cnt.collisions);
+                T_ray = T_ray * sT;
+                r_u = r_u * su;
+                r_l = r_l * sl;
+            }
+            return true;
+        }
+        cnt.hits++;
+        const hk_tri_meta& meta = sc.desc.meta[h.prim];
+        const hk_medium_interface& mi = sc.desc.media_interfaces[meta.medium_interface_idx];
+        V3 n = geometric_normal(sc, h.prim);
+        bool entering = dot(dir, n) < 0.0f;
+        if (!is_medium_transition(mi)) {
+            float bary[3] = {1.0f - h.u - h.v, h.u, h.v};
+            V2 uv = uv_barycentric(sc, h.prim, bary);
+            float alpha = surface_alpha(sc.mctx, mi.material, uv);
+            if (alpha < 1.0f) {
+                PCG32 rng = pcg32_init(pbrt_hash(ray_o), pbrt_hash(dir));
+                float au = pcg32_uniform_f32(rng);
+                if (au > alpha) {
+                    if (current_medium >= 0) {
+                        Spec sT, su, sl;
+                        transmittance_ratio_tracking(sc.media, current_medium, ray_o, dir, h.t, lambda, sT, su, sl, cnt.collisions);
+                        T_ray = T_ray * sT;
+                        r_u = r_u * su;
+                        r_l = r_l * sl;
+                    }
+                    ray_o = ray_o + dir * (h.t + 1e-4f);
+                    t_remaining = t_remaining - h.t - 1e-4f;
+                    continue;
+                }
+            }
+            T_ray = Spec(0.0f);
+            r_u = Spec(1.0f);
+            r_l = Spec(1.0f);
+            return false;
+        }
+        if (current_medium >= 0) {
+            Spec sT, su, sl;
+            transmittance_ratio_tracking(sc.media, current_medium, ray_o, dir, h.t, lambda, sT, su, sl, cnt.collisions);
+            T_ray = T_ray * sT;
+            r_u = r_u * su;
+            r_l = r_l * sl;
+        }
+        if (is_black(T_ray)) return true;
+        current_medium = entering ? mi.inside : mi.outside;
+        ray_o = ray_o + dir * (h.t + 1e-4f);
+        t_remaining = t_remaining - h.t - 1e-4f;
+    }
+    T_ray = Spec(0.0f);
+    r_u = Spec(1.0f);
+    r_l = Spec(1.0f);
+    return false;
+}
+
+// ---- camera medium detection (intersection.jl:690-747) -----------------------------------------
+static int32_t detect_camera_medium(const Scene& sc, V3 camera_pos, Counters& cnt) {
+    V3 d(0.57735027f, 0.57735027f, 0.57735027f);
+    V3 o = camera_pos;
+    for (int it = 0; it < 16; ++it) {
+        cnt.rays_closest++;
+        Hit h = sc.accel.closest_hit(o, d, INF_F, &cnt.nodes, &cnt.tris);
+        if (!h.hit) return -1;
+        const hk_medium_interface& mi = sc.desc.media_interfaces[sc.desc.meta[h.prim].medium_interface_idx];
+        V3 n = geometric_normal(sc, h.prim);
+        if (is_medium_transition(mi)) return get_medium_index(mi, -d, n);
+        V3 pi = o + d * h.t;
+        V3 off = dot(d, n) > 0.0f ? n : -n;
+        o = pi + off * 1e-4f;
+    }
+    return -1;
+}
+
+
+struct MediumSampleItem {  // VPMediumSampleWorkItem (workitems.jl) — filled by K3 for rays inside a medium
+    V3 o, d;
+    float time, t_max;
+    int32_t depth;
+    Wavelengths lambda;
+    int32_t pixel_index;
+    Spec beta, r_u, r_l;
+    float eta_scale;
+    bool specular_bounce, any_non_specular;
+    int32_t medium;
+    bool has_surface_hit, hit_valid;
+    HitItem* hit_store;
+};
+
+// evaluate_escaped_ray_spectral  physical-wavefront/lights.jl:408-443 (sum over every light, flat order)
+static Spec evaluate_escaped(const Scene& sc, V3 ray_d, const Wavelengths& lambda) {
+    Spec sum(0.0f);
+    for (int32_t i = 0; i < sc.desc.n_lights; ++i) {
+        const hk_light& l = sc.desc.lights[i];
+        if (l.kind == HK_LIGHT_AMBIENT)
+            sum = sum + l.scale * light_spectrum(sc.table, l, lambda);
+        else
+            sum = sum + Spec(0.0f);
+    }
+    (void)ray_d;
+    return sum;
+}
+// compute_env_light_pdf  physical-wavefront/lights.jl:445-467 (only EnvironmentLight contributes)
+static float env_light_pdf(const Scene& sc, V3 ray_d) {
+    (void)sc;
+    (void)ray_d;
+    return 0.0f;
+}
+static LightSample sample_light_full(const Scene& sc, int32_t light_idx_1based, V3 p, const Wavelengths& lambda, V2 u) {
+    return sample_light_spectral(sc.table, sc.textures, sc.desc.lights[light_idx_1based - 1], p, lambda, u);
+}
+
+struct RenderState {
+    int32_t width, height;
+    std::vector<float> pixel_L;       // 4N
+    std::vector<float> lambda, pdf;   // 4N
+    std::vector<float> filter_w;      // N
+    std::vector<float> s_direct_uc, s_indirect_uc, s_rr;  // N
+    std::vector<V2> s_direct_u, s_indirect_u;             // N
+};
+
+
+// K4-K6 (delta-tracking.jl:79-471, medium-scatter.jl:15-247): lands with the media widening.
+static void process_media_stage(const Scene&, RenderState&, std::vector<RayItem>&, std::vector<uint8_t>&, std::vector<MediumSampleItem>&, std::vector<HitItem>&,
+                                std::vector<EscapedItem>&, std::vector<RayItem>&, std::vector<ShadowItem>&, const hk_integrator_params&, std::vector<Counters>&,
+                                int32_t) {}
+
+static void render_one_sample(const Scene& sc, const hk_integrator_params& ip, const FilterParams& fp, const FilterSampler& fs, const hk_camera& cam,
+                              const SobolRNG& rng, RenderState& st, int32_t sample_idx, double* pixel_rgb, double* pixel_w, bool f64, float* rgb32, float* w32,
+                              Counters& cnt_total) {
+    const int32_t W = st.width, H = st.height, N = W * H;
+    int nthreads = 1;
+#if defined(_OPENMP)
+    nthreads = omp_get_max_threads();
+#endif
+    std::vector<Counters> cnts(nthreads);
+    auto tid = []() {
+#if defined(_OPENMP)
+        return omp_get_thread_num();
+#else
+        return 0;
+#endif
+    };
+    // initial medium
+    V3 cam_pos = xform_point(cam.camera_to_world, V3(0.0f));
+    int32_t initial_medium = detect_camera_medium(sc, cam_pos, cnts[0]);
+    std::fill(st.pixel_L.begin(), st.pixel_L.end(), 0.0f);
+
+    // ---- K1 ----
+    std::vector<RayItem> rays(N);
+    std::vector<uint8_t> valid(N, 0);
+#pragma omp parallel for schedule(static)
+    for (int32_t idx = 1; idx <= N; ++idx) {
+        int32_t pixel_idx = idx - 1;
+        int32_t x = pixel_idx % W + 1, y = pixel_idx / W + 1;
+        float wavelength_u = sample_1d(rng, x, y, sample_idx, 1);
+        V2 jit = sample_2d(rng, x, y, sample_idx, 3);
+        float time_u = sample_1d(rng, x, y, sample_idx, 4);
+        V2 lens = sample_2d(rng, x, y, sample_idx, 6);
+        FilterSample f = filter_sample(fp, fs, jit);
+        st.filter_w[pixel_idx] = f.weight;
+        Wavelengths lam = sample_wavelengths_visible(wavelength_u);
+        for (int k = 0; k < 4; ++k) {
+            st.lambda[4 * pixel_idx + k] = lam.lambda[k];
+            st.pdf[4 * pixel_idx + k] = lam.pdf[k];
+        }
+        V2 p_film((float)x + 0.5f + f.px, (float)H - (float)y + 1.0f + 0.5f + f.py);
+        CamRay cr = generate_ray(cam, p_film, lens, time_u);
+        RayItem& r = rays[pixel_idx];
+        r.o = cr.o;
+        r.d = cr.d;
+        r.t_max = INF_F;
+        r.time = cr.time;
+        r.depth = 0;
+        r.lambda = lam;
+        r.pixel_index = idx;
+        r.beta = Spec(1.0f);
+        r.r_u = Spec(1.0f);
+        r.r_l = Spec(1.0f);
+        r.eta_scale = 1.0f;
+        r.specular_bounce = false;
+        r.any_non_specular = false;
+        r.medium = initial_medium;
+        valid[pixel_idx] = 1;
+    }
+
+    const bool have_lights = sc.desc.n_lights > 0;
+    const bool have_media = sc.desc.n_media > 0;
+    for (int32_t depth = 0; depth < ip.max_depth; ++depth) {
+        const int32_t n_rays = (int32_t)rays.size();
+        if (n_rays == 0) break;
+        // ---- K2 ----
+#pragma omp parallel for schedule(static)
+        for (int32_t i = 0; i < n_rays; ++i) {
+            int32_t pix = rays[i].pixel_index;
+            int32_t p0 = pix - 1;
+            int32_t px = p0 % W + 1, py = p0 / W + 1;
+            int32_t base = 6 + 7 * depth;
+            st.s_direct_uc[p0] = sample_1d(rng, px, py, sample_idx, base + 1);
+            st.s_direct_u[p0] = sample_2d(rng, px, py, sample_idx, base + 3);
+            st.s_indirect_uc[p0] = sample_1d(rng, px, py, sample_idx, base + 4);
+            st.s_indirect_u[p0] = sample_2d(rng, px, py, sample_idx, base + 6);
+            st.s_rr[p0] = sample_1d(rng, px, py, sample_idx, base + 7);
+        }
+        // ---- K3 trace ----
+        std::vector<HitItem> hits(n_rays);
+        std::vector<EscapedItem> escaped(n_rays);
+        std::vector<MediumSampleItem> medium_samples(have_media ? n_rays : 0);
+        std::vector<uint8_t> kind(n_rays, 0);  // 0 none, 1 hit, 2 escaped, 3 medium
+#pragma omp parallel for schedule(dynamic, 256)
+        for (int32_t i = 0; i < n_rays; ++i) {
+            const RayItem& wk = rays[i];
+            Counters& cnt = cnts[tid()];
+            auto fill_hit = [&](HitItem& hi, const Hit& h, V3 ro, V3 rd) {
+                const hk_tri_meta& meta = sc.desc.meta[h.prim];
+                const hk_medium_interface& mi = sc.desc.media_interfaces[meta.medium_interface_idx];
+                float bary[3] = {1.0f - h.u - h.v, h.u, h.v};
+                hi.ray_o = wk.o;
+                hi.ray_d = wk.d;
+                hi.ray_time = wk.time;
+                hi.g = surface_geometry(sc, h.prim, bary, ro, rd, h.t);
+                hi.material = mi.material;
+                hi.iface = mi;
+                hi.face_idx = meta.primitive_index;
+                hi.bary[0] = bary[0];
+                hi.bary[1] = bary[1];
+                hi.bary[2] = bary[2];
+                hi.arealight = meta.arealight_flat_idx_1based;
+                hi.triangle_area = triangle_area(sc, h.prim);
+                hi.lambda = wk.lambda;
+                hi.pixel_index = wk.pixel_index;
+                hi.beta = wk.beta;
+                hi.r_u = wk.r_u;
+                hi.r_l = wk.r_l;
+                hi.depth = wk.depth;
+                hi.eta_scale = wk.eta_scale;
+                hi.specular_bounce = wk.specular_bounce;
+                hi.any_non_specular = wk.any_non_specular;
+                hi.current_medium = wk.medium;
+                hi.t_hit = h.t;
+            };
+            if (wk.medium >= 0) {
+                cnt.rays_closest++;
+                Hit h = sc.accel.closest_hit(wk.o, wk.d, wk.t_max, &cnt.nodes, &cnt.tris);
+                MediumSampleItem& ms = medium_samples[i];
+                ms.o = wk.o;
+                ms.d = wk.d;
+                ms.time = wk.time;
+                ms.depth = wk.depth;
+                ms.lambda = wk.lambda;
+                ms.pixel_index = wk.pixel_index;
+                ms.beta = wk.beta;
+                ms.r_u = wk.r_u;
+                ms.r_l = wk.r_l;
+                ms.eta_scale = wk.eta_scale;
+                ms.specular_bounce = wk.specular_bounce;
+                ms.any_non_specular = wk.any_non_specular;
+                ms.medium = wk.medium;
+                ms.has_surface_hit = h.hit;
+                ms.t_max = h.hit ? h.t : INF_F;
+                if (h.hit) {
+                    cnt.hits++;
+                    HitItem hi;
+                    fill_hit(hi, h, wk.o, wk.d);
+                    ms.hit_valid = true;
+                    ms.hit_store = new HitItem(hi);
+                } else {
+                    ms.hit_valid = false;
+                    ms.hit_store = nullptr;
+                }
+                kind[i] = 3;
+                continue;
+            }
+            V3 ro = wk.o, rd = wk.d;
+            for (int it = 0; it < 16; ++it) {
+                cnt.rays_closest++;
+                // alpha-skipped segments restart with a default Ray (t_max = Inf)
+                Hit h = sc.accel.closest_hit(ro, rd, it == 0 ? wk.t_max : INF_F, &cnt.nodes, &cnt.tris);
+                if (!h.hit) {
+                    EscapedItem& e = escaped[i];
+                    e.d = wk.d;
+                    e.lambda = wk.lambda;
+                    e.pixel_index = wk.pixel_index;
+                    e.beta = wk.beta;
+                    e.r_u = wk.r_u;
+                    e.r_l = wk.r_l;
+                    e.depth = wk.depth;
+                    e.specular_bounce = wk.specular_bounce;
+                    kind[i] = 2;
+                    break;
+                }
+                cnt.hits++;
+                const hk_tri_meta& meta = sc.desc.meta[h.prim];
+                const hk_medium_interface& mi = sc.desc.media_interfaces[meta.medium_interface_idx];
+                float bary[3] = {1.0f - h.u - h.v, h.u, h.v};
+                V2 uv = uv_barycentric(sc, h.prim, bary);
+                float alpha = surface_alpha(sc.mctx, mi.material, uv);
+                if (alpha < 1.0f) {
+                    PCG32 prng = pcg32_init(pbrt_hash(ro), pbrt_hash(rd));
+                    float au = pcg32_uniform_f32(prng);
+                    if (au > alpha) {
+                        V3 pi = ro + rd * h.t;
+                        V3 n = geometric_normal(sc, h.prim);
+                        V3 off = dot(rd, n) > 0.0f ? n : -n;
+                        ro = pi + off * 1e-4f;
+                        continue;
+                    }
+                }
+                fill_hit(hits[i], h, ro, rd);
+                kind[i] = 1;
+                break;
+            }
+        }
+        // ---- K4-K6 media (delta tracking, scatter NEE, phase sampling) ----
+        std::vector<RayItem> next_rays_media;
+        std::vector<ShadowItem> shadow_media;
+        if (have_media) {
+            process_media_stage(sc, st, rays, kind, medium_samples, hits, escaped, next_rays_media, shadow_media, ip, cnts, depth);
+        }
+        // ---- K7 escaped ----
+        if (have_lights) {
+#pragma omp parallel for schedule(static)
+            for (int32_t i = 0; i < n_rays; ++i) {
+                if (kind[i] != 2) continue;
+                const EscapedItem& wk = escaped[i];
+                Spec Le = evaluate_escaped(sc, wk.d, wk.lambda);
+                Spec contribution = wk.beta * Le;
+                if (is_black(contribution)) continue;
+                Spec final_c;
+                if (wk.depth == 0 || wk.specular_bounce)
+                    final_c = contribution / average(wk.r_u);
+                else {
+                    int32_t nl = sc.desc.n_lights;
+                    float choice = nl > 0 ? 1.0f / (float)nl : 0.0f;
+                    float light_pdf = env_light_pdf(sc, wk.d);
+                    Spec rl = wk.r_l * choice * light_pdf;
+                    Spec rsum = wk.r_u + rl;
+                    float den = average(rsum);
+                    final_c = den > 1e-10f ? contribution / den : contribution / average(wk.r_u);
+                }
+                float* L = &st.pixel_L[4 * (size_t)(wk.pixel_index - 1)];
+                for (int k = 0; k < 4; ++k) L[k] += final_c[k];
+            }
+        }
+        // ---- K8 surface hits ----
+        std::vector<MatItem> mats(n_rays);
+        std::vector<uint8_t> mat_valid(n_rays, 0);
+#pragma omp parallel for schedule(static)
+        for (int32_t i = 0; i < n_rays; ++i) {
+            if (kind[i] != 1) continue;
+            const HitItem& wk = hits[i];
+            Counters& cnt = cnts[tid()];
+            cnt.vertices++;
+            V3 wo = -wk.ray_d;
+            int32_t material_idx = resolve_mix_material(sc.mctx, wk.material, wk.g.pi, wo, wk.g.uv);
+            if (wk.arealight > 0) {
+                const hk_light& light = sc.desc.lights[wk.arealight - 1];
+                Spec Le = arealight_Le(sc.table, sc.textures, light, wo, wk.g.n, wk.g.uv, wk.lambda);
+                if (!is_black(Le)) {
+                    Spec contribution = wk.beta * Le;
+                    Spec final_c;
+                    if (wk.depth == 0 || wk.specular_bounce)
+                        final_c = contribution / average(wk.r_u);
+                    else {
+                        float choice = sc.sampler.pmf(wk.g.pi, wk.g.n, (int32_t)wk.arealight);
+                        float cos_theta = std::fabs(dot(wk.g.n, normalize(wk.ray_d)));
+                        float lightPDF = 0.0f;
+                        if (cos_theta > 0.0f && wk.triangle_area > 0.0f) {
+                            float pdf_li = (wk.t_hit * wk.t_hit) / (cos_theta * wk.triangle_area);
+                            lightPDF = choice * pdf_li;
+                        }
+                        Spec rl = wk.r_l * lightPDF;
+                        float den = average(wk.r_u + rl);
+                        final_c = den > 1e-10f ? contribution / den : contribution / average(wk.r_u);
+                    }
+                    float* L = &st.pixel_L[4 * (size_t)(wk.pixel_index - 1)];
+                    for (int k = 0; k < 4; ++k) L[k] += final_c[k];
+                }
+            }
+            MatItem& m = mats[i];
+            m.g = wk.g;
+            m.wo = wo;
+            m.material = material_idx;
+            m.iface = wk.iface;
+            m.lambda = wk.lambda;
+            m.pixel_index = wk.pixel_index;
+            m.beta = wk.beta;
+            m.r_u = wk.r_u;
+            m.r_l = wk.r_l;
+            m.depth = wk.depth;
+            m.eta_scale = wk.eta_scale;
+            m.specular_bounce = wk.specular_bounce;
+            m.any_non_specular = wk.any_non_specular;
+            m.current_medium = wk.current_medium;
+            mat_valid[i] = 1;
+        }
+        // ---- K9 direct lighting ----
+        std::vector<ShadowItem> shadows(n_rays);
+        std::vector<uint8_t> shadow_valid(n_rays, 0);
+        if (have_lights) {
+#pragma omp parallel for schedule(static)
+            for (int32_t i = 0; i < n_rays; ++i) {
+                if (!mat_valid[i]) continue;
+                const MatItem& wk = mats[i];
+                int32_t p0 = wk.pixel_index - 1;
+                V2 u_light = st.s_direct_u[p0];
+                float light_select = st.s_direct_uc[p0];
+                float light_pmf;
+                int32_t light_idx = sc.sampler.sample(wk.g.pi, wk.g.ns, light_select, light_pmf);
+                if (light_idx < 1 || light_idx > sc.desc.n_lights || light_pmf <= 0.0f) continue;
+                LightSample ls = sample_light_full(sc, light_idx, wk.g.pi, wk.lambda, u_light);
+                if (!(ls.pdf > 0.0f && !is_black(ls.Li))) continue;
+                float bsdf_pdf;
+                Spec bsdf_f = eval_bsdf(sc.mctx, wk.material, wk.wo, ls.wi, wk.g.ns, wk.g.uv, wk.lambda, bsdf_pdf);
+                if (is_black(bsdf_f)) continue;
+                // compute_direct_lighting_spectral  lights.jl:535-600
+                float cos_theta = std::fabs(dot(ls.wi, wk.g.ns));
+                Spec Ld = wk.beta * bsdf_f * ls.Li * cos_theta;
+                if (is_black(Ld)) continue;
+                V3 offset = 1e-4f * wk.g.ns;
+                V3 ray_origin = dot(ls.wi, wk.g.ns) > 0.0f ? wk.g.pi + offset : wk.g.pi - offset;
+                V3 to_light = ls.p_light - ray_origin;
+                float t_max = std::sqrt(dot(to_light, to_light)) - 1e-3f;
+                float new_bsdf_pdf = ls.is_delta ? 0.0f : bsdf_pdf;
+                ShadowItem& s = shadows[i];
+                s.o = ray_origin;
+                s.d = ls.wi;
+                s.t_max = t_max;
+                s.lambda = wk.lambda;
+                s.Ld = Ld;
+                s.r_u = wk.r_u * new_bsdf_pdf;
+                s.r_l = (wk.r_u * ls.pdf) * light_pmf;
+                s.pixel_index = wk.pixel_index;
+                s.medium = wk.current_medium;
+                shadow_valid[i] = 1;
+            }
+        }
+        // ---- K10 shadow rays (medium-scatter shadow items first: the reference pushes them in K5) ----
+        {
+            const int32_t nm = (int32_t)shadow_media.size();
+#pragma omp parallel for schedule(dynamic, 256)
+            for (int32_t i = 0; i < nm + n_rays; ++i) {
+                const ShadowItem* wkp;
+                if (i < nm)
+                    wkp = &shadow_media[i];
+                else {
+                    if (!shadow_valid[i - nm]) continue;
+                    wkp = &shadows[i - nm];
+                }
+                const ShadowItem& wk = *wkp;
+                Counters& cnt = cnts[tid()];
+                Spec T, tu, tl;
+                bool visible = trace_shadow_transmittance(sc, wk.o, wk.d, wk.t_max, wk.lambda, wk.medium, T, tu, tl, cnt);
+                if (visible && !is_black(T)) {
+                    Spec mis = wk.r_u * tu + wk.r_l * tl;
+                    float den = average(mis);
+                    if (den > 1e-10f) {
+                        Spec final_L = wk.Ld * T / den;
+                        if (!is_black(final_L)) {
+                            float* L = &st.pixel_L[4 * (size_t)(wk.pixel_index - 1)];
+                            for (int k = 0; k < 4; ++k) L[k] += final_L[k];
+                        }
+                    }
+                }
+            }
+        }
+        // ---- K11 evaluate materials ----
+        std::vector<RayItem> out(n_rays);
+        std::vector<uint8_t> out_valid(n_rays, 0);
+#pragma omp parallel for schedule(static)
+        for (int32_t i = 0; i < n_rays; ++i) {
+            if (!mat_valid[i]) continue;
+            const MatItem& wk = mats[i];
+            int32_t new_depth = wk.depth + 1;
+            if (new_depth >= ip.max_depth) continue;
+            int32_t p0 = wk.pixel_index - 1;
+            V2 u = st.s_indirect_u[p0];
+            float uc = st.s_indirect_uc[p0];
+            float rr = st.s_rr[p0];
+            bool regularize = ip.regularize && wk.any_non_specular;
+            BSDFSample s = sample_bsdf(sc.mctx, wk.material, wk.wo, wk.g.ns, wk.g.uv, wk.lambda, u, uc, regularize);
+            if (!(s.pdf > 0.0f && !is_black(s.f))) continue;
+            float cos_theta = std::fabs(dot(s.wi, wk.g.ns));
+            Spec new_beta = s.is_specular ? wk.beta * s.f : wk.beta * s.f * cos_theta / s.pdf;
+            float new_eta_scale = wk.eta_scale * s.eta_scale;
+            Spec new_r_l = s.is_specular ? wk.r_u : wk.r_u / s.pdf;
+            // russian_roulette_spectral  material-dispatch.jl:263-287 (min_depth = 3)
+            Spec final_beta = new_beta;
+            if (new_depth > 3) {
+                float q = maxf(0.05f, 1.0f - max_component(new_beta));
+                if (rr < q) continue;
+                final_beta = new_beta * (1.0f / (1.0f - q));
+            }
+            int32_t new_medium = is_medium_transition(wk.iface) ? get_medium_index(wk.iface, s.wi, wk.g.n) : wk.current_medium;
+            V3 off = dot(s.wi, wk.g.n) > 0.0f ? wk.g.n : -wk.g.n;
+            RayItem& r = out[i];
+            r.o = wk.g.pi + off * 0.0001f;
+            r.d = s.wi;
+            r.t_max = INF_F;
+            r.time = 0.0f;
+            r.depth = new_depth;
+            r.lambda = wk.lambda;
+            r.pixel_index = wk.pixel_index;
+            r.beta = final_beta;
+            r.r_u = wk.r_u;
+            r.r_l = new_r_l;
+            r.eta_scale = new_eta_scale;
+            r.specular_bounce = s.is_specular;
+            r.any_non_specular = wk.any_non_specular || !s.is_specular;
+            r.medium = new_medium;
+            out_valid[i] = 1;
+        }
+        std::vector<RayItem> next;
+        next.reserve(n_rays);
+        for (auto& r : next_rays_media) next.push_back(r);
+        for (int32_t i = 0; i < n_rays; ++i)
+            if (out_valid[i]) next.push_back(out[i]);
+        rays.swap(next);
+    }
+
+    // ---- K12 ----
+#pragma omp parallel for schedule(static)
+    for (int32_t p = 0; p < N; ++p) {
+        Spec L(st.pixel_L[4 * p], st.pixel_L[4 * p + 1], st.pixel_L[4 * p + 2], st.pixel_L[4 * p + 3]);
+        Wavelengths lam;
+        for (int k = 0; k < 4; ++k) {
+            lam.lambda[k] = st.lambda[4 * p + k];
+            lam.pdf[k] = st.pdf[4 * p + k];
+        }
+        V3 xyz = spectral_to_xyz(sc.cie, L, lam);
+        V3 rgb = xyz_to_linear_srgb(xyz);
+        rgb = V3(maxf(0.0f, rgb.x), maxf(0.0f, rgb.y), maxf(0.0f, rgb.z));
+        float m = maxf(maxf(rgb.x, rgb.y), rgb.z);
+        if (m > ip.max_component_value) rgb = rgb * (ip.max_component_value / m);
+        float wgt = st.filter_w[p];
+        if (f64) {
+            pixel_rgb[3 * p] += (double)(wgt * rgb.x);
+            pixel_rgb[3 * p + 1] += (double)(wgt * rgb.y);
+            pixel_rgb[3 * p + 2] += (double)(wgt * rgb.z);
+            pixel_w[p] += (double)wgt;
+        } else {
+            rgb32[3 * p] += wgt * rgb.x;
+            rgb32[3 * p + 1] += wgt * rgb.y;
+            rgb32[3 * p + 2] += wgt * rgb.z;
+            w32[p] += wgt;
+        }
+    }
+    for (auto& c : cnts) {
+        cnt_total.rays_closest += c.rays_closest;
+        cnt_total.rays_shadow += c.rays_shadow;
+        cnt_total.nodes += c.nodes;
+        cnt_total.tris += c.tris;
+        cnt_total.hits += c.hits;
+        cnt_total.vertices += c.vertices;
+        cnt_total.collisions += c.collisions;
+    }
+}
+
+}  // namespace hko
+
+// =====================================================================================================
+// C entry points (loaded by tests / smoke / bench cpu_baseline through ctypes)
+// =====================================================================================================
+using namespace hko;
+
+struct hko_scene {
+    Scene sc;
+};
+
+extern "C" {
+
+int32_t hko_scene_create(const hk_scene_desc* desc, const hk_tables* tables, hko_scene** out) {
+    hko_scene* s = new hko_scene();
+    Scene& sc = s->sc;
+    if (desc->n_media > 0) { delete s; return HK_ERR_UNSUPPORTED; }
+    sc.desc = *desc;  // borrowed pointers: the caller keeps the arrays alive for the scene's lifetime
+    sc.accel.build(desc->positions, desc->n_triangles);
+    sc.sampler.build(desc->lights, desc->n_lights);
+    sc.table.res = tables->rgb2spec_res;
+    sc.table.scale = tables->rgb2spec_scale;
+    sc.table.coeffs = tables->rgb2spec_coeffs;
+    sc.cie.x = tables->cie_x;
+    sc.cie.y = tables->cie_y;
+    sc.cie.z = tables->cie_z;
+    sc.sobol = tables->sobol_matrices;
+    sc.textures.tex = desc->textures;
+    sc.textures.n = desc->n_textures;
+    sc.mctx.table = &sc.table;
+    sc.mctx.textures = sc.textures;
+    sc.mctx.materials = desc->materials;
+    sc.mctx.n_materials = desc->n_materials;
+    sc.mctx.spectra = desc->spectra;
+    init_media(sc.media, desc, &sc.table);
+    *out = s;
+    return 0;
+}
+int32_t hko_scene_destroy(hko_scene* s) {
+    delete s;
+    return 0;
+}
+
+// Render samples first..first+n-1 (stride `stride`) on top of accum = [rgb 3N | weight N] (f32 or f64).
+int32_t hko_render(hko_scene* s, const hk_integrator_params* ip, const hk_camera* cam, int32_t width, int32_t height, int32_t first_sample_idx,
+                   int32_t n_samples, int32_t stride, void* accum, hk_stats* stats) {
+    Scene& sc = s->sc;
+    FilterParams fp = make_filter_params(*ip);
+    FilterSampler fs = build_filter_sampler(fp);
+    int spp = ip->samples_per_pixel > 4096 ? ip->samples_per_pixel : 4096;  // volpath.jl:475
+    SobolRNG rng = make_sobol_rng(sc.sobol, ip->sampler_seed, width, height, spp);
+    RenderState st;
+    st.width = width;
+    st.height = height;
+    size_t N = (size_t)width * height;
+    st.pixel_L.assign(4 * N, 0.0f);
+    st.lambda.assign(4 * N, 0.0f);
+    st.pdf.assign(4 * N, 0.0f);
+    st.filter_w.assign(N, 0.0f);
+    st.s_direct_uc.assign(N, 0.0f);
+    st.s_indirect_uc.assign(N, 0.0f);
+    st.s_rr.assign(N, 0.0f);
+    st.s_direct_u.assign(N, V2());
+    st.s_indirect_u.assign(N, V2());
+    bool f64 = ip->accumulate_f64 != 0;
+    Counters cnt;
+    for (int32_t k = 0; k < n_samples; ++k) {
+        int32_t sidx = first_sample_idx + k * stride;
+        if (f64)
+            render_one_sample(sc, *ip, fp, fs, *cam, rng, st, sidx, (double*)accum, (double*)accum + 3 * N, true, nullptr, nullptr, cnt);
+        else
+            render_one_sample(sc, *ip, fp, fs, *cam, rng, st, sidx, nullptr, nullptr, false, (float*)accum, (float*)accum + 3 * N, cnt);
+    }
+    if (stats) {
+        stats->rays_closest += cnt.rays_closest;
+        stats->rays_shadow += cnt.rays_shadow;
+        stats->bvh_nodes_visited += cnt.nodes;
+        stats->tris_tested += cnt.tris;
+        stats->hits_accepted += cnt.hits;
+        stats->path_vertices += cnt.vertices;
+        stats->medium_collisions += cnt.collisions;
+        stats->light_bvh_nodes = sc.sampler.nodes_evaluated;
+    }
+    return 0;
+}
+
+// K13: framebuffer[py,px] = rgb/weight as Julia Matrix{RGB{Float32}}[height,width] (column-major)
+int32_t hko_finalize(int32_t width, int32_t height, int32_t f64, const void* accum, float* out_hw3) {
+    size_t N = (size_t)width * height;
+    for (size_t p = 0; p < N; ++p) {
+        int32_t px = (int32_t)(p % width), py = (int32_t)(p / width);
+        float r, g, b;
+        if (f64) {
+            const double* a = (const double*)accum;
+            double w = a[3 * N + p];
+            if (w > 0.0) {
+                double inv = 1.0 / w;
+                r = (float)(a[3 * p] * inv);
+                g = (float)(a[3 * p + 1] * inv);
+                b = (float)(a[3 * p + 2] * inv);
+            } else
+                r = g = b = 0.0f;
+        } else {
+            const float* a = (const float*)accum;
+            float w = a[3 * N + p];
+            if (w > 0.0f) {
+                float inv = 1.0f / w;
+                r = a[3 * p] * inv;
+                g = a[3 * p + 1] * inv;
+                b = a[3 * p + 2] * inv;
+            } else
+                r = g = b = 0.0f;
+        }
+        float* o = out_hw3 + 3 * ((size_t)py + (size_t)height * px);
+        o[0] = r;
+        o[1] = g;
+        o[2] = b;
+    }
+    return 0;
+}
+
+int32_t hko_trace_closest(hko_scene* s, int32_t n, const float* o3, const float* d3, const float* tmax, float* out_t, int32_t* out_prim, float* out_uv2) {
+#pragma omp parallel for schedule(dynamic, 1024)
+    for (int32_t i = 0; i < n; ++i) {
+        Hit h = s->sc.accel.closest_hit(V3(o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]), V3(d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]), tmax[i]);
+        out_t[i] = h.hit ? h.t : INF_F;
+        out_prim[i] = h.hit ? h.prim : -1;
+        out_uv2[2 * i] = h.hit ? h.u : 0.0f;
+        out_uv2[2 * i + 1] = h.hit ? h.v : 0.0f;
+    }
+    return 0;
+}
+
+int32_t hko_sobol(const uint32_t* matrices, int32_t width, int32_t height, int32_t spp, uint32_t seed, int32_t n, const int32_t* px, const int32_t* py,
+                  const int32_t* sample_idx, const int32_t* dim, float* out_1d, float* out_2d) {
+    SobolRNG r = make_sobol_rng(matrices, seed, width, height, spp);
+    for (int32_t i = 0; i < n; ++i) {
+        out_1d[i] = sample_1d(r, px[i], py[i], sample_idx[i], dim[i]);
+        V2 v = sample_2d(r, px[i], py[i], sample_idx[i], dim[i]);
+        out_2d[2 * i] = v.x;
+        out_2d[2 * i + 1] = v.y;
+    }
+    return 0;
+}
+
+int32_t hko_camera(const uint32_t* matrices, const hk_integrator_params* ip, const hk_camera* cam, int32_t width, int32_t height, int32_t n, const int32_t* px,
+                   const int32_t* py, const int32_t* sample_idx, float* out15) {
+    FilterParams fp = make_filter_params(*ip);
+    FilterSampler fs = build_filter_sampler(fp);
+    int spp = ip->samples_per_pixel > 4096 ? ip->samples_per_pixel : 4096;
+    SobolRNG rng = make_sobol_rng(matrices, ip->sampler_seed, width, height, spp);
+    for (int32_t i = 0; i < n; ++i) {
+        int32_t x = px[i], y = py[i], s = sample_idx[i];
+        float wavelength_u = sample_1d(rng, x, y, s, 1);
+        V2 jit = sample_2d(rng, x, y, s, 3);
+        float time_u = sample_1d(rng, x, y, s, 4);
+        V2 lens = sample_2d(rng, x, y, s, 6);
+        FilterSample f = filter_sample(fp, fs, jit);
+        Wavelengths lam = sample_wavelengths_visible(wavelength_u);
+        V2 p_film((float)x + 0.5f + f.px, (float)height - (float)y + 1.0f + 0.5f + f.py);
+        CamRay cr = generate_ray(*cam, p_film, lens, time_u);
+        float* o = out15 + 15 * (size_t)i;
+        for (int k = 0; k < 4; ++k) {
+            o[k] = lam.lambda[k];
+            o[4 + k] = lam.pdf[k];
+        }
+        o[8] = f.weight;
+        o[9] = cr.o.x;
+        o[10] = cr.o.y;
+        o[11] = cr.o.z;
+        o[12] = cr.d.x;
+        o[13] = cr.d.y;
+        o[14] = cr.d.z;
+    }
+    return 0;
+}
+
+int32_t hko_uplift(const hk_tables* tables, int32_t mode, int32_t n, const float* rgb, const float* lambda, float* out) {
+    RGB2SpecTable t{tables->rgb2spec_res, tables->rgb2spec_scale, tables->rgb2spec_coeffs};
+    for (int32_t i = 0; i < n; ++i) {
+        Wavelengths w;
+        for (int k = 0; k < 4; ++k) {
+            w.lambda[k] = lambda[4 * i + k];
+            w.pdf[k] = 1.0f;
+        }
+        RGBA c(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]);
+        Spec s = mode == 0 ? uplift_rgb(t, c, w) : (mode == 1 ? uplift_rgb_unbounded(t, c, w) : uplift_rgb_illuminant(t, c, w));
+        for (int k = 0; k < 4; ++k) out[4 * i + k] = s[k];
+    }
+    return 0;
+}
+
+int32_t hko_light_bvh(hko_scene* s, int32_t n, const float* p3, const float* n3, const float* u, int32_t* out_light, float* out_pmf, const int32_t* query_light,
+                      float* out_query_pmf) {
+    for (int32_t i = 0; i < n; ++i) {
+        V3 p(p3[3 * i], p3[3 * i + 1], p3[3 * i + 2]), nn(n3[3 * i], n3[3 * i + 1], n3[3 * i + 2]);
+        float pmf;
+        out_light[i] = s->sc.sampler.sample(p, nn, u[i], pmf);
+        out_pmf[i] = pmf;
+        if (query_light && out_query_pmf) out_query_pmf[i] = s->sc.sampler.pmf(p, nn, query_light[i]);
+    }
+    return 0;
+}
+int32_t hko_light_bvh_copy(hko_scene* s, int32_t* n_nodes, float* nodes_out, uint32_t* bit_trails) {
+    const LightSampler& ls = s->sc.sampler;
+    *n_nodes = (int32_t)ls.nodes.size();
+    if (nodes_out)
+        for (size_t i = 0; i < ls.nodes.size(); ++i) {
+            const LightBVHNode& nd = ls.nodes[i];
+            float* o = nodes_out + 16 * i;
+            o[0] = nd.bmin.x; o[1] = nd.bmin.y; o[2] = nd.bmin.z;
+            o[3] = nd.bmax.x; o[4] = nd.bmax.y; o[5] = nd.bmax.z;
+            o[6] = nd.w.x; o[7] = nd.w.y; o[8] = nd.w.z;
+            o[9] = nd.phi; o[10] = nd.cos_o; o[11] = nd.cos_e;
+            o[12] = nd.two_sided ? 1.0f : 0.0f;
+            o[13] = (float)nd.child1_or_light;
+            o[14] = nd.is_leaf ? 1.0f : 0.0f;
+            o[15] = 0.0f;
+        }
+    if (bit_trails)
+        for (size_t i = 0; i < ls.bit_trail.size(); ++i) bit_trails[i] = ls.bit_trail[i];
+    return 0;
+}
+
+// known-answer helpers
+uint64_t hko_murmur64a(const uint8_t* data, int32_t n, uint64_t seed) { return murmur_hash_64a(data, n, seed); }
+uint64_t hko_mix_bits(uint64_t v) { return mix_bits(v); }
+void hko_pcg32(uint64_t seq, uint64_t seed, int32_t has_seed, int32_t n, uint32_t* out_u32, float* out_f32) {
+    PCG32 r = has_seed ? pcg32_init(seq, seed) : pcg32_init(seq);
+    PCG32 r2 = r;
+    for (int i = 0; i < n; ++i) {
+        out_u32[i] = pcg32_uniform_u32(r);
+        out_f32[i] = pcg32_uniform_f32(r2);
+    }
+}
+float hko_fresnel_dielectric(float c, float eta) { return fresnel_dielectric(c, eta); }
+float hko_fr_complex(float c, float eta, float k) { return fr_complex(c, eta, k); }
+float hko_filter_eval(const hk_integrator_params* ip, float x, float y) { return filter_evaluate(make_filter_params(*ip), x, y); }
+void hko_filter_sample(const hk_integrator_params* ip, int32_t n, const float* u2, float* out3, float* func_integral) {
+    FilterParams fp = make_filter_params(*ip);
+    FilterSampler fs = build_filter_sampler(fp);
+    if (func_integral) *func_integral = fs.valid ? fs.func_integral : 0.0f;
+    for (int i = 0; i < n; ++i) {
+        FilterSample s = filter_sample(fp, fs, V2(u2[2 * i], u2[2 * i + 1]));
+        out3[3 * i] = s.px;
+        out3[3 * i + 1] = s.py;
+        out3[3 * i + 2] = s.weight;
+    }
+}
+void hko_wavelengths(int32_t n, const float* u, float* out8) {
+    for (int i = 0; i < n; ++i) {
+        Wavelengths w = sample_wavelengths_visible(u[i]);
+        for (int k = 0; k < 4; ++k) {
+            out8[8 * i + k] = w.lambda[k];
+            out8[8 * i + 4 + k] = w.pdf[k];
+        }
+    }
+}
+float hko_sample_d65(float l) { return sample_d65(l); }
+
+}  // extern "C"

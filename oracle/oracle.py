@@ -1,0 +1,167 @@
+"""ctypes wrapper around oracle/liboracle.so — the CPU ORACLE (test infrastructure).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the product
+package (hikari.jl_amd) never does."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liboracle.so")
+_lib = None
+
+
+def build(force=False):
+    if force or not os.path.isfile(LIB_PATH):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        import hikari_jl_amd as hk
+        A = hk._abi
+        L = C.CDLL(LIB_PATH)
+        vp, i32, PF, PI = C.c_void_p, C.c_int32, A.PF, C.POINTER(C.c_int32)
+        L.hko_scene_create.argtypes = [C.POINTER(A.hk_scene_desc), C.POINTER(A.hk_tables), C.POINTER(vp)]
+        L.hko_scene_destroy.argtypes = [vp]
+        L.hko_render.argtypes = [vp, C.POINTER(A.hk_integrator_params), C.POINTER(A.hk_camera), i32, i32, i32, i32, i32, vp, C.POINTER(A.hk_stats)]
+        L.hko_finalize.argtypes = [i32, i32, i32, vp, PF]
+        L.hko_trace_closest.argtypes = [vp, i32, PF, PF, PF, PF, PI, PF]
+        L.hko_sobol.argtypes = [C.POINTER(C.c_uint32), i32, i32, i32, C.c_uint32, i32, PI, PI, PI, PI, PF, PF]
+        L.hko_camera.argtypes = [C.POINTER(C.c_uint32), C.POINTER(A.hk_integrator_params), C.POINTER(A.hk_camera), i32, i32, i32, PI, PI, PI, PF]
+        L.hko_uplift.argtypes = [C.POINTER(A.hk_tables), i32, i32, PF, PF, PF]
+        L.hko_light_bvh.argtypes = [vp, i32, PF, PF, PF, PI, PF, PI, PF]
+        L.hko_light_bvh_copy.argtypes = [vp, PI, PF, C.POINTER(C.c_uint32)]
+        L.hko_murmur64a.argtypes = [C.c_char_p, i32, C.c_uint64]
+        L.hko_murmur64a.restype = C.c_uint64
+        L.hko_mix_bits.argtypes = [C.c_uint64]
+        L.hko_mix_bits.restype = C.c_uint64
+        L.hko_pcg32.argtypes = [C.c_uint64, C.c_uint64, i32, i32, C.POINTER(C.c_uint32), PF]
+        L.hko_pcg32.restype = None
+        for n in ("hko_fresnel_dielectric", "hko_fr_complex", "hko_sample_d65"):
+            getattr(L, n).restype = C.c_float
+        L.hko_fresnel_dielectric.argtypes = [C.c_float, C.c_float]
+        L.hko_fr_complex.argtypes = [C.c_float, C.c_float, C.c_float]
+        L.hko_sample_d65.argtypes = [C.c_float]
+        L.hko_filter_eval.argtypes = [C.POINTER(A.hk_integrator_params), C.c_float, C.c_float]
+        L.hko_filter_eval.restype = C.c_float
+        L.hko_filter_sample.argtypes = [C.POINTER(A.hk_integrator_params), i32, PF, PF, PF]
+        L.hko_filter_sample.restype = None
+        L.hko_wavelengths.argtypes = [i32, PF, PF]
+        L.hko_wavelengths.restype = None
+        _lib = L
+    return _lib
+
+
+def _pf(a):
+    import hikari_jl_amd as hk
+    return a.ctypes.data_as(hk._abi.PF)
+
+
+def _pi(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+class OracleScene:
+    def __init__(self, scene):
+        import hikari_jl_amd as hk
+        self.scene = scene  # keeps the borrowed arrays alive
+        self.tables = hk.tables.load()
+        self.h = C.c_void_p()
+        st = lib().hko_scene_create(C.byref(scene.desc), C.byref(self.tables["struct"]), C.byref(self.h))
+        if st != 0:
+            raise RuntimeError("hko_scene_create failed: %d" % st)
+
+    def render(self, params, camera, width, height, n_samples, first=1, stride=1, accum=None):
+        """-> (accum[4N], stats).  accum = [rgb 3N | weight N]."""
+        import hikari_jl_amd as hk
+        n = width * height
+        dt = np.float64 if params.accumulate_f64 else np.float32
+        if accum is None:
+            accum = np.zeros(4 * n, dtype=dt)
+        stats = hk._abi.hk_stats()
+        cam = camera.record()
+        st = lib().hko_render(self.h, C.byref(params), C.byref(cam), width, height, first, n_samples, stride,
+                              accum.ctypes.data_as(C.c_void_p), C.byref(stats))
+        assert st == 0
+        return accum, stats
+
+    def trace(self, o, d, tmax):
+        n = o.shape[0]
+        o = np.ascontiguousarray(o, np.float32)
+        d = np.ascontiguousarray(d, np.float32)
+        tmax = np.ascontiguousarray(tmax, np.float32)
+        t = np.empty(n, np.float32)
+        prim = np.empty(n, np.int32)
+        uv = np.empty((n, 2), np.float32)
+        lib().hko_trace_closest(self.h, n, _pf(o), _pf(d), _pf(tmax), _pf(t), _pi(prim), _pf(uv))
+        return t, prim, uv
+
+    def light_bvh(self, p, n, u, query=None):
+        m = p.shape[0]
+        p = np.ascontiguousarray(p, np.float32)
+        n = np.ascontiguousarray(n, np.float32)
+        u = np.ascontiguousarray(u, np.float32)
+        li = np.empty(m, np.int32)
+        pmf = np.empty(m, np.float32)
+        qp = np.zeros(m, np.float32)
+        q = np.ascontiguousarray(query if query is not None else np.zeros(m), np.int32)
+        lib().hko_light_bvh(self.h, m, _pf(p), _pf(n), _pf(u), _pi(li), _pf(pmf), _pi(q), _pf(qp))
+        return li, pmf, qp
+
+    def light_bvh_nodes(self):
+        nn = C.c_int32()
+        lib().hko_light_bvh_copy(self.h, C.byref(nn), None, None)
+        nodes = np.zeros((max(nn.value, 1), 16), np.float32)
+        trails = np.zeros(max(self.scene.desc.n_lights, 1), np.uint32)
+        lib().hko_light_bvh_copy(self.h, C.byref(nn), _pf(nodes), trails.ctypes.data_as(C.POINTER(C.c_uint32)))
+        return nodes[:nn.value], trails[:self.scene.desc.n_lights]
+
+    def close(self):
+        if self.h:
+            lib().hko_scene_destroy(self.h)
+            self.h = None
+
+
+def finalize(accum, width, height):
+    """K13 -> framebuffer [h, w, 3]"""
+    out = np.empty((width, height, 3), np.float32)
+    lib().hko_finalize(width, height, 1 if accum.dtype == np.float64 else 0, accum.ctypes.data_as(C.c_void_p), _pf(out))
+    return np.transpose(out, (1, 0, 2)).copy()
+
+
+def sobol(width, height, spp, seed, px, py, sidx, dim):
+    import hikari_jl_amd as hk
+    t = hk.tables.load()
+    n = len(px)
+    a = [np.ascontiguousarray(x, np.int32) for x in (px, py, sidx, dim)]
+    o1 = np.empty(n, np.float32)
+    o2 = np.empty((n, 2), np.float32)
+    lib().hko_sobol(t["struct"].sobol_matrices, width, height, spp, seed, n, _pi(a[0]), _pi(a[1]), _pi(a[2]), _pi(a[3]), _pf(o1), _pf(o2))
+    return o1, o2
+
+
+def camera_samples(params, camera, width, height, px, py, sidx):
+    import hikari_jl_amd as hk
+    t = hk.tables.load()
+    n = len(px)
+    a = [np.ascontiguousarray(x, np.int32) for x in (px, py, sidx)]
+    out = np.empty((n, 15), np.float32)
+    cam = camera.record()
+    lib().hko_camera(t["struct"].sobol_matrices, C.byref(params), C.byref(cam), width, height, n, _pi(a[0]), _pi(a[1]), _pi(a[2]), _pf(out))
+    return out
+
+
+def uplift(mode, rgb, lam):
+    import hikari_jl_amd as hk
+    t = hk.tables.load()
+    rgb = np.ascontiguousarray(rgb, np.float32)
+    lam = np.ascontiguousarray(lam, np.float32)
+    out = np.empty_like(lam)
+    lib().hko_uplift(C.byref(t["struct"]), mode, rgb.shape[0], _pf(rgb), _pf(lam), _pf(out))
+    return out

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Extract the *data tables* embedded in the reference's Julia sources into binary fixtures.
+
+Run once in the build container (needs /root/reference); the outputs are committed:
+
+  hikari.jl_amd/data/sobol_matrices.bin   uint32[1024*52]  (sampler/sobol_matrices.jl:18-6675)
+  hikari.jl_amd/data/cie_xyz.bin          float32[3*471]   (spectral/color.jl:53-345, X then Y then Z)
+  hikari.jl_amd/data/metal_spectra.bin    see below        (spectral/metal-spectra.jl)
+
+These are numeric tables (pbrt-v4 / CIE data), not code.  SURVEY.md §8c(1) lists them as
+the known-answer data the build must share with the reference.
+"""
+import os, re, struct, sys
+import numpy as np
+
+REF = "/root/reference/src"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "hikari.jl_amd", "data")
+
+
+def grab_block(text, name):
+    m = re.search(r"const\s+%s\s*=\s*\w*\[(.*?)\n\]" % re.escape(name), text, re.S)
+    if not m:
+        raise SystemExit("table %s not found" % name)
+    body = re.sub(r"#.*", "", m.group(1))
+    return [t for t in re.split(r"[\s,]+", body) if t]
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    sob = open(os.path.join(REF, "sampler/sobol_matrices.jl")).read()
+    toks = grab_block(sob, "SobolMatrices32")
+    arr = np.array([int(t, 16) for t in toks], dtype=np.uint32)
+    assert arr.size == 1024 * 52, arr.size
+    arr.tofile(os.path.join(OUT, "sobol_matrices.bin"))
+
+    col = open(os.path.join(REF, "spectral/color.jl")).read()
+    xyz = []
+    for nm in ("CIE_X", "CIE_Y", "CIE_Z"):
+        t = grab_block(col, nm)
+        a = np.array([float(x.rstrip("f0")) if x.endswith("f0") else float(x) for x in t], dtype=np.float32)
+        assert a.size == 471, (nm, a.size)
+        xyz.append(a)
+    np.concatenate(xyz).tofile(os.path.join(OUT, "cie_xyz.bin"))
+    print("wrote", OUT)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,977 @@
+// hk_api.cpp — host side of the C-ABI (include/hikari_mi355x.h): contexts, scene upload (BVH + light-BVH
+// build, constant-colour baking), film, integrator state and the wavefront driver that replaces the
+// reference's host loop `render!` (src/integrators/volpath/volpath.jl:445-636).  Unlike the reference
+// loop (8-10 blocking `length(queue)` readbacks per bounce, workqueue.jl:108-111) nothing here reads
+// the device back inside a frame: queue sizes stay in HBM and every kernel sizes itself from them.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "bvh_build.h"
+#include "hikari_mi355x.h"
+#include "hk_types.h"
+
+namespace hk {
+void launch_camera(hipStream_t, const DPathState&, const DFrame&, const DTables&, const DFilter&, const DCamera&, const DSobol&, int);
+void launch_trace(hipStream_t, int, const DPathState&, const DScene&, const DTables&, const DFrame&, int, DStats*);
+void launch_shadow(hipStream_t, int, const DPathState&, const DScene&, const DTables&, const DFrame&, int, DStats*);
+void launch_escaped(hipStream_t, int, const DPathState&, const DScene&, const DTables&, int);
+void launch_shade(hipStream_t, int, int, const DPathState&, const DScene&, const DTables&, const DFrame&, const DSobol&, int, DStats*);
+void launch_film(hipStream_t, const DPathState&, const DFrame&, const DTables&, void*, bool);
+void launch_finalize(hipStream_t, const void*, bool, float*, int, int);
+void launch_test_trace(hipStream_t, const DScene&, int, const float*, const float*, const float*, float*, int*, float*);
+void launch_test_sobol(hipStream_t, const DTables&, const DSobol&, int, const int*, const int*, const int*, const int*, float*, float*);
+void launch_test_camera(hipStream_t, const DTables&, const DFilter&, const DCamera&, const DSobol&, int, int, const int*, const int*, const int*, float*);
+void launch_test_uplift(hipStream_t, const DTables&, int, int, const float*, const float*, float*);
+void launch_test_light_bvh(hipStream_t, const DScene&, int, const float*, const float*, const float*, int*, float*, const int*, float*);
+}  // namespace hk
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                                          \
+    do {                                                                                                       \
+        hipError_t e_ = (expr);                                                                                \
+        if (e_ != hipSuccess) return fail(HK_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+namespace {
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t n) {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = n;
+        if (n == 0) return hipSuccess;
+        return hipMalloc(&p, n);
+    }
+    hipError_t upload(const void* src, size_t n) {
+        hipError_t e = alloc(n ? n : 4);
+        if (e != hipSuccess) return e;
+        if (n) e = hipMemcpy(p, src, n, hipMemcpyHostToDevice);
+        return e;
+    }
+    template <class T>
+    T* as() const {
+        return reinterpret_cast<T*>(p);
+    }
+};
+}  // namespace
+
+struct hk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int n_cu = 256;
+    DevBuf sobol, cie, r2s_scale, r2s_coeffs, stats;
+    DTables tables{};
+    bool have_tables = false;
+    std::vector<float> h_r2s_scale, h_r2s_coeffs;
+    hk::RGB2Spec r2s_host;
+    int count_nodes = 0, time_kernels = 0;
+    // timing
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_events;
+    std::vector<hipEvent_t> event_pool;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    bool have_span = false;
+    double seconds_trace = 0.0, seconds_total = 0.0;
+    uint64_t trace_launches = 0;
+    DStats host_stats{};
+};
+
+struct hk_scene {
+    hk_ctx* ctx = nullptr;
+    DevBuf nodes, leaf_tris, positions, normals, uvs, tangents, meta, materials, textures, spectra, mis, lights, lnodes, trails, infinite;
+    std::vector<DevBuf*> tex_data;
+    std::vector<DevBuf*> spec_data;
+    DScene d{};
+    uint32_t kinds_mask = 0;
+    int bvh_nodes = 0, bvh_leaf_tris = 0, bvh_depth = 0;
+    hk::LightBVH lbvh;
+    ~hk_scene() {
+        for (auto* b : tex_data) delete b;
+        for (auto* b : spec_data) delete b;
+    }
+};
+
+struct hk_film {
+    hk_ctx* ctx = nullptr;
+    int width = 0, height = 0;
+    bool f64 = false;
+    DevBuf own;
+    void* accum = nullptr;  // device
+    DevBuf readback;
+};
+
+struct hk_integrator {
+    hk_ctx* ctx = nullptr;
+    hk_integrator_params p{};
+    DFilter filter{};
+    DevBuf f_func, f_mcdf, f_mfunc, f_ccdf;
+    // path state (the reference's VolPathState, volpath-state.jl:29-181)
+    DPathState st{};
+    std::vector<DevBuf*> bufs;
+    int st_capacity = 0, st_depth = 0;
+    ~hk_integrator() {
+        for (auto* b : bufs) delete b;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------
+extern "C" const char* hk_last_error(void) { return g_err.c_str(); }
+
+extern "C" int32_t hk_ctx_create(int32_t device_id, void* stream, hk_ctx** out) {
+    if (!out) return fail(HK_ERR_INVALID, "out is null");
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device_id < 0 || device_id >= n) return fail(HK_ERR_INVALID, "bad device id");
+    HIP_TRY(hipSetDevice(device_id));
+    hk_ctx* c = new hk_ctx();
+    c->device = device_id;
+    c->stream = (hipStream_t)stream;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    DStats zero{};
+    HIP_TRY(c->stats.upload(&zero, sizeof zero));
+    HIP_TRY(hipEventCreate(&c->ev_begin));
+    HIP_TRY(hipEventCreate(&c->ev_end));
+    *out = c;
+    return HK_OK;
+}
+extern "C" int32_t hk_ctx_destroy(hk_ctx* c) {
+    if (!c) return HK_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& e : c->trace_events) {
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
+    if (c->ev_end) (void)hipEventDestroy(c->ev_end);
+    delete c;
+    return HK_OK;
+}
+extern "C" int32_t hk_ctx_set_tables(hk_ctx* c, const hk_tables* t) {
+    if (!c || !t || !t->sobol_matrices || t->sobol_count < 104 || !t->cie_x || !t->rgb2spec_coeffs) return fail(HK_ERR_INVALID, "bad tables");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(c->sobol.upload(t->sobol_matrices, 104 * sizeof(uint32_t)));  // only Sobol dims 0,1 are ever read
+    std::vector<float> cie(3 * 471);
+    std::memcpy(&cie[0], t->cie_x, 471 * 4);
+    std::memcpy(&cie[471], t->cie_y, 471 * 4);
+    std::memcpy(&cie[942], t->cie_z, 471 * 4);
+    HIP_TRY(c->cie.upload(cie.data(), cie.size() * 4));
+    int res = t->rgb2spec_res;
+    size_t nco = (size_t)3 * res * res * res * 3;
+    c->h_r2s_scale.assign(t->rgb2spec_scale, t->rgb2spec_scale + res);
+    c->h_r2s_coeffs.assign(t->rgb2spec_coeffs, t->rgb2spec_coeffs + nco);
+    c->r2s_host.res = res;
+    c->r2s_host.scale = c->h_r2s_scale.data();
+    c->r2s_host.coeffs = c->h_r2s_coeffs.data();
+    HIP_TRY(c->r2s_scale.upload(t->rgb2spec_scale, res * 4));
+    HIP_TRY(c->r2s_coeffs.upload(t->rgb2spec_coeffs, nco * 4));
+    c->tables.sobol = c->sobol.as<uint32_t>();
+    c->tables.cie = c->cie.as<float>();
+    c->tables.rgb2spec_scale = c->r2s_scale.as<float>();
+    c->tables.rgb2spec_coeffs = c->r2s_coeffs.as<float>();
+    c->tables.rgb2spec_res = res;
+    c->have_tables = true;
+    return HK_OK;
+}
+
+// ---- constant-colour baking (host float32 arithmetic identical to the device/run-time path) ----------
+namespace {
+inline float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+inline float max3(float a, float b, float c) {
+    float m = a > b ? a : b;
+    return m > c ? m : c;
+}
+void bake_bounded(const hk::RGB2Spec& t, float r, float g, float b, float out[4]) {
+    hk::rgb_to_coeffs(t, r, g, b, out);
+    out[3] = 1.0f;
+}
+void bake_unbounded(const hk::RGB2Spec& t, float r, float g, float b, float out[4]) {  // uplift_rgb_unbounded (uplift.jl:286-308)
+    float m = max3(r, g, b);
+    if (m <= 0.0f) {
+        out[0] = out[1] = out[2] = out[3] = 0.0f;
+        return;
+    }
+    hk::rgb_to_coeffs(t, r / m, g / m, b / m, out);
+    out[3] = m / hk::poly_max(out);
+}
+void bake_illuminant(const hk::RGB2Spec& t, float r, float g, float b, float out[4]) {  // uplift.jl:514-538
+    float m = max3(r, g, b);
+    if (m <= 0.0f) {
+        out[0] = out[1] = out[2] = out[3] = 0.0f;
+        return;
+    }
+    float scale = 2.0f * m;
+    hk::rgb_to_coeffs(t, r / scale, g / scale, b / scale, out);
+    out[3] = scale;
+}
+enum { BAKE_BOUNDED, BAKE_BOUNDED_CLAMP, BAKE_UNBOUNDED };
+int bake_mode(int kind, int slot) {
+    if (kind == HK_MAT_MATTE && slot == 0) return BAKE_BOUNDED_CLAMP;  // clamp(kd_rgb) then uplift_rgb
+    if ((kind == HK_MAT_CONDUCTOR || kind == HK_MAT_COATED_CONDUCTOR) && slot < 2) return BAKE_UNBOUNDED;
+    return BAKE_BOUNDED;
+}
+}  // namespace
+
+extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene** out) {
+    if (!c || !d || !out) return fail(HK_ERR_INVALID, "null argument");
+    if (!c->have_tables) return fail(HK_ERR_INVALID, "hk_ctx_set_tables must be called first");
+    if (d->n_media > 0) return fail(HK_ERR_UNSUPPORTED, "participating media are not built yet (SURVEY 8 rows a27-a30)");
+    if (d->n_envmaps > 0) return fail(HK_ERR_UNSUPPORTED, "environment maps are not built yet (SURVEY 8 row a24)");
+    if (d->n_triangles < 0 || (d->n_triangles > 0 && (!d->positions || !d->meta))) return fail(HK_ERR_INVALID, "bad triangle arrays");
+    HIP_TRY(hipSetDevice(c->device));
+    hk_scene* s = new hk_scene();
+    s->ctx = c;
+    const int T = d->n_triangles;
+    // ---- classify surfaces: opaque = no medium transition and no alpha test possible ----
+    std::vector<uint8_t> mat_alpha(d->n_materials > 0 ? d->n_materials : 1, 0);
+    for (int i = 0; i < d->n_materials; ++i) {
+        const hk_material& m = d->materials[i];
+        if (m.kind == HK_MAT_MATTE && (m.rgb[0].tex >= 0 || m.rgb[0].c[3] < 1.0f)) mat_alpha[i] = 1;
+    }
+    bool all_opaque = true;
+    std::vector<uint8_t> mi_opaque(d->n_media_interfaces > 0 ? d->n_media_interfaces : 1, 1);
+    for (int i = 0; i < d->n_media_interfaces; ++i) {
+        const hk_medium_interface& mi = d->media_interfaces[i];
+        if (mi.material < 0 || mi.material >= d->n_materials) {
+            delete s;
+            return fail(HK_ERR_INVALID, "medium interface references a missing material");
+        }
+        bool op = mi.inside == mi.outside && !mat_alpha[mi.material];
+        mi_opaque[i] = op;
+        if (!op) all_opaque = false;
+    }
+    // ---- BVH ----
+    hk::BVH bvh;
+    hk::build_bvh(d->positions, T, bvh);
+    s->bvh_nodes = (int)bvh.nodes.size();
+    s->bvh_leaf_tris = (int)bvh.leaf_prims.size();
+    s->bvh_depth = bvh.max_depth;
+    std::vector<DNode> dn(bvh.nodes.size() ? bvh.nodes.size() : 1);
+    for (size_t i = 0; i < bvh.nodes.size(); ++i) {
+        const hk::BVHNode& n = bvh.nodes[i];
+        dn[i].a = make_float4(n.lo0[0], n.lo0[1], n.lo0[2], n.hi0[0]);
+        dn[i].b = make_float4(n.hi0[1], n.hi0[2], n.lo1[0], n.lo1[1]);
+        dn[i].c = make_float4(n.lo1[2], n.hi1[0], n.hi1[1], n.hi1[2]);
+        dn[i].c0 = n.c0;
+        dn[i].c1 = n.c1;
+        dn[i].pad0 = dn[i].pad1 = 0;
+    }
+    std::vector<float4> lt(3 * (bvh.leaf_prims.size() ? bvh.leaf_prims.size() : 1));
+    for (size_t i = 0; i < bvh.leaf_prims.size(); ++i) {
+        int prim = bvh.leaf_prims[i];
+        const float* p = d->positions + 9 * (size_t)prim;
+        uint32_t flags = 0;
+        uint32_t mi = d->meta[prim].medium_interface_idx;
+        if ((int)mi >= d->n_media_interfaces) {
+            delete s;
+            return fail(HK_ERR_INVALID, "triangle references a missing medium interface");
+        }
+        if (mi_opaque[mi]) flags |= HK_TRI_OPAQUE;
+        float pw, fw;
+        std::memcpy(&pw, &prim, 4);
+        std::memcpy(&fw, &flags, 4);
+        lt[3 * i + 0] = make_float4(p[0], p[1], p[2], pw);
+        lt[3 * i + 1] = make_float4(p[3] - p[0], p[4] - p[1], p[5] - p[2], fw);  // e1 = v1 - v0
+        lt[3 * i + 2] = make_float4(p[6] - p[0], p[7] - p[1], p[8] - p[2], 0.0f);  // e2 = v2 - v0
+    }
+    HIP_TRY(s->nodes.upload(dn.data(), dn.size() * sizeof(DNode)));
+    HIP_TRY(s->leaf_tris.upload(lt.data(), lt.size() * sizeof(float4)));
+    HIP_TRY(s->positions.upload(d->positions, (size_t)T * 9 * 4));
+    if (d->normals) HIP_TRY(s->normals.upload(d->normals, (size_t)T * 9 * 4));
+    if (d->uvs) HIP_TRY(s->uvs.upload(d->uvs, (size_t)T * 6 * 4));
+    if (d->tangents) HIP_TRY(s->tangents.upload(d->tangents, (size_t)T * 9 * 4));
+    static_assert(sizeof(DTriMeta) == sizeof(hk_tri_meta), "meta layout");
+    HIP_TRY(s->meta.upload(d->meta, (size_t)T * sizeof(hk_tri_meta)));
+    // ---- textures / spectra ----
+    std::vector<DTexture> dt(d->n_textures > 0 ? d->n_textures : 1);
+    for (int i = 0; i < d->n_textures; ++i) {
+        const hk_texture& t = d->textures[i];
+        DevBuf* b = new DevBuf();
+        s->tex_data.push_back(b);
+        HIP_TRY(b->upload(t.data, (size_t)t.width * t.height * t.channels * 4));
+        dt[i].data = b->as<float>();
+        dt[i].width = t.width;
+        dt[i].height = t.height;
+        dt[i].channels = t.channels;
+        dt[i].pad = 0;
+    }
+    HIP_TRY(s->textures.upload(dt.data(), dt.size() * sizeof(DTexture)));
+    std::vector<DPLSpectrum> dsp(d->n_spectra > 0 ? d->n_spectra : 1);
+    for (int i = 0; i < d->n_spectra; ++i) {
+        const hk_pl_spectrum& sp = d->spectra[i];
+        DevBuf* b = new DevBuf();
+        s->spec_data.push_back(b);
+        std::vector<float> both(2 * (size_t)sp.n);
+        std::memcpy(both.data(), sp.lambdas, sp.n * 4);
+        std::memcpy(both.data() + sp.n, sp.values, sp.n * 4);
+        HIP_TRY(b->upload(both.data(), both.size() * 4));
+        dsp[i].lambdas = b->as<float>();
+        dsp[i].values = b->as<float>() + sp.n;
+        dsp[i].n = sp.n;
+        dsp[i].pad = 0;
+    }
+    HIP_TRY(s->spectra.upload(dsp.data(), dsp.size() * sizeof(DPLSpectrum)));
+    // ---- materials: bake constant colours into sigmoid coefficients ----
+    std::vector<DMaterial> dm(d->n_materials > 0 ? d->n_materials : 1);
+    std::memset(dm.data(), 0, dm.size() * sizeof(DMaterial));
+    for (int i = 0; i < d->n_materials; ++i) {
+        const hk_material& m = d->materials[i];
+        DMaterial& o = dm[i];
+        o.kind = (m.kind >= 0 && m.kind <= HK_MAT_FALLBACK) ? m.kind : HK_MAT_FALLBACK;
+        o.flags = m.flags;
+        std::memcpy(o.i, m.i, sizeof o.i);
+        std::memcpy(o.spectrum, m.spectrum, sizeof o.spectrum);
+        std::memcpy(o.mix_key, m.mix_key, sizeof o.mix_key);
+        for (int k = 0; k < 4; ++k) {
+            DSpectrumParam& sp = o.rgb[k];
+            sp.tex = m.rgb[k].tex;
+            std::memcpy(sp.rgba, m.rgb[k].c, 16);
+            float cf[4] = {0, 0, 0, 0};
+            if (sp.tex < 0) {
+                float r = m.rgb[k].c[0], g = m.rgb[k].c[1], b = m.rgb[k].c[2];
+                switch (bake_mode(o.kind, k)) {
+                    case BAKE_BOUNDED_CLAMP:
+                        r = clampf(r, 0.0f, INFINITY);
+                        g = clampf(g, 0.0f, INFINITY);
+                        b = clampf(b, 0.0f, INFINITY);
+                        bake_bounded(c->r2s_host, r, g, b, cf);
+                        break;
+                    case BAKE_UNBOUNDED: bake_unbounded(c->r2s_host, r, g, b, cf); break;
+                    default: bake_bounded(c->r2s_host, r, g, b, cf); break;
+                }
+            }
+            sp.coef = make_float4(cf[0], cf[1], cf[2], cf[3]);
+        }
+        for (int k = 0; k < 8; ++k) {
+            o.f[k] = m.f[k].v;
+            o.ftex[k] = m.f[k].tex;
+        }
+        if (o.kind != HK_MAT_MIX) s->kinds_mask |= 1u << o.kind;
+        if (o.kind > HK_MAT_CONDUCTOR && o.kind != HK_MAT_MIX && o.kind != HK_MAT_FALLBACK) {
+            delete s;
+            return fail(HK_ERR_UNSUPPORTED, "layered / transmissive material kinds are not built yet (SURVEY 8 row a18)");
+        }
+    }
+    HIP_TRY(s->materials.upload(dm.data(), dm.size() * sizeof(DMaterial)));
+    static_assert(sizeof(DMediumInterface) == 16, "mi layout");
+    std::vector<DMediumInterface> dmi(d->n_media_interfaces > 0 ? d->n_media_interfaces : 1);
+    for (int i = 0; i < d->n_media_interfaces; ++i) dmi[i] = DMediumInterface{d->media_interfaces[i].material, d->media_interfaces[i].inside, d->media_interfaces[i].outside, 0};
+    HIP_TRY(s->mis.upload(dmi.data(), dmi.size() * sizeof(DMediumInterface)));
+    // ---- lights ----
+    std::vector<DLight> dl(d->n_lights > 0 ? d->n_lights : 1);
+    std::memset(dl.data(), 0, dl.size() * sizeof(DLight));
+    int has_escape = 0;
+    for (int i = 0; i < d->n_lights; ++i) {
+        const hk_light& l = d->lights[i];
+        DLight& o = dl[i];
+        o.kind = l.kind;
+        o.flags = (l.two_sided ? 1 : 0) | (l.spectrum_kind == HK_SPEC_ILLUMINANT ? 2 : 0);
+        o.scale = l.scale;
+        o.area = l.area;
+        o.Le_tex = -1;
+        float cf[4] = {0, 0, 0, 0};
+        if (l.kind == HK_LIGHT_DIFFUSE_AREA) {
+            o.Le_tex = l.Le.tex;
+            std::memcpy(o.Le_rgba, l.Le.c, 16);
+            if (l.Le.tex < 0) bake_bounded(c->r2s_host, l.Le.c[0] * l.scale, l.Le.c[1] * l.scale, l.Le.c[2] * l.scale, cf);  // uplift_rgb(Le*scale): Q3
+            std::memcpy(o.v, l.v, sizeof o.v);
+            std::memcpy(o.normal, l.normal, sizeof o.normal);
+            std::memcpy(o.uv, l.uv, sizeof o.uv);
+        } else {
+            if (l.spectrum_kind == HK_SPEC_ILLUMINANT) {
+                cf[0] = l.poly[0];
+                cf[1] = l.poly[1];
+                cf[2] = l.poly[2];
+                cf[3] = l.illum_scale;
+            } else
+                bake_illuminant(c->r2s_host, l.i_rgb[0], l.i_rgb[1], l.i_rgb[2], cf);
+            if (l.kind == HK_LIGHT_POINT || l.kind == HK_LIGHT_SPOT) std::memcpy(o.p, l.position, 12);
+            if (l.kind == HK_LIGHT_DIRECTIONAL || l.kind == HK_LIGHT_SUN) std::memcpy(o.p, l.direction, 12);
+            if (l.kind == HK_LIGHT_SPOT) {
+                const float* m = l.world_to_light;
+                float rows[9] = {m[0], m[1], m[2], m[4], m[5], m[6], m[8], m[9], m[10]};
+                std::memcpy(o.v, rows, sizeof rows);
+                o.cos_total_width = l.cos_total_width;
+                o.cos_falloff_start = l.cos_falloff_start;
+            }
+            if (l.kind == HK_LIGHT_AMBIENT || l.kind == HK_LIGHT_ENVIRONMENT) has_escape = 1;
+        }
+        o.coef = make_float4(cf[0], cf[1], cf[2], cf[3]);
+    }
+    HIP_TRY(s->lights.upload(dl.data(), dl.size() * sizeof(DLight)));
+    hk::build_light_bvh(d->lights, d->n_lights, s->lbvh);
+    static_assert(sizeof(DLightNode) == sizeof(hk::LightBVHNodeH) && sizeof(DLightNode) == 64, "light node layout");
+    {
+        std::vector<hk::LightBVHNodeH> tmp = s->lbvh.nodes;
+        if (tmp.empty()) tmp.resize(1);
+        HIP_TRY(s->lnodes.upload(tmp.data(), tmp.size() * sizeof(hk::LightBVHNodeH)));
+        std::vector<uint32_t> tr = s->lbvh.bit_trails;
+        if (tr.empty()) tr.resize(1);
+        HIP_TRY(s->trails.upload(tr.data(), tr.size() * 4));
+        std::vector<int32_t> inf = s->lbvh.infinite;
+        if (inf.empty()) inf.resize(1);
+        HIP_TRY(s->infinite.upload(inf.data(), inf.size() * 4));
+    }
+    DScene& D = s->d;
+    D.nodes = s->nodes.as<DNode>();
+    D.leaf_tris = s->leaf_tris.as<float4>();
+    D.root_ref = bvh.root_ref;
+    D.n_tris = T;
+    D.positions = s->positions.as<float>();
+    D.normals = d->normals ? s->normals.as<float>() : nullptr;
+    D.uvs = d->uvs ? s->uvs.as<float>() : nullptr;
+    D.tangents = d->tangents ? s->tangents.as<float>() : nullptr;
+    D.meta = s->meta.as<DTriMeta>();
+    D.materials = s->materials.as<DMaterial>();
+    D.textures = s->textures.as<DTexture>();
+    D.spectra = s->spectra.as<DPLSpectrum>();
+    D.mis = s->mis.as<DMediumInterface>();
+    D.lights = s->lights.as<DLight>();
+    D.n_lights = d->n_lights;
+    D.n_materials = d->n_materials;
+    D.lnodes = s->lnodes.as<DLightNode>();
+    D.bit_trails = s->trails.as<uint32_t>();
+    D.infinite_lights = s->infinite.as<int>();
+    D.num_bvh_lights = s->lbvh.num_bvh;
+    D.num_infinite_lights = (int)s->lbvh.infinite.size();
+    D.has_escape_lights = has_escape;
+    D.all_opaque = all_opaque ? 1 : 0;
+    *out = s;
+    return HK_OK;
+}
+extern "C" int32_t hk_scene_destroy(hk_scene* s) {
+    if (s) {
+        (void)hipSetDevice(s->ctx->device);
+        (void)hipStreamSynchronize(s->ctx->stream);
+        delete s;
+    }
+    return HK_OK;
+}
+extern "C" int32_t hk_scene_bvh_info(hk_scene* s, int32_t* n_nodes, int32_t* n_leaf_tris, int32_t* max_depth) {
+    if (!s) return fail(HK_ERR_INVALID, "null scene");
+    if (n_nodes) *n_nodes = s->bvh_nodes;
+    if (n_leaf_tris) *n_leaf_tris = s->bvh_leaf_tris;
+    if (max_depth) *max_depth = s->bvh_depth;
+    return HK_OK;
+}
+extern "C" int32_t hk_scene_light_bvh_copy(hk_scene* s, int32_t* n_nodes, float* nodes_out, uint32_t* bit_trails) {
+    if (!s || !n_nodes) return fail(HK_ERR_INVALID, "null argument");
+    *n_nodes = (int32_t)s->lbvh.nodes.size();
+    if (nodes_out)
+        for (size_t i = 0; i < s->lbvh.nodes.size(); ++i) {
+            const hk::LightBVHNodeH& n = s->lbvh.nodes[i];
+            float* o = nodes_out + 16 * i;
+            std::memcpy(o, n.bmin, 12);
+            std::memcpy(o + 3, n.bmax, 12);
+            std::memcpy(o + 6, n.w, 12);
+            o[9] = n.phi;
+            o[10] = n.cos_o;
+            o[11] = n.cos_e;
+            o[12] = (n.bits & 1u) ? 1.0f : 0.0f;
+            o[13] = (float)n.child1_or_light;
+            o[14] = (n.bits & 2u) ? 1.0f : 0.0f;
+            o[15] = 0.0f;
+        }
+    if (bit_trails)
+        for (size_t i = 0; i < s->lbvh.bit_trails.size(); ++i) bit_trails[i] = s->lbvh.bit_trails[i];
+    return HK_OK;
+}
+
+// ---- integrator: filter tabulation (GPUFilterSamplerData, filter.jl:636-725) -------------------------
+namespace {
+float gaussian_1d(float x, float sigma) { return std::exp(-(x * x) / (2.0f * (sigma * sigma))); }
+float mitchell_1d(float x, float B, float C) {
+    x = std::fabs(x);
+    if (x <= 1.0f) return ((12.0f - 9.0f * B - 6.0f * C) * (x * x * x) + (-18.0f + 12.0f * B + 6.0f * C) * (x * x) + (6.0f - 2.0f * B)) / 6.0f;
+    if (x <= 2.0f) return ((-B - 6.0f * C) * (x * x * x) + (6.0f * B + 30.0f * C) * (x * x) + (-12.0f * B - 48.0f * C) * x + (8.0f * B + 24.0f * C)) / 6.0f;
+    return 0.0f;
+}
+float sinc1(float x) {
+    x = std::fabs(x);
+    if (x < 1e-5f) return 1.0f;
+    x *= 3.14159265358979323846f;
+    return std::sin(x) / x;
+}
+float wsinc(float x, float r, float tau) {
+    x = std::fabs(x);
+    if (x > r) return 0.0f;
+    return sinc1(x) * sinc1(x / tau);
+}
+float filter_eval(const hk_integrator_params& p, float ex, float ey, float x, float y) {
+    float rx = p.filter_radius[0], ry = p.filter_radius[1];
+    switch (p.filter_type) {
+        case HK_FILTER_BOX: return (std::fabs(x) <= rx && std::fabs(y) <= ry) ? 1.0f : 0.0f;
+        case HK_FILTER_TRIANGLE: return std::fmax(0.0f, rx - std::fabs(x)) * std::fmax(0.0f, ry - std::fabs(y));
+        case HK_FILTER_GAUSSIAN: return std::fmax(0.0f, gaussian_1d(x, p.filter_param1) - ex) * std::fmax(0.0f, gaussian_1d(y, p.filter_param1) - ey);
+        case HK_FILTER_MITCHELL: return mitchell_1d(2.0f * x / rx, p.filter_param1, p.filter_param2) * mitchell_1d(2.0f * y / ry, p.filter_param1, p.filter_param2);
+        case HK_FILTER_LANCZOS: return wsinc(x, rx, p.filter_param1) * wsinc(y, ry, p.filter_param1);
+    }
+    return 0.0f;
+}
+}  // namespace
+
+extern "C" int32_t hk_integrator_create(hk_ctx* c, const hk_integrator_params* p, hk_integrator** out) {
+    if (!c || !p || !out) return fail(HK_ERR_INVALID, "null argument");
+    if (p->max_depth < 1 || p->max_depth > 255) return fail(HK_ERR_INVALID, "max_depth must be in 1..255");
+    if (p->filter_type < HK_FILTER_BOX || p->filter_type > HK_FILTER_LANCZOS) return fail(HK_ERR_INVALID, "bad filter type");
+    if (p->material_coherence < 0 || p->material_coherence > 2) return fail(HK_ERR_INVALID, "material_coherence must be :none, :sorted, :per_type");
+    HIP_TRY(hipSetDevice(c->device));
+    hk_integrator* I = new hk_integrator();
+    I->ctx = c;
+    I->p = *p;
+    DFilter& f = I->filter;
+    f.type = p->filter_type;
+    f.rx = p->filter_radius[0];
+    f.ry = p->filter_radius[1];
+    f.p1 = p->filter_param1;
+    f.p2 = p->filter_param2;
+    if (f.type != HK_FILTER_BOX && f.type != HK_FILTER_TRIANGLE) {
+        float ex = 0, ey = 0;
+        if (f.type == HK_FILTER_GAUSSIAN) {
+            ex = gaussian_1d(f.rx, f.p1);
+            ey = gaussian_1d(f.ry, f.p1);
+        }
+        int nx = (int)std::ceil(32 * f.rx), ny = (int)std::ceil(32 * f.ry);
+        if (nx < 8) nx = 8;
+        if (ny < 8) ny = 8;
+        float dmin_x = -f.rx, dmin_y = -f.ry, dmax_x = f.rx, dmax_y = f.ry;
+        float dx = (dmax_x - dmin_x) / (float)nx, dy = (dmax_y - dmin_y) / (float)ny;
+        std::vector<float> func((size_t)nx * ny), mfunc(ny, 0.0f), mcdf(ny + 1, 0.0f), ccdf((size_t)ny * (nx + 1), 0.0f);
+        for (int iy = 1; iy <= ny; ++iy)
+            for (int ix = 1; ix <= nx; ++ix) {
+                float px = dmin_x + ((float)ix - 0.5f) * dx, py = dmin_y + ((float)iy - 0.5f) * dy;
+                float v = filter_eval(*p, ex, ey, px, py);
+                func[(size_t)(iy - 1) * nx + ix - 1] = v > 0.0f ? v : 0.0f;
+            }
+        for (int iy = 0; iy < ny; ++iy)
+            for (int ix = 0; ix < nx; ++ix) mfunc[iy] += func[(size_t)iy * nx + ix];
+        for (int iy = 0; iy < ny; ++iy) mcdf[iy + 1] = mcdf[iy] + mfunc[iy];
+        float func_integral = mcdf[ny] * dx * dy;
+        float end = mcdf[ny];
+        if (end > 0.0f)
+            for (auto& v : mcdf) v /= end;
+        else
+            for (int iy = 0; iy <= ny; ++iy) mcdf[iy] = (float)iy / (float)ny;
+        for (int iy = 0; iy < ny; ++iy) {
+            float* row = &ccdf[(size_t)iy * (nx + 1)];
+            for (int ix = 0; ix < nx; ++ix) row[ix + 1] = row[ix] + func[(size_t)iy * nx + ix];
+            float rs = row[nx];
+            if (rs > 0.0f)
+                for (int ix = 0; ix <= nx; ++ix) row[ix] /= rs;
+            else
+                for (int ix = 0; ix <= nx; ++ix) row[ix] = (float)ix / (float)nx;
+        }
+        HIP_TRY(I->f_func.upload(func.data(), func.size() * 4));
+        HIP_TRY(I->f_mcdf.upload(mcdf.data(), mcdf.size() * 4));
+        HIP_TRY(I->f_mfunc.upload(mfunc.data(), mfunc.size() * 4));
+        HIP_TRY(I->f_ccdf.upload(ccdf.data(), ccdf.size() * 4));
+        f.nx = nx;
+        f.ny = ny;
+        f.func = I->f_func.as<float>();
+        f.marginal_cdf = I->f_mcdf.as<float>();
+        f.marginal_func = I->f_mfunc.as<float>();
+        f.conditional_cdf = I->f_ccdf.as<float>();
+        f.dmin_x = dmin_x;
+        f.dmin_y = dmin_y;
+        f.dmax_x = dmax_x;
+        f.dmax_y = dmax_y;
+        f.func_integral = func_integral;
+    }
+    *out = I;
+    return HK_OK;
+}
+extern "C" int32_t hk_integrator_destroy(hk_integrator* I) {
+    if (I) {
+        (void)hipSetDevice(I->ctx->device);
+        (void)hipStreamSynchronize(I->ctx->stream);
+        delete I;
+    }
+    return HK_OK;
+}
+
+// ---- film ---------------------------------------------------------------------------------------------
+extern "C" int32_t hk_film_create(hk_ctx* c, int32_t w, int32_t h, int32_t f64, void* external, hk_film** out) {
+    if (!c || !out || w < 1 || h < 1) return fail(HK_ERR_INVALID, "bad film arguments");
+    HIP_TRY(hipSetDevice(c->device));
+    hk_film* f = new hk_film();
+    f->ctx = c;
+    f->width = w;
+    f->height = h;
+    f->f64 = f64 != 0;
+    size_t bytes = (size_t)4 * w * h * (f64 ? 8 : 4);
+    if (external)
+        f->accum = external;
+    else {
+        HIP_TRY(f->own.alloc(bytes));
+        f->accum = f->own.p;
+        HIP_TRY(hipMemsetAsync(f->accum, 0, bytes, c->stream));
+    }
+    *out = f;
+    return HK_OK;
+}
+extern "C" int32_t hk_film_destroy(hk_film* f) {
+    if (f) {
+        (void)hipSetDevice(f->ctx->device);
+        (void)hipStreamSynchronize(f->ctx->stream);
+        delete f;
+    }
+    return HK_OK;
+}
+extern "C" int32_t hk_film_clear(hk_film* f) {
+    if (!f) return fail(HK_ERR_INVALID, "null film");
+    HIP_TRY(hipSetDevice(f->ctx->device));
+    HIP_TRY(hipMemsetAsync(f->accum, 0, (size_t)4 * f->width * f->height * (f->f64 ? 8 : 4), f->ctx->stream));
+    return HK_OK;
+}
+extern "C" void* hk_film_accum_device_ptr(hk_film* f) { return f ? f->accum : nullptr; }
+extern "C" int32_t hk_film_read_accum(hk_ctx* c, hk_film* f, void* out) {
+    if (!c || !f || !out) return fail(HK_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(out, f->accum, (size_t)4 * f->width * f->height * (f->f64 ? 8 : 4), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return HK_OK;
+}
+extern "C" int32_t hk_film_read_rgb(hk_ctx* c, hk_film* f, float* out) {
+    if (!c || !f || !out) return fail(HK_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    size_t bytes = (size_t)3 * f->width * f->height * 4;
+    if (f->readback.bytes != bytes) HIP_TRY(f->readback.alloc(bytes));
+    hk::launch_finalize(c->stream, f->accum, f->f64, f->readback.as<float>(), f->width, f->height);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, f->readback.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return HK_OK;
+}
+
+// ---- path state -----------------------------------------------------------------------------------------
+namespace {
+template <class T>
+hipError_t alloc_arr(hk_integrator* I, T*& dst, size_t n) {
+    DevBuf* b = new DevBuf();
+    I->bufs.push_back(b);
+    hipError_t e = b->alloc(n * sizeof(T));
+    dst = b->as<T>();
+    return e;
+}
+int ensure_state(hk_integrator* I, int capacity) {
+    if (I->st_capacity >= capacity && I->st_depth >= I->p.max_depth) return HK_OK;
+    for (auto* b : I->bufs) delete b;
+    I->bufs.clear();
+    DPathState& s = I->st;
+    size_t P = (size_t)capacity;
+    s.capacity = capacity;
+    HIP_TRY(alloc_arr(I, s.ray_o, P));
+    HIP_TRY(alloc_arr(I, s.ray_d, P));
+    HIP_TRY(alloc_arr(I, s.hit, P));
+    HIP_TRY(alloc_arr(I, s.mat_id, P));
+    HIP_TRY(alloc_arr(I, s.lambda, P));
+    HIP_TRY(alloc_arr(I, s.pdf, P));
+    HIP_TRY(alloc_arr(I, s.beta, P));
+    HIP_TRY(alloc_arr(I, s.r_u, P));
+    HIP_TRY(alloc_arr(I, s.r_l, P));
+    HIP_TRY(alloc_arr(I, s.L, P));
+    HIP_TRY(alloc_arr(I, s.flags, P));
+    HIP_TRY(alloc_arr(I, s.filter_w, P));
+    HIP_TRY(alloc_arr(I, s.sh_o, P));
+    HIP_TRY(alloc_arr(I, s.sh_d, P));
+    HIP_TRY(alloc_arr(I, s.sh_Ld, P));
+    HIP_TRY(alloc_arr(I, s.sh_ru, P));
+    HIP_TRY(alloc_arr(I, s.sh_rl, P));
+    HIP_TRY(alloc_arr(I, s.ray_q[0], P));
+    HIP_TRY(alloc_arr(I, s.ray_q[1], P));
+    HIP_TRY(alloc_arr(I, s.shadow_q, P));
+    HIP_TRY(alloc_arr(I, s.escaped_q, P));
+    HIP_TRY(alloc_arr(I, s.mat_q, P * HK_MAX_KINDS));
+    size_t nc = (size_t)(I->p.max_depth + 2) * Q_COUNT;
+    int* both = nullptr;
+    HIP_TRY(alloc_arr(I, both, 2 * nc));
+    s.counters = both;
+    s.cursors = both + nc;
+    I->st_capacity = capacity;
+    I->st_depth = I->p.max_depth;
+    return HK_OK;
+}
+int ceil_log2(long v) {
+    int l = 0;
+    while ((1L << l) < v) ++l;
+    return l;
+}
+DSobol make_sobol(const hk_integrator_params& p, int w, int h) {  // compute_zsobol_params, sobol.jl:317-323; volpath.jl:475
+    DSobol s;
+    int spp = p.samples_per_pixel > 4096 ? p.samples_per_pixel : 4096;
+    s.log2_spp = ceil_log2(spp < 1 ? 1 : spp);
+    int res_log2 = ceil_log2(w > h ? w : h);
+    s.n_base4_digits = res_log2 + (s.log2_spp + 1) / 2;
+    s.seed = p.sampler_seed;
+    s.width = w;
+    return s;
+}
+DCamera make_camera(const hk_camera& c) {
+    DCamera d;
+    std::memcpy(d.r2c, c.raster_to_camera, 64);
+    std::memcpy(d.c2w, c.camera_to_world, 64);
+    d.lens_radius = c.lens_radius;
+    d.focal_distance = c.focal_distance;
+    d.shutter_open = c.shutter_open;
+    d.shutter_close = c.shutter_close;
+    return d;
+}
+hipEvent_t get_event(hk_ctx* c) {
+    if (!c->event_pool.empty()) {
+        hipEvent_t e = c->event_pool.back();
+        c->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+}  // namespace
+
+extern "C" int32_t hk_render(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_film* film, const hk_camera* cam, int32_t first_sample_idx, int32_t n_samples,
+                             int32_t sample_stride) {
+    if (!c || !sc || !I || !film || !cam) return fail(HK_ERR_INVALID, "null argument");
+    if (n_samples < 0 || sample_stride < 1 || first_sample_idx < 1) return fail(HK_ERR_INVALID, "bad sample range");
+    if (film->f64 != (I->p.accumulate_f64 != 0)) return fail(HK_ERR_INVALID, "film / integrator accumulation type mismatch");
+    if (n_samples == 0) return HK_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    const int W = film->width, H = film->height;
+    DFrame fr{};
+    fr.width = W;
+    fr.height = H;
+    fr.tiles_x = (W + 7) / 8;
+    fr.tiles_y = (H + 7) / 8;
+    fr.n_pixels_padded = fr.tiles_x * fr.tiles_y * 64;
+    int S = I->p.samples_per_pass;
+    if (S <= 0) {
+        S = (int)(3000000L / fr.n_pixels_padded);
+        if (S < 1) S = 1;
+        if (S > 16) S = 16;
+    }
+    if (S > n_samples) S = n_samples;
+    if ((long)S * fr.n_pixels_padded > 0x3fffffffL) return fail(HK_ERR_INVALID, "pass too large");
+    int st = ensure_state(I, S * fr.n_pixels_padded);
+    if (st != HK_OK) return st;
+    fr.sample_stride = sample_stride;
+    fr.max_depth = I->p.max_depth;
+    fr.regularize = I->p.regularize;
+    fr.max_component_value = I->p.max_component_value;
+    fr.count_nodes = c->count_nodes;
+    DSobol sob = make_sobol(I->p, W, H);
+    DCamera dc = make_camera(*cam);
+    DStats* dstats = c->stats.as<DStats>();
+    const int trace_blocks = c->n_cu * 4, shade_blocks = c->n_cu * 4, light_blocks = c->n_cu * 4;
+    const size_t counter_bytes = (size_t)2 * (I->p.max_depth + 2) * Q_COUNT * sizeof(int);
+    hipStream_t s = c->stream;
+    if (!c->have_span) {
+        HIP_TRY(hipEventRecord(c->ev_begin, s));
+        c->have_span = true;
+    }
+    int done = 0;
+    while (done < n_samples) {
+        int k = n_samples - done < S ? n_samples - done : S;
+        fr.samples_in_pass = k;
+        fr.first_sample = first_sample_idx + done * sample_stride;
+        HIP_TRY(hipMemsetAsync(I->st.counters, 0, counter_bytes, s));
+        hk::launch_camera(s, I->st, fr, c->tables, I->filter, dc, sob, -1);
+        for (int depth = 0; depth < I->p.max_depth; ++depth) {
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (c->time_kernels) {
+                e0 = get_event(c);
+                e1 = get_event(c);
+                HIP_TRY(hipEventRecord(e0, s));
+            }
+            hk::launch_trace(s, trace_blocks, I->st, sc->d, c->tables, fr, depth, dstats);
+            if (c->time_kernels) {
+                HIP_TRY(hipEventRecord(e1, s));
+                c->trace_events.emplace_back(e0, e1);
+            }
+            c->trace_launches++;
+            if (sc->d.has_escape_lights) hk::launch_escaped(s, light_blocks, I->st, sc->d, c->tables, depth);
+            for (int kind = 0; kind < HK_MAX_KINDS; ++kind)
+                if (sc->kinds_mask & (1u << kind)) hk::launch_shade(s, shade_blocks, kind, I->st, sc->d, c->tables, fr, sob, depth, dstats);
+            if (sc->d.n_lights > 0) hk::launch_shadow(s, trace_blocks, I->st, sc->d, c->tables, fr, depth, dstats);
+        }
+        hk::launch_film(s, I->st, fr, c->tables, film->accum, film->f64);
+        done += k;
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev_end, s));
+    return HK_OK;
+}
+
+extern "C" int32_t hk_sync(hk_ctx* c) {
+    if (!c) return fail(HK_ERR_INVALID, "null ctx");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return HK_OK;
+}
+extern "C" int32_t hk_stats_enable_counters(hk_ctx* c, int32_t flags) {
+    if (!c) return fail(HK_ERR_INVALID, "null ctx");
+    c->count_nodes = (flags & 1) ? 1 : 0;
+    c->time_kernels = (flags & 2) ? 1 : 0;
+    return HK_OK;
+}
+extern "C" int32_t hk_stats_reset(hk_ctx* c) {
+    if (!c) return fail(HK_ERR_INVALID, "null ctx");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemset(c->stats.p, 0, sizeof(DStats)));
+    for (auto& e : c->trace_events) {
+        c->event_pool.push_back(e.first);
+        c->event_pool.push_back(e.second);
+    }
+    c->trace_events.clear();
+    c->seconds_trace = c->seconds_total = 0.0;
+    c->trace_launches = 0;
+    c->have_span = false;
+    return HK_OK;
+}
+extern "C" int32_t hk_stats_get(hk_ctx* c, hk_stats* out) {
+    if (!c || !out) return fail(HK_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    DStats h;
+    HIP_TRY(hipMemcpy(&h, c->stats.p, sizeof h, hipMemcpyDeviceToHost));
+    double tr = 0.0;
+    for (auto& e : c->trace_events) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) tr += ms * 1e-3;
+    }
+    double total = 0.0;
+    if (c->have_span) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, c->ev_begin, c->ev_end) == hipSuccess) total = ms * 1e-3;
+    }
+    std::memset(out, 0, sizeof *out);
+    out->rays_closest = h.rays_closest;
+    out->rays_shadow = h.rays_shadow;
+    out->bvh_nodes_visited = h.nodes;
+    out->tris_tested = h.tris;
+    out->hits_accepted = h.hits;
+    out->path_vertices = h.vertices;
+    out->medium_collisions = h.collisions;
+    out->light_bvh_nodes = h.light_nodes;
+    out->seconds_trace = tr;
+    out->seconds_total = total;
+    out->trace_launches = c->trace_launches;
+    return HK_OK;
+}
+
+// ---- sub-kernel entry points --------------------------------------------------------------------------
+namespace {
+struct Tmp {
+    std::vector<void*> ptrs;
+    ~Tmp() {
+        for (void* p : ptrs) (void)hipFree(p);
+    }
+    template <class T>
+    T* up(const T* src, size_t n) {
+        void* p = nullptr;
+        if (hipMalloc(&p, (n ? n : 1) * sizeof(T)) != hipSuccess) return nullptr;
+        ptrs.push_back(p);
+        if (src && n) (void)hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice);
+        return (T*)p;
+    }
+};
+}  // namespace
+
+extern "C" int32_t hk_trace_closest(hk_ctx* c, hk_scene* sc, int32_t n, const float* o3, const float* d3, const float* tmax, float* out_t, int32_t* out_prim,
+                                    float* out_uv2) {
+    if (!c || !sc || n < 0) return fail(HK_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    Tmp t;
+    float *o = t.up(o3, 3 * (size_t)n), *d = t.up(d3, 3 * (size_t)n), *tm = t.up(tmax, n);
+    float* ot = t.up<float>(nullptr, n);
+    int* op = t.up<int>(nullptr, n);
+    float* ouv = t.up<float>(nullptr, 2 * (size_t)n);
+    if (!o || !d || !tm || !ot || !op || !ouv) return fail(HK_ERR_DEVICE, "hipMalloc failed");
+    hk::launch_test_trace(c->stream, sc->d, n, o, d, tm, ot, op, ouv);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out_t, ot, n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_prim, op, n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_uv2, ouv, 2 * (size_t)n * 4, hipMemcpyDeviceToHost));
+    return HK_OK;
+}
+extern "C" int32_t hk_test_sobol(hk_ctx* c, int32_t width, int32_t height, int32_t spp, uint32_t seed, int32_t n, const int32_t* px, const int32_t* py,
+                                 const int32_t* sample_idx, const int32_t* dim, float* out_1d, float* out_2d) {
+    if (!c || !c->have_tables) return fail(HK_ERR_INVALID, "tables not set");
+    HIP_TRY(hipSetDevice(c->device));
+    hk_integrator_params p{};
+    p.samples_per_pixel = spp;
+    p.sampler_seed = seed;
+    DSobol sob;
+    sob.log2_spp = ceil_log2(spp < 1 ? 1 : spp);
+    sob.n_base4_digits = ceil_log2(width > height ? width : height) + (sob.log2_spp + 1) / 2;
+    sob.seed = seed;
+    sob.width = width;
+    Tmp t;
+    int *a = t.up(px, n), *b = t.up(py, n), *s = t.up(sample_idx, n), *dm = t.up(dim, n);
+    float *o1 = t.up<float>(nullptr, n), *o2 = t.up<float>(nullptr, 2 * (size_t)n);
+    hk::launch_test_sobol(c->stream, c->tables, sob, n, a, b, s, dm, o1, o2);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out_1d, o1, n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_2d, o2, 2 * (size_t)n * 4, hipMemcpyDeviceToHost));
+    return HK_OK;
+}
+extern "C" int32_t hk_test_camera(hk_ctx* c, hk_integrator* I, const hk_camera* cam, int32_t width, int32_t height, int32_t n, const int32_t* px, const int32_t* py,
+                                  const int32_t* sample_idx, float* out15) {
+    if (!c || !I || !cam) return fail(HK_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    DSobol sob = make_sobol(I->p, width, height);
+    DCamera dc = make_camera(*cam);
+    Tmp t;
+    int *a = t.up(px, n), *b = t.up(py, n), *s = t.up(sample_idx, n);
+    float* o = t.up<float>(nullptr, 15 * (size_t)n);
+    hk::launch_test_camera(c->stream, c->tables, I->filter, dc, sob, height, n, a, b, s, o);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out15, o, 15 * (size_t)n * 4, hipMemcpyDeviceToHost));
+    return HK_OK;
+}
+extern "C" int32_t hk_test_uplift(hk_ctx* c, int32_t mode, int32_t n, const float* rgb, const float* lambda, float* out) {
+    if (!c || !c->have_tables) return fail(HK_ERR_INVALID, "tables not set");
+    HIP_TRY(hipSetDevice(c->device));
+    Tmp t;
+    float *r = t.up(rgb, 3 * (size_t)n), *l = t.up(lambda, 4 * (size_t)n), *o = t.up<float>(nullptr, 4 * (size_t)n);
+    hk::launch_test_uplift(c->stream, c->tables, mode, n, r, l, o);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out, o, 4 * (size_t)n * 4, hipMemcpyDeviceToHost));
+    return HK_OK;
+}
+extern "C" int32_t hk_test_light_bvh(hk_ctx* c, hk_scene* sc, int32_t n, const float* p3, const float* n3, const float* u, int32_t* out_light, float* out_pmf,
+                                     const int32_t* query_light, float* out_query_pmf) {
+    if (!c || !sc) return fail(HK_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    Tmp t;
+    float *p = t.up(p3, 3 * (size_t)n), *nn = t.up(n3, 3 * (size_t)n), *uu = t.up(u, n);
+    int* ol = t.up<int>(nullptr, n);
+    float* op = t.up<float>(nullptr, n);
+    int* q = query_light ? t.up(query_light, n) : nullptr;
+    float* oq = t.up<float>(nullptr, n);
+    hk::launch_test_light_bvh(c->stream, sc->d, n, p, nn, uu, ol, op, q, oq);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out_light, ol, n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_pmf, op, n * 4, hipMemcpyDeviceToHost));
+    if (query_light && out_query_pmf) HIP_TRY(hipMemcpy(out_query_pmf, oq, n * 4, hipMemcpyDeviceToHost));
+    return HK_OK;
+}

@@ -1,0 +1,1257 @@
+// hk_device.h — device functions of the MI355X VolPath path (gfx950, wave64).
+//
+// Everything here is strict binary32 in the evaluation order of the Julia source it replaces (the
+// translation unit is built with -ffp-contract=off; the only fused operations are the explicit
+// fmaf() calls in the BVH slab test, which is result-neutral culling).  Reference lines are cited
+// per function; behaviour quirks are the ones SURVEY.md §8-Q lists.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "hk_types.h"
+
+#define HKD __device__ __forceinline__
+
+namespace hkd {
+
+static constexpr float PI_F = 3.14159265358979323846f;
+static constexpr float INF_F = __builtin_huge_valf();
+
+struct v3 {
+    float x, y, z;
+};
+struct v2 {
+    float x, y;
+};
+HKD v3 mk3(float x, float y, float z) { return v3{x, y, z}; }
+HKD v2 mk2(float x, float y) { return v2{x, y}; }
+HKD v3 operator+(v3 a, v3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+HKD v3 operator-(v3 a, v3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+HKD v3 operator-(v3 a) { return mk3(-a.x, -a.y, -a.z); }
+HKD v3 operator*(v3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+HKD v3 operator*(float s, v3 a) { return mk3(s * a.x, s * a.y, s * a.z); }
+HKD v3 operator/(v3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
+HKD float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+HKD v3 cross(v3 a, v3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+HKD float norm(v3 a) { return sqrtf(dot(a, a)); }
+HKD v3 normalize(v3 a) { return (1.0f / norm(a)) * a; }  // StaticArrays: inv(norm(a)) * a
+HKD bool is_zero(v3 a) { return a.x == 0.0f && a.y == 0.0f && a.z == 0.0f; }
+HKD float comp(v3 a, int k) { return k == 0 ? a.x : (k == 1 ? a.y : a.z); }
+
+HKD float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+HKD float maxf(float a, float b) { return a > b ? a : b; }
+HKD float minf(float a, float b) { return a < b ? a : b; }
+HKD int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+HKD float lerpf(float v1, float v2, float t) { return (1.0f - t) * v1 + t * v2; }  // spectrum.jl:33
+
+// SampledSpectrum{4}  (spectral/spectral.jl:10-111)
+struct S4 {
+    float x, y, z, w;
+};
+HKD S4 s4(float a) { return S4{a, a, a, a}; }
+HKD S4 s4(float a, float b, float c, float d) { return S4{a, b, c, d}; }
+HKD S4 ld4(const float4* p) {
+    float4 v = *p;
+    return S4{v.x, v.y, v.z, v.w};
+}
+HKD void st4(float4* p, S4 s) { *p = make_float4(s.x, s.y, s.z, s.w); }
+HKD S4 operator+(S4 a, S4 b) { return S4{a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
+HKD S4 operator-(S4 a, S4 b) { return S4{a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w}; }
+HKD S4 operator*(S4 a, S4 b) { return S4{a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w}; }
+HKD S4 operator/(S4 a, S4 b) { return S4{a.x / b.x, a.y / b.y, a.z / b.z, a.w / b.w}; }
+HKD S4 operator*(S4 a, float s) { return S4{a.x * s, a.y * s, a.z * s, a.w * s}; }
+HKD S4 operator*(float s, S4 a) { return a * s; }
+HKD S4 operator/(S4 a, float s) { return S4{a.x / s, a.y / s, a.z / s, a.w / s}; }
+HKD float average(S4 s) { return (((s.x + s.y) + s.z) + s.w) / 4.0f; }
+HKD float max_component(S4 s) { return maxf(maxf(maxf(s.x, s.y), s.z), s.w); }
+HKD bool is_black(S4 s) { return s.x == 0.0f && s.y == 0.0f && s.z == 0.0f && s.w == 0.0f; }
+HKD float at(S4 s, int i) { return i == 0 ? s.x : (i == 1 ? s.y : (i == 2 ? s.z : s.w)); }
+
+// ------------------------------------------------------------------------------------------------
+// hashes / RNG  (materials/spectral-eval.jl:575-815)
+// ------------------------------------------------------------------------------------------------
+HKD uint64_t mix_bits(uint64_t v) {
+    v ^= v >> 31;
+    v *= 0x7fb5d329728ea185ull;
+    v ^= v >> 27;
+    v *= 0x81dadef4bc2dd44dull;
+    v ^= v >> 33;
+    return v;
+}
+// MurmurHash64A over little-endian 32-bit words (all call sites hash 4-byte multiples)
+template <int NWORDS>
+HKD uint64_t murmur64a_words(const uint32_t* w) {
+    const uint64_t m = 0xc6a4a7935bd1e995ull;
+    const int r = 47;
+    uint64_t h = 0ull ^ ((uint64_t)(NWORDS * 4) * m);
+#pragma unroll
+    for (int i = 0; i < NWORDS / 2; ++i) {
+        uint64_t k = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
+        k *= m;
+        k ^= k >> r;
+        k *= m;
+        h ^= k;
+        h *= m;
+    }
+    if (NWORDS & 1) {  // 4 trailing bytes: the switch fall-through xors bytes 3..0, multiplies once
+        h ^= (uint64_t)w[NWORDS - 1];
+        h *= m;
+    }
+    h ^= h >> r;
+    h *= m;
+    h ^= h >> r;
+    return h;
+}
+HKD uint64_t pbrt_hash(v3 v) {
+    uint32_t w[3] = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z)};
+    return murmur64a_words<3>(w);
+}
+HKD uint64_t pbrt_hash(uint64_t seed, v3 v) {
+    uint32_t w[5] = {(uint32_t)seed, (uint32_t)(seed >> 32), __float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z)};
+    return murmur64a_words<5>(w);
+}
+HKD uint64_t pbrt_hash(float a, v2 p) {
+    uint32_t w[3] = {__float_as_uint(a), __float_as_uint(p.x), __float_as_uint(p.y)};
+    return murmur64a_words<3>(w);
+}
+struct PCG32 {
+    uint64_t state, inc;
+};
+HKD PCG32 pcg32_init(uint64_t seq, uint64_t seed) {
+    const uint64_t M = 0x5851f42d4c957f2dull;
+    PCG32 r;
+    r.inc = (seq << 1) | 1ull;
+    uint64_t s = 0;
+    s = s * M + r.inc;
+    s += seed;
+    s = s * M + r.inc;
+    r.state = s;
+    return r;
+}
+HKD uint32_t pcg32_u32(PCG32& g) {
+    uint64_t old = g.state;
+    g.state = old * 0x5851f42d4c957f2dull + g.inc;
+    uint32_t xs = (uint32_t)((((old >> 18) ^ old) >> 27) & 0xFFFFFFFFull);
+    uint32_t rot = (uint32_t)(old >> 59) & 31u;
+    return (xs >> rot) | (xs << ((32 - rot) & 31));
+}
+HKD float pcg32_f32(PCG32& g) {
+    float f = (float)pcg32_u32(g) * 2.3283064e-10f;
+    const float lim = 1.0f - 1.1920929e-7f;
+    return f < lim ? f : lim;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ZSobol  (sampler/sobol.jl:17-323).  Only Sobol dimensions 0 and 1 are ever read.
+// ------------------------------------------------------------------------------------------------
+HKD uint64_t left_shift2(uint64_t x) {
+    x &= 0xffffffffull;
+    x = (x ^ (x << 16)) & 0x0000ffff0000ffffull;
+    x = (x ^ (x << 8)) & 0x00ff00ff00ff00ffull;
+    x = (x ^ (x << 4)) & 0x0f0f0f0f0f0f0f0full;
+    x = (x ^ (x << 2)) & 0x3333333333333333ull;
+    x = (x ^ (x << 1)) & 0x5555555555555555ull;
+    return x;
+}
+HKD uint32_t fast_owen_scramble(uint32_t v, uint32_t seed) {
+    v = __brev(v);
+    v ^= v * 0x3d20adeau;
+    v += seed;
+    v *= (seed >> 16) | 1u;
+    v ^= v * 0x05526c56u;
+    v ^= v * 0x53a22864u;
+    return __brev(v);
+}
+HKD float sobol_sample(uint64_t a, int dimension, uint32_t scramble, const uint32_t* __restrict__ mats) {
+    uint32_t v = 0;
+    const uint32_t* m = mats + dimension * 52;
+    // bits above the index width are zero: iterate the 52 matrix columns with a uniform trip count so the
+    // column reads stay scalar loads
+#pragma unroll 4
+    for (int b = 0; b < 52; ++b) {
+        uint32_t mask = 0u - (uint32_t)((a >> b) & 1ull);
+        v ^= m[b] & mask;
+    }
+    v = fast_owen_scramble(v, scramble);
+    float f = (float)v * 2.3283064365386963e-10f;
+    const float lim = 1.0f - 1.1920929e-7f;
+    return f < lim ? f : lim;
+}
+// PERMUTATIONS_4WAY packed: 4 x 2 bits per permutation (sobol.jl:155-180)
+__device__ static const uint8_t kPerm4[24] = {
+    0xE4, 0xB4, 0xD8, 0x78, 0x6C, 0x9C, 0xE1, 0xB1, 0xC9, 0x39, 0x2D, 0x8D,
+    0xC6, 0x36, 0xD2, 0x72, 0x4E, 0x1E, 0x27, 0x87, 0x1B, 0x4B, 0x63, 0x93};
+HKD uint64_t zsobol_sample_index(uint64_t morton, int dimension, int log2_spp, int n_base4_digits) {
+    uint64_t sample_index = 0;
+    const int pow2 = log2_spp & 1;
+    const uint64_t dmix = 0x55555555ull * (uint64_t)(int64_t)dimension;
+    // digits i = n-1 .. last_digit; iterations with i < last_digit contribute nothing (sobol.jl:244-247)
+    for (int i = n_base4_digits - 1; i >= pow2; --i) {
+        int shift = 2 * i - pow2;
+        int digit = (int)((morton >> shift) & 3ull);
+        uint64_t higher = morton >> (shift + 2);
+        uint64_t h = mix_bits(higher ^ dmix);
+        int p = (int)((h >> 24) % 24ull);
+        uint64_t pd = (uint64_t)((kPerm4[p] >> (2 * digit)) & 3);
+        sample_index |= pd << shift;
+    }
+    if (pow2) {
+        uint64_t digit = morton & 1ull;
+        uint64_t xb = mix_bits((morton >> 1) ^ dmix) & 1ull;
+        sample_index |= (digit ^ xb);
+    }
+    return sample_index;
+}
+HKD uint64_t zsobol_hash(int dimension, uint32_t seed) {
+    uint32_t w[2] = {(uint32_t)dimension, seed};
+    return murmur64a_words<2>(w);
+}
+struct SobolCtx {
+    uint64_t morton_base;  // encode_morton2(px,py) << log2_spp | sample_idx
+    const uint32_t* mats;
+    int log2_spp, n_digits;
+    uint32_t seed;
+};
+HKD SobolCtx sobol_ctx(const DSobol& s, const uint32_t* mats, int px, int py, int sample_idx) {
+    SobolCtx c;
+    uint64_t m = (left_shift2((uint64_t)(uint32_t)py) << 1) | left_shift2((uint64_t)(uint32_t)px);
+    c.morton_base = (m << s.log2_spp) | (uint64_t)(int64_t)sample_idx;
+    c.mats = mats;
+    c.log2_spp = s.log2_spp;
+    c.n_digits = s.n_base4_digits;
+    c.seed = s.seed;
+    return c;
+}
+HKD float sobol_1d(const SobolCtx& c, int dim) {  // sobol.jl:269-282
+    uint64_t idx = zsobol_sample_index(c.morton_base, dim, c.log2_spp, c.n_digits);
+    uint32_t h = (uint32_t)zsobol_hash(dim + 1, c.seed);
+    return sobol_sample(idx, 0, h, c.mats);
+}
+HKD v2 sobol_2d(const SobolCtx& c, int dim) {  // sobol.jl:290-309
+    uint64_t idx = zsobol_sample_index(c.morton_base, dim, c.log2_spp, c.n_digits);
+    uint64_t bits = zsobol_hash(dim + 2, c.seed);
+    return mk2(sobol_sample(idx, 0, (uint32_t)bits, c.mats), sobol_sample(idx, 1, (uint32_t)(bits >> 32), c.mats));
+}
+
+// ------------------------------------------------------------------------------------------------
+// sampling primitives (sampler/sampling.jl:1-30)
+// ------------------------------------------------------------------------------------------------
+HKD v2 concentric_sample_disk(v2 u) {
+    float ox = 2.0f * u.x - 1.0f, oy = 2.0f * u.y - 1.0f;
+    float sx = ox + 1.0e-10f, sy = oy + 1.0e-10f;
+    bool xl = fabsf(ox) > fabsf(oy);
+    float r = xl ? ox : oy;
+    float theta = xl ? ((oy / sx) * PI_F) / 4.0f : PI_F / 2.0f - ((ox / sy) * PI_F) / 4.0f;
+    return mk2(r * cosf(theta), r * sinf(theta));
+}
+HKD v3 cosine_sample_hemisphere(v2 u) {
+    v2 d = concentric_sample_disk(u);
+    float z = sqrtf(maxf(0.0f, 1.0f - d.x * d.x - d.y * d.y));
+    return mk3(d.x, d.y, z);
+}
+
+// ------------------------------------------------------------------------------------------------
+// spectral (spectral/spectral.jl:192-249, rgb2spec.jl, uplift.jl, color.jl)
+// ------------------------------------------------------------------------------------------------
+HKD float visible_wavelengths_pdf(float l) {
+    if (l < 360.0f || l > 830.0f) return 0.0f;
+    float c = coshf(0.0072f * (l - 538.0f));
+    return 0.0039398042f / (c * c);
+}
+HKD float sample_visible_wavelength(float u) { return 538.0f - 138.888889f * atanhf(0.85691062f - 1.82750197f * u); }
+HKD void sample_wavelengths_visible(float u, S4& lambda, S4& pdf) {
+    float u2 = u + 0.25f;
+    u2 = u2 >= 1.0f ? u2 - 1.0f : u2;
+    float u3 = u + 0.5f;
+    u3 = u3 >= 1.0f ? u3 - 1.0f : u3;
+    float u4 = u + 0.75f;
+    u4 = u4 >= 1.0f ? u4 - 1.0f : u4;
+    lambda = s4(sample_visible_wavelength(u), sample_visible_wavelength(u2), sample_visible_wavelength(u3), sample_visible_wavelength(u4));
+    pdf = s4(visible_wavelengths_pdf(lambda.x), visible_wavelengths_pdf(lambda.y), visible_wavelengths_pdf(lambda.z), visible_wavelengths_pdf(lambda.w));
+}
+HKD float sigmoidf(float x) {
+    if (isinf(x)) return x > 0 ? 1.0f : 0.0f;
+    return 0.5f + x / (2.0f * sqrtf(1.0f + x * x));
+}
+HKD float poly_eval(float c0, float c1, float c2, float l) { return sigmoidf(c0 * l * l + c1 * l + c2); }
+HKD S4 poly_eval4(float4 c, S4 l) { return s4(poly_eval(c.x, c.y, c.z, l.x), poly_eval(c.x, c.y, c.z, l.y), poly_eval(c.x, c.y, c.z, l.z), poly_eval(c.x, c.y, c.z, l.w)); }
+HKD float poly_max_value(float c0, float c1, float c2) {
+    float r = maxf(poly_eval(c0, c1, c2, 360.0f), poly_eval(c0, c1, c2, 830.0f));
+    if (c0 != 0) {
+        float lc = -c1 / (2.0f * c0);
+        if (360.0f <= lc && lc <= 830.0f) r = maxf(r, poly_eval(c0, c1, c2, lc));
+    }
+    return r;
+}
+// run-time table lookup (textured colours only; constant colours are baked on the host)
+HKD void rgb_to_spectrum(const DTables& T, float r, float g, float b, float& c0, float& c1, float& c2) {
+    r = clampf(r, 0.0f, 1.0f);
+    g = clampf(g, 0.0f, 1.0f);
+    b = clampf(b, 0.0f, 1.0f);
+    if (r == g && g == b) {
+        c0 = c1 = 0.0f;
+        c2 = (r > 0.0f && r < 1.0f) ? (r - 0.5f) / sqrtf(r * (1.0f - r)) : (r <= 0.0f ? -1.0e10f : 1.0e10f);
+        return;
+    }
+    int maxc = r > g ? (r > b ? 1 : 3) : (g > b ? 2 : 3);
+    float z = maxc == 1 ? r : (maxc == 2 ? g : b);
+    float xc = maxc == 1 ? g : (maxc == 2 ? b : r);
+    float yc = maxc == 1 ? b : (maxc == 2 ? r : g);
+    int res = T.rgb2spec_res;
+    float x = xc * (float)(res - 1) / z, y = yc * (float)(res - 1) / z;
+    int zi = 1;
+    for (int i = 1; i <= res - 1; ++i)
+        if (T.rgb2spec_scale[i - 1] < z) zi = i;
+    zi = zi < res - 1 ? zi : res - 1;
+    int xi = (int)x + 1, yi = (int)y + 1;
+    xi = xi < res - 1 ? xi : res - 1;
+    yi = yi < res - 1 ? yi : res - 1;
+    float dx = x - (float)(xi - 1), dy = y - (float)(yi - 1);
+    float dz = (z - T.rgb2spec_scale[zi - 1]) / (T.rgb2spec_scale[zi] - T.rgb2spec_scale[zi - 1]);
+    size_t R = (size_t)res;
+    float out[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        auto A = [&](int zz, int yy, int xx) {
+            return T.rgb2spec_coeffs[(size_t)(maxc - 1) + 3 * ((size_t)(zz - 1) + R * ((size_t)(yy - 1) + R * ((size_t)(xx - 1) + R * (size_t)k)))];
+        };
+        out[k] = (1.0f - dz) * ((1.0f - dy) * ((1.0f - dx) * A(zi, yi, xi) + dx * A(zi, yi, xi + 1)) + dy * ((1.0f - dx) * A(zi, yi + 1, xi) + dx * A(zi, yi + 1, xi + 1))) +
+                 dz * ((1.0f - dy) * ((1.0f - dx) * A(zi + 1, yi, xi) + dx * A(zi + 1, yi, xi + 1)) + dy * ((1.0f - dx) * A(zi + 1, yi + 1, xi) + dx * A(zi + 1, yi + 1, xi + 1)));
+    }
+    c0 = out[0];
+    c1 = out[1];
+    c2 = out[2];
+}
+__device__ static const float kD65[107] = {
+    0.0341f,  1.6643f,  3.2945f,  11.7652f, 20.236f,  28.6447f, 37.0535f, 38.5011f, 39.9488f, 42.4302f, 44.9117f, 45.775f,
+    46.6383f, 49.3637f, 52.0891f, 51.0323f, 49.9755f, 52.3118f, 54.6482f, 68.7015f, 82.7549f, 87.1204f, 91.486f,  92.4589f,
+    93.4318f, 90.057f,  86.6823f, 95.7736f, 104.865f, 110.936f, 117.008f, 117.41f,  117.812f, 116.336f, 114.861f, 115.392f,
+    115.923f, 112.367f, 108.811f, 109.082f, 109.354f, 108.578f, 107.802f, 106.296f, 104.79f,  106.239f, 107.689f, 106.047f,
+    104.405f, 104.225f, 104.046f, 102.023f, 100.0f,   98.1671f, 96.3342f, 96.0611f, 95.788f,  92.2368f, 88.6856f, 89.3459f,
+    90.0062f, 89.8026f, 89.5991f, 88.6489f, 87.6987f, 85.4936f, 83.2886f, 83.4939f, 83.6992f, 81.863f,  80.0268f, 80.1207f,
+    80.2146f, 81.2462f, 82.2778f, 80.281f,  78.2842f, 74.0027f, 69.7213f, 70.6652f, 71.6091f, 72.979f,  74.349f,  67.9765f,
+    61.604f,  65.7448f, 69.8856f, 72.4863f, 75.087f,  69.3398f, 63.5927f, 55.0054f, 46.4182f, 56.6118f, 66.8054f, 65.0941f,
+    63.3828f, 63.8434f, 64.304f,  61.8779f, 59.4519f, 55.7054f, 51.959f,  54.6998f, 57.4406f, 58.8765f, 60.3125f};
+HKD float sample_d65(float l) {  // uplift.jl:437-457
+    if (l <= 300.0f) return kD65[0];
+    if (l >= 830.0f) return kD65[106];
+    float t = (l - 300.0f) / 5.0f;
+    float fl = floorf(t);
+    int idx = clampi((int)fl + 1, 1, 106);
+    float frac = t - fl;
+    return kD65[idx - 1] * (1.0f - frac) + kD65[idx] * frac;
+}
+HKD S4 d65_4(S4 l) { return s4(sample_d65(l.x), sample_d65(l.y), sample_d65(l.z), sample_d65(l.w)); }
+
+// the three uplifts, split into "coefficients" (host-baked or table lookup) and "evaluate"
+HKD float4 coef_bounded(const DTables& T, float r, float g, float b) {  // uplift_rgb
+    float c0, c1, c2;
+    rgb_to_spectrum(T, r, g, b, c0, c1, c2);
+    return make_float4(c0, c1, c2, 1.0f);
+}
+HKD float4 coef_unbounded(const DTables& T, float r, float g, float b) {  // uplift_rgb_unbounded (Q5)
+    float m = maxf(maxf(r, g), b);
+    if (m <= 0.0f) return make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // scale 0 => zero spectrum
+    float c0, c1, c2;
+    rgb_to_spectrum(T, r / m, g / m, b / m, c0, c1, c2);
+    return make_float4(c0, c1, c2, m / poly_max_value(c0, c1, c2));
+}
+HKD float4 coef_illuminant(const DTables& T, float r, float g, float b) {  // rgb_to_spectral_sigmoid_illuminant
+    float m = maxf(maxf(r, g), b);
+    if (m <= 0.0f) return make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float scale = 2.0f * m;
+    float c0, c1, c2;
+    rgb_to_spectrum(T, r / scale, g / scale, b / scale, c0, c1, c2);
+    return make_float4(c0, c1, c2, scale);
+}
+HKD S4 eval_bounded(float4 c, S4 l) { return poly_eval4(c, l); }
+HKD S4 eval_scaled(float4 c, S4 l) {  // scale * poly(lambda); scale == 0 encodes the m <= 0 early-out
+    if (c.w == 0.0f) return s4(0.0f);
+    S4 p = poly_eval4(c, l);
+    return s4(c.w * p.x, c.w * p.y, c.w * p.z, c.w * p.w);
+}
+HKD S4 eval_illuminant(float4 c, S4 l) {  // scale * poly(lambda) * D65(lambda)
+    if (c.w == 0.0f) return s4(0.0f);
+    S4 p = poly_eval4(c, l);
+    S4 d = d65_4(l);
+    return s4(c.w * p.x * d.x, c.w * p.y * d.y, c.w * p.z * d.z, c.w * p.w * d.w);
+}
+
+HKD float sample_cie(const float* tab, float l) {
+    int off = (int)rintf(l) - 360;
+    if (off < 0 || off >= 471) return 0.0f;
+    return tab[off];
+}
+HKD v3 spectral_to_rgb_clamped(const DTables& T, S4 L, S4 lambda, S4 pdf, float max_component_value) {  // volpath.jl:343-361
+    v3 sum = mk3(0.0f, 0.0f, 0.0f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float p = at(pdf, i);
+        if (p != 0.0f) {
+            float l = at(lambda, i), Li = at(L, i);
+            v3 cmf = mk3(sample_cie(T.cie, l), sample_cie(T.cie + 471, l), sample_cie(T.cie + 942, l));
+            sum = sum + (cmf * Li) / p;
+        }
+    }
+    v3 xyz = sum * 0.25f;
+    float X = xyz.x, Y = xyz.y, Z = xyz.z;
+    v3 rgb = mk3(3.2404542f * X - 1.5371385f * Y - 0.4985314f * Z, -0.9692660f * X + 1.8760108f * Y + 0.0415560f * Z,
+                 0.0556434f * X - 0.2040259f * Y + 1.0572252f * Z);
+    rgb = mk3(maxf(0.0f, rgb.x), maxf(0.0f, rgb.y), maxf(0.0f, rgb.z));
+    float m = maxf(maxf(rgb.x, rgb.y), rgb.z);
+    if (m > max_component_value) rgb = rgb * (max_component_value / m);
+    return rgb;
+}
+
+// ------------------------------------------------------------------------------------------------
+// textures (textures/texture-ref.jl:151-186)
+// ------------------------------------------------------------------------------------------------
+HKD void tex_bilinear(const DTexture& t, v2 uv, float out[4]) {
+    float ua0 = 1.0f - uv.y, ua1 = uv.x;
+    int h = t.height, w = t.width, ch = t.channels;
+    float px = ua1 * (float)(w - 1) + 1.0f, py = ua0 * (float)(h - 1) + 1.0f;
+    float fpx = floorf(px), fpy = floorf(py);
+    int x0 = (int)fpx, y0 = (int)fpy;
+    int x1 = clampi(x0 + 1, 1, w), y1 = clampi(y0 + 1, 1, h);
+    x0 = clampi(x0, 1, w);
+    y0 = clampi(y0, 1, h);
+    float fx = px - fpx, fy = py - fpy;
+    const float* p00 = t.data + ((size_t)(y0 - 1) + (size_t)h * (size_t)(x0 - 1)) * ch;
+    const float* p10 = t.data + ((size_t)(y0 - 1) + (size_t)h * (size_t)(x1 - 1)) * ch;
+    const float* p01 = t.data + ((size_t)(y1 - 1) + (size_t)h * (size_t)(x0 - 1)) * ch;
+    const float* p11 = t.data + ((size_t)(y1 - 1) + (size_t)h * (size_t)(x1 - 1)) * ch;
+    for (int c = 0; c < ch; ++c) {
+        float c0 = p00[c] * (1.0f - fx) + p10[c] * fx;
+        float c1 = p01[c] * (1.0f - fx) + p11[c] * fx;
+        out[c] = c0 * (1.0f - fy) + c1 * fy;
+    }
+}
+HKD float eval_f32(const DScene& sc, const DMaterial& m, int slot, v2 uv) {
+    if (m.ftex[slot] < 0) return m.f[slot];
+    float o[4] = {0, 0, 0, 0};
+    tex_bilinear(sc.textures[m.ftex[slot]], uv, o);
+    return o[0];
+}
+
+// ------------------------------------------------------------------------------------------------
+// pixel filter (filter.jl:733-953) and camera (camera/perspective.jl:95-128)
+// ------------------------------------------------------------------------------------------------
+HKD int find_interval20(const float* cdf, float u, int n) {
+    int lo = 1, hi = n + 1;
+#pragma unroll
+    for (int k = 0; k < 20; ++k) {
+        int mid = (lo + hi) >> 1;
+        bool c = cdf[mid - 1] <= u;
+        lo = c ? mid : lo;
+        hi = c ? hi : mid;
+    }
+    return lo;
+}
+HKD float sample_tent(float u, float r) {
+    if (u < 0.5f) return -r + r * sqrtf(2.0f * u);
+    return r * (1.0f - sqrtf(2.0f * (1.0f - u)));
+}
+HKD void filter_sample(const DFilter& f, v2 u, float& px, float& py, float& weight) {
+    if (f.type == HK_FILTER_BOX) {
+        px = lerpf(-f.rx, f.rx, u.x);
+        py = lerpf(-f.ry, f.ry, u.y);
+        weight = 1.0f;
+        return;
+    }
+    if (f.type == HK_FILTER_TRIANGLE) {
+        px = sample_tent(u.x, f.rx);
+        py = sample_tent(u.y, f.ry);
+        weight = 1.0f;
+        return;
+    }
+    int ny = f.ny, nx = f.nx;
+    int o = clampi(find_interval20(f.marginal_cdf, u.y, ny), 1, ny);
+    float du = u.y - f.marginal_cdf[o - 1];
+    float diff = f.marginal_cdf[o] - f.marginal_cdf[o - 1];
+    du = diff > 0.0f ? du / diff : 0.0f;
+    float pdf_y = f.func_integral > 0.0f ? f.marginal_func[o - 1] / f.func_integral : 0.0f;
+    py = lerpf(f.dmin_y, f.dmax_y, ((float)(o - 1) + du) / (float)ny);
+    float row_integral = f.marginal_func[o - 1];
+    const float* row = f.conditional_cdf + (size_t)(o - 1) * (nx + 1);
+    int ox = clampi(find_interval20(row, u.x, nx), 1, nx);
+    float dux = u.x - row[ox - 1];
+    float diffx = row[ox] - row[ox - 1];
+    dux = diffx > 0.0f ? dux / diffx : 0.0f;
+    float fval = f.func[(size_t)(o - 1) * nx + (ox - 1)];
+    float pdf_x = row_integral > 0.0f ? fval / row_integral : 0.0f;
+    px = lerpf(f.dmin_x, f.dmax_x, ((float)(ox - 1) + dux) / (float)nx);
+    float pdf = pdf_x * pdf_y;
+    weight = pdf > 0.0f ? fval / pdf : 0.0f;
+}
+HKD v3 xform_point(const float* m, v3 p) {
+    float x = m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3];
+    float y = m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7];
+    float z = m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11];
+    float w = m[12] * p.x + m[13] * p.y + m[14] * p.z + m[15];
+    if (w == 1.0f) return mk3(x, y, z);
+    float inv = 1.0f / w;
+    return mk3(x * inv, y * inv, z * inv);
+}
+HKD v3 xform_vector(const float* m, v3 v) {
+    return mk3(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z, m[8] * v.x + m[9] * v.y + m[10] * v.z);
+}
+HKD void generate_ray(const DCamera& cam, v2 film, v2 lens, float time_u, v3& ro, v3& rd, float& time) {
+    v3 pc = xform_point(cam.r2c, mk3(film.x, film.y, 0.0f));
+    v3 o = mk3(0.0f, 0.0f, 0.0f);
+    v3 d = normalize(pc);
+    if (cam.lens_radius > 0) {
+        v2 dsk = concentric_sample_disk(lens);
+        float plx = cam.lens_radius * dsk.x, ply = cam.lens_radius * dsk.y;
+        float t = -cam.focal_distance / d.z;
+        v3 pf = o + d * t;
+        o = mk3(plx, ply, 0.0f);
+        d = normalize(pf - o);
+    }
+    time = lerpf(cam.shutter_open, cam.shutter_close, time_u);
+    ro = xform_point(cam.c2w, o);
+    rd = normalize(xform_vector(cam.c2w, d));
+}
+
+// ------------------------------------------------------------------------------------------------
+// triangle intersection: the arithmetic DESIGN.md "Intersection arithmetic" fixes (== oracle/hko_accel.h)
+// ------------------------------------------------------------------------------------------------
+HKD bool intersect_triangle(v3 o, v3 d, float t_max, v3 v0, v3 e1, v3 e2, float& t, float& u, float& v) {
+    v3 p = cross(d, e2);
+    float det = dot(e1, p);
+    if (det == 0.0f) return false;
+    float inv = 1.0f / det;
+    v3 s = o - v0;
+    u = dot(s, p) * inv;
+    if (!(u >= 0.0f) || u > 1.0f) return false;
+    v3 q = cross(s, e1);
+    v = dot(d, q) * inv;
+    if (!(v >= 0.0f) || u + v > 1.0f) return false;
+    t = dot(e2, q) * inv;
+    return t > 0.0f && t < t_max;
+}
+
+struct HitRec {
+    float t;
+    int prim;  // original triangle index, -1 = miss
+    float u, v;
+};
+
+// Per-lane short stack lives in LDS: entry e of lane l at stack[e * 64 + l] (bank = lane => conflict-free).
+// MODE 0: closest hit (ties on t -> smaller prim index).  MODE 1: shadow segment — returns as soon as an
+// opaque triangle is hit (any opaque hit zeroes the contribution, intersection.jl:378-379), otherwise
+// closest hit among the non-opaque ones.
+template <int MODE, bool COUNT>
+HKD HitRec traverse(const DScene& sc, v3 o, v3 d, float t_max, int* __restrict__ stack, int lane, unsigned& n_nodes, unsigned& n_tris, bool& opaque_hit) {
+    HitRec best;
+    best.t = t_max;
+    best.prim = -1;
+    best.u = best.v = 0.0f;
+    opaque_hit = false;
+    if (sc.n_tris == 0) return best;
+    const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
+    const float ox = -o.x * ix, oy = -o.y * iy, oz = -o.z * iz;
+    int sp = 0;
+    int cur = sc.root_ref;
+    const float4* __restrict__ nodes4 = reinterpret_cast<const float4*>(sc.nodes);
+    while (true) {
+        if (cur >= 0) {
+            const float4* np = nodes4 + 4 * (size_t)cur;
+            float4 A = np[0], B = np[1], C = np[2], D = np[3];
+            if (COUNT) ++n_nodes;
+            // child 0: lo (A.x A.y A.z) hi (A.w B.x B.y) ; child 1: lo (B.z B.w C.x) hi (C.y C.z C.w)
+            float t0x = fmaf(A.x, ix, ox), t1x = fmaf(A.w, ix, ox);
+            float t0y = fmaf(A.y, iy, oy), t1y = fmaf(B.x, iy, oy);
+            float t0z = fmaf(A.z, iz, oz), t1z = fmaf(B.y, iz, oz);
+            float n0 = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.0f));
+            float f0 = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), best.t));
+            float u0x = fmaf(B.z, ix, ox), u1x = fmaf(C.y, ix, ox);
+            float u0y = fmaf(B.w, iy, oy), u1y = fmaf(C.z, iy, oy);
+            float u0z = fmaf(C.x, iz, oz), u1z = fmaf(C.w, iz, oz);
+            float n1 = fmaxf(fmaxf(fminf(u0x, u1x), fminf(u0y, u1y)), fmaxf(fminf(u0z, u1z), 0.0f));
+            float f1 = fminf(fminf(fmaxf(u0x, u1x), fmaxf(u0y, u1y)), fminf(fmaxf(u0z, u1z), best.t));
+            // widen by a few ulps: culling must never drop a triangle whose t equals the current best
+            bool h0 = n0 * 0.9999995f <= f0 * 1.0000005f;
+            bool h1 = n1 * 0.9999995f <= f1 * 1.0000005f;
+            int c0 = __float_as_int(D.x), c1 = __float_as_int(D.y);
+            if (h0 && h1) {
+                bool first0 = n0 <= n1;
+                int near = first0 ? c0 : c1, far = first0 ? c1 : c0;
+                stack[sp * 64 + lane] = far;
+                ++sp;
+                cur = near;
+            } else if (h0) {
+                cur = c0;
+            } else if (h1) {
+                cur = c1;
+            } else {
+                if (sp == 0) break;
+                --sp;
+                cur = stack[sp * 64 + lane];
+            }
+        } else {
+            int ref = ~cur;
+            int first = ref >> 3, count = (ref & 7) + 1;
+            for (int i = 0; i < count; ++i) {
+                const float4* tp = sc.leaf_tris + 3 * (size_t)(first + i);
+                float4 T0 = tp[0], T1 = tp[1], T2 = tp[2];
+                if (COUNT) ++n_tris;
+                float t, u, v;
+                if (intersect_triangle(o, d, t_max, mk3(T0.x, T0.y, T0.z), mk3(T1.x, T1.y, T1.z), mk3(T2.x, T2.y, T2.z), t, u, v)) {
+                    int prim = __float_as_int(T0.w);
+                    if (MODE == 1 && (__float_as_uint(T1.w) & HK_TRI_OPAQUE)) {
+                        opaque_hit = true;
+                        best.t = t;
+                        best.prim = prim;
+                        best.u = u;
+                        best.v = v;
+                        return best;
+                    }
+                    if (best.prim < 0 || t < best.t || (t == best.t && prim < best.prim)) {
+                        best.t = t;
+                        best.prim = prim;
+                        best.u = u;
+                        best.v = v;
+                    }
+                }
+            }
+            if (sp == 0) break;
+            --sp;
+            cur = stack[sp * 64 + lane];
+        }
+    }
+    return best;
+}
+
+// ------------------------------------------------------------------------------------------------
+// surface geometry at a hit (integrators/volpath/intersection.jl:13-182)
+// ------------------------------------------------------------------------------------------------
+struct Surface {
+    v3 pi, n, ns;
+    v2 uv;
+    float area;
+};
+HKD void tri_vertices(const DScene& sc, int prim, v3& a, v3& b, v3& c) {
+    const float* p = sc.positions + 9 * (size_t)prim;
+    a = mk3(p[0], p[1], p[2]);
+    b = mk3(p[3], p[4], p[5]);
+    c = mk3(p[6], p[7], p[8]);
+}
+HKD v3 geometric_normal(const DScene& sc, int prim) {
+    v3 a, b, c;
+    tri_vertices(sc, prim, a, b, c);
+    return normalize(cross(b - a, c - a));
+}
+HKD v2 uv_at(const DScene& sc, int prim, float w, float u, float v) {
+    if (sc.uvs) {
+        const float* q = sc.uvs + 6 * (size_t)prim;
+        return mk2(w * q[0] + u * q[2] + v * q[4], w * q[1] + u * q[3] + v * q[5]);
+    }
+    // default uvs (0,0),(1,0),(1,1)
+    return mk2(w * 0.0f + u * 1.0f + v * 1.0f, w * 0.0f + u * 0.0f + v * 1.0f);
+}
+// Only the fields the BSDFs consume are produced: dpdu/dpdv/shading tangents feed the texture-filter
+// context, which texture evaluation ignores (textures/texture-ref.jl:126-135), so they are not computed.
+HKD Surface surface_at(const DScene& sc, int prim, float bu, float bv, v3 ro, v3 rd, float t) {
+    Surface s;
+    float w = 1.0f - bu - bv;
+    s.pi = ro + rd * t;
+    v3 a, b, c;
+    tri_vertices(sc, prim, a, b, c);
+    v3 cr = cross(b - a, c - a);
+    v3 n = normalize(cr);
+    s.area = 0.5f * norm(cr);
+    s.uv = uv_at(sc, prim, w, bu, bv);
+    v3 ns = n;
+    if (sc.normals) {
+        const float* q = sc.normals + 9 * (size_t)prim;
+        if (!(isnan(q[0]) || isnan(q[3]) || isnan(q[6])))
+            ns = normalize(mk3(w * q[0] + bu * q[3] + bv * q[6], w * q[1] + bu * q[4] + bv * q[7], w * q[2] + bu * q[5] + bv * q[8]));
+    }
+    s.n = dot(n, ns) < 0.0f ? -n : n;
+    s.ns = ns;
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// materials: parameter fetch
+// ------------------------------------------------------------------------------------------------
+enum { UPLIFT_BOUNDED = 0, UPLIFT_UNBOUNDED = 1 };
+HKD float4 rgb_param_coef(const DScene& sc, const DTables& T, const DSpectrumParam& p, v2 uv, int mode, bool clamp_lo) {
+    if (p.tex < 0) return p.coef;
+    float o[4] = {0, 0, 0, 1};
+    tex_bilinear(sc.textures[p.tex], uv, o);
+    if (clamp_lo) {  // clamp(kd_rgb): [0, Inf)
+        o[0] = clampf(o[0], 0.0f, INF_F);
+        o[1] = clampf(o[1], 0.0f, INF_F);
+        o[2] = clampf(o[2], 0.0f, INF_F);
+    }
+    return mode == UPLIFT_BOUNDED ? coef_bounded(T, o[0], o[1], o[2]) : coef_unbounded(T, o[0], o[1], o[2]);
+}
+HKD float rgb_param_alpha(const DScene& sc, const DSpectrumParam& p, v2 uv) {
+    if (p.tex < 0) return p.rgba[3];
+    float o[4] = {0, 0, 0, 1};
+    tex_bilinear(sc.textures[p.tex], uv, o);
+    return o[3];
+}
+HKD float surface_alpha(const DScene& sc, int mat, v2 uv) {  // spectral-eval.jl:3882-3888
+    const DMaterial& m = sc.materials[mat];
+    if (m.kind == HK_MAT_MATTE) return rgb_param_alpha(sc, m.rgb[0], uv);
+    return 1.0f;
+}
+HKD float mix_hash_float(v3 p, v3 wo, const uint32_t* key) {  // mix-material.jl:96-127
+    uint64_t h = 0;
+    h ^= (uint64_t)__float_as_uint(p.x);
+    h *= 0xcc9e2d51ull;
+    h ^= (uint64_t)(uint32_t)(__float_as_uint(p.y) << 4);
+    h *= 0x1b873593ull;
+    h ^= (uint64_t)(uint32_t)(__float_as_uint(p.z) << 8);
+    h ^= (uint64_t)(uint32_t)(__float_as_uint(wo.x) << 16);
+    h *= 0xcc9e2d51ull;
+    h ^= (uint64_t)__float_as_uint(wo.y);
+    h *= 0x1b873593ull;
+    h ^= (uint64_t)(uint32_t)(__float_as_uint(wo.z) << 12);
+    h ^= (uint64_t)key[0] << 24;
+    h ^= (uint64_t)key[1];
+    h *= 0xcc9e2d51ull;
+    h ^= (uint64_t)key[2] << 28;
+    h ^= (uint64_t)key[3] << 4;
+    h *= 0x1b873593ull;
+    h ^= h >> 31;
+    h *= 0x7fb5d329728ea185ull;
+    h ^= h >> 27;
+    h *= 0x81dadef4bc2dd44dull;
+    h ^= h >> 33;
+    return (float)(uint32_t)(h & 0xFFFFFFFFull) * 2.3283064365386963e-10f;
+}
+HKD int resolve_mix_material(const DScene& sc, int idx, v3 p, v3 wo, v2 uv) {  // mix-material.jl:222-238
+    int cur = idx;
+    for (int it = 0; it < 8; ++it) {
+        const DMaterial& m = sc.materials[cur];
+        if (m.kind != HK_MAT_MIX) return cur;
+        float amt = eval_f32(sc, m, 0, uv);
+        if (amt <= 0.0f)
+            cur = m.i[0];
+        else if (amt >= 1.0f)
+            cur = m.i[1];
+        else
+            cur = amt < mix_hash_float(p, wo, m.mix_key) ? m.i[0] : m.i[1];
+    }
+    return cur;
+}
+
+// ------------------------------------------------------------------------------------------------
+// BSDFs (materials/spectral-eval.jl; helpers :3514-3864; reflection/bxdf.jl:67-100; microfacet.jl:83-99)
+// ------------------------------------------------------------------------------------------------
+struct BSDFSample {
+    v3 wi;
+    S4 f;
+    float pdf;
+    bool is_specular;
+    float eta_scale;
+};
+HKD BSDFSample invalid_sample() { return BSDFSample{mk3(0, 0, 1), s4(0.0f), 0.0f, false, 1.0f}; }
+HKD void coordinate_system(v3 n, v3& t, v3& b) {
+    if (fabsf(n.x) > fabsf(n.y)) {
+        float il = 1.0f / sqrtf(n.x * n.x + n.z * n.z);
+        t = mk3(n.z * il, 0.0f, -n.x * il);
+    } else {
+        float il = 1.0f / sqrtf(n.y * n.y + n.z * n.z);
+        t = mk3(0.0f, n.z * il, -n.y * il);
+    }
+    b = cross(n, t);
+}
+HKD v3 local_to_world(v3 l, v3 n, v3 t, v3 b) { return t * l.x + b * l.y + n * l.z; }
+HKD v3 world_to_local(v3 v, v3 n, v3 t, v3 b) { return mk3(dot(v, t), dot(v, b), dot(v, n)); }
+HKD v3 reflect(v3 wo, v3 n) { return -wo + 2.0f * dot(wo, n) * n; }
+HKD float fresnel_dielectric(float ci, float eta) {
+    ci = clampf(ci, -1.0f, 1.0f);
+    if (ci < 0.0f) {
+        eta = 1.0f / eta;
+        ci = -ci;
+    }
+    float s2i = 1.0f - ci * ci;
+    float s2t = s2i / (eta * eta);
+    if (s2t >= 1.0f) return 1.0f;
+    float ct = sqrtf(1.0f - s2t);
+    float rp = (eta * ci - ct) / (eta * ci + ct);
+    float rs = (ci - eta * ct) / (ci + eta * ct);
+    return 0.5f * (rp * rp + rs * rs);
+}
+HKD float fr_complex(float ci, float eta, float k) {
+    ci = clampf(ci, 0.0f, 1.0f);
+    float s2i = 1.0f - ci * ci;
+    float eta2 = eta * eta, k2 = k * k;
+    float er = eta2 - k2, ei = 2.0f * eta * k;
+    float den = er * er + ei * ei;
+    float s2tr = s2i * er / den, s2ti = -s2i * ei / den;
+    float c2tr = 1.0f - s2tr, c2ti = -s2ti;
+    float mag = sqrtf(c2tr * c2tr + c2ti * c2ti);
+    float ctr = sqrtf(0.5f * (mag + c2tr));
+    float cti = c2ti / (2.0f * ctr);
+    if (ctr == 0.0f) cti = sqrtf(0.5f * mag);
+    float ecr = eta * ci, eci = k * ci;
+    float npr = ecr - ctr, npi = eci - cti, dpr = ecr + ctr, dpi = eci + cti;
+    float dpm = dpr * dpr + dpi * dpi;
+    float rpr = (npr * dpr + npi * dpi) / dpm, rpi = (npi * dpr - npr * dpi) / dpm;
+    float etr = eta * ctr - k * cti, eti = eta * cti + k * ctr;
+    float nsr = ci - etr, nsi = -eti, dsr = ci + etr, dsi = eti;
+    float dsm = dsr * dsr + dsi * dsi;
+    float rsr = (nsr * dsr + nsi * dsi) / dsm, rsi = (nsi * dsr - nsr * dsi) / dsm;
+    return ((rpr * rpr + rpi * rpi) + (rsr * rsr + rsi * rsi)) * 0.5f;
+}
+HKD S4 fr_complex4(float c, S4 eta, S4 k) { return s4(fr_complex(c, eta.x, k.x), fr_complex(c, eta.y, k.y), fr_complex(c, eta.z, k.z), fr_complex(c, eta.w, k.w)); }
+HKD float cos2_theta(v3 w) { return w.z * w.z; }
+HKD float sin2_theta(v3 w) { return maxf(0.0f, 1.0f - cos2_theta(w)); }
+HKD float tan2_theta(v3 w) { return sin2_theta(w) / cos2_theta(w); }
+HKD float cos_phi(v3 w) {
+    float s = sqrtf(sin2_theta(w));
+    return s == 0.0f ? 1.0f : clampf(w.x / s, -1.0f, 1.0f);
+}
+HKD float sin_phi(v3 w) {
+    float s = sqrtf(sin2_theta(w));
+    return s == 0.0f ? 0.0f : clampf(w.y / s, -1.0f, 1.0f);
+}
+HKD bool tr_smooth(float ax, float ay) { return maxf(ax, ay) < 1e-3f; }
+HKD float tr_d(v3 wm, float ax, float ay) {
+    float t2 = tan2_theta(wm);
+    if (isinf(t2)) return 0.0f;
+    float c4 = cos2_theta(wm) * cos2_theta(wm);
+    if (c4 < 1e-16f) return 0.0f;
+    float a = cos_phi(wm) / ax, b = sin_phi(wm) / ay;
+    float e = t2 * (a * a + b * b);
+    return 1.0f / (PI_F * ax * ay * c4 * ((1.0f + e) * (1.0f + e)));
+}
+HKD float tr_lambda(v3 w, float ax, float ay) {
+    float t2 = tan2_theta(w);
+    if (isinf(t2)) return 0.0f;
+    float a = cos_phi(w) * ax, b = sin_phi(w) * ay;
+    return (sqrtf(1.0f + (a * a + b * b) * t2) - 1.0f) * 0.5f;
+}
+HKD float tr_g1(v3 w, float ax, float ay) { return 1.0f / (1.0f + tr_lambda(w, ax, ay)); }
+HKD float tr_g(v3 wo, v3 wi, float ax, float ay) { return 1.0f / (1.0f + tr_lambda(wo, ax, ay) + tr_lambda(wi, ax, ay)); }
+HKD float tr_pdf(v3 w, v3 wm, float ax, float ay) { return tr_g1(w, ax, ay) / fabsf(w.z) * tr_d(wm, ax, ay) * fabsf(dot(w, wm)); }
+HKD v3 tr_sample_wm(v3 w, v2 u, float ax, float ay) {
+    v3 wh = normalize(mk3(ax * w.x, ay * w.y, w.z));
+    if (wh.z < 0.0f) wh = -wh;
+    v3 t1 = wh.z < 0.99999f ? normalize(cross(mk3(0, 0, 1), wh)) : mk3(1, 0, 0);
+    v3 t2 = cross(wh, t1);
+    float r = sqrtf(u.x);
+    float phi = 2.0f * PI_F * u.y;
+    float px = r * cosf(phi), py = r * sinf(phi);
+    float h = sqrtf(1.0f - px * px);
+    py = lerpf(h, py, 0.5f * (1.0f + wh.z));
+    float pz = sqrtf(maxf(0.0f, 1.0f - px * px - py * py));
+    v3 nh = px * t1 + py * t2 + pz * wh;
+    return normalize(mk3(ax * nh.x, ay * nh.y, maxf(1e-6f, nh.z)));
+}
+HKD float pl_sample(const DPLSpectrum& s, float l) {  // spectral/piecewise-linear.jl
+    int N = s.n;
+    if (l <= s.lambdas[0]) return s.values[0];
+    if (l >= s.lambdas[N - 1]) return s.values[N - 1];
+    int lo = 1, hi = N;
+    while (lo + 1 < hi) {
+        int mid = (lo + hi) >> 1;
+        if (s.lambdas[mid - 1] <= l)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    float t = (l - s.lambdas[lo - 1]) / (s.lambdas[hi - 1] - s.lambdas[lo - 1]);
+    return s.values[lo - 1] * (1.0f - t) + s.values[hi - 1] * t;
+}
+HKD S4 eval_ior(const DScene& sc, const DTables& T, const DMaterial& m, int slot, v2 uv, S4 lambda) {
+    if (m.spectrum[slot] >= 0) {
+        const DPLSpectrum& s = sc.spectra[m.spectrum[slot]];
+        return s4(pl_sample(s, lambda.x), pl_sample(s, lambda.y), pl_sample(s, lambda.z), pl_sample(s, lambda.w));
+    }
+    return eval_scaled(rgb_param_coef(sc, T, m.rgb[slot], uv, UPLIFT_UNBOUNDED, false), lambda);
+}
+HKD BSDFSample sample_lambert(v3 wo, v3 n, v2 u, S4 f) {
+    float wdn = dot(wo, n);
+    v3 t, b;
+    coordinate_system(n, t, b);
+    v3 lw = cosine_sample_hemisphere(u);
+    float ct = lw.z;
+    if (ct < 1e-6f) return invalid_sample();
+    if (wdn < 0.0f) lw = mk3(lw.x, lw.y, -lw.z);
+    BSDFSample s;
+    s.wi = normalize(local_to_world(lw, n, t, b));
+    s.f = f;
+    s.pdf = ct / PI_F;
+    s.is_specular = false;
+    s.eta_scale = 1.0f;
+    return s;
+}
+
+// KIND is a compile-time constant in the per-kind shade kernels (material-sorted queues)
+template <int KIND>
+HKD BSDFSample sample_bsdf(const DScene& sc, const DTables& T, const DMaterial& m, v3 wo_w, v3 n, v2 uv, S4 lambda, v2 u, float uc, bool regularize) {
+    if (KIND == HK_MAT_MATTE) {  // spectral-eval.jl:42-101
+        float wdn = dot(wo_w, n);
+        if (fabsf(wdn) < 1e-6f) return invalid_sample();
+        S4 kd = eval_bounded(rgb_param_coef(sc, T, m.rgb[0], uv, UPLIFT_BOUNDED, true), lambda);
+        float sigma = eval_f32(sc, m, 0, uv);
+        S4 f;
+        if (sigma > 0.0f) {
+            float rf = 1.0f - 0.5f * sigma / (sigma + 0.33f);
+            f = kd * (rf / PI_F);
+        } else
+            f = kd * (1.0f / PI_F);
+        return sample_lambert(wo_w, n, u, f);
+    } else if (KIND == HK_MAT_MIRROR) {  // :108-132
+        float wdn = dot(wo_w, n);
+        if (fabsf(wdn) < 1e-6f) return invalid_sample();
+        BSDFSample s;
+        s.wi = reflect(wo_w, wdn < 0.0f ? -n : n);
+        s.f = eval_bounded(rgb_param_coef(sc, T, m.rgb[0], uv, UPLIFT_BOUNDED, false), lambda);
+        s.pdf = 1.0f;
+        s.is_specular = true;
+        s.eta_scale = 1.0f;
+        return s;
+    } else if (KIND == HK_MAT_GLASS) {  // :140-198
+        float ior = eval_f32(sc, m, 0, uv);
+        if (ior == 0.0f) ior = 1.0f;
+        float co = dot(wo_w, n);
+        bool entering = co > 0.0f;
+        v3 no = entering ? n : -n;
+        co = fabsf(co);
+        float eta = entering ? ior : (1.0f / ior);
+        float F = fresnel_dielectric(co, eta);
+        BSDFSample s;
+        s.pdf = 1.0f;
+        s.is_specular = true;
+        s.eta_scale = 1.0f;
+        bool do_reflect = uc < F;
+        float ctt = 0.0f;
+        if (!do_reflect) {
+            float s2i = maxf(0.0f, 1.0f - co * co);
+            float s2t = s2i / (eta * eta);
+            if (s2t >= 1.0f)
+                do_reflect = true;
+            else
+                ctt = sqrtf(1.0f - s2t);
+        }
+        if (do_reflect) {
+            s.wi = reflect(wo_w, no);
+            s.f = eval_bounded(rgb_param_coef(sc, T, m.rgb[0], uv, UPLIFT_BOUNDED, false), lambda);
+            return s;
+        }
+        s.wi = normalize(-wo_w / eta + (co / eta - ctt) * no);
+        s.f = eval_bounded(rgb_param_coef(sc, T, m.rgb[1], uv, UPLIFT_BOUNDED, false), lambda);
+        s.eta_scale = 1.0f / (eta * eta);
+        return s;
+    } else if (KIND == HK_MAT_CONDUCTOR) {  // :223-318
+        v3 t, b;
+        coordinate_system(n, t, b);
+        v3 wo = world_to_local(wo_w, n, t, b);
+        if (wo.z == 0.0f) return invalid_sample();
+        float rough = eval_f32(sc, m, 0, uv);
+        float ax = (m.flags & HK_MATF_REMAP_ROUGHNESS) ? sqrtf(rough) : rough;
+        float ay = ax;
+        if (regularize) {
+            ax = ax < 0.3f ? clampf(2.0f * ax, 0.1f, 0.3f) : ax;
+            ay = ay < 0.3f ? clampf(2.0f * ay, 0.1f, 0.3f) : ay;
+        }
+        if (!tr_smooth(ax, ay)) {
+            ax = maxf(ax, 1e-4f);
+            ay = maxf(ay, 1e-4f);
+        }
+        S4 eta = eval_ior(sc, T, m, 0, uv, lambda), k = eval_ior(sc, T, m, 1, uv, lambda);
+        BSDFSample s;
+        s.eta_scale = 1.0f;
+        if (tr_smooth(ax, ay)) {
+            v3 wi = mk3(-wo.x, -wo.y, wo.z);
+            float ci = fabsf(wi.z);
+            s.f = fr_complex4(ci, eta, k) / ci;
+            s.wi = local_to_world(wi, n, t, b);
+            s.pdf = 1.0f;
+            s.is_specular = true;
+            return s;
+        }
+        v3 wm = tr_sample_wm(wo, u, ax, ay);
+        v3 wi = -wo + 2.0f * dot(wo, wm) * wm;
+        if (!(wo.z * wi.z > 0.0f)) return invalid_sample();
+        float pdf = tr_pdf(wo, wm, ax, ay) / (4.0f * fabsf(dot(wo, wm)));
+        float co = fabsf(wo.z), ci = fabsf(wi.z);
+        if (ci == 0.0f || co == 0.0f) return invalid_sample();
+        S4 F = fr_complex4(fabsf(dot(wo, wm)), eta, k);
+        float D = tr_d(wm, ax, ay), G = tr_g(wo, wi, ax, ay);
+        s.f = D * F * G / (4.0f * ci * co);
+        s.wi = local_to_world(wi, n, t, b);
+        s.pdf = pdf;
+        s.is_specular = false;
+        return s;
+    } else {  // generic fallback (:322-359): gray 0.5 Lambertian (Q24)
+        float wdn = dot(wo_w, n);
+        if (fabsf(wdn) < 1e-6f) return invalid_sample();
+        return sample_lambert(wo_w, n, u, s4(0.5f) * (1.0f / PI_F));
+    }
+}
+template <int KIND>
+HKD S4 eval_bsdf(const DScene& sc, const DTables& T, const DMaterial& m, v3 wo_w, v3 wi_w, v3 n, v2 uv, S4 lambda, float& pdf) {
+    pdf = 0.0f;
+    if (KIND == HK_MAT_MATTE) {  // :371-398
+        float ci = dot(wi_w, n), co = dot(wo_w, n);
+        if (ci * co < 0.0f) return s4(0.0f);
+        float ct = fabsf(ci);
+        if (ct < 1e-6f) return s4(0.0f);
+        S4 kd = eval_bounded(rgb_param_coef(sc, T, m.rgb[0], uv, UPLIFT_BOUNDED, true), lambda);
+        pdf = ct / PI_F;
+        return kd / PI_F;
+    } else if (KIND == HK_MAT_MIRROR || KIND == HK_MAT_GLASS) {
+        return s4(0.0f);
+    } else if (KIND == HK_MAT_CONDUCTOR) {  // :422-488
+        v3 t, b;
+        coordinate_system(n, t, b);
+        v3 wo = world_to_local(wo_w, n, t, b), wi = world_to_local(wi_w, n, t, b);
+        if (!(wo.z * wi.z > 0.0f)) return s4(0.0f);
+        float rough = eval_f32(sc, m, 0, uv);
+        float ax = (m.flags & HK_MATF_REMAP_ROUGHNESS) ? sqrtf(rough) : rough;
+        float ay = ax;
+        if (!tr_smooth(ax, ay)) {
+            ax = maxf(ax, 1e-4f);
+            ay = maxf(ay, 1e-4f);
+        }
+        if (tr_smooth(ax, ay)) return s4(0.0f);
+        float co = fabsf(wo.z), ci = fabsf(wi.z);
+        if (ci == 0.0f || co == 0.0f) return s4(0.0f);
+        v3 wm = wi + wo;
+        if (dot(wm, wm) == 0.0f) return s4(0.0f);
+        wm = normalize(wm);
+        S4 eta = eval_ior(sc, T, m, 0, uv, lambda), k = eval_ior(sc, T, m, 1, uv, lambda);
+        S4 F = fr_complex4(fabsf(dot(wo, wm)), eta, k);
+        float D = tr_d(wm, ax, ay), G = tr_g(wo, wi, ax, ay);
+        S4 f = D * F * G / (4.0f * ci * co);
+        v3 wmp = wm.z < 0.0f ? -wm : wm;
+        pdf = tr_pdf(wo, wmp, ax, ay) / (4.0f * fabsf(dot(wo, wmp)));
+        return f;
+    } else {  // fallback (:491-511)
+        float ci = dot(wi_w, n), co = dot(wo_w, n);
+        if (ci * co < 0.0f) return s4(0.0f);
+        float ct = fabsf(ci);
+        if (ct < 1e-6f) return s4(0.0f);
+        pdf = ct / PI_F;
+        return s4(0.5f / PI_F);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// lights (integrators/physical-wavefront/lights.jl:39-297; lights/diffuse-area.jl:53-82)
+// ------------------------------------------------------------------------------------------------
+struct LightSample {
+    S4 Li;
+    v3 wi;
+    float pdf;
+    v3 p_light;
+    bool is_delta;
+};
+HKD S4 light_spectrum(const DLight& l, S4 lambda) { return eval_illuminant(l.coef, lambda); }
+HKD S4 arealight_Le(const DScene& sc, const DTables& T, const DLight& l, v3 wo, v3 n, v2 uv, S4 lambda) {
+    if (l.kind != HK_LIGHT_DIFFUSE_AREA) return s4(0.0f);
+    if (!(l.flags & 1) && dot(wo, n) < 0.0f) return s4(0.0f);
+    if (l.Le_tex < 0) return eval_bounded(l.coef, lambda);  // uplift_rgb(Le * scale), bounded (Q3)
+    float o[4] = {0, 0, 0, 1};
+    tex_bilinear(sc.textures[l.Le_tex], uv, o);
+    return eval_bounded(coef_bounded(T, o[0] * l.scale, o[1] * l.scale, o[2] * l.scale), lambda);
+}
+HKD LightSample sample_light(const DScene& sc, const DTables& T, const DLight& l, v3 p, S4 lambda, v2 u) {
+    LightSample s;
+    s.Li = s4(0.0f);
+    s.wi = mk3(0, 0, 1);
+    s.pdf = 0.0f;
+    s.p_light = mk3(0, 0, 0);
+    s.is_delta = false;
+    switch (l.kind) {
+        case HK_LIGHT_POINT:
+        case HK_LIGHT_SPOT: {
+            v3 pos = mk3(l.p[0], l.p[1], l.p[2]);
+            v3 tl = pos - p;
+            float d2 = dot(tl, tl);
+            float dist = sqrtf(d2);
+            if (dist < 1e-6f) return s;
+            v3 wi = tl / dist;
+            float falloff = 1.0f;
+            if (l.kind == HK_LIGHT_SPOT) {
+                v3 mw = -wi;
+                v3 wl = normalize(mk3(l.v[0] * mw.x + l.v[1] * mw.y + l.v[2] * mw.z, l.v[3] * mw.x + l.v[4] * mw.y + l.v[5] * mw.z,
+                                      l.v[6] * mw.x + l.v[7] * mw.y + l.v[8] * mw.z));
+                float ct = wl.z;
+                if (ct < l.cos_total_width) return s;
+                if (!(ct >= l.cos_falloff_start)) {
+                    float dl = (ct - l.cos_total_width) / (l.cos_falloff_start - l.cos_total_width);
+                    falloff = dl * dl * dl * dl;
+                }
+                s.Li = ((l.scale * light_spectrum(l, lambda)) * falloff) / d2;
+            } else
+                s.Li = (l.scale * light_spectrum(l, lambda)) / d2;
+            s.wi = wi;
+            s.pdf = 1.0f;
+            s.p_light = pos;
+            s.is_delta = true;
+            return s;
+        }
+        case HK_LIGHT_DIRECTIONAL:
+        case HK_LIGHT_SUN: {
+            v3 wi = -mk3(l.p[0], l.p[1], l.p[2]);
+            s.wi = wi;
+            s.p_light = p + 1.0e6f * wi;
+            s.Li = l.scale * light_spectrum(l, lambda);
+            s.pdf = 1.0f;
+            s.is_delta = true;
+            return s;
+        }
+        case HK_LIGHT_AMBIENT: {
+            float z = 1.0f - 2.0f * u.x;
+            float r = sqrtf(maxf(0.0f, 1.0f - z * z));
+            float phi = 2.0f * PI_F * u.y;
+            v3 wi = mk3(r * cosf(phi), r * sinf(phi), z);
+            s.wi = wi;
+            s.pdf = 1.0f / (4.0f * PI_F);
+            s.p_light = p + 1.0e6f * wi;
+            s.Li = l.scale * light_spectrum(l, lambda);
+            return s;
+        }
+        case HK_LIGHT_DIFFUSE_AREA: {
+            float b0, b1;
+            if (u.x < u.y) {
+                b0 = u.x / 2.0f;
+                b1 = u.y - b0;
+            } else {
+                b1 = u.y / 2.0f;
+                b0 = u.x - b1;
+            }
+            float b2 = 1.0f - b0 - b1;
+            v3 pl = b0 * mk3(l.v[0], l.v[1], l.v[2]) + b1 * mk3(l.v[3], l.v[4], l.v[5]) + b2 * mk3(l.v[6], l.v[7], l.v[8]);
+            v3 tl = pl - p;
+            float d2 = dot(tl, tl);
+            if (d2 < 1e-12f) return s;
+            float dist = sqrtf(d2);
+            v3 wi = tl / dist;
+            v3 ln = mk3(l.normal[0], l.normal[1], l.normal[2]);
+            float ct = fabsf(dot(ln, -wi));
+            if (ct < 1e-6f) return s;
+            float pdf = d2 / (ct * l.area);
+            v2 uvs = mk2(b0 * l.uv[0] + b1 * l.uv[2] + b2 * l.uv[4], b0 * l.uv[1] + b1 * l.uv[3] + b2 * l.uv[5]);
+            S4 Le = arealight_Le(sc, T, l, mk3(-wi.x, -wi.y, -wi.z), ln, uvs, lambda);
+            if (is_black(Le)) return s;
+            s.Li = Le;
+            s.wi = wi;
+            s.pdf = pdf;
+            s.p_light = pl;
+            return s;
+        }
+        default: return s;
+    }
+}
+
+// ---- light BVH (lights/bvh-light-sampler.jl:58-232, light-bounds.jl:96-109,177-182) ----
+HKD float cos_sub_clamped(float sA, float cA, float sB, float cB) { return cA > cB ? 1.0f : cA * cB + sA * sB; }
+HKD float sin_sub_clamped(float sA, float cA, float sB, float cB) { return cA > cB ? 0.0f : sA * cB - cA * sB; }
+HKD float node_importance(const DLightNode& nd, v3 p, v3 n) {
+    if (nd.phi == 0.0f) return 0.0f;
+    v3 bmin = mk3(nd.bmin[0], nd.bmin[1], nd.bmin[2]), bmax = mk3(nd.bmax[0], nd.bmax[1], nd.bmax[2]);
+    v3 pc = (bmin + bmax) * 0.5f;
+    v3 dp = p - pc;
+    float d2 = dot(dp, dp);
+    d2 = maxf(d2, norm(bmax - bmin) * 0.5f);
+    v3 wi = normalize(dp);
+    float cw = dot(mk3(nd.w[0], nd.w[1], nd.w[2]), wi);
+    if (nd.bits & 1u) cw = fabsf(cw);
+    float sw = sqrtf(maxf(0.0f, 1.0f - cw * cw));
+    float cb;
+    {
+        v3 r = bmax - pc;
+        float r2 = dot(r, r);
+        float dd = dot(dp, dp);
+        cb = dd < r2 ? -1.0f : sqrtf(maxf(0.0f, 1.0f - r2 / dd));
+    }
+    float sb = sqrtf(maxf(0.0f, 1.0f - cb * cb));
+    float so = sqrtf(maxf(0.0f, 1.0f - nd.cos_o * nd.cos_o));
+    float cx = cos_sub_clamped(sw, cw, so, nd.cos_o);
+    float sx = sin_sub_clamped(sw, cw, so, nd.cos_o);
+    float cp = cos_sub_clamped(sx, cx, sb, cb);
+    if (cp <= nd.cos_e) return 0.0f;
+    float imp = nd.phi * cp / d2;
+    if (!is_zero(n)) {
+        float ci = fabsf(dot(wi, n));
+        float si = sqrtf(maxf(0.0f, 1.0f - ci * ci));
+        imp *= cos_sub_clamped(si, ci, sb, cb);
+    }
+    return maxf(imp, 0.0f);
+}
+HKD int bvh_sample_light(const DScene& sc, v3 p, v3 n, float u, float& pmf_out, unsigned& visited) {
+    pmf_out = 0.0f;
+    int ninf = sc.num_infinite_lights, nbvh = sc.num_bvh_lights;
+    if (ninf + nbvh == 0) return 0;
+    bool has_bvh = nbvh > 0;
+    float p_inf = (float)ninf / (float)(ninf + (has_bvh ? 1 : 0));
+    if (ninf > 0 && u < p_inf) {
+        float ur = u / p_inf;
+        int idx = (int)floorf(ur * (float)ninf);
+        idx = (idx < ninf - 1 ? idx : ninf - 1) + 1;
+        pmf_out = p_inf / (float)ninf;
+        return sc.infinite_lights[idx - 1];
+    }
+    if (!has_bvh) return 0;
+    float ub = ninf > 0 ? minf((u - p_inf) / (1.0f - p_inf), 0.99999994f) : minf(u, 0.99999994f);
+    float pmf = 1.0f - p_inf;
+    int ni = 1;
+    for (int it = 0; it < 64; ++it) {
+        const DLightNode& nd = sc.lnodes[ni - 1];
+        if (nd.bits & 2u) {
+            pmf_out = pmf;
+            return (int)nd.child1_or_light;
+        }
+        int c0i = ni + 1, c1i = (int)nd.child1_or_light;
+        float c0 = node_importance(sc.lnodes[c0i - 1], p, n);
+        float c1 = node_importance(sc.lnodes[c1i - 1], p, n);
+        visited += 2;
+        if (c0 == 0.0f && c1 == 0.0f) return 0;
+        float p0 = c0 / (c0 + c1);
+        if (ub < p0) {
+            pmf *= p0;
+            ub = ub / p0;
+            ni = c0i;
+        } else {
+            pmf *= (1.0f - p0);
+            ub = (ub - p0) / (1.0f - p0);
+            ni = c1i;
+        }
+    }
+    return 0;
+}
+HKD float bvh_pmf(const DScene& sc, v3 p, v3 n, int light_1based, unsigned& visited) {
+    if (light_1based < 1) return 0.0f;
+    bool has_bvh = sc.num_bvh_lights > 0;
+    uint32_t trail = sc.bit_trails[light_1based - 1];
+    if (trail == 0xFFFFFFFFu) {
+        if (sc.num_infinite_lights == 0) return 0.0f;
+        return 1.0f / (float)(sc.num_infinite_lights + (has_bvh ? 1 : 0));
+    }
+    if (!has_bvh) return 0.0f;
+    float p_inf = (float)sc.num_infinite_lights / (float)(sc.num_infinite_lights + 1);
+    float pm = 1.0f - p_inf;
+    int ni = 1;
+    for (int it = 0; it < 64; ++it) {
+        const DLightNode& nd = sc.lnodes[ni - 1];
+        if (nd.bits & 2u) return pm;
+        int c0i = ni + 1, c1i = (int)nd.child1_or_light;
+        float c0 = node_importance(sc.lnodes[c0i - 1], p, n);
+        float c1 = node_importance(sc.lnodes[c1i - 1], p, n);
+        visited += 2;
+        float sum = c0 + c1;
+        if (sum <= 0.0f) return 0.0f;
+        if ((trail & 1u) == 0u) {
+            pm *= c0 / sum;
+            ni = c0i;
+        } else {
+            pm *= c1 / sum;
+            ni = c1i;
+        }
+        trail >>= 1;
+    }
+    return pm;
+}
+
+}  // namespace hkd

@@ -1,0 +1,644 @@
+// hk_kernels.hip — wavefront VolPath kernels for gfx950 (wave64).
+//
+// One "pass" carries S samples of every pixel through the bounce loop at once (paths = pixels x S, laid
+// out in 8x8 pixel tiles so a wave's camera rays are coherent).  Per bounce the host enqueues, with no
+// readback:
+//     k_trace     persistent closest-hit traversal (LDS per-lane stacks) -> hit records, paths
+//                 ballot-compacted into one queue per material kind (+ escaped queue)            [K3]
+//     k_escaped   environment/ambient lights for escaped paths                                   [K7]
+//     k_shade<K>  one specialisation per material kind present: emission MIS, light-BVH NEE,
+//                 BSDF sample, Russian roulette, next ray; Sobol dims generated in registers     [K2,K8,K9,K11]
+//     k_shadow    shadow-segment traversal, adds Ld*T/mis to the path's radiance                 [K10]
+// then k_film folds the S samples of each pixel into the film accumulators in sample order        [K12]
+// Queue sizes live in device memory (counters[depth][queue]); every kernel sizes itself from them.
+#include <hip/hip_runtime.h>
+
+#include "hikari_mi355x.h"
+#include "hk_device.h"
+
+using namespace hkd;
+
+namespace {
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+// wave-aggregated queue push: one atomic per wave per queue
+__device__ __forceinline__ void queue_push(uint32_t* __restrict__ q, int* __restrict__ counter, uint32_t value, bool active) {
+    unsigned long long mask = __ballot(active);
+    if (mask == 0ull) return;
+    int lane = lane_id();
+    int leader = __ffsll((long long)mask) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(counter, __popcll(mask));
+    base = __shfl(base, leader);
+    if (active) q[base + __popcll(mask & ((1ull << lane) - 1ull))] = value;
+}
+
+// persistent work distribution: a wave claims 64 consecutive queue entries at a time
+__device__ __forceinline__ int claim_chunk(int* __restrict__ cursor) {
+    int base = 0;
+    if (lane_id() == 0) base = atomicAdd(cursor, 64);
+    return __shfl(base, 0);
+}
+
+__device__ __forceinline__ void wave_add(unsigned long long* dst, unsigned v) {
+    // wave reduction then one atomic
+    unsigned s = v;
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if (lane_id() == 0 && s) atomicAdd(dst, (unsigned long long)s);
+}
+
+__device__ __forceinline__ void slot_to_pixel(const DFrame& fr, int slot_in_sample, int& px, int& py, bool& inside) {
+    int tile = slot_in_sample >> 6, l = slot_in_sample & 63;
+    int tx = tile % fr.tiles_x, ty = tile / fr.tiles_x;
+    px = tx * 8 + (l & 7);
+    py = ty * 8 + (l >> 3);
+    inside = px < fr.width && py < fr.height;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------
+// K1: camera rays (volpath.jl:125-205).  One thread per path slot of the pass.
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_camera(DPathState st, DFrame fr, DTables T, DFilter flt, DCamera cam, DSobol sob, int initial_medium) {
+    int total = fr.n_pixels_padded * fr.samples_in_pass;
+    for (int slot = blockIdx.x * blockDim.x + threadIdx.x; slot < ((total + 63) & ~63); slot += gridDim.x * blockDim.x) {
+        bool active = slot < total;
+        int px = 0, py = 0;
+        bool inside = false;
+        int k = 0;
+        if (active) {
+            k = slot / fr.n_pixels_padded;
+            slot_to_pixel(fr, slot - k * fr.n_pixels_padded, px, py, inside);
+        }
+        active = active && inside;
+        if (active) {
+            int sample_idx = fr.first_sample + k * fr.sample_stride;
+            int x = px + 1, y = py + 1;  // 1-based pixel coordinates (Q1)
+            SobolCtx sc = sobol_ctx(sob, T.sobol, x, y, sample_idx);
+            float wavelength_u = sobol_1d(sc, 1);
+            v2 jit = sobol_2d(sc, 3);
+            float time_u = sobol_1d(sc, 4);
+            v2 lens = sobol_2d(sc, 6);
+            float fx, fy, fw;
+            filter_sample(flt, jit, fx, fy, fw);
+            S4 lambda, pdf;
+            sample_wavelengths_visible(wavelength_u, lambda, pdf);
+            v2 pfilm = mk2((float)x + 0.5f + fx, (float)fr.height - (float)y + 1.0f + 0.5f + fy);  // Q2
+            v3 ro, rd;
+            float time;
+            generate_ray(cam, pfilm, lens, time_u, ro, rd, time);
+            st.ray_o[slot] = make_float4(ro.x, ro.y, ro.z, INF_F);
+            st.ray_d[slot] = make_float4(rd.x, rd.y, rd.z, time);
+            st4(&st.lambda[slot], lambda);
+            st4(&st.pdf[slot], pdf);
+            st4(&st.beta[slot], s4(1.0f));
+            st4(&st.r_u[slot], s4(1.0f));
+            st4(&st.r_l[slot], s4(1.0f));
+            st4(&st.L[slot], s4(0.0f));
+            st.filter_w[slot] = fw;
+            st.flags[slot] = (uint32_t)(initial_medium + 1) << 16;
+        }
+        queue_push(st.ray_q[0], &st.counters[0 * Q_COUNT + Q_RAY], (uint32_t)slot, active);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K3: closest-hit traversal + classification (intersection.jl:188-269).
+// ---------------------------------------------------------------------------------------------------
+template <bool COUNT>
+__global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace(DPathState st, DScene sc, DTables T, DFrame fr, int depth, DStats* stats) {
+    __shared__ int lds_stack[(HK_TRACE_BLOCK / 64) * HK_LDS_STACK * 64];
+    int* stack = lds_stack + (threadIdx.x >> 6) * (HK_LDS_STACK * 64);
+    const int lane = lane_id();
+    const uint32_t* __restrict__ queue = st.ray_q[depth & 1];
+    const int n = st.counters[depth * Q_COUNT + Q_RAY];
+    int* cursor = &st.cursors[depth * Q_COUNT + Q_RAY];
+    int* counters = st.counters + depth * Q_COUNT;
+    unsigned n_nodes = 0, n_tris = 0, n_casts = 0, n_hits = 0;
+    for (int base = claim_chunk(cursor); base < n; base = claim_chunk(cursor)) {
+        int i = base + lane;
+        bool active = i < n;
+        uint32_t slot = active ? queue[i] : 0u;
+        int kind = -1;  // -1 none, -2 escaped, >= 0 material kind
+        if (active) {
+            float4 O = st.ray_o[slot], D = st.ray_d[slot];
+            v3 ro = mk3(O.x, O.y, O.z), rd = mk3(D.x, D.y, D.z);
+            float tmax = O.w;
+            // alpha-test loop: alpha-killed surfaces are skipped without consuming depth (<= 16 casts)
+            for (int it = 0; it < 16; ++it) {
+                bool dummy;
+                ++n_casts;
+                HitRec h = traverse<0, COUNT>(sc, ro, rd, it == 0 ? tmax : INF_F, stack, lane, n_nodes, n_tris, dummy);
+                if (h.prim < 0) {
+                    kind = -2;
+                    break;
+                }
+                ++n_hits;
+                DTriMeta meta = sc.meta[h.prim];
+                int mat = sc.mis[meta.mi].material;
+                if (!sc.all_opaque) {
+                    float w = 1.0f - h.u - h.v;
+                    v2 uv = uv_at(sc, h.prim, w, h.u, h.v);
+                    float alpha = surface_alpha(sc, mat, uv);
+                    if (alpha < 1.0f) {
+                        PCG32 rng = pcg32_init(pbrt_hash(ro), pbrt_hash(rd));
+                        if (pcg32_f32(rng) > alpha) {
+                            v3 pi = ro + rd * h.t;
+                            v3 ng = geometric_normal(sc, h.prim);
+                            v3 off = dot(rd, ng) > 0.0f ? ng : -ng;
+                            ro = pi + off * 1e-4f;
+                            continue;
+                        }
+                    }
+                }
+                // MixMaterial is resolved here so the queue is sorted by the *final* material kind
+                if (sc.materials[mat].kind == HK_MAT_MIX) {
+                    float w = 1.0f - h.u - h.v;
+                    v2 uv = uv_at(sc, h.prim, w, h.u, h.v);
+                    mat = resolve_mix_material(sc, mat, ro + rd * h.t, -rd, uv);
+                }
+                kind = sc.materials[mat].kind;
+                if (kind == HK_MAT_MIX) kind = HK_MAT_FALLBACK;
+                st.hit[slot] = make_float4(h.t, __int_as_float(h.prim), h.u, h.v);
+                st.mat_id[slot] = mat;
+                if (it > 0) st.ray_o[slot] = make_float4(ro.x, ro.y, ro.z, INF_F);  // origin after alpha skips
+                break;
+            }
+        }
+        // ballot-compact into per-kind queues
+        queue_push(st.escaped_q, &counters[Q_ESCAPED], slot, kind == -2);
+        unsigned long long pending = __ballot(kind >= 0);
+        while (pending) {
+            int src = __ffsll((long long)pending) - 1;
+            int k = __shfl(kind, src);
+            bool mine = kind == k;
+            queue_push(st.mat_q + (size_t)k * st.capacity, &counters[Q_MAT0 + k], slot, mine);
+            pending &= ~__ballot(mine);
+        }
+    }
+    wave_add(&stats->rays_closest, n_casts);
+    wave_add(&stats->hits, n_hits);
+    if (COUNT) {
+        wave_add(&stats->nodes, n_nodes);
+        wave_add(&stats->tris, n_tris);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K7: escaped rays (intersection.jl:622-678; lights.jl:408-467).  MIS uses 1/num_lights (Q6).
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_escaped(DPathState st, DScene sc, DTables T, int depth) {
+    const uint32_t* __restrict__ queue = st.escaped_q;
+    const int n = st.counters[depth * Q_COUNT + Q_ESCAPED];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        uint32_t slot = queue[i];
+        S4 lambda = ld4(&st.lambda[slot]);
+        S4 Le = s4(0.0f);
+        for (int li = 0; li < sc.n_lights; ++li) {
+            const DLight& l = sc.lights[li];
+            if (l.kind == HK_LIGHT_AMBIENT) Le = Le + l.scale * light_spectrum(l, lambda);
+        }
+        S4 beta = ld4(&st.beta[slot]);
+        S4 contribution = beta * Le;
+        if (is_black(contribution)) continue;
+        uint32_t fl = st.flags[slot];
+        int pdepth = (int)(fl & 0xff);
+        bool specular = (fl >> 8) & 1u;
+        S4 r_u = ld4(&st.r_u[slot]);
+        S4 fin;
+        if (pdepth == 0 || specular)
+            fin = contribution / average(r_u);
+        else {
+            float choice = sc.n_lights > 0 ? 1.0f / (float)sc.n_lights : 0.0f;
+            float light_pdf = 0.0f;  // only EnvironmentLight has a pdf (lights.jl:445-467)
+            S4 rl = ld4(&st.r_l[slot]) * choice * light_pdf;
+            float den = average(r_u + rl);
+            fin = den > 1e-10f ? contribution / den : contribution / average(r_u);
+        }
+        st4(&st.L[slot], ld4(&st.L[slot]) + fin);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K8 + K9 + K11 fused per material kind (surface-eval.jl:147-220, 250-341, 396-512).
+// ---------------------------------------------------------------------------------------------------
+template <int KIND>
+__global__ void __launch_bounds__(256) k_shade(DPathState st, DScene sc, DTables T, DFrame fr, DSobol sob, int depth, DStats* stats) {
+    const uint32_t* __restrict__ queue = st.mat_q + (size_t)KIND * st.capacity;
+    const int n = st.counters[depth * Q_COUNT + Q_MAT0 + KIND];
+    int* cursor = &st.cursors[depth * Q_COUNT + Q_MAT0 + KIND];
+    int* counters = st.counters + depth * Q_COUNT;
+    int* next_counters = st.counters + (depth + 1) * Q_COUNT;
+    uint32_t* next_q = st.ray_q[(depth + 1) & 1];
+    const int lane = lane_id();
+    unsigned n_vertices = 0, n_lnodes = 0;
+    for (int base = claim_chunk(cursor); base < n; base = claim_chunk(cursor)) {
+        int i = base + lane;
+        bool active = i < n;
+        uint32_t slot = active ? queue[i] : 0u;
+        bool push_shadow = false, push_ray = false;
+        if (active) {
+            ++n_vertices;
+            float4 H = st.hit[slot];
+            float4 O = st.ray_o[slot], D = st.ray_d[slot];
+            v3 ro = mk3(O.x, O.y, O.z), rd = mk3(D.x, D.y, D.z);
+            float t_hit = H.x;
+            int prim = __float_as_int(H.y);
+            Surface sf = surface_at(sc, prim, H.z, H.w, ro, rd, t_hit);
+            v3 wo = -rd;
+            DTriMeta meta = sc.meta[prim];
+            DMediumInterface mi = sc.mis[meta.mi];
+            const DMaterial& mat = sc.materials[st.mat_id[slot]];
+            S4 lambda = ld4(&st.lambda[slot]);
+            S4 beta = ld4(&st.beta[slot]);
+            S4 r_u = ld4(&st.r_u[slot]);
+            S4 r_l = ld4(&st.r_l[slot]);
+            uint32_t fl = st.flags[slot];
+            int pdepth = (int)(fl & 0xff);
+            bool specular_bounce = (fl >> 8) & 1u, any_non_specular = (fl >> 9) & 1u;
+            int medium = (int)(fl >> 16) - 1;
+
+            // ---- K8: emission from an area light hit, MIS against the light-BVH pmf ----
+            if (meta.arealight > 0) {
+                const DLight& light = sc.lights[meta.arealight - 1];
+                S4 Le = arealight_Le(sc, T, light, wo, sf.n, sf.uv, lambda);
+                if (!is_black(Le)) {
+                    S4 contribution = beta * Le;
+                    S4 fin;
+                    if (pdepth == 0 || specular_bounce)
+                        fin = contribution / average(r_u);
+                    else {
+                        float choice = bvh_pmf(sc, sf.pi, sf.n, (int)meta.arealight, n_lnodes);
+                        float ct = fabsf(dot(sf.n, normalize(rd)));
+                        float light_pdf = 0.0f;
+                        if (ct > 0.0f && sf.area > 0.0f) light_pdf = choice * ((t_hit * t_hit) / (ct * sf.area));
+                        S4 rl = r_l * light_pdf;
+                        float den = average(r_u + rl);
+                        fin = den > 1e-10f ? contribution / den : contribution / average(r_u);
+                    }
+                    st4(&st.L[slot], ld4(&st.L[slot]) + fin);
+                }
+            }
+
+            // pixel coordinates for the Sobol dimensions of this bounce (volpath.jl:252-262, Q19)
+            int k = (int)slot / fr.n_pixels_padded;
+            int px, py;
+            bool inside;
+            slot_to_pixel(fr, (int)slot - k * fr.n_pixels_padded, px, py, inside);
+            SobolCtx sctx = sobol_ctx(sob, T.sobol, px + 1, py + 1, fr.first_sample + k * fr.sample_stride);
+            const int base_dim = 6 + 7 * pdepth;
+
+            // ---- K9: next-event estimation through the light BVH ----
+            if (sc.n_lights > 0) {
+                float light_select = sobol_1d(sctx, base_dim + 1);
+                v2 u_light = sobol_2d(sctx, base_dim + 3);
+                float light_pmf;
+                int light_idx = bvh_sample_light(sc, sf.pi, sf.ns, light_select, light_pmf, n_lnodes);
+                if (light_idx >= 1 && light_idx <= sc.n_lights && light_pmf > 0.0f) {
+                    LightSample ls = sample_light(sc, T, sc.lights[light_idx - 1], sf.pi, lambda, u_light);
+                    if (ls.pdf > 0.0f && !is_black(ls.Li)) {
+                        float bsdf_pdf;
+                        S4 f = eval_bsdf<KIND>(sc, T, mat, wo, ls.wi, sf.ns, sf.uv, lambda, bsdf_pdf);
+                        if (!is_black(f)) {
+                            float ct = fabsf(dot(ls.wi, sf.ns));
+                            S4 Ld = beta * f * ls.Li * ct;
+                            if (!is_black(Ld)) {
+                                v3 off = 1e-4f * sf.ns;  // NB: shading normal (Q9)
+                                v3 so = dot(ls.wi, sf.ns) > 0.0f ? sf.pi + off : sf.pi - off;
+                                v3 tl = ls.p_light - so;
+                                float tmax = sqrtf(dot(tl, tl)) - 1e-3f;
+                                float nbp = ls.is_delta ? 0.0f : bsdf_pdf;
+                                st.sh_o[slot] = make_float4(so.x, so.y, so.z, tmax);
+                                st.sh_d[slot] = make_float4(ls.wi.x, ls.wi.y, ls.wi.z, __int_as_float(medium));
+                                st4(&st.sh_Ld[slot], Ld);
+                                st4(&st.sh_ru[slot], r_u * nbp);
+                                st4(&st.sh_rl[slot], (r_u * ls.pdf) * light_pmf);
+                                push_shadow = true;
+                            }
+                        }
+                    }
+                }
+            }
+
+            // ---- K11: BSDF sampling, throughput, Russian roulette, continuation ray ----
+            int new_depth = pdepth + 1;
+            if (new_depth < fr.max_depth) {
+                float uc = sobol_1d(sctx, base_dim + 4);
+                v2 u = sobol_2d(sctx, base_dim + 6);
+                bool regularize = fr.regularize && any_non_specular;
+                BSDFSample s = sample_bsdf<KIND>(sc, T, mat, wo, sf.ns, sf.uv, lambda, u, uc, regularize);
+                if (s.pdf > 0.0f && !is_black(s.f)) {
+                    float ct = fabsf(dot(s.wi, sf.ns));
+                    S4 nb = s.is_specular ? beta * s.f : beta * s.f * ct / s.pdf;
+                    S4 nrl = s.is_specular ? r_u : r_u / s.pdf;
+                    bool cont = true;
+                    if (new_depth > 3) {  // russian_roulette_spectral, min_depth fixed at 3 (Q7)
+                        float rr = sobol_1d(sctx, base_dim + 7);
+                        float q = maxf(0.05f, 1.0f - max_component(nb));
+                        if (rr < q)
+                            cont = false;
+                        else
+                            nb = nb * (1.0f / (1.0f - q));
+                    }
+                    if (cont) {
+                        int new_medium = (mi.inside != mi.outside) ? (dot(s.wi, sf.n) > 0.0f ? mi.outside : mi.inside) : medium;
+                        v3 off = dot(s.wi, sf.n) > 0.0f ? sf.n : -sf.n;
+                        v3 no = sf.pi + off * 0.0001f;
+                        st.ray_o[slot] = make_float4(no.x, no.y, no.z, INF_F);
+                        st.ray_d[slot] = make_float4(s.wi.x, s.wi.y, s.wi.z, 0.0f);  // time = 0 (Q17)
+                        st4(&st.beta[slot], nb);
+                        st4(&st.r_l[slot], nrl);  // r_u unchanged
+                        bool ans = any_non_specular || !s.is_specular;
+                        st.flags[slot] = (uint32_t)new_depth | ((s.is_specular ? 1u : 0u) << 8) | ((ans ? 1u : 0u) << 9) | ((uint32_t)(new_medium + 1) << 16);
+                        push_ray = true;
+                    }
+                }
+            }
+        }
+        queue_push(st.shadow_q, &counters[Q_SHADOW], slot, push_shadow);
+        queue_push(next_q, &next_counters[Q_RAY], slot, push_ray);
+    }
+    wave_add(&stats->vertices, n_vertices);
+    wave_add(&stats->light_nodes, n_lnodes);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K10: shadow rays (intersection.jl:302-406, 565-600).  Surface-only scenes: one segment, early exit on
+// any opaque hit.  Medium-transition / alpha surfaces are walked through (<= 10 segments).
+// ---------------------------------------------------------------------------------------------------
+template <bool COUNT>
+__global__ void __launch_bounds__(HK_TRACE_BLOCK) k_shadow(DPathState st, DScene sc, DTables T, int depth, DStats* stats) {
+    __shared__ int lds_stack[(HK_TRACE_BLOCK / 64) * HK_LDS_STACK * 64];
+    int* stack = lds_stack + (threadIdx.x >> 6) * (HK_LDS_STACK * 64);
+    const int lane = lane_id();
+    const uint32_t* __restrict__ queue = st.shadow_q;
+    const int n = st.counters[depth * Q_COUNT + Q_SHADOW];
+    int* cursor = &st.cursors[depth * Q_COUNT + Q_SHADOW];
+    unsigned n_nodes = 0, n_tris = 0, n_casts = 0, n_hits = 0;
+    for (int base = claim_chunk(cursor); base < n; base = claim_chunk(cursor)) {
+        int i = base + lane;
+        if (i >= n) continue;
+        uint32_t slot = queue[i];
+        float4 O = st.sh_o[slot], D = st.sh_d[slot];
+        v3 ro = mk3(O.x, O.y, O.z), dir = mk3(D.x, D.y, D.z);
+        float t_remaining = O.w;
+        int medium = __float_as_int(D.w);
+        S4 T_ray = s4(1.0f), tr_u = s4(1.0f), tr_l = s4(1.0f);
+        bool visible = false, done = false;
+        for (int seg = 0; seg < 10 && !done; ++seg) {
+            if (t_remaining < 1e-6f) break;
+            bool opaque;
+            ++n_casts;
+            HitRec h = traverse<1, COUNT>(sc, ro, dir, t_remaining, stack, lane, n_nodes, n_tris, opaque);
+            if (h.prim < 0) {
+                visible = true;  // (medium transmittance for the remaining distance lands with the media rows)
+                done = true;
+                break;
+            }
+            ++n_hits;
+            if (opaque) {
+                done = true;
+                break;
+            }
+            DTriMeta meta = sc.meta[h.prim];
+            DMediumInterface mi = sc.mis[meta.mi];
+            v3 ng = geometric_normal(sc, h.prim);
+            bool entering = dot(dir, ng) < 0.0f;
+            if (mi.inside == mi.outside) {
+                float w = 1.0f - h.u - h.v;
+                float alpha = surface_alpha(sc, mi.material, uv_at(sc, h.prim, w, h.u, h.v));
+                bool pass = false;
+                if (alpha < 1.0f) {
+                    PCG32 rng = pcg32_init(pbrt_hash(ro), pbrt_hash(dir));
+                    pass = pcg32_f32(rng) > alpha;
+                }
+                if (!pass) {
+                    done = true;
+                    break;
+                }
+            } else {
+                medium = entering ? mi.inside : mi.outside;
+            }
+            ro = ro + dir * (h.t + 1e-4f);
+            t_remaining = t_remaining - h.t - 1e-4f;
+        }
+        if (visible && !is_black(T_ray)) {
+            S4 mis = ld4(&st.sh_ru[slot]) * tr_u + ld4(&st.sh_rl[slot]) * tr_l;
+            float den = average(mis);
+            if (den > 1e-10f) {
+                S4 fin = ld4(&st.sh_Ld[slot]) * T_ray / den;
+                if (!is_black(fin)) st4(&st.L[slot], ld4(&st.L[slot]) + fin);
+            }
+        }
+        (void)medium;
+    }
+    wave_add(&stats->rays_shadow, n_casts);
+    wave_add(&stats->hits, n_hits);
+    if (COUNT) {
+        wave_add(&stats->nodes, n_nodes);
+        wave_add(&stats->tris, n_tris);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K12: spectral -> RGB, firefly clamp, filter-weighted accumulation (volpath.jl:326-375).  The S samples of
+// a pixel are folded in sample order, so the fp32 sums equal the reference's sample-by-sample sums.
+// ---------------------------------------------------------------------------------------------------
+template <typename ACC>
+__global__ void __launch_bounds__(256) k_film(DPathState st, DFrame fr, DTables T, ACC* __restrict__ accum) {
+    int n = fr.n_pixels_padded;
+    size_t N = (size_t)fr.width * fr.height;
+    for (int tid = blockIdx.x * blockDim.x + threadIdx.x; tid < n; tid += gridDim.x * blockDim.x) {
+        int px, py;
+        bool inside;
+        slot_to_pixel(fr, tid, px, py, inside);
+        if (!inside) continue;
+        size_t p = (size_t)py * fr.width + px;
+        ACC r = accum[3 * p], g = accum[3 * p + 1], b = accum[3 * p + 2], w = accum[3 * N + p];
+        for (int k = 0; k < fr.samples_in_pass; ++k) {
+            size_t slot = (size_t)k * n + tid;
+            v3 rgb = spectral_to_rgb_clamped(T, ld4(&st.L[slot]), ld4(&st.lambda[slot]), ld4(&st.pdf[slot]), fr.max_component_value);
+            float fw = st.filter_w[slot];
+            r += (ACC)(fw * rgb.x);
+            g += (ACC)(fw * rgb.y);
+            b += (ACC)(fw * rgb.z);
+            w += (ACC)fw;
+        }
+        accum[3 * p] = r;
+        accum[3 * p + 1] = g;
+        accum[3 * p + 2] = b;
+        accum[3 * N + p] = w;
+    }
+}
+
+// K13 (volpath.jl:384-417): out = Julia Matrix{RGB{Float32}}[height,width] column-major
+template <typename ACC>
+__global__ void k_finalize(const ACC* __restrict__ accum, float* __restrict__ out, int width, int height) {
+    size_t N = (size_t)width * height;
+    for (size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x; p < N; p += (size_t)gridDim.x * blockDim.x) {
+        int px = (int)(p % width), py = (int)(p / width);
+        ACC w = accum[3 * N + p];
+        float r = 0.0f, g = 0.0f, b = 0.0f;
+        if (w > (ACC)0) {
+            ACC inv = (ACC)1 / w;
+            r = (float)(accum[3 * p] * inv);
+            g = (float)(accum[3 * p + 1] * inv);
+            b = (float)(accum[3 * p + 2] * inv);
+        }
+        float* o = out + 3 * ((size_t)py + (size_t)height * px);
+        o[0] = r;
+        o[1] = g;
+        o[2] = b;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// sub-kernel entry points used by the parity tests
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(HK_TRACE_BLOCK) k_test_trace(DScene sc, int n, const float* o3, const float* d3, const float* tmax, float* out_t, int* out_prim,
+                                                               float* out_uv) {
+    __shared__ int lds_stack[(HK_TRACE_BLOCK / 64) * HK_LDS_STACK * 64];
+    int* stack = lds_stack + (threadIdx.x >> 6) * (HK_LDS_STACK * 64);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        unsigned a = 0, b = 0;
+        bool dummy;
+        HitRec h = traverse<0, false>(sc, mk3(o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]), mk3(d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]), tmax[i], stack, lane_id(), a, b,
+                                      dummy);
+        out_t[i] = h.prim >= 0 ? h.t : INF_F;
+        out_prim[i] = h.prim;
+        out_uv[2 * i] = h.prim >= 0 ? h.u : 0.0f;
+        out_uv[2 * i + 1] = h.prim >= 0 ? h.v : 0.0f;
+    }
+}
+__global__ void k_test_sobol(DTables T, DSobol sob, int n, const int* px, const int* py, const int* sidx, const int* dim, float* o1, float* o2) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        SobolCtx c = sobol_ctx(sob, T.sobol, px[i], py[i], sidx[i]);
+        o1[i] = sobol_1d(c, dim[i]);
+        v2 v = sobol_2d(c, dim[i]);
+        o2[2 * i] = v.x;
+        o2[2 * i + 1] = v.y;
+    }
+}
+__global__ void k_test_camera(DTables T, DFilter flt, DCamera cam, DSobol sob, int height, int n, const int* px, const int* py, const int* sidx, float* out15) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        int x = px[i], y = py[i];
+        SobolCtx sc = sobol_ctx(sob, T.sobol, x, y, sidx[i]);
+        float wu = sobol_1d(sc, 1);
+        v2 jit = sobol_2d(sc, 3);
+        float tu = sobol_1d(sc, 4);
+        v2 lens = sobol_2d(sc, 6);
+        float fx, fy, fw;
+        filter_sample(flt, jit, fx, fy, fw);
+        S4 lambda, pdf;
+        sample_wavelengths_visible(wu, lambda, pdf);
+        v2 pfilm = mk2((float)x + 0.5f + fx, (float)height - (float)y + 1.0f + 0.5f + fy);
+        v3 ro, rd;
+        float time;
+        generate_ray(cam, pfilm, lens, tu, ro, rd, time);
+        float* o = out15 + 15 * (size_t)i;
+        o[0] = lambda.x; o[1] = lambda.y; o[2] = lambda.z; o[3] = lambda.w;
+        o[4] = pdf.x; o[5] = pdf.y; o[6] = pdf.z; o[7] = pdf.w;
+        o[8] = fw;
+        o[9] = ro.x; o[10] = ro.y; o[11] = ro.z;
+        o[12] = rd.x; o[13] = rd.y; o[14] = rd.z;
+    }
+}
+__global__ void k_test_uplift(DTables T, int mode, int n, const float* rgb, const float* lam, float* out) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        S4 l = s4(lam[4 * i], lam[4 * i + 1], lam[4 * i + 2], lam[4 * i + 3]);
+        float r = rgb[3 * i], g = rgb[3 * i + 1], b = rgb[3 * i + 2];
+        S4 s = mode == 0 ? eval_bounded(coef_bounded(T, r, g, b), l) : (mode == 1 ? eval_scaled(coef_unbounded(T, r, g, b), l) : eval_illuminant(coef_illuminant(T, r, g, b), l));
+        out[4 * i] = s.x;
+        out[4 * i + 1] = s.y;
+        out[4 * i + 2] = s.z;
+        out[4 * i + 3] = s.w;
+    }
+}
+__global__ void k_test_light_bvh(DScene sc, int n, const float* p3, const float* n3, const float* u, int* out_light, float* out_pmf, const int* query, float* out_qpmf) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        v3 p = mk3(p3[3 * i], p3[3 * i + 1], p3[3 * i + 2]), nn = mk3(n3[3 * i], n3[3 * i + 1], n3[3 * i + 2]);
+        float pmf;
+        unsigned vis = 0;
+        out_light[i] = bvh_sample_light(sc, p, nn, u[i], pmf, vis);
+        out_pmf[i] = pmf;
+        if (query) out_qpmf[i] = bvh_pmf(sc, p, nn, query[i], vis);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// launch wrappers (called from hk_api.cpp)
+// ---------------------------------------------------------------------------------------------------
+namespace hk {
+
+static inline int grid_for(int n, int block, int cap) {
+    long g = ((long)n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+void launch_camera(hipStream_t s, const DPathState& st, const DFrame& fr, const DTables& T, const DFilter& f, const DCamera& c, const DSobol& sob, int initial_medium) {
+    int total = fr.n_pixels_padded * fr.samples_in_pass;
+    hipLaunchKernelGGL(k_camera, dim3(grid_for(total, 256, 8192)), dim3(256), 0, s, st, fr, T, f, c, sob, initial_medium);
+}
+void launch_trace(hipStream_t s, int blocks, const DPathState& st, const DScene& sc, const DTables& T, const DFrame& fr, int depth, DStats* stats) {
+    if (fr.count_nodes)
+        hipLaunchKernelGGL(k_trace<true>, dim3(blocks), dim3(HK_TRACE_BLOCK), 0, s, st, sc, T, fr, depth, stats);
+    else
+        hipLaunchKernelGGL(k_trace<false>, dim3(blocks), dim3(HK_TRACE_BLOCK), 0, s, st, sc, T, fr, depth, stats);
+}
+void launch_shadow(hipStream_t s, int blocks, const DPathState& st, const DScene& sc, const DTables& T, const DFrame& fr, int depth, DStats* stats) {
+    if (fr.count_nodes)
+        hipLaunchKernelGGL(k_shadow<true>, dim3(blocks), dim3(HK_TRACE_BLOCK), 0, s, st, sc, T, depth, stats);
+    else
+        hipLaunchKernelGGL(k_shadow<false>, dim3(blocks), dim3(HK_TRACE_BLOCK), 0, s, st, sc, T, depth, stats);
+}
+void launch_escaped(hipStream_t s, int blocks, const DPathState& st, const DScene& sc, const DTables& T, int depth) {
+    hipLaunchKernelGGL(k_escaped, dim3(blocks), dim3(256), 0, s, st, sc, T, depth);
+}
+void launch_shade(hipStream_t s, int blocks, int kind, const DPathState& st, const DScene& sc, const DTables& T, const DFrame& fr, const DSobol& sob, int depth, DStats* stats) {
+#define HK_SHADE_CASE(K) \
+    case K: hipLaunchKernelGGL(k_shade<K>, dim3(blocks), dim3(256), 0, s, st, sc, T, fr, sob, depth, stats); break;
+    switch (kind) {
+        HK_SHADE_CASE(HK_MAT_MATTE)
+        HK_SHADE_CASE(HK_MAT_MIRROR)
+        HK_SHADE_CASE(HK_MAT_GLASS)
+        HK_SHADE_CASE(HK_MAT_CONDUCTOR)
+        default: hipLaunchKernelGGL(k_shade<HK_MAT_FALLBACK>, dim3(blocks), dim3(256), 0, s, st, sc, T, fr, sob, depth, stats); break;
+    }
+#undef HK_SHADE_CASE
+}
+void launch_film(hipStream_t s, const DPathState& st, const DFrame& fr, const DTables& T, void* accum, bool f64) {
+    int g = grid_for(fr.n_pixels_padded, 256, 4096);
+    if (f64)
+        hipLaunchKernelGGL(k_film<double>, dim3(g), dim3(256), 0, s, st, fr, T, (double*)accum);
+    else
+        hipLaunchKernelGGL(k_film<float>, dim3(g), dim3(256), 0, s, st, fr, T, (float*)accum);
+}
+void launch_finalize(hipStream_t s, const void* accum, bool f64, float* out, int w, int h) {
+    int g = grid_for(w * h, 256, 4096);
+    if (f64)
+        hipLaunchKernelGGL(k_finalize<double>, dim3(g), dim3(256), 0, s, (const double*)accum, out, w, h);
+    else
+        hipLaunchKernelGGL(k_finalize<float>, dim3(g), dim3(256), 0, s, (const float*)accum, out, w, h);
+}
+void launch_test_trace(hipStream_t s, const DScene& sc, int n, const float* o, const float* d, const float* tmax, float* t, int* prim, float* uv) {
+    hipLaunchKernelGGL(k_test_trace, dim3(grid_for(n, HK_TRACE_BLOCK, 1280)), dim3(HK_TRACE_BLOCK), 0, s, sc, n, o, d, tmax, t, prim, uv);
+}
+void launch_test_sobol(hipStream_t s, const DTables& T, const DSobol& sob, int n, const int* px, const int* py, const int* si, const int* dim, float* o1, float* o2) {
+    hipLaunchKernelGGL(k_test_sobol, dim3(grid_for(n, 256, 1024)), dim3(256), 0, s, T, sob, n, px, py, si, dim, o1, o2);
+}
+void launch_test_camera(hipStream_t s, const DTables& T, const DFilter& f, const DCamera& c, const DSobol& sob, int height, int n, const int* px, const int* py, const int* si,
+                        float* out) {
+    hipLaunchKernelGGL(k_test_camera, dim3(grid_for(n, 256, 1024)), dim3(256), 0, s, T, f, c, sob, height, n, px, py, si, out);
+}
+void launch_test_uplift(hipStream_t s, const DTables& T, int mode, int n, const float* rgb, const float* lam, float* out) {
+    hipLaunchKernelGGL(k_test_uplift, dim3(grid_for(n, 256, 1024)), dim3(256), 0, s, T, mode, n, rgb, lam, out);
+}
+void launch_test_light_bvh(hipStream_t s, const DScene& sc, int n, const float* p, const float* nn, const float* u, int* ol, float* op, const int* q, float* oq) {
+    hipLaunchKernelGGL(k_test_light_bvh, dim3(grid_for(n, 256, 1024)), dim3(256), 0, s, sc, n, p, nn, u, ol, op, q, oq);
+}
+
+}  // namespace hk

@@ -1,0 +1,191 @@
+// hk_types.h — device-resident records of the MI355X VolPath path (shared by host upload code and kernels).
+//
+// HBM layout (DESIGN.md "Data layout"):
+//   BVH2 nodes        64 B  = 4 x float4 : both child AABBs + 2 child refs        (one 64-B line per visit)
+//   leaf triangles    48 B  = 3 x float4 : v0|prim id, e1|flags, e2               (leaf order)
+//   shading triangles 36 B positions + 36 B normals + 24 B uvs + 12 B meta        (original prim order)
+//   path state        SoA float4 arrays indexed by path slot (pixel x sample-in-pass)
+//   queues            uint32 path slots + device-side counters (no host readback inside a frame)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define HK_MAX_KINDS 11          // HK_MAT_* count (Mix is resolved before queueing)
+#define HK_LDS_STACK 32          // per-lane traversal stack entries kept in LDS (builder bounds the depth)
+#define HK_TRACE_BLOCK 256
+
+// child reference: >= 0 inner node index; < 0 leaf: ~ref = (first_tri << 3) | (count - 1), count <= 4 (<=8 encodable)
+struct DNode {
+    float4 a;  // lo0.x lo0.y lo0.z hi0.x
+    float4 b;  // hi0.y hi0.z lo1.x lo1.y
+    float4 c;  // lo1.z hi1.x hi1.y hi1.z
+    int c0, c1;
+    int pad0, pad1;
+};
+
+#define HK_TRI_OPAQUE 1u  // e1.w bit: surface is neither a medium transition nor alpha-tested
+
+// sigmoid-polynomial spectrum with optional scale (c0,c1,c2,scale)
+struct DSpectrumParam {
+    float4 coef;     // baked (constant colour): sigmoid coefficients + scale
+    float rgba[4];   // raw value (needed when tex >= 0 is blended, or for alpha)
+    int tex;         // -1 constant
+    int pad[3];
+};
+
+struct DMaterial {
+    int kind, flags;
+    int i[4];
+    int spectrum[2];
+    DSpectrumParam rgb[4];
+    float f[8];
+    int ftex[8];
+    uint32_t mix_key[4];
+};
+
+struct DTexture {
+    const float* data;
+    int width, height, channels, pad;
+};
+
+struct DPLSpectrum {
+    const float* lambdas;
+    const float* values;
+    int n, pad;
+};
+
+// 128-byte light record
+struct DLight {
+    int kind;
+    int flags;        // bit0 two_sided, bit1 illuminant (multiply by D65)
+    float scale;      // light.scale
+    float area;
+    float4 coef;      // baked spectrum: sigmoid coefficients + scale (2m for illuminants; Le*scale for area lights)
+    float p[3];       // position | direction
+    float cos_total_width;
+    float cos_falloff_start;
+    float normal[3];
+    float v[9];       // area-light vertices | spot world_to_light 3x3
+    float uv[6];
+    int Le_tex;
+    float Le_rgba[4]; // raw Le (textured emission path)
+    int pad;
+};
+
+struct DLightNode {  // 64 B
+    float bmin[3], bmax[3], w[3];
+    float phi, cos_o, cos_e;
+    uint32_t bits;              // bit0 two_sided, bit1 is_leaf
+    uint32_t child1_or_light;   // 1-based
+    uint32_t pad[2];
+};
+
+struct DMediumInterface {
+    int material, inside, outside, pad;
+};
+
+struct DTriMeta {
+    uint32_t mi, prim_index, arealight;
+};
+
+struct DScene {
+    const DNode* nodes;
+    const float4* leaf_tris;    // 3 float4 per triangle in leaf order
+    int root_ref;
+    int n_tris;
+    const float* positions;     // [T][9]
+    const float* normals;       // [T][9] or null
+    const float* uvs;           // [T][6] or null
+    const float* tangents;      // [T][9] or null
+    const DTriMeta* meta;
+    const DMaterial* materials;
+    const DTexture* textures;
+    const DPLSpectrum* spectra;
+    const DMediumInterface* mis;
+    const DLight* lights;
+    int n_lights;
+    int n_materials;
+    const DLightNode* lnodes;
+    const uint32_t* bit_trails;
+    const int* infinite_lights;
+    int num_bvh_lights, num_infinite_lights;
+    int has_escape_lights;      // any ambient / environment light
+    int all_opaque;             // no medium transitions and no alpha-tested surfaces
+};
+
+struct DTables {
+    const uint32_t* sobol;      // dims 0 and 1 (2 x 52)
+    const float* cie;           // x[471] y[471] z[471]
+    const float* rgb2spec_scale;
+    const float* rgb2spec_coeffs;
+    int rgb2spec_res;
+};
+
+struct DFilter {
+    int type;
+    float rx, ry, p1, p2;
+    int nx, ny;
+    const float* func;            // ny*nx
+    const float* marginal_cdf;    // ny+1
+    const float* marginal_func;   // ny
+    const float* conditional_cdf; // ny*(nx+1)
+    float dmin_x, dmin_y, dmax_x, dmax_y;
+    float func_integral;
+};
+
+struct DCamera {
+    float r2c[16];
+    float c2w[16];
+    float lens_radius, focal_distance, shutter_open, shutter_close;
+};
+
+struct DSobol {
+    int log2_spp, n_base4_digits;
+    uint32_t seed;
+    int width;
+};
+
+// queue ids inside one depth's counter block
+enum { Q_RAY = 0, Q_SHADOW = 1, Q_ESCAPED = 2, Q_MAT0 = 3, Q_COUNT = Q_MAT0 + HK_MAX_KINDS };
+
+struct DPathState {
+    int capacity;          // path slots
+    float4* ray_o;         // o.xyz, t_max
+    float4* ray_d;         // d.xyz, time
+    float4* hit;           // t, prim(bits), u, v
+    int* mat_id;           // resolved material index of the hit
+    float4* lambda;
+    float4* pdf;
+    float4* beta;
+    float4* r_u;
+    float4* r_l;
+    float4* L;
+    uint32_t* flags;       // depth(8) | specular(1)<<8 | any_non_specular(1)<<9 | (medium+1)<<16
+    float* filter_w;
+    float4* sh_o;          // shadow ray: o.xyz, t_max
+    float4* sh_d;          // d.xyz, medium (bits)
+    float4* sh_Ld;
+    float4* sh_ru;
+    float4* sh_rl;
+    uint32_t* ray_q[2];    // ping-pong ray queues (path slots)
+    uint32_t* shadow_q;
+    uint32_t* escaped_q;
+    uint32_t* mat_q;       // HK_MAX_KINDS * capacity
+    int* counters;         // (max_depth + 2) * Q_COUNT queue sizes
+    int* cursors;          // work-stealing cursors, same shape
+};
+
+struct DStats {
+    unsigned long long rays_closest, rays_shadow, nodes, tris, hits, vertices, collisions, light_nodes;
+};
+
+struct DFrame {            // per-pass constants
+    int width, height, tiles_x, tiles_y;
+    int n_pixels_padded;   // tiles_x*tiles_y*64
+    int samples_in_pass;
+    int first_sample, sample_stride;   // sample index of pass-sample k = first_sample + k*sample_stride
+    int max_depth;
+    int regularize;
+    float max_component_value;
+    int count_nodes;       // 1: accumulate node/triangle counters
+};

@@ -1,0 +1,19 @@
+"""Multi-GPU sharding of the VolPath path: units are (pixel, sample_idx) paths with no
+cross-path communication, so each rank renders the sample indices  rank+1, rank+1+G, ...  for ALL pixels
+(ZSobol is a pure function of (px, py, sample_idx, dim), sampler/sobol.jl:269-309) and ONE sum-reduce of the
+film accumulators [pixel_rgb 3N | pixel_weight_sum N] to rank 0 finishes the frame.  torch.distributed is
+plumbing only (backend "nccl" is RCCL over xGMI on ROCm; "gloo" in the CPU tests)."""
+
+
+def shard_samples(total_samples, rank, world):
+    """-> (first_sample_idx (1-based), count, stride) for this rank."""
+    count = (total_samples - rank + world - 1) // world if total_samples > rank else 0
+    return rank + 1, count, world
+
+
+def reduce_film(accum_tensor, root=0):
+    """Sum-reduce the film accumulators onto `root` (16 MiB at 1024^2: one small collective per frame)."""
+    import torch.distributed as dist
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.reduce(accum_tensor, dst=root, op=dist.ReduceOp.SUM)
+    return accum_tensor

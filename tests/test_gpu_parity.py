@@ -1,0 +1,281 @@
+"""GPU parity tests (-m gpu): the HIP path, driven through the C-ABI, against the CPU oracle on the same
+seeded inputs.  Bars: sub-kernels bit-exact or <= 2 ulp; traversal hit identity exact;
+frames: relMSE <= 1e-3 and >= 99 % of pixels within 1e-2 relative L2 (tolerance is written in the test)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def ulp_diff(a, b):
+    a = np.ascontiguousarray(a, np.float32).view(np.int32).astype(np.int64)
+    b = np.ascontiguousarray(b, np.float32).view(np.int32).astype(np.int64)
+    a = np.where(a < 0, -(a & 0x7fffffff), a)
+    b = np.where(b < 0, -(b & 0x7fffffff), b)
+    return np.abs(a - b)
+
+
+def frame_metrics(gpu, ref):
+    rel_mse = float(np.mean((gpu - ref) ** 2 / (ref ** 2 + 1e-3)))
+    num = np.sqrt(((gpu - ref) ** 2).sum(axis=2))
+    den = np.sqrt((ref ** 2).sum(axis=2)) + 1e-6
+    frac_ok = float(np.mean(num / den <= 1e-2))
+    return rel_mse, frac_ok
+
+
+def _pi(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def test_sobol_bit_exact(hk, oracle, gpu_ctx):
+    rng = np.random.default_rng(11)
+    n = 100000
+    px = rng.integers(1, 1025, n).astype(np.int32)
+    py = rng.integers(1, 1025, n).astype(np.int32)
+    s = rng.integers(1, 4097, n).astype(np.int32)
+    dim = rng.integers(1, 230, n).astype(np.int32)
+    for spp in (4096, 8192):
+        o1, o2 = oracle.sobol(1024, 1024, spp, 0, px, py, s, dim)
+        g1 = np.empty(n, np.float32)
+        g2 = np.empty((n, 2), np.float32)
+        L = hk._lib.lib()
+        hk._lib.check(L.hk_test_sobol(gpu_ctx.h, 1024, 1024, spp, 0, n, _pi(px), _pi(py), _pi(s), _pi(dim),
+                                      g1.ctypes.data_as(hk._abi.PF), g2.ctypes.data_as(hk._abi.PF)), "hk_test_sobol")
+        assert np.array_equal(o1, g1) and np.array_equal(o2, g2)
+
+
+def test_uplift_le_2ulp(hk, oracle, gpu_ctx):
+    rng = np.random.default_rng(12)
+    n = 50000
+    rgb = rng.random((n, 3), dtype=np.float32)
+    rgb[:100] = rgb[:100, :1]          # grays
+    rgb[100:200] *= 20.0               # > 1 (clamped by the bounded uplift, scaled by the others)
+    lam = (360 + 470 * rng.random((n, 4), dtype=np.float32)).astype(np.float32)
+    L = hk._lib.lib()
+    for mode in (0, 1, 2):
+        ref = oracle.uplift(mode, rgb, lam)
+        out = np.empty_like(ref)
+        hk._lib.check(L.hk_test_uplift(gpu_ctx.h, mode, n, rgb.ctypes.data_as(hk._abi.PF), lam.ctypes.data_as(hk._abi.PF),
+                                       out.ctypes.data_as(hk._abi.PF)), "hk_test_uplift")
+        assert ulp_diff(out, ref).max() <= 2, mode
+
+
+def test_camera_stage(hk, oracle, gpu_ctx):
+    """K1: wavelengths (atanh/cosh differ by <= a few ulp between glibc and the device libm), filter weight and ray."""
+    from hikari_jl_amd import scenes
+    s, film, cam = scenes.cornell_box(800, 800)
+    p = hk.integrator_params(max_depth=8, samples=256)
+    rng = np.random.default_rng(13)
+    n = 20000
+    px = rng.integers(1, 801, n).astype(np.int32)
+    py = rng.integers(1, 801, n).astype(np.int32)
+    si = rng.integers(1, 257, n).astype(np.int32)
+    ref = oracle.camera_samples(p, cam, 800, 800, px, py, si)
+    L = hk._lib.lib()
+    integ = C.c_void_p()
+    hk._lib.check(L.hk_integrator_create(gpu_ctx.h, C.byref(p), C.byref(integ)), "hk_integrator_create")
+    out = np.empty((n, 15), np.float32)
+    rec = cam.record()
+    hk._lib.check(L.hk_test_camera(gpu_ctx.h, integ, C.byref(rec), 800, 800, n, _pi(px), _pi(py), _pi(si), out.ctypes.data_as(hk._abi.PF)), "hk_test_camera")
+    L.hk_integrator_destroy(integ)
+    assert np.allclose(out[:, :4], ref[:, :4], rtol=0, atol=2e-3)            # lambda [nm]
+    assert np.allclose(out[:, 4:8], ref[:, 4:8], rtol=2e-5, atol=1e-9)       # pdf
+    assert ulp_diff(out[:, 8], ref[:, 8]).max() <= 2                          # filter weight
+    assert np.array_equal(out[:, 9:12], ref[:, 9:12])                         # ray origin (no lens): exact
+    assert ulp_diff(out[:, 12:15], ref[:, 12:15]).max() <= 2                  # ray direction
+
+
+def _random_rays(rng, n, lo, hi):
+    o = (lo + (hi - lo) * rng.random((n, 3))).astype(np.float32)
+    d = rng.normal(size=(n, 3))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    return o, d
+
+
+@pytest.mark.parametrize("which", ["cornell", "single", "integration"])
+def test_closest_hit_parity_1M_rays(hk, oracle, gpu_ctx, which):
+    """K3 traversal over the product's SAH BVH vs the oracle's median BVH: same
+    (t, prim, bary) for 1 M random rays, including axis-aligned rays and rays grazing shared edges."""
+    from hikari_jl_amd import scenes
+    s, film, cam = {"cornell": scenes.cornell_box, "single": scenes.single_triangle, "integration": scenes.integration_test_scene}[which](64, 64)
+    rng = np.random.default_rng(21)
+    n = 1_000_000 if which == "cornell" else 200_000
+    o, d = _random_rays(rng, n, np.array([-1.2, -0.2, -1.2]), np.array([1.2, 2.2, 1.2]))
+    d[:1000] = np.array([0, -1, 0], np.float32)                  # axis-aligned
+    d[1000:2000] = np.array([1, 0, 0], np.float32)
+    tri = np.array(np.ctypeslib.as_array(s.desc.positions, shape=(s.desc.n_triangles * 9,))).reshape(-1, 3, 3)
+    k = min(20000, n - 2000)
+    tsel = rng.integers(0, tri.shape[0], k)
+    e = rng.random(k)[:, None]
+    target = tri[tsel, 0] * (1 - e) + tri[tsel, 1] * e            # points exactly on triangle edges
+    dd = target - o[2000:2000 + k]
+    d[2000:2000 + k] = (dd / np.linalg.norm(dd, axis=1, keepdims=True)).astype(np.float32)
+    tmax = np.full(n, np.inf, np.float32)
+    tmax[::7] = rng.random(len(tmax[::7])).astype(np.float32) * 2.0
+    rt, rp, ruv = oracle.OracleScene(s).trace(o, d, tmax)
+    sh = hk.scene_handle(gpu_ctx, s)
+    gt = np.empty(n, np.float32)
+    gp = np.empty(n, np.int32)
+    guv = np.empty((n, 2), np.float32)
+    L = hk._lib.lib()
+    hk._lib.check(L.hk_trace_closest(gpu_ctx.h, sh, n, o.ctypes.data_as(hk._abi.PF), d.ctypes.data_as(hk._abi.PF), tmax.ctypes.data_as(hk._abi.PF),
+                                     gt.ctypes.data_as(hk._abi.PF), _pi(gp), guv.ctypes.data_as(hk._abi.PF)), "hk_trace_closest")
+    assert (rp >= 0).mean() > 0.3
+    assert np.array_equal(rp, gp)
+    assert np.array_equal(rt, gt)
+    assert np.array_equal(ruv, guv)
+
+
+def test_light_bvh_parity(hk, oracle, gpu_ctx):
+    """Light-BVH: identical tree (host builders are independent) and <= 2 ulp sample/pmf on the device."""
+    from hikari_jl_amd import geometry as G
+    rng = np.random.default_rng(31)
+    s = hk.Scene()
+    s.push(hk.PointLight((0.3, 1.5, 0.2), hk.RGBSpectrum(15.0)))
+    s.push(hk.SpotLight((0.5, 1.9, -0.5), (0, 0, 0), hk.RGBSpectrum(30.0), 40.0, 30.0))
+    s.push(hk.AmbientLight(hk.RGBSpectrum(0.1, 0.2, 0.4)))
+    s.push(G.rect3f((-1, 0, -1), (2, 0.01, 2)), hk.MatteMaterial())
+    for i in range(40):  # emissive quads scattered in the box
+        c = rng.random(3) * np.array([1.6, 1.6, 1.6]) + np.array([-0.8, 0.2, -0.8])
+        q = G.quad(c, c + [0.1, 0, 0], c + [0.1, 0, 0.1], c + [0, 0, 0.1])
+        s.push(q, hk.MediumInterface(hk.MatteMaterial(), emission=hk.Emissive(Le=hk.RGBSpectrum(*(0.2 + 0.8 * rng.random(3))), scale=1.0 + i % 3, two_sided=bool(i % 2))))
+    s.sync()
+    osc = oracle.OracleScene(s)
+    on, ot = osc.light_bvh_nodes()
+    sh = hk.scene_handle(gpu_ctx, s)
+    L = hk._lib.lib()
+    nn = C.c_int32()
+    L.hk_scene_light_bvh_copy(sh, C.byref(nn), None, None)
+    gn = np.zeros((nn.value, 16), np.float32)
+    gtr = np.zeros(s.desc.n_lights, np.uint32)
+    L.hk_scene_light_bvh_copy(sh, C.byref(nn), gn.ctypes.data_as(hk._abi.PF), gtr.ctypes.data_as(C.POINTER(C.c_uint32)))
+    assert gn.shape == on.shape and np.array_equal(gtr, ot)
+    assert np.array_equal(gn[:, 12:15], on[:, 12:15])                         # topology identical
+    assert ulp_diff(gn[:, :12], on[:, :12]).max() <= 4                        # cone unions go through acos/sin/cos
+    n = 50000
+    p = (rng.random((n, 3)) * 2 - 1).astype(np.float32) + np.array([0, 1, 0], np.float32)
+    nrm = rng.normal(size=(n, 3))
+    nrm = (nrm / np.linalg.norm(nrm, axis=1, keepdims=True)).astype(np.float32)
+    nrm[:500] = 0                                                             # medium scattering: n = 0
+    u = rng.random(n, dtype=np.float32)
+    q = rng.integers(1, s.desc.n_lights + 1, n).astype(np.int32)
+    rl, rpmf, rq = osc.light_bvh(p, nrm, u, q)
+    gl = np.empty(n, np.int32)
+    gpmf = np.empty(n, np.float32)
+    gq = np.empty(n, np.float32)
+    hk._lib.check(L.hk_test_light_bvh(gpu_ctx.h, sh, n, p.ctypes.data_as(hk._abi.PF), nrm.ctypes.data_as(hk._abi.PF), u.ctypes.data_as(hk._abi.PF),
+                                      _pi(gl), gpmf.ctypes.data_as(hk._abi.PF), _pi(q), gq.ctypes.data_as(hk._abi.PF)), "hk_test_light_bvh")
+    same = gl == rl
+    assert same.mean() > 0.999                                                # a 1-ulp node difference may flip a knife-edge choice
+    assert np.allclose(gpmf[same], rpmf[same], rtol=2e-5, atol=0)
+    assert np.allclose(gq, rq, rtol=2e-5, atol=1e-12)
+    assert len(set(gl.tolist())) > 20
+
+
+FRAME_CASES = [
+    ("single", dict(max_depth=4, samples=16), (80, 60)),
+    ("cornell_area", dict(max_depth=8, samples=8), (96, 96)),
+    ("cornell_point", dict(max_depth=5, samples=8), (64, 64)),
+    ("integration", dict(max_depth=4, samples=4), (64, 64)),
+]
+
+
+def _scene(name, w, h):
+    from hikari_jl_amd import scenes
+    if name == "single":
+        return scenes.single_triangle(w, h)
+    if name == "cornell_area":
+        return scenes.cornell_box(w, h, light="area")
+    if name == "cornell_point":
+        return scenes.cornell_box(w, h, light="point")
+    return scenes.integration_test_scene(w, h)
+
+
+@pytest.mark.parametrize("name,kw,res", FRAME_CASES)
+def test_frame_parity(hk, oracle, name, kw, res):
+    """Whole-frame parity, same seed (0), same spp.  Tolerance: relMSE <= 1e-3 and >= 99 % of
+    pixels with relative L2 over RGB <= 1e-2.  (In practice the two agree to ~1e-6 except at the few pixels
+    where an atanh/cosh/sin/cos ulp flips a branch.)"""
+    w, h = res
+    s, film, cam = _scene(name, w, h)
+    p = hk.integrator_params(**kw)
+    acc, ost = oracle.OracleScene(s).render(p, cam, w, h, kw["samples"])
+    ref = oracle.finalize(acc, w, h)
+    vp = hk.VolPath(**kw)
+    vp(s, film, cam)
+    rel_mse, frac_ok = frame_metrics(film.framebuffer, ref)
+    assert np.isfinite(film.framebuffer).all()
+    assert rel_mse <= 1e-3 and frac_ok >= 0.99, (name, rel_mse, frac_ok)
+    st = vp.stats()
+    # same work: identical ray counts up to the few flipped branches
+    assert abs(int(st.rays_closest) - int(ost.rays_closest)) <= 0.002 * ost.rays_closest + 4
+    assert abs(int(st.rays_shadow) - int(ost.rays_shadow)) <= 0.002 * ost.rays_shadow + 4
+    # samples_per_pass is a pure scheduling knob: 1 sample/pass == auto
+    film2 = hk.Film((w, h))
+    vp2 = hk.VolPath(samples_per_pass=1, **kw)
+    vp2(s, film2, cam)
+    assert np.array_equal(film2.framebuffer, film.framebuffer)
+    vp.close()
+    vp2.close()
+
+
+def test_progressive_and_sharded_rendering(hk):
+    """render! adds one sample on top of the accumulators (volpath.jl:488-499); sample-index sharding
+     over strided index sets reproduces the single-device film up to fp32 summation order."""
+    from hikari_jl_amd import scenes
+    s, film, cam = scenes.cornell_box(64, 64, light="area")
+    vp = hk.VolPath(max_depth=6, samples=8)
+    vp(s, film, cam)
+    full = film.framebuffer.copy()
+    acc_full = vp.read_accumulators(film)
+    film2 = hk.Film((64, 64))
+    vp2 = hk.VolPath(max_depth=6, samples=8)
+    vp2._ensure(film2)
+    vp2.clear()
+    for _ in range(8):
+        vp2.render(s, film2, cam)
+    assert film2.iteration_index == 8
+    assert np.array_equal(film2.framebuffer, full)
+    parts = []
+    for rank in range(2):
+        f = hk.Film((64, 64))
+        v = hk.VolPath(max_depth=6, samples=8)
+        v._ensure(f)
+        v.clear()
+        v.render_samples(s, f, cam, 4, stride=2, first=rank + 1, readback=False)
+        parts.append(v.read_accumulators(f))
+        v.close()
+    assert np.allclose(parts[0] + parts[1], acc_full, rtol=1e-5, atol=1e-6)
+    vp.close()
+    vp2.close()
+
+
+def test_full_size_properties(hk):
+    """BASELINE config 2 at full size (800x800, depth 8) on a few samples: size-independent properties —
+    finite, non-negative, deterministic re-render, weight sum == spp * filter integral."""
+    from hikari_jl_amd import scenes
+    s, film, cam = scenes.cornell_box(800, 800, light="area")
+    vp = hk.VolPath(max_depth=8, samples=4)
+    vp(s, film, cam)
+    a = film.framebuffer.copy()
+    acc = vp.read_accumulators(film)
+    assert np.isfinite(a).all() and (a >= 0).all() and a.mean() > 0.05
+    vp(s, film, cam)
+    assert np.array_equal(a, film.framebuffer)
+    w = acc[3 * 640000:]
+    assert np.allclose(w, w[0], rtol=1e-2) and w[0] > 0
+    st = vp.stats()
+    assert st.rays_closest >= 4 * 640000
+    vp.close()
+
+
+def test_error_behaviour(hk, gpu_ctx):
+    L = hk._lib.lib()
+    p = hk.integrator_params(max_depth=0)
+    h = C.c_void_p()
+    assert L.hk_integrator_create(gpu_ctx.h, C.byref(p), C.byref(h)) == hk._abi.HK_ERR_INVALID
+    assert b"max_depth" in L.hk_last_error()
+    with pytest.raises(AssertionError):
+        hk.VolPath(material_coherence="bogus")

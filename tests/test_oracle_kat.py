@@ -1,0 +1,291 @@
+"""Pins the oracle against known answers that do not need the (un-runnable) Julia reference:
+public-algorithm KATs re-implemented independently in Python, analytic identities the reference's own
+tests assert (test/materials.jl:1-5, test/film.jl:1-6, test/filter.jl:9-52, test/rgb2spec_gpu.jl:104-139),
+and closed-form scene checks."""
+import ctypes as C
+import struct
+
+import numpy as np
+import pytest
+
+M64 = (1 << 64) - 1
+
+
+def py_murmur64a(data: bytes, seed=0):
+    m, r = 0xc6a4a7935bd1e995, 47
+    h = (seed ^ (len(data) * m)) & M64
+    nb = len(data) // 8
+    for i in range(nb):
+        k = struct.unpack_from("<Q", data, 8 * i)[0]
+        k = (k * m) & M64
+        k ^= k >> r
+        k = (k * m) & M64
+        h ^= k
+        h = (h * m) & M64
+    tail = data[8 * nb:]
+    if tail:
+        for i in range(len(tail) - 1, -1, -1):
+            h ^= tail[i] << (8 * i)
+        h = (h * m) & M64
+    h ^= h >> r
+    h = (h * m) & M64
+    h ^= h >> r
+    return h
+
+
+def py_mix_bits(v):
+    v ^= v >> 31
+    v = (v * 0x7fb5d329728ea185) & M64
+    v ^= v >> 27
+    v = (v * 0x81dadef4bc2dd44d) & M64
+    v ^= v >> 33
+    return v
+
+
+def test_murmur_and_mixbits(oracle):
+    L = oracle.lib()
+    rng = np.random.default_rng(1)
+    for n in (0, 1, 3, 4, 7, 8, 12, 20, 33):
+        data = bytes(rng.integers(0, 256, n, dtype=np.uint8))
+        for seed in (0, 0x1234567890abcdef):
+            assert L.hko_murmur64a(data, n, seed) == py_murmur64a(data, seed)
+    for v in (0, 1, 0xdeadbeef, M64, 0x0123456789abcdef):
+        assert L.hko_mix_bits(v) == py_mix_bits(v)
+
+
+def test_pcg32_reference_vector(oracle):
+    """pcg32 demo vector (pcg-c-basic `pcg32_srandom(42, 54)`): pbrt's SetSequence(seq=54, seed=42)."""
+    L = oracle.lib()
+    u = (C.c_uint32 * 6)()
+    f = (C.c_float * 6)()
+    L.hko_pcg32(54, 42, 1, 6, u, f)
+    assert [hex(x) for x in u] == ["0xa15c02b7", "0x7b47f409", "0xba1d3330", "0x83d2f293", "0xbfa4784b", "0xcbed606e"]
+    assert all(0.0 <= x < 1.0 for x in f)
+    assert abs(f[0] - 0xa15c02b7 / 2 ** 32) < 1e-7
+
+
+# ---- independent Python ZSobol (pbrt-v4 ZSobolSampler as restated by sampler/sobol.jl) ----
+PERMS = [(0, 1, 2, 3), (0, 1, 3, 2), (0, 2, 1, 3), (0, 2, 3, 1), (0, 3, 2, 1), (0, 3, 1, 2), (1, 0, 2, 3), (1, 0, 3, 2),
+         (1, 2, 0, 3), (1, 2, 3, 0), (1, 3, 2, 0), (1, 3, 0, 2), (2, 1, 0, 3), (2, 1, 3, 0), (2, 0, 1, 3), (2, 0, 3, 1),
+         (2, 3, 0, 1), (2, 3, 1, 0), (3, 1, 2, 0), (3, 1, 0, 2), (3, 2, 1, 0), (3, 2, 0, 1), (3, 0, 2, 1), (3, 0, 1, 2)]
+
+
+def py_morton2(x, y):
+    r = 0
+    for b in range(32):
+        r |= ((x >> b) & 1) << (2 * b)
+        r |= ((y >> b) & 1) << (2 * b + 1)
+    return r
+
+
+def py_brev(v):
+    return int("{:032b}".format(v)[::-1], 2)
+
+
+def py_owen(v, seed):
+    M = 0xffffffff
+    v = py_brev(v)
+    v ^= (v * 0x3d20adea) & M
+    v = (v + seed) & M
+    v = (v * ((seed >> 16) | 1)) & M
+    v ^= (v * 0x05526c56) & M
+    v ^= (v * 0x53a22864) & M
+    return py_brev(v)
+
+
+def py_sobol(a, dim, scramble, mats):
+    v = 0
+    i = dim * 52
+    while a:
+        if a & 1:
+            v ^= int(mats[i])
+        a >>= 1
+        i += 1
+    v = py_owen(v, scramble)
+    f = np.float32(np.float32(v) * np.float32(2.3283064365386963e-10))
+    return min(f, np.float32(1.0) - np.float32(1.1920929e-7))
+
+
+def py_sample_index(morton, dim, log2spp, ndig):
+    idx = 0
+    pow2 = log2spp & 1
+    last = 1 if pow2 else 0
+    for i in range(ndig - 1, last - 1, -1):
+        shift = 2 * i - (1 if pow2 else 0)
+        digit = (morton >> shift) & 3
+        higher = morton >> (shift + 2)
+        p = (py_mix_bits(higher ^ ((0x55555555 * dim) & M64)) >> 24) % 24
+        idx |= PERMS[p][digit] << shift
+    if pow2:
+        digit = morton & 1
+        idx |= digit ^ (py_mix_bits((morton >> 1) ^ ((0x55555555 * dim) & M64)) & 1)
+    return idx
+
+
+def py_zsobol(px, py, s, dim, w, h, spp, seed, mats):
+    log2spp = int(np.ceil(np.log2(max(1, spp))))
+    ndig = int(np.ceil(np.log2(max(w, h)))) + (log2spp + 1) // 2
+    morton = (py_morton2(px, py) << log2spp) | s
+    idx = py_sample_index(morton, dim, log2spp, ndig)
+    h1 = py_murmur64a(struct.pack("<iI", dim + 1, seed)) & 0xffffffff
+    bits = py_murmur64a(struct.pack("<iI", dim + 2, seed))
+    return (py_sobol(idx, 0, h1, mats), (py_sobol(idx, 0, bits & 0xffffffff, mats), py_sobol(idx, 1, bits >> 32, mats)))
+
+
+@pytest.mark.parametrize("spp", [4096, 8192])
+def test_zsobol_against_independent_python(hk, oracle, spp):
+    mats = hk.tables.load()["sobol"]
+    rng = np.random.default_rng(3)
+    n = 200
+    px = rng.integers(1, 801, n)
+    py = rng.integers(1, 801, n)
+    s = rng.integers(1, 257, n)
+    dim = rng.integers(1, 70, n)
+    o1, o2 = oracle.sobol(800, 800, spp, 0, px, py, s, dim)
+    for i in range(n):
+        e1, e2 = py_zsobol(int(px[i]), int(py[i]), int(s[i]), int(dim[i]), 800, 800, spp, 0, mats)
+        assert o1[i] == e1 and o2[i, 0] == e2[0] and o2[i, 1] == e2[1]
+    assert (o1 >= 0).all() and (o1 < 1).all() and (o2 >= 0).all() and (o2 < 1).all()
+
+
+def test_sobol_matrices_first_dimension_is_van_der_corput(hk):
+    m = hk.tables.load()["sobol"]
+    assert [int(x) for x in m[:4]] == [0x80000000, 0x40000000, 0x20000000, 0x10000000]
+    assert int(m[52]) == 0x80000000 and int(m[53]) == 0xc0000000
+
+
+def test_fresnel_identities(oracle):
+    """test/materials.jl:1-5: fresnel_dielectric(c, 1, 1) == 0; plus normal incidence ((n-1)/(n+1))^2."""
+    L = oracle.lib()
+    for c in (1.0, 0.5, 0.1):
+        assert abs(L.hko_fresnel_dielectric(c, 1.0)) < 1e-6
+    assert abs(L.hko_fresnel_dielectric(1.0, 1.5) - 0.04) < 1e-6
+    assert L.hko_fresnel_dielectric(0.1, 1.0 / 1.5) == 1.0  # total internal reflection
+    # conductor with k = 0 reduces to the dielectric formula
+    for c in (1.0, 0.7, 0.3):
+        assert abs(L.hko_fr_complex(c, 1.5, 0.0) - L.hko_fresnel_dielectric(c, 1.5)) < 1e-6
+
+
+def test_lanczos_and_gaussian_filters(hk, oracle):
+    """test/film.jl:1-6 (Lanczos(0)=1, Lanczos(r)<1e-6) and test/filter.jl:9-52 (weight == func_integral)."""
+    L = oracle.lib()
+    lz = hk.integrator_params(filter=hk.LanczosSincFilter())
+    assert abs(L.hko_filter_eval(C.byref(lz), 0.0, 0.0) - 1.0) < 1e-6
+    assert abs(L.hko_filter_eval(C.byref(lz), 4.0, 0.0)) < 1e-6
+    for flt in (hk.GaussianFilter(), hk.MitchellFilter(), hk.GaussianFilter(radius=(2.0, 2.0), sigma=0.8)):
+        p = hk.integrator_params(filter=flt)
+        rng = np.random.default_rng(5)
+        u = rng.random((20000, 2), dtype=np.float32)
+        out = np.empty((20000, 3), np.float32)
+        fi = C.c_float()
+        L.hko_filter_sample(C.byref(p), 20000, u.ctypes.data_as(hk._abi.PF), out.ctypes.data_as(hk._abi.PF), C.byref(fi))
+        assert np.all(np.abs(out[:, 0]) <= flt.radius[0]) and np.all(np.abs(out[:, 1]) <= flt.radius[1])
+        w = out[:, 2]
+        if isinstance(flt, hk.GaussianFilter):   # positive filter: weight is the constant func_integral
+            assert abs(w.mean() - fi.value) < 1e-3 * fi.value
+            assert abs(w.min() - fi.value) < 1e-2 * fi.value and abs(w.max() - fi.value) < 1e-2 * fi.value
+            # numeric integral of the (truncated, shifted) Gaussian within 2 %
+            xs = np.linspace(-flt.radius[0], flt.radius[0], 801)
+            g = np.maximum(0, np.exp(-xs ** 2 / (2 * flt.p1 ** 2)) - np.exp(-flt.radius[0] ** 2 / (2 * flt.p1 ** 2)))
+            assert abs(np.trapezoid(g, xs) ** 2 - fi.value) < 0.02 * fi.value
+
+
+def test_uplift_identities(hk, oracle):
+    """rgb2spec.jl:90-102 / test/rgb2spec_gpu.jl:104-139: gray => constant spectrum equal to the gray level;
+    unbounded uplift preserves the max component at the spectrum's peak; illuminant = 2m*poly*D65."""
+    lam = np.tile(np.array([[420.0, 530.0, 610.0, 700.0]], np.float32), (4, 1))
+    gray = np.array([[0.2] * 3, [0.5] * 3, [0.73] * 3, [1.0] * 3], np.float32)
+    out = oracle.uplift(0, gray, lam)
+    assert np.allclose(out, gray[:, :1], atol=2e-6)
+    L = oracle.lib()
+    assert L.hko_sample_d65(560.0) == 100.0
+    ill = oracle.uplift(2, np.array([[2.0, 2.0, 2.0]] * 4, np.float32), lam)
+    d65 = np.array([L.hko_sample_d65(float(x)) for x in lam[0]], np.float32)
+    assert np.allclose(ill[0], 4.0 * 0.5 * d65, rtol=1e-6)      # Li = 2*D65 for RGBSpectrum(2)
+    red = oracle.uplift(0, np.array([[0.65, 0.05, 0.05]] * 4, np.float32), lam)
+    assert red[0, 3] > red[0, 1] and (red >= 0).all() and (red <= 1).all()
+    # round trip: integrate the uplifted reflectance against CIE*D65 -> back to (roughly) the same sRGB
+    t = hk.tables.load()
+    wl = np.arange(360, 831, dtype=np.float32)
+    rgb_in = np.array([[0.65, 0.05, 0.05], [0.12, 0.45, 0.15], [0.2, 0.3, 0.8]], np.float32)
+    for c in rgb_in:
+        spec = np.concatenate([oracle.uplift(0, c[None].repeat(1, 0), wl[i:i + 4][None]) if len(wl[i:i + 4]) == 4 else
+                               oracle.uplift(0, c[None], np.pad(wl[i:], (0, 4 - len(wl[i:])), mode="edge")[None])[:, :len(wl[i:])]
+                               for i in range(0, 471, 4)], axis=1)[0]
+        d = np.array([L.hko_sample_d65(float(x)) for x in wl])
+        X, Y, Z = (np.sum(t["cie"][k] * spec * d) for k in range(3))
+        Yn = np.sum(t["cie"][1] * d)
+        xyz = np.array([X, Y, Z]) / Yn
+        M = np.array([[3.2404542, -1.5371385, -0.4985314], [-0.9692660, 1.8760108, 0.0415560], [0.0556434, -0.2040259, 1.0572252]])
+        assert np.allclose(M @ xyz, c, atol=0.02)
+
+
+def test_wavelength_sampling(oracle, hk):
+    u = np.linspace(0.0, 0.999, 64, dtype=np.float32)
+    out = np.empty((64, 8), np.float32)
+    oracle.lib().hko_wavelengths(64, u.ctypes.data_as(hk._abi.PF), out.ctypes.data_as(hk._abi.PF))
+    lam, pdf = out[:, :4], out[:, 4:]
+    assert (lam >= 360).all() and (lam <= 830).all() and (pdf > 0).all()
+    # pdf integrates to 1 over [360, 830]
+    xs = np.linspace(360, 830, 4001)
+    assert abs(np.trapezoid(0.0039398042 / np.cosh(0.0072 * (xs - 538)) ** 2, xs) - 1.0) < 1e-3
+
+
+def test_single_triangle_centre_pixel_closed_form(hk, oracle):
+    """Config 1: lit Lambertian triangle under a directional light, no occluder:
+    L = Kd/pi * Li * cos(theta) per wavelength  =>  film value = rgb(L) summed over the hero wavelengths."""
+    from hikari_jl_amd import scenes
+    s, film, cam = scenes.single_triangle(16, 12)
+    osc = oracle.OracleScene(s)
+    p = hk.integrator_params(max_depth=4, samples=64, max_component_value=1e9)   # no firefly clamp
+    acc, st = osc.render(p, cam, 16, 12, 64)
+    img = oracle.finalize(acc, 16, 12)
+    assert np.isfinite(img).all()
+    c = img[6, 8].astype(np.float64)                        # looks at the origin: bary = (1/3, 1/3, 1/3)
+    ns = np.array([0.7, 0.7, 2.428]) / np.linalg.norm([0.7, 0.7, 2.428])
+    expected_Y = 0.8 / np.pi * ns[2] * 2.0 * 10566.864      # Kd/pi * cos * Li, Li = 2*D65, sum(ybar*D65) = 10566.86
+    Y = 0.2126729 * c[0] + 0.7151522 * c[1] + 0.0721750 * c[2]
+    assert abs(Y - expected_Y) < 0.08 * expected_Y, (Y, expected_Y)
+    assert img[0, 0].max() == 0.0                           # background: no lights seen by escaped rays
+    assert st.rays_closest > 0 and st.rays_shadow > 0
+    # with the default clamp every sample saturates at max_component_value = 10 (Q14)
+    p2 = hk.integrator_params(max_depth=4, samples=8)
+    acc2, _ = osc.render(p2, cam, 16, 12, 8)
+    assert 5.0 < oracle.finalize(acc2, 16, 12)[6, 8].max() <= 10.0 + 1e-4
+
+
+def test_white_furnace_like_energy_bound(hk, oracle):
+    """Closed Lambertian box lit by an interior point light: every pixel finite, non-negative, and the
+    render is reproducible bit-for-bit (deterministic sampler)."""
+    from hikari_jl_amd import scenes
+    s, film, cam = scenes.cornell_box(32, 32, light="point", spheres=False)
+    osc = oracle.OracleScene(s)
+    p = hk.integrator_params(max_depth=5, samples=4)
+    a1, _ = osc.render(p, cam, 32, 32, 4)
+    a2, _ = osc.render(p, cam, 32, 32, 4)
+    assert np.array_equal(a1, a2)
+    img = oracle.finalize(a1, 32, 32)
+    assert np.isfinite(img).all() and (img >= 0).all() and img.mean() > 1e-3
+    # progressive == one-shot: 2+2 samples on the same accumulators equals 4 samples
+    b, _ = osc.render(p, cam, 32, 32, 2)
+    b, _ = osc.render(p, cam, 32, 32, 2, first=3, accum=b)
+    assert np.array_equal(a1, b)
+    # sample-index sharding (2 "GPUs"): union of strided sample sets == single-device sample set
+    s0, _ = osc.render(p, cam, 32, 32, 2, first=1, stride=2)
+    s1, _ = osc.render(p, cam, 32, 32, 2, first=2, stride=2)
+    assert np.allclose(s0 + s1, a1, rtol=1e-5, atol=1e-6)
+
+
+def test_integration_envelope(hk, oracle):
+    """test/volpath_integration.jl:96-113 envelope on the 64x64 scene (fog omitted until the media rows):
+    no NaN/Inf, 0.001 < mean(ACES, gamma 2.2) < 10."""
+    from hikari_jl_amd import scenes
+    s, film, cam = scenes.integration_test_scene(64, 64)
+    osc = oracle.OracleScene(s)
+    p = hk.integrator_params(max_depth=4, samples=4)
+    acc, _ = osc.render(p, cam, 64, 64, 4)
+    img = oracle.finalize(acc, 64, 64)
+    assert img.shape == (64, 64, 3) and np.isfinite(img).all() and (img.sum(axis=2) > 0).any()
+    x = img * 1.0
+    aces = np.clip((x * (2.51 * x + 0.03)) / (x * (2.43 * x + 0.59) + 0.14), 0, 1) ** (1 / 2.2)
+    assert 0.001 < aces.mean() < 10

@@ -549,8 +549,14 @@ HKD HitRec traverse(const DScene& sc, v3 o, v3 d, float t_max, int* __restrict__
     best.u = best.v = 0.0f;
     opaque_hit = false;
     if (sc.n_tris == 0) return best;
-    const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
+    // slab test in FMA form t = b*inv_d + (-o*inv_d).  inv_d is clamped to +-1e30 so axis-parallel rays give
+    // +-huge instead of inf - inf = NaN (the test only culls; 1e30 is beyond any scene scale).
+    const float ix = clampf(1.0f / d.x, -1e30f, 1e30f), iy = clampf(1.0f / d.y, -1e30f, 1e30f), iz = clampf(1.0f / d.z, -1e30f, 1e30f);
     const float ox = -o.x * ix, oy = -o.y * iy, oz = -o.z * iz;
+    // rounding slack of the FMA form: |err(t)| <= 2^-24 (|o*inv_d| + |t|).  Culling must never drop a triangle
+    // whose computed t ties the current best (coplanar faces of abutting boxes), so the interval is widened by
+    // an absolute term from |o*inv_d| plus a relative 1e-5.
+    const float eps_abs = 2.4e-7f * fmaxf(fmaxf(fabsf(ix) < 1e30f ? fabsf(ox) : 0.0f, fabsf(iy) < 1e30f ? fabsf(oy) : 0.0f), fabsf(iz) < 1e30f ? fabsf(oz) : 0.0f);
     int sp = 0;
     int cur = sc.root_ref;
     const float4* __restrict__ nodes4 = reinterpret_cast<const float4*>(sc.nodes);
@@ -570,9 +576,8 @@ HKD HitRec traverse(const DScene& sc, v3 o, v3 d, float t_max, int* __restrict__
             float u0z = fmaf(C.x, iz, oz), u1z = fmaf(C.w, iz, oz);
             float n1 = fmaxf(fmaxf(fminf(u0x, u1x), fminf(u0y, u1y)), fmaxf(fminf(u0z, u1z), 0.0f));
             float f1 = fminf(fminf(fmaxf(u0x, u1x), fmaxf(u0y, u1y)), fminf(fmaxf(u0z, u1z), best.t));
-            // widen by a few ulps: culling must never drop a triangle whose t equals the current best
-            bool h0 = n0 * 0.9999995f <= f0 * 1.0000005f;
-            bool h1 = n1 * 0.9999995f <= f1 * 1.0000005f;
+            bool h0 = n0 * 0.99999f - eps_abs <= f0 * 1.00001f + eps_abs;
+            bool h1 = n1 * 0.99999f - eps_abs <= f1 * 1.00001f + eps_abs;
             int c0 = __float_as_int(D.x), c1 = __float_as_int(D.y);
             if (h0 && h1) {
                 bool first0 = n0 <= n1;

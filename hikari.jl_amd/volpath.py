@@ -164,6 +164,7 @@ class VolPath:
         film.iteration_index = 0
         self._ensure(film)
         self.clear()
+        self.reset_stats()
         self.render_samples(scene, film, camera, self.samples_per_pixel)
         return film
 
@@ -171,6 +172,17 @@ class VolPath:
         s = A.hk_stats()
         _lib.check(_lib.lib().hk_stats_get(self._ctx.h, C.byref(s)), "hk_stats_get")
         return s
+
+    def reset_stats(self):
+        _lib.check(_lib.lib().hk_stats_reset(self._ctx.h), "hk_stats_reset")
+
+    def enable_counters(self, count_nodes=False, time_kernels=False):
+        self._ensure_ctx()
+        _lib.check(_lib.lib().hk_stats_enable_counters(self._ctx.h, (1 if count_nodes else 0) | (2 if time_kernels else 0)), "hk_stats_enable_counters")
+
+    def _ensure_ctx(self):
+        if self._ctx is None:
+            self._ctx = Context.get(self.device)
 
     def sync(self):
         _lib.check(_lib.lib().hk_sync(self._ctx.h), "hk_sync")

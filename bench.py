@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py — Mrays/s of the VolPath hot path on BASELINE.json configs[1]:
+Cornell box (diffuse + area light), 800x800, depth 8, 256 spp, 1 x MI355X.
+
+A "step" is one wavefront pass of the hot path over one batch of synthetic input: SPP_PER_STEP (=4)
+samples of every pixel of the 800x800 frame carried through the 8-bounce loop (2.56 M paths).  The default
+64 steps are exactly the 256-spp frame, so `seconds_to_256spp` is the timed region itself.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU; rank g renders sample indices g+1, g+1+N, ... (weak scaling: K steps each), then
+ONE RCCL sum-reduce of the film accumulators to rank 0 inside the timed region.  value = rays of all ranks /
+max-over-ranks time.  The scene, BVH and film live in HBM before the timed region starts.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+W, H, DEPTH, SPP_PER_STEP, FULL_SPP = 800, 800, 8, 4, 256
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+S_NODE, B_TRI, B_HIT, B_RAY_IN, B_HIT_OUT = 64, 36, 96, 32, 16   # SURVEY.md §8(d) algorithmic bytes per cast
+S_STATE = 104                  # compact path state, read + written once per path vertex
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=FULL_SPP // SPP_PER_STEP)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-spp", type=int, default=1)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 or world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local_rank)
+
+    import hikari_jl_amd as hk
+    from hikari_jl_amd import distributed as hd
+    from hikari_jl_amd import scenes
+
+    scene, film, cam = scenes.cornell_box(W, H, light="area")
+    n_pix = W * H
+    # film accumulators live in a torch tensor so torch.distributed (RCCL) can reduce them in place
+    accum = torch.zeros(4 * n_pix, dtype=torch.float32, device="cuda")
+    vp = hk.VolPath(max_depth=DEPTH, samples=FULL_SPP, samples_per_pass=SPP_PER_STEP, device=local_rank)
+    vp.use_external_accumulators(accum.data_ptr())
+    vp._ensure(film)
+    L = hk._lib.lib()
+
+    def run_steps(first_step, n_steps, readback=False):
+        # step k of this rank covers sample indices (rank+1) + world*(SPP_PER_STEP*k + j), j < SPP_PER_STEP
+        first = rank + 1 + world * SPP_PER_STEP * first_step
+        vp.render_samples(scene, film, cam, SPP_PER_STEP * n_steps, stride=world, first=first, readback=readback)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        vp.sync()
+        torch.cuda.synchronize()
+
+    # ---- warmup (untimed): also uploads the scene / builds the BVH ----
+    t0 = time.time()
+    run_steps(0, max(args.warmup, 1) if args.warmup > 0 else 0)
+    barrier()
+    setup_s = time.time() - t0
+    accum.zero_()
+    vp.enable_counters(count_nodes=False, time_kernels=True)   # HIP events around every launch, on the launch stream
+    vp.reset_stats()
+    barrier()
+
+    # ---- timed region: EXACTLY K steps + (N>1) the film reduce ----
+    t0 = time.perf_counter()
+    run_steps(0, args.steps)
+    if world > 1:
+        hd.reduce_film(accum, root=0)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    st = vp.stats()
+    rays_local = int(st.rays_closest) + int(st.rays_shadow)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    rays = torch.tensor([float(rays_local)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(rays, op=dist.ReduceOp.SUM)
+    elapsed_max = float(tmax.item())
+    total_rays = float(rays.item())
+
+    result = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel: counts from an instrumented (untimed) replay of the same steps ----
+        timed = dict(trace=st.seconds_trace, shadow=st.seconds_shadow, shade=st.seconds_shade, other=st.seconds_other)
+        launches = dict(trace=int(st.trace_launches), shadow=int(st.shadow_launches), shade=int(st.shade_launches))
+        casts = dict(trace=int(st.rays_closest), shadow=int(st.rays_shadow))
+        vertices = int(st.path_vertices)
+        accum_keep = accum.clone()
+        vp.enable_counters(count_nodes=True, time_kernels=False)
+        vp.reset_stats()
+        run_steps(0, args.steps)
+        vp.sync()
+        sc = vp.stats()
+        accum.copy_(accum_keep)
+        vp.enable_counters(False, False)
+        hits = int(sc.hits_accepted)
+        dom = max(("trace", "shadow", "shade"), key=lambda k: timed[k])
+        if dom == "trace":
+            hit_frac_bytes = B_HIT * min(int(sc.rays_closest), hits)   # shading attributes fetched once per accepted hit
+            alg_bytes = casts["trace"] * (B_RAY_IN + B_HIT_OUT) + S_NODE * int(sc.trace_nodes) + B_TRI * int(sc.trace_tris) + hit_frac_bytes
+        elif dom == "shadow":
+            alg_bytes = casts["shadow"] * (B_RAY_IN + B_HIT_OUT) + S_NODE * int(sc.shadow_nodes) + B_TRI * int(sc.shadow_tris)
+        else:
+            alg_bytes = vertices * (2 * S_STATE + 64 + 96) + 60 * int(sc.light_bvh_nodes)
+        n_launch = max(launches[dom], 1)
+        avg_s = timed[dom] / n_launch
+        achieved = alg_bytes / n_launch / avg_s / 1e9 if avg_s > 0 else 0.0
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.isfile(pmc_path):
+            try:
+                traffic = json.load(open(pmc_path)).get({"trace": "k_trace", "shadow": "k_shadow", "shade": "k_shade"}[dom], {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": {"trace": "k_trace", "shadow": "k_shadow", "shade": "k_shade"}[dom], "achieved": round(achieved, 2),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "algorithmic_bytes_per_launch": int(alg_bytes / n_launch), "avg_launch_ms": round(avg_s * 1e3, 4), "launches": n_launch,
+                    "nodes_per_cast": round(int(sc.trace_nodes) / max(int(sc.rays_closest), 1), 2),
+                    "tris_per_cast": round(int(sc.trace_tris) / max(int(sc.rays_closest), 1), 2),
+                    "kernel_seconds": {k: round(v, 4) for k, v in timed.items()}}
+
+        # ---- CPU baseline: the oracle (a port, NOT Julia / KernelAbstractions.CPU()) on a bounded sample ----
+        cpu = None
+        if not args.no_cpu_baseline:
+            import oracle
+            oracle.build()
+            osc = oracle.OracleScene(scene)
+            p = hk.integrator_params(max_depth=DEPTH, samples=FULL_SPP)
+            c0 = time.perf_counter()
+            _, ost = osc.render(p, cam, W, H, args.cpu_spp)
+            cdt = time.perf_counter() - c0
+            crays = int(ost.rays_closest) + int(ost.rays_shadow)
+            cpu = {"value": round(crays / cdt / 1e6, 4), "unit": "Mrays/s", "cores": os.cpu_count(), "kind": "port",
+                   "sample": "%d spp of the same %dx%d depth-%d Cornell frame (%.1f s); CPU restatement of Hikari VolPath, not Julia" % (args.cpu_spp, W, H, DEPTH, cdt),
+                   "seconds_to_256spp_extrapolated": round(cdt * FULL_SPP / args.cpu_spp, 1)}
+            osc.close()
+
+        value = total_rays / elapsed_max / 1e6
+        spp_done = SPP_PER_STEP * args.steps * world
+        result = {
+            "metric": "Mrays/s", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed_max / max(args.steps, 1) * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "Cornell box (diffuse + area light), 800x800, VolPath depth 8, %d spp per step" % SPP_PER_STEP,
+                       "resolution": [W, H], "max_depth": DEPTH, "spp_per_step": SPP_PER_STEP, "spp_rendered": spp_done,
+                       "triangles": int(scene.desc.n_triangles), "lights": int(scene.desc.n_lights), "parallelism": "sample-index sharding x%d + film reduce" % world},
+            "seconds_timed": round(elapsed_max, 4),
+            "seconds_to_256spp": round(elapsed_max * FULL_SPP / spp_done * world, 4) if world == 1 else round(elapsed_max * (FULL_SPP / spp_done), 4),
+            "rays": {"closest": int(st.rays_closest), "shadow": int(st.rays_shadow), "total_all_ranks": int(total_rays)},
+            "setup_seconds": round(setup_s, 3),
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    vp.close()
+    return result
+
+
+if __name__ == "__main__":
+    main()

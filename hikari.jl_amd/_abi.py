@@ -108,7 +108,10 @@ class hk_stats(C.Structure):
     _fields_ = [("rays_closest", C.c_uint64), ("rays_shadow", C.c_uint64), ("bvh_nodes_visited", C.c_uint64),
                 ("tris_tested", C.c_uint64), ("hits_accepted", C.c_uint64), ("path_vertices", C.c_uint64),
                 ("medium_collisions", C.c_uint64), ("light_bvh_nodes", C.c_uint64), ("seconds_trace", C.c_double),
-                ("seconds_total", C.c_double), ("trace_launches", C.c_uint64)]
+                ("seconds_total", C.c_double), ("trace_launches", C.c_uint64), ("trace_nodes", C.c_uint64),
+                ("trace_tris", C.c_uint64), ("shadow_nodes", C.c_uint64), ("shadow_tris", C.c_uint64),
+                ("shadow_launches", C.c_uint64), ("shade_launches", C.c_uint64), ("seconds_shadow", C.c_double),
+                ("seconds_shade", C.c_double), ("seconds_other", C.c_double)]
 
 
 # every symbol include/hikari_mi355x.h declares (tests check the built library exports all of them)

@@ -79,7 +79,9 @@ struct hk_ctx {
     hk::RGB2Spec r2s_host;
     int count_nodes = 0, time_kernels = 0;
     // timing
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_events;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_events;   // class 0
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> class_events[4];  // 1 shadow, 2 shade, 3 other
+    uint64_t shadow_launches = 0, shade_launches = 0;
     std::vector<hipEvent_t> event_pool;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool have_span = false;
@@ -788,26 +790,36 @@ extern "C" int32_t hk_render(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_film*
         fr.samples_in_pass = k;
         fr.first_sample = first_sample_idx + done * sample_stride;
         HIP_TRY(hipMemsetAsync(I->st.counters, 0, counter_bytes, s));
-        hk::launch_camera(s, I->st, fr, c->tables, I->filter, dc, sob, -1);
-        for (int depth = 0; depth < I->p.max_depth; ++depth) {
+        auto timed = [&](int cls, auto&& fn) -> int {
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (c->time_kernels) {
                 e0 = get_event(c);
                 e1 = get_event(c);
-                HIP_TRY(hipEventRecord(e0, s));
+                if (hipEventRecord(e0, s) != hipSuccess) return HK_ERR_DEVICE;
             }
-            hk::launch_trace(s, trace_blocks, I->st, sc->d, c->tables, fr, depth, dstats);
+            fn();
             if (c->time_kernels) {
-                HIP_TRY(hipEventRecord(e1, s));
-                c->trace_events.emplace_back(e0, e1);
+                if (hipEventRecord(e1, s) != hipSuccess) return HK_ERR_DEVICE;
+                (cls == 0 ? c->trace_events : c->class_events[cls]).emplace_back(e0, e1);
             }
+            return HK_OK;
+        };
+        if (timed(3, [&] { hk::launch_camera(s, I->st, fr, c->tables, I->filter, dc, sob, -1); }) != HK_OK) return fail(HK_ERR_DEVICE, "event record failed");
+        for (int depth = 0; depth < I->p.max_depth; ++depth) {
+            timed(0, [&] { hk::launch_trace(s, trace_blocks, I->st, sc->d, c->tables, fr, depth, dstats); });
             c->trace_launches++;
-            if (sc->d.has_escape_lights) hk::launch_escaped(s, light_blocks, I->st, sc->d, c->tables, depth);
+            if (sc->d.has_escape_lights) timed(3, [&] { hk::launch_escaped(s, light_blocks, I->st, sc->d, c->tables, depth); });
             for (int kind = 0; kind < HK_MAX_KINDS; ++kind)
-                if (sc->kinds_mask & (1u << kind)) hk::launch_shade(s, shade_blocks, kind, I->st, sc->d, c->tables, fr, sob, depth, dstats);
-            if (sc->d.n_lights > 0) hk::launch_shadow(s, trace_blocks, I->st, sc->d, c->tables, fr, depth, dstats);
+                if (sc->kinds_mask & (1u << kind)) {
+                    timed(2, [&] { hk::launch_shade(s, shade_blocks, kind, I->st, sc->d, c->tables, fr, sob, depth, dstats); });
+                    c->shade_launches++;
+                }
+            if (sc->d.n_lights > 0) {
+                timed(1, [&] { hk::launch_shadow(s, trace_blocks, I->st, sc->d, c->tables, fr, depth, dstats); });
+                c->shadow_launches++;
+            }
         }
-        hk::launch_film(s, I->st, fr, c->tables, film->accum, film->f64);
+        timed(3, [&] { hk::launch_film(s, I->st, fr, c->tables, film->accum, film->f64); });
         done += k;
     }
     HIP_TRY(hipGetLastError());
@@ -837,8 +849,15 @@ extern "C" int32_t hk_stats_reset(hk_ctx* c) {
         c->event_pool.push_back(e.second);
     }
     c->trace_events.clear();
+    for (auto& v : c->class_events) {
+        for (auto& e : v) {
+            c->event_pool.push_back(e.first);
+            c->event_pool.push_back(e.second);
+        }
+        v.clear();
+    }
     c->seconds_trace = c->seconds_total = 0.0;
-    c->trace_launches = 0;
+    c->trace_launches = c->shadow_launches = c->shade_launches = 0;
     c->have_span = false;
     return HK_OK;
 }
@@ -870,6 +889,23 @@ extern "C" int32_t hk_stats_get(hk_ctx* c, hk_stats* out) {
     out->seconds_trace = tr;
     out->seconds_total = total;
     out->trace_launches = c->trace_launches;
+    out->trace_nodes = h.nodes;
+    out->trace_tris = h.tris;
+    out->shadow_nodes = h.sh_nodes;
+    out->shadow_tris = h.sh_tris;
+    out->bvh_nodes_visited = h.nodes + h.sh_nodes;
+    out->tris_tested = h.tris + h.sh_tris;
+    out->shadow_launches = c->shadow_launches;
+    out->shade_launches = c->shade_launches;
+    double cls[4] = {0, 0, 0, 0};
+    for (int k = 1; k < 4; ++k)
+        for (auto& e : c->class_events[k]) {
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) cls[k] += ms * 1e-3;
+        }
+    out->seconds_shadow = cls[1];
+    out->seconds_shade = cls[2];
+    out->seconds_other = cls[3];
     return HK_OK;
 }
 

@@ -437,8 +437,8 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_shadow(DPathState st, DScene
     wave_add(&stats->rays_shadow, n_casts);
     wave_add(&stats->hits, n_hits);
     if (COUNT) {
-        wave_add(&stats->nodes, n_nodes);
-        wave_add(&stats->tris, n_tris);
+        wave_add(&stats->sh_nodes, n_nodes);
+        wave_add(&stats->sh_tris, n_tris);
     }
 }
 

@@ -176,7 +176,7 @@ struct DPathState {
 };
 
 struct DStats {
-    unsigned long long rays_closest, rays_shadow, nodes, tris, hits, vertices, collisions, light_nodes;
+    unsigned long long rays_closest, rays_shadow, nodes, tris, hits, vertices, collisions, light_nodes, sh_nodes, sh_tris;
 };
 
 struct DFrame {            // per-pass constants

@@ -76,8 +76,7 @@ enum {
                                     rgb[3]=albedo, f[0]=iface u_rough, f[1]=iface v_rough, f[2]=iface eta,
                                     f[3]=cond u_rough, f[4]=cond v_rough, f[5]=thickness, f[6]=g,
                                     i[0]=max_depth, i[1]=n_samples, flags&USE_ETA_K */
-    HK_MAT_MIX = 9,              /* f[0]=amount, i[0]=material1, i[1]=material2 (indices into materials),
-                                    i[2]/i[3] = SetKey(type_idx, vec_idx) of material1 packed (type<<24|vec)... see below */
+    HK_MAT_MIX = 9,              /* f[0]=amount, i[0]=material1, i[1]=material2 (indices into materials), mix_key */
     HK_MAT_FALLBACK = 10         /* any other Material (e.g. a bare Emissive): gray 0.5 Lambertian, Q24 */
 };
 #define HK_MATF_REMAP_ROUGHNESS 1
@@ -284,9 +283,14 @@ typedef struct hk_stats {
     uint64_t path_vertices;    /* surface shading events */
     uint64_t medium_collisions;
     uint64_t light_bvh_nodes;
-    double seconds_trace;      /* HIP-event time spent in the traversal kernel */
-    double seconds_total;      /* HIP-event time of all kernels of the last hk_render */
+    double seconds_trace;      /* HIP-event time spent in the closest-hit traversal kernel (k_trace) */
+    double seconds_total;      /* HIP-event span from the first hk_render after hk_stats_reset to the last */
     uint64_t trace_launches;
+    /* per-kernel-class breakdown (filled when hk_stats_enable_counters flags are set) */
+    uint64_t trace_nodes, trace_tris;    /* k_trace only (needs flag bit 0) */
+    uint64_t shadow_nodes, shadow_tris;  /* k_shadow only */
+    uint64_t shadow_launches, shade_launches;
+    double seconds_shadow, seconds_shade, seconds_other; /* HIP-event sums (flag bit 1) */
 } hk_stats;
 
 typedef struct hk_ctx hk_ctx;
@@ -331,8 +335,9 @@ void* hk_film_accum_device_ptr(hk_film* film);
 int32_t hk_sync(hk_ctx* ctx);
 int32_t hk_stats_get(hk_ctx* ctx, hk_stats* out);
 int32_t hk_stats_reset(hk_ctx* ctx);
-/* count BVH nodes/triangles per cast during the next renders (adds two counters per lane; off for timing). */
-int32_t hk_stats_enable_counters(hk_ctx* ctx, int32_t enable);
+/* flags bit 0: count BVH nodes/triangles per cast during the next renders (adds two counters per lane; keep
+ * off while timing); bit 1: bracket every kernel launch with HIP events on ctx's stream. */
+int32_t hk_stats_enable_counters(hk_ctx* ctx, int32_t flags);
 
 /* ---- sub-kernel entry points (parity tests drive these through the same ABI) ---- */
 /* closest-hit of n rays (host arrays): t (inf = miss), prim (index into scene triangles, -1 = miss), bary u,v */

@@ -20,7 +20,7 @@ void launch_camera(hipStream_t, const DPathState&, const DFrame&, const DTables&
 void launch_trace(hipStream_t, int, const DPathState&, const DScene&, const DTables&, const DFrame&, int, DStats*);
 void launch_shadow(hipStream_t, int, const DPathState&, const DScene&, const DTables&, const DFrame&, int, DStats*);
 void launch_escaped(hipStream_t, int, const DPathState&, const DScene&, const DTables&, int);
-void launch_shade(hipStream_t, int, int, const DPathState&, const DScene&, const DTables&, const DFrame&, const DSobol&, int, DStats*);
+void launch_shade(hipStream_t, int, int, const DPathState&, const DScene&, const DTables&, const DFrame&, const DSobol&, int, int, DStats*);
 void launch_film(hipStream_t, const DPathState&, const DFrame&, const DTables&, void*, bool);
 void launch_finalize(hipStream_t, const void*, bool, float*, int, int);
 void launch_test_trace(hipStream_t, const DScene&, int, const float*, const float*, const float*, float*, int*, float*);
@@ -72,6 +72,7 @@ struct hk_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     int n_cu = 256;
+    int n_waves = 4096;
     DevBuf sobol, cie, r2s_scale, r2s_coeffs, stats;
     DTables tables{};
     bool have_tables = false;
@@ -143,8 +144,12 @@ extern "C" int32_t hk_ctx_create(int32_t device_id, void* stream, hk_ctx** out) 
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device_id));
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    DStats zero{};
-    HIP_TRY(c->stats.upload(&zero, sizeof zero));
+    c->n_waves = c->n_cu * 16;  // 4 blocks of 256 threads per CU: every wave-mapped kernel uses this geometry
+    {
+        std::vector<DStats> zero((size_t)c->n_waves);
+        std::memset(zero.data(), 0, zero.size() * sizeof(DStats));
+        HIP_TRY(c->stats.upload(zero.data(), zero.size() * sizeof(DStats)));
+    }
     HIP_TRY(hipEventCreate(&c->ev_begin));
     HIP_TRY(hipEventCreate(&c->ev_end));
     *out = c;
@@ -676,7 +681,12 @@ int ensure_state(hk_integrator* I, int capacity) {
     I->bufs.clear();
     DPathState& s = I->st;
     size_t P = (size_t)capacity;
+    const int W = I->ctx->n_waves;
+    const int chunks = (capacity + 63) / 64;
     s.capacity = capacity;
+    s.n_waves = W;
+    s.wave_cap = ((chunks + W - 1) / W) * 64;
+    const size_t Q = (size_t)W * s.wave_cap;
     HIP_TRY(alloc_arr(I, s.ray_o, P));
     HIP_TRY(alloc_arr(I, s.ray_d, P));
     HIP_TRY(alloc_arr(I, s.hit, P));
@@ -694,16 +704,14 @@ int ensure_state(hk_integrator* I, int capacity) {
     HIP_TRY(alloc_arr(I, s.sh_Ld, P));
     HIP_TRY(alloc_arr(I, s.sh_ru, P));
     HIP_TRY(alloc_arr(I, s.sh_rl, P));
-    HIP_TRY(alloc_arr(I, s.ray_q[0], P));
-    HIP_TRY(alloc_arr(I, s.ray_q[1], P));
-    HIP_TRY(alloc_arr(I, s.shadow_q, P));
-    HIP_TRY(alloc_arr(I, s.escaped_q, P));
-    HIP_TRY(alloc_arr(I, s.mat_q, P * HK_MAX_KINDS));
-    size_t nc = (size_t)(I->p.max_depth + 2) * Q_COUNT;
-    int* both = nullptr;
-    HIP_TRY(alloc_arr(I, both, 2 * nc));
-    s.counters = both;
-    s.cursors = both + nc;
+    HIP_TRY(alloc_arr(I, s.ray_q[0], Q));
+    HIP_TRY(alloc_arr(I, s.ray_q[1], Q));
+    HIP_TRY(alloc_arr(I, s.shadow_q, Q));
+    HIP_TRY(alloc_arr(I, s.escaped_q, Q));
+    HIP_TRY(alloc_arr(I, s.mat_q, Q * HK_MAX_KINDS));
+    size_t nc = (size_t)(I->p.max_depth + 2) * Q_COUNT * W;
+    HIP_TRY(alloc_arr(I, s.counters, nc));
+    HIP_TRY(hipMemset(s.counters, 0, nc * sizeof(int)));
     I->st_capacity = capacity;
     I->st_depth = I->p.max_depth;
     return HK_OK;
@@ -777,8 +785,7 @@ extern "C" int32_t hk_render(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_film*
     DSobol sob = make_sobol(I->p, W, H);
     DCamera dc = make_camera(*cam);
     DStats* dstats = c->stats.as<DStats>();
-    const int trace_blocks = c->n_cu * 4, shade_blocks = c->n_cu * 4, light_blocks = c->n_cu * 4;
-    const size_t counter_bytes = (size_t)2 * (I->p.max_depth + 2) * Q_COUNT * sizeof(int);
+    const int trace_blocks = c->n_waves / 4, shade_blocks = c->n_waves / 4, light_blocks = c->n_waves / 4;
     hipStream_t s = c->stream;
     if (!c->have_span) {
         HIP_TRY(hipEventRecord(c->ev_begin, s));
@@ -789,7 +796,6 @@ extern "C" int32_t hk_render(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_film*
         int k = n_samples - done < S ? n_samples - done : S;
         fr.samples_in_pass = k;
         fr.first_sample = first_sample_idx + done * sample_stride;
-        HIP_TRY(hipMemsetAsync(I->st.counters, 0, counter_bytes, s));
         auto timed = [&](int cls, auto&& fn) -> int {
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (c->time_kernels) {
@@ -809,9 +815,11 @@ extern "C" int32_t hk_render(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_film*
             timed(0, [&] { hk::launch_trace(s, trace_blocks, I->st, sc->d, c->tables, fr, depth, dstats); });
             c->trace_launches++;
             if (sc->d.has_escape_lights) timed(3, [&] { hk::launch_escaped(s, light_blocks, I->st, sc->d, c->tables, depth); });
+            int first_kind = 1;
             for (int kind = 0; kind < HK_MAX_KINDS; ++kind)
                 if (sc->kinds_mask & (1u << kind)) {
-                    timed(2, [&] { hk::launch_shade(s, shade_blocks, kind, I->st, sc->d, c->tables, fr, sob, depth, dstats); });
+                    timed(2, [&] { hk::launch_shade(s, shade_blocks, kind, I->st, sc->d, c->tables, fr, sob, depth, first_kind, dstats); });
+                    first_kind = 0;
                     c->shade_launches++;
                 }
             if (sc->d.n_lights > 0) {
@@ -843,7 +851,7 @@ extern "C" int32_t hk_stats_reset(hk_ctx* c) {
     if (!c) return fail(HK_ERR_INVALID, "null ctx");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemset(c->stats.p, 0, sizeof(DStats)));
+    HIP_TRY(hipMemset(c->stats.p, 0, (size_t)c->n_waves * sizeof(DStats)));
     for (auto& e : c->trace_events) {
         c->event_pool.push_back(e.first);
         c->event_pool.push_back(e.second);
@@ -865,8 +873,23 @@ extern "C" int32_t hk_stats_get(hk_ctx* c, hk_stats* out) {
     if (!c || !out) return fail(HK_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    DStats h;
-    HIP_TRY(hipMemcpy(&h, c->stats.p, sizeof h, hipMemcpyDeviceToHost));
+    DStats h{};
+    {
+        std::vector<DStats> rows((size_t)c->n_waves);
+        HIP_TRY(hipMemcpy(rows.data(), c->stats.p, rows.size() * sizeof(DStats), hipMemcpyDeviceToHost));
+        for (const DStats& r : rows) {
+            h.rays_closest += r.rays_closest;
+            h.rays_shadow += r.rays_shadow;
+            h.nodes += r.nodes;
+            h.tris += r.tris;
+            h.hits += r.hits;
+            h.vertices += r.vertices;
+            h.collisions += r.collisions;
+            h.light_nodes += r.light_nodes;
+            h.sh_nodes += r.sh_nodes;
+            h.sh_tris += r.sh_tris;
+        }
+    }
     double tr = 0.0;
     for (auto& e : c->trace_events) {
         float ms = 0.0f;

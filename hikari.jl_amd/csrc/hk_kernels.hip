@@ -22,30 +22,31 @@ namespace {
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
-// wave-aggregated queue push: one atomic per wave per queue
-__device__ __forceinline__ void queue_push(uint32_t* __restrict__ q, int* __restrict__ counter, uint32_t value, bool active) {
+// Wave-private segmented queues: wave w owns entries [w*wave_cap, (w+1)*wave_cap) of every queue and the
+// count word counts[..][w].  A path never leaves the wave that generated its camera ray, so compaction is pure
+// ballot/popcount arithmetic: no atomics, no cursors, deterministic order.  (A single global queue counter
+// serialises at ~88 atomics/us on this chip: 40 k wave-pushes per launch cost ~0.45 ms per kernel.)
+struct WaveQ {
+    uint32_t* base;
+    int count;  // wave-uniform
+};
+__device__ __forceinline__ int global_wave() { return (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)); }
+__device__ __forceinline__ WaveQ wq_open(uint32_t* q, const DPathState& st, int gw) { return WaveQ{q + (size_t)gw * st.wave_cap, 0}; }
+__device__ __forceinline__ void wq_push(WaveQ& q, uint32_t value, bool active) {
     unsigned long long mask = __ballot(active);
-    if (mask == 0ull) return;
-    int lane = lane_id();
-    int leader = __ffsll((long long)mask) - 1;
-    int base = 0;
-    if (lane == leader) base = atomicAdd(counter, __popcll(mask));
-    base = __shfl(base, leader);
-    if (active) q[base + __popcll(mask & ((1ull << lane) - 1ull))] = value;
+    if (active) q.base[q.count + __popcll(mask & ((1ull << lane_id()) - 1ull))] = value;
+    q.count += __popcll(mask);
+}
+__device__ __forceinline__ int* count_ptr(const DPathState& st, int depth, int q, int gw) { return st.counters + ((size_t)(depth * Q_COUNT + q) * st.n_waves + gw); }
+__device__ __forceinline__ void wq_close(const WaveQ& q, int* cnt) {
+    if (lane_id() == 0) *cnt = q.count;
 }
 
-// persistent work distribution: a wave claims 64 consecutive queue entries at a time
-__device__ __forceinline__ int claim_chunk(int* __restrict__ cursor) {
-    int base = 0;
-    if (lane_id() == 0) base = atomicAdd(cursor, 64);
-    return __shfl(base, 0);
-}
-
+// per-wave statistics rows (summed on the host): plain read-modify-write, the row belongs to this wave
 __device__ __forceinline__ void wave_add(unsigned long long* dst, unsigned v) {
-    // wave reduction then one atomic
     unsigned s = v;
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
-    if (lane_id() == 0 && s) atomicAdd(dst, (unsigned long long)s);
+    if (lane_id() == 0 && s) *dst += (unsigned long long)s;
 }
 
 __device__ __forceinline__ void slot_to_pixel(const DFrame& fr, int slot_in_sample, int& px, int& py, bool& inside) {
@@ -62,17 +63,17 @@ __device__ __forceinline__ void slot_to_pixel(const DFrame& fr, int slot_in_samp
 // K1: camera rays (volpath.jl:125-205).  One thread per path slot of the pass.
 // ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_camera(DPathState st, DFrame fr, DTables T, DFilter flt, DCamera cam, DSobol sob, int initial_medium) {
-    int total = fr.n_pixels_padded * fr.samples_in_pass;
-    for (int slot = blockIdx.x * blockDim.x + threadIdx.x; slot < ((total + 63) & ~63); slot += gridDim.x * blockDim.x) {
-        bool active = slot < total;
-        int px = 0, py = 0;
-        bool inside = false;
-        int k = 0;
-        if (active) {
-            k = slot / fr.n_pixels_padded;
-            slot_to_pixel(fr, slot - k * fr.n_pixels_padded, px, py, inside);
-        }
-        active = active && inside;
+    const int total = fr.n_pixels_padded * fr.samples_in_pass;
+    const int n_chunks = total >> 6;
+    const int gw = global_wave();
+    WaveQ out = wq_open(st.ray_q[0], st, gw);
+    // wave w generates chunks w, w+W, w+2W, ... (8x8 pixel tiles interleaved across waves for load balance)
+    for (int chunk = gw; chunk < n_chunks; chunk += st.n_waves) {
+        int slot = chunk * 64 + lane_id();
+        int k = slot / fr.n_pixels_padded;
+        int px, py;
+        bool active;
+        slot_to_pixel(fr, slot - k * fr.n_pixels_padded, px, py, active);
         if (active) {
             int sample_idx = fr.first_sample + k * fr.sample_stride;
             int x = px + 1, y = py + 1;  // 1-based pixel coordinates (Q1)
@@ -100,8 +101,9 @@ __global__ void __launch_bounds__(256) k_camera(DPathState st, DFrame fr, DTable
             st.filter_w[slot] = fw;
             st.flags[slot] = (uint32_t)(initial_medium + 1) << 16;
         }
-        queue_push(st.ray_q[0], &st.counters[0 * Q_COUNT + Q_RAY], (uint32_t)slot, active);
+        wq_push(out, (uint32_t)slot, active);
     }
+    wq_close(out, count_ptr(st, 0, Q_RAY, gw));
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -112,12 +114,15 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace(DPathState st, DScene 
     __shared__ int lds_stack[(HK_TRACE_BLOCK / 64) * HK_LDS_STACK * 64];
     int* stack = lds_stack + (threadIdx.x >> 6) * (HK_LDS_STACK * 64);
     const int lane = lane_id();
-    const uint32_t* __restrict__ queue = st.ray_q[depth & 1];
-    const int n = st.counters[depth * Q_COUNT + Q_RAY];
-    int* cursor = &st.cursors[depth * Q_COUNT + Q_RAY];
-    int* counters = st.counters + depth * Q_COUNT;
+    const int gw = global_wave();
+    const uint32_t* __restrict__ queue = st.ray_q[depth & 1] + (size_t)gw * st.wave_cap;
+    const int n = *count_ptr(st, depth, Q_RAY, gw);
+    WaveQ q_escaped = wq_open(st.escaped_q, st, gw);
+    int kind_count[HK_MAX_KINDS];
+#pragma unroll
+    for (int k = 0; k < HK_MAX_KINDS; ++k) kind_count[k] = 0;
     unsigned n_nodes = 0, n_tris = 0, n_casts = 0, n_hits = 0;
-    for (int base = claim_chunk(cursor); base < n; base = claim_chunk(cursor)) {
+    for (int base = 0; base < n; base += 64) {
         int i = base + lane;
         bool active = i < n;
         uint32_t slot = active ? queue[i] : 0u;
@@ -167,17 +172,30 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace(DPathState st, DScene 
                 break;
             }
         }
-        // ballot-compact into per-kind queues
-        queue_push(st.escaped_q, &counters[Q_ESCAPED], slot, kind == -2);
+        // ballot-compact into this wave's per-kind queue segments
+        wq_push(q_escaped, slot, kind == -2);
         unsigned long long pending = __ballot(kind >= 0);
         while (pending) {
             int src = __ffsll((long long)pending) - 1;
             int k = __shfl(kind, src);
             bool mine = kind == k;
-            queue_push(st.mat_q + (size_t)k * st.capacity, &counters[Q_MAT0 + k], slot, mine);
-            pending &= ~__ballot(mine);
+            unsigned long long m = __ballot(mine);
+            int cnt = 0;
+#pragma unroll
+            for (int kk = 0; kk < HK_MAX_KINDS; ++kk) cnt = (kk == k) ? kind_count[kk] : cnt;
+            if (mine) st.mat_q[((size_t)k * st.n_waves + gw) * st.wave_cap + cnt + __popcll(m & ((1ull << lane) - 1ull))] = slot;
+            int add = __popcll(m);
+#pragma unroll
+            for (int kk = 0; kk < HK_MAX_KINDS; ++kk) kind_count[kk] += (kk == k) ? add : 0;
+            pending &= ~m;
         }
     }
+    wq_close(q_escaped, count_ptr(st, depth, Q_ESCAPED, gw));
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < HK_MAX_KINDS; ++k) *count_ptr(st, depth, Q_MAT0 + k, gw) = kind_count[k];
+    }
+    stats += gw;
     wave_add(&stats->rays_closest, n_casts);
     wave_add(&stats->hits, n_hits);
     if (COUNT) {
@@ -190,9 +208,10 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace(DPathState st, DScene 
 // K7: escaped rays (intersection.jl:622-678; lights.jl:408-467).  MIS uses 1/num_lights (Q6).
 // ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_escaped(DPathState st, DScene sc, DTables T, int depth) {
-    const uint32_t* __restrict__ queue = st.escaped_q;
-    const int n = st.counters[depth * Q_COUNT + Q_ESCAPED];
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int gw = global_wave();
+    const uint32_t* __restrict__ queue = st.escaped_q + (size_t)gw * st.wave_cap;
+    const int n = *count_ptr(st, depth, Q_ESCAPED, gw);
+    for (int i = lane_id(); i < n; i += 64) {
         uint32_t slot = queue[i];
         S4 lambda = ld4(&st.lambda[slot]);
         S4 Le = s4(0.0f);
@@ -225,16 +244,20 @@ __global__ void __launch_bounds__(256) k_escaped(DPathState st, DScene sc, DTabl
 // K8 + K9 + K11 fused per material kind (surface-eval.jl:147-220, 250-341, 396-512).
 // ---------------------------------------------------------------------------------------------------
 template <int KIND>
-__global__ void __launch_bounds__(256) k_shade(DPathState st, DScene sc, DTables T, DFrame fr, DSobol sob, int depth, DStats* stats) {
-    const uint32_t* __restrict__ queue = st.mat_q + (size_t)KIND * st.capacity;
-    const int n = st.counters[depth * Q_COUNT + Q_MAT0 + KIND];
-    int* cursor = &st.cursors[depth * Q_COUNT + Q_MAT0 + KIND];
-    int* counters = st.counters + depth * Q_COUNT;
-    int* next_counters = st.counters + (depth + 1) * Q_COUNT;
-    uint32_t* next_q = st.ray_q[(depth + 1) & 1];
+__global__ void __launch_bounds__(256) k_shade(DPathState st, DScene sc, DTables T, DFrame fr, DSobol sob, int depth, int first_kind, DStats* stats) {
+    const int gw = global_wave();
+    const uint32_t* __restrict__ queue = st.mat_q + ((size_t)KIND * st.n_waves + gw) * st.wave_cap;
+    const int n = *count_ptr(st, depth, Q_MAT0 + KIND, gw);
+    // several kinds append to the same shadow / next-ray segments: continue from the counts left by the kinds before
+    WaveQ q_shadow = wq_open(st.shadow_q, st, gw);
+    WaveQ q_next = wq_open(st.ray_q[(depth + 1) & 1], st, gw);
+    if (!first_kind) {
+        q_shadow.count = *count_ptr(st, depth, Q_SHADOW, gw);
+        q_next.count = *count_ptr(st, depth + 1, Q_RAY, gw);
+    }
     const int lane = lane_id();
     unsigned n_vertices = 0, n_lnodes = 0;
-    for (int base = claim_chunk(cursor); base < n; base = claim_chunk(cursor)) {
+    for (int base = 0; base < n; base += 64) {
         int i = base + lane;
         bool active = i < n;
         uint32_t slot = active ? queue[i] : 0u;
@@ -357,9 +380,12 @@ __global__ void __launch_bounds__(256) k_shade(DPathState st, DScene sc, DTables
                 }
             }
         }
-        queue_push(st.shadow_q, &counters[Q_SHADOW], slot, push_shadow);
-        queue_push(next_q, &next_counters[Q_RAY], slot, push_ray);
+        wq_push(q_shadow, slot, push_shadow);
+        wq_push(q_next, slot, push_ray);
     }
+    wq_close(q_shadow, count_ptr(st, depth, Q_SHADOW, gw));
+    wq_close(q_next, count_ptr(st, depth + 1, Q_RAY, gw));
+    stats += gw;
     wave_add(&stats->vertices, n_vertices);
     wave_add(&stats->light_nodes, n_lnodes);
 }
@@ -373,11 +399,11 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_shadow(DPathState st, DScene
     __shared__ int lds_stack[(HK_TRACE_BLOCK / 64) * HK_LDS_STACK * 64];
     int* stack = lds_stack + (threadIdx.x >> 6) * (HK_LDS_STACK * 64);
     const int lane = lane_id();
-    const uint32_t* __restrict__ queue = st.shadow_q;
-    const int n = st.counters[depth * Q_COUNT + Q_SHADOW];
-    int* cursor = &st.cursors[depth * Q_COUNT + Q_SHADOW];
+    const int gw = global_wave();
+    const uint32_t* __restrict__ queue = st.shadow_q + (size_t)gw * st.wave_cap;
+    const int n = *count_ptr(st, depth, Q_SHADOW, gw);
     unsigned n_nodes = 0, n_tris = 0, n_casts = 0, n_hits = 0;
-    for (int base = claim_chunk(cursor); base < n; base = claim_chunk(cursor)) {
+    for (int base = 0; base < n; base += 64) {
         int i = base + lane;
         if (i >= n) continue;
         uint32_t slot = queue[i];
@@ -434,6 +460,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_shadow(DPathState st, DScene
         }
         (void)medium;
     }
+    stats += gw;
     wave_add(&stats->rays_shadow, n_casts);
     wave_add(&stats->hits, n_hits);
     if (COUNT) {
@@ -580,8 +607,7 @@ static inline int grid_for(int n, int block, int cap) {
 }
 
 void launch_camera(hipStream_t s, const DPathState& st, const DFrame& fr, const DTables& T, const DFilter& f, const DCamera& c, const DSobol& sob, int initial_medium) {
-    int total = fr.n_pixels_padded * fr.samples_in_pass;
-    hipLaunchKernelGGL(k_camera, dim3(grid_for(total, 256, 8192)), dim3(256), 0, s, st, fr, T, f, c, sob, initial_medium);
+    hipLaunchKernelGGL(k_camera, dim3(st.n_waves / 4), dim3(256), 0, s, st, fr, T, f, c, sob, initial_medium);
 }
 void launch_trace(hipStream_t s, int blocks, const DPathState& st, const DScene& sc, const DTables& T, const DFrame& fr, int depth, DStats* stats) {
     if (fr.count_nodes)
@@ -598,15 +624,15 @@ void launch_shadow(hipStream_t s, int blocks, const DPathState& st, const DScene
 void launch_escaped(hipStream_t s, int blocks, const DPathState& st, const DScene& sc, const DTables& T, int depth) {
     hipLaunchKernelGGL(k_escaped, dim3(blocks), dim3(256), 0, s, st, sc, T, depth);
 }
-void launch_shade(hipStream_t s, int blocks, int kind, const DPathState& st, const DScene& sc, const DTables& T, const DFrame& fr, const DSobol& sob, int depth, DStats* stats) {
+void launch_shade(hipStream_t s, int blocks, int kind, const DPathState& st, const DScene& sc, const DTables& T, const DFrame& fr, const DSobol& sob, int depth, int first_kind, DStats* stats) {
 #define HK_SHADE_CASE(K) \
-    case K: hipLaunchKernelGGL(k_shade<K>, dim3(blocks), dim3(256), 0, s, st, sc, T, fr, sob, depth, stats); break;
+    case K: hipLaunchKernelGGL(k_shade<K>, dim3(blocks), dim3(256), 0, s, st, sc, T, fr, sob, depth, first_kind, stats); break;
     switch (kind) {
         HK_SHADE_CASE(HK_MAT_MATTE)
         HK_SHADE_CASE(HK_MAT_MIRROR)
         HK_SHADE_CASE(HK_MAT_GLASS)
         HK_SHADE_CASE(HK_MAT_CONDUCTOR)
-        default: hipLaunchKernelGGL(k_shade<HK_MAT_FALLBACK>, dim3(blocks), dim3(256), 0, s, st, sc, T, fr, sob, depth, stats); break;
+        default: hipLaunchKernelGGL(k_shade<HK_MAT_FALLBACK>, dim3(blocks), dim3(256), 0, s, st, sc, T, fr, sob, depth, first_kind, stats); break;
     }
 #undef HK_SHADE_CASE
 }

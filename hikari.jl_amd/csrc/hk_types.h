@@ -150,6 +150,8 @@ enum { Q_RAY = 0, Q_SHADOW = 1, Q_ESCAPED = 2, Q_MAT0 = 3, Q_COUNT = Q_MAT0 + HK
 
 struct DPathState {
     int capacity;          // path slots
+    int n_waves;           // W: every queue is split into W wave-private segments
+    int wave_cap;          // entries per wave segment (multiple of 64); W * wave_cap >= capacity
     float4* ray_o;         // o.xyz, t_max
     float4* ray_d;         // d.xyz, time
     float4* hit;           // t, prim(bits), u, v
@@ -170,9 +172,8 @@ struct DPathState {
     uint32_t* ray_q[2];    // ping-pong ray queues (path slots)
     uint32_t* shadow_q;
     uint32_t* escaped_q;
-    uint32_t* mat_q;       // HK_MAX_KINDS * capacity
-    int* counters;         // (max_depth + 2) * Q_COUNT queue sizes
-    int* cursors;          // work-stealing cursors, same shape
+    uint32_t* mat_q;       // HK_MAX_KINDS * W * wave_cap
+    int* counters;         // [(max_depth + 2) * Q_COUNT][W] per-wave queue sizes
 };
 
 struct DStats {

@@ -187,7 +187,20 @@ extern "C" int32_t hk_ctx_set_tables(hk_ctx* c, const hk_tables* t) {
     c->r2s_host.coeffs = c->h_r2s_coeffs.data();
     HIP_TRY(c->r2s_scale.upload(t->rgb2spec_scale, res * 4));
     HIP_TRY(c->r2s_coeffs.upload(t->rgb2spec_coeffs, nco * 4));
-    c->tables.sobol = c->sobol.as<uint32_t>();
+    // Sobol dims 0/1 have closed forms (hk_device.h sobol_matrix_product); use them only if the caller's table
+    // really is that matrix, otherwise keep the table loop.
+    bool closed = true;
+    {
+        uint32_t col = 0x80000000u;
+        for (int b = 0; b < 52; ++b) {
+            uint32_t d0 = b < 32 ? (0x80000000u >> b) : 0u;
+            if (t->sobol_matrices[b] != d0) closed = false;
+            if (b % 32 == 0) col = 0x80000000u;
+            if (t->sobol_matrices[52 + b] != col) closed = false;
+            col ^= col >> 1;
+        }
+    }
+    c->tables.sobol = closed ? nullptr : c->sobol.as<uint32_t>();
     c->tables.cie = c->cie.as<float>();
     c->tables.rgb2spec_scale = c->r2s_scale.as<float>();
     c->tables.rgb2spec_coeffs = c->r2s_coeffs.as<float>();

@@ -163,17 +163,36 @@ HKD uint32_t fast_owen_scramble(uint32_t v, uint32_t seed) {
     v ^= v * 0x53a22864u;
     return __brev(v);
 }
-HKD float sobol_sample(uint64_t a, int dimension, uint32_t scramble, const uint32_t* __restrict__ mats) {
+// Generator-matrix product for Sobol dimensions 0 and 1 in closed form (hk_ctx_set_tables verifies that the
+// caller's SobolMatrices32 really has this structure, otherwise the table loop below is used):
+//   dim 0: column b = 0x80000000 >> b (b < 32), 0 beyond          =>  v = bitreverse(low 32 bits of a)
+//   dim 1: column b = (1+x)^b over GF(2), period 32 in b          =>  v = bitreverse(zeta(lo)) ^ bitreverse(zeta(hi))
+//          where zeta is the superset-sum transform (Lucas: C(b,j) odd iff j is a sub-mask of b).
+HKD uint32_t sobol_pascal32(uint32_t a) {
+    a ^= (a >> 1) & 0x55555555u;
+    a ^= (a >> 2) & 0x33333333u;
+    a ^= (a >> 4) & 0x0f0f0f0fu;
+    a ^= (a >> 8) & 0x00ff00ffu;
+    a ^= (a >> 16) & 0x0000ffffu;
+    return __brev(a);
+}
+HKD uint32_t sobol_matrix_product(uint64_t a, int dimension, const uint32_t* __restrict__ mats) {
+    if (mats == nullptr) {  // closed forms (wave-uniform branch)
+        uint32_t lo = (uint32_t)a, hi = (uint32_t)(a >> 32);
+        if (dimension == 0) return __brev(lo);
+        return sobol_pascal32(lo) ^ sobol_pascal32(hi);
+    }
     uint32_t v = 0;
     const uint32_t* m = mats + dimension * 52;
-    // bits above the index width are zero: iterate the 52 matrix columns with a uniform trip count so the
-    // column reads stay scalar loads
 #pragma unroll 4
     for (int b = 0; b < 52; ++b) {
         uint32_t mask = 0u - (uint32_t)((a >> b) & 1ull);
         v ^= m[b] & mask;
     }
-    v = fast_owen_scramble(v, scramble);
+    return v;
+}
+HKD float sobol_sample(uint64_t a, int dimension, uint32_t scramble, const uint32_t* __restrict__ mats) {
+    uint32_t v = fast_owen_scramble(sobol_matrix_product(a, dimension, mats), scramble);
     float f = (float)v * 2.3283064365386963e-10f;
     const float lim = 1.0f - 1.1920929e-7f;
     return f < lim ? f : lim;
@@ -192,7 +211,9 @@ HKD uint64_t zsobol_sample_index(uint64_t morton, int dimension, int log2_spp, i
         int digit = (int)((morton >> shift) & 3ull);
         uint64_t higher = morton >> (shift + 2);
         uint64_t h = mix_bits(higher ^ dmix);
-        int p = (int)((h >> 24) % 24ull);
+        // (h >> 24) % 24 on a 40-bit value with 32-bit arithmetic: 2^32 mod 24 == 16
+        uint32_t xlo = (uint32_t)(h >> 24), xhi = (uint32_t)(h >> 56);
+        int p = (int)((xhi * 16u + xlo % 24u) % 24u);
         uint64_t pd = (uint64_t)((kPerm4[p] >> (2 * digit)) & 3);
         sample_index |= pd << shift;
     }

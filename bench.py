@@ -150,13 +150,14 @@ def main():
         if not args.no_cpu_baseline:
             import oracle
             oracle.build()
+            oracle.set_threads(os.cpu_count() or 1)
             osc = oracle.OracleScene(scene)
             p = hk.integrator_params(max_depth=DEPTH, samples=FULL_SPP)
             c0 = time.perf_counter()
             _, ost = osc.render(p, cam, W, H, args.cpu_spp)
             cdt = time.perf_counter() - c0
             crays = int(ost.rays_closest) + int(ost.rays_shadow)
-            cpu = {"value": round(crays / cdt / 1e6, 4), "unit": "Mrays/s", "cores": os.cpu_count(), "kind": "port",
+            cpu = {"value": round(crays / cdt / 1e6, 4), "unit": "Mrays/s", "cores": oracle.max_threads(), "kind": "port",
                    "sample": "%d spp of the same %dx%d depth-%d Cornell frame (%.1f s); CPU restatement of Hikari VolPath, not Julia" % (args.cpu_spp, W, H, DEPTH, cdt),
                    "seconds_to_256spp_extrapolated": round(cdt * FULL_SPP / args.cpu_spp, 1)}
             osc.close()

@@ -1022,6 +1022,22 @@ int32_t hko_light_bvh_copy(hko_scene* s, int32_t* n_nodes, float* nodes_out, uin
     return 0;
 }
 
+// OpenMP team size: tiny test frames run faster on a few threads than on a 256-core host
+void hko_set_threads(int32_t n) {
+#if defined(_OPENMP)
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+int32_t hko_max_threads(void) {
+#if defined(_OPENMP)
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
 // known-answer helpers
 uint64_t hko_murmur64a(const uint8_t* data, int32_t n, uint64_t seed) { return murmur_hash_64a(data, n, seed); }
 uint64_t hko_mix_bits(uint64_t v) { return mix_bits(v); }

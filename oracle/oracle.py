@@ -54,8 +54,22 @@ def lib():
         L.hko_filter_sample.restype = None
         L.hko_wavelengths.argtypes = [i32, PF, PF]
         L.hko_wavelengths.restype = None
+        L.hko_set_threads.argtypes = [i32]
+        L.hko_set_threads.restype = None
+        L.hko_max_threads.restype = i32
         _lib = L
+        set_threads(min(os.cpu_count() or 1, 16))   # tests render tiny frames; bench raises this to all cores
     return _lib
+
+
+def set_threads(n):
+    lib().hko_set_threads(int(n)) if _lib is not None else None
+    if _lib is None:
+        lib().hko_set_threads(int(n))
+
+
+def max_threads():
+    return int(lib().hko_max_threads())
 
 
 def _pf(a):

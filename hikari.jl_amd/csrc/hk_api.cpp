@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -16,7 +17,7 @@
 #include "hk_types.h"
 
 namespace hk {
-void launch_camera(hipStream_t, const DPathState&, const DFrame&, const DTables&, const DFilter&, const DCamera&, const DSobol&, int);
+void launch_camera(hipStream_t, int, const DPathState&, const DFrame&, const DTables&, const DFilter&, const DCamera&, const DSobol&, int);
 void launch_trace(hipStream_t, int, const DPathState&, const DScene&, const DTables&, const DFrame&, int, DStats*);
 void launch_shadow(hipStream_t, int, const DPathState&, const DScene&, const DTables&, const DFrame&, int, DStats*);
 void launch_escaped(hipStream_t, int, const DPathState&, const DScene&, const DTables&, int);
@@ -144,7 +145,12 @@ extern "C" int32_t hk_ctx_create(int32_t device_id, void* stream, hk_ctx** out) 
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device_id));
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    c->n_waves = c->n_cu * 16;  // 4 blocks of 256 threads per CU: every wave-mapped kernel uses this geometry
+    {
+        // W virtual wave segments (queues are split W ways; kernels walk them with however many waves are resident)
+        int per_cu = 16;
+        if (const char* e = std::getenv("HK_WAVES_PER_CU")) per_cu = std::atoi(e) > 0 ? std::atoi(e) : 16;
+        c->n_waves = c->n_cu * per_cu;
+    }
     {
         std::vector<DStats> zero((size_t)c->n_waves);
         std::memset(zero.data(), 0, zero.size() * sizeof(DStats));
@@ -798,7 +804,7 @@ extern "C" int32_t hk_render(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_film*
     DSobol sob = make_sobol(I->p, W, H);
     DCamera dc = make_camera(*cam);
     DStats* dstats = c->stats.as<DStats>();
-    const int trace_blocks = c->n_waves / 4, shade_blocks = c->n_waves / 4, light_blocks = c->n_waves / 4;
+    const int trace_blocks = c->n_cu, shade_blocks = c->n_cu, light_blocks = c->n_cu;  // launchers size the grid from residency
     hipStream_t s = c->stream;
     if (!c->have_span) {
         HIP_TRY(hipEventRecord(c->ev_begin, s));
@@ -823,7 +829,7 @@ extern "C" int32_t hk_render(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_film*
             }
             return HK_OK;
         };
-        if (timed(3, [&] { hk::launch_camera(s, I->st, fr, c->tables, I->filter, dc, sob, -1); }) != HK_OK) return fail(HK_ERR_DEVICE, "event record failed");
+        if (timed(3, [&] { hk::launch_camera(s, c->n_cu, I->st, fr, c->tables, I->filter, dc, sob, -1); }) != HK_OK) return fail(HK_ERR_DEVICE, "event record failed");
         for (int depth = 0; depth < I->p.max_depth; ++depth) {
             timed(0, [&] { hk::launch_trace(s, trace_blocks, I->st, sc->d, c->tables, fr, depth, dstats); });
             c->trace_launches++;

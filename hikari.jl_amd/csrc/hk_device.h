@@ -580,9 +580,13 @@ HKD HitRec traverse(const DScene& sc, v3 o, v3 d, float t_max, int* __restrict__
     const float eps_abs = 2.4e-7f * fmaxf(fmaxf(fabsf(ix) < 1e30f ? fabsf(ox) : 0.0f, fabsf(iy) < 1e30f ? fabsf(oy) : 0.0f), fabsf(iz) < 1e30f ? fabsf(oz) : 0.0f);
     int sp = 0;
     int cur = sc.root_ref;
+    const int DONE = (int)0x80000000;
     const float4* __restrict__ nodes4 = reinterpret_cast<const float4*>(sc.nodes);
-    while (true) {
-        if (cur >= 0) {
+    // "while-while" traversal: every lane first walks inner nodes until it holds a leaf (lanes that already hold
+    // one idle), then the wave tests leaves together.  Mixing both per iteration makes a divergent wave pay the
+    // node code AND the 4-triangle leaf loop on every step.
+    while (cur != DONE) {
+        while (cur >= 0) {
             const float4* np = nodes4 + 4 * (size_t)cur;
             float4 A = np[0], B = np[1], C = np[2], D = np[3];
             if (COUNT) ++n_nodes;
@@ -602,20 +606,18 @@ HKD HitRec traverse(const DScene& sc, v3 o, v3 d, float t_max, int* __restrict__
             int c0 = __float_as_int(D.x), c1 = __float_as_int(D.y);
             if (h0 && h1) {
                 bool first0 = n0 <= n1;
-                int near = first0 ? c0 : c1, far = first0 ? c1 : c0;
-                stack[sp * 64 + lane] = far;
+                stack[sp * 64 + lane] = first0 ? c1 : c0;
                 ++sp;
-                cur = near;
-            } else if (h0) {
-                cur = c0;
-            } else if (h1) {
-                cur = c1;
-            } else {
-                if (sp == 0) break;
+                cur = first0 ? c0 : c1;
+            } else if (h0 || h1) {
+                cur = h0 ? c0 : c1;
+            } else if (sp > 0) {
                 --sp;
                 cur = stack[sp * 64 + lane];
-            }
-        } else {
+            } else
+                cur = DONE;
+        }
+        if (cur != DONE) {
             int ref = ~cur;
             int first = ref >> 3, count = (ref & 7) + 1;
             for (int i = 0; i < count; ++i) {
@@ -641,9 +643,11 @@ HKD HitRec traverse(const DScene& sc, v3 o, v3 d, float t_max, int* __restrict__
                     }
                 }
             }
-            if (sp == 0) break;
-            --sp;
-            cur = stack[sp * 64 + lane];
+            if (sp > 0) {
+                --sp;
+                cur = stack[sp * 64 + lane];
+            } else
+                cur = DONE;
         }
     }
     return best;

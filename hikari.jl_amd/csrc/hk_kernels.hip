@@ -31,6 +31,10 @@ struct WaveQ {
     int count;  // wave-uniform
 };
 __device__ __forceinline__ int global_wave() { return (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)); }
+__device__ __forceinline__ int physical_waves() { return (int)(gridDim.x * (blockDim.x >> 6)); }
+// A kernel is launched with as many physical waves as are resident for ITS register/LDS budget; each physical
+// wave walks the virtual wave segments v = p, p + P, p + 2P, ... so all kernels share the same W segments.
+#define HK_FOR_EACH_WAVE_SEGMENT(gw, st) for (int gw = global_wave(); gw < (st).n_waves; gw += physical_waves())
 __device__ __forceinline__ WaveQ wq_open(uint32_t* q, const DPathState& st, int gw) { return WaveQ{q + (size_t)gw * st.wave_cap, 0}; }
 __device__ __forceinline__ void wq_push(WaveQ& q, uint32_t value, bool active) {
     unsigned long long mask = __ballot(active);
@@ -65,7 +69,7 @@ __device__ __forceinline__ void slot_to_pixel(const DFrame& fr, int slot_in_samp
 __global__ void __launch_bounds__(256) k_camera(DPathState st, DFrame fr, DTables T, DFilter flt, DCamera cam, DSobol sob, int initial_medium) {
     const int total = fr.n_pixels_padded * fr.samples_in_pass;
     const int n_chunks = total >> 6;
-    const int gw = global_wave();
+    HK_FOR_EACH_WAVE_SEGMENT(gw, st) {
     WaveQ out = wq_open(st.ray_q[0], st, gw);
     // wave w generates chunks w, w+W, w+2W, ... (8x8 pixel tiles interleaved across waves for load balance)
     for (int chunk = gw; chunk < n_chunks; chunk += st.n_waves) {
@@ -80,8 +84,15 @@ __global__ void __launch_bounds__(256) k_camera(DPathState st, DFrame fr, DTable
             SobolCtx sc = sobol_ctx(sob, T.sobol, x, y, sample_idx);
             float wavelength_u = sobol_1d(sc, 1);
             v2 jit = sobol_2d(sc, 3);
-            float time_u = sobol_1d(sc, 4);
-            v2 lens = sobol_2d(sc, 6);
+            // dims 4 (time) and 6 (lens) only matter with a finite aperture: ray.time is carried by the reference
+            // but never read on this path (no motion blur in VolPath), and the lens sample is unused when
+            // lens_radius == 0 (perspective.jl:103-112).  Both draws are pure functions, so skipping them is exact.
+            float time_u = 0.0f;
+            v2 lens = mk2(0.0f, 0.0f);
+            if (cam.lens_radius > 0) {
+                time_u = sobol_1d(sc, 4);
+                lens = sobol_2d(sc, 6);
+            }
             float fx, fy, fw;
             filter_sample(flt, jit, fx, fy, fw);
             S4 lambda, pdf;
@@ -91,7 +102,7 @@ __global__ void __launch_bounds__(256) k_camera(DPathState st, DFrame fr, DTable
             float time;
             generate_ray(cam, pfilm, lens, time_u, ro, rd, time);
             st.ray_o[slot] = make_float4(ro.x, ro.y, ro.z, INF_F);
-            st.ray_d[slot] = make_float4(rd.x, rd.y, rd.z, time);
+            st.ray_d[slot] = make_float4(rd.x, rd.y, rd.z, 0.0f);
             st4(&st.lambda[slot], lambda);
             st4(&st.pdf[slot], pdf);
             st4(&st.beta[slot], s4(1.0f));
@@ -104,6 +115,7 @@ __global__ void __launch_bounds__(256) k_camera(DPathState st, DFrame fr, DTable
         wq_push(out, (uint32_t)slot, active);
     }
     wq_close(out, count_ptr(st, 0, Q_RAY, gw));
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -114,14 +126,14 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace(DPathState st, DScene 
     __shared__ int lds_stack[(HK_TRACE_BLOCK / 64) * HK_LDS_STACK * 64];
     int* stack = lds_stack + (threadIdx.x >> 6) * (HK_LDS_STACK * 64);
     const int lane = lane_id();
-    const int gw = global_wave();
+    unsigned n_nodes = 0, n_tris = 0, n_casts = 0, n_hits = 0;
+    HK_FOR_EACH_WAVE_SEGMENT(gw, st) {
     const uint32_t* __restrict__ queue = st.ray_q[depth & 1] + (size_t)gw * st.wave_cap;
     const int n = *count_ptr(st, depth, Q_RAY, gw);
     WaveQ q_escaped = wq_open(st.escaped_q, st, gw);
     int kind_count[HK_MAX_KINDS];
 #pragma unroll
     for (int k = 0; k < HK_MAX_KINDS; ++k) kind_count[k] = 0;
-    unsigned n_nodes = 0, n_tris = 0, n_casts = 0, n_hits = 0;
     for (int base = 0; base < n; base += 64) {
         int i = base + lane;
         bool active = i < n;
@@ -195,7 +207,8 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace(DPathState st, DScene 
 #pragma unroll
         for (int k = 0; k < HK_MAX_KINDS; ++k) *count_ptr(st, depth, Q_MAT0 + k, gw) = kind_count[k];
     }
-    stats += gw;
+    }
+    stats += global_wave();
     wave_add(&stats->rays_closest, n_casts);
     wave_add(&stats->hits, n_hits);
     if (COUNT) {
@@ -208,7 +221,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace(DPathState st, DScene 
 // K7: escaped rays (intersection.jl:622-678; lights.jl:408-467).  MIS uses 1/num_lights (Q6).
 // ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_escaped(DPathState st, DScene sc, DTables T, int depth) {
-    const int gw = global_wave();
+    HK_FOR_EACH_WAVE_SEGMENT(gw, st) {
     const uint32_t* __restrict__ queue = st.escaped_q + (size_t)gw * st.wave_cap;
     const int n = *count_ptr(st, depth, Q_ESCAPED, gw);
     for (int i = lane_id(); i < n; i += 64) {
@@ -238,14 +251,20 @@ __global__ void __launch_bounds__(256) k_escaped(DPathState st, DScene sc, DTabl
         }
         st4(&st.L[slot], ld4(&st.L[slot]) + fin);
     }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
 // K8 + K9 + K11 fused per material kind (surface-eval.jl:147-220, 250-341, 396-512).
 // ---------------------------------------------------------------------------------------------------
+#ifndef HK_SHADE_MIN_WAVES
+#define HK_SHADE_MIN_WAVES 1
+#endif
 template <int KIND>
-__global__ void __launch_bounds__(256) k_shade(DPathState st, DScene sc, DTables T, DFrame fr, DSobol sob, int depth, int first_kind, DStats* stats) {
-    const int gw = global_wave();
+__global__ void __launch_bounds__(256, HK_SHADE_MIN_WAVES) k_shade(DPathState st, DScene sc, DTables T, DFrame fr, DSobol sob, int depth, int first_kind, DStats* stats) {
+    const int lane = lane_id();
+    unsigned n_vertices = 0, n_lnodes = 0;
+    HK_FOR_EACH_WAVE_SEGMENT(gw, st) {
     const uint32_t* __restrict__ queue = st.mat_q + ((size_t)KIND * st.n_waves + gw) * st.wave_cap;
     const int n = *count_ptr(st, depth, Q_MAT0 + KIND, gw);
     // several kinds append to the same shadow / next-ray segments: continue from the counts left by the kinds before
@@ -255,8 +274,6 @@ __global__ void __launch_bounds__(256) k_shade(DPathState st, DScene sc, DTables
         q_shadow.count = *count_ptr(st, depth, Q_SHADOW, gw);
         q_next.count = *count_ptr(st, depth + 1, Q_RAY, gw);
     }
-    const int lane = lane_id();
-    unsigned n_vertices = 0, n_lnodes = 0;
     for (int base = 0; base < n; base += 64) {
         int i = base + lane;
         bool active = i < n;
@@ -311,16 +328,21 @@ __global__ void __launch_bounds__(256) k_shade(DPathState st, DScene sc, DTables
             bool inside;
             slot_to_pixel(fr, (int)slot - k * fr.n_pixels_padded, px, py, inside);
             SobolCtx sctx = sobol_ctx(sob, T.sobol, px + 1, py + 1, fr.first_sample + k * fr.sample_stride);
-            const int base_dim = 6 + 7 * pdepth;
+            // every path in the depth-d queues has work.depth == d, so the dimension (and its scramble hashes) is
+            // wave-uniform: derived from the kernel argument it stays in scalar registers
+            const int base_dim = 6 + 7 * depth;
 
             // ---- K9: next-event estimation through the light BVH ----
             if (sc.n_lights > 0) {
                 float light_select = sobol_1d(sctx, base_dim + 1);
-                v2 u_light = sobol_2d(sctx, base_dim + 3);
                 float light_pmf;
                 int light_idx = bvh_sample_light(sc, sf.pi, sf.ns, light_select, light_pmf, n_lnodes);
                 if (light_idx >= 1 && light_idx <= sc.n_lights && light_pmf > 0.0f) {
-                    LightSample ls = sample_light(sc, T, sc.lights[light_idx - 1], sf.pi, lambda, u_light);
+                    const DLight& sel = sc.lights[light_idx - 1];
+                    // delta lights ignore the 2-D sample (lights.jl:39-131): draw it only for lights that use it
+                    v2 u_light = mk2(0.0f, 0.0f);
+                    if (sel.kind >= HK_LIGHT_AMBIENT) u_light = sobol_2d(sctx, base_dim + 3);
+                    LightSample ls = sample_light(sc, T, sel, sf.pi, lambda, u_light);
                     if (ls.pdf > 0.0f && !is_black(ls.Li)) {
                         float bsdf_pdf;
                         S4 f = eval_bsdf<KIND>(sc, T, mat, wo, ls.wi, sf.ns, sf.uv, lambda, bsdf_pdf);
@@ -348,8 +370,9 @@ __global__ void __launch_bounds__(256) k_shade(DPathState st, DScene sc, DTables
             // ---- K11: BSDF sampling, throughput, Russian roulette, continuation ray ----
             int new_depth = pdepth + 1;
             if (new_depth < fr.max_depth) {
-                float uc = sobol_1d(sctx, base_dim + 4);
-                v2 u = sobol_2d(sctx, base_dim + 6);
+                // the 1-D component sample is read only by BSDFs that choose a lobe (Glass and the layered kinds)
+                float uc = (KIND == HK_MAT_GLASS || KIND > HK_MAT_CONDUCTOR) && KIND != HK_MAT_FALLBACK ? sobol_1d(sctx, base_dim + 4) : 0.0f;
+                v2 u = (KIND == HK_MAT_MIRROR || KIND == HK_MAT_GLASS) ? mk2(0.0f, 0.0f) : sobol_2d(sctx, base_dim + 6);
                 bool regularize = fr.regularize && any_non_specular;
                 BSDFSample s = sample_bsdf<KIND>(sc, T, mat, wo, sf.ns, sf.uv, lambda, u, uc, regularize);
                 if (s.pdf > 0.0f && !is_black(s.f)) {
@@ -385,7 +408,8 @@ __global__ void __launch_bounds__(256) k_shade(DPathState st, DScene sc, DTables
     }
     wq_close(q_shadow, count_ptr(st, depth, Q_SHADOW, gw));
     wq_close(q_next, count_ptr(st, depth + 1, Q_RAY, gw));
-    stats += gw;
+    }
+    stats += global_wave();
     wave_add(&stats->vertices, n_vertices);
     wave_add(&stats->light_nodes, n_lnodes);
 }
@@ -399,10 +423,10 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_shadow(DPathState st, DScene
     __shared__ int lds_stack[(HK_TRACE_BLOCK / 64) * HK_LDS_STACK * 64];
     int* stack = lds_stack + (threadIdx.x >> 6) * (HK_LDS_STACK * 64);
     const int lane = lane_id();
-    const int gw = global_wave();
+    unsigned n_nodes = 0, n_tris = 0, n_casts = 0, n_hits = 0;
+    HK_FOR_EACH_WAVE_SEGMENT(gw, st) {
     const uint32_t* __restrict__ queue = st.shadow_q + (size_t)gw * st.wave_cap;
     const int n = *count_ptr(st, depth, Q_SHADOW, gw);
-    unsigned n_nodes = 0, n_tris = 0, n_casts = 0, n_hits = 0;
     for (int base = 0; base < n; base += 64) {
         int i = base + lane;
         if (i >= n) continue;
@@ -460,7 +484,8 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_shadow(DPathState st, DScene
         }
         (void)medium;
     }
-    stats += gw;
+    }
+    stats += global_wave();
     wave_add(&stats->rays_shadow, n_casts);
     wave_add(&stats->hits, n_hits);
     if (COUNT) {
@@ -606,33 +631,57 @@ static inline int grid_for(int n, int block, int cap) {
     return (int)g;
 }
 
-void launch_camera(hipStream_t s, const DPathState& st, const DFrame& fr, const DTables& T, const DFilter& f, const DCamera& c, const DSobol& sob, int initial_medium) {
-    hipLaunchKernelGGL(k_camera, dim3(st.n_waves / 4), dim3(256), 0, s, st, fr, T, f, c, sob, initial_medium);
+// blocks per CU that are actually resident for a kernel (occupancy API, capped): the wave-segment loop makes any
+// grid size correct, so the grid is sized to residency instead of oversubscribing and paying a tail round.
+template <class K>
+static int resident_blocks(K kernel, int block, int n_cu, int cap_per_cu) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (per_cu > cap_per_cu) per_cu = cap_per_cu;
+    return per_cu * n_cu;
 }
-void launch_trace(hipStream_t s, int blocks, const DPathState& st, const DScene& sc, const DTables& T, const DFrame& fr, int depth, DStats* stats) {
+static int clamp_blocks(int blocks, const DPathState& st) {
+    int maxb = st.n_waves / 4;
+    return blocks > maxb ? maxb : blocks;
+}
+
+void launch_camera(hipStream_t s, int n_cu, const DPathState& st, const DFrame& fr, const DTables& T, const DFilter& f, const DCamera& c, const DSobol& sob, int initial_medium) {
+    static int blocks = resident_blocks(k_camera, 256, n_cu, 8);
+    hipLaunchKernelGGL(k_camera, dim3(clamp_blocks(blocks, st)), dim3(256), 0, s, st, fr, T, f, c, sob, initial_medium);
+}
+void launch_trace(hipStream_t s, int n_cu, const DPathState& st, const DScene& sc, const DTables& T, const DFrame& fr, int depth, DStats* stats) {
+    static int b0 = resident_blocks(k_trace<false>, HK_TRACE_BLOCK, n_cu, 8), b1 = resident_blocks(k_trace<true>, HK_TRACE_BLOCK, n_cu, 8);
     if (fr.count_nodes)
-        hipLaunchKernelGGL(k_trace<true>, dim3(blocks), dim3(HK_TRACE_BLOCK), 0, s, st, sc, T, fr, depth, stats);
+        hipLaunchKernelGGL(k_trace<true>, dim3(clamp_blocks(b1, st)), dim3(HK_TRACE_BLOCK), 0, s, st, sc, T, fr, depth, stats);
     else
-        hipLaunchKernelGGL(k_trace<false>, dim3(blocks), dim3(HK_TRACE_BLOCK), 0, s, st, sc, T, fr, depth, stats);
+        hipLaunchKernelGGL(k_trace<false>, dim3(clamp_blocks(b0, st)), dim3(HK_TRACE_BLOCK), 0, s, st, sc, T, fr, depth, stats);
 }
-void launch_shadow(hipStream_t s, int blocks, const DPathState& st, const DScene& sc, const DTables& T, const DFrame& fr, int depth, DStats* stats) {
+void launch_shadow(hipStream_t s, int n_cu, const DPathState& st, const DScene& sc, const DTables& T, const DFrame& fr, int depth, DStats* stats) {
+    static int b0 = resident_blocks(k_shadow<false>, HK_TRACE_BLOCK, n_cu, 8), b1 = resident_blocks(k_shadow<true>, HK_TRACE_BLOCK, n_cu, 8);
     if (fr.count_nodes)
-        hipLaunchKernelGGL(k_shadow<true>, dim3(blocks), dim3(HK_TRACE_BLOCK), 0, s, st, sc, T, depth, stats);
+        hipLaunchKernelGGL(k_shadow<true>, dim3(clamp_blocks(b1, st)), dim3(HK_TRACE_BLOCK), 0, s, st, sc, T, depth, stats);
     else
-        hipLaunchKernelGGL(k_shadow<false>, dim3(blocks), dim3(HK_TRACE_BLOCK), 0, s, st, sc, T, depth, stats);
+        hipLaunchKernelGGL(k_shadow<false>, dim3(clamp_blocks(b0, st)), dim3(HK_TRACE_BLOCK), 0, s, st, sc, T, depth, stats);
 }
-void launch_escaped(hipStream_t s, int blocks, const DPathState& st, const DScene& sc, const DTables& T, int depth) {
-    hipLaunchKernelGGL(k_escaped, dim3(blocks), dim3(256), 0, s, st, sc, T, depth);
+void launch_escaped(hipStream_t s, int n_cu, const DPathState& st, const DScene& sc, const DTables& T, int depth) {
+    static int blocks = resident_blocks(k_escaped, 256, n_cu, 8);
+    hipLaunchKernelGGL(k_escaped, dim3(clamp_blocks(blocks, st)), dim3(256), 0, s, st, sc, T, depth);
 }
-void launch_shade(hipStream_t s, int blocks, int kind, const DPathState& st, const DScene& sc, const DTables& T, const DFrame& fr, const DSobol& sob, int depth, int first_kind, DStats* stats) {
-#define HK_SHADE_CASE(K) \
-    case K: hipLaunchKernelGGL(k_shade<K>, dim3(blocks), dim3(256), 0, s, st, sc, T, fr, sob, depth, first_kind, stats); break;
+void launch_shade(hipStream_t s, int n_cu, int kind, const DPathState& st, const DScene& sc, const DTables& T, const DFrame& fr, const DSobol& sob, int depth, int first_kind, DStats* stats) {
+#define HK_SHADE_CASE(K)                                                                                                          \
+    case K: {                                                                                                                     \
+        static int blocks = resident_blocks(k_shade<K>, 256, n_cu, 8);                                                            \
+        hipLaunchKernelGGL(k_shade<K>, dim3(clamp_blocks(blocks, st)), dim3(256), 0, s, st, sc, T, fr, sob, depth, first_kind, stats); \
+    } break;
     switch (kind) {
         HK_SHADE_CASE(HK_MAT_MATTE)
         HK_SHADE_CASE(HK_MAT_MIRROR)
         HK_SHADE_CASE(HK_MAT_GLASS)
         HK_SHADE_CASE(HK_MAT_CONDUCTOR)
-        default: hipLaunchKernelGGL(k_shade<HK_MAT_FALLBACK>, dim3(blocks), dim3(256), 0, s, st, sc, T, fr, sob, depth, first_kind, stats); break;
+        default: {
+            static int blocks = resident_blocks(k_shade<HK_MAT_FALLBACK>, 256, n_cu, 8);
+            hipLaunchKernelGGL(k_shade<HK_MAT_FALLBACK>, dim3(clamp_blocks(blocks, st)), dim3(256), 0, s, st, sc, T, fr, sob, depth, first_kind, stats);
+        } break;
     }
 #undef HK_SHADE_CASE
 }

@@ -18,8 +18,8 @@ def main(path):
         print("%-60s %7d %12.1f %11.2f %11.2f %11.2f %6.2f %5d %5d %7d %8d %5d/%-3d" % (name, r[1], r[2] / 1e3, r[3] / 1e3, r[4] / 1e3, r[5] / 1e3,
                                                                                  100.0 * r[2] / total, r[6], r[7], r[8], r[9], r[10], r[11]))
     try:
-        pmc = cur.execute("""select k.name, p.counter_name, count(*), sum(p.value) from pmc_events p join kernels k on k.dispatch_id = p.dispatch_id
-                             group by k.name, p.counter_name order by k.name""").fetchall()
+        pmc = cur.execute("""select name, counter_name, count(*), sum(counter_value) from pmc_events
+                             group by name, counter_name order by name""").fetchall()
     except sqlite3.Error:
         pmc = []
     if pmc:

@@ -1,0 +1,308 @@
+"""Host-side mirror of Hikari's participating media records (src/integrators/volpath/media.jl:762-776, 873-935;
+nanovdb.jl:153-191) and their host-side builders: `build_majorant_grid` (media.jl:1459-1487),
+`build_nanovdb_from_dense` (nanovdb.jl:602-858) and `build_nanovdb_majorant_grid` (nanovdb.jl:1174-1235).
+These run once per scene on the host (the reference builds them on the CPU too); the per-ray work
+(delta tracking, ratio tracking, NanoVDB tree walks) is in the HIP library."""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi as A
+from .materials import RGBSpectrum
+
+f32 = np.float32
+
+
+class Medium:
+    kind = -1
+
+    def fill_record(self, rec, keep):
+        raise NotImplementedError
+
+
+def _identity16():
+    return [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1]
+
+
+def _base_record(rec, kind, sigma_a, sigma_s, Le, g):
+    rec.kind = kind
+    rec.sigma_a[:] = sigma_a.c
+    rec.sigma_s[:] = sigma_s.c
+    rec.Le[:] = Le.c
+    rec.g = float(f32(g))
+    rec.sigma_scale = rec.Le_scale = 1.0
+    rec.render_to_medium[:] = _identity16()
+    rec.medium_to_render[:] = _identity16()
+
+
+class HomogeneousMedium(Medium):
+    """HomogeneousMedium(; σ_a=0.01, σ_s=1, Le=0, g=0)  (media.jl:762-776)"""
+    kind = A.HK_MEDIUM_HOMOGENEOUS
+
+    def __init__(self, sigma_a=RGBSpectrum(0.01), sigma_s=RGBSpectrum(1.0), Le=RGBSpectrum(0.0), g=0.0):
+        self.sigma_a, self.sigma_s, self.Le, self.g = sigma_a, sigma_s, Le, g
+
+    def fill_record(self, rec, keep):
+        _base_record(rec, self.kind, self.sigma_a, self.sigma_s, self.Le, self.g)
+
+
+def build_majorant_grid(density, res):
+    """media.jl:1459-1487.  density[nx, ny, nz]; returns float32[rx*ry*rz] indexed x + rx*(y + ry*z)."""
+    nx, ny, nz = density.shape
+    rx, ry, rz = res
+    out = np.zeros(rx * ry * rz, dtype=f32)
+    for iz in range(rz):
+        z0 = max(1, int(np.floor(iz * nz / rz)) + 1)
+        z1 = min(nz, int(np.ceil((iz + 1) * nz / rz)))
+        for iy in range(ry):
+            y0 = max(1, int(np.floor(iy * ny / ry)) + 1)
+            y1 = min(ny, int(np.ceil((iy + 1) * ny / ry)))
+            for ix in range(rx):
+                x0 = max(1, int(np.floor(ix * nx / rx)) + 1)
+                x1 = min(nx, int(np.ceil((ix + 1) * nx / rx)))
+                blk = density[x0 - 1:x1, y0 - 1:y1, z0 - 1:z1]
+                out[ix + rx * (iy + ry * iz)] = max(0.0, float(blk.max())) if blk.size else 0.0
+    return out
+
+
+class GridMedium(Medium):
+    """GridMedium(density; σ_a, σ_s, g, bounds, transform, majorant_res=(16,16,16))  (media.jl:873-935)."""
+    kind = A.HK_MEDIUM_GRID
+
+    def __init__(self, density, sigma_a=RGBSpectrum(0.01), sigma_s=RGBSpectrum(1.0), g=0.0, bounds=((0, 0, 0), (1, 1, 1)),
+                 transform=None, majorant_res=(16, 16, 16)):
+        self.density = np.ascontiguousarray(density, dtype=f32)        # [nx, ny, nz]
+        self.sigma_a, self.sigma_s, self.g = sigma_a, sigma_s, g
+        self.bounds = (tuple(float(f32(v)) for v in bounds[0]), tuple(float(f32(v)) for v in bounds[1]))
+        self.medium_to_render = np.eye(4, dtype=f32) if transform is None else np.asarray(transform, dtype=f32)
+        self.render_to_medium = np.linalg.inv(self.medium_to_render.astype(np.float64)).astype(f32)
+        self.majorant_res = tuple(int(v) for v in majorant_res)
+        self.majorant = build_majorant_grid(self.density, self.majorant_res)
+        self.max_density = float(self.density.max())
+
+    def fill_record(self, rec, keep):
+        _base_record(rec, self.kind, self.sigma_a, self.sigma_s, RGBSpectrum(0.0), self.g)
+        rec.bounds_min[:] = self.bounds[0]
+        rec.bounds_max[:] = self.bounds[1]
+        rec.render_to_medium[:] = [float(x) for x in self.render_to_medium.reshape(-1)]
+        rec.medium_to_render[:] = [float(x) for x in self.medium_to_render.reshape(-1)]
+        rec.res[:] = self.density.shape
+        jl = np.ascontiguousarray(np.transpose(self.density, (2, 1, 0)))   # C [z][y][x] == Julia [x,y,z] column-major
+        keep.append(jl)
+        rec.density = jl.ctypes.data_as(A.PF)
+        rec.majorant_res[:] = self.majorant_res
+        rec.majorant = self.majorant.ctypes.data_as(A.PF)
+        rec.max_density = self.max_density
+
+
+# ---- NanoVDB -----------------------------------------------------------------------------------------------
+LEAF_DIM, LOWER_DIM, UPPER_DIM = 8, 16, 32
+LOWER_MASK, UPPER_MASK = 127, 4095
+LEAFDATA_SIZE, LEAF_VALUES, LEAF_MASK_OFF, LEAF_MIN_OFF = 2144, 96, 16, 80
+LOWER_TABLE, LOWER_CHILDMASK, LOWER_VALUEMASK = 1088, 544, 32
+UPPER_TABLE, UPPER_CHILDMASK, UPPER_VALUEMASK = 8256, 4128, 32
+UPPER_NODE_SIZE = UPPER_TABLE + 32768 * 8
+LOWER_NODE_SIZE = LOWER_TABLE + 4096 * 8
+ROOT_HEADER, ROOTTILE_SIZE = 64, 32
+
+
+def _root_key(c):
+    x, y, z = (int(v) & 0xffffffff for v in c)
+    return ((z >> 12) & 0x1fffff) | (((y >> 12) & 0x1fffff) << 21) | (((x >> 12) & 0x1fffff) << 42)
+
+
+def _upper_off(c):
+    x, y, z = (int(v) & 0xffffffff for v in c)
+    return (((x >> 7) & 31) << 10) | (((y >> 7) & 31) << 5) | ((z >> 7) & 31)
+
+
+def _lower_off(c):
+    x, y, z = (int(v) & 0xffffffff for v in c)
+    return (((x >> 3) & 15) << 8) | (((y >> 3) & 15) << 4) | ((z >> 3) & 15)
+
+
+def build_nanovdb_from_dense(data, origin, extent, background=0.0):
+    """nanovdb.jl:602-858.  data[nx, ny, nz] float32 -> (buffer uint8[], metadata dict).  Buffer layout
+    [Root | Upper nodes | Lower nodes | Leaf nodes], child offsets relative to the parent, 0-based positions
+    here; the `*_offset` metadata are the reference's 1-based byte offsets."""
+    data = np.asarray(data, dtype=f32)
+    nx, ny, nz = data.shape
+    dx, dy, dz = (f32(extent[0]) / nx, f32(extent[1]) / ny, f32(extent[2]) / nz)
+    nbx, nby, nbz = -(-nx // 8), -(-ny // 8), -(-nz // 8)
+    pad = np.full((nbx * 8, nby * 8, nbz * 8), background, dtype=f32)
+    pad[:nx, :ny, :nz] = data
+    leaf_coords, leaf_values = [], []
+    for bz in range(nbz):
+        for by in range(nby):
+            for bx in range(nbx):
+                blk = pad[bx * 8:bx * 8 + 8, by * 8:by * 8 + 8, bz * 8:bz * 8 + 8]
+                if np.any(blk != background):
+                    leaf_coords.append((bx * 8, by * 8, bz * 8))
+                    leaf_values.append(np.ascontiguousarray(blk).reshape(-1))   # index (lx<<6)|(ly<<3)|lz == C order [lx][ly][lz]
+    n_leaves = len(leaf_coords)
+    lower_to_leaves = {}
+    for li, c in enumerate(leaf_coords):
+        lower_to_leaves.setdefault(tuple(v & ~LOWER_MASK for v in c), []).append(li)
+    lower_bases = sorted(lower_to_leaves)
+    upper_to_lowers = {}
+    for low_i, lb in enumerate(lower_bases):
+        upper_to_lowers.setdefault(tuple(v & ~UPPER_MASK for v in lb), []).append(low_i)
+    upper_bases = sorted(upper_to_lowers)
+    n_lowers, n_uppers = len(lower_bases), len(upper_bases)
+    root_size = ROOT_HEADER + n_uppers * ROOTTILE_SIZE
+    upper_section, lower_section = n_uppers * UPPER_NODE_SIZE, n_lowers * LOWER_NODE_SIZE
+    total = root_size + upper_section + lower_section + n_leaves * LEAFDATA_SIZE
+    buf = np.zeros(total, dtype=np.uint8)
+    upper_pos = lambda i: root_size + i * UPPER_NODE_SIZE
+    lower_pos = lambda i: root_size + upper_section + i * LOWER_NODE_SIZE
+    order = sorted(range(n_leaves), key=lambda i: leaf_coords[i])
+    leaf_pos = [0] * n_leaves
+    for slot, li in enumerate(order):
+        leaf_pos[li] = root_size + upper_section + lower_section + slot * LEAFDATA_SIZE
+
+    def w32(off, v, dt):
+        buf[off:off + 4] = np.array([v], dtype=dt).view(np.uint8)
+
+    def w64(off, v, dt=np.int64):
+        buf[off:off + 8] = np.array([v], dtype=dt).view(np.uint8)
+
+    def set_bit(mask_off, n):
+        buf[mask_off + (n >> 3)] |= np.uint8(1 << (n & 7))
+
+    for li in range(n_leaves):
+        c, vals, off = leaf_coords[li], leaf_values[li], leaf_pos[li]
+        for k in range(3):
+            w32(off + 4 * k, c[k], np.int32)
+        buf[off + 12:off + 15] = 7
+        active = vals != background
+        bits = np.packbits(active.astype(np.uint8), bitorder="little")
+        buf[off + LEAF_MASK_OFF:off + LEAF_MASK_OFF + 64] = bits
+        w32(off + LEAF_MIN_OFF, vals.min(), f32)
+        w32(off + LEAF_MIN_OFF + 4, vals.max(), f32)
+        buf[off + LEAF_VALUES:off + LEAF_VALUES + 2048] = vals.view(np.uint8)
+    for low_i, lb in enumerate(lower_bases):
+        off = lower_pos(low_i)
+        for k in range(3):
+            w32(off + 4 * k, lb[k], np.int32)
+            w32(off + 12 + 4 * k, lb[k] + 127, np.int32)
+        for li in lower_to_leaves[lb]:
+            n = _lower_off(leaf_coords[li])
+            set_bit(off + LOWER_CHILDMASK, n)
+            set_bit(off + LOWER_VALUEMASK, n)
+            w64(off + LOWER_TABLE + n * 8, leaf_pos[li] - off)
+    for up_i, ub in enumerate(upper_bases):
+        off = upper_pos(up_i)
+        for k in range(3):
+            w32(off + 4 * k, ub[k], np.int32)
+            w32(off + 12 + 4 * k, ub[k] + 4095, np.int32)
+        for low_i in upper_to_lowers[ub]:
+            n = _upper_off(lower_bases[low_i])
+            set_bit(off + UPPER_CHILDMASK, n)
+            set_bit(off + UPPER_VALUEMASK, n)
+            w64(off + UPPER_TABLE + n * 8, lower_pos(low_i) - off)
+    cs = np.array(leaf_coords, dtype=np.int64).reshape(-1, 3)
+    idx_min = tuple(int(v) for v in cs.min(axis=0)) if n_leaves else (0, 0, 0)
+    idx_max = tuple(int(v) + 8 for v in cs.max(axis=0)) if n_leaves else (0, 0, 0)
+    for k in range(3):
+        w32(4 * k, idx_min[k], np.int32)
+        w32(12 + 4 * k, idx_max[k], np.int32)
+    w32(24, n_uppers, np.uint32)
+    w32(28, background, f32)
+    for ti, ub in enumerate(upper_bases):
+        t = ROOT_HEADER + ti * ROOTTILE_SIZE
+        w64(t, _root_key(ub), np.uint64)
+        w64(t + 8, upper_pos(ti))
+        w32(t + 16, 1, np.uint32)
+        w32(t + 20, background, f32)
+    meta = dict(
+        world_min=tuple(float(f32(v)) for v in origin),
+        world_max=tuple(float(f32(origin[k]) + f32(extent[k])) for k in range(3)),
+        inv_mat=(float(f32(1) / dx), 0.0, 0.0, 0.0, float(f32(1) / dy), 0.0, 0.0, 0.0, float(f32(1) / dz)),
+        vec=(float(f32(origin[0]) + dx / f32(2)), float(f32(origin[1]) + dy / f32(2)), float(f32(origin[2]) + dz / f32(2))),
+        root_offset=1, upper_offset=upper_pos(0) + 1, lower_offset=lower_pos(0) + 1,
+        leaf_offset=(leaf_pos[order[0]] + 1) if n_leaves else 1,
+        leaf_count=n_leaves, lower_count=n_lowers, upper_count=n_uppers, root_table_size=n_uppers,
+        index_min=idx_min, index_max=idx_max, dense=pad, dense_shape=(nx, ny, nz), background=float(background))
+    return buf, meta
+
+
+def build_nanovdb_majorant_grid(meta, bounds, res=(64, 64, 64)):
+    """nanovdb.jl:1174-1235: max over index-space voxels [floor(min-1), ceil(max+1)] clipped to the index bbox.
+    Voxel values come from the dense array the tree was built from (identical to nanovdb_get_value_raw for
+    every index inside the bbox; outside leaves the tree returns the background)."""
+    pad = meta["dense"]
+    bg = f32(meta["background"])
+    inv, vec = meta["inv_mat"], meta["vec"]
+    bmin, bmax = np.array(bounds[0], dtype=f32), np.array(bounds[1], dtype=f32)
+    diag = (bmax - bmin).astype(f32)
+    rx, ry, rz = res
+    out = np.zeros(rx * ry * rz, dtype=f32)
+    imin, imax = meta["index_min"], meta["index_max"]
+
+    def rng(axis, i, r):
+        p0 = f32(bmin[axis] + diag[axis] * f32(i) / f32(r))
+        p1 = f32(bmin[axis] + diag[axis] * f32(i + 1) / f32(r))
+        a = f32(f32(inv[4 * axis]) * f32(p0 - f32(vec[axis])))
+        b = f32(f32(inv[4 * axis]) * f32(p1 - f32(vec[axis])))
+        lo = max(int(np.floor(min(a, b) - f32(1))), imin[axis])
+        hi = min(int(np.ceil(max(a, b) + f32(1))), imax[axis])
+        return lo, hi
+
+    xr = [rng(0, i, rx) for i in range(rx)]
+    yr = [rng(1, i, ry) for i in range(ry)]
+    zr = [rng(2, i, rz) for i in range(rz)]
+    sx, sy, sz = pad.shape
+
+    def clip(lo, hi, n):
+        return max(lo, 0), min(hi, n - 1)
+
+    for iz in range(rz):
+        z0, z1 = zr[iz]
+        for iy in range(ry):
+            y0, y1 = yr[iy]
+            for ix in range(rx):
+                x0, x1 = xr[ix]
+                m = f32(0)
+                if x0 <= x1 and y0 <= y1 and z0 <= z1:
+                    cx0, cx1 = clip(x0, x1, sx)
+                    cy0, cy1 = clip(y0, y1, sy)
+                    cz0, cz1 = clip(z0, z1, sz)
+                    if cx0 <= cx1 and cy0 <= cy1 and cz0 <= cz1:
+                        m = max(m, f32(pad[cx0:cx1 + 1, cy0:cy1 + 1, cz0:cz1 + 1].max()))
+                    if (x0 < 0 or y0 < 0 or z0 < 0 or x1 >= sx or y1 >= sy or z1 >= sz):
+                        m = max(m, bg)
+                out[ix + rx * (iy + ry * iz)] = m
+    return out
+
+
+class NanoVDBMedium(Medium):
+    """NanoVDBMedium(data; bounds, σ_a=0, σ_s=1, g=0, majorant_res=(64,64,64))  (nanovdb.jl:964-1004)."""
+    kind = A.HK_MEDIUM_NANOVDB
+
+    def __init__(self, data, bounds, sigma_a=RGBSpectrum(0.0), sigma_s=RGBSpectrum(1.0), g=0.0, majorant_res=(64, 64, 64)):
+        self.bounds = (tuple(float(f32(v)) for v in bounds[0]), tuple(float(f32(v)) for v in bounds[1]))
+        origin = self.bounds[0]
+        extent = tuple(float(f32(self.bounds[1][k]) - f32(self.bounds[0][k])) for k in range(3))
+        self.buffer, self.meta = build_nanovdb_from_dense(data, origin, extent)
+        self.majorant_res = tuple(int(v) for v in majorant_res)
+        self.majorant = build_nanovdb_majorant_grid(self.meta, self.bounds, self.majorant_res)
+        self.max_density = float(self.majorant.max())
+        self.sigma_a, self.sigma_s, self.g = sigma_a, sigma_s, g
+
+    def fill_record(self, rec, keep):
+        _base_record(rec, self.kind, self.sigma_a, self.sigma_s, RGBSpectrum(0.0), self.g)
+        m = self.meta
+        rec.bounds_min[:] = self.bounds[0]
+        rec.bounds_max[:] = self.bounds[1]
+        rec.majorant_res[:] = self.majorant_res
+        rec.majorant = self.majorant.ctypes.data_as(A.PF)
+        rec.max_density = self.max_density
+        rec.nvdb_bytes = self.buffer.ctypes.data_as(C.POINTER(C.c_uint8))
+        rec.nvdb_size = self.buffer.size
+        rec.root_offset_1based, rec.upper_offset_1based = m["root_offset"], m["upper_offset"]
+        rec.lower_offset_1based, rec.leaf_offset_1based = m["lower_offset"], m["leaf_offset"]
+        rec.upper_count, rec.lower_count, rec.leaf_count, rec.root_table_size = m["upper_count"], m["lower_count"], m["leaf_count"], m["root_table_size"]
+        rec.inv_mat[:] = m["inv_mat"]
+        rec.vec[:] = m["vec"]
+        rec.index_bbox_min[:] = m["index_min"]
+        rec.index_bbox_max[:] = m["index_max"]

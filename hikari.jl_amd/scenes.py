@@ -57,8 +57,8 @@ def cornell_box(width=800, height=800, light="area", spheres=True, tess=32):
     return s, film, cam
 
 
-def integration_test_scene(width=64, height=64, with_fog=False):
-    """test/volpath_integration.jl:9-115 (fog medium optional until the media rows land)."""
+def integration_test_scene(width=64, height=64, with_fog=True):
+    """test/volpath_integration.jl:9-115: matte walls, fog-filled glass sphere, gold conductor sphere, PointLight(15)."""
     white = MatteMaterial(Kd=RGBSpectrum(0.73, 0.73, 0.73))
     red = MatteMaterial(Kd=RGBSpectrum(0.65, 0.05, 0.05))
     green = MatteMaterial(Kd=RGBSpectrum(0.12, 0.45, 0.15))
@@ -70,10 +70,71 @@ def integration_test_scene(width=64, height=64, with_fog=False):
     s.push(G.rect3f((-half, 0, half - 0.01), (box, box, 0.01)), white)
     s.push(G.rect3f((-half, 0, -half), (0.01, box, box)), red)
     s.push(G.rect3f((half - 0.01, 0, -half), (0.01, box, box)), green)
-    s.push(G.sphere((-0.4, 0.4, 0.0), 0.35, 32), glass)
+    if with_fog:
+        from .media import HomogeneousMedium
+        fog = HomogeneousMedium(sigma_a=RGBSpectrum(0.01), sigma_s=RGBSpectrum(0.3), Le=RGBSpectrum(0.0), g=0.3)
+        s.push(G.sphere((-0.4, 0.4, 0.0), 0.35, 32), MediumInterface(glass, inside=fog, outside=None))
+    else:
+        s.push(G.sphere((-0.4, 0.4, 0.0), 0.35, 32), glass)
     s.push(G.sphere((0.4, 0.35, 0.0), 0.3, 32), gold)
     s.push(PointLight((0, 1.8, 0), RGBSpectrum(15.0)))
     s.sync()
     film = Film((width, height))
     cam = PerspectiveCamera((0, 1, -3.5), (0, 1, 0), film, fov=40.0)
+    return s, film, cam
+
+
+def slab_scene(width=32, height=32, medium=None, thickness=1.0):
+    """Closed-form check scene: the camera looks through a slab of `medium` (index-matched
+    interface: GlassMaterial(Kr=0, Kt=1, index=1)) at a large two-sided emitter; pixel ~ Le * exp(-sigma_t * d)."""
+    s = Scene()
+    emitter = G.quad((-4, -4, 3), (4, -4, 3), (4, 4, 3), (-4, 4, 3), normal=(0, 0, -1))
+    s.push(emitter, MediumInterface(MatteMaterial(Kd=RGBSpectrum(0.0)), emission=Emissive(Le=RGBSpectrum(0.5), scale=1.0, two_sided=True)))
+    if medium is not None:
+        iface = MediumInterface(GlassMaterial(Kr=RGBSpectrum(0.0), Kt=RGBSpectrum(1.0), index=1.0), inside=medium, outside=None)
+        s.push(G.rect3f((-2.5, -2.6, 1.0), (5.0, 5.2, thickness)), iface)
+    s.sync()
+    film = Film((width, height))
+    cam = PerspectiveCamera((0, 0, -2), (0, 0, 1), film, fov=20.0)
+    return s, film, cam
+
+
+def cloud_density(n=(64, 64, 32), seed=7, fill=0.35):
+    """Seeded synthetic cloud field (worley-ish blobs, thresholded) standing in for the BOMEX LES data that is
+    not in the reference tree."""
+    rng = np.random.default_rng(seed)
+    nx, ny, nz = n
+    x, y, z = np.meshgrid(np.linspace(0, 1, nx), np.linspace(0, 1, ny), np.linspace(0, 1, nz), indexing="ij")
+    d = np.zeros(n, dtype=np.float64)
+    for _ in range(24):
+        c = rng.random(3) * np.array([1, 1, 0.6]) + np.array([0, 0, 0.2])
+        r = 0.06 + 0.12 * rng.random()
+        d += np.exp(-(((x - c[0]) ** 2 + (y - c[1]) ** 2 + ((z - c[2]) * 1.6) ** 2) / (r * r)))
+    d = np.clip(d - np.quantile(d, 1.0 - fill), 0, None)
+    d = d / max(d.max(), 1e-9)
+    return d.astype(np.float32)
+
+
+def cloud_scene(width=1024, height=1024, kind="nanovdb", res=(128, 128, 64), sigma_scale=60.0):
+    """Config 4 stand-in: synthetic cloud in a 1.2 cube at (-0.6, 0.3, -0.6), sigma_a = 0, sigma_s = 1,
+    g = 0.877, index-matched glass cube as MediumInterface(inside = cloud); Ambient(.03,.07,.23) + Directional(2.6,2.5,2.3)
+    (examples/bomex_cloud_example.jl:131-143), matte ground plane; camera looking at the cloud."""
+    from .lights import AmbientLight
+    from .media import GridMedium, NanoVDBMedium
+    dens = cloud_density(res) * np.float32(sigma_scale)
+    lo, hi = (-0.6, 0.3, -0.6), (0.6, 1.5, 0.6)
+    if kind == "nanovdb":
+        med = NanoVDBMedium(dens, bounds=(lo, hi), sigma_a=RGBSpectrum(0.0), sigma_s=RGBSpectrum(1.0), g=0.877, majorant_res=(32, 32, 32))
+    else:
+        med = GridMedium(dens, sigma_a=RGBSpectrum(0.0), sigma_s=RGBSpectrum(1.0), g=0.877, bounds=(lo, hi))
+    s = Scene()
+    s.push(AmbientLight(RGBSpectrum(0.03, 0.07, 0.23)))
+    s.push(DirectionalLight(RGBSpectrum(2.6, 2.5, 2.3), (-0.5826, -0.766, -0.2717)))
+    s.push(G.rect3f((-4, -0.01, -4), (8, 0.01, 8)), MatteMaterial(Kd=RGBSpectrum(0.35, 0.33, 0.3)))
+    eps = 1e-3
+    iface = MediumInterface(GlassMaterial(Kr=RGBSpectrum(0.0), Kt=RGBSpectrum(1.0), index=1.0), inside=med, outside=None)
+    s.push(G.rect3f((lo[0] - eps, lo[1] - eps, lo[2] - eps), (1.2 + 2 * eps, 1.2 + 2 * eps, 1.2 + 2 * eps)), iface)
+    s.sync()
+    film = Film((width, height))
+    cam = PerspectiveCamera((0.0, 1.0, -3.2), (0.0, 0.85, 0.0), film, fov=35.0)
     return s, film, cam

@@ -325,8 +325,17 @@ struct MediumSampleItem {  // VPMediumSampleWorkItem (workitems.jl) — filled b
     float eta_scale;
     bool specular_bounce, any_non_specular;
     int32_t medium;
-    bool has_surface_hit, hit_valid;
-    HitItem* hit_store;
+    bool has_surface_hit;
+};
+struct ScatterItem {  // VPMediumScatterWorkItem (workitems.jl)
+    V3 p, wo;
+    float time;
+    Wavelengths lambda;
+    int32_t pixel_index;
+    Spec beta, r_u;
+    int32_t depth;
+    int32_t medium;
+    float g;
 };
 
 // evaluate_escaped_ray_spectral  physical-wavefront/lights.jl:408-443 (sum over every light, flat order)
@@ -362,10 +371,216 @@ struct RenderState {
 };
 
 
-// K4-K6 (delta-tracking.jl:79-471, medium-scatter.jl:15-247): lands with the media widening.
-static void process_media_stage(const Scene&, RenderState&, std::vector<RayItem>&, std::vector<uint8_t>&, std::vector<MediumSampleItem>&, std::vector<HitItem>&,
-                                std::vector<EscapedItem>&, std::vector<RayItem>&, std::vector<ShadowItem>&, const hk_integrator_params&, std::vector<Counters>&,
-                                int32_t) {}
+// K4 (delta-tracking.jl:79-453), K5 (medium-scatter.jl:15-138), K6 (medium-scatter.jl:148-216)
+static void process_media_stage(const Scene& sc, RenderState& st, std::vector<RayItem>& rays, std::vector<uint8_t>& kind, std::vector<MediumSampleItem>& msamples,
+                                std::vector<HitItem>& hits, std::vector<EscapedItem>& escaped, std::vector<RayItem>& next_rays, std::vector<ShadowItem>& shadow_out,
+                                const hk_integrator_params& ip, std::vector<Counters>& cnts, int32_t depth) {
+    (void)rays;
+    (void)depth;
+    const int32_t n = (int32_t)kind.size();
+    std::vector<ScatterItem> scat(n);
+    std::vector<uint8_t> scat_valid(n, 0);
+    const int32_t max_depth = ip.max_depth;
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int32_t i = 0; i < n; ++i) {
+        if (kind[i] != 3) continue;
+        const MediumSampleItem& wk = msamples[i];
+#if defined(_OPENMP)
+        Counters& cnt = cnts[omp_get_thread_num()];
+#else
+        Counters& cnt = cnts[0];
+#endif
+        Spec beta = wk.beta, r_u = wk.r_u, r_l = wk.r_l;
+        uint64_t rng = lcg_init(wk.o, wk.d, wk.t_max);
+        MajorantIter it = create_majorant_iterator(sc.media, wk.medium, wk.o, wk.d, wk.t_max, wk.lambda);
+        V3 ray_d = wk.d;
+        bool done = false;
+        for (int segi = 0; segi < 256 && !done; ++segi) {  // sample_T_maj_loop!
+            MajorantSegment seg;
+            if (!majorant_next(it, seg)) break;
+            // sample_segment!
+            Spec sm = seg.sigma_maj;
+            float sm0 = sm[0];
+            if (sm0 < 1e-10f) continue;
+            float t = seg.t_min;
+            V3 ray_o = wk.o + ray_d * t;
+            for (int k = 0; k < 1024; ++k) {
+                float u = lcg_next(rng);
+                float dt = -std::log(maxf(1e-10f, 1.0f - u)) / sm0;
+                float t_sample = t + dt;
+                if (t_sample >= seg.t_max) {
+                    float dt_remain = seg.t_max - t;
+                    Spec T_maj = exp(-dt_remain * sm);
+                    float T0 = T_maj[0];
+                    if (T0 > 1e-10f) {
+                        beta = beta * T_maj / T0;
+                        r_u = r_u * T_maj / T0;
+                        r_l = r_l * T_maj / T0;
+                    }
+                    break;
+                }
+                Spec T_maj = exp(-dt * sm);
+                V3 p = ray_o + ray_d * dt;
+                cnt.collisions++;
+                MediumProperties mp = sample_point(sc.media, wk.medium, p, wk.lambda);
+                if (!is_black(mp.Le) && wk.depth < max_depth) {
+                    float pr = sm0 * T_maj[0];
+                    if (pr > 1e-10f) {
+                        Spec r_e = r_u * sm * T_maj / pr;
+                        if (!is_black(r_e)) {
+                            Spec Le_c = beta * mp.sigma_a * T_maj * mp.Le / (pr * average(r_e));
+                            float* L = &st.pixel_L[4 * (size_t)(wk.pixel_index - 1)];
+                            for (int c = 0; c < 4; ++c) L[c] += Le_c[c];
+                        }
+                    }
+                }
+                float p_absorb = mp.sigma_a[0] / sm0;
+                float p_scatter = mp.sigma_s[0] / sm0;
+                float u_event = lcg_next(rng);
+                if (u_event < p_absorb) {
+                    beta = Spec(0.0f);
+                    done = true;
+                    break;
+                } else if (u_event < p_absorb + p_scatter) {
+                    if (wk.depth >= max_depth) {
+                        done = true;
+                        break;
+                    }
+                    float pdf = T_maj[0] * mp.sigma_s[0];
+                    if (pdf > 1e-10f) {
+                        beta = beta * T_maj * mp.sigma_s / pdf;
+                        r_u = r_u * T_maj * mp.sigma_s / pdf;
+                    }
+                    ScatterItem& si = scat[i];
+                    si.p = p;
+                    si.wo = -ray_d;
+                    si.time = wk.time;
+                    si.lambda = wk.lambda;
+                    si.pixel_index = wk.pixel_index;
+                    si.beta = beta;
+                    si.r_u = r_u;
+                    si.depth = wk.depth;
+                    si.medium = wk.medium;
+                    si.g = mp.g;
+                    scat_valid[i] = 1;
+                    done = true;
+                    break;
+                } else {
+                    Spec sn = sm - mp.sigma_a - mp.sigma_s;
+                    sn = Spec(maxf(sn[0], 0.0f), maxf(sn[1], 0.0f), maxf(sn[2], 0.0f), maxf(sn[3], 0.0f));
+                    float pdf = T_maj[0] * sn[0];
+                    if (pdf > 1e-10f) {
+                        beta = beta * T_maj * sn / pdf;
+                        r_u = r_u * T_maj * sn / pdf;
+                        r_l = r_l * T_maj * sm / pdf;
+                    } else {
+                        beta = Spec(0.0f);
+                        done = true;
+                        break;
+                    }
+                    t = t_sample;
+                    ray_o = p;  // apply_deflection is the identity (media.jl:2039)
+                    if (is_black(beta) || is_black(r_u)) {
+                        done = true;
+                        break;
+                    }
+                }
+            }
+        }
+        if (done) {
+            kind[i] = 0;
+            continue;
+        }
+        if (is_black(beta) || is_black(r_u) || wk.depth >= max_depth) {
+            kind[i] = 0;
+            continue;
+        }
+        if (!wk.has_surface_hit) {
+            EscapedItem& e = escaped[i];
+            e.d = ray_d;
+            e.lambda = wk.lambda;
+            e.pixel_index = wk.pixel_index;
+            e.beta = beta;
+            e.r_u = r_u;
+            e.r_l = r_l;
+            e.depth = wk.depth;
+            e.specular_bounce = wk.specular_bounce;
+            kind[i] = 2;
+        } else {
+            hits[i].beta = beta;
+            hits[i].r_u = r_u;
+            hits[i].r_l = r_l;
+            kind[i] = 1;
+        }
+    }
+    // ---- K5: direct lighting at medium scattering events (n = 0 for the light BVH) ----
+    std::vector<ShadowItem> sh(n);
+    std::vector<uint8_t> sh_valid(n, 0);
+    std::vector<RayItem> nr(n);
+    std::vector<uint8_t> nr_valid(n, 0);
+#pragma omp parallel for schedule(static)
+    for (int32_t i = 0; i < n; ++i) {
+        if (!scat_valid[i]) continue;
+        const ScatterItem& wk = scat[i];
+        int32_t p0 = wk.pixel_index - 1;
+        if (sc.desc.n_lights >= 1) {
+            V2 u_light = st.s_direct_u[p0];
+            float light_select = st.s_direct_uc[p0];
+            float light_pmf;
+            int32_t light_idx = sc.sampler.sample(wk.p, V3(0.0f), light_select, light_pmf);
+            if (!(light_idx < 1 || light_idx > sc.desc.n_lights || light_pmf <= 0.0f)) {
+                LightSample ls = sample_light_full(sc, light_idx, wk.p, wk.lambda, u_light);
+                if (ls.pdf > 0.0f && !is_black(ls.Li)) {
+                    float cos_t = dot(wk.wo, ls.wi);
+                    float phase_val = hg_p(wk.g, cos_t);
+                    if (phase_val > 0.0f) {
+                        ShadowItem& s = sh[i];
+                        s.Ld = wk.beta * phase_val * ls.Li;
+                        float light_pdf = ls.pdf * light_pmf;
+                        float phase_pdf = ls.is_delta ? 0.0f : phase_val;
+                        s.r_u = wk.r_u * phase_pdf;
+                        s.r_l = wk.r_u * light_pdf;
+                        s.o = wk.p;
+                        s.d = ls.wi;
+                        s.t_max = ls.is_delta ? norm(ls.p_light - wk.p) - 0.001f : 1.0e6f;
+                        s.lambda = wk.lambda;
+                        s.pixel_index = wk.pixel_index;
+                        s.medium = wk.medium;
+                        sh_valid[i] = 1;
+                    }
+                }
+            }
+        }
+        // ---- K6: phase-function sampling ----
+        int32_t new_depth = wk.depth + 1;
+        if (new_depth >= max_depth) continue;
+        V2 u = st.s_indirect_u[p0];
+        float phase_pdf;
+        V3 wi = sample_hg(wk.g, wk.wo, u, phase_pdf);
+        if (phase_pdf > 0.0f) {
+            RayItem& r = nr[i];
+            r.o = wk.p;
+            r.d = wi;
+            r.t_max = INF_F;
+            r.time = wk.time;
+            r.depth = new_depth;
+            r.lambda = wk.lambda;
+            r.pixel_index = wk.pixel_index;
+            r.beta = wk.beta;
+            r.r_u = wk.r_u;
+            r.r_l = wk.r_u / phase_pdf;
+            r.eta_scale = 1.0f;
+            r.specular_bounce = false;
+            r.any_non_specular = true;
+            r.medium = wk.medium;
+            nr_valid[i] = 1;
+        }
+    }
+    for (int32_t i = 0; i < n; ++i) {
+        if (sh_valid[i]) shadow_out.push_back(sh[i]);
+        if (nr_valid[i]) next_rays.push_back(nr[i]);
+    }
+}
 
 static void render_one_sample(const Scene& sc, const hk_integrator_params& ip, const FilterParams& fp, const FilterSampler& fs, const hk_camera& cam,
                               const SobolRNG& rng, RenderState& st, int32_t sample_idx, double* pixel_rgb, double* pixel_w, bool f64, float* rgb32, float* w32,
@@ -502,13 +717,7 @@ static void render_one_sample(const Scene& sc, const hk_integrator_params& ip, c
                 ms.t_max = h.hit ? h.t : INF_F;
                 if (h.hit) {
                     cnt.hits++;
-                    HitItem hi;
-                    fill_hit(hi, h, wk.o, wk.d);
-                    ms.hit_valid = true;
-                    ms.hit_store = new HitItem(hi);
-                } else {
-                    ms.hit_valid = false;
-                    ms.hit_store = nullptr;
+                    fill_hit(hits[i], h, wk.o, wk.d);
                 }
                 kind[i] = 3;
                 continue;
@@ -814,7 +1023,6 @@ extern "C" {
 int32_t hko_scene_create(const hk_scene_desc* desc, const hk_tables* tables, hko_scene** out) {
     hko_scene* s = new hko_scene();
     Scene& sc = s->sc;
-    if (desc->n_media > 0) { delete s; return HK_ERR_UNSUPPORTED; }
     sc.desc = *desc;  // borrowed pointers: the caller keeps the arrays alive for the scene's lifetime
     sc.accel.build(desc->positions, desc->n_triangles);
     sc.sampler.build(desc->lights, desc->n_lights);

@@ -21,6 +21,8 @@ void launch_camera(hipStream_t, int, const DPathState&, const DFrame&, const DTa
 void launch_trace(hipStream_t, int, const DPathState&, const DScene&, const DTables&, const DFrame&, int, DStats*);
 void launch_shadow(hipStream_t, int, const DPathState&, const DScene&, const DTables&, const DFrame&, int, DStats*);
 void launch_escaped(hipStream_t, int, const DPathState&, const DScene&, const DTables&, int);
+void launch_medium(hipStream_t, int, const DPathState&, const DScene&, const DTables&, const DFrame&, const DSobol&, int, DStats*);
+void launch_detect_camera_medium(hipStream_t, const DPathState&, const DScene&, float, float, float, DStats*);
 void launch_shade(hipStream_t, int, int, const DPathState&, const DScene&, const DTables&, const DFrame&, const DSobol&, int, int, DStats*);
 void launch_film(hipStream_t, const DPathState&, const DFrame&, const DTables&, void*, bool);
 void launch_finalize(hipStream_t, const void*, bool, float*, int, int);
@@ -97,6 +99,8 @@ struct hk_scene {
     DevBuf nodes, leaf_tris, positions, normals, uvs, tangents, meta, materials, textures, spectra, mis, lights, lnodes, trails, infinite;
     std::vector<DevBuf*> tex_data;
     std::vector<DevBuf*> spec_data;
+    std::vector<DevBuf*> media_data;
+    DevBuf media;
     DScene d{};
     uint32_t kinds_mask = 0;
     int bvh_nodes = 0, bvh_leaf_tris = 0, bvh_depth = 0;
@@ -104,6 +108,7 @@ struct hk_scene {
     ~hk_scene() {
         for (auto* b : tex_data) delete b;
         for (auto* b : spec_data) delete b;
+        for (auto* b : media_data) delete b;
     }
 };
 
@@ -256,7 +261,6 @@ int bake_mode(int kind, int slot) {
 extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene** out) {
     if (!c || !d || !out) return fail(HK_ERR_INVALID, "null argument");
     if (!c->have_tables) return fail(HK_ERR_INVALID, "hk_ctx_set_tables must be called first");
-    if (d->n_media > 0) return fail(HK_ERR_UNSUPPORTED, "participating media are not built yet (SURVEY 8 rows a27-a30)");
     if (d->n_envmaps > 0) return fail(HK_ERR_UNSUPPORTED, "environment maps are not built yet (SURVEY 8 row a24)");
     if (d->n_triangles < 0 || (d->n_triangles > 0 && (!d->positions || !d->meta))) return fail(HK_ERR_INVALID, "bad triangle arrays");
     HIP_TRY(hipSetDevice(c->device));
@@ -453,7 +457,61 @@ extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene**
         if (inf.empty()) inf.resize(1);
         HIP_TRY(s->infinite.upload(inf.data(), inf.size() * 4));
     }
+    // ---- media: bake sigma_a / sigma_s / Le with uplift_rgb_unbounded, upload grids / NanoVDB bytes ----
+    std::vector<DMedium> dmed(d->n_media > 0 ? d->n_media : 1);
+    std::memset(dmed.data(), 0, dmed.size() * sizeof(DMedium));
+    for (int i = 0; i < d->n_media; ++i) {
+        const hk_medium& m = d->media[i];
+        DMedium& o = dmed[i];
+        if (m.kind != HK_MEDIUM_HOMOGENEOUS && m.kind != HK_MEDIUM_GRID && m.kind != HK_MEDIUM_NANOVDB) {
+            delete s;
+            return fail(HK_ERR_UNSUPPORTED, "RGBGridMedium is not built yet (SURVEY 8 row a27)");
+        }
+        o.kind = m.kind;
+        o.g = m.g;
+        float cf[4];
+        bake_unbounded(c->r2s_host, m.sigma_a[0], m.sigma_a[1], m.sigma_a[2], cf);
+        o.sigma_a = make_float4(cf[0], cf[1], cf[2], cf[3]);
+        bake_unbounded(c->r2s_host, m.sigma_s[0], m.sigma_s[1], m.sigma_s[2], cf);
+        o.sigma_s = make_float4(cf[0], cf[1], cf[2], cf[3]);
+        bake_unbounded(c->r2s_host, m.Le[0], m.Le[1], m.Le[2], cf);
+        o.Le = make_float4(cf[0], cf[1], cf[2], cf[3]);
+        std::memcpy(o.bmin, m.bounds_min, 12);
+        std::memcpy(o.bmax, m.bounds_max, 12);
+        std::memcpy(o.r2m, m.render_to_medium, 48);
+        std::memcpy(o.res, m.res, 12);
+        std::memcpy(o.mres, m.majorant_res, 12);
+        std::memcpy(o.inv_mat, m.inv_mat, 36);
+        std::memcpy(o.vec, m.vec, 12);
+        o.root_off = m.root_offset_1based;
+        o.root_table_size = m.root_table_size;
+        if (m.kind != HK_MEDIUM_HOMOGENEOUS) {
+            if (!m.majorant) {
+                delete s;
+                return fail(HK_ERR_INVALID, "heterogeneous medium without a majorant grid");
+            }
+            DevBuf* mb = new DevBuf();
+            s->media_data.push_back(mb);
+            HIP_TRY(mb->upload(m.majorant, (size_t)m.majorant_res[0] * m.majorant_res[1] * m.majorant_res[2] * 4));
+            o.majorant = mb->as<float>();
+        }
+        if (m.kind == HK_MEDIUM_GRID) {
+            DevBuf* db = new DevBuf();
+            s->media_data.push_back(db);
+            HIP_TRY(db->upload(m.density, (size_t)m.res[0] * m.res[1] * m.res[2] * 4));
+            o.density = db->as<float>();
+        }
+        if (m.kind == HK_MEDIUM_NANOVDB) {
+            DevBuf* nb = new DevBuf();
+            s->media_data.push_back(nb);
+            HIP_TRY(nb->upload(m.nvdb_bytes, (size_t)m.nvdb_size));
+            o.nvdb = nb->as<unsigned char>();
+        }
+    }
+    HIP_TRY(s->media.upload(dmed.data(), dmed.size() * sizeof(DMedium)));
     DScene& D = s->d;
+    D.media = s->media.as<DMedium>();
+    D.n_media = d->n_media;
     D.nodes = s->nodes.as<DNode>();
     D.leaf_tris = s->leaf_tris.as<float4>();
     D.root_ref = bvh.root_ref;
@@ -727,6 +785,9 @@ int ensure_state(hk_integrator* I, int capacity) {
     HIP_TRY(alloc_arr(I, s.ray_q[1], Q));
     HIP_TRY(alloc_arr(I, s.shadow_q, Q));
     HIP_TRY(alloc_arr(I, s.escaped_q, Q));
+    HIP_TRY(alloc_arr(I, s.medium_q, Q));
+    HIP_TRY(alloc_arr(I, s.initial_medium, 1));
+    HIP_TRY(hipMemset(s.initial_medium, 0xff, sizeof(int)));
     HIP_TRY(alloc_arr(I, s.mat_q, Q * HK_MAX_KINDS));
     size_t nc = (size_t)(I->p.max_depth + 2) * Q_COUNT * W;
     HIP_TRY(alloc_arr(I, s.counters, nc));
@@ -810,6 +871,20 @@ extern "C" int32_t hk_render(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_film*
         HIP_TRY(hipEventRecord(c->ev_begin, s));
         c->have_span = true;
     }
+    // K14: camera medium, decided on the device (no readback)
+    if (sc->d.n_media > 0) {
+        const float* m = cam->camera_to_world;
+        float w = m[15];
+        float cx = m[3], cy = m[7], cz = m[11];
+        if (w != 1.0f) {
+            float inv = 1.0f / w;
+            cx *= inv;
+            cy *= inv;
+            cz *= inv;
+        }
+        hk::launch_detect_camera_medium(s, I->st, sc->d, cx, cy, cz, dstats);
+    } else
+        HIP_TRY(hipMemsetAsync(I->st.initial_medium, 0xff, sizeof(int), s));
     int done = 0;
     while (done < n_samples) {
         int k = n_samples - done < S ? n_samples - done : S;
@@ -833,8 +908,12 @@ extern "C" int32_t hk_render(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_film*
         for (int depth = 0; depth < I->p.max_depth; ++depth) {
             timed(0, [&] { hk::launch_trace(s, trace_blocks, I->st, sc->d, c->tables, fr, depth, dstats); });
             c->trace_launches++;
-            if (sc->d.has_escape_lights) timed(3, [&] { hk::launch_escaped(s, light_blocks, I->st, sc->d, c->tables, depth); });
             int first_kind = 1;
+            if (sc->d.n_media > 0) {
+                timed(3, [&] { hk::launch_medium(s, c->n_cu, I->st, sc->d, c->tables, fr, sob, depth, dstats); });
+                first_kind = 0;
+            }
+            if (sc->d.has_escape_lights) timed(3, [&] { hk::launch_escaped(s, light_blocks, I->st, sc->d, c->tables, depth); });
             for (int kind = 0; kind < HK_MAX_KINDS; ++kind)
                 if (sc->kinds_mask & (1u << kind)) {
                     timed(2, [&] { hk::launch_shade(s, shade_blocks, kind, I->st, sc->d, c->tables, fr, sob, depth, first_kind, dstats); });

@@ -1284,4 +1284,369 @@ HKD float bvh_pmf(const DScene& sc, v3 p, v3 n, int light_1based, unsigned& visi
     return pm;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// participating media (integrators/volpath/media.jl, nanovdb.jl, delta-tracking.jl:18-58, intersection.jl:422-542)
+// ------------------------------------------------------------------------------------------------
+HKD float hg_p(float g, float ct) {  // media.jl:36-40
+    float g2 = g * g;
+    float denom = 1.0f + g2 - 2.0f * g * ct;
+    return (1.0f - g2) / (4.0f * PI_F * denom * sqrtf(denom));
+}
+HKD v3 sample_hg(float g, v3 wo, v2 u, float& pdf) {  // media.jl:51-72
+    float ct;
+    if (fabsf(g) < 1e-3f)
+        ct = 1.0f - 2.0f * u.x;
+    else {
+        float g2 = g * g;
+        float sq = (1.0f - g2) / (1.0f - g + 2.0f * g * u.x);
+        ct = clampf((1.0f + g2 - sq * sq) / (2.0f * g), -1.0f, 1.0f);
+    }
+    float st = sqrtf(maxf(0.0f, 1.0f - ct * ct));
+    float phi = 2.0f * PI_F * u.y;
+    v3 t1, t2;
+    coordinate_system(-wo, t1, t2);
+    v3 wi = st * cosf(phi) * t1 + st * sinf(phi) * t2 + ct * (-wo);
+    wi = normalize(wi);
+    pdf = hg_p(g, ct);
+    return wi;
+}
+HKD uint64_t lcg_init(v3 o, v3 d, float t_max) {
+    uint64_t ox = __float_as_uint(o.x), oy = __float_as_uint(o.y), oz = __float_as_uint(o.z), tm = __float_as_uint(t_max);
+    uint64_t dx = __float_as_uint(d.x), dy = __float_as_uint(d.y), dz = __float_as_uint(d.z);
+    return mix_bits(ox ^ (oy << 16) ^ (oz << 32) ^ tm) ^ mix_bits(dx ^ (dy << 16) ^ (dz << 32));
+}
+HKD float lcg_next(uint64_t& s) {
+    s = s * 0x5DEECE66Dull + 11ull;
+    float r = (float)(uint32_t)(s >> 32) * 2.3283064365386963e-10f;
+    const float lim = 1.0f - 1.1920929e-7f;
+    return r < lim ? r : lim;
+}
+HKD S4 s4max0(S4 a) { return s4(maxf(a.x, 0.0f), maxf(a.y, 0.0f), maxf(a.z, 0.0f), maxf(a.w, 0.0f)); }
+HKD S4 s4exp(S4 a) { return s4(expf(a.x), expf(a.y), expf(a.z), expf(a.w)); }
+
+struct MajorantIter {  // RayMajorantIterator (media.jl:517-560)
+    int mode;          // 0 exhausted, 1 homogeneous, 2 DDA
+    S4 sigma_t;
+    float t_min, t_max;
+    bool hom_called;
+    const float* grid;
+    int res[3];
+    float next_t[3], delta_t[3];
+    int step[3], limit[3], voxel[3];
+};
+HKD void ray_bounds_intersect(v3 o, v3 d, const float* bmin, const float* bmax, float& t_enter, float& t_exit) {  // media.jl:1698-1734
+    float te = -INF_F, tx = INF_F;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float dk = comp(d, k), ok = comp(o, k);
+        float inv = fabsf(dk) > 1e-10f ? 1.0f / dk : (dk >= 0 ? INF_F : -INF_F);
+        float t0 = (bmin[k] - ok) * inv, t1 = (bmax[k] - ok) * inv;
+        if (t0 > t1) {
+            float tmp = t0;
+            t0 = t1;
+            t1 = tmp;
+        }
+        te = k == 0 ? t0 : maxf(te, t0);
+        tx = k == 0 ? t1 : minf(tx, t1);
+    }
+    t_enter = te;
+    t_exit = tx;
+}
+HKD MajorantIter exhausted_iter() {
+    MajorantIter it;
+    it.mode = 0;
+    it.sigma_t = s4(0.0f);
+    it.t_min = INF_F;
+    it.t_max = -INF_F;
+    it.hom_called = true;
+    it.grid = nullptr;
+    return it;
+}
+HKD MajorantIter create_majorant_iterator(const DMedium& m, v3 ro, v3 rd, float t_max, S4 lambda) {
+    MajorantIter it = exhausted_iter();
+    S4 sigma_t = eval_scaled(m.sigma_a, lambda) + eval_scaled(m.sigma_s, lambda);
+    if (m.kind == HK_MEDIUM_HOMOGENEOUS) {
+        it.mode = (0.0f >= t_max) ? 0 : 1;
+        it.sigma_t = sigma_t;
+        it.t_min = 0.0f;
+        it.t_max = t_max;
+        it.hom_called = false;
+        return it;
+    }
+    v3 o = ro, d = rd;
+    if (m.kind == HK_MEDIUM_GRID) {
+        const float* M = m.r2m;
+        o = mk3(M[0] * ro.x + M[1] * ro.y + M[2] * ro.z + M[3], M[4] * ro.x + M[5] * ro.y + M[6] * ro.z + M[7], M[8] * ro.x + M[9] * ro.y + M[10] * ro.z + M[11]);
+        d = mk3(M[0] * rd.x + M[1] * rd.y + M[2] * rd.z, M[4] * rd.x + M[5] * rd.y + M[6] * rd.z, M[8] * rd.x + M[9] * rd.y + M[10] * rd.z);
+        if (d.x * d.x + d.y * d.y + d.z * d.z < 1e-20f) return it;
+    }
+    float t_enter, t_exit;
+    ray_bounds_intersect(o, d, m.bmin, m.bmax, t_enter, t_exit);
+    t_enter = maxf(t_enter, 0.0f);
+    t_exit = minf(t_exit, t_max);
+    if (t_enter >= t_exit) return it;
+    // create_dda_iterator (media.jl:229-340)
+    it.grid = m.majorant;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        int res = m.mres[k];
+        it.res[k] = res;
+        float diag = m.bmax[k] - m.bmin[k];
+        float go = (comp(o, k) - m.bmin[k]) / diag;
+        float inv_diag = fabsf(diag) > 1e-10f ? 1.0f / diag : 0.0f;
+        float gd = comp(d, k) * inv_diag;
+        float gi = go + gd * t_enter;
+        int v = clampi((int)floorf(gi * (float)res), 0, res - 1);
+        it.voxel[k] = v;
+        it.delta_t[k] = fabsf(gd) > 1e-10f ? 1.0f / (fabsf(gd) * (float)res) : INF_F;
+        if (gd >= 0.0f) {
+            float nvp = (float)(v + 1) / (float)res;
+            it.next_t[k] = gd > 1e-10f ? t_enter + (nvp - gi) / gd : INF_F;
+            it.step[k] = 1;
+            it.limit[k] = res;
+        } else {
+            float nvp = (float)v / (float)res;
+            it.next_t[k] = gd < -1e-10f ? t_enter + (nvp - gi) / gd : INF_F;
+            it.step[k] = -1;
+            it.limit[k] = -1;
+        }
+    }
+    it.sigma_t = sigma_t;
+    it.t_min = t_enter;
+    it.t_max = t_exit;
+    it.hom_called = false;
+    it.mode = 2;
+    return it;
+}
+HKD bool majorant_next(MajorantIter& it, float& seg_t_min, float& seg_t_max, S4& sigma_maj) {  // media.jl:625-729
+    if (it.mode == 0) return false;
+    if (it.mode == 1) {
+        if (it.hom_called || it.t_min >= it.t_max) {
+            it.mode = 0;
+            return false;
+        }
+        seg_t_min = it.t_min;
+        seg_t_max = it.t_max;
+        sigma_maj = it.sigma_t;
+        it.hom_called = true;
+        return true;
+    }
+    if (it.t_min >= it.t_max) {
+        it.mode = 0;
+        return false;
+    }
+    float tx = it.next_t[0], ty = it.next_t[1], tz = it.next_t[2];
+    int axis = (tx < ty) ? ((tx < tz) ? 0 : 2) : ((ty < tz) ? 1 : 2);
+    float nt = axis == 0 ? tx : (axis == 1 ? ty : tz);
+    float stm = minf(nt, it.t_max);
+    float rho = it.grid[it.voxel[0] + it.res[0] * (it.voxel[1] + it.res[1] * it.voxel[2])];
+    seg_t_min = it.t_min;
+    seg_t_max = stm;
+    sigma_maj = it.sigma_t * rho;
+    it.t_min = stm;
+    if (axis == 0) {
+        it.voxel[0] += it.step[0];
+        it.next_t[0] += it.delta_t[0];
+    } else if (axis == 1) {
+        it.voxel[1] += it.step[1];
+        it.next_t[1] += it.delta_t[1];
+    } else {
+        it.voxel[2] += it.step[2];
+        it.next_t[2] += it.delta_t[2];
+    }
+    if (it.voxel[0] == it.limit[0] || it.voxel[1] == it.limit[1] || it.voxel[2] == it.limit[2]) {
+        it.mode = 0;
+        it.t_min = it.t_max;
+    }
+    return true;
+}
+
+// NanoVDB tree walk (nanovdb.jl:315-388).  Offsets are 1-based byte positions like the reference's fields.
+HKD float nv_f32(const unsigned char* b, long long off1) { return *reinterpret_cast<const float*>(b + (((off1 - 1) >> 2) << 2)); }
+HKD long long nv_i64(const unsigned char* b, long long off1) { return *reinterpret_cast<const long long*>(b + (((off1 - 1) >> 3) << 3)); }
+HKD bool nv_mask(const unsigned char* b, long long mask_off1, int n) { return ((b[mask_off1 - 1 + (n >> 3)] >> (n & 7)) & 1) != 0; }
+// Result of walking down to the 8^3 block that contains (x,y,z): either a leaf (values at leaf_off) or a constant.
+struct NvBlock {
+    int kx, ky, kz;      // block coordinates (x>>3, y>>3, z>>3) this entry is valid for
+    long long leaf_off;  // 1-based offset of the leaf node, 0 => constant `value` for the whole block
+    float value;
+    bool valid;
+};
+HKD NvBlock nv_find_block(const DMedium& m, int x, int y, int z) {
+    const unsigned char* b = m.nvdb;
+    NvBlock r;
+    r.kx = x >> 3;
+    r.ky = y >> 3;
+    r.kz = z >> 3;
+    r.leaf_off = 0;
+    r.valid = true;
+    unsigned xu = (unsigned)x, yu = (unsigned)y, zu = (unsigned)z;
+    unsigned long long key = (unsigned long long)((zu >> 12) & 0x1fffff) | ((unsigned long long)((yu >> 12) & 0x1fffff) << 21) | ((unsigned long long)((xu >> 12) & 0x1fffff) << 42);
+    long long root = m.root_off, tile = 0;
+    bool found = false;
+    for (int i = 0; i < m.root_table_size; ++i) {
+        long long t_off = root + 64 + (long long)i * 32;
+        if ((unsigned long long)nv_i64(b, t_off) == key) {
+            found = true;
+            tile = t_off;
+            break;
+        }
+    }
+    if (!found) {
+        r.value = nv_f32(b, root + 28);
+        return r;
+    }
+    long long child = nv_i64(b, tile + 8);
+    if (child == 0) {
+        r.value = nv_f32(b, tile + 20);
+        return r;
+    }
+    long long upper = root + child;
+    int n_upper = (int)(((xu >> 7) & 31) << 10) | (int)(((yu >> 7) & 31) << 5) | (int)((zu >> 7) & 31);
+    if (!nv_mask(b, upper + 4128, n_upper)) {
+        r.value = nv_f32(b, upper + 8256 + (long long)n_upper * 8);
+        return r;
+    }
+    long long lower = upper + nv_i64(b, upper + 8256 + (long long)n_upper * 8);
+    int n_lower = (int)(((xu >> 3) & 15) << 8) | (int)(((yu >> 3) & 15) << 4) | (int)((zu >> 3) & 15);
+    if (!nv_mask(b, lower + 544, n_lower)) {
+        r.value = nv_f32(b, lower + 1088 + (long long)n_lower * 8);
+        return r;
+    }
+    r.leaf_off = lower + nv_i64(b, lower + 1088 + (long long)n_lower * 8);
+    r.value = 0.0f;
+    return r;
+}
+// the 8 trilinear taps touch at most 8 blocks but almost always 1-2: the last block is cached per lane so the
+// 4-level pointer chase (>= 4 dependent loads) is paid once per distinct block, not once per tap
+HKD float nv_value(const DMedium& m, NvBlock& cache, int x, int y, int z) {
+    if (!(cache.valid && cache.kx == (x >> 3) && cache.ky == (y >> 3) && cache.kz == (z >> 3))) cache = nv_find_block(m, x, y, z);
+    if (cache.leaf_off == 0) return cache.value;
+    int n_leaf = ((x & 7) << 6) | ((y & 7) << 3) | (z & 7);
+    return nv_f32(m.nvdb, cache.leaf_off + 96 + (long long)n_leaf * 4);
+}
+HKD float sample_nanovdb_density(const DMedium& m, v3 p) {  // nanovdb.jl:400-469
+    float px = p.x - m.vec[0], py = p.y - m.vec[1], pz = p.z - m.vec[2];
+    float fxi = m.inv_mat[0] * px + m.inv_mat[1] * py + m.inv_mat[2] * pz;
+    float fyi = m.inv_mat[3] * px + m.inv_mat[4] * py + m.inv_mat[5] * pz;
+    float fzi = m.inv_mat[6] * px + m.inv_mat[7] * py + m.inv_mat[8] * pz;
+    float flx = floorf(fxi), fly = floorf(fyi), flz = floorf(fzi);
+    int ix = (int)flx, iy = (int)fly, iz = (int)flz;
+    float fx = fxi - (float)ix, fy = fyi - (float)iy, fz = fzi - (float)iz;
+    NvBlock c;
+    c.valid = false;
+    float v000 = nv_value(m, c, ix, iy, iz), v001 = nv_value(m, c, ix, iy, iz + 1);
+    float v010 = nv_value(m, c, ix, iy + 1, iz), v011 = nv_value(m, c, ix, iy + 1, iz + 1);
+    float v100 = nv_value(m, c, ix + 1, iy, iz), v101 = nv_value(m, c, ix + 1, iy, iz + 1);
+    float v110 = nv_value(m, c, ix + 1, iy + 1, iz), v111 = nv_value(m, c, ix + 1, iy + 1, iz + 1);
+    float fx1 = 1.0f - fx, fy1 = 1.0f - fy, fz1 = 1.0f - fz;
+    float v00 = v000 * fz1 + v001 * fz, v01 = v010 * fz1 + v011 * fz;
+    float v10 = v100 * fz1 + v101 * fz, v11 = v110 * fz1 + v111 * fz;
+    float v0 = v00 * fy1 + v01 * fy, v1 = v10 * fy1 + v11 * fy;
+    return v0 * fx1 + v1 * fx;
+}
+HKD float sample_grid_density(const DMedium& m, v3 pm) {  // media.jl:1527-1575
+    float pn0 = (pm.x - m.bmin[0]) / (m.bmax[0] - m.bmin[0]), pn1 = (pm.y - m.bmin[1]) / (m.bmax[1] - m.bmin[1]), pn2 = (pm.z - m.bmin[2]) / (m.bmax[2] - m.bmin[2]);
+    if (pn0 < 0.0f || pn1 < 0.0f || pn2 < 0.0f || pn0 > 1.0f || pn1 > 1.0f || pn2 > 1.0f) return 0.0f;
+    int nx = m.res[0], ny = m.res[1], nz = m.res[2];
+    float gx = pn0 * (float)nx + 0.5f, gy = pn1 * (float)ny + 0.5f, gz = pn2 * (float)nz + 0.5f;
+    int ix = clampi((int)floorf(gx), 1, nx - 1), iy = clampi((int)floorf(gy), 1, ny - 1), iz = clampi((int)floorf(gz), 1, nz - 1);
+    float fx = clampf(gx - (float)ix, 0.0f, 1.0f), fy = clampf(gy - (float)iy, 0.0f, 1.0f), fz = clampf(gz - (float)iz, 0.0f, 1.0f);
+    const float* D = m.density;
+    size_t sx = 1, sy = (size_t)nx, sz = (size_t)nx * ny;
+    size_t base = (size_t)(ix - 1) + sy * (size_t)(iy - 1) + sz * (size_t)(iz - 1);
+    float d000 = D[base], d100 = D[base + sx], d010 = D[base + sy], d110 = D[base + sx + sy];
+    float d001 = D[base + sz], d101 = D[base + sx + sz], d011 = D[base + sy + sz], d111 = D[base + sx + sy + sz];
+    float fx1 = 1.0f - fx;
+    float d00 = d000 * fx1 + d100 * fx, d10 = d010 * fx1 + d110 * fx, d01 = d001 * fx1 + d101 * fx, d11 = d011 * fx1 + d111 * fx;
+    float fy1 = 1.0f - fy;
+    float d0 = d00 * fy1 + d10 * fy, d1 = d01 * fy1 + d11 * fy;
+    return d0 * (1.0f - fz) + d1 * fz;
+}
+struct MediumProps {
+    S4 sigma_a, sigma_s, Le;
+    float g;
+};
+// sigma_a/sigma_s spectra are constant per medium and wavelength set: callers evaluate them once per ray
+// (`base_*`) and sample_point only fetches the density (same arithmetic: uplift * d)
+HKD MediumProps sample_point(const DMedium& m, S4 base_a, S4 base_s, S4 base_Le, v3 p) {
+    MediumProps mp;
+    mp.g = m.g;
+    if (m.kind == HK_MEDIUM_HOMOGENEOUS) {
+        mp.sigma_a = base_a;
+        mp.sigma_s = base_s;
+        mp.Le = base_Le;
+        return mp;
+    }
+    float d;
+    if (m.kind == HK_MEDIUM_GRID) {
+        const float* M = m.r2m;
+        d = sample_grid_density(m, mk3(M[0] * p.x + M[1] * p.y + M[2] * p.z + M[3], M[4] * p.x + M[5] * p.y + M[6] * p.z + M[7], M[8] * p.x + M[9] * p.y + M[10] * p.z + M[11]));
+    } else
+        d = sample_nanovdb_density(m, p);
+    mp.sigma_a = base_a * d;
+    mp.sigma_s = base_s * d;
+    mp.Le = s4(0.0f);
+    return mp;
+}
+// compute_transmittance_ratio_tracking (intersection.jl:422-542)
+HKD void ratio_tracking(const DMedium& m, v3 origin, v3 dir, float t_max, S4 lambda, S4& T_ray, S4& r_u, S4& r_l, unsigned& collisions) {
+    T_ray = s4(1.0f);
+    r_u = s4(1.0f);
+    r_l = s4(1.0f);
+    S4 base_a = eval_scaled(m.sigma_a, lambda), base_s = eval_scaled(m.sigma_s, lambda), base_Le = eval_scaled(m.Le, lambda);
+    MajorantIter it = create_majorant_iterator(m, origin, dir, t_max, lambda);
+    PCG32 rng = pcg32_init(pbrt_hash(origin), pbrt_hash(dir));
+    for (int s = 0; s < 256; ++s) {
+        float seg0, seg1;
+        S4 sm;
+        if (!majorant_next(it, seg0, seg1, sm)) break;
+        float sm0 = sm.x;
+        if (sm0 < 1e-10f) continue;
+        float t = seg0;
+        for (int k = 0; k < 100; ++k) {
+            float u = pcg32_f32(rng);
+            float dt = -logf(maxf(1e-10f, 1.0f - u)) / sm0;
+            float ts = t + dt;
+            if (ts >= seg1) {
+                float dr = seg1 - t;
+                S4 Tm = s4exp((-dr) * sm);
+                float T0 = Tm.x;
+                if (T0 > 1e-10f) {
+                    T_ray = T_ray * Tm / T0;
+                    r_l = r_l * Tm / T0;
+                    r_u = r_u * Tm / T0;
+                }
+                break;
+            }
+            ++collisions;
+            MediumProps mp = sample_point(m, base_a, base_s, base_Le, origin + dir * ts);
+            S4 sn = s4max0(sm - mp.sigma_a - mp.sigma_s);
+            S4 Tm = s4exp((-dt) * sm);
+            float pr = Tm.x * sm0;
+            if (pr > 1e-10f) {
+                T_ray = T_ray * Tm * sn / pr;
+                r_l = r_l * Tm * sm / pr;
+                r_u = r_u * Tm * sn / pr;
+            } else {
+                T_ray = s4(0.0f);
+                return;
+            }
+            S4 est = T_ray / maxf(1e-10f, average(r_l + r_u));
+            if (max_component(est) < 0.05f) {
+                float rr = pcg32_f32(rng);
+                if (rr < 0.75f) {
+                    T_ray = s4(0.0f);
+                    return;
+                }
+                T_ray = T_ray / (1.0f - 0.75f);
+            }
+            if (is_black(T_ray)) return;
+            t = ts;
+        }
+        if (is_black(T_ray)) break;
+    }
+}
+
 }  // namespace hkd

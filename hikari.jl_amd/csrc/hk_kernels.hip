@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(256) k_camera(DPathState st, DFrame fr, DTable
             st4(&st.r_l[slot], s4(1.0f));
             st4(&st.L[slot], s4(0.0f));
             st.filter_w[slot] = fw;
-            st.flags[slot] = (uint32_t)(initial_medium + 1) << 16;
+            st.flags[slot] = (uint32_t)(*st.initial_medium + 1) << 16;
         }
         wq_push(out, (uint32_t)slot, active);
     }
@@ -131,6 +131,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace(DPathState st, DScene 
     const uint32_t* __restrict__ queue = st.ray_q[depth & 1] + (size_t)gw * st.wave_cap;
     const int n = *count_ptr(st, depth, Q_RAY, gw);
     WaveQ q_escaped = wq_open(st.escaped_q, st, gw);
+    WaveQ q_medium = wq_open(st.medium_q, st, gw);
     int kind_count[HK_MAX_KINDS];
 #pragma unroll
     for (int k = 0; k < HK_MAX_KINDS; ++k) kind_count[k] = 0;
@@ -139,7 +140,24 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace(DPathState st, DScene 
         bool active = i < n;
         uint32_t slot = active ? queue[i] : 0u;
         int kind = -1;  // -1 none, -2 escaped, >= 0 material kind
-        if (active) {
+        bool in_medium = false;
+        if (active && sc.n_media > 0 && (st.flags[slot] >> 16) != 0u) {
+            // ray travels inside a medium: one cast (no alpha test, intersection.jl:198-221), then delta tracking
+            // (k_medium) decides whether the stored surface hit is ever reached
+            in_medium = true;
+            float4 O = st.ray_o[slot], D = st.ray_d[slot];
+            bool dummy;
+            ++n_casts;
+            HitRec h = traverse<0, COUNT>(sc, mk3(O.x, O.y, O.z), mk3(D.x, D.y, D.z), O.w, stack, lane, n_nodes, n_tris, dummy);
+            if (h.prim >= 0) {
+                ++n_hits;
+                st.hit[slot] = make_float4(h.t, __int_as_float(h.prim), h.u, h.v);
+                st.mat_id[slot] = sc.mis[sc.meta[h.prim].mi].material;
+            } else
+                st.hit[slot] = make_float4(INF_F, __int_as_float(-1), 0.0f, 0.0f);
+        }
+        wq_push(q_medium, slot, in_medium);
+        if (active && !in_medium) {
             float4 O = st.ray_o[slot], D = st.ray_d[slot];
             v3 ro = mk3(O.x, O.y, O.z), rd = mk3(D.x, D.y, D.z);
             float tmax = O.w;
@@ -203,6 +221,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace(DPathState st, DScene 
         }
     }
     wq_close(q_escaped, count_ptr(st, depth, Q_ESCAPED, gw));
+    wq_close(q_medium, count_ptr(st, depth, Q_MEDIUM, gw));
     if (lane == 0) {
 #pragma unroll
         for (int k = 0; k < HK_MAX_KINDS; ++k) *count_ptr(st, depth, Q_MAT0 + k, gw) = kind_count[k];
@@ -215,6 +234,246 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace(DPathState st, DScene 
         wave_add(&stats->nodes, n_nodes);
         wave_add(&stats->tris, n_tris);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K4 + K5 + K6 fused: delta tracking with null collisions (delta-tracking.jl:79-453), direct lighting at the
+// scattering vertex (medium-scatter.jl:15-138) and phase-function sampling (medium-scatter.jl:148-216).
+// Runs after k_trace: paths that survive to their stored surface hit are appended to the material-kind
+// queues (Mix resolved here), paths that leave the scene to the escaped queue.
+// ---------------------------------------------------------------------------------------------------
+template <bool COUNT>
+__global__ void __launch_bounds__(256) k_medium(DPathState st, DScene sc, DTables T, DFrame fr, DSobol sob, int depth, DStats* stats) {
+    const int lane = lane_id();
+    unsigned n_coll = 0, n_lnodes = 0;
+    HK_FOR_EACH_WAVE_SEGMENT(gw, st) {
+        const uint32_t* __restrict__ queue = st.medium_q + (size_t)gw * st.wave_cap;
+        const int n = *count_ptr(st, depth, Q_MEDIUM, gw);
+        WaveQ q_escaped = wq_open(st.escaped_q, st, gw);
+        q_escaped.count = *count_ptr(st, depth, Q_ESCAPED, gw);
+        WaveQ q_shadow = wq_open(st.shadow_q, st, gw);            // first writer of this depth's shadow / next-ray segments
+        WaveQ q_next = wq_open(st.ray_q[(depth + 1) & 1], st, gw);
+        int kind_count[HK_MAX_KINDS];
+#pragma unroll
+        for (int k = 0; k < HK_MAX_KINDS; ++k) kind_count[k] = *count_ptr(st, depth, Q_MAT0 + k, gw);
+        for (int base = 0; base < n; base += 64) {
+            int i = base + lane;
+            bool active = i < n;
+            uint32_t slot = active ? queue[i] : 0u;
+            int kind = -1;  // -1 terminated, -2 escaped, >= 0 reached its surface hit of that material kind
+            bool push_shadow = false, push_ray = false;
+            if (active) {
+                float4 O = st.ray_o[slot], D = st.ray_d[slot], H = st.hit[slot];
+                v3 ro = mk3(O.x, O.y, O.z), rd = mk3(D.x, D.y, D.z);
+                const float t_max = H.x;
+                const int prim = __float_as_int(H.y);
+                uint32_t fl = st.flags[slot];
+                const int medium_idx = (int)(fl >> 16) - 1;
+                const DMedium& med = sc.media[medium_idx];
+                S4 lambda = ld4(&st.lambda[slot]);
+                S4 beta = ld4(&st.beta[slot]), r_u = ld4(&st.r_u[slot]), r_l = ld4(&st.r_l[slot]);
+                S4 base_a = eval_scaled(med.sigma_a, lambda), base_s = eval_scaled(med.sigma_s, lambda), base_Le = eval_scaled(med.Le, lambda);
+                uint64_t rng = lcg_init(ro, rd, t_max);
+                MajorantIter it = create_majorant_iterator(med, ro, rd, t_max, lambda);
+                bool done = false, scattered = false;
+                v3 sp = mk3(0, 0, 0);
+                float sg = 0.0f;
+                for (int segi = 0; segi < 256 && !done; ++segi) {
+                    float seg0, seg1;
+                    S4 sm;
+                    if (!majorant_next(it, seg0, seg1, sm)) break;
+                    float sm0 = sm.x;
+                    if (sm0 < 1e-10f) continue;
+                    float t = seg0;
+                    v3 cur_o = ro + rd * t;
+                    for (int k = 0; k < 1024; ++k) {
+                        float u = lcg_next(rng);
+                        float dt = -logf(maxf(1e-10f, 1.0f - u)) / sm0;
+                        float ts = t + dt;
+                        if (ts >= seg1) {
+                            float dr = seg1 - t;
+                            S4 Tm = s4exp((-dr) * sm);
+                            float T0 = Tm.x;
+                            if (T0 > 1e-10f) {
+                                beta = beta * Tm / T0;
+                                r_u = r_u * Tm / T0;
+                                r_l = r_l * Tm / T0;
+                            }
+                            break;
+                        }
+                        S4 Tm = s4exp((-dt) * sm);
+                        v3 p = cur_o + rd * dt;
+                        ++n_coll;
+                        MediumProps mp = sample_point(med, base_a, base_s, base_Le, p);
+                        if (!is_black(mp.Le) && depth < fr.max_depth) {
+                            float pr = sm0 * Tm.x;
+                            if (pr > 1e-10f) {
+                                S4 r_e = r_u * sm * Tm / pr;
+                                if (!is_black(r_e)) st4(&st.L[slot], ld4(&st.L[slot]) + beta * mp.sigma_a * Tm * mp.Le / (pr * average(r_e)));
+                            }
+                        }
+                        float p_absorb = mp.sigma_a.x / sm0, p_scatter = mp.sigma_s.x / sm0;
+                        float ue = lcg_next(rng);
+                        if (ue < p_absorb) {
+                            done = true;
+                            break;
+                        } else if (ue < p_absorb + p_scatter) {
+                            done = true;
+                            if (depth >= fr.max_depth) break;
+                            float pdf = Tm.x * mp.sigma_s.x;
+                            if (pdf > 1e-10f) {
+                                beta = beta * Tm * mp.sigma_s / pdf;
+                                r_u = r_u * Tm * mp.sigma_s / pdf;
+                            }
+                            scattered = true;
+                            sp = p;
+                            sg = mp.g;
+                            break;
+                        } else {
+                            S4 sn = s4max0(sm - mp.sigma_a - mp.sigma_s);
+                            float pdf = Tm.x * sn.x;
+                            if (pdf > 1e-10f) {
+                                beta = beta * Tm * sn / pdf;
+                                r_u = r_u * Tm * sn / pdf;
+                                r_l = r_l * Tm * sm / pdf;
+                            } else {
+                                done = true;
+                                break;
+                            }
+                            t = ts;
+                            cur_o = p;
+                            if (is_black(beta) || is_black(r_u)) {
+                                done = true;
+                                break;
+                            }
+                        }
+                    }
+                }
+                if (scattered) {
+                    v3 wo = -rd;
+                    int k = (int)slot / fr.n_pixels_padded;
+                    int px, py;
+                    bool inside;
+                    slot_to_pixel(fr, (int)slot - k * fr.n_pixels_padded, px, py, inside);
+                    SobolCtx sctx = sobol_ctx(sob, T.sobol, px + 1, py + 1, fr.first_sample + k * fr.sample_stride);
+                    const int base_dim = 6 + 7 * depth;
+                    // ---- K5: light-BVH NEE with n = 0, HG evaluated with cos = wo.wi (medium-scatter.jl:46-49) ----
+                    if (sc.n_lights > 0) {
+                        float light_select = sobol_1d(sctx, base_dim + 1);
+                        float light_pmf;
+                        int light_idx = bvh_sample_light(sc, sp, mk3(0, 0, 0), light_select, light_pmf, n_lnodes);
+                        if (light_idx >= 1 && light_idx <= sc.n_lights && light_pmf > 0.0f) {
+                            const DLight& sel = sc.lights[light_idx - 1];
+                            v2 u_light = mk2(0.0f, 0.0f);
+                            if (sel.kind >= HK_LIGHT_AMBIENT) u_light = sobol_2d(sctx, base_dim + 3);
+                            LightSample ls = sample_light(sc, T, sel, sp, lambda, u_light);
+                            if (ls.pdf > 0.0f && !is_black(ls.Li)) {
+                                float phase_val = hg_p(sg, dot(wo, ls.wi));
+                                if (phase_val > 0.0f) {
+                                    float light_pdf = ls.pdf * light_pmf;
+                                    float phase_pdf = ls.is_delta ? 0.0f : phase_val;
+                                    float tmx = ls.is_delta ? norm(ls.p_light - sp) - 0.001f : 1.0e6f;
+                                    st.sh_o[slot] = make_float4(sp.x, sp.y, sp.z, tmx);
+                                    st.sh_d[slot] = make_float4(ls.wi.x, ls.wi.y, ls.wi.z, __int_as_float(medium_idx));
+                                    st4(&st.sh_Ld[slot], beta * phase_val * ls.Li);
+                                    st4(&st.sh_ru[slot], r_u * phase_pdf);
+                                    st4(&st.sh_rl[slot], r_u * light_pdf);
+                                    push_shadow = true;
+                                }
+                            }
+                        }
+                    }
+                    // ---- K6: sample the phase function, continue in the same medium ----
+                    int new_depth = depth + 1;
+                    if (new_depth < fr.max_depth) {
+                        v2 u = sobol_2d(sctx, base_dim + 6);
+                        float ppdf;
+                        v3 wi = sample_hg(sg, wo, u, ppdf);
+                        if (ppdf > 0.0f) {
+                            st.ray_o[slot] = make_float4(sp.x, sp.y, sp.z, INF_F);
+                            st.ray_d[slot] = make_float4(wi.x, wi.y, wi.z, D.w);
+                            st4(&st.beta[slot], beta);
+                            st4(&st.r_u[slot], r_u);
+                            st4(&st.r_l[slot], r_u / ppdf);
+                            st.flags[slot] = (uint32_t)new_depth | (1u << 9) | ((uint32_t)(medium_idx + 1) << 16);  // specular = false, any_non_specular = true
+                            push_ray = true;
+                        }
+                    }
+                } else if (!done && !(is_black(beta) || is_black(r_u) || depth >= fr.max_depth)) {
+                    // survived to t_max: hand the stored surface hit / the escape over with the updated throughput
+                    st4(&st.beta[slot], beta);
+                    st4(&st.r_u[slot], r_u);
+                    st4(&st.r_l[slot], r_l);
+                    if (prim < 0)
+                        kind = -2;
+                    else {
+                        int mat = st.mat_id[slot];
+                        if (sc.materials[mat].kind == HK_MAT_MIX) {
+                            float w = 1.0f - H.z - H.w;
+                            mat = resolve_mix_material(sc, mat, ro + rd * t_max, -rd, uv_at(sc, prim, w, H.z, H.w));
+                            st.mat_id[slot] = mat;
+                        }
+                        kind = sc.materials[mat].kind;
+                        if (kind == HK_MAT_MIX) kind = HK_MAT_FALLBACK;
+                    }
+                }
+            }
+            wq_push(q_shadow, slot, push_shadow);
+            wq_push(q_next, slot, push_ray);
+            wq_push(q_escaped, slot, kind == -2);
+            unsigned long long pending = __ballot(kind >= 0);
+            while (pending) {
+                int src = __ffsll((long long)pending) - 1;
+                int k = __shfl(kind, src);
+                bool mine = kind == k;
+                unsigned long long m = __ballot(mine);
+                int cnt = 0;
+#pragma unroll
+                for (int kk = 0; kk < HK_MAX_KINDS; ++kk) cnt = (kk == k) ? kind_count[kk] : cnt;
+                if (mine) st.mat_q[((size_t)k * st.n_waves + gw) * st.wave_cap + cnt + __popcll(m & ((1ull << lane) - 1ull))] = slot;
+                int add = __popcll(m);
+#pragma unroll
+                for (int kk = 0; kk < HK_MAX_KINDS; ++kk) kind_count[kk] += (kk == k) ? add : 0;
+                pending &= ~m;
+            }
+        }
+        wq_close(q_shadow, count_ptr(st, depth, Q_SHADOW, gw));
+        wq_close(q_next, count_ptr(st, depth + 1, Q_RAY, gw));
+        wq_close(q_escaped, count_ptr(st, depth, Q_ESCAPED, gw));
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < HK_MAX_KINDS; ++k) *count_ptr(st, depth, Q_MAT0 + k, gw) = kind_count[k];
+        }
+    }
+    stats += global_wave();
+    wave_add(&stats->collisions, n_coll);
+    wave_add(&stats->light_nodes, n_lnodes);
+}
+
+// K14: which medium is the camera in?  (intersection.jl:690-747)  One lane, result stays on the device.
+__global__ void __launch_bounds__(64) k_detect_camera_medium(DPathState st, DScene sc, float cx, float cy, float cz, DStats* stats) {
+    __shared__ int lds_stack[HK_LDS_STACK * 64];
+    if (threadIdx.x != 0) return;
+    v3 d = mk3(0.57735027f, 0.57735027f, 0.57735027f);
+    v3 o = mk3(cx, cy, cz);
+    int result = -1;
+    unsigned a = 0, b = 0, casts = 0;
+    for (int it = 0; it < 16; ++it) {
+        bool dummy;
+        ++casts;
+        HitRec h = traverse<0, false>(sc, o, d, INF_F, lds_stack, 0, a, b, dummy);
+        if (h.prim < 0) break;
+        DMediumInterface mi = sc.mis[sc.meta[h.prim].mi];
+        v3 n = geometric_normal(sc, h.prim);
+        if (mi.inside != mi.outside) {
+            result = dot(-d, n) > 0.0f ? mi.outside : mi.inside;
+            break;
+        }
+        v3 off = dot(d, n) > 0.0f ? n : -n;
+        o = (o + d * h.t) + off * 1e-4f;
+    }
+    *st.initial_medium = result;
+    stats->rays_closest += casts;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -423,7 +682,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_shadow(DPathState st, DScene
     __shared__ int lds_stack[(HK_TRACE_BLOCK / 64) * HK_LDS_STACK * 64];
     int* stack = lds_stack + (threadIdx.x >> 6) * (HK_LDS_STACK * 64);
     const int lane = lane_id();
-    unsigned n_nodes = 0, n_tris = 0, n_casts = 0, n_hits = 0;
+    unsigned n_nodes = 0, n_tris = 0, n_casts = 0, n_hits = 0, n_coll = 0;
     HK_FOR_EACH_WAVE_SEGMENT(gw, st) {
     const uint32_t* __restrict__ queue = st.shadow_q + (size_t)gw * st.wave_cap;
     const int n = *count_ptr(st, depth, Q_SHADOW, gw);
@@ -436,6 +695,8 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_shadow(DPathState st, DScene
         float t_remaining = O.w;
         int medium = __float_as_int(D.w);
         S4 T_ray = s4(1.0f), tr_u = s4(1.0f), tr_l = s4(1.0f);
+        S4 lambda = s4(0.0f);
+        if (sc.n_media > 0) lambda = ld4(&st.lambda[slot]);
         bool visible = false, done = false;
         for (int seg = 0; seg < 10 && !done; ++seg) {
             if (t_remaining < 1e-6f) break;
@@ -443,7 +704,14 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_shadow(DPathState st, DScene
             ++n_casts;
             HitRec h = traverse<1, COUNT>(sc, ro, dir, t_remaining, stack, lane, n_nodes, n_tris, opaque);
             if (h.prim < 0) {
-                visible = true;  // (medium transmittance for the remaining distance lands with the media rows)
+                if (medium >= 0) {  // transmittance of the remaining distance (intersection.jl:326-336)
+                    S4 sT, su, sl;
+                    ratio_tracking(sc.media[medium], ro, dir, t_remaining, lambda, sT, su, sl, n_coll);
+                    T_ray = T_ray * sT;
+                    tr_u = tr_u * su;
+                    tr_l = tr_l * sl;
+                }
+                visible = true;
                 done = true;
                 break;
             }
@@ -468,7 +736,20 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_shadow(DPathState st, DScene
                     done = true;
                     break;
                 }
-            } else {
+            }
+            if (medium >= 0) {  // transmittance up to this surface
+                S4 sT, su, sl;
+                ratio_tracking(sc.media[medium], ro, dir, h.t, lambda, sT, su, sl, n_coll);
+                T_ray = T_ray * sT;
+                tr_u = tr_u * su;
+                tr_l = tr_l * sl;
+            }
+            if (mi.inside != mi.outside) {
+                if (is_black(T_ray)) {
+                    visible = true;
+                    done = true;
+                    break;
+                }
                 medium = entering ? mi.inside : mi.outside;
             }
             ro = ro + dir * (h.t + 1e-4f);
@@ -486,6 +767,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_shadow(DPathState st, DScene
     }
     }
     stats += global_wave();
+    wave_add(&stats->collisions, n_coll);
     wave_add(&stats->rays_shadow, n_casts);
     wave_add(&stats->hits, n_hits);
     if (COUNT) {
@@ -662,6 +944,13 @@ void launch_shadow(hipStream_t s, int n_cu, const DPathState& st, const DScene& 
         hipLaunchKernelGGL(k_shadow<true>, dim3(clamp_blocks(b1, st)), dim3(HK_TRACE_BLOCK), 0, s, st, sc, T, depth, stats);
     else
         hipLaunchKernelGGL(k_shadow<false>, dim3(clamp_blocks(b0, st)), dim3(HK_TRACE_BLOCK), 0, s, st, sc, T, depth, stats);
+}
+void launch_medium(hipStream_t s, int n_cu, const DPathState& st, const DScene& sc, const DTables& T, const DFrame& fr, const DSobol& sob, int depth, DStats* stats) {
+    static int blocks = resident_blocks(k_medium<false>, 256, n_cu, 8);
+    hipLaunchKernelGGL(k_medium<false>, dim3(clamp_blocks(blocks, st)), dim3(256), 0, s, st, sc, T, fr, sob, depth, stats);
+}
+void launch_detect_camera_medium(hipStream_t s, const DPathState& st, const DScene& sc, float x, float y, float z, DStats* stats) {
+    hipLaunchKernelGGL(k_detect_camera_medium, dim3(1), dim3(64), 0, s, st, sc, x, y, z, stats);
 }
 void launch_escaped(hipStream_t s, int n_cu, const DPathState& st, const DScene& sc, const DTables& T, int depth) {
     static int blocks = resident_blocks(k_escaped, 256, n_cu, 8);

@@ -80,6 +80,22 @@ struct DLightNode {  // 64 B
     uint32_t pad[2];
 };
 
+struct DMedium {
+    int kind;
+    float g;
+    float4 sigma_a, sigma_s, Le;   // baked uplift_rgb_unbounded coefficients (c0,c1,c2,scale)
+    float bmin[3], bmax[3];
+    float r2m[12];                 // render_to_medium rows 0..2 (affine)
+    int res[3];
+    const float* density;          // Grid: [nx,ny,nz] x fastest
+    int mres[3];
+    const float* majorant;         // x + rx*(y + ry*z)
+    const unsigned char* nvdb;     // NanoVDB bytes (tree part)
+    long long root_off;            // 1-based like the reference
+    int root_table_size;
+    float inv_mat[9], vec[3];
+};
+
 struct DMediumInterface {
     int material, inside, outside, pad;
 };
@@ -109,6 +125,8 @@ struct DScene {
     const uint32_t* bit_trails;
     const int* infinite_lights;
     int num_bvh_lights, num_infinite_lights;
+    const DMedium* media;
+    int n_media;
     int has_escape_lights;      // any ambient / environment light
     int all_opaque;             // no medium transitions and no alpha-tested surfaces
 };
@@ -146,7 +164,7 @@ struct DSobol {
 };
 
 // queue ids inside one depth's counter block
-enum { Q_RAY = 0, Q_SHADOW = 1, Q_ESCAPED = 2, Q_MAT0 = 3, Q_COUNT = Q_MAT0 + HK_MAX_KINDS };
+enum { Q_RAY = 0, Q_SHADOW = 1, Q_ESCAPED = 2, Q_MEDIUM = 3, Q_MAT0 = 4, Q_COUNT = Q_MAT0 + HK_MAX_KINDS };
 
 struct DPathState {
     int capacity;          // path slots
@@ -172,6 +190,8 @@ struct DPathState {
     uint32_t* ray_q[2];    // ping-pong ray queues (path slots)
     uint32_t* shadow_q;
     uint32_t* escaped_q;
+    uint32_t* medium_q;    // rays that travel inside a medium (delta tracking before their surface hit is processed)
+    int* initial_medium;   // camera medium detected on the device (K14)
     uint32_t* mat_q;       // HK_MAX_KINDS * W * wave_cap
     int* counters;         // [(max_depth + 2) * Q_COUNT][W] per-wave queue sizes
 };

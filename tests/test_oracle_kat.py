@@ -289,3 +289,40 @@ def test_integration_envelope(hk, oracle):
     x = img * 1.0
     aces = np.clip((x * (2.51 * x + 0.03)) / (x * (2.43 * x + 0.59) + 0.14), 0, 1) ** (1 / 2.2)
     assert 0.001 < aces.mean() < 10
+
+
+def test_homogeneous_slab_transmittance_closed_form(hk, oracle):
+    """purely absorbing slab seen against an emitter: pixel ratio == exp(-sigma_a * d); the same
+    constant density stored as GridMedium and as a NanoVDB tree must give the same attenuation."""
+    from hikari_jl_amd import scenes
+    p = hk.integrator_params(max_depth=6, samples=64, max_component_value=1e9)
+    s0, _, c0 = scenes.slab_scene(16, 16, None)
+    a0, _ = oracle.OracleScene(s0).render(p, c0, 16, 16, 64)
+    base = oracle.finalize(a0, 16, 16).mean()
+    R = hk.RGBSpectrum
+    bounds = ((-2.5, -2.6, 1.0), (2.5, 2.6, 2.0))
+    cases = [(hk.HomogeneousMedium(sigma_a=R(1.0), sigma_s=R(0.0)), np.exp(-1.0)),
+             (hk.HomogeneousMedium(sigma_a=R(0.5), sigma_s=R(0.0)), np.exp(-0.5)),
+             (hk.GridMedium(np.full((8, 8, 8), 0.7, np.float32), sigma_a=R(1.0), sigma_s=R(0.0), bounds=bounds), np.exp(-0.7)),
+             (hk.NanoVDBMedium(np.full((16, 16, 16), 0.7, np.float32), bounds=bounds, sigma_a=R(1.0), sigma_s=R(0.0), majorant_res=(8, 8, 8)), np.exp(-0.7))]
+    for med, expected in cases:
+        s1, _, c1 = scenes.slab_scene(16, 16, med)
+        a1, st = oracle.OracleScene(s1).render(p, c1, 16, 16, 64)
+        ratio = oracle.finalize(a1, 16, 16).mean() / base
+        assert abs(ratio - expected) < 0.02 * expected + 0.004, (type(med).__name__, ratio, expected)
+        assert st.medium_collisions > 0
+
+
+def test_nanovdb_tree_matches_dense_data(hk):
+    """build_nanovdb_from_dense (nanovdb.jl:602-858) restated in hikari.jl_amd/media.py: tree layout invariants."""
+    rng = np.random.default_rng(9)
+    d = np.zeros((40, 24, 17), np.float32)
+    d[3:20, 2:9, 5:16] = rng.random((17, 7, 11)).astype(np.float32) + 0.1
+    d[30:39, 16:23, 0:4] = 1.5
+    m = hk.NanoVDBMedium(d, bounds=((0, 0, 0), (4.0, 2.4, 1.7)))
+    meta = m.meta
+    assert meta["leaf_count"] == sum(1 for bx in range(5) for by in range(3) for bz in range(3) if np.any(d[bx*8:bx*8+8, by*8:by*8+8, bz*8:bz*8+8] != 0))
+    assert meta["upper_count"] == 1 and meta["lower_count"] == 1 and meta["root_offset"] == 1
+    assert m.buffer.size == 64 + 32 + (8256 + 32768 * 8) + (1088 + 4096 * 8) + meta["leaf_count"] * 2144
+    assert abs(m.max_density - d.max()) < 1e-6 and m.majorant.shape == (64 ** 3,)
+    assert abs(meta["inv_mat"][0] - 10.0) < 1e-4 and abs(meta["vec"][0] - 0.05) < 1e-6

@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=1)
+    ap.add_argument("--config", default="cornell", choices=["cornell", "cloud"],
+                    help="cornell = BASELINE configs[1] (the bench line); cloud = configs[3] stand-in (synthetic NanoVDB cloud, 1024x1024, depth 32)")
     args = ap.parse_args()
 
     import numpy as np
@@ -57,7 +59,14 @@ def main():
     from hikari_jl_amd import distributed as hd
     from hikari_jl_amd import scenes
 
-    scene, film, cam = scenes.cornell_box(W, H, light="area")
+    global W, H, DEPTH
+    if args.config == "cloud":
+        W, H, DEPTH = 1024, 1024, 32
+        scene, film, cam = scenes.cloud_scene(W, H, "nanovdb", res=(256, 256, 128), sigma_scale=620.0 / 4)
+        workload = "synthetic BOMEX-like NanoVDB cloud (256x256x128, delta tracking), 1024x1024, VolPath depth 32, %d spp per step" % SPP_PER_STEP
+    else:
+        scene, film, cam = scenes.cornell_box(W, H, light="area")
+        workload = "Cornell box (diffuse + area light), 800x800, VolPath depth 8, %d spp per step" % SPP_PER_STEP
     n_pix = W * H
     # film accumulators live in a torch tensor so torch.distributed (RCCL) can reduce them in place
     accum = torch.zeros(4 * n_pix, dtype=torch.float32, device="cuda")
@@ -158,7 +167,7 @@ def main():
             cdt = time.perf_counter() - c0
             crays = int(ost.rays_closest) + int(ost.rays_shadow)
             cpu = {"value": round(crays / cdt / 1e6, 4), "unit": "Mrays/s", "cores": oracle.max_threads(), "kind": "port",
-                   "sample": "%d spp of the same %dx%d depth-%d Cornell frame (%.1f s); CPU restatement of Hikari VolPath, not Julia" % (args.cpu_spp, W, H, DEPTH, cdt),
+                   "sample": "%d spp of the same %dx%d depth-%d frame (%.1f s); CPU restatement of Hikari VolPath, not Julia" % (args.cpu_spp, W, H, DEPTH, cdt),
                    "seconds_to_256spp_extrapolated": round(cdt * FULL_SPP / args.cpu_spp, 1)}
             osc.close()
 
@@ -168,12 +177,12 @@ def main():
             "metric": "Mrays/s", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed_max / max(args.steps, 1) * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "Cornell box (diffuse + area light), 800x800, VolPath depth 8, %d spp per step" % SPP_PER_STEP,
+            "config": {"workload": workload,
                        "resolution": [W, H], "max_depth": DEPTH, "spp_per_step": SPP_PER_STEP, "spp_rendered": spp_done,
                        "triangles": int(scene.desc.n_triangles), "lights": int(scene.desc.n_lights), "parallelism": "sample-index sharding x%d + film reduce" % world},
             "seconds_timed": round(elapsed_max, 4),
             "seconds_to_256spp": round(elapsed_max * FULL_SPP / spp_done * world, 4) if world == 1 else round(elapsed_max * (FULL_SPP / spp_done), 4),
-            "rays": {"closest": int(st.rays_closest), "shadow": int(st.rays_shadow), "total_all_ranks": int(total_rays)},
+            "rays": {"closest": int(st.rays_closest), "shadow": int(st.rays_shadow), "total_all_ranks": int(total_rays), "medium_collisions": int(st.medium_collisions)},
             "setup_seconds": round(setup_s, 3),
             "roofline": roofline, "cpu_baseline": cpu,
         }

@@ -31,6 +31,7 @@ void launch_test_sobol(hipStream_t, const DTables&, const DSobol&, int, const in
 void launch_test_camera(hipStream_t, const DTables&, const DFilter&, const DCamera&, const DSobol&, int, int, const int*, const int*, const int*, float*);
 void launch_test_uplift(hipStream_t, const DTables&, int, int, const float*, const float*, float*);
 void launch_test_light_bvh(hipStream_t, const DScene&, int, const float*, const float*, const float*, int*, float*, const int*, float*);
+void launch_test_bsdf(hipStream_t, const DScene&, const DTables&, int, int, int, int, const float*, const float*, const float*, const float*, const float*, const float*, float*);
 }  // namespace hk
 
 static thread_local std::string g_err;
@@ -103,6 +104,7 @@ struct hk_scene {
     DevBuf media;
     DScene d{};
     uint32_t kinds_mask = 0;
+    int n_materials = 0;
     int bvh_nodes = 0, bvh_leaf_tris = 0, bvh_depth = 0;
     hk::LightBVH lbvh;
     ~hk_scene() {
@@ -374,6 +376,12 @@ extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene**
             float cf[4] = {0, 0, 0, 0};
             if (sp.tex < 0) {
                 float r = m.rgb[k].c[0], g = m.rgb[k].c[1], b = m.rgb[k].c[2];
+                if (o.kind == HK_MAT_DIFFUSE_TRANSMISSION && k < 2) {  // clamp(rgb * scale, 0, 1) (spectral-eval.jl:2098-2103)
+                    const float sc = m.f[0].v;
+                    r = clampf(r * sc, 0.0f, 1.0f), g = clampf(g * sc, 0.0f, 1.0f), b = clampf(b * sc, 0.0f, 1.0f);
+                }
+                if (o.kind == HK_MAT_COATED_CONDUCTOR && k == 2)  // reflectance mode: clamp(r, 0, 0.9999) (:2924-2928)
+                    r = clampf(r, 0.0f, 0.9999f), g = clampf(g, 0.0f, 0.9999f), b = clampf(b, 0.0f, 0.9999f);
                 switch (bake_mode(o.kind, k)) {
                     case BAKE_BOUNDED_CLAMP:
                         r = clampf(r, 0.0f, INFINITY);
@@ -392,11 +400,8 @@ extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene**
             o.ftex[k] = m.f[k].tex;
         }
         if (o.kind != HK_MAT_MIX) s->kinds_mask |= 1u << o.kind;
-        if (o.kind > HK_MAT_CONDUCTOR && o.kind != HK_MAT_MIX && o.kind != HK_MAT_FALLBACK) {
-            delete s;
-            return fail(HK_ERR_UNSUPPORTED, "layered / transmissive material kinds are not built yet (SURVEY 8 row a18)");
-        }
     }
+    s->n_materials = d->n_materials;
     HIP_TRY(s->materials.upload(dm.data(), dm.size() * sizeof(DMaterial)));
     static_assert(sizeof(DMediumInterface) == 16, "mi layout");
     std::vector<DMediumInterface> dmi(d->n_media_interfaces > 0 ? d->n_media_interfaces : 1);
@@ -1112,6 +1117,20 @@ extern "C" int32_t hk_test_uplift(hk_ctx* c, int32_t mode, int32_t n, const floa
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpy(out, o, 4 * (size_t)n * 4, hipMemcpyDeviceToHost));
+    return HK_OK;
+}
+extern "C" int32_t hk_test_bsdf(hk_ctx* c, hk_scene* sc, int32_t mode, int32_t mat_idx, int32_t regularize, int32_t n, const float* wo, const float* wi, const float* ns,
+                                const float* lambda, const float* u, const float* uc, float* out) {
+    if (!c || !sc || !wo || !wi || !ns || !lambda || !u || !uc || !out) return fail(HK_ERR_INVALID, "null argument");
+    if (mat_idx < 0 || mat_idx >= sc->n_materials) return fail(HK_ERR_INVALID, "material index out of range");
+    HIP_TRY(hipSetDevice(c->device));
+    Tmp t;
+    float *dwo = t.up(wo, 3 * (size_t)n), *dwi = t.up(wi, 3 * (size_t)n), *dns = t.up(ns, 3 * (size_t)n), *dl = t.up(lambda, 4 * (size_t)n);
+    float *du = t.up(u, 2 * (size_t)n), *duc = t.up(uc, (size_t)n), *o = t.up<float>(nullptr, 10 * (size_t)n);
+    hk::launch_test_bsdf(c->stream, sc->d, c->tables, mode, mat_idx, regularize, n, dwo, dwi, dns, dl, du, duc, o);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out, o, 10 * (size_t)n * 4, hipMemcpyDeviceToHost));
     return HK_OK;
 }
 extern "C" int32_t hk_test_light_bvh(hk_ctx* c, hk_scene* sc, int32_t n, const float* p3, const float* n3, const float* u, int32_t* out_light, float* out_pmf,

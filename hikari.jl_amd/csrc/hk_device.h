@@ -914,6 +914,10 @@ HKD BSDFSample sample_lambert(v3 wo, v3 n, v2 u, S4 f) {
     return s;
 }
 
+}  // namespace hkd
+#include "hk_layered.h"
+namespace hkd {
+
 // KIND is a compile-time constant in the per-kind shade kernels (material-sorted queues)
 template <int KIND>
 HKD BSDFSample sample_bsdf(const DScene& sc, const DTables& T, const DMaterial& m, v3 wo_w, v3 n, v2 uv, S4 lambda, v2 u, float uc, bool regularize) {
@@ -1012,6 +1016,16 @@ HKD BSDFSample sample_bsdf(const DScene& sc, const DTables& T, const DMaterial& 
         s.pdf = pdf;
         s.is_specular = false;
         return s;
+    } else if (KIND == HK_MAT_COATED_DIFFUSE) {  // :1233-1441
+        return layered_sample<false>(layered_params<false>(sc, T, m, uv, lambda, regularize), wo_w, n, u, uc);
+    } else if (KIND == HK_MAT_COATED_DIFFUSE_TRANSMISSION) {  // :2341-2497
+        return layered_sample<true>(layered_params<true>(sc, T, m, uv, lambda, regularize), wo_w, n, u, uc);
+    } else if (KIND == HK_MAT_COATED_CONDUCTOR) {  // :2877-3231
+        return cc_sample(cc_params(sc, T, m, uv, lambda, regularize), wo_w, n, u, uc);
+    } else if (KIND == HK_MAT_THIN_DIELECTRIC) {  // :1975-2037
+        return thin_dielectric_sample(eval_f32(sc, m, 0, uv), wo_w, n, uc);
+    } else if (KIND == HK_MAT_DIFFUSE_TRANSMISSION) {  // :2083-2163
+        return dt_sample(dt_params(sc, T, m, uv, lambda), wo_w, n, u, uc);
     } else {  // generic fallback (:322-359): gray 0.5 Lambertian (Q24)
         float wdn = dot(wo_w, n);
         if (fabsf(wdn) < 1e-6f) return invalid_sample();
@@ -1056,6 +1070,16 @@ HKD S4 eval_bsdf(const DScene& sc, const DTables& T, const DMaterial& m, v3 wo_w
         v3 wmp = wm.z < 0.0f ? -wm : wm;
         pdf = tr_pdf(wo, wmp, ax, ay) / (4.0f * fabsf(dot(wo, wmp)));
         return f;
+    } else if (KIND == HK_MAT_COATED_DIFFUSE) {  // :1563-1937
+        return layered_eval<false>(layered_params<false>(sc, T, m, uv, lambda, false), wo_w, wi_w, n, pdf);
+    } else if (KIND == HK_MAT_COATED_DIFFUSE_TRANSMISSION) {  // :2501-2832
+        return layered_eval<true>(layered_params<true>(sc, T, m, uv, lambda, false), wo_w, wi_w, n, pdf);
+    } else if (KIND == HK_MAT_COATED_CONDUCTOR) {  // :3238-3420
+        return cc_eval(cc_params(sc, T, m, uv, lambda, false), wo_w, wi_w, n, pdf);
+    } else if (KIND == HK_MAT_THIN_DIELECTRIC) {  // :2045-2051
+        return s4(0.0f);
+    } else if (KIND == HK_MAT_DIFFUSE_TRANSMISSION) {  // :2170-2218
+        return dt_eval(dt_params(sc, T, m, uv, lambda), wo_w, wi_w, n, pdf);
     } else {  // fallback (:491-511)
         float ci = dot(wi_w, n), co = dot(wo_w, n);
         if (ci * co < 0.0f) return s4(0.0f);

@@ -631,7 +631,7 @@ __global__ void __launch_bounds__(256, HK_SHADE_MIN_WAVES) k_shade(DPathState st
             if (new_depth < fr.max_depth) {
                 // the 1-D component sample is read only by BSDFs that choose a lobe (Glass and the layered kinds)
                 float uc = (KIND == HK_MAT_GLASS || KIND > HK_MAT_CONDUCTOR) && KIND != HK_MAT_FALLBACK ? sobol_1d(sctx, base_dim + 4) : 0.0f;
-                v2 u = (KIND == HK_MAT_MIRROR || KIND == HK_MAT_GLASS) ? mk2(0.0f, 0.0f) : sobol_2d(sctx, base_dim + 6);
+                v2 u = (KIND == HK_MAT_MIRROR || KIND == HK_MAT_GLASS || KIND == HK_MAT_THIN_DIELECTRIC) ? mk2(0.0f, 0.0f) : sobol_2d(sctx, base_dim + 6);
                 bool regularize = fr.regularize && any_non_specular;
                 BSDFSample s = sample_bsdf<KIND>(sc, T, mat, wo, sf.ns, sf.uv, lambda, u, uc, regularize);
                 if (s.pdf > 0.0f && !is_black(s.f)) {
@@ -967,6 +967,11 @@ void launch_shade(hipStream_t s, int n_cu, int kind, const DPathState& st, const
         HK_SHADE_CASE(HK_MAT_MIRROR)
         HK_SHADE_CASE(HK_MAT_GLASS)
         HK_SHADE_CASE(HK_MAT_CONDUCTOR)
+        HK_SHADE_CASE(HK_MAT_COATED_DIFFUSE)
+        HK_SHADE_CASE(HK_MAT_THIN_DIELECTRIC)
+        HK_SHADE_CASE(HK_MAT_DIFFUSE_TRANSMISSION)
+        HK_SHADE_CASE(HK_MAT_COATED_DIFFUSE_TRANSMISSION)
+        HK_SHADE_CASE(HK_MAT_COATED_CONDUCTOR)
         default: {
             static int blocks = resident_blocks(k_shade<HK_MAT_FALLBACK>, 256, n_cu, 8);
             hipLaunchKernelGGL(k_shade<HK_MAT_FALLBACK>, dim3(clamp_blocks(blocks, st)), dim3(256), 0, s, st, sc, T, fr, sob, depth, first_kind, stats);
@@ -988,6 +993,45 @@ void launch_finalize(hipStream_t s, const void* accum, bool f64, float* out, int
     else
         hipLaunchKernelGGL(k_finalize<float>, dim3(g), dim3(256), 0, s, (const float*)accum, out, w, h);
 }
+template <int KIND>
+__device__ void test_bsdf_one(const DScene& sc, const DTables& T, const DMaterial& m, int mode, bool regularize, v3 wo, v3 wi, v3 ns, S4 lambda, v2 u, float uc, float* r) {
+    if (mode == 0) {
+        BSDFSample b = sample_bsdf<KIND>(sc, T, m, wo, ns, mk2(0.0f, 0.0f), lambda, u, uc, regularize);
+        r[0] = b.wi.x, r[1] = b.wi.y, r[2] = b.wi.z;
+        r[3] = b.f.x, r[4] = b.f.y, r[5] = b.f.z, r[6] = b.f.w;
+        r[7] = b.pdf, r[8] = b.is_specular ? 1.0f : 0.0f, r[9] = b.eta_scale;
+    } else {
+        float pdf;
+        S4 f = eval_bsdf<KIND>(sc, T, m, wo, wi, ns, mk2(0.0f, 0.0f), lambda, pdf);
+        r[0] = f.x, r[1] = f.y, r[2] = f.z, r[3] = f.w, r[4] = pdf;
+        r[5] = r[6] = r[7] = r[8] = r[9] = 0.0f;
+    }
+}
+__global__ void k_test_bsdf(DScene sc, DTables T, int mode, int mat_idx, int regularize, int n, const float* wo, const float* wi, const float* ns, const float* lambda,
+                            const float* u, const float* uc, float* out) {
+    const DMaterial& m = sc.materials[mat_idx];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    v3 o = mk3(wo[3 * i], wo[3 * i + 1], wo[3 * i + 2]), d = mk3(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]), nn = mk3(ns[3 * i], ns[3 * i + 1], ns[3 * i + 2]);
+    S4 l = s4(lambda[4 * i], lambda[4 * i + 1], lambda[4 * i + 2], lambda[4 * i + 3]);
+    v2 uu = mk2(u[2 * i], u[2 * i + 1]);
+    float* r = out + 10 * (size_t)i;
+#define HK_TB_CASE(K) \
+    case K: test_bsdf_one<K>(sc, T, m, mode, regularize != 0, o, d, nn, l, uu, uc[i], r); break;
+    switch (m.kind) {
+        HK_TB_CASE(HK_MAT_MATTE)
+        HK_TB_CASE(HK_MAT_MIRROR)
+        HK_TB_CASE(HK_MAT_GLASS)
+        HK_TB_CASE(HK_MAT_CONDUCTOR)
+        HK_TB_CASE(HK_MAT_COATED_DIFFUSE)
+        HK_TB_CASE(HK_MAT_THIN_DIELECTRIC)
+        HK_TB_CASE(HK_MAT_DIFFUSE_TRANSMISSION)
+        HK_TB_CASE(HK_MAT_COATED_DIFFUSE_TRANSMISSION)
+        HK_TB_CASE(HK_MAT_COATED_CONDUCTOR)
+        default: test_bsdf_one<HK_MAT_FALLBACK>(sc, T, m, mode, regularize != 0, o, d, nn, l, uu, uc[i], r); break;
+    }
+    }
+#undef HK_TB_CASE
+}
 void launch_test_trace(hipStream_t s, const DScene& sc, int n, const float* o, const float* d, const float* tmax, float* t, int* prim, float* uv) {
     hipLaunchKernelGGL(k_test_trace, dim3(grid_for(n, HK_TRACE_BLOCK, 1280)), dim3(HK_TRACE_BLOCK), 0, s, sc, n, o, d, tmax, t, prim, uv);
 }
@@ -1003,6 +1047,10 @@ void launch_test_uplift(hipStream_t s, const DTables& T, int mode, int n, const 
 }
 void launch_test_light_bvh(hipStream_t s, const DScene& sc, int n, const float* p, const float* nn, const float* u, int* ol, float* op, const int* q, float* oq) {
     hipLaunchKernelGGL(k_test_light_bvh, dim3(grid_for(n, 256, 1024)), dim3(256), 0, s, sc, n, p, nn, u, ol, op, q, oq);
+}
+void launch_test_bsdf(hipStream_t s, const DScene& sc, const DTables& T, int mode, int mat_idx, int regularize, int n, const float* wo, const float* wi, const float* ns,
+                      const float* lambda, const float* u, const float* uc, float* out) {
+    hipLaunchKernelGGL(k_test_bsdf, dim3(grid_for(n, 64, 4096)), dim3(64), 0, s, sc, T, mode, mat_idx, regularize, n, wo, wi, ns, lambda, u, uc, out);
 }
 
 }  // namespace hk

@@ -138,3 +138,34 @@ def cloud_scene(width=1024, height=1024, kind="nanovdb", res=(128, 128, 64), sig
     film = Film((width, height))
     cam = PerspectiveCamera((0.0, 1.0, -3.2), (0.0, 0.85, 0.0), film, fov=35.0)
     return s, film, cam
+
+
+def material_scene(width=64, height=64, material=None, light="both", thin_panel=False):
+    """Cornell-like box whose sphere + tilted slab carry `material` (the kinds of Appendix A that the Cornell /
+    integration scenes do not exercise: coated / thin / transmissive).  `thin_panel` hangs a single-sided-thin
+    quad of the material in front of the back wall so transmission lobes carry light."""
+    white = MatteMaterial(Kd=RGBSpectrum(0.73, 0.73, 0.73))
+    red = MatteMaterial(Kd=RGBSpectrum(0.65, 0.05, 0.05))
+    green = MatteMaterial(Kd=RGBSpectrum(0.12, 0.45, 0.15))
+    box, half = 2.0, 1.0
+    s = Scene()
+    s.push(G.rect3f((-half, 0, -half), (box, 0.01, box)), white)
+    s.push(G.rect3f((-half, box - 0.01, -half), (box, 0.01, box)), white)
+    s.push(G.rect3f((-half, 0, half - 0.01), (box, box, 0.01)), white)
+    s.push(G.rect3f((-half, 0, -half), (0.01, box, box)), red)
+    s.push(G.rect3f((half - 0.01, 0, -half), (0.01, box, box)), green)
+    s.push(G.sphere((-0.4, 0.4, 0.1), 0.35, 24), material)
+    if thin_panel:
+        s.push(G.quad((0.05, 0.1, 0.45), (0.85, 0.1, 0.15), (0.85, 1.3, 0.15), (0.05, 1.3, 0.45), normal=(-0.35, 0.0, -0.94)), material)
+    else:
+        s.push(G.rect3f((0.15, 0.0, -0.1), (0.5, 0.6, 0.5)), material)
+    if light in ("point", "both"):
+        s.push(PointLight.from_spectrum_first(RGBSpectrum(4.0), (0.3, 1.7, -0.6)))
+    if light in ("area", "both"):
+        y = 1.98
+        q = G.quad((-0.25, y, -0.25), (0.25, y, -0.25), (0.25, y, 0.25), (-0.25, y, 0.25), normal=(0, -1, 0))
+        s.push(q, MediumInterface(MatteMaterial(Kd=RGBSpectrum(0.0)), emission=Emissive(Le=RGBSpectrum(6.0), scale=1.0, two_sided=False)))
+    s.sync()
+    film = Film((width, height))
+    cam = PerspectiveCamera((0, 1, -3.5), (0, 1, 0), film, fov=40.0)
+    return s, film, cam

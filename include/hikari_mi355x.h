@@ -355,6 +355,12 @@ int32_t hk_test_uplift(hk_ctx* ctx, int32_t mode, int32_t n, const float* rgb, c
 /* light-BVH: sample (light_idx_1based, pmf) and pmf of a given light for n shading points */
 int32_t hk_test_light_bvh(hk_ctx* ctx, hk_scene* scene, int32_t n, const float* p3, const float* n3, const float* u,
                           int32_t* out_light, float* out_pmf, const int32_t* query_light, float* out_query_pmf);
+/* point-wise BSDFs of a scene's material `mat_idx` (material-dispatch.jl:23-53; spectral-eval.jl) at uv=(0,0):
+   mode 0 = sample_bsdf_spectral(wo, ns, lambda, u, uc, regularize) -> out[10n] = wi3, f4, pdf, is_specular, eta_scale
+   mode 1 = evaluate_bsdf_spectral(wo, wi, ns, lambda)              -> out[10n] = f4, pdf, 0...
+   wo/wi/ns: 3n floats, lambda: 4n, u: 2n, uc: n. */
+int32_t hk_test_bsdf(hk_ctx* ctx, hk_scene* scene, int32_t mode, int32_t mat_idx, int32_t regularize, int32_t n, const float* wo,
+                     const float* wi, const float* ns, const float* lambda, const float* u, const float* uc, float* out);
 
 /* introspection used by tests/bench */
 int32_t hk_scene_bvh_info(hk_scene* scene, int32_t* n_nodes, int32_t* n_leaf_tris, int32_t* max_depth);

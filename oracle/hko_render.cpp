@@ -25,7 +25,7 @@
 #include <vector>
 
 #include "hikari_mi355x.h"
-#include "hko_bsdf.h"
+#include "hko_layered.h"
 #include "hko_filter_camera.h"
 #include "hko_media.h"
 
@@ -862,7 +862,7 @@ static void render_one_sample(const Scene& sc, const hk_integrator_params& ip, c
                 LightSample ls = sample_light_full(sc, light_idx, wk.g.pi, wk.lambda, u_light);
                 if (!(ls.pdf > 0.0f && !is_black(ls.Li))) continue;
                 float bsdf_pdf;
-                Spec bsdf_f = eval_bsdf(sc.mctx, wk.material, wk.wo, ls.wi, wk.g.ns, wk.g.uv, wk.lambda, bsdf_pdf);
+                Spec bsdf_f = eval_bsdf_all(sc.mctx, wk.material, wk.wo, ls.wi, wk.g.ns, wk.g.uv, wk.lambda, bsdf_pdf);
                 if (is_black(bsdf_f)) continue;
                 // compute_direct_lighting_spectral  lights.jl:535-600
                 float cos_theta = std::fabs(dot(ls.wi, wk.g.ns));
@@ -929,7 +929,7 @@ static void render_one_sample(const Scene& sc, const hk_integrator_params& ip, c
             float uc = st.s_indirect_uc[p0];
             float rr = st.s_rr[p0];
             bool regularize = ip.regularize && wk.any_non_specular;
-            BSDFSample s = sample_bsdf(sc.mctx, wk.material, wk.wo, wk.g.ns, wk.g.uv, wk.lambda, u, uc, regularize);
+            BSDFSample s = sample_bsdf_all(sc.mctx, wk.material, wk.wo, wk.g.ns, wk.g.uv, wk.lambda, u, uc, regularize);
             if (!(s.pdf > 0.0f && !is_black(s.f))) continue;
             float cos_theta = std::fabs(dot(s.wi, wk.g.ns));
             Spec new_beta = s.is_specular ? wk.beta * s.f : wk.beta * s.f * cos_theta / s.pdf;
@@ -1227,6 +1227,34 @@ int32_t hko_light_bvh_copy(hko_scene* s, int32_t* n_nodes, float* nodes_out, uin
         }
     if (bit_trails)
         for (size_t i = 0; i < ls.bit_trail.size(); ++i) bit_trails[i] = ls.bit_trail[i];
+    return 0;
+}
+
+// Point-wise BSDF evaluation against a scene's material table (material-dispatch.jl:23-53), n vertices:
+//   wo/wi/ns: 3 floats each, lambda: 4, u: 2, uc: 1; mode 0 = sample (out: wi3, f4, pdf, is_specular, eta_scale = 10),
+//   mode 1 = evaluate (out: f4, pdf, 0... = 10).  uv = (0,0).
+int32_t hko_bsdf(hko_scene* s, int32_t mode, int32_t mat_idx, int32_t regularize, int32_t n, const float* wo, const float* wi, const float* ns, const float* lambda,
+                 const float* u, const float* uc, float* out) {
+    Scene& sc = s->sc;
+    for (int i = 0; i < n; ++i) {
+        Wavelengths w;
+        for (int k = 0; k < 4; ++k) w.lambda[k] = lambda[4 * i + k], w.pdf[k] = 1.0f;
+        V3 o(wo[3 * i], wo[3 * i + 1], wo[3 * i + 2]), nn(ns[3 * i], ns[3 * i + 1], ns[3 * i + 2]);
+        float* r = out + 10 * (size_t)i;
+        for (int k = 0; k < 10; ++k) r[k] = 0.0f;
+        if (mode == 0) {
+            BSDFSample b = sample_bsdf_all(sc.mctx, mat_idx, o, nn, V2(0, 0), w, V2(u[2 * i], u[2 * i + 1]), uc[i], regularize != 0);
+            r[0] = b.wi.x, r[1] = b.wi.y, r[2] = b.wi.z;
+            for (int k = 0; k < 4; ++k) r[3 + k] = b.f[k];
+            r[7] = b.pdf, r[8] = b.is_specular ? 1.0f : 0.0f, r[9] = b.eta_scale;
+        } else {
+            V3 d(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]);
+            float pdf = 0.0f;
+            Spec f = eval_bsdf_all(sc.mctx, mat_idx, o, d, nn, V2(0, 0), w, pdf);
+            for (int k = 0; k < 4; ++k) r[k] = f[k];
+            r[4] = pdf;
+        }
+    }
     return 0;
 }
 

@@ -52,6 +52,7 @@ def lib():
         "hk_test_camera": ([vp, vp, C.POINTER(A.hk_camera), i32, i32, i32, PI, PI, PI, PF], i32),
         "hk_test_uplift": ([vp, i32, i32, PF, PF, PF], i32),
         "hk_test_light_bvh": ([vp, vp, i32, PF, PF, PF, PI, PF, PI, PF], i32),
+        "hk_test_light": ([vp, vp, i32, i32, i32, PF, PF, PF, PF], i32),
         "hk_test_bsdf": ([vp, vp, i32, i32, i32, i32, PF, PF, PF, PF, PF, PF, PF], i32),
         "hk_scene_bvh_info": ([vp, PI, PI, PI], i32),
         "hk_scene_light_bvh_copy": ([vp, PI, PF, C.POINTER(C.c_uint32)], i32),

@@ -31,6 +31,7 @@ void launch_test_sobol(hipStream_t, const DTables&, const DSobol&, int, const in
 void launch_test_camera(hipStream_t, const DTables&, const DFilter&, const DCamera&, const DSobol&, int, int, const int*, const int*, const int*, float*);
 void launch_test_uplift(hipStream_t, const DTables&, int, int, const float*, const float*, float*);
 void launch_test_light_bvh(hipStream_t, const DScene&, int, const float*, const float*, const float*, int*, float*, const int*, float*);
+void launch_test_light(hipStream_t, const DScene&, const DTables&, int, int, int, const float*, const float*, const float*, float*);
 void launch_test_bsdf(hipStream_t, const DScene&, const DTables&, int, int, int, int, const float*, const float*, const float*, const float*, const float*, const float*, float*);
 }  // namespace hk
 
@@ -101,6 +102,8 @@ struct hk_scene {
     std::vector<DevBuf*> tex_data;
     std::vector<DevBuf*> spec_data;
     std::vector<DevBuf*> media_data;
+    std::vector<DevBuf*> env_data;
+    DevBuf envmaps;
     DevBuf media;
     DScene d{};
     uint32_t kinds_mask = 0;
@@ -111,6 +114,7 @@ struct hk_scene {
         for (auto* b : tex_data) delete b;
         for (auto* b : spec_data) delete b;
         for (auto* b : media_data) delete b;
+        for (auto* b : env_data) delete b;
     }
 };
 
@@ -263,7 +267,10 @@ int bake_mode(int kind, int slot) {
 extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene** out) {
     if (!c || !d || !out) return fail(HK_ERR_INVALID, "null argument");
     if (!c->have_tables) return fail(HK_ERR_INVALID, "hk_ctx_set_tables must be called first");
-    if (d->n_envmaps > 0) return fail(HK_ERR_UNSUPPORTED, "environment maps are not built yet (SURVEY 8 row a24)");
+    if (d->n_envmaps > 0 && !d->envmaps) return fail(HK_ERR_INVALID, "n_envmaps > 0 but envmaps is null");
+    for (int i = 0; i < d->n_lights; ++i)
+        if (d->lights[i].kind == HK_LIGHT_ENVIRONMENT && (d->lights[i].envmap < 0 || d->lights[i].envmap >= d->n_envmaps))
+            return fail(HK_ERR_INVALID, "environment light refers to a missing envmap");
     if (d->n_triangles < 0 || (d->n_triangles > 0 && (!d->positions || !d->meta))) return fail(HK_ERR_INVALID, "bad triangle arrays");
     HIP_TRY(hipSetDevice(c->device));
     hk_scene* s = new hk_scene();
@@ -445,6 +452,10 @@ extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene**
                 o.cos_falloff_start = l.cos_falloff_start;
             }
             if (l.kind == HK_LIGHT_AMBIENT || l.kind == HK_LIGHT_ENVIRONMENT) has_escape = 1;
+            if (l.kind == HK_LIGHT_ENVIRONMENT) {  // scale::RGBSpectrum rides in Le_rgba, the map index in Le_tex
+                std::memcpy(o.Le_rgba, l.i_rgb, 16);
+                o.Le_tex = l.envmap;
+            }
         }
         o.coef = make_float4(cf[0], cf[1], cf[2], cf[3]);
     }
@@ -461,6 +472,39 @@ extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene**
         std::vector<int32_t> inf = s->lbvh.infinite;
         if (inf.empty()) inf.resize(1);
         HIP_TRY(s->infinite.upload(inf.data(), inf.size() * 4));
+    }
+    // ---- environment maps: texels + Distribution2D tables, layouts as the reference holds them ----
+    {
+        std::vector<DEnvMap> de(d->n_envmaps > 0 ? d->n_envmaps : 1);
+        std::memset(de.data(), 0, de.size() * sizeof(DEnvMap));
+        for (int i = 0; i < d->n_envmaps; ++i) {
+            const hk_envmap& e = d->envmaps[i];
+            if (e.width <= 0 || e.height <= 0 || e.nu <= 0 || e.nv <= 0 || !e.data || !e.conditional_func || !e.conditional_cdf || !e.conditional_func_int ||
+                !e.marginal_func || !e.marginal_cdf) {
+                delete s;
+                return fail(HK_ERR_INVALID, "incomplete hk_envmap record");
+            }
+            auto up = [&](const float* src, size_t n, const float** dst) -> hipError_t {
+                DevBuf* b = new DevBuf();
+                s->env_data.push_back(b);
+                hipError_t err = b->upload(src, n * 4);
+                *dst = b->as<float>();
+                return err;
+            };
+            DEnvMap& o = de[i];
+            const float* texels = nullptr;
+            HIP_TRY(up(e.data, (size_t)e.width * e.height * 4, &texels));
+            o.data = reinterpret_cast<const float4*>(texels);
+            HIP_TRY(up(e.conditional_func, (size_t)e.nu * e.nv, &o.cond_func));
+            HIP_TRY(up(e.conditional_cdf, (size_t)(e.nu + 1) * e.nv, &o.cond_cdf));
+            HIP_TRY(up(e.conditional_func_int, (size_t)e.nv, &o.cond_func_int));
+            HIP_TRY(up(e.marginal_func, (size_t)e.nv, &o.marg_func));
+            HIP_TRY(up(e.marginal_cdf, (size_t)e.nv + 1, &o.marg_cdf));
+            o.marg_func_int = e.marginal_func_int;
+            o.width = e.width, o.height = e.height, o.nu = e.nu, o.nv = e.nv;
+            std::memcpy(o.rot, e.rotation, sizeof o.rot);
+        }
+        HIP_TRY(s->envmaps.upload(de.data(), de.size() * sizeof(DEnvMap)));
     }
     // ---- media: bake sigma_a / sigma_s / Le with uplift_rgb_unbounded, upload grids / NanoVDB bytes ----
     std::vector<DMedium> dmed(d->n_media > 0 ? d->n_media : 1);
@@ -538,6 +582,8 @@ extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene**
     D.infinite_lights = s->infinite.as<int>();
     D.num_bvh_lights = s->lbvh.num_bvh;
     D.num_infinite_lights = (int)s->lbvh.infinite.size();
+    D.envmaps = s->envmaps.as<DEnvMap>();
+    D.n_envmaps = d->n_envmaps;
     D.has_escape_lights = has_escape;
     D.all_opaque = all_opaque ? 1 : 0;
     *out = s;
@@ -1117,6 +1163,19 @@ extern "C" int32_t hk_test_uplift(hk_ctx* c, int32_t mode, int32_t n, const floa
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpy(out, o, 4 * (size_t)n * 4, hipMemcpyDeviceToHost));
+    return HK_OK;
+}
+extern "C" int32_t hk_test_light(hk_ctx* c, hk_scene* sc, int32_t mode, int32_t light_idx_1based, int32_t n, const float* p3, const float* in3, const float* lambda,
+                                 float* out) {
+    if (!c || !sc || !p3 || !in3 || !lambda || !out) return fail(HK_ERR_INVALID, "null argument");
+    if (mode == 0 && (light_idx_1based < 1 || light_idx_1based > sc->d.n_lights)) return fail(HK_ERR_INVALID, "light index out of range");
+    HIP_TRY(hipSetDevice(c->device));
+    Tmp t;
+    float *dp = t.up(p3, 3 * (size_t)n), *di = t.up(in3, 3 * (size_t)n), *dl = t.up(lambda, 4 * (size_t)n), *o = t.up<float>(nullptr, 12 * (size_t)n);
+    hk::launch_test_light(c->stream, sc->d, c->tables, mode, light_idx_1based, n, dp, di, dl, o);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out, o, 12 * (size_t)n * 4, hipMemcpyDeviceToHost));
     return HK_OK;
 }
 extern "C" int32_t hk_test_bsdf(hk_ctx* c, hk_scene* sc, int32_t mode, int32_t mat_idx, int32_t regularize, int32_t n, const float* wo, const float* wi, const float* ns,

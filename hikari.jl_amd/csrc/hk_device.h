@@ -1091,6 +1091,111 @@ HKD S4 eval_bsdf(const DScene& sc, const DTables& T, const DMaterial& m, v3 wo_w
 }
 
 // ------------------------------------------------------------------------------------------------
+// environment map (textures/environment_map.jl:78-160, 200-229, 290-371; sampler/sampling.jl:264-361)
+// ------------------------------------------------------------------------------------------------
+HKD v2 equal_area_sphere_to_square(v3 d) {
+    float x = fabsf(d.x), y = fabsf(d.y), z = fabsf(d.z);
+    float r = sqrtf(1.0f - z);
+    float a = maxf(x, y);
+    float b = a == 0.0f ? 0.0f : minf(x, y) / a;
+    const float t1 = 0.406758566246788489601959989e-5f, t2 = 0.636226545274016134946890922156f, t3 = 0.61572017898280213493197203466e-2f,
+                t4 = -0.247333733281268944196501420480f, t5 = 0.881770664775316294736387951347e-1f, t6 = 0.419038818029165735901852432784e-1f,
+                t7 = -0.251390972343483509333252996350e-1f;
+    float phi = t1 + b * (t2 + b * (t3 + b * (t4 + b * (t5 + b * (t6 + b * t7)))));
+    if (x < y) phi = 1.0f - phi;
+    float v = phi * r;
+    float u = r - v;
+    if (d.z < 0.0f) {
+        float tu = u;
+        u = 1.0f - v;
+        v = 1.0f - tu;
+    }
+    u = copysignf(u, d.x);
+    v = copysignf(v, d.y);
+    return mk2(0.5f * (u + 1.0f), 0.5f * (v + 1.0f));
+}
+HKD v3 equal_area_square_to_sphere(v2 p) {
+    float u = 2.0f * p.x - 1.0f, v = 2.0f * p.y - 1.0f;
+    float up = fabsf(u), vp = fabsf(v);
+    float sd = 1.0f - (up + vp);
+    float r = 1.0f - fabsf(sd);
+    float phi = (r == 0.0f ? 1.0f : (vp - up) / r + 1.0f) * PI_F / 4.0f;
+    float z = copysignf(1.0f - r * r, sd);
+    float cp = copysignf(cosf(phi), u), sp = copysignf(sinf(phi), v);
+    float rc = r * sqrtf(2.0f - r * r);
+    return mk3(cp * rc, sp * rc, z);
+}
+HKD v2 env_direction_to_uv(const DEnvMap& e, v3 d) {  // transpose(rotation) * dir
+    const float* R = e.rot;
+    return equal_area_sphere_to_square(mk3(R[0] * d.x + R[3] * d.y + R[6] * d.z, R[1] * d.x + R[4] * d.y + R[7] * d.z, R[2] * d.x + R[5] * d.y + R[8] * d.z));
+}
+HKD v3 env_uv_to_direction(const DEnvMap& e, v2 uv) {  // rotation * dir_light
+    const float* R = e.rot;
+    v3 d = equal_area_square_to_sphere(uv);
+    return mk3(R[0] * d.x + R[1] * d.y + R[2] * d.z, R[3] * d.x + R[4] * d.y + R[5] * d.z, R[6] * d.x + R[7] * d.y + R[8] * d.z);
+}
+HKD float4 env_texel(const DEnvMap& e, int y1, int x1) { return e.data[(size_t)(y1 - 1) + (size_t)e.height * (size_t)(x1 - 1)]; }
+HKD float4 env_eval(const DEnvMap& e, v3 dir) {  // bilinear: escaped rays
+    v2 uv = env_direction_to_uv(e, dir);
+    int h = e.height, w = e.width;
+    float x = uv.x * (float)(w - 1) + 1.0f, y = uv.y * (float)(h - 1) + 1.0f;
+    float flx = floorf(x), fly = floorf(y);
+    int x0 = (int)flx, y0 = (int)fly;
+    int x1 = x0 + 1, y1 = y0 + 1;
+    x0 = clampi(x0, 1, w), x1 = clampi(x1, 1, w), y0 = clampi(y0, 1, h), y1 = clampi(y1, 1, h);
+    x1 = x1 > w ? 1 : x1;
+    float fx = x - flx, fy = y - fly;
+    float4 c00 = env_texel(e, y0, x0), c10 = env_texel(e, y0, x1), c01 = env_texel(e, y1, x0), c11 = env_texel(e, y1, x1);
+    float4 o;
+    o.x = (c00.x * (1.0f - fx) + c10.x * fx) * (1.0f - fy) + (c01.x * (1.0f - fx) + c11.x * fx) * fy;
+    o.y = (c00.y * (1.0f - fx) + c10.y * fx) * (1.0f - fy) + (c01.y * (1.0f - fx) + c11.y * fx) * fy;
+    o.z = (c00.z * (1.0f - fx) + c10.z * fx) * (1.0f - fy) + (c01.z * (1.0f - fx) + c11.z * fx) * fy;
+    o.w = 1.0f;
+    return o;
+}
+HKD float4 env_lookup_uv(const DEnvMap& e, v2 uv) {  // nearest: sampled directions
+    int ui = clampi((int)floorf(uv.x * (float)e.width) + 1, 1, e.width);
+    int vi = clampi((int)floorf(uv.y * (float)e.height) + 1, 1, e.height);
+    return env_texel(e, vi, ui);
+}
+HKD int find_interval_binary20(const float* cdf, int n, float u) {  // sampling.jl:305-333
+    int lo = 1, hi = n;
+#pragma unroll
+    for (int k = 0; k < 20; ++k) {
+        int mid = (lo + hi + 1) / 2;
+        bool c = cdf[mid - 1] <= u;
+        lo = c ? mid : lo;
+        hi = c ? hi : mid - 1;
+    }
+    return lo;
+}
+HKD v2 dist2d_sample(const DEnvMap& e, v2 u, float& pdf) {
+    const int nu = e.nu, nv = e.nv;
+    int vo = clampi(find_interval_binary20(e.marg_cdf, nv + 1, u.y), 1, nv);
+    float c0 = e.marg_cdf[vo - 1], c1 = e.marg_cdf[vo];
+    float du_v = u.y - c0, den_v = c1 - c0;
+    if (den_v > 0.0f) du_v /= den_v;
+    float v_s = ((float)(vo - 1) + du_v) / (float)nv;
+    float pdf_v = e.marg_func_int > 0.0f ? e.marg_func[vo - 1] / e.marg_func_int : 0.0f;
+    const float* ccdf = e.cond_cdf + (size_t)(vo - 1) * (size_t)(nu + 1);
+    int uo = clampi(find_interval_binary20(ccdf, nu + 1, u.x), 1, nu);
+    float d0 = ccdf[uo - 1], d1 = ccdf[uo];
+    float du_u = u.x - d0, den_u = d1 - d0;
+    if (den_u > 0.0f) du_u /= den_u;
+    float u_s = ((float)(uo - 1) + du_u) / (float)nu;
+    float fiv = e.cond_func_int[vo - 1];
+    float pdf_u = fiv > 0.0f ? e.cond_func[(size_t)(vo - 1) * nu + (uo - 1)] / fiv : 0.0f;
+    pdf = pdf_u * pdf_v;
+    return mk2(u_s, v_s);
+}
+HKD float env_pdf_li(const DEnvMap& e, v3 wi) {  // lights.jl:336-347
+    v2 uv = env_direction_to_uv(e, wi);
+    int iu = clampi((int)floorf(uv.x * (float)e.nu) + 1, 1, e.nu);
+    int iv = clampi((int)floorf(uv.y * (float)e.nv) + 1, 1, e.nv);
+    return (e.cond_func[(size_t)(iv - 1) * e.nu + (iu - 1)] / e.marg_func_int) / (4.0f * PI_F);
+}
+
+// ------------------------------------------------------------------------------------------------
 // lights (integrators/physical-wavefront/lights.jl:39-297; lights/diffuse-area.jl:53-82)
 // ------------------------------------------------------------------------------------------------
 struct LightSample {
@@ -1164,6 +1269,20 @@ HKD LightSample sample_light(const DScene& sc, const DTables& T, const DLight& l
             s.pdf = 1.0f / (4.0f * PI_F);
             s.p_light = p + 1.0e6f * wi;
             s.Li = l.scale * light_spectrum(l, lambda);
+            return s;
+        }
+        case HK_LIGHT_ENVIRONMENT: {  // lights.jl:158-190
+            const DEnvMap& e = sc.envmaps[l.Le_tex];
+            float map_pdf;
+            v2 uv = dist2d_sample(e, u, map_pdf);
+            v3 wi = env_uv_to_direction(e, uv);
+            float pdf = map_pdf / (4.0f * PI_F);
+            if (pdf <= 0.0f) return s;
+            float4 t = env_lookup_uv(e, uv);
+            s.wi = wi;
+            s.pdf = pdf;
+            s.p_light = p + 1.0e6f * wi;
+            s.Li = eval_illuminant(coef_illuminant(T, t.x * l.Le_rgba[0], t.y * l.Le_rgba[1], t.z * l.Le_rgba[2]), lambda);
             return s;
         }
         case HK_LIGHT_DIFFUSE_AREA: {

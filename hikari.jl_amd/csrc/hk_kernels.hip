@@ -487,9 +487,20 @@ __global__ void __launch_bounds__(256) k_escaped(DPathState st, DScene sc, DTabl
         uint32_t slot = queue[i];
         S4 lambda = ld4(&st.lambda[slot]);
         S4 Le = s4(0.0f);
+        v3 rd = mk3(0, 0, 1);
+        bool have_dir = false;
         for (int li = 0; li < sc.n_lights; ++li) {
             const DLight& l = sc.lights[li];
             if (l.kind == HK_LIGHT_AMBIENT) Le = Le + l.scale * light_spectrum(l, lambda);
+            if (l.kind == HK_LIGHT_ENVIRONMENT) {  // bilinear env(dir) * scale, illuminant uplift (lights.jl:408-419)
+                if (!have_dir) {
+                    float4 D = st.ray_d[slot];
+                    rd = mk3(D.x, D.y, D.z);
+                    have_dir = true;
+                }
+                float4 t = env_eval(sc.envmaps[l.Le_tex], rd);
+                Le = Le + eval_illuminant(coef_illuminant(T, t.x * l.Le_rgba[0], t.y * l.Le_rgba[1], t.z * l.Le_rgba[2]), lambda);
+            }
         }
         S4 beta = ld4(&st.beta[slot]);
         S4 contribution = beta * Le;
@@ -504,6 +515,11 @@ __global__ void __launch_bounds__(256) k_escaped(DPathState st, DScene sc, DTabl
         else {
             float choice = sc.n_lights > 0 ? 1.0f / (float)sc.n_lights : 0.0f;
             float light_pdf = 0.0f;  // only EnvironmentLight has a pdf (lights.jl:445-467)
+            if (sc.n_envmaps > 0)
+                for (int li = 0; li < sc.n_lights; ++li) {
+                    const DLight& l = sc.lights[li];
+                    light_pdf = light_pdf + (l.kind == HK_LIGHT_ENVIRONMENT ? env_pdf_li(sc.envmaps[l.Le_tex], rd) : 0.0f);
+                }
             S4 rl = ld4(&st.r_l[slot]) * choice * light_pdf;
             float den = average(r_u + rl);
             fin = den > 1e-10f ? contribution / den : contribution / average(r_u);
@@ -1032,6 +1048,33 @@ __global__ void k_test_bsdf(DScene sc, DTables T, int mode, int mat_idx, int reg
     }
 #undef HK_TB_CASE
 }
+__global__ void k_test_light(DScene sc, DTables T, int mode, int light_idx, int n, const float* p3, const float* in3, const float* lambda, float* out) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        S4 l = s4(lambda[4 * i], lambda[4 * i + 1], lambda[4 * i + 2], lambda[4 * i + 3]);
+        v3 a = mk3(in3[3 * i], in3[3 * i + 1], in3[3 * i + 2]);
+        float* r = out + 12 * (size_t)i;
+        for (int k = 0; k < 12; ++k) r[k] = 0.0f;
+        if (mode == 0) {
+            LightSample ls = sample_light(sc, T, sc.lights[light_idx - 1], mk3(p3[3 * i], p3[3 * i + 1], p3[3 * i + 2]), l, mk2(a.x, a.y));
+            r[0] = ls.wi.x, r[1] = ls.wi.y, r[2] = ls.wi.z, r[3] = ls.pdf;
+            r[4] = ls.Li.x, r[5] = ls.Li.y, r[6] = ls.Li.z, r[7] = ls.Li.w;
+            r[8] = ls.p_light.x, r[9] = ls.p_light.y, r[10] = ls.p_light.z, r[11] = ls.is_delta ? 1.0f : 0.0f;
+        } else {
+            S4 Le = s4(0.0f);
+            float pdf = 0.0f;
+            for (int li = 0; li < sc.n_lights; ++li) {
+                const DLight& L = sc.lights[li];
+                if (L.kind == HK_LIGHT_AMBIENT) Le = Le + L.scale * light_spectrum(L, l);
+                if (L.kind == HK_LIGHT_ENVIRONMENT) {
+                    float4 t = env_eval(sc.envmaps[L.Le_tex], a);
+                    Le = Le + eval_illuminant(coef_illuminant(T, t.x * L.Le_rgba[0], t.y * L.Le_rgba[1], t.z * L.Le_rgba[2]), l);
+                    pdf = pdf + env_pdf_li(sc.envmaps[L.Le_tex], a);
+                }
+            }
+            r[0] = Le.x, r[1] = Le.y, r[2] = Le.z, r[3] = Le.w, r[4] = pdf;
+        }
+    }
+}
 void launch_test_trace(hipStream_t s, const DScene& sc, int n, const float* o, const float* d, const float* tmax, float* t, int* prim, float* uv) {
     hipLaunchKernelGGL(k_test_trace, dim3(grid_for(n, HK_TRACE_BLOCK, 1280)), dim3(HK_TRACE_BLOCK), 0, s, sc, n, o, d, tmax, t, prim, uv);
 }
@@ -1051,6 +1094,9 @@ void launch_test_light_bvh(hipStream_t s, const DScene& sc, int n, const float* 
 void launch_test_bsdf(hipStream_t s, const DScene& sc, const DTables& T, int mode, int mat_idx, int regularize, int n, const float* wo, const float* wi, const float* ns,
                       const float* lambda, const float* u, const float* uc, float* out) {
     hipLaunchKernelGGL(k_test_bsdf, dim3(grid_for(n, 64, 4096)), dim3(64), 0, s, sc, T, mode, mat_idx, regularize, n, wo, wi, ns, lambda, u, uc, out);
+}
+void launch_test_light(hipStream_t s, const DScene& sc, const DTables& T, int mode, int light_idx, int n, const float* p3, const float* in3, const float* lambda, float* out) {
+    hipLaunchKernelGGL(k_test_light, dim3(grid_for(n, 64, 4096)), dim3(64), 0, s, sc, T, mode, light_idx, n, p3, in3, lambda, out);
 }
 
 }  // namespace hk

@@ -72,6 +72,19 @@ struct DLight {
     int pad;
 };
 
+// EnvironmentMap + Distribution2D (textures/environment_map.jl:9-45; sampler/sampling.jl:179-262), Julia layouts kept
+struct DEnvMap {
+    const float4* data;            // texel (y, x) at [y + height * x]
+    const float* cond_func;        // [nu, nv]: (u, v) at [u + nu * v]
+    const float* cond_cdf;         // [nu + 1, nv]
+    const float* cond_func_int;    // [nv]
+    const float* marg_func;        // [nv]
+    const float* marg_cdf;         // [nv + 1]
+    float marg_func_int;
+    int width, height, nu, nv;
+    float rot[9];                  // row-major Mat3f
+};
+
 struct DLightNode {  // 64 B
     float bmin[3], bmax[3], w[3];
     float phi, cos_o, cos_e;
@@ -127,6 +140,8 @@ struct DScene {
     int num_bvh_lights, num_infinite_lights;
     const DMedium* media;
     int n_media;
+    const DEnvMap* envmaps;
+    int n_envmaps;
     int has_escape_lights;      // any ambient / environment light
     int all_opaque;             // no medium transitions and no alpha-tested surfaces
 };

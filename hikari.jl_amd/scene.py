@@ -29,6 +29,7 @@ class Scene:
         self._meshes = []           # (Mesh world-space, per-face metas)
         self.textures = []
         self.spectra = []
+        self._envmaps = []
         self._desc = None
         self._keep = None
         self.bounds = None
@@ -153,6 +154,13 @@ class Scene:
         self.textures.append(tex)
         return len(self.textures) - 1
 
+    def _envmap_index(self, env):
+        for i, e in enumerate(self._envmaps):
+            if e is env:
+                return i
+        self._envmaps.append(env)
+        return len(self._envmaps) - 1
+
     def _spectrum_index(self, sp):
         for i, s in enumerate(self.spectra):
             if s is sp:
@@ -235,6 +243,12 @@ class Scene:
             r.Le = self._tex_rgba(l.Le, keep)
             r.two_sided = 1 if l.two_sided else 0
             return r
+        if l.kind == A.HK_LIGHT_ENVIRONMENT:
+            r.spectrum_kind = A.HK_SPEC_RGB
+            r.i_rgb[:] = l.scale_rgb.c
+            r.scale = 1.0
+            r.envmap = self._envmap_index(l.env_map)
+            return r
         sf = L._spec_fields(l.i)
         r.spectrum_kind = sf["spectrum_kind"]
         r.i_rgb[:] = sf["i_rgb"]
@@ -274,6 +288,7 @@ class Scene:
         for i, (a, b, c) in enumerate(self.media_interfaces):
             mis[i].material, mis[i].inside, mis[i].outside = a, b, c
         fl = self.flat_lights()
+        self._envmaps = []
         lts = (A.hk_light * max(1, len(fl)))()
         for i, l in enumerate(fl):
             lts[i] = self._light_record(l, keep)
@@ -295,7 +310,10 @@ class Scene:
         keep.append(media_keep)
         d = A.hk_scene_desc()
         d.n_triangles, d.n_materials, d.n_textures = T, len(self.materials), len(self.textures)
-        d.n_media_interfaces, d.n_lights, d.n_envmaps, d.n_media, d.n_spectra = len(self.media_interfaces), len(fl), 0, len(self.media), len(self.spectra)
+        envs = (A.hk_envmap * max(1, len(self._envmaps)))()
+        for i, e in enumerate(self._envmaps):
+            envs[i] = e.record()
+        d.n_media_interfaces, d.n_lights, d.n_envmaps, d.n_media, d.n_spectra = len(self.media_interfaces), len(fl), len(self._envmaps), len(self.media), len(self.spectra)
         d.positions = P.ctypes.data_as(A.PF)
         d.normals = Nn.ctypes.data_as(A.PF) if Nn is not None else None
         d.uvs = np.ascontiguousarray(Uv, dtype=f32).ctypes.data_as(A.PF) if Uv is not None else None
@@ -308,8 +326,8 @@ class Scene:
         d.tangents = None
         d.meta = metas.ctypes.data_as(C.POINTER(A.hk_tri_meta))
         d.materials, d.textures, d.media_interfaces, d.lights = mats, texs, mis, lts
-        d.envmaps, d.media, d.spectra = None, media_recs, specs
-        self._keep = (P, Nn, Uv, metas, mats, mis, lts, texs, specs, keep, media_recs)
+        d.envmaps, d.media, d.spectra = envs, media_recs, specs
+        self._keep = (P, Nn, Uv, metas, mats, mis, lts, texs, specs, keep, media_recs, envs, list(self._envmaps))
         self._desc = d
         if T:
             lo, hi = P.reshape(-1, 3).min(axis=0), P.reshape(-1, 3).max(axis=0)

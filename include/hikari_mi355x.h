@@ -361,6 +361,11 @@ int32_t hk_test_light_bvh(hk_ctx* ctx, hk_scene* scene, int32_t n, const float* 
    wo/wi/ns: 3n floats, lambda: 4n, u: 2n, uc: n. */
 int32_t hk_test_bsdf(hk_ctx* ctx, hk_scene* scene, int32_t mode, int32_t mat_idx, int32_t regularize, int32_t n, const float* wo,
                      const float* wi, const float* ns, const float* lambda, const float* u, const float* uc, float* out);
+/* point-wise lights (physical-wavefront/lights.jl:39-297, 408-467):
+   mode 0 = sample_light_spectral(light_idx_1based, p, lambda, u = in3.xy) -> out[12n] = wi3, pdf, Li4, p_light3, is_delta
+   mode 1 = escaped ray along in3 -> out[12n] = Le4 summed over every light, environment pdf, 0... */
+int32_t hk_test_light(hk_ctx* ctx, hk_scene* scene, int32_t mode, int32_t light_idx_1based, int32_t n, const float* p3,
+                      const float* in3, const float* lambda, float* out);
 
 /* introspection used by tests/bench */
 int32_t hk_scene_bvh_info(hk_scene* scene, int32_t* n_nodes, int32_t* n_leaf_tris, int32_t* max_depth);

@@ -19,6 +19,7 @@ namespace hko {
 struct TextureSet {
     const hk_texture* tex = nullptr;
     int32_t n = 0;
+    const hk_envmap* envmaps = nullptr;  // EnvironmentLight.env_map records (the reference derefs them through `lights`)
 };
 // _sample_texture_bilinear  src/textures/texture-ref.jl:151-186
 inline void tex_fetch(const hk_texture& t, int32_t y1b, int32_t x1b, float* out) {
@@ -60,6 +61,128 @@ inline float eval_tex(const TextureSet& ts, const hk_tex_f32& f, V2 uv) {
     sample_texture_bilinear(ts.tex[f.tex], uv, o);
     return o[0];
 }
+
+// ---- EnvironmentMap + Distribution2D -------------------------------------------------------------
+//   equal_area_sphere_to_square / square_to_sphere   src/textures/environment_map.jl:78-160
+//   direction_to_uv / uv_to_direction                src/textures/environment_map.jl:200-229
+//   env(dir) bilinear :290-338 ; lookup_uv nearest :358-371
+//   Distribution2D sample_continuous / pdf           src/sampler/sampling.jl:264-361
+inline V2 equal_area_sphere_to_square(V3 d) {
+    float x = std::fabs(d.x), y = std::fabs(d.y), z = std::fabs(d.z);
+    float r = std::sqrt(1.0f - z);
+    float a = maxf(x, y);
+    float b = a == 0.0f ? 0.0f : minf(x, y) / a;
+    const float t1 = 0.406758566246788489601959989e-5f, t2 = 0.636226545274016134946890922156f, t3 = 0.61572017898280213493197203466e-2f,
+                t4 = -0.247333733281268944196501420480f, t5 = 0.881770664775316294736387951347e-1f, t6 = 0.419038818029165735901852432784e-1f,
+                t7 = -0.251390972343483509333252996350e-1f;
+    float phi = t1 + b * (t2 + b * (t3 + b * (t4 + b * (t5 + b * (t6 + b * t7)))));
+    if (x < y) phi = 1.0f - phi;
+    float v = phi * r;
+    float u = r - v;
+    if (d.z < 0.0f) {
+        float tu = u;
+        u = v;
+        v = tu;
+        u = 1.0f - u;
+        v = 1.0f - v;
+    }
+    u = std::copysign(u, d.x);
+    v = std::copysign(v, d.y);
+    return V2(0.5f * (u + 1.0f), 0.5f * (v + 1.0f));
+}
+inline V3 equal_area_square_to_sphere(V2 p) {
+    float u = 2.0f * p.x - 1.0f, v = 2.0f * p.y - 1.0f;
+    float up = std::fabs(u), vp = std::fabs(v);
+    float sd = 1.0f - (up + vp);
+    float d = std::fabs(sd);
+    float r = 1.0f - d;
+    float phi = (r == 0.0f ? 1.0f : (vp - up) / r + 1.0f) * PI_F / 4.0f;
+    float z = std::copysign(1.0f - r * r, sd);
+    float cos_phi = std::copysign(std::cos(phi), u);
+    float sin_phi = std::copysign(std::sin(phi), v);
+    float r_cyl = r * std::sqrt(2.0f - r * r);
+    return V3(cos_phi * r_cyl, sin_phi * r_cyl, z);
+}
+// rotation is the reference's Mat3f, row-major in the record: R[i][j] = rotation[3*i + j]
+inline V3 env_rotate(const hk_envmap& e, V3 d) {  // rotation * d
+    const float* R = e.rotation;
+    return V3(R[0] * d.x + R[1] * d.y + R[2] * d.z, R[3] * d.x + R[4] * d.y + R[5] * d.z, R[6] * d.x + R[7] * d.y + R[8] * d.z);
+}
+inline V3 env_rotate_t(const hk_envmap& e, V3 d) {  // transpose(rotation) * d
+    const float* R = e.rotation;
+    return V3(R[0] * d.x + R[3] * d.y + R[6] * d.z, R[1] * d.x + R[4] * d.y + R[7] * d.z, R[2] * d.x + R[5] * d.y + R[8] * d.z);
+}
+inline V2 env_direction_to_uv(const hk_envmap& e, V3 dir) { return equal_area_sphere_to_square(env_rotate_t(e, dir)); }
+inline V3 env_uv_to_direction(const hk_envmap& e, V2 uv) { return env_rotate(e, equal_area_square_to_sphere(uv)); }
+inline RGBA env_texel(const hk_envmap& e, int32_t y1b, int32_t x1b) {  // data[y, x], Julia Matrix{RGBSpectrum}[h, w]
+    const float* p = e.data + ((size_t)(y1b - 1) + (size_t)e.height * (size_t)(x1b - 1)) * 4;
+    return RGBA(p[0], p[1], p[2], p[3]);
+}
+inline RGBA env_eval(const hk_envmap& e, V3 dir) {  // bilinear, :290-338
+    V2 uv = env_direction_to_uv(e, dir);
+    int32_t h = e.height, w = e.width;
+    float x = uv.x * (float)(w - 1) + 1.0f;
+    float y = uv.y * (float)(h - 1) + 1.0f;
+    int32_t x0 = floor_int32(x), y0 = floor_int32(y);
+    int32_t x1 = x0 + 1, y1 = y0 + 1;
+    x0 = clampi(x0, 1, w);
+    x1 = clampi(x1, 1, w);
+    y0 = clampi(y0, 1, h);
+    y1 = clampi(y1, 1, h);
+    x1 = x1 > w ? 1 : x1;
+    float fx = x - (float)floor_int32(x), fy = y - (float)floor_int32(y);
+    RGBA c00 = env_texel(e, y0, x0), c10 = env_texel(e, y0, x1), c01 = env_texel(e, y1, x0), c11 = env_texel(e, y1, x1);
+    RGBA o;
+    for (int c = 0; c < 4; ++c) {
+        float c0 = c00.c[c] * (1.0f - fx) + c10.c[c] * fx;
+        float c1 = c01.c[c] * (1.0f - fx) + c11.c[c] * fx;
+        o.c[c] = c0 * (1.0f - fy) + c1 * fy;
+    }
+    return o;
+}
+inline RGBA env_lookup_uv(const hk_envmap& e, V2 uv) {  // nearest, :358-371
+    int32_t ui = clampi(floor_int32(uv.x * (float)e.width) + 1, 1, e.width);
+    int32_t vi = clampi(floor_int32(uv.y * (float)e.height) + 1, 1, e.height);
+    return env_texel(e, vi, ui);
+}
+// branchless 20-step search (sampling.jl:305-333): last index with cdf[idx] <= u, 1-based over n entries of stride 1
+inline int32_t find_interval_binary20(const float* cdf, int32_t n, float u) {
+    int32_t lo = 1, hi = n;
+    for (int k = 0; k < 20; ++k) {
+        int32_t mid = (lo + hi + 1) / 2;
+        bool c = cdf[mid - 1] <= u;
+        lo = c ? mid : lo;
+        hi = c ? hi : mid - 1;
+    }
+    return lo;
+}
+inline V2 dist2d_sample(const hk_envmap& e, V2 u, float& pdf) {
+    const int32_t nu = e.nu, nv = e.nv;
+    int32_t vo = clampi(find_interval_binary20(e.marginal_cdf, nv + 1, u.y), 1, nv);
+    float du_v = u.y - e.marginal_cdf[vo - 1];
+    float den_v = e.marginal_cdf[vo] - e.marginal_cdf[vo - 1];
+    if (den_v > 0.0f) du_v /= den_v;
+    float v_s = ((float)(vo - 1) + du_v) / (float)nv;
+    float pdf_v = e.marginal_func_int > 0.0f ? e.marginal_func[vo - 1] / e.marginal_func_int : 0.0f;
+    const float* ccdf = e.conditional_cdf + (size_t)(vo - 1) * (size_t)(nu + 1);
+    int32_t uo = clampi(find_interval_binary20(ccdf, nu + 1, u.x), 1, nu);
+    float du_u = u.x - ccdf[uo - 1];
+    float den_u = ccdf[uo] - ccdf[uo - 1];
+    if (den_u > 0.0f) du_u /= den_u;
+    float u_s = ((float)(uo - 1) + du_u) / (float)nu;
+    float fiv = e.conditional_func_int[vo - 1];
+    float pdf_u = fiv > 0.0f ? e.conditional_func[(size_t)(vo - 1) * nu + (uo - 1)] / fiv : 0.0f;
+    pdf = pdf_u * pdf_v;
+    return V2(u_s, v_s);
+}
+inline float dist2d_pdf(const hk_envmap& e, V2 uv) {
+    int32_t iu = clampi(floor_int32(uv.x * (float)e.nu) + 1, 1, e.nu);
+    int32_t iv = clampi(floor_int32(uv.y * (float)e.nv) + 1, 1, e.nv);
+    return e.conditional_func[(size_t)(iv - 1) * e.nu + (iu - 1)] / e.marginal_func_int;
+}
+inline RGBA rgba_mul(const RGBA& a, const RGBA& b) { return RGBA(a.c[0] * b.c[0], a.c[1] * b.c[1], a.c[2] * b.c[2], a.c[3] * b.c[3]); }
+// pdf_li_spectral(EnvironmentLight)  physical-wavefront/lights.jl:336-347
+inline float env_pdf_li(const hk_envmap& e, V3 wi) { return dist2d_pdf(e, env_direction_to_uv(e, wi)) / (4.0f * PI_F); }
 
 struct LightSample {
     Spec Li;
@@ -144,6 +267,21 @@ inline LightSample sample_light_spectral(const RGB2SpecTable& t, const TextureSe
             s.pdf = 1.0f / (4.0f * PI_F);
             s.p_light = p + 1.0e6f * wi;
             s.Li = l.scale * light_spectrum(t, l, w);
+            s.is_delta = false;
+            return s;
+        }
+        case HK_LIGHT_ENVIRONMENT: {  // lights.jl:158-190
+            const hk_envmap& e = ts.envmaps[l.envmap];
+            float map_pdf;
+            V2 uv = dist2d_sample(e, u, map_pdf);
+            V3 wi = env_uv_to_direction(e, uv);
+            float pdf = map_pdf / (4.0f * PI_F);
+            if (pdf <= 0.0f) return s;
+            RGBA Li_rgb = rgba_mul(env_lookup_uv(e, uv), RGBA(l.i_rgb[0], l.i_rgb[1], l.i_rgb[2], l.i_rgb[3]));
+            s.wi = wi;
+            s.pdf = pdf;
+            s.p_light = p + 1.0e6f * wi;
+            s.Li = uplift_rgb_illuminant(t, Li_rgb, w);
             s.is_delta = false;
             return s;
         }

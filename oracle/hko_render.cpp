@@ -345,17 +345,22 @@ static Spec evaluate_escaped(const Scene& sc, V3 ray_d, const Wavelengths& lambd
         const hk_light& l = sc.desc.lights[i];
         if (l.kind == HK_LIGHT_AMBIENT)
             sum = sum + l.scale * light_spectrum(sc.table, l, lambda);
-        else
+        else if (l.kind == HK_LIGHT_ENVIRONMENT) {  // lights.jl:408-419: bilinear env(dir) * scale, illuminant uplift
+            RGBA Le_rgb = rgba_mul(env_eval(sc.desc.envmaps[l.envmap], ray_d), RGBA(l.i_rgb[0], l.i_rgb[1], l.i_rgb[2], l.i_rgb[3]));
+            sum = sum + uplift_rgb_illuminant(sc.table, Le_rgb, lambda);
+        } else
             sum = sum + Spec(0.0f);
     }
-    (void)ray_d;
     return sum;
 }
 // compute_env_light_pdf  physical-wavefront/lights.jl:445-467 (only EnvironmentLight contributes)
 static float env_light_pdf(const Scene& sc, V3 ray_d) {
-    (void)sc;
-    (void)ray_d;
-    return 0.0f;
+    float sum = 0.0f;
+    for (int32_t i = 0; i < sc.desc.n_lights; ++i) {
+        const hk_light& l = sc.desc.lights[i];
+        sum = sum + (l.kind == HK_LIGHT_ENVIRONMENT ? env_pdf_li(sc.desc.envmaps[l.envmap], ray_d) : 0.0f);
+    }
+    return sum;
 }
 static LightSample sample_light_full(const Scene& sc, int32_t light_idx_1based, V3 p, const Wavelengths& lambda, V2 u) {
     return sample_light_spectral(sc.table, sc.textures, sc.desc.lights[light_idx_1based - 1], p, lambda, u);
@@ -1035,6 +1040,7 @@ int32_t hko_scene_create(const hk_scene_desc* desc, const hk_tables* tables, hko
     sc.sobol = tables->sobol_matrices;
     sc.textures.tex = desc->textures;
     sc.textures.n = desc->n_textures;
+    sc.textures.envmaps = desc->envmaps;
     sc.mctx.table = &sc.table;
     sc.mctx.textures = sc.textures;
     sc.mctx.materials = desc->materials;
@@ -1253,6 +1259,31 @@ int32_t hko_bsdf(hko_scene* s, int32_t mode, int32_t mat_idx, int32_t regularize
             Spec f = eval_bsdf_all(sc.mctx, mat_idx, o, d, nn, V2(0, 0), w, pdf);
             for (int k = 0; k < 4; ++k) r[k] = f[k];
             r[4] = pdf;
+        }
+    }
+    return 0;
+}
+
+// Point-wise light sampling / escaped-ray evaluation (physical-wavefront/lights.jl:39-297, 408-467), n points:
+//   mode 0: sample_light_spectral(light `light_idx_1based`, p, lambda, u = in3.xy) -> out[12] = wi3, pdf, Li4, p_light3, is_delta
+//   mode 1: escaped ray with direction in3: out[12] = Le4 (all lights), env pdf, 0...
+int32_t hko_light(hko_scene* s, int32_t mode, int32_t light_idx_1based, int32_t n, const float* p3, const float* in3, const float* lambda, float* out) {
+    Scene& sc = s->sc;
+    for (int i = 0; i < n; ++i) {
+        Wavelengths w;
+        for (int k = 0; k < 4; ++k) w.lambda[k] = lambda[4 * i + k], w.pdf[k] = 1.0f;
+        float* r = out + 12 * (size_t)i;
+        for (int k = 0; k < 12; ++k) r[k] = 0.0f;
+        V3 a(in3[3 * i], in3[3 * i + 1], in3[3 * i + 2]);
+        if (mode == 0) {
+            LightSample ls = sample_light_full(sc, light_idx_1based, V3(p3[3 * i], p3[3 * i + 1], p3[3 * i + 2]), w, V2(a.x, a.y));
+            r[0] = ls.wi.x, r[1] = ls.wi.y, r[2] = ls.wi.z, r[3] = ls.pdf;
+            for (int k = 0; k < 4; ++k) r[4 + k] = ls.Li[k];
+            r[8] = ls.p_light.x, r[9] = ls.p_light.y, r[10] = ls.p_light.z, r[11] = ls.is_delta ? 1.0f : 0.0f;
+        } else {
+            Spec Le = evaluate_escaped(sc, a, w);
+            for (int k = 0; k < 4; ++k) r[k] = Le[k];
+            r[4] = env_light_pdf(sc, a);
         }
     }
     return 0;

@@ -36,6 +36,7 @@ def lib():
         L.hko_camera.argtypes = [C.POINTER(C.c_uint32), C.POINTER(A.hk_integrator_params), C.POINTER(A.hk_camera), i32, i32, i32, PI, PI, PI, PF]
         L.hko_uplift.argtypes = [C.POINTER(A.hk_tables), i32, i32, PF, PF, PF]
         L.hko_light_bvh.argtypes = [vp, i32, PF, PF, PF, PI, PF, PI, PF]
+        L.hko_light.argtypes = [vp, i32, i32, i32, PF, PF, PF, PF]
         L.hko_bsdf.argtypes = [vp, i32, i32, i32, i32, PF, PF, PF, PF, PF, PF, PF]
         L.hko_light_bvh_copy.argtypes = [vp, PI, PF, C.POINTER(C.c_uint32)]
         L.hko_murmur64a.argtypes = [C.c_char_p, i32, C.c_uint64]
@@ -128,6 +129,15 @@ class OracleScene:
         q = np.ascontiguousarray(query if query is not None else np.zeros(m), np.int32)
         lib().hko_light_bvh(self.h, m, _pf(p), _pf(n), _pf(u), _pi(li), _pf(pmf), _pi(q), _pf(qp))
         return li, pmf, qp
+
+    def light(self, mode, light_idx_1based, p, x, lam):
+        """mode 0: sample_light_spectral(light, p, lambda, u = x[:, :2]) -> [n, 12] = wi3, pdf, Li4, p_light3, is_delta;
+        mode 1: escaped ray along x -> Le4 (all lights), env pdf"""
+        a = [np.ascontiguousarray(v, np.float32) for v in (p, x, lam)]
+        n = a[0].shape[0]
+        out = np.zeros((n, 12), np.float32)
+        lib().hko_light(self.h, mode, light_idx_1based, n, *[_pf(v) for v in a], _pf(out))
+        return out
 
     def bsdf(self, mode, mat_idx, wo, wi, ns, lam, u, uc, regularize=False):
         """point-wise sample_bsdf_spectral (mode 0) / evaluate_bsdf_spectral (mode 1) -> [n, 10]"""

@@ -15,7 +15,7 @@ from .materials import (CoatedConductorMaterial, CoatedDiffuseMaterial, CoatedDi
                         ConductorMaterial, DiffuseTransmissionMaterial, Emissive, GlassMaterial, MatteMaterial,
                         MediumInterface, MirrorMaterial, MixMaterial, PiecewiseLinearSpectrum, PlasticMaterial,
                         RGBSpectrum, Texture, ThinDielectricMaterial)
-from .media import GridMedium, HomogeneousMedium, NanoVDBMedium
+from .media import GridMedium, HomogeneousMedium, NanoVDBMedium, RGBGridMedium
 from .scene import Scene
 from .volpath import (BoxFilter, Context, GaussianFilter, LanczosSincFilter, MitchellFilter, TriangleFilter, VolPath,
                       integrator_params, scene_handle)

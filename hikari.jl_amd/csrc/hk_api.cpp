@@ -512,9 +512,13 @@ extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene**
     for (int i = 0; i < d->n_media; ++i) {
         const hk_medium& m = d->media[i];
         DMedium& o = dmed[i];
-        if (m.kind != HK_MEDIUM_HOMOGENEOUS && m.kind != HK_MEDIUM_GRID && m.kind != HK_MEDIUM_NANOVDB) {
+        if (m.kind < HK_MEDIUM_HOMOGENEOUS || m.kind > HK_MEDIUM_NANOVDB) {
             delete s;
-            return fail(HK_ERR_UNSUPPORTED, "RGBGridMedium is not built yet (SURVEY 8 row a27)");
+            return fail(HK_ERR_INVALID, "unknown medium kind");
+        }
+        if (m.kind == HK_MEDIUM_RGB_GRID && ((!m.sigma_a_grid && !m.sigma_s_grid) || (m.Le_grid && !m.sigma_a_grid))) {  // media.jl:1073-1079
+            delete s;
+            return fail(HK_ERR_INVALID, "RGBGridMedium needs sigma_a_grid or sigma_s_grid (and sigma_a_grid when Le_grid is given)");
         }
         o.kind = m.kind;
         o.g = m.g;
@@ -549,6 +553,20 @@ extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene**
             s->media_data.push_back(db);
             HIP_TRY(db->upload(m.density, (size_t)m.res[0] * m.res[1] * m.res[2] * 4));
             o.density = db->as<float>();
+        }
+        if (m.kind == HK_MEDIUM_RGB_GRID) {
+            const size_t nvox = (size_t)m.res[0] * m.res[1] * m.res[2];
+            const float* src[3] = {m.sigma_a_grid, m.sigma_s_grid, m.Le_grid};
+            const float4** dst[3] = {&o.rgb_a, &o.rgb_s, &o.rgb_Le};
+            for (int g = 0; g < 3; ++g) {
+                if (!src[g]) continue;
+                DevBuf* gb = new DevBuf();
+                s->media_data.push_back(gb);
+                HIP_TRY(gb->upload(src[g], nvox * 16));
+                *dst[g] = gb->as<float4>();
+            }
+            o.sigma_scale = m.sigma_scale;
+            o.Le_scale = m.Le_scale;
         }
         if (m.kind == HK_MEDIUM_NANOVDB) {
             DevBuf* nb = new DevBuf();

@@ -1518,7 +1518,7 @@ HKD MajorantIter create_majorant_iterator(const DMedium& m, v3 ro, v3 rd, float 
         return it;
     }
     v3 o = ro, d = rd;
-    if (m.kind == HK_MEDIUM_GRID) {
+    if (m.kind == HK_MEDIUM_GRID || m.kind == HK_MEDIUM_RGB_GRID) {
         const float* M = m.r2m;
         o = mk3(M[0] * ro.x + M[1] * ro.y + M[2] * ro.z + M[3], M[4] * ro.x + M[5] * ro.y + M[6] * ro.z + M[7], M[8] * ro.x + M[9] * ro.y + M[10] * ro.z + M[11]);
         d = mk3(M[0] * rd.x + M[1] * rd.y + M[2] * rd.z, M[4] * rd.x + M[5] * rd.y + M[6] * rd.z, M[8] * rd.x + M[9] * rd.y + M[10] * rd.z);
@@ -1555,7 +1555,7 @@ HKD MajorantIter create_majorant_iterator(const DMedium& m, v3 ro, v3 rd, float 
             it.limit[k] = -1;
         }
     }
-    it.sigma_t = sigma_t;
+    it.sigma_t = m.kind == HK_MEDIUM_RGB_GRID ? s4(1.0f) : sigma_t;  // RGBGrid: unit sigma_t, scale is in the majorant grid (media.jl:1408-1420)
     it.t_min = t_enter;
     it.t_max = t_exit;
     it.hom_called = false;
@@ -1713,13 +1713,45 @@ struct MediumProps {
 };
 // sigma_a/sigma_s spectra are constant per medium and wavelength set: callers evaluate them once per ray
 // (`base_*`) and sample_point only fetches the density (same arithmetic: uplift * d)
-HKD MediumProps sample_point(const DMedium& m, S4 base_a, S4 base_s, S4 base_Le, v3 p) {
+HKD float4 rgb_grid_at(const float4* g, const DMedium& m, int ix, int iy, int iz) {
+    return g[(size_t)(ix - 1) + (size_t)m.res[0] * ((size_t)(iy - 1) + (size_t)m.res[1] * (size_t)(iz - 1))];
+}
+HKD float4 lerp4(float4 a, float wa, float4 b, float wb) { return make_float4(a.x * wa + b.x * wb, a.y * wa + b.y * wb, a.z * wa + b.z * wb, 0.0f); }
+HKD float4 sample_rgb_grid(const float4* g, const DMedium& m, v3 pn) {  // media.jl:1282-1324
+    if (pn.x < 0.0f || pn.y < 0.0f || pn.z < 0.0f || pn.x > 1.0f || pn.y > 1.0f || pn.z > 1.0f) return make_float4(0, 0, 0, 0);
+    int nx = m.res[0], ny = m.res[1], nz = m.res[2];
+    float gx = pn.x * (float)nx + 0.5f, gy = pn.y * (float)ny + 0.5f, gz = pn.z * (float)nz + 0.5f;
+    int ix = clampi((int)floorf(gx), 1, nx - 1), iy = clampi((int)floorf(gy), 1, ny - 1), iz = clampi((int)floorf(gz), 1, nz - 1);
+    float fx = clampf(gx - (float)ix, 0.0f, 1.0f), fy = clampf(gy - (float)iy, 0.0f, 1.0f), fz = clampf(gz - (float)iz, 0.0f, 1.0f);
+    float fx1 = 1.0f - fx, fy1 = 1.0f - fy;
+    float4 c00 = lerp4(rgb_grid_at(g, m, ix, iy, iz), fx1, rgb_grid_at(g, m, ix + 1, iy, iz), fx);
+    float4 c10 = lerp4(rgb_grid_at(g, m, ix, iy + 1, iz), fx1, rgb_grid_at(g, m, ix + 1, iy + 1, iz), fx);
+    float4 c01 = lerp4(rgb_grid_at(g, m, ix, iy, iz + 1), fx1, rgb_grid_at(g, m, ix + 1, iy, iz + 1), fx);
+    float4 c11 = lerp4(rgb_grid_at(g, m, ix, iy + 1, iz + 1), fx1, rgb_grid_at(g, m, ix + 1, iy + 1, iz + 1), fx);
+    return lerp4(lerp4(c00, fy1, c10, fy), 1.0f - fz, lerp4(c01, fy1, c11, fy), fz);
+}
+HKD MediumProps sample_point(const DTables& T, S4 lambda, const DMedium& m, S4 base_a, S4 base_s, S4 base_Le, v3 p) {
     MediumProps mp;
     mp.g = m.g;
     if (m.kind == HK_MEDIUM_HOMOGENEOUS) {
         mp.sigma_a = base_a;
         mp.sigma_s = base_s;
         mp.Le = base_Le;
+        return mp;
+    }
+    if (m.kind == HK_MEDIUM_RGB_GRID) {  // media.jl:1327-1370: per-point uplift_rgb_unbounded of the interpolated RGB
+        const float* M = m.r2m;
+        v3 pm = mk3(M[0] * p.x + M[1] * p.y + M[2] * p.z + M[3], M[4] * p.x + M[5] * p.y + M[6] * p.z + M[7], M[8] * p.x + M[9] * p.y + M[10] * p.z + M[11]);
+        v3 pn = mk3((pm.x - m.bmin[0]) / (m.bmax[0] - m.bmin[0]), (pm.y - m.bmin[1]) / (m.bmax[1] - m.bmin[1]), (pm.z - m.bmin[2]) / (m.bmax[2] - m.bmin[2]));
+        float4 a = m.rgb_a ? sample_rgb_grid(m.rgb_a, m, pn) : make_float4(1, 1, 1, 1);
+        float4 sc = m.rgb_s ? sample_rgb_grid(m.rgb_s, m, pn) : make_float4(1, 1, 1, 1);
+        mp.sigma_a = eval_scaled(coef_unbounded(T, a.x, a.y, a.z), lambda) * m.sigma_scale;
+        mp.sigma_s = eval_scaled(coef_unbounded(T, sc.x, sc.y, sc.z), lambda) * m.sigma_scale;
+        mp.Le = s4(0.0f);
+        if (m.rgb_Le && m.Le_scale > 0.0f) {
+            float4 e = sample_rgb_grid(m.rgb_Le, m, pn);
+            mp.Le = eval_scaled(coef_unbounded(T, e.x, e.y, e.z), lambda) * m.Le_scale;
+        }
         return mp;
     }
     float d;
@@ -1734,7 +1766,7 @@ HKD MediumProps sample_point(const DMedium& m, S4 base_a, S4 base_s, S4 base_Le,
     return mp;
 }
 // compute_transmittance_ratio_tracking (intersection.jl:422-542)
-HKD void ratio_tracking(const DMedium& m, v3 origin, v3 dir, float t_max, S4 lambda, S4& T_ray, S4& r_u, S4& r_l, unsigned& collisions) {
+HKD void ratio_tracking(const DTables& T, const DMedium& m, v3 origin, v3 dir, float t_max, S4 lambda, S4& T_ray, S4& r_u, S4& r_l, unsigned& collisions) {
     T_ray = s4(1.0f);
     r_u = s4(1.0f);
     r_l = s4(1.0f);
@@ -1764,7 +1796,7 @@ HKD void ratio_tracking(const DMedium& m, v3 origin, v3 dir, float t_max, S4 lam
                 break;
             }
             ++collisions;
-            MediumProps mp = sample_point(m, base_a, base_s, base_Le, origin + dir * ts);
+            MediumProps mp = sample_point(T, lambda, m, base_a, base_s, base_Le, origin + dir * ts);
             S4 sn = s4max0(sm - mp.sigma_a - mp.sigma_s);
             S4 Tm = s4exp((-dt) * sm);
             float pr = Tm.x * sm0;

@@ -304,7 +304,7 @@ __global__ void __launch_bounds__(256) k_medium(DPathState st, DScene sc, DTable
                         S4 Tm = s4exp((-dt) * sm);
                         v3 p = cur_o + rd * dt;
                         ++n_coll;
-                        MediumProps mp = sample_point(med, base_a, base_s, base_Le, p);
+                        MediumProps mp = sample_point(T, lambda, med, base_a, base_s, base_Le, p);
                         if (!is_black(mp.Le) && depth < fr.max_depth) {
                             float pr = sm0 * Tm.x;
                             if (pr > 1e-10f) {
@@ -722,7 +722,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_shadow(DPathState st, DScene
             if (h.prim < 0) {
                 if (medium >= 0) {  // transmittance of the remaining distance (intersection.jl:326-336)
                     S4 sT, su, sl;
-                    ratio_tracking(sc.media[medium], ro, dir, t_remaining, lambda, sT, su, sl, n_coll);
+                    ratio_tracking(T, sc.media[medium], ro, dir, t_remaining, lambda, sT, su, sl, n_coll);
                     T_ray = T_ray * sT;
                     tr_u = tr_u * su;
                     tr_l = tr_l * sl;
@@ -755,7 +755,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_shadow(DPathState st, DScene
             }
             if (medium >= 0) {  // transmittance up to this surface
                 S4 sT, su, sl;
-                ratio_tracking(sc.media[medium], ro, dir, h.t, lambda, sT, su, sl, n_coll);
+                ratio_tracking(T, sc.media[medium], ro, dir, h.t, lambda, sT, su, sl, n_coll);
                 T_ray = T_ray * sT;
                 tr_u = tr_u * su;
                 tr_l = tr_l * sl;

@@ -101,6 +101,10 @@ struct DMedium {
     float r2m[12];                 // render_to_medium rows 0..2 (affine)
     int res[3];
     const float* density;          // Grid: [nx,ny,nz] x fastest
+    const float4* rgb_a;           // RGBGrid: sigma_a / sigma_s / Le voxels (null = absent)
+    const float4* rgb_s;
+    const float4* rgb_Le;
+    float sigma_scale, Le_scale;
     int mres[3];
     const float* majorant;         // x + rx*(y + ry*z)
     const unsigned char* nvdb;     // NanoVDB bytes (tree part)

@@ -95,6 +95,78 @@ class GridMedium(Medium):
         rec.max_density = self.max_density
 
 
+def build_rgb_majorant_grid(sigma_a_grid, sigma_s_grid, sigma_scale, grid_size, res):
+    """build_rgb_majorant_grid (media.jl:1122-1183): sigma_scale * (max sigma_a component + max sigma_s component) per
+    coarse voxel; an absent grid counts as 1.  Returns float32[rx*ry*rz] indexed x + rx*(y + ry*z)."""
+    nx, ny, nz = grid_size
+    rx, ry, rz = res
+    out = np.zeros(rx * ry * rz, dtype=f32)
+    amax = sigma_a_grid[..., :3].max(axis=3) if sigma_a_grid is not None else None
+    smax = sigma_s_grid[..., :3].max(axis=3) if sigma_s_grid is not None else None
+    for iz in range(rz):
+        z0 = max(1, int(np.floor(iz * nz / rz)) + 1)
+        z1 = min(nz, int(np.ceil((iz + 1) * nz / rz)))
+        for iy in range(ry):
+            y0 = max(1, int(np.floor(iy * ny / ry)) + 1)
+            y1 = min(ny, int(np.ceil((iy + 1) * ny / ry)))
+            for ix in range(rx):
+                x0 = max(1, int(np.floor(ix * nx / rx)) + 1)
+                x1 = min(nx, int(np.ceil((ix + 1) * nx / rx)))
+                ma = f32(1.0) if amax is None else f32(max(0.0, float(amax[x0 - 1:x1, y0 - 1:y1, z0 - 1:z1].max(initial=0.0))))
+                ms = f32(1.0) if smax is None else f32(max(0.0, float(smax[x0 - 1:x1, y0 - 1:y1, z0 - 1:z1].max(initial=0.0))))
+                out[ix + rx * (iy + ry * iz)] = f32(sigma_scale) * (ma + ms)
+    return out
+
+
+class RGBGridMedium(Medium):
+    """RGBGridMedium(; σ_a_grid, σ_s_grid, Le_grid, sigma_scale=1, Le_scale=0, g=0, bounds, transform, majorant_res=(16,16,16))
+    (media.jl:1002-1113).  Grids are [nx, ny, nz, 3|4] RGB(A) voxels; an absent σ grid reads as RGBSpectrum(1)."""
+    kind = A.HK_MEDIUM_RGB_GRID
+
+    def __init__(self, sigma_a_grid=None, sigma_s_grid=None, Le_grid=None, sigma_scale=1.0, Le_scale=0.0, g=0.0,
+                 bounds=((0, 0, 0), (1, 1, 1)), transform=None, majorant_res=(16, 16, 16)):
+        assert sigma_a_grid is not None or sigma_s_grid is not None, "At least one of σ_a_grid or σ_s_grid must be provided"
+        if Le_grid is not None:
+            assert sigma_a_grid is not None, "Le_grid requires σ_a_grid to be provided (following pbrt-v4)"
+
+        def rgba(gd):
+            if gd is None:
+                return None
+            gd = np.asarray(gd, dtype=f32)
+            assert gd.ndim == 4 and gd.shape[3] in (3, 4)
+            if gd.shape[3] == 3:
+                gd = np.concatenate([gd, np.ones(gd.shape[:3] + (1,), f32)], axis=3)
+            return np.ascontiguousarray(gd)
+
+        self.sigma_a_grid, self.sigma_s_grid, self.Le_grid = rgba(sigma_a_grid), rgba(sigma_s_grid), rgba(Le_grid)
+        shapes = {gd.shape[:3] for gd in (self.sigma_a_grid, self.sigma_s_grid, self.Le_grid) if gd is not None}
+        assert len(shapes) == 1, "grids must have the same dimensions"
+        self.res = shapes.pop()
+        self.sigma_scale, self.Le_scale, self.g = float(f32(sigma_scale)), float(f32(Le_scale)), g
+        self.bounds = (tuple(float(f32(v)) for v in bounds[0]), tuple(float(f32(v)) for v in bounds[1]))
+        self.medium_to_render = np.eye(4, dtype=f32) if transform is None else np.asarray(transform, dtype=f32)
+        self.render_to_medium = np.linalg.inv(self.medium_to_render.astype(np.float64)).astype(f32)
+        self.majorant_res = tuple(int(v) for v in majorant_res)
+        self.majorant = build_rgb_majorant_grid(self.sigma_a_grid, self.sigma_s_grid, self.sigma_scale, self.res, self.majorant_res)
+
+    def fill_record(self, rec, keep):
+        _base_record(rec, self.kind, RGBSpectrum(0.0), RGBSpectrum(0.0), RGBSpectrum(0.0), self.g)
+        rec.sigma_scale, rec.Le_scale = self.sigma_scale, self.Le_scale
+        rec.bounds_min[:] = self.bounds[0]
+        rec.bounds_max[:] = self.bounds[1]
+        rec.render_to_medium[:] = [float(x) for x in self.render_to_medium.reshape(-1)]
+        rec.medium_to_render[:] = [float(x) for x in self.medium_to_render.reshape(-1)]
+        rec.res[:] = self.res
+        for name in ("sigma_a_grid", "sigma_s_grid", "Le_grid"):
+            gd = getattr(self, name)
+            if gd is not None:
+                jl = np.ascontiguousarray(np.transpose(gd, (2, 1, 0, 3)))   # C [z][y][x][c] == Julia [x,y,z] of RGBSpectrum
+                keep.append(jl)
+                setattr(rec, name, jl.ctypes.data_as(A.PF))
+        rec.majorant_res[:] = self.majorant_res
+        rec.majorant = self.majorant.ctypes.data_as(A.PF)
+
+
 # ---- NanoVDB -----------------------------------------------------------------------------------------------
 LEAF_DIM, LOWER_DIM, UPPER_DIM = 8, 16, 32
 LOWER_MASK, UPPER_MASK = 127, 4095

@@ -261,6 +261,28 @@ inline float sample_grid_density(const hk_medium& m, V3 pm) {
     float d0 = d00 * fy1 + d10 * fy, d1 = d01 * fy1 + d11 * fy;
     return d0 * (1.0f - fz) + d1 * fz;
 }
+// RGBGridMedium grids (media.jl:1252-1324): RGBSpectrum[x,y,z] Julia layout, 4 floats per voxel, cell-centred trilinear
+inline RGBA rgb_grid_at(const float* g, const hk_medium& m, int32_t ix, int32_t iy, int32_t iz) {
+    const float* p = g + 4 * ((size_t)(ix - 1) + (size_t)m.res[0] * ((size_t)(iy - 1) + (size_t)m.res[1] * (size_t)(iz - 1)));
+    return RGBA(p[0], p[1], p[2], p[3]);
+}
+inline RGBA rgba_lerp(const RGBA& a, float wa, const RGBA& b, float wb) {  // a*wa + b*wb
+    return RGBA(a.c[0] * wa + b.c[0] * wb, a.c[1] * wa + b.c[1] * wb, a.c[2] * wa + b.c[2] * wb, a.c[3] * wa + b.c[3] * wb);
+}
+inline RGBA sample_rgb_grid(const float* g, const hk_medium& m, const float pn[3]) {
+    if (pn[0] < 0.0f || pn[1] < 0.0f || pn[2] < 0.0f || pn[0] > 1.0f || pn[1] > 1.0f || pn[2] > 1.0f) return RGBA(0, 0, 0, 0);
+    int32_t nx = m.res[0], ny = m.res[1], nz = m.res[2];
+    float gx = pn[0] * (float)nx + 0.5f, gy = pn[1] * (float)ny + 0.5f, gz = pn[2] * (float)nz + 0.5f;
+    int32_t ix = clampi(floor_int32(gx), 1, nx - 1), iy = clampi(floor_int32(gy), 1, ny - 1), iz = clampi(floor_int32(gz), 1, nz - 1);
+    float fx = clampf(gx - (float)ix, 0.0f, 1.0f), fy = clampf(gy - (float)iy, 0.0f, 1.0f), fz = clampf(gz - (float)iz, 0.0f, 1.0f);
+    float fx1 = 1.0f - fx, fy1 = 1.0f - fy;
+    RGBA c00 = rgba_lerp(rgb_grid_at(g, m, ix, iy, iz), fx1, rgb_grid_at(g, m, ix + 1, iy, iz), fx);
+    RGBA c10 = rgba_lerp(rgb_grid_at(g, m, ix, iy + 1, iz), fx1, rgb_grid_at(g, m, ix + 1, iy + 1, iz), fx);
+    RGBA c01 = rgba_lerp(rgb_grid_at(g, m, ix, iy, iz + 1), fx1, rgb_grid_at(g, m, ix + 1, iy, iz + 1), fx);
+    RGBA c11 = rgba_lerp(rgb_grid_at(g, m, ix, iy + 1, iz + 1), fx1, rgb_grid_at(g, m, ix + 1, iy + 1, iz + 1), fx);
+    RGBA c0 = rgba_lerp(c00, fy1, c10, fy), c1 = rgba_lerp(c01, fy1, c11, fy);
+    return rgba_lerp(c0, 1.0f - fz, c1, fz);
+}
 inline V3 xform_affine_point(const float* M, V3 p) {
     return V3(M[0] * p.x + M[1] * p.y + M[2] * p.z + M[3], M[4] * p.x + M[5] * p.y + M[6] * p.z + M[7], M[8] * p.x + M[9] * p.y + M[10] * p.z + M[11]);
 }
@@ -284,6 +306,18 @@ inline MediumProperties sample_point(const MediaCtx& mc, int32_t idx, V3 p, cons
             mp.sigma_a = medium_uplift(mc, m.sigma_a, w) * d;
             mp.sigma_s = medium_uplift(mc, m.sigma_s, w) * d;
             mp.Le = Spec(0.0f);
+            return mp;
+        }
+        case HK_MEDIUM_RGB_GRID: {  // media.jl:1327-1370
+            V3 pm = xform_affine_point(m.render_to_medium, p);
+            float pn[3];
+            for (int k = 0; k < 3; ++k) pn[k] = (pm[k] - m.bounds_min[k]) / (m.bounds_max[k] - m.bounds_min[k]);
+            RGBA a = m.sigma_a_grid ? sample_rgb_grid(m.sigma_a_grid, m, pn) : RGBA(1, 1, 1, 1);
+            RGBA sc = m.sigma_s_grid ? sample_rgb_grid(m.sigma_s_grid, m, pn) : RGBA(1, 1, 1, 1);
+            mp.sigma_a = uplift_rgb_unbounded(*mc.table, a, w) * m.sigma_scale;
+            mp.sigma_s = uplift_rgb_unbounded(*mc.table, sc, w) * m.sigma_scale;
+            mp.Le = Spec(0.0f);
+            if (m.Le_grid && m.Le_scale > 0.0f) mp.Le = uplift_rgb_unbounded(*mc.table, sample_rgb_grid(m.Le_grid, m, pn), w) * m.Le_scale;
             return mp;
         }
         case HK_MEDIUM_NANOVDB: {
@@ -310,7 +344,7 @@ inline MajorantIter create_majorant_iterator(const MediaCtx& mc, int32_t idx, V3
         return it;
     }
     V3 o = ro, d = rd;
-    if (m.kind == HK_MEDIUM_GRID) {
+    if (m.kind == HK_MEDIUM_GRID || m.kind == HK_MEDIUM_RGB_GRID) {
         o = xform_affine_point(m.render_to_medium, ro);
         d = xform_affine_dir(m.render_to_medium, rd);
         float len_sq = d.x * d.x + d.y * d.y + d.z * d.z;
@@ -321,7 +355,8 @@ inline MajorantIter create_majorant_iterator(const MediaCtx& mc, int32_t idx, V3
     t_enter = maxf(t_enter, 0.0f);
     t_exit = minf(t_exit, t_max);
     if (t_enter >= t_exit) return it;
-    return create_dda(m.majorant, m.majorant_res, m.bounds_min, m.bounds_max, o, d, t_enter, t_exit, sa + ss);
+    // RGBGridMedium: unit sigma_t, the scale lives in the majorant grid (media.jl:1408-1420)
+    return create_dda(m.majorant, m.majorant_res, m.bounds_min, m.bounds_max, o, d, t_enter, t_exit, m.kind == HK_MEDIUM_RGB_GRID ? Spec(1.0f) : sa + ss);
 }
 
 // compute_transmittance_ratio_tracking + _ratio_tracking_dda (intersection.jl:422-542)

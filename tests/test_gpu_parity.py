@@ -192,6 +192,8 @@ MEDIA_CASES = [
     ("slab_homogeneous", dict(max_depth=6, samples=64), (24, 24)),
     ("slab_absorbing", dict(max_depth=6, samples=16), (24, 24)),
     ("slab_grid", dict(max_depth=6, samples=64), (24, 24)),
+    ("slab_rgbgrid", dict(max_depth=6, samples=64), (24, 24)),
+    ("slab_rgbgrid_absorbing", dict(max_depth=6, samples=16), (24, 24)),
     ("cloud_nanovdb", dict(max_depth=12, samples=32), (40, 40)),
     ("cloud_grid", dict(max_depth=12, samples=32), (40, 40)),
 ]
@@ -220,6 +222,17 @@ def _scene(name, w, h):
         dens = (rng.random((12, 10, 6)) ** 2).astype(np.float32) * 3.0
         return scenes.slab_scene(w, h, hk.GridMedium(dens, sigma_a=hk.RGBSpectrum(0.1), sigma_s=hk.RGBSpectrum(1.0, 0.9, 0.8), g=-0.2,
                                                     bounds=((-2.5, -2.6, 1.0), (2.5, 2.6, 2.0)), majorant_res=(4, 4, 2)))
+    if name in ("slab_rgbgrid", "slab_rgbgrid_absorbing"):
+        import hikari_jl_amd as hk
+        import numpy as np
+        rng = np.random.default_rng(11)
+        sa = (rng.random((10, 8, 6, 3)) * np.array([0.6, 0.9, 1.3])).astype(np.float32)
+        ss = (rng.random((10, 8, 6, 3)) ** 2 * np.array([2.0, 1.6, 1.2])).astype(np.float32)
+        le = (rng.random((10, 8, 6, 3)) * np.array([0.3, 0.1, 0.02])).astype(np.float32)
+        if name == "slab_rgbgrid_absorbing":
+            ss = np.zeros_like(ss)
+        return scenes.slab_scene(w, h, hk.RGBGridMedium(sigma_a_grid=sa, sigma_s_grid=ss, Le_grid=le, sigma_scale=1.5, Le_scale=0.8, g=0.3,
+                                                       bounds=((-2.5, -2.6, 1.0), (2.5, 2.6, 2.0)), majorant_res=(4, 4, 2)))
     if name == "cloud_nanovdb":
         return scenes.cloud_scene(w, h, "nanovdb", res=(48, 48, 24))
     if name == "cloud_grid":
@@ -332,7 +345,7 @@ def test_media_frame_parity_statistical(hk, oracle, name, kw, res):
     st = vp.stats()
     assert abs(int(st.rays_closest) - int(ostA.rays_closest)) <= 0.03 * ostA.rays_closest + 8
     assert int(st.rays_shadow) <= int(ostA.rays_shadow) * 1.03 + 8   # opaque early-exit can only save shadow segments
-    if name == "slab_absorbing":                                     # no scattering => no re-seeding => strict parity holds
+    if name in ("slab_absorbing", "slab_rgbgrid_absorbing"):        # no scattering => no re-seeding => strict parity holds
         rel_mse, frac_ok = frame_metrics(G, A)
         assert rel_mse <= 1e-3 and frac_ok >= 0.99, (rel_mse, frac_ok)
         assert int(st.medium_collisions) == int(ostA.medium_collisions)

@@ -304,7 +304,10 @@ def test_homogeneous_slab_transmittance_closed_form(hk, oracle):
     cases = [(hk.HomogeneousMedium(sigma_a=R(1.0), sigma_s=R(0.0)), np.exp(-1.0)),
              (hk.HomogeneousMedium(sigma_a=R(0.5), sigma_s=R(0.0)), np.exp(-0.5)),
              (hk.GridMedium(np.full((8, 8, 8), 0.7, np.float32), sigma_a=R(1.0), sigma_s=R(0.0), bounds=bounds), np.exp(-0.7)),
-             (hk.NanoVDBMedium(np.full((16, 16, 16), 0.7, np.float32), bounds=bounds, sigma_a=R(1.0), sigma_s=R(0.0), majorant_res=(8, 8, 8)), np.exp(-0.7))]
+             (hk.NanoVDBMedium(np.full((16, 16, 16), 0.7, np.float32), bounds=bounds, sigma_a=R(1.0), sigma_s=R(0.0), majorant_res=(8, 8, 8)), np.exp(-0.7)),
+             # RGBGridMedium (media.jl:1002-1370): grey sigma_a voxels 0.35 * sigma_scale 2, no scattering grid value (0)
+             (hk.RGBGridMedium(sigma_a_grid=np.full((6, 5, 4, 3), 0.35, np.float32), sigma_s_grid=np.zeros((6, 5, 4, 3), np.float32), sigma_scale=2.0,
+                               bounds=bounds, majorant_res=(3, 3, 2)), np.exp(-0.7))]
     for med, expected in cases:
         s1, _, c1 = scenes.slab_scene(16, 16, med)
         a1, st = oracle.OracleScene(s1).render(p, c1, 16, 16, 64)

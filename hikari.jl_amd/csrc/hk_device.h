@@ -718,11 +718,15 @@ HKD float4 rgb_param_coef(const DScene& sc, const DTables& T, const DSpectrumPar
     }
     return mode == UPLIFT_BOUNDED ? coef_bounded(T, o[0], o[1], o[2]) : coef_unbounded(T, o[0], o[1], o[2]);
 }
+// alpha goes through eval_tex(ctx, ref, uv::Point2f) == _sample_texture_data: NEAREST texel by truncation
+// (textures/basic.jl:19-26; spectral-eval.jl:3882-3885), unlike shading, which is bilinear (quirk Q28)
 HKD float rgb_param_alpha(const DScene& sc, const DSpectrumParam& p, v2 uv) {
     if (p.tex < 0) return p.rgba[3];
-    float o[4] = {0, 0, 0, 1};
-    tex_bilinear(sc.textures[p.tex], uv, o);
-    return o[3];
+    const DTexture& t = sc.textures[p.tex];
+    if (t.channels < 4) return 1.0f;
+    int i = clampi((int)(1.0f + (float)(t.height - 1) * (1.0f - uv.y)), 1, t.height);
+    int j = clampi((int)(1.0f + (float)(t.width - 1) * uv.x), 1, t.width);
+    return t.data[((size_t)(i - 1) + (size_t)t.height * (size_t)(j - 1)) * 4 + 3];
 }
 HKD float surface_alpha(const DScene& sc, int mat, v2 uv) {  // spectral-eval.jl:3882-3888
     const DMaterial& m = sc.materials[mat];

@@ -106,7 +106,16 @@ class Scene:
             uv = mesh.uvs[i] if mesh.uvs is not None else np.array([[0, 0], [1, 0], [1, 1]], dtype=f32)
             Le = em.Le
             if isinstance(Le, M.Texture):
-                raise NotImplementedError("textured emission")
+                # evaluate_face_emission (scene-mesh.jl:49): the texture is point-sampled ONCE at the face's centroid uv
+                # (evaluate_texture -> _sample_texture_data: nearest texel, (1-v, u) flip); the light carries that constant
+                cu = f32(f32(f32(uv[0][0] + uv[1][0]) + uv[2][0]) / f32(3))
+                cv = f32(f32(f32(uv[0][1] + uv[1][1]) + uv[2][1]) / f32(3))
+                d = Le.data
+                th, tw = d.shape[:2]
+                ti = min(max(int(f32(1) + f32(th - 1) * f32(f32(1) - cv)), 1), th)
+                tj = min(max(int(f32(1) + f32(tw - 1) * cu), 1), tw)
+                texel = d[ti - 1, tj - 1]
+                Le = M.RGBSpectrum(*[float(x) for x in np.atleast_1d(texel)[:4]]) if np.ndim(texel) else M.RGBSpectrum(float(texel))
             if _luminance(Le.c) < 1e-4:
                 continue
             e1, e2 = (vs[1] - vs[0]).astype(f32), (vs[2] - vs[0]).astype(f32)

@@ -3,6 +3,8 @@ way the reference's own examples/tests are written (examples/single_triangle_tes
 test/volpath_integration.jl:9-115; sizes and parameters per SURVEY.md §8d)."""
 import numpy as np
 
+f32 = np.float32
+
 from . import geometry as G
 from .camera import PerspectiveCamera
 from .film import Film
@@ -193,4 +195,42 @@ def sky_scene(width=800, height=800, env_res=128, gold=None, sun=True, tess=64):
     s.sync()
     film = Film((width, height))
     cam = PerspectiveCamera((4.0, -5.0, 2.5), (0, 0, -0.3), film, up=(0, 0, 1), fov=40.0)
+    return s, film, cam
+
+
+def textured_scene(width=64, height=64):
+    """Texture paths of SURVEY row a32 in one box: RGBA Kd texture (bilinear, (1-v, u) flip), alpha cut-outs (stochastic alpha
+    test in closest-hit and shadow rays, intersection.jl:142-221, 302-406), Float32 roughness / sigma textures, textured
+    CoatedDiffuse reflectance and a textured emitter (diffuse-area.jl:53-82)."""
+    from .materials import CoatedDiffuseMaterial, Texture
+    rng = np.random.default_rng(3)
+    yy, xx = np.mgrid[0:16, 0:16]
+    checker = np.where(((xx // 2 + yy // 2) % 2)[..., None] == 0, np.array([0.8, 0.75, 0.2], f32), np.array([0.15, 0.2, 0.7], f32)).astype(f32)
+    checker = np.concatenate([checker, np.ones((16, 16, 1), f32)], axis=2)
+    leaf = np.zeros((12, 12, 4), f32)
+    leaf[..., 0:3] = np.array([0.2, 0.7, 0.25], f32) * (0.6 + 0.4 * rng.random((12, 12, 1)).astype(f32))
+    r = np.hypot(xx[:12, :12] - 5.5, yy[:12, :12] - 5.5)
+    leaf[..., 3] = np.clip((6.0 - r) / 2.0, 0.0, 1.0)           # opaque disc, soft edge, transparent corners
+    rough = (0.02 + 0.5 * rng.random((8, 8))).astype(f32)
+    sigma = (40.0 * rng.random((4, 4))).astype(f32)
+    refl = rng.random((8, 8, 3)).astype(f32)
+    glow = (np.array([1.0, 0.9, 0.7], f32) * (0.3 + 0.7 * rng.random((6, 6, 1)).astype(f32))).astype(f32)
+    white = MatteMaterial(Kd=RGBSpectrum(0.73, 0.73, 0.73))
+    box, half = 2.0, 1.0
+    s = Scene()
+    s.push(G.rect3f((-half, 0, -half), (box, 0.01, box)), MatteMaterial(Kd=Texture(checker), sigma=Texture(sigma)))
+    s.push(G.rect3f((-half, box - 0.01, -half), (box, 0.01, box)), white)
+    s.push(G.rect3f((-half, 0, half - 0.01), (box, box, 0.01)), white)
+    s.push(G.rect3f((-half, 0, -half), (0.01, box, box)), MatteMaterial(Kd=RGBSpectrum(0.65, 0.05, 0.05)))
+    s.push(G.rect3f((half - 0.01, 0, -half), (0.01, box, box)), MatteMaterial(Kd=RGBSpectrum(0.12, 0.45, 0.15)))
+    s.push(G.sphere((-0.45, 0.35, 0.1), 0.35, 24), ConductorMaterial(eta=RGBSpectrum(0.2, 0.92, 1.1), k=RGBSpectrum(3.9, 2.45, 2.14), roughness=Texture(rough)))
+    s.push(G.rect3f((0.2, 0.0, 0.0), (0.5, 0.6, 0.5)), CoatedDiffuseMaterial(reflectance=Texture(refl), u_roughness=0.1, v_roughness=0.1))
+    s.push(G.quad((-0.7, 0.2, -0.5), (0.3, 0.2, -0.6), (0.3, 1.2, -0.6), (-0.7, 1.2, -0.5), normal=(0.1, 0.0, -0.995)), MatteMaterial(Kd=Texture(leaf)))
+    y = 1.98
+    q = G.quad((-0.3, y, -0.3), (0.3, y, -0.3), (0.3, y, 0.3), (-0.3, y, 0.3), normal=(0, -1, 0))
+    s.push(q, MediumInterface(MatteMaterial(Kd=RGBSpectrum(0.0)), emission=Emissive(Le=Texture(glow), scale=6.0, two_sided=False)))
+    s.push(PointLight.from_spectrum_first(RGBSpectrum(2.0), (0.5, 1.6, -0.7)))
+    s.sync()
+    film = Film((width, height))
+    cam = PerspectiveCamera((0, 1, -3.5), (0, 1, 0), film, fov=40.0)
     return s, film, cam

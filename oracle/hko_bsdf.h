@@ -358,7 +358,7 @@ inline Spec eval_bsdf(const MaterialCtx& c, int32_t mat_idx, V3 wo_world, V3 wi_
 // get_surface_alpha (spectral-eval.jl:3882-3888): Matte -> Kd alpha, everything else 1
 inline float surface_alpha(const MaterialCtx& c, int32_t mat_idx, V2 uv) {
     const hk_material& m = c.materials[mat_idx];
-    if (m.kind == HK_MAT_MATTE) return eval_tex(c.textures, m.rgb[0], uv).c[3];
+    if (m.kind == HK_MAT_MATTE) return eval_tex_nearest(c.textures, m.rgb[0], uv).c[3];  // Point2f method => nearest texel (quirk Q28)
     return 1.0f;
 }
 

@@ -49,6 +49,21 @@ inline void sample_texture_bilinear(const hk_texture& t, V2 uv, float* out) {
         out[c] = c0 * (1.0f - fy) + c1 * fy;
     }
 }
+// _sample_texture_data (textures/basic.jl:19-26): NEAREST texel by truncation, same (1-v, u) flip.  This is what
+// eval_tex(ctx, ref, uv::Point2f) resolves to, i.e. the alpha test (spectral-eval.jl:3882-3885); shading goes through the
+// TextureFilterContext method, which is bilinear (texture-ref.jl:71-74, 151-186).
+inline void sample_texture_nearest(const hk_texture& t, V2 uv, float* out) {
+    float a0 = 1.0f - uv.y, a1 = uv.x;
+    int32_t i = clampi((int32_t)(1.0f + (float)(t.height - 1) * a0), 1, t.height);
+    int32_t j = clampi((int32_t)(1.0f + (float)(t.width - 1) * a1), 1, t.width);
+    tex_fetch(t, i, j, out);
+}
+inline RGBA eval_tex_nearest(const TextureSet& ts, const hk_tex_rgba& f, V2 uv) {
+    if (f.tex < 0) return RGBA(f.c[0], f.c[1], f.c[2], f.c[3]);
+    float o[4] = {0, 0, 0, 1};
+    sample_texture_nearest(ts.tex[f.tex], uv, o);
+    return RGBA(o[0], o[1], o[2], o[3]);
+}
 inline RGBA eval_tex(const TextureSet& ts, const hk_tex_rgba& f, V2 uv) {
     if (f.tex < 0) return RGBA(f.c[0], f.c[1], f.c[2], f.c[3]);
     float o[4] = {0, 0, 0, 1};

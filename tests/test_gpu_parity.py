@@ -179,6 +179,7 @@ FRAME_CASES = [
     ("cornell_area", dict(max_depth=8, samples=8), (96, 96)),
     ("cornell_point", dict(max_depth=5, samples=8), (64, 64)),
     ("integration_nofog", dict(max_depth=5, samples=4), (64, 64)),
+    ("textured", dict(max_depth=1, samples=8), (64, 64)),   # deeper: alpha tests / coated walks re-seed from ray bits -> statistical case below
 ]
 
 # Scenes with participating media.  The reference seeds its delta-tracking / ratio-tracking RNGs by hashing the
@@ -192,6 +193,7 @@ MEDIA_CASES = [
     ("slab_homogeneous", dict(max_depth=6, samples=64), (24, 24)),
     ("slab_absorbing", dict(max_depth=6, samples=16), (24, 24)),
     ("slab_grid", dict(max_depth=6, samples=64), (24, 24)),
+    ("textured", dict(max_depth=5, samples=32), (40, 40)),
     ("slab_rgbgrid", dict(max_depth=6, samples=64), (24, 24)),
     ("slab_rgbgrid_absorbing", dict(max_depth=6, samples=16), (24, 24)),
     ("cloud_nanovdb", dict(max_depth=12, samples=32), (40, 40)),
@@ -209,6 +211,8 @@ def _scene(name, w, h):
         return scenes.cornell_box(w, h, light="point")
     if name == "integration_nofog":
         return scenes.integration_test_scene(w, h, with_fog=False)
+    if name == "textured":
+        return scenes.textured_scene(w, h)
     if name == "slab_homogeneous":
         import hikari_jl_amd as hk
         return scenes.slab_scene(w, h, hk.HomogeneousMedium(sigma_a=hk.RGBSpectrum(0.2, 0.3, 0.1), sigma_s=hk.RGBSpectrum(0.8, 0.6, 0.9), Le=hk.RGBSpectrum(0.05, 0.0, 0.0), g=0.4))

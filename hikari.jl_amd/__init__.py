@@ -14,7 +14,7 @@ from .lights import (AmbientLight, DiffuseAreaLight, DirectionalLight, PointLigh
 from .materials import (CoatedConductorMaterial, CoatedDiffuseMaterial, CoatedDiffuseTransmissionMaterial,
                         ConductorMaterial, DiffuseTransmissionMaterial, Emissive, GlassMaterial, MatteMaterial,
                         MediumInterface, MirrorMaterial, MixMaterial, PiecewiseLinearSpectrum, PlasticMaterial,
-                        RGBSpectrum, Texture, ThinDielectricMaterial)
+                        RGBSpectrum, Texture, ThinDielectricMaterial, VertexColorTexture)
 from .media import GridMedium, HomogeneousMedium, NanoVDBMedium, RGBGridMedium
 from .scene import Scene
 from .volpath import (BoxFilter, Context, GaussianFilter, LanczosSincFilter, MitchellFilter, TriangleFilter, VolPath,

@@ -22,7 +22,7 @@ HK_COHERENCE_NONE, HK_COHERENCE_SORTED, HK_COHERENCE_PER_TYPE = 0, 1, 2
 
 
 class hk_texture(C.Structure):
-    _fields_ = [("width", c_i), ("height", c_i), ("channels", c_i), ("_pad", c_i), ("data", PF)]
+    _fields_ = [("width", c_i), ("height", c_i), ("channels", c_i), ("kind", c_i), ("data", PF)]
 
 
 class hk_tex_rgba(C.Structure):

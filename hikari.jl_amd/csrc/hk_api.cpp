@@ -347,7 +347,7 @@ extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene**
         dt[i].width = t.width;
         dt[i].height = t.height;
         dt[i].channels = t.channels;
-        dt[i].pad = 0;
+        dt[i].pad = t.kind;  // 0 image, 1 vertex colours
     }
     HIP_TRY(s->textures.upload(dt.data(), dt.size() * sizeof(DTexture)));
     std::vector<DPLSpectrum> dsp(d->n_spectra > 0 ? d->n_spectra : 1);

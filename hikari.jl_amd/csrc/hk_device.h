@@ -448,7 +448,40 @@ HKD void tex_bilinear(const DTexture& t, v2 uv, float out[4]) {
         out[c] = c0 * (1.0f - fy) + c1 * fy;
     }
 }
-HKD float eval_f32(const DScene& sc, const DMaterial& m, int slot, v2 uv) {
+// eval_tex(ctx, ref, uv::Point2f) == _sample_texture_data (textures/basic.jl:19-26): NEAREST texel by truncation
+HKD float eval_f32_nearest(const DScene& sc, const DMaterial& m, int slot, v2 uv) {
+    if (m.ftex[slot] < 0) return m.f[slot];
+    const DTexture& t = sc.textures[m.ftex[slot]];
+    if (t.pad == 1) return 0.5f;
+    int i = clampi((int)(1.0f + (float)(t.height - 1) * (1.0f - uv.y)), 1, t.height);
+    int j = clampi((int)(1.0f + (float)(t.width - 1) * uv.x), 1, t.width);
+    return t.data[((size_t)(i - 1) + (size_t)t.height * (size_t)(j - 1)) * t.channels];
+}
+// TextureFilterContext as far as the path reads it (texture-ref.jl:21-29): uv + (face_idx, bary) for vertex-colour textures.
+// A plain uv converts implicitly (face 0 = "no face": vertex-colour textures then read their gray placeholder, :245).
+struct TexCtx {
+    v2 uv;
+    uint32_t face;   // TriangleMeta.primitive_index (1-based face in its mesh)
+    float bu, bv;    // barycentrics of vertices 1 and 2; vertex 0 gets w = 1 - bu - bv
+    HKD TexCtx(v2 u) : uv(u), face(0u), bu(0.0f), bv(0.0f) {}
+    HKD TexCtx(v2 u, uint32_t f, float a, float b) : uv(u), face(f), bu(a), bv(b) {}
+};
+// eval_tex(ctx, tex, tfc): image textures are bilinear (texture-ref.jl:71-74, 151-186); a VertexColorTexture interpolates the
+// three colours of face `face_idx` with (w, u, v) (texture-ref.jl:230-235).  kind rides in DTexture.pad.
+HKD void tex_bilinear(const DTexture& t, const TexCtx& tc, float out[4]) {
+    if (t.pad == 1) {
+        if (tc.face == 0u) {  // UV-only evaluation: gray placeholder RGBSpectrum(0.5f0)
+            for (int c = 0; c < t.channels; ++c) out[c] = c < 3 ? 0.5f : 1.0f;
+            return;
+        }
+        const float* f = t.data + (size_t)(tc.face - 1u) * 3u * (size_t)t.channels;
+        float w = 1.0f - tc.bu - tc.bv;
+        for (int c = 0; c < t.channels; ++c) out[c] = f[c] * w + f[t.channels + c] * tc.bu + f[2 * t.channels + c] * tc.bv;
+        return;
+    }
+    tex_bilinear(t, tc.uv, out);
+}
+HKD float eval_f32(const DScene& sc, const DMaterial& m, int slot, const TexCtx& uv) {
     if (m.ftex[slot] < 0) return m.f[slot];
     float o[4] = {0, 0, 0, 0};
     tex_bilinear(sc.textures[m.ftex[slot]], uv, o);
@@ -707,7 +740,7 @@ HKD Surface surface_at(const DScene& sc, int prim, float bu, float bv, v3 ro, v3
 // materials: parameter fetch
 // ------------------------------------------------------------------------------------------------
 enum { UPLIFT_BOUNDED = 0, UPLIFT_UNBOUNDED = 1 };
-HKD float4 rgb_param_coef(const DScene& sc, const DTables& T, const DSpectrumParam& p, v2 uv, int mode, bool clamp_lo) {
+HKD float4 rgb_param_coef(const DScene& sc, const DTables& T, const DSpectrumParam& p, const TexCtx& uv, int mode, bool clamp_lo) {
     if (p.tex < 0) return p.coef;
     float o[4] = {0, 0, 0, 1};
     tex_bilinear(sc.textures[p.tex], uv, o);
@@ -720,15 +753,15 @@ HKD float4 rgb_param_coef(const DScene& sc, const DTables& T, const DSpectrumPar
 }
 // alpha goes through eval_tex(ctx, ref, uv::Point2f) == _sample_texture_data: NEAREST texel by truncation
 // (textures/basic.jl:19-26; spectral-eval.jl:3882-3885), unlike shading, which is bilinear (quirk Q28)
-HKD float rgb_param_alpha(const DScene& sc, const DSpectrumParam& p, v2 uv) {
+HKD float rgb_param_alpha(const DScene& sc, const DSpectrumParam& p, const TexCtx& uv) {
     if (p.tex < 0) return p.rgba[3];
     const DTexture& t = sc.textures[p.tex];
-    if (t.channels < 4) return 1.0f;
-    int i = clampi((int)(1.0f + (float)(t.height - 1) * (1.0f - uv.y)), 1, t.height);
-    int j = clampi((int)(1.0f + (float)(t.width - 1) * uv.x), 1, t.width);
+    if (t.channels < 4 || t.pad == 1) return 1.0f;  // vertex colours: the Point2f method returns RGBSpectrum(0.5f0), alpha 1
+    int i = clampi((int)(1.0f + (float)(t.height - 1) * (1.0f - uv.uv.y)), 1, t.height);
+    int j = clampi((int)(1.0f + (float)(t.width - 1) * uv.uv.x), 1, t.width);
     return t.data[((size_t)(i - 1) + (size_t)t.height * (size_t)(j - 1)) * 4 + 3];
 }
-HKD float surface_alpha(const DScene& sc, int mat, v2 uv) {  // spectral-eval.jl:3882-3888
+HKD float surface_alpha(const DScene& sc, int mat, const TexCtx& uv) {  // spectral-eval.jl:3882-3888
     const DMaterial& m = sc.materials[mat];
     if (m.kind == HK_MAT_MATTE) return rgb_param_alpha(sc, m.rgb[0], uv);
     return 1.0f;
@@ -763,7 +796,7 @@ HKD int resolve_mix_material(const DScene& sc, int idx, v3 p, v3 wo, v2 uv) {  /
     for (int it = 0; it < 8; ++it) {
         const DMaterial& m = sc.materials[cur];
         if (m.kind != HK_MAT_MIX) return cur;
-        float amt = eval_f32(sc, m, 0, uv);
+        float amt = eval_f32_nearest(sc, m, 0, uv);  // eval_tex(ctx, mix.amount, uv::Point2f): nearest texel (Q28)
         if (amt <= 0.0f)
             cur = m.i[0];
         else if (amt >= 1.0f)
@@ -894,7 +927,7 @@ HKD float pl_sample(const DPLSpectrum& s, float l) {  // spectral/piecewise-line
     float t = (l - s.lambdas[lo - 1]) / (s.lambdas[hi - 1] - s.lambdas[lo - 1]);
     return s.values[lo - 1] * (1.0f - t) + s.values[hi - 1] * t;
 }
-HKD S4 eval_ior(const DScene& sc, const DTables& T, const DMaterial& m, int slot, v2 uv, S4 lambda) {
+HKD S4 eval_ior(const DScene& sc, const DTables& T, const DMaterial& m, int slot, const TexCtx& uv, S4 lambda) {
     if (m.spectrum[slot] >= 0) {
         const DPLSpectrum& s = sc.spectra[m.spectrum[slot]];
         return s4(pl_sample(s, lambda.x), pl_sample(s, lambda.y), pl_sample(s, lambda.z), pl_sample(s, lambda.w));
@@ -924,7 +957,7 @@ namespace hkd {
 
 // KIND is a compile-time constant in the per-kind shade kernels (material-sorted queues)
 template <int KIND>
-HKD BSDFSample sample_bsdf(const DScene& sc, const DTables& T, const DMaterial& m, v3 wo_w, v3 n, v2 uv, S4 lambda, v2 u, float uc, bool regularize) {
+HKD BSDFSample sample_bsdf(const DScene& sc, const DTables& T, const DMaterial& m, v3 wo_w, v3 n, const TexCtx& uv, S4 lambda, v2 u, float uc, bool regularize) {
     if (KIND == HK_MAT_MATTE) {  // spectral-eval.jl:42-101
         float wdn = dot(wo_w, n);
         if (fabsf(wdn) < 1e-6f) return invalid_sample();
@@ -1037,7 +1070,7 @@ HKD BSDFSample sample_bsdf(const DScene& sc, const DTables& T, const DMaterial& 
     }
 }
 template <int KIND>
-HKD S4 eval_bsdf(const DScene& sc, const DTables& T, const DMaterial& m, v3 wo_w, v3 wi_w, v3 n, v2 uv, S4 lambda, float& pdf) {
+HKD S4 eval_bsdf(const DScene& sc, const DTables& T, const DMaterial& m, v3 wo_w, v3 wi_w, v3 n, const TexCtx& uv, S4 lambda, float& pdf) {
     pdf = 0.0f;
     if (KIND == HK_MAT_MATTE) {  // :371-398
         float ci = dot(wi_w, n), co = dot(wo_w, n);

@@ -620,7 +620,7 @@ __global__ void __launch_bounds__(256, HK_SHADE_MIN_WAVES) k_shade(DPathState st
                     LightSample ls = sample_light(sc, T, sel, sf.pi, lambda, u_light);
                     if (ls.pdf > 0.0f && !is_black(ls.Li)) {
                         float bsdf_pdf;
-                        S4 f = eval_bsdf<KIND>(sc, T, mat, wo, ls.wi, sf.ns, sf.uv, lambda, bsdf_pdf);
+                        S4 f = eval_bsdf<KIND>(sc, T, mat, wo, ls.wi, sf.ns, TexCtx(sf.uv, meta.prim_index, H.z, H.w), lambda, bsdf_pdf);
                         if (!is_black(f)) {
                             float ct = fabsf(dot(ls.wi, sf.ns));
                             S4 Ld = beta * f * ls.Li * ct;
@@ -649,7 +649,7 @@ __global__ void __launch_bounds__(256, HK_SHADE_MIN_WAVES) k_shade(DPathState st
                 float uc = (KIND == HK_MAT_GLASS || KIND > HK_MAT_CONDUCTOR) && KIND != HK_MAT_FALLBACK ? sobol_1d(sctx, base_dim + 4) : 0.0f;
                 v2 u = (KIND == HK_MAT_MIRROR || KIND == HK_MAT_GLASS || KIND == HK_MAT_THIN_DIELECTRIC) ? mk2(0.0f, 0.0f) : sobol_2d(sctx, base_dim + 6);
                 bool regularize = fr.regularize && any_non_specular;
-                BSDFSample s = sample_bsdf<KIND>(sc, T, mat, wo, sf.ns, sf.uv, lambda, u, uc, regularize);
+                BSDFSample s = sample_bsdf<KIND>(sc, T, mat, wo, sf.ns, TexCtx(sf.uv, meta.prim_index, H.z, H.w), lambda, u, uc, regularize);
                 if (s.pdf > 0.0f && !is_black(s.f)) {
                     float ct = fabsf(dot(s.wi, sf.ns));
                     S4 nb = s.is_specular ? beta * s.f : beta * s.f * ct / s.pdf;

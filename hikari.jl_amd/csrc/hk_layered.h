@@ -244,7 +244,7 @@ struct LayeredParams {
 };
 
 // raw (r,g,b) of a colour parameter: constant or bilinear texture value
-HKD void rgb_param_raw(const DScene& sc, const DSpectrumParam& p, v2 uv, float o[4]) {
+HKD void rgb_param_raw(const DScene& sc, const DSpectrumParam& p, const TexCtx& uv, float o[4]) {
     if (p.tex < 0) {
         o[0] = p.rgba[0], o[1] = p.rgba[1], o[2] = p.rgba[2], o[3] = p.rgba[3];
         return;
@@ -258,7 +258,7 @@ HKD S4 param_bounded(const DScene& sc, const DTables& T, const DSpectrumParam& p
 }
 
 template <bool DT>
-HKD LayeredParams layered_params(const DScene& sc, const DTables& T, const DMaterial& m, v2 uv, S4 lambda, bool regularize) {
+HKD LayeredParams layered_params(const DScene& sc, const DTables& T, const DMaterial& m, const TexCtx& uv, S4 lambda, bool regularize) {
     LayeredParams P;
     float raw[4];
     rgb_param_raw(sc, m.rgb[0], uv, raw);
@@ -537,7 +537,7 @@ struct CCParams {
     float ieta, iax, iay, cax, cay, thickness;
     bool has_medium;
 };
-HKD CCParams cc_params(const DScene& sc, const DTables& T, const DMaterial& m, v2 uv, S4 lambda, bool regularize) {
+HKD CCParams cc_params(const DScene& sc, const DTables& T, const DMaterial& m, const TexCtx& uv, S4 lambda, bool regularize) {
     CCParams P;
     P.ieta = eval_f32(sc, m, 2, uv);
     if (P.ieta == 0.0f) P.ieta = 1.0f;
@@ -781,7 +781,7 @@ struct DTParams {
     S4 r, t;
     float pr, pt;
 };
-HKD DTParams dt_params(const DScene& sc, const DTables& T, const DMaterial& m, v2 uv, S4 lambda) {
+HKD DTParams dt_params(const DScene& sc, const DTables& T, const DMaterial& m, const TexCtx& uv, S4 lambda) {
     // the host bakes clamp(rgb * scale, 0, 1) when both the colour and the scale are constants
     float scale = eval_f32(sc, m, 0, uv);
     bool baked = m.ftex[0] < 0;

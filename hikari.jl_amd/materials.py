@@ -36,6 +36,19 @@ class Texture:
         self.data = d  # [h, w] or [h, w, 4]
 
 
+class VertexColorTexture(Texture):
+    """VertexColorTexture(face_colors[3, n_faces]) (textures/basic.jl:42-46): three RGB(A) colours per face, interpolated
+    with the hit's barycentrics (texture-ref.jl:230-235).  `face_colors` here is [n_faces, 3, 3|4]."""
+
+    def __init__(self, face_colors):
+        d = np.asarray(face_colors, dtype=f32)
+        assert d.ndim == 3 and d.shape[1] == 3 and d.shape[2] in (3, 4)
+        if d.shape[2] == 3:
+            d = np.concatenate([d, np.ones(d.shape[:2] + (1,), dtype=f32)], axis=2)
+        self.data = np.ascontiguousarray(d)
+        self.n_faces = d.shape[0]
+
+
 def _rgb(v):
     if isinstance(v, (RGBSpectrum, Texture)):
         return v

@@ -304,6 +304,11 @@ class Scene:
         texs = (A.hk_texture * max(1, len(self.textures)))()
         for i, t in enumerate(self.textures):
             d = t.data
+            if isinstance(t, M.VertexColorTexture):      # Julia face_colors[3, n_faces]: a face's 3 colours are adjacent
+                keep.append(d)
+                texs[i].width, texs[i].height, texs[i].channels, texs[i].kind = t.n_faces, 3, 4, 1
+                texs[i].data = d.ctypes.data_as(A.PF)
+                continue
             h, w = d.shape[:2]
             ch = 1 if d.ndim == 2 else d.shape[2]
             jl = np.ascontiguousarray(np.transpose(d.reshape(h, w, ch), (1, 0, 2)))  # [w][h][c] == Julia [h,w] column-major

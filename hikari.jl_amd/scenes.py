@@ -220,7 +220,9 @@ def textured_scene(width=64, height=64):
     s = Scene()
     s.push(G.rect3f((-half, 0, -half), (box, 0.01, box)), MatteMaterial(Kd=Texture(checker), sigma=Texture(sigma)))
     s.push(G.rect3f((-half, box - 0.01, -half), (box, 0.01, box)), white)
-    s.push(G.rect3f((-half, 0, half - 0.01), (box, box, 0.01)), white)
+    from .materials import VertexColorTexture
+    back = G.rect3f((-half, 0, half - 0.01), (box, box, 0.01))
+    s.push(back, MatteMaterial(Kd=VertexColorTexture(0.2 + 0.7 * rng.random((back.n_faces, 3, 3)).astype(f32))))   # per-face vertex colours
     s.push(G.rect3f((-half, 0, -half), (0.01, box, box)), MatteMaterial(Kd=RGBSpectrum(0.65, 0.05, 0.05)))
     s.push(G.rect3f((half - 0.01, 0, -half), (0.01, box, box)), MatteMaterial(Kd=RGBSpectrum(0.12, 0.45, 0.15)))
     s.push(G.sphere((-0.45, 0.35, 0.1), 0.35, 24), ConductorMaterial(eta=RGBSpectrum(0.2, 0.92, 1.1), k=RGBSpectrum(3.9, 2.45, 2.14), roughness=Texture(rough)))

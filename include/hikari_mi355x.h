@@ -41,7 +41,9 @@ extern "C" {
  * ------------------------------------------------------------------------------------------- */
 typedef struct hk_texture {
     int32_t width, height, channels;
-    int32_t _pad;
+    int32_t kind; /* 0: 2-D image (above).  1: VertexColorTexture (textures/basic.jl:42-46; texture-ref.jl:230-235):
+                     data = face_colors[3, n_faces] (Julia layout: the 3 colours of a face are adjacent), height = 3,
+                     width = n_faces; looked up with the hit's face index and barycentrics, not with uv */
     const float* data;
 } hk_texture;
 

@@ -160,7 +160,7 @@ inline float pl_sample(const hk_pl_spectrum& s, float lam) {
     return s.values[lo - 1] * (1.0f - t) + s.values[hi - 1] * t;
 }
 // eval_ior_spectral  spectral-eval.jl:204-208
-inline Spec eval_ior(const MaterialCtx& c, const hk_material& m, int slot, V2 uv, const Wavelengths& w) {
+inline Spec eval_ior(const MaterialCtx& c, const hk_material& m, int slot, const TexCtx& uv, const Wavelengths& w) {
     if (m.spectrum[slot] >= 0) {
         const hk_pl_spectrum& s = c.spectra[m.spectrum[slot]];
         return Spec(pl_sample(s, w.lambda[0]), pl_sample(s, w.lambda[1]), pl_sample(s, w.lambda[2]), pl_sample(s, w.lambda[3]));
@@ -187,7 +187,7 @@ inline BSDFSample sample_lambert(V3 wo, V3 n, V2 u, const Spec& f_scaled) {
 }
 
 // sample_bsdf_spectral dispatch (material-dispatch.jl:23-31)
-inline BSDFSample sample_bsdf(const MaterialCtx& c, int32_t mat_idx, V3 wo_world, V3 n, V2 uv, const Wavelengths& w, V2 u, float rng, bool regularize) {
+inline BSDFSample sample_bsdf(const MaterialCtx& c, int32_t mat_idx, V3 wo_world, V3 n, const TexCtx& uv, const Wavelengths& w, V2 u, float rng, bool regularize) {
     const hk_material& m = c.materials[mat_idx];
     const RGB2SpecTable& T = *c.table;
     switch (m.kind) {
@@ -300,7 +300,7 @@ inline BSDFSample sample_bsdf(const MaterialCtx& c, int32_t mat_idx, V3 wo_world
 }
 
 // evaluate_bsdf_spectral dispatch (material-dispatch.jl:46-53): returns f, pdf
-inline Spec eval_bsdf(const MaterialCtx& c, int32_t mat_idx, V3 wo_world, V3 wi_world, V3 n, V2 uv, const Wavelengths& w, float& pdf) {
+inline Spec eval_bsdf(const MaterialCtx& c, int32_t mat_idx, V3 wo_world, V3 wi_world, V3 n, const TexCtx& uv, const Wavelengths& w, float& pdf) {
     const hk_material& m = c.materials[mat_idx];
     const RGB2SpecTable& T = *c.table;
     pdf = 0.0f;
@@ -394,7 +394,7 @@ inline int32_t resolve_mix_material(const MaterialCtx& c, int32_t idx, V3 p, V3 
     for (int it = 0; it < 8; ++it) {
         const hk_material& m = c.materials[cur];
         if (m.kind != HK_MAT_MIX) return cur;
-        float amt = eval_tex(c.textures, m.f[0], uv);
+        float amt = eval_tex_nearest(c.textures, m.f[0], uv);  // eval_tex(ctx, mix.amount, uv::Point2f): nearest texel (Q28)
         if (amt <= 0.0f)
             cur = m.i[0];
         else if (amt >= 1.0f)

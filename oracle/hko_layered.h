@@ -494,7 +494,7 @@ inline bool rgb_is_black(const RGBA& a) { return a.c[0] == 0.0f && a.c[1] == 0.0
 inline float max3(const RGBA& a) { return maxf(maxf(a.c[0], a.c[1]), a.c[2]); }
 
 // parameter gathering for HK_MAT_COATED_DIFFUSE / HK_MAT_COATED_DIFFUSE_TRANSMISSION
-inline LayeredParams layered_params(const MaterialCtx& c, const hk_material& m, V2 uv, const Wavelengths& w, bool regularize) {
+inline LayeredParams layered_params(const MaterialCtx& c, const hk_material& m, const TexCtx& uv, const Wavelengths& w, bool regularize) {
     const RGB2SpecTable& T = *c.table;
     LayeredParams P;
     bool dt = m.kind == HK_MAT_COATED_DIFFUSE_TRANSMISSION;
@@ -532,7 +532,7 @@ struct CCParams {
     Spec ce, ck, albedo;
     bool has_medium;
 };
-inline CCParams cc_params(const MaterialCtx& c, const hk_material& m, V2 uv, const Wavelengths& w, bool regularize) {
+inline CCParams cc_params(const MaterialCtx& c, const hk_material& m, const TexCtx& uv, const Wavelengths& w, bool regularize) {
     const RGB2SpecTable& T = *c.table;
     CCParams P;
     P.ieta = eval_tex(c.textures, m.f[2], uv);
@@ -792,7 +792,7 @@ struct DTParams {
     Spec r, t;
     float pr, pt;
 };
-inline DTParams dt_params(const MaterialCtx& c, const hk_material& m, V2 uv, const Wavelengths& w) {
+inline DTParams dt_params(const MaterialCtx& c, const hk_material& m, const TexCtx& uv, const Wavelengths& w) {
     float scale = eval_tex(c.textures, m.f[0], uv);
     RGBA r = clamp01_rgb(eval_tex(c.textures, m.rgb[0], uv) * scale), t = clamp01_rgb(eval_tex(c.textures, m.rgb[1], uv) * scale);
     DTParams P;
@@ -836,7 +836,7 @@ inline Spec dt_eval(const DTParams& P, V3 wo_world, V3 wi_world, V3 n, float& pd
 }
 
 // material-dispatch.jl:23-53 over every material kind: the kinds of this header, else hko_bsdf.h
-inline BSDFSample sample_bsdf_all(const MaterialCtx& c, int32_t mat_idx, V3 wo, V3 n, V2 uv, const Wavelengths& w, V2 u, float rng, bool regularize) {
+inline BSDFSample sample_bsdf_all(const MaterialCtx& c, int32_t mat_idx, V3 wo, V3 n, const TexCtx& uv, const Wavelengths& w, V2 u, float rng, bool regularize) {
     const hk_material& m = c.materials[mat_idx];
     switch (m.kind) {
         case HK_MAT_COATED_DIFFUSE:
@@ -847,7 +847,7 @@ inline BSDFSample sample_bsdf_all(const MaterialCtx& c, int32_t mat_idx, V3 wo, 
         default: return sample_bsdf(c, mat_idx, wo, n, uv, w, u, rng, regularize);
     }
 }
-inline Spec eval_bsdf_all(const MaterialCtx& c, int32_t mat_idx, V3 wo, V3 wi, V3 n, V2 uv, const Wavelengths& w, float& pdf) {
+inline Spec eval_bsdf_all(const MaterialCtx& c, int32_t mat_idx, V3 wo, V3 wi, V3 n, const TexCtx& uv, const Wavelengths& w, float& pdf) {
     const hk_material& m = c.materials[mat_idx];
     switch (m.kind) {
         case HK_MAT_COATED_DIFFUSE:

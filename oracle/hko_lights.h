@@ -53,6 +53,10 @@ inline void sample_texture_bilinear(const hk_texture& t, V2 uv, float* out) {
 // eval_tex(ctx, ref, uv::Point2f) resolves to, i.e. the alpha test (spectral-eval.jl:3882-3885); shading goes through the
 // TextureFilterContext method, which is bilinear (texture-ref.jl:71-74, 151-186).
 inline void sample_texture_nearest(const hk_texture& t, V2 uv, float* out) {
+    if (t.kind == 1) {  // eval_tex(::VertexColorTexture, ::Point2f) = RGBSpectrum(0.5f0)
+        for (int c = 0; c < t.channels; ++c) out[c] = c < 3 ? 0.5f : 1.0f;
+        return;
+    }
     float a0 = 1.0f - uv.y, a1 = uv.x;
     int32_t i = clampi((int32_t)(1.0f + (float)(t.height - 1) * a0), 1, t.height);
     int32_t j = clampi((int32_t)(1.0f + (float)(t.width - 1) * a1), 1, t.width);
@@ -64,16 +68,44 @@ inline RGBA eval_tex_nearest(const TextureSet& ts, const hk_tex_rgba& f, V2 uv) 
     sample_texture_nearest(ts.tex[f.tex], uv, o);
     return RGBA(o[0], o[1], o[2], o[3]);
 }
-inline RGBA eval_tex(const TextureSet& ts, const hk_tex_rgba& f, V2 uv) {
-    if (f.tex < 0) return RGBA(f.c[0], f.c[1], f.c[2], f.c[3]);
-    float o[4] = {0, 0, 0, 1};
-    sample_texture_bilinear(ts.tex[f.tex], uv, o);
-    return RGBA(o[0], o[1], o[2], o[3]);
-}
-inline float eval_tex(const TextureSet& ts, const hk_tex_f32& f, V2 uv) {
+inline float eval_tex_nearest(const TextureSet& ts, const hk_tex_f32& f, V2 uv) {
     if (f.tex < 0) return f.v;
     float o[4] = {0, 0, 0, 0};
-    sample_texture_bilinear(ts.tex[f.tex], uv, o);
+    sample_texture_nearest(ts.tex[f.tex], uv, o);
+    return o[0];
+}
+// TextureFilterContext as far as the path reads it (texture-ref.jl:21-29): uv + (face_idx, bary) for vertex colours.
+// A bare uv converts implicitly (face 0: a VertexColorTexture then yields its gray placeholder, texture-ref.jl:245).
+struct TexCtx {
+    V2 uv;
+    uint32_t face = 0;
+    float bary[3] = {0, 0, 0};  // (w, u, v)
+    TexCtx(V2 u) : uv(u) {}
+    TexCtx(V2 u, uint32_t f, const float b[3]) : uv(u), face(f), bary{b[0], b[1], b[2]} {}
+};
+// eval_tex(ctx, tex, tfc): bilinear for images (texture-ref.jl:71-74), barycentric for VertexColorTexture (:230-235)
+inline void sample_texture_ctx(const hk_texture& t, const TexCtx& tc, float* out) {
+    if (t.kind == 1) {
+        if (tc.face == 0) {
+            for (int c = 0; c < t.channels; ++c) out[c] = c < 3 ? 0.5f : 1.0f;
+            return;
+        }
+        const float* f = t.data + (size_t)(tc.face - 1) * 3 * (size_t)t.channels;
+        for (int c = 0; c < t.channels; ++c) out[c] = f[c] * tc.bary[0] + f[t.channels + c] * tc.bary[1] + f[2 * t.channels + c] * tc.bary[2];
+        return;
+    }
+    sample_texture_bilinear(t, tc.uv, out);
+}
+inline RGBA eval_tex(const TextureSet& ts, const hk_tex_rgba& f, const TexCtx& uv) {
+    if (f.tex < 0) return RGBA(f.c[0], f.c[1], f.c[2], f.c[3]);
+    float o[4] = {0, 0, 0, 1};
+    sample_texture_ctx(ts.tex[f.tex], uv, o);
+    return RGBA(o[0], o[1], o[2], o[3]);
+}
+inline float eval_tex(const TextureSet& ts, const hk_tex_f32& f, const TexCtx& uv) {
+    if (f.tex < 0) return f.v;
+    float o[4] = {0, 0, 0, 0};
+    sample_texture_ctx(ts.tex[f.tex], uv, o);
     return o[0];
 }
 

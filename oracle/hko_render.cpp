@@ -75,6 +75,8 @@ struct HitItem {  // VPHitSurfaceWorkItem
 };
 struct MatItem {  // VPMaterialEvalWorkItem
     SurfaceGeom g;
+    uint32_t face_idx;
+    float bary[3];
     V3 wo;
     int32_t material;
     hk_medium_interface iface;
@@ -835,6 +837,8 @@ static void render_one_sample(const Scene& sc, const hk_integrator_params& ip, c
             }
             MatItem& m = mats[i];
             m.g = wk.g;
+            m.face_idx = wk.face_idx;
+            m.bary[0] = wk.bary[0], m.bary[1] = wk.bary[1], m.bary[2] = wk.bary[2];
             m.wo = wo;
             m.material = material_idx;
             m.iface = wk.iface;
@@ -867,7 +871,7 @@ static void render_one_sample(const Scene& sc, const hk_integrator_params& ip, c
                 LightSample ls = sample_light_full(sc, light_idx, wk.g.pi, wk.lambda, u_light);
                 if (!(ls.pdf > 0.0f && !is_black(ls.Li))) continue;
                 float bsdf_pdf;
-                Spec bsdf_f = eval_bsdf_all(sc.mctx, wk.material, wk.wo, ls.wi, wk.g.ns, wk.g.uv, wk.lambda, bsdf_pdf);
+                Spec bsdf_f = eval_bsdf_all(sc.mctx, wk.material, wk.wo, ls.wi, wk.g.ns, TexCtx(wk.g.uv, wk.face_idx, wk.bary), wk.lambda, bsdf_pdf);
                 if (is_black(bsdf_f)) continue;
                 // compute_direct_lighting_spectral  lights.jl:535-600
                 float cos_theta = std::fabs(dot(ls.wi, wk.g.ns));
@@ -934,7 +938,7 @@ static void render_one_sample(const Scene& sc, const hk_integrator_params& ip, c
             float uc = st.s_indirect_uc[p0];
             float rr = st.s_rr[p0];
             bool regularize = ip.regularize && wk.any_non_specular;
-            BSDFSample s = sample_bsdf_all(sc.mctx, wk.material, wk.wo, wk.g.ns, wk.g.uv, wk.lambda, u, uc, regularize);
+            BSDFSample s = sample_bsdf_all(sc.mctx, wk.material, wk.wo, wk.g.ns, TexCtx(wk.g.uv, wk.face_idx, wk.bary), wk.lambda, u, uc, regularize);
             if (!(s.pdf > 0.0f && !is_black(s.f))) continue;
             float cos_theta = std::fabs(dot(s.wi, wk.g.ns));
             Spec new_beta = s.is_specular ? wk.beta * s.f : wk.beta * s.f * cos_theta / s.pdf;

@@ -532,11 +532,21 @@ __global__ void __launch_bounds__(256) k_escaped(DPathState st, DScene sc, DTabl
 // ---------------------------------------------------------------------------------------------------
 // K8 + K9 + K11 fused per material kind (surface-eval.jl:147-220, 250-341, 396-512).
 // ---------------------------------------------------------------------------------------------------
+// Register budget: 512 VGPRs per SIMD lane => 3 waves/SIMD need <= 168, 4 need <= 128.  The simple kinds sit a few registers
+// above 168 without a hint; asking for 3 waves costs a handful of scratch spills and buys a third more latency hiding.
+// The walk kinds (coated diffuse / transmission) are far above: they keep the default.
+#ifndef HK_SHADE_WAVES
+#define HK_SHADE_WAVES 3
+#endif
+template <int KIND>
+struct ShadeWaves {
+    static constexpr int value = (KIND == HK_MAT_COATED_DIFFUSE || KIND == HK_MAT_COATED_DIFFUSE_TRANSMISSION) ? 1 : HK_SHADE_WAVES;
+};
 #ifndef HK_SHADE_MIN_WAVES
 #define HK_SHADE_MIN_WAVES 1
 #endif
 template <int KIND>
-__global__ void __launch_bounds__(256, HK_SHADE_MIN_WAVES) k_shade(DPathState st, DScene sc, DTables T, DFrame fr, DSobol sob, int depth, int first_kind, DStats* stats) {
+__global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_per_eu(ShadeWaves<KIND>::value))) k_shade(DPathState st, DScene sc, DTables T, DFrame fr, DSobol sob, int depth, int first_kind, DStats* stats) {
     const int lane = lane_id();
     unsigned n_vertices = 0, n_lnodes = 0;
     HK_FOR_EACH_WAVE_SEGMENT(gw, st) {
@@ -693,7 +703,9 @@ __global__ void __launch_bounds__(256, HK_SHADE_MIN_WAVES) k_shade(DPathState st
 // K10: shadow rays (intersection.jl:302-406, 565-600).  Surface-only scenes: one segment, early exit on
 // any opaque hit.  Medium-transition / alpha surfaces are walked through (<= 10 segments).
 // ---------------------------------------------------------------------------------------------------
-template <bool COUNT>
+// SURFACES_ONLY (no media, every surface opaque) is the lean instantiation: one any-hit cast, ~1/3 of the registers of the
+// general walk (whose ratio tracking + run-time RGB uplift would otherwise set the occupancy of every scene).
+template <bool COUNT, bool SURFACES_ONLY>
 __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_shadow(DPathState st, DScene sc, DTables T, int depth, DStats* stats) {
     __shared__ int lds_stack[(HK_TRACE_BLOCK / 64) * HK_LDS_STACK * 64];
     int* stack = lds_stack + (threadIdx.x >> 6) * (HK_LDS_STACK * 64);
@@ -714,6 +726,16 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_shadow(DPathState st, DScene
         S4 lambda = s4(0.0f);
         if (sc.n_media > 0) lambda = ld4(&st.lambda[slot]);
         bool visible = false, done = false;
+        if (SURFACES_ONLY) {
+            if (t_remaining >= 1e-6f) {
+                bool opaque;
+                ++n_casts;
+                HitRec h = traverse<1, COUNT>(sc, ro, dir, t_remaining, stack, lane, n_nodes, n_tris, opaque);
+                visible = h.prim < 0;
+                if (!visible) ++n_hits;
+            }
+            done = true;
+        }
         for (int seg = 0; seg < 10 && !done; ++seg) {
             if (t_remaining < 1e-6f) break;
             bool opaque;
@@ -955,11 +977,18 @@ void launch_trace(hipStream_t s, int n_cu, const DPathState& st, const DScene& s
         hipLaunchKernelGGL(k_trace<false>, dim3(clamp_blocks(b0, st)), dim3(HK_TRACE_BLOCK), 0, s, st, sc, T, fr, depth, stats);
 }
 void launch_shadow(hipStream_t s, int n_cu, const DPathState& st, const DScene& sc, const DTables& T, const DFrame& fr, int depth, DStats* stats) {
-    static int b0 = resident_blocks(k_shadow<false>, HK_TRACE_BLOCK, n_cu, 8), b1 = resident_blocks(k_shadow<true>, HK_TRACE_BLOCK, n_cu, 8);
-    if (fr.count_nodes)
-        hipLaunchKernelGGL(k_shadow<true>, dim3(clamp_blocks(b1, st)), dim3(HK_TRACE_BLOCK), 0, s, st, sc, T, depth, stats);
-    else
-        hipLaunchKernelGGL(k_shadow<false>, dim3(clamp_blocks(b0, st)), dim3(HK_TRACE_BLOCK), 0, s, st, sc, T, depth, stats);
+    const bool lean = sc.all_opaque && sc.n_media == 0;
+#define HK_SHADOW_LAUNCH(C, L)                                                                                                  \
+    {                                                                                                                           \
+        static int blocks = resident_blocks(k_shadow<C, L>, HK_TRACE_BLOCK, n_cu, 8);                                            \
+        hipLaunchKernelGGL((k_shadow<C, L>), dim3(clamp_blocks(blocks, st)), dim3(HK_TRACE_BLOCK), 0, s, st, sc, T, depth, stats); \
+    }
+    if (fr.count_nodes) {
+        if (lean) HK_SHADOW_LAUNCH(true, true) else HK_SHADOW_LAUNCH(true, false)
+    } else {
+        if (lean) HK_SHADOW_LAUNCH(false, true) else HK_SHADOW_LAUNCH(false, false)
+    }
+#undef HK_SHADOW_LAUNCH
 }
 void launch_medium(hipStream_t s, int n_cu, const DPathState& st, const DScene& sc, const DTables& T, const DFrame& fr, const DSobol& sob, int depth, DStats* stats) {
     static int blocks = resident_blocks(k_medium<false>, 256, n_cu, 8);

@@ -38,8 +38,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=1)
-    ap.add_argument("--config", default="cornell", choices=["cornell", "cloud"],
-                    help="cornell = BASELINE configs[1] (the bench line); cloud = configs[3] stand-in (synthetic NanoVDB cloud, 1024x1024, depth 32)")
+    ap.add_argument("--config", default="cornell", choices=["cornell", "cloud", "sky", "manylight"],
+                    help="cornell = BASELINE configs[1] (the bench line); sky = configs[2] stand-in (glass sphere + gold slab + env map + sun, depth 12); "
+                         "cloud = configs[3] stand-in (synthetic NanoVDB cloud, 1024x1024, depth 32); manylight = configs[4] stand-in (10^6 triangles, "
+                         "5*10^4 area lights, 1024x1024, depth 8)")
     args = ap.parse_args()
 
     import numpy as np
@@ -64,6 +66,14 @@ def main():
         W, H, DEPTH = 1024, 1024, 32
         scene, film, cam = scenes.cloud_scene(W, H, "nanovdb", res=(256, 256, 128), sigma_scale=620.0 / 4)
         workload = "synthetic BOMEX-like NanoVDB cloud (256x256x128, delta tracking), 1024x1024, VolPath depth 32, %d spp per step" % SPP_PER_STEP
+    elif args.config == "sky":
+        W, H, DEPTH = 800, 800, 12
+        scene, film, cam = scenes.sky_scene(W, H, env_res=512)
+        workload = "glass sphere + gold slab + 512^2 equal-area env map + sun (README scene stand-in), 800x800, VolPath depth 12, %d spp per step" % SPP_PER_STEP
+    elif args.config == "manylight":
+        W, H, DEPTH = 1024, 1024, 8
+        scene, film, cam = scenes.many_light_scene(W, H)
+        workload = "synthetic many-light barrel (10^6 triangles, ~5*10^4 area lights in the light BVH), 1024x1024, VolPath depth 8, %d spp per step" % SPP_PER_STEP
     else:
         scene, film, cam = scenes.cornell_box(W, H, light="area")
         workload = "Cornell box (diffuse + area light), 800x800, VolPath depth 8, %d spp per step" % SPP_PER_STEP

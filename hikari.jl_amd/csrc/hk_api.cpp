@@ -579,6 +579,8 @@ extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene**
     DScene& D = s->d;
     D.media = s->media.as<DMedium>();
     D.n_media = d->n_media;
+    D.media_mask = 0;
+    for (int i = 0; i < d->n_media; ++i) D.media_mask |= 1 << d->media[i].kind;
     D.nodes = s->nodes.as<DNode>();
     D.leaf_tris = s->leaf_tris.as<float4>();
     D.root_ref = bvh.root_ref;
@@ -855,6 +857,7 @@ int ensure_state(hk_integrator* I, int capacity) {
     HIP_TRY(alloc_arr(I, s.shadow_q, Q));
     HIP_TRY(alloc_arr(I, s.escaped_q, Q));
     HIP_TRY(alloc_arr(I, s.medium_q, Q));
+    HIP_TRY(alloc_arr(I, s.scatter_q, Q));
     HIP_TRY(alloc_arr(I, s.initial_medium, 1));
     HIP_TRY(hipMemset(s.initial_medium, 0xff, sizeof(int)));
     HIP_TRY(alloc_arr(I, s.mat_q, Q * HK_MAX_KINDS));

@@ -1543,10 +1543,14 @@ HKD MajorantIter exhausted_iter() {
     it.grid = nullptr;
     return it;
 }
+// MM is the set of medium kinds present in the scene (bit k = HK_MEDIUM_* k): the media kernels are instantiated per set so a
+// NanoVDB-only scene does not carry the registers of the RGB-grid run-time uplift (and vice versa).
+#define HK_HAS_MEDIUM(MM, K) (((MM) >> (K)) & 1)
+template <int MM>
 HKD MajorantIter create_majorant_iterator(const DMedium& m, v3 ro, v3 rd, float t_max, S4 lambda) {
     MajorantIter it = exhausted_iter();
     S4 sigma_t = eval_scaled(m.sigma_a, lambda) + eval_scaled(m.sigma_s, lambda);
-    if (m.kind == HK_MEDIUM_HOMOGENEOUS) {
+    if (HK_HAS_MEDIUM(MM, HK_MEDIUM_HOMOGENEOUS) && m.kind == HK_MEDIUM_HOMOGENEOUS) {
         it.mode = (0.0f >= t_max) ? 0 : 1;
         it.sigma_t = sigma_t;
         it.t_min = 0.0f;
@@ -1555,7 +1559,7 @@ HKD MajorantIter create_majorant_iterator(const DMedium& m, v3 ro, v3 rd, float 
         return it;
     }
     v3 o = ro, d = rd;
-    if (m.kind == HK_MEDIUM_GRID || m.kind == HK_MEDIUM_RGB_GRID) {
+    if ((HK_HAS_MEDIUM(MM, HK_MEDIUM_GRID) && m.kind == HK_MEDIUM_GRID) || (HK_HAS_MEDIUM(MM, HK_MEDIUM_RGB_GRID) && m.kind == HK_MEDIUM_RGB_GRID)) {
         const float* M = m.r2m;
         o = mk3(M[0] * ro.x + M[1] * ro.y + M[2] * ro.z + M[3], M[4] * ro.x + M[5] * ro.y + M[6] * ro.z + M[7], M[8] * ro.x + M[9] * ro.y + M[10] * ro.z + M[11]);
         d = mk3(M[0] * rd.x + M[1] * rd.y + M[2] * rd.z, M[4] * rd.x + M[5] * rd.y + M[6] * rd.z, M[8] * rd.x + M[9] * rd.y + M[10] * rd.z);
@@ -1592,7 +1596,7 @@ HKD MajorantIter create_majorant_iterator(const DMedium& m, v3 ro, v3 rd, float 
             it.limit[k] = -1;
         }
     }
-    it.sigma_t = m.kind == HK_MEDIUM_RGB_GRID ? s4(1.0f) : sigma_t;  // RGBGrid: unit sigma_t, scale is in the majorant grid (media.jl:1408-1420)
+    it.sigma_t = (HK_HAS_MEDIUM(MM, HK_MEDIUM_RGB_GRID) && m.kind == HK_MEDIUM_RGB_GRID) ? s4(1.0f) : sigma_t;  // RGBGrid: unit sigma_t, scale is in the majorant grid (media.jl:1408-1420)
     it.t_min = t_enter;
     it.t_max = t_exit;
     it.hom_called = false;
@@ -1767,16 +1771,17 @@ HKD float4 sample_rgb_grid(const float4* g, const DMedium& m, v3 pn) {  // media
     float4 c11 = lerp4(rgb_grid_at(g, m, ix, iy + 1, iz + 1), fx1, rgb_grid_at(g, m, ix + 1, iy + 1, iz + 1), fx);
     return lerp4(lerp4(c00, fy1, c10, fy), 1.0f - fz, lerp4(c01, fy1, c11, fy), fz);
 }
+template <int MM>
 HKD MediumProps sample_point(const DTables& T, S4 lambda, const DMedium& m, S4 base_a, S4 base_s, S4 base_Le, v3 p) {
     MediumProps mp;
     mp.g = m.g;
-    if (m.kind == HK_MEDIUM_HOMOGENEOUS) {
+    if (HK_HAS_MEDIUM(MM, HK_MEDIUM_HOMOGENEOUS) && m.kind == HK_MEDIUM_HOMOGENEOUS) {
         mp.sigma_a = base_a;
         mp.sigma_s = base_s;
         mp.Le = base_Le;
         return mp;
     }
-    if (m.kind == HK_MEDIUM_RGB_GRID) {  // media.jl:1327-1370: per-point uplift_rgb_unbounded of the interpolated RGB
+    if (HK_HAS_MEDIUM(MM, HK_MEDIUM_RGB_GRID) && m.kind == HK_MEDIUM_RGB_GRID) {  // media.jl:1327-1370: per-point uplift_rgb_unbounded of the interpolated RGB
         const float* M = m.r2m;
         v3 pm = mk3(M[0] * p.x + M[1] * p.y + M[2] * p.z + M[3], M[4] * p.x + M[5] * p.y + M[6] * p.z + M[7], M[8] * p.x + M[9] * p.y + M[10] * p.z + M[11]);
         v3 pn = mk3((pm.x - m.bmin[0]) / (m.bmax[0] - m.bmin[0]), (pm.y - m.bmin[1]) / (m.bmax[1] - m.bmin[1]), (pm.z - m.bmin[2]) / (m.bmax[2] - m.bmin[2]));
@@ -1792,7 +1797,7 @@ HKD MediumProps sample_point(const DTables& T, S4 lambda, const DMedium& m, S4 b
         return mp;
     }
     float d;
-    if (m.kind == HK_MEDIUM_GRID) {
+    if (HK_HAS_MEDIUM(MM, HK_MEDIUM_GRID) && (m.kind == HK_MEDIUM_GRID || !HK_HAS_MEDIUM(MM, HK_MEDIUM_NANOVDB))) {
         const float* M = m.r2m;
         d = sample_grid_density(m, mk3(M[0] * p.x + M[1] * p.y + M[2] * p.z + M[3], M[4] * p.x + M[5] * p.y + M[6] * p.z + M[7], M[8] * p.x + M[9] * p.y + M[10] * p.z + M[11]));
     } else
@@ -1803,12 +1808,13 @@ HKD MediumProps sample_point(const DTables& T, S4 lambda, const DMedium& m, S4 b
     return mp;
 }
 // compute_transmittance_ratio_tracking (intersection.jl:422-542)
+template <int MM>
 HKD void ratio_tracking(const DTables& T, const DMedium& m, v3 origin, v3 dir, float t_max, S4 lambda, S4& T_ray, S4& r_u, S4& r_l, unsigned& collisions) {
     T_ray = s4(1.0f);
     r_u = s4(1.0f);
     r_l = s4(1.0f);
     S4 base_a = eval_scaled(m.sigma_a, lambda), base_s = eval_scaled(m.sigma_s, lambda), base_Le = eval_scaled(m.Le, lambda);
-    MajorantIter it = create_majorant_iterator(m, origin, dir, t_max, lambda);
+    MajorantIter it = create_majorant_iterator<MM>(m, origin, dir, t_max, lambda);
     PCG32 rng = pcg32_init(pbrt_hash(origin), pbrt_hash(dir));
     for (int s = 0; s < 256; ++s) {
         float seg0, seg1;
@@ -1833,7 +1839,7 @@ HKD void ratio_tracking(const DTables& T, const DMedium& m, v3 origin, v3 dir, f
                 break;
             }
             ++collisions;
-            MediumProps mp = sample_point(T, lambda, m, base_a, base_s, base_Le, origin + dir * ts);
+            MediumProps mp = sample_point<MM>(T, lambda, m, base_a, base_s, base_Le, origin + dir * ts);
             S4 sn = s4max0(sm - mp.sigma_a - mp.sigma_s);
             S4 Tm = s4exp((-dt) * sm);
             float pr = Tm.x * sm0;

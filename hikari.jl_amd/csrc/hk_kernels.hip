@@ -237,208 +237,216 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace(DPathState st, DScene 
 }
 
 // ---------------------------------------------------------------------------------------------------
-// K4 + K5 + K6 fused: delta tracking with null collisions (delta-tracking.jl:79-453), direct lighting at the
-// scattering vertex (medium-scatter.jl:15-138) and phase-function sampling (medium-scatter.jl:148-216).
-// Runs after k_trace: paths that survive to their stored surface hit are appended to the material-kind
-// queues (Mix resolved here), paths that leave the scene to the escaped queue.
+// K4: delta tracking with null collisions (delta-tracking.jl:79-453), after k_trace, for the paths that travel inside a
+// medium.  The collision count per path is wildly uneven (0 .. 1000s), so the wave does not walk its queue 64 entries at
+// a time: every lane is a little state machine that takes ONE step per iteration (next majorant segment, or one tentative
+// collision) and, when its path is finished, waits for the next refill, where finished paths are routed with
+// ballot/popcount pushes (scatter queue -> k_scatter, escaped queue, material-kind queues with Mix resolved) and idle lanes
+// pull the next entries of the wave's own queue segment.  Still no atomics: queue, cursor and counts are wave-private.
+// Arithmetic and RNG consumption per path are exactly those of the sequential loop.
 // ---------------------------------------------------------------------------------------------------
-template <bool COUNT>
-__global__ void __launch_bounds__(256) k_medium(DPathState st, DScene sc, DTables T, DFrame fr, DSobol sob, int depth, DStats* stats) {
+#ifndef HK_REFILL_MIN_IDLE
+#define HK_REFILL_MIN_IDLE 16
+#endif
+#ifndef HK_TRACK_ADVANCE
+#define HK_TRACK_ADVANCE 8
+#endif
+enum { TR_BUSY = -101, TR_EMPTY = -100, TR_SCATTER = -3, TR_ESCAPED = -2 };  // >= 0: reached its surface hit of that material kind
+
+template <int MM>
+__global__ void __launch_bounds__(256) k_track(DPathState st, DScene sc, DTables T, DFrame fr, int depth, DStats* stats) {
     const int lane = lane_id();
-    unsigned n_coll = 0, n_lnodes = 0;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    unsigned n_coll = 0;
     HK_FOR_EACH_WAVE_SEGMENT(gw, st) {
         const uint32_t* __restrict__ queue = st.medium_q + (size_t)gw * st.wave_cap;
         const int n = *count_ptr(st, depth, Q_MEDIUM, gw);
         WaveQ q_escaped = wq_open(st.escaped_q, st, gw);
         q_escaped.count = *count_ptr(st, depth, Q_ESCAPED, gw);
-        WaveQ q_shadow = wq_open(st.shadow_q, st, gw);            // first writer of this depth's shadow / next-ray segments
-        WaveQ q_next = wq_open(st.ray_q[(depth + 1) & 1], st, gw);
+        WaveQ q_scatter = wq_open(st.scatter_q, st, gw);
         int kind_count[HK_MAX_KINDS];
 #pragma unroll
         for (int k = 0; k < HK_MAX_KINDS; ++k) kind_count[k] = *count_ptr(st, depth, Q_MAT0 + k, gw);
-        for (int base = 0; base < n; base += 64) {
-            int i = base + lane;
-            bool active = i < n;
-            uint32_t slot = active ? queue[i] : 0u;
-            int kind = -1;  // -1 terminated, -2 escaped, >= 0 reached its surface hit of that material kind
-            bool push_shadow = false, push_ray = false;
-            if (active) {
-                float4 O = st.ray_o[slot], D = st.ray_d[slot], H = st.hit[slot];
-                v3 ro = mk3(O.x, O.y, O.z), rd = mk3(D.x, D.y, D.z);
-                const float t_max = H.x;
-                const int prim = __float_as_int(H.y);
-                uint32_t fl = st.flags[slot];
-                const int medium_idx = (int)(fl >> 16) - 1;
+        int cursor = 0;     // wave-uniform: next unread entry of this wave's queue segment
+        int state = TR_EMPTY;
+        uint32_t slot = 0;
+        v3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 1), cur_o = mk3(0, 0, 0);
+        S4 lambda = s4(0.0f), beta = s4(0.0f), r_u = s4(0.0f), r_l = s4(0.0f), base_a = s4(0.0f), base_s = s4(0.0f), base_Le = s4(0.0f), sm = s4(0.0f);
+        uint64_t rng = 0;
+        MajorantIter it = exhausted_iter();
+        float seg1 = 0.0f, sm0 = 0.0f, t = 0.0f;
+        bool in_seg = false, pending = false;
+        float pend_dt = 0.0f;
+        int k_in_seg = 0, segi = 0, medium_idx = 0;
+        for (;;) {
+            const unsigned long long busy_m = __ballot(state == TR_BUSY);
+            if (busy_m == 0ull || (64 - __popcll(busy_m) >= HK_REFILL_MIN_IDLE && cursor < n)) {
+                // ---- route the finished paths ----
+                wq_push(q_scatter, slot, state == TR_SCATTER);
+                wq_push(q_escaped, slot, state == TR_ESCAPED);
+                unsigned long long pending = __ballot(state >= 0);
+                while (pending) {
+                    int src = __ffsll((long long)pending) - 1;
+                    int k = __shfl(state, src);
+                    bool mine = state == k;
+                    unsigned long long m = __ballot(mine);
+                    int cnt = 0;
+#pragma unroll
+                    for (int kk = 0; kk < HK_MAX_KINDS; ++kk) cnt = (kk == k) ? kind_count[kk] : cnt;
+                    if (mine) st.mat_q[((size_t)k * st.n_waves + gw) * st.wave_cap + cnt + __popcll(m & lt_mask)] = slot;
+                    int add = __popcll(m);
+#pragma unroll
+                    for (int kk = 0; kk < HK_MAX_KINDS; ++kk) kind_count[kk] += (kk == k) ? add : 0;
+                    pending &= ~m;
+                }
+                if (state != TR_BUSY) state = TR_EMPTY;
+                // ---- refill idle lanes from the wave's queue ----
+                const unsigned long long want = __ballot(state == TR_EMPTY);
+                const int avail = n - cursor;
+                const int rank = __popcll(want & lt_mask);
+                if (state == TR_EMPTY && rank < avail) {
+                    slot = queue[cursor + rank];
+                    float4 O = st.ray_o[slot], D = st.ray_d[slot];
+                    ro = mk3(O.x, O.y, O.z);
+                    rd = mk3(D.x, D.y, D.z);
+                    const float t_max = st.hit[slot].x;
+                    medium_idx = (int)(st.flags[slot] >> 16) - 1;
+                    const DMedium& med = sc.media[medium_idx];
+                    lambda = ld4(&st.lambda[slot]);
+                    beta = ld4(&st.beta[slot]);
+                    r_u = ld4(&st.r_u[slot]);
+                    r_l = ld4(&st.r_l[slot]);
+                    base_a = eval_scaled(med.sigma_a, lambda);
+                    base_s = eval_scaled(med.sigma_s, lambda);
+                    if (HK_HAS_MEDIUM(MM, HK_MEDIUM_HOMOGENEOUS)) base_Le = eval_scaled(med.Le, lambda);
+                    rng = lcg_init(ro, rd, t_max);
+                    it = create_majorant_iterator<MM>(med, ro, rd, t_max, lambda);
+                    in_seg = false;
+                    pending = false;
+                    segi = 0;
+                    state = TR_BUSY;
+                }
+                const int want_n = __popcll(want);
+                cursor += want_n < avail ? want_n : (avail > 0 ? avail : 0);
+                if (__ballot(state == TR_BUSY) == 0ull) break;
+            }
+            // ---- phase A: cheap steps (next majorant cell, free-flight sample, cell-boundary crossing) until every busy lane
+            //      either holds a tentative collision or has run out of segments ----
+            bool survived = false;
+#pragma unroll 1
+            for (int adv = 0; adv < HK_TRACK_ADVANCE; ++adv) {
+                const bool need = state == TR_BUSY && !pending && !survived;
+                if (__ballot(need) == 0ull) break;
+                if (!need) continue;
+                if (!in_seg) {
+                    float seg0;
+                    if (segi >= 256 || !majorant_next(it, seg0, seg1, sm))
+                        survived = true;  // ran out of segments with the path still alive
+                    else {
+                        ++segi;
+                        sm0 = sm.x;
+                        if (sm0 >= 1e-10f) {
+                            t = seg0;
+                            cur_o = ro + rd * t;
+                            in_seg = true;
+                            k_in_seg = 0;
+                        }
+                    }
+                } else if (k_in_seg >= 1024) {
+                    in_seg = false;
+                } else {
+                    ++k_in_seg;
+                    float u = lcg_next(rng);
+                    pend_dt = -logf(maxf(1e-10f, 1.0f - u)) / sm0;
+                    float ts = t + pend_dt;
+                    if (ts >= seg1) {
+                        float dr = seg1 - t;
+                        S4 Tm = s4exp((-dr) * sm);
+                        float T0 = Tm.x;
+                        if (T0 > 1e-10f) {
+                            beta = beta * Tm / T0;
+                            r_u = r_u * Tm / T0;
+                            r_l = r_l * Tm / T0;
+                        }
+                        in_seg = false;
+                    } else
+                        pending = true;
+                }
+            }
+            // ---- phase B: the tentative collisions (medium lookup, absorb / scatter / null) ----
+            if (state == TR_BUSY && pending) {
+                pending = false;
+                const float dt = pend_dt;
+                const float ts = t + dt;
                 const DMedium& med = sc.media[medium_idx];
-                S4 lambda = ld4(&st.lambda[slot]);
-                S4 beta = ld4(&st.beta[slot]), r_u = ld4(&st.r_u[slot]), r_l = ld4(&st.r_l[slot]);
-                S4 base_a = eval_scaled(med.sigma_a, lambda), base_s = eval_scaled(med.sigma_s, lambda), base_Le = eval_scaled(med.Le, lambda);
-                uint64_t rng = lcg_init(ro, rd, t_max);
-                MajorantIter it = create_majorant_iterator(med, ro, rd, t_max, lambda);
-                bool done = false, scattered = false;
-                v3 sp = mk3(0, 0, 0);
-                float sg = 0.0f;
-                for (int segi = 0; segi < 256 && !done; ++segi) {
-                    float seg0, seg1;
-                    S4 sm;
-                    if (!majorant_next(it, seg0, seg1, sm)) break;
-                    float sm0 = sm.x;
-                    if (sm0 < 1e-10f) continue;
-                    float t = seg0;
-                    v3 cur_o = ro + rd * t;
-                    for (int k = 0; k < 1024; ++k) {
-                        float u = lcg_next(rng);
-                        float dt = -logf(maxf(1e-10f, 1.0f - u)) / sm0;
-                        float ts = t + dt;
-                        if (ts >= seg1) {
-                            float dr = seg1 - t;
-                            S4 Tm = s4exp((-dr) * sm);
-                            float T0 = Tm.x;
-                            if (T0 > 1e-10f) {
-                                beta = beta * Tm / T0;
-                                r_u = r_u * Tm / T0;
-                                r_l = r_l * Tm / T0;
-                            }
-                            break;
-                        }
-                        S4 Tm = s4exp((-dt) * sm);
-                        v3 p = cur_o + rd * dt;
-                        ++n_coll;
-                        MediumProps mp = sample_point(T, lambda, med, base_a, base_s, base_Le, p);
-                        if (!is_black(mp.Le) && depth < fr.max_depth) {
-                            float pr = sm0 * Tm.x;
-                            if (pr > 1e-10f) {
-                                S4 r_e = r_u * sm * Tm / pr;
-                                if (!is_black(r_e)) st4(&st.L[slot], ld4(&st.L[slot]) + beta * mp.sigma_a * Tm * mp.Le / (pr * average(r_e)));
-                            }
-                        }
-                        float p_absorb = mp.sigma_a.x / sm0, p_scatter = mp.sigma_s.x / sm0;
-                        float ue = lcg_next(rng);
-                        if (ue < p_absorb) {
-                            done = true;
-                            break;
-                        } else if (ue < p_absorb + p_scatter) {
-                            done = true;
-                            if (depth >= fr.max_depth) break;
-                            float pdf = Tm.x * mp.sigma_s.x;
-                            if (pdf > 1e-10f) {
-                                beta = beta * Tm * mp.sigma_s / pdf;
-                                r_u = r_u * Tm * mp.sigma_s / pdf;
-                            }
-                            scattered = true;
-                            sp = p;
-                            sg = mp.g;
-                            break;
-                        } else {
-                            S4 sn = s4max0(sm - mp.sigma_a - mp.sigma_s);
-                            float pdf = Tm.x * sn.x;
-                            if (pdf > 1e-10f) {
-                                beta = beta * Tm * sn / pdf;
-                                r_u = r_u * Tm * sn / pdf;
-                                r_l = r_l * Tm * sm / pdf;
-                            } else {
-                                done = true;
-                                break;
-                            }
-                            t = ts;
-                            cur_o = p;
-                            if (is_black(beta) || is_black(r_u)) {
-                                done = true;
-                                break;
-                            }
-                        }
+                S4 Tm = s4exp((-dt) * sm);
+                v3 p = cur_o + rd * dt;
+                ++n_coll;
+                MediumProps mp = sample_point<MM>(T, lambda, med, base_a, base_s, base_Le, p);
+                if ((HK_HAS_MEDIUM(MM, HK_MEDIUM_HOMOGENEOUS) || HK_HAS_MEDIUM(MM, HK_MEDIUM_RGB_GRID)) && !is_black(mp.Le) && depth < fr.max_depth) {
+                    float pr = sm0 * Tm.x;
+                    if (pr > 1e-10f) {
+                        S4 r_e = r_u * sm * Tm / pr;
+                        if (!is_black(r_e)) st4(&st.L[slot], ld4(&st.L[slot]) + beta * mp.sigma_a * Tm * mp.Le / (pr * average(r_e)));
                     }
                 }
-                if (scattered) {
-                    v3 wo = -rd;
-                    int k = (int)slot / fr.n_pixels_padded;
-                    int px, py;
-                    bool inside;
-                    slot_to_pixel(fr, (int)slot - k * fr.n_pixels_padded, px, py, inside);
-                    SobolCtx sctx = sobol_ctx(sob, T.sobol, px + 1, py + 1, fr.first_sample + k * fr.sample_stride);
-                    const int base_dim = 6 + 7 * depth;
-                    // ---- K5: light-BVH NEE with n = 0, HG evaluated with cos = wo.wi (medium-scatter.jl:46-49) ----
-                    if (sc.n_lights > 0) {
-                        float light_select = sobol_1d(sctx, base_dim + 1);
-                        float light_pmf;
-                        int light_idx = bvh_sample_light(sc, sp, mk3(0, 0, 0), light_select, light_pmf, n_lnodes);
-                        if (light_idx >= 1 && light_idx <= sc.n_lights && light_pmf > 0.0f) {
-                            const DLight& sel = sc.lights[light_idx - 1];
-                            v2 u_light = mk2(0.0f, 0.0f);
-                            if (sel.kind >= HK_LIGHT_AMBIENT) u_light = sobol_2d(sctx, base_dim + 3);
-                            LightSample ls = sample_light(sc, T, sel, sp, lambda, u_light);
-                            if (ls.pdf > 0.0f && !is_black(ls.Li)) {
-                                float phase_val = hg_p(sg, dot(wo, ls.wi));
-                                if (phase_val > 0.0f) {
-                                    float light_pdf = ls.pdf * light_pmf;
-                                    float phase_pdf = ls.is_delta ? 0.0f : phase_val;
-                                    float tmx = ls.is_delta ? norm(ls.p_light - sp) - 0.001f : 1.0e6f;
-                                    st.sh_o[slot] = make_float4(sp.x, sp.y, sp.z, tmx);
-                                    st.sh_d[slot] = make_float4(ls.wi.x, ls.wi.y, ls.wi.z, __int_as_float(medium_idx));
-                                    st4(&st.sh_Ld[slot], beta * phase_val * ls.Li);
-                                    st4(&st.sh_ru[slot], r_u * phase_pdf);
-                                    st4(&st.sh_rl[slot], r_u * light_pdf);
-                                    push_shadow = true;
-                                }
-                            }
+                float p_absorb = mp.sigma_a.x / sm0, p_scatter = mp.sigma_s.x / sm0;
+                float ue = lcg_next(rng);
+                if (ue < p_absorb) {
+                    state = TR_EMPTY;  // absorbed
+                } else if (ue < p_absorb + p_scatter) {
+                    if (depth >= fr.max_depth)
+                        state = TR_EMPTY;
+                    else {
+                        float pdf = Tm.x * mp.sigma_s.x;
+                        if (pdf > 1e-10f) {
+                            beta = beta * Tm * mp.sigma_s / pdf;
+                            r_u = r_u * Tm * mp.sigma_s / pdf;
                         }
+                        st4(&st.beta[slot], beta);
+                        st4(&st.r_u[slot], r_u);
+                        st.ray_o[slot] = make_float4(p.x, p.y, p.z, INF_F);  // the scattering vertex: k_scatter continues from here
+                        state = TR_SCATTER;
                     }
-                    // ---- K6: sample the phase function, continue in the same medium ----
-                    int new_depth = depth + 1;
-                    if (new_depth < fr.max_depth) {
-                        v2 u = sobol_2d(sctx, base_dim + 6);
-                        float ppdf;
-                        v3 wi = sample_hg(sg, wo, u, ppdf);
-                        if (ppdf > 0.0f) {
-                            st.ray_o[slot] = make_float4(sp.x, sp.y, sp.z, INF_F);
-                            st.ray_d[slot] = make_float4(wi.x, wi.y, wi.z, D.w);
-                            st4(&st.beta[slot], beta);
-                            st4(&st.r_u[slot], r_u);
-                            st4(&st.r_l[slot], r_u / ppdf);
-                            st.flags[slot] = (uint32_t)new_depth | (1u << 9) | ((uint32_t)(medium_idx + 1) << 16);  // specular = false, any_non_specular = true
-                            push_ray = true;
-                        }
-                    }
-                } else if (!done && !(is_black(beta) || is_black(r_u) || depth >= fr.max_depth)) {
+                } else {
+                    S4 sn = s4max0(sm - mp.sigma_a - mp.sigma_s);
+                    float pdf = Tm.x * sn.x;
+                    if (pdf > 1e-10f) {
+                        beta = beta * Tm * sn / pdf;
+                        r_u = r_u * Tm * sn / pdf;
+                        r_l = r_l * Tm * sm / pdf;
+                        t = ts;
+                        cur_o = p;
+                        if (is_black(beta) || is_black(r_u)) state = TR_EMPTY;
+                    } else
+                        state = TR_EMPTY;
+                }
+            }
+            if (survived) {
+                state = TR_EMPTY;
+                if (!(is_black(beta) || is_black(r_u) || depth >= fr.max_depth)) {
                     // survived to t_max: hand the stored surface hit / the escape over with the updated throughput
                     st4(&st.beta[slot], beta);
                     st4(&st.r_u[slot], r_u);
                     st4(&st.r_l[slot], r_l);
+                    float4 H = st.hit[slot];
+                    const int prim = __float_as_int(H.y);
                     if (prim < 0)
-                        kind = -2;
+                        state = TR_ESCAPED;
                     else {
                         int mat = st.mat_id[slot];
                         if (sc.materials[mat].kind == HK_MAT_MIX) {
                             float w = 1.0f - H.z - H.w;
-                            mat = resolve_mix_material(sc, mat, ro + rd * t_max, -rd, uv_at(sc, prim, w, H.z, H.w));
+                            mat = resolve_mix_material(sc, mat, ro + rd * H.x, -rd, uv_at(sc, prim, w, H.z, H.w));
                             st.mat_id[slot] = mat;
                         }
-                        kind = sc.materials[mat].kind;
-                        if (kind == HK_MAT_MIX) kind = HK_MAT_FALLBACK;
+                        int kind = sc.materials[mat].kind;
+                        state = kind == HK_MAT_MIX ? HK_MAT_FALLBACK : kind;
                     }
                 }
             }
-            wq_push(q_shadow, slot, push_shadow);
-            wq_push(q_next, slot, push_ray);
-            wq_push(q_escaped, slot, kind == -2);
-            unsigned long long pending = __ballot(kind >= 0);
-            while (pending) {
-                int src = __ffsll((long long)pending) - 1;
-                int k = __shfl(kind, src);
-                bool mine = kind == k;
-                unsigned long long m = __ballot(mine);
-                int cnt = 0;
-#pragma unroll
-                for (int kk = 0; kk < HK_MAX_KINDS; ++kk) cnt = (kk == k) ? kind_count[kk] : cnt;
-                if (mine) st.mat_q[((size_t)k * st.n_waves + gw) * st.wave_cap + cnt + __popcll(m & ((1ull << lane) - 1ull))] = slot;
-                int add = __popcll(m);
-#pragma unroll
-                for (int kk = 0; kk < HK_MAX_KINDS; ++kk) kind_count[kk] += (kk == k) ? add : 0;
-                pending &= ~m;
-            }
         }
-        wq_close(q_shadow, count_ptr(st, depth, Q_SHADOW, gw));
-        wq_close(q_next, count_ptr(st, depth + 1, Q_RAY, gw));
+        wq_close(q_scatter, count_ptr(st, depth, Q_SCATTER, gw));
         wq_close(q_escaped, count_ptr(st, depth, Q_ESCAPED, gw));
         if (lane == 0) {
 #pragma unroll
@@ -447,6 +455,83 @@ __global__ void __launch_bounds__(256) k_medium(DPathState st, DScene sc, DTable
     }
     stats += global_wave();
     wave_add(&stats->collisions, n_coll);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K5 + K6: direct lighting at a medium scattering vertex (light-BVH NEE with n = 0, HG evaluated with cos = wo.wi,
+// medium-scatter.jl:15-138) and phase-function sampling (medium-scatter.jl:148-216).  First writer of this depth's shadow /
+// next-ray segments.
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_scatter(DPathState st, DScene sc, DTables T, DFrame fr, DSobol sob, int depth, DStats* stats) {
+    unsigned n_lnodes = 0;
+    HK_FOR_EACH_WAVE_SEGMENT(gw, st) {
+        const uint32_t* __restrict__ queue = st.scatter_q + (size_t)gw * st.wave_cap;
+        const int n = *count_ptr(st, depth, Q_SCATTER, gw);
+        WaveQ q_shadow = wq_open(st.shadow_q, st, gw);
+        WaveQ q_next = wq_open(st.ray_q[(depth + 1) & 1], st, gw);
+        for (int base = 0; base < n; base += 64) {
+            int i = base + lane_id();
+            bool active = i < n;
+            uint32_t slot = active ? queue[i] : 0u;
+            bool push_shadow = false, push_ray = false;
+            if (active) {
+                float4 O = st.ray_o[slot], D = st.ray_d[slot];
+                v3 sp = mk3(O.x, O.y, O.z), wo = mk3(-D.x, -D.y, -D.z);
+                const int medium_idx = (int)(st.flags[slot] >> 16) - 1;
+                const float sg = sc.media[medium_idx].g;
+                S4 lambda = ld4(&st.lambda[slot]);
+                S4 beta = ld4(&st.beta[slot]), r_u = ld4(&st.r_u[slot]);
+                int k = (int)slot / fr.n_pixels_padded;
+                int px, py;
+                bool inside;
+                slot_to_pixel(fr, (int)slot - k * fr.n_pixels_padded, px, py, inside);
+                SobolCtx sctx = sobol_ctx(sob, T.sobol, px + 1, py + 1, fr.first_sample + k * fr.sample_stride);
+                const int base_dim = 6 + 7 * depth;
+                if (sc.n_lights > 0) {
+                    float light_select = sobol_1d(sctx, base_dim + 1);
+                    float light_pmf;
+                    int light_idx = bvh_sample_light(sc, sp, mk3(0, 0, 0), light_select, light_pmf, n_lnodes);
+                    if (light_idx >= 1 && light_idx <= sc.n_lights && light_pmf > 0.0f) {
+                        const DLight& sel = sc.lights[light_idx - 1];
+                        v2 u_light = mk2(0.0f, 0.0f);
+                        if (sel.kind >= HK_LIGHT_AMBIENT) u_light = sobol_2d(sctx, base_dim + 3);
+                        LightSample ls = sample_light(sc, T, sel, sp, lambda, u_light);
+                        if (ls.pdf > 0.0f && !is_black(ls.Li)) {
+                            float phase_val = hg_p(sg, dot(wo, ls.wi));
+                            if (phase_val > 0.0f) {
+                                float light_pdf = ls.pdf * light_pmf;
+                                float phase_pdf = ls.is_delta ? 0.0f : phase_val;
+                                float tmx = ls.is_delta ? norm(ls.p_light - sp) - 0.001f : 1.0e6f;
+                                st.sh_o[slot] = make_float4(sp.x, sp.y, sp.z, tmx);
+                                st.sh_d[slot] = make_float4(ls.wi.x, ls.wi.y, ls.wi.z, __int_as_float(medium_idx));
+                                st4(&st.sh_Ld[slot], beta * phase_val * ls.Li);
+                                st4(&st.sh_ru[slot], r_u * phase_pdf);
+                                st4(&st.sh_rl[slot], r_u * light_pdf);
+                                push_shadow = true;
+                            }
+                        }
+                    }
+                }
+                int new_depth = depth + 1;
+                if (new_depth < fr.max_depth) {
+                    v2 u = sobol_2d(sctx, base_dim + 6);
+                    float ppdf;
+                    v3 wi = sample_hg(sg, wo, u, ppdf);
+                    if (ppdf > 0.0f) {
+                        st.ray_d[slot] = make_float4(wi.x, wi.y, wi.z, D.w);  // ray_o already holds the vertex, t_max = Inf
+                        st4(&st.r_l[slot], r_u / ppdf);
+                        st.flags[slot] = (uint32_t)new_depth | (1u << 9) | ((uint32_t)(medium_idx + 1) << 16);  // specular = false, any_non_specular = true
+                        push_ray = true;
+                    }
+                }
+            }
+            wq_push(q_shadow, slot, push_shadow);
+            wq_push(q_next, slot, push_ray);
+        }
+        wq_close(q_shadow, count_ptr(st, depth, Q_SHADOW, gw));
+        wq_close(q_next, count_ptr(st, depth + 1, Q_RAY, gw));
+    }
+    stats += global_wave();
     wave_add(&stats->light_nodes, n_lnodes);
 }
 
@@ -700,17 +785,29 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
 }
 
 // ---------------------------------------------------------------------------------------------------
-// K10: shadow rays (intersection.jl:302-406, 565-600).  Surface-only scenes: one segment, early exit on
-// any opaque hit.  Medium-transition / alpha surfaces are walked through (<= 10 segments).
+// K10: shadow rays (intersection.jl:302-406, 565-600).
+//   k_shadow       scenes without media whose surfaces are all opaque: one any-hit cast per ray.
+//   k_shadow_walk  the general walk through medium-transition / alpha surfaces (<= 10 segments) with ratio tracking
+//                  (intersection.jl:422-542) in the medium segments.  Like k_track it is a per-lane state machine with
+//                  wave-private refill: a lane alternates between "needs a cast" and "tracking steps", casts are done
+//                  together for all lanes that need one, and finished lanes pull the next shadow ray of the wave's queue.
 // ---------------------------------------------------------------------------------------------------
-// SURFACES_ONLY (no media, every surface opaque) is the lean instantiation: one any-hit cast, ~1/3 of the registers of the
-// general walk (whose ratio tracking + run-time RGB uplift would otherwise set the occupancy of every scene).
-template <bool COUNT, bool SURFACES_ONLY>
-__global__ void __launch_bounds__(HK_TRACE_BLOCK) k_shadow(DPathState st, DScene sc, DTables T, int depth, DStats* stats) {
+HKD void shadow_contribute(DPathState& st, uint32_t slot, S4 T_ray, S4 tr_u, S4 tr_l) {
+    if (is_black(T_ray)) return;
+    S4 mis = ld4(&st.sh_ru[slot]) * tr_u + ld4(&st.sh_rl[slot]) * tr_l;
+    float den = average(mis);
+    if (den > 1e-10f) {
+        S4 fin = ld4(&st.sh_Ld[slot]) * T_ray / den;
+        if (!is_black(fin)) st4(&st.L[slot], ld4(&st.L[slot]) + fin);
+    }
+}
+
+template <bool COUNT>
+__global__ void __launch_bounds__(HK_TRACE_BLOCK) k_shadow(DPathState st, DScene sc, int depth, DStats* stats) {
     __shared__ int lds_stack[(HK_TRACE_BLOCK / 64) * HK_LDS_STACK * 64];
     int* stack = lds_stack + (threadIdx.x >> 6) * (HK_LDS_STACK * 64);
     const int lane = lane_id();
-    unsigned n_nodes = 0, n_tris = 0, n_casts = 0, n_hits = 0, n_coll = 0;
+    unsigned n_nodes = 0, n_tris = 0, n_casts = 0, n_hits = 0;
     HK_FOR_EACH_WAVE_SEGMENT(gw, st) {
     const uint32_t* __restrict__ queue = st.shadow_q + (size_t)gw * st.wave_cap;
     const int n = *count_ptr(st, depth, Q_SHADOW, gw);
@@ -719,89 +816,258 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_shadow(DPathState st, DScene
         if (i >= n) continue;
         uint32_t slot = queue[i];
         float4 O = st.sh_o[slot], D = st.sh_d[slot];
-        v3 ro = mk3(O.x, O.y, O.z), dir = mk3(D.x, D.y, D.z);
-        float t_remaining = O.w;
-        int medium = __float_as_int(D.w);
-        S4 T_ray = s4(1.0f), tr_u = s4(1.0f), tr_l = s4(1.0f);
-        S4 lambda = s4(0.0f);
-        if (sc.n_media > 0) lambda = ld4(&st.lambda[slot]);
-        bool visible = false, done = false;
-        if (SURFACES_ONLY) {
-            if (t_remaining >= 1e-6f) {
-                bool opaque;
-                ++n_casts;
-                HitRec h = traverse<1, COUNT>(sc, ro, dir, t_remaining, stack, lane, n_nodes, n_tris, opaque);
-                visible = h.prim < 0;
-                if (!visible) ++n_hits;
+        if (O.w < 1e-6f) continue;
+        bool opaque;
+        ++n_casts;
+        HitRec h = traverse<1, COUNT>(sc, mk3(O.x, O.y, O.z), mk3(D.x, D.y, D.z), O.w, stack, lane, n_nodes, n_tris, opaque);
+        if (h.prim < 0)
+            shadow_contribute(st, slot, s4(1.0f), s4(1.0f), s4(1.0f));
+        else
+            ++n_hits;
+    }
+    }
+    stats += global_wave();
+    wave_add(&stats->rays_shadow, n_casts);
+    wave_add(&stats->hits, n_hits);
+    if (COUNT) {
+        wave_add(&stats->sh_nodes, n_nodes);
+        wave_add(&stats->sh_tris, n_tris);
+    }
+}
+
+enum { SH_EMPTY = 0, SH_CAST = 1, SH_TRACK = 2 };
+#ifndef HK_SHADOW_TRACK_BATCH
+#define HK_SHADOW_TRACK_BATCH 4
+#endif
+
+template <bool COUNT, int MM>
+__global__ void __launch_bounds__(HK_TRACE_BLOCK) k_shadow_walk(DPathState st, DScene sc, DTables T, int depth, DStats* stats) {
+    __shared__ int lds_stack[(HK_TRACE_BLOCK / 64) * HK_LDS_STACK * 64];
+    int* stack = lds_stack + (threadIdx.x >> 6) * (HK_LDS_STACK * 64);
+    const int lane = lane_id();
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    unsigned n_nodes = 0, n_tris = 0, n_casts = 0, n_hits = 0, n_coll = 0;
+    HK_FOR_EACH_WAVE_SEGMENT(gw, st) {
+    const uint32_t* __restrict__ queue = st.shadow_q + (size_t)gw * st.wave_cap;
+    const int n = *count_ptr(st, depth, Q_SHADOW, gw);
+    int cursor = 0;
+    int state = SH_EMPTY;
+    uint32_t slot = 0;
+    v3 ro = mk3(0, 0, 0), dir = mk3(0, 0, 1);
+    float t_remaining = 0.0f, hit_t = 0.0f;
+    int medium = -1, next_medium = -1, seg = 0;
+    bool miss_case = false, transition = false;
+    S4 T_ray = s4(1.0f), tr_u = s4(1.0f), tr_l = s4(1.0f), lambda = s4(0.0f);
+    // ratio-tracking state of the current medium segment
+    S4 sT = s4(1.0f), su = s4(1.0f), sl = s4(1.0f), base_a = s4(0.0f), base_s = s4(0.0f), base_Le = s4(0.0f), sm = s4(0.0f);
+    MajorantIter it = exhausted_iter();
+    PCG32 rng = PCG32{0ull, 0ull};
+    float seg1 = 0.0f, sm0 = 0.0f, t = 0.0f;
+    bool in_seg = false, after_inner = false, pending = false;
+    float pend_dt = 0.0f;
+    int k_in_seg = 0, segi = 0;
+    for (;;) {
+        // ---- refill ----
+        const unsigned long long busy_m = __ballot(state != SH_EMPTY);
+        if (busy_m == 0ull || (64 - __popcll(busy_m) >= HK_REFILL_MIN_IDLE && cursor < n)) {
+            const unsigned long long want = ~busy_m;
+            const int avail = n - cursor;
+            const int rank = __popcll(want & lt_mask);
+            if (state == SH_EMPTY && rank < avail) {
+                slot = queue[cursor + rank];
+                float4 O = st.sh_o[slot], D = st.sh_d[slot];
+                ro = mk3(O.x, O.y, O.z);
+                dir = mk3(D.x, D.y, D.z);
+                t_remaining = O.w;
+                medium = __float_as_int(D.w);
+                T_ray = s4(1.0f);
+                tr_u = s4(1.0f);
+                tr_l = s4(1.0f);
+                if (MM != 0) lambda = ld4(&st.lambda[slot]);
+                seg = 0;
+                state = t_remaining < 1e-6f ? SH_EMPTY : SH_CAST;  // a degenerate ray is simply not visible
             }
-            done = true;
+            const int want_n = __popcll(want);
+            cursor += want_n < avail ? want_n : (avail > 0 ? avail : 0);
+            if (__ballot(state != SH_EMPTY) == 0ull) {
+                if (cursor >= n) break;
+                continue;  // every fetched ray was degenerate: fetch again
+            }
         }
-        for (int seg = 0; seg < 10 && !done; ++seg) {
-            if (t_remaining < 1e-6f) break;
-            bool opaque;
-            ++n_casts;
-            HitRec h = traverse<1, COUNT>(sc, ro, dir, t_remaining, stack, lane, n_nodes, n_tris, opaque);
-            if (h.prim < 0) {
-                if (medium >= 0) {  // transmittance of the remaining distance (intersection.jl:326-336)
-                    S4 sT, su, sl;
-                    ratio_tracking(T, sc.media[medium], ro, dir, t_remaining, lambda, sT, su, sl, n_coll);
+        // ---- casts, for all lanes that need one (when enough of them wait, or nothing else can run) ----
+        {
+            const unsigned long long cast_m = __ballot(state == SH_CAST);
+            const unsigned long long track_m = __ballot(state == SH_TRACK);
+            if (cast_m != 0ull && (track_m == 0ull || __popcll(cast_m) >= HK_REFILL_MIN_IDLE)) {
+                if (state == SH_CAST) {
+                    bool opaque;
+                    ++n_casts;
+                    HitRec h = traverse<1, COUNT>(sc, ro, dir, t_remaining, stack, lane, n_nodes, n_tris, opaque);
+                    bool alive = true;
+                    if (h.prim < 0) {
+                        miss_case = true;
+                        hit_t = t_remaining;
+                    } else {
+                        ++n_hits;
+                        miss_case = false;
+                        hit_t = h.t;
+                        if (opaque)
+                            alive = false;
+                        else {
+                            DTriMeta meta = sc.meta[h.prim];
+                            DMediumInterface mi = sc.mis[meta.mi];
+                            v3 ng = geometric_normal(sc, h.prim);
+                            bool entering = dot(dir, ng) < 0.0f;
+                            transition = mi.inside != mi.outside;
+                            next_medium = transition ? (entering ? mi.inside : mi.outside) : medium;
+                            if (!transition) {
+                                float w = 1.0f - h.u - h.v;
+                                float alpha = surface_alpha(sc, mi.material, uv_at(sc, h.prim, w, h.u, h.v));
+                                bool pass = false;
+                                if (alpha < 1.0f) {
+                                    PCG32 arng = pcg32_init(pbrt_hash(ro), pbrt_hash(dir));
+                                    pass = pcg32_f32(arng) > alpha;
+                                }
+                                alive = pass;
+                            }
+                        }
+                    }
+                    if (!alive)
+                        state = SH_EMPTY;  // blocked
+                    else if (MM != 0 && medium >= 0) {
+                        // ratio tracking over [0, hit_t] of this segment (intersection.jl:326-336, 376-386)
+                        const DMedium& m = sc.media[medium];
+                        sT = s4(1.0f);
+                        su = s4(1.0f);
+                        sl = s4(1.0f);
+                        base_a = eval_scaled(m.sigma_a, lambda);
+                        base_s = eval_scaled(m.sigma_s, lambda);
+                        if (HK_HAS_MEDIUM(MM, HK_MEDIUM_HOMOGENEOUS)) base_Le = eval_scaled(m.Le, lambda);
+                        it = create_majorant_iterator<MM>(m, ro, dir, hit_t, lambda);
+                        rng = pcg32_init(pbrt_hash(ro), pbrt_hash(dir));
+                        in_seg = false;
+                        after_inner = false;
+                        pending = false;
+                        segi = 0;
+                        state = SH_TRACK;
+                    } else if (miss_case) {
+                        shadow_contribute(st, slot, T_ray, tr_u, tr_l);
+                        state = SH_EMPTY;
+                    } else {
+                        // step over the surface (no medium on this side)
+                        bool stop = false;
+                        if (transition) {
+                            if (is_black(T_ray)) stop = true;
+                            medium = next_medium;
+                        }
+                        ro = ro + dir * (hit_t + 1e-4f);
+                        t_remaining = t_remaining - hit_t - 1e-4f;
+                        ++seg;
+                        state = (stop || seg >= 10 || t_remaining < 1e-6f) ? SH_EMPTY : SH_CAST;
+                    }
+                }
+            }
+        }
+        // ---- a few ratio-tracking rounds: cheap steps until a tentative collision is pending, then the collisions ----
+        if (MM != 0) {
+#pragma unroll 1
+            for (int batch = 0; batch < HK_SHADOW_TRACK_BATCH; ++batch) {
+                if (__ballot(state == SH_TRACK) == 0ull) break;
+                bool track_done = false;
+#pragma unroll 1
+                for (int adv = 0; adv < HK_TRACK_ADVANCE; ++adv) {
+                    const bool need = state == SH_TRACK && !pending && !track_done;
+                    if (__ballot(need) == 0ull) break;
+                    if (!need) continue;
+                    if (!in_seg) {
+                        float seg0;
+                        if (after_inner && is_black(sT))
+                            track_done = true;
+                        else if (segi >= 256 || !majorant_next(it, seg0, seg1, sm))
+                            track_done = true;
+                        else {
+                            ++segi;
+                            sm0 = sm.x;
+                            if (sm0 >= 1e-10f) {
+                                t = seg0;
+                                in_seg = true;
+                                k_in_seg = 0;
+                            }
+                        }
+                        after_inner = false;
+                    } else if (k_in_seg >= 100) {
+                        in_seg = false;
+                        after_inner = true;
+                    } else {
+                        ++k_in_seg;
+                        float u = pcg32_f32(rng);
+                        pend_dt = -logf(maxf(1e-10f, 1.0f - u)) / sm0;
+                        float ts = t + pend_dt;
+                        if (ts >= seg1) {
+                            float dr = seg1 - t;
+                            S4 Tm = s4exp((-dr) * sm);
+                            float T0 = Tm.x;
+                            if (T0 > 1e-10f) {
+                                sT = sT * Tm / T0;
+                                sl = sl * Tm / T0;
+                                su = su * Tm / T0;
+                            }
+                            in_seg = false;
+                            after_inner = true;
+                        } else
+                            pending = true;
+                    }
+                }
+                if (state == SH_TRACK && pending) {
+                    pending = false;
+                    const float dt = pend_dt;
+                    const float ts = t + dt;
+                    ++n_coll;
+                    MediumProps mp = sample_point<MM>(T, lambda, sc.media[medium], base_a, base_s, base_Le, ro + dir * ts);
+                    S4 sn = s4max0(sm - mp.sigma_a - mp.sigma_s);
+                    S4 Tm = s4exp((-dt) * sm);
+                    float pr = Tm.x * sm0;
+                    if (pr > 1e-10f) {
+                        sT = sT * Tm * sn / pr;
+                        sl = sl * Tm * sm / pr;
+                        su = su * Tm * sn / pr;
+                        S4 est = sT / maxf(1e-10f, average(sl + su));
+                        if (max_component(est) < 0.05f) {
+                            float rr = pcg32_f32(rng);
+                            if (rr < 0.75f) {
+                                sT = s4(0.0f);
+                                track_done = true;
+                            } else
+                                sT = sT / (1.0f - 0.75f);
+                        }
+                        if (is_black(sT)) track_done = true;
+                        t = ts;
+                    } else {
+                        sT = s4(0.0f);
+                        track_done = true;
+                    }
+                }
+                if (track_done) {
                     T_ray = T_ray * sT;
                     tr_u = tr_u * su;
                     tr_l = tr_l * sl;
+                    if (miss_case) {
+                        shadow_contribute(st, slot, T_ray, tr_u, tr_l);
+                        state = SH_EMPTY;
+                    } else {
+                        bool stop = false;
+                        if (transition) {
+                            if (is_black(T_ray)) stop = true;
+                            medium = next_medium;
+                        }
+                        ro = ro + dir * (hit_t + 1e-4f);
+                        t_remaining = t_remaining - hit_t - 1e-4f;
+                        ++seg;
+                        state = (stop || seg >= 10 || t_remaining < 1e-6f) ? SH_EMPTY : SH_CAST;
+                    }
                 }
-                visible = true;
-                done = true;
-                break;
-            }
-            ++n_hits;
-            if (opaque) {
-                done = true;
-                break;
-            }
-            DTriMeta meta = sc.meta[h.prim];
-            DMediumInterface mi = sc.mis[meta.mi];
-            v3 ng = geometric_normal(sc, h.prim);
-            bool entering = dot(dir, ng) < 0.0f;
-            if (mi.inside == mi.outside) {
-                float w = 1.0f - h.u - h.v;
-                float alpha = surface_alpha(sc, mi.material, uv_at(sc, h.prim, w, h.u, h.v));
-                bool pass = false;
-                if (alpha < 1.0f) {
-                    PCG32 rng = pcg32_init(pbrt_hash(ro), pbrt_hash(dir));
-                    pass = pcg32_f32(rng) > alpha;
-                }
-                if (!pass) {
-                    done = true;
-                    break;
-                }
-            }
-            if (medium >= 0) {  // transmittance up to this surface
-                S4 sT, su, sl;
-                ratio_tracking(T, sc.media[medium], ro, dir, h.t, lambda, sT, su, sl, n_coll);
-                T_ray = T_ray * sT;
-                tr_u = tr_u * su;
-                tr_l = tr_l * sl;
-            }
-            if (mi.inside != mi.outside) {
-                if (is_black(T_ray)) {
-                    visible = true;
-                    done = true;
-                    break;
-                }
-                medium = entering ? mi.inside : mi.outside;
-            }
-            ro = ro + dir * (h.t + 1e-4f);
-            t_remaining = t_remaining - h.t - 1e-4f;
-        }
-        if (visible && !is_black(T_ray)) {
-            S4 mis = ld4(&st.sh_ru[slot]) * tr_u + ld4(&st.sh_rl[slot]) * tr_l;
-            float den = average(mis);
-            if (den > 1e-10f) {
-                S4 fin = ld4(&st.sh_Ld[slot]) * T_ray / den;
-                if (!is_black(fin)) st4(&st.L[slot], ld4(&st.L[slot]) + fin);
             }
         }
-        (void)medium;
     }
     }
     stats += global_wave();
@@ -976,23 +1242,58 @@ void launch_trace(hipStream_t s, int n_cu, const DPathState& st, const DScene& s
     else
         hipLaunchKernelGGL(k_trace<false>, dim3(clamp_blocks(b0, st)), dim3(HK_TRACE_BLOCK), 0, s, st, sc, T, fr, depth, stats);
 }
+// media kernels are instantiated for a single medium kind or for all four (15)
+static int media_mask_class(const DScene& sc) {
+    int m = sc.media_mask;
+    return (m == 1 || m == 2 || m == 4 || m == 8) ? m : 15;
+}
 void launch_shadow(hipStream_t s, int n_cu, const DPathState& st, const DScene& sc, const DTables& T, const DFrame& fr, int depth, DStats* stats) {
-    const bool lean = sc.all_opaque && sc.n_media == 0;
-#define HK_SHADOW_LAUNCH(C, L)                                                                                                  \
-    {                                                                                                                           \
-        static int blocks = resident_blocks(k_shadow<C, L>, HK_TRACE_BLOCK, n_cu, 8);                                            \
-        hipLaunchKernelGGL((k_shadow<C, L>), dim3(clamp_blocks(blocks, st)), dim3(HK_TRACE_BLOCK), 0, s, st, sc, T, depth, stats); \
+    if (sc.all_opaque && sc.n_media == 0) {
+        static int b0 = resident_blocks(k_shadow<false>, HK_TRACE_BLOCK, n_cu, 8), b1 = resident_blocks(k_shadow<true>, HK_TRACE_BLOCK, n_cu, 8);
+        if (fr.count_nodes)
+            hipLaunchKernelGGL(k_shadow<true>, dim3(clamp_blocks(b1, st)), dim3(HK_TRACE_BLOCK), 0, s, st, sc, depth, stats);
+        else
+            hipLaunchKernelGGL(k_shadow<false>, dim3(clamp_blocks(b0, st)), dim3(HK_TRACE_BLOCK), 0, s, st, sc, depth, stats);
+        return;
+    }
+#define HK_SHADOW_LAUNCH(C, MM)                                                                                                        \
+    {                                                                                                                                  \
+        static int blocks = resident_blocks(k_shadow_walk<C, MM>, HK_TRACE_BLOCK, n_cu, 8);                                             \
+        hipLaunchKernelGGL((k_shadow_walk<C, MM>), dim3(clamp_blocks(blocks, st)), dim3(HK_TRACE_BLOCK), 0, s, st, sc, T, depth, stats); \
+    }
+#define HK_SHADOW_MM(C)                                   \
+    switch (sc.n_media > 0 ? media_mask_class(sc) : 0) {  \
+        case 0: HK_SHADOW_LAUNCH(C, 0) break;             \
+        case 1: HK_SHADOW_LAUNCH(C, 1) break;             \
+        case 2: HK_SHADOW_LAUNCH(C, 2) break;             \
+        case 4: HK_SHADOW_LAUNCH(C, 4) break;             \
+        case 8: HK_SHADOW_LAUNCH(C, 8) break;             \
+        default: HK_SHADOW_LAUNCH(C, 15) break;           \
     }
     if (fr.count_nodes) {
-        if (lean) HK_SHADOW_LAUNCH(true, true) else HK_SHADOW_LAUNCH(true, false)
+        HK_SHADOW_MM(true)
     } else {
-        if (lean) HK_SHADOW_LAUNCH(false, true) else HK_SHADOW_LAUNCH(false, false)
+        HK_SHADOW_MM(false)
     }
+#undef HK_SHADOW_MM
 #undef HK_SHADOW_LAUNCH
 }
 void launch_medium(hipStream_t s, int n_cu, const DPathState& st, const DScene& sc, const DTables& T, const DFrame& fr, const DSobol& sob, int depth, DStats* stats) {
-    static int blocks = resident_blocks(k_medium<false>, 256, n_cu, 8);
-    hipLaunchKernelGGL(k_medium<false>, dim3(clamp_blocks(blocks, st)), dim3(256), 0, s, st, sc, T, fr, sob, depth, stats);
+#define HK_TRACK_LAUNCH(MM)                                                                                              \
+    {                                                                                                                    \
+        static int blocks = resident_blocks(k_track<MM>, 256, n_cu, 8);                                                   \
+        hipLaunchKernelGGL((k_track<MM>), dim3(clamp_blocks(blocks, st)), dim3(256), 0, s, st, sc, T, fr, depth, stats);   \
+    }
+    switch (media_mask_class(sc)) {
+        case 1: HK_TRACK_LAUNCH(1) break;
+        case 2: HK_TRACK_LAUNCH(2) break;
+        case 4: HK_TRACK_LAUNCH(4) break;
+        case 8: HK_TRACK_LAUNCH(8) break;
+        default: HK_TRACK_LAUNCH(15) break;
+    }
+#undef HK_TRACK_LAUNCH
+    static int sblocks = resident_blocks(k_scatter, 256, n_cu, 8);
+    hipLaunchKernelGGL(k_scatter, dim3(clamp_blocks(sblocks, st)), dim3(256), 0, s, st, sc, T, fr, sob, depth, stats);
 }
 void launch_detect_camera_medium(hipStream_t s, const DPathState& st, const DScene& sc, float x, float y, float z, DStats* stats) {
     hipLaunchKernelGGL(k_detect_camera_medium, dim3(1), dim3(64), 0, s, st, sc, x, y, z, stats);

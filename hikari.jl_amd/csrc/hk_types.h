@@ -144,6 +144,7 @@ struct DScene {
     int num_bvh_lights, num_infinite_lights;
     const DMedium* media;
     int n_media;
+    int media_mask;             // bit k set: a medium of kind k (HK_MEDIUM_*) is present
     const DEnvMap* envmaps;
     int n_envmaps;
     int has_escape_lights;      // any ambient / environment light
@@ -183,7 +184,7 @@ struct DSobol {
 };
 
 // queue ids inside one depth's counter block
-enum { Q_RAY = 0, Q_SHADOW = 1, Q_ESCAPED = 2, Q_MEDIUM = 3, Q_MAT0 = 4, Q_COUNT = Q_MAT0 + HK_MAX_KINDS };
+enum { Q_RAY = 0, Q_SHADOW = 1, Q_ESCAPED = 2, Q_MEDIUM = 3, Q_SCATTER = 4, Q_MAT0 = 5, Q_COUNT = Q_MAT0 + HK_MAX_KINDS };
 
 struct DPathState {
     int capacity;          // path slots
@@ -210,6 +211,7 @@ struct DPathState {
     uint32_t* shadow_q;
     uint32_t* escaped_q;
     uint32_t* medium_q;    // rays that travel inside a medium (delta tracking before their surface hit is processed)
+    uint32_t* scatter_q;   // paths that scattered inside a medium at this depth (K5/K6 input)
     int* initial_medium;   // camera medium detected on the device (K14)
     uint32_t* mat_q;       // HK_MAX_KINDS * W * wave_cap
     int* counters;         // [(max_depth + 2) * Q_COUNT][W] per-wave queue sizes

@@ -236,3 +236,64 @@ def textured_scene(width=64, height=64):
     film = Film((width, height))
     cam = PerspectiveCamera((0, 1, -3.5), (0, 1, 0), film, fov=40.0)
     return s, film, cam
+
+
+def _boxes_mesh(centers, half, angle):
+    """n axis-rotated (about y) boxes as one triangle soup, vectorised: 12 triangles per box, flat normals, uv per face."""
+    n = centers.shape[0]
+    sx = np.array([-1, 1, 1, -1, -1, 1, 1, -1], np.float64)
+    sy = np.array([-1, -1, 1, 1, -1, -1, 1, 1], np.float64)
+    sz = np.array([-1, -1, -1, -1, 1, 1, 1, 1], np.float64)
+    lx, ly, lz = half[:, 0:1] * sx, half[:, 1:2] * sy, half[:, 2:3] * sz          # [n, 8]
+    ca, sa = np.cos(angle)[:, None], np.sin(angle)[:, None]
+    wx = centers[:, 0:1] + ca * lx + sa * lz
+    wy = centers[:, 1:2] + ly
+    wz = centers[:, 2:3] - sa * lx + ca * lz
+    V = np.stack([wx, wy, wz], axis=-1)                                              # [n, 8, 3]
+    quads = np.array([[0, 3, 2, 1], [4, 5, 6, 7], [0, 1, 5, 4], [3, 7, 6, 2], [0, 4, 7, 3], [1, 2, 6, 5]])   # outward CCW
+    tris = np.concatenate([quads[:, [0, 1, 2]], quads[:, [0, 2, 3]]], axis=0)       # [12, 3]
+    P = V[:, tris, :].reshape(n * 12, 3, 3).astype(f32)
+    e1, e2 = P[:, 1] - P[:, 0], P[:, 2] - P[:, 0]
+    nrm = np.cross(e1, e2)
+    nrm = nrm / np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-20)
+    N = np.repeat(nrm[:, None, :], 3, axis=1).astype(f32)
+    return P, N
+
+
+def many_light_scene(width=1024, height=1024, n_boxes=83334, emissive_frac=0.05, seed=1):
+    """Config 5 stand-in: ~10^6 triangles as boxes in concentric barrel layers around the z axis, 5 % of the boxes
+    emissive with a random Le in [0.2, 1] per face (=> ~5*10^4 DiffuseAreaLights in the light BVH), the rest matte / conductor.
+    Per-face emission colours come through the reference's own mechanism: a textured Emissive is point-sampled at each face's
+    centroid uv (scene-mesh.jl:49), so every face of the emissive mesh carries a uv that selects one texel."""
+    from .geometry import Mesh
+    from .materials import Texture
+    rng = np.random.default_rng(seed)
+    layers = 12
+    layer = rng.integers(0, layers, n_boxes)
+    radius = 1.0 + 0.45 * layer + 0.1 * rng.random(n_boxes)
+    phi = rng.random(n_boxes) * 2 * np.pi
+    zpos = (rng.random(n_boxes) * 2 - 1) * 6.0
+    centers = np.stack([radius * np.cos(phi), radius * np.sin(phi), zpos], axis=1)
+    half = 0.012 + 0.03 * rng.random((n_boxes, 3))
+    P, N = _boxes_mesh(centers, half, rng.random(n_boxes) * np.pi)
+    group = rng.random(n_boxes)
+    em = group < emissive_frac
+    cond = (group >= emissive_frac) & (group < emissive_frac + 0.25)
+    matte = ~(em | cond)
+    sel = lambda m: np.repeat(m, 12)
+    s = Scene()
+    s.push(Mesh(P[sel(matte)], N[sel(matte)], None), MatteMaterial(Kd=RGBSpectrum(0.6, 0.6, 0.62)))
+    s.push(Mesh(P[sel(cond)], N[sel(cond)], None), ConductorMaterial(eta=RGBSpectrum(0.2, 0.92, 1.1), k=RGBSpectrum(3.9, 2.45, 2.14), roughness=0.2))
+    tex_res = 256
+    le_tex = (0.2 + 0.8 * rng.random((tex_res, tex_res, 3))).astype(f32)
+    n_em = int(em.sum()) * 12
+    tu, tv = rng.integers(0, tex_res, n_em), rng.integers(0, tex_res, n_em)
+    # nearest lookup idx = trunc(1 + (res - 1) * coord): put the uv at the texel's exact coordinate ((1 - v) selects the row)
+    uu = (tu / (tex_res - 1)).astype(f32)
+    vv = (1.0 - tv / (tex_res - 1)).astype(f32)
+    UV = np.repeat(np.stack([uu, vv], axis=1)[:, None, :], 3, axis=1).astype(f32)
+    s.push(Mesh(P[sel(em)], N[sel(em)], UV), MediumInterface(MatteMaterial(Kd=RGBSpectrum(0.0)), emission=Emissive(Le=Texture(le_tex), scale=4.0, two_sided=False)))
+    s.sync()
+    film = Film((width, height))
+    cam = PerspectiveCamera((0.0, -0.2, 9.0), (0.8, 0.3, 0.0), film, up=(0, 1, 0), fov=60.0)
+    return s, film, cam

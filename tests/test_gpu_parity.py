@@ -179,6 +179,7 @@ FRAME_CASES = [
     ("cornell_area", dict(max_depth=8, samples=8), (96, 96)),
     ("cornell_point", dict(max_depth=5, samples=8), (64, 64)),
     ("integration_nofog", dict(max_depth=5, samples=4), (64, 64)),
+    ("many_light", dict(max_depth=4, samples=4), (64, 64)),   # config 5 in miniature: 48 k triangles, ~2.5 k area lights in the light BVH
     ("textured", dict(max_depth=1, samples=8), (64, 64)),   # deeper: alpha tests / coated walks re-seed from ray bits -> statistical case below
 ]
 
@@ -213,6 +214,8 @@ def _scene(name, w, h):
         return scenes.integration_test_scene(w, h, with_fog=False)
     if name == "textured":
         return scenes.textured_scene(w, h)
+    if name == "many_light":
+        return scenes.many_light_scene(w, h, n_boxes=4000)
     if name == "slab_homogeneous":
         import hikari_jl_amd as hk
         return scenes.slab_scene(w, h, hk.HomogeneousMedium(sigma_a=hk.RGBSpectrum(0.2, 0.3, 0.1), sigma_s=hk.RGBSpectrum(0.8, 0.6, 0.9), Le=hk.RGBSpectrum(0.05, 0.0, 0.0), g=0.4))

@@ -1505,15 +1505,14 @@ HKD float lcg_next(uint64_t& s) {
 HKD S4 s4max0(S4 a) { return s4(maxf(a.x, 0.0f), maxf(a.y, 0.0f), maxf(a.z, 0.0f), maxf(a.w, 0.0f)); }
 HKD S4 s4exp(S4 a) { return s4(expf(a.x), expf(a.y), expf(a.z), expf(a.w)); }
 
-struct MajorantIter {  // RayMajorantIterator (media.jl:517-560)
-    int mode;          // 0 exhausted, 1 homogeneous, 2 DDA
-    S4 sigma_t;
+// RayMajorantIterator (media.jl:517-560), kept small because it lives in registers across the whole tracking loop: the
+// grid pointer / resolution are re-read from the medium record, step (+1/-1) and limit (res/-1) are a sign bit per axis,
+// and sigma_t is passed in by the caller (it is base_a + base_s, which the caller holds anyway).
+struct MajorantIter {
+    int mode;          // 0 exhausted, 1 homogeneous (not yet returned), 2 DDA; bits 8..10: axis steps negative
     float t_min, t_max;
-    bool hom_called;
-    const float* grid;
-    int res[3];
     float next_t[3], delta_t[3];
-    int step[3], limit[3], voxel[3];
+    int voxel[3];
 };
 HKD void ray_bounds_intersect(v3 o, v3 d, const float* bmin, const float* bmax, float& t_enter, float& t_exit) {  // media.jl:1698-1734
     float te = -INF_F, tx = INF_F;
@@ -1536,26 +1535,20 @@ HKD void ray_bounds_intersect(v3 o, v3 d, const float* bmin, const float* bmax, 
 HKD MajorantIter exhausted_iter() {
     MajorantIter it;
     it.mode = 0;
-    it.sigma_t = s4(0.0f);
     it.t_min = INF_F;
     it.t_max = -INF_F;
-    it.hom_called = true;
-    it.grid = nullptr;
     return it;
 }
 // MM is the set of medium kinds present in the scene (bit k = HK_MEDIUM_* k): the media kernels are instantiated per set so a
 // NanoVDB-only scene does not carry the registers of the RGB-grid run-time uplift (and vice versa).
 #define HK_HAS_MEDIUM(MM, K) (((MM) >> (K)) & 1)
 template <int MM>
-HKD MajorantIter create_majorant_iterator(const DMedium& m, v3 ro, v3 rd, float t_max, S4 lambda) {
+HKD MajorantIter create_majorant_iterator(const DMedium& m, v3 ro, v3 rd, float t_max) {
     MajorantIter it = exhausted_iter();
-    S4 sigma_t = eval_scaled(m.sigma_a, lambda) + eval_scaled(m.sigma_s, lambda);
     if (HK_HAS_MEDIUM(MM, HK_MEDIUM_HOMOGENEOUS) && m.kind == HK_MEDIUM_HOMOGENEOUS) {
         it.mode = (0.0f >= t_max) ? 0 : 1;
-        it.sigma_t = sigma_t;
         it.t_min = 0.0f;
         it.t_max = t_max;
-        it.hom_called = false;
         return it;
     }
     v3 o = ro, d = rd;
@@ -1571,11 +1564,10 @@ HKD MajorantIter create_majorant_iterator(const DMedium& m, v3 ro, v3 rd, float 
     t_exit = minf(t_exit, t_max);
     if (t_enter >= t_exit) return it;
     // create_dda_iterator (media.jl:229-340)
-    it.grid = m.majorant;
+    int mode = 2;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         int res = m.mres[k];
-        it.res[k] = res;
         float diag = m.bmax[k] - m.bmin[k];
         float go = (comp(o, k) - m.bmin[k]) / diag;
         float inv_diag = fabsf(diag) > 1e-10f ? 1.0f / diag : 0.0f;
@@ -1587,59 +1579,64 @@ HKD MajorantIter create_majorant_iterator(const DMedium& m, v3 ro, v3 rd, float 
         if (gd >= 0.0f) {
             float nvp = (float)(v + 1) / (float)res;
             it.next_t[k] = gd > 1e-10f ? t_enter + (nvp - gi) / gd : INF_F;
-            it.step[k] = 1;
-            it.limit[k] = res;
         } else {
             float nvp = (float)v / (float)res;
             it.next_t[k] = gd < -1e-10f ? t_enter + (nvp - gi) / gd : INF_F;
-            it.step[k] = -1;
-            it.limit[k] = -1;
+            mode |= 0x100 << k;
         }
     }
-    it.sigma_t = (HK_HAS_MEDIUM(MM, HK_MEDIUM_RGB_GRID) && m.kind == HK_MEDIUM_RGB_GRID) ? s4(1.0f) : sigma_t;  // RGBGrid: unit sigma_t, scale is in the majorant grid (media.jl:1408-1420)
     it.t_min = t_enter;
     it.t_max = t_exit;
-    it.hom_called = false;
-    it.mode = 2;
+    it.mode = mode;
     return it;
 }
-HKD bool majorant_next(MajorantIter& it, float& seg_t_min, float& seg_t_max, S4& sigma_maj) {  // media.jl:625-729
-    if (it.mode == 0) return false;
-    if (it.mode == 1) {
-        if (it.hom_called || it.t_min >= it.t_max) {
-            it.mode = 0;
-            return false;
-        }
+// sigma_t: the medium's sigma_a + sigma_s at the path's wavelengths (base_a + base_s); RGBGrid media use a unit sigma_t, the
+// scale is in their majorant grid (media.jl:1408-1420)
+template <int MM>
+HKD bool majorant_next(MajorantIter& it, const DMedium& m, S4 sigma_t, float& seg_t_min, float& seg_t_max, S4& sigma_maj) {  // media.jl:625-729
+    const int mode = it.mode & 0xff;
+    if (mode == 0) return false;
+    if (mode == 1) {
+        it.mode = 0;
+        if (it.t_min >= it.t_max) return false;
         seg_t_min = it.t_min;
         seg_t_max = it.t_max;
-        sigma_maj = it.sigma_t;
-        it.hom_called = true;
+        sigma_maj = sigma_t;
         return true;
     }
     if (it.t_min >= it.t_max) {
         it.mode = 0;
         return false;
     }
+    if (HK_HAS_MEDIUM(MM, HK_MEDIUM_RGB_GRID) && m.kind == HK_MEDIUM_RGB_GRID) sigma_t = s4(1.0f);
     float tx = it.next_t[0], ty = it.next_t[1], tz = it.next_t[2];
     int axis = (tx < ty) ? ((tx < tz) ? 0 : 2) : ((ty < tz) ? 1 : 2);
     float nt = axis == 0 ? tx : (axis == 1 ? ty : tz);
     float stm = minf(nt, it.t_max);
-    float rho = it.grid[it.voxel[0] + it.res[0] * (it.voxel[1] + it.res[1] * it.voxel[2])];
+    const int rx = m.mres[0], ry = m.mres[1], rz = m.mres[2];
+    float rho = m.majorant[it.voxel[0] + rx * (it.voxel[1] + ry * it.voxel[2])];
     seg_t_min = it.t_min;
     seg_t_max = stm;
-    sigma_maj = it.sigma_t * rho;
+    sigma_maj = sigma_t * rho;
     it.t_min = stm;
+    bool out;
     if (axis == 0) {
-        it.voxel[0] += it.step[0];
+        bool neg = it.mode & 0x100;
+        it.voxel[0] += neg ? -1 : 1;
         it.next_t[0] += it.delta_t[0];
+        out = it.voxel[0] == (neg ? -1 : rx);
     } else if (axis == 1) {
-        it.voxel[1] += it.step[1];
+        bool neg = it.mode & 0x200;
+        it.voxel[1] += neg ? -1 : 1;
         it.next_t[1] += it.delta_t[1];
+        out = it.voxel[1] == (neg ? -1 : ry);
     } else {
-        it.voxel[2] += it.step[2];
+        bool neg = it.mode & 0x400;
+        it.voxel[2] += neg ? -1 : 1;
         it.next_t[2] += it.delta_t[2];
+        out = it.voxel[2] == (neg ? -1 : rz);
     }
-    if (it.voxel[0] == it.limit[0] || it.voxel[1] == it.limit[1] || it.voxel[2] == it.limit[2]) {
+    if (out) {
         it.mode = 0;
         it.t_min = it.t_max;
     }
@@ -1807,64 +1804,4 @@ HKD MediumProps sample_point(const DTables& T, S4 lambda, const DMedium& m, S4 b
     mp.Le = s4(0.0f);
     return mp;
 }
-// compute_transmittance_ratio_tracking (intersection.jl:422-542)
-template <int MM>
-HKD void ratio_tracking(const DTables& T, const DMedium& m, v3 origin, v3 dir, float t_max, S4 lambda, S4& T_ray, S4& r_u, S4& r_l, unsigned& collisions) {
-    T_ray = s4(1.0f);
-    r_u = s4(1.0f);
-    r_l = s4(1.0f);
-    S4 base_a = eval_scaled(m.sigma_a, lambda), base_s = eval_scaled(m.sigma_s, lambda), base_Le = eval_scaled(m.Le, lambda);
-    MajorantIter it = create_majorant_iterator<MM>(m, origin, dir, t_max, lambda);
-    PCG32 rng = pcg32_init(pbrt_hash(origin), pbrt_hash(dir));
-    for (int s = 0; s < 256; ++s) {
-        float seg0, seg1;
-        S4 sm;
-        if (!majorant_next(it, seg0, seg1, sm)) break;
-        float sm0 = sm.x;
-        if (sm0 < 1e-10f) continue;
-        float t = seg0;
-        for (int k = 0; k < 100; ++k) {
-            float u = pcg32_f32(rng);
-            float dt = -logf(maxf(1e-10f, 1.0f - u)) / sm0;
-            float ts = t + dt;
-            if (ts >= seg1) {
-                float dr = seg1 - t;
-                S4 Tm = s4exp((-dr) * sm);
-                float T0 = Tm.x;
-                if (T0 > 1e-10f) {
-                    T_ray = T_ray * Tm / T0;
-                    r_l = r_l * Tm / T0;
-                    r_u = r_u * Tm / T0;
-                }
-                break;
-            }
-            ++collisions;
-            MediumProps mp = sample_point<MM>(T, lambda, m, base_a, base_s, base_Le, origin + dir * ts);
-            S4 sn = s4max0(sm - mp.sigma_a - mp.sigma_s);
-            S4 Tm = s4exp((-dt) * sm);
-            float pr = Tm.x * sm0;
-            if (pr > 1e-10f) {
-                T_ray = T_ray * Tm * sn / pr;
-                r_l = r_l * Tm * sm / pr;
-                r_u = r_u * Tm * sn / pr;
-            } else {
-                T_ray = s4(0.0f);
-                return;
-            }
-            S4 est = T_ray / maxf(1e-10f, average(r_l + r_u));
-            if (max_component(est) < 0.05f) {
-                float rr = pcg32_f32(rng);
-                if (rr < 0.75f) {
-                    T_ray = s4(0.0f);
-                    return;
-                }
-                T_ray = T_ray / (1.0f - 0.75f);
-            }
-            if (is_black(T_ray)) return;
-            t = ts;
-        }
-        if (is_black(T_ray)) break;
-    }
-}
-
 }  // namespace hkd

@@ -246,7 +246,12 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace(DPathState st, DScene 
 // Arithmetic and RNG consumption per path are exactly those of the sequential loop.
 // ---------------------------------------------------------------------------------------------------
 #ifndef HK_REFILL_MIN_IDLE
-#define HK_REFILL_MIN_IDLE 16
+#define HK_REFILL_MIN_IDLE 8
+#endif
+// the tracking loops wait on dependent loads (NanoVDB tree, majorant cells) ~60 % of the time at 2 waves/SIMD: trade a few
+// spilled registers for a third wave
+#ifndef HK_MEDIA_WAVES
+#define HK_MEDIA_WAVES 4
 #endif
 #ifndef HK_TRACK_ADVANCE
 #define HK_TRACK_ADVANCE 8
@@ -254,7 +259,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace(DPathState st, DScene 
 enum { TR_BUSY = -101, TR_EMPTY = -100, TR_SCATTER = -3, TR_ESCAPED = -2 };  // >= 0: reached its surface hit of that material kind
 
 template <int MM>
-__global__ void __launch_bounds__(256) k_track(DPathState st, DScene sc, DTables T, DFrame fr, int depth, DStats* stats) {
+__global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_per_eu(HK_MEDIA_WAVES))) k_track(DPathState st, DScene sc, DTables T, DFrame fr, int depth, DStats* stats) {
     const int lane = lane_id();
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     unsigned n_coll = 0;
@@ -320,7 +325,7 @@ __global__ void __launch_bounds__(256) k_track(DPathState st, DScene sc, DTables
                     base_s = eval_scaled(med.sigma_s, lambda);
                     if (HK_HAS_MEDIUM(MM, HK_MEDIUM_HOMOGENEOUS)) base_Le = eval_scaled(med.Le, lambda);
                     rng = lcg_init(ro, rd, t_max);
-                    it = create_majorant_iterator<MM>(med, ro, rd, t_max, lambda);
+                    it = create_majorant_iterator<MM>(med, ro, rd, t_max);
                     in_seg = false;
                     pending = false;
                     segi = 0;
@@ -340,7 +345,7 @@ __global__ void __launch_bounds__(256) k_track(DPathState st, DScene sc, DTables
                 if (!need) continue;
                 if (!in_seg) {
                     float seg0;
-                    if (segi >= 256 || !majorant_next(it, seg0, seg1, sm))
+                    if (segi >= 256 || !majorant_next<MM>(it, sc.media[medium_idx], base_a + base_s, seg0, seg1, sm))
                         survived = true;  // ran out of segments with the path still alive
                     else {
                         ++segi;
@@ -837,11 +842,11 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_shadow(DPathState st, DScene
 
 enum { SH_EMPTY = 0, SH_CAST = 1, SH_TRACK = 2 };
 #ifndef HK_SHADOW_TRACK_BATCH
-#define HK_SHADOW_TRACK_BATCH 4
+#define HK_SHADOW_TRACK_BATCH 2
 #endif
 
 template <bool COUNT, int MM>
-__global__ void __launch_bounds__(HK_TRACE_BLOCK) k_shadow_walk(DPathState st, DScene sc, DTables T, int depth, DStats* stats) {
+__global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TRACE_BLOCK), amdgpu_waves_per_eu(MM == 0 ? 4 : HK_MEDIA_WAVES))) k_shadow_walk(DPathState st, DScene sc, DTables T, int depth, DStats* stats) {
     __shared__ int lds_stack[(HK_TRACE_BLOCK / 64) * HK_LDS_STACK * 64];
     int* stack = lds_stack + (threadIdx.x >> 6) * (HK_LDS_STACK * 64);
     const int lane = lane_id();
@@ -943,7 +948,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_shadow_walk(DPathState st, D
                         base_a = eval_scaled(m.sigma_a, lambda);
                         base_s = eval_scaled(m.sigma_s, lambda);
                         if (HK_HAS_MEDIUM(MM, HK_MEDIUM_HOMOGENEOUS)) base_Le = eval_scaled(m.Le, lambda);
-                        it = create_majorant_iterator<MM>(m, ro, dir, hit_t, lambda);
+                        it = create_majorant_iterator<MM>(m, ro, dir, hit_t);
                         rng = pcg32_init(pbrt_hash(ro), pbrt_hash(dir));
                         in_seg = false;
                         after_inner = false;
@@ -983,7 +988,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_shadow_walk(DPathState st, D
                         float seg0;
                         if (after_inner && is_black(sT))
                             track_done = true;
-                        else if (segi >= 256 || !majorant_next(it, seg0, seg1, sm))
+                        else if (segi >= 256 || !majorant_next<MM>(it, sc.media[medium], base_a + base_s, seg0, seg1, sm))
                             track_done = true;
                         else {
                             ++segi;

@@ -14,6 +14,7 @@
 
 #include "bvh_build.h"
 #include "hikari_mi355x.h"
+#include "hk_nanovdb.h"
 #include "hk_types.h"
 
 namespace hk {
@@ -573,6 +574,32 @@ extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene**
             s->media_data.push_back(nb);
             HIP_TRY(nb->upload(m.nvdb_bytes, (size_t)m.nvdb_size));
             o.nvdb = nb->as<unsigned char>();
+            // flatten the tree over the index bounding box (+1 block of margin for the trilinear +1 taps)
+            long long dim[3], total = 1;
+            for (int k = 0; k < 3; ++k) {
+                o.nvb_min[k] = (m.index_bbox_min[k] >> 3) - 1;
+                dim[k] = (long long)(m.index_bbox_max[k] >> 3) + 1 - o.nvb_min[k] + 1;
+                if (dim[k] < 1) dim[k] = 1;
+                total *= dim[k];
+            }
+            if (total <= (1ll << 26) && m.leaf_offset_1based < (1ll << 32) && m.nvdb_size < (1ll << 32)) {  // <= 512 MB of table, 32-bit leaf offsets
+                std::vector<uint2> table((size_t)total);
+                for (long long bx = 0; bx < dim[0]; ++bx)
+                    for (long long by = 0; by < dim[1]; ++by)
+                        for (long long bz = 0; bz < dim[2]; ++bz) {
+                            float value;
+                            long long leaf = hknv::find_block(m.nvdb_bytes, m.root_offset_1based, m.root_table_size, (int)((o.nvb_min[0] + bx) * 8), (int)((o.nvb_min[1] + by) * 8),
+                                                              (int)((o.nvb_min[2] + bz) * 8), value);
+                            uint32_t bits;
+                            std::memcpy(&bits, &value, 4);
+                            table[(size_t)bz + (size_t)dim[2] * ((size_t)by + (size_t)dim[1] * (size_t)bx)] = make_uint2((uint32_t)leaf, bits);
+                        }
+                DevBuf* tb = new DevBuf();
+                s->media_data.push_back(tb);
+                HIP_TRY(tb->upload(table.data(), table.size() * sizeof(uint2)));
+                o.nv_blocks = tb->as<uint2>();
+                for (int k = 0; k < 3; ++k) o.nvb_dim[k] = (int)dim[k];
+            }
         }
     }
     HIP_TRY(s->media.upload(dmed.data(), dmed.size() * sizeof(DMedium)));
@@ -858,6 +885,7 @@ int ensure_state(hk_integrator* I, int capacity) {
     HIP_TRY(alloc_arr(I, s.escaped_q, Q));
     HIP_TRY(alloc_arr(I, s.medium_q, Q));
     HIP_TRY(alloc_arr(I, s.scatter_q, Q));
+    HIP_TRY(alloc_arr(I, s.tickets, (size_t)(I->p.max_depth + 2) * 2));
     HIP_TRY(alloc_arr(I, s.initial_medium, 1));
     HIP_TRY(hipMemset(s.initial_medium, 0xff, sizeof(int)));
     HIP_TRY(alloc_arr(I, s.mat_q, Q * HK_MAX_KINDS));
@@ -976,6 +1004,7 @@ extern "C" int32_t hk_render(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_film*
             }
             return HK_OK;
         };
+        if (sc->d.n_media > 0 || !sc->d.all_opaque) HIP_TRY(hipMemsetAsync(I->st.tickets, 0, (size_t)(I->p.max_depth + 2) * 2 * sizeof(int), s));
         if (timed(3, [&] { hk::launch_camera(s, c->n_cu, I->st, fr, c->tables, I->filter, dc, sob, -1); }) != HK_OK) return fail(HK_ERR_DEVICE, "event record failed");
         for (int depth = 0; depth < I->p.max_depth; ++depth) {
             timed(0, [&] { hk::launch_trace(s, trace_blocks, I->st, sc->d, c->tables, fr, depth, dstats); });

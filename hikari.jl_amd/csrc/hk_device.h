@@ -11,6 +11,8 @@
 
 #include "hk_types.h"
 
+#include "hk_nanovdb.h"
+
 #define HKD __device__ __forceinline__
 
 namespace hkd {
@@ -1503,7 +1505,21 @@ HKD float lcg_next(uint64_t& s) {
     return r < lim ? r : lim;
 }
 HKD S4 s4max0(S4 a) { return s4(maxf(a.x, 0.0f), maxf(a.y, 0.0f), maxf(a.z, 0.0f), maxf(a.w, 0.0f)); }
-HKD S4 s4exp(S4 a) { return s4(expf(a.x), expf(a.y), expf(a.z), expf(a.w)); }
+HKD S4 s4exp(S4 a) {
+    // grey media (all four wavelengths see the same sigma): one expf, bit-identical to four
+    if (a.x == a.y && a.x == a.z && a.x == a.w) {
+        float e = expf(a.x);
+        return s4(e, e, e, e);
+    }
+    return s4(expf(a.x), expf(a.y), expf(a.z), expf(a.w));
+}
+// a / y through one correctly-rounded reciprocal: each component within 1 ulp of the IEEE quotient, at a third of the
+// instructions (a full-precision f32 division is ~10 VALU ops on CDNA).  Used in the tracking loops only, whose paths cannot
+// be bit-reproduced across platforms anyway (their RNG streams are seeded from libm-dependent ray bits).
+HKD S4 div4(S4 a, float y) {
+    float r = 1.0f / y;
+    return s4(a.x * r, a.y * r, a.z * r, a.w * r);
+}
 
 // RayMajorantIterator (media.jl:517-560), kept small because it lives in registers across the whole tracking loop: the
 // grid pointer / resolution are re-read from the medium record, step (+1/-1) and limit (res/-1) are a sign bit per axis,
@@ -1643,11 +1659,10 @@ HKD bool majorant_next(MajorantIter& it, const DMedium& m, S4 sigma_t, float& se
     return true;
 }
 
-// NanoVDB tree walk (nanovdb.jl:315-388).  Offsets are 1-based byte positions like the reference's fields.
-HKD float nv_f32(const unsigned char* b, long long off1) { return *reinterpret_cast<const float*>(b + (((off1 - 1) >> 2) << 2)); }
-HKD long long nv_i64(const unsigned char* b, long long off1) { return *reinterpret_cast<const long long*>(b + (((off1 - 1) >> 3) << 3)); }
-HKD bool nv_mask(const unsigned char* b, long long mask_off1, int n) { return ((b[mask_off1 - 1 + (n >> 3)] >> (n & 7)) & 1) != 0; }
-// Result of walking down to the 8^3 block that contains (x,y,z): either a leaf (values at leaf_off) or a constant.
+// NanoVDB lookups.  The tree walk itself (nanovdb.jl:315-388) is in hk_nanovdb.h; on the device it is the fallback: at scene
+// upload the host flattens the tree over the grid's index bounding box into a block table (one 8-byte entry per 8^3 block:
+// leaf offset, or the block's constant tile / background value), so a voxel fetch is table entry -> leaf value, two dependent
+// loads instead of six.  Values are those the walk returns, by construction.
 struct NvBlock {
     int kx, ky, kz;      // block coordinates (x>>3, y>>3, z>>3) this entry is valid for
     long long leaf_off;  // 1-based offset of the leaf node, 0 => constant `value` for the whole block
@@ -1655,52 +1670,22 @@ struct NvBlock {
     bool valid;
 };
 HKD NvBlock nv_find_block(const DMedium& m, int x, int y, int z) {
-    const unsigned char* b = m.nvdb;
     NvBlock r;
     r.kx = x >> 3;
     r.ky = y >> 3;
     r.kz = z >> 3;
-    r.leaf_off = 0;
     r.valid = true;
-    unsigned xu = (unsigned)x, yu = (unsigned)y, zu = (unsigned)z;
-    unsigned long long key = (unsigned long long)((zu >> 12) & 0x1fffff) | ((unsigned long long)((yu >> 12) & 0x1fffff) << 21) | ((unsigned long long)((xu >> 12) & 0x1fffff) << 42);
-    long long root = m.root_off, tile = 0;
-    bool found = false;
-    for (int i = 0; i < m.root_table_size; ++i) {
-        long long t_off = root + 64 + (long long)i * 32;
-        if ((unsigned long long)nv_i64(b, t_off) == key) {
-            found = true;
-            tile = t_off;
-            break;
-        }
-    }
-    if (!found) {
-        r.value = nv_f32(b, root + 28);
+    const int bx = r.kx - m.nvb_min[0], by = r.ky - m.nvb_min[1], bz = r.kz - m.nvb_min[2];
+    if (m.nv_blocks && (unsigned)bx < (unsigned)m.nvb_dim[0] && (unsigned)by < (unsigned)m.nvb_dim[1] && (unsigned)bz < (unsigned)m.nvb_dim[2]) {
+        uint2 e = m.nv_blocks[(size_t)bz + (size_t)m.nvb_dim[2] * ((size_t)by + (size_t)m.nvb_dim[1] * (size_t)bx)];
+        r.leaf_off = (long long)e.x;
+        r.value = __uint_as_float(e.y);
         return r;
     }
-    long long child = nv_i64(b, tile + 8);
-    if (child == 0) {
-        r.value = nv_f32(b, tile + 20);
-        return r;
-    }
-    long long upper = root + child;
-    int n_upper = (int)(((xu >> 7) & 31) << 10) | (int)(((yu >> 7) & 31) << 5) | (int)((zu >> 7) & 31);
-    if (!nv_mask(b, upper + 4128, n_upper)) {
-        r.value = nv_f32(b, upper + 8256 + (long long)n_upper * 8);
-        return r;
-    }
-    long long lower = upper + nv_i64(b, upper + 8256 + (long long)n_upper * 8);
-    int n_lower = (int)(((xu >> 3) & 15) << 8) | (int)(((yu >> 3) & 15) << 4) | (int)((zu >> 3) & 15);
-    if (!nv_mask(b, lower + 544, n_lower)) {
-        r.value = nv_f32(b, lower + 1088 + (long long)n_lower * 8);
-        return r;
-    }
-    r.leaf_off = lower + nv_i64(b, lower + 1088 + (long long)n_lower * 8);
-    r.value = 0.0f;
+    r.leaf_off = hknv::find_block(m.nvdb, m.root_off, m.root_table_size, x, y, z, r.value);
     return r;
 }
-// the 8 trilinear taps touch at most 8 blocks but almost always 1-2: the last block is cached per lane so the
-// 4-level pointer chase (>= 4 dependent loads) is paid once per distinct block, not once per tap
+HKD float nv_f32(const unsigned char* b, long long off1) { return hknv::f32(b, off1); }
 HKD float nv_value(const DMedium& m, NvBlock& cache, int x, int y, int z) {
     if (!(cache.valid && cache.kx == (x >> 3) && cache.ky == (y >> 3) && cache.kz == (z >> 3))) cache = nv_find_block(m, x, y, z);
     if (cache.leaf_off == 0) return cache.value;

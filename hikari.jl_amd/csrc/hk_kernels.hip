@@ -35,6 +35,14 @@ __device__ __forceinline__ int physical_waves() { return (int)(gridDim.x * (bloc
 // A kernel is launched with as many physical waves as are resident for ITS register/LDS budget; each physical
 // wave walks the virtual wave segments v = p, p + P, p + 2P, ... so all kernels share the same W segments.
 #define HK_FOR_EACH_WAVE_SEGMENT(gw, st) for (int gw = global_wave(); gw < (st).n_waves; gw += physical_waves())
+// Media kernels: the work per segment is wildly uneven (a tile that looks into a cloud vs one that sees the sky), so segments
+// are handed to physical waves through a ticket (one atomic per SEGMENT, a few thousand per launch) instead of round-robin.
+__device__ __forceinline__ int next_segment(int* ticket) {
+    int v = 0;
+    if (lane_id() == 0) v = atomicAdd(ticket, 1);
+    return __builtin_amdgcn_readfirstlane(v);
+}
+#define HK_FOR_EACH_WAVE_SEGMENT_DYNAMIC(gw, st, ticket) for (int gw = next_segment(ticket); gw < (st).n_waves; gw = next_segment(ticket))
 __device__ __forceinline__ WaveQ wq_open(uint32_t* q, const DPathState& st, int gw) { return WaveQ{q + (size_t)gw * st.wave_cap, 0}; }
 __device__ __forceinline__ void wq_push(WaveQ& q, uint32_t value, bool active) {
     unsigned long long mask = __ballot(active);
@@ -263,7 +271,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
     const int lane = lane_id();
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     unsigned n_coll = 0;
-    HK_FOR_EACH_WAVE_SEGMENT(gw, st) {
+    HK_FOR_EACH_WAVE_SEGMENT_DYNAMIC(gw, st, st.tickets + 2 * depth) {
         const uint32_t* __restrict__ queue = st.medium_q + (size_t)gw * st.wave_cap;
         const int n = *count_ptr(st, depth, Q_MEDIUM, gw);
         WaveQ q_escaped = wq_open(st.escaped_q, st, gw);
@@ -335,97 +343,105 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
                 cursor += want_n < avail ? want_n : (avail > 0 ? avail : 0);
                 if (__ballot(state == TR_BUSY) == 0ull) break;
             }
-            // ---- phase A: cheap steps (next majorant cell, free-flight sample, cell-boundary crossing) until every busy lane
-            //      either holds a tentative collision or has run out of segments ----
+            // The medium record is read through a wave-uniform index (scalar loads into SGPRs): lanes are served medium by medium
+            // ("waterfall"), which is a single trip for the usual one-medium scene.
             bool survived = false;
-#pragma unroll 1
-            for (int adv = 0; adv < HK_TRACK_ADVANCE; ++adv) {
-                const bool need = state == TR_BUSY && !pending && !survived;
-                if (__ballot(need) == 0ull) break;
-                if (!need) continue;
-                if (!in_seg) {
-                    float seg0;
-                    if (segi >= 256 || !majorant_next<MM>(it, sc.media[medium_idx], base_a + base_s, seg0, seg1, sm))
-                        survived = true;  // ran out of segments with the path still alive
-                    else {
-                        ++segi;
-                        sm0 = sm.x;
-                        if (sm0 >= 1e-10f) {
-                            t = seg0;
-                            cur_o = ro + rd * t;
-                            in_seg = true;
-                            k_in_seg = 0;
+            unsigned long long todo = __ballot(state == TR_BUSY);
+            while (todo) {
+                const int m_uniform = __builtin_amdgcn_readlane(medium_idx, __ffsll((long long)todo) - 1);
+                const bool mine = state == TR_BUSY && medium_idx == m_uniform;
+                const DMedium& med = sc.media[m_uniform];
+                // ---- phase A: cheap steps (next majorant cell, free-flight sample, cell-boundary crossing) until every busy lane
+                //      either holds a tentative collision or has run out of segments ----
+    #pragma unroll 1
+                for (int adv = 0; adv < HK_TRACK_ADVANCE; ++adv) {
+                    const bool need = mine && state == TR_BUSY && !pending && !survived;
+                    if (__ballot(need) == 0ull) break;
+                    if (!need) continue;
+                    if (!in_seg) {
+                        float seg0;
+                        if (segi >= 256 || !majorant_next<MM>(it, med, base_a + base_s, seg0, seg1, sm))
+                            survived = true;  // ran out of segments with the path still alive
+                        else {
+                            ++segi;
+                            sm0 = sm.x;
+                            if (sm0 >= 1e-10f) {
+                                t = seg0;
+                                cur_o = ro + rd * t;
+                                in_seg = true;
+                                k_in_seg = 0;
+                            }
                         }
-                    }
-                } else if (k_in_seg >= 1024) {
-                    in_seg = false;
-                } else {
-                    ++k_in_seg;
-                    float u = lcg_next(rng);
-                    pend_dt = -logf(maxf(1e-10f, 1.0f - u)) / sm0;
-                    float ts = t + pend_dt;
-                    if (ts >= seg1) {
-                        float dr = seg1 - t;
-                        S4 Tm = s4exp((-dr) * sm);
-                        float T0 = Tm.x;
-                        if (T0 > 1e-10f) {
-                            beta = beta * Tm / T0;
-                            r_u = r_u * Tm / T0;
-                            r_l = r_l * Tm / T0;
-                        }
+                    } else if (k_in_seg >= 1024) {
                         in_seg = false;
-                    } else
-                        pending = true;
-                }
-            }
-            // ---- phase B: the tentative collisions (medium lookup, absorb / scatter / null) ----
-            if (state == TR_BUSY && pending) {
-                pending = false;
-                const float dt = pend_dt;
-                const float ts = t + dt;
-                const DMedium& med = sc.media[medium_idx];
-                S4 Tm = s4exp((-dt) * sm);
-                v3 p = cur_o + rd * dt;
-                ++n_coll;
-                MediumProps mp = sample_point<MM>(T, lambda, med, base_a, base_s, base_Le, p);
-                if ((HK_HAS_MEDIUM(MM, HK_MEDIUM_HOMOGENEOUS) || HK_HAS_MEDIUM(MM, HK_MEDIUM_RGB_GRID)) && !is_black(mp.Le) && depth < fr.max_depth) {
-                    float pr = sm0 * Tm.x;
-                    if (pr > 1e-10f) {
-                        S4 r_e = r_u * sm * Tm / pr;
-                        if (!is_black(r_e)) st4(&st.L[slot], ld4(&st.L[slot]) + beta * mp.sigma_a * Tm * mp.Le / (pr * average(r_e)));
+                    } else {
+                        ++k_in_seg;
+                        float u = lcg_next(rng);
+                        pend_dt = -logf(maxf(1e-10f, 1.0f - u)) / sm0;
+                        float ts = t + pend_dt;
+                        if (ts >= seg1) {
+                            float dr = seg1 - t;
+                            S4 Tm = s4exp((-dr) * sm);
+                            float T0 = Tm.x;
+                            if (T0 > 1e-10f) {
+                                beta = div4(beta * Tm, T0);
+                                r_u = div4(r_u * Tm, T0);
+                                r_l = div4(r_l * Tm, T0);
+                            }
+                            in_seg = false;
+                        } else
+                            pending = true;
                     }
                 }
-                float p_absorb = mp.sigma_a.x / sm0, p_scatter = mp.sigma_s.x / sm0;
-                float ue = lcg_next(rng);
-                if (ue < p_absorb) {
-                    state = TR_EMPTY;  // absorbed
-                } else if (ue < p_absorb + p_scatter) {
-                    if (depth >= fr.max_depth)
-                        state = TR_EMPTY;
-                    else {
-                        float pdf = Tm.x * mp.sigma_s.x;
-                        if (pdf > 1e-10f) {
-                            beta = beta * Tm * mp.sigma_s / pdf;
-                            r_u = r_u * Tm * mp.sigma_s / pdf;
+                // ---- phase B: the tentative collisions (medium lookup, absorb / scatter / null) ----
+                if (mine && state == TR_BUSY && pending) {
+                    pending = false;
+                    const float dt = pend_dt;
+                    const float ts = t + dt;
+                    S4 Tm = s4exp((-dt) * sm);
+                    v3 p = cur_o + rd * dt;
+                    ++n_coll;
+                    MediumProps mp = sample_point<MM>(T, lambda, med, base_a, base_s, base_Le, p);
+                    if ((HK_HAS_MEDIUM(MM, HK_MEDIUM_HOMOGENEOUS) || HK_HAS_MEDIUM(MM, HK_MEDIUM_RGB_GRID)) && !is_black(mp.Le) && depth < fr.max_depth) {
+                        float pr = sm0 * Tm.x;
+                        if (pr > 1e-10f) {
+                            S4 r_e = r_u * sm * Tm / pr;
+                            if (!is_black(r_e)) st4(&st.L[slot], ld4(&st.L[slot]) + beta * mp.sigma_a * Tm * mp.Le / (pr * average(r_e)));
                         }
-                        st4(&st.beta[slot], beta);
-                        st4(&st.r_u[slot], r_u);
-                        st.ray_o[slot] = make_float4(p.x, p.y, p.z, INF_F);  // the scattering vertex: k_scatter continues from here
-                        state = TR_SCATTER;
                     }
-                } else {
-                    S4 sn = s4max0(sm - mp.sigma_a - mp.sigma_s);
-                    float pdf = Tm.x * sn.x;
-                    if (pdf > 1e-10f) {
-                        beta = beta * Tm * sn / pdf;
-                        r_u = r_u * Tm * sn / pdf;
-                        r_l = r_l * Tm * sm / pdf;
-                        t = ts;
-                        cur_o = p;
-                        if (is_black(beta) || is_black(r_u)) state = TR_EMPTY;
-                    } else
-                        state = TR_EMPTY;
+                    float p_absorb = mp.sigma_a.x / sm0, p_scatter = mp.sigma_s.x / sm0;
+                    float ue = lcg_next(rng);
+                    if (ue < p_absorb) {
+                        state = TR_EMPTY;  // absorbed
+                    } else if (ue < p_absorb + p_scatter) {
+                        if (depth >= fr.max_depth)
+                            state = TR_EMPTY;
+                        else {
+                            float pdf = Tm.x * mp.sigma_s.x;
+                            if (pdf > 1e-10f) {
+                                beta = div4(beta * Tm * mp.sigma_s, pdf);
+                                r_u = div4(r_u * Tm * mp.sigma_s, pdf);
+                            }
+                            st4(&st.beta[slot], beta);
+                            st4(&st.r_u[slot], r_u);
+                            st.ray_o[slot] = make_float4(p.x, p.y, p.z, INF_F);  // the scattering vertex: k_scatter continues from here
+                            state = TR_SCATTER;
+                        }
+                    } else {
+                        S4 sn = s4max0(sm - mp.sigma_a - mp.sigma_s);
+                        float pdf = Tm.x * sn.x;
+                        if (pdf > 1e-10f) {
+                            beta = div4(beta * Tm * sn, pdf);
+                            r_u = div4(r_u * Tm * sn, pdf);
+                            r_l = div4(r_l * Tm * sm, pdf);
+                            t = ts;
+                            cur_o = p;
+                            if (is_black(beta) || is_black(r_u)) state = TR_EMPTY;
+                        } else
+                            state = TR_EMPTY;
+                    }
                 }
+                todo &= ~__ballot(mine);
             }
             if (survived) {
                 state = TR_EMPTY;
@@ -852,7 +868,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
     const int lane = lane_id();
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     unsigned n_nodes = 0, n_tris = 0, n_casts = 0, n_hits = 0, n_coll = 0;
-    HK_FOR_EACH_WAVE_SEGMENT(gw, st) {
+    HK_FOR_EACH_WAVE_SEGMENT_DYNAMIC(gw, st, st.tickets + 2 * depth + 1) {
     const uint32_t* __restrict__ queue = st.shadow_q + (size_t)gw * st.wave_cap;
     const int n = *count_ptr(st, depth, Q_SHADOW, gw);
     int cursor = 0;
@@ -973,104 +989,112 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
                 }
             }
         }
-        // ---- a few ratio-tracking rounds: cheap steps until a tentative collision is pending, then the collisions ----
+        // ---- a few ratio-tracking rounds: cheap steps until a tentative collision is pending, then the collisions.  Lanes are
+        //      served medium by medium so that the medium record is read through a wave-uniform index (scalar loads) ----
         if (MM != 0) {
+            unsigned long long todo = __ballot(state == SH_TRACK);
+            while (todo) {
+                const int m_uniform = __builtin_amdgcn_readlane(medium, __ffsll((long long)todo) - 1);
+                const bool mine = state == SH_TRACK && medium == m_uniform;
+                const DMedium& med = sc.media[m_uniform];
 #pragma unroll 1
-            for (int batch = 0; batch < HK_SHADOW_TRACK_BATCH; ++batch) {
-                if (__ballot(state == SH_TRACK) == 0ull) break;
-                bool track_done = false;
+                for (int batch = 0; batch < HK_SHADOW_TRACK_BATCH; ++batch) {
+                    if (__ballot(mine && state == SH_TRACK) == 0ull) break;
+                    bool track_done = false;
 #pragma unroll 1
-                for (int adv = 0; adv < HK_TRACK_ADVANCE; ++adv) {
-                    const bool need = state == SH_TRACK && !pending && !track_done;
-                    if (__ballot(need) == 0ull) break;
-                    if (!need) continue;
-                    if (!in_seg) {
-                        float seg0;
-                        if (after_inner && is_black(sT))
-                            track_done = true;
-                        else if (segi >= 256 || !majorant_next<MM>(it, sc.media[medium], base_a + base_s, seg0, seg1, sm))
-                            track_done = true;
-                        else {
-                            ++segi;
-                            sm0 = sm.x;
-                            if (sm0 >= 1e-10f) {
-                                t = seg0;
-                                in_seg = true;
-                                k_in_seg = 0;
+                    for (int adv = 0; adv < HK_TRACK_ADVANCE; ++adv) {
+                        const bool need = mine && state == SH_TRACK && !pending && !track_done;
+                        if (__ballot(need) == 0ull) break;
+                        if (!need) continue;
+                        if (!in_seg) {
+                            float seg0;
+                            if (after_inner && is_black(sT))
+                                track_done = true;
+                            else if (segi >= 256 || !majorant_next<MM>(it, med, base_a + base_s, seg0, seg1, sm))
+                                track_done = true;
+                            else {
+                                ++segi;
+                                sm0 = sm.x;
+                                if (sm0 >= 1e-10f) {
+                                    t = seg0;
+                                    in_seg = true;
+                                    k_in_seg = 0;
+                                }
                             }
-                        }
-                        after_inner = false;
-                    } else if (k_in_seg >= 100) {
-                        in_seg = false;
-                        after_inner = true;
-                    } else {
-                        ++k_in_seg;
-                        float u = pcg32_f32(rng);
-                        pend_dt = -logf(maxf(1e-10f, 1.0f - u)) / sm0;
-                        float ts = t + pend_dt;
-                        if (ts >= seg1) {
-                            float dr = seg1 - t;
-                            S4 Tm = s4exp((-dr) * sm);
-                            float T0 = Tm.x;
-                            if (T0 > 1e-10f) {
-                                sT = sT * Tm / T0;
-                                sl = sl * Tm / T0;
-                                su = su * Tm / T0;
-                            }
+                            after_inner = false;
+                        } else if (k_in_seg >= 100) {
                             in_seg = false;
                             after_inner = true;
-                        } else
-                            pending = true;
-                    }
-                }
-                if (state == SH_TRACK && pending) {
-                    pending = false;
-                    const float dt = pend_dt;
-                    const float ts = t + dt;
-                    ++n_coll;
-                    MediumProps mp = sample_point<MM>(T, lambda, sc.media[medium], base_a, base_s, base_Le, ro + dir * ts);
-                    S4 sn = s4max0(sm - mp.sigma_a - mp.sigma_s);
-                    S4 Tm = s4exp((-dt) * sm);
-                    float pr = Tm.x * sm0;
-                    if (pr > 1e-10f) {
-                        sT = sT * Tm * sn / pr;
-                        sl = sl * Tm * sm / pr;
-                        su = su * Tm * sn / pr;
-                        S4 est = sT / maxf(1e-10f, average(sl + su));
-                        if (max_component(est) < 0.05f) {
-                            float rr = pcg32_f32(rng);
-                            if (rr < 0.75f) {
-                                sT = s4(0.0f);
-                                track_done = true;
+                        } else {
+                            ++k_in_seg;
+                            float u = pcg32_f32(rng);
+                            pend_dt = -logf(maxf(1e-10f, 1.0f - u)) / sm0;
+                            float ts = t + pend_dt;
+                            if (ts >= seg1) {
+                                float dr = seg1 - t;
+                                S4 Tm = s4exp((-dr) * sm);
+                                float T0 = Tm.x;
+                                if (T0 > 1e-10f) {
+                                    sT = div4(sT * Tm, T0);
+                                    sl = div4(sl * Tm, T0);
+                                    su = div4(su * Tm, T0);
+                                }
+                                in_seg = false;
+                                after_inner = true;
                             } else
-                                sT = sT / (1.0f - 0.75f);
+                                pending = true;
                         }
-                        if (is_black(sT)) track_done = true;
-                        t = ts;
-                    } else {
-                        sT = s4(0.0f);
-                        track_done = true;
+                    }
+                    if (mine && state == SH_TRACK && pending) {
+                        pending = false;
+                        const float dt = pend_dt;
+                        const float ts = t + dt;
+                        ++n_coll;
+                        MediumProps mp = sample_point<MM>(T, lambda, med, base_a, base_s, base_Le, ro + dir * ts);
+                        S4 sn = s4max0(sm - mp.sigma_a - mp.sigma_s);
+                        S4 Tm = s4exp((-dt) * sm);
+                        float pr = Tm.x * sm0;
+                        if (pr > 1e-10f) {
+                            sT = div4(sT * Tm * sn, pr);
+                            sl = div4(sl * Tm * sm, pr);
+                            su = div4(su * Tm * sn, pr);
+                            S4 est = div4(sT, maxf(1e-10f, average(sl + su)));
+                            if (max_component(est) < 0.05f) {
+                                float rr = pcg32_f32(rng);
+                                if (rr < 0.75f) {
+                                    sT = s4(0.0f);
+                                    track_done = true;
+                                } else
+                                    sT = sT / (1.0f - 0.75f);
+                            }
+                            if (is_black(sT)) track_done = true;
+                            t = ts;
+                        } else {
+                            sT = s4(0.0f);
+                            track_done = true;
+                        }
+                    }
+                    if (track_done) {
+                        T_ray = T_ray * sT;
+                        tr_u = tr_u * su;
+                        tr_l = tr_l * sl;
+                        if (miss_case) {
+                            shadow_contribute(st, slot, T_ray, tr_u, tr_l);
+                            state = SH_EMPTY;
+                        } else {
+                            bool stop = false;
+                            if (transition) {
+                                if (is_black(T_ray)) stop = true;
+                                medium = next_medium;
+                            }
+                            ro = ro + dir * (hit_t + 1e-4f);
+                            t_remaining = t_remaining - hit_t - 1e-4f;
+                            ++seg;
+                            state = (stop || seg >= 10 || t_remaining < 1e-6f) ? SH_EMPTY : SH_CAST;
+                        }
                     }
                 }
-                if (track_done) {
-                    T_ray = T_ray * sT;
-                    tr_u = tr_u * su;
-                    tr_l = tr_l * sl;
-                    if (miss_case) {
-                        shadow_contribute(st, slot, T_ray, tr_u, tr_l);
-                        state = SH_EMPTY;
-                    } else {
-                        bool stop = false;
-                        if (transition) {
-                            if (is_black(T_ray)) stop = true;
-                            medium = next_medium;
-                        }
-                        ro = ro + dir * (hit_t + 1e-4f);
-                        t_remaining = t_remaining - hit_t - 1e-4f;
-                        ++seg;
-                        state = (stop || seg >= 10 || t_remaining < 1e-6f) ? SH_EMPTY : SH_CAST;
-                    }
-                }
+                todo &= ~__ballot(mine);
             }
         }
     }

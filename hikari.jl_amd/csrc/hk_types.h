@@ -108,6 +108,8 @@ struct DMedium {
     int mres[3];
     const float* majorant;         // x + rx*(y + ry*z)
     const unsigned char* nvdb;     // NanoVDB bytes (tree part)
+    const uint2* nv_blocks;        // flattened tree over the index bbox: {leaf offset (1-based, 0 = constant block), value bits}
+    int nvb_min[3], nvb_dim[3];    // block-coordinate origin / extent of nv_blocks ([bx][by][bz], bz fastest)
     long long root_off;            // 1-based like the reference
     int root_table_size;
     float inv_mat[9], vec[3];
@@ -215,6 +217,7 @@ struct DPathState {
     int* initial_medium;   // camera medium detected on the device (K14)
     uint32_t* mat_q;       // HK_MAX_KINDS * W * wave_cap
     int* counters;         // [(max_depth + 2) * Q_COUNT][W] per-wave queue sizes
+    int* tickets;          // [(max_depth + 2) * 2] segment tickets of the media kernels (dynamic segment -> wave assignment), zeroed per pass
 };
 
 struct DStats {

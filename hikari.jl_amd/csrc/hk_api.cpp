@@ -574,32 +574,45 @@ extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene**
             s->media_data.push_back(nb);
             HIP_TRY(nb->upload(m.nvdb_bytes, (size_t)m.nvdb_size));
             o.nvdb = nb->as<unsigned char>();
-            // flatten the tree over the index bounding box (+1 block of margin for the trilinear +1 taps)
+            // flatten the tree over the index bounding box (+1 block of margin for the trilinear +1 taps); blocks further out hold
+            // the background value, which the margin itself must confirm
             long long dim[3], total = 1;
             for (int k = 0; k < 3; ++k) {
                 o.nvb_min[k] = (m.index_bbox_min[k] >> 3) - 1;
                 dim[k] = (long long)(m.index_bbox_max[k] >> 3) + 1 - o.nvb_min[k] + 1;
-                if (dim[k] < 1) dim[k] = 1;
+                if (dim[k] < 3) dim[k] = 3;
                 total *= dim[k];
             }
-            if (total <= (1ll << 26) && m.leaf_offset_1based < (1ll << 32) && m.nvdb_size < (1ll << 32)) {  // <= 512 MB of table, 32-bit leaf offsets
-                std::vector<uint2> table((size_t)total);
-                for (long long bx = 0; bx < dim[0]; ++bx)
-                    for (long long by = 0; by < dim[1]; ++by)
-                        for (long long bz = 0; bz < dim[2]; ++bz) {
-                            float value;
-                            long long leaf = hknv::find_block(m.nvdb_bytes, m.root_offset_1based, m.root_table_size, (int)((o.nvb_min[0] + bx) * 8), (int)((o.nvb_min[1] + by) * 8),
-                                                              (int)((o.nvb_min[2] + bz) * 8), value);
-                            uint32_t bits;
-                            std::memcpy(&bits, &value, 4);
-                            table[(size_t)bz + (size_t)dim[2] * ((size_t)by + (size_t)dim[1] * (size_t)bx)] = make_uint2((uint32_t)leaf, bits);
-                        }
-                DevBuf* tb = new DevBuf();
-                s->media_data.push_back(tb);
-                HIP_TRY(tb->upload(table.data(), table.size() * sizeof(uint2)));
-                o.nv_blocks = tb->as<uint2>();
-                for (int k = 0; k < 3; ++k) o.nvb_dim[k] = (int)dim[k];
+            if (total > (1ll << 27) || m.nvdb_size >= (1ll << 32)) {
+                delete s;
+                return fail(HK_ERR_UNSUPPORTED, "NanoVDB grid too large for the device block table (index bbox > 2^27 blocks or buffer >= 4 GiB)");
             }
+            float bg_probe;
+            (void)hknv::find_block(m.nvdb_bytes, m.root_offset_1based, m.root_table_size, (o.nvb_min[0] - 4096) * 8, (o.nvb_min[1] - 4096) * 8, (o.nvb_min[2] - 4096) * 8, bg_probe);
+            o.nv_background = bg_probe;
+            std::vector<uint2> table((size_t)total);
+            bool margin_ok = true;
+            for (long long bx = 0; bx < dim[0]; ++bx)
+                for (long long by = 0; by < dim[1]; ++by)
+                    for (long long bz = 0; bz < dim[2]; ++bz) {
+                        float value;
+                        long long leaf = hknv::find_block(m.nvdb_bytes, m.root_offset_1based, m.root_table_size, (int)((o.nvb_min[0] + bx) * 8), (int)((o.nvb_min[1] + by) * 8),
+                                                          (int)((o.nvb_min[2] + bz) * 8), value);
+                        uint32_t bits;
+                        std::memcpy(&bits, &value, 4);
+                        table[(size_t)bz + (size_t)dim[2] * ((size_t)by + (size_t)dim[1] * (size_t)bx)] = make_uint2((uint32_t)leaf, bits);
+                        const bool on_margin = bx == 0 || by == 0 || bz == 0 || bx == dim[0] - 1 || by == dim[1] - 1 || bz == dim[2] - 1;
+                        if (on_margin && (leaf != 0 || value != bg_probe)) margin_ok = false;
+                    }
+            if (!margin_ok) {
+                delete s;
+                return fail(HK_ERR_INVALID, "NanoVDB index_bbox does not bound the active voxels (non-background data outside it)");
+            }
+            DevBuf* tb = new DevBuf();
+            s->media_data.push_back(tb);
+            HIP_TRY(tb->upload(table.data(), table.size() * sizeof(uint2)));
+            o.nv_blocks = tb->as<uint2>();
+            for (int k = 0; k < 3; ++k) o.nvb_dim[k] = (int)dim[k];
         }
     }
     HIP_TRY(s->media.upload(dmed.data(), dmed.size() * sizeof(DMedium)));

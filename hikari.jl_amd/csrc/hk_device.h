@@ -1659,39 +1659,29 @@ HKD bool majorant_next(MajorantIter& it, const DMedium& m, S4 sigma_t, float& se
     return true;
 }
 
-// NanoVDB lookups.  The tree walk itself (nanovdb.jl:315-388) is in hk_nanovdb.h; on the device it is the fallback: at scene
-// upload the host flattens the tree over the grid's index bounding box into a block table (one 8-byte entry per 8^3 block:
-// leaf offset, or the block's constant tile / background value), so a voxel fetch is table entry -> leaf value, two dependent
-// loads instead of six.  Values are those the walk returns, by construction.
+// NanoVDB lookups.  The tree walk (nanovdb.jl:315-388, hk_nanovdb.h) runs on the HOST, once, at scene upload: it flattens the
+// tree over the grid's index bounding box (+1 block of margin) into a block table, one 8-byte entry per 8^3 block = {leaf
+// offset, or 0 and the block's constant tile / background value}.  On the device a voxel fetch is table entry -> leaf value:
+// two dependent loads instead of six, and no tree-walk code (and registers) in the tracking kernels.  Blocks outside the
+// table hold the background value (the upload checks that the margin does).  Values are those the walk returns.
 struct NvBlock {
-    int kx, ky, kz;      // block coordinates (x>>3, y>>3, z>>3) this entry is valid for
-    long long leaf_off;  // 1-based offset of the leaf node, 0 => constant `value` for the whole block
+    uint32_t leaf_off;   // 1-based byte offset of the leaf node, 0 => constant `value` for the whole block
     float value;
-    bool valid;
 };
-HKD NvBlock nv_find_block(const DMedium& m, int x, int y, int z) {
+HKD NvBlock nv_find_block(const DMedium& m, int kx, int ky, int kz) {  // block coordinates (x>>3, y>>3, z>>3)
     NvBlock r;
-    r.kx = x >> 3;
-    r.ky = y >> 3;
-    r.kz = z >> 3;
-    r.valid = true;
-    const int bx = r.kx - m.nvb_min[0], by = r.ky - m.nvb_min[1], bz = r.kz - m.nvb_min[2];
-    if (m.nv_blocks && (unsigned)bx < (unsigned)m.nvb_dim[0] && (unsigned)by < (unsigned)m.nvb_dim[1] && (unsigned)bz < (unsigned)m.nvb_dim[2]) {
+    const int bx = kx - m.nvb_min[0], by = ky - m.nvb_min[1], bz = kz - m.nvb_min[2];
+    if ((unsigned)bx < (unsigned)m.nvb_dim[0] && (unsigned)by < (unsigned)m.nvb_dim[1] && (unsigned)bz < (unsigned)m.nvb_dim[2]) {
         uint2 e = m.nv_blocks[(size_t)bz + (size_t)m.nvb_dim[2] * ((size_t)by + (size_t)m.nvb_dim[1] * (size_t)bx)];
-        r.leaf_off = (long long)e.x;
+        r.leaf_off = e.x;
         r.value = __uint_as_float(e.y);
-        return r;
+    } else {
+        r.leaf_off = 0u;
+        r.value = m.nv_background;
     }
-    r.leaf_off = hknv::find_block(m.nvdb, m.root_off, m.root_table_size, x, y, z, r.value);
     return r;
 }
-HKD float nv_f32(const unsigned char* b, long long off1) { return hknv::f32(b, off1); }
-HKD float nv_value(const DMedium& m, NvBlock& cache, int x, int y, int z) {
-    if (!(cache.valid && cache.kx == (x >> 3) && cache.ky == (y >> 3) && cache.kz == (z >> 3))) cache = nv_find_block(m, x, y, z);
-    if (cache.leaf_off == 0) return cache.value;
-    int n_leaf = ((x & 7) << 6) | ((y & 7) << 3) | (z & 7);
-    return nv_f32(m.nvdb, cache.leaf_off + 96 + (long long)n_leaf * 4);
-}
+HKD float nv_leaf_value(const DMedium& m, uint32_t leaf_off, int n_leaf) { return hknv::f32(m.nvdb, (long long)leaf_off + 96 + (long long)n_leaf * 4); }
 HKD float sample_nanovdb_density(const DMedium& m, v3 p) {  // nanovdb.jl:400-469
     float px = p.x - m.vec[0], py = p.y - m.vec[1], pz = p.z - m.vec[2];
     float fxi = m.inv_mat[0] * px + m.inv_mat[1] * py + m.inv_mat[2] * pz;
@@ -1700,12 +1690,40 @@ HKD float sample_nanovdb_density(const DMedium& m, v3 p) {  // nanovdb.jl:400-46
     float flx = floorf(fxi), fly = floorf(fyi), flz = floorf(fzi);
     int ix = (int)flx, iy = (int)fly, iz = (int)flz;
     float fx = fxi - (float)ix, fy = fyi - (float)iy, fz = fzi - (float)iz;
-    NvBlock c;
-    c.valid = false;
-    float v000 = nv_value(m, c, ix, iy, iz), v001 = nv_value(m, c, ix, iy, iz + 1);
-    float v010 = nv_value(m, c, ix, iy + 1, iz), v011 = nv_value(m, c, ix, iy + 1, iz + 1);
-    float v100 = nv_value(m, c, ix + 1, iy, iz), v101 = nv_value(m, c, ix + 1, iy, iz + 1);
-    float v110 = nv_value(m, c, ix + 1, iy + 1, iz), v111 = nv_value(m, c, ix + 1, iy + 1, iz + 1);
+    float v000, v001, v010, v011, v100, v101, v110, v111;
+    if ((ix & 7) != 7 && (iy & 7) != 7 && (iz & 7) != 7) {
+        // all eight taps in one 8^3 block (2 of 3 lookups): one table entry, eight independent leaf loads
+        NvBlock c = nv_find_block(m, ix >> 3, iy >> 3, iz >> 3);
+        if (c.leaf_off == 0u)
+            v000 = v001 = v010 = v011 = v100 = v101 = v110 = v111 = c.value;
+        else {
+            int n = ((ix & 7) << 6) | ((iy & 7) << 3) | (iz & 7);
+            v000 = nv_leaf_value(m, c.leaf_off, n);
+            v001 = nv_leaf_value(m, c.leaf_off, n + 1);
+            v010 = nv_leaf_value(m, c.leaf_off, n + 8);
+            v011 = nv_leaf_value(m, c.leaf_off, n + 9);
+            v100 = nv_leaf_value(m, c.leaf_off, n + 64);
+            v101 = nv_leaf_value(m, c.leaf_off, n + 65);
+            v110 = nv_leaf_value(m, c.leaf_off, n + 72);
+            v111 = nv_leaf_value(m, c.leaf_off, n + 73);
+        }
+    } else {
+        v000 = v001 = v010 = v011 = v100 = v101 = v110 = v111 = 0.0f;
+#pragma unroll 1
+        for (int tap = 0; tap < 8; ++tap) {
+            int x = ix + (tap >> 2), y = iy + ((tap >> 1) & 1), z = iz + (tap & 1);
+            NvBlock c = nv_find_block(m, x >> 3, y >> 3, z >> 3);
+            float v = c.leaf_off == 0u ? c.value : nv_leaf_value(m, c.leaf_off, ((x & 7) << 6) | ((y & 7) << 3) | (z & 7));
+            v000 = tap == 0 ? v : v000;
+            v001 = tap == 1 ? v : v001;
+            v010 = tap == 2 ? v : v010;
+            v011 = tap == 3 ? v : v011;
+            v100 = tap == 4 ? v : v100;
+            v101 = tap == 5 ? v : v101;
+            v110 = tap == 6 ? v : v110;
+            v111 = tap == 7 ? v : v111;
+        }
+    }
     float fx1 = 1.0f - fx, fy1 = 1.0f - fy, fz1 = 1.0f - fz;
     float v00 = v000 * fz1 + v001 * fz, v01 = v010 * fz1 + v011 * fz;
     float v10 = v100 * fz1 + v101 * fz, v11 = v110 * fz1 + v111 * fz;

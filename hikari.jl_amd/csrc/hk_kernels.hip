@@ -259,7 +259,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace(DPathState st, DScene 
 // the tracking loops wait on dependent loads (NanoVDB tree, majorant cells) ~60 % of the time at 2 waves/SIMD: trade a few
 // spilled registers for a third wave
 #ifndef HK_MEDIA_WAVES
-#define HK_MEDIA_WAVES 4
+#define HK_MEDIA_WAVES 2
 #endif
 #ifndef HK_TRACK_ADVANCE
 #define HK_TRACK_ADVANCE 8

@@ -110,6 +110,7 @@ struct DMedium {
     const unsigned char* nvdb;     // NanoVDB bytes (tree part)
     const uint2* nv_blocks;        // flattened tree over the index bbox: {leaf offset (1-based, 0 = constant block), value bits}
     int nvb_min[3], nvb_dim[3];    // block-coordinate origin / extent of nv_blocks ([bx][by][bz], bz fastest)
+    float nv_background;           // value of every block outside the table
     long long root_off;            // 1-based like the reference
     int root_table_size;
     float inv_mat[9], vec[3];

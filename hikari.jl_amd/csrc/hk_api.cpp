@@ -79,6 +79,7 @@ struct hk_ctx {
     hipStream_t stream = nullptr;
     int n_cu = 256;
     int n_waves = 4096;
+    bool waves_from_env = false;
     DevBuf sobol, cie, r2s_scale, r2s_coeffs, stats;
     DTables tables{};
     bool have_tables = false;
@@ -160,11 +161,14 @@ extern "C" int32_t hk_ctx_create(int32_t device_id, void* stream, hk_ctx** out) 
     {
         // W virtual wave segments (queues are split W ways; kernels walk them with however many waves are resident)
         int per_cu = 16;
-        if (const char* e = std::getenv("HK_WAVES_PER_CU")) per_cu = std::atoi(e) > 0 ? std::atoi(e) : 16;
+        if (const char* e = std::getenv("HK_WAVES_PER_CU")) {
+            per_cu = std::atoi(e) > 0 ? std::atoi(e) : 16;
+            c->waves_from_env = true;
+        }
         c->n_waves = c->n_cu * per_cu;
     }
     {
-        std::vector<DStats> zero((size_t)c->n_waves);
+        std::vector<DStats> zero((size_t)c->n_waves * 2);  // rows are indexed by physical wave; media scenes run up to 2 * n_waves of them
         std::memset(zero.data(), 0, zero.size() * sizeof(DStats));
         HIP_TRY(c->stats.upload(zero.data(), zero.size() * sizeof(DStats)));
     }
@@ -863,13 +867,16 @@ hipError_t alloc_arr(hk_integrator* I, T*& dst, size_t n) {
     dst = b->as<T>();
     return e;
 }
-int ensure_state(hk_integrator* I, int capacity) {
-    if (I->st_capacity >= capacity && I->st_depth >= I->p.max_depth) return HK_OK;
+// W virtual wave segments: ctx->n_waves for surface scenes; twice as many (finer, ticket-scheduled segments) when the scene has
+// media, where the work per segment is very uneven.  stats rows are indexed by PHYSICAL wave (< ctx->n_waves * 2 rows allocated).
+int ensure_state(hk_integrator* I, int capacity, bool media) {
+    const int W_want = I->ctx->n_waves * ((media && !I->ctx->waves_from_env) ? 2 : 1);
+    if (I->st_capacity >= capacity && I->st_depth >= I->p.max_depth && I->st.n_waves == W_want) return HK_OK;
     for (auto* b : I->bufs) delete b;
     I->bufs.clear();
     DPathState& s = I->st;
     size_t P = (size_t)capacity;
-    const int W = I->ctx->n_waves;
+    const int W = W_want;
     const int chunks = (capacity + 63) / 64;
     s.capacity = capacity;
     s.n_waves = W;
@@ -968,7 +975,7 @@ extern "C" int32_t hk_render(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_film*
     }
     if (S > n_samples) S = n_samples;
     if ((long)S * fr.n_pixels_padded > 0x3fffffffL) return fail(HK_ERR_INVALID, "pass too large");
-    int st = ensure_state(I, S * fr.n_pixels_padded);
+    int st = ensure_state(I, S * fr.n_pixels_padded, sc->d.n_media > 0);
     if (st != HK_OK) return st;
     fr.sample_stride = sample_stride;
     fr.max_depth = I->p.max_depth;
@@ -1063,7 +1070,7 @@ extern "C" int32_t hk_stats_reset(hk_ctx* c) {
     if (!c) return fail(HK_ERR_INVALID, "null ctx");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemset(c->stats.p, 0, (size_t)c->n_waves * sizeof(DStats)));
+    HIP_TRY(hipMemset(c->stats.p, 0, (size_t)c->n_waves * 2 * sizeof(DStats)));
     for (auto& e : c->trace_events) {
         c->event_pool.push_back(e.first);
         c->event_pool.push_back(e.second);
@@ -1087,7 +1094,7 @@ extern "C" int32_t hk_stats_get(hk_ctx* c, hk_stats* out) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     DStats h{};
     {
-        std::vector<DStats> rows((size_t)c->n_waves);
+        std::vector<DStats> rows((size_t)c->n_waves * 2);
         HIP_TRY(hipMemcpy(rows.data(), c->stats.p, rows.size() * sizeof(DStats), hipMemcpyDeviceToHost));
         for (const DStats& r : rows) {
             h.rays_closest += r.rays_closest;

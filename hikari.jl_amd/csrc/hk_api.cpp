@@ -32,6 +32,7 @@ void launch_test_sobol(hipStream_t, const DTables&, const DSobol&, int, const in
 void launch_test_camera(hipStream_t, const DTables&, const DFilter&, const DCamera&, const DSobol&, int, int, const int*, const int*, const int*, float*);
 void launch_test_uplift(hipStream_t, const DTables&, int, int, const float*, const float*, float*);
 void launch_test_light_bvh(hipStream_t, const DScene&, int, const float*, const float*, const float*, int*, float*, const int*, float*);
+void launch_sobol_table(hipStream_t, const DSobol&, const DFrame&, uint32_t*, int);
 void launch_test_light(hipStream_t, const DScene&, const DTables&, int, int, int, const float*, const float*, const float*, float*);
 void launch_test_bsdf(hipStream_t, const DScene&, const DTables&, int, int, int, int, const float*, const float*, const float*, const float*, const float*, const float*, float*);
 }  // namespace hk
@@ -138,6 +139,8 @@ struct hk_integrator {
     DPathState st{};
     std::vector<DevBuf*> bufs;
     int st_capacity = 0, st_depth = 0;
+    DevBuf sobol_table;  // DSobol::hi_table
+    int sobol_rows = 0, sobol_stride = 0, sobol_log2 = -1, sobol_digits = -1;
     ~hk_integrator() {
         for (auto* b : bufs) delete b;
     }
@@ -929,6 +932,8 @@ DSobol make_sobol(const hk_integrator_params& p, int w, int h) {  // compute_zso
     s.n_base4_digits = res_log2 + (s.log2_spp + 1) / 2;
     s.seed = p.sampler_seed;
     s.width = w;
+    s.hi_table = nullptr;
+    s.hi_rows = s.hi_stride = 0;
     return s;
 }
 DCamera make_camera(const hk_camera& c) {
@@ -983,6 +988,21 @@ extern "C" int32_t hk_render(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_film*
     fr.max_component_value = I->p.max_component_value;
     fr.count_nodes = c->count_nodes;
     DSobol sob = make_sobol(I->p, W, H);
+    {   // pixel-digit table of the sampler: depends on film size, spp exponent and max_depth only
+        const int rows = 4 + 5 * (I->p.max_depth + 1);
+        if (I->sobol_rows != rows || I->sobol_stride != fr.n_pixels_padded || I->sobol_log2 != sob.log2_spp || I->sobol_digits != sob.n_base4_digits) {
+            HIP_TRY(I->sobol_table.alloc((size_t)rows * fr.n_pixels_padded * sizeof(uint32_t)));
+            hk::launch_sobol_table(c->stream, sob, fr, I->sobol_table.as<uint32_t>(), rows);
+            HIP_TRY(hipGetLastError());
+            I->sobol_rows = rows;
+            I->sobol_stride = fr.n_pixels_padded;
+            I->sobol_log2 = sob.log2_spp;
+            I->sobol_digits = sob.n_base4_digits;
+        }
+        sob.hi_table = I->sobol_table.as<uint32_t>();
+        sob.hi_rows = rows;
+        sob.hi_stride = fr.n_pixels_padded;
+    }
     DCamera dc = make_camera(*cam);
     DStats* dstats = c->stats.as<DStats>();
     const int trace_blocks = c->n_cu, shade_blocks = c->n_cu, light_blocks = c->n_cu;  // launchers size the grid from residency

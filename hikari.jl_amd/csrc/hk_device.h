@@ -203,12 +203,11 @@ HKD float sobol_sample(uint64_t a, int dimension, uint32_t scramble, const uint3
 __device__ static const uint8_t kPerm4[24] = {
     0xE4, 0xB4, 0xD8, 0x78, 0x6C, 0x9C, 0xE1, 0xB1, 0xC9, 0x39, 0x2D, 0x8D,
     0xC6, 0x36, 0xD2, 0x72, 0x4E, 0x1E, 0x27, 0x87, 0x1B, 0x4B, 0x63, 0x93};
-HKD uint64_t zsobol_sample_index(uint64_t morton, int dimension, int log2_spp, int n_base4_digits) {
+// Digits i = i_hi .. i_lo of the permuted index (sobol.jl:225-262).  The full index is digits n-1 .. pow2 plus the last-bit
+// special case; the digits whose bits lie above the sample bits (shift >= log2_spp) do not depend on the sample index.
+HKD uint64_t zsobol_digits(uint64_t morton, uint64_t dmix, int pow2, int i_hi, int i_lo) {
     uint64_t sample_index = 0;
-    const int pow2 = log2_spp & 1;
-    const uint64_t dmix = 0x55555555ull * (uint64_t)(int64_t)dimension;
-    // digits i = n-1 .. last_digit; iterations with i < last_digit contribute nothing (sobol.jl:244-247)
-    for (int i = n_base4_digits - 1; i >= pow2; --i) {
+    for (int i = i_hi; i >= i_lo; --i) {
         int shift = 2 * i - pow2;
         int digit = (int)((morton >> shift) & 3ull);
         uint64_t higher = morton >> (shift + 2);
@@ -219,12 +218,45 @@ HKD uint64_t zsobol_sample_index(uint64_t morton, int dimension, int log2_spp, i
         uint64_t pd = (uint64_t)((kPerm4[p] >> (2 * digit)) & 3);
         sample_index |= pd << shift;
     }
+    return sample_index;
+}
+HKD int zsobol_first_pixel_digit(int log2_spp) { return (log2_spp + 1) >> 1; }  // smallest i with 2i - pow2 >= log2_spp
+HKD uint64_t zsobol_sample_index(uint64_t morton, int dimension, int log2_spp, int n_base4_digits) {
+    const int pow2 = log2_spp & 1;
+    const uint64_t dmix = 0x55555555ull * (uint64_t)(int64_t)dimension;
+    // digits i = n-1 .. last_digit; iterations with i < last_digit contribute nothing (sobol.jl:244-247)
+    uint64_t sample_index = zsobol_digits(morton, dmix, pow2, n_base4_digits - 1, pow2);
     if (pow2) {
         uint64_t digit = morton & 1ull;
         uint64_t xb = mix_bits((morton >> 1) ^ dmix) & 1ull;
         sample_index |= (digit ^ xb);
     }
     return sample_index;
+}
+// same value, with the pixel digits read from the table entry `hi` (= their permuted digits >> log2_spp)
+HKD uint64_t zsobol_sample_index_cached(uint64_t morton, int dimension, int log2_spp, uint32_t hi) {
+    const int pow2 = log2_spp & 1;
+    const uint64_t dmix = 0x55555555ull * (uint64_t)(int64_t)dimension;
+    uint64_t sample_index = ((uint64_t)hi << log2_spp) | zsobol_digits(morton, dmix, pow2, zsobol_first_pixel_digit(log2_spp) - 1, pow2);
+    if (pow2) {
+        uint64_t digit = morton & 1ull;
+        uint64_t xb = mix_bits((morton >> 1) ^ dmix) & 1ull;
+        sample_index |= (digit ^ xb);
+    }
+    return sample_index;
+}
+// Dimensions the path draws (volpath.jl:252-262): camera 1,3,4,6 and, per depth d, 6+7d + {1,3,4,6,7}.  Row index into the
+// pixel-digit table, or -1 for a dimension that is not tabulated.
+HKD int sobol_row(int dim) {
+    if (dim < 7) return dim == 1 ? 0 : (dim == 3 ? 1 : (dim == 4 ? 2 : (dim == 6 ? 3 : -1)));
+    int d = (dim - 6) / 7, o = (dim - 6) - 7 * d;   // o == 0 is the previous depth's "+7"
+    int j = o == 0 ? 0 : (o == 1 ? 1 : (o == 3 ? 2 : (o == 4 ? 3 : (o == 6 ? 4 : -1))));
+    return j < 0 ? -1 : 4 + 5 * d + j;
+}
+HKD int sobol_row_dim(int row) {  // inverse of sobol_row
+    if (row < 4) return row == 0 ? 1 : (row == 1 ? 3 : (row == 2 ? 4 : 6));
+    int d = (row - 4) / 5, j = (row - 4) - 5 * d;
+    return 6 + 7 * d + (j == 0 ? 0 : (j == 1 ? 1 : (j == 2 ? 3 : (j == 3 ? 4 : 6))));
 }
 HKD uint64_t zsobol_hash(int dimension, uint32_t seed) {
     uint32_t w[2] = {(uint32_t)dimension, seed};
@@ -233,26 +265,39 @@ HKD uint64_t zsobol_hash(int dimension, uint32_t seed) {
 struct SobolCtx {
     uint64_t morton_base;  // encode_morton2(px,py) << log2_spp | sample_idx
     const uint32_t* mats;
+    const uint32_t* hi;    // pixel-digit table column of this pixel (null: compute every digit)
+    int hi_rows, hi_stride;
     int log2_spp, n_digits;
     uint32_t seed;
 };
-HKD SobolCtx sobol_ctx(const DSobol& s, const uint32_t* mats, int px, int py, int sample_idx) {
+// pix_slot: the pixel's slot within one sample of the pass (tile-major), or -1 when the caller has no table column
+HKD SobolCtx sobol_ctx(const DSobol& s, const uint32_t* mats, int px, int py, int sample_idx, int pix_slot = -1) {
     SobolCtx c;
     uint64_t m = (left_shift2((uint64_t)(uint32_t)py) << 1) | left_shift2((uint64_t)(uint32_t)px);
     c.morton_base = (m << s.log2_spp) | (uint64_t)(int64_t)sample_idx;
     c.mats = mats;
+    // the table holds the digits above the sample bits: valid only while the sample index fits in them
+    const bool cached = s.hi_table != nullptr && pix_slot >= 0 && ((unsigned)sample_idx >> s.log2_spp) == 0u;
+    c.hi = cached ? s.hi_table + pix_slot : nullptr;
+    c.hi_rows = s.hi_rows;
+    c.hi_stride = s.hi_stride;
     c.log2_spp = s.log2_spp;
     c.n_digits = s.n_base4_digits;
     c.seed = s.seed;
     return c;
 }
+HKD uint64_t sobol_index(const SobolCtx& c, int dim) {
+    const int row = sobol_row(dim);
+    if (c.hi != nullptr && row >= 0 && row < c.hi_rows) return zsobol_sample_index_cached(c.morton_base, dim, c.log2_spp, c.hi[(size_t)row * c.hi_stride]);
+    return zsobol_sample_index(c.morton_base, dim, c.log2_spp, c.n_digits);
+}
 HKD float sobol_1d(const SobolCtx& c, int dim) {  // sobol.jl:269-282
-    uint64_t idx = zsobol_sample_index(c.morton_base, dim, c.log2_spp, c.n_digits);
+    uint64_t idx = sobol_index(c, dim);
     uint32_t h = (uint32_t)zsobol_hash(dim + 1, c.seed);
     return sobol_sample(idx, 0, h, c.mats);
 }
 HKD v2 sobol_2d(const SobolCtx& c, int dim) {  // sobol.jl:290-309
-    uint64_t idx = zsobol_sample_index(c.morton_base, dim, c.log2_spp, c.n_digits);
+    uint64_t idx = sobol_index(c, dim);
     uint64_t bits = zsobol_hash(dim + 2, c.seed);
     return mk2(sobol_sample(idx, 0, (uint32_t)bits, c.mats), sobol_sample(idx, 1, (uint32_t)(bits >> 32), c.mats));
 }

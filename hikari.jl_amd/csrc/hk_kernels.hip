@@ -71,6 +71,24 @@ __device__ __forceinline__ void slot_to_pixel(const DFrame& fr, int slot_in_samp
 
 }  // namespace
 
+// Pixel-digit table of the ZSobol index (DSobol::hi_table): entry (row, pixel slot) = the permuted base-4 digits above the
+// sample bits, for the dimension of that row.  Built once per film size / sampler seed.
+__global__ void __launch_bounds__(256) k_sobol_table(DSobol sob, DFrame fr, uint32_t* table, int rows) {
+    const long total = (long)rows * fr.n_pixels_padded;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int row = (int)(i / fr.n_pixels_padded), pix = (int)(i - (long)row * fr.n_pixels_padded);
+        int px, py;
+        bool inside;
+        slot_to_pixel(fr, pix, px, py, inside);
+        const int dim = sobol_row_dim(row);
+        uint64_t m = (left_shift2((uint64_t)(uint32_t)(py + 1)) << 1) | left_shift2((uint64_t)(uint32_t)(px + 1));
+        uint64_t morton = m << sob.log2_spp;
+        const int pow2 = sob.log2_spp & 1;
+        uint64_t hi = zsobol_digits(morton, 0x55555555ull * (uint64_t)(int64_t)dim, pow2, sob.n_base4_digits - 1, zsobol_first_pixel_digit(sob.log2_spp));
+        table[i] = (uint32_t)(hi >> sob.log2_spp);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // K1: camera rays (volpath.jl:125-205).  One thread per path slot of the pass.
 // ---------------------------------------------------------------------------------------------------
@@ -89,7 +107,7 @@ __global__ void __launch_bounds__(256) k_camera(DPathState st, DFrame fr, DTable
         if (active) {
             int sample_idx = fr.first_sample + k * fr.sample_stride;
             int x = px + 1, y = py + 1;  // 1-based pixel coordinates (Q1)
-            SobolCtx sc = sobol_ctx(sob, T.sobol, x, y, sample_idx);
+            SobolCtx sc = sobol_ctx(sob, T.sobol, x, y, sample_idx, slot - k * fr.n_pixels_padded);
             float wavelength_u = sobol_1d(sc, 1);
             v2 jit = sobol_2d(sc, 3);
             // dims 4 (time) and 6 (lens) only matter with a finite aperture: ray.time is carried by the reference
@@ -506,7 +524,7 @@ __global__ void __launch_bounds__(256) k_scatter(DPathState st, DScene sc, DTabl
                 int px, py;
                 bool inside;
                 slot_to_pixel(fr, (int)slot - k * fr.n_pixels_padded, px, py, inside);
-                SobolCtx sctx = sobol_ctx(sob, T.sobol, px + 1, py + 1, fr.first_sample + k * fr.sample_stride);
+                SobolCtx sctx = sobol_ctx(sob, T.sobol, px + 1, py + 1, fr.first_sample + k * fr.sample_stride, (int)slot - k * fr.n_pixels_padded);
                 const int base_dim = 6 + 7 * depth;
                 if (sc.n_lights > 0) {
                     float light_select = sobol_1d(sctx, base_dim + 1);
@@ -718,7 +736,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
             int px, py;
             bool inside;
             slot_to_pixel(fr, (int)slot - k * fr.n_pixels_padded, px, py, inside);
-            SobolCtx sctx = sobol_ctx(sob, T.sobol, px + 1, py + 1, fr.first_sample + k * fr.sample_stride);
+            SobolCtx sctx = sobol_ctx(sob, T.sobol, px + 1, py + 1, fr.first_sample + k * fr.sample_stride, (int)slot - k * fr.n_pixels_padded);
             // every path in the depth-d queues has work.depth == d, so the dimension (and its scramble hashes) is
             // wave-uniform: derived from the kernel argument it stays in scalar registers
             const int base_dim = 6 + 7 * depth;
@@ -1456,6 +1474,9 @@ void launch_test_bsdf(hipStream_t s, const DScene& sc, const DTables& T, int mod
 }
 void launch_test_light(hipStream_t s, const DScene& sc, const DTables& T, int mode, int light_idx, int n, const float* p3, const float* in3, const float* lambda, float* out) {
     hipLaunchKernelGGL(k_test_light, dim3(grid_for(n, 64, 4096)), dim3(64), 0, s, sc, T, mode, light_idx, n, p3, in3, lambda, out);
+}
+void launch_sobol_table(hipStream_t s, const DSobol& sob, const DFrame& fr, uint32_t* table, int rows) {
+    hipLaunchKernelGGL(k_sobol_table, dim3(grid_for((long)rows * fr.n_pixels_padded > 0x3fffffff ? 0x3fffffff : rows * fr.n_pixels_padded, 256, 8192)), dim3(256), 0, s, sob, fr, table, rows);
 }
 
 }  // namespace hk

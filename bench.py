@@ -172,6 +172,7 @@ def main():
             oracle.set_threads(os.cpu_count() or 1)
             osc = oracle.OracleScene(scene)
             p = hk.integrator_params(max_depth=DEPTH, samples=FULL_SPP)
+            osc.render(p, cam, W, H, 1, first=FULL_SPP)       # untimed: thread team start-up, first-touch of the work arrays
             c0 = time.perf_counter()
             _, ost = osc.render(p, cam, W, H, args.cpu_spp)
             cdt = time.perf_counter() - c0

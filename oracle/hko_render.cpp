@@ -50,6 +50,76 @@ struct RayItem {  // VPRayWorkItem  workitems.jl:14-41
     bool specular_bounce, any_non_specular;
     int32_t medium;
 };
+// Per-stage work arrays: entries are written before they are read (guarded by the stage's valid/kind flags), so they are left
+// uninitialised — value-initialising ~1 KB per pixel per depth on one thread was the oracle's scaling limit on many-core hosts.
+template <class T>
+struct RawBuf {
+    T* p;
+    size_t n;
+    explicit RawBuf(size_t count) : p((T*)std::malloc((count ? count : 1) * sizeof(T))), n(count) {}
+    ~RawBuf() { std::free(p); }
+    RawBuf(const RawBuf&) = delete;
+    RawBuf& operator=(const RawBuf&) = delete;
+    T& operator[](size_t i) { return p[i]; }
+    const T& operator[](size_t i) const { return p[i]; }
+    size_t size() const { return n; }
+};
+// growable array without value-initialisation (same reason), plus an order-preserving parallel compaction into it
+template <class T>
+struct RawVec {
+    T* p = nullptr;
+    size_t n = 0, cap = 0;
+    RawVec() {}
+    explicit RawVec(size_t count) { reserve(count), n = count; }
+    ~RawVec() { std::free(p); }
+    RawVec(const RawVec&) = delete;
+    RawVec& operator=(const RawVec&) = delete;
+    void reserve(size_t c) {
+        if (c <= cap) return;
+        p = (T*)std::realloc(p, c * sizeof(T));
+        cap = c;
+    }
+    void push_back(const T& v) {
+        if (n == cap) reserve(cap ? 2 * cap : 1024);
+        std::memcpy(&p[n++], &v, sizeof(T));
+    }
+    T& operator[](size_t i) { return p[i]; }
+    const T& operator[](size_t i) const { return p[i]; }
+    size_t size() const { return n; }
+    void swap(RawVec& o) {
+        std::swap(p, o.p), std::swap(n, o.n), std::swap(cap, o.cap);
+    }
+    T* begin() { return p; }
+    T* end() { return p + n; }
+};
+template <class T>
+static void append_compact(RawVec<T>& dst, const T* src, const uint8_t* valid, int32_t n) {
+#if defined(_OPENMP)
+    const int nt = omp_get_max_threads();
+#else
+    const int nt = 1;
+#endif
+    std::vector<size_t> cnt((size_t)nt + 1, 0);
+    const int32_t chunk = (n + nt - 1) / nt;
+#pragma omp parallel for schedule(static, 1)
+    for (int t = 0; t < nt; ++t) {
+        int32_t lo = t * chunk, hi = lo + chunk < n ? lo + chunk : n;
+        size_t c = 0;
+        for (int32_t i = lo; i < hi; ++i) c += valid[i] ? 1 : 0;
+        cnt[(size_t)t + 1] = c;
+    }
+    for (int t = 0; t < nt; ++t) cnt[(size_t)t + 1] += cnt[(size_t)t];
+    const size_t base = dst.n;
+    dst.reserve(base + cnt[(size_t)nt]);
+#pragma omp parallel for schedule(static, 1)
+    for (int t = 0; t < nt; ++t) {
+        int32_t lo = t * chunk, hi = lo + chunk < n ? lo + chunk : n;
+        size_t o = base + cnt[(size_t)t];
+        for (int32_t i = lo; i < hi; ++i)
+            if (valid[i]) std::memcpy(&dst.p[o++], &src[i], sizeof(T));
+    }
+    dst.n = base + cnt[(size_t)nt];
+}
 struct SurfaceGeom {
     V3 pi, n, dpdu, dpdv, ns, dpdus, dpdvs;
     V2 uv;
@@ -379,8 +449,8 @@ struct RenderState {
 
 
 // K4 (delta-tracking.jl:79-453), K5 (medium-scatter.jl:15-138), K6 (medium-scatter.jl:148-216)
-static void process_media_stage(const Scene& sc, RenderState& st, std::vector<RayItem>& rays, std::vector<uint8_t>& kind, std::vector<MediumSampleItem>& msamples,
-                                std::vector<HitItem>& hits, std::vector<EscapedItem>& escaped, std::vector<RayItem>& next_rays, std::vector<ShadowItem>& shadow_out,
+static void process_media_stage(const Scene& sc, RenderState& st, RawVec<RayItem>& rays, std::vector<uint8_t>& kind, std::vector<MediumSampleItem>& msamples,
+                                RawBuf<HitItem>& hits, RawBuf<EscapedItem>& escaped, RawVec<RayItem>& next_rays, RawVec<ShadowItem>& shadow_out,
                                 const hk_integrator_params& ip, std::vector<Counters>& cnts, int32_t depth) {
     (void)rays;
     (void)depth;
@@ -521,9 +591,9 @@ static void process_media_stage(const Scene& sc, RenderState& st, std::vector<Ra
         }
     }
     // ---- K5: direct lighting at medium scattering events (n = 0 for the light BVH) ----
-    std::vector<ShadowItem> sh(n);
+    RawVec<ShadowItem> sh(n);
     std::vector<uint8_t> sh_valid(n, 0);
-    std::vector<RayItem> nr(n);
+    RawVec<RayItem> nr(n);
     std::vector<uint8_t> nr_valid(n, 0);
 #pragma omp parallel for schedule(static)
     for (int32_t i = 0; i < n; ++i) {
@@ -583,10 +653,8 @@ static void process_media_stage(const Scene& sc, RenderState& st, std::vector<Ra
             nr_valid[i] = 1;
         }
     }
-    for (int32_t i = 0; i < n; ++i) {
-        if (sh_valid[i]) shadow_out.push_back(sh[i]);
-        if (nr_valid[i]) next_rays.push_back(nr[i]);
-    }
+    append_compact(shadow_out, sh.p, sh_valid.data(), n);
+    append_compact(next_rays, nr.p, nr_valid.data(), n);
 }
 
 static void render_one_sample(const Scene& sc, const hk_integrator_params& ip, const FilterParams& fp, const FilterSampler& fs, const hk_camera& cam,
@@ -611,7 +679,7 @@ static void render_one_sample(const Scene& sc, const hk_integrator_params& ip, c
     std::fill(st.pixel_L.begin(), st.pixel_L.end(), 0.0f);
 
     // ---- K1 ----
-    std::vector<RayItem> rays(N);
+    RawVec<RayItem> rays(N);
     std::vector<uint8_t> valid(N, 0);
 #pragma omp parallel for schedule(static)
     for (int32_t idx = 1; idx <= N; ++idx) {
@@ -667,8 +735,8 @@ static void render_one_sample(const Scene& sc, const hk_integrator_params& ip, c
             st.s_rr[p0] = sample_1d(rng, px, py, sample_idx, base + 7);
         }
         // ---- K3 trace ----
-        std::vector<HitItem> hits(n_rays);
-        std::vector<EscapedItem> escaped(n_rays);
+        RawBuf<HitItem> hits(n_rays);
+        RawBuf<EscapedItem> escaped(n_rays);
         std::vector<MediumSampleItem> medium_samples(have_media ? n_rays : 0);
         std::vector<uint8_t> kind(n_rays, 0);  // 0 none, 1 hit, 2 escaped, 3 medium
 #pragma omp parallel for schedule(dynamic, 256)
@@ -770,8 +838,8 @@ static void render_one_sample(const Scene& sc, const hk_integrator_params& ip, c
             }
         }
         // ---- K4-K6 media (delta tracking, scatter NEE, phase sampling) ----
-        std::vector<RayItem> next_rays_media;
-        std::vector<ShadowItem> shadow_media;
+        RawVec<RayItem> next_rays_media;
+        RawVec<ShadowItem> shadow_media;
         if (have_media) {
             process_media_stage(sc, st, rays, kind, medium_samples, hits, escaped, next_rays_media, shadow_media, ip, cnts, depth);
         }
@@ -801,7 +869,7 @@ static void render_one_sample(const Scene& sc, const hk_integrator_params& ip, c
             }
         }
         // ---- K8 surface hits ----
-        std::vector<MatItem> mats(n_rays);
+        RawBuf<MatItem> mats(n_rays);
         std::vector<uint8_t> mat_valid(n_rays, 0);
 #pragma omp parallel for schedule(static)
         for (int32_t i = 0; i < n_rays; ++i) {
@@ -855,7 +923,7 @@ static void render_one_sample(const Scene& sc, const hk_integrator_params& ip, c
             mat_valid[i] = 1;
         }
         // ---- K9 direct lighting ----
-        std::vector<ShadowItem> shadows(n_rays);
+        RawBuf<ShadowItem> shadows(n_rays);
         std::vector<uint8_t> shadow_valid(n_rays, 0);
         if (have_lights) {
 #pragma omp parallel for schedule(static)
@@ -925,7 +993,7 @@ static void render_one_sample(const Scene& sc, const hk_integrator_params& ip, c
             }
         }
         // ---- K11 evaluate materials ----
-        std::vector<RayItem> out(n_rays);
+        RawBuf<RayItem> out(n_rays);
         std::vector<uint8_t> out_valid(n_rays, 0);
 #pragma omp parallel for schedule(static)
         for (int32_t i = 0; i < n_rays; ++i) {
@@ -970,11 +1038,10 @@ static void render_one_sample(const Scene& sc, const hk_integrator_params& ip, c
             r.medium = new_medium;
             out_valid[i] = 1;
         }
-        std::vector<RayItem> next;
-        next.reserve(n_rays);
+        RawVec<RayItem> next;
+        next.reserve(n_rays + next_rays_media.size());
         for (auto& r : next_rays_media) next.push_back(r);
-        for (int32_t i = 0; i < n_rays; ++i)
-            if (out_valid[i]) next.push_back(out[i]);
+        append_compact(next, out.p, out_valid.data(), n_rays);
         rays.swap(next);
     }
 

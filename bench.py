@@ -69,7 +69,7 @@ def main():
     elif args.config == "sky":
         W, H, DEPTH = 800, 800, 12
         scene, film, cam = scenes.sky_scene(W, H, env_res=512)
-        workload = "glass sphere + gold slab + 512^2 equal-area env map + sun (README scene stand-in), 800x800, VolPath depth 12, %d spp per step" % SPP_PER_STEP
+        workload = "README scene: glass sphere + Gold(roughness=0.01) slab + Hosek-Wilkie sun-sky (512^2 equal-area env map + SunLight), 800x800, VolPath depth 12, %d spp per step" % SPP_PER_STEP
     elif args.config == "manylight":
         W, H, DEPTH = 1024, 1024, 8
         scene, film, cam = scenes.many_light_scene(W, H)

@@ -11,11 +11,12 @@ from .envmap import Distribution2D, EnvironmentLight, EnvironmentMap, analytic_s
 from .film import Film
 from .lights import (AmbientLight, DiffuseAreaLight, DirectionalLight, PointLight, RGBIlluminantSpectrum, SpotLight,
                      SunLight)
-from .materials import (CoatedConductorMaterial, CoatedDiffuseMaterial, CoatedDiffuseTransmissionMaterial,
+from .materials import (Aluminum, Brass, Copper, Gold, Silver, CoatedConductorMaterial, CoatedDiffuseMaterial, CoatedDiffuseTransmissionMaterial,
                         ConductorMaterial, DiffuseTransmissionMaterial, Emissive, GlassMaterial, MatteMaterial,
                         MediumInterface, MirrorMaterial, MixMaterial, PiecewiseLinearSpectrum, PlasticMaterial,
                         RGBSpectrum, Texture, ThinDielectricMaterial, VertexColorTexture)
 from .media import GridMedium, HomogeneousMedium, NanoVDBMedium, RGBGridMedium
 from .scene import Scene
+from .sunsky import sunsky_to_envlight
 from .volpath import (BoxFilter, Context, GaussianFilter, LanczosSincFilter, MitchellFilter, TriangleFilter, VolPath,
                       integrator_params, scene_handle)

@@ -93,11 +93,59 @@ class PiecewiseLinearSpectrum:
 class ConductorMaterial(Material):
     kind = A.HK_MAT_CONDUCTOR
 
-    def __init__(self, eta=RGBSpectrum(0.2, 0.92, 1.1), k=RGBSpectrum(3.9, 2.45, 2.14), roughness=0.0,
+    def __init__(self, eta=RGBSpectrum(0.2, 0.2, 0.2), k=RGBSpectrum(3.9, 3.9, 3.9), roughness=0.1,
                  reflectance=RGBSpectrum(1.0), remap_roughness=True):
+        """keyword constructor defaults of uber-material.jl:418-426"""
         self.eta = eta if isinstance(eta, PiecewiseLinearSpectrum) else _rgb(eta)
         self.k = k if isinstance(k, PiecewiseLinearSpectrum) else _rgb(k)
         self.roughness, self.reflectance, self.remap_roughness = roughness, _rgb(reflectance), remap_roughness
+
+
+def _metal_spectra():
+    """measured eta/k of Ag, Al, Au, Cu, CuZn (spectral/metal-spectra.jl; data/metal_spectra.bin)"""
+    import os
+    import struct
+    if not _METALS:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "metal_spectra.bin")
+        with open(path, "rb") as f:
+            (count,) = struct.unpack("<i", f.read(4))
+            for _ in range(count):
+                (ln,) = struct.unpack("<i", f.read(4))
+                name = f.read(ln).decode()
+                (n,) = struct.unpack("<i", f.read(4))
+                lam = np.frombuffer(f.read(4 * n), dtype=f32).copy()
+                val = np.frombuffer(f.read(4 * n), dtype=f32).copy()
+                _METALS[name] = PiecewiseLinearSpectrum(lam, val)
+    return _METALS
+
+
+_METALS = {}
+
+
+def _metal(prefix, roughness, reflectance, remap_roughness):
+    m = _metal_spectra()
+    return ConductorMaterial(m[prefix + "_ETA_SPECTRUM"], m[prefix + "_K_SPECTRUM"], roughness, reflectance, remap_roughness)
+
+
+def Gold(roughness=0.0, reflectance=RGBSpectrum(1.0), remap_roughness=True):
+    """Gold(; roughness=0, reflectance=(1,1,1), remap_roughness=true) (uber-material.jl:469-470): measured Au eta/k"""
+    return _metal("AU", roughness, reflectance, remap_roughness)
+
+
+def Silver(roughness=0.0, reflectance=RGBSpectrum(1.0), remap_roughness=True):
+    return _metal("AG", roughness, reflectance, remap_roughness)
+
+
+def Copper(roughness=0.0, reflectance=RGBSpectrum(1.0), remap_roughness=True):
+    return _metal("CU", roughness, reflectance, remap_roughness)
+
+
+def Aluminum(roughness=0.0, reflectance=RGBSpectrum(1.0), remap_roughness=True):
+    return _metal("AL", roughness, reflectance, remap_roughness)
+
+
+def Brass(roughness=0.0, reflectance=RGBSpectrum(1.0), remap_roughness=True):
+    return _metal("CUZN", roughness, reflectance, remap_roughness)
 
 
 class CoatedDiffuseMaterial(Material):

@@ -173,25 +173,29 @@ def material_scene(width=64, height=64, material=None, light="both", thin_panel=
     return s, film, cam
 
 
-def sky_scene(width=800, height=800, env_res=128, gold=None, sun=True, tess=64):
-    """Config 3 (README.md:62-75): glass sphere r = 1 at the origin, gold slab Rect3f((-2,-2,-1),(4,4,.01)), z-up sun + sky
-    from direction (1,2,9): EnvironmentLight(equal-area map, scale = intensity/10567) + SunLight(RGB(5,4.75,4.25), -dir)
-    (RGB ctor => scale 1/10567).  The Hosek-Wilkie bake (lights/sun_sky.jl) is host-side scene construction; the
-    map here is `analytic_sky`, a synthetic equal-area image of the same structure."""
+def sky_scene(width=800, height=800, env_res=512, gold=None, sun=True, tess=64, analytic=False, intensity=1.0, turbidity=3.0):
+    """Config 3 (README.md:62-75): glass sphere r = 1 at the origin, `Gold(roughness=0.01)` slab Rect3f((-2,-2,-1),(4,4,.01)),
+    `SunSkyLight(Vec3f(1,2,9); intensity=1, turbidity=3, ground_enabled=false)` = the Hosek-Wilkie bake of lights/sun_sky.jl:
+    EnvironmentLight(512^2 equal-area map, scale = intensity/10567) + SunLight(RGB(5,4.75,4.25)*intensity, -dir).
+    `analytic=True` swaps the bake for `analytic_sky` (a synthetic map with a hot spot, used by the importance-sampling tests)."""
     from .envmap import EnvironmentLight, EnvironmentMap, analytic_sky
     from .lights import D65_PHOTOMETRIC, SunLight
+    from .materials import Gold
+    from .sunsky import sunsky_to_envlight
     import numpy as _np
     s = Scene()
     s.push(G.sphere((0, 0, 0), 1.0, tess), GlassMaterial(Kr=RGBSpectrum(1.0), Kt=RGBSpectrum(1.0), index=1.5))
-    if gold is None:
-        gold = ConductorMaterial(eta=RGBSpectrum(0.15557, 0.42415, 1.3831), k=RGBSpectrum(3.6024, 2.4721, 1.9155), roughness=0.01)
-    s.push(G.rect3f((-2, -2, -1), (4, 4, 0.01)), gold)
+    s.push(G.rect3f((-2, -2, -1), (4, 4, 0.01)), gold if gold is not None else Gold(roughness=0.01))
     sun_dir = (1.0, 2.0, 9.0)
-    env = EnvironmentMap(analytic_sky(env_res, sun_dir=sun_dir))
-    inv = float(_np.float32(1) / _np.float32(D65_PHOTOMETRIC))
-    s.push(EnvironmentLight(env, RGBSpectrum(inv, inv, inv)))
+    if analytic:
+        inv = float(_np.float32(intensity) / _np.float32(D65_PHOTOMETRIC))
+        env_light = EnvironmentLight(EnvironmentMap(analytic_sky(env_res, sun_dir=sun_dir)), RGBSpectrum(inv, inv, inv))
+        sun_light = SunLight.from_rgb((5.0 * intensity, 4.75 * intensity, 4.25 * intensity), tuple(-v for v in sun_dir))
+    else:
+        env_light, sun_light = sunsky_to_envlight(sun_dir, intensity=intensity, turbidity=turbidity, ground_enabled=False, resolution=env_res)
+    s.push(env_light)
     if sun:
-        s.push(SunLight.from_rgb((5.0, 4.75, 4.25), tuple(-v for v in sun_dir)))
+        s.push(sun_light)
     s.sync()
     film = Film((width, height))
     cam = PerspectiveCamera((4.0, -5.0, 2.5), (0, 0, -0.3), film, up=(0, 0, 1), fov=40.0)

@@ -41,6 +41,28 @@ def main():
         assert a.size == 471, (nm, a.size)
         xyz.append(a)
     np.concatenate(xyz).tofile(os.path.join(OUT, "cie_xyz.bin"))
+
+    # measured metal eta/k (pbrt-v4 spectrum data): [name, n, lambdas[n], values[n]] as float32, one record per spectrum
+    met = open(os.path.join(REF, "spectral/metal-spectra.jl")).read()
+    with open(os.path.join(OUT, "metal_spectra.bin"), "wb") as f:
+        names = re.findall(r"const\s+(\w+_(?:ETA|K)_SPECTRUM)\s*=\s*from_interleaved\(PiecewiseLinearSpectrum\{(\d+)\},\s*\((.*?)\)\)", met, re.S)
+        f.write(struct.pack("<i", len(names)))
+        for name, n, body in names:
+            vals = np.array([float(t.rstrip("f0")) if t.endswith("f0") else float(t) for t in re.split(r"[\s,]+", re.sub(r"#.*", "", body)) if t], dtype=np.float32)
+            assert vals.size == 2 * int(n), (name, vals.size, n)
+            nb = name.encode()
+            f.write(struct.pack("<i", len(nb)) + nb + struct.pack("<i", int(n)))
+            vals[0::2].tofile(f)
+            vals[1::2].tofile(f)
+
+    # Hosek-Wilkie sky model coefficients (c) 2012-2013 Lukas Hosek and Alexander Wilkie, BSD 3-clause (see data/README):
+    # 11 bands x 1080 config doubles, then 11 bands x 120 radiance doubles (lights/hosek_wilkie_data.jl:6-1610)
+    hw = open(os.path.join(REF, "lights/hosek_wilkie_data.jl")).read()
+    bands = [320 + 40 * i for i in range(11)]
+    cfg = [np.array([float(t) for t in grab_block(hw, "_HOSEK_SPECTRAL_CONFIG_%d" % b)], dtype=np.float64) for b in bands]
+    rad = [np.array([float(t) for t in grab_block(hw, "_HOSEK_SPECTRAL_RAD_%d" % b)], dtype=np.float64) for b in bands]
+    assert all(c.size == 1080 for c in cfg) and all(r.size == 120 for r in rad)
+    np.concatenate(cfg + rad).tofile(os.path.join(OUT, "hosek_wilkie_sky.bin"))
     print("wrote", OUT)
 
 

@@ -581,21 +581,65 @@ extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene**
             s->media_data.push_back(nb);
             HIP_TRY(nb->upload(m.nvdb_bytes, (size_t)m.nvdb_size));
             o.nvdb = nb->as<unsigned char>();
-            // flatten the tree over the index bounding box (+1 block of margin for the trilinear +1 taps); blocks further out hold
-            // the background value, which the margin itself must confirm
+            // flatten the tree into the block table.  Extent = every 8^3 block that is a leaf or lies in a non-background tile (the
+            // node tables are scanned, so nothing the walk could return differently is left outside), united with the record's
+            // index bbox, +1 block of margin for the trilinear +1 taps.  Blocks further out hold the root background.
+            float bg_probe;
+            {
+                const unsigned char* B = m.nvdb_bytes;
+                bg_probe = hknv::f32(B, m.root_offset_1based + 28);
+                int lo[3] = {m.index_bbox_min[0] >> 3, m.index_bbox_min[1] >> 3, m.index_bbox_min[2] >> 3};
+                int hi[3] = {m.index_bbox_max[0] >> 3, m.index_bbox_max[1] >> 3, m.index_bbox_max[2] >> 3};
+                auto include = [&](long long x0, long long y0, long long z0, long long nblk) {  // voxel origin, extent in blocks
+                    long long o[3] = {x0 >> 3, y0 >> 3, z0 >> 3};
+                    for (int k = 0; k < 3; ++k) {
+                        if (o[k] < lo[k]) lo[k] = (int)o[k];
+                        if (o[k] + nblk - 1 > hi[k]) hi[k] = (int)(o[k] + nblk - 1);
+                    }
+                };
+                auto sext21 = [](unsigned long long v) { return (long long)((v & 0x100000ull) ? (v | ~0x1fffffull) : v); };
+                bool unbounded = false;
+                for (int i = 0; i < m.root_table_size; ++i) {
+                    long long tile = m.root_offset_1based + 64 + (long long)i * 32;
+                    unsigned long long key = (unsigned long long)hknv::i64(B, tile);
+                    long long tz = sext21(key & 0x1fffffull) << 12, ty = sext21((key >> 21) & 0x1fffffull) << 12, tx = sext21((key >> 42) & 0x1fffffull) << 12;
+                    long long child = hknv::i64(B, tile + 8);
+                    if (child == 0) {
+                        if (hknv::f32(B, tile + 20) != bg_probe) unbounded = true;  // a 4096^3 constant tile: not tabulated
+                        continue;
+                    }
+                    long long upper = m.root_offset_1based + child;
+                    for (int nu = 0; nu < 32768; ++nu) {
+                        long long ux = tx + (((nu >> 10) & 31) << 7), uy = ty + (((nu >> 5) & 31) << 7), uz = tz + ((nu & 31) << 7);
+                        if (!hknv::mask(B, upper + 4128, nu)) {
+                            if (hknv::f32(B, upper + 8256 + (long long)nu * 8) != bg_probe) include(ux, uy, uz, 16);
+                            continue;
+                        }
+                        long long lower = upper + hknv::i64(B, upper + 8256 + (long long)nu * 8);
+                        for (int nl = 0; nl < 4096; ++nl) {
+                            long long lx = ux + (((nl >> 8) & 15) << 3), ly = uy + (((nl >> 4) & 15) << 3), lz = uz + ((nl & 15) << 3);
+                            if (hknv::mask(B, lower + 544, nl) || hknv::f32(B, lower + 1088 + (long long)nl * 8) != bg_probe) include(lx, ly, lz, 1);
+                        }
+                    }
+                }
+                if (unbounded) {
+                    delete s;
+                    return fail(HK_ERR_UNSUPPORTED, "NanoVDB grid with a non-background root tile (4096^3 constant region) is not supported");
+                }
+                for (int k = 0; k < 3; ++k) {
+                    o.nvb_min[k] = lo[k] - 1;
+                    o.nvb_dim[k] = hi[k] - lo[k] + 3;
+                }
+            }
             long long dim[3], total = 1;
             for (int k = 0; k < 3; ++k) {
-                o.nvb_min[k] = (m.index_bbox_min[k] >> 3) - 1;
-                dim[k] = (long long)(m.index_bbox_max[k] >> 3) + 1 - o.nvb_min[k] + 1;
-                if (dim[k] < 3) dim[k] = 3;
+                dim[k] = o.nvb_dim[k] < 3 ? 3 : o.nvb_dim[k];
                 total *= dim[k];
             }
             if (total > (1ll << 27) || m.nvdb_size >= (1ll << 32)) {
                 delete s;
                 return fail(HK_ERR_UNSUPPORTED, "NanoVDB grid too large for the device block table (index bbox > 2^27 blocks or buffer >= 4 GiB)");
             }
-            float bg_probe;
-            (void)hknv::find_block(m.nvdb_bytes, m.root_offset_1based, m.root_table_size, (o.nvb_min[0] - 4096) * 8, (o.nvb_min[1] - 4096) * 8, (o.nvb_min[2] - 4096) * 8, bg_probe);
             o.nv_background = bg_probe;
             std::vector<uint2> table((size_t)total);
             bool margin_ok = true;
@@ -609,11 +653,11 @@ extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene**
                         std::memcpy(&bits, &value, 4);
                         table[(size_t)bz + (size_t)dim[2] * ((size_t)by + (size_t)dim[1] * (size_t)bx)] = make_uint2((uint32_t)leaf, bits);
                         const bool on_margin = bx == 0 || by == 0 || bz == 0 || bx == dim[0] - 1 || by == dim[1] - 1 || bz == dim[2] - 1;
-                        if (on_margin && (leaf != 0 || value != bg_probe)) margin_ok = false;
+                        if (on_margin && (leaf != 0 || value != bg_probe)) margin_ok = false;  // cannot happen after the scan above
                     }
             if (!margin_ok) {
                 delete s;
-                return fail(HK_ERR_INVALID, "NanoVDB index_bbox does not bound the active voxels (non-background data outside it)");
+                return fail(HK_ERR_INVALID, "NanoVDB block table: non-background data on the margin (corrupt tree?)");
             }
             DevBuf* tb = new DevBuf();
             s->media_data.push_back(tb);

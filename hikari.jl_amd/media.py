@@ -299,52 +299,131 @@ def build_nanovdb_from_dense(data, origin, extent, background=0.0):
 
 
 def build_nanovdb_majorant_grid(meta, bounds, res=(64, 64, 64)):
-    """nanovdb.jl:1174-1235: max over index-space voxels [floor(min-1), ceil(max+1)] clipped to the index bbox.
-    Voxel values come from the dense array the tree was built from (identical to nanovdb_get_value_raw for
-    every index inside the bbox; outside leaves the tree returns the background)."""
+    """nanovdb.jl:1174-1235: per majorant cell, the two cell corners go through world_to_index_f_raw (full 3x3 inv_mat), the
+    integer range is [floor(min - 1), ceil(max + 1)] clipped to [index_min, index_max], and the cell value is the max voxel
+    value in that range.  Voxel values come from `meta["dense"]` (index `dense_origin` at [0,0,0]): the array the tree was
+    built from, or the tree decoded back to dense (identical to nanovdb_get_value_raw inside it; background outside)."""
     pad = meta["dense"]
+    org = meta.get("dense_origin", (0, 0, 0))
     bg = f32(meta["background"])
-    inv, vec = meta["inv_mat"], meta["vec"]
+    inv = [f32(v) for v in meta["inv_mat"]]
+    vec = [f32(v) for v in meta["vec"]]
     bmin, bmax = np.array(bounds[0], dtype=f32), np.array(bounds[1], dtype=f32)
     diag = (bmax - bmin).astype(f32)
     rx, ry, rz = res
     out = np.zeros(rx * ry * rz, dtype=f32)
     imin, imax = meta["index_min"], meta["index_max"]
-
-    def rng(axis, i, r):
-        p0 = f32(bmin[axis] + diag[axis] * f32(i) / f32(r))
-        p1 = f32(bmin[axis] + diag[axis] * f32(i + 1) / f32(r))
-        a = f32(f32(inv[4 * axis]) * f32(p0 - f32(vec[axis])))
-        b = f32(f32(inv[4 * axis]) * f32(p1 - f32(vec[axis])))
-        lo = max(int(np.floor(min(a, b) - f32(1))), imin[axis])
-        hi = min(int(np.ceil(max(a, b) + f32(1))), imax[axis])
-        return lo, hi
-
-    xr = [rng(0, i, rx) for i in range(rx)]
-    yr = [rng(1, i, ry) for i in range(ry)]
-    zr = [rng(2, i, rz) for i in range(rz)]
     sx, sy, sz = pad.shape
 
-    def clip(lo, hi, n):
-        return max(lo, 0), min(hi, n - 1)
+    def edge(axis, r):   # cell boundaries p_min[i], p_max[i] along one axis, Float32 like the reference
+        i = np.arange(r, dtype=f32)
+        return (bmin[axis] + diag[axis] * i / f32(r)).astype(f32), (bmin[axis] + diag[axis] * (i + f32(1)) / f32(r)).astype(f32)
+
+    ex, ey, ez = edge(0, rx), edge(1, ry), edge(2, rz)
+
+    def to_index(px, py, pz):
+        qx, qy, qz = px - vec[0], py - vec[1], pz - vec[2]
+        return (inv[0] * qx + inv[1] * qy + inv[2] * qz, inv[3] * qx + inv[4] * qy + inv[5] * qz, inv[6] * qx + inv[7] * qy + inv[8] * qz)
 
     for iz in range(rz):
-        z0, z1 = zr[iz]
         for iy in range(ry):
-            y0, y1 = yr[iy]
+            a = to_index(ex[0], ey[0][iy], ez[0][iz])          # vectors over ix
+            b = to_index(ex[1], ey[1][iy], ez[1][iz])
+            lo = [np.maximum(np.floor(np.minimum(a[k], b[k]) - f32(1)).astype(np.int64), imin[k]) for k in range(3)]
+            hi = [np.minimum(np.ceil(np.maximum(a[k], b[k]) + f32(1)).astype(np.int64), imax[k]) for k in range(3)]
             for ix in range(rx):
-                x0, x1 = xr[ix]
+                x0, x1, y0, y1, z0, z1 = int(lo[0][ix]), int(hi[0][ix]), int(lo[1][ix]), int(hi[1][ix]), int(lo[2][ix]), int(hi[2][ix])
                 m = f32(0)
                 if x0 <= x1 and y0 <= y1 and z0 <= z1:
-                    cx0, cx1 = clip(x0, x1, sx)
-                    cy0, cy1 = clip(y0, y1, sy)
-                    cz0, cz1 = clip(z0, z1, sz)
+                    cx0, cx1 = max(x0 - org[0], 0), min(x1 - org[0], sx - 1)
+                    cy0, cy1 = max(y0 - org[1], 0), min(y1 - org[1], sy - 1)
+                    cz0, cz1 = max(z0 - org[2], 0), min(z1 - org[2], sz - 1)
                     if cx0 <= cx1 and cy0 <= cy1 and cz0 <= cz1:
                         m = max(m, f32(pad[cx0:cx1 + 1, cy0:cy1 + 1, cz0:cz1 + 1].max()))
-                    if (x0 < 0 or y0 < 0 or z0 < 0 or x1 >= sx or y1 >= sy or z1 >= sz):
+                    if x0 - org[0] < 0 or y0 - org[1] < 0 or z0 - org[2] < 0 or x1 - org[0] >= sx or y1 - org[1] >= sy or z1 - org[2] >= sz:
                         m = max(m, bg)
                 out[ix + rx * (iy + ry * iz)] = m
     return out
+
+
+# ---- NanoVDB file IO (nanovdb.jl:868-946 save, 1037-1166 load) ----------------------------------------------------------
+GRIDDATA_SIZE, TREEDATA_SIZE = 672, 64
+MAP_OFFSET0, WORLDBBOX_OFFSET0 = 296, 560     # 0-based byte offsets of GridData.mMap / mWorldBBox
+
+
+def save_nanovdb(filepath, buffer, meta):
+    """save_nanovdb(filepath, buffer, metadata) (nanovdb.jl:868-946): 736-byte GridData + TreeData header (map, world bbox,
+    node offsets/counts), the node data, zlib level 6."""
+    import zlib
+    header = GRIDDATA_SIZE + TREEDATA_SIZE
+    full = np.zeros(header + buffer.size, dtype=np.uint8)
+    full[header:] = buffer
+    inv = np.array(meta["inv_mat"], dtype=f32)
+    m = inv.astype(np.float64)
+    cof = np.array([m[4] * m[8] - m[5] * m[7], m[2] * m[7] - m[1] * m[8], m[1] * m[5] - m[2] * m[4],
+                    m[5] * m[6] - m[3] * m[8], m[0] * m[8] - m[2] * m[6], m[2] * m[3] - m[0] * m[5],
+                    m[3] * m[7] - m[4] * m[6], m[1] * m[6] - m[0] * m[7], m[0] * m[4] - m[1] * m[3]])
+    det = m[0] * cof[0] + m[1] * cof[3] + m[2] * cof[6]
+    full[MAP_OFFSET0:MAP_OFFSET0 + 36] = (cof / det).astype(f32).view(np.uint8)
+    full[MAP_OFFSET0 + 36:MAP_OFFSET0 + 72] = inv.view(np.uint8)
+    full[MAP_OFFSET0 + 72:MAP_OFFSET0 + 84] = np.array(meta["vec"], dtype=f32).view(np.uint8)
+    full[WORLDBBOX_OFFSET0:WORLDBBOX_OFFSET0 + 48] = np.array(list(meta["world_min"]) + list(meta["world_max"]), dtype=np.float64).view(np.uint8)
+    offs = np.array([meta["leaf_offset"] + 63, meta["lower_offset"] + 63, meta["upper_offset"] + 63, meta["root_offset"] + 63], dtype=np.uint64)
+    full[GRIDDATA_SIZE:GRIDDATA_SIZE + 32] = offs.view(np.uint8)
+    full[GRIDDATA_SIZE + 32:GRIDDATA_SIZE + 44] = np.array([meta["leaf_count"], meta["lower_count"], meta["upper_count"]], dtype=np.uint32).view(np.uint8)
+    with open(filepath, "wb") as f:
+        f.write(zlib.compress(full.tobytes(), 6))
+
+
+def extract_nanovdb_metadata(buffer):
+    """extract_nanovdb_metadata (nanovdb.jl:1109-1166) of a decompressed FULL buffer (GridData + TreeData + nodes)."""
+    wb = buffer[WORLDBBOX_OFFSET0:WORLDBBOX_OFFSET0 + 48].view(np.float64)
+    inv = buffer[MAP_OFFSET0 + 36:MAP_OFFSET0 + 72].view(f32)
+    vec = buffer[MAP_OFFSET0 + 72:MAP_OFFSET0 + 84].view(f32)
+    offs = buffer[GRIDDATA_SIZE:GRIDDATA_SIZE + 32].view(np.uint64)
+    counts = buffer[GRIDDATA_SIZE + 32:GRIDDATA_SIZE + 44].view(np.uint32)
+    start = GRIDDATA_SIZE + 1
+    leaf_off, lower_off, upper_off, root_off = (int(start + int(o)) for o in offs)
+    root_table_size = int(buffer[root_off - 1 + 24:root_off - 1 + 28].view(np.uint32)[0])
+    background = float(buffer[root_off - 1 + 28:root_off - 1 + 32].view(f32)[0])
+    n_leaf = int(counts[0])
+    co = np.stack([buffer[leaf_off - 1 + i * LEAFDATA_SIZE:leaf_off - 1 + i * LEAFDATA_SIZE + 12].view(np.int32) for i in range(n_leaf)]) if n_leaf else np.zeros((0, 3), np.int32)
+    idx_min = tuple(int(v) for v in co.min(axis=0)) if n_leaf else (0, 0, 0)
+    idx_max = tuple(int(v) + LEAF_DIM for v in co.max(axis=0)) if n_leaf else (0, 0, 0)
+    return dict(world_min=tuple(float(f32(v)) for v in wb[:3]), world_max=tuple(float(f32(v)) for v in wb[3:]), inv_mat=tuple(float(v) for v in inv),
+                vec=tuple(float(v) for v in vec), root_offset=root_off, upper_offset=upper_off, lower_offset=lower_off, leaf_offset=leaf_off,
+                leaf_count=n_leaf, lower_count=int(counts[1]), upper_count=int(counts[2]), root_table_size=root_table_size,
+                index_min=idx_min, index_max=idx_max, background=background)
+
+
+def parse_nanovdb_buffer(filepath):
+    """parse_nanovdb_buffer (nanovdb.jl:1085-1107): find the zlib stream in the first 500 bytes, inflate, read the metadata."""
+    import zlib
+    raw = open(filepath, "rb").read()
+    start = -1
+    for i in range(min(500, len(raw) - 1)):
+        if raw[i] == 0x78 and raw[i + 1] in (0x01, 0x5e, 0x9c, 0xda):
+            start = i
+            break
+    if start < 0:
+        raise ValueError("Could not find zlib header in NanoVDB file")
+    buffer = np.frombuffer(zlib.decompress(raw[start:]), dtype=np.uint8).copy()
+    return buffer, extract_nanovdb_metadata(buffer)
+
+
+def nanovdb_to_dense(buffer, meta):
+    """Decode the leaves of a tree back into a dense array over [index_min, index_max) (background elsewhere); the majorant
+    builder reads voxels from it.  Non-background tiles are not expected in density grids and are rejected."""
+    lo, hi = meta["index_min"], meta["index_max"]
+    shape = tuple(max(hi[k] - lo[k], 1) for k in range(3))
+    dense = np.full(shape, meta["background"], dtype=f32)
+    for i in range(meta["leaf_count"]):
+        off = meta["leaf_offset"] - 1 + i * LEAFDATA_SIZE
+        c = buffer[off:off + 12].view(np.int32)
+        vals = buffer[off + LEAF_VALUES:off + LEAF_VALUES + 2048].view(f32).reshape(8, 8, 8)      # [x][y][z]
+        x, y, z = int(c[0]) - lo[0], int(c[1]) - lo[1], int(c[2]) - lo[2]
+        dense[x:x + 8, y:y + 8, z:z + 8] = vals
+    return dense
 
 
 class NanoVDBMedium(Medium):
@@ -360,6 +439,34 @@ class NanoVDBMedium(Medium):
         self.majorant = build_nanovdb_majorant_grid(self.meta, self.bounds, self.majorant_res)
         self.max_density = float(self.majorant.max())
         self.sigma_a, self.sigma_s, self.g = sigma_a, sigma_s, g
+
+    @classmethod
+    def from_file(cls, filepath, sigma_a=RGBSpectrum(0.5), sigma_s=RGBSpectrum(10.0), g=0.0, transform=None, majorant_res=(64, 64, 64)):
+        """NanoVDBMedium(filepath; σ_a=0.5, σ_s=10, g=0, transform=I (3x3 medium-to-world), majorant_res=64^3)
+        (nanovdb.jl:1320-1422): inv_mat := nanovdb_inv_mat * inv(transform), world bounds = bbox of the transformed corners."""
+        self = cls.__new__(cls)
+        buffer, meta = parse_nanovdb_buffer(filepath)
+        T = np.eye(3, dtype=f32) if transform is None else np.asarray(transform, dtype=f32).reshape(3, 3)
+        inv_mat = (np.array(meta["inv_mat"], dtype=f32).reshape(3, 3) @ np.linalg.inv(T.astype(np.float64)).astype(f32)).astype(f32)
+        wmin, wmax = meta["world_min"], meta["world_max"]
+        corners = np.array([[(wmin, wmax)[i][0], (wmin, wmax)[j][1], (wmin, wmax)[k][2]] for i in (0, 1) for j in (0, 1) for k in (0, 1)], dtype=f32)
+        cw = (T @ corners.T).T.astype(f32)
+        self.bounds = (tuple(float(v) for v in cw.min(axis=0)), tuple(float(v) for v in cw.max(axis=0)))
+        meta = dict(meta, inv_mat=tuple(float(v) for v in inv_mat.reshape(-1)))
+        meta["dense"] = nanovdb_to_dense(buffer, meta)
+        meta["dense_origin"] = meta["index_min"]
+        self.buffer, self.meta = buffer, meta
+        self.majorant_res = tuple(int(v) for v in majorant_res)
+        self.majorant = build_nanovdb_majorant_grid(meta, self.bounds, self.majorant_res)
+        self.max_density = float(self.majorant.max())
+        self.sigma_a, self.sigma_s, self.g = sigma_a, sigma_s, g
+        return self
+
+    def save(self, filepath):
+        """save_nanovdb(filepath, buffer, metadata) of this medium's tree (node-only buffers get the 736-byte header)"""
+        if self.meta["root_offset"] != 1:
+            raise ValueError("this medium already holds a full file buffer; write self.buffer with zlib instead")
+        save_nanovdb(filepath, self.buffer, self.meta)
 
     def fill_record(self, rec, keep):
         _base_record(rec, self.kind, self.sigma_a, self.sigma_s, RGBSpectrum(0.0), self.g)

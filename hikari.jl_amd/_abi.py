@@ -16,6 +16,7 @@ HK_MATF_REMAP_ROUGHNESS, HK_MATF_USE_ETA_K = 1, 2
 (HK_LIGHT_POINT, HK_LIGHT_SPOT, HK_LIGHT_DIRECTIONAL, HK_LIGHT_SUN, HK_LIGHT_AMBIENT, HK_LIGHT_ENVIRONMENT,
  HK_LIGHT_DIFFUSE_AREA) = range(7)
 HK_SPEC_RGB, HK_SPEC_ILLUMINANT = 0, 1
+HK_TONEMAP_NONE, HK_TONEMAP_REINHARD, HK_TONEMAP_REINHARD_EXT, HK_TONEMAP_ACES, HK_TONEMAP_UNCHARTED2, HK_TONEMAP_FILMIC = range(6)
 HK_MEDIUM_HOMOGENEOUS, HK_MEDIUM_GRID, HK_MEDIUM_RGB_GRID, HK_MEDIUM_NANOVDB = range(4)
 HK_FILTER_BOX, HK_FILTER_TRIANGLE, HK_FILTER_GAUSSIAN, HK_FILTER_MITCHELL, HK_FILTER_LANCZOS = 1, 2, 3, 4, 5
 HK_COHERENCE_NONE, HK_COHERENCE_SORTED, HK_COHERENCE_PER_TYPE = 0, 1, 2
@@ -98,6 +99,11 @@ class hk_integrator_params(C.Structure):
                 ("sampler_seed", c_u), ("samples_per_pass", c_i)]
 
 
+class hk_postprocess_params(C.Structure):
+    _fields_ = [("exposure", c_f), ("tonemap", c_i), ("inv_gamma", c_f), ("apply_gamma", c_i), ("white_point", c_f),
+                ("imaging_ratio", c_f), ("apply_wb", c_i), ("wb", c_f * 9), ("mask_escaped", c_i), ("bg", c_f * 3)]
+
+
 class hk_camera(C.Structure):
     _fields_ = [("raster_to_camera", c_f * 16), ("camera_to_world", c_f * 16), ("lens_radius", c_f),
                 ("focal_distance", c_f), ("shutter_open", c_f), ("shutter_close", c_f), ("dx_camera", c_f * 3),
@@ -120,5 +126,5 @@ EXPORTED_SYMBOLS = [
     "hk_integrator_create", "hk_integrator_destroy", "hk_film_create", "hk_film_destroy", "hk_film_clear", "hk_render",
     "hk_film_read_rgb", "hk_film_read_accum", "hk_film_accum_device_ptr", "hk_sync", "hk_stats_get", "hk_stats_reset",
     "hk_stats_enable_counters", "hk_trace_closest", "hk_test_sobol", "hk_test_camera", "hk_test_uplift",
-    "hk_test_light_bvh", "hk_test_bsdf", "hk_test_light", "hk_scene_bvh_info", "hk_scene_light_bvh_copy",
+    "hk_test_light_bvh", "hk_test_bsdf", "hk_film_postprocess", "hk_postprocess", "hk_test_light", "hk_scene_bvh_info", "hk_scene_light_bvh_copy",
 ]

@@ -32,6 +32,7 @@ void launch_test_sobol(hipStream_t, const DTables&, const DSobol&, int, const in
 void launch_test_camera(hipStream_t, const DTables&, const DFilter&, const DCamera&, const DSobol&, int, int, const int*, const int*, const int*, float*);
 void launch_test_uplift(hipStream_t, const DTables&, int, int, const float*, const float*, float*);
 void launch_test_light_bvh(hipStream_t, const DScene&, int, const float*, const float*, const float*, int*, float*, const int*, float*);
+void launch_postprocess(hipStream_t, const hk_postprocess_params&, const float*, const float*, float*, int, int);
 void launch_sobol_table(hipStream_t, const DSobol&, const DFrame&, uint32_t*, int);
 void launch_test_light(hipStream_t, const DScene&, const DTables&, int, int, int, const float*, const float*, const float*, float*);
 void launch_test_bsdf(hipStream_t, const DScene&, const DTables&, int, int, int, int, const float*, const float*, const float*, const float*, const float*, const float*, float*);
@@ -902,6 +903,38 @@ extern "C" int32_t hk_film_read_rgb(hk_ctx* c, hk_film* f, float* out) {
     HIP_TRY(hipMemcpyAsync(out, f->readback.p, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return HK_OK;
+}
+
+namespace {
+int run_postprocess(hk_ctx* c, const hk_postprocess_params* P, int w, int h, const float* src_dev, const float* depth_host, float* dst_host, DevBuf& out) {
+    const size_t bytes = (size_t)3 * w * h * 4;
+    HIP_TRY(out.alloc(bytes));
+    DevBuf dd;
+    if (depth_host && P->mask_escaped) HIP_TRY(dd.upload(depth_host, (size_t)w * h * 4));
+    hk::launch_postprocess(c->stream, *P, src_dev, dd.as<float>(), out.as<float>(), h, w);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(dst_host, out.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return HK_OK;
+}
+}  // namespace
+extern "C" int32_t hk_film_postprocess(hk_ctx* c, hk_film* f, const hk_postprocess_params* P, const float* depth, float* dst) {
+    if (!c || !f || !P || !dst) return fail(HK_ERR_INVALID, "null argument");
+    if (P->tonemap < HK_TONEMAP_NONE || P->tonemap > HK_TONEMAP_FILMIC) return fail(HK_ERR_INVALID, "unknown tonemap");
+    HIP_TRY(hipSetDevice(c->device));
+    size_t bytes = (size_t)3 * f->width * f->height * 4;
+    if (f->readback.bytes != bytes) HIP_TRY(f->readback.alloc(bytes));
+    hk::launch_finalize(c->stream, f->accum, f->f64, f->readback.as<float>(), f->width, f->height);
+    DevBuf out;
+    return run_postprocess(c, P, f->width, f->height, f->readback.as<float>(), depth, dst, out);
+}
+extern "C" int32_t hk_postprocess(hk_ctx* c, const hk_postprocess_params* P, int32_t w, int32_t h, const float* src, const float* depth, float* dst) {
+    if (!c || !P || !src || !dst || w <= 0 || h <= 0) return fail(HK_ERR_INVALID, "bad argument");
+    if (P->tonemap < HK_TONEMAP_NONE || P->tonemap > HK_TONEMAP_FILMIC) return fail(HK_ERR_INVALID, "unknown tonemap");
+    HIP_TRY(hipSetDevice(c->device));
+    DevBuf in, out;
+    HIP_TRY(in.upload(src, (size_t)3 * w * h * 4));
+    return run_postprocess(c, P, w, h, in.as<float>(), depth, dst, out);
 }
 
 // ---- path state -----------------------------------------------------------------------------------------

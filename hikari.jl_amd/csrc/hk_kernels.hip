@@ -1180,6 +1180,72 @@ __global__ void k_finalize(const ACC* __restrict__ accum, float* __restrict__ ou
 }
 
 // ---------------------------------------------------------------------------------------------------
+// postprocess_kernel! (src/postprocess.jl:185-250): exposure, white balance, imaging ratio, tone curve, gamma, escaped-ray mask.
+// src/dst: Julia [h,w] RGB layout (3 floats per pixel, linear index i = row + h*col); depth likewise.
+// ---------------------------------------------------------------------------------------------------
+HKD float pp_unch2(float x) {
+    const float A = 0.15f, B = 0.50f, C = 0.10f, D = 0.20f, E = 0.02f, F = 0.30f;
+    return ((x * (A * x + C * B) + D * E) / (x * (A * x + B) + D * F)) - E / F;
+}
+HKD float pp_filmic(float x) {
+    x = maxf(0.0f, x - 0.004f);
+    return (x * (6.2f * x + 0.5f)) / (x * (6.2f * x + 1.7f) + 0.06f);
+}
+__global__ void __launch_bounds__(256) k_postprocess(hk_postprocess_params P, const float* __restrict__ src, const float* __restrict__ depth, float* __restrict__ dst, int h, int w) {
+    const long n = (long)h * w;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float r = src[3 * i] * P.exposure, g = src[3 * i + 1] * P.exposure, b = src[3 * i + 2] * P.exposure;
+        if (P.apply_wb) {
+            float ro = P.wb[0] * r + P.wb[1] * g + P.wb[2] * b, go = P.wb[3] * r + P.wb[4] * g + P.wb[5] * b, bo = P.wb[6] * r + P.wb[7] * g + P.wb[8] * b;
+            r = maxf(0.0f, ro), g = maxf(0.0f, go), b = maxf(0.0f, bo);
+        }
+        r = r * P.imaging_ratio, g = g * P.imaging_ratio, b = b * P.imaging_ratio;
+        switch (P.tonemap) {
+            case HK_TONEMAP_REINHARD: {
+                float lum = 0.2126f * r + 0.7152f * g + 0.0722f * b;
+                float sc = lum > 0.0f ? 1.0f / (1.0f + lum) : 1.0f;
+                r = clampf(r * sc, 0.0f, 1.0f), g = clampf(g * sc, 0.0f, 1.0f), b = clampf(b * sc, 0.0f, 1.0f);
+            } break;
+            case HK_TONEMAP_REINHARD_EXT: {
+                float lum = 0.2126f * r + 0.7152f * g + 0.0722f * b;
+                float lw2 = P.white_point * P.white_point;
+                float sc = lum > 0.0f ? (1.0f + lum / lw2) / (1.0f + lum) : 1.0f;
+                r = clampf(r * sc, 0.0f, 1.0f), g = clampf(g * sc, 0.0f, 1.0f), b = clampf(b * sc, 0.0f, 1.0f);
+            } break;
+            case HK_TONEMAP_ACES: {
+                const float a = 2.51f, bc = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f;
+                r = clampf((r * (a * r + bc)) / (r * (c * r + d) + e), 0.0f, 1.0f);
+                g = clampf((g * (a * g + bc)) / (g * (c * g + d) + e), 0.0f, 1.0f);
+                b = clampf((b * (a * b + bc)) / (b * (c * b + d) + e), 0.0f, 1.0f);
+            } break;
+            case HK_TONEMAP_UNCHARTED2: {
+                float ws = 1.0f / pp_unch2(11.2f);
+                r = clampf(pp_unch2(r * 2.0f) * ws, 0.0f, 1.0f), g = clampf(pp_unch2(g * 2.0f) * ws, 0.0f, 1.0f), b = clampf(pp_unch2(b * 2.0f) * ws, 0.0f, 1.0f);
+            } break;
+            case HK_TONEMAP_FILMIC: r = pp_filmic(r), g = pp_filmic(g), b = pp_filmic(b); break;
+            default: r = clampf(r, 0.0f, 1.0f), g = clampf(g, 0.0f, 1.0f), b = clampf(b, 0.0f, 1.0f); break;
+        }
+        if (P.apply_gamma) r = powf(r, P.inv_gamma), g = powf(g, P.inv_gamma), b = powf(b, P.inv_gamma);
+        if (P.mask_escaped && depth) {
+            int row = (int)(i % h) + 1, col = (int)(i / h) + 1;
+            int d_row = h - row + 1;  // Y flip
+            int escaped = 0, total = 0;
+            for (int dr = -1; dr <= 1; ++dr)
+                for (int dc = -1; dc <= 1; ++dc) {
+                    int nr = d_row + dr, nc = col + dc;
+                    if (nr >= 1 && nr <= h && nc >= 1 && nc <= w) {
+                        escaped += isinf(depth[(long)(nc - 1) * h + nr - 1]) ? 1 : 0;
+                        total += 1;
+                    }
+                }
+            float alpha = (float)escaped / (float)total;
+            r = r * (1.0f - alpha) + P.bg[0] * alpha, g = g * (1.0f - alpha) + P.bg[1] * alpha, b = b * (1.0f - alpha) + P.bg[2] * alpha;
+        }
+        dst[3 * i] = r, dst[3 * i + 1] = g, dst[3 * i + 2] = b;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // sub-kernel entry points used by the parity tests
 // ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_test_trace(DScene sc, int n, const float* o3, const float* d3, const float* tmax, float* out_t, int* out_prim,
@@ -1477,6 +1543,9 @@ void launch_test_light(hipStream_t s, const DScene& sc, const DTables& T, int mo
 }
 void launch_sobol_table(hipStream_t s, const DSobol& sob, const DFrame& fr, uint32_t* table, int rows) {
     hipLaunchKernelGGL(k_sobol_table, dim3(grid_for((long)rows * fr.n_pixels_padded > 0x3fffffff ? 0x3fffffff : rows * fr.n_pixels_padded, 256, 8192)), dim3(256), 0, s, sob, fr, table, rows);
+}
+void launch_postprocess(hipStream_t s, const hk_postprocess_params& P, const float* src, const float* depth, float* dst, int h, int w) {
+    hipLaunchKernelGGL(k_postprocess, dim3(grid_for(h * w, 256, 8192)), dim3(256), 0, s, P, src, depth, dst, h, w);
 }
 
 }  // namespace hk

@@ -8,6 +8,8 @@ class Film:
         self.resolution = (int(resolution[0]), int(resolution[1]))  # (width, height) = Point2f(w, h)
         w, h = self.resolution
         self.framebuffer = np.zeros((h, w, 3), dtype=np.float32)
+        self.postprocess_buffer = np.zeros((h, w, 3), dtype=np.float32)   # film.postprocess
+        self.depth = None                                                 # film.depth [h, w] when aux buffers were filled
         self.iteration_index = 0
 
     @property
@@ -21,3 +23,24 @@ class Film:
     def clear(self):
         self.framebuffer[...] = 0
         self.iteration_index = 0
+
+    def postprocess(self, exposure=1.0, tonemap="aces", gamma=2.2, white_point=4.0, sensor=None, background=None, device=0):
+        """postprocess!(film; exposure, tonemap, gamma, white_point, sensor, background) (src/postprocess.jl:293-357): reads
+        film.framebuffer, writes and returns film.postprocess; non-destructive, runs on the device through the C-ABI."""
+        import ctypes as C
+        from . import _abi as A
+        from . import _lib
+        from .postprocess import make_params
+        from .volpath import Context
+        p = make_params(exposure, tonemap, gamma, white_point, sensor, background)
+        ctx = Context.get(device)
+        h, w = self.framebuffer.shape[:2]
+        src = np.ascontiguousarray(np.transpose(self.framebuffer, (1, 0, 2)), np.float32)
+        dst = np.empty_like(src)
+        dp = None
+        if background is not None and self.depth is not None:
+            dp = np.ascontiguousarray(np.transpose(self.depth, (1, 0)), np.float32)
+        _lib.check(_lib.lib().hk_postprocess(ctx.h, C.byref(p), w, h, src.ctypes.data_as(A.PF), dp.ctypes.data_as(A.PF) if dp is not None else None,
+                                             dst.ctypes.data_as(A.PF)), "hk_postprocess")
+        self.postprocess_buffer = np.transpose(dst, (1, 0, 2)).copy()
+        return self.postprocess_buffer

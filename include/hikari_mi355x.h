@@ -357,6 +357,32 @@ int32_t hk_test_uplift(hk_ctx* ctx, int32_t mode, int32_t n, const float* rgb, c
 /* light-BVH: sample (light_idx_1based, pmf) and pmf of a given light for n shading points */
 int32_t hk_test_light_bvh(hk_ctx* ctx, hk_scene* scene, int32_t n, const float* p3, const float* n3, const float* u,
                           int32_t* out_light, float* out_pmf, const int32_t* query_light, float* out_query_pmf);
+/* ---------------------------------------------------------------------------------------------
+ * postprocess!(film; exposure, tonemap, gamma, white_point, sensor, background)  (src/postprocess.jl:293-357).
+ * Non-destructive: reads the film's current rgb/weight, writes tonemapped RGB to `dst` (host, Julia [h,w] RGB{Float32}
+ * layout like hk_film_read_rgb).  Parameters are the kernel arguments of postprocess_kernel! (:185-250): the host side
+ * resolves symbols / sensor / white-balance matrix (compute_white_balance_matrix, spectral/color.jl:522-547).
+ * depth: optional host float[h*w] (film.depth, Julia [h,w]); with mask_escaped != 0 pixels are blended towards `bg` by the
+ * fraction of +Inf depths in their 3x3 neighbourhood.
+ * ------------------------------------------------------------------------------------------- */
+enum { HK_TONEMAP_NONE = 0, HK_TONEMAP_REINHARD = 1, HK_TONEMAP_REINHARD_EXT = 2, HK_TONEMAP_ACES = 3, HK_TONEMAP_UNCHARTED2 = 4, HK_TONEMAP_FILMIC = 5 };
+typedef struct hk_postprocess_params {
+    float exposure;
+    int32_t tonemap;
+    float inv_gamma;
+    int32_t apply_gamma;
+    float white_point;
+    float imaging_ratio; /* sensor.exposure_time * sensor.iso / 100 */
+    int32_t apply_wb;
+    float wb[9];         /* row-major 3x3 Bradford matrix */
+    int32_t mask_escaped;
+    float bg[3];
+} hk_postprocess_params;
+int32_t hk_film_postprocess(hk_ctx* ctx, hk_film* film, const hk_postprocess_params* params, const float* depth, float* dst_rgb);
+/* the same kernel on a caller-supplied framebuffer (host, Julia [h,w] RGB layout) */
+int32_t hk_postprocess(hk_ctx* ctx, const hk_postprocess_params* params, int32_t width, int32_t height, const float* src_rgb,
+                       const float* depth, float* dst_rgb);
+
 /* point-wise BSDFs of a scene's material `mat_idx` (material-dispatch.jl:23-53; spectral-eval.jl) at uv=(0,0):
    mode 0 = sample_bsdf_spectral(wo, ns, lambda, u, uc, regularize) -> out[10n] = wi3, f4, pdf, is_specular, eta_scale
    mode 1 = evaluate_bsdf_spectral(wo, wi, ns, lambda)              -> out[10n] = f4, pdf, 0...

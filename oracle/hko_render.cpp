@@ -1360,6 +1360,62 @@ int32_t hko_light(hko_scene* s, int32_t mode, int32_t light_idx_1based, int32_t 
     return 0;
 }
 
+// postprocess_kernel! (src/postprocess.jl:185-250) on a Julia-layout [h,w] RGB framebuffer
+static float pp_unch2(float x) {
+    const float A = 0.15f, B = 0.50f, C = 0.10f, D = 0.20f, E = 0.02f, F = 0.30f;
+    return ((x * (A * x + C * B) + D * E) / (x * (A * x + B) + D * F)) - E / F;
+}
+static float pp_filmic(float x) {
+    x = maxf(0.0f, x - 0.004f);
+    return (x * (6.2f * x + 0.5f)) / (x * (6.2f * x + 1.7f) + 0.06f);
+}
+int32_t hko_postprocess(const hk_postprocess_params* Pp, int32_t w, int32_t h, const float* src, const float* depth, float* dst) {
+    const hk_postprocess_params& P = *Pp;
+    const long n = (long)h * w;
+    for (long i = 0; i < n; ++i) {
+        float r = src[3 * i] * P.exposure, g = src[3 * i + 1] * P.exposure, b = src[3 * i + 2] * P.exposure;
+        if (P.apply_wb) {
+            float ro = P.wb[0] * r + P.wb[1] * g + P.wb[2] * b, go = P.wb[3] * r + P.wb[4] * g + P.wb[5] * b, bo = P.wb[6] * r + P.wb[7] * g + P.wb[8] * b;
+            r = maxf(0.0f, ro), g = maxf(0.0f, go), b = maxf(0.0f, bo);
+        }
+        r = r * P.imaging_ratio, g = g * P.imaging_ratio, b = b * P.imaging_ratio;
+        if (P.tonemap == HK_TONEMAP_REINHARD || P.tonemap == HK_TONEMAP_REINHARD_EXT) {
+            float lum = 0.2126f * r + 0.7152f * g + 0.0722f * b;
+            float sc = 1.0f;
+            if (lum > 0.0f) sc = P.tonemap == HK_TONEMAP_REINHARD ? 1.0f / (1.0f + lum) : (1.0f + lum / (P.white_point * P.white_point)) / (1.0f + lum);
+            r = clampf(r * sc, 0.0f, 1.0f), g = clampf(g * sc, 0.0f, 1.0f), b = clampf(b * sc, 0.0f, 1.0f);
+        } else if (P.tonemap == HK_TONEMAP_ACES) {
+            const float a = 2.51f, bc = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f;
+            r = clampf((r * (a * r + bc)) / (r * (c * r + d) + e), 0.0f, 1.0f);
+            g = clampf((g * (a * g + bc)) / (g * (c * g + d) + e), 0.0f, 1.0f);
+            b = clampf((b * (a * b + bc)) / (b * (c * b + d) + e), 0.0f, 1.0f);
+        } else if (P.tonemap == HK_TONEMAP_UNCHARTED2) {
+            float ws = 1.0f / pp_unch2(11.2f);
+            r = clampf(pp_unch2(r * 2.0f) * ws, 0.0f, 1.0f), g = clampf(pp_unch2(g * 2.0f) * ws, 0.0f, 1.0f), b = clampf(pp_unch2(b * 2.0f) * ws, 0.0f, 1.0f);
+        } else if (P.tonemap == HK_TONEMAP_FILMIC) {
+            r = pp_filmic(r), g = pp_filmic(g), b = pp_filmic(b);
+        } else
+            r = clampf(r, 0.0f, 1.0f), g = clampf(g, 0.0f, 1.0f), b = clampf(b, 0.0f, 1.0f);
+        if (P.apply_gamma) r = std::pow(r, P.inv_gamma), g = std::pow(g, P.inv_gamma), b = std::pow(b, P.inv_gamma);
+        if (P.mask_escaped && depth) {
+            int row = (int)(i % h) + 1, col = (int)(i / h) + 1, d_row = h - row + 1;
+            int escaped = 0, total = 0;
+            for (int dr = -1; dr <= 1; ++dr)
+                for (int dc = -1; dc <= 1; ++dc) {
+                    int nr = d_row + dr, nc = col + dc;
+                    if (nr >= 1 && nr <= h && nc >= 1 && nc <= w) {
+                        escaped += std::isinf(depth[(long)(nc - 1) * h + nr - 1]) ? 1 : 0;
+                        total += 1;
+                    }
+                }
+            float alpha = (float)escaped / (float)total;
+            r = r * (1.0f - alpha) + P.bg[0] * alpha, g = g * (1.0f - alpha) + P.bg[1] * alpha, b = b * (1.0f - alpha) + P.bg[2] * alpha;
+        }
+        dst[3 * i] = r, dst[3 * i + 1] = g, dst[3 * i + 2] = b;
+    }
+    return 0;
+}
+
 // OpenMP team size: tiny test frames run faster on a few threads than on a 256-core host
 void hko_set_threads(int32_t n) {
 #if defined(_OPENMP)

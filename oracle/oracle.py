@@ -36,6 +36,7 @@ def lib():
         L.hko_camera.argtypes = [C.POINTER(C.c_uint32), C.POINTER(A.hk_integrator_params), C.POINTER(A.hk_camera), i32, i32, i32, PI, PI, PI, PF]
         L.hko_uplift.argtypes = [C.POINTER(A.hk_tables), i32, i32, PF, PF, PF]
         L.hko_light_bvh.argtypes = [vp, i32, PF, PF, PF, PI, PF, PI, PF]
+        L.hko_postprocess.argtypes = [C.POINTER(A.hk_postprocess_params), i32, i32, PF, PF, PF]
         L.hko_light.argtypes = [vp, i32, i32, i32, PF, PF, PF, PF]
         L.hko_bsdf.argtypes = [vp, i32, i32, i32, i32, PF, PF, PF, PF, PF, PF, PF]
         L.hko_light_bvh_copy.argtypes = [vp, PI, PF, C.POINTER(C.c_uint32)]
@@ -198,3 +199,13 @@ def uplift(mode, rgb, lam):
     out = np.empty_like(lam)
     lib().hko_uplift(C.byref(t["struct"]), mode, rgb.shape[0], _pf(rgb), _pf(lam), _pf(out))
     return out
+
+
+def postprocess(params, framebuffer, depth=None):
+    """postprocess_kernel! on a framebuffer [h, w, 3] (and film.depth [h, w]) -> [h, w, 3]"""
+    h, w = framebuffer.shape[:2]
+    src = np.ascontiguousarray(np.transpose(framebuffer, (1, 0, 2)), np.float32)       # Julia [h,w] column-major
+    dst = np.empty_like(src)
+    dp = np.ascontiguousarray(np.transpose(depth, (1, 0)), np.float32) if depth is not None else None
+    lib().hko_postprocess(C.byref(params), w, h, _pf(src), _pf(dp) if dp is not None else None, _pf(dst))
+    return np.transpose(dst, (1, 0, 2)).copy()

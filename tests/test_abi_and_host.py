@@ -137,3 +137,38 @@ def test_shard_samples_partition(hk):
                 first, count, stride = hd.shard_samples(total, r, world)
                 seen += [first + k * stride for k in range(count)]
             assert sorted(seen) == list(range(1, total + 1))
+
+
+def test_postprocess_oracle_closed_forms(hk, oracle):
+    """postprocess_kernel! (src/postprocess.jl:185-250) restated in the oracle, against the formulas written out in numpy:
+    ACES / Reinhard / extended Reinhard / Uncharted 2 / filmic / linear clamp, gamma, sensor imaging ratio, Bradford white
+    balance (identity at the D65 temperature ~6504 K), and the 3x3 escaped-ray mask."""
+    from hikari_jl_amd.postprocess import make_params, compute_white_balance_matrix
+    rng = np.random.default_rng(2)
+    fb = (rng.random((6, 5, 3)) * 3).astype(np.float32)
+    x = fb.astype(np.float64)
+    out = oracle.postprocess(make_params(exposure=1.5, tonemap="aces", gamma=2.2), fb)
+    e = x * 1.5
+    ref = np.clip((e * (2.51 * e + 0.03)) / (e * (2.43 * e + 0.59) + 0.14), 0, 1) ** (1 / 2.2)
+    assert np.allclose(out, ref, rtol=2e-5, atol=1e-6)
+    out = oracle.postprocess(make_params(tonemap="reinhard", gamma=None), fb)
+    lum = 0.2126 * x[..., 0] + 0.7152 * x[..., 1] + 0.0722 * x[..., 2]
+    assert np.allclose(out, np.clip(x / (1 + lum)[..., None], 0, 1), rtol=2e-5, atol=1e-6)
+    out = oracle.postprocess(make_params(tonemap="reinhard_extended", gamma=None, white_point=2.0), fb)
+    assert np.allclose(out, np.clip(x * ((1 + lum / 4.0) / (1 + lum))[..., None], 0, 1), rtol=2e-5, atol=1e-6)
+    out = oracle.postprocess(make_params(tonemap=None, gamma=None, sensor=hk.FilmSensor(iso=50, exposure_time=0.5)), fb)
+    assert np.allclose(out, np.clip(x * 0.25, 0, 1), rtol=1e-6)
+    f = lambda v: (np.maximum(v - 0.004, 0) * (6.2 * np.maximum(v - 0.004, 0) + 0.5)) / (np.maximum(v - 0.004, 0) * (6.2 * np.maximum(v - 0.004, 0) + 1.7) + 0.06)
+    assert np.allclose(oracle.postprocess(make_params(tonemap="filmic", gamma=None), fb), f(x), rtol=2e-5, atol=1e-6)
+    u2 = lambda v: ((v * (0.15 * v + 0.05) + 0.004) / (v * (0.15 * v + 0.5) + 0.06)) - 0.02 / 0.3
+    assert np.allclose(oracle.postprocess(make_params(tonemap="uncharted2", gamma=None), fb), np.clip(u2(2 * x) / u2(11.2), 0, 1), rtol=5e-5, atol=1e-6)
+    M = compute_white_balance_matrix(6504.0)
+    assert np.allclose(M, np.eye(3), atol=4e-2)            # the Planckian locus at 6504 K is close to, not on, the D65 white point
+    M5 = compute_white_balance_matrix(5000.0)
+    assert M5[2, 2] > 1.05 and M5[0, 0] < 1.0            # warm source -> boost blue, cut red
+    depth = np.full((6, 5), 2.0, np.float32)
+    depth[:, 3:] = np.inf
+    out = oracle.postprocess(make_params(tonemap=None, gamma=None, background=(0.2, 0.4, 0.6)), fb, depth)
+    assert np.allclose(out[:, 4], [0.2, 0.4, 0.6], atol=1e-6)                                      # fully escaped neighbourhood
+    assert np.allclose(out[:, 0], np.clip(fb[:, 0], 0, 1), atol=1e-6)                              # untouched far from the edge
+    assert not np.allclose(out[:, 2], np.clip(fb[:, 2], 0, 1), atol=1e-3)                          # blended at the silhouette

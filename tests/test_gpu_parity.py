@@ -417,3 +417,21 @@ def test_error_behaviour(hk, gpu_ctx):
     assert b"max_depth" in L.hk_last_error()
     with pytest.raises(AssertionError):
         hk.VolPath(material_coherence="bogus")
+
+
+@pytest.mark.parametrize("tonemap", [None, "reinhard", "reinhard_extended", "aces", "uncharted2", "filmic"])
+def test_postprocess_parity(hk, oracle, gpu_ctx, tonemap):
+    """postprocess! on the device (hk_postprocess / Film.postprocess) vs the oracle: same kernel arguments, <= 2e-6 absolute
+    (powf ulps); sensor white balance and the escaped-ray background mask included."""
+    from hikari_jl_amd.postprocess import make_params
+    rng = np.random.default_rng(4)
+    film = hk.Film((37, 23))
+    film.framebuffer[...] = (rng.random((23, 37, 3)) ** 3 * 6).astype(np.float32)
+    film.depth = np.where(rng.random((23, 37)) < 0.3, np.inf, 1.0).astype(np.float32)
+    kw = dict(exposure=1.3, tonemap=tonemap, gamma=2.2, white_point=3.0, sensor=hk.FilmSensor(iso=90, white_balance=5000), background=(0.1, 0.2, 0.3))
+    got = film.postprocess(**kw)
+    ref = oracle.postprocess(make_params(**kw), film.framebuffer, film.depth)
+    assert got.shape == (23, 37, 3) and np.isfinite(got).all()
+    assert np.abs(got - ref).max() <= 2e-6, np.abs(got - ref).max()
+    got2 = film.postprocess(exposure=1.0, tonemap=tonemap, gamma=None)
+    assert np.abs(got2 - oracle.postprocess(make_params(exposure=1.0, tonemap=tonemap, gamma=None), film.framebuffer)).max() <= 1e-6

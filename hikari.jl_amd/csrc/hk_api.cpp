@@ -32,6 +32,7 @@ void launch_test_sobol(hipStream_t, const DTables&, const DSobol&, int, const in
 void launch_test_camera(hipStream_t, const DTables&, const DFilter&, const DCamera&, const DSobol&, int, int, const int*, const int*, const int*, float*);
 void launch_test_uplift(hipStream_t, const DTables&, int, int, const float*, const float*, float*);
 void launch_test_light_bvh(hipStream_t, const DScene&, int, const float*, const float*, const float*, int*, float*, const int*, float*);
+void launch_aux(hipStream_t, const DScene&, const DCamera&, int, int, float, float*, float*, float*);
 void launch_postprocess(hipStream_t, const hk_postprocess_params&, const float*, const float*, float*, int, int);
 void launch_sobol_table(hipStream_t, const DSobol&, const DFrame&, uint32_t*, int);
 void launch_test_light(hipStream_t, const DScene&, const DTables&, int, int, int, const float*, const float*, const float*, float*);
@@ -1148,6 +1149,23 @@ extern "C" int32_t hk_render(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_film*
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev_end, s));
+    return HK_OK;
+}
+
+extern "C" int32_t hk_film_fill_aux(hk_ctx* c, hk_scene* sc, const hk_camera* cam, int32_t w, int32_t h, int32_t has_infinite_lights, float* albedo, float* normal, float* depth) {
+    if (!c || !sc || !cam || !albedo || !normal || !depth || w <= 0 || h <= 0) return fail(HK_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    DevBuf da, dn, dd;
+    const size_t n = (size_t)w * h;
+    HIP_TRY(da.alloc(n * 12));
+    HIP_TRY(dn.alloc(n * 12));
+    HIP_TRY(dd.alloc(n * 4));
+    hk::launch_aux(c->stream, sc->d, make_camera(*cam), h, w, has_infinite_lights ? 1e30f : INFINITY, da.as<float>(), dn.as<float>(), dd.as<float>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(albedo, da.p, n * 12, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(normal, dn.p, n * 12, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(depth, dd.p, n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return HK_OK;
 }
 

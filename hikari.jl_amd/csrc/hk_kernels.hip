@@ -1245,6 +1245,37 @@ __global__ void __launch_bounds__(256) k_postprocess(hk_postprocess_params P, co
     }
 }
 
+// aux_buffer_kernel! (src/film.jl:435-483): first-hit albedo / normal / depth per pixel centre, Julia [h,w] layout
+__global__ void __launch_bounds__(HK_TRACE_BLOCK) k_aux(DScene sc, DCamera cam, int h, int w, float miss_depth, float* __restrict__ albedo, float* __restrict__ normal,
+                                                      float* __restrict__ depth) {
+    __shared__ int lds_stack[(HK_TRACE_BLOCK / 64) * HK_LDS_STACK * 64];
+    int* stack = lds_stack + (threadIdx.x >> 6) * (HK_LDS_STACK * 64);
+    const int lane = lane_id();
+    unsigned a = 0, b = 0;
+    const long n = (long)h * w;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        int row = (int)(i % h) + 1, col = (int)(i / h) + 1;
+        v2 pixel = mk2(((float)col - 1.0f) + 0.5f, ((float)row - 1.0f) + 0.5f);
+        v3 ro, rd;
+        float time;
+        generate_ray(cam, pixel, mk2(0.5f, 0.5f), 0.0f, ro, rd, time);
+        bool opaque;
+        HitRec hr = traverse<0, false>(sc, ro, rd, INF_F, stack, lane, a, b, opaque);
+        float alb = 0.0f, d = miss_depth;
+        v3 nn = mk3(0, 0, 0);
+        if (hr.prim >= 0) {
+            nn = geometric_normal(sc, hr.prim);
+            v3 hp = ro + rd * hr.t;
+            v3 dd = hp - ro;
+            d = sqrtf(dd.x * dd.x + dd.y * dd.y + dd.z * dd.z);
+            alb = 0.8f;
+        }
+        albedo[3 * i] = albedo[3 * i + 1] = albedo[3 * i + 2] = alb;
+        normal[3 * i] = nn.x, normal[3 * i + 1] = nn.y, normal[3 * i + 2] = nn.z;
+        depth[i] = d;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // sub-kernel entry points used by the parity tests
 // ---------------------------------------------------------------------------------------------------
@@ -1546,6 +1577,9 @@ void launch_sobol_table(hipStream_t s, const DSobol& sob, const DFrame& fr, uint
 }
 void launch_postprocess(hipStream_t s, const hk_postprocess_params& P, const float* src, const float* depth, float* dst, int h, int w) {
     hipLaunchKernelGGL(k_postprocess, dim3(grid_for(h * w, 256, 8192)), dim3(256), 0, s, P, src, depth, dst, h, w);
+}
+void launch_aux(hipStream_t s, const DScene& sc, const DCamera& cam, int h, int w, float miss_depth, float* albedo, float* normal, float* depth) {
+    hipLaunchKernelGGL(k_aux, dim3(grid_for(h * w, HK_TRACE_BLOCK, 2048)), dim3(HK_TRACE_BLOCK), 0, s, sc, cam, h, w, miss_depth, albedo, normal, depth);
 }
 
 }  // namespace hk

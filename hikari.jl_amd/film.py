@@ -24,6 +24,21 @@ class Film:
         self.framebuffer[...] = 0
         self.iteration_index = 0
 
+    def fill_aux_buffers(self, scene, camera, has_infinite_lights=False, device=0):
+        """fill_aux_buffers!(film, scene, camera; has_infinite_lights) (src/film.jl:410-433): film.albedo / normal / depth"""
+        import ctypes as C
+        from . import _abi as A
+        from . import _lib
+        from .volpath import Context, scene_handle
+        ctx = Context.get(device)
+        w, h = self.resolution
+        a, n, d = np.zeros((w, h, 3), np.float32), np.zeros((w, h, 3), np.float32), np.zeros((w, h), np.float32)
+        cam = camera.record()
+        _lib.check(_lib.lib().hk_film_fill_aux(ctx.h, scene_handle(ctx, scene), C.byref(cam), w, h, 1 if has_infinite_lights else 0, a.ctypes.data_as(A.PF),
+                                               n.ctypes.data_as(A.PF), d.ctypes.data_as(A.PF)), "hk_film_fill_aux")
+        self.albedo, self.normal, self.depth = np.transpose(a, (1, 0, 2)).copy(), np.transpose(n, (1, 0, 2)).copy(), np.transpose(d, (1, 0)).copy()
+        return self
+
     def postprocess(self, exposure=1.0, tonemap="aces", gamma=2.2, white_point=4.0, sensor=None, background=None, device=0):
         """postprocess!(film; exposure, tonemap, gamma, white_point, sensor, background) (src/postprocess.jl:293-357): reads
         film.framebuffer, writes and returns film.postprocess; non-destructive, runs on the device through the C-ABI."""

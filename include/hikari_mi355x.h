@@ -383,6 +383,13 @@ int32_t hk_film_postprocess(hk_ctx* ctx, hk_film* film, const hk_postprocess_par
 int32_t hk_postprocess(hk_ctx* ctx, const hk_postprocess_params* params, int32_t width, int32_t height, const float* src_rgb,
                        const float* depth, float* dst_rgb);
 
+/* fill_aux_buffers!(film, scene, camera; has_infinite_lights) (src/film.jl:410-483): one primary ray through every pixel
+ * centre; albedo = (0.8,0.8,0.8) on a hit else 0, normal = geometric normal of the hit triangle (Raycore's si.core.n is not
+ * available here: normalize((v1-v0) x (v2-v0)), un-flipped) else 0, depth = |hit - ray.o|, else +Inf (or 1e30 when the scene
+ * has infinite lights).  Outputs are host arrays in Julia [h,w] layout: albedo/normal 3 floats per pixel, depth 1. */
+int32_t hk_film_fill_aux(hk_ctx* ctx, hk_scene* scene, const hk_camera* cam, int32_t width, int32_t height, int32_t has_infinite_lights,
+                         float* albedo, float* normal, float* depth);
+
 /* point-wise BSDFs of a scene's material `mat_idx` (material-dispatch.jl:23-53; spectral-eval.jl) at uv=(0,0):
    mode 0 = sample_bsdf_spectral(wo, ns, lambda, u, uc, regularize) -> out[10n] = wi3, f4, pdf, is_specular, eta_scale
    mode 1 = evaluate_bsdf_spectral(wo, wi, ns, lambda)              -> out[10n] = f4, pdf, 0...

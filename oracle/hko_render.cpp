@@ -1416,6 +1416,33 @@ int32_t hko_postprocess(const hk_postprocess_params* Pp, int32_t w, int32_t h, c
     return 0;
 }
 
+// aux_buffer_kernel! (src/film.jl:435-483); outputs in Julia [h,w] layout
+int32_t hko_fill_aux(hko_scene* s, const hk_camera* cam, int32_t w, int32_t h, int32_t has_infinite_lights, float* albedo, float* normal, float* depth) {
+    Scene& sc = s->sc;
+    const float miss_depth = has_infinite_lights ? 1e30f : INF_F;
+    const long n = (long)h * w;
+#pragma omp parallel for schedule(dynamic, 256)
+    for (long i = 0; i < n; ++i) {
+        int row = (int)(i % h) + 1, col = (int)(i / h) + 1;
+        CamRay cr = generate_ray(*cam, V2(((float)col - 1.0f) + 0.5f, ((float)row - 1.0f) + 0.5f), V2(0.5f, 0.5f), 0.0f);
+        Hit hit = sc.accel.closest_hit(cr.o, cr.d, INF_F);
+        float alb = 0.0f, d = miss_depth;
+        V3 nn(0.0f);
+        if (hit.prim >= 0) {
+            V3 v0, v1, v2;
+            tri_vertices(sc, hit.prim, v0, v1, v2);
+            nn = normalize(cross(v1 - v0, v2 - v0));
+            V3 dd = (cr.o + cr.d * hit.t) - cr.o;
+            d = std::sqrt(dd.x * dd.x + dd.y * dd.y + dd.z * dd.z);
+            alb = 0.8f;
+        }
+        albedo[3 * i] = albedo[3 * i + 1] = albedo[3 * i + 2] = alb;
+        normal[3 * i] = nn.x, normal[3 * i + 1] = nn.y, normal[3 * i + 2] = nn.z;
+        depth[i] = d;
+    }
+    return 0;
+}
+
 // OpenMP team size: tiny test frames run faster on a few threads than on a 256-core host
 void hko_set_threads(int32_t n) {
 #if defined(_OPENMP)

@@ -36,6 +36,7 @@ def lib():
         L.hko_camera.argtypes = [C.POINTER(C.c_uint32), C.POINTER(A.hk_integrator_params), C.POINTER(A.hk_camera), i32, i32, i32, PI, PI, PI, PF]
         L.hko_uplift.argtypes = [C.POINTER(A.hk_tables), i32, i32, PF, PF, PF]
         L.hko_light_bvh.argtypes = [vp, i32, PF, PF, PF, PI, PF, PI, PF]
+        L.hko_fill_aux.argtypes = [vp, C.POINTER(A.hk_camera), i32, i32, i32, PF, PF, PF]
         L.hko_postprocess.argtypes = [C.POINTER(A.hk_postprocess_params), i32, i32, PF, PF, PF]
         L.hko_light.argtypes = [vp, i32, i32, i32, PF, PF, PF, PF]
         L.hko_bsdf.argtypes = [vp, i32, i32, i32, i32, PF, PF, PF, PF, PF, PF, PF]
@@ -130,6 +131,14 @@ class OracleScene:
         q = np.ascontiguousarray(query if query is not None else np.zeros(m), np.int32)
         lib().hko_light_bvh(self.h, m, _pf(p), _pf(n), _pf(u), _pi(li), _pf(pmf), _pi(q), _pf(qp))
         return li, pmf, qp
+
+    def fill_aux(self, camera, width, height, has_infinite_lights=False):
+        """fill_aux_buffers! -> (albedo [h,w,3], normal [h,w,3], depth [h,w])"""
+        n = width * height
+        a, nn, d = np.zeros((width, height, 3), np.float32), np.zeros((width, height, 3), np.float32), np.zeros((width, height), np.float32)
+        cam = camera.record()
+        lib().hko_fill_aux(self.h, C.byref(cam), width, height, 1 if has_infinite_lights else 0, _pf(a), _pf(nn), _pf(d))
+        return np.transpose(a, (1, 0, 2)).copy(), np.transpose(nn, (1, 0, 2)).copy(), np.transpose(d, (1, 0)).copy()
 
     def light(self, mode, light_idx_1based, p, x, lam):
         """mode 0: sample_light_spectral(light, p, lambda, u = x[:, :2]) -> [n, 12] = wi3, pdf, Li4, p_light3, is_delta;

@@ -435,3 +435,16 @@ def test_postprocess_parity(hk, oracle, gpu_ctx, tonemap):
     assert np.abs(got - ref).max() <= 2e-6, np.abs(got - ref).max()
     got2 = film.postprocess(exposure=1.0, tonemap=tonemap, gamma=None)
     assert np.abs(got2 - oracle.postprocess(make_params(exposure=1.0, tonemap=tonemap, gamma=None), film.framebuffer)).max() <= 1e-6
+
+
+def test_aux_buffers_parity(hk, oracle, gpu_ctx):
+    """fill_aux_buffers! (src/film.jl:410-483): first-hit normal / depth / albedo per pixel centre, GPU == oracle (depth and
+    normal bit-exact: same intersection arithmetic), and the escaped mask they feed into postprocess."""
+    from hikari_jl_amd import scenes
+    s, film, cam = scenes.sky_scene(48, 40, env_res=16, tess=16, analytic=True)
+    film.fill_aux_buffers(s, cam)
+    a, n, d = oracle.OracleScene(s).fill_aux(cam, 48, 40)
+    assert film.depth.shape == (40, 48) and np.array_equal(film.depth, d) and np.array_equal(film.normal, n) and np.array_equal(film.albedo, a)
+    assert np.isinf(d).any() and (d[np.isfinite(d)] > 0).all() and set(np.unique(a)) == {np.float32(0.0), np.float32(0.8)}
+    film.fill_aux_buffers(s, cam, has_infinite_lights=True)
+    assert not np.isinf(film.depth).any() and (film.depth.max() == np.float32(1e30))

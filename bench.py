@@ -51,10 +51,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # HK_BENCH_SINGLE_DEVICE=1 (test hook): every rank shares cuda:0 and the process group is gloo, so the N > 1 code path can be
+    # exercised on a 1-GPU box.  The driver's runs never set it: one process per GPU over RCCL ("nccl").
+    single_device = os.environ.get("HK_BENCH_SINGLE_DEVICE") == "1"
     if args.gpus > 1 or world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo" if single_device else "nccl", rank=rank, world_size=world)
+    if single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
 
     import hikari_jl_amd as hk
@@ -115,8 +120,9 @@ def main():
     elapsed = time.perf_counter() - t0
     st = vp.stats()
     rays_local = int(st.rays_closest) + int(st.rays_shadow)
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    rays = torch.tensor([float(rays_local)], dtype=torch.float64, device="cuda")
+    stat_dev = "cpu" if single_device else "cuda"
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=stat_dev)
+    rays = torch.tensor([float(rays_local)], dtype=torch.float64, device=stat_dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)

@@ -15,5 +15,10 @@ def reduce_film(accum_tensor, root=0):
     """Sum-reduce the film accumulators onto `root` (16 MiB at 1024^2: one small collective per frame)."""
     import torch.distributed as dist
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.reduce(accum_tensor, dst=root, op=dist.ReduceOp.SUM)
+        if dist.get_backend() == "gloo" and accum_tensor.is_cuda:   # CPU-side test configuration: stage through the host
+            host = accum_tensor.cpu()
+            dist.reduce(host, dst=root, op=dist.ReduceOp.SUM)
+            accum_tensor.copy_(host)
+        else:
+            dist.reduce(accum_tensor, dst=root, op=dist.ReduceOp.SUM)
     return accum_tensor

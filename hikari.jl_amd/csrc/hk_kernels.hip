@@ -263,6 +263,200 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace(DPathState st, DScene 
 }
 
 // ---------------------------------------------------------------------------------------------------
+// K3 / K10 for scenes without media whose surfaces are all opaque (the common case): while-while traversal with wave-private
+// dynamic fetch.  The step count per ray varies by 3-4x inside a wave of incoherent rays; instead of letting finished lanes
+// idle until the slowest ray of the batch is done, a lane whose ray is finished keeps its result until the next flush, where
+// results are classified / pushed with ballots and idle lanes pull the next rays of the wave's own queue segment.
+// Same arithmetic and same per-ray result as traverse<>() (closest hit: min (t, prim); shadow: any hit).
+// ---------------------------------------------------------------------------------------------------
+#ifndef HK_TRACE_MIN_IDLE
+#define HK_TRACE_MIN_IDLE 12
+#endif
+struct LaneRay {   // per-lane traversal state
+    v3 o, d;
+    float ix, iy, iz, ox, oy, oz, eps_abs;
+    float t_max;
+    HitRec best;
+    int cur, sp;
+};
+HKD void lane_ray_start(LaneRay& r, const DScene& sc, v3 o, v3 d, float t_max) {
+    r.o = o;
+    r.d = d;
+    r.t_max = t_max;
+    r.best.t = t_max;
+    r.best.prim = -1;
+    r.best.u = r.best.v = 0.0f;
+    r.ix = clampf(1.0f / d.x, -1e30f, 1e30f), r.iy = clampf(1.0f / d.y, -1e30f, 1e30f), r.iz = clampf(1.0f / d.z, -1e30f, 1e30f);
+    r.ox = -o.x * r.ix, r.oy = -o.y * r.iy, r.oz = -o.z * r.iz;
+    r.eps_abs = 2.4e-7f * fmaxf(fmaxf(fabsf(r.ix) < 1e30f ? fabsf(r.ox) : 0.0f, fabsf(r.iy) < 1e30f ? fabsf(r.oy) : 0.0f), fabsf(r.iz) < 1e30f ? fabsf(r.oz) : 0.0f);
+    r.sp = 0;
+    r.cur = sc.n_tris == 0 ? (int)0x80000000 : sc.root_ref;
+}
+// one while-while round for the lanes with `active`: inner nodes until every such lane holds a leaf (or is done), then the leaves.
+// ANYHIT: the first accepted triangle ends the ray (cur = DONE, best.prim >= 0).
+template <bool ANYHIT, bool COUNT>
+HKD void lane_ray_round(LaneRay& r, bool active, const DScene& sc, int* __restrict__ stack, int lane, unsigned& n_nodes, unsigned& n_tris) {
+    const int DONE = (int)0x80000000;
+    const float4* __restrict__ nodes4 = reinterpret_cast<const float4*>(sc.nodes);
+    while (__ballot(active && r.cur >= 0)) {
+        if (active && r.cur >= 0) {
+            const float4* np = nodes4 + 4 * (size_t)r.cur;
+            float4 A = np[0], B = np[1], C = np[2], D = np[3];
+            if (COUNT) ++n_nodes;
+            float t0x = fmaf(A.x, r.ix, r.ox), t1x = fmaf(A.w, r.ix, r.ox);
+            float t0y = fmaf(A.y, r.iy, r.oy), t1y = fmaf(B.x, r.iy, r.oy);
+            float t0z = fmaf(A.z, r.iz, r.oz), t1z = fmaf(B.y, r.iz, r.oz);
+            float n0 = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.0f));
+            float f0 = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), r.best.t));
+            float u0x = fmaf(B.z, r.ix, r.ox), u1x = fmaf(C.y, r.ix, r.ox);
+            float u0y = fmaf(B.w, r.iy, r.oy), u1y = fmaf(C.z, r.iy, r.oy);
+            float u0z = fmaf(C.x, r.iz, r.oz), u1z = fmaf(C.w, r.iz, r.oz);
+            float n1 = fmaxf(fmaxf(fminf(u0x, u1x), fminf(u0y, u1y)), fmaxf(fminf(u0z, u1z), 0.0f));
+            float f1 = fminf(fminf(fmaxf(u0x, u1x), fmaxf(u0y, u1y)), fminf(fmaxf(u0z, u1z), r.best.t));
+            bool h0 = n0 * 0.99999f - r.eps_abs <= f0 * 1.00001f + r.eps_abs;
+            bool h1 = n1 * 0.99999f - r.eps_abs <= f1 * 1.00001f + r.eps_abs;
+            int c0 = __float_as_int(D.x), c1 = __float_as_int(D.y);
+            if (h0 && h1) {
+                bool first0 = n0 <= n1;
+                stack[r.sp * 64 + lane] = first0 ? c1 : c0;
+                ++r.sp;
+                r.cur = first0 ? c0 : c1;
+            } else if (h0 || h1) {
+                r.cur = h0 ? c0 : c1;
+            } else if (r.sp > 0) {
+                --r.sp;
+                r.cur = stack[r.sp * 64 + lane];
+            } else
+                r.cur = DONE;
+        }
+    }
+    if (active && r.cur != DONE) {
+        int ref = ~r.cur;
+        int first = ref >> 3, count = (ref & 7) + 1;
+        bool stop = false;
+        for (int i = 0; i < count && !stop; ++i) {
+            const float4* tp = sc.leaf_tris + 3 * (size_t)(first + i);
+            float4 T0 = tp[0], T1 = tp[1], T2 = tp[2];
+            if (COUNT) ++n_tris;
+            float t, u, v;
+            if (intersect_triangle(r.o, r.d, r.t_max, mk3(T0.x, T0.y, T0.z), mk3(T1.x, T1.y, T1.z), mk3(T2.x, T2.y, T2.z), t, u, v)) {
+                int prim = __float_as_int(T0.w);
+                if (ANYHIT) {
+                    r.best.t = t;
+                    r.best.prim = prim;
+                    stop = true;
+                } else if (r.best.prim < 0 || t < r.best.t || (t == r.best.t && prim < r.best.prim)) {
+                    r.best.t = t;
+                    r.best.prim = prim;
+                    r.best.u = u;
+                    r.best.v = v;
+                }
+            }
+        }
+        if (stop)
+            r.cur = DONE;
+        else if (r.sp > 0) {
+            --r.sp;
+            r.cur = stack[r.sp * 64 + lane];
+        } else
+            r.cur = DONE;
+    }
+}
+
+enum { LR_EMPTY = 0, LR_ACTIVE = 1 };
+
+template <bool COUNT>
+__global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace_lean(DPathState st, DScene sc, int depth, DStats* stats) {
+    __shared__ int lds_stack[(HK_TRACE_BLOCK / 64) * HK_LDS_STACK * 64];
+    int* stack = lds_stack + (threadIdx.x >> 6) * (HK_LDS_STACK * 64);
+    const int lane = lane_id();
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const int DONE = (int)0x80000000;
+    unsigned n_nodes = 0, n_tris = 0, n_casts = 0, n_hits = 0;
+    HK_FOR_EACH_WAVE_SEGMENT(gw, st) {
+    const uint32_t* __restrict__ queue = st.ray_q[depth & 1] + (size_t)gw * st.wave_cap;
+    const int n = *count_ptr(st, depth, Q_RAY, gw);
+    WaveQ q_escaped = wq_open(st.escaped_q, st, gw);
+    int kind_count[HK_MAX_KINDS];
+#pragma unroll
+    for (int k = 0; k < HK_MAX_KINDS; ++k) kind_count[k] = 0;
+    int cursor = 0;
+    int state = LR_EMPTY;
+    uint32_t slot = 0;
+    LaneRay r;
+    r.cur = DONE;
+    for (;;) {
+        const unsigned long long run_m = __ballot(state == LR_ACTIVE && r.cur != DONE);
+        if (run_m == 0ull || (64 - __popcll(run_m) >= HK_TRACE_MIN_IDLE && cursor < n)) {
+            // ---- flush: classify the finished rays, push them to the escaped / material-kind queues ----
+            int kind = -1;
+            if (state == LR_ACTIVE && r.cur == DONE) {
+                if (r.best.prim < 0)
+                    kind = -2;
+                else {
+                    ++n_hits;
+                    int mat = sc.mis[sc.meta[r.best.prim].mi].material;
+                    if (sc.materials[mat].kind == HK_MAT_MIX) {   // MixMaterial is resolved here so the queue is sorted by the final kind
+                        float w = 1.0f - r.best.u - r.best.v;
+                        mat = resolve_mix_material(sc, mat, r.o + r.d * r.best.t, -r.d, uv_at(sc, r.best.prim, w, r.best.u, r.best.v));
+                    }
+                    kind = sc.materials[mat].kind;
+                    if (kind == HK_MAT_MIX) kind = HK_MAT_FALLBACK;
+                    st.hit[slot] = make_float4(r.best.t, __int_as_float(r.best.prim), r.best.u, r.best.v);
+                    st.mat_id[slot] = mat;
+                }
+                state = LR_EMPTY;
+            }
+            wq_push(q_escaped, slot, kind == -2);
+            unsigned long long pending = __ballot(kind >= 0);
+            while (pending) {
+                int src = __ffsll((long long)pending) - 1;
+                int k = __shfl(kind, src);
+                bool mine = kind == k;
+                unsigned long long m = __ballot(mine);
+                int cnt = 0;
+#pragma unroll
+                for (int kk = 0; kk < HK_MAX_KINDS; ++kk) cnt = (kk == k) ? kind_count[kk] : cnt;
+                if (mine) st.mat_q[((size_t)k * st.n_waves + gw) * st.wave_cap + cnt + __popcll(m & lt_mask)] = slot;
+                int add = __popcll(m);
+#pragma unroll
+                for (int kk = 0; kk < HK_MAX_KINDS; ++kk) kind_count[kk] += (kk == k) ? add : 0;
+                pending &= ~m;
+            }
+            // ---- refill ----
+            const unsigned long long want = __ballot(state == LR_EMPTY);
+            const int avail = n - cursor;
+            const int rank = __popcll(want & lt_mask);
+            if (state == LR_EMPTY && rank < avail) {
+                slot = queue[cursor + rank];
+                float4 O = st.ray_o[slot], D = st.ray_d[slot];
+                ++n_casts;
+                lane_ray_start(r, sc, mk3(O.x, O.y, O.z), mk3(D.x, D.y, D.z), O.w);
+                state = LR_ACTIVE;
+            }
+            const int want_n = __popcll(want);
+            cursor += want_n < avail ? want_n : (avail > 0 ? avail : 0);
+            if (__ballot(state == LR_ACTIVE) == 0ull) break;
+        }
+        lane_ray_round<false, COUNT>(r, state == LR_ACTIVE && r.cur != DONE, sc, stack, lane, n_nodes, n_tris);
+    }
+    wq_close(q_escaped, count_ptr(st, depth, Q_ESCAPED, gw));
+    if (lane == 0) {
+        *count_ptr(st, depth, Q_MEDIUM, gw) = 0;
+#pragma unroll
+        for (int k = 0; k < HK_MAX_KINDS; ++k) *count_ptr(st, depth, Q_MAT0 + k, gw) = kind_count[k];
+    }
+    }
+    stats += global_wave();
+    wave_add(&stats->rays_closest, n_casts);
+    wave_add(&stats->hits, n_hits);
+    if (COUNT) {
+        wave_add(&stats->nodes, n_nodes);
+        wave_add(&stats->tris, n_tris);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // K4: delta tracking with null collisions (delta-tracking.jl:79-453), after k_trace, for the paths that travel inside a
 // medium.  The collision count per path is wildly uneven (0 .. 1000s), so the wave does not walk its queue 64 entries at
 // a time: every lane is a little state machine that takes ONE step per iteration (next majorant segment, or one tentative
@@ -846,23 +1040,47 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_shadow(DPathState st, DScene
     __shared__ int lds_stack[(HK_TRACE_BLOCK / 64) * HK_LDS_STACK * 64];
     int* stack = lds_stack + (threadIdx.x >> 6) * (HK_LDS_STACK * 64);
     const int lane = lane_id();
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const int DONE = (int)0x80000000;
     unsigned n_nodes = 0, n_tris = 0, n_casts = 0, n_hits = 0;
     HK_FOR_EACH_WAVE_SEGMENT(gw, st) {
     const uint32_t* __restrict__ queue = st.shadow_q + (size_t)gw * st.wave_cap;
     const int n = *count_ptr(st, depth, Q_SHADOW, gw);
-    for (int base = 0; base < n; base += 64) {
-        int i = base + lane;
-        if (i >= n) continue;
-        uint32_t slot = queue[i];
-        float4 O = st.sh_o[slot], D = st.sh_d[slot];
-        if (O.w < 1e-6f) continue;
-        bool opaque;
-        ++n_casts;
-        HitRec h = traverse<1, COUNT>(sc, mk3(O.x, O.y, O.z), mk3(D.x, D.y, D.z), O.w, stack, lane, n_nodes, n_tris, opaque);
-        if (h.prim < 0)
-            shadow_contribute(st, slot, s4(1.0f), s4(1.0f), s4(1.0f));
-        else
-            ++n_hits;
+    int cursor = 0;
+    bool have = false;
+    uint32_t slot = 0;
+    LaneRay r;
+    r.cur = DONE;
+    for (;;) {
+        const unsigned long long run_m = __ballot(have && r.cur != DONE);
+        if (run_m == 0ull || (64 - __popcll(run_m) >= HK_TRACE_MIN_IDLE && cursor < n)) {
+            if (have && r.cur == DONE) {   // finished: an unoccluded shadow ray delivers its contribution
+                if (r.best.prim < 0)
+                    shadow_contribute(st, slot, s4(1.0f), s4(1.0f), s4(1.0f));
+                else
+                    ++n_hits;
+                have = false;
+            }
+            const unsigned long long want = __ballot(!have);
+            const int avail = n - cursor;
+            const int rank = __popcll(want & lt_mask);
+            if (!have && rank < avail) {
+                slot = queue[cursor + rank];
+                float4 O = st.sh_o[slot], D = st.sh_d[slot];
+                if (O.w >= 1e-6f) {   // a degenerate shadow ray is simply not visible
+                    ++n_casts;
+                    lane_ray_start(r, sc, mk3(O.x, O.y, O.z), mk3(D.x, D.y, D.z), O.w);
+                    have = true;
+                }
+            }
+            const int want_n = __popcll(want);
+            cursor += want_n < avail ? want_n : (avail > 0 ? avail : 0);
+            if (__ballot(have) == 0ull) {
+                if (cursor >= n) break;
+                continue;
+            }
+        }
+        lane_ray_round<true, COUNT>(r, have && r.cur != DONE, sc, stack, lane, n_nodes, n_tris);
     }
     }
     stats += global_wave();
@@ -1380,6 +1598,14 @@ void launch_camera(hipStream_t s, int n_cu, const DPathState& st, const DFrame& 
     hipLaunchKernelGGL(k_camera, dim3(clamp_blocks(blocks, st)), dim3(256), 0, s, st, fr, T, f, c, sob, initial_medium);
 }
 void launch_trace(hipStream_t s, int n_cu, const DPathState& st, const DScene& sc, const DTables& T, const DFrame& fr, int depth, DStats* stats) {
+    if (sc.all_opaque && sc.n_media == 0) {
+        static int l0 = resident_blocks(k_trace_lean<false>, HK_TRACE_BLOCK, n_cu, 8), l1 = resident_blocks(k_trace_lean<true>, HK_TRACE_BLOCK, n_cu, 8);
+        if (fr.count_nodes)
+            hipLaunchKernelGGL(k_trace_lean<true>, dim3(clamp_blocks(l1, st)), dim3(HK_TRACE_BLOCK), 0, s, st, sc, depth, stats);
+        else
+            hipLaunchKernelGGL(k_trace_lean<false>, dim3(clamp_blocks(l0, st)), dim3(HK_TRACE_BLOCK), 0, s, st, sc, depth, stats);
+        return;
+    }
     static int b0 = resident_blocks(k_trace<false>, HK_TRACE_BLOCK, n_cu, 8), b1 = resident_blocks(k_trace<true>, HK_TRACE_BLOCK, n_cu, 8);
     if (fr.count_nodes)
         hipLaunchKernelGGL(k_trace<true>, dim3(clamp_blocks(b1, st)), dim3(HK_TRACE_BLOCK), 0, s, st, sc, T, fr, depth, stats);

@@ -11,7 +11,9 @@
 #include <stdint.h>
 
 #define HK_MAX_KINDS 11          // HK_MAT_* count (Mix is resolved before queueing)
+#ifndef HK_LDS_STACK
 #define HK_LDS_STACK 32          // per-lane traversal stack entries kept in LDS (builder bounds the depth)
+#endif
 #define HK_TRACE_BLOCK 256
 
 // child reference: >= 0 inner node index; < 0 leaf: ~ref = (first_tri << 3) | (count - 1), count <= 4 (<=8 encodable)

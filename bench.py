@@ -2,9 +2,11 @@
 """bench.py — Mrays/s of the VolPath hot path on BASELINE.json configs[1]:
 Cornell box (diffuse + area light), 800x800, depth 8, 256 spp, 1 x MI355X.
 
-A "step" is one wavefront pass of the hot path over one batch of synthetic input: SPP_PER_STEP (=4)
-samples of every pixel of the 800x800 frame carried through the 8-bounce loop (2.56 M paths).  The default
-64 steps are exactly the 256-spp frame, so `seconds_to_256spp` is the timed region itself.
+A "step" is one wavefront pass of the hot path over one batch of synthetic input: SPP_PER_STEP (=64)
+samples of every pixel of the 800x800 frame carried through the 8-bounce loop (41 M paths in flight: the
+chip needs ~100 paths per resident lane for the deeper bounces of a pass to keep it busy; ~16 GB of path
+state in HBM).  The default 4 steps are exactly the 256-spp frame, so `seconds_to_256spp` is the timed
+region itself (--spp-per-step changes the batch; --steps defaults to 256 / spp-per-step).
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
@@ -25,19 +27,21 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-W, H, DEPTH, SPP_PER_STEP, FULL_SPP = 800, 800, 8, 4, 256
+W, H, DEPTH, SPP_PER_STEP, FULL_SPP = 800, 800, 8, 64, 256
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 S_NODE, B_TRI, B_HIT, B_RAY_IN, B_HIT_OUT = 64, 36, 96, 32, 16   # SURVEY.md §8(d) algorithmic bytes per cast
 S_STATE = 104                  # compact path state, read + written once per path vertex
 
 
 def main():
+    global SPP_PER_STEP
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=FULL_SPP // SPP_PER_STEP)
+    ap.add_argument("--steps", type=int, default=None, help="default: the full 256-spp frame (256 / spp-per-step)")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=1)
+    ap.add_argument("--spp-per-step", type=int, default=SPP_PER_STEP, help="samples of every pixel in flight per wavefront pass (one step)")
     ap.add_argument("--config", default="cornell", choices=["cornell", "cloud", "sky", "manylight"],
                     help="cornell = BASELINE configs[1] (the bench line); sky = configs[2] stand-in (glass sphere + gold slab + env map + sun, depth 12); "
                          "cloud = configs[3] stand-in (synthetic NanoVDB cloud, 1024x1024, depth 32); manylight = configs[4] stand-in (10^6 triangles, "
@@ -67,6 +71,9 @@ def main():
     from hikari_jl_amd import scenes
 
     global W, H, DEPTH
+    SPP_PER_STEP = args.spp_per_step
+    if args.steps is None:
+        args.steps = max(FULL_SPP // SPP_PER_STEP, 1)
     if args.config == "cloud":
         W, H, DEPTH = 1024, 1024, 32
         scene, film, cam = scenes.cloud_scene(W, H, "nanovdb", res=(256, 256, 128), sigma_scale=620.0 / 4)

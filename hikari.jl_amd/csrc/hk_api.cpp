@@ -1052,9 +1052,15 @@ extern "C" int32_t hk_render(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_film*
     fr.n_pixels_padded = fr.tiles_x * fr.tiles_y * 64;
     int S = I->p.samples_per_pass;
     if (S <= 0) {
-        S = (int)(3000000L / fr.n_pixels_padded);
+        // auto: ~48 M paths in flight (64 spp of an 800x800 frame).  The chip holds 256 CUs x 16..32 waves x 64 lanes, and the
+        // deeper bounces of a pass only keep it busy when the pass starts with ~100 paths per lane; path state is ~400 B per
+        // path, so this is < 20 GB of the 288 GB of HBM (halved until it fits in half of the free memory).
+        S = (int)((48L << 20) / fr.n_pixels_padded);
         if (S < 1) S = 1;
-        if (S > 16) S = 16;
+        if (S > 64) S = 64;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+            while (S > 1 && (size_t)S * fr.n_pixels_padded * 400 > free_b / 2) S /= 2;
     }
     if (S > n_samples) S = n_samples;
     if ((long)S * fr.n_pixels_padded > 0x3fffffffL) return fail(HK_ERR_INVALID, "pass too large");

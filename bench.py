@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--steps", type=int, default=None, help="default: the full 256-spp frame (256 / spp-per-step)")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-spp", type=int, default=1)
+    ap.add_argument("--cpu-spp", type=int, default=0, help="samples per pixel of the CPU baseline sample (0 = about 15 s of work)")
     ap.add_argument("--spp-per-step", type=int, default=SPP_PER_STEP, help="samples of every pixel in flight per wavefront pass (one step)")
     ap.add_argument("--config", default="cornell", choices=["cornell", "cloud", "sky", "manylight"],
                     help="cornell = BASELINE configs[1] (the bench line); sky = configs[2] stand-in (glass sphere + gold slab + env map + sun, depth 12); "
@@ -182,10 +182,13 @@ def main():
         if not args.no_cpu_baseline:
             import oracle
             oracle.build()
-            oracle.set_threads(os.cpu_count() or 1)
+            oracle.set_threads(oracle.available_cores())     # affinity mask and cgroup quota, not the host's core count
             osc = oracle.OracleScene(scene)
             p = hk.integrator_params(max_depth=DEPTH, samples=FULL_SPP)
+            c0 = time.perf_counter()
             osc.render(p, cam, W, H, 1, first=FULL_SPP)       # untimed: thread team start-up, first-touch of the work arrays
+            if args.cpu_spp <= 0:                             # auto: about 15 s of CPU work
+                args.cpu_spp = max(1, min(32, int(15.0 / max(time.perf_counter() - c0, 1e-3))))
             c0 = time.perf_counter()
             _, ost = osc.render(p, cam, W, H, args.cpu_spp)
             cdt = time.perf_counter() - c0

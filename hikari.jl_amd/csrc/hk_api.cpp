@@ -81,8 +81,8 @@ struct hk_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     int n_cu = 256;
-    int n_waves = 4096;
-    bool waves_from_env = false;
+    int waves_per_cu = 0;      // HK_WAVES_PER_CU: fixed number of wave segments per CU (0 = sized from the pass)
+    int stat_rows = 8192;      // DStats rows, indexed by PHYSICAL wave: n_cu * 32 (8 waves x 4 SIMDs is the residency limit)
     DevBuf sobol, cie, r2s_scale, r2s_coeffs, stats;
     DTables tables{};
     bool have_tables = false;
@@ -164,16 +164,11 @@ extern "C" int32_t hk_ctx_create(int32_t device_id, void* stream, hk_ctx** out) 
     HIP_TRY(hipGetDeviceProperties(&prop, device_id));
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     {
-        // W virtual wave segments (queues are split W ways; kernels walk them with however many waves are resident)
-        int per_cu = 16;
-        if (const char* e = std::getenv("HK_WAVES_PER_CU")) {
-            per_cu = std::atoi(e) > 0 ? std::atoi(e) : 16;
-            c->waves_from_env = true;
-        }
-        c->n_waves = c->n_cu * per_cu;
+        if (const char* e = std::getenv("HK_WAVES_PER_CU")) c->waves_per_cu = std::atoi(e) > 0 ? std::atoi(e) : 0;
+        c->stat_rows = c->n_cu * 32;
     }
     {
-        std::vector<DStats> zero((size_t)c->n_waves * 2);  // rows are indexed by physical wave; media scenes run up to 2 * n_waves of them
+        std::vector<DStats> zero((size_t)c->stat_rows);
         std::memset(zero.data(), 0, zero.size() * sizeof(DStats));
         HIP_TRY(c->stats.upload(zero.data(), zero.size() * sizeof(DStats)));
     }
@@ -699,6 +694,7 @@ extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene**
     D.n_envmaps = d->n_envmaps;
     D.has_escape_lights = has_escape;
     D.all_opaque = all_opaque ? 1 : 0;
+    D.bvh_depth = bvh.max_depth;
     *out = s;
     return HK_OK;
 }
@@ -948,16 +944,24 @@ hipError_t alloc_arr(hk_integrator* I, T*& dst, size_t n) {
     dst = b->as<T>();
     return e;
 }
-// W virtual wave segments: ctx->n_waves for surface scenes; twice as many (finer, ticket-scheduled segments) when the scene has
-// media, where the work per segment is very uneven.  stats rows are indexed by PHYSICAL wave (< ctx->n_waves * 2 rows allocated).
+// W virtual wave segments: every queue is split W ways and a segment is processed by whichever physical wave draws its ticket,
+// so W is independent of each kernel's residency.  Finer segments balance better (and media / escaping paths make the work
+// per segment very uneven), but every segment should keep >= 16 chunks (1024 paths) so its per-kind queues fill whole waves:
+// W = chunks / 16 clamped to [4, 48] segments per CU (64 with media).  stats rows are indexed by PHYSICAL wave (ctx->stat_rows).
 int ensure_state(hk_integrator* I, int capacity, bool media) {
-    const int W_want = I->ctx->n_waves * ((media && !I->ctx->waves_from_env) ? 2 : 1);
-    if (I->st_capacity >= capacity && I->st_depth >= I->p.max_depth && I->st.n_waves == W_want) return HK_OK;
+    const int n_cu = I->ctx->n_cu;
+    const long cap_per_cu = media ? 64 : 48;   // the media kernels draw tickets and their segments are the most uneven: finer
+    long W_want = ((long)(capacity + 63) / 64) / 16;
+    if (W_want < 4L * n_cu) W_want = 4L * n_cu;
+    if (W_want > cap_per_cu * n_cu) W_want = cap_per_cu * n_cu;
+    if (I->ctx->waves_per_cu > 0) W_want = (long)I->ctx->waves_per_cu * n_cu;
+    W_want = (W_want + 3) / 4 * 4;
+    if (I->st_capacity >= capacity && I->st_depth >= I->p.max_depth && I->st.n_waves == (int)W_want) return HK_OK;
     for (auto* b : I->bufs) delete b;
     I->bufs.clear();
     DPathState& s = I->st;
     size_t P = (size_t)capacity;
-    const int W = W_want;
+    const int W = (int)W_want;
     const int chunks = (capacity + 63) / 64;
     s.capacity = capacity;
     s.n_waves = W;
@@ -986,7 +990,8 @@ int ensure_state(hk_integrator* I, int capacity, bool media) {
     HIP_TRY(alloc_arr(I, s.escaped_q, Q));
     HIP_TRY(alloc_arr(I, s.medium_q, Q));
     HIP_TRY(alloc_arr(I, s.scatter_q, Q));
-    HIP_TRY(alloc_arr(I, s.tickets, (size_t)(I->p.max_depth + 2) * 2));
+    s.ticket_rows = I->p.max_depth + 2;
+    HIP_TRY(alloc_arr(I, s.tickets, (size_t)s.ticket_rows * HK_TICKET_COLS));
     HIP_TRY(alloc_arr(I, s.initial_medium, 1));
     HIP_TRY(hipMemset(s.initial_medium, 0xff, sizeof(int)));
     HIP_TRY(alloc_arr(I, s.mat_q, Q * HK_MAX_KINDS));
@@ -1128,7 +1133,7 @@ extern "C" int32_t hk_render(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_film*
             }
             return HK_OK;
         };
-        if (sc->d.n_media > 0 || !sc->d.all_opaque) HIP_TRY(hipMemsetAsync(I->st.tickets, 0, (size_t)(I->p.max_depth + 2) * 2 * sizeof(int), s));
+        HIP_TRY(hipMemsetAsync(I->st.tickets, 0, (size_t)I->st.ticket_rows * HK_TICKET_COLS * sizeof(int), s));
         if (timed(3, [&] { hk::launch_camera(s, c->n_cu, I->st, fr, c->tables, I->filter, dc, sob, -1); }) != HK_OK) return fail(HK_ERR_DEVICE, "event record failed");
         for (int depth = 0; depth < I->p.max_depth; ++depth) {
             timed(0, [&] { hk::launch_trace(s, trace_blocks, I->st, sc->d, c->tables, fr, depth, dstats); });
@@ -1191,7 +1196,7 @@ extern "C" int32_t hk_stats_reset(hk_ctx* c) {
     if (!c) return fail(HK_ERR_INVALID, "null ctx");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemset(c->stats.p, 0, (size_t)c->n_waves * 2 * sizeof(DStats)));
+    HIP_TRY(hipMemset(c->stats.p, 0, (size_t)c->stat_rows * sizeof(DStats)));
     for (auto& e : c->trace_events) {
         c->event_pool.push_back(e.first);
         c->event_pool.push_back(e.second);
@@ -1215,7 +1220,7 @@ extern "C" int32_t hk_stats_get(hk_ctx* c, hk_stats* out) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     DStats h{};
     {
-        std::vector<DStats> rows((size_t)c->n_waves * 2);
+        std::vector<DStats> rows((size_t)c->stat_rows);
         HIP_TRY(hipMemcpy(rows.data(), c->stats.p, rows.size() * sizeof(DStats), hipMemcpyDeviceToHost));
         for (const DStats& r : rows) {
             h.rays_closest += r.rays_closest;

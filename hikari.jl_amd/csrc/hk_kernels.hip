@@ -34,15 +34,27 @@ __device__ __forceinline__ int global_wave() { return (int)(blockIdx.x * (blockD
 __device__ __forceinline__ int physical_waves() { return (int)(gridDim.x * (blockDim.x >> 6)); }
 // A kernel is launched with as many physical waves as are resident for ITS register/LDS budget; each physical
 // wave walks the virtual wave segments v = p, p + P, p + 2P, ... so all kernels share the same W segments.
-#define HK_FOR_EACH_WAVE_SEGMENT(gw, st) for (int gw = global_wave(); gw < (st).n_waves; gw += physical_waves())
-// Media kernels: the work per segment is wildly uneven (a tile that looks into a cloud vs one that sees the sky), so segments
-// are handed to physical waves through a ticket (one atomic per SEGMENT, a few thousand per launch) instead of round-robin.
+// Segments are handed to physical waves through a ticket (one atomic per SEGMENT, a few thousand per launch) instead of
+// round-robin: residency differs per kernel (12 .. 28 waves per CU) and W is rarely a multiple of it, so a static stride leaves
+// a tail round with a fraction of the waves busy (shade at W = 16/CU, 12 resident: 12 % slower than at W = 24); in media
+// scenes the work per segment is wildly uneven on top (a tile that looks into a cloud vs one that sees the sky).
 __device__ __forceinline__ int next_segment(int* ticket) {
     int v = 0;
     if (lane_id() == 0) v = atomicAdd(ticket, 1);
     return __builtin_amdgcn_readfirstlane(v);
 }
 #define HK_FOR_EACH_WAVE_SEGMENT_DYNAMIC(gw, st, ticket) for (int gw = next_segment(ticket); gw < (st).n_waves; gw = next_segment(ticket))
+#ifndef HK_STATIC_SEGMENTS
+#define HK_STATIC_SEGMENTS 1
+#endif
+#if HK_STATIC_SEGMENTS
+#define HK_FOR_EACH_WAVE_SEGMENT(gw, st, ticket) for (int gw = global_wave(); gw < (st).n_waves; gw += physical_waves())
+#else
+#define HK_FOR_EACH_WAVE_SEGMENT(gw, st, ticket) HK_FOR_EACH_WAVE_SEGMENT_DYNAMIC(gw, st, ticket)
+#endif
+// ticket words: row = bounce depth (row max_depth + 1: camera / film), column = kernel
+enum { TK_TRACE = 0, TK_TRACK = 1, TK_SHADOW = 2, TK_ESCAPED = 3, TK_SCATTER = 4, TK_SHADE0 = 5, TK_CAMERA = 0, TK_FILM = 1 };
+__device__ __forceinline__ int* ticket_ptr(const DPathState& st, int row, int col) { return st.tickets + row * HK_TICKET_COLS + col; }
 __device__ __forceinline__ WaveQ wq_open(uint32_t* q, const DPathState& st, int gw) { return WaveQ{q + (size_t)gw * st.wave_cap, 0}; }
 __device__ __forceinline__ void wq_push(WaveQ& q, uint32_t value, bool active) {
     unsigned long long mask = __ballot(active);
@@ -95,7 +107,7 @@ __global__ void __launch_bounds__(256) k_sobol_table(DSobol sob, DFrame fr, uint
 __global__ void __launch_bounds__(256) k_camera(DPathState st, DFrame fr, DTables T, DFilter flt, DCamera cam, DSobol sob, int initial_medium) {
     const int total = fr.n_pixels_padded * fr.samples_in_pass;
     const int n_chunks = total >> 6;
-    HK_FOR_EACH_WAVE_SEGMENT(gw, st) {
+    HK_FOR_EACH_WAVE_SEGMENT(gw, st, ticket_ptr(st, st.ticket_rows - 1, TK_CAMERA)) {
     WaveQ out = wq_open(st.ray_q[0], st, gw);
     // wave w generates chunks w, w+W, w+2W, ... (8x8 pixel tiles interleaved across waves for load balance)
     for (int chunk = gw; chunk < n_chunks; chunk += st.n_waves) {
@@ -153,7 +165,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace(DPathState st, DScene 
     int* stack = lds_stack + (threadIdx.x >> 6) * (HK_LDS_STACK * 64);
     const int lane = lane_id();
     unsigned n_nodes = 0, n_tris = 0, n_casts = 0, n_hits = 0;
-    HK_FOR_EACH_WAVE_SEGMENT(gw, st) {
+    HK_FOR_EACH_WAVE_SEGMENT(gw, st, ticket_ptr(st, depth, TK_TRACE)) {
     const uint32_t* __restrict__ queue = st.ray_q[depth & 1] + (size_t)gw * st.wave_cap;
     const int n = *count_ptr(st, depth, Q_RAY, gw);
     WaveQ q_escaped = wq_open(st.escaped_q, st, gw);
@@ -365,15 +377,17 @@ HKD void lane_ray_round(LaneRay& r, bool active, const DScene& sc, int* __restri
 
 enum { LR_EMPTY = 0, LR_ACTIVE = 1 };
 
-template <bool COUNT>
+// STACK: LDS stack entries per lane.  The stack holds at most one entry per inner level, so a BVH of depth <= 16 (every scene
+// but the 10^6-triangle one) runs with half the LDS: 16 KB per block instead of 32, and LDS stops limiting residency.
+template <bool COUNT, int STACK>
 __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace_lean(DPathState st, DScene sc, int depth, DStats* stats) {
-    __shared__ int lds_stack[(HK_TRACE_BLOCK / 64) * HK_LDS_STACK * 64];
-    int* stack = lds_stack + (threadIdx.x >> 6) * (HK_LDS_STACK * 64);
+    __shared__ int lds_stack[(HK_TRACE_BLOCK / 64) * STACK * 64];
+    int* stack = lds_stack + (threadIdx.x >> 6) * (STACK * 64);
     const int lane = lane_id();
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const int DONE = (int)0x80000000;
     unsigned n_nodes = 0, n_tris = 0, n_casts = 0, n_hits = 0;
-    HK_FOR_EACH_WAVE_SEGMENT(gw, st) {
+    HK_FOR_EACH_WAVE_SEGMENT(gw, st, ticket_ptr(st, depth, TK_TRACE)) {
     const uint32_t* __restrict__ queue = st.ray_q[depth & 1] + (size_t)gw * st.wave_cap;
     const int n = *count_ptr(st, depth, Q_RAY, gw);
     WaveQ q_escaped = wq_open(st.escaped_q, st, gw);
@@ -483,7 +497,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
     const int lane = lane_id();
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     unsigned n_coll = 0;
-    HK_FOR_EACH_WAVE_SEGMENT_DYNAMIC(gw, st, st.tickets + 2 * depth) {
+    HK_FOR_EACH_WAVE_SEGMENT_DYNAMIC(gw, st, ticket_ptr(st, depth, TK_TRACK)) {
         const uint32_t* __restrict__ queue = st.medium_q + (size_t)gw * st.wave_cap;
         const int n = *count_ptr(st, depth, Q_MEDIUM, gw);
         WaveQ q_escaped = wq_open(st.escaped_q, st, gw);
@@ -697,7 +711,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
 // ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_scatter(DPathState st, DScene sc, DTables T, DFrame fr, DSobol sob, int depth, DStats* stats) {
     unsigned n_lnodes = 0;
-    HK_FOR_EACH_WAVE_SEGMENT(gw, st) {
+    HK_FOR_EACH_WAVE_SEGMENT(gw, st, ticket_ptr(st, depth, TK_SCATTER)) {
         const uint32_t* __restrict__ queue = st.scatter_q + (size_t)gw * st.wave_cap;
         const int n = *count_ptr(st, depth, Q_SCATTER, gw);
         WaveQ q_shadow = wq_open(st.shadow_q, st, gw);
@@ -798,7 +812,7 @@ __global__ void __launch_bounds__(64) k_detect_camera_medium(DPathState st, DSce
 // K7: escaped rays (intersection.jl:622-678; lights.jl:408-467).  MIS uses 1/num_lights (Q6).
 // ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_escaped(DPathState st, DScene sc, DTables T, int depth) {
-    HK_FOR_EACH_WAVE_SEGMENT(gw, st) {
+    HK_FOR_EACH_WAVE_SEGMENT(gw, st, ticket_ptr(st, depth, TK_ESCAPED)) {
     const uint32_t* __restrict__ queue = st.escaped_q + (size_t)gw * st.wave_cap;
     const int n = *count_ptr(st, depth, Q_ESCAPED, gw);
     for (int i = lane_id(); i < n; i += 64) {
@@ -867,7 +881,7 @@ template <int KIND>
 __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_per_eu(ShadeWaves<KIND>::value))) k_shade(DPathState st, DScene sc, DTables T, DFrame fr, DSobol sob, int depth, int first_kind, DStats* stats) {
     const int lane = lane_id();
     unsigned n_vertices = 0, n_lnodes = 0;
-    HK_FOR_EACH_WAVE_SEGMENT(gw, st) {
+    HK_FOR_EACH_WAVE_SEGMENT(gw, st, ticket_ptr(st, depth, TK_SHADE0 + KIND)) {
     const uint32_t* __restrict__ queue = st.mat_q + ((size_t)KIND * st.n_waves + gw) * st.wave_cap;
     const int n = *count_ptr(st, depth, Q_MAT0 + KIND, gw);
     // several kinds append to the same shadow / next-ray segments: continue from the counts left by the kinds before
@@ -1035,15 +1049,15 @@ HKD void shadow_contribute(DPathState& st, uint32_t slot, S4 T_ray, S4 tr_u, S4 
     }
 }
 
-template <bool COUNT>
+template <bool COUNT, int STACK>
 __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_shadow(DPathState st, DScene sc, int depth, DStats* stats) {
-    __shared__ int lds_stack[(HK_TRACE_BLOCK / 64) * HK_LDS_STACK * 64];
-    int* stack = lds_stack + (threadIdx.x >> 6) * (HK_LDS_STACK * 64);
+    __shared__ int lds_stack[(HK_TRACE_BLOCK / 64) * STACK * 64];
+    int* stack = lds_stack + (threadIdx.x >> 6) * (STACK * 64);
     const int lane = lane_id();
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const int DONE = (int)0x80000000;
     unsigned n_nodes = 0, n_tris = 0, n_casts = 0, n_hits = 0;
-    HK_FOR_EACH_WAVE_SEGMENT(gw, st) {
+    HK_FOR_EACH_WAVE_SEGMENT(gw, st, ticket_ptr(st, depth, TK_SHADOW)) {
     const uint32_t* __restrict__ queue = st.shadow_q + (size_t)gw * st.wave_cap;
     const int n = *count_ptr(st, depth, Q_SHADOW, gw);
     int cursor = 0;
@@ -1104,7 +1118,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
     const int lane = lane_id();
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     unsigned n_nodes = 0, n_tris = 0, n_casts = 0, n_hits = 0, n_coll = 0;
-    HK_FOR_EACH_WAVE_SEGMENT_DYNAMIC(gw, st, st.tickets + 2 * depth + 1) {
+    HK_FOR_EACH_WAVE_SEGMENT_DYNAMIC(gw, st, ticket_ptr(st, depth, TK_SHADOW)) {
     const uint32_t* __restrict__ queue = st.shadow_q + (size_t)gw * st.wave_cap;
     const int n = *count_ptr(st, depth, Q_SHADOW, gw);
     int cursor = 0;
@@ -1588,9 +1602,24 @@ static int resident_blocks(K kernel, int block, int n_cu, int cap_per_cu) {
     if (per_cu > cap_per_cu) per_cu = cap_per_cu;
     return per_cu * n_cu;
 }
+// Segments are walked with a static stride, so the number of physical waves must DIVIDE W or the last round runs with a
+// fraction of the waves (shade at W = 16/CU with 12 resident: 12 % slower than at W = 24): the largest divisor of the
+// 4-wave block count that is resident.
 static int clamp_blocks(int blocks, const DPathState& st) {
-    int maxb = st.n_waves / 4;
-    return blocks > maxb ? maxb : blocks;
+    const int units = st.n_waves / 4;
+    if (blocks >= units) return units;
+#if HK_STATIC_SEGMENTS
+    int best = 1;
+    for (int b = blocks; b >= 1; --b)
+        if (units % b == 0) {
+            best = b;
+            break;
+        }
+    // a divisor far below residency wastes more than the tail round it avoids
+    return best * 4 >= blocks * 3 ? best : blocks;
+#else
+    return blocks;
+#endif
 }
 
 void launch_camera(hipStream_t s, int n_cu, const DPathState& st, const DFrame& fr, const DTables& T, const DFilter& f, const DCamera& c, const DSobol& sob, int initial_medium) {
@@ -1599,11 +1628,20 @@ void launch_camera(hipStream_t s, int n_cu, const DPathState& st, const DFrame& 
 }
 void launch_trace(hipStream_t s, int n_cu, const DPathState& st, const DScene& sc, const DTables& T, const DFrame& fr, int depth, DStats* stats) {
     if (sc.all_opaque && sc.n_media == 0) {
-        static int l0 = resident_blocks(k_trace_lean<false>, HK_TRACE_BLOCK, n_cu, 8), l1 = resident_blocks(k_trace_lean<true>, HK_TRACE_BLOCK, n_cu, 8);
-        if (fr.count_nodes)
-            hipLaunchKernelGGL(k_trace_lean<true>, dim3(clamp_blocks(l1, st)), dim3(HK_TRACE_BLOCK), 0, s, st, sc, depth, stats);
-        else
-            hipLaunchKernelGGL(k_trace_lean<false>, dim3(clamp_blocks(l0, st)), dim3(HK_TRACE_BLOCK), 0, s, st, sc, depth, stats);
+#define HK_LEAN_LAUNCH(K, C, S)                                                                                       \
+    {                                                                                                                 \
+        static int blocks = resident_blocks(K<C, S>, HK_TRACE_BLOCK, n_cu, 8);                                         \
+        hipLaunchKernelGGL((K<C, S>), dim3(clamp_blocks(blocks, st)), dim3(HK_TRACE_BLOCK), 0, s, st, sc, depth, stats); \
+    }
+#define HK_LEAN_DISPATCH(K)                                        \
+    if (sc.bvh_depth <= 16) {                                      \
+        if (fr.count_nodes) HK_LEAN_LAUNCH(K, true, 16)            \
+        else HK_LEAN_LAUNCH(K, false, 16)                          \
+    } else {                                                       \
+        if (fr.count_nodes) HK_LEAN_LAUNCH(K, true, HK_LDS_STACK)  \
+        else HK_LEAN_LAUNCH(K, false, HK_LDS_STACK)                \
+    }
+        HK_LEAN_DISPATCH(k_trace_lean)
         return;
     }
     static int b0 = resident_blocks(k_trace<false>, HK_TRACE_BLOCK, n_cu, 8), b1 = resident_blocks(k_trace<true>, HK_TRACE_BLOCK, n_cu, 8);
@@ -1619,11 +1657,7 @@ static int media_mask_class(const DScene& sc) {
 }
 void launch_shadow(hipStream_t s, int n_cu, const DPathState& st, const DScene& sc, const DTables& T, const DFrame& fr, int depth, DStats* stats) {
     if (sc.all_opaque && sc.n_media == 0) {
-        static int b0 = resident_blocks(k_shadow<false>, HK_TRACE_BLOCK, n_cu, 8), b1 = resident_blocks(k_shadow<true>, HK_TRACE_BLOCK, n_cu, 8);
-        if (fr.count_nodes)
-            hipLaunchKernelGGL(k_shadow<true>, dim3(clamp_blocks(b1, st)), dim3(HK_TRACE_BLOCK), 0, s, st, sc, depth, stats);
-        else
-            hipLaunchKernelGGL(k_shadow<false>, dim3(clamp_blocks(b0, st)), dim3(HK_TRACE_BLOCK), 0, s, st, sc, depth, stats);
+        HK_LEAN_DISPATCH(k_shadow)
         return;
     }
 #define HK_SHADOW_LAUNCH(C, MM)                                                                                                        \

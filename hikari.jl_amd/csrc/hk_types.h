@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#define HK_TICKET_COLS 16       // kernels per bounce that draw segment tickets (5 + HK_MAX_KINDS)
 #define HK_MAX_KINDS 11          // HK_MAT_* count (Mix is resolved before queueing)
 #ifndef HK_LDS_STACK
 #define HK_LDS_STACK 32          // per-lane traversal stack entries kept in LDS (builder bounds the depth)
@@ -154,6 +155,7 @@ struct DScene {
     int n_envmaps;
     int has_escape_lights;      // any ambient / environment light
     int all_opaque;             // no medium transitions and no alpha-tested surfaces
+    int bvh_depth;              // deepest BVH level (bounds the traversal stack)
 };
 
 struct DTables {
@@ -225,7 +227,8 @@ struct DPathState {
     int* initial_medium;   // camera medium detected on the device (K14)
     uint32_t* mat_q;       // HK_MAX_KINDS * W * wave_cap
     int* counters;         // [(max_depth + 2) * Q_COUNT][W] per-wave queue sizes
-    int* tickets;          // [(max_depth + 2) * 2] segment tickets of the media kernels (dynamic segment -> wave assignment), zeroed per pass
+    int* tickets;          // [ticket_rows * HK_TICKET_COLS] segment tickets (dynamic segment -> wave assignment), one word per launch, zeroed per pass
+    int ticket_rows;       // max_depth + 2
 };
 
 struct DStats {

@@ -67,9 +67,28 @@ def lib():
 
 
 def set_threads(n):
-    lib().hko_set_threads(int(n)) if _lib is not None else None
-    if _lib is None:
-        lib().hko_set_threads(int(n))
+    lib().hko_set_threads(int(n))
+
+
+def available_cores():
+    """Host cores this process may actually use: min(affinity mask, cgroup CPU quota).  A container with a 16-CPU quota on a
+    256-thread host runs 256 oracle threads 10x slower than 16."""
+    import math
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]          # cgroup v2
+        if quota != "max":
+            n = min(n, max(1, math.ceil(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())          # cgroup v1
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                n = min(n, max(1, math.ceil(q / per)))
+        except (OSError, ValueError):
+            pass
+    return max(n, 1)
 
 
 def max_threads():

@@ -8,6 +8,7 @@ from . import _abi, geometry, tables
 from ._lib import HikariMI355XError, LIB_PATH
 from .camera import PerspectiveCamera
 from .envmap import Distribution2D, EnvironmentLight, EnvironmentMap, analytic_sky, rotation_matrix
+from .denoise import DenoiseConfig
 from .film import Film
 from .lights import (AmbientLight, DiffuseAreaLight, DirectionalLight, PointLight, RGBIlluminantSpectrum, SpotLight,
                      SunLight)

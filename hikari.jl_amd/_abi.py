@@ -104,6 +104,10 @@ class hk_postprocess_params(C.Structure):
                 ("imaging_ratio", c_f), ("apply_wb", c_i), ("wb", c_f * 9), ("mask_escaped", c_i), ("bg", c_f * 3)]
 
 
+class hk_denoise_params(C.Structure):
+    _fields_ = [("iterations", c_i), ("sigma_color", c_f), ("sigma_normal", c_f), ("sigma_depth", c_f), ("use_variance", c_i)]
+
+
 class hk_camera(C.Structure):
     _fields_ = [("raster_to_camera", c_f * 16), ("camera_to_world", c_f * 16), ("lens_radius", c_f),
                 ("focal_distance", c_f), ("shutter_open", c_f), ("shutter_close", c_f), ("dx_camera", c_f * 3),
@@ -127,4 +131,5 @@ EXPORTED_SYMBOLS = [
     "hk_film_read_rgb", "hk_film_read_accum", "hk_film_accum_device_ptr", "hk_sync", "hk_stats_get", "hk_stats_reset",
     "hk_stats_enable_counters", "hk_trace_closest", "hk_test_sobol", "hk_test_camera", "hk_test_uplift",
     "hk_test_light_bvh", "hk_test_bsdf", "hk_film_postprocess", "hk_film_fill_aux", "hk_postprocess", "hk_test_light", "hk_scene_bvh_info", "hk_scene_light_bvh_copy",
+    "hk_denoise",
 ]

@@ -54,6 +54,7 @@ def lib():
         "hk_test_light_bvh": ([vp, vp, i32, PF, PF, PF, PI, PF, PI, PF], i32),
         "hk_film_postprocess": ([vp, vp, C.POINTER(A.hk_postprocess_params), PF, PF], i32),
         "hk_postprocess": ([vp, C.POINTER(A.hk_postprocess_params), i32, i32, PF, PF, PF], i32),
+        "hk_denoise": ([vp, C.POINTER(A.hk_denoise_params), i32, i32, PF, PF, PF, PF, PF], i32),
         "hk_film_fill_aux": ([vp, vp, C.POINTER(A.hk_camera), i32, i32, i32, PF, PF, PF], i32),
         "hk_test_light": ([vp, vp, i32, i32, i32, PF, PF, PF, PF], i32),
         "hk_test_bsdf": ([vp, vp, i32, i32, i32, i32, PF, PF, PF, PF, PF, PF, PF], i32),

@@ -34,6 +34,8 @@ void launch_test_uplift(hipStream_t, const DTables&, int, int, const float*, con
 void launch_test_light_bvh(hipStream_t, const DScene&, int, const float*, const float*, const float*, int*, float*, const int*, float*);
 void launch_aux(hipStream_t, const DScene&, const DCamera&, int, int, float, float*, float*, float*);
 void launch_postprocess(hipStream_t, const hk_postprocess_params&, const float*, const float*, float*, int, int);
+void launch_denoise_variance(hipStream_t, const float*, float*, int, int);
+void launch_denoise_atrous(hipStream_t, const hk_denoise_params&, int, const float*, const float*, const float*, const float*, float*, int, int);
 void launch_sobol_table(hipStream_t, const DSobol&, const DFrame&, uint32_t*, int);
 void launch_test_light(hipStream_t, const DScene&, const DTables&, int, int, int, const float*, const float*, const float*, float*);
 void launch_test_bsdf(hipStream_t, const DScene&, const DTables&, int, int, int, int, const float*, const float*, const float*, const float*, const float*, const float*, float*);
@@ -932,6 +934,32 @@ extern "C" int32_t hk_postprocess(hk_ctx* c, const hk_postprocess_params* P, int
     DevBuf in, out;
     HIP_TRY(in.upload(src, (size_t)3 * w * h * 4));
     return run_postprocess(c, P, w, h, in.as<float>(), depth, dst, out);
+}
+
+extern "C" int32_t hk_denoise(hk_ctx* c, const hk_denoise_params* P, int32_t w, int32_t h, const float* src, const float* normal, const float* depth, float* dst,
+                              float* src_after) {
+    if (!c || !P || !src || !normal || !depth || !dst || w <= 0 || h <= 0) return fail(HK_ERR_INVALID, "bad argument");
+    if (P->iterations < 0 || P->iterations > 30) return fail(HK_ERR_INVALID, "iterations out of range");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t npx = (size_t)w * h;
+    DevBuf a, b, nn, dd, var;
+    HIP_TRY(a.upload(src, npx * 12));
+    HIP_TRY(b.alloc(npx * 12));
+    HIP_TRY(nn.upload(normal, npx * 12));
+    HIP_TRY(dd.upload(depth, npx * 4));
+    HIP_TRY(var.alloc(npx * 4));
+    if (P->use_variance) hk::launch_denoise_variance(c->stream, a.as<float>(), var.as<float>(), h, w);
+    for (int i = 1; i <= P->iterations; ++i) {   // odd passes a -> b, even passes b -> a (denoise.jl:337-361)
+        const float* in = (i & 1) ? a.as<float>() : b.as<float>();
+        float* out = (i & 1) ? b.as<float>() : a.as<float>();
+        hk::launch_denoise_atrous(c->stream, *P, 1 << (i - 1), in, nn.as<float>(), dd.as<float>(), var.as<float>(), out, h, w);
+    }
+    HIP_TRY(hipGetLastError());
+    // film.postprocess <- the last written buffer; with iterations == 0 that is the untouched framebuffer (:365-371)
+    HIP_TRY(hipMemcpyAsync(dst, (P->iterations & 1) ? b.p : a.p, npx * 12, hipMemcpyDeviceToHost, c->stream));
+    if (src_after) HIP_TRY(hipMemcpyAsync(src_after, a.p, npx * 12, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return HK_OK;
 }
 
 // ---- path state -----------------------------------------------------------------------------------------

@@ -1582,6 +1582,74 @@ __global__ void k_test_light_bvh(DScene sc, int n, const float* p3, const float*
 }
 
 // ---------------------------------------------------------------------------------------------------
+// denoise! (src/denoise.jl): 3x3 luminance variance (:236-286) and one a-trous pass (:136-229).  Buffers are Julia [h,w]
+// column-major: linear index i = (col-1)*h + (row-1), exactly the reference's idx -> (row, col) mapping.
+// ---------------------------------------------------------------------------------------------------
+HKD float denoise_luminance(float r, float g, float b) { return 0.2126f * r + 0.7152f * g + 0.0722f * b; }
+__global__ void __launch_bounds__(256) k_denoise_variance(const float* __restrict__ src, float* __restrict__ variance, int h, int w) {
+    const long n = (long)h * w;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        int row = (int)(i % h), col = (int)(i / h);
+        float sum = 0.0f, sum_sq = 0.0f;
+        int count = 0;
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                int qr = row + dy, qc = col + dx;
+                if (qr >= 0 && qr < h && qc >= 0 && qc < w) {
+                    const float* q = src + 3 * ((long)qc * h + qr);
+                    float lum = denoise_luminance(q[0], q[1], q[2]);
+                    sum += lum;
+                    sum_sq += lum * lum;
+                    ++count;
+                }
+            }
+        float mean = sum / (float)count, mean_sq = sum_sq / (float)count;
+        variance[i] = maxf(0.0f, mean_sq - mean * mean);
+    }
+}
+__global__ void __launch_bounds__(256) k_denoise_atrous(hk_denoise_params P, int step, const float* __restrict__ src, const float* __restrict__ normal,
+                                                        const float* __restrict__ depth, const float* __restrict__ variance, float* __restrict__ dst, int h, int w) {
+    const float K1D[5] = {1.0f / 16.0f, 1.0f / 4.0f, 3.0f / 8.0f, 1.0f / 4.0f, 1.0f / 16.0f};
+    const long n = (long)h * w;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        int row = (int)(i % h), col = (int)(i / h);
+        float r_p = src[3 * i], g_p = src[3 * i + 1], b_p = src[3 * i + 2];
+        float lum_p = denoise_luminance(r_p, g_p, b_p);
+        float nx = normal[3 * i], ny = normal[3 * i + 1], nz = normal[3 * i + 2];
+        float d_p = depth[i];
+        float var_p = P.use_variance ? variance[i] : 0.0f;
+        // weight_color's sigma (:76-88) depends on the centre pixel only
+        float sigma_c = var_p > 0.0f ? P.sigma_color * sqrtf(var_p) + 1.0e-4f : P.sigma_color;
+        float sigma_d = P.sigma_depth * (float)step + 1.0e-4f;
+        float sr = 0.0f, sg = 0.0f, sb = 0.0f, sw = 0.0f;
+        for (int dyi = 0; dyi < 5; ++dyi)
+            for (int dxi = 0; dxi < 5; ++dxi) {
+                int qr = row + (dyi - 2) * step, qc = col + (dxi - 2) * step;
+                qr = qr < 0 ? 0 : (qr > h - 1 ? h - 1 : qr);
+                qc = qc < 0 ? 0 : (qc > w - 1 ? w - 1 : qc);
+                long q = (long)qc * h + qr;
+                float r_q = src[3 * q], g_q = src[3 * q + 1], b_q = src[3 * q + 2];
+                float lum_q = denoise_luminance(r_q, g_q, b_q);
+                float w_spatial = K1D[dxi] * K1D[dyi];
+                float w_color = expf(-fabsf(lum_p - lum_q) / sigma_c);
+                float dotv = nx * normal[3 * q] + ny * normal[3 * q + 1] + nz * normal[3 * q + 2];
+                float w_norm = powf(maxf(0.0f, dotv), P.sigma_normal);
+                float w_depth = expf(-fabsf(d_p - depth[q]) / sigma_d);
+                float weight = w_spatial * w_color * w_norm * w_depth;
+                sr += r_q * weight;
+                sg += g_q * weight;
+                sb += b_q * weight;
+                sw += weight;
+            }
+        if (sw > 1.0e-6f) {   // false for NaN (centre depth +Inf against +Inf neighbours): the pixel is kept
+            float inv = 1.0f / sw;
+            dst[3 * i] = sr * inv, dst[3 * i + 1] = sg * inv, dst[3 * i + 2] = sb * inv;
+        } else
+            dst[3 * i] = r_p, dst[3 * i + 1] = g_p, dst[3 * i + 2] = b_p;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // launch wrappers (called from hk_api.cpp)
 // ---------------------------------------------------------------------------------------------------
 namespace hk {
@@ -1837,6 +1905,13 @@ void launch_sobol_table(hipStream_t s, const DSobol& sob, const DFrame& fr, uint
 }
 void launch_postprocess(hipStream_t s, const hk_postprocess_params& P, const float* src, const float* depth, float* dst, int h, int w) {
     hipLaunchKernelGGL(k_postprocess, dim3(grid_for(h * w, 256, 8192)), dim3(256), 0, s, P, src, depth, dst, h, w);
+}
+void launch_denoise_variance(hipStream_t s, const float* src, float* variance, int h, int w) {
+    hipLaunchKernelGGL(k_denoise_variance, dim3(grid_for(h * w, 256, 8192)), dim3(256), 0, s, src, variance, h, w);
+}
+void launch_denoise_atrous(hipStream_t s, const hk_denoise_params& P, int step, const float* src, const float* normal, const float* depth, const float* variance,
+                           float* dst, int h, int w) {
+    hipLaunchKernelGGL(k_denoise_atrous, dim3(grid_for(h * w, 256, 8192)), dim3(256), 0, s, P, step, src, normal, depth, variance, dst, h, w);
 }
 void launch_aux(hipStream_t s, const DScene& sc, const DCamera& cam, int h, int w, float miss_depth, float* albedo, float* normal, float* depth) {
     hipLaunchKernelGGL(k_aux, dim3(grid_for(h * w, HK_TRACE_BLOCK, 2048)), dim3(HK_TRACE_BLOCK), 0, s, sc, cam, h, w, miss_depth, albedo, normal, depth);

@@ -383,6 +383,24 @@ int32_t hk_film_postprocess(hk_ctx* ctx, hk_film* film, const hk_postprocess_par
 int32_t hk_postprocess(hk_ctx* ctx, const hk_postprocess_params* params, int32_t width, int32_t height, const float* src_rgb,
                        const float* depth, float* dst_rgb);
 
+/* ---------------------------------------------------------------------------------------------
+ * denoise!(film; config) (src/denoise.jl:301-376): edge-avoiding a-trous wavelet filter.  compute_variance_kernel! (:236-286,
+ * 3x3 luminance variance, in-bounds neighbours only) when use_variance, then `iterations` passes of atrous_denoise_kernel!
+ * (:136-229; 5x5 B-spline taps at spacing 2^(i-1), clamped to the edge, weights = spatial * colour * normal * depth) ping-ponging
+ * between the framebuffer and a scratch buffer.  All buffers are host arrays in Julia [h,w] layout (rgb / normal 3 floats per
+ * pixel, depth 1).  dst_rgb receives film.postprocess.  The reference's even passes write INTO film.framebuffer, so after
+ * denoise! with iterations >= 2 the framebuffer holds the output of the last even pass: src_after (optional) receives it.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct hk_denoise_params {
+    int32_t iterations;   /* DenoiseConfig defaults (denoise.jl:41-47): 5 */
+    float sigma_color;    /* 4 */
+    float sigma_normal;   /* 128 */
+    float sigma_depth;    /* 1 */
+    int32_t use_variance; /* true */
+} hk_denoise_params;
+int32_t hk_denoise(hk_ctx* ctx, const hk_denoise_params* params, int32_t width, int32_t height, const float* src_rgb, const float* normal,
+                   const float* depth, float* dst_rgb, float* src_after);
+
 /* fill_aux_buffers!(film, scene, camera; has_infinite_lights) (src/film.jl:410-483): one primary ray through every pixel
  * centre; albedo = (0.8,0.8,0.8) on a hit else 0, normal = geometric normal of the hit triangle (Raycore's si.core.n is not
  * available here: normalize((v1-v0) x (v2-v0)), un-flipped) else 0, depth = |hit - ray.o|, else +Inf (or 1e30 when the scene

@@ -1369,6 +1369,80 @@ static float pp_filmic(float x) {
     x = maxf(0.0f, x - 0.004f);
     return (x * (6.2f * x + 0.5f)) / (x * (6.2f * x + 1.7f) + 0.06f);
 }
+// denoise! (src/denoise.jl:301-376): variance (:236-286) + a-trous passes (:136-229), Julia [h,w] buffers; see hk_denoise.
+static inline float dn_lum(float r, float g, float b) { return 0.2126f * r + 0.7152f * g + 0.0722f * b; }
+int32_t hko_denoise(const hk_denoise_params* Pp, int32_t w, int32_t h, const float* src, const float* normal, const float* depth, float* dst, float* src_after) {
+    const hk_denoise_params& P = *Pp;
+    const long n = (long)h * w;
+    std::vector<float> a(src, src + 3 * n), b(3 * n, 0.0f), var(n, 0.0f);
+    if (P.use_variance) {
+#pragma omp parallel for schedule(static)
+        for (long i = 0; i < n; ++i) {
+            int row = (int)(i % h), col = (int)(i / h);
+            float sum = 0.0f, sum_sq = 0.0f;
+            int count = 0;
+            for (int dy = -1; dy <= 1; ++dy)
+                for (int dx = -1; dx <= 1; ++dx) {
+                    int qr = row + dy, qc = col + dx;
+                    if (qr >= 0 && qr < h && qc >= 0 && qc < w) {
+                        const float* q = &a[3 * ((long)qc * h + qr)];
+                        float lum = dn_lum(q[0], q[1], q[2]);
+                        sum += lum;
+                        sum_sq += lum * lum;
+                        ++count;
+                    }
+                }
+            float mean = sum / (float)count, mean_sq = sum_sq / (float)count;
+            var[i] = maxf(0.0f, mean_sq - mean * mean);
+        }
+    }
+    const float K1D[5] = {1.0f / 16.0f, 1.0f / 4.0f, 3.0f / 8.0f, 1.0f / 4.0f, 1.0f / 16.0f};
+    for (int it = 1; it <= P.iterations; ++it) {
+        const int step = 1 << (it - 1);
+        const std::vector<float>& in = (it & 1) ? a : b;
+        std::vector<float>& out = (it & 1) ? b : a;
+#pragma omp parallel for schedule(static)
+        for (long i = 0; i < n; ++i) {
+            int row = (int)(i % h), col = (int)(i / h);
+            float r_p = in[3 * i], g_p = in[3 * i + 1], b_p = in[3 * i + 2];
+            float lum_p = dn_lum(r_p, g_p, b_p);
+            float nx = normal[3 * i], ny = normal[3 * i + 1], nz = normal[3 * i + 2];
+            float d_p = depth[i];
+            float var_p = P.use_variance ? var[i] : 0.0f;
+            float sr = 0.0f, sg = 0.0f, sb = 0.0f, sw = 0.0f;
+            for (int dyi = 0; dyi < 5; ++dyi)
+                for (int dxi = 0; dxi < 5; ++dxi) {
+                    int qr = row + (dyi - 2) * step, qc = col + (dxi - 2) * step;
+                    qr = std::min(std::max(qr, 0), h - 1);
+                    qc = std::min(std::max(qc, 0), w - 1);
+                    long q = (long)qc * h + qr;
+                    float r_q = in[3 * q], g_q = in[3 * q + 1], b_q = in[3 * q + 2];
+                    float lum_q = dn_lum(r_q, g_q, b_q);
+                    float w_spatial = K1D[dxi] * K1D[dyi];
+                    float diff = std::fabs(lum_p - lum_q);
+                    float eff = var_p > 0.0f ? P.sigma_color * std::sqrt(var_p) + 1.0e-4f : P.sigma_color;   // weight_color :76-88
+                    float w_color = std::exp(-diff / eff);
+                    float dotv = nx * normal[3 * q] + ny * normal[3 * q + 1] + nz * normal[3 * q + 2];
+                    float w_norm = std::pow(maxf(0.0f, dotv), P.sigma_normal);                                    // weight_normal :96-103
+                    float w_depth = std::exp(-std::fabs(d_p - depth[q]) / (P.sigma_depth * (float)step + 1.0e-4f));  // weight_depth :111-118
+                    float weight = w_spatial * w_color * w_norm * w_depth;
+                    sr += r_q * weight;
+                    sg += g_q * weight;
+                    sb += b_q * weight;
+                    sw += weight;
+                }
+            if (sw > 1.0e-6f) {
+                float inv = 1.0f / sw;
+                out[3 * i] = sr * inv, out[3 * i + 1] = sg * inv, out[3 * i + 2] = sb * inv;
+            } else
+                out[3 * i] = r_p, out[3 * i + 1] = g_p, out[3 * i + 2] = b_p;
+        }
+    }
+    const std::vector<float>& last = (P.iterations & 1) ? b : a;
+    std::memcpy(dst, last.data(), sizeof(float) * 3 * n);
+    if (src_after) std::memcpy(src_after, a.data(), sizeof(float) * 3 * n);
+    return 0;
+}
 int32_t hko_postprocess(const hk_postprocess_params* Pp, int32_t w, int32_t h, const float* src, const float* depth, float* dst) {
     const hk_postprocess_params& P = *Pp;
     const long n = (long)h * w;

@@ -38,6 +38,7 @@ def lib():
         L.hko_light_bvh.argtypes = [vp, i32, PF, PF, PF, PI, PF, PI, PF]
         L.hko_fill_aux.argtypes = [vp, C.POINTER(A.hk_camera), i32, i32, i32, PF, PF, PF]
         L.hko_postprocess.argtypes = [C.POINTER(A.hk_postprocess_params), i32, i32, PF, PF, PF]
+        L.hko_denoise.argtypes = [C.POINTER(A.hk_denoise_params), i32, i32, PF, PF, PF, PF, PF]
         L.hko_light.argtypes = [vp, i32, i32, i32, PF, PF, PF, PF]
         L.hko_bsdf.argtypes = [vp, i32, i32, i32, i32, PF, PF, PF, PF, PF, PF, PF]
         L.hko_light_bvh_copy.argtypes = [vp, PI, PF, C.POINTER(C.c_uint32)]
@@ -227,6 +228,17 @@ def uplift(mode, rgb, lam):
     out = np.empty_like(lam)
     lib().hko_uplift(C.byref(t["struct"]), mode, rgb.shape[0], _pf(rgb), _pf(lam), _pf(out))
     return out
+
+
+def denoise(params, framebuffer, normal, depth):
+    """denoise! on framebuffer / film.normal [h, w, 3] and film.depth [h, w] -> (film.postprocess, framebuffer after the call)"""
+    h, w = framebuffer.shape[:2]
+    src = np.ascontiguousarray(np.transpose(framebuffer, (1, 0, 2)), np.float32)       # Julia [h,w] column-major
+    nn = np.ascontiguousarray(np.transpose(normal, (1, 0, 2)), np.float32)
+    dp = np.ascontiguousarray(np.transpose(depth, (1, 0)), np.float32)
+    dst, after = np.empty_like(src), np.empty_like(src)
+    lib().hko_denoise(C.byref(params), w, h, _pf(src), _pf(nn), _pf(dp), _pf(dst), _pf(after))
+    return np.transpose(dst, (1, 0, 2)).copy(), np.transpose(after, (1, 0, 2)).copy()
 
 
 def postprocess(params, framebuffer, depth=None):

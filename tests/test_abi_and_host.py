@@ -46,6 +46,9 @@ def test_missing_gpu_or_library_fails_loudly(hk):
     L = hk._lib.lib()
     h = C.c_void_p()
     st = L.hk_ctx_create(0, None, C.byref(h))
+    if st == 0:                      # a device the HIP runtime sees even though torch does not
+        L.hk_ctx_destroy(h)
+        pytest.skip("GPU present")
     assert st != 0 and L.hk_last_error()
     with pytest.raises(hk.HikariMI355XError):
         from hikari_jl_amd import scenes

@@ -390,6 +390,37 @@ def test_progressive_and_sharded_rendering(hk):
     vp2.close()
 
 
+def test_converged_image_within_mc_variance(hk, oracle):
+    """SURVEY 8(d) converged-image check: a 256-spp GPU frame of sample indices the oracle never saw (1025..1280) against the
+    oracle's 1024-spp frame (indices 1..1024).  Both estimate the same image, so their relMSE is var/256 + var/1024; var/256 is
+    measured on the oracle itself (its two 512-sample halves differ by var/512 + var/512).  Bound: 2 x that figure."""
+    from hikari_jl_amd import scenes
+    w = h = 32
+    kw = dict(max_depth=6, samples=1024)
+    s, film, cam = scenes.cornell_box(w, h, light="area")
+    p = hk.integrator_params(**kw)
+    osc = oracle.OracleScene(s)
+    a1, _ = osc.render(p, cam, w, h, 512, first=1)
+    a2, _ = osc.render(p, cam, w, h, 512, first=513)
+    half1, half2 = oracle.finalize(a1, w, h), oracle.finalize(a2, w, h)
+    ref = oracle.finalize(a1 + a2, w, h)
+    vp = hk.VolPath(**kw)
+    vp._ensure(film)
+    vp.clear()
+    vp.render_samples(s, film, cam, 256, stride=1, first=1025, readback=True)
+    gpu = film.framebuffer.copy()
+    vp.close()
+    osc.close()
+    def rel_mse(a, b):
+        return float(np.mean((a - b) ** 2 / (b ** 2 + 1e-3)))
+    var_256 = rel_mse(half1, half2)
+    got = rel_mse(gpu, ref)
+    assert np.isfinite(gpu).all() and var_256 > 0
+    assert got <= 2.0 * var_256, (got, var_256)
+    # and no bias: the mean radiance agrees within 3 standard errors of the 256-sample mean
+    assert abs(gpu.mean() - ref.mean()) <= 3.0 * np.sqrt(var_256 / gpu.size) * max(ref.mean(), 1e-3) + 1e-3 * ref.mean()
+
+
 def test_full_size_properties(hk):
     """BASELINE config 2 at full size (800x800, depth 8) on a few samples: size-independent properties —
     finite, non-negative, deterministic re-render, weight sum == spp * filter integral."""

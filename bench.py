@@ -165,7 +165,7 @@ def main():
         achieved = alg_bytes / n_launch / avg_s / 1e9 if avg_s > 0 else 0.0
         traffic = None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.isfile(pmc_path):
+        if os.path.isfile(pmc_path) and args.config == "cornell" and SPP_PER_STEP == 64:   # the PMC passes were taken on this workload
             try:
                 traffic = json.load(open(pmc_path)).get({"trace": "k_trace", "shadow": "k_shadow", "shade": "k_shade"}[dom], {}).get("hbm_bytes_per_launch")
             except Exception:

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -55,7 +56,7 @@ struct Builder {
     std::vector<int> idx;
     BVH& out;
     int max_depth_seen = 0;
-    static constexpr int LEAF = 4;
+    int LEAF = 4;
     static constexpr int NBINS = 16;
     static constexpr int DEPTH_BUDGET = 30;  // < HK_LDS_STACK
 
@@ -71,7 +72,7 @@ struct Builder {
         }
     }
     // levels a median-split subtree with `count` triangles still needs (leaf capacity LEAF)
-    static int levels_needed(int count) { return count <= LEAF ? 0 : ceil_log2((count + LEAF - 1) / LEAF); }
+    int levels_needed(int count) const { return count <= LEAF ? 0 : ceil_log2((count + LEAF - 1) / LEAF); }
 
     int make_leaf(int first, int count) {
         int start = (int)out.leaf_prims.size();
@@ -182,6 +183,7 @@ void build_bvh(const float* positions, int n_tris, BVH& out) {
     out.root_ref = ~0;  // empty leaf marker handled by n_tris == 0
     if (n_tris <= 0) return;
     Builder b(positions, n_tris, out);
+    if (const char* e = std::getenv("HK_BVH_LEAF")) b.LEAF = std::atoi(e) >= 1 && std::atoi(e) <= 8 ? std::atoi(e) : 4;
     Box box;
     out.root_ref = b.build(0, n_tris, 0, box);
     out.max_depth = b.max_depth_seen;

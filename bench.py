@@ -92,7 +92,9 @@ def main():
     n_pix = W * H
     # film accumulators live in a torch tensor so torch.distributed (RCCL) can reduce them in place
     accum = torch.zeros(4 * n_pix, dtype=torch.float32, device="cuda")
-    vp = hk.VolPath(max_depth=DEPTH, samples=FULL_SPP, samples_per_pass=SPP_PER_STEP, device=local_rank)
+    # `samples` only sizes the ZSobol index (log2 of max(samples, 4096)): cover every sample index this run touches
+    vp = hk.VolPath(max_depth=DEPTH, samples=max(FULL_SPP, SPP_PER_STEP * max(args.steps, args.warmup, 1) * world), samples_per_pass=SPP_PER_STEP,
+                    device=local_rank)
     vp.use_external_accumulators(accum.data_ptr())
     vp._ensure(film)
     L = hk._lib.lib()

@@ -975,15 +975,16 @@ hipError_t alloc_arr(hk_integrator* I, T*& dst, size_t n) {
 // W virtual wave segments: every queue is split W ways and a segment is processed by whichever physical wave draws its ticket,
 // so W is independent of each kernel's residency.  Finer segments balance better (and media / escaping paths make the work
 // per segment very uneven), but every segment should keep >= 16 chunks (1024 paths) so its per-kind queues fill whole waves:
-// W = chunks / 16 clamped to [4, 48] segments per CU (64 with media).  stats rows are indexed by PHYSICAL wave (ctx->stat_rows).
+// W = chunks / 16 clamped to [4, 48] segments per CU (96 with media, where every kernel draws tickets).  stats rows are indexed by PHYSICAL wave (ctx->stat_rows).
 int ensure_state(hk_integrator* I, int capacity, bool media) {
     const int n_cu = I->ctx->n_cu;
-    const long cap_per_cu = media ? 64 : 48;   // the media kernels draw tickets and their segments are the most uneven: finer
+    const long cap_per_cu = media ? 96 : 48;   // media scenes draw tickets in every kernel and their segments are the most uneven: finer
     long W_want = ((long)(capacity + 63) / 64) / 16;
     if (W_want < 4L * n_cu) W_want = 4L * n_cu;
     if (W_want > cap_per_cu * n_cu) W_want = cap_per_cu * n_cu;
     if (I->ctx->waves_per_cu > 0) W_want = (long)I->ctx->waves_per_cu * n_cu;
     W_want = (W_want + 3) / 4 * 4;
+    I->st.dynamic_segments = media ? 1 : 0;
     if (I->st_capacity >= capacity && I->st_depth >= I->p.max_depth && I->st.n_waves == (int)W_want) return HK_OK;
     for (auto* b : I->bufs) delete b;
     I->bufs.clear();

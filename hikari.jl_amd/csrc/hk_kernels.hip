@@ -44,14 +44,11 @@ __device__ __forceinline__ int next_segment(int* ticket) {
     return __builtin_amdgcn_readfirstlane(v);
 }
 #define HK_FOR_EACH_WAVE_SEGMENT_DYNAMIC(gw, st, ticket) for (int gw = next_segment(ticket); gw < (st).n_waves; gw = next_segment(ticket))
-#ifndef HK_STATIC_SEGMENTS
-#define HK_STATIC_SEGMENTS 1
-#endif
-#if HK_STATIC_SEGMENTS
-#define HK_FOR_EACH_WAVE_SEGMENT(gw, st, ticket) for (int gw = global_wave(); gw < (st).n_waves; gw += physical_waves())
-#else
-#define HK_FOR_EACH_WAVE_SEGMENT(gw, st, ticket) HK_FOR_EACH_WAVE_SEGMENT_DYNAMIC(gw, st, ticket)
-#endif
+// Surface scenes walk the segments with a static stride (the grid is clamped to a divisor of W, see clamp_blocks); scenes with
+// media draw tickets in every kernel (st.dynamic_segments): measured on the cloud config +9 %, on the sky config -16 %.
+#define HK_FOR_EACH_WAVE_SEGMENT(gw, st, ticket)                                                             \
+    for (int gw = (st).dynamic_segments ? next_segment(ticket) : global_wave(); gw < (st).n_waves;           \
+         gw = (st).dynamic_segments ? next_segment(ticket) : gw + physical_waves())
 // ticket words: row = bounce depth (row max_depth + 1: camera / film), column = kernel
 enum { TK_TRACE = 0, TK_TRACK = 1, TK_SHADOW = 2, TK_ESCAPED = 3, TK_SCATTER = 4, TK_SHADE0 = 5, TK_CAMERA = 0, TK_FILM = 1 };
 __device__ __forceinline__ int* ticket_ptr(const DPathState& st, int row, int col) { return st.tickets + row * HK_TICKET_COLS + col; }
@@ -1676,7 +1673,7 @@ static int resident_blocks(K kernel, int block, int n_cu, int cap_per_cu) {
 static int clamp_blocks(int blocks, const DPathState& st) {
     const int units = st.n_waves / 4;
     if (blocks >= units) return units;
-#if HK_STATIC_SEGMENTS
+    if (st.dynamic_segments) return blocks;
     int best = 1;
     for (int b = blocks; b >= 1; --b)
         if (units % b == 0) {
@@ -1685,9 +1682,6 @@ static int clamp_blocks(int blocks, const DPathState& st) {
         }
     // a divisor far below residency wastes more than the tail round it avoids
     return best * 4 >= blocks * 3 ? best : blocks;
-#else
-    return blocks;
-#endif
 }
 
 void launch_camera(hipStream_t s, int n_cu, const DPathState& st, const DFrame& fr, const DTables& T, const DFilter& f, const DCamera& c, const DSobol& sob, int initial_medium) {

@@ -229,6 +229,7 @@ struct DPathState {
     int* counters;         // [(max_depth + 2) * Q_COUNT][W] per-wave queue sizes
     int* tickets;          // [ticket_rows * HK_TICKET_COLS] segment tickets (dynamic segment -> wave assignment), one word per launch, zeroed per pass
     int ticket_rows;       // max_depth + 2
+    int dynamic_segments;  // 1: every kernel draws its segments from the tickets (scenes with media); 0: static stride
 };
 
 struct DStats {

@@ -468,11 +468,40 @@ extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene**
     }
     HIP_TRY(s->lights.upload(dl.data(), dl.size() * sizeof(DLight)));
     hk::build_light_bvh(d->lights, d->n_lights, s->lbvh);
-    static_assert(sizeof(DLightNode) == sizeof(hk::LightBVHNodeH) && sizeof(DLightNode) == 64, "light node layout");
+    static_assert(sizeof(DLightNode) == 64, "light node layout");
     {
-        std::vector<hk::LightBVHNodeH> tmp = s->lbvh.nodes;
-        if (tmp.empty()) tmp.resize(1);
-        HIP_TRY(s->lnodes.upload(tmp.data(), tmp.size() * sizeof(hk::LightBVHNodeH)));
+        std::vector<DLightNode> tmp(s->lbvh.nodes.size() ? s->lbvh.nodes.size() : 1);
+        std::memset(tmp.data(), 0, tmp.size() * sizeof(DLightNode));
+        for (size_t i = 0; i < s->lbvh.nodes.size(); ++i) {
+            const hk::LightBVHNodeH& n = s->lbvh.nodes[i];
+            DLightNode& o = tmp[i];
+            // volatile: every intermediate is rounded to binary32 exactly where the device code rounded it
+            volatile float c[3], dg[3], r[3];
+            for (int k = 0; k < 3; ++k) {
+                volatile float sum = n.bmin[k] + n.bmax[k];
+                c[k] = sum * 0.5f;
+                dg[k] = n.bmax[k] - n.bmin[k];
+            }
+            for (int k = 0; k < 3; ++k) r[k] = n.bmax[k] - c[k];
+            auto dot3 = [](volatile float* a) {
+                volatile float xx = a[0] * a[0], yy = a[1] * a[1], zz = a[2] * a[2];
+                volatile float xy = xx + yy;
+                volatile float t = xy + zz;
+                return (float)t;
+            };
+            for (int k = 0; k < 3; ++k) o.centre[k] = c[k];
+            volatile float nd = std::sqrt(dot3(dg));
+            o.half_diag = nd * 0.5f;
+            o.r2 = dot3(r);
+            for (int k = 0; k < 3; ++k) o.w[k] = n.w[k];
+            o.phi = n.phi, o.cos_o = n.cos_o, o.cos_e = n.cos_e;
+            volatile float cc = n.cos_o * n.cos_o;
+            volatile float om = 1.0f - cc;
+            o.sin_o = std::sqrt(om > 0.0f ? (float)om : 0.0f);
+            o.bits = n.bits;
+            o.child1_or_light = n.child1_or_light;
+        }
+        HIP_TRY(s->lnodes.upload(tmp.data(), tmp.size() * sizeof(DLightNode)));
         std::vector<uint32_t> tr = s->lbvh.bit_trails;
         if (tr.empty()) tr.resize(1);
         HIP_TRY(s->trails.upload(tr.data(), tr.size() * 4));

@@ -1407,24 +1407,17 @@ HKD float cos_sub_clamped(float sA, float cA, float sB, float cB) { return cA > 
 HKD float sin_sub_clamped(float sA, float cA, float sB, float cB) { return cA > cB ? 0.0f : sA * cB - cA * sB; }
 HKD float node_importance(const DLightNode& nd, v3 p, v3 n) {
     if (nd.phi == 0.0f) return 0.0f;
-    v3 bmin = mk3(nd.bmin[0], nd.bmin[1], nd.bmin[2]), bmax = mk3(nd.bmax[0], nd.bmax[1], nd.bmax[2]);
-    v3 pc = (bmin + bmax) * 0.5f;
+    v3 pc = mk3(nd.centre[0], nd.centre[1], nd.centre[2]);
     v3 dp = p - pc;
-    float d2 = dot(dp, dp);
-    d2 = maxf(d2, norm(bmax - bmin) * 0.5f);
+    float dd = dot(dp, dp);
+    float d2 = maxf(dd, nd.half_diag);
     v3 wi = normalize(dp);
     float cw = dot(mk3(nd.w[0], nd.w[1], nd.w[2]), wi);
     if (nd.bits & 1u) cw = fabsf(cw);
     float sw = sqrtf(maxf(0.0f, 1.0f - cw * cw));
-    float cb;
-    {
-        v3 r = bmax - pc;
-        float r2 = dot(r, r);
-        float dd = dot(dp, dp);
-        cb = dd < r2 ? -1.0f : sqrtf(maxf(0.0f, 1.0f - r2 / dd));
-    }
+    float cb = dd < nd.r2 ? -1.0f : sqrtf(maxf(0.0f, 1.0f - nd.r2 / dd));
     float sb = sqrtf(maxf(0.0f, 1.0f - cb * cb));
-    float so = sqrtf(maxf(0.0f, 1.0f - nd.cos_o * nd.cos_o));
+    float so = nd.sin_o;
     float cx = cos_sub_clamped(sw, cw, so, nd.cos_o);
     float sx = sin_sub_clamped(sw, cw, so, nd.cos_o);
     float cp = cos_sub_clamped(sx, cx, sb, cb);
@@ -1445,9 +1438,9 @@ HKD DLightNode load_light_node(const DLightNode* __restrict__ nodes, int idx0) {
     const float4* q = reinterpret_cast<const float4*>(nodes + idx0);
     float4 a = q[0], b = q[1], c = q[2], d = q[3];
     DLightNode n;
-    n.bmin[0] = a.x, n.bmin[1] = a.y, n.bmin[2] = a.z, n.bmax[0] = a.w;
-    n.bmax[1] = b.x, n.bmax[2] = b.y, n.w[0] = b.z, n.w[1] = b.w;
-    n.w[2] = c.x, n.phi = c.y, n.cos_o = c.z, n.cos_e = c.w;
+    n.centre[0] = a.x, n.centre[1] = a.y, n.centre[2] = a.z, n.half_diag = a.w;
+    n.r2 = b.x, n.w[0] = b.y, n.w[1] = b.z, n.w[2] = b.w;
+    n.phi = c.x, n.cos_o = c.y, n.cos_e = c.z, n.sin_o = c.w;
     n.bits = __float_as_uint(d.x), n.child1_or_light = __float_as_uint(d.y);
     n.pad[0] = n.pad[1] = 0u;
     return n;

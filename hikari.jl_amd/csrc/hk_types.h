@@ -88,9 +88,16 @@ struct DEnvMap {
     float rot[9];                  // row-major Mat3f
 };
 
-struct DLightNode {  // 64 B
-    float bmin[3], bmax[3], w[3];
-    float phi, cos_o, cos_e;
+// Light-BVH node as the device walks it, 64 B.  The quantities of node_importance that depend on the node alone are evaluated
+// once on the host with the same binary32 operations, in the same order, as the per-visit code they replace
+// (light-bounds.jl:96-109, bvh-light-sampler.jl:177-182): centre = (bmin + bmax) * 0.5, half_diag = norm(bmax - bmin) * 0.5,
+// r2 = |bmax - centre|^2, sin_o = sqrt(max(0, 1 - cos_o^2)).
+struct DLightNode {
+    float centre[3];
+    float half_diag;
+    float r2;
+    float w[3];
+    float phi, cos_o, cos_e, sin_o;
     uint32_t bits;              // bit0 two_sided, bit1 is_leaf
     uint32_t child1_or_light;   // 1-based
     uint32_t pad[2];

@@ -6,7 +6,7 @@ contains a dot, so import it through the `hikari_jl_amd` shim at the repository 
 """
 from . import _abi, geometry, tables
 from ._lib import HikariMI355XError, LIB_PATH
-from .camera import PerspectiveCamera
+from .camera import MatrixCamera, PerspectiveCamera
 from .envmap import Distribution2D, EnvironmentLight, EnvironmentMap, analytic_sky, rotation_matrix
 from .denoise import DenoiseConfig
 from .film import Film

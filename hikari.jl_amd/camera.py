@@ -1,4 +1,4 @@
-"""PerspectiveCamera (src/camera/perspective.jl:1-128): builds raster_to_camera / camera_to_world in float32
+"""PerspectiveCamera (src/camera/perspective.jl:1-128) and MatrixCamera (src/camera/matrix.jl:13-115): builds raster_to_camera / camera_to_world in float32
 the way ProjectiveCamera does and exposes them as one hk_camera record (the C-ABI carries matrices only)."""
 import numpy as np
 
@@ -43,3 +43,31 @@ class PerspectiveCamera:
         c.dx_camera[:] = [float(x) for x in self.dx_camera]
         c.dy_camera[:] = [float(x) for x in self.dy_camera]
         return c
+
+
+class MatrixCamera(PerspectiveCamera):
+    """MatrixCamera(view, projection, resolution[, screen_window]) (src/camera/matrix.jl:30-97): Makie-style world-to-camera
+    `view` and camera-to-clip `projection` (OpenGL conventions, camera looks along -z).  camera_to_world = inv(view),
+    raster_to_camera = inv(projection) * raster_to_screen; no depth of field (generate_ray, matrix.jl:99-115, is the
+    PerspectiveCamera ray without a lens), shutter 0..1 — so it is the same hk_camera record with lens_radius = 0."""
+
+    def __init__(self, view, projection, resolution, screen_window=((-1, -1), (1, 1))):
+        view = np.asarray(view, dtype=np.float64).astype(f32)            # Mat4f(view): Makie stores Float64
+        projection = np.asarray(projection, dtype=np.float64).astype(f32)
+        self.camera_to_world = G.inv(view)
+        (x0, y0), (x1, y1) = screen_window
+        w, h = (resolution.resolution if hasattr(resolution, "resolution") else resolution)
+        res_scale = G.scale(w, h, 1)
+        inv_bounds = G.scale(f32(1) / f32(x1 - x0), f32(1) / f32(y1 - y0), 1)
+        offset = G.translate((-x0, -y0, 0))
+        raster_to_screen = (G.inv(offset) @ G.inv(inv_bounds) @ G.inv(res_scale)).astype(f32)
+        self.raster_to_camera = (G.inv(projection) @ raster_to_screen).astype(f32)
+        self.lens_radius, self.focal_distance = 0.0, 1e6
+        self.shutter_open, self.shutter_close = 0.0, 1.0
+        p_min = self._apply_point(self.raster_to_camera, (0, 0, 0))
+        p_max = self._apply_point(self.raster_to_camera, (w, h, 0))
+        self.dx_camera = self._apply_point(self.raster_to_camera, (1, 0, 0)) - p_min
+        self.dy_camera = self._apply_point(self.raster_to_camera, (0, 1, 0)) - p_min
+        pp = p_min[:2] / p_min[2] - p_max[:2] / p_max[2]
+        self.A = float(abs(pp[0] * pp[1]))
+        self.film = resolution if hasattr(resolution, "resolution") else None

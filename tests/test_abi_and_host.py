@@ -97,6 +97,32 @@ def test_camera_matches_reference_conventions(hk, oracle):
     assert d[0, 1] > d[2, 1]                                   # film y = height - y + 1.5: pixel row y=1 is the TOP of the image (Q2)
 
 
+def test_matrix_camera_equals_perspective_camera(hk, oracle):
+    """MatrixCamera (camera/matrix.jl) fed the view / projection a PerspectiveCamera is built from gives the same rays; a flipped
+    OpenGL view (camera looking along -z) turns them around."""
+    from hikari_jl_amd import geometry as G
+    film = hk.Film((40, 30))
+    pc = hk.PerspectiveCamera((1, 2, -5), (0, 0.5, 0), film, fov=35.0)
+    view = G.look_at((1, 2, -5), (0, 0.5, 0), (0, 1, 0))
+    proj = G.perspective(35.0, 0.01, 1000.0)
+    mc = hk.MatrixCamera(view, proj, film)
+    assert np.allclose(mc.raster_to_camera, pc.raster_to_camera, rtol=1e-6, atol=1e-7)
+    assert np.allclose(mc.camera_to_world, pc.camera_to_world, rtol=1e-6, atol=1e-7)
+    assert np.allclose(mc.dx_camera, pc.dx_camera, atol=1e-7) and mc.A > 0
+    p = hk.integrator_params()
+    rng = np.random.default_rng(4)
+    px, py = rng.integers(1, 41, 50).astype(np.int32), rng.integers(1, 31, 50).astype(np.int32)
+    idx = rng.integers(1, 64, 50).astype(np.int32)
+    a = oracle.camera_samples(p, pc, 40, 30, px, py, idx)
+    b = oracle.camera_samples(p, mc, 40, 30, px, py, idx)
+    assert np.allclose(a, b, rtol=1e-5, atol=1e-6)
+    rec = mc.record()
+    assert rec.lens_radius == 0.0 and rec.shutter_open == 0.0 and rec.shutter_close == 1.0
+    # resolution may be given as a (w, h) pair, as the reference's Point2f
+    mc2 = hk.MatrixCamera(view.astype(np.float64), proj.astype(np.float64), (40, 30))
+    assert np.array_equal(mc2.raster_to_camera, mc.raster_to_camera)
+
+
 WORKER = r'''
 import os, sys
 sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "oracle"))

@@ -172,8 +172,22 @@ def main():
                 traffic = json.load(open(pmc_path)).get({"trace": "k_trace", "shadow": "k_shadow", "shade": "k_shade"}[dom], {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        # measured HBM ceiling of this box beside the nominal peak: device-to-device copy, read + write bytes
+        a = torch.empty(1 << 28, dtype=torch.float32, device="cuda")    # 1 GiB
+        b = torch.empty_like(a)
+        b.copy_(a)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 10 * 2 * a.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del a, b
         roofline = {"bound": "hbm", "kernel": {"trace": "k_trace", "shadow": "k_shadow", "shade": "k_shade"}[dom], "achieved": round(achieved, 2),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "measured_copy_gbs": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 5),
                     "algorithmic_bytes_per_launch": int(alg_bytes / n_launch), "avg_launch_ms": round(avg_s * 1e3, 4), "launches": n_launch,
                     "nodes_per_cast": round(int(sc.trace_nodes) / max(int(sc.rays_closest), 1), 2),
                     "tris_per_cast": round(int(sc.trace_tris) / max(int(sc.rays_closest), 1), 2),

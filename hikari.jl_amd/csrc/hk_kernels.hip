@@ -283,7 +283,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace(DPathState st, DScene 
 #endif
 struct LaneRay {   // per-lane traversal state
     v3 o, d;
-    float ix, iy, iz, ox, oy, oz, eps_abs;
+    float ix, iy, iz, ox, oy, oz, eps3;   // eps3 = 3 x the absolute slack of the slab test (see traverse())
     float t_max;
     HitRec best;
     int cur, sp;
@@ -297,7 +297,7 @@ HKD void lane_ray_start(LaneRay& r, const DScene& sc, v3 o, v3 d, float t_max) {
     r.best.u = r.best.v = 0.0f;
     r.ix = clampf(1.0f / d.x, -1e30f, 1e30f), r.iy = clampf(1.0f / d.y, -1e30f, 1e30f), r.iz = clampf(1.0f / d.z, -1e30f, 1e30f);
     r.ox = -o.x * r.ix, r.oy = -o.y * r.iy, r.oz = -o.z * r.iz;
-    r.eps_abs = 2.4e-7f * fmaxf(fmaxf(fabsf(r.ix) < 1e30f ? fabsf(r.ox) : 0.0f, fabsf(r.iy) < 1e30f ? fabsf(r.oy) : 0.0f), fabsf(r.iz) < 1e30f ? fabsf(r.oz) : 0.0f);
+    r.eps3 = 3.0f * (2.4e-7f * fmaxf(fmaxf(fabsf(r.ix) < 1e30f ? fabsf(r.ox) : 0.0f, fabsf(r.iy) < 1e30f ? fabsf(r.oy) : 0.0f), fabsf(r.iz) < 1e30f ? fabsf(r.oz) : 0.0f));
     r.sp = 0;
     r.cur = sc.n_tris == 0 ? (int)0x80000000 : sc.root_ref;
 }
@@ -322,21 +322,22 @@ HKD void lane_ray_round(LaneRay& r, bool active, const DScene& sc, int* __restri
             float u0z = fmaf(C.x, r.iz, r.oz), u1z = fmaf(C.w, r.iz, r.oz);
             float n1 = fmaxf(fmaxf(fminf(u0x, u1x), fminf(u0y, u1y)), fmaxf(fminf(u0z, u1z), 0.0f));
             float f1 = fminf(fminf(fmaxf(u0x, u1x), fmaxf(u0y, u1y)), fminf(fmaxf(u0z, u1z), r.best.t));
-            bool h0 = n0 * 0.99999f - r.eps_abs <= f0 * 1.00001f + r.eps_abs;
-            bool h1 = n1 * 0.99999f - r.eps_abs <= f1 * 1.00001f + r.eps_abs;
+            // the whole slack sits on the far side: n <= f * (1 + 3e-5) + 3 eps admits everything the symmetric form
+            // n * 0.99999 - eps <= f * 1.00001 + eps admitted (n >= 0), in one fma per child
+            bool h0 = n0 <= fmaf(f0, 1.00003f, r.eps3);
+            bool h1 = n1 <= fmaf(f1, 1.00003f, r.eps3);
             int c0 = __float_as_int(D.x), c1 = __float_as_int(D.y);
-            if (h0 && h1) {
-                bool first0 = n0 <= n1;
-                stack[r.sp * 64 + lane] = first0 ? c1 : c0;
-                ++r.sp;
-                r.cur = first0 ? c0 : c1;
-            } else if (h0 || h1) {
-                r.cur = h0 ? c0 : c1;
-            } else if (r.sp > 0) {
-                --r.sp;
-                r.cur = stack[r.sp * 64 + lane];
-            } else
-                r.cur = DONE;
+            // selects instead of a four-way branch: a divergent wave would walk every arm (and wait on LDS in two of them)
+            const bool both = h0 && h1, any = h0 || h1;
+            const bool first0 = n0 <= n1;
+            const int near_c = (both ? first0 : h0) ? c0 : c1;
+            if (both) stack[r.sp * 64 + lane] = first0 ? c1 : c0;
+            r.sp += both ? 1 : 0;
+            const bool pop = !any && r.sp > 0;
+            r.sp -= pop ? 1 : 0;
+            int popped = DONE;
+            if (pop) popped = stack[r.sp * 64 + lane];
+            r.cur = any ? near_c : popped;
         }
     }
     if (active && r.cur != DONE) {
@@ -346,6 +347,9 @@ HKD void lane_ray_round(LaneRay& r, bool active, const DScene& sc, int* __restri
         for (int i = 0; i < count && !stop; ++i) {
             const float4* tp = sc.leaf_tris + 3 * (size_t)(first + i);
             float4 T0 = tp[0], T1 = tp[1], T2 = tp[2];
+            // all three loads are issued here: left alone, the compiler sinks the v0 load behind the det != 0 test and
+            // every triangle pays a second memory round trip
+            asm volatile("" ::"v"(T0.x), "v"(T0.y), "v"(T0.z), "v"(T0.w));
             if (COUNT) ++n_tris;
             float t, u, v;
             if (intersect_triangle(r.o, r.d, r.t_max, mk3(T0.x, T0.y, T0.z), mk3(T1.x, T1.y, T1.z), mk3(T2.x, T2.y, T2.z), t, u, v)) {

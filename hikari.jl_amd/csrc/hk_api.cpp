@@ -310,9 +310,9 @@ extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene**
     std::vector<DNode> dn(bvh.nodes.size() ? bvh.nodes.size() : 1);
     for (size_t i = 0; i < bvh.nodes.size(); ++i) {
         const hk::BVHNode& n = bvh.nodes[i];
-        dn[i].a = make_float4(n.lo0[0], n.lo0[1], n.lo0[2], n.hi0[0]);
-        dn[i].b = make_float4(n.hi0[1], n.hi0[2], n.lo1[0], n.lo1[1]);
-        dn[i].c = make_float4(n.lo1[2], n.hi1[0], n.hi1[1], n.hi1[2]);
+        dn[i].a = make_float4(n.lo0[0], n.hi0[0], n.lo0[1], n.hi0[1]);
+        dn[i].b = make_float4(n.lo0[2], n.hi0[2], n.lo1[0], n.hi1[0]);
+        dn[i].c = make_float4(n.lo1[1], n.hi1[1], n.lo1[2], n.hi1[2]);
         dn[i].c0 = n.c0;
         dn[i].c1 = n.c1;
         dn[i].pad0 = dn[i].pad1 = 0;

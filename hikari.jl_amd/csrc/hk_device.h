@@ -638,7 +638,52 @@ struct HitRec {
     float u, v;
 };
 
-// Per-lane short stack lives in LDS: entry e of lane l at stack[e * 64 + l] (bank = lane => conflict-free).
+// Per-ray constants of the slab test in FMA form t = b*inv_d + (-o*inv_d).  inv_d is clamped to +-1e30 so axis-parallel rays give
+// +-huge instead of inf - inf = NaN (the test only culls; 1e30 is beyond any scene scale).  Rounding slack of the FMA form:
+// |err(t)| <= 2^-24 (|o*inv_d| + |t|).  Culling must never drop a triangle whose computed t ties the current best (coplanar
+// faces of abutting boxes), so the interval is widened by an absolute term from |o*inv_d| plus a relative 1e-5 on either end;
+// the whole slack sits on the far side: n <= f * (1 + 3e-5) + 3 eps admits everything n * 0.99999 - eps <= f * 1.00001 + eps
+// admits (n >= 0), in one fma per child.
+struct RaySlab {
+    float ix, iy, iz, ox, oy, oz, eps3;
+};
+HKD RaySlab ray_slab(v3 o, v3 d) {
+    RaySlab r;
+    r.ix = clampf(1.0f / d.x, -1e30f, 1e30f), r.iy = clampf(1.0f / d.y, -1e30f, 1e30f), r.iz = clampf(1.0f / d.z, -1e30f, 1e30f);
+    r.ox = -o.x * r.ix, r.oy = -o.y * r.iy, r.oz = -o.z * r.iz;
+    r.eps3 = 3.0f * (2.4e-7f * fmaxf(fmaxf(fabsf(r.ix) < 1e30f ? fabsf(r.ox) : 0.0f, fabsf(r.iy) < 1e30f ? fabsf(r.oy) : 0.0f), fabsf(r.iz) < 1e30f ? fabsf(r.oz) : 0.0f));
+    return r;
+}
+typedef float hk_f2 __attribute__((ext_vector_type(2)));
+// One inner-node step of a lane: both child boxes (DNode: the (lo, hi) pair of an axis sits in adjacent words, so one packed fma
+// gives both plane distances), nearest hit child first, the other pushed.  Per-lane stack in LDS: entry e of lane l at
+// stack[e * 64 + l] (bank = lane => conflict-free).  Selects instead of a four-way branch: a divergent wave would walk every arm.
+HKD void node_step(const DScene& sc, const RaySlab& rs, float t_best, int* __restrict__ stack, int lane, int& cur, int& sp) {
+    const float4* np = reinterpret_cast<const float4*>(sc.nodes) + 4 * (size_t)cur;
+    const float4 A = np[0], B = np[1], C = np[2], D = np[3];
+    const hk_f2 IX = {rs.ix, rs.ix}, IY = {rs.iy, rs.iy}, IZ = {rs.iz, rs.iz}, OX = {rs.ox, rs.ox}, OY = {rs.oy, rs.oy}, OZ = {rs.oz, rs.oz};
+    const hk_f2 x0 = __builtin_elementwise_fma((hk_f2){A.x, A.y}, IX, OX), y0 = __builtin_elementwise_fma((hk_f2){A.z, A.w}, IY, OY);
+    const hk_f2 z0 = __builtin_elementwise_fma((hk_f2){B.x, B.y}, IZ, OZ), x1 = __builtin_elementwise_fma((hk_f2){B.z, B.w}, IX, OX);
+    const hk_f2 y1 = __builtin_elementwise_fma((hk_f2){C.x, C.y}, IY, OY), z1 = __builtin_elementwise_fma((hk_f2){C.z, C.w}, IZ, OZ);
+    const float n0 = fmaxf(fmaxf(fminf(x0.x, x0.y), fminf(y0.x, y0.y)), fmaxf(fminf(z0.x, z0.y), 0.0f));
+    const float f0 = fminf(fminf(fmaxf(x0.x, x0.y), fmaxf(y0.x, y0.y)), fminf(fmaxf(z0.x, z0.y), t_best));
+    const float n1 = fmaxf(fmaxf(fminf(x1.x, x1.y), fminf(y1.x, y1.y)), fmaxf(fminf(z1.x, z1.y), 0.0f));
+    const float f1 = fminf(fminf(fmaxf(x1.x, x1.y), fmaxf(y1.x, y1.y)), fminf(fmaxf(z1.x, z1.y), t_best));
+    const bool h0 = n0 <= fmaf(f0, 1.00003f, rs.eps3);
+    const bool h1 = n1 <= fmaf(f1, 1.00003f, rs.eps3);
+    const int c0 = __float_as_int(D.x), c1 = __float_as_int(D.y);
+    const bool both = h0 && h1, any = h0 || h1;
+    const bool first0 = n0 <= n1;
+    const int near_c = (both ? first0 : h0) ? c0 : c1;
+    if (both) stack[sp * 64 + lane] = first0 ? c1 : c0;
+    sp += both ? 1 : 0;
+    const bool pop = !any && sp > 0;
+    sp -= pop ? 1 : 0;
+    int popped = (int)0x80000000;
+    if (pop) popped = stack[sp * 64 + lane];
+    cur = any ? near_c : popped;
+}
+
 // MODE 0: closest hit (ties on t -> smaller prim index).  MODE 1: shadow segment — returns as soon as an
 // opaque triangle is hit (any opaque hit zeroes the contribution, intersection.jl:378-379), otherwise
 // closest hit among the non-opaque ones.
@@ -650,52 +695,17 @@ HKD HitRec traverse(const DScene& sc, v3 o, v3 d, float t_max, int* __restrict__
     best.u = best.v = 0.0f;
     opaque_hit = false;
     if (sc.n_tris == 0) return best;
-    // slab test in FMA form t = b*inv_d + (-o*inv_d).  inv_d is clamped to +-1e30 so axis-parallel rays give
-    // +-huge instead of inf - inf = NaN (the test only culls; 1e30 is beyond any scene scale).
-    const float ix = clampf(1.0f / d.x, -1e30f, 1e30f), iy = clampf(1.0f / d.y, -1e30f, 1e30f), iz = clampf(1.0f / d.z, -1e30f, 1e30f);
-    const float ox = -o.x * ix, oy = -o.y * iy, oz = -o.z * iz;
-    // rounding slack of the FMA form: |err(t)| <= 2^-24 (|o*inv_d| + |t|).  Culling must never drop a triangle
-    // whose computed t ties the current best (coplanar faces of abutting boxes), so the interval is widened by
-    // an absolute term from |o*inv_d| plus a relative 1e-5.
-    const float eps_abs = 2.4e-7f * fmaxf(fmaxf(fabsf(ix) < 1e30f ? fabsf(ox) : 0.0f, fabsf(iy) < 1e30f ? fabsf(oy) : 0.0f), fabsf(iz) < 1e30f ? fabsf(oz) : 0.0f);
+    const RaySlab rs = ray_slab(o, d);
     int sp = 0;
     int cur = sc.root_ref;
     const int DONE = (int)0x80000000;
-    const float4* __restrict__ nodes4 = reinterpret_cast<const float4*>(sc.nodes);
     // "while-while" traversal: every lane first walks inner nodes until it holds a leaf (lanes that already hold
     // one idle), then the wave tests leaves together.  Mixing both per iteration makes a divergent wave pay the
     // node code AND the 4-triangle leaf loop on every step.
     while (cur != DONE) {
         while (cur >= 0) {
-            const float4* np = nodes4 + 4 * (size_t)cur;
-            float4 A = np[0], B = np[1], C = np[2], D = np[3];
             if (COUNT) ++n_nodes;
-            // child 0: lo (A.x A.y A.z) hi (A.w B.x B.y) ; child 1: lo (B.z B.w C.x) hi (C.y C.z C.w)
-            float t0x = fmaf(A.x, ix, ox), t1x = fmaf(A.w, ix, ox);
-            float t0y = fmaf(A.y, iy, oy), t1y = fmaf(B.x, iy, oy);
-            float t0z = fmaf(A.z, iz, oz), t1z = fmaf(B.y, iz, oz);
-            float n0 = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.0f));
-            float f0 = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), best.t));
-            float u0x = fmaf(B.z, ix, ox), u1x = fmaf(C.y, ix, ox);
-            float u0y = fmaf(B.w, iy, oy), u1y = fmaf(C.z, iy, oy);
-            float u0z = fmaf(C.x, iz, oz), u1z = fmaf(C.w, iz, oz);
-            float n1 = fmaxf(fmaxf(fminf(u0x, u1x), fminf(u0y, u1y)), fmaxf(fminf(u0z, u1z), 0.0f));
-            float f1 = fminf(fminf(fmaxf(u0x, u1x), fmaxf(u0y, u1y)), fminf(fmaxf(u0z, u1z), best.t));
-            bool h0 = n0 * 0.99999f - eps_abs <= f0 * 1.00001f + eps_abs;
-            bool h1 = n1 * 0.99999f - eps_abs <= f1 * 1.00001f + eps_abs;
-            int c0 = __float_as_int(D.x), c1 = __float_as_int(D.y);
-            if (h0 && h1) {
-                bool first0 = n0 <= n1;
-                stack[sp * 64 + lane] = first0 ? c1 : c0;
-                ++sp;
-                cur = first0 ? c0 : c1;
-            } else if (h0 || h1) {
-                cur = h0 ? c0 : c1;
-            } else if (sp > 0) {
-                --sp;
-                cur = stack[sp * 64 + lane];
-            } else
-                cur = DONE;
+            node_step(sc, rs, best.t, stack, lane, cur, sp);
         }
         if (cur != DONE) {
             int ref = ~cur;
@@ -703,6 +713,7 @@ HKD HitRec traverse(const DScene& sc, v3 o, v3 d, float t_max, int* __restrict__
             for (int i = 0; i < count; ++i) {
                 const float4* tp = sc.leaf_tris + 3 * (size_t)(first + i);
                 float4 T0 = tp[0], T1 = tp[1], T2 = tp[2];
+                asm volatile("" ::"v"(T0.x), "v"(T0.y), "v"(T0.z), "v"(T0.w));   // issue the three loads together (see lane_ray_round)
                 if (COUNT) ++n_tris;
                 float t, u, v;
                 if (intersect_triangle(o, d, t_max, mk3(T0.x, T0.y, T0.z), mk3(T1.x, T1.y, T1.z), mk3(T2.x, T2.y, T2.z), t, u, v)) {

@@ -283,7 +283,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace(DPathState st, DScene 
 #endif
 struct LaneRay {   // per-lane traversal state
     v3 o, d;
-    float ix, iy, iz, ox, oy, oz, eps3;   // eps3 = 3 x the absolute slack of the slab test (see traverse())
+    RaySlab rs;
     float t_max;
     HitRec best;
     int cur, sp;
@@ -295,9 +295,7 @@ HKD void lane_ray_start(LaneRay& r, const DScene& sc, v3 o, v3 d, float t_max) {
     r.best.t = t_max;
     r.best.prim = -1;
     r.best.u = r.best.v = 0.0f;
-    r.ix = clampf(1.0f / d.x, -1e30f, 1e30f), r.iy = clampf(1.0f / d.y, -1e30f, 1e30f), r.iz = clampf(1.0f / d.z, -1e30f, 1e30f);
-    r.ox = -o.x * r.ix, r.oy = -o.y * r.iy, r.oz = -o.z * r.iz;
-    r.eps3 = 3.0f * (2.4e-7f * fmaxf(fmaxf(fabsf(r.ix) < 1e30f ? fabsf(r.ox) : 0.0f, fabsf(r.iy) < 1e30f ? fabsf(r.oy) : 0.0f), fabsf(r.iz) < 1e30f ? fabsf(r.oz) : 0.0f));
+    r.rs = ray_slab(o, d);
     r.sp = 0;
     r.cur = sc.n_tris == 0 ? (int)0x80000000 : sc.root_ref;
 }
@@ -306,38 +304,10 @@ HKD void lane_ray_start(LaneRay& r, const DScene& sc, v3 o, v3 d, float t_max) {
 template <bool ANYHIT, bool COUNT>
 HKD void lane_ray_round(LaneRay& r, bool active, const DScene& sc, int* __restrict__ stack, int lane, unsigned& n_nodes, unsigned& n_tris) {
     const int DONE = (int)0x80000000;
-    const float4* __restrict__ nodes4 = reinterpret_cast<const float4*>(sc.nodes);
     while (__ballot(active && r.cur >= 0)) {
         if (active && r.cur >= 0) {
-            const float4* np = nodes4 + 4 * (size_t)r.cur;
-            float4 A = np[0], B = np[1], C = np[2], D = np[3];
             if (COUNT) ++n_nodes;
-            float t0x = fmaf(A.x, r.ix, r.ox), t1x = fmaf(A.w, r.ix, r.ox);
-            float t0y = fmaf(A.y, r.iy, r.oy), t1y = fmaf(B.x, r.iy, r.oy);
-            float t0z = fmaf(A.z, r.iz, r.oz), t1z = fmaf(B.y, r.iz, r.oz);
-            float n0 = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.0f));
-            float f0 = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), r.best.t));
-            float u0x = fmaf(B.z, r.ix, r.ox), u1x = fmaf(C.y, r.ix, r.ox);
-            float u0y = fmaf(B.w, r.iy, r.oy), u1y = fmaf(C.z, r.iy, r.oy);
-            float u0z = fmaf(C.x, r.iz, r.oz), u1z = fmaf(C.w, r.iz, r.oz);
-            float n1 = fmaxf(fmaxf(fminf(u0x, u1x), fminf(u0y, u1y)), fmaxf(fminf(u0z, u1z), 0.0f));
-            float f1 = fminf(fminf(fmaxf(u0x, u1x), fmaxf(u0y, u1y)), fminf(fmaxf(u0z, u1z), r.best.t));
-            // the whole slack sits on the far side: n <= f * (1 + 3e-5) + 3 eps admits everything the symmetric form
-            // n * 0.99999 - eps <= f * 1.00001 + eps admitted (n >= 0), in one fma per child
-            bool h0 = n0 <= fmaf(f0, 1.00003f, r.eps3);
-            bool h1 = n1 <= fmaf(f1, 1.00003f, r.eps3);
-            int c0 = __float_as_int(D.x), c1 = __float_as_int(D.y);
-            // selects instead of a four-way branch: a divergent wave would walk every arm (and wait on LDS in two of them)
-            const bool both = h0 && h1, any = h0 || h1;
-            const bool first0 = n0 <= n1;
-            const int near_c = (both ? first0 : h0) ? c0 : c1;
-            if (both) stack[r.sp * 64 + lane] = first0 ? c1 : c0;
-            r.sp += both ? 1 : 0;
-            const bool pop = !any && r.sp > 0;
-            r.sp -= pop ? 1 : 0;
-            int popped = DONE;
-            if (pop) popped = stack[r.sp * 64 + lane];
-            r.cur = any ? near_c : popped;
+            node_step(sc, r.rs, r.best.t, stack, lane, r.cur, r.sp);
         }
     }
     if (active && r.cur != DONE) {

@@ -19,9 +19,9 @@
 
 // child reference: >= 0 inner node index; < 0 leaf: ~ref = (first_tri << 3) | (count - 1), count <= 4 (<=8 encodable)
 struct DNode {
-    float4 a;  // lo0.x lo0.y lo0.z hi0.x
-    float4 b;  // hi0.y hi0.z lo1.x lo1.y
-    float4 c;  // lo1.z hi1.x hi1.y hi1.z
+    float4 a;  // lo0.x hi0.x lo0.y hi0.y   (the (lo, hi) pair of an axis in adjacent words: one packed fma per pair)
+    float4 b;  // lo0.z hi0.z lo1.x hi1.x
+    float4 c;  // lo1.y hi1.y lo1.z hi1.z
     int c0, c1;
     int pad0, pad1;
 };

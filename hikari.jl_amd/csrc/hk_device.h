@@ -703,11 +703,17 @@ HKD HitRec traverse(const DScene& sc, v3 o, v3 d, float t_max, int* __restrict__
     // one idle), then the wave tests leaves together.  Mixing both per iteration makes a divergent wave pay the
     // node code AND the 4-triangle leaf loop on every step.
     while (cur != DONE) {
-        while (cur >= 0) {
-            if (COUNT) ++n_nodes;
-            node_step(sc, rs, best.t, stack, lane, cur, sp);
+        for (;;) {
+            const unsigned long long in_nodes = __ballot(cur >= 0);
+            if (in_nodes == 0ull) break;
+            // stragglers: fewer lanes still descending than waiting with a leaf -> leaves first (see lane_ray_round)
+            if (__popcll(in_nodes) < __popcll(__ballot(cur < 0))) break;
+            if (cur >= 0) {
+                if (COUNT) ++n_nodes;
+                node_step(sc, rs, best.t, stack, lane, cur, sp);
+            }
         }
-        if (cur != DONE) {
+        if (cur < 0 && cur != DONE) {
             int ref = ~cur;
             int first = ref >> 3, count = (ref & 7) + 1;
             for (int i = 0; i < count; ++i) {

@@ -304,13 +304,19 @@ HKD void lane_ray_start(LaneRay& r, const DScene& sc, v3 o, v3 d, float t_max) {
 template <bool ANYHIT, bool COUNT>
 HKD void lane_ray_round(LaneRay& r, bool active, const DScene& sc, int* __restrict__ stack, int lane, unsigned& n_nodes, unsigned& n_tris) {
     const int DONE = (int)0x80000000;
-    while (__ballot(active && r.cur >= 0)) {
+    for (;;) {
+        const unsigned long long in_nodes = __ballot(active && r.cur >= 0);
+        if (in_nodes == 0ull) break;
+        // stragglers: once fewer lanes are still descending than are waiting with a leaf, test the leaves first — the descending
+        // lanes keep their state and go on in the next round.  (Running the node loop until the LAST lane holds a leaf cost
+        // half of the traversal time in the 10^6-triangle scene: trace 0.94 -> 0.46 s, shadow 0.30 -> 0.19 s.)
+        if (__popcll(in_nodes) < __popcll(__ballot(active && r.cur < 0 && r.cur != DONE))) break;
         if (active && r.cur >= 0) {
             if (COUNT) ++n_nodes;
             node_step(sc, r.rs, r.best.t, stack, lane, r.cur, r.sp);
         }
     }
-    if (active && r.cur != DONE) {
+    if (active && r.cur < 0 && r.cur != DONE) {
         int ref = ~r.cur;
         int first = ref >> 3, count = (ref & 7) + 1;
         bool stop = false;

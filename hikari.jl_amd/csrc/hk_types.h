@@ -26,6 +26,7 @@ struct DNode {
     int pad0, pad1;
 };
 
+#define HK_MAT_EMISSIVE_BIT 0x40000000   // DPathState::mat_id: the hit triangle carries an area light (set by the trace kernels)
 #define HK_TRI_OPAQUE 1u  // e1.w bit: surface is neither a medium transition nor alpha-tested
 
 // sigmoid-polynomial spectrum with optional scale (c0,c1,c2,scale)

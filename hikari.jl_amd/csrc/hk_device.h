@@ -303,6 +303,69 @@ HKD v2 sobol_2d(const SobolCtx& c, int dim) {  // sobol.jl:290-309
 }
 
 // ------------------------------------------------------------------------------------------------
+// sin / cos of a binary32 argument the way Julia's Base computes them (base/special/trig.jl, a port of FreeBSD msun's k_sinf /
+// k_cosf / e_rem_pio2f): argument reduction and the polynomial kernels in binary64, ONE rounding to binary32 at the end.  The
+// reference calls Base.sin / Base.cos on Float32, the oracle evaluates the same expressions (oracle/hko_core.h), so the two sides
+// agree bit for bit here — and a double-precision kernel is ~25 fp64 operations for both results, against ~330 instructions for
+// each of ocml's sinf and cosf.
+// ------------------------------------------------------------------------------------------------
+HKD float jl_sin_kernel(double y) {
+    const double S1 = -0.16666666641626524, S2 = 0.008333329385889463, S3 = -0.00019839334836096632, S4 = 2.718311493989822e-6;
+    double z = y * y, w = z * z;
+    double r = S3 + z * S4, s = z * y;
+    return (float)((y + s * (S1 + z * S2)) + s * w * r);
+}
+HKD float jl_cos_kernel(double y) {
+    const double C0 = -0.499999997251031, C1 = 0.04166662332373906, C2 = -0.001388676377460993, C3 = 2.439044879627741e-5;
+    double z = y * y, w = z * z;
+    double r = C2 + z * C3;
+    return (float)(((1.0 + z * C0) + w * C1) + (w * z) * r);
+}
+// rem_pio2_kernel(x::Float32): n and the reduced argument (binary64) with x = n * pi/2 + y, |x| < 2^28 * pi/2
+HKD int jl_rem_pio2(float x, double& y) {
+    const double PI = 3.141592653589793;
+    const double xd = (double)x, ax = fabs(xd);
+    if (ax <= PI * 5 / 4) {
+        if (ax <= PI * 3 / 4) {
+            y = x > 0 ? xd - PI / 2 : xd + PI / 2;
+            return x > 0 ? 1 : -1;
+        }
+        y = x > 0 ? xd - PI : xd + PI;
+        return x > 0 ? 2 : -2;
+    }
+    if (ax <= PI * 9 / 4) {
+        if (ax <= PI * 7 / 4) {
+            y = x > 0 ? xd - 3 * (PI / 2) : xd + 3 * (PI / 2);
+            return x > 0 ? 3 : -3;
+        }
+        y = x > 0 ? xd - 2 * PI : xd + 2 * PI;
+        return x > 0 ? 4 : -4;
+    }
+    const double fn = rint(xd * 6.36619772367581382433e-01);   // Cody-Waite with a 33 + 53 bit pi/2
+    const double r = xd - fn * 1.57079631090164184570e+00, w = fn * 1.58932547735281966916e-08;
+    y = r - w;
+    return (int)fn;
+}
+HKD void jl_sincos(float x, float& s, float& c) {
+    const float ax = fabsf(x);
+    if (ax < 0.7853982f) {   // Float32(pi)/4: no reduction
+        s = ax < 0.00034526698f ? x : jl_sin_kernel((double)x);      // sqrt(eps(Float32))
+        c = ax < 0.00024414062f ? 1.0f : jl_cos_kernel((double)x);   // sqrt(eps(Float32)/2)
+        return;
+    }
+    if (!(ax < 2.1e8f)) {   // beyond the medium range (never reached by the sampling code): libm
+        s = sinf(x);
+        c = cosf(x);
+        return;
+    }
+    double y;
+    const int n = jl_rem_pio2(x, y) & 3;
+    const float sk = jl_sin_kernel(y), ck = jl_cos_kernel(y);
+    s = n == 0 ? sk : (n == 1 ? ck : (n == 2 ? -sk : -ck));
+    c = n == 0 ? ck : (n == 1 ? -sk : (n == 2 ? -ck : sk));
+}
+
+// ------------------------------------------------------------------------------------------------
 // sampling primitives (sampler/sampling.jl:1-30)
 // ------------------------------------------------------------------------------------------------
 HKD v2 concentric_sample_disk(v2 u) {
@@ -311,7 +374,9 @@ HKD v2 concentric_sample_disk(v2 u) {
     bool xl = fabsf(ox) > fabsf(oy);
     float r = xl ? ox : oy;
     float theta = xl ? ((oy / sx) * PI_F) / 4.0f : PI_F / 2.0f - ((ox / sy) * PI_F) / 4.0f;
-    return mk2(r * cosf(theta), r * sinf(theta));
+    float st, ct;
+    jl_sincos(theta, st, ct);
+    return mk2(r * ct, r * st);
 }
 HKD v3 cosine_sample_hemisphere(v2 u) {
     v2 d = concentric_sample_disk(u);
@@ -969,7 +1034,9 @@ HKD v3 tr_sample_wm(v3 w, v2 u, float ax, float ay) {
     v3 t2 = cross(wh, t1);
     float r = sqrtf(u.x);
     float phi = 2.0f * PI_F * u.y;
-    float px = r * cosf(phi), py = r * sinf(phi);
+    float sphi, cphi;
+    jl_sincos(phi, sphi, cphi);
+    float px = r * cphi, py = r * sphi;
     float h = sqrtf(1.0f - px * px);
     py = lerpf(h, py, 0.5f * (1.0f + wh.z));
     float pz = sqrtf(maxf(0.0f, 1.0f - px * px - py * py));
@@ -1222,7 +1289,9 @@ HKD v3 equal_area_square_to_sphere(v2 p) {
     float r = 1.0f - fabsf(sd);
     float phi = (r == 0.0f ? 1.0f : (vp - up) / r + 1.0f) * PI_F / 4.0f;
     float z = copysignf(1.0f - r * r, sd);
-    float cp = copysignf(cosf(phi), u), sp = copysignf(sinf(phi), v);
+    float sphi, cphi;
+    jl_sincos(phi, sphi, cphi);
+    float cp = copysignf(cphi, u), sp = copysignf(sphi, v);
     float rc = r * sqrtf(2.0f - r * r);
     return mk3(cp * rc, sp * rc, z);
 }
@@ -1365,7 +1434,9 @@ HKD LightSample sample_light(const DScene& sc, const DTables& T, const DLight& l
             float z = 1.0f - 2.0f * u.x;
             float r = sqrtf(maxf(0.0f, 1.0f - z * z));
             float phi = 2.0f * PI_F * u.y;
-            v3 wi = mk3(r * cosf(phi), r * sinf(phi), z);
+            float sphi, cphi;
+            jl_sincos(phi, sphi, cphi);
+            v3 wi = mk3(r * cphi, r * sphi, z);
             s.wi = wi;
             s.pdf = 1.0f / (4.0f * PI_F);
             s.p_light = p + 1.0e6f * wi;
@@ -1572,7 +1643,9 @@ HKD v3 sample_hg(float g, v3 wo, v2 u, float& pdf) {  // media.jl:51-72
     float phi = 2.0f * PI_F * u.y;
     v3 t1, t2;
     coordinate_system(-wo, t1, t2);
-    v3 wi = st * cosf(phi) * t1 + st * sinf(phi) * t2 + ct * (-wo);
+    float sphi, cphi;
+    jl_sincos(phi, sphi, cphi);
+    v3 wi = st * cphi * t1 + st * sphi * t2 + ct * (-wo);
     wi = normalize(wi);
     pdf = hg_p(g, ct);
     return wi;

@@ -52,7 +52,9 @@ HKD v3 lhg_sample(float g, v3 wo, v2 u, float& p) {
     float phi = 2.0f * PI_F * u.y;
     v3 t1, t2;
     coordinate_system(-wo, t1, t2);
-    v3 wi = st * cosf(phi) * t1 + st * sinf(phi) * t2 + ct * (-wo);
+    float sphi, cphi;
+    jl_sincos(phi, sphi, cphi);
+    v3 wi = st * cphi * t1 + st * sphi * t2 + ct * (-wo);
     wi = normalize(wi);
     p = lhg_pdf(g, ct);
     return wi;

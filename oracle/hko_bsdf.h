@@ -136,7 +136,9 @@ inline V3 tr_sample_wm(V3 w, V2 u, float ax, float ay) {
     V3 t2 = cross(wh, t1);
     float r = std::sqrt(u.x);
     float phi = 2.0f * PI_F * u.y;
-    float px = r * std::cos(phi), py = r * std::sin(phi);
+    float sphi, cphi;
+    jl_sincos(phi, sphi, cphi);
+    float px = r * cphi, py = r * sphi;
     float h = std::sqrt(1.0f - px * px);
     py = lerpf(h, py, 0.5f * (1.0f + wh.z));
     float pz = std::sqrt(maxf(0.0f, 1.0f - px * px - py * py));

@@ -115,4 +115,65 @@ inline RGBA clamp_rgb(const RGBA& a) {
 // luminance(::RGBSpectrum)     src/lights/light-sampler.jl:448-450
 inline float luminance(const RGBA& s) { return 0.212671f * s.c[0] + 0.715160f * s.c[1] + 0.072169f * s.c[2]; }
 
+// ------------------------------------------------------------------------------------------------
+// sin / cos of a binary32 argument the way Julia's Base computes them (base/special/trig.jl, a port of FreeBSD msun's k_sinf /
+// k_cosf / e_rem_pio2f): argument reduction and the polynomial kernels in binary64, ONE rounding to binary32 at the end.  The
+// reference calls Base.sin / Base.cos on Float32: this is that arithmetic (CPU ORACLE, test infrastructure).
+// ------------------------------------------------------------------------------------------------
+inline float jl_sin_kernel(double y) {
+    const double S1 = -0.16666666641626524, S2 = 0.008333329385889463, S3 = -0.00019839334836096632, S4 = 2.718311493989822e-6;
+    double z = y * y, w = z * z;
+    double r = S3 + z * S4, s = z * y;
+    return (float)((y + s * (S1 + z * S2)) + s * w * r);
+}
+inline float jl_cos_kernel(double y) {
+    const double C0 = -0.499999997251031, C1 = 0.04166662332373906, C2 = -0.001388676377460993, C3 = 2.439044879627741e-5;
+    double z = y * y, w = z * z;
+    double r = C2 + z * C3;
+    return (float)(((1.0 + z * C0) + w * C1) + (w * z) * r);
+}
+// rem_pio2_kernel(x::Float32): n and the reduced argument (binary64) with x = n * pi/2 + y, |x| < 2^28 * pi/2
+inline int jl_rem_pio2(float x, double& y) {
+    const double PI = 3.141592653589793;
+    const double xd = (double)x, ax = std::fabs(xd);
+    if (ax <= PI * 5 / 4) {
+        if (ax <= PI * 3 / 4) {
+            y = x > 0 ? xd - PI / 2 : xd + PI / 2;
+            return x > 0 ? 1 : -1;
+        }
+        y = x > 0 ? xd - PI : xd + PI;
+        return x > 0 ? 2 : -2;
+    }
+    if (ax <= PI * 9 / 4) {
+        if (ax <= PI * 7 / 4) {
+            y = x > 0 ? xd - 3 * (PI / 2) : xd + 3 * (PI / 2);
+            return x > 0 ? 3 : -3;
+        }
+        y = x > 0 ? xd - 2 * PI : xd + 2 * PI;
+        return x > 0 ? 4 : -4;
+    }
+    const double fn = std::rint(xd * 6.36619772367581382433e-01);   // Cody-Waite with a 33 + 53 bit pi/2
+    const double r = xd - fn * 1.57079631090164184570e+00, w = fn * 1.58932547735281966916e-08;
+    y = r - w;
+    return (int)fn;
+}
+inline void jl_sincos(float x, float& s, float& c) {
+    const float ax = std::fabs(x);
+    if (ax < 0.7853982f) {   // Float32(pi)/4: no reduction
+        s = ax < 0.00034526698f ? x : jl_sin_kernel((double)x);      // sqrt(eps(Float32))
+        c = ax < 0.00024414062f ? 1.0f : jl_cos_kernel((double)x);   // sqrt(eps(Float32)/2)
+        return;
+    }
+    if (!(ax < 2.1e8f)) {   // beyond the medium range (never reached by the sampling code): libm
+        s = std::sin(x);
+        c = std::cos(x);
+        return;
+    }
+    double y;
+    const int n = jl_rem_pio2(x, y) & 3;
+    const float sk = jl_sin_kernel(y), ck = jl_cos_kernel(y);
+    s = n == 0 ? sk : (n == 1 ? ck : (n == 2 ? -sk : -ck));
+    c = n == 0 ? ck : (n == 1 ? -sk : (n == 2 ? -ck : sk));
+}
+
 }  // namespace hko

@@ -53,7 +53,9 @@ inline V3 sample_hg_phase(float g, V3 wo, V2 u, float& p) {
     float phi = 2.0f * PI_F * u.y;
     V3 t1, t2;
     coordinate_system(-wo, t1, t2);
-    V3 wi = sin_t * std::cos(phi) * t1 + sin_t * std::sin(phi) * t2 + cos_t * (-wo);
+    float sphi, cphi;
+    jl_sincos(phi, sphi, cphi);
+    V3 wi = sin_t * cphi * t1 + sin_t * sphi * t2 + cos_t * (-wo);
     wi = normalize(wi);
     p = hg_phase_pdf(g, cos_t);
     return wi;

@@ -145,8 +145,10 @@ inline V3 equal_area_square_to_sphere(V2 p) {
     float r = 1.0f - d;
     float phi = (r == 0.0f ? 1.0f : (vp - up) / r + 1.0f) * PI_F / 4.0f;
     float z = std::copysign(1.0f - r * r, sd);
-    float cos_phi = std::copysign(std::cos(phi), u);
-    float sin_phi = std::copysign(std::sin(phi), v);
+    float sphi, cphi;
+    jl_sincos(phi, sphi, cphi);
+    float cos_phi = std::copysign(cphi, u);
+    float sin_phi = std::copysign(sphi, v);
     float r_cyl = r * std::sqrt(2.0f - r * r);
     return V3(cos_phi * r_cyl, sin_phi * r_cyl, z);
 }
@@ -309,7 +311,9 @@ inline LightSample sample_light_spectral(const RGB2SpecTable& t, const TextureSe
             float z = 1.0f - 2.0f * u.x;
             float r = std::sqrt(maxf(0.0f, 1.0f - z * z));
             float phi = 2.0f * PI_F * u.y;
-            V3 wi(r * std::cos(phi), r * std::sin(phi), z);
+            float sphi, cphi;
+            jl_sincos(phi, sphi, cphi);
+            V3 wi(r * cphi, r * sphi, z);
             s.wi = wi;
             s.pdf = 1.0f / (4.0f * PI_F);
             s.p_light = p + 1.0e6f * wi;

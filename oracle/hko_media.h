@@ -43,7 +43,9 @@ inline V3 sample_hg(float g, V3 wo, V2 u, float& pdf) {  // media.jl:51-72
     float phi = 2.0f * PI_F * u.y;
     V3 t1, t2;
     coordinate_system_m(-wo, t1, t2);
-    V3 wi = sin_t * std::cos(phi) * t1 + sin_t * std::sin(phi) * t2 + cos_t * (-wo);
+    float sphi, cphi;
+    jl_sincos(phi, sphi, cphi);
+    V3 wi = sin_t * cphi * t1 + sin_t * sphi * t2 + cos_t * (-wo);
     wi = normalize(wi);
     pdf = hg_p(g, cos_t);
     return wi;

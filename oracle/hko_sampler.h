@@ -258,7 +258,9 @@ inline V2 concentric_sample_disk(V2 u) {
     bool xl = ax > ay;
     float r = xl ? ox : oy;
     float theta = xl ? ((oy / sx) * PI_F) / 4.0f : PI_F / 2.0f - ((ox / sy) * PI_F) / 4.0f;
-    return V2(r * std::cos(theta), r * std::sin(theta));
+    float st, ct;
+    jl_sincos(theta, st, ct);
+    return V2(r * ct, r * st);
 }
 inline V3 cosine_sample_hemisphere(V2 u) {
     V2 d = concentric_sample_disk(u);

@@ -115,6 +115,9 @@ def main():
     run_steps(0, max(args.warmup, 1) if args.warmup > 0 else 0)
     barrier()
     setup_s = time.time() - t0
+    if world > 1:
+        hd.reduce_film(accum, root=0)   # untimed: RCCL sets up the reduce's channels on first use
+        barrier()
     accum.zero_()
     vp.enable_counters(count_nodes=False, time_kernels=True)   # HIP events around every launch, on the launch stream
     vp.reset_stats()

@@ -199,10 +199,10 @@ HKD float sobol_sample(uint64_t a, int dimension, uint32_t scramble, const uint3
     const float lim = 1.0f - 1.1920929e-7f;
     return f < lim ? f : lim;
 }
-// PERMUTATIONS_4WAY packed: 4 x 2 bits per permutation (sobol.jl:155-180)
-__device__ static const uint8_t kPerm4[24] = {
-    0xE4, 0xB4, 0xD8, 0x78, 0x6C, 0x9C, 0xE1, 0xB1, 0xC9, 0x39, 0x2D, 0x8D,
-    0xC6, 0x36, 0xD2, 0x72, 0x4E, 0x1E, 0x27, 0x87, 0x1B, 0x4B, 0x63, 0x93};
+// PERMUTATIONS_4WAY packed: 4 x 2 bits per permutation (sobol.jl:155-180):
+//    0xE4, 0xB4, 0xD8, 0x78, 0x6C, 0x9C, 0xE1, 0xB1, 0xC9, 0x39, 0x2D, 0x8D, 0xC6, 0x36, 0xD2, 0x72, 0x4E, 0x1E, 0x27, 0x87, 0x1B, 0x4B, 0x63, 0x93
+// held as three 64-bit immediates (8 permutations each): as a constant array the lookup is a byte load with a per-lane index, 24
+// of them per path vertex, and per-lane cache-line lookups are what these kernels run out of (k_shade -11 % without them).
 // Digits i = i_hi .. i_lo of the permuted index (sobol.jl:225-262).  The full index is digits n-1 .. pow2 plus the last-bit
 // special case; the digits whose bits lie above the sample bits (shift >= log2_spp) do not depend on the sample index.
 HKD uint64_t zsobol_digits(uint64_t morton, uint64_t dmix, int pow2, int i_hi, int i_lo) {
@@ -215,7 +215,8 @@ HKD uint64_t zsobol_digits(uint64_t morton, uint64_t dmix, int pow2, int i_hi, i
         // (h >> 24) % 24 on a 40-bit value with 32-bit arithmetic: 2^32 mod 24 == 16
         uint32_t xlo = (uint32_t)(h >> 24), xhi = (uint32_t)(h >> 56);
         int p = (int)((xhi * 16u + xlo % 24u) % 24u);
-        uint64_t pd = (uint64_t)((kPerm4[p] >> (2 * digit)) & 3);
+        const uint64_t pw = p < 8 ? 0xb1e19c6c78d8b4e4ull : (p < 16 ? 0x72d236c68d2d39c9ull : 0x93634b1b87271e4eull);
+        uint64_t pd = (pw >> (8 * (p & 7) + 2 * digit)) & 3ull;
         sample_index |= pd << shift;
     }
     return sample_index;

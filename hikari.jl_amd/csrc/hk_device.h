@@ -857,9 +857,13 @@ HKD Surface surface_at(const DScene& sc, int prim, float bu, float bv, v3 ro, v3
     s.uv = uv_at(sc, prim, w, bu, bv);
     v3 ns = n;
     if (sc.normals) {
+        // the nine floats in three loads up front: read field by field behind the NaN test they become twelve per-lane loads
+        typedef float hk_f4u __attribute__((ext_vector_type(4), aligned(4)));
         const float* q = sc.normals + 9 * (size_t)prim;
-        if (!(isnan(q[0]) || isnan(q[3]) || isnan(q[6])))
-            ns = normalize(mk3(w * q[0] + bu * q[3] + bv * q[6], w * q[1] + bu * q[4] + bv * q[7], w * q[2] + bu * q[5] + bv * q[8]));
+        const hk_f4u q0 = *reinterpret_cast<const hk_f4u*>(q), q1 = *reinterpret_cast<const hk_f4u*>(q + 4);
+        const float q8 = q[8];
+        if (!(isnan(q0.x) || isnan(q0.w) || isnan(q1.z)))
+            ns = normalize(mk3(w * q0.x + bu * q0.w + bv * q1.z, w * q0.y + bu * q1.x + bv * q1.w, w * q0.z + bu * q1.y + bv * q8));
     }
     s.n = dot(n, ns) < 0.0f ? -n : n;
     s.ns = ns;

@@ -17,6 +17,7 @@ from .materials import (Aluminum, Brass, Copper, Gold, Silver, CoatedConductorMa
                         MediumInterface, MirrorMaterial, MixMaterial, PiecewiseLinearSpectrum, PlasticMaterial,
                         RGBSpectrum, Texture, ThinDielectricMaterial, VertexColorTexture)
 from .media import GridMedium, HomogeneousMedium, NanoVDBMedium, RGBGridMedium
+from .media_presets import Coffee, Fog, Juice, Milk, Smoke, SubsurfaceMedium, Wine, get_medium_preset
 from .postprocess import FilmSensor, compute_white_balance_matrix
 from .scene import Scene
 from .sunsky import sunsky_to_envlight

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -271,6 +272,55 @@ int bake_mode(int kind, int slot) {
 }
 }  // namespace
 
+
+namespace {
+// Range checks of a scene description: texture / spectrum / Mix child / area-light / medium indices.
+std::string validate_desc(const hk_scene_desc& d) {
+    auto need = [](int n, const void* p) { return n <= 0 || p != nullptr; };
+    if (d.n_materials < 0 || d.n_textures < 0 || d.n_media_interfaces < 0 || d.n_lights < 0 || d.n_envmaps < 0 || d.n_media < 0 || d.n_spectra < 0) return "negative count";
+    if (!need(d.n_materials, d.materials) || !need(d.n_textures, d.textures) || !need(d.n_media_interfaces, d.media_interfaces) || !need(d.n_lights, d.lights) ||
+        !need(d.n_media, d.media) || !need(d.n_spectra, d.spectra))
+        return "count > 0 with a null array";
+    auto tex_ok = [&](int t, int channels) { return t < 0 || (t < d.n_textures && (channels == 0 || d.textures[t].channels == channels || d.textures[t].kind == 1)); };
+    for (int i = 0; i < d.n_textures; ++i) {
+        const hk_texture& t = d.textures[i];
+        if (!t.data || t.width <= 0 || t.height <= 0 || (t.channels != 1 && t.channels != 4) || (t.kind != 0 && t.kind != 1)) return "bad texture record " + std::to_string(i);
+        if (t.kind == 1 && (t.height != 3 || t.channels != 4)) return "vertex-colour texture must be face_colors[3, n_faces] RGBA";
+    }
+    for (int i = 0; i < d.n_spectra; ++i)
+        if (d.spectra[i].n < 1 || !d.spectra[i].lambdas || !d.spectra[i].values) return "bad spectrum record " + std::to_string(i);
+    for (int i = 0; i < d.n_materials; ++i) {
+        const hk_material& m = d.materials[i];
+        for (int k = 0; k < 4; ++k)
+            if (!tex_ok(m.rgb[k].tex, 0)) return "material " + std::to_string(i) + ": rgb texture index out of range";
+        for (int k = 0; k < 8; ++k)
+            if (!tex_ok(m.f[k].tex, 0)) return "material " + std::to_string(i) + ": float texture index out of range";
+        const bool reads_spectra = m.kind == HK_MAT_CONDUCTOR || m.kind == HK_MAT_COATED_CONDUCTOR;
+        for (int k = 0; k < 2; ++k)
+            if (reads_spectra && m.spectrum[k] >= d.n_spectra) return "material " + std::to_string(i) + ": spectrum index out of range";
+        if (m.kind == HK_MAT_MIX && (m.i[0] < 0 || m.i[0] >= d.n_materials || m.i[1] < 0 || m.i[1] >= d.n_materials))
+            return "MixMaterial " + std::to_string(i) + ": child material index out of range";
+    }
+    for (int i = 0; i < d.n_media_interfaces; ++i) {
+        const hk_medium_interface& mi = d.media_interfaces[i];
+        if (mi.material < 0 || mi.material >= d.n_materials) return "medium interface references a missing material";
+        if (mi.inside < -1 || mi.inside >= d.n_media || mi.outside < -1 || mi.outside >= d.n_media) return "medium interface references a missing medium";
+    }
+    for (int i = 0; i < d.n_lights; ++i) {
+        const hk_light& l = d.lights[i];
+        if (l.kind < HK_LIGHT_POINT || l.kind > HK_LIGHT_DIFFUSE_AREA) return "unknown light kind";
+        if (l.kind == HK_LIGHT_DIFFUSE_AREA && !tex_ok(l.Le.tex, 0)) return "area light: Le texture index out of range";
+    }
+    for (int t = 0; t < d.n_triangles; ++t) {
+        const hk_tri_meta& m = d.meta[t];
+        if ((int64_t)m.medium_interface_idx >= d.n_media_interfaces) return "triangle references a missing medium interface";
+        if ((int64_t)m.arealight_flat_idx_1based > d.n_lights) return "triangle references a missing area light";
+        if (m.arealight_flat_idx_1based > 0 && d.lights[m.arealight_flat_idx_1based - 1].kind != HK_LIGHT_DIFFUSE_AREA) return "triangle's area-light index is not a DiffuseAreaLight";
+    }
+    return std::string();
+}
+}  // namespace
+
 extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene** out) {
     if (!c || !d || !out) return fail(HK_ERR_INVALID, "null argument");
     if (!c->have_tables) return fail(HK_ERR_INVALID, "hk_ctx_set_tables must be called first");
@@ -279,8 +329,14 @@ extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene**
         if (d->lights[i].kind == HK_LIGHT_ENVIRONMENT && (d->lights[i].envmap < 0 || d->lights[i].envmap >= d->n_envmaps))
             return fail(HK_ERR_INVALID, "environment light refers to a missing envmap");
     if (d->n_triangles < 0 || (d->n_triangles > 0 && (!d->positions || !d->meta))) return fail(HK_ERR_INVALID, "bad triangle arrays");
+    {   // every index the device will follow is checked here: a malformed description is an error, never an out-of-bounds read
+        std::string bad = validate_desc(*d);
+        if (!bad.empty()) return fail(HK_ERR_INVALID, bad);
+    }
     HIP_TRY(hipSetDevice(c->device));
-    hk_scene* s = new hk_scene();
+    // the scene is owned by `guard` until it is handed to the caller: every error return below frees what was built so far
+    std::unique_ptr<hk_scene> guard(new hk_scene());
+    hk_scene* s = guard.get();
     s->ctx = c;
     const int T = d->n_triangles;
     // ---- classify surfaces: opaque = no medium transition and no alpha test possible ----
@@ -294,7 +350,6 @@ extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene**
     for (int i = 0; i < d->n_media_interfaces; ++i) {
         const hk_medium_interface& mi = d->media_interfaces[i];
         if (mi.material < 0 || mi.material >= d->n_materials) {
-            delete s;
             return fail(HK_ERR_INVALID, "medium interface references a missing material");
         }
         bool op = mi.inside == mi.outside && !mat_alpha[mi.material];
@@ -324,7 +379,6 @@ extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene**
         uint32_t flags = 0;
         uint32_t mi = d->meta[prim].medium_interface_idx;
         if ((int)mi >= d->n_media_interfaces) {
-            delete s;
             return fail(HK_ERR_INVALID, "triangle references a missing medium interface");
         }
         if (mi_opaque[mi]) flags |= HK_TRI_OPAQUE;
@@ -517,7 +571,6 @@ extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene**
             const hk_envmap& e = d->envmaps[i];
             if (e.width <= 0 || e.height <= 0 || e.nu <= 0 || e.nv <= 0 || !e.data || !e.conditional_func || !e.conditional_cdf || !e.conditional_func_int ||
                 !e.marginal_func || !e.marginal_cdf) {
-                delete s;
                 return fail(HK_ERR_INVALID, "incomplete hk_envmap record");
             }
             auto up = [&](const float* src, size_t n, const float** dst) -> hipError_t {
@@ -549,11 +602,9 @@ extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene**
         const hk_medium& m = d->media[i];
         DMedium& o = dmed[i];
         if (m.kind < HK_MEDIUM_HOMOGENEOUS || m.kind > HK_MEDIUM_NANOVDB) {
-            delete s;
             return fail(HK_ERR_INVALID, "unknown medium kind");
         }
         if (m.kind == HK_MEDIUM_RGB_GRID && ((!m.sigma_a_grid && !m.sigma_s_grid) || (m.Le_grid && !m.sigma_a_grid))) {  // media.jl:1073-1079
-            delete s;
             return fail(HK_ERR_INVALID, "RGBGridMedium needs sigma_a_grid or sigma_s_grid (and sigma_a_grid when Le_grid is given)");
         }
         o.kind = m.kind;
@@ -576,7 +627,6 @@ extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene**
         o.root_table_size = m.root_table_size;
         if (m.kind != HK_MEDIUM_HOMOGENEOUS) {
             if (!m.majorant) {
-                delete s;
                 return fail(HK_ERR_INVALID, "heterogeneous medium without a majorant grid");
             }
             DevBuf* mb = new DevBuf();
@@ -651,7 +701,6 @@ extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene**
                     }
                 }
                 if (unbounded) {
-                    delete s;
                     return fail(HK_ERR_UNSUPPORTED, "NanoVDB grid with a non-background root tile (4096^3 constant region) is not supported");
                 }
                 for (int k = 0; k < 3; ++k) {
@@ -665,7 +714,6 @@ extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene**
                 total *= dim[k];
             }
             if (total > (1ll << 27) || m.nvdb_size >= (1ll << 32)) {
-                delete s;
                 return fail(HK_ERR_UNSUPPORTED, "NanoVDB grid too large for the device block table (index bbox > 2^27 blocks or buffer >= 4 GiB)");
             }
             o.nv_background = bg_probe;
@@ -684,7 +732,6 @@ extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene**
                         if (on_margin && (leaf != 0 || value != bg_probe)) margin_ok = false;  // cannot happen after the scan above
                     }
             if (!margin_ok) {
-                delete s;
                 return fail(HK_ERR_INVALID, "NanoVDB block table: non-background data on the margin (corrupt tree?)");
             }
             DevBuf* tb = new DevBuf();
@@ -726,7 +773,7 @@ extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene**
     D.has_escape_lights = has_escape;
     D.all_opaque = all_opaque ? 1 : 0;
     D.bvh_depth = bvh.max_depth;
-    *out = s;
+    *out = guard.release();
     return HK_OK;
 }
 extern "C" int32_t hk_scene_destroy(hk_scene* s) {
@@ -1103,6 +1150,8 @@ extern "C" int32_t hk_render(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_film*
                              int32_t sample_stride) {
     if (!c || !sc || !I || !film || !cam) return fail(HK_ERR_INVALID, "null argument");
     if (n_samples < 0 || sample_stride < 1 || first_sample_idx < 1) return fail(HK_ERR_INVALID, "bad sample range");
+    if (!c->have_tables) return fail(HK_ERR_INVALID, "hk_ctx_set_tables must be called first");
+    if (sc->ctx != c || I->ctx != c || film->ctx != c) return fail(HK_ERR_INVALID, "scene / integrator / film belong to another context");
     if (film->f64 != (I->p.accumulate_f64 != 0)) return fail(HK_ERR_INVALID, "film / integrator accumulation type mismatch");
     if (n_samples == 0) return HK_OK;
     HIP_TRY(hipSetDevice(c->device));
@@ -1192,6 +1241,9 @@ extern "C" int32_t hk_render(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_film*
             return HK_OK;
         };
         HIP_TRY(hipMemsetAsync(I->st.tickets, 0, (size_t)I->st.ticket_rows * HK_TICKET_COLS * sizeof(int), s));
+        // queue sizes start every pass at zero: a depth at which no shade / scatter kernel runs (a triangle-free scene lit by an
+        // environment map, say) must not see the ray / shadow counts an earlier render left behind
+        HIP_TRY(hipMemsetAsync(I->st.counters, 0, (size_t)(I->st_depth + 2) * Q_COUNT * I->st.n_waves * sizeof(int), s));
         if (timed(3, [&] { hk::launch_camera(s, c->n_cu, I->st, fr, c->tables, I->filter, dc, sob, -1); }) != HK_OK) return fail(HK_ERR_DEVICE, "event record failed");
         for (int depth = 0; depth < I->p.max_depth; ++depth) {
             timed(0, [&] { hk::launch_trace(s, trace_blocks, I->st, sc->d, c->tables, fr, depth, dstats); });

@@ -1692,6 +1692,17 @@ static int resident_blocks(K kernel, int block, int n_cu, int cap_per_cu) {
     if (per_cu > cap_per_cu) per_cu = cap_per_cu;
     return per_cu * n_cu;
 }
+// Residency is a property of (kernel, device): cached per kernel instantiation AND per device, so one process can drive several
+// GPUs (the in-library multi-device path) without one device's answer leaking to another.
+#define HK_MAX_DEVICES 64
+template <auto Kernel>
+static int cached_blocks(int block, int n_cu, int cap_per_cu) {
+    static int cache[HK_MAX_DEVICES];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= HK_MAX_DEVICES) return resident_blocks(Kernel, block, n_cu, cap_per_cu);
+    if (cache[dev] == 0) cache[dev] = resident_blocks(Kernel, block, n_cu, cap_per_cu);
+    return cache[dev];
+}
 // Segments are walked with a static stride, so the number of physical waves must DIVIDE W or the last round runs with a
 // fraction of the waves (shade at W = 16/CU with 12 resident: 12 % slower than at W = 24): the largest divisor of the
 // 4-wave block count that is resident.
@@ -1710,14 +1721,14 @@ static int clamp_blocks(int blocks, const DPathState& st) {
 }
 
 void launch_camera(hipStream_t s, int n_cu, const DPathState& st, const DFrame& fr, const DTables& T, const DFilter& f, const DCamera& c, const DSobol& sob, int initial_medium) {
-    static int blocks = resident_blocks(k_camera, 256, n_cu, 8);
+    const int blocks = cached_blocks<k_camera>(256, n_cu, 8);
     hipLaunchKernelGGL(k_camera, dim3(clamp_blocks(blocks, st)), dim3(256), 0, s, st, fr, T, f, c, sob, initial_medium);
 }
 void launch_trace(hipStream_t s, int n_cu, const DPathState& st, const DScene& sc, const DTables& T, const DFrame& fr, int depth, DStats* stats) {
     if (sc.all_opaque && sc.n_media == 0) {
 #define HK_LEAN_LAUNCH(K, C, S)                                                                                       \
     {                                                                                                                 \
-        static int blocks = resident_blocks(K<C, S>, HK_TRACE_BLOCK, n_cu, 8);                                         \
+        const int blocks = cached_blocks<K<C, S>>(HK_TRACE_BLOCK, n_cu, 8);                                         \
         hipLaunchKernelGGL((K<C, S>), dim3(clamp_blocks(blocks, st)), dim3(HK_TRACE_BLOCK), 0, s, st, sc, depth, stats); \
     }
 #define HK_LEAN_DISPATCH(K)                                        \
@@ -1731,7 +1742,7 @@ void launch_trace(hipStream_t s, int n_cu, const DPathState& st, const DScene& s
         HK_LEAN_DISPATCH(k_trace_lean)
         return;
     }
-    static int b0 = resident_blocks(k_trace<false>, HK_TRACE_BLOCK, n_cu, 8), b1 = resident_blocks(k_trace<true>, HK_TRACE_BLOCK, n_cu, 8);
+    const int b0 = cached_blocks<k_trace<false>>(HK_TRACE_BLOCK, n_cu, 8), b1 = cached_blocks<k_trace<true>>(HK_TRACE_BLOCK, n_cu, 8);
     if (fr.count_nodes)
         hipLaunchKernelGGL(k_trace<true>, dim3(clamp_blocks(b1, st)), dim3(HK_TRACE_BLOCK), 0, s, st, sc, T, fr, depth, stats);
     else
@@ -1749,7 +1760,7 @@ void launch_shadow(hipStream_t s, int n_cu, const DPathState& st, const DScene& 
     }
 #define HK_SHADOW_LAUNCH(C, MM)                                                                                                        \
     {                                                                                                                                  \
-        static int blocks = resident_blocks(k_shadow_walk<C, MM>, HK_TRACE_BLOCK, n_cu, 8);                                             \
+        const int blocks = cached_blocks<k_shadow_walk<C, MM>>(HK_TRACE_BLOCK, n_cu, 8);                                             \
         hipLaunchKernelGGL((k_shadow_walk<C, MM>), dim3(clamp_blocks(blocks, st)), dim3(HK_TRACE_BLOCK), 0, s, st, sc, T, depth, stats); \
     }
 #define HK_SHADOW_MM(C)                                   \
@@ -1772,7 +1783,7 @@ void launch_shadow(hipStream_t s, int n_cu, const DPathState& st, const DScene& 
 void launch_medium(hipStream_t s, int n_cu, const DPathState& st, const DScene& sc, const DTables& T, const DFrame& fr, const DSobol& sob, int depth, DStats* stats) {
 #define HK_TRACK_LAUNCH(MM)                                                                                              \
     {                                                                                                                    \
-        static int blocks = resident_blocks(k_track<MM>, 256, n_cu, 8);                                                   \
+        const int blocks = cached_blocks<k_track<MM>>(256, n_cu, 8);                                                   \
         hipLaunchKernelGGL((k_track<MM>), dim3(clamp_blocks(blocks, st)), dim3(256), 0, s, st, sc, T, fr, depth, stats);   \
     }
     switch (media_mask_class(sc)) {
@@ -1783,20 +1794,20 @@ void launch_medium(hipStream_t s, int n_cu, const DPathState& st, const DScene& 
         default: HK_TRACK_LAUNCH(15) break;
     }
 #undef HK_TRACK_LAUNCH
-    static int sblocks = resident_blocks(k_scatter, 256, n_cu, 8);
+    const int sblocks = cached_blocks<k_scatter>(256, n_cu, 8);
     hipLaunchKernelGGL(k_scatter, dim3(clamp_blocks(sblocks, st)), dim3(256), 0, s, st, sc, T, fr, sob, depth, stats);
 }
 void launch_detect_camera_medium(hipStream_t s, const DPathState& st, const DScene& sc, float x, float y, float z, DStats* stats) {
     hipLaunchKernelGGL(k_detect_camera_medium, dim3(1), dim3(64), 0, s, st, sc, x, y, z, stats);
 }
 void launch_escaped(hipStream_t s, int n_cu, const DPathState& st, const DScene& sc, const DTables& T, int depth) {
-    static int blocks = resident_blocks(k_escaped, 256, n_cu, 8);
+    const int blocks = cached_blocks<k_escaped>(256, n_cu, 8);
     hipLaunchKernelGGL(k_escaped, dim3(clamp_blocks(blocks, st)), dim3(256), 0, s, st, sc, T, depth);
 }
 void launch_shade(hipStream_t s, int n_cu, int kind, const DPathState& st, const DScene& sc, const DTables& T, const DFrame& fr, const DSobol& sob, int depth, int first_kind, DStats* stats) {
 #define HK_SHADE_CASE(K)                                                                                                          \
     case K: {                                                                                                                     \
-        static int blocks = resident_blocks(k_shade<K>, 256, n_cu, 8);                                                            \
+        const int blocks = cached_blocks<k_shade<K>>(256, n_cu, 8);                                                            \
         hipLaunchKernelGGL(k_shade<K>, dim3(clamp_blocks(blocks, st)), dim3(256), 0, s, st, sc, T, fr, sob, depth, first_kind, stats); \
     } break;
     switch (kind) {
@@ -1810,7 +1821,7 @@ void launch_shade(hipStream_t s, int n_cu, int kind, const DPathState& st, const
         HK_SHADE_CASE(HK_MAT_COATED_DIFFUSE_TRANSMISSION)
         HK_SHADE_CASE(HK_MAT_COATED_CONDUCTOR)
         default: {
-            static int blocks = resident_blocks(k_shade<HK_MAT_FALLBACK>, 256, n_cu, 8);
+            const int blocks = cached_blocks<k_shade<HK_MAT_FALLBACK>>(256, n_cu, 8);
             hipLaunchKernelGGL(k_shade<HK_MAT_FALLBACK>, dim3(clamp_blocks(blocks, st)), dim3(256), 0, s, st, sc, T, fr, sob, depth, first_kind, stats);
         } break;
     }

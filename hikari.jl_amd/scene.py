@@ -32,6 +32,7 @@ class Scene:
         self._envmaps = []
         self._desc = None
         self._keep = None
+        self._device = {}           # id(ctx) -> hk_scene handle (owned: released by close() / the next sync())
         self.bounds = None
 
     # ---- push! ---------------------------------------------------------------------------------
@@ -276,6 +277,7 @@ class Scene:
 
     def sync(self):
         """sync!(scene): flatten to hk_scene_desc (kept alive on self) and compute world bounds."""
+        self.close()                # device scenes built from the previous description are released, not leaked
         keep = []
         P = np.concatenate([m.positions for m, _ in self._meshes], axis=0) if self._meshes else np.zeros((0, 3, 3), f32)
         T = P.shape[0]
@@ -349,6 +351,21 @@ class Scene:
             self.bounds = (lo, hi, c, float(np.linalg.norm(hi - c)))
         self._device = {}
         return self
+
+    def close(self):
+        """Release every device scene (BVH, leaf triangles, textures, env maps, media) created from this Scene."""
+        dev, self._device = getattr(self, "_device", None) or {}, {}
+        if dev:
+            from . import _lib
+            L = _lib.lib()
+            for h in dev.values():
+                L.hk_scene_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     @property
     def desc(self):

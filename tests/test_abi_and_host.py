@@ -201,3 +201,30 @@ def test_postprocess_oracle_closed_forms(hk, oracle):
     assert np.allclose(out[:, 4], [0.2, 0.4, 0.6], atol=1e-6)                                      # fully escaped neighbourhood
     assert np.allclose(out[:, 0], np.clip(fb[:, 0], 0, 1), atol=1e-6)                              # untouched far from the edge
     assert not np.allclose(out[:, 2], np.clip(fb[:, 2], 0, 1), atol=1e-3)                          # blended at the silhouette
+
+
+def test_medium_presets_table_and_constructors(hk):
+    """volpath/media.jl:1769-1829 (40 named media) and the constructors :1874-2032: values as float32, scale multiplies both
+    coefficients, Smoke / Fog follow their density / albedo formulas, unknown names are errors."""
+    f32 = np.float32
+    from hikari_jl_amd import media_presets as MP
+    assert len(MP._presets()) == 40
+    p = hk.get_medium_preset("Wholemilk")
+    assert p["sigma_s"] == [2.55, 3.21, 3.77] and p["sigma_a"] == [0.0011, 0.0024, 0.014]
+    assert hk.get_medium_preset("Spectralon")["sigma_a"] == [0.0, 0.0, 0.0]
+    m = hk.Milk(scale=0.5, g=0.8)
+    assert m.sigma_s.c[:3] == tuple(float(f32(v) * f32(0.5)) for v in (2.55, 3.21, 3.77)) and m.g == float(f32(0.8))
+    assert hk.Coffee().sigma_a.c[:3] == tuple(float(f32(v)) for v in (4.80, 6.58, 8.85))
+    assert hk.Juice("grape").sigma_s.c[:3] == (float(f32(5.4e-5)), 0.0, 0.0)
+    assert hk.Wine("merlot", scale=2).sigma_a.c[:3] == tuple(float(f32(v) * f32(2)) for v in (0.116, 0.252, 0.294))
+    assert hk.SubsurfaceMedium("Ketchup").sigma_a.c[1] == float(f32(0.97))
+    s = hk.Smoke(density=2.0, albedo=0.75)
+    assert s.sigma_s.c[0] == 1.5 and s.sigma_a.c[0] == 0.5 and s.sigma_s.c[0] == s.sigma_s.c[2]
+    fog = hk.Fog(density=0.3)
+    assert fog.sigma_s.c[0] == float(f32(0.3)) and fog.sigma_a.c[0] == float(f32(0.3) * f32(0.001))
+    for bad in (lambda: hk.get_medium_preset("Mercury"), lambda: hk.Juice("mango"), lambda: hk.Wine("rioja")):
+        with pytest.raises(KeyError):
+            bad()
+    rec = hk._abi.hk_medium()
+    m.fill_record(rec, [])
+    assert rec.kind == hk._abi.HK_MEDIUM_HOMOGENEOUS and rec.sigma_s[2] == f32(3.77) * f32(0.5)

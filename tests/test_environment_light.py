@@ -122,7 +122,10 @@ def test_hosek_wilkie_bake(hk):
     assert np.isclose(env.scale_rgb.c[0], 2.0 / 10567.0, rtol=1e-6) and np.isclose(sun.scale, 1.0 / 10567.0, rtol=1e-6)
     n = np.array([1, 2, 9]) / np.linalg.norm([1, 2, 9])
     assert np.allclose(sun.direction, -n, atol=1e-6)
-    assert np.allclose(sun.i.c[:3] if hasattr(sun.i, "c") else (10.0, 9.5, 8.5), (10.0, 9.5, 8.5)) or True
+    # SunLight(RGB(5, 4.75, 4.25) * intensity, ...) bakes rgb_illuminant_spectrum: scale = 2 max(rgb), poly of rgb / scale
+    from hikari_jl_amd.tables import rgb_to_spectrum
+    assert np.isclose(sun.i.scale, 20.0, rtol=1e-6)
+    assert np.allclose(sun.i.poly, rgb_to_spectrum(np.float32(0.5), np.float32(0.475), np.float32(0.425)), rtol=1e-6)
     from hikari_jl_amd.envmap import equal_area_square_to_sphere
     c = (np.arange(64) + 0.5) / 64
     uu, vv = np.meshgrid(c, c)

@@ -63,6 +63,17 @@ def main():
     rad = [np.array([float(t) for t in grab_block(hw, "_HOSEK_SPECTRAL_RAD_%d" % b)], dtype=np.float64) for b in bands]
     assert all(c.size == 1080 for c in cfg) and all(r.size == 120 for r in rad)
     np.concatenate(cfg + rad).tofile(os.path.join(OUT, "hosek_wilkie_sky.bin"))
+    # measured medium presets (pbrt-v4 "named media": Jensen et al. 2001, Narasimhan et al. 2006), volpath/media.jl:1769-1829
+    med = open(os.path.join(REF, "integrators/volpath/media.jl")).read()
+    blk = re.search(r"const _MEDIUM_PRESETS = Dict\{.*?\}\((.*?)\n\)\n", med, re.S).group(1)
+    num = lambda t: float(re.sub(r"f(-?\d+)$", r"e\1", t.strip()))
+    presets = {}
+    for name, ss, sa in re.findall(r'"(\w+)"\s*=>\s*\(σ_s=\(([^)]*)\),\s*σ_a=\(([^)]*)\)\)', blk):
+        presets[name] = {"sigma_s": [num(t) for t in ss.split(",")], "sigma_a": [num(t) for t in sa.split(",")]}
+    assert len(presets) == 40, len(presets)
+    import json
+    with open(os.path.join(OUT, "medium_presets.json"), "w") as f:
+        json.dump(presets, f, indent=0, sort_keys=True)
     print("wrote", OUT)
 
 

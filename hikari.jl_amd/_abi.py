@@ -131,5 +131,5 @@ EXPORTED_SYMBOLS = [
     "hk_film_read_rgb", "hk_film_read_accum", "hk_film_accum_device_ptr", "hk_sync", "hk_stats_get", "hk_stats_reset",
     "hk_stats_enable_counters", "hk_trace_closest", "hk_test_sobol", "hk_test_camera", "hk_test_uplift",
     "hk_test_light_bvh", "hk_test_bsdf", "hk_film_postprocess", "hk_film_fill_aux", "hk_postprocess", "hk_test_light", "hk_scene_bvh_info", "hk_scene_light_bvh_copy",
-    "hk_denoise",
+    "hk_denoise", "hk_test_mix", "hk_test_medium", "hk_test_trace_lean",
 ]

@@ -58,6 +58,9 @@ def lib():
         "hk_film_fill_aux": ([vp, vp, C.POINTER(A.hk_camera), i32, i32, i32, PF, PF, PF], i32),
         "hk_test_light": ([vp, vp, i32, i32, i32, PF, PF, PF, PF], i32),
         "hk_test_bsdf": ([vp, vp, i32, i32, i32, i32, PF, PF, PF, PF, PF, PF, PF], i32),
+        "hk_test_mix": ([vp, vp, i32, i32, PF, PF, PF, PI], i32),
+        "hk_test_medium": ([vp, vp, i32, i32, i32, PF, PF, PF, PF, PF], i32),
+        "hk_test_trace_lean": ([vp, vp, i32, i32, PF, PF, PF, PF, PI, PF], i32),
         "hk_scene_bvh_info": ([vp, PI, PI, PI], i32),
         "hk_scene_light_bvh_copy": ([vp, PI, PF, C.POINTER(C.c_uint32)], i32),
     }

@@ -40,6 +40,10 @@ void launch_denoise_atrous(hipStream_t, const hk_denoise_params&, int, const flo
 void launch_sobol_table(hipStream_t, const DSobol&, const DFrame&, uint32_t*, int);
 void launch_test_light(hipStream_t, const DScene&, const DTables&, int, int, int, const float*, const float*, const float*, float*);
 void launch_test_bsdf(hipStream_t, const DScene&, const DTables&, int, int, int, int, const float*, const float*, const float*, const float*, const float*, const float*, float*);
+void launch_test_mix(hipStream_t, const DScene&, int, int, const float*, const float*, const float*, int*);
+void launch_test_medium(hipStream_t, const DScene&, const DTables&, int, int, int, const float*, const float*, const float*, const float*, float*);
+int test_majorant_stride();
+void launch_test_trace_lean(hipStream_t, int, const DScene&, int, int, const float*, const float*, const float*, float*, int*, float*);
 }  // namespace hk
 
 static thread_local std::string g_err;
@@ -1514,5 +1518,51 @@ extern "C" int32_t hk_test_light_bvh(hk_ctx* c, hk_scene* sc, int32_t n, const f
     HIP_TRY(hipMemcpy(out_light, ol, n * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(out_pmf, op, n * 4, hipMemcpyDeviceToHost));
     if (query_light && out_query_pmf) HIP_TRY(hipMemcpy(out_query_pmf, oq, n * 4, hipMemcpyDeviceToHost));
+    return HK_OK;
+}
+
+extern "C" int32_t hk_test_mix(hk_ctx* c, hk_scene* sc, int32_t mat_idx, int32_t n, const float* p3, const float* wo3, const float* uv2, int32_t* out_mat) {
+    if (!c || !sc || !p3 || !wo3 || !uv2 || !out_mat) return fail(HK_ERR_INVALID, "null argument");
+    if (mat_idx < 0 || mat_idx >= sc->n_materials) return fail(HK_ERR_INVALID, "material index out of range");
+    HIP_TRY(hipSetDevice(c->device));
+    Tmp t;
+    float *dp = t.up(p3, 3 * (size_t)n), *dw = t.up(wo3, 3 * (size_t)n), *du = t.up(uv2, 2 * (size_t)n);
+    int* o = t.up<int>(nullptr, (size_t)n);
+    hk::launch_test_mix(c->stream, sc->d, mat_idx, n, dp, dw, du, o);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out_mat, o, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return HK_OK;
+}
+extern "C" int32_t hk_test_medium(hk_ctx* c, hk_scene* sc, int32_t mode, int32_t medium_idx, int32_t n, const float* a3, const float* b3, const float* tmax,
+                                  const float* lambda, float* out) {
+    if (!c || !sc || !a3 || !lambda || !out || (mode == 1 && (!b3 || !tmax))) return fail(HK_ERR_INVALID, "null argument");
+    if (mode != 0 && mode != 1) return fail(HK_ERR_INVALID, "mode must be 0 (sample_point) or 1 (majorant segments)");
+    if (medium_idx < 0 || medium_idx >= sc->d.n_media) return fail(HK_ERR_INVALID, "medium index out of range");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t stride = mode == 0 ? 13 : (size_t)hk::test_majorant_stride();
+    Tmp t;
+    float *da = t.up(a3, 3 * (size_t)n), *db = b3 ? t.up(b3, 3 * (size_t)n) : nullptr, *dt = tmax ? t.up(tmax, (size_t)n) : nullptr, *dl = t.up(lambda, 4 * (size_t)n);
+    float* o = t.up<float>(nullptr, stride * (size_t)n);
+    hk::launch_test_medium(c->stream, sc->d, c->tables, mode, medium_idx, n, da, db, dt, dl, o);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out, o, stride * (size_t)n * 4, hipMemcpyDeviceToHost));
+    return HK_OK;
+}
+extern "C" int32_t hk_test_trace_lean(hk_ctx* c, hk_scene* sc, int32_t anyhit, int32_t n, const float* o3, const float* d3, const float* tmax, float* out_t, int32_t* out_prim,
+                                      float* out_uv2) {
+    if (!c || !sc || !o3 || !d3 || !tmax || !out_t || !out_prim || !out_uv2) return fail(HK_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    Tmp t;
+    float *o = t.up(o3, 3 * (size_t)n), *d = t.up(d3, 3 * (size_t)n), *tm = t.up(tmax, (size_t)n);
+    float *ot = t.up<float>(nullptr, (size_t)n), *ouv = t.up<float>(nullptr, 2 * (size_t)n);
+    int* op = t.up<int>(nullptr, (size_t)n);
+    hk::launch_test_trace_lean(c->stream, c->n_cu, sc->d, anyhit, n, o, d, tm, ot, op, ouv);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out_t, ot, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_prim, op, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_uv2, ouv, 2 * (size_t)n * 4, hipMemcpyDeviceToHost));
     return HK_OK;
 }

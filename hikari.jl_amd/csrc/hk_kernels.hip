@@ -1603,6 +1603,91 @@ __global__ void k_test_light_bvh(DScene sc, int n, const float* p3, const float*
     }
 }
 
+// resolve_mix_material (mix-material.jl:222-238) for n hit points: out = index of the material a MixMaterial resolves to
+__global__ void k_test_mix(DScene sc, int mat_idx, int n, const float* p3, const float* wo3, const float* uv2, int* out) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        out[i] = resolve_mix_material(sc, mat_idx, mk3(p3[3 * i], p3[3 * i + 1], p3[3 * i + 2]), mk3(wo3[3 * i], wo3[3 * i + 1], wo3[3 * i + 2]), mk2(uv2[2 * i], uv2[2 * i + 1]));
+}
+// media: mode 0 = sample_point (media.jl:1327-1370, 1527-1575; nanovdb.jl:400-469) -> out[13] = sigma_a4, sigma_s4, Le4, g;
+//        mode 1 = majorant iterator along a ray (media.jl:229-340, 625-729) -> out[1 + 3*HK_TEST_MAJ_SEGS] = segment count, then
+//                 (t_min, t_max, sigma_maj[0]) of the first HK_TEST_MAJ_SEGS segments.  Same MM instantiation as the tracking kernels.
+#define HK_TEST_MAJ_SEGS 16
+template <int MM>
+__global__ void k_test_medium(DScene sc, DTables T, int mode, int medium_idx, int n, const float* a3, const float* b3, const float* tmax, const float* lambda, float* out) {
+    const DMedium& med = sc.media[medium_idx];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const S4 l = s4(lambda[4 * i], lambda[4 * i + 1], lambda[4 * i + 2], lambda[4 * i + 3]);
+        const v3 a = mk3(a3[3 * i], a3[3 * i + 1], a3[3 * i + 2]);
+        const S4 base_a = eval_scaled(med.sigma_a, l), base_s = eval_scaled(med.sigma_s, l), base_Le = eval_scaled(med.Le, l);
+        if (mode == 0) {
+            MediumProps mp = sample_point<MM>(T, l, med, base_a, base_s, base_Le, a);
+            float* r = out + 13 * (size_t)i;
+            r[0] = mp.sigma_a.x, r[1] = mp.sigma_a.y, r[2] = mp.sigma_a.z, r[3] = mp.sigma_a.w;
+            r[4] = mp.sigma_s.x, r[5] = mp.sigma_s.y, r[6] = mp.sigma_s.z, r[7] = mp.sigma_s.w;
+            r[8] = mp.Le.x, r[9] = mp.Le.y, r[10] = mp.Le.z, r[11] = mp.Le.w;
+            r[12] = mp.g;
+        } else {
+            const v3 d = mk3(b3[3 * i], b3[3 * i + 1], b3[3 * i + 2]);
+            float* r = out + (1 + 3 * HK_TEST_MAJ_SEGS) * (size_t)i;
+            for (int k = 0; k < 1 + 3 * HK_TEST_MAJ_SEGS; ++k) r[k] = 0.0f;
+            MajorantIter it = create_majorant_iterator<MM>(med, a, d, tmax[i]);
+            int count = 0;
+            float t0, t1;
+            S4 sm;
+            while (count < 256 && majorant_next<MM>(it, med, base_a + base_s, t0, t1, sm)) {
+                if (count < HK_TEST_MAJ_SEGS) r[1 + 3 * count] = t0, r[2 + 3 * count] = t1, r[3 + 3 * count] = sm.x;
+                ++count;
+            }
+            r[0] = (float)count;
+        }
+    }
+}
+// The traversal of the surfaces-only bench path: lane_ray_round (while-while rounds, straggler exit, LDS stack of STACK entries)
+// driven by the same per-lane refill as k_trace_lean / k_shadow, over a plain ray array.  Every wave owns a contiguous range of
+// rays.  ANYHIT = the shadow kernel's first-accepted-hit mode (out_prim >= 0 <=> occluded).
+template <bool ANYHIT, int STACK>
+__global__ void __launch_bounds__(HK_TRACE_BLOCK) k_test_trace_lean(DScene sc, int n, const float* o3, const float* d3, const float* tmax, float* out_t, int* out_prim, float* out_uv) {
+    __shared__ int lds_stack[(HK_TRACE_BLOCK / 64) * STACK * 64];
+    int* stack = lds_stack + (threadIdx.x >> 6) * (STACK * 64);
+    const int lane = lane_id();
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const int DONE = (int)0x80000000;
+    const int waves = physical_waves();
+    const int per_wave = (n + waves - 1) / waves;
+    const int first = global_wave() * per_wave;
+    const int count = first >= n ? 0 : (n - first < per_wave ? n - first : per_wave);
+    unsigned n_nodes = 0, n_tris = 0;
+    int cursor = 0;
+    bool have = false;
+    int idx = 0;
+    LaneRay r;
+    r.cur = DONE;
+    for (;;) {
+        const unsigned long long run_m = __ballot(have && r.cur != DONE);
+        if (run_m == 0ull || (64 - __popcll(run_m) >= HK_TRACE_MIN_IDLE && cursor < count)) {
+            if (have && r.cur == DONE) {
+                out_t[idx] = r.best.prim >= 0 ? r.best.t : INF_F;
+                out_prim[idx] = r.best.prim;
+                out_uv[2 * idx] = r.best.prim >= 0 ? r.best.u : 0.0f;
+                out_uv[2 * idx + 1] = r.best.prim >= 0 ? r.best.v : 0.0f;
+                have = false;
+            }
+            const unsigned long long want = __ballot(!have);
+            const int avail = count - cursor;
+            const int rank = __popcll(want & lt_mask);
+            if (!have && rank < avail) {
+                idx = first + cursor + rank;
+                lane_ray_start(r, sc, mk3(o3[3 * idx], o3[3 * idx + 1], o3[3 * idx + 2]), mk3(d3[3 * idx], d3[3 * idx + 1], d3[3 * idx + 2]), tmax[idx]);
+                have = true;
+            }
+            const int want_n = __popcll(want);
+            cursor += want_n < avail ? want_n : (avail > 0 ? avail : 0);
+            if (__ballot(have) == 0ull) break;
+        }
+        lane_ray_round<ANYHIT, false>(r, have && r.cur != DONE, sc, stack, lane, n_nodes, n_tris);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // denoise! (src/denoise.jl): 3x3 luminance variance (:236-286) and one a-trous pass (:136-229).  Buffers are Julia [h,w]
 // column-major: linear index i = (col-1)*h + (row-1), exactly the reference's idx -> (row, col) mapping.
@@ -1906,6 +1991,32 @@ __global__ void k_test_light(DScene sc, DTables T, int mode, int light_idx, int 
             r[0] = Le.x, r[1] = Le.y, r[2] = Le.z, r[3] = Le.w, r[4] = pdf;
         }
     }
+}
+void launch_test_mix(hipStream_t s, const DScene& sc, int mat_idx, int n, const float* p3, const float* wo3, const float* uv2, int* out) {
+    hipLaunchKernelGGL(k_test_mix, dim3(grid_for(n, 256, 1024)), dim3(256), 0, s, sc, mat_idx, n, p3, wo3, uv2, out);
+}
+void launch_test_medium(hipStream_t s, const DScene& sc, const DTables& T, int mode, int medium_idx, int n, const float* a3, const float* b3, const float* tmax, const float* lambda,
+                        float* out) {
+#define HK_TM_LAUNCH(MM) hipLaunchKernelGGL((k_test_medium<MM>), dim3(grid_for(n, 64, 4096)), dim3(64), 0, s, sc, T, mode, medium_idx, n, a3, b3, tmax, lambda, out)
+    switch (media_mask_class(sc)) {
+        case 1: HK_TM_LAUNCH(1); break;
+        case 2: HK_TM_LAUNCH(2); break;
+        case 4: HK_TM_LAUNCH(4); break;
+        case 8: HK_TM_LAUNCH(8); break;
+        default: HK_TM_LAUNCH(15); break;
+    }
+#undef HK_TM_LAUNCH
+}
+int test_majorant_stride() { return 1 + 3 * HK_TEST_MAJ_SEGS; }
+void launch_test_trace_lean(hipStream_t s, int n_cu, const DScene& sc, int anyhit, int n, const float* o, const float* d, const float* tmax, float* t, int* prim, float* uv) {
+    const int blocks = n_cu * 2;
+#define HK_TL_LAUNCH(A, S) hipLaunchKernelGGL((k_test_trace_lean<A, S>), dim3(blocks), dim3(HK_TRACE_BLOCK), 0, s, sc, n, o, d, tmax, t, prim, uv)
+    if (sc.bvh_depth <= 16) {
+        if (anyhit) HK_TL_LAUNCH(true, 16); else HK_TL_LAUNCH(false, 16);
+    } else {
+        if (anyhit) HK_TL_LAUNCH(true, HK_LDS_STACK); else HK_TL_LAUNCH(false, HK_LDS_STACK);
+    }
+#undef HK_TL_LAUNCH
 }
 void launch_test_trace(hipStream_t s, const DScene& sc, int n, const float* o, const float* d, const float* tmax, float* t, int* prim, float* uv) {
     hipLaunchKernelGGL(k_test_trace, dim3(grid_for(n, HK_TRACE_BLOCK, 1280)), dim3(HK_TRACE_BLOCK), 0, s, sc, n, o, d, tmax, t, prim, uv);

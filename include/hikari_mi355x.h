@@ -420,6 +420,22 @@ int32_t hk_test_bsdf(hk_ctx* ctx, hk_scene* scene, int32_t mode, int32_t mat_idx
 int32_t hk_test_light(hk_ctx* ctx, hk_scene* scene, int32_t mode, int32_t light_idx_1based, int32_t n, const float* p3,
                       const float* in3, const float* lambda, float* out);
 
+/* resolve_mix_material (mix-material.jl:96-127, 222-238) for n hit points (p, wo, uv): out_mat = the material index a
+   MixMaterial `mat_idx` resolves to (nested mixes followed, textured amount looked up nearest-texel, Q28) */
+int32_t hk_test_mix(hk_ctx* ctx, hk_scene* scene, int32_t mat_idx, int32_t n, const float* p3, const float* wo3, const float* uv2,
+                    int32_t* out_mat);
+/* point-wise media (volpath/media.jl, nanovdb.jl), medium `medium_idx` (0-based), lambda: 4n:
+   mode 0 = sample_point at p = a3 (media.jl:1327-1370, 1527-1575; nanovdb.jl:400-469) -> out[13n] = sigma_a4, sigma_s4, Le4, g
+   mode 1 = majorant iterator along ray (o = a3, d = b3, t_max) (media.jl:229-340, 625-729; nanovdb.jl:509-554)
+            -> out[49n] = number of segments (<= 256), then (t_min, t_max, sigma_maj[lambda 1]) of the first 16 segments */
+int32_t hk_test_medium(hk_ctx* ctx, hk_scene* scene, int32_t mode, int32_t medium_idx, int32_t n, const float* a3, const float* b3,
+                       const float* tmax, const float* lambda, float* out);
+/* hk_trace_closest through the traversal of the surfaces-only render path (k_trace_lean / k_shadow: while-while rounds with
+   per-lane refill and the 16- or 32-entry LDS stack the scene's BVH depth selects).  anyhit != 0: the shadow kernel's
+   first-accepted-hit mode, out_prim >= 0 <=> occluded (t / uv then belong to the hit that stopped the ray). */
+int32_t hk_test_trace_lean(hk_ctx* ctx, hk_scene* scene, int32_t anyhit, int32_t n, const float* o3, const float* d3, const float* tmax,
+                           float* out_t, int32_t* out_prim, float* out_uv2);
+
 /* introspection used by tests/bench */
 int32_t hk_scene_bvh_info(hk_scene* scene, int32_t* n_nodes, int32_t* n_leaf_tris, int32_t* max_depth);
 int32_t hk_scene_light_bvh_copy(hk_scene* scene, int32_t* n_nodes, float* nodes_out /* 16 floats per node */,

@@ -1360,6 +1360,44 @@ int32_t hko_light(hko_scene* s, int32_t mode, int32_t light_idx_1based, int32_t 
     return 0;
 }
 
+// resolve_mix_material (mix-material.jl:222-238) for n hit points
+int32_t hko_mix_resolve(hko_scene* s, int32_t mat_idx, int32_t n, const float* p3, const float* wo3, const float* uv2, int32_t* out_mat) {
+    for (int i = 0; i < n; ++i)
+        out_mat[i] = resolve_mix_material(s->sc.mctx, mat_idx, V3(p3[3 * i], p3[3 * i + 1], p3[3 * i + 2]), V3(wo3[3 * i], wo3[3 * i + 1], wo3[3 * i + 2]),
+                                          V2(uv2[2 * i], uv2[2 * i + 1]));
+    return 0;
+}
+
+// Point-wise media: mode 0 = sample_point -> out[13] = sigma_a4, sigma_s4, Le4, g (through the NanoVDB TREE WALK, nanovdb.jl:315-388);
+// mode 1 = create_majorant_iterator + ray_majorant_next -> out[49] = segment count (<= 256), (t_min, t_max, sigma_maj[1]) of the first 16
+int32_t hko_medium(hko_scene* s, int32_t mode, int32_t medium_idx, int32_t n, const float* a3, const float* b3, const float* tmax, const float* lambda, float* out) {
+    Scene& sc = s->sc;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) {
+        Wavelengths w;
+        for (int k = 0; k < 4; ++k) w.lambda[k] = lambda[4 * i + k], w.pdf[k] = 1.0f;
+        V3 a(a3[3 * i], a3[3 * i + 1], a3[3 * i + 2]);
+        if (mode == 0) {
+            MediumProperties mp = sample_point(sc.media, medium_idx, a, w);
+            float* r = out + 13 * (size_t)i;
+            for (int k = 0; k < 4; ++k) r[k] = mp.sigma_a[k], r[4 + k] = mp.sigma_s[k], r[8 + k] = mp.Le[k];
+            r[12] = mp.g;
+        } else {
+            float* r = out + 49 * (size_t)i;
+            for (int k = 0; k < 49; ++k) r[k] = 0.0f;
+            MajorantIter it = create_majorant_iterator(sc.media, medium_idx, a, V3(b3[3 * i], b3[3 * i + 1], b3[3 * i + 2]), tmax[i], w);
+            MajorantSegment seg;
+            int count = 0;
+            while (count < 256 && majorant_next(it, seg)) {
+                if (count < 16) r[1 + 3 * count] = seg.t_min, r[2 + 3 * count] = seg.t_max, r[3 + 3 * count] = seg.sigma_maj[0];
+                ++count;
+            }
+            r[0] = (float)count;
+        }
+    }
+    return 0;
+}
+
 // postprocess_kernel! (src/postprocess.jl:185-250) on a Julia-layout [h,w] RGB framebuffer
 static float pp_unch2(float x) {
     const float A = 0.15f, B = 0.50f, C = 0.10f, D = 0.20f, E = 0.02f, F = 0.30f;
@@ -1531,6 +1569,61 @@ int32_t hko_max_threads(void) {
 #else
     return 1;
 #endif
+}
+
+// ---- point-wise helpers for the independent float64 pins (tests/ref64.py, tests/test_independent_pins.py) ----
+// Trowbridge-Reitz: out[8] per point = D(wm), Lambda(w), G1(w), G(w, wm taken as wi), pdf(w, wm), sample_wm(w, u).xyz
+void hko_tr(int32_t n, const float* w3, const float* wm3, const float* u2, float ax, float ay, float* out) {
+    for (int i = 0; i < n; ++i) {
+        V3 w(w3[3 * i], w3[3 * i + 1], w3[3 * i + 2]), wm(wm3[3 * i], wm3[3 * i + 1], wm3[3 * i + 2]);
+        float* r = out + 8 * (size_t)i;
+        r[0] = tr_d(wm, ax, ay);
+        r[1] = tr_lambda(w, ax, ay);
+        r[2] = tr_g1(w, ax, ay);
+        r[3] = tr_g(w, wm, ax, ay);
+        r[4] = tr_pdf(w, wm, ax, ay);
+        V3 s = tr_sample_wm(w, V2(u2[2 * i], u2[2 * i + 1]), ax, ay);
+        r[5] = s.x, r[6] = s.y, r[7] = s.z;
+    }
+}
+// Henyey-Greenstein: out[5] = sample_hg(g, wo, u) -> wi.xyz, pdf; hg_p(g, cos_in)
+void hko_hg(int32_t n, float g, const float* wo3, const float* u2, const float* cos_in, float* out) {
+    for (int i = 0; i < n; ++i) {
+        float pdf;
+        V3 wi = sample_hg(g, V3(wo3[3 * i], wo3[3 * i + 1], wo3[3 * i + 2]), V2(u2[2 * i], u2[2 * i + 1]), pdf);
+        float* r = out + 5 * (size_t)i;
+        r[0] = wi.x, r[1] = wi.y, r[2] = wi.z, r[3] = pdf, r[4] = hg_p(g, cos_in[i]);
+    }
+}
+// equal-area mapping: out[5] = square_to_sphere(uv).xyz, sphere_to_square(dir).uv
+void hko_equal_area(int32_t n, const float* uv2, const float* dir3, float* out) {
+    for (int i = 0; i < n; ++i) {
+        V3 d = equal_area_square_to_sphere(V2(uv2[2 * i], uv2[2 * i + 1]));
+        V2 q = equal_area_sphere_to_square(V3(dir3[3 * i], dir3[3 * i + 1], dir3[3 * i + 2]));
+        float* r = out + 5 * (size_t)i;
+        r[0] = d.x, r[1] = d.y, r[2] = d.z, r[3] = q.x, r[4] = q.y;
+    }
+}
+// Distribution2D of an hk_envmap record: out[5] = sample_continuous(u) -> uv.xy, pdf; pdf(uv_in)
+void hko_dist2d(const hk_envmap* e, int32_t n, const float* u2, const float* uv_in2, float* out) {
+    for (int i = 0; i < n; ++i) {
+        float pdf;
+        V2 s = dist2d_sample(*e, V2(u2[2 * i], u2[2 * i + 1]), pdf);
+        float* r = out + 4 * (size_t)i;
+        r[0] = s.x, r[1] = s.y, r[2] = pdf, r[3] = dist2d_pdf(*e, V2(uv_in2[2 * i], uv_in2[2 * i + 1]));
+    }
+}
+// node_importance of light-BVH node `node_idx` (0-based) of a scene at n points
+void hko_node_importance(hko_scene* s, int32_t node_idx, int32_t n, const float* p3, const float* n3, float* out) {
+    const LightBVHNode& nd = s->sc.sampler.nodes[node_idx];
+    for (int i = 0; i < n; ++i) out[i] = node_importance(nd, V3(p3[3 * i], p3[3 * i + 1], p3[3 * i + 2]), V3(n3[3 * i], n3[3 * i + 1], n3[3 * i + 2]));
+}
+// cosine_sample_hemisphere / concentric disk (sampler/sampling.jl)
+void hko_cosine_hemisphere(int32_t n, const float* u2, float* out3) {
+    for (int i = 0; i < n; ++i) {
+        V3 d = cosine_sample_hemisphere(V2(u2[2 * i], u2[2 * i + 1]));
+        out3[3 * i] = d.x, out3[3 * i + 1] = d.y, out3[3 * i + 2] = d.z;
+    }
 }
 
 // known-answer helpers

@@ -42,6 +42,8 @@ def lib():
         L.hko_light.argtypes = [vp, i32, i32, i32, PF, PF, PF, PF]
         L.hko_bsdf.argtypes = [vp, i32, i32, i32, i32, PF, PF, PF, PF, PF, PF, PF]
         L.hko_light_bvh_copy.argtypes = [vp, PI, PF, C.POINTER(C.c_uint32)]
+        L.hko_mix_resolve.argtypes = [vp, i32, i32, PF, PF, PF, PI]
+        L.hko_medium.argtypes = [vp, i32, i32, i32, PF, PF, PF, PF, PF]
         L.hko_murmur64a.argtypes = [C.c_char_p, i32, C.c_uint64]
         L.hko_murmur64a.restype = C.c_uint64
         L.hko_mix_bits.argtypes = [C.c_uint64]
@@ -59,6 +61,18 @@ def lib():
         L.hko_filter_sample.restype = None
         L.hko_wavelengths.argtypes = [i32, PF, PF]
         L.hko_wavelengths.restype = None
+        L.hko_tr.argtypes = [i32, PF, PF, PF, C.c_float, C.c_float, PF]
+        L.hko_tr.restype = None
+        L.hko_hg.argtypes = [i32, C.c_float, PF, PF, PF, PF]
+        L.hko_hg.restype = None
+        L.hko_equal_area.argtypes = [i32, PF, PF, PF]
+        L.hko_equal_area.restype = None
+        L.hko_dist2d.argtypes = [C.POINTER(A.hk_envmap), i32, PF, PF, PF]
+        L.hko_dist2d.restype = None
+        L.hko_node_importance.argtypes = [vp, i32, i32, PF, PF, PF]
+        L.hko_node_importance.restype = None
+        L.hko_cosine_hemisphere.argtypes = [i32, PF, PF]
+        L.hko_cosine_hemisphere.restype = None
         L.hko_set_threads.argtypes = [i32]
         L.hko_set_threads.restype = None
         L.hko_max_threads.restype = i32
@@ -177,6 +191,31 @@ class OracleScene:
         lib().hko_bsdf(self.h, mode, mat_idx, 1 if regularize else 0, n, *[_pf(x) for x in a], _pf(out))
         return out
 
+    def mix_resolve(self, mat_idx, p, wo, uv):
+        """resolve_mix_material(mat_idx, p, wo, uv) -> material index per point"""
+        a = [np.ascontiguousarray(x, np.float32) for x in (p, wo, uv)]
+        out = np.empty(a[0].shape[0], np.int32)
+        lib().hko_mix_resolve(self.h, mat_idx, a[0].shape[0], *[_pf(x) for x in a], _pi(out))
+        return out
+
+    def medium(self, mode, medium_idx, a, lam, b=None, tmax=None):
+        """mode 0: sample_point(medium, p = a, lambda) -> [n, 13] = sigma_a4, sigma_s4, Le4, g;
+        mode 1: majorant segments along (o = a, d = b, tmax) -> [n, 49] = count, (t_min, t_max, sigma_maj[1]) x 16"""
+        n = a.shape[0]
+        a = np.ascontiguousarray(a, np.float32)
+        lam = np.ascontiguousarray(lam, np.float32)
+        b = np.ascontiguousarray(b if b is not None else np.zeros((n, 3)), np.float32)
+        tmax = np.ascontiguousarray(tmax if tmax is not None else np.zeros(n), np.float32)
+        out = np.zeros((n, 13 if mode == 0 else 49), np.float32)
+        lib().hko_medium(self.h, mode, medium_idx, n, _pf(a), _pf(b), _pf(tmax), _pf(lam), _pf(out))
+        return out
+
+    def node_importance(self, node_idx, p, n):
+        p, n = np.ascontiguousarray(p, np.float32), np.ascontiguousarray(n, np.float32)
+        out = np.zeros(p.shape[0], np.float32)
+        lib().hko_node_importance(self.h, node_idx, p.shape[0], _pf(p), _pf(n), _pf(out))
+        return out
+
     def light_bvh_nodes(self):
         nn = C.c_int32()
         lib().hko_light_bvh_copy(self.h, C.byref(nn), None, None)
@@ -249,3 +288,47 @@ def postprocess(params, framebuffer, depth=None):
     dp = np.ascontiguousarray(np.transpose(depth, (1, 0)), np.float32) if depth is not None else None
     lib().hko_postprocess(C.byref(params), w, h, _pf(src), _pf(dp) if dp is not None else None, _pf(dst))
     return np.transpose(dst, (1, 0, 2)).copy()
+
+
+# ---- point-wise helpers (independent float64 pins, tests/test_independent_pins.py) ----
+def _f(a):
+    return np.ascontiguousarray(a, np.float32)
+
+
+def tr(w, wm, u, ax, ay):
+    """-> [n, 8] = D(wm), Lambda(w), G1(w), G(w, wm), pdf(w, wm), sample_wm(w, u).xyz"""
+    w, wm, u = _f(w), _f(wm), _f(u)
+    out = np.zeros((w.shape[0], 8), np.float32)
+    lib().hko_tr(w.shape[0], _pf(w), _pf(wm), _pf(u), ax, ay, _pf(out))
+    return out
+
+
+def hg(g, wo, u, cos_in):
+    """-> [n, 5] = sample_hg(g, wo, u) (wi.xyz, pdf), hg_p(g, cos_in)"""
+    wo, u, c = _f(wo), _f(u), _f(cos_in)
+    out = np.zeros((wo.shape[0], 5), np.float32)
+    lib().hko_hg(wo.shape[0], g, _pf(wo), _pf(u), _pf(c), _pf(out))
+    return out
+
+
+def equal_area(uv, d):
+    """-> [n, 5] = equal_area_square_to_sphere(uv).xyz, equal_area_sphere_to_square(d).uv"""
+    uv, d = _f(uv), _f(d)
+    out = np.zeros((uv.shape[0], 5), np.float32)
+    lib().hko_equal_area(uv.shape[0], _pf(uv), _pf(d), _pf(out))
+    return out
+
+
+def dist2d(envmap_record, u, uv_in):
+    """-> [n, 4] = Distribution2D.sample_continuous(u) (uv.xy, pdf), pdf(uv_in)"""
+    u, q = _f(u), _f(uv_in)
+    out = np.zeros((u.shape[0], 4), np.float32)
+    lib().hko_dist2d(C.byref(envmap_record), u.shape[0], _pf(u), _pf(q), _pf(out))
+    return out
+
+
+def cosine_hemisphere(u):
+    u = _f(u)
+    out = np.zeros((u.shape[0], 3), np.float32)
+    lib().hko_cosine_hemisphere(u.shape[0], _pf(u), _pf(out))
+    return out

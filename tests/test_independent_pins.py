@@ -1,0 +1,505 @@
+"""Independent pins of the oracle: every oracle header is checked from a direction that shares no code with it.
+
+  * tests/ref64.py — float64 numpy written from the formulas in the Julia text (numpy complex Fresnel, angle-form
+    Trowbridge-Reitz, arctan2 equal-area map, searchsorted Distribution2D): the oracle must agree to binary32 rounding;
+  * the properties the reference's own tests use (test/gpu_compat.jl, test_env_light_pbrt_compat.jl:83-140, test/materials.jl):
+    normalisation of D and of phase functions, reciprocity of eval, white furnace (albedo <= 1), agreement of `sample` with `pdf`
+    (histogram chi^2), env-light integral = 4 pi L, UV <-> direction round trip;
+  * a brute-force Monte-Carlo evaluation of the LayeredBxDF (many independent walks written here in numpy) against the oracle's
+    stochastic evaluate for CoatedDiffuse;
+  * Hosek-Wilkie: the published closed form F(theta, gamma) and two radiance values computed here in float64 directly from the
+    coefficient table, against the baked map.
+
+What stays single-sourced is listed in DESIGN.md §2."""
+import numpy as np
+import pytest
+
+import ref64 as R
+
+f32 = np.float32
+
+
+def _unit(v):
+    return v / np.linalg.norm(v, axis=-1, keepdims=True)
+
+
+def _dirs(rng, n, upper=False):
+    d = _unit(rng.normal(size=(n, 3)))
+    if upper:
+        d[:, 2] = np.abs(d[:, 2])
+    return d.astype(f32)
+
+
+# ---------------------------------------------------------------------------------------------------- Fresnel
+def test_fresnel_against_float64(oracle):
+    L = oracle.lib()
+    rng = np.random.default_rng(1)
+    c = rng.uniform(-1, 1, 4000).astype(f32)
+    for eta in (1.5, 1.33, 2.4, 1.0 / 1.5):
+        got = np.array([L.hko_fresnel_dielectric(float(x), eta) for x in c])
+        assert np.allclose(got, R.fresnel_dielectric(c, eta), rtol=2e-5, atol=2e-6), eta
+    c = rng.uniform(0, 1, 3000).astype(f32)
+    for eta, k in ((0.2, 3.9), (1.1, 2.14), (0.15557, 3.6024), (2.5, 0.0), (1.0, 1.0)):
+        got = np.array([L.hko_fr_complex(float(x), eta, k) for x in c])
+        assert np.allclose(got, R.fr_complex(c, eta, k), rtol=3e-5, atol=1e-6), (eta, k)
+    # normal incidence closed form ((n-1)^2 + k^2) / ((n+1)^2 + k^2)
+    assert np.isclose(L.hko_fr_complex(1.0, 0.2, 3.9), ((0.2 - 1) ** 2 + 3.9 ** 2) / ((0.2 + 1) ** 2 + 3.9 ** 2), rtol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------------- Trowbridge-Reitz
+@pytest.mark.parametrize("ax,ay", [(0.3, 0.3), (0.05, 0.2), (0.7, 0.1), (1e-3 * 1.5, 1e-3 * 1.5)])
+def test_trowbridge_reitz_against_float64(oracle, ax, ay):
+    rng = np.random.default_rng(2)
+    n = 20000
+    w, wm = _dirs(rng, n), _dirs(rng, n, upper=True)
+    u = rng.random((n, 2)).astype(f32)
+    T = oracle.tr(w, wm, u, ax, ay)
+    ok = (np.abs(w[:, 2]) > 1e-3) & (wm[:, 2] > 1e-3)          # away from the grazing singularities where float32 loses digits
+    assert np.allclose(T[ok, 0], R.tr_d(wm, ax, ay)[ok], rtol=2e-4, atol=1e-12)
+    assert np.allclose(T[ok, 1], R.tr_lambda(w, ax, ay)[ok], rtol=2e-4, atol=1e-6)
+    assert np.allclose(T[ok, 2], R.tr_g1(w, ax, ay)[ok], rtol=2e-4)
+    assert np.allclose(T[ok, 3], R.tr_g(w, wm, ax, ay)[ok], rtol=2e-4)
+    assert np.allclose(T[ok, 4], R.tr_pdf(w, wm, ax, ay)[ok], rtol=4e-4, atol=1e-12)
+    s = R.tr_sample_wm(w, u, ax, ay)
+    # (for near-grazing w the stretched frame amplifies float32 rounding by 1 / (alpha |w.z|): compare where that is bounded)
+    whz = np.abs(w[:, 2].astype(np.float64)) / np.sqrt((ax * w[:, 0].astype(np.float64)) ** 2 + (ay * w[:, 1].astype(np.float64)) ** 2 + w[:, 2].astype(np.float64) ** 2)
+    knife = np.abs(whz - 0.99999) < 3e-7        # `wh.z < 0.99999f0` picks the tangent frame: a different (equally valid) frame either side
+    good = ok & ~knife & (np.abs(w[:, 2]) > 0.05) & (np.abs(u[:, 0] - 0.5) < 0.499) & (np.abs(np.linalg.norm(T[:, 5:8], axis=1) - 1) < 1e-4)
+    assert good.mean() > 0.9
+    assert np.abs(T[good, 5:8] - s[good]).max() < 3e-4
+
+
+def test_trowbridge_reitz_properties(oracle):
+    """pbrt's defining identities: the projected area of the microfacets is 1 (int D(wm) cos = 1) and the visible-normal density
+    integrates to 1; sample_wm is distributed as that density (chi^2 over a 16 x 8 (phi, cos) grid)."""
+    ax, ay = 0.35, 0.2
+    nt, nphi = 800, 1600                                               # midpoint rule over the hemisphere in (theta, phi)
+    th = (np.arange(nt) + 0.5) / nt * (np.pi / 2)
+    ph = (np.arange(nphi) + 0.5) / nphi * 2 * np.pi
+    T, P = np.meshgrid(th, ph, indexing="ij")
+    wm = np.stack([np.sin(T) * np.cos(P), np.sin(T) * np.sin(P), np.cos(T)], -1).reshape(-1, 3)
+    dw = (np.sin(T) * (np.pi / 2 / nt) * (2 * np.pi / nphi)).reshape(-1)
+    w = np.tile(_unit(np.array([[0.5, -0.3, 0.6]])), (wm.shape[0], 1))
+    O = oracle.tr(w, wm, np.zeros((wm.shape[0], 2)), ax, ay)
+    assert abs((O[:, 0] * wm[:, 2] * dw).sum() - 1.0) < 2e-3              # int D cos = 1
+    facing = (w * wm).sum(1) > 0                                           # the VNDF is normalised over the microfacets that FACE w
+    assert abs((O[:, 4] * dw)[facing].sum() - 1.0) < 2e-3                  # int D_w(wm) = 1
+    rng = np.random.default_rng(3)
+    n = 200000
+    u = rng.random((n, 2)).astype(f32)
+    S = oracle.tr(np.tile(w[:1], (n, 1)), np.tile(w[:1], (n, 1)), u, ax, ay)[:, 5:8].astype(np.float64)
+    bins_c, bins_p = 8, 16
+    ic = np.clip((S[:, 2] * bins_c).astype(int), 0, bins_c - 1)
+    ip = np.clip(((np.arctan2(S[:, 1], S[:, 0]) % (2 * np.pi)) / (2 * np.pi) * bins_p).astype(int), 0, bins_p - 1)
+    obs = np.bincount(ic * bins_p + ip, minlength=bins_c * bins_p).astype(np.float64)
+    jc = np.clip((wm[:, 2] * bins_c).astype(int), 0, bins_c - 1)
+    jp = np.clip((P.reshape(-1) / (2 * np.pi) * bins_p).astype(int), 0, bins_p - 1)
+    exp = np.bincount(jc * bins_p + jp, weights=R.tr_pdf(w, wm, ax, ay) * dw * facing, minlength=bins_c * bins_p) * n
+    use = exp > 30
+    chi2 = (((obs - exp) ** 2) / np.maximum(exp, 1e-9))[use].sum()
+    assert use.sum() > 40 and chi2 < 2.0 * use.sum(), (chi2, use.sum())   # E[chi2] = dof; quadrature error allowed for
+
+
+# ---------------------------------------------------------------------------------------------------- simple BSDFs through hko_bsdf
+def _palette(hk):
+    from hikari_jl_amd import geometry as G
+    mats = [
+        hk.MatteMaterial(Kd=hk.RGBSpectrum(0.6, 0.4, 0.2)),                                              # 0
+        hk.MatteMaterial(Kd=hk.RGBSpectrum(0.6, 0.4, 0.2), sigma=20.0),                                  # 1 (Q12)
+        hk.MirrorMaterial(Kr=hk.RGBSpectrum(0.9, 0.8, 0.7)),                                             # 2
+        hk.GlassMaterial(Kr=hk.RGBSpectrum(0.9), Kt=hk.RGBSpectrum(0.8, 0.9, 1.0), index=1.5),           # 3
+        hk.ConductorMaterial(eta=hk.RGBSpectrum(0.2, 0.92, 1.1), k=hk.RGBSpectrum(3.9, 2.45, 2.14), roughness=0.09),    # 4 rough (alpha 0.3)
+        hk.ConductorMaterial(eta=hk.RGBSpectrum(0.2, 0.92, 1.1), k=hk.RGBSpectrum(3.9, 2.45, 2.14), roughness=0.0),     # 5 smooth
+        hk.Gold(roughness=0.04),                                                                         # 6 measured eta / k
+    ]
+    s = hk.Scene()
+    for i, m in enumerate(mats):
+        s.push(G.quad((i, 0, 0), (i + 0.5, 0, 0), (i + 0.5, 0.5, 0), (i, 0.5, 0)), m)
+    s.push(hk.PointLight((0, 3, 0), hk.RGBSpectrum(1.0)))
+    s.sync()
+    return s
+
+
+def _bsdf_inputs(n, seed):
+    rng = np.random.default_rng(seed)
+    z = np.tile(np.array([[0, 0, 1]], f32), (n, 1))
+    lam = (360 + 470 * rng.random((n, 4))).astype(f32)
+    return _dirs(rng, n), _dirs(rng, n), z, lam, rng.random((n, 2)).astype(f32), rng.random(n).astype(f32)
+
+
+def test_matte_mirror_glass_closed_forms(hk, oracle):
+    """spectral-eval.jl:42-198, 371-420 by formula: Matte f = uplift(Kd)/pi (x (1 - sigma/(2 sigma + 0.66)) in sample only: Q12),
+    cosine-hemisphere direction flipped to wo's side; Mirror f = uplift(Kr), wi = mirror of wo, specular; Glass picks R with
+    probability F(|cos|, eta or 1/eta), f = Kr | Kt, pdf 1, eta_scale = 1/eta^2 on transmission (Q12)."""
+    osc = oracle.OracleScene(_palette(hk))
+    n = 6000
+    wo, wi, ns, lam, u, uc = _bsdf_inputs(n, 5)
+    kd = oracle.uplift(0, np.tile([[0.6, 0.4, 0.2]], (n, 1)), lam).astype(np.float64)
+    S0, S1 = osc.bsdf(0, 0, wo, wi, ns, lam, u, uc), osc.bsdf(0, 1, wo, wi, ns, lam, u, uc)
+    loc = R.cosine_hemisphere(u)
+    ok = (S0[:, 7] > 0)
+    assert ok.mean() > 0.99
+    want_wi = loc * np.where(wo[:, 2:3] < 0, np.array([1, 1, -1.0]), 1.0)          # n = +z: tangent frame is (t, b, n) = (x', y', z)
+    wc = ok & (loc[:, 2] > 0.05)                     # z = sqrt(1 - x^2 - y^2) loses digits towards grazing: compare where well-conditioned
+    assert np.allclose(np.abs(S0[wc, 2]), loc[wc, 2], atol=3e-6) and np.allclose(S0[wc, 7], loc[wc, 2] / np.pi, rtol=5e-5)
+    assert (np.sign(S0[ok, 2]) == np.sign(wo[ok, 2])).all() and want_wi.shape == (n, 3)
+    assert np.allclose(S0[ok, 3:7], kd[ok] / np.pi, rtol=2e-5)
+    fac = 1 - 0.5 * 20.0 / (20.0 + 0.33)
+    assert np.allclose(S1[ok, 3:7], kd[ok] * fac / np.pi, rtol=3e-5) and np.array_equal(S1[:, 0:3], S0[:, 0:3])
+    E0, E1 = osc.bsdf(1, 0, wo, wi, ns, lam, u, uc), osc.bsdf(1, 1, wo, wi, ns, lam, u, uc)
+    same = wo[:, 2] * wi[:, 2] > 0
+    assert np.array_equal(E0, E1)                                                    # eval ignores sigma (Q12)
+    assert not E0[~same].any() and np.allclose(E0[same, 0:4], kd[same] / np.pi, rtol=2e-5) and np.allclose(E0[same, 4], np.abs(wi[same, 2]) / np.pi, rtol=2e-5)
+    # Mirror
+    S = osc.bsdf(0, 2, wo, wi, ns, lam, u, uc)
+    kr = oracle.uplift(0, np.tile([[0.9, 0.8, 0.7]], (n, 1)), lam)
+    assert np.allclose(S[:, 0:3], wo * np.array([-1, -1, 1]), atol=1e-6) and np.allclose(S[:, 3:7], kr, rtol=1e-6)
+    assert (S[:, 7] == 1).all() and (S[:, 8] == 1).all() and (S[:, 9] == 1).all() and not osc.bsdf(1, 2, wo, wi, ns, lam, u, uc).any()
+    # Glass
+    S = osc.bsdf(0, 3, wo, wi, ns, lam, u, uc)
+    F = R.fresnel_dielectric(wo[:, 2], 1.5)
+    sure = np.abs(uc - F) > 1e-5
+    refl = uc < F
+    kr = oracle.uplift(0, np.tile([[0.9, 0.9, 0.9]], (n, 1)), lam)
+    kt = oracle.uplift(0, np.tile([[0.8, 0.9, 1.0]], (n, 1)), lam)
+    m = refl & sure
+    assert np.allclose(S[m, 0:3], (wo * np.array([-1, -1, 1]))[m], atol=1e-6) and np.allclose(S[m, 3:7], kr[m], rtol=1e-6) and (S[m, 9] == 1).all()
+    m = ~refl & sure
+    eta = np.where(wo[:, 2] > 0, 1.5, 1 / 1.5)
+    c = np.abs(wo[:, 2].astype(np.float64))
+    ct = np.sqrt(np.maximum(0.0, 1 - (1 - c * c) / eta ** 2))
+    want = -wo / eta[:, None] + ((c / eta - ct) * np.sign(wo[:, 2]))[:, None] * np.array([0, 0, 1.0])
+    assert m.sum() > 1000 and np.allclose(S[m, 0:3], _unit(want)[m], atol=3e-6) and np.allclose(S[m, 3:7], kt[m], rtol=1e-6)
+    assert np.allclose(S[m, 9], 1 / eta[m] ** 2, rtol=1e-6) and (S[:, 7] == 1).all() and (S[:, 8] == 1).all()
+    osc.close()
+
+
+def test_conductor_against_float64(hk, oracle):
+    """spectral-eval.jl:223-318, 423-488 by formula: rough = D F G / (4 cos cos) with F = FrComplex(|wo.wm|), pdf = D_wo(wm) /
+    (4 |wo.wm|); smooth = mirror direction, f = F(cos)/cos, pdf 1 (Q21); measured Au eta/k interpolated linearly in lambda."""
+    s = _palette(hk)
+    osc = oracle.OracleScene(s)
+    n = 8000
+    wo, wi, ns, lam, u, uc = _bsdf_inputs(n, 7)
+    eta = oracle.uplift(1, np.tile([[0.2, 0.92, 1.1]], (n, 1)), lam).astype(np.float64)
+    k = oracle.uplift(1, np.tile([[3.9, 2.45, 2.14]], (n, 1)), lam).astype(np.float64)
+    a = float(np.sqrt(f32(0.09)))
+    E = osc.bsdf(1, 4, wo, wi, ns, lam, u, uc)
+    same = (wo[:, 2] * wi[:, 2] > 0) & (np.abs(wo[:, 2]) > 0.02) & (np.abs(wi[:, 2]) > 0.02)
+    f, pdf = R.conductor_f(wo, wi, a, a, eta, k)
+    assert not E[wo[:, 2] * wi[:, 2] < 0].any()
+    assert np.allclose(E[same, 0:4], f[same], rtol=5e-4, atol=1e-7) and np.allclose(E[same, 4], pdf[same], rtol=5e-4, atol=1e-7)
+    # sample: wi = reflect(wo, wm(u)); f and pdf equal evaluate() at that direction
+    S = osc.bsdf(0, 4, wo, wi, ns, lam, u, uc)
+    ok = (S[:, 7] > 0) & (np.abs(wo[:, 2]) > 0.02) & (np.abs(S[:, 2]) > 0.02)
+    assert ok.mean() > 0.85
+    wm = R.tr_sample_wm(wo, u, a, a)
+    refl = -wo + 2 * (wo * wm).sum(-1, keepdims=True) * wm
+    assert np.abs(S[ok, 0:3] - refl[ok]).max() < 5e-4
+    E2 = osc.bsdf(1, 4, wo, S[:, 0:3].copy(), ns, lam, u, uc)
+    assert np.allclose(E2[ok, 0:4], S[ok, 3:7], rtol=2e-3, atol=1e-6) and np.allclose(E2[ok, 4], S[ok, 7], rtol=2e-3, atol=1e-6)
+    # smooth
+    S = osc.bsdf(0, 5, wo, wi, ns, lam, u, uc)
+    c = np.abs(wo[:, 2].astype(np.float64))
+    assert np.allclose(S[:, 0:3], wo * np.array([-1, -1, 1]), atol=1e-6) and (S[:, 8] == 1).all() and (S[:, 7] == 1).all()
+    g = c > 1e-3
+    assert np.allclose(S[g, 3:7], (R.fr_complex(c[:, None], eta, k) / c[:, None])[g], rtol=1e-4)
+    assert not osc.bsdf(1, 5, wo, wi, ns, lam, u, uc).any()
+    # Gold(): measured spectrum, piecewise-linear in lambda
+    from hikari_jl_amd.materials import _metal_spectra
+    au_e, au_k = _metal_spectra()["AU_ETA_SPECTRUM"], _metal_spectra()["AU_K_SPECTRUM"]
+    ge = np.stack([np.interp(lam[:, j], au_e.lambdas, au_e.values) for j in range(4)], 1)
+    gk = np.stack([np.interp(lam[:, j], au_k.lambdas, au_k.values) for j in range(4)], 1)
+    a = float(np.sqrt(f32(0.04)))
+    E = osc.bsdf(1, 6, wo, wi, ns, lam, u, uc)
+    f, pdf = R.conductor_f(wo, wi, a, a, ge, gk)
+    assert np.allclose(E[same, 0:4], f[same], rtol=1e-3, atol=1e-7) and np.allclose(E[same, 4], pdf[same], rtol=1e-3, atol=1e-7)
+    osc.close()
+
+
+def test_reciprocity_and_white_furnace(hk, oracle):
+    """f(wo, wi) = f(wi, wo) for the closed-form reflective lobes; the cosine-weighted estimator f cos / pdf of `sample` never
+    reflects more than it receives on average (energy <= 1 + MC noise) — test/gpu_compat.jl's sanity bounds."""
+    from test_layered_materials import MATERIAL_NAMES, palette_scene
+    osc = oracle.OracleScene(_palette(hk))
+    n = 20000
+    wo, wi, ns, lam, u, uc = _bsdf_inputs(n, 11)
+    wo[:, 2], wi[:, 2] = np.abs(wo[:, 2]), np.abs(wi[:, 2])
+    for idx in (0, 4, 6):
+        a, b = osc.bsdf(1, idx, wo, wi, ns, lam, u, uc), osc.bsdf(1, idx, wi, wo, ns, lam, u, uc)
+        assert np.allclose(a[:, 0:4], b[:, 0:4], rtol=2e-4, atol=1e-7), idx
+    for idx in range(7):
+        S = osc.bsdf(0, idx, wo, wi, ns, lam, u, uc)
+        spec = S[:, 8] == 1
+        w = np.where(spec[:, None], S[:, 3:7] * (np.abs(S[:, 2:3]) if idx in (5,) else 1.0), S[:, 3:7] * np.abs(S[:, 2:3]) / np.maximum(S[:, 7:8], 1e-30))
+        w = np.where((S[:, 7:8] > 0), w, 0.0)
+        if idx == 3:          # glass: reflection + transmission weights are Kr / Kt themselves (each lobe picked with its probability)
+            assert (w <= 1.0 + 1e-5).all()
+        else:
+            assert w.mean(0).max() <= 1.0 + 0.02, (idx, w.mean(0))
+    osc.close()
+    osc = oracle.OracleScene(palette_scene(hk))
+    for name in ("dt", "cc_rr", "cc_sr", "cd_rough", "cdt"):
+        idx = MATERIAL_NAMES.index(name)
+        S = osc.bsdf(0, idx, wo, wi, ns, lam, u, uc)
+        w = np.where((S[:, 7:8] > 0) & (S[:, 8:9] == 0), S[:, 3:7] * np.abs(S[:, 2:3]) / np.maximum(S[:, 7:8], 1e-30), 0.0)
+        # CoatedConductor with a ROUGH interface is not energy-conserving in the reference: its coat lobe returns f = D G / (4 cos cos)
+        # WITHOUT the Fresnel factor while being picked with probability F (spectral-eval.jl:3118-3140), so that branch alone
+        # contributes E[f cos / pdf] = G / G1 ~ 1 and the metal lobe comes on top: albedo up to ~ 1 + F_metal T_in T_out (Q13)
+        bound = 2.0 if name == "cc_rr" else 1.0 + 0.05
+        assert np.isfinite(w).all() and w.mean(0).max() <= bound, (name, w.mean(0))
+        if name == "cc_rr":
+            assert w.mean(0).min() > 1.0
+    osc.close()
+
+
+# ---------------------------------------------------------------------------------------------------- sampling helpers
+def test_cosine_hemisphere_and_hg(oracle):
+    rng = np.random.default_rng(4)
+    n = 50000
+    u = rng.random((n, 2)).astype(f32)
+    ch, want = oracle.cosine_hemisphere(u), R.cosine_hemisphere(u)
+    assert np.abs(ch[:, :2] - want[:, :2]).max() < 3e-7 and np.abs(ch[:, 2] - want[:, 2])[want[:, 2] > 0.05].max() < 3e-6
+    wo = _dirs(rng, n)
+    for g in (0.0, 0.3, -0.6, 0.877):
+        c_in = rng.uniform(-1, 1, n).astype(f32)
+        H = oracle.hg(g, wo, u, c_in)
+        assert np.allclose(H[:, 4], R.hg_phase(g, c_in), rtol=3e-5)
+        cos_s = -(H[:, 0:3].astype(np.float64) * wo).sum(1)               # polar angle measured from -wo (media.jl:66-71)
+        assert np.abs(cos_s - R.hg_cos_from_u(g, u[:, 0])).max() < 2e-5 and np.allclose(np.linalg.norm(H[:, 0:3], axis=1), 1, atol=2e-6)
+        assert np.allclose(H[:, 3], R.hg_phase(g, cos_s), rtol=2e-4)
+        # the phase function is a density on the sphere ...
+        x = (np.arange(20000) + 0.5) / 20000 * 2 - 1
+        assert abs((R.hg_phase(g, x) * 2 * np.pi * (2 / 20000)).sum() - 1) < 1e-4
+        # ... and the sampled cosines follow its CDF (Kolmogorov distance of 50 k samples)
+        srt = np.sort(cos_s)
+        assert np.abs(R.hg_cdf(g, srt) - (np.arange(n) + 0.5) / n).max() < 0.01, g
+
+
+def test_equal_area_mapping(oracle):
+    """environment_map.jl:78-160: the polynomial atan of sphere_to_square agrees with arctan2 to 1e-5 (the polynomial's stated
+    accuracy), square_to_sphere is exact trigonometry; round trip 1e-4 (test_env_light_pbrt_compat.jl); the map is equal-area:
+    uniform uv -> uniform directions (mean of z^2 = 1/3, octant counts equal)."""
+    rng = np.random.default_rng(6)
+    n = 100000
+    uv = rng.random((n, 2)).astype(f32)
+    d = _dirs(rng, n)
+    E = oracle.equal_area(uv, d)
+    assert np.abs(E[:, 0:3] - R.equal_area_square_to_sphere(uv)).max() < 3e-6
+    assert np.abs(E[:, 3:5] - R.equal_area_sphere_to_square(d)).max() < 2e-5
+    back = oracle.equal_area(E[:, 3:5].copy(), d)[:, 0:3]
+    assert np.abs(back - d).max() < 1e-4
+    dirs = E[:, 0:3].astype(np.float64)
+    assert np.allclose(np.linalg.norm(dirs, axis=1), 1, atol=2e-6) and abs((dirs[:, 2] ** 2).mean() - 1 / 3) < 5e-3
+    octant = (dirs[:, 0] > 0) * 4 + (dirs[:, 1] > 0) * 2 + (dirs[:, 2] > 0)
+    assert np.abs(np.bincount(octant, minlength=8) / n - 0.125).max() < 5e-3
+
+
+def test_distribution2d_against_float64(hk, oracle):
+    rng = np.random.default_rng(8)
+    img = (rng.random((24, 24, 3)) ** 4).astype(f32)
+    img[5, 7] = 50.0                                                        # a hot texel
+    img[10:12, :] = 0.0                                                     # two empty rows
+    em = hk.EnvironmentMap(img)
+    rec = em.record()
+    lum = 0.212671 * img[..., 0].astype(np.float64) + 0.715160 * img[..., 1] + 0.072169 * img[..., 2]
+    ref = R.PiecewiseConstant2D(lum)
+    n = 20000
+    u = rng.random((n, 2)).astype(f32)
+    q = rng.random((n, 2)).astype(f32)
+    D = oracle.dist2d(rec, u, q)
+    want = np.array([(*ref.sample(x)[0], ref.sample(x)[1]) for x in u.astype(np.float64)])
+    edge = (np.abs(D[:, 0] * 24 - np.round(D[:, 0] * 24)) < 1e-3) | (np.abs(D[:, 1] * 24 - np.round(D[:, 1] * 24)) < 1e-3)
+    assert np.abs(D[~edge, 0:2] - want[~edge, 0:2]).max() < 2e-4 and np.allclose(D[~edge, 2], want[~edge, 2], rtol=2e-4)
+    assert np.allclose(D[:, 3], [ref.pdf(x) for x in q.astype(np.float64)], rtol=2e-5)
+    # pdf is a density on the unit square and the hot texel is found with its probability mass
+    cells = (np.arange(24) + 0.5) / 24
+    cu, cv = np.meshgrid(cells, cells)
+    pd = oracle.dist2d(rec, u[:576], np.stack([cu.ravel(), cv.ravel()], 1))[:, 3]
+    assert abs(pd.mean() - 1) < 1e-5
+    hit = ((D[:, 0] * 24).astype(int) == 7) & ((D[:, 1] * 24).astype(int) == 5)
+    mass = lum[5, 7] / lum.sum()
+    assert abs(hit.mean() - mass) < 4 * np.sqrt(mass * (1 - mass) / n)
+
+
+def test_environment_light_integral(hk, oracle):
+    """test_env_light_pbrt_compat.jl:83-140: a constant map of radiance L integrates to 4 pi L through sample / pdf."""
+    from hikari_jl_amd import geometry as G
+    L0 = 0.75
+    em = hk.EnvironmentMap(np.full((16, 16, 3), L0, f32))
+    s = hk.Scene()
+    s.push(hk.EnvironmentLight(em, hk.RGBSpectrum(1.0)))
+    s.push(G.quad((0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0)), hk.MatteMaterial())
+    s.sync()
+    osc = oracle.OracleScene(s)
+    rng = np.random.default_rng(9)
+    n = 20000
+    lam = np.full((n, 4), 550.0, f32)
+    x = np.zeros((n, 3), f32)
+    x[:, :2] = rng.random((n, 2))
+    S = osc.light(0, 1, np.zeros((n, 3), f32), x, lam)
+    est = (S[:, 4] / S[:, 3]).mean()
+    direct = osc.light(1, 0, np.zeros((4, 3), f32), np.array([[0, 0, 1], [1, 0, 0], [0, -1, 0], [0, 0, -1]], f32), lam[:4])
+    assert np.allclose(S[:, 3], 1 / (4 * np.pi), rtol=1e-5)
+    assert np.allclose(direct[:, 0], direct[0, 0], rtol=1e-6) and np.isclose(est, 4 * np.pi * direct[0, 0], rtol=5e-2)
+    osc.close()
+
+
+def test_node_importance_against_float64(hk, oracle):
+    from hikari_jl_amd import geometry as G
+    rng = np.random.default_rng(10)
+    s = hk.Scene()
+    s.push(G.rect3f((-1, 0, -1), (2, 0.01, 2)), hk.MatteMaterial())
+    for i in range(12):
+        c = rng.random(3) * 1.6 + np.array([-0.8, 0.2, -0.8])
+        q = G.quad(c, c + [0.2, 0, 0], c + [0.2, 0, 0.15], c + [0, 0, 0.15])
+        s.push(q, hk.MediumInterface(hk.MatteMaterial(), emission=hk.Emissive(Le=hk.RGBSpectrum(*(0.2 + 0.8 * rng.random(3))), scale=1.0 + i % 3, two_sided=bool(i % 2))))
+    s.push(hk.PointLight((0.3, 1.5, 0.2), hk.RGBSpectrum(15.0)))
+    s.sync()
+    osc = oracle.OracleScene(s)
+    nodes, _ = osc.light_bvh_nodes()
+    n = 400
+    p = (rng.random((n, 3)) * 3 - 1.5 + np.array([0, 1, 0])).astype(f32)
+    nr = _dirs(rng, n)
+    nr[:40] = 0
+    checked = 0
+    for idx in range(nodes.shape[0]):
+        nd = nodes[idx]
+        got = osc.node_importance(idx, p, nr)
+        want = np.array([R.node_importance(p[i], nr[i], nd[0:3], nd[3:6], nd[6:9], nd[9], nd[10], nd[11], nd[12] != 0) for i in range(n)])
+        knife = np.abs(got - want) > 1e-4 * np.maximum(np.abs(want), 1e-6)     # cos_p ~ cos_e knife edges flip between f32 and f64
+        assert knife.mean() < 0.01, (idx, knife.mean())
+        checked += 1
+    assert checked >= 20
+    osc.close()
+
+
+# ---------------------------------------------------------------------------------------------------- LayeredBxDF, brute force
+def test_coated_diffuse_against_bruteforce_walk(hk, oracle):
+    """CoatedDiffuse (spectral-eval.jl:1232-1441, 1564-1840): the oracle's stochastic evaluate(), averaged over uniformly
+    distributed wi, against an independent brute-force photon simulation written here in numpy float64 (smooth eta = 1.5 coat
+    over a Lambertian base of albedo rho, no medium): photons enter at wo, bounce between the interface (Fresnel R / T, specular)
+    and the base (cosine lobe) until they leave.
+
+    The PHYSICAL diffuse albedo is what the photon count gives (and what the reference's own sample() estimator reproduces).
+    The reference's evaluate() differs from it by two factors that follow from its text — quirk Q29:
+      * sample_dielectric_interface returns f = T / |cos| for specular transmission WITHOUT pbrt's radiance-mode 1 / eta^2
+        (spectral-eval.jl:1008 vs pbrt-v4 DielectricBxDF::Sample_f `ft /= Sqr(etap)`): x eta^2 = 2.25;
+      * the next-event term at the diffuse base applies the MIS weight PowerHeuristic(wis.pdf = 1, cos'/pi) even when the exit
+        interface is specular, where pbrt uses wt = 1 (`if !exit_at_bottom || !is_smooth`, :1780): x <wt> ~ 0.92.
+    so E[evaluate] integrates to albedo_physical * eta^2 * <wt>, <wt> being the T(wi) cos(wi)-weighted mean of
+    1 / (1 + (cos'(wi) / pi)^2) — computed here by quadrature.  The oracle must land on that number."""
+    from test_layered_materials import MATERIAL_NAMES, palette_scene
+    osc = oracle.OracleScene(palette_scene(hk))
+    idx = MATERIAL_NAMES.index("cd_smooth")
+    rng = np.random.default_rng(12)
+    lam = np.full((1, 4), 550.0, f32)
+    rho = float(oracle.uplift(0, np.array([[0.5, 0.3, 0.2]], f32), lam)[0, 0])
+    eta = 1.5
+    c = (np.arange(20000) + 0.5) / 20000                              # cos(wi), uniform in solid angle
+    T_i = 1 - R.fresnel_dielectric(c, eta)
+    c_in = np.sqrt(1 - (1 - c * c) / eta ** 2)                        # refracted cosine inside the coat
+    thick = 0.01                                                      # like pbrt, the slab attenuates by exp(-thickness / |cos|) per traversal even without a medium
+    wt_mean = (T_i * c * np.exp(-thick / c_in) / (1 + (c_in / np.pi) ** 2)).sum() / (T_i * c * np.exp(-thick / c_in)).sum()
+    assert 0.90 < wt_mean < 0.95
+    for cos_o in (0.9, 0.5):
+        wo1 = np.array([np.sqrt(1 - cos_o ** 2), 0, cos_o])
+        n = 200000
+        wo = np.tile(wo1.astype(f32), (n, 1))
+        z = np.tile(np.array([[0, 0, 1]], f32), (n, 1))
+        wi = _dirs(rng, n, upper=True)
+        wi[:, 2] = rng.random(n)                                     # uniform in solid angle: cos uniform in [0, 1]
+        sxy = np.sqrt(np.maximum(0, 1 - wi[:, 2] ** 2)) / np.maximum(np.linalg.norm(wi[:, :2], axis=1), 1e-20)
+        wi[:, 0] *= sxy
+        wi[:, 1] *= sxy
+        E = osc.bsdf(1, idx, wo, wi, z, np.tile(lam, (n, 1)), np.zeros((n, 2), f32), np.zeros(n, f32))
+        w = E[:, 0].astype(np.float64) * wi[:, 2] * 2 * np.pi        # f cos / pdf with pdf = 1 / 2 pi
+        eval_albedo, se = w.mean(), w.std() / np.sqrt(n)
+        # the reference's sample() estimator: f cos / pdf of the non-specular samples = the physical diffuse albedo
+        S = osc.bsdf(0, idx, wo, wo, z, np.tile(lam, (n, 1)), rng.random((n, 2)).astype(f32), rng.random(n).astype(f32))
+        ws = np.where((S[:, 7] > 0) & (S[:, 8] == 0), S[:, 3] * np.abs(S[:, 2]) / np.maximum(S[:, 7], 1e-30), 0.0)
+        # brute force: photon counting
+        m = 400000
+        alive = np.ones(m, bool)
+        weight = np.ones(m)
+        out = np.zeros(m)
+        R0 = R.fresnel_dielectric(np.full(m, cos_o), eta)
+        alive &= ~(rng.random(m) < R0)                              # reflected off the coat at once: specular, not part of evaluate()
+        weight *= np.exp(-thick / np.sqrt(1 - (1 - cos_o ** 2) / eta ** 2))   # first traversal, along the refracted wo
+        for _ in range(64):                                         # inside: base bounce (albedo rho, cosine lobe), then the interface from below
+            if not alive.any():
+                break
+            weight[alive] *= rho
+            c_up = np.sqrt(np.maximum(rng.random(m), 1e-12))        # cosine-distributed polar cosine inside the coat
+            weight[alive] *= np.exp(-thick / c_up[alive])           # up to the interface
+            esc = alive & (rng.random(m) >= R.fresnel_dielectric(-c_up, eta))   # leaving the denser medium (TIR included)
+            out[esc] = weight[esc]
+            alive &= ~esc
+            weight[alive] *= np.exp(-thick / c_up[alive])           # reflected back down to the base
+        physical, se_bf = out.mean(), out.std() / np.sqrt(m)
+        assert abs(ws.mean() - physical) < 4 * np.hypot(ws.std() / np.sqrt(n), se_bf) + 0.04 * physical, (cos_o, ws.mean(), physical)
+        want = physical * eta ** 2 * wt_mean
+        assert abs(eval_albedo - want) < 4 * np.hypot(se, se_bf * eta ** 2) + 0.02 * want, (cos_o, eval_albedo, want, physical)
+    osc.close()
+
+
+# ---------------------------------------------------------------------------------------------------- Hosek-Wilkie
+def test_hosek_wilkie_published_form(hk):
+    """The Hosek-Wilkie radiance distribution (Hosek & Wilkie 2012, eq. 4 with the 2013 coefficients the reference embeds):
+        F(theta, gamma) = (1 + A e^{B/(cos theta + 0.01)}) (C + D e^{E gamma} + F cos^2 gamma + G chi(H, gamma) + I sqrt(cos theta))
+        chi(g, a) = (1 + cos^2 a) / (1 + g^2 - 2 g cos a)^{3/2},      L = F * L_M
+    evaluated here in float64 straight from the coefficient table (quintic Bezier in (elevation/(pi/2))^(1/3), linear in albedo
+    and turbidity) at two directions, against the baked map's texels converted the way sun_sky.jl does (13 wavelengths -> XYZ /
+    CIE_Y_integral -> linear sRGB)."""
+    import os
+    from hikari_jl_amd import sunsky as SS
+    from hikari_jl_amd.envmap import equal_area_square_to_sphere
+    raw = np.fromfile(os.path.join(os.path.dirname(os.path.abspath(SS.__file__)), "data", "hosek_wilkie_sky.bin"), dtype=np.float64)
+    assert raw.size == 11 * 1080 + 11 * 120
+    cfg, rad = raw[:11 * 1080].reshape(11, 2, 10, 6, 9), raw[11 * 1080:].reshape(11, 2, 10, 6)
+    turb, albedo = 3.0, 0.5
+    sun = np.array([1.0, 2.0, 9.0])
+    sun /= np.linalg.norm(sun)
+    elev = np.arcsin(sun[2])
+    x = (elev / (np.pi / 2)) ** (1 / 3)
+    bern = np.array([(1 - x) ** 5, 5 * (1 - x) ** 4 * x, 10 * (1 - x) ** 3 * x ** 2, 10 * (1 - x) ** 2 * x ** 3, 5 * (1 - x) * x ** 4, x ** 5])
+    it = int(turb)
+    ft = turb - it
+
+    def interp(tab):                 # tab[albedo 0/1][turbidity 1..10][6 control points][...]
+        def at(a, t):
+            return np.tensordot(bern, tab[a, t - 1], axes=(0, 0))
+        lo = (1 - albedo) * at(0, it) + albedo * at(1, it)
+        hi = (1 - albedo) * at(0, min(it + 1, 10)) + albedo * at(1, min(it + 1, 10))
+        return (1 - ft) * lo + ft * hi
+
+    def radiance(band, theta, gamma):
+        A, B, C, D, E, F, G, I, H = interp(cfg[band])      # the data set stores the 9 parameters in this order (H and I swapped)
+        LM = interp(rad[band])
+        chi = (1 + np.cos(gamma) ** 2) / (1 + H * H - 2 * H * np.cos(gamma)) ** 1.5
+        return (1 + A * np.exp(B / (np.cos(theta) + 0.01))) * (C + D * np.exp(E * gamma) + F * np.cos(gamma) ** 2 + G * chi + I * np.sqrt(np.cos(theta))) * LM
+
+    env, _ = hk.sunsky_to_envlight((1, 2, 9), intensity=1.0, turbidity=turb, ground_enabled=False, resolution=64)
+    data = env.env_map.data[..., :3].astype(np.float64)
+    c = (np.arange(64) + 0.5) / 64
+    uu, vv = np.meshgrid(c, c)
+    dx, dy, dz = equal_area_square_to_sphere(uu, vv)
+    cie = np.fromfile(os.path.join(os.path.dirname(os.path.abspath(SS.__file__)), "data", "cie_xyz.bin"), dtype=np.float32).reshape(3, 471).astype(np.float64)
+    M = np.array([[3.2404542, -1.5371385, -0.4985314], [-0.9692660, 1.8760108, 0.0415560], [0.0556434, -0.2040259, 1.0572252]])
+    checked = 0
+    for (iy, ix) in ((40, 40), (52, 20), (33, 47)):
+        d = np.array([dx[iy, ix], dy[iy, ix], dz[iy, ix]])
+        if d[2] < 0.05:
+            continue
+        theta, gamma = np.arccos(d[2]), np.arccos(np.clip(d @ sun, -1, 1))
+        # sun_sky.jl: 13 wavelengths 320 ... 720 (linear between the 11 bands), then a 1-nm sum over the CIE tables 360 ... 830 with the
+        # 13 samples interpolated linearly and held constant beyond 720 nm, divided by CIE_Y_integral
+        wl = 320.0 + np.arange(13) * (400.0 / 12)
+        sp13 = np.interp(wl, 320 + 40 * np.arange(11), np.array([radiance(b, theta, gamma) for b in range(11)]))
+        s1nm = np.interp(360.0 + np.arange(471), wl, sp13)
+        xyz = (cie * s1nm[None, :]).sum(1) / 106.856895
+        rgb = np.maximum(M @ xyz, 0)
+        got = data[iy, ix]
+        assert np.allclose(got, rgb, rtol=2e-5, atol=1e-7), ((iy, ix), got, rgb)
+        checked += 1
+    assert checked >= 2

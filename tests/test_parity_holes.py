@@ -1,0 +1,581 @@
+"""GPU parity for the code paths no round-1 test executed (VERDICT r1 "What's missing" 4-7, "weak" 2-3): every sub-case goes through
+the C-ABI on the HIP path and is compared with the oracle on the same seeded inputs.
+
+  a9   Box / Triangle / Mitchell / Lanczos filter samplers            test_camera_stage_filters_lens_matrix
+  a10  thin lens (lens_radius > 0), MatrixCamera record                test_camera_stage_filters_lens_matrix, test_thin_lens_and_spot_frames
+  a11  lane_ray_round (closest + any-hit), 32-entry stack              test_lean_traversal_parity
+  a14  resolve_mix_material (nested, textured amount), Mix in a frame  test_mix_resolve_bit_exact, test_mix_mirror_frame
+  a17  Matte(sigma) / Mirror / Glass / Conductor (RGB, measured)       test_simple_bsdf_pointwise_parity, test_mix_mirror_frame
+  a23  Float64 film accumulators                                       test_f64_film_frame
+  a24  Point / Spot / Directional / Sun / DiffuseArea sample_light     test_light_sampling_pointwise
+  a28  Grid / RGBGrid / NanoVDB sample_point + majorant DDA, bit-exact test_medium_pointwise_bit_exact (incl. the bench-size cloud)
+  N4   material_coherence = none / sorted / per_type                   test_material_coherence_is_result_neutral
+  configs[3], configs[4] at full size                                  test_full_size_many_light, test_full_size_cloud
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+def _pf(hk, a):
+    return a.ctypes.data_as(hk._abi.PF)
+
+
+def _pi(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def _unit(v):
+    return (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(f32)
+
+
+def ulp_diff(a, b):
+    a = np.ascontiguousarray(a, f32).view(np.int32).astype(np.int64)
+    b = np.ascontiguousarray(b, f32).view(np.int32).astype(np.int64)
+    a = np.where(a < 0, -(a & 0x7fffffff), a)
+    b = np.where(b < 0, -(b & 0x7fffffff), b)
+    return np.abs(a - b)
+
+
+def frame_metrics(gpu, ref):
+    rel_mse = float(np.mean((gpu - ref) ** 2 / (ref ** 2 + 1e-3)))
+    num = np.sqrt(((gpu - ref) ** 2).sum(axis=2))
+    den = np.sqrt((ref ** 2).sum(axis=2)) + 1e-6
+    return rel_mse, float(np.mean(num / den <= 1e-2))
+
+
+def _frame_both(hk, oracle, s, cam, w, h, **kw):
+    film = hk.Film((w, h))
+    vp = hk.VolPath(**kw)
+    vp(s, film, cam)
+    st = vp.stats()
+    vp.close()
+    okw = {k: v for k, v in kw.items() if k != "samples_per_pass"}
+    acc, ost = oracle.OracleScene(s).render(hk.integrator_params(**okw), cam, w, h, kw["samples"])
+    return film.framebuffer.copy(), oracle.finalize(acc, w, h), st, ost
+
+
+# ---------------------------------------------------------------------------------------------------- a17: simple BSDFs
+SIMPLE = ["matte", "matte_sigma", "mirror", "glass", "conductor_rough", "conductor_smooth", "gold_measured"]
+
+
+@pytest.mark.parametrize("name", SIMPLE)
+def test_simple_bsdf_pointwise_parity(hk, oracle, gpu_ctx, name):
+    """sample_bsdf / eval_bsdf of the four closed-form kinds (spectral-eval.jl:42-488) on 20 k random (wo, wi, ns, lambda, u, uc),
+    random shading normals, with and without regularisation.  Same arithmetic order on both sides: values agree to libm ulps
+    (rtol 2e-4 covers sqrt/div-exact code with a few sin/cos), and a Fresnel-vs-uc knife edge may flip a lobe on < 0.05 %."""
+    from test_independent_pins import _palette
+    s = _palette(hk)
+    osc = oracle.OracleScene(s)
+    idx = SIMPLE.index(name)
+    n = 20000
+    rng = np.random.default_rng(17)
+    wo, wi, ns = _unit(rng.normal(size=(n, 3))), _unit(rng.normal(size=(n, 3))), _unit(rng.normal(size=(n, 3)))
+    lam = (360 + 470 * rng.random((n, 4))).astype(f32)
+    u, uc = rng.random((n, 2), dtype=f32), rng.random(n, dtype=f32)
+    sh = hk.scene_handle(gpu_ctx, s)
+    L = hk._lib.lib()
+    for mode in (0, 1):
+        for reg in ((False, True) if mode == 0 else (False,)):
+            ref = osc.bsdf(mode, idx, wo, wi, ns, lam, u, uc, regularize=reg)
+            out = np.zeros((n, 10), f32)
+            hk._lib.check(L.hk_test_bsdf(gpu_ctx.h, sh, mode, idx, 1 if reg else 0, n, *[_pf(hk, a) for a in (wo, wi, ns, lam, u, uc, out)]), "hk_test_bsdf")
+            assert np.isfinite(out).all()
+            close = np.isclose(out, ref, rtol=2e-4, atol=1e-6).all(axis=1)
+            assert close.mean() >= 0.9995, (name, mode, reg, close.mean())
+            if name in ("matte", "matte_sigma", "mirror"):          # no transcendental beyond sin/cos of the disk map
+                assert close.all() and ulp_diff(out[:, 3:8], ref[:, 3:8]).max() <= 4
+    osc.close()
+
+
+# ---------------------------------------------------------------------------------------------------- a14: MixMaterial
+def _mix_scene(hk, frame=False, w=48, h=48):
+    """Cornell-like box whose sphere carries a NESTED mix (matte | (mirror | conductor)) with a TEXTURED outer amount and whose
+    block carries mirror | glass at a constant amount; plus a plain mirror panel."""
+    from hikari_jl_amd import geometry as G
+    from hikari_jl_amd import scenes
+    from hikari_jl_amd.materials import Texture
+    rng = np.random.default_rng(23)
+    amount = np.clip(rng.random((8, 8)) * 1.4 - 0.2, 0.0, 1.0).astype(f32)      # includes exact 0 and 1 texels (both short-cuts)
+    inner = hk.MixMaterial((hk.MirrorMaterial(Kr=hk.RGBSpectrum(0.9, 0.85, 0.7)),
+                            hk.ConductorMaterial(eta=hk.RGBSpectrum(0.2, 0.92, 1.1), k=hk.RGBSpectrum(3.9, 2.45, 2.14), roughness=0.05)), 0.35)
+    outer = hk.MixMaterial((hk.MatteMaterial(Kd=hk.RGBSpectrum(0.7, 0.3, 0.2)), inner), Texture(amount))
+    block = hk.MixMaterial((hk.MirrorMaterial(Kr=hk.RGBSpectrum(0.95)), hk.GlassMaterial(index=1.5)), 0.6)
+    white = hk.MatteMaterial(Kd=hk.RGBSpectrum(0.73, 0.73, 0.73))
+    s = hk.Scene()
+    box, half = 2.0, 1.0
+    s.push(G.rect3f((-half, 0, -half), (box, 0.01, box)), white)
+    s.push(G.rect3f((-half, box - 0.01, -half), (box, 0.01, box)), white)
+    s.push(G.rect3f((-half, 0, half - 0.01), (box, box, 0.01)), white)
+    s.push(G.rect3f((-half, 0, -half), (0.01, box, box)), hk.MatteMaterial(Kd=hk.RGBSpectrum(0.65, 0.05, 0.05)))
+    s.push(G.rect3f((half - 0.01, 0, -half), (0.01, box, box)), hk.MatteMaterial(Kd=hk.RGBSpectrum(0.12, 0.45, 0.15)))
+    s.push(G.sphere((-0.4, 0.4, 0.1), 0.35, 24), outer)
+    s.push(G.rect3f((0.15, 0.0, -0.1), (0.5, 0.6, 0.5)), block)
+    s.push(G.quad((-0.9, 0.3, 0.6), (-0.3, 0.3, 0.9), (-0.3, 1.4, 0.9), (-0.9, 1.4, 0.6), normal=(0.45, 0.0, -0.89)), hk.MirrorMaterial())
+    s.push(hk.PointLight((0, 1.8, 0), hk.RGBSpectrum(15.0)))
+    y = 1.98
+    s.push(G.quad((-0.25, y, -0.25), (0.25, y, -0.25), (0.25, y, 0.25), (-0.25, y, 0.25), normal=(0, -1, 0)),
+           hk.MediumInterface(hk.MatteMaterial(Kd=hk.RGBSpectrum(0.0)), emission=hk.Emissive(Le=hk.RGBSpectrum(1.0), scale=1.0, two_sided=False)))
+    s.sync()
+    film = hk.Film((w, h))
+    cam = hk.PerspectiveCamera((0, 1, -3.5), (0, 1, 0), film, fov=40.0)
+    return s, film, cam
+
+
+def test_mix_resolve_bit_exact(hk, oracle, gpu_ctx):
+    """resolve_mix_material (mix-material.jl:96-127, 222-238): 64-bit hash of the bit patterns of (p, wo) and the SetKeys of the two
+    children against the nearest-texel amount (Q28); nested mixes are followed.  Integer arithmetic: identical material index
+    for every one of 200 k points, for every Mix in the scene."""
+    s, _, _ = _mix_scene(hk)
+    osc = oracle.OracleScene(s)
+    sh = hk.scene_handle(gpu_ctx, s)
+    L = hk._lib.lib()
+    kinds = [s.desc.materials[i].kind for i in range(s.desc.n_materials)]
+    mixes = [i for i, k in enumerate(kinds) if k == hk._abi.HK_MAT_MIX]
+    assert len(mixes) == 3
+    rng = np.random.default_rng(29)
+    n = 200000
+    p = (rng.random((n, 3)) * 2 - 1).astype(f32)
+    wo = _unit(rng.normal(size=(n, 3)))
+    uv = rng.random((n, 2), dtype=f32)
+    uv[:100] = np.array([0.0, 0.0], f32)
+    uv[100:200] = np.array([1.0, 1.0], f32)
+    for m in mixes:
+        ref = osc.mix_resolve(m, p, wo, uv)
+        out = np.empty(n, np.int32)
+        hk._lib.check(L.hk_test_mix(gpu_ctx.h, sh, m, n, _pf(hk, p), _pf(hk, wo), _pf(hk, uv), _pi(out)), "hk_test_mix")
+        assert np.array_equal(out, ref), m
+        assert all(kinds[i] != hk._abi.HK_MAT_MIX for i in np.unique(out)) and len(np.unique(out)) >= 2
+    osc.close()
+
+
+def test_mix_mirror_frame(hk, oracle):
+    """Mix (nested, textured amount) and Mirror objects through the whole K1..K13 loop: k_shade<MIRROR>, resolve_mix_material in
+    the trace kernel (queue sorted by the RESOLVED kind), specular chains.  Strict frame tolerance; the ray counts
+    of both sides agree because every Mix decision is integer arithmetic on identical bits at the first vertex."""
+    w = h = 48
+    s, film, cam = _mix_scene(hk, w=w, h=h)
+    for depth, spp in ((1, 8), (3, 8), (6, 8)):
+        g, r, st, ost = _frame_both(hk, oracle, s, cam, w, h, max_depth=depth, samples=spp)
+        rel_mse, frac = frame_metrics(g, r)
+        assert np.isfinite(g).all() and rel_mse <= 1e-3 and frac >= 0.99, (depth, rel_mse, frac)
+        assert abs(int(st.rays_closest) - int(ost.rays_closest)) <= 0.002 * ost.rays_closest + 4
+        assert abs(int(st.rays_shadow) - int(ost.rays_shadow)) <= 0.002 * ost.rays_shadow + 4
+
+
+# ---------------------------------------------------------------------------------------------------- a24: lights
+def _light_scene(hk):
+    from hikari_jl_amd import geometry as G
+    from hikari_jl_amd.materials import Texture
+    rng = np.random.default_rng(31)
+    s = hk.Scene()
+    s.push(hk.PointLight((0.3, 1.5, 0.2), hk.RGBSpectrum(15.0, 12.0, 9.0)))                                  # scale 1 (Q4)
+    s.push(hk.PointLight.from_rgb((2.0, 1.0, 0.5), (-0.4, 0.8, 0.1), power=50.0))                              # illuminant spectrum, power scale
+    s.push(hk.SpotLight((0.5, 1.9, -0.5), (0.1, 0, 0.2), hk.RGBSpectrum(30.0), 35.0, 20.0))
+    s.push(hk.DirectionalLight(hk.RGBSpectrum(2.0, 1.9, 1.7), (0.2, -1.0, 0.3)))
+    s.push(hk.DirectionalLight.from_rgb((3.0, 2.5, 2.0), (0.0, -1.0, 0.0), illuminance=4.0))
+    s.push(hk.SunLight.from_rgb((5.0, 4.75, 4.25), (-0.1, -0.2, -0.9)))
+    s.push(G.rect3f((-1, 0, -1), (2, 0.01, 2)), hk.MatteMaterial(Kd=Texture(rng.random((4, 4, 3)).astype(f32))))   # gives the scene a texture
+    q1 = G.quad((-0.5, 1.2, -0.5), (0.1, 1.2, -0.5), (0.1, 1.2, 0.2), (-0.5, 1.2, 0.2), normal=(0, -1, 0))
+    s.push(q1, hk.MediumInterface(hk.MatteMaterial(), emission=hk.Emissive(Le=hk.RGBSpectrum(0.9, 0.6, 0.3), scale=0.8, two_sided=False)))
+    q2 = G.quad((0.3, 0.5, 0.3), (0.8, 0.5, 0.3), (0.8, 1.0, 0.5), (0.3, 1.0, 0.5))
+    s.push(q2, hk.MediumInterface(hk.MatteMaterial(), emission=hk.Emissive(Le=hk.RGBSpectrum(0.3, 0.5, 0.9), scale=1.0, two_sided=True)))
+    s.sync()
+    # a TEXTURED area light at the ABI level (the host mirror resolves textured emission per face like scene-mesh.jl:49 does; a
+    # `ccall` user may hand the texture over): point the last light's Le at the scene's texture 0
+    last = s.desc.n_lights - 1
+    assert s.desc.lights[last].kind == hk._abi.HK_LIGHT_DIFFUSE_AREA and s.desc.n_textures >= 1
+    s.desc.lights[last].Le.tex = 0
+    return s
+
+
+def test_light_sampling_pointwise(hk, oracle, gpu_ctx):
+    """sample_light_spectral for every light kind the point-wise test of round 1 skipped (physical-wavefront/lights.jl:39-131,
+    205-297): Point (both constructors), Spot — points inside the inner cone, in the falloff ring and outside the cone —,
+    Directional, Sun, DiffuseArea one-sided / two-sided / textured, 100 k points each.  Only +,-,*,/,sqrt on both sides and one
+    exp per sigmoid: <= 4 ulp on Li, wi / p_light / pdf exact or <= 2 ulp."""
+    s = _light_scene(hk)
+    osc = oracle.OracleScene(s)
+    sh = hk.scene_handle(gpu_ctx, s)
+    L = hk._lib.lib()
+    A = hk._abi
+    rng = np.random.default_rng(37)
+    n = 100000
+    p = (rng.random((n, 3)) * np.array([3.0, 2.5, 3.0]) - np.array([1.5, 0.2, 1.5])).astype(f32)
+    x = np.zeros((n, 3), f32)
+    x[:, :2] = rng.random((n, 2), dtype=f32)
+    lam = (360 + 470 * rng.random((n, 4))).astype(f32)
+    seen = {}
+    for li in range(1, s.desc.n_lights + 1):
+        kind = s.desc.lights[li - 1].kind
+        ref = osc.light(0, li, p, x, lam)
+        out = np.zeros((n, 12), f32)
+        hk._lib.check(L.hk_test_light(gpu_ctx.h, sh, 0, li, n, _pf(hk, p), _pf(hk, x), _pf(hk, lam), _pf(hk, out)), "hk_test_light")
+        assert np.isfinite(out).all()
+        lit = ref[:, 3] > 0
+        assert np.array_equal(out[:, 3] > 0, lit), (li, kind)                   # same accept / reject decision at every point
+        assert np.array_equal(out[:, 11], ref[:, 11])
+        assert ulp_diff(out[lit, 0:3], ref[lit, 0:3]).max() <= 2 and ulp_diff(out[lit, 3], ref[lit, 3]).max() <= 2, (li, kind)
+        assert ulp_diff(out[lit, 8:11], ref[lit, 8:11]).max() <= 2
+        assert np.allclose(out[lit, 4:8], ref[lit, 4:8], rtol=3e-6, atol=0), (li, kind, np.abs(out[lit, 4:8] / ref[lit, 4:8] - 1).max())
+        if kind == A.HK_LIGHT_SPOT:
+            l = s.desc.lights[li - 1]
+            d = _unit(p - np.array(l.position[:], f32))
+            axis = _unit(np.array([[0.1 - 0.5, 0 - 1.9, 0.2 + 0.5]], f32))[0]
+            ct = d @ axis
+            inner, ring, outside = ct >= l.cos_falloff_start, (ct < l.cos_falloff_start) & (ct >= l.cos_total_width), ct < l.cos_total_width
+            assert inner.sum() > 500 and ring.sum() > 500 and outside.sum() > 5000
+            assert not lit[outside & (ct < l.cos_total_width - 1e-5)].any() and lit[inner].all()
+        if kind == A.HK_LIGHT_DIFFUSE_AREA:
+            l = s.desc.lights[li - 1]
+            if not l.two_sided:
+                assert (~lit).sum() > 1000                                        # points behind a one-sided emitter receive nothing
+        seen.setdefault(kind, 0)
+        seen[kind] += 1
+    assert seen.get(A.HK_LIGHT_POINT) == 2 and seen.get(A.HK_LIGHT_SPOT) == 1 and seen.get(A.HK_LIGHT_DIRECTIONAL) == 2
+    assert seen.get(A.HK_LIGHT_SUN) == 1 and seen.get(A.HK_LIGHT_DIFFUSE_AREA, 0) >= 4
+    osc.close()
+
+
+# ---------------------------------------------------------------------------------------------------- a9 / a10: filters, lens, MatrixCamera
+def _filters(hk):
+    return {"box": hk.BoxFilter(), "triangle": hk.TriangleFilter(), "gaussian": hk.GaussianFilter(), "gaussian_wide": hk.GaussianFilter((2.0, 2.5), 0.8),
+            "mitchell": hk.MitchellFilter(), "lanczos": hk.LanczosSincFilter()}
+
+
+@pytest.mark.parametrize("fname", ["box", "triangle", "gaussian", "gaussian_wide", "mitchell", "lanczos"])
+def test_camera_stage_filters_lens_matrix(hk, oracle, gpu_ctx, fname):
+    """K1 with every pixel filter (filter.jl:574-604, 733-953: Box and Triangle sample analytically, the others through the
+    tabulated 2-D distribution), a thin-lens PerspectiveCamera (perspective.jl:103-112: concentric disk, focal plane) and a
+    MatrixCamera record built from Makie-style view / projection matrices (camera/matrix.jl:13-115)."""
+    film = hk.Film((200, 120))
+    cams = {
+        "pinhole": hk.PerspectiveCamera((0, 1, -3.5), (0, 1, 0), film, fov=40.0),
+        "thin_lens": hk.PerspectiveCamera((0.5, 1.2, -3.0), (0, 0.8, 0), film, fov=35.0, lens_radius=0.08, focal_distance=3.2),
+    }
+    from hikari_jl_amd import geometry as G
+    view = G.look_at((1.0, 2.0, -4.0), (0, 0.5, 0), (0, 1, 0)).astype(np.float64)
+    flip = np.diag([1.0, 1.0, -1.0, 1.0])                       # OpenGL camera looks along -z
+    fovy, near, far, aspect = np.deg2rad(45.0), 0.1, 100.0, 200 / 120
+    t = 1 / np.tan(fovy / 2)
+    proj = np.array([[t / aspect, 0, 0, 0], [0, t, 0, 0], [0, 0, (far + near) / (near - far), 2 * far * near / (near - far)], [0, 0, -1, 0]])
+    cams["matrix"] = hk.MatrixCamera(flip @ view, proj, film)
+    p = hk.integrator_params(max_depth=5, samples=64, filter=_filters(hk)[fname])
+    rng = np.random.default_rng(41)
+    n = 20000
+    px = rng.integers(1, 201, n).astype(np.int32)
+    py = rng.integers(1, 121, n).astype(np.int32)
+    si = rng.integers(1, 65, n).astype(np.int32)
+    L = hk._lib.lib()
+    integ = C.c_void_p()
+    hk._lib.check(L.hk_integrator_create(gpu_ctx.h, C.byref(p), C.byref(integ)), "hk_integrator_create")
+    for cname, cam in cams.items():
+        ref = oracle.camera_samples(p, cam, 200, 120, px, py, si)
+        out = np.empty((n, 15), f32)
+        rec = cam.record()
+        hk._lib.check(L.hk_test_camera(gpu_ctx.h, integ, C.byref(rec), 200, 120, n, _pi(px), _pi(py), _pi(si), _pf(hk, out)), "hk_test_camera")
+        assert np.isfinite(out).all(), (fname, cname)
+        assert np.allclose(out[:, :4], ref[:, :4], rtol=0, atol=2e-3) and np.allclose(out[:, 4:8], ref[:, 4:8], rtol=2e-5, atol=1e-9)
+        assert ulp_diff(out[:, 8], ref[:, 8]).max() <= 2, (fname, cname)                       # filter weight
+        if cname == "thin_lens":
+            assert ulp_diff(out[:, 9:15], ref[:, 9:15]).max() <= 4, (fname, cname)              # lens point + refocused direction
+            assert np.ptp(out[:, 9]) > 0.05                                                     # the origins do spread over the lens
+        else:
+            assert np.array_equal(out[:, 9:12], ref[:, 9:12]) and ulp_diff(out[:, 12:15], ref[:, 12:15]).max() <= 2, (fname, cname)
+    L.hk_integrator_destroy(integ)
+    if fname in ("box", "triangle"):
+        w = ref[:, 8]
+        assert np.allclose(w, w[0])                                                             # analytic samplers: constant weight
+
+
+def test_thin_lens_and_spot_frames(hk, oracle):
+    """Whole frames through k_camera's lens branch (dims 4 and 6 are drawn only when lens_radius > 0) and through a SpotLight
+    picked by the light BVH (cone importance, lights.jl:91-98 falloff), each with a non-default filter; strict tolerance."""
+    from hikari_jl_amd import scenes
+    w = h = 56
+    s, film, _ = scenes.cornell_box(w, h, light="area")
+    cam = hk.PerspectiveCamera((0, 1, -3.5), (0, 1, 0), film, fov=40.0, lens_radius=0.06, focal_distance=3.4)
+    g, r, st, ost = _frame_both(hk, oracle, s, cam, w, h, max_depth=5, samples=8, filter=hk.MitchellFilter())
+    rel_mse, frac = frame_metrics(g, r)
+    assert rel_mse <= 1e-3 and frac >= 0.99, (rel_mse, frac)
+    assert abs(int(st.rays_closest) - int(ost.rays_closest)) <= 0.002 * ost.rays_closest + 4
+    pin = hk.PerspectiveCamera((0, 1, -3.5), (0, 1, 0), film, fov=40.0)
+    g0, _, _, _ = _frame_both(hk, oracle, s, pin, w, h, max_depth=5, samples=8, filter=hk.MitchellFilter())
+    assert np.abs(g - g0).mean() > 1e-3                                                         # and the lens does blur
+    from hikari_jl_amd import geometry as G
+    s2, film2, cam2 = scenes.cornell_box(w, h, light="none")
+    s2.push(hk.SpotLight((0.0, 1.9, -0.3), (0.2, 0.0, 0.2), hk.RGBSpectrum(40.0, 36.0, 30.0), 30.0, 18.0))
+    s2.push(hk.SpotLight((-0.8, 1.0, -0.8), (0.4, 0.4, 0.4), hk.RGBSpectrum(10.0, 14.0, 20.0), 25.0, 5.0))
+    s2.sync()
+    g, r, st, ost = _frame_both(hk, oracle, s2, cam2, w, h, max_depth=4, samples=8, filter=hk.TriangleFilter())
+    rel_mse, frac = frame_metrics(g, r)
+    assert g.mean() > 1e-3 and rel_mse <= 1e-3 and frac >= 0.99, (rel_mse, frac)
+    assert abs(int(st.rays_shadow) - int(ost.rays_shadow)) <= 0.002 * ost.rays_shadow + 4
+
+
+# ---------------------------------------------------------------------------------------------------- a23: Float64 film
+def test_f64_film_frame(hk, oracle):
+    """accumulation_eltype = Float64 (volpath.jl:38, 83, 86): k_film<double> / k_finalize<double>.  Against the oracle's f64
+    accumulators (strict frame tolerance); against the f32 film of the same samples (identical per-sample values, different sum
+    precision: <= 1e-6 relative, and NOT bit-equal over 64 samples, which shows the double path really ran); progressive adds
+    on top of f64 accumulators are bit-identical to one call."""
+    from hikari_jl_amd import scenes
+    w = h = 40
+    s, film, cam = scenes.cornell_box(w, h, light="area")
+    kw = dict(max_depth=5, samples=64)
+    g64, r64, st, ost = _frame_both(hk, oracle, s, cam, w, h, accumulation_eltype="Float64", **kw)
+    rel_mse, frac = frame_metrics(g64, r64)
+    assert rel_mse <= 1e-3 and frac >= 0.99
+    f32film = hk.Film((w, h))
+    v32 = hk.VolPath(**kw)
+    v32(s, f32film, cam)
+    a32 = v32.read_accumulators(f32film)
+    v32.close()
+    v64 = hk.VolPath(accumulation_eltype="Float64", **kw)
+    f64film = hk.Film((w, h))
+    v64(s, f64film, cam)
+    a64 = v64.read_accumulators(f64film)
+    assert a64.dtype == np.float64 and a32.dtype == np.float32
+    assert np.allclose(a64, a32, rtol=2e-6, atol=1e-7) and not np.array_equal(a64.astype(np.float32), a32)
+    # the f64 sum of f32 terms is exact to ~1e-16 relative: re-rendering in 8 progressive steps gives the same doubles
+    v64.clear()
+    f64film.iteration_index = 0
+    for k in range(8):
+        v64.render_samples(s, f64film, cam, 8, readback=False)
+    assert np.array_equal(v64.read_accumulators(f64film), a64)
+    v64.close()
+    # the ABI rejects a film / integrator precision mismatch instead of reinterpreting memory
+    L = hk._lib.lib()
+    ctx = hk.Context.get(0)
+    p64 = hk.integrator_params(accumulation_eltype="Float64", **kw)
+    integ, fh = C.c_void_p(), C.c_void_p()
+    hk._lib.check(L.hk_integrator_create(ctx.h, C.byref(p64), C.byref(integ)), "hk_integrator_create")
+    hk._lib.check(L.hk_film_create(ctx.h, w, h, 0, None, C.byref(fh)), "hk_film_create")
+    rec = cam.record()
+    assert L.hk_render(ctx.h, hk.scene_handle(ctx, s), integ, fh, C.byref(rec), 1, 1, 1) == hk._abi.HK_ERR_INVALID
+    L.hk_film_destroy(fh)
+    L.hk_integrator_destroy(integ)
+
+
+# ---------------------------------------------------------------------------------------------------- a28: media, point-wise
+def _media_scene(hk, which):
+    """-> (scene, medium index, bounding box lo / hi in render space)"""
+    from hikari_jl_amd import scenes
+    rng = np.random.default_rng(43)
+    if which == "homogeneous":
+        med = hk.HomogeneousMedium(sigma_a=hk.RGBSpectrum(0.2, 0.3, 0.1), sigma_s=hk.RGBSpectrum(0.8, 0.6, 0.9), Le=hk.RGBSpectrum(0.05, 0.0, 0.02), g=0.4)
+        s, _, _ = scenes.slab_scene(16, 16, med)
+        return s, (-2.5, -2.6, 1.0), (2.5, 2.6, 2.0)
+    if which == "grid":
+        dens = (rng.random((21, 17, 9)) ** 2).astype(f32) * 3.0
+        med = hk.GridMedium(dens, sigma_a=hk.RGBSpectrum(0.1, 0.2, 0.3), sigma_s=hk.RGBSpectrum(1.0, 0.9, 0.8), g=-0.2, bounds=((-2.5, -2.6, 1.0), (2.5, 2.6, 2.0)),
+                            majorant_res=(5, 4, 3))
+        s, _, _ = scenes.slab_scene(16, 16, med)
+        return s, (-2.5, -2.6, 1.0), (2.5, 2.6, 2.0)
+    if which == "rgbgrid":
+        sa = (rng.random((10, 8, 6, 3)) * np.array([0.6, 0.9, 1.3])).astype(f32)
+        ss = (rng.random((10, 8, 6, 3)) ** 2 * np.array([2.0, 1.6, 1.2])).astype(f32)
+        le = (rng.random((10, 8, 6, 3)) * np.array([0.3, 0.1, 0.02])).astype(f32)
+        med = hk.RGBGridMedium(sigma_a_grid=sa, sigma_s_grid=ss, Le_grid=le, sigma_scale=1.5, Le_scale=0.8, g=0.3, bounds=((-2.5, -2.6, 1.0), (2.5, 2.6, 2.0)),
+                               majorant_res=(4, 4, 2))
+        s, _, _ = scenes.slab_scene(16, 16, med)
+        return s, (-2.5, -2.6, 1.0), (2.5, 2.6, 2.0)
+    if which == "nanovdb_small":
+        s, _, _ = scenes.cloud_scene(16, 16, "nanovdb", res=(48, 48, 24))
+        return s, (-0.6, 0.3, -0.6), (0.6, 1.5, 0.6)
+    assert which == "nanovdb_bench"            # BASELINE configs[3] stand-in exactly as bench.py builds it
+    s, _, _ = scenes.cloud_scene(16, 16, "nanovdb", res=(256, 256, 128), sigma_scale=620.0 / 4)
+    return s, (-0.6, 0.3, -0.6), (0.6, 1.5, 0.6)
+
+
+@pytest.mark.parametrize("which", ["homogeneous", "grid", "rgbgrid", "nanovdb_small", "nanovdb_bench"])
+def test_medium_pointwise_bit_exact(hk, oracle, gpu_ctx, which):
+    """sample_point and the majorant DDA of every medium kind, device vs oracle, 100 k points / 50 k rays each, BIT-EXACT.
+    For NanoVDB the two sides are different algorithms: the oracle walks root -> upper -> lower -> leaf per voxel tap like the
+    reference (nanovdb.jl:315-388), the device reads the host-flattened block table (hk_nanovdb.h) — values and the trilinear
+    blend (:400-469) must be identical, inside, on the boundary of and outside the grid's index bounding box.  RGBGrid applies a
+    per-point sigmoid uplift (one exp per wavelength): <= 2 ulp there, exact elsewhere."""
+    s, lo, hi = _media_scene(hk, which)
+    osc = oracle.OracleScene(s)
+    sh = hk.scene_handle(gpu_ctx, s)
+    L = hk._lib.lib()
+    lo, hi = np.array(lo, f32), np.array(hi, f32)
+    rng = np.random.default_rng(47)
+    n = 100000
+    p = (lo - 0.1 * (hi - lo) + 1.2 * (hi - lo) * rng.random((n, 3))).astype(f32)              # 20 % of the points fall outside the bounds
+    p[:300] = lo
+    p[300:600] = hi
+    p[600:900, 0] = lo[0]
+    lam = (360 + 470 * rng.random((n, 4))).astype(f32)
+    ref = osc.medium(0, 0, p, lam)
+    out = np.zeros((n, 13), f32)
+    hk._lib.check(L.hk_test_medium(gpu_ctx.h, sh, 0, 0, n, _pf(hk, p), None, None, _pf(hk, lam), _pf(hk, out)), "hk_test_medium")
+    assert np.isfinite(out).all() and (ref[:, 4:8] > 0).mean() > 0.02
+    if which == "rgbgrid":
+        assert ulp_diff(out, ref).max() <= 2
+    else:
+        assert np.array_equal(out, ref), (which, np.abs(out - ref).max())
+    m = 50000
+    o = (lo - 0.5 * (hi - lo) + 2.0 * (hi - lo) * rng.random((m, 3))).astype(f32)
+    target = (lo + (hi - lo) * rng.random((m, 3))).astype(f32)
+    d = _unit(target - o)
+    d[:200] = np.array([0, 0, 1], f32)                                                          # axis-parallel rays (infinite DDA steps on two axes)
+    d[200:400] = np.array([1, 0, 0], f32)
+    tmax = np.where(rng.random(m) < 0.3, rng.random(m) * 3.0, np.inf).astype(f32)
+    refm = osc.medium(1, 0, o, lam[:m], d, tmax)
+    outm = np.zeros((m, 49), f32)
+    hk._lib.check(L.hk_test_medium(gpu_ctx.h, sh, 1, 0, m, _pf(hk, o), _pf(hk, d), _pf(hk, tmax), _pf(hk, lam[:m]), _pf(hk, outm)), "hk_test_medium")
+    assert np.array_equal(outm[:, 0], refm[:, 0]) and refm[:, 0].max() >= (1 if which == "homogeneous" else 4)
+    assert np.array_equal(outm, refm), (which, np.abs(outm - refm).max())
+    osc.close()
+
+
+# ---------------------------------------------------------------------------------------------------- a11: the lean traversal
+@pytest.mark.parametrize("which", ["cornell", "many_light_full"])
+def test_lean_traversal_parity(hk, oracle, gpu_ctx, which):
+    """The traversal the bench path runs — lane_ray_round (while-while rounds, straggler exit, per-lane refill) with the LDS stack
+    the BVH depth selects — against the oracle's closest hit: (t, prim, bary) bit-exact on 1 M rays; any-hit mode: occluded
+    <=> the oracle's closest hit exists inside t_max, and the reported hit is a genuine one (its t equals the oracle's t for
+    that primitive or lies behind the closest one).  `many_light_full` is the 10^6-triangle scene of BASELINE configs[4]: the only
+    BVH deeper than 16 levels, i.e. the only user of the 32-entry-stack instantiations."""
+    from hikari_jl_amd import scenes
+    if which == "cornell":
+        s, _, _ = scenes.cornell_box(64, 64)
+        lo, hi = np.array([-1.2, -0.2, -1.2]), np.array([1.2, 2.2, 1.2])
+    else:
+        s, _, _ = scenes.many_light_scene(64, 64)
+        lo, hi = np.array([-7.0, -7.0, -7.0]), np.array([7.0, 7.0, 7.0])
+    sh = hk.scene_handle(gpu_ctx, s)
+    L = hk._lib.lib()
+    depth = C.c_int32()
+    L.hk_scene_bvh_info(sh, None, None, C.byref(depth))
+    assert (depth.value > 16) == (which == "many_light_full"), depth.value
+    rng = np.random.default_rng(53)
+    n = 1_000_000
+    o = (lo + (hi - lo) * rng.random((n, 3))).astype(f32)
+    d = _unit(rng.normal(size=(n, 3)))
+    d[:1000] = np.array([0, -1, 0], f32)
+    d[1000:2000] = np.array([1, 0, 0], f32)
+    tmax = np.full(n, np.inf, f32)
+    tmax[::5] = (rng.random(len(tmax[::5])) * (2.0 if which == "cornell" else 6.0)).astype(f32)
+    tmax[7::97] = 0.0
+    osc = oracle.OracleScene(s)
+    rt, rp, ruv = osc.trace(o, d, tmax)
+    assert 0.2 < (rp >= 0).mean() < 0.999
+    args = [_pf(hk, o), _pf(hk, d), _pf(hk, tmax)]
+    gt, gp, guv = np.empty(n, f32), np.empty(n, np.int32), np.empty((n, 2), f32)
+    hk._lib.check(L.hk_test_trace_lean(gpu_ctx.h, sh, 0, n, *args, _pf(hk, gt), _pi(gp), _pf(hk, guv)), "hk_test_trace_lean")
+    assert np.array_equal(gp, rp) and np.array_equal(gt, rt) and np.array_equal(guv, ruv)
+    # the general-path traversal (traverse<>) on the same rays: the deep scene was never run through it either
+    hk._lib.check(L.hk_trace_closest(gpu_ctx.h, sh, n, *args, _pf(hk, gt), _pi(gp), _pf(hk, guv)), "hk_trace_closest")
+    assert np.array_equal(gp, rp) and np.array_equal(gt, rt) and np.array_equal(guv, ruv)
+    at, ap, auv = np.empty(n, f32), np.empty(n, np.int32), np.empty((n, 2), f32)
+    hk._lib.check(L.hk_test_trace_lean(gpu_ctx.h, sh, 1, n, *args, _pf(hk, at), _pi(ap), _pf(hk, auv)), "hk_test_trace_lean")
+    assert np.array_equal(ap >= 0, rp >= 0)                                                      # occlusion decision identical
+    occ = ap >= 0
+    assert (at[occ] >= rt[occ]).all() and (at[occ] < tmax[occ]).all()                            # a real hit, never in front of the closest one
+    same = occ & (ap == rp)
+    assert same.mean() > 0.2 and np.array_equal(at[same], rt[same])
+    osc.close()
+
+
+# ---------------------------------------------------------------------------------------------------- N4: material_coherence
+def test_material_coherence_is_result_neutral(hk):
+    """material_coherence = :none / :sorted / :per_type (multi-material-eval.jl:169-286, 516-549) only reorders material
+    evaluation in the reference; here the queue is always compacted per resolved kind.  All three values are accepted and give
+    bit-identical films and ray counts on a scene with seven material kinds incl. Mix."""
+    w = h = 40
+    s, film, cam = _mix_scene(hk, w=w, h=h)
+    frames, rays = [], []
+    for mode in ("none", "sorted", "per_type"):
+        f = hk.Film((w, h))
+        vp = hk.VolPath(max_depth=5, samples=4, material_coherence=mode)
+        assert vp.params.material_coherence == ("none", "sorted", "per_type").index(mode)
+        vp(s, f, cam)
+        frames.append(f.framebuffer.copy())
+        st = vp.stats()
+        rays.append((int(st.rays_closest), int(st.rays_shadow)))
+        vp.close()
+    assert np.array_equal(frames[0], frames[1]) and np.array_equal(frames[0], frames[2]) and rays[0] == rays[1] == rays[2]
+    assert frames[0].mean() > 0.01
+
+
+# ---------------------------------------------------------------------------------------------------- configs[3] / configs[4] at full size
+def test_full_size_many_light(hk, oracle):
+    """BASELINE configs[4] stand-in at FULL size (10^6 triangles, ~5 * 10^4 area lights, 1024^2, depth 8), one sample per pixel:
+    size-independent properties — finite, non-negative, deterministic, sharded == whole (sample-index sharding over 2 ranks
+    bit-equal in the accumulators up to fp32 summation order), filter weight sum constant — and oracle parity on a 96 x 96 crop
+    rendered through the SAME scene (the oracle builds its own BVH over the 10^6 triangles): strict frame tolerance."""
+    from hikari_jl_amd import scenes
+    s, film, cam = scenes.many_light_scene(1024, 1024)
+    assert s.desc.n_triangles >= 1_000_000 and s.desc.n_lights > 40_000
+    vp = hk.VolPath(max_depth=8, samples=2)
+    vp(s, film, cam)
+    a = film.framebuffer.copy()
+    acc = vp.read_accumulators(film)
+    st = vp.stats()
+    assert np.isfinite(a).all() and (a >= 0).all() and a.mean() > 1e-3
+    assert st.rays_closest >= 2 * 1024 * 1024 and st.rays_shadow > 1024 * 1024
+    wsum = acc[3 * 1024 * 1024:]
+    assert np.allclose(wsum, wsum[0], rtol=1e-2)
+    vp(s, film, cam)
+    assert np.array_equal(a, film.framebuffer)
+    parts = []
+    for rank in range(2):
+        f = hk.Film((1024, 1024))
+        v = hk.VolPath(max_depth=8, samples=2)
+        v._ensure(f)
+        v.clear()
+        v.render_samples(s, f, cam, 1, stride=2, first=rank + 1, readback=False)
+        parts.append(v.read_accumulators(f))
+        v.close()
+    assert np.allclose(parts[0] + parts[1], acc, rtol=1e-5, atol=1e-6)
+    vp.close()
+    w = h = 96
+    small = hk.Film((w, h))
+    cam_s = hk.PerspectiveCamera((0.0, -0.2, 9.0), (0.8, 0.3, 0.0), small, up=(0, 1, 0), fov=60.0)
+    g, r, st, ost = _frame_both(hk, oracle, s, cam_s, w, h, max_depth=4, samples=2)
+    rel_mse, frac = frame_metrics(g, r)
+    assert rel_mse <= 1e-3 and frac >= 0.99, (rel_mse, frac)
+    assert abs(int(st.rays_closest) - int(ost.rays_closest)) <= 0.002 * ost.rays_closest + 4
+
+
+def test_full_size_cloud(hk, oracle):
+    """BASELINE configs[3] stand-in at FULL size exactly as bench.py builds it (256 x 256 x 128 NanoVDB, sigma scale 155, 1024^2,
+    depth 32), one sample per pixel: finite, non-negative, deterministic (film and collision counter), plus the ABSORBING-only
+    variant of the same grid — no scattering, so no re-seeding from direction bits — against the oracle on a 64 x 64
+    frame: strict tolerance and an identical collision count (delta tracking consumes the same RNG stream on both sides)."""
+    from hikari_jl_amd import scenes
+    s, film, cam = scenes.cloud_scene(1024, 1024, "nanovdb", res=(256, 256, 128), sigma_scale=620.0 / 4)
+    vp = hk.VolPath(max_depth=32, samples=1)
+    vp(s, film, cam)
+    a = film.framebuffer.copy()
+    c1 = int(vp.stats().medium_collisions)
+    assert np.isfinite(a).all() and (a >= 0).all() and a.mean() > 0.01 and c1 > 10_000_000
+    vp(s, film, cam)
+    assert np.array_equal(a, film.framebuffer) and int(vp.stats().medium_collisions) == c1
+    vp.close()
+    from hikari_jl_amd import geometry as G
+    from hikari_jl_amd.media import NanoVDBMedium
+    dens = scenes.cloud_density((256, 256, 128)) * np.float32(620.0 / 4 / 10)      # optical depth of a few: the absorbing cloud stays see-through at its rim
+    lo, hi = (-0.6, 0.3, -0.6), (0.6, 1.5, 0.6)
+    med = NanoVDBMedium(dens, bounds=(lo, hi), sigma_a=hk.RGBSpectrum(0.9, 1.0, 1.2), sigma_s=hk.RGBSpectrum(0.0), g=0.0, majorant_res=(32, 32, 32))
+    s2 = hk.Scene()
+    s2.push(hk.AmbientLight(hk.RGBSpectrum(0.03, 0.07, 0.23)))
+    s2.push(hk.DirectionalLight(hk.RGBSpectrum(2.6, 2.5, 2.3), (-0.5826, -0.766, -0.2717)))
+    s2.push(G.rect3f((-4, -0.01, -4), (8, 0.01, 8)), hk.MatteMaterial(Kd=hk.RGBSpectrum(0.35, 0.33, 0.3)))
+    eps = 1e-3
+    s2.push(G.rect3f((lo[0] - eps, lo[1] - eps, lo[2] - eps), (1.2 + 2 * eps,) * 3),
+            hk.MediumInterface(hk.GlassMaterial(Kr=hk.RGBSpectrum(0.0), Kt=hk.RGBSpectrum(1.0), index=1.0), inside=med, outside=None))
+    s2.sync()
+    w = h = 64
+    f2 = hk.Film((w, h))
+    cam2 = hk.PerspectiveCamera((0.0, 1.0, -3.2), (0.0, 0.85, 0.0), f2, fov=35.0)
+    g, r, st, ost = _frame_both(hk, oracle, s2, cam2, w, h, max_depth=6, samples=8)
+    rel_mse, frac = frame_metrics(g, r)
+    assert rel_mse <= 1e-3 and frac >= 0.99, (rel_mse, frac)
+    assert int(st.medium_collisions) == int(ost.medium_collisions) and int(st.medium_collisions) > 10_000

@@ -22,7 +22,7 @@ namespace hk {
 void launch_camera(hipStream_t, int, const DPathState&, const DFrame&, const DTables&, const DFilter&, const DCamera&, const DSobol&, int);
 void launch_trace(hipStream_t, int, const DPathState&, const DScene&, const DTables&, const DFrame&, int, DStats*);
 void launch_shadow(hipStream_t, int, const DPathState&, const DScene&, const DTables&, const DFrame&, int, DStats*);
-void launch_escaped(hipStream_t, int, const DPathState&, const DScene&, const DTables&, int);
+void launch_escaped(hipStream_t, int, const DPathState&, const DScene&, const DTables&, const DFrame&, int);
 void launch_medium(hipStream_t, int, const DPathState&, const DScene&, const DTables&, const DFrame&, const DSobol&, int, DStats*);
 void launch_detect_camera_medium(hipStream_t, const DPathState&, const DScene&, float, float, float, DStats*);
 void launch_shade(hipStream_t, int, int, const DPathState&, const DScene&, const DTables&, const DFrame&, const DSobol&, int, int, DStats*);
@@ -1076,31 +1076,33 @@ int ensure_state(hk_integrator* I, int capacity, bool media) {
     s.n_waves = W;
     s.wave_cap = ((chunks + W - 1) / W) * 64;
     const size_t Q = (size_t)W * s.wave_cap;
-    HIP_TRY(alloc_arr(I, s.ray_o, P));
-    HIP_TRY(alloc_arr(I, s.ray_d, P));
-    HIP_TRY(alloc_arr(I, s.hit, P));
-    HIP_TRY(alloc_arr(I, s.mat_id, P));
-    HIP_TRY(alloc_arr(I, s.lambda, P));
+    for (int gidx = 0; gidx < 2; ++gidx) {   // two generations of path records in queue order (DPathGen)
+        DPathGen& g = s.gen[gidx];
+        HIP_TRY(alloc_arr(I, g.ray_o, Q));
+        HIP_TRY(alloc_arr(I, g.ray_d, Q));
+        HIP_TRY(alloc_arr(I, g.beta, Q));
+        HIP_TRY(alloc_arr(I, g.r_u, Q));
+        HIP_TRY(alloc_arr(I, g.r_l, Q));
+        HIP_TRY(alloc_arr(I, g.lambda, Q));
+        HIP_TRY(alloc_arr(I, g.meta, Q));
+    }
+    HIP_TRY(alloc_arr(I, s.hit, Q));
+    HIP_TRY(alloc_arr(I, s.mat_id, Q));
+    HIP_TRY(alloc_arr(I, s.lambda_s, P));
     HIP_TRY(alloc_arr(I, s.pdf, P));
-    HIP_TRY(alloc_arr(I, s.beta, P));
-    HIP_TRY(alloc_arr(I, s.r_u, P));
-    HIP_TRY(alloc_arr(I, s.r_l, P));
     HIP_TRY(alloc_arr(I, s.L, P));
-    HIP_TRY(alloc_arr(I, s.flags, P));
     HIP_TRY(alloc_arr(I, s.filter_w, P));
-    HIP_TRY(alloc_arr(I, s.sh_o, P));
-    HIP_TRY(alloc_arr(I, s.sh_d, P));
-    HIP_TRY(alloc_arr(I, s.sh_Ld, P));
-    HIP_TRY(alloc_arr(I, s.sh_ru, P));
-    HIP_TRY(alloc_arr(I, s.sh_rl, P));
-    HIP_TRY(alloc_arr(I, s.ray_q[0], Q));
-    HIP_TRY(alloc_arr(I, s.ray_q[1], Q));
-    HIP_TRY(alloc_arr(I, s.shadow_q, Q));
+    HIP_TRY(alloc_arr(I, s.sh_o, Q));
+    HIP_TRY(alloc_arr(I, s.sh_d, Q));
+    HIP_TRY(alloc_arr(I, s.sh_Ld, Q));
+    HIP_TRY(alloc_arr(I, s.sh_ru, Q));
+    HIP_TRY(alloc_arr(I, s.sh_rl, Q));
+    HIP_TRY(alloc_arr(I, s.sh_slot, Q));
     HIP_TRY(alloc_arr(I, s.escaped_q, Q));
     HIP_TRY(alloc_arr(I, s.medium_q, Q));
     HIP_TRY(alloc_arr(I, s.scatter_q, Q));
     s.ticket_rows = I->p.max_depth + 2;
-    HIP_TRY(alloc_arr(I, s.tickets, (size_t)s.ticket_rows * HK_TICKET_COLS));
+    HIP_TRY(alloc_arr(I, s.tickets, (size_t)s.ticket_rows * HK_TICKET_COLS * HK_TICKET_WAYS * HK_TICKET_STRIDE));
     HIP_TRY(alloc_arr(I, s.initial_medium, 1));
     HIP_TRY(hipMemset(s.initial_medium, 0xff, sizeof(int)));
     HIP_TRY(alloc_arr(I, s.mat_q, Q * HK_MAX_KINDS));
@@ -1169,14 +1171,14 @@ extern "C" int32_t hk_render(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_film*
     int S = I->p.samples_per_pass;
     if (S <= 0) {
         // auto: ~48 M paths in flight (64 spp of an 800x800 frame).  The chip holds 256 CUs x 16..32 waves x 64 lanes, and the
-        // deeper bounces of a pass only keep it busy when the pass starts with ~100 paths per lane; path state is ~400 B per
+        // deeper bounces of a pass only keep it busy when the pass starts with ~100 paths per lane; path state is ~440 B per
         // path, so this is < 20 GB of the 288 GB of HBM (halved until it fits in half of the free memory).
         S = (int)((48L << 20) / fr.n_pixels_padded);
         if (S < 1) S = 1;
         if (S > 64) S = 64;
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-            while (S > 1 && (size_t)S * fr.n_pixels_padded * 400 > free_b / 2) S /= 2;
+            while (S > 1 && (size_t)S * fr.n_pixels_padded * 440 > free_b / 2) S /= 2;
     }
     if (S > n_samples) S = n_samples;
     if ((long)S * fr.n_pixels_padded > 0x3fffffffL) return fail(HK_ERR_INVALID, "pass too large");
@@ -1187,6 +1189,7 @@ extern "C" int32_t hk_render(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_film*
     fr.regularize = I->p.regularize;
     fr.max_component_value = I->p.max_component_value;
     fr.count_nodes = c->count_nodes;
+    fr.implicit_ones = sc->d.n_media == 0 ? 1 : 0;
     DSobol sob = make_sobol(I->p, W, H);
     {   // pixel-digit table of the sampler: depends on film size, spp exponent and max_depth only
         const int rows = 4 + 5 * (I->p.max_depth + 1);
@@ -1244,7 +1247,7 @@ extern "C" int32_t hk_render(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_film*
             }
             return HK_OK;
         };
-        HIP_TRY(hipMemsetAsync(I->st.tickets, 0, (size_t)I->st.ticket_rows * HK_TICKET_COLS * sizeof(int), s));
+        HIP_TRY(hipMemsetAsync(I->st.tickets, 0, (size_t)I->st.ticket_rows * HK_TICKET_COLS * HK_TICKET_WAYS * HK_TICKET_STRIDE * sizeof(int), s));
         // queue sizes start every pass at zero: a depth at which no shade / scatter kernel runs (a triangle-free scene lit by an
         // environment map, say) must not see the ray / shadow counts an earlier render left behind
         HIP_TRY(hipMemsetAsync(I->st.counters, 0, (size_t)(I->st_depth + 2) * Q_COUNT * I->st.n_waves * sizeof(int), s));
@@ -1257,7 +1260,7 @@ extern "C" int32_t hk_render(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_film*
                 timed(3, [&] { hk::launch_medium(s, c->n_cu, I->st, sc->d, c->tables, fr, sob, depth, dstats); });
                 first_kind = 0;
             }
-            if (sc->d.has_escape_lights) timed(3, [&] { hk::launch_escaped(s, light_blocks, I->st, sc->d, c->tables, depth); });
+            if (sc->d.has_escape_lights) timed(3, [&] { hk::launch_escaped(s, light_blocks, I->st, sc->d, c->tables, fr, depth); });
             for (int kind = 0; kind < HK_MAX_KINDS; ++kind)
                 if (sc->kinds_mask & (1u << kind)) {
                     timed(2, [&] { hk::launch_shade(s, shade_blocks, kind, I->st, sc->d, c->tables, fr, sob, depth, first_kind, dstats); });

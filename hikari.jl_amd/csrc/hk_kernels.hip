@@ -22,41 +22,83 @@ namespace {
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
-// Wave-private segmented queues: wave w owns entries [w*wave_cap, (w+1)*wave_cap) of every queue and the
-// count word counts[..][w].  A path never leaves the wave that generated its camera ray, so compaction is pure
-// ballot/popcount arithmetic: no atomics, no cursors, deterministic order.  (A single global queue counter
-// serialises at ~88 atomics/us on this chip: 40 k wave-pushes per launch cost ~0.45 ms per kernel.)
+// Wave-private segmented queues: wave segment w owns entries [w*wave_cap, (w+1)*wave_cap) of every queue and the count word
+// counts[..][w].  A path never leaves the segment that generated its camera ray, so compaction is pure ballot/popcount
+// arithmetic: no atomics, no cursors, deterministic order.  (A single global queue counter serialises at ~88 atomics/us on this
+// chip: 40 k wave-pushes per launch cost ~0.45 ms per kernel.)
 struct WaveQ {
     uint32_t* base;
     int count;  // wave-uniform
 };
 __device__ __forceinline__ int global_wave() { return (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)); }
 __device__ __forceinline__ int physical_waves() { return (int)(gridDim.x * (blockDim.x >> 6)); }
-// A kernel is launched with as many physical waves as are resident for ITS register/LDS budget; each physical
-// wave walks the virtual wave segments v = p, p + P, p + 2P, ... so all kernels share the same W segments.
-// Segments are handed to physical waves through a ticket (one atomic per SEGMENT, a few thousand per launch) instead of
-// round-robin: residency differs per kernel (12 .. 28 waves per CU) and W is rarely a multiple of it, so a static stride leaves
-// a tail round with a fraction of the waves busy (shade at W = 16/CU, 12 resident: 12 % slower than at W = 24); in media
-// scenes the work per segment is wildly uneven on top (a tile that looks into a cloud vs one that sees the sky).
-__device__ __forceinline__ int next_segment(int* ticket) {
-    int v = 0;
-    if (lane_id() == 0) v = atomicAdd(ticket, 1);
-    return __builtin_amdgcn_readfirstlane(v);
+// A kernel is launched with as many physical waves as are resident for ITS register/LDS budget; each physical wave walks the
+// virtual wave segments.  Surface scenes walk them with a static stride (the grid is clamped to a divisor of W, see
+// clamp_blocks: residency differs per kernel — 12 .. 28 waves per CU — and a stride that does not divide W leaves a tail round
+// with a fraction of the waves busy).  Scenes with media, whose work per segment is wildly uneven (a tile that looks into a
+// cloud vs one that sees the sky), hand the segments out through tickets: +9 % on the cloud config, -16 % on the sky config.
+// One ticket = one atomic, and ONE WORD takes ~88 atomics/us on this chip: with a single ticket word a launch over W = 24 k
+// segments cost 0.3 ms even when every segment was empty — the launch floor of the deep bounces of the cloud config in round 1
+// (k_escaped / k_scatter / k_shade min 316 - 328 us).  Handing out several segments per ticket is no way out (4 per ticket made the
+// shadow walk 48 % slower: tail).  The ticket is therefore split HK_TICKET_WAYS = 64 ways: counter k, in its own 256-byte line
+// (so another memory channel), hands out the segments k, k + K, k + 2K, ...; a wave starts at counter (wave mod K) and moves on
+// to the next live counter when one is exhausted, never to come back.  Same one-segment granularity and the same stealing
+// behaviour, 1/K of the serialisation.
+struct SegTickets {
+    int* cnt;                   // HK_TICKET_WAYS (= 64: one per lane) counters, HK_TICKET_STRIDE ints apart
+    unsigned long long alive;   // counters not yet seen exhausted (wave-uniform)
+    int k0;                     // where this wave starts looking
+};
+__device__ __forceinline__ int seg_per_way(int n_segments, int k) { return (n_segments - k + HK_TICKET_WAYS - 1) / HK_TICKET_WAYS; }
+// all 64 counters are inspected with ONE parallel load (lane k reads counter k): an exhausted launch costs a wave one memory
+// round trip and no atomic at all
+__device__ __forceinline__ SegTickets seg_open(int* cnt, int n_segments) {
+    const int lane = lane_id();
+    const int v = __hip_atomic_load(cnt + lane * HK_TICKET_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return SegTickets{cnt, __ballot(v < seg_per_way(n_segments, lane)), global_wave() & (HK_TICKET_WAYS - 1)};
 }
-#define HK_FOR_EACH_WAVE_SEGMENT_DYNAMIC(gw, st, ticket) for (int gw = next_segment(ticket); gw < (st).n_waves; gw = next_segment(ticket))
-// Surface scenes walk the segments with a static stride (the grid is clamped to a divisor of W, see clamp_blocks); scenes with
-// media draw tickets in every kernel (st.dynamic_segments): measured on the cloud config +9 %, on the sky config -16 %.
-#define HK_FOR_EACH_WAVE_SEGMENT(gw, st, ticket)                                                             \
-    for (int gw = (st).dynamic_segments ? next_segment(ticket) : global_wave(); gw < (st).n_waves;           \
-         gw = (st).dynamic_segments ? next_segment(ticket) : gw + physical_waves())
+__device__ __forceinline__ int seg_next(SegTickets& it, int n_segments) {   // -> segment index, or n_segments when none is left
+    while (it.alive != 0ull) {
+        // first live counter at or after k0 (cyclically)
+        const unsigned long long rot = it.k0 == 0 ? it.alive : ((it.alive >> it.k0) | (it.alive << (64 - it.k0)));
+        const int k = (it.k0 + __ffsll((long long)rot) - 1) & (HK_TICKET_WAYS - 1);
+        const int per_k = seg_per_way(n_segments, k);
+        int t = 0;
+        if (lane_id() == 0) t = atomicAdd(it.cnt + k * HK_TICKET_STRIDE, 1);
+        t = __builtin_amdgcn_readfirstlane(t);
+        it.k0 = k;
+        if (t < per_k) return k + t * HK_TICKET_WAYS;
+        it.alive &= ~(1ull << k);   // counters only grow: exhausted once, exhausted for good
+    }
+    return n_segments;
+}
+#define HK_FOR_EACH_WAVE_SEGMENT_DYNAMIC(gw, st, ticket) \
+    for (SegTickets gw##_t = seg_open(ticket, (st).n_waves); gw##_t.cnt; gw##_t.cnt = nullptr) \
+        for (int gw = seg_next(gw##_t, (st).n_waves); gw < (st).n_waves; gw = seg_next(gw##_t, (st).n_waves))
+#define HK_FOR_EACH_WAVE_SEGMENT(gw, st, ticket)                                                              \
+    for (SegTickets gw##_t = (st).dynamic_segments ? seg_open(ticket, (st).n_waves) : SegTickets{ticket, 0ull, 0}; gw##_t.cnt; gw##_t.cnt = nullptr) \
+        for (int gw = (st).dynamic_segments ? seg_next(gw##_t, (st).n_waves) : global_wave(); gw < (st).n_waves; \
+             gw = (st).dynamic_segments ? seg_next(gw##_t, (st).n_waves) : gw + physical_waves())
 // ticket words: row = bounce depth (row max_depth + 1: camera / film), column = kernel
 enum { TK_TRACE = 0, TK_TRACK = 1, TK_SHADOW = 2, TK_ESCAPED = 3, TK_SCATTER = 4, TK_SHADE0 = 5, TK_CAMERA = 0, TK_FILM = 1 };
-__device__ __forceinline__ int* ticket_ptr(const DPathState& st, int row, int col) { return st.tickets + row * HK_TICKET_COLS + col; }
+__device__ __forceinline__ int* ticket_ptr(const DPathState& st, int row, int col) { return st.tickets + (size_t)(row * HK_TICKET_COLS + col) * (HK_TICKET_WAYS * HK_TICKET_STRIDE); }
 __device__ __forceinline__ WaveQ wq_open(uint32_t* q, const DPathState& st, int gw) { return WaveQ{q + (size_t)gw * st.wave_cap, 0}; }
 __device__ __forceinline__ void wq_push(WaveQ& q, uint32_t value, bool active) {
     unsigned long long mask = __ballot(active);
     if (active) q.base[q.count + __popcll(mask & ((1ull << lane_id()) - 1ull))] = value;
     q.count += __popcll(mask);
+}
+// beta / r_u / r_l of generation entry p; `ones`: the depth-0 records of a scene without media hold the constant 1 implicitly
+__device__ __forceinline__ S4 ld_throughput(const float4* arr, size_t p, bool ones) { return ones ? s4(1.0f) : ld4(&arr[p]); }
+// dense append of a whole record: the position the pushing lanes get inside the segment (count + rank among the pushing lanes)
+struct WavePos {
+    int count;  // wave-uniform: entries already in the segment
+};
+__device__ __forceinline__ int wp_push(WavePos& q, bool active) {   // returns this lane's position (valid where active)
+    unsigned long long mask = __ballot(active);
+    int pos = q.count + __popcll(mask & ((1ull << lane_id()) - 1ull));
+    q.count += __popcll(mask);
+    return pos;
 }
 __device__ __forceinline__ int* count_ptr(const DPathState& st, int depth, int q, int gw) { return st.counters + ((size_t)(depth * Q_COUNT + q) * st.n_waves + gw); }
 __device__ __forceinline__ void wq_close(const WaveQ& q, int* cnt) {
@@ -104,8 +146,10 @@ __global__ void __launch_bounds__(256) k_sobol_table(DSobol sob, DFrame fr, uint
 __global__ void __launch_bounds__(256) k_camera(DPathState st, DFrame fr, DTables T, DFilter flt, DCamera cam, DSobol sob, int initial_medium) {
     const int total = fr.n_pixels_padded * fr.samples_in_pass;
     const int n_chunks = total >> 6;
+    const DPathGen g0 = st.gen[0];
     HK_FOR_EACH_WAVE_SEGMENT(gw, st, ticket_ptr(st, st.ticket_rows - 1, TK_CAMERA)) {
-    WaveQ out = wq_open(st.ray_q[0], st, gw);
+    WavePos out{0};
+    const size_t seg = (size_t)gw * st.wave_cap;
     // wave w generates chunks w, w+W, w+2W, ... (8x8 pixel tiles interleaved across waves for load balance)
     for (int chunk = gw; chunk < n_chunks; chunk += st.n_waves) {
         int slot = chunk * 64 + lane_id();
@@ -113,6 +157,7 @@ __global__ void __launch_bounds__(256) k_camera(DPathState st, DFrame fr, DTable
         int px, py;
         bool active;
         slot_to_pixel(fr, slot - k * fr.n_pixels_padded, px, py, active);
+        const size_t p = seg + (size_t)wp_push(out, active);   // generation 0 holds the pass's paths in camera order, film padding squeezed out
         if (active) {
             int sample_idx = fr.first_sample + k * fr.sample_stride;
             int x = px + 1, y = py + 1;  // 1-based pixel coordinates (Q1)
@@ -136,20 +181,24 @@ __global__ void __launch_bounds__(256) k_camera(DPathState st, DFrame fr, DTable
             v3 ro, rd;
             float time;
             generate_ray(cam, pfilm, lens, time_u, ro, rd, time);
-            st.ray_o[slot] = make_float4(ro.x, ro.y, ro.z, INF_F);
-            st.ray_d[slot] = make_float4(rd.x, rd.y, rd.z, 0.0f);
-            st4(&st.lambda[slot], lambda);
+            g0.ray_o[p] = make_float4(ro.x, ro.y, ro.z, INF_F);
+            g0.ray_d[p] = make_float4(rd.x, rd.y, rd.z, 0.0f);
+            st4(&g0.lambda[p], lambda);
+            // beta = r_u = r_l = 1 at depth 0 (volpath.jl:190-197): in scenes without media nothing changes them before the first
+            // shading event, so they are not stored and the depth-0 readers substitute the constant (ld_throughput)
+            if (!fr.implicit_ones) {
+                st4(&g0.beta[p], s4(1.0f));
+                st4(&g0.r_u[p], s4(1.0f));
+                st4(&g0.r_l[p], s4(1.0f));
+            }
+            g0.meta[p] = make_uint2((uint32_t)(*st.initial_medium + 1) << 16, (uint32_t)slot);
+            st4(&st.lambda_s[slot], lambda);
             st4(&st.pdf[slot], pdf);
-            st4(&st.beta[slot], s4(1.0f));
-            st4(&st.r_u[slot], s4(1.0f));
-            st4(&st.r_l[slot], s4(1.0f));
             st4(&st.L[slot], s4(0.0f));
             st.filter_w[slot] = fw;
-            st.flags[slot] = (uint32_t)(*st.initial_medium + 1) << 16;
         }
-        wq_push(out, (uint32_t)slot, active);
     }
-    wq_close(out, count_ptr(st, 0, Q_RAY, gw));
+    if (lane_id() == 0) *count_ptr(st, 0, Q_RAY, gw) = out.count;
     }
 }
 
@@ -163,7 +212,8 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace(DPathState st, DScene 
     const int lane = lane_id();
     unsigned n_nodes = 0, n_tris = 0, n_casts = 0, n_hits = 0;
     HK_FOR_EACH_WAVE_SEGMENT(gw, st, ticket_ptr(st, depth, TK_TRACE)) {
-    const uint32_t* __restrict__ queue = st.ray_q[depth & 1] + (size_t)gw * st.wave_cap;
+    const DPathGen g = st.gen[depth & 1];
+    const uint32_t seg = (uint32_t)gw * (uint32_t)st.wave_cap;   // the segment's live rays are entries seg .. seg + n - 1 of this generation
     const int n = *count_ptr(st, depth, Q_RAY, gw);
     WaveQ q_escaped = wq_open(st.escaped_q, st, gw);
     WaveQ q_medium = wq_open(st.medium_q, st, gw);
@@ -173,14 +223,14 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace(DPathState st, DScene 
     for (int base = 0; base < n; base += 64) {
         int i = base + lane;
         bool active = i < n;
-        uint32_t slot = active ? queue[i] : 0u;
+        uint32_t slot = seg + (uint32_t)(active ? i : 0);   // generation index of the path
         int kind = -1;  // -1 none, -2 escaped, >= 0 material kind
         bool in_medium = false;
-        if (active && sc.n_media > 0 && (st.flags[slot] >> 16) != 0u) {
+        if (active && sc.n_media > 0 && (g.meta[slot].x >> 16) != 0u) {
             // ray travels inside a medium: one cast (no alpha test, intersection.jl:198-221), then delta tracking
             // (k_medium) decides whether the stored surface hit is ever reached
             in_medium = true;
-            float4 O = st.ray_o[slot], D = st.ray_d[slot];
+            float4 O = g.ray_o[slot], D = g.ray_d[slot];
             bool dummy;
             ++n_casts;
             HitRec h = traverse<0, COUNT>(sc, mk3(O.x, O.y, O.z), mk3(D.x, D.y, D.z), O.w, stack, lane, n_nodes, n_tris, dummy);
@@ -194,7 +244,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace(DPathState st, DScene 
         }
         wq_push(q_medium, slot, in_medium);
         if (active && !in_medium) {
-            float4 O = st.ray_o[slot], D = st.ray_d[slot];
+            float4 O = g.ray_o[slot], D = g.ray_d[slot];
             v3 ro = mk3(O.x, O.y, O.z), rd = mk3(D.x, D.y, D.z);
             float tmax = O.w;
             // alpha-test loop: alpha-killed surfaces are skipped without consuming depth (<= 16 casts)
@@ -234,7 +284,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace(DPathState st, DScene 
                 if (kind == HK_MAT_MIX) kind = HK_MAT_FALLBACK;
                 st.hit[slot] = make_float4(h.t, __int_as_float(h.prim), h.u, h.v);
                 st.mat_id[slot] = mat | (meta.arealight > 0 ? HK_MAT_EMISSIVE_BIT : 0);
-                if (it > 0) st.ray_o[slot] = make_float4(ro.x, ro.y, ro.z, INF_F);  // origin after alpha skips
+                if (it > 0) g.ray_o[slot] = make_float4(ro.x, ro.y, ro.z, INF_F);  // origin after alpha skips
                 break;
             }
         }
@@ -366,7 +416,8 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace_lean(DPathState st, DS
     const int DONE = (int)0x80000000;
     unsigned n_nodes = 0, n_tris = 0, n_casts = 0, n_hits = 0;
     HK_FOR_EACH_WAVE_SEGMENT(gw, st, ticket_ptr(st, depth, TK_TRACE)) {
-    const uint32_t* __restrict__ queue = st.ray_q[depth & 1] + (size_t)gw * st.wave_cap;
+    const DPathGen g = st.gen[depth & 1];
+    const uint32_t seg = (uint32_t)gw * (uint32_t)st.wave_cap;   // the rays of this segment: entries seg .. seg + n - 1, read in order (no index queue)
     const int n = *count_ptr(st, depth, Q_RAY, gw);
     WaveQ q_escaped = wq_open(st.escaped_q, st, gw);
     int kind_count[HK_MAX_KINDS];
@@ -421,8 +472,8 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace_lean(DPathState st, DS
             const int avail = n - cursor;
             const int rank = __popcll(want & lt_mask);
             if (state == LR_EMPTY && rank < avail) {
-                slot = queue[cursor + rank];
-                float4 O = st.ray_o[slot], D = st.ray_d[slot];
+                slot = seg + (uint32_t)(cursor + rank);
+                float4 O = g.ray_o[slot], D = g.ray_d[slot];
                 ++n_casts;
                 lane_ray_start(r, sc, mk3(O.x, O.y, O.z), mk3(D.x, D.y, D.z), O.w);
                 state = LR_ACTIVE;
@@ -478,6 +529,8 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
     unsigned n_coll = 0;
     HK_FOR_EACH_WAVE_SEGMENT_DYNAMIC(gw, st, ticket_ptr(st, depth, TK_TRACK)) {
         const uint32_t* __restrict__ queue = st.medium_q + (size_t)gw * st.wave_cap;
+        const DPathGen g = st.gen[depth & 1];   // throughput / scattering vertex are updated IN PLACE in the current generation
+        const bool ones = depth == 0 && fr.implicit_ones;
         const int n = *count_ptr(st, depth, Q_MEDIUM, gw);
         WaveQ q_escaped = wq_open(st.escaped_q, st, gw);
         q_escaped.count = *count_ptr(st, depth, Q_ESCAPED, gw);
@@ -487,7 +540,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
         for (int k = 0; k < HK_MAX_KINDS; ++k) kind_count[k] = *count_ptr(st, depth, Q_MAT0 + k, gw);
         int cursor = 0;     // wave-uniform: next unread entry of this wave's queue segment
         int state = TR_EMPTY;
-        uint32_t slot = 0;
+        uint32_t slot = 0, pslot = 0;   // generation index of the lane's path; its path slot (pixel-sample id: where L lives)
         v3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 1), cur_o = mk3(0, 0, 0);
         S4 lambda = s4(0.0f), beta = s4(0.0f), r_u = s4(0.0f), r_l = s4(0.0f), base_a = s4(0.0f), base_s = s4(0.0f), base_Le = s4(0.0f), sm = s4(0.0f);
         uint64_t rng = 0;
@@ -524,16 +577,18 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
                 const int rank = __popcll(want & lt_mask);
                 if (state == TR_EMPTY && rank < avail) {
                     slot = queue[cursor + rank];
-                    float4 O = st.ray_o[slot], D = st.ray_d[slot];
+                    float4 O = g.ray_o[slot], D = g.ray_d[slot];
                     ro = mk3(O.x, O.y, O.z);
                     rd = mk3(D.x, D.y, D.z);
                     const float t_max = st.hit[slot].x;
-                    medium_idx = (int)(st.flags[slot] >> 16) - 1;
+                    const uint2 meta = g.meta[slot];
+                    medium_idx = (int)(meta.x >> 16) - 1;
+                    pslot = meta.y;
                     const DMedium& med = sc.media[medium_idx];
-                    lambda = ld4(&st.lambda[slot]);
-                    beta = ld4(&st.beta[slot]);
-                    r_u = ld4(&st.r_u[slot]);
-                    r_l = ld4(&st.r_l[slot]);
+                    lambda = ld4(&g.lambda[slot]);
+                    beta = ld_throughput(g.beta, slot, ones);
+                    r_u = ld_throughput(g.r_u, slot, ones);
+                    r_l = ld_throughput(g.r_l, slot, ones);
                     base_a = eval_scaled(med.sigma_a, lambda);
                     base_s = eval_scaled(med.sigma_s, lambda);
                     if (HK_HAS_MEDIUM(MM, HK_MEDIUM_HOMOGENEOUS)) base_Le = eval_scaled(med.Le, lambda);
@@ -611,7 +666,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
                         float pr = sm0 * Tm.x;
                         if (pr > 1e-10f) {
                             S4 r_e = r_u * sm * Tm / pr;
-                            if (!is_black(r_e)) st4(&st.L[slot], ld4(&st.L[slot]) + beta * mp.sigma_a * Tm * mp.Le / (pr * average(r_e)));
+                            if (!is_black(r_e)) st4(&st.L[pslot], ld4(&st.L[pslot]) + beta * mp.sigma_a * Tm * mp.Le / (pr * average(r_e)));
                         }
                     }
                     float p_absorb = mp.sigma_a.x / sm0, p_scatter = mp.sigma_s.x / sm0;
@@ -627,9 +682,9 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
                                 beta = div4(beta * Tm * mp.sigma_s, pdf);
                                 r_u = div4(r_u * Tm * mp.sigma_s, pdf);
                             }
-                            st4(&st.beta[slot], beta);
-                            st4(&st.r_u[slot], r_u);
-                            st.ray_o[slot] = make_float4(p.x, p.y, p.z, INF_F);  // the scattering vertex: k_scatter continues from here
+                            st4(&g.beta[slot], beta);
+                            st4(&g.r_u[slot], r_u);
+                            g.ray_o[slot] = make_float4(p.x, p.y, p.z, INF_F);  // the scattering vertex: k_scatter continues from here
                             state = TR_SCATTER;
                         }
                     } else {
@@ -652,9 +707,9 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
                 state = TR_EMPTY;
                 if (!(is_black(beta) || is_black(r_u) || depth >= fr.max_depth)) {
                     // survived to t_max: hand the stored surface hit / the escape over with the updated throughput
-                    st4(&st.beta[slot], beta);
-                    st4(&st.r_u[slot], r_u);
-                    st4(&st.r_l[slot], r_l);
+                    st4(&g.beta[slot], beta);
+                    st4(&g.r_u[slot], r_u);
+                    st4(&g.r_l[slot], r_l);
                     float4 H = st.hit[slot];
                     const int prim = __float_as_int(H.y);
                     if (prim < 0)
@@ -694,25 +749,34 @@ __global__ void __launch_bounds__(256) k_scatter(DPathState st, DScene sc, DTabl
     HK_FOR_EACH_WAVE_SEGMENT(gw, st, ticket_ptr(st, depth, TK_SCATTER)) {
         const uint32_t* __restrict__ queue = st.scatter_q + (size_t)gw * st.wave_cap;
         const int n = *count_ptr(st, depth, Q_SCATTER, gw);
-        WaveQ q_shadow = wq_open(st.shadow_q, st, gw);
-        WaveQ q_next = wq_open(st.ray_q[(depth + 1) & 1], st, gw);
+        const DPathGen g = st.gen[depth & 1], gn = st.gen[(depth + 1) & 1];
+        const size_t seg = (size_t)gw * st.wave_cap;
+        WavePos q_shadow{0}, q_next{0};   // first writer of this depth's shadow records and of the next generation
         for (int base = 0; base < n; base += 64) {
             int i = base + lane_id();
             bool active = i < n;
             uint32_t slot = active ? queue[i] : 0u;
             bool push_shadow = false, push_ray = false;
+            // records of the two pushes (written after the wave-wide position is known)
+            float4 shO = make_float4(0, 0, 0, 0), shD = shO, nD = shO, O = shO;
+            S4 shLd = s4(0.0f), shRu = s4(0.0f), shRl = s4(0.0f), lambda = s4(0.0f), beta = s4(0.0f), r_u = s4(0.0f), n_rl = s4(0.0f);
+            uint32_t pslot = 0, nflags = 0;
             if (active) {
-                float4 O = st.ray_o[slot], D = st.ray_d[slot];
+                O = g.ray_o[slot];
+                const float4 D = g.ray_d[slot];
                 v3 sp = mk3(O.x, O.y, O.z), wo = mk3(-D.x, -D.y, -D.z);
-                const int medium_idx = (int)(st.flags[slot] >> 16) - 1;
+                const uint2 meta = g.meta[slot];
+                pslot = meta.y;
+                const int medium_idx = (int)(meta.x >> 16) - 1;
                 const float sg = sc.media[medium_idx].g;
-                S4 lambda = ld4(&st.lambda[slot]);
-                S4 beta = ld4(&st.beta[slot]), r_u = ld4(&st.r_u[slot]);
-                int k = (int)slot / fr.n_pixels_padded;
+                lambda = ld4(&g.lambda[slot]);
+                beta = ld4(&g.beta[slot]);
+                r_u = ld4(&g.r_u[slot]);
+                int k = (int)pslot / fr.n_pixels_padded;
                 int px, py;
                 bool inside;
-                slot_to_pixel(fr, (int)slot - k * fr.n_pixels_padded, px, py, inside);
-                SobolCtx sctx = sobol_ctx(sob, T.sobol, px + 1, py + 1, fr.first_sample + k * fr.sample_stride, (int)slot - k * fr.n_pixels_padded);
+                slot_to_pixel(fr, (int)pslot - k * fr.n_pixels_padded, px, py, inside);
+                SobolCtx sctx = sobol_ctx(sob, T.sobol, px + 1, py + 1, fr.first_sample + k * fr.sample_stride, (int)pslot - k * fr.n_pixels_padded);
                 const int base_dim = 6 + 7 * depth;
                 if (sc.n_lights > 0) {
                     float light_select = sobol_1d(sctx, base_dim + 1);
@@ -729,11 +793,11 @@ __global__ void __launch_bounds__(256) k_scatter(DPathState st, DScene sc, DTabl
                                 float light_pdf = ls.pdf * light_pmf;
                                 float phase_pdf = ls.is_delta ? 0.0f : phase_val;
                                 float tmx = ls.is_delta ? norm(ls.p_light - sp) - 0.001f : 1.0e6f;
-                                st.sh_o[slot] = make_float4(sp.x, sp.y, sp.z, tmx);
-                                st.sh_d[slot] = make_float4(ls.wi.x, ls.wi.y, ls.wi.z, __int_as_float(medium_idx));
-                                st4(&st.sh_Ld[slot], beta * phase_val * ls.Li);
-                                st4(&st.sh_ru[slot], r_u * phase_pdf);
-                                st4(&st.sh_rl[slot], r_u * light_pdf);
+                                shO = make_float4(sp.x, sp.y, sp.z, tmx);
+                                shD = make_float4(ls.wi.x, ls.wi.y, ls.wi.z, __int_as_float(medium_idx));
+                                shLd = beta * phase_val * ls.Li;
+                                shRu = r_u * phase_pdf;
+                                shRl = r_u * light_pdf;
                                 push_shadow = true;
                             }
                         }
@@ -745,18 +809,37 @@ __global__ void __launch_bounds__(256) k_scatter(DPathState st, DScene sc, DTabl
                     float ppdf;
                     v3 wi = sample_hg(sg, wo, u, ppdf);
                     if (ppdf > 0.0f) {
-                        st.ray_d[slot] = make_float4(wi.x, wi.y, wi.z, D.w);  // ray_o already holds the vertex, t_max = Inf
-                        st4(&st.r_l[slot], r_u / ppdf);
-                        st.flags[slot] = (uint32_t)new_depth | (1u << 9) | ((uint32_t)(medium_idx + 1) << 16);  // specular = false, any_non_specular = true
+                        nD = make_float4(wi.x, wi.y, wi.z, D.w);  // ray_o already holds the vertex, t_max = Inf
+                        n_rl = r_u / ppdf;
+                        nflags = (uint32_t)new_depth | (1u << 9) | ((uint32_t)(medium_idx + 1) << 16);  // specular = false, any_non_specular = true
                         push_ray = true;
                     }
                 }
             }
-            wq_push(q_shadow, slot, push_shadow);
-            wq_push(q_next, slot, push_ray);
+            const size_t ps = seg + (size_t)wp_push(q_shadow, push_shadow);
+            if (push_shadow) {
+                st.sh_o[ps] = shO;
+                st.sh_d[ps] = shD;
+                st4(&st.sh_Ld[ps], shLd);
+                st4(&st.sh_ru[ps], shRu);
+                st4(&st.sh_rl[ps], shRl);
+                st.sh_slot[ps] = pslot;
+            }
+            const size_t pn = seg + (size_t)wp_push(q_next, push_ray);
+            if (push_ray) {   // the continuing path's record, whole, at its position in the next generation
+                gn.ray_o[pn] = O;
+                gn.ray_d[pn] = nD;
+                st4(&gn.beta[pn], beta);
+                st4(&gn.r_u[pn], r_u);
+                st4(&gn.r_l[pn], n_rl);
+                st4(&gn.lambda[pn], lambda);
+                gn.meta[pn] = make_uint2(nflags, pslot);
+            }
         }
-        wq_close(q_shadow, count_ptr(st, depth, Q_SHADOW, gw));
-        wq_close(q_next, count_ptr(st, depth + 1, Q_RAY, gw));
+        if (lane_id() == 0) {
+            *count_ptr(st, depth, Q_SHADOW, gw) = q_shadow.count;
+            *count_ptr(st, depth + 1, Q_RAY, gw) = q_next.count;
+        }
     }
     stats += global_wave();
     wave_add(&stats->light_nodes, n_lnodes);
@@ -791,13 +874,15 @@ __global__ void __launch_bounds__(64) k_detect_camera_medium(DPathState st, DSce
 // ---------------------------------------------------------------------------------------------------
 // K7: escaped rays (intersection.jl:622-678; lights.jl:408-467).  MIS uses 1/num_lights (Q6).
 // ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_escaped(DPathState st, DScene sc, DTables T, int depth) {
+__global__ void __launch_bounds__(256) k_escaped(DPathState st, DScene sc, DTables T, int depth, int implicit_ones) {
     HK_FOR_EACH_WAVE_SEGMENT(gw, st, ticket_ptr(st, depth, TK_ESCAPED)) {
     const uint32_t* __restrict__ queue = st.escaped_q + (size_t)gw * st.wave_cap;
     const int n = *count_ptr(st, depth, Q_ESCAPED, gw);
+    const DPathGen g = st.gen[depth & 1];
+    const bool ones = depth == 0 && implicit_ones;
     for (int i = lane_id(); i < n; i += 64) {
         uint32_t slot = queue[i];
-        S4 lambda = ld4(&st.lambda[slot]);
+        S4 lambda = ld4(&g.lambda[slot]);
         S4 Le = s4(0.0f);
         v3 rd = mk3(0, 0, 1);
         bool have_dir = false;
@@ -806,7 +891,7 @@ __global__ void __launch_bounds__(256) k_escaped(DPathState st, DScene sc, DTabl
             if (l.kind == HK_LIGHT_AMBIENT) Le = Le + l.scale * light_spectrum(l, lambda);
             if (l.kind == HK_LIGHT_ENVIRONMENT) {  // bilinear env(dir) * scale, illuminant uplift (lights.jl:408-419)
                 if (!have_dir) {
-                    float4 D = st.ray_d[slot];
+                    float4 D = g.ray_d[slot];
                     rd = mk3(D.x, D.y, D.z);
                     have_dir = true;
                 }
@@ -814,13 +899,14 @@ __global__ void __launch_bounds__(256) k_escaped(DPathState st, DScene sc, DTabl
                 Le = Le + eval_illuminant(coef_illuminant(T, t.x * l.Le_rgba[0], t.y * l.Le_rgba[1], t.z * l.Le_rgba[2]), lambda);
             }
         }
-        S4 beta = ld4(&st.beta[slot]);
+        S4 beta = ld_throughput(g.beta, slot, ones);
         S4 contribution = beta * Le;
         if (is_black(contribution)) continue;
-        uint32_t fl = st.flags[slot];
+        const uint2 meta = g.meta[slot];
+        uint32_t fl = meta.x;
         int pdepth = (int)(fl & 0xff);
         bool specular = (fl >> 8) & 1u;
-        S4 r_u = ld4(&st.r_u[slot]);
+        S4 r_u = ld_throughput(g.r_u, slot, ones);
         S4 fin;
         if (pdepth == 0 || specular)
             fin = contribution / average(r_u);
@@ -832,11 +918,11 @@ __global__ void __launch_bounds__(256) k_escaped(DPathState st, DScene sc, DTabl
                     const DLight& l = sc.lights[li];
                     light_pdf = light_pdf + (l.kind == HK_LIGHT_ENVIRONMENT ? env_pdf_li(sc.envmaps[l.Le_tex], rd) : 0.0f);
                 }
-            S4 rl = ld4(&st.r_l[slot]) * choice * light_pdf;
+            S4 rl = ld_throughput(g.r_l, slot, ones) * choice * light_pdf;
             float den = average(r_u + rl);
             fin = den > 1e-10f ? contribution / den : contribution / average(r_u);
         }
-        st4(&st.L[slot], ld4(&st.L[slot]) + fin);
+        st4(&st.L[meta.y], ld4(&st.L[meta.y]) + fin);
     }
     }
 }
@@ -851,9 +937,9 @@ __global__ void __launch_bounds__(256) k_escaped(DPathState st, DScene sc, DTabl
 #define HK_SHADE_WAVES 3
 #endif
 // K8 for one flagged vertex (surface-eval.jl:147-220): L += beta * Le / MIS denominator.
-HKD void shade_emission(DPathState& st, const DScene& sc, const DTables& T, uint32_t slot, unsigned& n_lnodes) {
+HKD void shade_emission(DPathState& st, const DPathGen& g, bool ones, const DScene& sc, const DTables& T, uint32_t slot, unsigned& n_lnodes) {
     const float4 H = st.hit[slot];
-    const float4 O = st.ray_o[slot], D = st.ray_d[slot];
+    const float4 O = g.ray_o[slot], D = g.ray_d[slot];
     const v3 ro = mk3(O.x, O.y, O.z), rd = mk3(D.x, D.y, D.z);
     const float t_hit = H.x;
     const int prim = __float_as_int(H.y);
@@ -861,12 +947,13 @@ HKD void shade_emission(DPathState& st, const DScene& sc, const DTables& T, uint
     if (meta.arealight <= 0) return;
     const Surface sf = surface_at(sc, prim, H.z, H.w, ro, rd, t_hit);
     const v3 wo = -rd;
-    const S4 lambda = ld4(&st.lambda[slot]);
+    const S4 lambda = ld4(&g.lambda[slot]);
     const DLight& light = sc.lights[meta.arealight - 1];
     S4 Le = arealight_Le(sc, T, light, wo, sf.n, sf.uv, lambda);
     if (is_black(Le)) return;
-    const S4 beta = ld4(&st.beta[slot]), r_u = ld4(&st.r_u[slot]), r_l = ld4(&st.r_l[slot]);
-    const uint32_t fl = st.flags[slot];
+    const S4 beta = ld_throughput(g.beta, slot, ones), r_u = ld_throughput(g.r_u, slot, ones), r_l = ld_throughput(g.r_l, slot, ones);
+    const uint2 pmeta = g.meta[slot];
+    const uint32_t fl = pmeta.x;
     const int pdepth = (int)(fl & 0xff);
     const bool specular_bounce = (fl >> 8) & 1u;
     S4 contribution = beta * Le;
@@ -882,7 +969,7 @@ HKD void shade_emission(DPathState& st, const DScene& sc, const DTables& T, uint
         float den = average(r_u + rl);
         fin = den > 1e-10f ? contribution / den : contribution / average(r_u);
     }
-    st4(&st.L[slot], ld4(&st.L[slot]) + fin);
+    st4(&st.L[pmeta.y], ld4(&st.L[pmeta.y]) + fin);
 }
 
 template <int KIND>
@@ -900,18 +987,19 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
     HK_FOR_EACH_WAVE_SEGMENT(gw, st, ticket_ptr(st, depth, TK_SHADE0 + KIND)) {
     const uint32_t* __restrict__ queue = st.mat_q + ((size_t)KIND * st.n_waves + gw) * st.wave_cap;
     const int n = *count_ptr(st, depth, Q_MAT0 + KIND, gw);
-    // several kinds append to the same shadow / next-ray segments: continue from the counts left by the kinds before
-    WaveQ q_shadow = wq_open(st.shadow_q, st, gw);
-    WaveQ q_next = wq_open(st.ray_q[(depth + 1) & 1], st, gw);
+    const DPathGen g = st.gen[depth & 1], gn = st.gen[(depth + 1) & 1];
+    const size_t seg = (size_t)gw * st.wave_cap;
+    const bool ones = depth == 0 && fr.implicit_ones;
+    // several kinds append to the same shadow-record / next-generation segments: continue from the counts left by the kinds before
+    WavePos q_shadow{0}, q_next{0};
     if (!first_kind) {
         q_shadow.count = *count_ptr(st, depth, Q_SHADOW, gw);
         q_next.count = *count_ptr(st, depth + 1, Q_RAY, gw);
     }
     // ---- K8 first, densely: emission from area-light hits, MIS against the light-BVH pmf (surface-eval.jl:147-220).  The trace
-    //      kernels flag such hits in mat_id; their slots are gathered in a wave-private LDS list and handled 64 at a time, BEFORE
-    //      the main pass overwrites the path state.  Done inline in the main pass, a wave walks the light BVH (bvh_pmf, ~2 log2 n
-    //      node evaluations) whenever ANY of its 64 vertices sits on an emitter: with 5 % emissive faces that is 96 % of the
-    //      waves at 5 % lane utilisation. ----
+    //      kernels flag such hits in mat_id; their entries are gathered in a wave-private LDS list and handled 64 at a time.  Done
+    //      inline in the main pass, a wave walks the light BVH (bvh_pmf, ~2 log2 n node evaluations) whenever ANY of its 64
+    //      vertices sits on an emitter: with 5 % emissive faces that is 96 % of the waves at 5 % lane utilisation. ----
     {
         uint32_t* elist = emit_list + (threadIdx.x >> 6) * 128;
         int n_emit = 0;
@@ -927,7 +1015,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             const int take = n_emit < 64 ? n_emit : 64;
-            if (lane < take) shade_emission(st, sc, T, elist[lane], n_lnodes);
+            if (lane < take) shade_emission(st, g, ones, sc, T, elist[lane], n_lnodes);
             const int rest = n_emit - take;
             const uint32_t moved = lane < rest ? elist[64 + lane] : 0u;
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -938,41 +1026,53 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
     for (int base = 0; base < n; base += 64) {
         int i = base + lane;
         bool active = i < n;
-        uint32_t slot = active ? queue[i] : 0u;
+        uint32_t slot = active ? queue[i] : 0u;   // generation index of the path (the kind queue is a sorted subset of the segment)
         bool push_shadow = false, push_ray = false;
+        // state shared by the two halves of the vertex (NEE, then BSDF sampling): loaded once
+        float4 H = make_float4(0, 0, 0, 0);
+        Surface sf;
+        v3 wo = mk3(0, 0, 1);
+        DTriMeta meta{0u, 0u, 0u};
+        S4 lambda = s4(0.0f), beta = s4(0.0f), r_u = s4(0.0f);
+        uint32_t fl = 0, pslot = 0;
+        int pdepth = 0, medium = -1;
+        bool any_non_specular = false;
+        SobolCtx sctx;
+        // every path in the depth-d queues has work.depth == d, so the dimension (and its scramble hashes) is
+        // wave-uniform: derived from the kernel argument it stays in scalar registers
+        const int base_dim = 6 + 7 * depth;
+        float4 shO = make_float4(0, 0, 0, 0), shD = shO;
+        S4 shLd = s4(0.0f), shRu = s4(0.0f), shRl = s4(0.0f);
         if (active) {
             ++n_vertices;
-            float4 H = st.hit[slot];
-            float4 O = st.ray_o[slot], D = st.ray_d[slot];
+            H = st.hit[slot];
+            float4 O = g.ray_o[slot], D = g.ray_d[slot];
             v3 ro = mk3(O.x, O.y, O.z), rd = mk3(D.x, D.y, D.z);
             float t_hit = H.x;
             int prim = __float_as_int(H.y);
-            Surface sf = surface_at(sc, prim, H.z, H.w, ro, rd, t_hit);
-            v3 wo = -rd;
-            DTriMeta meta = sc.meta[prim];
-            DMediumInterface mi = sc.mis[meta.mi];
-            const DMaterial& mat = sc.materials[st.mat_id[slot] & ~HK_MAT_EMISSIVE_BIT];
-            S4 lambda = ld4(&st.lambda[slot]);
-            S4 beta = ld4(&st.beta[slot]);
-            S4 r_u = ld4(&st.r_u[slot]);
-            S4 r_l = ld4(&st.r_l[slot]);
-            uint32_t fl = st.flags[slot];
-            int pdepth = (int)(fl & 0xff);
-            bool specular_bounce = (fl >> 8) & 1u, any_non_specular = (fl >> 9) & 1u;
-            int medium = (int)(fl >> 16) - 1;
+            sf = surface_at(sc, prim, H.z, H.w, ro, rd, t_hit);
+            wo = -rd;
+            meta = sc.meta[prim];
+            lambda = ld4(&g.lambda[slot]);
+            beta = ld_throughput(g.beta, slot, ones);
+            r_u = ld_throughput(g.r_u, slot, ones);
+            const uint2 pmeta = g.meta[slot];
+            fl = pmeta.x;
+            pslot = pmeta.y;
+            pdepth = (int)(fl & 0xff);
+            any_non_specular = (fl >> 9) & 1u;
+            medium = (int)(fl >> 16) - 1;
 
             // pixel coordinates for the Sobol dimensions of this bounce (volpath.jl:252-262, Q19)
-            int k = (int)slot / fr.n_pixels_padded;
+            int k = (int)pslot / fr.n_pixels_padded;
             int px, py;
             bool inside;
-            slot_to_pixel(fr, (int)slot - k * fr.n_pixels_padded, px, py, inside);
-            SobolCtx sctx = sobol_ctx(sob, T.sobol, px + 1, py + 1, fr.first_sample + k * fr.sample_stride, (int)slot - k * fr.n_pixels_padded);
-            // every path in the depth-d queues has work.depth == d, so the dimension (and its scramble hashes) is
-            // wave-uniform: derived from the kernel argument it stays in scalar registers
-            const int base_dim = 6 + 7 * depth;
+            slot_to_pixel(fr, (int)pslot - k * fr.n_pixels_padded, px, py, inside);
+            sctx = sobol_ctx(sob, T.sobol, px + 1, py + 1, fr.first_sample + k * fr.sample_stride, (int)pslot - k * fr.n_pixels_padded);
 
             // ---- K9: next-event estimation through the light BVH ----
             if (sc.n_lights > 0) {
+                const DMaterial& mat = sc.materials[st.mat_id[slot] & ~HK_MAT_EMISSIVE_BIT];
                 float light_select = sobol_1d(sctx, base_dim + 1);
                 float light_pmf;
                 int light_idx = bvh_sample_light(sc, sf.pi, sf.ns, light_select, light_pmf, n_lnodes);
@@ -994,21 +1094,39 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
                                 v3 tl = ls.p_light - so;
                                 float tmax = sqrtf(dot(tl, tl)) - 1e-3f;
                                 float nbp = ls.is_delta ? 0.0f : bsdf_pdf;
-                                st.sh_o[slot] = make_float4(so.x, so.y, so.z, tmax);
-                                st.sh_d[slot] = make_float4(ls.wi.x, ls.wi.y, ls.wi.z, __int_as_float(medium));
-                                st4(&st.sh_Ld[slot], Ld);
-                                st4(&st.sh_ru[slot], r_u * nbp);
-                                st4(&st.sh_rl[slot], (r_u * ls.pdf) * light_pmf);
+                                shO = make_float4(so.x, so.y, so.z, tmax);
+                                shD = make_float4(ls.wi.x, ls.wi.y, ls.wi.z, __int_as_float(medium));
+                                shLd = Ld;
+                                shRu = r_u * nbp;
+                                shRl = (r_u * ls.pdf) * light_pmf;
                                 push_shadow = true;
                             }
                         }
                     }
                 }
             }
-
-            // ---- K11: BSDF sampling, throughput, Russian roulette, continuation ray ----
+        }
+        // the shadow record goes to its position in the segment's shadow queue: k_shadow streams the records
+        {
+            const size_t ps = seg + (size_t)wp_push(q_shadow, push_shadow);
+            if (push_shadow) {
+                st.sh_o[ps] = shO;
+                st.sh_d[ps] = shD;
+                st4(&st.sh_Ld[ps], shLd);
+                st4(&st.sh_ru[ps], shRu);
+                st4(&st.sh_rl[ps], shRl);
+                st.sh_slot[ps] = pslot;
+            }
+        }
+        // ---- K11: BSDF sampling, throughput, Russian roulette, continuation ray ----
+        float4 nO = make_float4(0, 0, 0, 0), nD = nO;
+        S4 nb = s4(0.0f), nrl = s4(0.0f);
+        uint32_t nflags = 0;
+        if (active) {
             int new_depth = pdepth + 1;
             if (new_depth < fr.max_depth) {
+                const DMaterial& mat = sc.materials[st.mat_id[slot] & ~HK_MAT_EMISSIVE_BIT];
+                const DMediumInterface mi = sc.mis[meta.mi];
                 // the 1-D component sample is read only by BSDFs that choose a lobe (Glass and the layered kinds)
                 float uc = (KIND == HK_MAT_GLASS || KIND > HK_MAT_CONDUCTOR) && KIND != HK_MAT_FALLBACK ? sobol_1d(sctx, base_dim + 4) : 0.0f;
                 v2 u = (KIND == HK_MAT_MIRROR || KIND == HK_MAT_GLASS || KIND == HK_MAT_THIN_DIELECTRIC) ? mk2(0.0f, 0.0f) : sobol_2d(sctx, base_dim + 6);
@@ -1016,8 +1134,8 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
                 BSDFSample s = sample_bsdf<KIND>(sc, T, mat, wo, sf.ns, TexCtx(sf.uv, meta.prim_index, H.z, H.w), lambda, u, uc, regularize);
                 if (s.pdf > 0.0f && !is_black(s.f)) {
                     float ct = fabsf(dot(s.wi, sf.ns));
-                    S4 nb = s.is_specular ? beta * s.f : beta * s.f * ct / s.pdf;
-                    S4 nrl = s.is_specular ? r_u : r_u / s.pdf;
+                    nb = s.is_specular ? beta * s.f : beta * s.f * ct / s.pdf;
+                    nrl = s.is_specular ? r_u : r_u / s.pdf;
                     bool cont = true;
                     if (new_depth > 3) {  // russian_roulette_spectral, min_depth fixed at 3 (Q7)
                         float rr = sobol_1d(sctx, base_dim + 7);
@@ -1031,22 +1149,32 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
                         int new_medium = (mi.inside != mi.outside) ? (dot(s.wi, sf.n) > 0.0f ? mi.outside : mi.inside) : medium;
                         v3 off = dot(s.wi, sf.n) > 0.0f ? sf.n : -sf.n;
                         v3 no = sf.pi + off * 0.0001f;
-                        st.ray_o[slot] = make_float4(no.x, no.y, no.z, INF_F);
-                        st.ray_d[slot] = make_float4(s.wi.x, s.wi.y, s.wi.z, 0.0f);  // time = 0 (Q17)
-                        st4(&st.beta[slot], nb);
-                        st4(&st.r_l[slot], nrl);  // r_u unchanged
+                        nO = make_float4(no.x, no.y, no.z, INF_F);
+                        nD = make_float4(s.wi.x, s.wi.y, s.wi.z, 0.0f);  // time = 0 (Q17)
                         bool ans = any_non_specular || !s.is_specular;
-                        st.flags[slot] = (uint32_t)new_depth | ((s.is_specular ? 1u : 0u) << 8) | ((ans ? 1u : 0u) << 9) | ((uint32_t)(new_medium + 1) << 16);
+                        nflags = (uint32_t)new_depth | ((s.is_specular ? 1u : 0u) << 8) | ((ans ? 1u : 0u) << 9) | ((uint32_t)(new_medium + 1) << 16);
                         push_ray = true;
                     }
                 }
             }
         }
-        wq_push(q_shadow, slot, push_shadow);
-        wq_push(q_next, slot, push_ray);
+        {   // the continuing path's record, whole, at its position in the next generation (r_u is unchanged by a surface event)
+            const size_t pn = seg + (size_t)wp_push(q_next, push_ray);
+            if (push_ray) {
+                gn.ray_o[pn] = nO;
+                gn.ray_d[pn] = nD;
+                st4(&gn.beta[pn], nb);
+                st4(&gn.r_u[pn], r_u);
+                st4(&gn.r_l[pn], nrl);
+                st4(&gn.lambda[pn], lambda);
+                gn.meta[pn] = make_uint2(nflags, pslot);
+            }
+        }
     }
-    wq_close(q_shadow, count_ptr(st, depth, Q_SHADOW, gw));
-    wq_close(q_next, count_ptr(st, depth + 1, Q_RAY, gw));
+    if (lane == 0) {
+        *count_ptr(st, depth, Q_SHADOW, gw) = q_shadow.count;
+        *count_ptr(st, depth + 1, Q_RAY, gw) = q_next.count;
+    }
     }
     stats += global_wave();
     wave_add(&stats->vertices, n_vertices);
@@ -1061,13 +1189,17 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
 //                  wave-private refill: a lane alternates between "needs a cast" and "tracking steps", casts are done
 //                  together for all lanes that need one, and finished lanes pull the next shadow ray of the wave's queue.
 // ---------------------------------------------------------------------------------------------------
-HKD void shadow_contribute(DPathState& st, uint32_t slot, S4 T_ray, S4 tr_u, S4 tr_l) {
+// rec: index of the shadow record (segment * wave_cap + position in the segment's shadow queue)
+HKD void shadow_contribute(DPathState& st, uint32_t rec, S4 T_ray, S4 tr_u, S4 tr_l) {
     if (is_black(T_ray)) return;
-    S4 mis = ld4(&st.sh_ru[slot]) * tr_u + ld4(&st.sh_rl[slot]) * tr_l;
+    S4 mis = ld4(&st.sh_ru[rec]) * tr_u + ld4(&st.sh_rl[rec]) * tr_l;
     float den = average(mis);
     if (den > 1e-10f) {
-        S4 fin = ld4(&st.sh_Ld[slot]) * T_ray / den;
-        if (!is_black(fin)) st4(&st.L[slot], ld4(&st.L[slot]) + fin);
+        S4 fin = ld4(&st.sh_Ld[rec]) * T_ray / den;
+        if (!is_black(fin)) {
+            const uint32_t pslot = st.sh_slot[rec];
+            st4(&st.L[pslot], ld4(&st.L[pslot]) + fin);
+        }
     }
 }
 
@@ -1080,7 +1212,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_shadow(DPathState st, DScene
     const int DONE = (int)0x80000000;
     unsigned n_nodes = 0, n_tris = 0, n_casts = 0, n_hits = 0;
     HK_FOR_EACH_WAVE_SEGMENT(gw, st, ticket_ptr(st, depth, TK_SHADOW)) {
-    const uint32_t* __restrict__ queue = st.shadow_q + (size_t)gw * st.wave_cap;
+    const uint32_t seg = (uint32_t)gw * (uint32_t)st.wave_cap;   // the segment's shadow records: entries seg .. seg + n - 1, streamed in order
     const int n = *count_ptr(st, depth, Q_SHADOW, gw);
     int cursor = 0;
     bool have = false;
@@ -1101,7 +1233,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_shadow(DPathState st, DScene
             const int avail = n - cursor;
             const int rank = __popcll(want & lt_mask);
             if (!have && rank < avail) {
-                slot = queue[cursor + rank];
+                slot = seg + (uint32_t)(cursor + rank);
                 float4 O = st.sh_o[slot], D = st.sh_d[slot];
                 if (O.w >= 1e-6f) {   // a degenerate shadow ray is simply not visible
                     ++n_casts;
@@ -1141,7 +1273,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     unsigned n_nodes = 0, n_tris = 0, n_casts = 0, n_hits = 0, n_coll = 0;
     HK_FOR_EACH_WAVE_SEGMENT_DYNAMIC(gw, st, ticket_ptr(st, depth, TK_SHADOW)) {
-    const uint32_t* __restrict__ queue = st.shadow_q + (size_t)gw * st.wave_cap;
+    const uint32_t rec0 = (uint32_t)gw * (uint32_t)st.wave_cap;   // the segment's shadow records: entries rec0 .. rec0 + n - 1
     const int n = *count_ptr(st, depth, Q_SHADOW, gw);
     int cursor = 0;
     int state = SH_EMPTY;
@@ -1167,7 +1299,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
             const int avail = n - cursor;
             const int rank = __popcll(want & lt_mask);
             if (state == SH_EMPTY && rank < avail) {
-                slot = queue[cursor + rank];
+                slot = rec0 + (uint32_t)(cursor + rank);
                 float4 O = st.sh_o[slot], D = st.sh_d[slot];
                 ro = mk3(O.x, O.y, O.z);
                 dir = mk3(D.x, D.y, D.z);
@@ -1176,7 +1308,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
                 T_ray = s4(1.0f);
                 tr_u = s4(1.0f);
                 tr_l = s4(1.0f);
-                if (MM != 0) lambda = ld4(&st.lambda[slot]);
+                if (MM != 0) lambda = ld4(&st.lambda_s[st.sh_slot[slot]]);
                 seg = 0;
                 state = t_remaining < 1e-6f ? SH_EMPTY : SH_CAST;  // a degenerate ray is simply not visible
             }
@@ -1398,7 +1530,7 @@ __global__ void __launch_bounds__(256) k_film(DPathState st, DFrame fr, DTables 
         ACC r = accum[3 * p], g = accum[3 * p + 1], b = accum[3 * p + 2], w = accum[3 * N + p];
         for (int k = 0; k < fr.samples_in_pass; ++k) {
             size_t slot = (size_t)k * n + tid;
-            v3 rgb = spectral_to_rgb_clamped(T, ld4(&st.L[slot]), ld4(&st.lambda[slot]), ld4(&st.pdf[slot]), fr.max_component_value);
+            v3 rgb = spectral_to_rgb_clamped(T, ld4(&st.L[slot]), ld4(&st.lambda_s[slot]), ld4(&st.pdf[slot]), fr.max_component_value);
             float fw = st.filter_w[slot];
             r += (ACC)(fw * rgb.x);
             g += (ACC)(fw * rgb.y);
@@ -1885,9 +2017,9 @@ void launch_medium(hipStream_t s, int n_cu, const DPathState& st, const DScene& 
 void launch_detect_camera_medium(hipStream_t s, const DPathState& st, const DScene& sc, float x, float y, float z, DStats* stats) {
     hipLaunchKernelGGL(k_detect_camera_medium, dim3(1), dim3(64), 0, s, st, sc, x, y, z, stats);
 }
-void launch_escaped(hipStream_t s, int n_cu, const DPathState& st, const DScene& sc, const DTables& T, int depth) {
+void launch_escaped(hipStream_t s, int n_cu, const DPathState& st, const DScene& sc, const DTables& T, const DFrame& fr, int depth) {
     const int blocks = cached_blocks<k_escaped>(256, n_cu, 8);
-    hipLaunchKernelGGL(k_escaped, dim3(clamp_blocks(blocks, st)), dim3(256), 0, s, st, sc, T, depth);
+    hipLaunchKernelGGL(k_escaped, dim3(clamp_blocks(blocks, st)), dim3(256), 0, s, st, sc, T, depth, fr.implicit_ones);
 }
 void launch_shade(hipStream_t s, int n_cu, int kind, const DPathState& st, const DScene& sc, const DTables& T, const DFrame& fr, const DSobol& sob, int depth, int first_kind, DStats* stats) {
 #define HK_SHADE_CASE(K)                                                                                                          \

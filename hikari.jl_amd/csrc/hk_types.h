@@ -4,13 +4,16 @@
 //   BVH2 nodes        64 B  = 4 x float4 : both child AABBs + 2 child refs        (one 64-B line per visit)
 //   leaf triangles    48 B  = 3 x float4 : v0|prim id, e1|flags, e2               (leaf order)
 //   shading triangles 36 B positions + 36 B normals + 24 B uvs + 12 B meta        (original prim order)
-//   path state        SoA float4 arrays indexed by path slot (pixel x sample-in-pass)
-//   queues            uint32 path slots + device-side counters (no host readback inside a frame)
+//   path state        SoA float4 arrays in QUEUE ORDER, two generations ping-ponged by depth (DPathGen); film inputs per path slot
+//   queues            the generation arrays are the ray queue; per-kind / escaped / medium queues hold uint32 generation indices;
+//                     shadow records are stored in shadow-queue order; device-side counters (no host readback inside a frame)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #define HK_TICKET_COLS 16       // kernels per bounce that draw segment tickets (5 + HK_MAX_KINDS)
+#define HK_TICKET_WAYS 64       // counters one ticket is split into: one per lane of a wave
+#define HK_TICKET_STRIDE 64     // ints between two counters of a ticket: one 256-byte line each
 #define HK_MAX_KINDS 11          // HK_MAT_* count (Mix is resolved before queueing)
 #ifndef HK_LDS_STACK
 #define HK_LDS_STACK 32          // per-lane traversal stack entries kept in LDS (builder bounds the depth)
@@ -206,36 +209,48 @@ struct DSobol {
 // queue ids inside one depth's counter block
 enum { Q_RAY = 0, Q_SHADOW = 1, Q_ESCAPED = 2, Q_MEDIUM = 3, Q_SCATTER = 4, Q_MAT0 = 5, Q_COUNT = Q_MAT0 + HK_MAX_KINDS };
 
-struct DPathState {
-    int capacity;          // path slots
-    int n_waves;           // W: every queue is split into W wave-private segments
-    int wave_cap;          // entries per wave segment (multiple of 64); W * wave_cap >= capacity
+// One generation of live-path records IN QUEUE ORDER.  Entry p = segment * wave_cap + position: the paths of wave segment `gw`
+// that are alive at depth d occupy the dense prefix [gw * wave_cap, gw * wave_cap + count) of gen[d & 1].  Every kernel that
+// continues a path (shade, scatter) writes the whole record at the path's position in the NEXT generation, so a bounce reads and
+// writes contiguous memory however few of the pass's paths are still alive (round 1 indexed these arrays by the fixed path slot:
+// deep bounces then used a fraction of every 128-byte line — 1.8x the touched bytes in k_shade, 2.8x in k_shadow).
+struct DPathGen {
     float4* ray_o;         // o.xyz, t_max
     float4* ray_d;         // d.xyz, time
-    float4* hit;           // t, prim(bits), u, v
-    int* mat_id;           // resolved material index of the hit
-    float4* lambda;
-    float4* pdf;
     float4* beta;
     float4* r_u;
     float4* r_l;
+    float4* lambda;
+    uint2* meta;           // x = flags: depth(8) | specular(1)<<8 | any_non_specular(1)<<9 | (medium+1)<<16;  y = path slot
+};
+
+struct DPathState {
+    int capacity;          // path slots (pixel x sample-in-pass)
+    int n_waves;           // W: every queue is split into W wave-private segments
+    int wave_cap;          // entries per wave segment (multiple of 64); W * wave_cap >= capacity
+    DPathGen gen[2];       // gen[depth & 1]: the ray queue of that depth IS this array (no index queue)
+    float4* hit;           // per entry of the current generation: t, prim(bits), u, v
+    int* mat_id;           // per entry of the current generation: resolved material index of the hit (| HK_MAT_EMISSIVE_BIT)
+    // per path slot: written once by the camera kernel, accumulated into (L) along the path, read by the film kernel
+    float4* lambda_s;
+    float4* pdf;
     float4* L;
-    uint32_t* flags;       // depth(8) | specular(1)<<8 | any_non_specular(1)<<9 | (medium+1)<<16
     float* filter_w;
+    // shadow records, dense in shadow-queue order (entry = segment * wave_cap + position in the segment's shadow queue)
     float4* sh_o;          // shadow ray: o.xyz, t_max
     float4* sh_d;          // d.xyz, medium (bits)
     float4* sh_Ld;
     float4* sh_ru;
     float4* sh_rl;
-    uint32_t* ray_q[2];    // ping-pong ray queues (path slots)
-    uint32_t* shadow_q;
+    uint32_t* sh_slot;     // path slot whose L receives the contribution
+    // index queues: entries are generation indices p of the current depth
     uint32_t* escaped_q;
     uint32_t* medium_q;    // rays that travel inside a medium (delta tracking before their surface hit is processed)
     uint32_t* scatter_q;   // paths that scattered inside a medium at this depth (K5/K6 input)
     int* initial_medium;   // camera medium detected on the device (K14)
     uint32_t* mat_q;       // HK_MAX_KINDS * W * wave_cap
     int* counters;         // [(max_depth + 2) * Q_COUNT][W] per-wave queue sizes
-    int* tickets;          // [ticket_rows * HK_TICKET_COLS] segment tickets (dynamic segment -> wave assignment), one word per launch, zeroed per pass
+    int* tickets;          // [ticket_rows * HK_TICKET_COLS][HK_TICKET_WAYS * HK_TICKET_STRIDE] segment tickets (dynamic segment -> wave assignment), zeroed per pass
     int ticket_rows;       // max_depth + 2
     int dynamic_segments;  // 1: every kernel draws its segments from the tickets (scenes with media); 0: static stride
 };
@@ -253,4 +268,5 @@ struct DFrame {            // per-pass constants
     int regularize;
     float max_component_value;
     int count_nodes;       // 1: accumulate node/triangle counters
+    int implicit_ones;     // 1: scene without media: the depth-0 records do not store beta = r_u = r_l = 1
 };

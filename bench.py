@@ -12,7 +12,9 @@ region itself (--spp-per-step changes the batch; --steps defaults to 256 / spp-p
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 N > 1: one process per GPU; rank g renders sample indices g+1, g+1+N, ... (weak scaling: K steps each), then
-ONE RCCL sum-reduce of the film accumulators to rank 0 inside the timed region.  value = rays of all ranks /
+ONE RCCL sum-reduce of the film accumulators to rank 0 inside the timed region — the library's own hk_film_reduce
+(ncclReduce on the render stream; torch.distributed only carries the 128-byte communicator id and the final
+statistics, and its reduce serves as the untimed cross-check of the result).  value = rays of all ranks /
 max-over-ranks time.  The scene, BVH and film live in HBM before the timed region starts.
 """
 import argparse
@@ -110,14 +112,37 @@ def main():
         vp.sync()
         torch.cuda.synchronize()
 
+    # ---- the film reduce of N > 1: hk_comm over RCCL inside the library (the C-ABI's own exchange step) ----
+    comm = None
+    if world > 1 and not single_device:
+        uid = [hk.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)        # the launcher's side channel for the 128-byte id
+        comm = hk.Comm.rank(vp._ctx, uid[0], rank, world)
+
+    def reduce_films():
+        if comm is not None:
+            comm.reduce_films([vp], root=0)
+        else:                                         # HK_BENCH_SINGLE_DEVICE test hook: every rank shares cuda:0, gloo stages through the host
+            hd.reduce_film(accum, root=0)
+
     # ---- warmup (untimed): also uploads the scene / builds the BVH ----
     t0 = time.time()
     run_steps(0, max(args.warmup, 1) if args.warmup > 0 else 0)
     barrier()
     setup_s = time.time() - t0
+    reduce_check = None
     if world > 1:
-        hd.reduce_film(accum, root=0)   # untimed: RCCL sets up the reduce's channels on first use
+        # untimed: RCCL sets up the reduce's channels on first use; and the cross-check of the in-library reduce against
+        # torch.distributed's on the warm-up film (same inputs, same ring: identical sums)
+        keep = accum.clone()
+        reduce_films()
         barrier()
+        mine = accum.clone()
+        accum.copy_(keep)
+        hd.reduce_film(accum, root=0)
+        barrier()
+        if rank == 0:
+            reduce_check = bool(torch.allclose(mine, accum, rtol=1e-6, atol=1e-7))
     accum.zero_()
     vp.enable_counters(count_nodes=False, time_kernels=True)   # HIP events around every launch, on the launch stream
     vp.reset_stats()
@@ -127,7 +152,7 @@ def main():
     t0 = time.perf_counter()
     run_steps(0, args.steps)
     if world > 1:
-        hd.reduce_film(accum, root=0)
+        reduce_films()
     barrier()
     elapsed = time.perf_counter() - t0
     st = vp.stats()
@@ -225,7 +250,8 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload,
                        "resolution": [W, H], "max_depth": DEPTH, "spp_per_step": SPP_PER_STEP, "spp_rendered": spp_done,
-                       "triangles": int(scene.desc.n_triangles), "lights": int(scene.desc.n_lights), "parallelism": "sample-index sharding x%d + film reduce" % world},
+                       "triangles": int(scene.desc.n_triangles), "lights": int(scene.desc.n_lights), "parallelism": "sample-index sharding x%d + in-library RCCL film reduce (hk_film_reduce)" % world,
+                       "reduce_matches_torch_distributed": reduce_check},
             "seconds_timed": round(elapsed_max, 4),
             "seconds_to_256spp": round(elapsed_max * FULL_SPP / spp_done * world, 4) if world == 1 else round(elapsed_max * (FULL_SPP / spp_done), 4),
             "rays": {"closest": int(st.rays_closest), "shadow": int(st.rays_shadow), "total_all_ranks": int(total_rays), "medium_collisions": int(st.medium_collisions)},
@@ -233,6 +259,8 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(result))
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -21,5 +21,5 @@ from .media_presets import Coffee, Fog, Juice, Milk, Smoke, SubsurfaceMedium, Wi
 from .postprocess import FilmSensor, compute_white_balance_matrix
 from .scene import Scene
 from .sunsky import sunsky_to_envlight
-from .volpath import (BoxFilter, Context, GaussianFilter, LanczosSincFilter, MitchellFilter, TriangleFilter, VolPath,
+from .volpath import (BoxFilter, Comm, Context, GaussianFilter, LanczosSincFilter, MitchellFilter, TriangleFilter, VolPath,
                       integrator_params, scene_handle)

@@ -40,6 +40,12 @@ def lib():
         "hk_film_destroy": ([vp], i32),
         "hk_film_clear": ([vp], i32),
         "hk_render": ([vp, vp, vp, vp, C.POINTER(A.hk_camera), i32, i32, i32], i32),
+        "hk_render_tile": ([vp, vp, vp, vp, C.POINTER(A.hk_camera), i32, i32, i32, i32, i32, i32, i32], i32),
+        "hk_comm_create": ([C.POINTER(vp), i32, C.POINTER(vp)], i32),
+        "hk_comm_unique_id": ([C.POINTER(C.c_uint8)], i32),
+        "hk_comm_create_rank": ([vp, C.POINTER(C.c_uint8), i32, i32, C.POINTER(vp)], i32),
+        "hk_comm_destroy": ([vp], i32),
+        "hk_film_reduce": ([vp, C.POINTER(vp), i32, i32], i32),
         "hk_film_read_rgb": ([vp, vp, PF], i32),
         "hk_film_read_accum": ([vp, vp, vp], i32),
         "hk_film_accum_device_ptr": ([vp], vp),

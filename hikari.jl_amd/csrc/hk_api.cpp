@@ -10,6 +10,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
+
+#include <dlfcn.h>
 #include <string>
 #include <vector>
 
@@ -149,7 +152,7 @@ struct hk_integrator {
     std::vector<DevBuf*> bufs;
     int st_capacity = 0, st_depth = 0;
     DevBuf sobol_table;  // DSobol::hi_table
-    int sobol_rows = 0, sobol_stride = 0, sobol_log2 = -1, sobol_digits = -1;
+    int sobol_rows = 0, sobol_stride = 0, sobol_log2 = -1, sobol_digits = -1, sobol_x0 = -1, sobol_y0 = -1, sobol_tiles_x = -1;
     ~hk_integrator() {
         for (auto* b : bufs) delete b;
     }
@@ -1154,7 +1157,15 @@ hipEvent_t get_event(hk_ctx* c) {
 
 extern "C" int32_t hk_render(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_film* film, const hk_camera* cam, int32_t first_sample_idx, int32_t n_samples,
                              int32_t sample_stride) {
+    if (!film) return fail(HK_ERR_INVALID, "null argument");
+    return hk_render_tile(c, sc, I, film, cam, first_sample_idx, n_samples, sample_stride, 0, 0, film->width, film->height);
+}
+
+extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_film* film, const hk_camera* cam, int32_t first_sample_idx, int32_t n_samples,
+                                  int32_t sample_stride, int32_t x0, int32_t y0, int32_t x1, int32_t y1) {
     if (!c || !sc || !I || !film || !cam) return fail(HK_ERR_INVALID, "null argument");
+    if (x0 < 0 || y0 < 0 || x1 > film->width || y1 > film->height || x0 > x1 || y0 > y1) return fail(HK_ERR_INVALID, "pixel range outside the film");
+    if (x0 == x1 || y0 == y1) return HK_OK;
     if (n_samples < 0 || sample_stride < 1 || first_sample_idx < 1) return fail(HK_ERR_INVALID, "bad sample range");
     if (!c->have_tables) return fail(HK_ERR_INVALID, "hk_ctx_set_tables must be called first");
     if (sc->ctx != c || I->ctx != c || film->ctx != c) return fail(HK_ERR_INVALID, "scene / integrator / film belong to another context");
@@ -1165,8 +1176,9 @@ extern "C" int32_t hk_render(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_film*
     DFrame fr{};
     fr.width = W;
     fr.height = H;
-    fr.tiles_x = (W + 7) / 8;
-    fr.tiles_y = (H + 7) / 8;
+    fr.x0 = x0, fr.y0 = y0, fr.x1 = x1, fr.y1 = y1;
+    fr.tiles_x = (x1 - x0 + 7) / 8;
+    fr.tiles_y = (y1 - y0 + 7) / 8;
     fr.n_pixels_padded = fr.tiles_x * fr.tiles_y * 64;
     int S = I->p.samples_per_pass;
     if (S <= 0) {
@@ -1193,7 +1205,8 @@ extern "C" int32_t hk_render(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_film*
     DSobol sob = make_sobol(I->p, W, H);
     {   // pixel-digit table of the sampler: depends on film size, spp exponent and max_depth only
         const int rows = 4 + 5 * (I->p.max_depth + 1);
-        if (I->sobol_rows != rows || I->sobol_stride != fr.n_pixels_padded || I->sobol_log2 != sob.log2_spp || I->sobol_digits != sob.n_base4_digits) {
+        if (I->sobol_rows != rows || I->sobol_stride != fr.n_pixels_padded || I->sobol_log2 != sob.log2_spp || I->sobol_digits != sob.n_base4_digits ||
+            I->sobol_x0 != x0 || I->sobol_y0 != y0 || I->sobol_tiles_x != fr.tiles_x) {
             HIP_TRY(I->sobol_table.alloc((size_t)rows * fr.n_pixels_padded * sizeof(uint32_t)));
             hk::launch_sobol_table(c->stream, sob, fr, I->sobol_table.as<uint32_t>(), rows);
             HIP_TRY(hipGetLastError());
@@ -1201,6 +1214,7 @@ extern "C" int32_t hk_render(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_film*
             I->sobol_stride = fr.n_pixels_padded;
             I->sobol_log2 = sob.log2_spp;
             I->sobol_digits = sob.n_base4_digits;
+            I->sobol_x0 = x0, I->sobol_y0 = y0, I->sobol_tiles_x = fr.tiles_x;
         }
         sob.hi_table = I->sobol_table.as<uint32_t>();
         sob.hi_rows = rows;
@@ -1567,5 +1581,153 @@ extern "C" int32_t hk_test_trace_lean(hk_ctx* c, hk_scene* sc, int32_t anyhit, i
     HIP_TRY(hipMemcpy(out_t, ot, (size_t)n * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(out_prim, op, (size_t)n * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(out_uv2, ouv, 2 * (size_t)n * 4, hipMemcpyDeviceToHost));
+    return HK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Multi-GPU behind the C-ABI: the ONE exchange step of the path is a sum-reduce of the film accumulators
+// [pixel_rgb 3N | pixel_weight_sum N] (volpath.jl:364-373, volpath-state.jl:122-131) to one device after the last sample.  It is done
+// here with RCCL directly (ncclReduce over xGMI), so a caller without torch — the Julia shim with `devices = 0:7` — shards a frame
+// over the GPUs of a node: one hk_ctx per device, hk_render on each (asynchronous, each on its context's stream), hk_film_reduce,
+// hk_film_read_rgb on the root.  librccl is loaded on first use (dlopen): single-GPU users never touch it.
+// ---------------------------------------------------------------------------------------------------------------------------
+namespace {
+struct Rccl {
+    void* lib = nullptr;
+    // the few entry points used, with the prototypes of <rccl/rccl.h> (ncclResult_t = int, ncclComm_t = opaque pointer,
+    // ncclUniqueId = 128 opaque bytes passed by value, ncclDataType_t: ncclFloat32 = 7, ncclFloat64 = 8, ncclRedOp_t: ncclSum = 0)
+    struct UniqueId {
+        char internal[128];
+    };
+    int (*GetUniqueId)(UniqueId*) = nullptr;
+    int (*CommInitRank)(void**, int, UniqueId, int) = nullptr;
+    int (*CommInitAll)(void**, int, const int*) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*Reduce)(const void*, void*, size_t, int, int, int, void*, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::string error;
+};
+Rccl& rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names) {
+            r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (r.lib) break;
+        }
+        if (!r.lib) {
+            r.error = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "?");
+            return;
+        }
+        auto sym = [&](const char* name) {
+            void* p = dlsym(r.lib, name);
+            if (!p && r.error.empty()) r.error = std::string("librccl lacks ") + name;
+            return p;
+        };
+        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+        r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+        r.Reduce = reinterpret_cast<decltype(r.Reduce)>(sym("ncclReduce"));
+        r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+        r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    });
+    return r;
+}
+int rccl_fail(const char* what, int code) {
+    Rccl& r = rccl();
+    return fail(HK_ERR_DEVICE, std::string(what) + ": " + (r.GetErrorString ? r.GetErrorString(code) : "RCCL error"));
+}
+#define RCCL_TRY(expr)                              \
+    do {                                            \
+        int rc_ = (expr);                           \
+        if (rc_ != 0) return rccl_fail(#expr, rc_); \
+    } while (0)
+}  // namespace
+
+struct hk_comm {
+    std::vector<hk_ctx*> ctxs;     // local ranks of this process (1 in the one-process-per-GPU layout)
+    std::vector<void*> comms;      // ncclComm_t per local rank
+    int world = 1;
+};
+
+extern "C" int32_t hk_comm_create(hk_ctx* const* ctxs, int32_t n, hk_comm** out) {
+    if (!ctxs || n < 1 || !out) return fail(HK_ERR_INVALID, "bad argument");
+    for (int i = 0; i < n; ++i) {
+        if (!ctxs[i]) return fail(HK_ERR_INVALID, "null context");
+        for (int j = 0; j < i; ++j)
+            if (ctxs[j]->device == ctxs[i]->device) return fail(HK_ERR_INVALID, "two contexts on the same device in one communicator");
+    }
+    Rccl& r = rccl();
+    if (!r.error.empty()) return fail(HK_ERR_UNSUPPORTED, r.error);
+    std::unique_ptr<hk_comm> c(new hk_comm());
+    c->ctxs.assign(ctxs, ctxs + n);
+    c->comms.assign(n, nullptr);
+    c->world = n;
+    std::vector<int> devs(n);
+    for (int i = 0; i < n; ++i) devs[i] = ctxs[i]->device;
+    RCCL_TRY(r.CommInitAll(c->comms.data(), n, devs.data()));
+    *out = c.release();
+    return HK_OK;
+}
+extern "C" int32_t hk_comm_unique_id(uint8_t* id_out128) {
+    if (!id_out128) return fail(HK_ERR_INVALID, "null argument");
+    Rccl& r = rccl();
+    if (!r.error.empty()) return fail(HK_ERR_UNSUPPORTED, r.error);
+    Rccl::UniqueId id;
+    RCCL_TRY(r.GetUniqueId(&id));
+    std::memcpy(id_out128, id.internal, 128);
+    return HK_OK;
+}
+extern "C" int32_t hk_comm_create_rank(hk_ctx* ctx, const uint8_t* id128, int32_t rank, int32_t world, hk_comm** out) {
+    if (!ctx || !id128 || !out || world < 1 || rank < 0 || rank >= world) return fail(HK_ERR_INVALID, "bad argument");
+    Rccl& r = rccl();
+    if (!r.error.empty()) return fail(HK_ERR_UNSUPPORTED, r.error);
+    HIP_TRY(hipSetDevice(ctx->device));
+    Rccl::UniqueId id;
+    std::memcpy(id.internal, id128, 128);
+    std::unique_ptr<hk_comm> c(new hk_comm());
+    c->ctxs.assign(1, ctx);
+    c->comms.assign(1, nullptr);
+    c->world = world;
+    RCCL_TRY(r.CommInitRank(&c->comms[0], world, id, rank));
+    *out = c.release();
+    return HK_OK;
+}
+extern "C" int32_t hk_comm_destroy(hk_comm* c) {
+    if (!c) return HK_OK;
+    Rccl& r = rccl();
+    for (size_t i = 0; i < c->comms.size(); ++i)
+        if (c->comms[i] && r.CommDestroy) {
+            (void)hipSetDevice(c->ctxs[i]->device);
+            (void)hipStreamSynchronize(c->ctxs[i]->stream);
+            (void)r.CommDestroy(c->comms[i]);
+        }
+    delete c;
+    return HK_OK;
+}
+extern "C" int32_t hk_film_reduce(hk_comm* c, hk_film* const* films, int32_t n_films, int32_t root) {
+    if (!c || !films || n_films != (int32_t)c->comms.size()) return fail(HK_ERR_INVALID, "one film per local rank of the communicator is required");
+    if (root < 0 || root >= c->world) return fail(HK_ERR_INVALID, "root out of range");
+    for (int i = 0; i < n_films; ++i) {
+        if (!films[i] || films[i]->ctx != c->ctxs[i]) return fail(HK_ERR_INVALID, "film i must live on the communicator's context i");
+        if (films[i]->width != films[0]->width || films[i]->height != films[0]->height || films[i]->f64 != films[0]->f64)
+            return fail(HK_ERR_INVALID, "films differ in size or accumulation type");
+    }
+    Rccl& r = rccl();
+    if (!r.error.empty()) return fail(HK_ERR_UNSUPPORTED, r.error);
+    const size_t count = (size_t)4 * films[0]->width * films[0]->height;
+    const int dtype = films[0]->f64 ? 8 : 7;   // ncclFloat64 : ncclFloat32
+    if (n_films > 1) RCCL_TRY(r.GroupStart());
+    for (int i = 0; i < n_films; ++i) {
+        HIP_TRY(hipSetDevice(c->ctxs[i]->device));
+        // in place: the root's accumulators receive the sum; ordered after the renders already enqueued on the context's stream
+        RCCL_TRY(r.Reduce(films[i]->accum, films[i]->accum, count, dtype, 0 /* ncclSum */, root, c->comms[i], c->ctxs[i]->stream));
+    }
+    if (n_films > 1) RCCL_TRY(r.GroupEnd());
     return HK_OK;
 }

@@ -115,9 +115,9 @@ __device__ __forceinline__ void wave_add(unsigned long long* dst, unsigned v) {
 __device__ __forceinline__ void slot_to_pixel(const DFrame& fr, int slot_in_sample, int& px, int& py, bool& inside) {
     int tile = slot_in_sample >> 6, l = slot_in_sample & 63;
     int tx = tile % fr.tiles_x, ty = tile / fr.tiles_x;
-    px = tx * 8 + (l & 7);
-    py = ty * 8 + (l >> 3);
-    inside = px < fr.width && py < fr.height;
+    px = fr.x0 + tx * 8 + (l & 7);
+    py = fr.y0 + ty * 8 + (l >> 3);
+    inside = px < fr.x1 && py < fr.y1;
 }
 
 }  // namespace

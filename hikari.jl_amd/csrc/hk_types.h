@@ -260,7 +260,8 @@ struct DStats {
 };
 
 struct DFrame {            // per-pass constants
-    int width, height, tiles_x, tiles_y;
+    int width, height, tiles_x, tiles_y;   // film size; 8x8 pixel tiles of the rendered pixel range
+    int x0, y0, x1, y1;    // rendered pixel range [x0, x1) x [y0, y1) (0-based; the whole film unless hk_render_tile narrows it)
     int n_pixels_padded;   // tiles_x*tiles_y*64
     int samples_in_pass;
     int first_sample, sample_stride;   // sample index of pass-sample k = first_sample + k*sample_stride

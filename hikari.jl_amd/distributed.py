@@ -11,6 +11,15 @@ def shard_samples(total_samples, rank, world):
     return rank + 1, count, world
 
 
+def shard_tiles(width, height, rank, world):
+    """Pixel-tile sharding (the other partition of SURVEY 8e): `world` horizontal bands whose heights are multiples of the 8-row
+    path tile (so no band splits a wave's 8x8 pixel block) -> (x0, y0, x1, y1) of this rank; bands of the last ranks may be empty."""
+    rows8 = (height + 7) // 8
+    lo = (rows8 * rank) // world * 8
+    hi = (rows8 * (rank + 1)) // world * 8
+    return 0, min(lo, height), width, min(hi, height)
+
+
 def reduce_film(accum_tensor, root=0):
     """Sum-reduce the film accumulators onto `root` (16 MiB at 1024^2: one small collective per frame)."""
     import torch.distributed as dist

@@ -93,6 +93,45 @@ def scene_handle(ctx, scene):
     return dev[id(ctx)]
 
 
+class Comm:
+    """hk_comm: the RCCL communicator of the film reduce (include/hikari_mi355x.h).  Comm.local([ctx, ...]) spans the GPUs of this
+    process; Comm.rank(ctx, unique_id, rank, world) is one rank of a one-process-per-GPU job (unique_id from Comm.unique_id() on
+    rank 0, handed to the other ranks by the launcher's side channel)."""
+
+    def __init__(self, handle, ctxs):
+        self.h, self.ctxs = handle, ctxs
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * 128)()
+        _lib.check(_lib.lib().hk_comm_unique_id(buf), "hk_comm_unique_id")
+        return bytes(buf)
+
+    @classmethod
+    def local(cls, ctxs):
+        arr = (C.c_void_p * len(ctxs))(*[c.h for c in ctxs])
+        h = C.c_void_p()
+        _lib.check(_lib.lib().hk_comm_create(arr, len(ctxs), C.byref(h)), "hk_comm_create")
+        return cls(h, list(ctxs))
+
+    @classmethod
+    def rank(cls, ctx, unique_id, rank, world):
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().hk_comm_create_rank(ctx.h, buf, int(rank), int(world), C.byref(h)), "hk_comm_create_rank")
+        return cls(h, [ctx])
+
+    def reduce_films(self, integrators, root=0):
+        """Sum-reduce the film accumulators of `integrators` (one VolPath per local rank, in communicator order) onto rank `root`."""
+        films = (C.c_void_p * len(integrators))(*[vp._film[0] for vp in integrators])
+        _lib.check(_lib.lib().hk_film_reduce(self.h, films, len(integrators), int(root)), "hk_film_reduce")
+
+    def close(self):
+        if self.h:
+            _lib.lib().hk_comm_destroy(self.h)
+            self.h = None
+
+
 class VolPath:
     def __init__(self, max_depth=8, samples=64, russian_roulette_depth=3, regularize=True, material_coherence="none",
                  max_component_value=10.0, filter=None, accumulation_eltype="Float32", device=0, samples_per_pass=0):
@@ -131,15 +170,20 @@ class VolPath:
         if self._film is not None:
             _lib.check(_lib.lib().hk_film_clear(self._film[0]), "hk_film_clear")
 
-    def render_samples(self, scene, film, camera, n_samples, stride=1, first=None, readback=True):
-        """Render `n_samples` more samples (sample indices first, first+stride, ...)."""
+    def render_samples(self, scene, film, camera, n_samples, stride=1, first=None, readback=True, tile=None):
+        """Render `n_samples` more samples (sample indices first, first+stride, ...); tile = (x0, y0, x1, y1) restricts the call to
+        the pixels [x0, x1) x [y0, y1) (pixel-tile sharding, hk_render_tile)."""
         self._ensure(film)
         L = _lib.lib()
         sh = scene_handle(self._ctx, scene)
         cam = camera.record()
         if first is None:
             first = film.iteration_index + 1
-        _lib.check(L.hk_render(self._ctx.h, sh, self._integ, self._film[0], C.byref(cam), int(first), int(n_samples), int(stride)), "hk_render")
+        if tile is None:
+            _lib.check(L.hk_render(self._ctx.h, sh, self._integ, self._film[0], C.byref(cam), int(first), int(n_samples), int(stride)), "hk_render")
+        else:
+            _lib.check(L.hk_render_tile(self._ctx.h, sh, self._integ, self._film[0], C.byref(cam), int(first), int(n_samples), int(stride),
+                                        *[int(v) for v in tile]), "hk_render_tile")
         film.iteration_index = first + (n_samples - 1) * stride
         if readback:
             self.read_framebuffer(film)

@@ -327,6 +327,31 @@ int32_t hk_film_clear(hk_film* film); /* clear!(vp), volpath.jl:108-113 */
 int32_t hk_render(hk_ctx* ctx, hk_scene* scene, hk_integrator* integ, hk_film* film, const hk_camera* cam,
                   int32_t first_sample_idx, int32_t n_samples, int32_t sample_stride);
 
+/* The same, restricted to the pixels [x0, x1) x [y0, y1) (0-based, py counted like the film rows of hk_film_read_rgb): the
+ * pixel-tile sharding mode of SURVEY 8(e).  Paths are independent (volpath.jl:538-612 reads no other pixel) and ZSobol is a
+ * pure function of (px, py, sample_idx, dim), so a pixel gets bit-identical accumulators whichever range it is rendered in;
+ * pixels outside the range are left untouched, so the sum-reduce of zero-initialised films gathers disjoint tiles. */
+int32_t hk_render_tile(hk_ctx* ctx, hk_scene* scene, hk_integrator* integ, hk_film* film, const hk_camera* cam,
+                       int32_t first_sample_idx, int32_t n_samples, int32_t sample_stride, int32_t x0, int32_t y0, int32_t x1, int32_t y1);
+
+/* ---------------------------------------------------------------------------------------------
+ * Multi-GPU: units = (pixel, sample_idx) paths, no communication between paths; each device renders its share
+ * (sample indices g+1, g+1+G, ... through `sample_stride`, or a pixel tile through hk_render_tile) of the same replicated scene,
+ * and ONE exchange finishes the frame: ncclReduce(sum) of [pixel_rgb 3N | pixel_weight_sum N] (volpath.jl:364-373,
+ * volpath-state.jl:122-131) onto the root over xGMI.  RCCL is loaded on first use.
+ *   one process, several GPUs (the Julia shim's `devices = 0:7`): hk_ctx per device, hk_comm_create over them, hk_render on
+ *     each, hk_film_reduce(comm, films, n, root), hk_film_read_rgb on films[root];
+ *   one process per GPU (torchrun-style): rank 0 calls hk_comm_unique_id and hands the 128 bytes to the others (any side
+ *     channel), every rank hk_comm_create_rank, then hk_film_reduce(comm, &film, 1, root).
+ * The reduce is enqueued on each context's stream, after the renders already enqueued there, in place.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct hk_comm hk_comm;
+int32_t hk_comm_create(hk_ctx* const* ctxs, int32_t n, hk_comm** out);
+int32_t hk_comm_unique_id(uint8_t* id_out128);
+int32_t hk_comm_create_rank(hk_ctx* ctx, const uint8_t* id128, int32_t rank, int32_t world, hk_comm** out);
+int32_t hk_comm_destroy(hk_comm* comm);
+int32_t hk_film_reduce(hk_comm* comm, hk_film* const* films, int32_t n_films, int32_t root);
+
 /* K13 finalize (volpath.jl:384-417): writes rgb/weight as Julia Matrix{RGB{Float32}}[height,width]
  * (`out_hw3` = 3 floats per pixel, column-major over (py,px)) into host memory; synchronises. */
 int32_t hk_film_read_rgb(hk_ctx* ctx, hk_film* film, float* out_hw3);

@@ -181,25 +181,57 @@ def main():
         sc = vp.stats()
         accum.copy_(accum_keep)
         vp.enable_counters(False, False)
-        hits = int(sc.hits_accepted)
-        dom = max(("trace", "shadow", "shade"), key=lambda k: timed[k])
-        if dom == "trace":
-            hit_frac_bytes = B_HIT * min(int(sc.rays_closest), hits)   # shading attributes fetched once per accepted hit
-            alg_bytes = casts["trace"] * (B_RAY_IN + B_HIT_OUT) + S_NODE * int(sc.trace_nodes) + B_TRI * int(sc.trace_tris) + hit_frac_bytes
-        elif dom == "shadow":
-            alg_bytes = casts["shadow"] * (B_RAY_IN + B_HIT_OUT) + S_NODE * int(sc.shadow_nodes) + B_TRI * int(sc.shadow_tris)
-        else:
-            alg_bytes = vertices * (2 * S_STATE + 64 + 96) + 60 * int(sc.light_bvh_nodes)
-        n_launch = max(launches[dom], 1)
-        avg_s = timed[dom] / n_launch
-        achieved = alg_bytes / n_launch / avg_s / 1e9 if avg_s > 0 else 0.0
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.isfile(pmc_path) and args.config == "cornell" and SPP_PER_STEP == 64:   # the PMC passes were taken on this workload
+        # ---- per-kernel-class ceilings: ALGORITHMIC bytes from the counted replay (hk_stats.bytes_algorithmic_*) over the
+        #      HIP-event time of that class's launches in the timed region; PMC traffic / L2 hit rate / VALU issue / lane utilisation
+        #      from the rocprofv3 passes committed under profiles/ for the same workload (tools/profile_round.sh) ----
+        alg = dict(trace=int(sc.bytes_algorithmic_trace), shadow=int(sc.bytes_algorithmic_shadow), shade=int(sc.bytes_algorithmic_shade))
+        kname = {"trace": "k_trace", "shadow": "k_shadow", "shade": "k_shade"}
+
+        def committed(stem):
+            path = os.path.join(ROOT, "profiles", "%s_%s.json" % (stem, args.config))
             try:
-                traffic = json.load(open(pmc_path)).get({"trace": "k_trace", "shadow": "k_shadow", "shade": "k_shade"}[dom], {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+                return json.load(open(path)) if SPP_PER_STEP == 64 else {}     # the PMC passes were taken at 64 spp per step
+            except (OSError, ValueError):
+                return {}
+
+        pmc, util = committed("pmc_traffic"), committed("utilisation")
+        rooflines = []
+        for cls in ("trace", "shadow", "shade"):
+            n_launch = max(launches[cls], 1)
+            avg_s = timed[cls] / n_launch
+            if timed[cls] <= 0:
+                continue
+            achieved = alg[cls] / n_launch / avg_s / 1e9
+            e = {"kernel": kname[cls], "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                 "algorithmic_bytes_per_launch": int(alg[cls] / n_launch), "avg_launch_ms": round(avg_s * 1e3, 4), "launches": n_launch,
+                 "seconds": round(timed[cls], 4)}
+            t = pmc.get(kname[cls], {})
+            e["traffic"] = t.get("hbm_bytes_per_launch")
+            if e["traffic"]:
+                # the PMC launches average over the same depths as the bench's (whole passes): traffic per launch is comparable
+                e["traffic_over_algorithmic"] = round(e["traffic"] / max(alg[cls] / n_launch, 1), 3)
+                e["hbm_frac_by_traffic"] = round(e["traffic"] / avg_s / 1e9 / HBM_PEAK_GBS, 4)
+            if "l2_hit_rate" in t:
+                e["l2_hit_rate"] = t["l2_hit_rate"]
+            u = util.get(kname[cls], {})
+            for k in ("valu_issue_frac", "lane_util", "wait_frac"):
+                if k in u:
+                    e[k] = u[k]
+            hb, vi = e.get("hbm_frac_by_traffic"), e.get("valu_issue_frac")
+            if hb is None or vi is None:
+                e["binding"] = "unprofiled on this workload"
+            elif hb >= 0.5:
+                e["binding"] = "HBM traffic (%.0f %% of peak)" % (100 * hb)
+            elif vi >= 0.5:
+                e["binding"] = "VALU issue (%.0f %% of the issue cycles)" % (100 * vi)
+            else:
+                e["binding"] = "latency: HBM traffic at %.0f %% of peak, VALU issue >= %.0f %% of cycles at %.0f %% lane utilisation" % (100 * hb, 100 * vi, 100 * e.get("lane_util", 0))
+            rooflines.append(e)
+        # BVH nodes come from L1 / L2, not HBM: the SURVEY 8(d) byte formula is an upper bound of traversal's HBM need, not a ceiling
+        for e in rooflines:
+            if e["kernel"] in ("k_trace", "k_shadow"):
+                e["note"] = "algorithmic bytes count every BVH node / triangle visit at full size; measured HBM traffic is the `traffic` field"
+        dom = max(("trace", "shadow", "shade"), key=lambda k: timed[k])
         # measured HBM ceiling of this box beside the nominal peak: device-to-device copy, read + write bytes
         a = torch.empty(1 << 28, dtype=torch.float32, device="cuda")    # 1 GiB
         b = torch.empty_like(a)
@@ -213,13 +245,11 @@ def main():
         torch.cuda.synchronize()
         copy_gbs = 10 * 2 * a.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del a, b
-        roofline = {"bound": "hbm", "kernel": {"trace": "k_trace", "shadow": "k_shadow", "shade": "k_shade"}[dom], "achieved": round(achieved, 2),
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "measured_copy_gbs": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 5),
-                    "algorithmic_bytes_per_launch": int(alg_bytes / n_launch), "avg_launch_ms": round(avg_s * 1e3, 4), "launches": n_launch,
-                    "nodes_per_cast": round(int(sc.trace_nodes) / max(int(sc.rays_closest), 1), 2),
-                    "tris_per_cast": round(int(sc.trace_tris) / max(int(sc.rays_closest), 1), 2),
-                    "kernel_seconds": {k: round(v, 4) for k, v in timed.items()}}
+        roofline = dict(next(e for e in rooflines if e["kernel"] == kname[dom]))
+        roofline.update({"measured_copy_gbs": round(copy_gbs, 1), "frac_of_measured_copy": round(roofline["achieved"] / copy_gbs, 5),
+                         "nodes_per_cast": round(int(sc.trace_nodes) / max(int(sc.rays_closest), 1), 2),
+                         "tris_per_cast": round(int(sc.trace_tris) / max(int(sc.rays_closest), 1), 2),
+                         "kernel_seconds": {k: round(v, 4) for k, v in timed.items()}})
 
         # ---- CPU baseline: the oracle (a port, NOT Julia / KernelAbstractions.CPU()) on a bounded sample ----
         cpu = None
@@ -256,7 +286,7 @@ def main():
             "seconds_to_256spp": round(elapsed_max * FULL_SPP / spp_done * world, 4) if world == 1 else round(elapsed_max * (FULL_SPP / spp_done), 4),
             "rays": {"closest": int(st.rays_closest), "shadow": int(st.rays_shadow), "total_all_ranks": int(total_rays), "medium_collisions": int(st.medium_collisions)},
             "setup_seconds": round(setup_s, 3),
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "rooflines": rooflines, "cpu_baseline": cpu,
         }
         print(json.dumps(result))
     if comm is not None:

@@ -1405,6 +1405,12 @@ extern "C" int32_t hk_stats_get(hk_ctx* c, hk_stats* out) {
     out->seconds_shadow = cls[1];
     out->seconds_shade = cls[2];
     out->seconds_other = cls[3];
+    {   // SURVEY 8(d) algorithmic bytes over the counted units
+        const uint64_t hits_closest = h.hits < h.rays_closest ? h.hits : h.rays_closest;   // shading attributes are fetched once per accepted closest hit
+        out->bytes_algorithmic_trace = h.rays_closest * (32 + 16) + 64 * h.nodes + 36 * h.tris + 96 * hits_closest;
+        out->bytes_algorithmic_shadow = h.rays_shadow * (32 + 16) + 64 * h.sh_nodes + 36 * h.sh_tris;
+        out->bytes_algorithmic_shade = h.vertices * (2 * 104 + 64 + 96) + 60 * h.light_nodes;
+    }
     return HK_OK;
 }
 

@@ -293,6 +293,10 @@ typedef struct hk_stats {
     uint64_t shadow_nodes, shadow_tris;  /* k_shadow only */
     uint64_t shadow_launches, shade_launches;
     double seconds_shadow, seconds_shade, seconds_other; /* HIP-event sums (flag bit 1) */
+    /* ALGORITHMIC bytes of the three hot kernel classes, SURVEY 8(d): per cast 32 (ray in) + 64 per BVH node visited + 36 per
+       triangle tested + 96 per accepted hit (closest-hit only) + 16 (hit out); per path vertex 2*104 (state read + written) + 64
+       (material record) + 96 (light record) + 60 per light-BVH node.  The node / triangle terms need counter flag bit 0. */
+    uint64_t bytes_algorithmic_trace, bytes_algorithmic_shadow, bytes_algorithmic_shade;
 } hk_stats;
 
 typedef struct hk_ctx hk_ctx;

@@ -78,7 +78,8 @@ def main():
         args.steps = max(FULL_SPP // SPP_PER_STEP, 1)
     if args.config == "cloud":
         W, H, DEPTH = 1024, 1024, 32
-        scene, film, cam = scenes.cloud_scene(W, H, "nanovdb", res=(256, 256, 128), sigma_scale=620.0 / 4)
+        mres = int(os.environ.get("HK_CLOUD_MAJORANT", "32"))
+        scene, film, cam = scenes.cloud_scene(W, H, "nanovdb", res=(256, 256, 128), sigma_scale=620.0 / 4, majorant_res=(mres, mres, mres))
         workload = "synthetic BOMEX-like NanoVDB cloud (256x256x128, delta tracking), 1024x1024, VolPath depth 32, %d spp per step" % SPP_PER_STEP
     elif args.config == "sky":
         W, H, DEPTH = 800, 800, 12

@@ -640,6 +640,15 @@ extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene**
             s->media_data.push_back(mb);
             HIP_TRY(mb->upload(m.majorant, (size_t)m.majorant_res[0] * m.majorant_res[1] * m.majorant_res[2] * 4));
             o.majorant = mb->as<float>();
+            // one bit per majorant cell: value exactly 0 (DMedium::maj_zero, majorant_skip_zero)
+            const size_t ncell = (size_t)m.majorant_res[0] * m.majorant_res[1] * m.majorant_res[2];
+            std::vector<uint32_t> zero((ncell + 31) / 32, 0u);
+            for (size_t i = 0; i < ncell; ++i)
+                if (m.majorant[i] == 0.0f) zero[i >> 5] |= 1u << (i & 31);
+            DevBuf* zb = new DevBuf();
+            s->media_data.push_back(zb);
+            HIP_TRY(zb->upload(zero.data(), zero.size() * 4));
+            o.maj_zero = zb->as<uint32_t>();
         }
         if (m.kind == HK_MEDIUM_GRID) {
             DevBuf* db = new DevBuf();
@@ -746,6 +755,31 @@ extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene**
             HIP_TRY(tb->upload(table.data(), table.size() * sizeof(uint2)));
             o.nv_blocks = tb->as<uint2>();
             for (int k = 0; k < 3; ++k) o.nvb_dim[k] = (int)dim[k];
+            // dense bricks: every block of the table materialised (leaf values copied, constant blocks filled) so that the device
+            // fetches a voxel with ONE load at a computed address.  2 KB per block: taken when it fits HK_NVDB_DENSE_MB (default
+            // 4096 MB — 288 GB of HBM are there to be used; the bench cloud needs 47 MB), else the table + leaves path stays.
+            {
+                size_t budget_mb = 4096;
+                if (const char* e = std::getenv("HK_NVDB_DENSE_MB")) budget_mb = (size_t)std::atol(e);
+                const size_t brick_bytes = (size_t)total * 512 * sizeof(float);
+                if (brick_bytes <= budget_mb * (size_t)(1 << 20)) {
+                    std::vector<float> bricks((size_t)total * 512);
+                    for (size_t b = 0; b < (size_t)total; ++b) {
+                        const uint2 e = table[b];
+                        float* dst = bricks.data() + b * 512;
+                        if (e.x == 0u) {
+                            float v;
+                            std::memcpy(&v, &e.y, 4);
+                            for (int n = 0; n < 512; ++n) dst[n] = v;
+                        } else
+                            for (int n = 0; n < 512; ++n) dst[n] = hknv::f32(m.nvdb_bytes, (long long)e.x + 96 + (long long)n * 4);
+                    }
+                    DevBuf* bb = new DevBuf();
+                    s->media_data.push_back(bb);
+                    HIP_TRY(bb->upload(bricks.data(), brick_bytes));
+                    o.nv_bricks = bb->as<float>();
+                }
+            }
         }
     }
     HIP_TRY(s->media.upload(dmed.data(), dmed.size() * sizeof(DMedium)));
@@ -1364,7 +1398,14 @@ extern "C" int32_t hk_stats_get(hk_ctx* c, hk_stats* out) {
             h.light_nodes += r.light_nodes;
             h.sh_nodes += r.sh_nodes;
             h.sh_tris += r.sh_tris;
+#ifdef HK_DEBUG_UTIL
+            for (int k = 0; k < 16; ++k) h.dbg[k] += r.dbg[k];
+#endif
         }
+#ifdef HK_DEBUG_UTIL
+        for (int k = 0; k < 8; ++k)
+            if (h.dbg[2 * k]) std::fprintf(stderr, "HK_DEBUG_UTIL[%d]: %.3f of %llu lane-slots\n", k, (double)h.dbg[2 * k + 1] / (double)h.dbg[2 * k], h.dbg[2 * k]);
+#endif
     }
     double tr = 0.0;
     for (auto& e : c->trace_events) {
@@ -1559,8 +1600,8 @@ extern "C" int32_t hk_test_mix(hk_ctx* c, hk_scene* sc, int32_t mat_idx, int32_t
 }
 extern "C" int32_t hk_test_medium(hk_ctx* c, hk_scene* sc, int32_t mode, int32_t medium_idx, int32_t n, const float* a3, const float* b3, const float* tmax,
                                   const float* lambda, float* out) {
-    if (!c || !sc || !a3 || !lambda || !out || (mode == 1 && (!b3 || !tmax))) return fail(HK_ERR_INVALID, "null argument");
-    if (mode != 0 && mode != 1) return fail(HK_ERR_INVALID, "mode must be 0 (sample_point) or 1 (majorant segments)");
+    if (!c || !sc || !a3 || !lambda || !out || (mode >= 1 && (!b3 || !tmax))) return fail(HK_ERR_INVALID, "null argument");
+    if (mode < 0 || mode > 2) return fail(HK_ERR_INVALID, "mode must be 0 (sample_point), 1 (majorant segments) or 2 (majorant segments with the zero-cell fast-forward)");
     if (medium_idx < 0 || medium_idx >= sc->d.n_media) return fail(HK_ERR_INVALID, "medium index out of range");
     HIP_TRY(hipSetDevice(c->device));
     const size_t stride = mode == 0 ? 13 : (size_t)hk::test_majorant_stride();

@@ -79,6 +79,30 @@ __device__ __forceinline__ int seg_next(SegTickets& it, int n_segments) {   // -
     for (SegTickets gw##_t = (st).dynamic_segments ? seg_open(ticket, (st).n_waves) : SegTickets{ticket, 0ull, 0}; gw##_t.cnt; gw##_t.cnt = nullptr) \
         for (int gw = (st).dynamic_segments ? seg_next(gw##_t, (st).n_waves) : global_wave(); gw < (st).n_waves; \
              gw = (st).dynamic_segments ? seg_next(gw##_t, (st).n_waves) : gw + physical_waves())
+// A kernel whose lanes leave nothing behind in their segment (the shadow kernels: results go to L[slot]) does not have to drain its
+// lanes at the end of every segment: SegStream hands the wave one segment after another — tickets in media scenes, static stride
+// otherwise — and the per-lane refill simply continues with the next segment's entries.  The only drain left is the one at the end
+// of the launch (the shadow walk of the cloud config ran a third of its lane-slots empty in the tails of its ~1000-entry segments).
+struct SegStream {
+    SegTickets tk;
+    int gw;        // next static segment (static mode)
+    int step;      // static stride
+    bool dynamic;
+};
+__device__ __forceinline__ SegStream stream_open(const DPathState& st, int* ticket, bool force_dynamic) {
+    SegStream s;
+    s.dynamic = force_dynamic || st.dynamic_segments != 0;
+    s.tk = s.dynamic ? seg_open(ticket, st.n_waves) : SegTickets{ticket, 0ull, 0};
+    s.gw = global_wave();
+    s.step = physical_waves();
+    return s;
+}
+__device__ __forceinline__ int stream_next(SegStream& s, int n_segments) {   // -> segment index, or n_segments when the stream is exhausted
+    if (s.dynamic) return seg_next(s.tk, n_segments);
+    const int g = s.gw;
+    s.gw = g < n_segments ? g + s.step : g;
+    return g < n_segments ? g : n_segments;
+}
 // ticket words: row = bounce depth (row max_depth + 1: camera / film), column = kernel
 enum { TK_TRACE = 0, TK_TRACK = 1, TK_SHADOW = 2, TK_ESCAPED = 3, TK_SCATTER = 4, TK_SHADE0 = 5, TK_CAMERA = 0, TK_FILM = 1 };
 __device__ __forceinline__ int* ticket_ptr(const DPathState& st, int row, int col) { return st.tickets + (size_t)(row * HK_TICKET_COLS + col) * (HK_TICKET_WAYS * HK_TICKET_STRIDE); }
@@ -105,6 +129,15 @@ __device__ __forceinline__ void wq_close(const WaveQ& q, int* cnt) {
     if (lane_id() == 0) *cnt = q.count;
 }
 
+#ifdef HK_DEBUG_UTIL
+#define HK_DBG_DECL unsigned long long dbg_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define HK_DBG(i, active) do { dbg_[2 * (i)] += 64; dbg_[2 * (i) + 1] += __popcll(__ballot(active)); } while (0)
+#define HK_DBG_FLUSH(stats) do { if (lane_id() == 0) for (int k_ = 0; k_ < 16; ++k_) (stats)->dbg[k_] += dbg_[k_]; } while (0)
+#else
+#define HK_DBG_DECL
+#define HK_DBG(i, active) do { } while (0)
+#define HK_DBG_FLUSH(stats) do { } while (0)
+#endif
 // per-wave statistics rows (summed on the host): plain read-modify-write, the row belongs to this wave
 __device__ __forceinline__ void wave_add(unsigned long long* dst, unsigned v) {
     unsigned s = v;
@@ -293,7 +326,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace(DPathState st, DScene 
         unsigned long long pending = __ballot(kind >= 0);
         while (pending) {
             int src = __ffsll((long long)pending) - 1;
-            int k = __shfl(kind, src);
+            const int k = __builtin_amdgcn_readlane(kind, src);   // src is wave-uniform: the kind and every count below stay in scalar registers
             bool mine = kind == k;
             unsigned long long m = __ballot(mine);
             int cnt = 0;
@@ -455,7 +488,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace_lean(DPathState st, DS
             unsigned long long pending = __ballot(kind >= 0);
             while (pending) {
                 int src = __ffsll((long long)pending) - 1;
-                int k = __shfl(kind, src);
+                const int k = __builtin_amdgcn_readlane(kind, src);   // src is wave-uniform: the kind and every count below stay in scalar registers
                 bool mine = kind == k;
                 unsigned long long m = __ballot(mine);
                 int cnt = 0;
@@ -518,28 +551,55 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace_lean(DPathState st, DS
 #define HK_MEDIA_WAVES 2
 #endif
 #ifndef HK_TRACK_ADVANCE
-#define HK_TRACK_ADVANCE 8
+#define HK_TRACK_ADVANCE 4
+#endif
+#ifndef HK_SKIP_ZERO
+#define HK_SKIP_ZERO 0
 #endif
 enum { TR_BUSY = -101, TR_EMPTY = -100, TR_SCATTER = -3, TR_ESCAPED = -2 };  // >= 0: reached its surface hit of that material kind
 
+// One open output segment of k_track: the wave owns its count words while it is open.
+struct TrackSeg {
+    int gw;                       // segment index, -1 = slot free
+    int esc, sca;                 // entries in the segment's escaped / scatter queues
+    int kind_count[HK_MAX_KINDS]; // entries in its per-kind queues
+};
 template <int MM>
 __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_per_eu(HK_MEDIA_WAVES))) k_track(DPathState st, DScene sc, DTables T, DFrame fr, int depth, DStats* stats) {
     const int lane = lane_id();
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     unsigned n_coll = 0;
-    HK_FOR_EACH_WAVE_SEGMENT_DYNAMIC(gw, st, ticket_ptr(st, depth, TK_TRACK)) {
-        const uint32_t* __restrict__ queue = st.medium_q + (size_t)gw * st.wave_cap;
-        const DPathGen g = st.gen[depth & 1];   // throughput / scattering vertex are updated IN PLACE in the current generation
-        const bool ones = depth == 0 && fr.implicit_ones;
-        const int n = *count_ptr(st, depth, Q_MEDIUM, gw);
-        WaveQ q_escaped = wq_open(st.escaped_q, st, gw);
-        q_escaped.count = *count_ptr(st, depth, Q_ESCAPED, gw);
-        WaveQ q_scatter = wq_open(st.scatter_q, st, gw);
-        int kind_count[HK_MAX_KINDS];
+    const DPathGen g = st.gen[depth & 1];   // throughput / scattering vertex are updated IN PLACE in the current generation
+    const bool ones = depth == 0 && fr.implicit_ones;
+    // The wave streams segment after segment (SegStream) WITHOUT draining its lanes in between: the collision count per path is so
+    // uneven that a third of the lane-slots of a segment-at-a-time walk sat empty in the segment's tail.  A finished path must be
+    // pushed into the queues of ITS segment, so two segments are open at any time — `cur` (tag cur_tag) feeds the refill, the other
+    // slot holds the previous segment until its last lane has finished — and every lane carries the tag of its segment.
+    SegStream stream = stream_open(st, ticket_ptr(st, depth, TK_TRACK), true);
+    TrackSeg seg[2];
+    seg[0].gw = seg[1].gw = -1;
+    int cur_tag = 0;
+    const uint32_t* __restrict__ queue = st.medium_q;
+    int n = 0, cursor = 0;
+    bool more = true;
+    auto open_seg = [&](TrackSeg& s, int gw) {
+        s.gw = gw;
+        s.esc = *count_ptr(st, depth, Q_ESCAPED, gw);
+        s.sca = 0;
 #pragma unroll
-        for (int k = 0; k < HK_MAX_KINDS; ++k) kind_count[k] = *count_ptr(st, depth, Q_MAT0 + k, gw);
-        int cursor = 0;     // wave-uniform: next unread entry of this wave's queue segment
-        int state = TR_EMPTY;
+        for (int k = 0; k < HK_MAX_KINDS; ++k) s.kind_count[k] = *count_ptr(st, depth, Q_MAT0 + k, gw);
+    };
+    auto close_seg = [&](TrackSeg& s) {
+        if (s.gw >= 0 && lane == 0) {
+            *count_ptr(st, depth, Q_SCATTER, s.gw) = s.sca;
+            *count_ptr(st, depth, Q_ESCAPED, s.gw) = s.esc;
+#pragma unroll
+            for (int k = 0; k < HK_MAX_KINDS; ++k) *count_ptr(st, depth, Q_MAT0 + k, s.gw) = s.kind_count[k];
+        }
+        s.gw = -1;
+    };
+    {
+        int state = TR_EMPTY, tag = 0;
         uint32_t slot = 0, pslot = 0;   // generation index of the lane's path; its path slot (pixel-sample id: where L lives)
         v3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 1), cur_o = mk3(0, 0, 0);
         S4 lambda = s4(0.0f), beta = s4(0.0f), r_u = s4(0.0f), r_l = s4(0.0f), base_a = s4(0.0f), base_s = s4(0.0f), base_Le = s4(0.0f), sm = s4(0.0f);
@@ -551,32 +611,65 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
         int k_in_seg = 0, segi = 0, medium_idx = 0;
         for (;;) {
             const unsigned long long busy_m = __ballot(state == TR_BUSY);
-            if (busy_m == 0ull || (64 - __popcll(busy_m) >= HK_REFILL_MIN_IDLE && cursor < n)) {
-                // ---- route the finished paths ----
-                wq_push(q_scatter, slot, state == TR_SCATTER);
-                wq_push(q_escaped, slot, state == TR_ESCAPED);
-                unsigned long long pending = __ballot(state >= 0);
-                while (pending) {
-                    int src = __ffsll((long long)pending) - 1;
-                    int k = __shfl(state, src);
-                    bool mine = state == k;
-                    unsigned long long m = __ballot(mine);
-                    int cnt = 0;
+            if (busy_m == 0ull || (64 - __popcll(busy_m) >= HK_REFILL_MIN_IDLE && (cursor < n || more))) {
+                // ---- route the finished paths into the queues of their own segment ----
 #pragma unroll
-                    for (int kk = 0; kk < HK_MAX_KINDS; ++kk) cnt = (kk == k) ? kind_count[kk] : cnt;
-                    if (mine) st.mat_q[((size_t)k * st.n_waves + gw) * st.wave_cap + cnt + __popcll(m & lt_mask)] = slot;
-                    int add = __popcll(m);
+                for (int tg = 0; tg < 2; ++tg) {
+                    TrackSeg& S = seg[tg];
+                    const bool sel = tag == tg && state != TR_BUSY && state != TR_EMPTY;
+                    if (__ballot(sel) == 0ull) continue;
+                    const size_t base = (size_t)S.gw * st.wave_cap;
+                    {
+                        const unsigned long long m = __ballot(sel && state == TR_SCATTER);
+                        if (sel && state == TR_SCATTER) st.scatter_q[base + S.sca + __popcll(m & lt_mask)] = slot;
+                        S.sca += __popcll(m);
+                    }
+                    {
+                        const unsigned long long m = __ballot(sel && state == TR_ESCAPED);
+                        if (sel && state == TR_ESCAPED) st.escaped_q[base + S.esc + __popcll(m & lt_mask)] = slot;
+                        S.esc += __popcll(m);
+                    }
+                    unsigned long long todo_k = __ballot(sel && state >= 0);
+                    while (todo_k) {
+                        int src = __ffsll((long long)todo_k) - 1;
+                        const int k = __builtin_amdgcn_readlane(state, src);   // wave-uniform: counts stay in scalar registers
+                        bool mine = sel && state == k;
+                        unsigned long long m = __ballot(mine);
+                        int cnt = 0;
 #pragma unroll
-                    for (int kk = 0; kk < HK_MAX_KINDS; ++kk) kind_count[kk] += (kk == k) ? add : 0;
-                    pending &= ~m;
+                        for (int kk = 0; kk < HK_MAX_KINDS; ++kk) cnt = (kk == k) ? S.kind_count[kk] : cnt;
+                        if (mine) st.mat_q[((size_t)k * st.n_waves + S.gw) * st.wave_cap + cnt + __popcll(m & lt_mask)] = slot;
+                        int add = __popcll(m);
+#pragma unroll
+                        for (int kk = 0; kk < HK_MAX_KINDS; ++kk) S.kind_count[kk] += (kk == k) ? add : 0;
+                        todo_k &= ~m;
+                    }
                 }
                 if (state != TR_BUSY) state = TR_EMPTY;
-                // ---- refill idle lanes from the wave's queue ----
+                // ---- the current segment is used up: open the next one in the other slot as soon as that slot's last lane is done ----
+                while (more && cursor >= n) {
+                    const int other = cur_tag ^ 1;
+                    const bool other_busy = __ballot(state == TR_BUSY && tag == other) != 0ull;
+                    if (other_busy) break;   // both slots hold lanes in flight: no third segment, the refill waits
+                    if (other == 0) close_seg(seg[0]); else close_seg(seg[1]);
+                    const int gw = stream_next(stream, st.n_waves);
+                    if (gw >= st.n_waves) {
+                        more = false;
+                        break;
+                    }
+                    if (other == 0) open_seg(seg[0], gw); else open_seg(seg[1], gw);
+                    cur_tag = other;
+                    queue = st.medium_q + (size_t)gw * st.wave_cap;
+                    n = *count_ptr(st, depth, Q_MEDIUM, gw);
+                    cursor = 0;
+                }
+                // ---- refill idle lanes from the current segment's queue ----
                 const unsigned long long want = __ballot(state == TR_EMPTY);
                 const int avail = n - cursor;
                 const int rank = __popcll(want & lt_mask);
                 if (state == TR_EMPTY && rank < avail) {
                     slot = queue[cursor + rank];
+                    tag = cur_tag;
                     float4 O = g.ray_o[slot], D = g.ray_d[slot];
                     ro = mk3(O.x, O.y, O.z);
                     rd = mk3(D.x, D.y, D.z);
@@ -601,7 +694,10 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
                 }
                 const int want_n = __popcll(want);
                 cursor += want_n < avail ? want_n : (avail > 0 ? avail : 0);
-                if (__ballot(state == TR_BUSY) == 0ull) break;
+                if (__ballot(state == TR_BUSY) == 0ull) {
+                    if (cursor >= n && !more) break;
+                    continue;
+                }
             }
             // The medium record is read through a wave-uniform index (scalar loads into SGPRs): lanes are served medium by medium
             // ("waterfall"), which is a single trip for the usual one-medium scene.
@@ -620,6 +716,9 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
                     if (!need) continue;
                     if (!in_seg) {
                         float seg0;
+#if HK_SKIP_ZERO
+                        majorant_skip_zero<MM>(it, med, segi);   // empty cells: DDA steps only, no majorant fetch, no outer iteration
+#endif
                         if (segi >= 256 || !majorant_next<MM>(it, med, base_a + base_s, seg0, seg1, sm))
                             survived = true;  // ran out of segments with the path still alive
                         else {
@@ -728,13 +827,9 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
                 }
             }
         }
-        wq_close(q_scatter, count_ptr(st, depth, Q_SCATTER, gw));
-        wq_close(q_escaped, count_ptr(st, depth, Q_ESCAPED, gw));
-        if (lane == 0) {
-#pragma unroll
-            for (int k = 0; k < HK_MAX_KINDS; ++k) *count_ptr(st, depth, Q_MAT0 + k, gw) = kind_count[k];
-        }
     }
+    close_seg(seg[0]);
+    close_seg(seg[1]);
     stats += global_wave();
     wave_add(&stats->collisions, n_coll);
 }
@@ -1211,23 +1306,33 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_shadow(DPathState st, DScene
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const int DONE = (int)0x80000000;
     unsigned n_nodes = 0, n_tris = 0, n_casts = 0, n_hits = 0;
-    HK_FOR_EACH_WAVE_SEGMENT(gw, st, ticket_ptr(st, depth, TK_SHADOW)) {
-    const uint32_t seg = (uint32_t)gw * (uint32_t)st.wave_cap;   // the segment's shadow records: entries seg .. seg + n - 1, streamed in order
-    const int n = *count_ptr(st, depth, Q_SHADOW, gw);
-    int cursor = 0;
+    SegStream stream = stream_open(st, ticket_ptr(st, depth, TK_SHADOW), false);
+    uint32_t seg = 0;   // current segment's shadow records: entries seg .. seg + n - 1, streamed in order
+    int n = 0, cursor = 0;
+    bool more = true;
     bool have = false;
     uint32_t slot = 0;
     LaneRay r;
     r.cur = DONE;
     for (;;) {
         const unsigned long long run_m = __ballot(have && r.cur != DONE);
-        if (run_m == 0ull || (64 - __popcll(run_m) >= HK_TRACE_MIN_IDLE && cursor < n)) {
+        if (run_m == 0ull || (64 - __popcll(run_m) >= HK_TRACE_MIN_IDLE && (cursor < n || more))) {
             if (have && r.cur == DONE) {   // finished: an unoccluded shadow ray delivers its contribution
                 if (r.best.prim < 0)
                     shadow_contribute(st, slot, s4(1.0f), s4(1.0f), s4(1.0f));
                 else
                     ++n_hits;
                 have = false;
+            }
+            while (more && cursor >= n) {   // this segment is used up: go on with the next one, the lanes in flight keep running
+                const int gw = stream_next(stream, st.n_waves);
+                if (gw >= st.n_waves) {
+                    more = false;
+                    break;
+                }
+                seg = (uint32_t)gw * (uint32_t)st.wave_cap;
+                n = *count_ptr(st, depth, Q_SHADOW, gw);
+                cursor = 0;
             }
             const unsigned long long want = __ballot(!have);
             const int avail = n - cursor;
@@ -1244,12 +1349,11 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_shadow(DPathState st, DScene
             const int want_n = __popcll(want);
             cursor += want_n < avail ? want_n : (avail > 0 ? avail : 0);
             if (__ballot(have) == 0ull) {
-                if (cursor >= n) break;
+                if (cursor >= n && !more) break;
                 continue;
             }
         }
         lane_ray_round<true, COUNT>(r, have && r.cur != DONE, sc, stack, lane, n_nodes, n_tris);
-    }
     }
     stats += global_wave();
     wave_add(&stats->rays_shadow, n_casts);
@@ -1262,7 +1366,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_shadow(DPathState st, DScene
 
 enum { SH_EMPTY = 0, SH_CAST = 1, SH_TRACK = 2 };
 #ifndef HK_SHADOW_TRACK_BATCH
-#define HK_SHADOW_TRACK_BATCH 2
+#define HK_SHADOW_TRACK_BATCH 4
 #endif
 
 template <bool COUNT, int MM>
@@ -1272,10 +1376,11 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
     const int lane = lane_id();
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     unsigned n_nodes = 0, n_tris = 0, n_casts = 0, n_hits = 0, n_coll = 0;
-    HK_FOR_EACH_WAVE_SEGMENT_DYNAMIC(gw, st, ticket_ptr(st, depth, TK_SHADOW)) {
-    const uint32_t rec0 = (uint32_t)gw * (uint32_t)st.wave_cap;   // the segment's shadow records: entries rec0 .. rec0 + n - 1
-    const int n = *count_ptr(st, depth, Q_SHADOW, gw);
-    int cursor = 0;
+    HK_DBG_DECL
+    SegStream stream = stream_open(st, ticket_ptr(st, depth, TK_SHADOW), true);
+    uint32_t rec0 = 0;   // current segment's shadow records: entries rec0 .. rec0 + n - 1 (the wave streams segment after segment)
+    int n = 0, cursor = 0;
+    bool more = true;
     int state = SH_EMPTY;
     uint32_t slot = 0;
     v3 ro = mk3(0, 0, 0), dir = mk3(0, 0, 1);
@@ -1294,7 +1399,17 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
     for (;;) {
         // ---- refill ----
         const unsigned long long busy_m = __ballot(state != SH_EMPTY);
-        if (busy_m == 0ull || (64 - __popcll(busy_m) >= HK_REFILL_MIN_IDLE && cursor < n)) {
+        if (busy_m == 0ull || (64 - __popcll(busy_m) >= HK_REFILL_MIN_IDLE && (cursor < n || more))) {
+            while (more && cursor >= n) {   // this segment is used up: go on with the next one, the lanes in flight keep running
+                const int gw = stream_next(stream, st.n_waves);
+                if (gw >= st.n_waves) {
+                    more = false;
+                    break;
+                }
+                rec0 = (uint32_t)gw * (uint32_t)st.wave_cap;
+                n = *count_ptr(st, depth, Q_SHADOW, gw);
+                cursor = 0;
+            }
             const unsigned long long want = ~busy_m;
             const int avail = n - cursor;
             const int rank = __popcll(want & lt_mask);
@@ -1315,8 +1430,8 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
             const int want_n = __popcll(want);
             cursor += want_n < avail ? want_n : (avail > 0 ? avail : 0);
             if (__ballot(state != SH_EMPTY) == 0ull) {
-                if (cursor >= n) break;
-                continue;  // every fetched ray was degenerate: fetch again
+                if (cursor >= n && !more) break;
+                continue;  // every fetched ray was degenerate (or the segment was empty): fetch again
             }
         }
         // ---- casts, for all lanes that need one (when enough of them wait, or nothing else can run) ----
@@ -1324,6 +1439,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
             const unsigned long long cast_m = __ballot(state == SH_CAST);
             const unsigned long long track_m = __ballot(state == SH_TRACK);
             if (cast_m != 0ull && (track_m == 0ull || __popcll(cast_m) >= HK_REFILL_MIN_IDLE)) {
+                HK_DBG(0, state == SH_CAST);
                 if (state == SH_CAST) {
                     bool opaque;
                     ++n_casts;
@@ -1409,9 +1525,13 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
                     for (int adv = 0; adv < HK_TRACK_ADVANCE; ++adv) {
                         const bool need = mine && state == SH_TRACK && !pending && !track_done;
                         if (__ballot(need) == 0ull) break;
+                        HK_DBG(1, need);
                         if (!need) continue;
                         if (!in_seg) {
                             float seg0;
+#if HK_SKIP_ZERO
+                            if (!(after_inner && is_black(sT))) majorant_skip_zero<MM>(it, med, segi);   // empty cells: DDA steps only
+#endif
                             if (after_inner && is_black(sT))
                                 track_done = true;
                             else if (segi >= 256 || !majorant_next<MM>(it, med, base_a + base_s, seg0, seg1, sm))
@@ -1449,6 +1569,10 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
                                 pending = true;
                         }
                     }
+                    HK_DBG(2, mine && state == SH_TRACK && pending);
+                    HK_DBG(3, state == SH_TRACK);
+                    HK_DBG(4, state == SH_CAST);
+                    HK_DBG(5, state == SH_EMPTY);
                     if (mine && state == SH_TRACK && pending) {
                         pending = false;
                         const float dt = pend_dt;
@@ -1502,8 +1626,8 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
             }
         }
     }
-    }
     stats += global_wave();
+    HK_DBG_FLUSH(stats);
     wave_add(&stats->collisions, n_coll);
     wave_add(&stats->rays_shadow, n_casts);
     wave_add(&stats->hits, n_hits);
@@ -1743,6 +1867,8 @@ __global__ void k_test_mix(DScene sc, int mat_idx, int n, const float* p3, const
 // media: mode 0 = sample_point (media.jl:1327-1370, 1527-1575; nanovdb.jl:400-469) -> out[13] = sigma_a4, sigma_s4, Le4, g;
 //        mode 1 = majorant iterator along a ray (media.jl:229-340, 625-729) -> out[1 + 3*HK_TEST_MAJ_SEGS] = segment count, then
 //                 (t_min, t_max, sigma_maj[0]) of the first HK_TEST_MAJ_SEGS segments.  Same MM instantiation as the tracking kernels.
+//        mode 2 = the same walk with majorant_skip_zero in front of every majorant_next (what the tracking kernels do): total
+//                 segment count incl. the skipped ones, then the first HK_TEST_MAJ_SEGS segments that were NOT skipped.
 #define HK_TEST_MAJ_SEGS 16
 template <int MM>
 __global__ void k_test_medium(DScene sc, DTables T, int mode, int medium_idx, int n, const float* a3, const float* b3, const float* tmax, const float* lambda, float* out) {
@@ -1763,11 +1889,15 @@ __global__ void k_test_medium(DScene sc, DTables T, int mode, int medium_idx, in
             float* r = out + (1 + 3 * HK_TEST_MAJ_SEGS) * (size_t)i;
             for (int k = 0; k < 1 + 3 * HK_TEST_MAJ_SEGS; ++k) r[k] = 0.0f;
             MajorantIter it = create_majorant_iterator<MM>(med, a, d, tmax[i]);
-            int count = 0;
+            int count = 0, kept = 0;
             float t0, t1;
             S4 sm;
-            while (count < 256 && majorant_next<MM>(it, med, base_a + base_s, t0, t1, sm)) {
-                if (count < HK_TEST_MAJ_SEGS) r[1 + 3 * count] = t0, r[2 + 3 * count] = t1, r[3 + 3 * count] = sm.x;
+            for (;;) {
+                if (mode == 2) majorant_skip_zero<MM>(it, med, count);   // the tracking kernels' fast-forward over zero cells
+                if (count >= 256 || !majorant_next<MM>(it, med, base_a + base_s, t0, t1, sm)) break;
+                // mode 1 records every segment, mode 2 the segments that survive the fast-forward (zero cells excluded)
+                if (kept < HK_TEST_MAJ_SEGS) r[1 + 3 * kept] = t0, r[2 + 3 * kept] = t1, r[3 + 3 * kept] = sm.x;
+                ++kept;
                 ++count;
             }
             r[0] = (float)count;

@@ -121,9 +121,12 @@ struct DMedium {
     float sigma_scale, Le_scale;
     int mres[3];
     const float* majorant;         // x + rx*(y + ry*z)
+    const uint32_t* maj_zero;      // bit c set <=> majorant[c] == 0: empty cells are skipped without touching the float grid
     const unsigned char* nvdb;     // NanoVDB bytes (tree part)
     const uint2* nv_blocks;        // flattened tree over the index bbox: {leaf offset (1-based, 0 = constant block), value bits}
     int nvb_min[3], nvb_dim[3];    // block-coordinate origin / extent of nv_blocks ([bx][by][bz], bz fastest)
+    const float* nv_bricks;        // optional: every block of the table materialised as a dense 8^3 brick (512 floats, leaf order): a voxel
+                                   // fetch is then ONE load at a computed address instead of table entry -> leaf value (null: use nv_blocks)
     float nv_background;           // value of every block outside the table
     long long root_off;            // 1-based like the reference
     int root_table_size;
@@ -257,6 +260,9 @@ struct DPathState {
 
 struct DStats {
     unsigned long long rays_closest, rays_shadow, nodes, tris, hits, vertices, collisions, light_nodes, sh_nodes, sh_tris;
+#ifdef HK_DEBUG_UTIL   // lane-utilisation bookkeeping of the media state machines (debug builds only: scratch/util_debug.sh)
+    unsigned long long dbg[16];
+#endif
 };
 
 struct DFrame {            // per-pass constants

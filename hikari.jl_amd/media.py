@@ -325,6 +325,41 @@ def build_nanovdb_majorant_grid(meta, bounds, res=(64, 64, 64)):
         qx, qy, qz = px - vec[0], py - vec[1], pz - vec[2]
         return (inv[0] * qx + inv[1] * qy + inv[2] * qz, inv[3] * qx + inv[4] * qy + inv[5] * qz, inv[6] * qx + inv[7] * qy + inv[8] * qz)
 
+    if all(inv[k] == 0 for k in (1, 2, 3, 5, 6, 7)):
+        # axis-aligned grid (the usual case): a cell's index range factorises per axis, so the box maximum is three successive
+        # 1-D range maxima (x, then y, then z) — the same integer ranges and the same voxel values as the general loop below
+        def axis_ranges(k, e, n_src):
+            a, b = inv[4 * k] * (e[0] - vec[k]), inv[4 * k] * (e[1] - vec[k])
+            lo = np.maximum(np.floor(np.minimum(a, b) - f32(1)).astype(np.int64), imin[k])
+            hi = np.minimum(np.ceil(np.maximum(a, b) + f32(1)).astype(np.int64), imax[k])
+            return lo, hi, np.clip(lo - org[k], 0, n_src - 1), np.clip(hi - org[k], 0, n_src - 1), (lo - org[k] < 0) | (hi - org[k] >= n_src), lo > hi
+
+        def reduce_axis(src, axis, c0, c1):
+            out_shape = list(src.shape)
+            out_shape[axis] = len(c0)
+            dst = np.zeros(out_shape, dtype=f32)
+            for i in range(len(c0)):
+                sl = [slice(None)] * 3
+                sl[axis] = slice(int(c0[i]), int(c1[i]) + 1)
+                dl = [slice(None)] * 3
+                dl[axis] = i
+                if c0[i] <= c1[i]:
+                    dst[tuple(dl)] = src[tuple(sl)].max(axis=axis)
+            return dst
+
+        rx_ = axis_ranges(0, ex, sx)
+        ry_ = axis_ranges(1, ey, sy)
+        rz_ = axis_ranges(2, ez, sz)
+        m = reduce_axis(reduce_axis(reduce_axis(np.maximum(pad, f32(0)).astype(f32), 0, rx_[2], rx_[3]), 1, ry_[2], ry_[3]), 2, rz_[2], rz_[3])
+        outside = rx_[4][:, None, None] | ry_[4][None, :, None] | rz_[4][None, None, :]
+        empty = rx_[5][:, None, None] | ry_[5][None, :, None] | rz_[5][None, None, :]
+        # a range entirely off the stored array leaves no voxel inside: clip() above would have picked an edge voxel
+        off = ((rx_[1] - org[0] < 0) | (rx_[0] - org[0] >= sx))[:, None, None] | ((ry_[1] - org[1] < 0) | (ry_[0] - org[1] >= sy))[None, :, None] | \
+              ((rz_[1] - org[2] < 0) | (rz_[0] - org[2] >= sz))[None, None, :]
+        m = np.where(off, f32(0), m)
+        m = np.where(outside, np.maximum(m, bg), m)
+        m = np.where(empty, f32(0), m)
+        return np.ascontiguousarray(np.transpose(m, (2, 1, 0))).reshape(-1).astype(f32)      # index x + rx*(y + ry*z)
     for iz in range(rz):
         for iy in range(ry):
             a = to_index(ex[0], ey[0][iy], ez[0][iz])          # vectors over ix

@@ -117,7 +117,7 @@ def cloud_density(n=(64, 64, 32), seed=7, fill=0.35):
     return d.astype(np.float32)
 
 
-def cloud_scene(width=1024, height=1024, kind="nanovdb", res=(128, 128, 64), sigma_scale=60.0):
+def cloud_scene(width=1024, height=1024, kind="nanovdb", res=(128, 128, 64), sigma_scale=60.0, majorant_res=(32, 32, 32)):
     """Config 4 stand-in: synthetic cloud in a 1.2 cube at (-0.6, 0.3, -0.6), sigma_a = 0, sigma_s = 1,
     g = 0.877, index-matched glass cube as MediumInterface(inside = cloud); Ambient(.03,.07,.23) + Directional(2.6,2.5,2.3)
     (examples/bomex_cloud_example.jl:131-143), matte ground plane; camera looking at the cloud."""
@@ -126,7 +126,7 @@ def cloud_scene(width=1024, height=1024, kind="nanovdb", res=(128, 128, 64), sig
     dens = cloud_density(res) * np.float32(sigma_scale)
     lo, hi = (-0.6, 0.3, -0.6), (0.6, 1.5, 0.6)
     if kind == "nanovdb":
-        med = NanoVDBMedium(dens, bounds=(lo, hi), sigma_a=RGBSpectrum(0.0), sigma_s=RGBSpectrum(1.0), g=0.877, majorant_res=(32, 32, 32))
+        med = NanoVDBMedium(dens, bounds=(lo, hi), sigma_a=RGBSpectrum(0.0), sigma_s=RGBSpectrum(1.0), g=0.877, majorant_res=tuple(majorant_res))
     else:
         med = GridMedium(dens, sigma_a=RGBSpectrum(0.0), sigma_s=RGBSpectrum(1.0), g=0.877, bounds=(lo, hi))
     s = Scene()

@@ -456,7 +456,9 @@ int32_t hk_test_mix(hk_ctx* ctx, hk_scene* scene, int32_t mat_idx, int32_t n, co
 /* point-wise media (volpath/media.jl, nanovdb.jl), medium `medium_idx` (0-based), lambda: 4n:
    mode 0 = sample_point at p = a3 (media.jl:1327-1370, 1527-1575; nanovdb.jl:400-469) -> out[13n] = sigma_a4, sigma_s4, Le4, g
    mode 1 = majorant iterator along ray (o = a3, d = b3, t_max) (media.jl:229-340, 625-729; nanovdb.jl:509-554)
-            -> out[49n] = number of segments (<= 256), then (t_min, t_max, sigma_maj[lambda 1]) of the first 16 segments */
+            -> out[49n] = number of segments (<= 256), then (t_min, t_max, sigma_maj[lambda 1]) of the first 16 segments
+   mode 2 = mode 1 walked the way the tracking kernels do — cells whose majorant is exactly 0 are fast-forwarded without fetching
+            the grid — -> out[49n] = number of segments INCLUDING the skipped ones, then the first 16 segments that were not skipped */
 int32_t hk_test_medium(hk_ctx* ctx, hk_scene* scene, int32_t mode, int32_t medium_idx, int32_t n, const float* a3, const float* b3,
                        const float* tmax, const float* lambda, float* out);
 /* hk_trace_closest through the traversal of the surfaces-only render path (k_trace_lean / k_shadow: while-while rounds with

@@ -431,6 +431,21 @@ def test_medium_pointwise_bit_exact(hk, oracle, gpu_ctx, which):
     hk._lib.check(L.hk_test_medium(gpu_ctx.h, sh, 1, 0, m, _pf(hk, o), _pf(hk, d), _pf(hk, tmax), _pf(hk, lam[:m]), _pf(hk, outm)), "hk_test_medium")
     assert np.array_equal(outm[:, 0], refm[:, 0]) and refm[:, 0].max() >= (1 if which == "homogeneous" else 4)
     assert np.array_equal(outm, refm), (which, np.abs(outm - refm).max())
+    # mode 2: the walk the tracking kernels really do — cells whose majorant is exactly 0 are fast-forwarded without fetching the
+    # grid (majorant_skip_zero).  Same total segment count (the 256-segment cap counts skipped cells too) and, among the oracle's
+    # first 16 segments, exactly the non-zero ones, bit for bit, in order.
+    out2 = np.zeros((m, 49), f32)
+    hk._lib.check(L.hk_test_medium(gpu_ctx.h, sh, 2, 0, m, _pf(hk, o), _pf(hk, d), _pf(hk, tmax), _pf(hk, lam[:m]), _pf(hk, out2)), "hk_test_medium")
+    assert np.array_equal(out2[:, 0], refm[:, 0])
+    segs_ref, segs_gpu = refm[:, 1:].reshape(m, 16, 3), out2[:, 1:].reshape(m, 16, 3)
+    n_ref = np.minimum(refm[:, 0], 16).astype(int)
+    skipped_any = 0
+    for i in range(0, m, 7):
+        keep = [k for k in range(n_ref[i]) if segs_ref[i, k, 2] != 0.0]
+        skipped_any += len(keep) < n_ref[i]
+        assert np.array_equal(segs_gpu[i, :len(keep)], segs_ref[i, keep]), (which, i)
+    if which not in ("homogeneous", "rgbgrid", "grid"):
+        assert skipped_any > 100                                                                # the clouds do have empty cells
     osc.close()
 
 

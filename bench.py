@@ -2,11 +2,12 @@
 """bench.py — Mrays/s of the VolPath hot path on BASELINE.json configs[1]:
 Cornell box (diffuse + area light), 800x800, depth 8, 256 spp, 1 x MI355X.
 
-A "step" is one wavefront pass of the hot path over one batch of synthetic input: SPP_PER_STEP (=64)
-samples of every pixel of the 800x800 frame carried through the 8-bounce loop (41 M paths in flight: the
-chip needs ~100 paths per resident lane for the deeper bounces of a pass to keep it busy; ~16 GB of path
-state in HBM).  The default 4 steps are exactly the 256-spp frame, so `seconds_to_256spp` is the timed
-region itself (--spp-per-step changes the batch; --steps defaults to 256 / spp-per-step).
+A "step" is one wavefront pass of the hot path over one batch of synthetic input: SPP_PER_STEP (=256)
+samples of every pixel of the 800x800 frame carried through the 8-bounce loop (164 M paths in flight, ~72 GB
+of path state of the 288 GB of HBM: the deeper bounces of a pass only keep the chip busy when the pass starts
+with hundreds of paths per resident lane — 5.9 G rays/s at 32 spp per pass, 6.3 at 64, 6.45 at 128, 6.56 at
+256).  The default single step is exactly the 256-spp frame, so `seconds_to_256spp` is the timed region itself
+(--spp-per-step changes the batch; --steps defaults to 256 / spp-per-step).
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
@@ -29,7 +30,7 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-W, H, DEPTH, SPP_PER_STEP, FULL_SPP = 800, 800, 8, 64, 256
+W, H, DEPTH, SPP_PER_STEP, FULL_SPP = 800, 800, 8, 256, 256
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 S_NODE, B_TRI, B_HIT, B_RAY_IN, B_HIT_OUT = 64, 36, 96, 32, 16   # SURVEY.md §8(d) algorithmic bytes per cast
 S_STATE = 104                  # compact path state, read + written once per path vertex
@@ -191,7 +192,7 @@ def main():
         def committed(stem):
             path = os.path.join(ROOT, "profiles", "%s_%s.json" % (stem, args.config))
             try:
-                return json.load(open(path)) if SPP_PER_STEP == 64 else {}     # the PMC passes were taken at 64 spp per step
+                return json.load(open(path)) if SPP_PER_STEP == 256 else {}     # the PMC passes were taken at the default 256 spp per step
             except (OSError, ValueError):
                 return {}
 

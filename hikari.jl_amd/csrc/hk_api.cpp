@@ -1216,12 +1216,15 @@ extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_
     fr.n_pixels_padded = fr.tiles_x * fr.tiles_y * 64;
     int S = I->p.samples_per_pass;
     if (S <= 0) {
-        // auto: ~48 M paths in flight (64 spp of an 800x800 frame).  The chip holds 256 CUs x 16..32 waves x 64 lanes, and the
-        // deeper bounces of a pass only keep it busy when the pass starts with ~100 paths per lane; path state is ~440 B per
-        // path, so this is < 20 GB of the 288 GB of HBM (halved until it fits in half of the free memory).
-        S = (int)((48L << 20) / fr.n_pixels_padded);
+        // auto: up to ~192 M paths in flight (256 spp of an 800x800 frame).  The chip holds 256 CUs x 16..32 waves x 64 lanes, and
+        // the deeper bounces of a pass only keep it busy when the pass starts with hundreds of paths per lane (Cornell 800^2: 5.9 G
+        // rays/s at 32 spp per pass, 6.3 at 64, 6.45 at 128, 6.56 at 256); path state is ~440 B per path, i.e. up to ~80 GB of the
+        // 288 GB of HBM, halved until it fits in half of the free memory.  HK_MAX_PATHS_M overrides the cap (millions of paths).
+        long max_paths = 192L << 20;
+        if (const char* e = std::getenv("HK_MAX_PATHS_M")) max_paths = std::atol(e) > 0 ? std::atol(e) << 20 : max_paths;
+        S = (int)(max_paths / fr.n_pixels_padded);
         if (S < 1) S = 1;
-        if (S > 64) S = 64;
+        if (S > 256) S = 256;
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
             while (S > 1 && (size_t)S * fr.n_pixels_padded * 440 > free_b / 2) S /= 2;

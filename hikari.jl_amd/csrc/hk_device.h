@@ -604,10 +604,14 @@ HKD float eval_f32(const DScene& sc, const DMaterial& m, int slot, const TexCtx&
 // ------------------------------------------------------------------------------------------------
 // pixel filter (filter.jl:733-953) and camera (camera/perspective.jl:95-128)
 // ------------------------------------------------------------------------------------------------
+// The reference's search is 20 branchless halvings whatever the table size (filter.jl:876-953).  Once hi - lo == 1 a further step
+// re-tests cdf[lo - 1] <= u — true by construction (cdf[0] = 0 <= u, or lo was set by a passed test) — and changes nothing, so the
+// loop may stop after ceil(log2(n)) steps with the identical index: 6 dependent table loads instead of 20 for the 48-entry filter
+// tables.  n is wave-uniform (kernel argument), so is the trip count.
 HKD int find_interval20(const float* cdf, float u, int n) {
     int lo = 1, hi = n + 1;
-#pragma unroll
-    for (int k = 0; k < 20; ++k) {
+    const int steps = n <= 1 ? 0 : (32 - __builtin_clz((unsigned)(n - 1)));
+    for (int k = 0; k < steps && k < 20; ++k) {
         int mid = (lo + hi) >> 1;
         bool c = cdf[mid - 1] <= u;
         lo = c ? mid : lo;
@@ -1091,6 +1095,35 @@ HKD BSDFSample sample_lambert(v3 wo, v3 n, v2 u, S4 f) {
 #include "hk_layered.h"
 namespace hkd {
 
+// MatteMaterial with its reflectance spectrum already evaluated: k_shade evaluates kd = uplift(clamp(Kd))(lambda) ONCE per vertex and
+// hands it to both the next-event evaluation and the BSDF sample (the two would each run the four sigmoid evaluations — a
+// square root and a division per wavelength — on the same inputs).  Same operations, same order as the generic entry points.
+HKD S4 matte_kd(const DScene& sc, const DTables& T, const DMaterial& m, const TexCtx& uv, S4 lambda) {
+    return eval_bounded(rgb_param_coef(sc, T, m.rgb[0], uv, UPLIFT_BOUNDED, true), lambda);
+}
+HKD S4 eval_matte_kd(S4 kd, v3 wo_w, v3 wi_w, v3 n, float& pdf) {  // spectral-eval.jl:371-398
+    pdf = 0.0f;
+    float ci = dot(wi_w, n), co = dot(wo_w, n);
+    if (ci * co < 0.0f) return s4(0.0f);
+    float ct = fabsf(ci);
+    if (ct < 1e-6f) return s4(0.0f);
+    pdf = ct / PI_F;
+    return kd / PI_F;
+}
+HKD BSDFSample sample_lambert(v3 wo, v3 n, v2 u, S4 f);
+HKD BSDFSample sample_matte_kd(const DScene& sc, const DMaterial& m, S4 kd, v3 wo_w, v3 n, const TexCtx& uv, v2 u) {  // :42-101
+    float wdn = dot(wo_w, n);
+    if (fabsf(wdn) < 1e-6f) return invalid_sample();
+    float sigma = eval_f32(sc, m, 0, uv);
+    S4 f;
+    if (sigma > 0.0f) {
+        float rf = 1.0f - 0.5f * sigma / (sigma + 0.33f);
+        f = kd * (rf / PI_F);
+    } else
+        f = kd * (1.0f / PI_F);
+    return sample_lambert(wo_w, n, u, f);
+}
+
 // KIND is a compile-time constant in the per-kind shade kernels (material-sorted queues)
 template <int KIND>
 HKD BSDFSample sample_bsdf(const DScene& sc, const DTables& T, const DMaterial& m, v3 wo_w, v3 n, const TexCtx& uv, S4 lambda, v2 u, float uc, bool regularize) {
@@ -1335,8 +1368,10 @@ HKD float4 env_lookup_uv(const DEnvMap& e, v2 uv) {  // nearest: sampled directi
 }
 HKD int find_interval_binary20(const float* cdf, int n, float u) {  // sampling.jl:305-333
     int lo = 1, hi = n;
-#pragma unroll
-    for (int k = 0; k < 20; ++k) {
+    // hi - lo at least halves per step; once lo == hi the remaining steps of the reference's fixed 20 re-test cdf[lo - 1] <= u
+    // (true by construction) and leave lo alone: floor(log2(n - 1)) + 1 steps give the identical index (10 for a 512-row map)
+    const int steps = n <= 1 ? 0 : (32 - __builtin_clz((unsigned)(n - 1)));
+    for (int k = 0; k < steps && k < 20; ++k) {
         int mid = (lo + hi + 1) / 2;
         bool c = cdf[mid - 1] <= u;
         lo = c ? mid : lo;

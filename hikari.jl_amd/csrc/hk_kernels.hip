@@ -553,6 +553,9 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace_lean(DPathState st, DS
 #ifndef HK_TRACK_ADVANCE
 #define HK_TRACK_ADVANCE 4
 #endif
+#ifndef HK_DELTA_ADVANCE
+#define HK_DELTA_ADVANCE 6   // k_track's own advance-loop length (the shadow walk keeps HK_TRACK_ADVANCE)
+#endif
 #ifndef HK_SKIP_ZERO
 #define HK_SKIP_ZERO 0
 #endif
@@ -710,7 +713,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
                 // ---- phase A: cheap steps (next majorant cell, free-flight sample, cell-boundary crossing) until every busy lane
                 //      either holds a tentative collision or has run out of segments ----
     #pragma unroll 1
-                for (int adv = 0; adv < HK_TRACK_ADVANCE; ++adv) {
+                for (int adv = 0; adv < HK_DELTA_ADVANCE; ++adv) {
                     const bool need = mine && state == TR_BUSY && !pending && !survived;
                     if (__ballot(need) == 0ull) break;
                     if (!need) continue;
@@ -1128,7 +1131,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
         Surface sf;
         v3 wo = mk3(0, 0, 1);
         DTriMeta meta{0u, 0u, 0u};
-        S4 lambda = s4(0.0f), beta = s4(0.0f), r_u = s4(0.0f);
+        S4 lambda = s4(0.0f), beta = s4(0.0f), r_u = s4(0.0f), kd_matte = s4(0.0f);
         uint32_t fl = 0, pslot = 0;
         int pdepth = 0, medium = -1;
         bool any_non_specular = false;
@@ -1165,6 +1168,8 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
             slot_to_pixel(fr, (int)pslot - k * fr.n_pixels_padded, px, py, inside);
             sctx = sobol_ctx(sob, T.sobol, px + 1, py + 1, fr.first_sample + k * fr.sample_stride, (int)pslot - k * fr.n_pixels_padded);
 
+            if (KIND == HK_MAT_MATTE) kd_matte = matte_kd(sc, T, sc.materials[st.mat_id[slot] & ~HK_MAT_EMISSIVE_BIT], TexCtx(sf.uv, meta.prim_index, H.z, H.w), lambda);
+
             // ---- K9: next-event estimation through the light BVH ----
             if (sc.n_lights > 0) {
                 const DMaterial& mat = sc.materials[st.mat_id[slot] & ~HK_MAT_EMISSIVE_BIT];
@@ -1179,7 +1184,8 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
                     LightSample ls = sample_light(sc, T, sel, sf.pi, lambda, u_light);
                     if (ls.pdf > 0.0f && !is_black(ls.Li)) {
                         float bsdf_pdf;
-                        S4 f = eval_bsdf<KIND>(sc, T, mat, wo, ls.wi, sf.ns, TexCtx(sf.uv, meta.prim_index, H.z, H.w), lambda, bsdf_pdf);
+                        S4 f = KIND == HK_MAT_MATTE ? eval_matte_kd(kd_matte, wo, ls.wi, sf.ns, bsdf_pdf)
+                                                    : eval_bsdf<KIND>(sc, T, mat, wo, ls.wi, sf.ns, TexCtx(sf.uv, meta.prim_index, H.z, H.w), lambda, bsdf_pdf);
                         if (!is_black(f)) {
                             float ct = fabsf(dot(ls.wi, sf.ns));
                             S4 Ld = beta * f * ls.Li * ct;
@@ -1226,7 +1232,8 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
                 float uc = (KIND == HK_MAT_GLASS || KIND > HK_MAT_CONDUCTOR) && KIND != HK_MAT_FALLBACK ? sobol_1d(sctx, base_dim + 4) : 0.0f;
                 v2 u = (KIND == HK_MAT_MIRROR || KIND == HK_MAT_GLASS || KIND == HK_MAT_THIN_DIELECTRIC) ? mk2(0.0f, 0.0f) : sobol_2d(sctx, base_dim + 6);
                 bool regularize = fr.regularize && any_non_specular;
-                BSDFSample s = sample_bsdf<KIND>(sc, T, mat, wo, sf.ns, TexCtx(sf.uv, meta.prim_index, H.z, H.w), lambda, u, uc, regularize);
+                BSDFSample s = KIND == HK_MAT_MATTE ? sample_matte_kd(sc, mat, kd_matte, wo, sf.ns, TexCtx(sf.uv, meta.prim_index, H.z, H.w), u)
+                                                    : sample_bsdf<KIND>(sc, T, mat, wo, sf.ns, TexCtx(sf.uv, meta.prim_index, H.z, H.w), lambda, u, uc, regularize);
                 if (s.pdf > 0.0f && !is_black(s.f)) {
                     float ct = fabsf(dot(s.wi, sf.ns));
                     nb = s.is_specular ? beta * s.f : beta * s.f * ct / s.pdf;

@@ -20,11 +20,11 @@ prof() {  # name, config, extra bench args, counters...
   python3 tools/rocpd_summary.py $O/$name/*/*_results.db > $O/${R}_$name.txt 2>&1
 }
 prof kernel_stats_cornell800 cornell ""
-prof kernel_stats_cloud1024 cloud "--steps 1 --warmup 1"
-prof kernel_stats_manylight1024 manylight "--steps 1 --warmup 1"
+prof kernel_stats_cloud1024 cloud "--warmup 1"
+prof kernel_stats_manylight1024 manylight "--warmup 1"
 prof kernel_stats_sky800 sky ""
 for cfg in cornell cloud manylight; do
-  extra="--steps 2 --warmup 1"; if [ "$cfg" != "cornell" ]; then extra="--steps 1 --warmup 1"; fi
+  extra="--warmup 1"
   prof pmc_fetch_$cfg $cfg "$extra" FETCH_SIZE
   prof pmc_write_$cfg $cfg "$extra" WRITE_SIZE
   prof pmc_l2_$cfg $cfg "$extra" TCC_HIT_sum TCC_MISS_sum

@@ -40,7 +40,7 @@ void launch_aux(hipStream_t, const DScene&, const DCamera&, int, int, float, flo
 void launch_postprocess(hipStream_t, const hk_postprocess_params&, const float*, const float*, float*, int, int);
 void launch_denoise_variance(hipStream_t, const float*, float*, int, int);
 void launch_denoise_atrous(hipStream_t, const hk_denoise_params&, int, const float*, const float*, const float*, const float*, float*, int, int);
-void launch_sobol_table(hipStream_t, const DSobol&, const DFrame&, uint32_t*, int);
+void launch_sobol_table(hipStream_t, const DSobol&, const DFrame&, uint2*, int);
 void launch_test_light(hipStream_t, const DScene&, const DTables&, int, int, int, const float*, const float*, const float*, float*);
 void launch_test_bsdf(hipStream_t, const DScene&, const DTables&, int, int, int, int, const float*, const float*, const float*, const float*, const float*, const float*, float*);
 void launch_test_mix(hipStream_t, const DScene&, int, int, const float*, const float*, const float*, int*);
@@ -1244,8 +1244,8 @@ extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_
         const int rows = 4 + 5 * (I->p.max_depth + 1);
         if (I->sobol_rows != rows || I->sobol_stride != fr.n_pixels_padded || I->sobol_log2 != sob.log2_spp || I->sobol_digits != sob.n_base4_digits ||
             I->sobol_x0 != x0 || I->sobol_y0 != y0 || I->sobol_tiles_x != fr.tiles_x) {
-            HIP_TRY(I->sobol_table.alloc((size_t)rows * fr.n_pixels_padded * sizeof(uint32_t)));
-            hk::launch_sobol_table(c->stream, sob, fr, I->sobol_table.as<uint32_t>(), rows);
+            HIP_TRY(I->sobol_table.alloc((size_t)rows * fr.n_pixels_padded * sizeof(uint2)));
+            hk::launch_sobol_table(c->stream, sob, fr, I->sobol_table.as<uint2>(), rows);
             HIP_TRY(hipGetLastError());
             I->sobol_rows = rows;
             I->sobol_stride = fr.n_pixels_padded;
@@ -1253,7 +1253,7 @@ extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_
             I->sobol_digits = sob.n_base4_digits;
             I->sobol_x0 = x0, I->sobol_y0 = y0, I->sobol_tiles_x = fr.tiles_x;
         }
-        sob.hi_table = I->sobol_table.as<uint32_t>();
+        sob.hi_table = I->sobol_table.as<uint2>();
         sob.hi_rows = rows;
         sob.hi_stride = fr.n_pixels_padded;
     }

@@ -205,19 +205,23 @@ HKD float sobol_sample(uint64_t a, int dimension, uint32_t scramble, const uint3
 // of them per path vertex, and per-lane cache-line lookups are what these kernels run out of (k_shade -11 % without them).
 // Digits i = i_hi .. i_lo of the permuted index (sobol.jl:225-262).  The full index is digits n-1 .. pow2 plus the last-bit
 // special case; the digits whose bits lie above the sample bits (shift >= log2_spp) do not depend on the sample index.
+// index (0..23) of the digit permutation chosen by the digits above: (mix_bits(higher ^ dmix) >> 24) % 24
+HKD int zsobol_perm_index(uint64_t higher, uint64_t dmix) {
+    uint64_t h = mix_bits(higher ^ dmix);
+    // (h >> 24) % 24 on a 40-bit value with 32-bit arithmetic: 2^32 mod 24 == 16
+    uint32_t xlo = (uint32_t)(h >> 24), xhi = (uint32_t)(h >> 56);
+    return (int)((xhi * 16u + xlo % 24u) % 24u);
+}
+HKD uint64_t zsobol_permute_digit(int p, int digit) {
+    const uint64_t pw = p < 8 ? 0xb1e19c6c78d8b4e4ull : (p < 16 ? 0x72d236c68d2d39c9ull : 0x93634b1b87271e4eull);
+    return (pw >> (8 * (p & 7) + 2 * digit)) & 3ull;
+}
 HKD uint64_t zsobol_digits(uint64_t morton, uint64_t dmix, int pow2, int i_hi, int i_lo) {
     uint64_t sample_index = 0;
     for (int i = i_hi; i >= i_lo; --i) {
         int shift = 2 * i - pow2;
         int digit = (int)((morton >> shift) & 3ull);
-        uint64_t higher = morton >> (shift + 2);
-        uint64_t h = mix_bits(higher ^ dmix);
-        // (h >> 24) % 24 on a 40-bit value with 32-bit arithmetic: 2^32 mod 24 == 16
-        uint32_t xlo = (uint32_t)(h >> 24), xhi = (uint32_t)(h >> 56);
-        int p = (int)((xhi * 16u + xlo % 24u) % 24u);
-        const uint64_t pw = p < 8 ? 0xb1e19c6c78d8b4e4ull : (p < 16 ? 0x72d236c68d2d39c9ull : 0x93634b1b87271e4eull);
-        uint64_t pd = (pw >> (8 * (p & 7) + 2 * digit)) & 3ull;
-        sample_index |= pd << shift;
+        sample_index |= zsobol_permute_digit(zsobol_perm_index(morton >> (shift + 2), dmix), digit) << shift;
     }
     return sample_index;
 }
@@ -234,11 +238,43 @@ HKD uint64_t zsobol_sample_index(uint64_t morton, int dimension, int log2_spp, i
     }
     return sample_index;
 }
-// same value, with the pixel digits read from the table entry `hi` (= their permuted digits >> log2_spp)
-HKD uint64_t zsobol_sample_index_cached(uint64_t morton, int dimension, int log2_spp, uint32_t hi) {
+// The permutation of a digit is chosen by a hash of the digits ABOVE it.  For the top sample digit those are the pixel's digits alone;
+// for the second one, the pixel's digits and the top sample digit (4 cases): per (pixel, dimension) five permutation indices, 5 bits
+// each, are tabulated next to the permuted pixel digits (k_sobol_table), and a draw hashes only the remaining sample digits
+// (4 instead of 6 at log2_spp = 12: two 64-bit mix_bits and two mod-24 fewer per draw, five draws per path vertex).
+HKD uint32_t zsobol_top_perms(uint64_t morton_pixel_shifted, uint64_t dmix, int log2_spp) {   // morton with zero sample bits
+    const int pow2 = log2_spp & 1;
+    const int i5 = zsobol_first_pixel_digit(log2_spp) - 1;
+    uint32_t packed = 0;
+    if (i5 >= pow2) packed = (uint32_t)zsobol_perm_index(morton_pixel_shifted >> (2 * i5 - pow2 + 2), dmix);
+    if (i5 - 1 >= pow2) {
+        const int shift5 = 2 * i5 - pow2, shift4 = shift5 - 2;
+        for (int d5 = 0; d5 < 4; ++d5)
+            packed |= (uint32_t)zsobol_perm_index((morton_pixel_shifted | ((uint64_t)d5 << shift5)) >> (shift4 + 2), dmix) << (5 + 5 * d5);
+    }
+    return packed;
+}
+// same value as zsobol_sample_index, with the pixel digits (`hi` = their permuted digits >> log2_spp) and the permutation indices
+// of the two top sample digits (`perms`, zsobol_top_perms) read from the table entry
+HKD uint64_t zsobol_sample_index_cached(uint64_t morton, int dimension, int log2_spp, uint32_t hi, uint32_t perms) {
     const int pow2 = log2_spp & 1;
     const uint64_t dmix = 0x55555555ull * (uint64_t)(int64_t)dimension;
-    uint64_t sample_index = ((uint64_t)hi << log2_spp) | zsobol_digits(morton, dmix, pow2, zsobol_first_pixel_digit(log2_spp) - 1, pow2);
+    const int i5 = zsobol_first_pixel_digit(log2_spp) - 1;
+    uint64_t sample_index = (uint64_t)hi << log2_spp;
+    int next = i5;
+    if (i5 >= pow2) {
+        const int shift5 = 2 * i5 - pow2;
+        const int d5 = (int)((morton >> shift5) & 3ull);
+        sample_index |= zsobol_permute_digit((int)(perms & 31u), d5) << shift5;
+        next = i5 - 1;
+        if (i5 - 1 >= pow2) {
+            const int shift4 = shift5 - 2;
+            const int d4 = (int)((morton >> shift4) & 3ull);
+            sample_index |= zsobol_permute_digit((int)((perms >> (5 + 5 * d5)) & 31u), d4) << shift4;
+            next = i5 - 2;
+        }
+    }
+    sample_index |= zsobol_digits(morton, dmix, pow2, next, pow2);
     if (pow2) {
         uint64_t digit = morton & 1ull;
         uint64_t xb = mix_bits((morton >> 1) ^ dmix) & 1ull;
@@ -266,7 +302,7 @@ HKD uint64_t zsobol_hash(int dimension, uint32_t seed) {
 struct SobolCtx {
     uint64_t morton_base;  // encode_morton2(px,py) << log2_spp | sample_idx
     const uint32_t* mats;
-    const uint32_t* hi;    // pixel-digit table column of this pixel (null: compute every digit)
+    const uint2* hi;       // pixel-digit table column of this pixel (null: compute every digit)
     int hi_rows, hi_stride;
     int log2_spp, n_digits;
     uint32_t seed;
@@ -289,7 +325,10 @@ HKD SobolCtx sobol_ctx(const DSobol& s, const uint32_t* mats, int px, int py, in
 }
 HKD uint64_t sobol_index(const SobolCtx& c, int dim) {
     const int row = sobol_row(dim);
-    if (c.hi != nullptr && row >= 0 && row < c.hi_rows) return zsobol_sample_index_cached(c.morton_base, dim, c.log2_spp, c.hi[(size_t)row * c.hi_stride]);
+    if (c.hi != nullptr && row >= 0 && row < c.hi_rows) {
+        const uint2 e = c.hi[(size_t)row * c.hi_stride];
+        return zsobol_sample_index_cached(c.morton_base, dim, c.log2_spp, e.x, e.y);
+    }
     return zsobol_sample_index(c.morton_base, dim, c.log2_spp, c.n_digits);
 }
 HKD float sobol_1d(const SobolCtx& c, int dim) {  // sobol.jl:269-282

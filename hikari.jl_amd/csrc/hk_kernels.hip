@@ -157,7 +157,7 @@ __device__ __forceinline__ void slot_to_pixel(const DFrame& fr, int slot_in_samp
 
 // Pixel-digit table of the ZSobol index (DSobol::hi_table): entry (row, pixel slot) = the permuted base-4 digits above the
 // sample bits, for the dimension of that row.  Built once per film size / sampler seed.
-__global__ void __launch_bounds__(256) k_sobol_table(DSobol sob, DFrame fr, uint32_t* table, int rows) {
+__global__ void __launch_bounds__(256) k_sobol_table(DSobol sob, DFrame fr, uint2* table, int rows) {
     const long total = (long)rows * fr.n_pixels_padded;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         int row = (int)(i / fr.n_pixels_padded), pix = (int)(i - (long)row * fr.n_pixels_padded);
@@ -168,8 +168,9 @@ __global__ void __launch_bounds__(256) k_sobol_table(DSobol sob, DFrame fr, uint
         uint64_t m = (left_shift2((uint64_t)(uint32_t)(py + 1)) << 1) | left_shift2((uint64_t)(uint32_t)(px + 1));
         uint64_t morton = m << sob.log2_spp;
         const int pow2 = sob.log2_spp & 1;
-        uint64_t hi = zsobol_digits(morton, 0x55555555ull * (uint64_t)(int64_t)dim, pow2, sob.n_base4_digits - 1, zsobol_first_pixel_digit(sob.log2_spp));
-        table[i] = (uint32_t)(hi >> sob.log2_spp);
+        const uint64_t dmix = 0x55555555ull * (uint64_t)(int64_t)dim;
+        uint64_t hi = zsobol_digits(morton, dmix, pow2, sob.n_base4_digits - 1, zsobol_first_pixel_digit(sob.log2_spp));
+        table[i] = make_uint2((uint32_t)(hi >> sob.log2_spp), zsobol_top_perms(morton, dmix, sob.log2_spp));
     }
 }
 
@@ -2310,7 +2311,7 @@ void launch_test_bsdf(hipStream_t s, const DScene& sc, const DTables& T, int mod
 void launch_test_light(hipStream_t s, const DScene& sc, const DTables& T, int mode, int light_idx, int n, const float* p3, const float* in3, const float* lambda, float* out) {
     hipLaunchKernelGGL(k_test_light, dim3(grid_for(n, 64, 4096)), dim3(64), 0, s, sc, T, mode, light_idx, n, p3, in3, lambda, out);
 }
-void launch_sobol_table(hipStream_t s, const DSobol& sob, const DFrame& fr, uint32_t* table, int rows) {
+void launch_sobol_table(hipStream_t s, const DSobol& sob, const DFrame& fr, uint2* table, int rows) {
     hipLaunchKernelGGL(k_sobol_table, dim3(grid_for((long)rows * fr.n_pixels_padded > 0x3fffffff ? 0x3fffffff : rows * fr.n_pixels_padded, 256, 8192)), dim3(256), 0, s, sob, fr, table, rows);
 }
 void launch_postprocess(hipStream_t s, const hk_postprocess_params& P, const float* src, const float* depth, float* dst, int h, int w) {

@@ -205,7 +205,7 @@ struct DSobol {
     // Pixel part of the permuted ZSobol index, per (dimension row, pixel slot): the base-4 digits above the sample bits and
     // their permutations depend on (pixel, dimension) only, so they are tabulated once per film size (10 of the 16 digit
     // hashes of a draw at 800^2).  row = sobol_row(dimension), entry = permuted digits >> log2_spp.  Null = compute in full.
-    const uint32_t* hi_table;
+    const uint2* hi_table;     // x = permuted digits above the sample bits (>> log2_spp); y = permutation indices of the two top SAMPLE digits (zsobol_top_perms)
     int hi_rows, hi_stride;   // rows available, entries per row (= n_pixels_padded)
 };
 

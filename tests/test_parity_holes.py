@@ -594,3 +594,30 @@ def test_full_size_cloud(hk, oracle):
     rel_mse, frac = frame_metrics(g, r)
     assert rel_mse <= 1e-3 and frac >= 0.99, (rel_mse, frac)
     assert int(st.medium_collisions) == int(ost.medium_collisions) and int(st.medium_collisions) > 10_000
+
+
+# ---------------------------------------------------------------------------------------------------- a8: tabulated ZSobol digits
+@pytest.mark.parametrize("spp_setting", [64, 8192, 40000])
+def test_zsobol_pixel_table_all_index_widths(hk, oracle, spp_setting):
+    """The render kernels read the permuted pixel digits and the permutation indices of the two top sample digits from a table
+    (k_sobol_table, zsobol_top_perms); hk_test_sobol exercises the untabulated arithmetic only.  Frames are therefore compared
+    with the oracle for an even (log2 = 12: every `samples` <= 4096), an odd (8192 -> 13) and a wide (40000 -> 16) index width —
+    a handful of samples of each, on a ragged film — bit-tight: a wrong digit would decorrelate every pixel."""
+    from hikari_jl_amd import scenes
+    w, h = 37, 29
+    s, film, cam = scenes.cornell_box(w, h, light="area")
+    kw = dict(max_depth=4, samples=spp_setting)
+    p = hk.integrator_params(**kw)
+    osc = oracle.OracleScene(s)
+    acc, ost = osc.render(p, cam, w, h, 3, first=5)
+    ref = oracle.finalize(acc, w, h)
+    vp = hk.VolPath(**kw)
+    vp._ensure(film)
+    vp.clear()
+    vp.reset_stats()
+    vp.render_samples(s, film, cam, 3, first=5)
+    st = vp.stats()
+    vp.close()
+    rel_mse, frac = frame_metrics(film.framebuffer, ref)
+    assert rel_mse <= 1e-5 and frac >= 0.995, (spp_setting, rel_mse, frac)
+    assert abs(int(st.rays_closest) - int(ost.rays_closest)) <= 0.002 * ost.rays_closest + 4

@@ -37,13 +37,16 @@ def cases():
     }
 
 
-def render(name):
+STATISTICAL = ("slab_homogeneous", "coated_diffuse")   # RNG streams seeded from float bit patterns: compared through an independent second frame
+
+
+def render(name, first=1):
     import hikari_jl_amd as hk
     import oracle
     build, kw, (w, h) = cases()[name]
     scene, film, cam = build(w, h)
     osc = oracle.OracleScene(scene)
-    acc, st = osc.render(hk.integrator_params(**kw), cam, w, h, kw["samples"])
+    acc, st = osc.render(hk.integrator_params(**kw), cam, w, h, kw["samples"], first=first)
     osc.close()
     return oracle.finalize(acc, w, h), np.array([int(st.rays_closest), int(st.rays_shadow), int(st.path_vertices)], np.int64)
 
@@ -65,7 +68,7 @@ def kat_vectors():
 
 def table_hashes():
     d = os.path.join(ROOT, "hikari.jl_amd", "data")
-    return {f: hashlib.sha256(open(os.path.join(d, f), "rb").read()).hexdigest() for f in ("sobol_matrices.bin", "cie_xyz.bin", "metal_spectra.bin", "hosek_wilkie_sky.bin")}
+    return {f: hashlib.sha256(open(os.path.join(d, f), "rb").read()).hexdigest() for f in ("sobol_matrices.bin", "cie_xyz.bin", "metal_spectra.bin", "hosek_wilkie_sky.bin", "medium_presets.json")}
 
 
 def main():
@@ -73,7 +76,10 @@ def main():
     oracle.build()
     for name in cases():
         img, counts = render(name)
-        np.savez_compressed(os.path.join(HERE, name + ".npz"), framebuffer=img, counts=counts)
+        extra = {}
+        if name in STATISTICAL:   # frame B: the NEXT `samples` sample indices — the yardstick of the statistical comparison
+            extra["framebuffer_b"] = render(name, first=cases()[name][1]["samples"] + 1)[0]
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), framebuffer=img, counts=counts, **extra)
         print(name, img.shape, float(img.mean()), counts)
     np.savez_compressed(os.path.join(HERE, "kat_vectors.npz"), **kat_vectors())
     json.dump(table_hashes(), open(os.path.join(HERE, "data_tables.json"), "w"), indent=1)

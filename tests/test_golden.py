@@ -77,7 +77,7 @@ def test_oracle_reproduces_kat_vectors():
 def test_gpu_matches_golden_frames(hk, name):
     """the HIP path through the C-ABI against the committed frames: the frame-parity bar of SURVEY 8(d) (relMSE <= 1e-3 and
     >= 99 % of pixels within 1e-2); the medium and coated-walk cases are statistical (their RNG streams are seeded from the bit
-    patterns of rays / directions, so one differing ulp re-rolls a walk): mean within 5 %"""
+    patterns of rays / directions, so one differing ulp re-rolls a walk): no farther from frame A than the committed independent frame B"""
     mk = _mk()
     build, kw, (w, h) = mk.cases()[name]
     scene, film, cam = build(w, h)
@@ -89,7 +89,15 @@ def test_gpu_matches_golden_frames(hk, name):
     got, ref = film.framebuffer, g["framebuffer"]
     assert np.isfinite(got).all()
     if name in ("slab_homogeneous", "coated_diffuse"):   # RNG streams seeded from float bit patterns (media, coated random walks)
-        assert abs(got.mean() - ref.mean()) <= 0.05 * ref.mean()
+        # the committed frame B (the next sample indices, same oracle) is the yardstick: the GPU frame must be no farther from frame A
+        # than an independent frame of the oracle itself is, and its mean no further off than B's
+        b = g["framebuffer_b"]
+
+        def dist(x, y):
+            return float(np.mean((x - y) ** 2 / (0.25 * (x + y) ** 2 + 1e-2)))
+
+        assert dist(got, ref) <= 1.5 * dist(b, ref) + 1e-4, (name, dist(got, ref), dist(b, ref))
+        assert abs(got.mean() - ref.mean()) <= max(0.02 * ref.mean(), 1.5 * abs(b.mean() - ref.mean())), (name, got.mean(), ref.mean(), b.mean())
         return
     rel_mse = float(np.mean((got - ref) ** 2 / (ref ** 2 + 1e-3)))
     num = np.sqrt(((got - ref) ** 2).sum(axis=2))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""profiles/pmc_traffic.json from three rocprofv3 rocpd databases (separate --pmc passes of the same bench command):
-    pmc_traffic.py FETCH.db WRITE.db L2.db "<description of the command>" > profiles/pmc_traffic.json
+"""profiles/pmc_traffic_<config>.json from three rocprofv3 rocpd databases (separate --pmc passes of the same bench command):
+    pmc_traffic.py FETCH.db WRITE.db L2.db "<description of the command>" > profiles/pmc_traffic_<config>.json
 Per kernel family (k_trace*, k_shade*, k_shadow*, k_camera, k_film, k_track*, k_scatter): FETCH_SIZE / WRITE_SIZE averages per
 launch in KB and hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024 — FETCH_SIZE doubled per
 /opt/skills/guides/MI355X_MICROARCH.md (gfx950 tallies the 128-B requests of these 16 B/lane reads at 64 B); raw kept alongside."""

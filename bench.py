@@ -171,7 +171,7 @@ def main():
     result = None
     if rank == 0:
         # ---- roofline of the dominant kernel: counts from an instrumented (untimed) replay of the same steps ----
-        timed = dict(trace=st.seconds_trace, shadow=st.seconds_shadow, shade=st.seconds_shade, other=st.seconds_other)
+        timed = dict(trace=st.seconds_trace, shadow=st.seconds_shadow, shade=st.seconds_shade, media=st.seconds_media, other=st.seconds_other)
         launches = dict(trace=int(st.trace_launches), shadow=int(st.shadow_launches), shade=int(st.shade_launches))
         casts = dict(trace=int(st.rays_closest), shadow=int(st.rays_shadow))
         vertices = int(st.path_vertices)

@@ -101,7 +101,7 @@ struct hk_ctx {
     int count_nodes = 0, time_kernels = 0;
     // timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_events;   // class 0
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> class_events[4];  // 1 shadow, 2 shade, 3 other
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> class_events[5];  // 1 shadow, 2 shade, 3 other, 4 media
     uint64_t shadow_launches = 0, shade_launches = 0;
     std::vector<hipEvent_t> event_pool;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
@@ -1308,7 +1308,7 @@ extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_
             c->trace_launches++;
             int first_kind = 1;
             if (sc->d.n_media > 0) {
-                timed(3, [&] { hk::launch_medium(s, c->n_cu, I->st, sc->d, c->tables, fr, sob, depth, dstats); });
+                timed(4, [&] { hk::launch_medium(s, c->n_cu, I->st, sc->d, c->tables, fr, sob, depth, dstats); });
                 first_kind = 0;
             }
             if (sc->d.has_escape_lights) timed(3, [&] { hk::launch_escaped(s, light_blocks, I->st, sc->d, c->tables, fr, depth); });
@@ -1440,8 +1440,8 @@ extern "C" int32_t hk_stats_get(hk_ctx* c, hk_stats* out) {
     out->tris_tested = h.tris + h.sh_tris;
     out->shadow_launches = c->shadow_launches;
     out->shade_launches = c->shade_launches;
-    double cls[4] = {0, 0, 0, 0};
-    for (int k = 1; k < 4; ++k)
+    double cls[5] = {0, 0, 0, 0, 0};
+    for (int k = 1; k < 5; ++k)
         for (auto& e : c->class_events[k]) {
             float ms = 0.0f;
             if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) cls[k] += ms * 1e-3;
@@ -1449,6 +1449,7 @@ extern "C" int32_t hk_stats_get(hk_ctx* c, hk_stats* out) {
     out->seconds_shadow = cls[1];
     out->seconds_shade = cls[2];
     out->seconds_other = cls[3];
+    out->seconds_media = cls[4];
     {   // SURVEY 8(d) algorithmic bytes over the counted units
         const uint64_t hits_closest = h.hits < h.rays_closest ? h.hits : h.rays_closest;   // shading attributes are fetched once per accepted closest hit
         out->bytes_algorithmic_trace = h.rays_closest * (32 + 16) + 64 * h.nodes + 36 * h.tris + 96 * hits_closest;

@@ -1170,6 +1170,58 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
             sctx = sobol_ctx(sob, T.sobol, px + 1, py + 1, fr.first_sample + k * fr.sample_stride, (int)pslot - k * fr.n_pixels_padded);
 
             if (KIND == HK_MAT_MATTE) kd_matte = matte_kd(sc, T, sc.materials[st.mat_id[slot] & ~HK_MAT_EMISSIVE_BIT], TexCtx(sf.uv, meta.prim_index, H.z, H.w), lambda);
+#ifdef HK_ABLATE
+            // cost attribution by duplication (tools/ablate.md): stage HK_ABLATE runs a second time on laundered inputs, its result is
+            // kept alive but unused; the k_shade time delta against the plain build is that stage's cost.  Never defined in the product.
+            {
+                float sink = 0.0f;
+                if (HK_ABLATE == 1) {   // every Sobol draw of a matte vertex
+                    uint32_t ps2 = pslot;
+                    int d2 = base_dim;
+                    asm volatile("" : "+v"(ps2));
+                    asm volatile("" : "+s"(d2));
+                    int k2 = (int)ps2 / fr.n_pixels_padded, px2, py2;
+                    bool in2;
+                    slot_to_pixel(fr, (int)ps2 - k2 * fr.n_pixels_padded, px2, py2, in2);
+                    SobolCtx c2 = sobol_ctx(sob, T.sobol, px2 + 1, py2 + 1, fr.first_sample + k2 * fr.sample_stride, (int)ps2 - k2 * fr.n_pixels_padded);
+                    v2 a = sobol_2d(c2, d2 + 3), b = sobol_2d(c2, d2 + 6);
+                    sink = sobol_1d(c2, d2 + 1) + a.x + a.y + b.x + b.y + sobol_1d(c2, d2 + 7);
+                }
+                if (HK_ABLATE == 2 && sc.n_lights > 0) {   // light-BVH descent
+                    float u2 = H.z, pmf2;
+                    asm volatile("" : "+v"(u2));
+                    unsigned dummy = 0;
+                    sink = (float)bvh_sample_light(sc, sf.pi, sf.ns, u2, pmf2, dummy) + pmf2;
+                }
+                if (HK_ABLATE == 3 && sc.n_lights > 0) {   // sample_light on a pseudo-random light
+                    uint32_t li = pslot;
+                    asm volatile("" : "+v"(li));
+                    LightSample l2 = sample_light(sc, T, sc.lights[li % (uint32_t)sc.n_lights], sf.pi, lambda, mk2(H.z, H.w));
+                    sink = l2.pdf + l2.Li.x + l2.Li.w + l2.wi.x + l2.p_light.z;
+                }
+                if (HK_ABLATE == 4) {   // matte_kd (spectral reflectance at four wavelengths)
+                    S4 l2 = lambda;
+                    asm volatile("" : "+v"(l2.x), "+v"(l2.y), "+v"(l2.z), "+v"(l2.w));
+                    S4 k2 = matte_kd(sc, T, sc.materials[st.mat_id[slot] & ~HK_MAT_EMISSIVE_BIT], TexCtx(sf.uv, meta.prim_index, H.z, H.w), l2);
+                    sink = k2.x + k2.y + k2.z + k2.w;
+                }
+                if (HK_ABLATE == 5) {   // surface_at
+                    float b2 = H.z;
+                    asm volatile("" : "+v"(b2));
+                    Surface s2 = surface_at(sc, prim, b2, H.w, ro, rd, t_hit);
+                    sink = s2.pi.x + s2.n.y + s2.ns.z + s2.uv.x + s2.area;
+                }
+                if (HK_ABLATE == 6) {   // eval_matte_kd + sample_matte_kd on laundered directions
+                    v3 w2 = wo;
+                    asm volatile("" : "+v"(w2.x), "+v"(w2.y), "+v"(w2.z));
+                    float p2;
+                    S4 f2 = eval_matte_kd(kd_matte, w2, sf.n, sf.ns, p2);
+                    BSDFSample s2 = sample_matte_kd(sc, sc.materials[st.mat_id[slot] & ~HK_MAT_EMISSIVE_BIT], kd_matte, w2, sf.ns, TexCtx(sf.uv, meta.prim_index, H.z, H.w), mk2(H.z, H.w));
+                    sink = f2.x + f2.w + p2 + s2.pdf + s2.wi.x + s2.f.y;
+                }
+                asm volatile("" : : "v"(sink));
+            }
+#endif
 
             // ---- K9: next-event estimation through the light BVH ----
             if (sc.n_lights > 0) {

@@ -297,6 +297,7 @@ typedef struct hk_stats {
        triangle tested + 96 per accepted hit (closest-hit only) + 16 (hit out); per path vertex 2*104 (state read + written) + 64
        (material record) + 96 (light record) + 60 per light-BVH node.  The node / triangle terms need counter flag bit 0. */
     uint64_t bytes_algorithmic_trace, bytes_algorithmic_shadow, bytes_algorithmic_shade;
+    double seconds_media;      /* HIP-event sum of the delta-tracking kernels (k_track + k_scatter); not part of seconds_other */
 } hk_stats;
 
 typedef struct hk_ctx hk_ctx;

@@ -1283,6 +1283,12 @@ extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_
     while (done < n_samples) {
         int k = n_samples - done < S ? n_samples - done : S;
         fr.samples_in_pass = k;
+        {   // reciprocal of the pass's sample count: M = ceil(2^(30+L) / k), L = ceil(log2 k); exact for slots below 2^30 (checked above)
+            int L = 0;
+            while ((1 << L) < k) ++L;
+            fr.s_shr = 30 + L;
+            fr.s_mul = (uint32_t)((((uint64_t)1 << fr.s_shr) + (uint64_t)k - 1) / (uint64_t)k);
+        }
         fr.first_sample = first_sample_idx + done * sample_stride;
         auto timed = [&](int cls, auto&& fn) -> int {
             hipEvent_t e0 = nullptr, e1 = nullptr;

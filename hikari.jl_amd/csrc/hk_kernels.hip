@@ -145,6 +145,14 @@ __device__ __forceinline__ void wave_add(unsigned long long* dst, unsigned v) {
     if (lane_id() == 0 && s) *dst += (unsigned long long)s;
 }
 
+// Path slot of a pass -> (pixel slot, pass-sample k).  The samples of a pixel are ADJACENT slots (slot = pixel slot * S + k): a wave of
+// camera rays is 64 samples of one pixel, the per-(pixel, dimension) sampler tables are read by neighbouring lanes, and k_film walks
+// a contiguous run.  Division by the pass's sample count through a host-made reciprocal (DFrame::s_mul / s_shr, exact below 2^30).
+__device__ __forceinline__ void split_slot(const DFrame& fr, uint32_t slot, int& pix, int& k) {
+    const uint32_t q = (uint32_t)(((uint64_t)slot * fr.s_mul) >> fr.s_shr);
+    pix = (int)q;
+    k = (int)(slot - q * (uint32_t)fr.samples_in_pass);
+}
 __device__ __forceinline__ void slot_to_pixel(const DFrame& fr, int slot_in_sample, int& px, int& py, bool& inside) {
     int tile = slot_in_sample >> 6, l = slot_in_sample & 63;
     int tx = tile % fr.tiles_x, ty = tile / fr.tiles_x;
@@ -184,18 +192,19 @@ __global__ void __launch_bounds__(256) k_camera(DPathState st, DFrame fr, DTable
     HK_FOR_EACH_WAVE_SEGMENT(gw, st, ticket_ptr(st, st.ticket_rows - 1, TK_CAMERA)) {
     WavePos out{0};
     const size_t seg = (size_t)gw * st.wave_cap;
-    // wave w generates chunks w, w+W, w+2W, ... (8x8 pixel tiles interleaved across waves for load balance)
+    // wave w generates chunks w, w+W, w+2W, ... (64 consecutive slots = samples of one pixel, or of 64 / S pixels; interleaved across waves for load balance)
     for (int chunk = gw; chunk < n_chunks; chunk += st.n_waves) {
         int slot = chunk * 64 + lane_id();
-        int k = slot / fr.n_pixels_padded;
+        int pix, k;
+        split_slot(fr, (uint32_t)slot, pix, k);
         int px, py;
         bool active;
-        slot_to_pixel(fr, slot - k * fr.n_pixels_padded, px, py, active);
+        slot_to_pixel(fr, pix, px, py, active);
         const size_t p = seg + (size_t)wp_push(out, active);   // generation 0 holds the pass's paths in camera order, film padding squeezed out
         if (active) {
             int sample_idx = fr.first_sample + k * fr.sample_stride;
             int x = px + 1, y = py + 1;  // 1-based pixel coordinates (Q1)
-            SobolCtx sc = sobol_ctx(sob, T.sobol, x, y, sample_idx, slot - k * fr.n_pixels_padded);
+            SobolCtx sc = sobol_ctx(sob, T.sobol, x, y, sample_idx, pix);
             float wavelength_u = sobol_1d(sc, 1);
             v2 jit = sobol_2d(sc, 3);
             // dims 4 (time) and 6 (lens) only matter with a finite aperture: ray.time is carried by the reference
@@ -871,11 +880,12 @@ __global__ void __launch_bounds__(256) k_scatter(DPathState st, DScene sc, DTabl
                 lambda = ld4(&g.lambda[slot]);
                 beta = ld4(&g.beta[slot]);
                 r_u = ld4(&g.r_u[slot]);
-                int k = (int)pslot / fr.n_pixels_padded;
+                int pix, k;
+                split_slot(fr, pslot, pix, k);
                 int px, py;
                 bool inside;
-                slot_to_pixel(fr, (int)pslot - k * fr.n_pixels_padded, px, py, inside);
-                SobolCtx sctx = sobol_ctx(sob, T.sobol, px + 1, py + 1, fr.first_sample + k * fr.sample_stride, (int)pslot - k * fr.n_pixels_padded);
+                slot_to_pixel(fr, pix, px, py, inside);
+                SobolCtx sctx = sobol_ctx(sob, T.sobol, px + 1, py + 1, fr.first_sample + k * fr.sample_stride, pix);
                 const int base_dim = 6 + 7 * depth;
                 if (sc.n_lights > 0) {
                     float light_select = sobol_1d(sctx, base_dim + 1);
@@ -1163,11 +1173,12 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
             medium = (int)(fl >> 16) - 1;
 
             // pixel coordinates for the Sobol dimensions of this bounce (volpath.jl:252-262, Q19)
-            int k = (int)pslot / fr.n_pixels_padded;
+            int pix, k;
+            split_slot(fr, pslot, pix, k);
             int px, py;
             bool inside;
-            slot_to_pixel(fr, (int)pslot - k * fr.n_pixels_padded, px, py, inside);
-            sctx = sobol_ctx(sob, T.sobol, px + 1, py + 1, fr.first_sample + k * fr.sample_stride, (int)pslot - k * fr.n_pixels_padded);
+            slot_to_pixel(fr, pix, px, py, inside);
+            sctx = sobol_ctx(sob, T.sobol, px + 1, py + 1, fr.first_sample + k * fr.sample_stride, pix);
 
             if (KIND == HK_MAT_MATTE) kd_matte = matte_kd(sc, T, sc.materials[st.mat_id[slot] & ~HK_MAT_EMISSIVE_BIT], TexCtx(sf.uv, meta.prim_index, H.z, H.w), lambda);
 #ifdef HK_ABLATE
@@ -1180,10 +1191,11 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
                     int d2 = base_dim;
                     asm volatile("" : "+v"(ps2));
                     asm volatile("" : "+s"(d2));
-                    int k2 = (int)ps2 / fr.n_pixels_padded, px2, py2;
+                    int pix2, k2, px2, py2;
+                    split_slot(fr, ps2, pix2, k2);
                     bool in2;
-                    slot_to_pixel(fr, (int)ps2 - k2 * fr.n_pixels_padded, px2, py2, in2);
-                    SobolCtx c2 = sobol_ctx(sob, T.sobol, px2 + 1, py2 + 1, fr.first_sample + k2 * fr.sample_stride, (int)ps2 - k2 * fr.n_pixels_padded);
+                    slot_to_pixel(fr, pix2, px2, py2, in2);
+                    SobolCtx c2 = sobol_ctx(sob, T.sobol, px2 + 1, py2 + 1, fr.first_sample + k2 * fr.sample_stride, pix2);
                     v2 a = sobol_2d(c2, d2 + 3), b = sobol_2d(c2, d2 + 6);
                     sink = sobol_1d(c2, d2 + 1) + a.x + a.y + b.x + b.y + sobol_1d(c2, d2 + 7);
                 }
@@ -1703,28 +1715,49 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
 // ---------------------------------------------------------------------------------------------------
 template <typename ACC>
 __global__ void __launch_bounds__(256) k_film(DPathState st, DFrame fr, DTables T, ACC* __restrict__ accum) {
-    int n = fr.n_pixels_padded;
-    size_t N = (size_t)fr.width * fr.height;
-    for (int tid = blockIdx.x * blockDim.x + threadIdx.x; tid < n; tid += gridDim.x * blockDim.x) {
+    // One wave per 8x8 pixel tile = a contiguous run of 64 * S path slots.  The run is read 64 slots at a time (coalesced; the colour
+    // conversion runs on all lanes), the weighted colours go through LDS, and the lane that OWNS a pixel adds that pixel's entries one
+    // after the other: the sums are formed in sample order, as the reference forms them.
+    __shared__ float4 buf[4][64];
+    float4* mine = buf[threadIdx.x >> 6];
+    const int lane = lane_id();
+    const int S = fr.samples_in_pass;
+    const int n_tiles = fr.n_pixels_padded >> 6;
+    const size_t N = (size_t)fr.width * fr.height;
+    const int n_waves = (int)(gridDim.x * (blockDim.x >> 6));
+    for (int tile = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)); tile < n_tiles; tile += n_waves) {
         int px, py;
         bool inside;
-        slot_to_pixel(fr, tid, px, py, inside);
-        if (!inside) continue;
-        size_t p = (size_t)py * fr.width + px;
-        ACC r = accum[3 * p], g = accum[3 * p + 1], b = accum[3 * p + 2], w = accum[3 * N + p];
-        for (int k = 0; k < fr.samples_in_pass; ++k) {
-            size_t slot = (size_t)k * n + tid;
-            v3 rgb = spectral_to_rgb_clamped(T, ld4(&st.L[slot]), ld4(&st.lambda_s[slot]), ld4(&st.pdf[slot]), fr.max_component_value);
-            float fw = st.filter_w[slot];
-            r += (ACC)(fw * rgb.x);
-            g += (ACC)(fw * rgb.y);
-            b += (ACC)(fw * rgb.z);
-            w += (ACC)fw;
+        slot_to_pixel(fr, tile * 64 + lane, px, py, inside);
+        const size_t p = inside ? (size_t)py * fr.width + px : 0;
+        ACC r = 0, g = 0, b = 0, w = 0;
+        if (inside) r = accum[3 * p], g = accum[3 * p + 1], b = accum[3 * p + 2], w = accum[3 * N + p];
+        const size_t base = (size_t)tile * 64 * S;
+        const int lo = lane * S, hi = lo + S;   // this lane's pixel owns entries [lo, hi) of the run
+        for (int j = 0; j < 64 * S; j += 64) {
+            const size_t slot = base + j + lane;
+            // slots of film padding were never written by k_camera: whatever they hold is converted but never added
+            const v3 rgb = spectral_to_rgb_clamped(T, ld4(&st.L[slot]), ld4(&st.lambda_s[slot]), ld4(&st.pdf[slot]), fr.max_component_value);
+            const float fw = st.filter_w[slot];
+            mine[lane] = make_float4(fw * rgb.x, fw * rgb.y, fw * rgb.z, fw);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            const int a = lo > j ? lo : j, e = hi < j + 64 ? hi : j + 64;
+            if (inside)
+                for (int t = a; t < e; ++t) {
+                    const float4 c = mine[t - j];
+                    r += (ACC)c.x;
+                    g += (ACC)c.y;
+                    b += (ACC)c.z;
+                    w += (ACC)c.w;
+                }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         }
-        accum[3 * p] = r;
-        accum[3 * p + 1] = g;
-        accum[3 * p + 2] = b;
-        accum[3 * N + p] = w;
+        if (inside) {
+            accum[3 * p] = r;
+            accum[3 * p + 1] = g;
+            accum[3 * p + 2] = b;
+            accum[3 * N + p] = w;
+        }
     }
 }
 
@@ -2235,7 +2268,7 @@ void launch_shade(hipStream_t s, int n_cu, int kind, const DPathState& st, const
 #undef HK_SHADE_CASE
 }
 void launch_film(hipStream_t s, const DPathState& st, const DFrame& fr, const DTables& T, void* accum, bool f64) {
-    int g = grid_for(fr.n_pixels_padded, 256, 4096);
+    int g = grid_for(fr.n_pixels_padded >> 6, 4, 4096);   // one wave per 8x8 tile
     if (f64)
         hipLaunchKernelGGL(k_film<double>, dim3(g), dim3(256), 0, s, st, fr, T, (double*)accum);
     else

@@ -270,6 +270,8 @@ struct DFrame {            // per-pass constants
     int x0, y0, x1, y1;    // rendered pixel range [x0, x1) x [y0, y1) (0-based; the whole film unless hk_render_tile narrows it)
     int n_pixels_padded;   // tiles_x*tiles_y*64
     int samples_in_pass;
+    uint32_t s_mul;        // slot / samples_in_pass == (slot * s_mul) >> s_shr for slot < 2^30 (path slot = pixel slot * samples_in_pass + k)
+    int s_shr;
     int first_sample, sample_stride;   // sample index of pass-sample k = first_sample + k*sample_stride
     int max_depth;
     int regularize;

@@ -97,16 +97,19 @@ def main():
     # film accumulators live in a torch tensor so torch.distributed (RCCL) can reduce them in place
     accum = torch.zeros(4 * n_pix, dtype=torch.float32, device="cuda")
     # `samples` only sizes the ZSobol index (log2 of max(samples, 4096)): cover every sample index this run touches
-    vp = hk.VolPath(max_depth=DEPTH, samples=max(FULL_SPP, SPP_PER_STEP * max(args.steps, args.warmup, 1) * world), samples_per_pass=SPP_PER_STEP,
+    vp = hk.VolPath(max_depth=DEPTH, samples=max(FULL_SPP, SPP_PER_STEP * world), samples_per_pass=SPP_PER_STEP,
                     device=local_rank)
     vp.use_external_accumulators(accum.data_ptr())
     vp._ensure(film)
     L = hk._lib.lib()
 
     def run_steps(first_step, n_steps, readback=False):
-        # step k of this rank covers sample indices (rank+1) + world*(SPP_PER_STEP*k + j), j < SPP_PER_STEP
-        first = rank + 1 + world * SPP_PER_STEP * first_step
-        vp.render_samples(scene, film, cam, SPP_PER_STEP * n_steps, stride=world, first=first, readback=readback)
+        # A step is one frame, the way the reference's `integrator(scene, film, camera)` renders one: clear the film, then
+        # SPP_PER_STEP samples per pixel — on this rank the sample indices (rank+1) + world*j, j < SPP_PER_STEP.  Every step
+        # renders the same sample indices (a frame loop), so the sampler tables built by the first frame serve the later ones.
+        for _ in range(n_steps):
+            vp.clear()
+            vp.render_samples(scene, film, cam, SPP_PER_STEP, stride=world, first=rank + 1, readback=readback)
 
     def barrier():
         if world > 1:

@@ -41,6 +41,7 @@ void launch_postprocess(hipStream_t, const hk_postprocess_params&, const float*,
 void launch_denoise_variance(hipStream_t, const float*, float*, int, int);
 void launch_denoise_atrous(hipStream_t, const hk_denoise_params&, int, const float*, const float*, const float*, const float*, float*, int, int);
 void launch_sobol_table(hipStream_t, const DSobol&, const DFrame&, uint2*, int);
+void launch_sobol_lo_table(hipStream_t, const DSobol&, const DFrame&, uint16_t*, int, int, int, int);
 void launch_test_light(hipStream_t, const DScene&, const DTables&, int, int, int, const float*, const float*, const float*, float*);
 void launch_test_bsdf(hipStream_t, const DScene&, const DTables&, int, int, int, int, const float*, const float*, const float*, const float*, const float*, const float*, float*);
 void launch_test_mix(hipStream_t, const DScene&, int, int, const float*, const float*, const float*, int*);
@@ -153,6 +154,8 @@ struct hk_integrator {
     int st_capacity = 0, st_depth = 0;
     DevBuf sobol_table;  // DSobol::hi_table
     int sobol_rows = 0, sobol_stride = 0, sobol_log2 = -1, sobol_digits = -1, sobol_x0 = -1, sobol_y0 = -1, sobol_tiles_x = -1;
+    DevBuf sobol_lo;     // DSobol::lo_table
+    int lo_rows = 0, lo_base = -1, lo_sample_stride = -1, lo_count = 0;
     ~hk_integrator() {
         for (auto* b : bufs) delete b;
     }
@@ -1165,6 +1168,8 @@ DSobol make_sobol(const hk_integrator_params& p, int w, int h) {  // compute_zso
     s.width = w;
     s.hi_table = nullptr;
     s.hi_rows = s.hi_stride = 0;
+    s.lo_table = nullptr;
+    s.lo_rows = s.lo_count = s.lo_offset = 0;
     return s;
 }
 DCamera make_camera(const hk_camera& c) {
@@ -1242,8 +1247,9 @@ extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_
     DSobol sob = make_sobol(I->p, W, H);
     {   // pixel-digit table of the sampler: depends on film size, spp exponent and max_depth only
         const int rows = 4 + 5 * (I->p.max_depth + 1);
-        if (I->sobol_rows != rows || I->sobol_stride != fr.n_pixels_padded || I->sobol_log2 != sob.log2_spp || I->sobol_digits != sob.n_base4_digits ||
-            I->sobol_x0 != x0 || I->sobol_y0 != y0 || I->sobol_tiles_x != fr.tiles_x) {
+        const bool table_same = !(I->sobol_rows != rows || I->sobol_stride != fr.n_pixels_padded || I->sobol_log2 != sob.log2_spp || I->sobol_digits != sob.n_base4_digits ||
+                                  I->sobol_x0 != x0 || I->sobol_y0 != y0 || I->sobol_tiles_x != fr.tiles_x);
+        if (!table_same) {
             HIP_TRY(I->sobol_table.alloc((size_t)rows * fr.n_pixels_padded * sizeof(uint2)));
             hk::launch_sobol_table(c->stream, sob, fr, I->sobol_table.as<uint2>(), rows);
             HIP_TRY(hipGetLastError());
@@ -1256,6 +1262,39 @@ extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_
         sob.hi_table = I->sobol_table.as<uint2>();
         sob.hi_rows = rows;
         sob.hi_stride = fr.n_pixels_padded;
+        // sample-bit table: worth building when the call draws many samples per pixel (a frame), not for one-sample progressive calls.
+        // Two bytes per (row, pixel, sample): rows are cut to HK_SOBOL_LO_GB (default 32 GB, and a quarter of the free memory) —
+        // the deep rows serve few paths and fall back to hashing the sample digits.
+        const long last_idx = (long)first_sample_idx + (long)(n_samples - 1) * sample_stride;
+        if (n_samples >= 16 && sob.log2_spp >= 2 && sob.log2_spp <= 16 && (last_idx >> sob.log2_spp) == 0) {
+            const int base = sample_stride == 1 ? (first_sample_idx & ~3) : first_sample_idx;
+            const int count = (int)((((last_idx - base) / sample_stride + 1) + 3) & ~3L);
+            bool same = table_same && I->lo_base == base && I->lo_sample_stride == sample_stride && I->lo_count == count && I->lo_rows > 0;
+            if (!same) {
+                double gb = 32.0;
+                if (const char* e = std::getenv("HK_SOBOL_LO_GB")) gb = std::atof(e);
+                size_t budget = (size_t)(gb * 1e9), free_b = 0, total_b = 0;
+                // the buffer of the previous table is reused when it is large enough (another sample range of the same film)
+                if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (free_b + I->sobol_lo.bytes) / 4 < budget) budget = (free_b + I->sobol_lo.bytes) / 4;
+                const size_t per_row = (size_t)fr.n_pixels_padded * count * sizeof(uint16_t);
+                int lo_rows = (int)(budget / per_row < (size_t)rows ? budget / per_row : (size_t)rows);
+                I->lo_rows = 0;
+                if (lo_rows > 0 && (size_t)fr.n_pixels_padded * count < 0xffffffffull) {
+                    if (I->sobol_lo.bytes < per_row * lo_rows || I->sobol_lo.bytes > 2 * per_row * lo_rows) HIP_TRY(I->sobol_lo.alloc(per_row * lo_rows));
+                    hk::launch_sobol_lo_table(c->stream, sob, fr, I->sobol_lo.as<uint16_t>(), lo_rows, base, sample_stride, count);
+                    HIP_TRY(hipGetLastError());
+                    I->lo_rows = lo_rows;
+                    I->lo_base = base;
+                    I->lo_sample_stride = sample_stride;
+                    I->lo_count = count;
+                }
+            }
+            if (I->lo_rows > 0) {
+                sob.lo_table = I->sobol_lo.as<uint16_t>();
+                sob.lo_rows = I->lo_rows;
+                sob.lo_count = I->lo_count;
+            }
+        }
     }
     DCamera dc = make_camera(*cam);
     DStats* dstats = c->stats.as<DStats>();
@@ -1290,6 +1329,7 @@ extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_
             fr.s_mul = (uint32_t)((((uint64_t)1 << fr.s_shr) + (uint64_t)k - 1) / (uint64_t)k);
         }
         fr.first_sample = first_sample_idx + done * sample_stride;
+        if (sob.lo_table) sob.lo_offset = (fr.first_sample - I->lo_base) / sample_stride;
         auto timed = [&](int cls, auto&& fn) -> int {
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (c->time_kernels) {

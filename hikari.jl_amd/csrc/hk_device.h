@@ -300,36 +300,80 @@ HKD uint64_t zsobol_hash(int dimension, uint32_t seed) {
     return murmur64a_words<2>(w);
 }
 struct SobolCtx {
-    uint64_t morton_base;  // encode_morton2(px,py) << log2_spp | sample_idx
+    // the pixel (1-based) either directly or as its tile-major slot within the rendered range: the Morton code is needed only by
+    // the draws that miss the tables, and is formed there (two integer divisions and two bit spreads per path vertex otherwise)
+    int px, py;            // 1-based pixel coordinates, or px == 0: derive from pix_slot
+    int pix_slot, x0, y0, tiles_x;
+    int sample_idx;
     const uint32_t* mats;
     const uint2* hi;       // pixel-digit table column of this pixel (null: compute every digit)
+    const uint16_t* lo;    // this path's entry of row 0 in the sample-bit table (null: hash the sample digits)
+    int lo_rows;
+    uint32_t lo_row_stride;   // entries per row of the sample-bit table (pixel slots * entries per pixel)
     int hi_rows, hi_stride;
     int log2_spp, n_digits;
     uint32_t seed;
 };
-// pix_slot: the pixel's slot within one sample of the pass (tile-major), or -1 when the caller has no table column
-HKD SobolCtx sobol_ctx(const DSobol& s, const uint32_t* mats, int px, int py, int sample_idx, int pix_slot = -1) {
-    SobolCtx c;
-    uint64_t m = (left_shift2((uint64_t)(uint32_t)py) << 1) | left_shift2((uint64_t)(uint32_t)px);
-    c.morton_base = (m << s.log2_spp) | (uint64_t)(int64_t)sample_idx;
+HKD void sobol_ctx_tables(SobolCtx& c, const DSobol& s, const uint32_t* mats, int sample_idx, int pix_slot, int k) {
+    c.sample_idx = sample_idx;
+    c.pix_slot = pix_slot;
     c.mats = mats;
     // the table holds the digits above the sample bits: valid only while the sample index fits in them
     const bool cached = s.hi_table != nullptr && pix_slot >= 0 && ((unsigned)sample_idx >> s.log2_spp) == 0u;
     c.hi = cached ? s.hi_table + pix_slot : nullptr;
+    const bool low = cached && s.lo_table != nullptr && k >= 0 && (unsigned)(s.lo_offset + k) < (unsigned)s.lo_count;
+    c.lo = low ? s.lo_table + ((size_t)pix_slot * s.lo_count + (size_t)(s.lo_offset + k)) : nullptr;
+    c.lo_rows = low ? s.lo_rows : 0;
+    c.lo_row_stride = (uint32_t)s.hi_stride * (uint32_t)s.lo_count;
     c.hi_rows = s.hi_rows;
     c.hi_stride = s.hi_stride;
     c.log2_spp = s.log2_spp;
     c.n_digits = s.n_base4_digits;
     c.seed = s.seed;
+}
+// px, py: 1-based pixel coordinates; pix_slot: the pixel's slot within one sample of the pass (tile-major), or -1 when the caller has
+// no table column; k: the path's sample within the pass (sample_idx = first_sample + k * stride), or -1
+HKD SobolCtx sobol_ctx(const DSobol& s, const uint32_t* mats, int px, int py, int sample_idx, int pix_slot = -1, int k = -1) {
+    SobolCtx c;
+    c.px = px;
+    c.py = py;
+    c.x0 = c.y0 = 0;
+    c.tiles_x = 1;
+    sobol_ctx_tables(c, s, mats, sample_idx, pix_slot, k);
     return c;
 }
+// the render kernels' form: the pixel as its slot of the rendered range [x0, ..) x [y0, ..) in 8x8 tiles, tiles_x tiles per row
+HKD SobolCtx sobol_ctx_slot(const DSobol& s, const uint32_t* mats, int x0, int y0, int tiles_x, int pix_slot, int k, int sample_idx) {
+    SobolCtx c;
+    c.px = c.py = 0;
+    c.x0 = x0;
+    c.y0 = y0;
+    c.tiles_x = tiles_x;
+    sobol_ctx_tables(c, s, mats, sample_idx, pix_slot, k);
+    return c;
+}
+HKD uint64_t sobol_morton_base(const SobolCtx& c) {   // encode_morton2(px, py) << log2_spp | sample_idx
+    int px = c.px, py = c.py;
+    if (px == 0) {
+        const int tile = c.pix_slot >> 6, l = c.pix_slot & 63;
+        const int ty = tile / c.tiles_x, tx = tile - ty * c.tiles_x;
+        px = c.x0 + tx * 8 + (l & 7) + 1;
+        py = c.y0 + ty * 8 + (l >> 3) + 1;
+    }
+    const uint64_t m = (left_shift2((uint64_t)(uint32_t)py) << 1) | left_shift2((uint64_t)(uint32_t)px);
+    return (m << c.log2_spp) | (uint64_t)(int64_t)c.sample_idx;
+}
+// The draws that miss the sample-bit table (rows beyond the table's budget, one-sample progressive calls, the point-wise test kernels)
+// hash the digits in line: moved out of line (noinline) the call made k_shade<0> 3 % and k_track 3 % slower (288 B of scratch for the
+// callee's frame) although it removes ~1600 static instructions from every path vertex.
 HKD uint64_t sobol_index(const SobolCtx& c, int dim) {
     const int row = sobol_row(dim);
     if (c.hi != nullptr && row >= 0 && row < c.hi_rows) {
         const uint2 e = c.hi[(size_t)row * c.hi_stride];
-        return zsobol_sample_index_cached(c.morton_base, dim, c.log2_spp, e.x, e.y);
+        if (row < c.lo_rows) return ((uint64_t)e.x << c.log2_spp) | (uint64_t)c.lo[(size_t)row * c.lo_row_stride];
+        return zsobol_sample_index_cached(sobol_morton_base(c), dim, c.log2_spp, e.x, e.y);
     }
-    return zsobol_sample_index(c.morton_base, dim, c.log2_spp, c.n_digits);
+    return zsobol_sample_index(sobol_morton_base(c), dim, c.log2_spp, c.n_digits);
 }
 HKD float sobol_1d(const SobolCtx& c, int dim) {  // sobol.jl:269-282
     uint64_t idx = sobol_index(c, dim);

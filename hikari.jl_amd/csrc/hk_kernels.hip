@@ -182,6 +182,38 @@ __global__ void __launch_bounds__(256) k_sobol_table(DSobol sob, DFrame fr, uint
     }
 }
 
+// Sample-bit table (DSobol::lo_table): the low log2_spp bits of the permuted index for sample indices base + j * stride, j < count.
+// One thread per four entries.  With stride 1 and base a multiple of 4 the four share every digit but the last, and the last
+// digit's permutation is chosen by the digits above it: one evaluation plus one hash instead of four evaluations.
+__global__ void __launch_bounds__(256) k_sobol_lo_table(DSobol sob, DFrame fr, uint16_t* table, int rows, int base, int stride, int count) {
+    const long groups = count >> 2;
+    const long total = (long)rows * fr.n_pixels_padded * groups;
+    const uint32_t mask = (1u << sob.log2_spp) - 1u;
+    const int pow2 = sob.log2_spp & 1;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long rp = i / groups;
+        const int q = (int)(i - rp * groups);
+        const int row = (int)(rp / fr.n_pixels_padded), pix = (int)(rp - (long)row * fr.n_pixels_padded);
+        int px, py;
+        bool inside;
+        slot_to_pixel(fr, pix, px, py, inside);
+        const int dim = sobol_row_dim(row);
+        const uint64_t m = ((left_shift2((uint64_t)(uint32_t)(py + 1)) << 1) | left_shift2((uint64_t)(uint32_t)(px + 1))) << sob.log2_spp;
+        const uint2 e = sob.hi_table[(size_t)row * sob.hi_stride + pix];
+        uint32_t v[4];
+        const int s0 = base + 4 * q * stride;
+        if (stride == 1 && pow2 == 0 && (s0 & 3) == 0) {
+            const uint64_t morton = m | (uint64_t)(uint32_t)s0;
+            const uint32_t first = (uint32_t)zsobol_sample_index_cached(morton, dim, sob.log2_spp, e.x, e.y) & mask;
+            const int p = zsobol_perm_index(morton >> 2, 0x55555555ull * (uint64_t)(int64_t)dim);
+            for (int t = 0; t < 4; ++t) v[t] = (first & ~3u) | (uint32_t)zsobol_permute_digit(p, t);
+        } else {
+            for (int t = 0; t < 4; ++t) v[t] = (uint32_t)zsobol_sample_index_cached(m | (uint64_t)(uint32_t)(s0 + t * stride), dim, sob.log2_spp, e.x, e.y) & mask;
+        }
+        reinterpret_cast<uint2*>(table)[i] = make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16));
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // K1: camera rays (volpath.jl:125-205).  One thread per path slot of the pass.
 // ---------------------------------------------------------------------------------------------------
@@ -204,7 +236,7 @@ __global__ void __launch_bounds__(256) k_camera(DPathState st, DFrame fr, DTable
         if (active) {
             int sample_idx = fr.first_sample + k * fr.sample_stride;
             int x = px + 1, y = py + 1;  // 1-based pixel coordinates (Q1)
-            SobolCtx sc = sobol_ctx(sob, T.sobol, x, y, sample_idx, pix);
+            SobolCtx sc = sobol_ctx(sob, T.sobol, x, y, sample_idx, pix, k);
             float wavelength_u = sobol_1d(sc, 1);
             v2 jit = sobol_2d(sc, 3);
             // dims 4 (time) and 6 (lens) only matter with a finite aperture: ray.time is carried by the reference
@@ -882,10 +914,7 @@ __global__ void __launch_bounds__(256) k_scatter(DPathState st, DScene sc, DTabl
                 r_u = ld4(&g.r_u[slot]);
                 int pix, k;
                 split_slot(fr, pslot, pix, k);
-                int px, py;
-                bool inside;
-                slot_to_pixel(fr, pix, px, py, inside);
-                SobolCtx sctx = sobol_ctx(sob, T.sobol, px + 1, py + 1, fr.first_sample + k * fr.sample_stride, pix);
+                SobolCtx sctx = sobol_ctx_slot(sob, T.sobol, fr.x0, fr.y0, fr.tiles_x, pix, k, fr.first_sample + k * fr.sample_stride);
                 const int base_dim = 6 + 7 * depth;
                 if (sc.n_lights > 0) {
                     float light_select = sobol_1d(sctx, base_dim + 1);
@@ -1042,6 +1071,9 @@ __global__ void __launch_bounds__(256) k_escaped(DPathState st, DScene sc, DTabl
 // Register budget: 512 VGPRs per SIMD lane => 3 waves/SIMD need <= 168, 4 need <= 128.  The simple kinds sit a few registers
 // above 168 without a hint; asking for 3 waves costs a handful of scratch spills and buys a third more latency hiding.
 // The walk kinds (coated diffuse / transmission) are far above: they keep the default.
+#ifndef HK_SHADE_WAVES_MATTE
+#define HK_SHADE_WAVES_MATTE 4
+#endif
 #ifndef HK_SHADE_WAVES
 #define HK_SHADE_WAVES 3
 #endif
@@ -1083,7 +1115,9 @@ HKD void shade_emission(DPathState& st, const DPathGen& g, bool ones, const DSce
 
 template <int KIND>
 struct ShadeWaves {
-    static constexpr int value = (KIND == HK_MAT_COATED_DIFFUSE || KIND == HK_MAT_COATED_DIFFUSE_TRANSMISSION) ? 1 : HK_SHADE_WAVES;
+    // Matte runs faster at 4 waves per SIMD with 224 B of scratch than at 3 with 48 B (Cornell k_shade -5 %); the kinds with larger
+    // BSDFs lose more to the spills than the fourth wave returns (sky: conductor + glass +7 %)
+    static constexpr int value = (KIND == HK_MAT_COATED_DIFFUSE || KIND == HK_MAT_COATED_DIFFUSE_TRANSMISSION) ? 1 : (KIND == HK_MAT_MATTE ? HK_SHADE_WAVES_MATTE : HK_SHADE_WAVES);
 };
 #ifndef HK_SHADE_MIN_WAVES
 #define HK_SHADE_MIN_WAVES 1
@@ -1175,10 +1209,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
             // pixel coordinates for the Sobol dimensions of this bounce (volpath.jl:252-262, Q19)
             int pix, k;
             split_slot(fr, pslot, pix, k);
-            int px, py;
-            bool inside;
-            slot_to_pixel(fr, pix, px, py, inside);
-            sctx = sobol_ctx(sob, T.sobol, px + 1, py + 1, fr.first_sample + k * fr.sample_stride, pix);
+            sctx = sobol_ctx_slot(sob, T.sobol, fr.x0, fr.y0, fr.tiles_x, pix, k, fr.first_sample + k * fr.sample_stride);
 
             if (KIND == HK_MAT_MATTE) kd_matte = matte_kd(sc, T, sc.materials[st.mat_id[slot] & ~HK_MAT_EMISSIVE_BIT], TexCtx(sf.uv, meta.prim_index, H.z, H.w), lambda);
 #ifdef HK_ABLATE
@@ -1191,11 +1222,9 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
                     int d2 = base_dim;
                     asm volatile("" : "+v"(ps2));
                     asm volatile("" : "+s"(d2));
-                    int pix2, k2, px2, py2;
+                    int pix2, k2;
                     split_slot(fr, ps2, pix2, k2);
-                    bool in2;
-                    slot_to_pixel(fr, pix2, px2, py2, in2);
-                    SobolCtx c2 = sobol_ctx(sob, T.sobol, px2 + 1, py2 + 1, fr.first_sample + k2 * fr.sample_stride, pix2);
+                    SobolCtx c2 = sobol_ctx_slot(sob, T.sobol, fr.x0, fr.y0, fr.tiles_x, pix2, k2, fr.first_sample + k2 * fr.sample_stride);
                     v2 a = sobol_2d(c2, d2 + 3), b = sobol_2d(c2, d2 + 6);
                     sink = sobol_1d(c2, d2 + 1) + a.x + a.y + b.x + b.y + sobol_1d(c2, d2 + 7);
                 }
@@ -2398,6 +2427,9 @@ void launch_test_light(hipStream_t s, const DScene& sc, const DTables& T, int mo
 }
 void launch_sobol_table(hipStream_t s, const DSobol& sob, const DFrame& fr, uint2* table, int rows) {
     hipLaunchKernelGGL(k_sobol_table, dim3(grid_for((long)rows * fr.n_pixels_padded > 0x3fffffff ? 0x3fffffff : rows * fr.n_pixels_padded, 256, 8192)), dim3(256), 0, s, sob, fr, table, rows);
+}
+void launch_sobol_lo_table(hipStream_t s, const DSobol& sob, const DFrame& fr, uint16_t* table, int rows, int base, int stride, int count) {
+    hipLaunchKernelGGL(k_sobol_lo_table, dim3(65536), dim3(256), 0, s, sob, fr, table, rows, base, stride, count);
 }
 void launch_postprocess(hipStream_t s, const hk_postprocess_params& P, const float* src, const float* depth, float* dst, int h, int w) {
     hipLaunchKernelGGL(k_postprocess, dim3(grid_for(h * w, 256, 8192)), dim3(256), 0, s, P, src, depth, dst, h, w);

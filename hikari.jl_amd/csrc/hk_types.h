@@ -207,6 +207,13 @@ struct DSobol {
     // hashes of a draw at 800^2).  row = sobol_row(dimension), entry = permuted digits >> log2_spp.  Null = compute in full.
     const uint2* hi_table;     // x = permuted digits above the sample bits (>> log2_spp); y = permutation indices of the two top SAMPLE digits (zsobol_top_perms)
     int hi_rows, hi_stride;   // rows available, entries per row (= n_pixels_padded)
+    // The permuted SAMPLE bits (low log2_spp bits of the index) of every sample index one render call draws, per (row, pixel slot):
+    // entry ((row * hi_stride + pixel slot) * lo_count + j) belongs to sample index lo_base + j * sample_stride.  With path slots
+    // sample-fastest the lanes of a wave read neighbouring entries; a draw is then one 2-byte load instead of a 64-bit hash and a
+    // mod-24 per remaining base-4 digit.  Built per (film, first sample, stride, count) when a call renders enough samples.
+    const uint16_t* lo_table;
+    int lo_rows, lo_count;    // rows tabulated (the first lo_rows of the hi rows), entries per (row, pixel slot)
+    int lo_offset;            // per pass: entry index of the pass's sample k = 0
 };
 
 // queue ids inside one depth's counter block

@@ -621,3 +621,35 @@ def test_zsobol_pixel_table_all_index_widths(hk, oracle, spp_setting):
     rel_mse, frac = frame_metrics(film.framebuffer, ref)
     assert rel_mse <= 1e-5 and frac >= 0.995, (spp_setting, rel_mse, frac)
     assert abs(int(st.rays_closest) - int(ost.rays_closest)) <= 0.002 * ost.rays_closest + 4
+
+
+@pytest.mark.parametrize("first,n,stride,per_pass,spp_setting", [(1, 16, 1, 0, 64), (3, 21, 1, 8, 64), (2, 17, 3, 5, 64), (1, 20, 1, 0, 8192), (6, 16, 2, 0, 40000)])
+def test_zsobol_sample_bit_table(hk, oracle, monkeypatch, first, n, stride, per_pass, spp_setting):
+    """A call that renders >= 16 samples reads the permuted sample bits from a table (k_sobol_lo_table, DSobol::lo_table) instead of
+    hashing the remaining base-4 digits.  The table must not change a single bit: the accumulators of the same call with the table
+    switched off (HK_SOBOL_LO_GB=0) are compared exactly — over aligned and unaligned first samples, strides, several passes per
+    call (per-pass table offset), the last pass shorter than the others, even / odd / wide index widths — and the frame with the oracle."""
+    from hikari_jl_amd import scenes
+    w, h = 21, 19
+    s, film, cam = scenes.cornell_box(w, h, light="area")
+    kw = dict(max_depth=4, samples=spp_setting, samples_per_pass=per_pass)
+
+    def run():
+        vp = hk.VolPath(**kw)
+        vp._ensure(film)
+        vp.clear()
+        vp.render_samples(s, film, cam, n, stride=stride, first=first)
+        acc = vp.read_accumulators(film).copy()
+        fb = film.framebuffer.copy()
+        vp.close()
+        return acc, fb
+
+    acc_table, fb = run()
+    monkeypatch.setenv("HK_SOBOL_LO_GB", "0")
+    acc_hashed, _ = run()
+    assert np.array_equal(acc_table.view(np.uint32), acc_hashed.view(np.uint32))
+    osc = oracle.OracleScene(s)
+    p = hk.integrator_params(max_depth=4, samples=spp_setting)
+    oacc, _ = osc.render(p, cam, w, h, n, first=first, stride=stride)
+    rel_mse, frac = frame_metrics(fb, oracle.finalize(oacc, w, h))
+    assert rel_mse <= 1e-5 and frac >= 0.995, (rel_mse, frac)

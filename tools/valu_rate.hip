@@ -51,7 +51,14 @@
     X(39, "v_div_scale+fmas+fixup (IEEE a/b)", "v_div_scale_f32 %0, vcc, %0, %2, %0\n v_div_fmas_f32 %0, %0, %2, %3\n v_div_fixup_f32 %0, %0, %2, %3", "vcc") \
     X(40, "s_nop (SALU only loop)", "s_nop 0", "s22") \
     X(41, "ds_bpermute_b32 + wait", "ds_bpermute_b32 %0, %2, %0\n s_waitcnt lgkmcnt(0)", "s22") \
-    X(42, "v_cmpx_lt_f32 (writes exec)", "v_cmpx_lt_f32 exec, %3, %2", "s22")
+    X(42, "v_cmpx_lt_f32 (writes exec)", "v_cmpx_lt_f32 exec, %3, %2", "s22") \
+    X(43, "v_fma_f32 + s_add_u32 (pair)", "v_fma_f32 %0, %0, %2, %3\n s_add_u32 s22, s22, 1", "s22", "scc") \
+    X(44, "v_fma_f32 + 2 s_add_u32", "v_fma_f32 %0, %0, %2, %3\n s_add_u32 s22, s22, 1\n s_add_u32 s23, s23, 1", "s22", "s23", "scc") \
+    X(45, "s_add_u32 alone", "s_add_u32 s22, s22, 1", "s22", "scc") \
+    X(46, "v_fma_f32 + s_nop 0", "v_fma_f32 %0, %0, %2, %3\n s_nop 0", "s22") \
+    X(47, "v_fma_f32 + ds_read_b32 (no wait)", "v_fma_f32 %0, %0, %2, %3\n ds_read_b64 %1, %2", "s22") \
+    X(48, "v_fma_f32 + s_and_b64 + s_cbranch (not taken)", "v_fma_f32 %0, %0, %2, %3\n s_and_b64 s[20:21], exec, exec\n s_cbranch_scc0 1f\n1:", "s20", "s21", "scc") \
+    X(49, "2 v_fma_f32 (dependent pair)", "v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %0, %0, %2, %3", "s22")
 
 
 template <int KIND>
@@ -63,7 +70,8 @@ __global__ __launch_bounds__(256) void k_rate(float* out, int iters, float a, fl
     asm volatile("s_mov_b64 vcc, exec\n s_mov_b64 s[20:21], exec" : : : "vcc", "s20", "s21");
     for (int i = 0; i < iters; ++i) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {      // eight independent chains: no dependency stall
+        for (int kk = 0; kk < 64; ++kk) {      // 64 statements per loop trip (the loop's own s_add / s_cmp / s_cbranch are 5 % of the stream), eight independent chains
+            const int k = kk & 7;
             // operands: %0 = x[k] (32-bit, in/out), %1 = y[k] (register pair, in/out), %2 = a, %3 = b (32-bit inputs), %4 = a2 (pair input)
 #define X(I, LABEL, ASM, ...) if (KIND == I) asm volatile(ASM : "+v"(x[k]), "+v"(y[k]) : "v"(a), "v"(b), "v"(a2) : __VA_ARGS__);
             KINDS(X)
@@ -77,7 +85,7 @@ __global__ __launch_bounds__(256) void k_rate(float* out, int iters, float a, fl
 
 template <int KIND>
 static void run(const char* name, int n_cu, int khz) {
-    const int iters = 1 << 13;
+    const int iters = 1 << 10;
     std::printf("%-36s", name);
     for (int waves_per_simd : {1, 2, 4, 8}) {
         const int blocks = n_cu * waves_per_simd;      // 256 threads = 4 waves = one per SIMD; waves_per_simd blocks per CU
@@ -86,14 +94,14 @@ static void run(const char* name, int n_cu, int khz) {
         hipEvent_t e0, e1;
         CHECK(hipEventCreate(&e0));
         CHECK(hipEventCreate(&e1));
-        k_rate<KIND><<<blocks, 256>>>(out, 64, 1.0001f, 0.5f);
+        k_rate<KIND><<<blocks, 256>>>(out, 8, 1.0001f, 0.5f);
         CHECK(hipEventRecord(e0));
         k_rate<KIND><<<blocks, 256>>>(out, iters, 1.0001f, 0.5f);
         CHECK(hipEventRecord(e1));
         CHECK(hipDeviceSynchronize());
         float ms = 0;
         CHECK(hipEventElapsedTime(&ms, e0, e1));
-        const double steps_per_simd = (double)iters * 8 * waves_per_simd;    // asm statements one SIMD executed
+        const double steps_per_simd = (double)iters * 64 * waves_per_simd;    // asm statements one SIMD executed
         std::printf("  %6.2f", ms * 1e-3 * khz * 1e3 / steps_per_simd);
         CHECK(hipFree(out));
         CHECK(hipEventDestroy(e0));
@@ -109,7 +117,7 @@ int main() {
     int khz = 0;
     CHECK(hipDeviceGetAttribute(&khz, hipDeviceAttributeClockRate, 0));
     std::printf("%s, %d CUs; cycles (at the %d MHz max clock) one SIMD spends per statement, at 1 / 2 / 4 / 8 waves per SIMD;\n"
-                "each statement runs in 8 independent chains per wave (launch overhead of ~10 us is included)\n", p.name, p.multiProcessorCount, khz / 1000);
+                "each statement runs in 8 independent chains per wave, 64 statements per loop trip (launch overhead of ~10 us is included)\n", p.name, p.multiProcessorCount, khz / 1000);
     std::printf("%-36s  %6s  %6s  %6s  %6s\n", "statement", "1", "2", "4", "8");
 #define X(I, LABEL, ASM, ...) run<I>(LABEL, p.multiProcessorCount, khz);
     KINDS(X)

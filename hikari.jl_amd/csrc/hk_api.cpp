@@ -1105,6 +1105,7 @@ int ensure_state(hk_integrator* I, int capacity, bool media) {
     if (I->ctx->waves_per_cu > 0) W_want = (long)I->ctx->waves_per_cu * n_cu;
     W_want = (W_want + 3) / 4 * 4;
     I->st.dynamic_segments = media ? 1 : 0;
+    I->st.compact = media ? 0 : 1;
     if (I->st_capacity >= capacity && I->st_depth >= I->p.max_depth && I->st.n_waves == (int)W_want) return HK_OK;
     for (auto* b : I->bufs) delete b;
     I->bufs.clear();

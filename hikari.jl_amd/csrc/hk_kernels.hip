@@ -114,6 +114,41 @@ __device__ __forceinline__ void wq_push(WaveQ& q, uint32_t value, bool active) {
 }
 // beta / r_u / r_l of generation entry p; `ones`: the depth-0 records of a scene without media hold the constant 1 implicitly
 __device__ __forceinline__ S4 ld_throughput(const float4* arr, size_t p, bool ones) { return ones ? s4(1.0f) : ld4(&arr[p]); }
+// r_u / r_l of generation entry p and the MIS weights of a shadow record, in either representation (DPathState::compact)
+__device__ __forceinline__ S4 ld_ru(const DPathGen& g, size_t p, bool ones, bool compact) { return (ones || compact) ? s4(1.0f) : ld4(&g.r_u[p]); }
+__device__ __forceinline__ S4 ld_rl(const DPathGen& g, size_t p, bool ones, bool compact) {
+    if (ones) return s4(1.0f);
+    if (compact) return s4(reinterpret_cast<const float*>(g.r_l)[p]);
+    return ld4(&g.r_l[p]);
+}
+__device__ __forceinline__ void st_ru_rl(const DPathGen& g, size_t p, S4 r_u, S4 r_l, bool compact) {
+    if (compact)
+        reinterpret_cast<float*>(g.r_l)[p] = r_l.x;
+    else {
+        st4(&g.r_u[p], r_u);
+        st4(&g.r_l[p], r_l);
+    }
+}
+__device__ __forceinline__ void st_shadow_weights(const DPathState& st, size_t rec, S4 ru, S4 rl) {
+    if (st.compact)
+        reinterpret_cast<float2*>(st.sh_ru)[rec] = make_float2(ru.x, rl.x);
+    else {
+        st4(&st.sh_ru[rec], ru);
+        st4(&st.sh_rl[rec], rl);
+    }
+}
+// COMPACT is a compile-time fact in the shadow kernels: k_shadow and k_shadow_walk<.., 0> only run in scenes without media
+template <bool COMPACT>
+__device__ __forceinline__ void ld_shadow_weights(const DPathState& st, size_t rec, S4& ru, S4& rl) {
+    if (COMPACT) {
+        const float2 w = reinterpret_cast<const float2*>(st.sh_ru)[rec];
+        ru = s4(w.x);
+        rl = s4(w.y);
+    } else {
+        ru = ld4(&st.sh_ru[rec]);
+        rl = ld4(&st.sh_rl[rec]);
+    }
+}
 // dense append of a whole record: the position the pushing lanes get inside the segment (count + rank among the pushing lanes)
 struct WavePos {
     int count;  // wave-uniform: entries already in the segment
@@ -1044,7 +1079,7 @@ __global__ void __launch_bounds__(256) k_escaped(DPathState st, DScene sc, DTabl
         uint32_t fl = meta.x;
         int pdepth = (int)(fl & 0xff);
         bool specular = (fl >> 8) & 1u;
-        S4 r_u = ld_throughput(g.r_u, slot, ones);
+        S4 r_u = ld_ru(g, slot, ones, st.compact != 0);
         S4 fin;
         if (pdepth == 0 || specular)
             fin = contribution / average(r_u);
@@ -1056,7 +1091,7 @@ __global__ void __launch_bounds__(256) k_escaped(DPathState st, DScene sc, DTabl
                     const DLight& l = sc.lights[li];
                     light_pdf = light_pdf + (l.kind == HK_LIGHT_ENVIRONMENT ? env_pdf_li(sc.envmaps[l.Le_tex], rd) : 0.0f);
                 }
-            S4 rl = ld_throughput(g.r_l, slot, ones) * choice * light_pdf;
+            S4 rl = ld_rl(g, slot, ones, st.compact != 0) * choice * light_pdf;
             float den = average(r_u + rl);
             fin = den > 1e-10f ? contribution / den : contribution / average(r_u);
         }
@@ -1092,7 +1127,7 @@ HKD void shade_emission(DPathState& st, const DPathGen& g, bool ones, const DSce
     const DLight& light = sc.lights[meta.arealight - 1];
     S4 Le = arealight_Le(sc, T, light, wo, sf.n, sf.uv, lambda);
     if (is_black(Le)) return;
-    const S4 beta = ld_throughput(g.beta, slot, ones), r_u = ld_throughput(g.r_u, slot, ones), r_l = ld_throughput(g.r_l, slot, ones);
+    const S4 beta = ld_throughput(g.beta, slot, ones), r_u = ld_ru(g, slot, ones, st.compact != 0), r_l = ld_rl(g, slot, ones, st.compact != 0);
     const uint2 pmeta = g.meta[slot];
     const uint32_t fl = pmeta.x;
     const int pdepth = (int)(fl & 0xff);
@@ -1198,7 +1233,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
             meta = sc.meta[prim];
             lambda = ld4(&g.lambda[slot]);
             beta = ld_throughput(g.beta, slot, ones);
-            r_u = ld_throughput(g.r_u, slot, ones);
+            r_u = ld_ru(g, slot, ones, st.compact != 0);
             const uint2 pmeta = g.meta[slot];
             fl = pmeta.x;
             pslot = pmeta.y;
@@ -1308,8 +1343,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
                 st.sh_o[ps] = shO;
                 st.sh_d[ps] = shD;
                 st4(&st.sh_Ld[ps], shLd);
-                st4(&st.sh_ru[ps], shRu);
-                st4(&st.sh_rl[ps], shRl);
+                st_shadow_weights(st, ps, shRu, shRl);
                 st.sh_slot[ps] = pslot;
             }
         }
@@ -1360,8 +1394,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
                 gn.ray_o[pn] = nO;
                 gn.ray_d[pn] = nD;
                 st4(&gn.beta[pn], nb);
-                st4(&gn.r_u[pn], r_u);
-                st4(&gn.r_l[pn], nrl);
+                st_ru_rl(gn, pn, r_u, nrl, st.compact != 0);
                 st4(&gn.lambda[pn], lambda);
                 gn.meta[pn] = make_uint2(nflags, pslot);
             }
@@ -1386,9 +1419,12 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
 //                  together for all lanes that need one, and finished lanes pull the next shadow ray of the wave's queue.
 // ---------------------------------------------------------------------------------------------------
 // rec: index of the shadow record (segment * wave_cap + position in the segment's shadow queue)
+template <bool COMPACT>
 HKD void shadow_contribute(DPathState& st, uint32_t rec, S4 T_ray, S4 tr_u, S4 tr_l) {
     if (is_black(T_ray)) return;
-    S4 mis = ld4(&st.sh_ru[rec]) * tr_u + ld4(&st.sh_rl[rec]) * tr_l;
+    S4 w_u, w_l;
+    ld_shadow_weights<COMPACT>(st, rec, w_u, w_l);
+    S4 mis = w_u * tr_u + w_l * tr_l;
     float den = average(mis);
     if (den > 1e-10f) {
         S4 fin = ld4(&st.sh_Ld[rec]) * T_ray / den;
@@ -1420,7 +1456,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_shadow(DPathState st, DScene
         if (run_m == 0ull || (64 - __popcll(run_m) >= HK_TRACE_MIN_IDLE && (cursor < n || more))) {
             if (have && r.cur == DONE) {   // finished: an unoccluded shadow ray delivers its contribution
                 if (r.best.prim < 0)
-                    shadow_contribute(st, slot, s4(1.0f), s4(1.0f), s4(1.0f));
+                    shadow_contribute<true>(st, slot, s4(1.0f), s4(1.0f), s4(1.0f));
                 else
                     ++n_hits;
                 have = false;
@@ -1593,7 +1629,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
                         segi = 0;
                         state = SH_TRACK;
                     } else if (miss_case) {
-                        shadow_contribute(st, slot, T_ray, tr_u, tr_l);
+                        shadow_contribute<MM == 0>(st, slot, T_ray, tr_u, tr_l);
                         state = SH_EMPTY;
                     } else {
                         // step over the surface (no medium on this side)
@@ -1708,7 +1744,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
                         tr_u = tr_u * su;
                         tr_l = tr_l * sl;
                         if (miss_case) {
-                            shadow_contribute(st, slot, T_ray, tr_u, tr_l);
+                            shadow_contribute<MM == 0>(st, slot, T_ray, tr_u, tr_l);
                             state = SH_EMPTY;
                         } else {
                             bool stop = false;

@@ -30,6 +30,7 @@ void launch_medium(hipStream_t, int, const DPathState&, const DScene&, const DTa
 void launch_detect_camera_medium(hipStream_t, const DPathState&, const DScene&, float, float, float, DStats*);
 void launch_shade(hipStream_t, int, int, const DPathState&, const DScene&, const DTables&, const DFrame&, const DSobol&, int, int, DStats*);
 void launch_film(hipStream_t, const DPathState&, const DFrame&, const DTables&, void*, bool);
+void launch_segment_lists(hipStream_t, const DPathState&, int, const int*, const int*);
 void launch_finalize(hipStream_t, const void*, bool, float*, int, int);
 void launch_test_trace(hipStream_t, const DScene&, int, const float*, const float*, const float*, float*, int*, float*);
 void launch_test_sobol(hipStream_t, const DTables&, const DSobol&, int, const int*, const int*, const int*, const int*, float*, float*);
@@ -1092,19 +1093,24 @@ hipError_t alloc_arr(hk_integrator* I, T*& dst, size_t n) {
     dst = b->as<T>();
     return e;
 }
-// W virtual wave segments: every queue is split W ways and a segment is processed by whichever physical wave draws its ticket,
-// so W is independent of each kernel's residency.  Finer segments balance better (and media / escaping paths make the work
-// per segment very uneven), but every segment should keep >= 16 chunks (1024 paths) so its per-kind queues fill whole waves:
-// W = chunks / 16 clamped to [4, 48] segments per CU (96 with media, where every kernel draws tickets).  stats rows are indexed by PHYSICAL wave (ctx->stat_rows).
-int ensure_state(hk_integrator* I, int capacity, bool media) {
+// W virtual wave segments: every queue is split W ways and a segment is processed by one wave per kernel, so W is independent of each
+// kernel's residency.  Finer segments balance better, but every segment should keep >= 16 chunks (1024 paths) so its per-kind queues
+// fill whole waves: W = chunks / 16, capped per CU.  Measured on the four bench scenes (work lists + 64-way XCD-affine tickets):
+//   media                     tickets, 256 per CU   (cloud 2.21 -> 2.32 G rays/s against 96; the work per segment is wildly uneven)
+//   surfaces, closed scene    tickets, 192 per CU   (Cornell 7.19 -> 7.55, many-light 1.11 -> 1.19: trace -10 %, light-BVH shading -9 %)
+//   surfaces, open scene      static stride, 48 per CU   (sky: most paths escape after 1-2 vertices; finer segments only fragment
+//                             the per-kind queues: k_shade +7 % at 96, +15 % at 256, whichever way they are handed out)
+// HK_WAVES_PER_CU / HK_DYNAMIC_SEGMENTS override.  stats rows are indexed by PHYSICAL wave (ctx->stat_rows).
+int ensure_state(hk_integrator* I, int capacity, bool media, bool open_scene) {
     const int n_cu = I->ctx->n_cu;
-    const long cap_per_cu = media ? 96 : 48;   // media scenes draw tickets in every kernel and their segments are the most uneven: finer
+    const long cap_per_cu = media ? 256 : (open_scene ? 48 : 192);
     long W_want = ((long)(capacity + 63) / 64) / 16;
     if (W_want < 4L * n_cu) W_want = 4L * n_cu;
     if (W_want > cap_per_cu * n_cu) W_want = cap_per_cu * n_cu;
     if (I->ctx->waves_per_cu > 0) W_want = (long)I->ctx->waves_per_cu * n_cu;
     W_want = (W_want + 3) / 4 * 4;
-    I->st.dynamic_segments = media ? 1 : 0;
+    I->st.dynamic_segments = (media || !open_scene) ? 1 : 0;
+    if (const char* e = std::getenv("HK_DYNAMIC_SEGMENTS")) I->st.dynamic_segments = std::atoi(e) ? 1 : 0;
     I->st.compact = media ? 0 : 1;
     if (I->st_capacity >= capacity && I->st_depth >= I->p.max_depth && I->st.n_waves == (int)W_want) return HK_OK;
     for (auto* b : I->bufs) delete b;
@@ -1150,6 +1156,8 @@ int ensure_state(hk_integrator* I, int capacity, bool media) {
     size_t nc = (size_t)(I->p.max_depth + 2) * Q_COUNT * W;
     HIP_TRY(alloc_arr(I, s.counters, nc));
     HIP_TRY(hipMemset(s.counters, 0, nc * sizeof(int)));
+    HIP_TRY(alloc_arr(I, s.seg_list, nc));
+    HIP_TRY(alloc_arr(I, s.seg_list_n, (size_t)(I->p.max_depth + 2) * Q_COUNT));
     I->st_capacity = capacity;
     I->st_depth = I->p.max_depth;
     return HK_OK;
@@ -1237,7 +1245,7 @@ extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_
     }
     if (S > n_samples) S = n_samples;
     if ((long)S * fr.n_pixels_padded > 0x3fffffffL) return fail(HK_ERR_INVALID, "pass too large");
-    int st = ensure_state(I, S * fr.n_pixels_padded, sc->d.n_media > 0);
+    int st = ensure_state(I, S * fr.n_pixels_padded, sc->d.n_media > 0, sc->d.has_escape_lights != 0);
     if (st != HK_OK) return st;
     fr.sample_stride = sample_stride;
     fr.max_depth = I->p.max_depth;
@@ -1350,6 +1358,16 @@ extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_
         // environment map, say) must not see the ray / shadow counts an earlier render left behind
         HIP_TRY(hipMemsetAsync(I->st.counters, 0, (size_t)(I->st_depth + 2) * Q_COUNT * I->st.n_waves * sizeof(int), s));
         if (timed(3, [&] { hk::launch_camera(s, c->n_cu, I->st, fr, c->tables, I->filter, dc, sob, -1); }) != HK_OK) return fail(HK_ERR_DEVICE, "event record failed");
+        // work lists: after every producer, the non-empty segments of the queues it filled (consumers never visit an empty segment)
+        auto lists = [&](std::initializer_list<std::pair<int, int>> dq, bool kinds_of_depth = false, int kd = 0) {
+            int dd[HK_MAX_KINDS + 6], qq[HK_MAX_KINDS + 6], n = 0;
+            for (auto& e : dq) dd[n] = e.first, qq[n] = e.second, ++n;
+            if (kinds_of_depth)
+                for (int kind = 0; kind < HK_MAX_KINDS; ++kind)
+                    if (sc->kinds_mask & (1u << kind)) dd[n] = kd, qq[n] = Q_MAT0 + kind, ++n;
+            timed(3, [&] { hk::launch_segment_lists(s, I->st, n, dd, qq); });
+        };
+        lists({{0, Q_RAY}});
         for (int depth = 0; depth < I->p.max_depth; ++depth) {
             timed(0, [&] { hk::launch_trace(s, trace_blocks, I->st, sc->d, c->tables, fr, depth, dstats); });
             c->trace_launches++;
@@ -1358,6 +1376,10 @@ extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_
                 timed(4, [&] { hk::launch_medium(s, c->n_cu, I->st, sc->d, c->tables, fr, sob, depth, dstats); });
                 first_kind = 0;
             }
+            if (sc->d.has_escape_lights)
+                lists({{depth, Q_ESCAPED}}, true, depth);
+            else
+                lists({}, true, depth);
             if (sc->d.has_escape_lights) timed(3, [&] { hk::launch_escaped(s, light_blocks, I->st, sc->d, c->tables, fr, depth); });
             for (int kind = 0; kind < HK_MAX_KINDS; ++kind)
                 if (sc->kinds_mask & (1u << kind)) {
@@ -1365,6 +1387,7 @@ extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_
                     first_kind = 0;
                     c->shade_launches++;
                 }
+            lists({{depth, Q_SHADOW}, {depth + 1, Q_RAY}});
             if (sc->d.n_lights > 0) {
                 timed(1, [&] { hk::launch_shadow(s, trace_blocks, I->st, sc->d, c->tables, fr, depth, dstats); });
                 c->shadow_launches++;

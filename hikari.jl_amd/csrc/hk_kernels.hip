@@ -44,65 +44,88 @@ __device__ __forceinline__ int physical_waves() { return (int)(gridDim.x * (bloc
 // (so another memory channel), hands out the segments k, k + K, k + 2K, ...; a wave starts at counter (wave mod K) and moves on
 // to the next live counter when one is exhausted, never to come back.  Same one-segment granularity and the same stealing
 // behaviour, 1/K of the serialisation.
+// WORK LISTS.  At the deep bounces most segments of a queue are empty (an open scene loses half of its paths per bounce), and a
+// launch that visits all W segments pays a count-word round trip (plus a ticket) per empty one.  After every producer the host
+// launches k_segment_lists, which writes, per queue, the ascending list of its non-empty segments and their number; consumers
+// iterate over the list — statically (entry w, w + waves, ...) or by ticket — and never see an empty segment.
 struct SegTickets {
     int* cnt;                   // HK_TICKET_WAYS (= 64: one per lane) counters, HK_TICKET_STRIDE ints apart
     unsigned long long alive;   // counters not yet seen exhausted (wave-uniform)
     int k0;                     // where this wave starts looking
+    const int* list;            // non-empty segments of the consumed queue, ascending (null: every segment 0 .. n - 1)
+    int n;                      // entries to hand out
+    int pos, step;              // static mode: next entry of this wave, stride (step == 0: ticket mode)
+    unsigned long long own;     // ticket mode: the counters whose segments the static stride would give to this wave's XCD
 };
-__device__ __forceinline__ int seg_per_way(int n_segments, int k) { return (n_segments - k + HK_TICKET_WAYS - 1) / HK_TICKET_WAYS; }
-// all 64 counters are inspected with ONE parallel load (lane k reads counter k): an exhausted launch costs a wave one memory
-// round trip and no atomic at all
-__device__ __forceinline__ SegTickets seg_open(int* cnt, int n_segments) {
-    const int lane = lane_id();
-    const int v = __hip_atomic_load(cnt + lane * HK_TICKET_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return SegTickets{cnt, __ballot(v < seg_per_way(n_segments, lane)), global_wave() & (HK_TICKET_WAYS - 1)};
+// Static stride: block b runs on XCD b % 8 and its wave w takes the list entries 4b + w, 4b + w + waves, ...: the records one kernel
+// writes are read by the next kernel from the SAME XCD's L2 while they are still there (the per-XCD L2s do not share).  Tickets keep
+// that affinity: counter k hands out entries k, k + 64, ..., all congruent to k mod 32, so counter k "belongs" to XCD (k / 4) % 8; a wave
+// draws from the eight counters of its own XCD first and steals from the others only when those are exhausted (sky scene: the
+// deep, sparse bounces fit in L2 — shade +12 % slower with XCD-blind tickets).
+__device__ __forceinline__ unsigned long long xcd_counters() {
+    int x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    x &= 7;
+    return (0xfull << (4 * x)) | (0xfull << (4 * x + 32));
 }
+__device__ __forceinline__ int seg_per_way(int n_segments, int k) { return (n_segments - k + HK_TICKET_WAYS - 1) / HK_TICKET_WAYS; }
+__device__ __forceinline__ const int* seg_list_ptr(const DPathState& st, int depth, int q) { return st.seg_list + (size_t)(depth * Q_COUNT + q) * st.n_waves; }
+// dynamic: all 64 counters are inspected with ONE parallel load (lane k reads counter k): an exhausted launch costs a wave one
+// memory round trip and no atomic at all.  depth < 0: no list, every segment (the camera kernel).
+__device__ __forceinline__ SegTickets seg_open(const DPathState& st, int* cnt, bool dynamic, int depth, int q) {
+    SegTickets it;
+    it.cnt = cnt;
+    it.list = depth >= 0 ? seg_list_ptr(st, depth, q) : nullptr;
+    it.n = depth >= 0 ? st.seg_list_n[depth * Q_COUNT + q] : st.n_waves;
+    it.k0 = global_wave() & (HK_TICKET_WAYS - 1);
+    it.pos = global_wave();
+    it.step = dynamic ? 0 : physical_waves();
+    it.alive = 0ull;
+    it.own = 0ull;
+    if (dynamic) {
+        it.own = xcd_counters();
+        const int lane = lane_id();
+        const int v = __hip_atomic_load(cnt + lane * HK_TICKET_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        it.alive = __ballot(v < seg_per_way(it.n, lane));
+    }
+    return it;
+}
+__device__ __forceinline__ int seg_entry(const SegTickets& it, int i) { return it.list ? it.list[i] : i; }
 __device__ __forceinline__ int seg_next(SegTickets& it, int n_segments) {   // -> segment index, or n_segments when none is left
+    if (it.step != 0) {
+        const int i = it.pos;
+        if (i >= it.n) return n_segments;
+        it.pos = i + it.step;
+        return seg_entry(it, i);
+    }
     while (it.alive != 0ull) {
         // first live counter at or after k0 (cyclically)
-        const unsigned long long rot = it.k0 == 0 ? it.alive : ((it.alive >> it.k0) | (it.alive << (64 - it.k0)));
+        const unsigned long long cand = (it.alive & it.own) != 0ull ? (it.alive & it.own) : it.alive;
+        const unsigned long long rot = it.k0 == 0 ? cand : ((cand >> it.k0) | (cand << (64 - it.k0)));
         const int k = (it.k0 + __ffsll((long long)rot) - 1) & (HK_TICKET_WAYS - 1);
-        const int per_k = seg_per_way(n_segments, k);
+        const int per_k = seg_per_way(it.n, k);
         int t = 0;
         if (lane_id() == 0) t = atomicAdd(it.cnt + k * HK_TICKET_STRIDE, 1);
         t = __builtin_amdgcn_readfirstlane(t);
         it.k0 = k;
-        if (t < per_k) return k + t * HK_TICKET_WAYS;
+        if (t < per_k) return seg_entry(it, k + t * HK_TICKET_WAYS);
         it.alive &= ~(1ull << k);   // counters only grow: exhausted once, exhausted for good
     }
     return n_segments;
 }
-#define HK_FOR_EACH_WAVE_SEGMENT_DYNAMIC(gw, st, ticket) \
-    for (SegTickets gw##_t = seg_open(ticket, (st).n_waves); gw##_t.cnt; gw##_t.cnt = nullptr) \
+// depth / q: the queue the kernel consumes (its work list); depth < 0: all segments
+#define HK_FOR_EACH_WAVE_SEGMENT(gw, st, ticket, depth, q)                                                        \
+    for (SegTickets gw##_t = seg_open(st, ticket, (st).dynamic_segments != 0, depth, q); gw##_t.cnt; gw##_t.cnt = nullptr) \
         for (int gw = seg_next(gw##_t, (st).n_waves); gw < (st).n_waves; gw = seg_next(gw##_t, (st).n_waves))
-#define HK_FOR_EACH_WAVE_SEGMENT(gw, st, ticket)                                                              \
-    for (SegTickets gw##_t = (st).dynamic_segments ? seg_open(ticket, (st).n_waves) : SegTickets{ticket, 0ull, 0}; gw##_t.cnt; gw##_t.cnt = nullptr) \
-        for (int gw = (st).dynamic_segments ? seg_next(gw##_t, (st).n_waves) : global_wave(); gw < (st).n_waves; \
-             gw = (st).dynamic_segments ? seg_next(gw##_t, (st).n_waves) : gw + physical_waves())
 // A kernel whose lanes leave nothing behind in their segment (the shadow kernels: results go to L[slot]) does not have to drain its
-// lanes at the end of every segment: SegStream hands the wave one segment after another — tickets in media scenes, static stride
-// otherwise — and the per-lane refill simply continues with the next segment's entries.  The only drain left is the one at the end
-// of the launch (the shadow walk of the cloud config ran a third of its lane-slots empty in the tails of its ~1000-entry segments).
-struct SegStream {
-    SegTickets tk;
-    int gw;        // next static segment (static mode)
-    int step;      // static stride
-    bool dynamic;
-};
-__device__ __forceinline__ SegStream stream_open(const DPathState& st, int* ticket, bool force_dynamic) {
-    SegStream s;
-    s.dynamic = force_dynamic || st.dynamic_segments != 0;
-    s.tk = s.dynamic ? seg_open(ticket, st.n_waves) : SegTickets{ticket, 0ull, 0};
-    s.gw = global_wave();
-    s.step = physical_waves();
-    return s;
+// lanes at the end of every segment: it asks for one segment after another and the per-lane refill simply continues with the next
+// segment's entries.  The only drain left is the one at the end of the launch (the shadow walk of the cloud config ran a third of
+// its lane-slots empty in the tails of its ~1000-entry segments).
+typedef SegTickets SegStream;
+__device__ __forceinline__ SegStream stream_open(const DPathState& st, int* ticket, bool force_dynamic, int depth, int q) {
+    return seg_open(st, ticket, force_dynamic || st.dynamic_segments != 0, depth, q);
 }
-__device__ __forceinline__ int stream_next(SegStream& s, int n_segments) {   // -> segment index, or n_segments when the stream is exhausted
-    if (s.dynamic) return seg_next(s.tk, n_segments);
-    const int g = s.gw;
-    s.gw = g < n_segments ? g + s.step : g;
-    return g < n_segments ? g : n_segments;
-}
+__device__ __forceinline__ int stream_next(SegStream& s, int n_segments) { return seg_next(s, n_segments); }
 // ticket words: row = bounce depth (row max_depth + 1: camera / film), column = kernel
 enum { TK_TRACE = 0, TK_TRACK = 1, TK_SHADOW = 2, TK_ESCAPED = 3, TK_SCATTER = 4, TK_SHADE0 = 5, TK_CAMERA = 0, TK_FILM = 1 };
 __device__ __forceinline__ int* ticket_ptr(const DPathState& st, int row, int col) { return st.tickets + (size_t)(row * HK_TICKET_COLS + col) * (HK_TICKET_WAYS * HK_TICKET_STRIDE); }
@@ -217,6 +240,37 @@ __global__ void __launch_bounds__(256) k_sobol_table(DSobol sob, DFrame fr, uint
     }
 }
 
+// Work lists (see SegTickets): one block per queue writes the ascending list of that queue's non-empty segments and its length.
+struct SegQueues {
+    int n;
+    int depth[HK_MAX_KINDS + 6], q[HK_MAX_KINDS + 6];
+};
+__global__ void __launch_bounds__(1024) k_segment_lists(DPathState st, SegQueues qs) {
+    __shared__ int wave_total[16];
+    const int d = qs.depth[blockIdx.x], q = qs.q[blockIdx.x];
+    const int* __restrict__ cnt = st.counters + (size_t)(d * Q_COUNT + q) * st.n_waves;
+    int* __restrict__ out = st.seg_list + (size_t)(d * Q_COUNT + q) * st.n_waves;
+    const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
+    int base = 0;
+    for (int start = 0; start < st.n_waves; start += 1024) {
+        const int i = start + (int)threadIdx.x;
+        const bool nz = i < st.n_waves && cnt[i] != 0;
+        const unsigned long long m = __ballot(nz);
+        if (lane == 0) wave_total[wave] = __popcll(m);
+        __syncthreads();
+        int before = 0, total = 0;
+        for (int w = 0; w < 16; ++w) {
+            const int t = wave_total[w];
+            before += w < wave ? t : 0;
+            total += t;
+        }
+        if (nz) out[base + before + __popcll(m & ((1ull << lane) - 1ull))] = i;
+        base += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) st.seg_list_n[d * Q_COUNT + q] = base;
+}
+
 // Sample-bit table (DSobol::lo_table): the low log2_spp bits of the permuted index for sample indices base + j * stride, j < count.
 // One thread per four entries.  With stride 1 and base a multiple of 4 the four share every digit but the last, and the last
 // digit's permutation is chosen by the digits above it: one evaluation plus one hash instead of four evaluations.
@@ -256,7 +310,7 @@ __global__ void __launch_bounds__(256) k_camera(DPathState st, DFrame fr, DTable
     const int total = fr.n_pixels_padded * fr.samples_in_pass;
     const int n_chunks = total >> 6;
     const DPathGen g0 = st.gen[0];
-    HK_FOR_EACH_WAVE_SEGMENT(gw, st, ticket_ptr(st, st.ticket_rows - 1, TK_CAMERA)) {
+    HK_FOR_EACH_WAVE_SEGMENT(gw, st, ticket_ptr(st, st.ticket_rows - 1, TK_CAMERA), -1, 0) {
     WavePos out{0};
     const size_t seg = (size_t)gw * st.wave_cap;
     // wave w generates chunks w, w+W, w+2W, ... (64 consecutive slots = samples of one pixel, or of 64 / S pixels; interleaved across waves for load balance)
@@ -321,7 +375,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace(DPathState st, DScene 
     int* stack = lds_stack + (threadIdx.x >> 6) * (HK_LDS_STACK * 64);
     const int lane = lane_id();
     unsigned n_nodes = 0, n_tris = 0, n_casts = 0, n_hits = 0;
-    HK_FOR_EACH_WAVE_SEGMENT(gw, st, ticket_ptr(st, depth, TK_TRACE)) {
+    HK_FOR_EACH_WAVE_SEGMENT(gw, st, ticket_ptr(st, depth, TK_TRACE), depth, Q_RAY) {
     const DPathGen g = st.gen[depth & 1];
     const uint32_t seg = (uint32_t)gw * (uint32_t)st.wave_cap;   // the segment's live rays are entries seg .. seg + n - 1 of this generation
     const int n = *count_ptr(st, depth, Q_RAY, gw);
@@ -525,7 +579,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace_lean(DPathState st, DS
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const int DONE = (int)0x80000000;
     unsigned n_nodes = 0, n_tris = 0, n_casts = 0, n_hits = 0;
-    HK_FOR_EACH_WAVE_SEGMENT(gw, st, ticket_ptr(st, depth, TK_TRACE)) {
+    HK_FOR_EACH_WAVE_SEGMENT(gw, st, ticket_ptr(st, depth, TK_TRACE), depth, Q_RAY) {
     const DPathGen g = st.gen[depth & 1];
     const uint32_t seg = (uint32_t)gw * (uint32_t)st.wave_cap;   // the rays of this segment: entries seg .. seg + n - 1, read in order (no index queue)
     const int n = *count_ptr(st, depth, Q_RAY, gw);
@@ -655,7 +709,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
     // uneven that a third of the lane-slots of a segment-at-a-time walk sat empty in the segment's tail.  A finished path must be
     // pushed into the queues of ITS segment, so two segments are open at any time — `cur` (tag cur_tag) feeds the refill, the other
     // slot holds the previous segment until its last lane has finished — and every lane carries the tag of its segment.
-    SegStream stream = stream_open(st, ticket_ptr(st, depth, TK_TRACK), true);
+    SegStream stream = stream_open(st, ticket_ptr(st, depth, TK_TRACK), true, depth, Q_MEDIUM);
     TrackSeg seg[2];
     seg[0].gw = seg[1].gw = -1;
     int cur_tag = 0;
@@ -921,7 +975,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
 // ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_scatter(DPathState st, DScene sc, DTables T, DFrame fr, DSobol sob, int depth, DStats* stats) {
     unsigned n_lnodes = 0;
-    HK_FOR_EACH_WAVE_SEGMENT(gw, st, ticket_ptr(st, depth, TK_SCATTER)) {
+    HK_FOR_EACH_WAVE_SEGMENT(gw, st, ticket_ptr(st, depth, TK_SCATTER), depth, Q_SCATTER) {
         const uint32_t* __restrict__ queue = st.scatter_q + (size_t)gw * st.wave_cap;
         const int n = *count_ptr(st, depth, Q_SCATTER, gw);
         const DPathGen g = st.gen[depth & 1], gn = st.gen[(depth + 1) & 1];
@@ -1048,7 +1102,7 @@ __global__ void __launch_bounds__(64) k_detect_camera_medium(DPathState st, DSce
 // K7: escaped rays (intersection.jl:622-678; lights.jl:408-467).  MIS uses 1/num_lights (Q6).
 // ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_escaped(DPathState st, DScene sc, DTables T, int depth, int implicit_ones) {
-    HK_FOR_EACH_WAVE_SEGMENT(gw, st, ticket_ptr(st, depth, TK_ESCAPED)) {
+    HK_FOR_EACH_WAVE_SEGMENT(gw, st, ticket_ptr(st, depth, TK_ESCAPED), depth, Q_ESCAPED) {
     const uint32_t* __restrict__ queue = st.escaped_q + (size_t)gw * st.wave_cap;
     const int n = *count_ptr(st, depth, Q_ESCAPED, gw);
     const DPathGen g = st.gen[depth & 1];
@@ -1162,7 +1216,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
     __shared__ uint32_t emit_list[4 * 128];   // per wave: slots of flagged (emissive-hit) vertices waiting for the dense K8 pass
     const int lane = lane_id();
     unsigned n_vertices = 0, n_lnodes = 0;
-    HK_FOR_EACH_WAVE_SEGMENT(gw, st, ticket_ptr(st, depth, TK_SHADE0 + KIND)) {
+    HK_FOR_EACH_WAVE_SEGMENT(gw, st, ticket_ptr(st, depth, TK_SHADE0 + KIND), depth, Q_MAT0 + KIND) {
     const uint32_t* __restrict__ queue = st.mat_q + ((size_t)KIND * st.n_waves + gw) * st.wave_cap;
     const int n = *count_ptr(st, depth, Q_MAT0 + KIND, gw);
     const DPathGen g = st.gen[depth & 1], gn = st.gen[(depth + 1) & 1];
@@ -1443,7 +1497,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_shadow(DPathState st, DScene
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const int DONE = (int)0x80000000;
     unsigned n_nodes = 0, n_tris = 0, n_casts = 0, n_hits = 0;
-    SegStream stream = stream_open(st, ticket_ptr(st, depth, TK_SHADOW), false);
+    SegStream stream = stream_open(st, ticket_ptr(st, depth, TK_SHADOW), false, depth, Q_SHADOW);
     uint32_t seg = 0;   // current segment's shadow records: entries seg .. seg + n - 1, streamed in order
     int n = 0, cursor = 0;
     bool more = true;
@@ -1514,7 +1568,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     unsigned n_nodes = 0, n_tris = 0, n_casts = 0, n_hits = 0, n_coll = 0;
     HK_DBG_DECL
-    SegStream stream = stream_open(st, ticket_ptr(st, depth, TK_SHADOW), true);
+    SegStream stream = stream_open(st, ticket_ptr(st, depth, TK_SHADOW), true, depth, Q_SHADOW);
     uint32_t rec0 = 0;   // current segment's shadow records: entries rec0 .. rec0 + n - 1 (the wave streams segment after segment)
     int n = 0, cursor = 0;
     bool more = true;
@@ -2285,7 +2339,22 @@ void launch_shadow(hipStream_t s, int n_cu, const DPathState& st, const DScene& 
 #undef HK_SHADOW_MM
 #undef HK_SHADOW_LAUNCH
 }
+// work lists of up to HK_MAX_KINDS + 6 queues (pairs depth, queue id) in one launch
+void launch_segment_lists(hipStream_t s, const DPathState& st, int n, const int* depths, const int* queues) {
+    if (n <= 0) return;
+    SegQueues qs;
+    qs.n = n;
+    for (int i = 0; i < n; ++i) {
+        qs.depth[i] = depths[i];
+        qs.q[i] = queues[i];
+    }
+    hipLaunchKernelGGL(k_segment_lists, dim3(n), dim3(1024), 0, s, st, qs);
+}
 void launch_medium(hipStream_t s, int n_cu, const DPathState& st, const DScene& sc, const DTables& T, const DFrame& fr, const DSobol& sob, int depth, DStats* stats) {
+    {
+        const int d = depth, q = Q_MEDIUM;
+        launch_segment_lists(s, st, 1, &d, &q);
+    }
 #define HK_TRACK_LAUNCH(MM)                                                                                              \
     {                                                                                                                    \
         const int blocks = cached_blocks<k_track<MM>>(256, n_cu, 8);                                                   \
@@ -2299,6 +2368,10 @@ void launch_medium(hipStream_t s, int n_cu, const DPathState& st, const DScene& 
         default: HK_TRACK_LAUNCH(15) break;
     }
 #undef HK_TRACK_LAUNCH
+    {
+        const int d = depth, q = Q_SCATTER;
+        launch_segment_lists(s, st, 1, &d, &q);
+    }
     const int sblocks = cached_blocks<k_scatter>(256, n_cu, 8);
     hipLaunchKernelGGL(k_scatter, dim3(clamp_blocks(sblocks, st)), dim3(256), 0, s, st, sc, T, fr, sob, depth, stats);
 }

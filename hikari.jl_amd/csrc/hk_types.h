@@ -262,6 +262,8 @@ struct DPathState {
     int* counters;         // [(max_depth + 2) * Q_COUNT][W] per-wave queue sizes
     int* tickets;          // [ticket_rows * HK_TICKET_COLS][HK_TICKET_WAYS * HK_TICKET_STRIDE] segment tickets (dynamic segment -> wave assignment), zeroed per pass
     int ticket_rows;       // max_depth + 2
+    int* seg_list;         // [depth][queue][n_waves]: ascending non-empty segments of each queue (k_segment_lists), laid out like `counters`
+    int* seg_list_n;       // [depth][queue]: their number
     int dynamic_segments;  // 1: every kernel draws its segments from the tickets (scenes with media); 0: static stride
     // 1 (scenes without media): r_u is 1 on every path and the four components of r_l are equal (r_l = r_u / pdf of a scalar pdf,
     // only media rescale them per wavelength) — r_u is not stored, r_l is one float per record (the float4 array's memory, read as

@@ -95,7 +95,7 @@ struct hk_ctx {
     int n_cu = 256;
     int waves_per_cu = 0;      // HK_WAVES_PER_CU: fixed number of wave segments per CU (0 = sized from the pass)
     int stat_rows = 8192;      // DStats rows, indexed by PHYSICAL wave: n_cu * 32 (8 waves x 4 SIMDs is the residency limit)
-    DevBuf sobol, cie, r2s_scale, r2s_coeffs, stats;
+    DevBuf sobol, cie, r2s_scale, r2s_coeffs, r2s_points, stats;
     DTables tables{};
     bool have_tables = false;
     std::vector<float> h_r2s_scale, h_r2s_coeffs;
@@ -223,6 +223,23 @@ extern "C" int32_t hk_ctx_set_tables(hk_ctx* c, const hk_tables* t) {
     c->r2s_host.coeffs = c->h_r2s_coeffs.data();
     HIP_TRY(c->r2s_scale.upload(t->rgb2spec_scale, res * 4));
     HIP_TRY(c->r2s_coeffs.upload(t->rgb2spec_coeffs, nco * 4));
+    {   // corner-per-load copy of the coefficient table and the monotonicity the device's cell search relies on
+        const size_t R = (size_t)res;
+        std::vector<float> pts(3 * R * R * R * 4);
+        for (size_t m = 0; m < 3; ++m)
+            for (size_t z = 0; z < R; ++z)
+                for (size_t y = 0; y < R; ++y)
+                    for (size_t x = 0; x < R; ++x) {
+                        float* o = &pts[((((m * R + z) * R + y) * R) + x) * 4];
+                        for (size_t k = 0; k < 3; ++k) o[k] = t->rgb2spec_coeffs[m + 3 * (z + R * (y + R * (x + R * k)))];
+                        o[3] = 0.0f;
+                    }
+        HIP_TRY(c->r2s_points.upload(pts.data(), pts.size() * 4));
+        bool sorted = true;
+        for (int i = 1; i < res; ++i)
+            if (!(t->rgb2spec_scale[i - 1] <= t->rgb2spec_scale[i])) sorted = false;
+        c->tables.rgb2spec_sorted = sorted ? 1 : 0;
+    }
     // Sobol dims 0/1 have closed forms (hk_device.h sobol_matrix_product); use them only if the caller's table
     // really is that matrix, otherwise keep the table loop.
     bool closed = true;
@@ -241,6 +258,7 @@ extern "C" int32_t hk_ctx_set_tables(hk_ctx* c, const hk_tables* t) {
     c->tables.rgb2spec_scale = c->r2s_scale.as<float>();
     c->tables.rgb2spec_coeffs = c->r2s_coeffs.as<float>();
     c->tables.rgb2spec_res = res;
+    c->tables.rgb2spec_points = c->r2s_points.as<float4>();
     c->have_tables = true;
     return HK_OK;
 }

@@ -502,6 +502,7 @@ HKD float poly_max_value(float c0, float c1, float c2) {
     return r;
 }
 // run-time table lookup (textured colours only; constant colours are baked on the host)
+template <bool TWO_PLANES = false>
 HKD void rgb_to_spectrum(const DTables& T, float r, float g, float b, float& c0, float& c1, float& c2) {
     r = clampf(r, 0.0f, 1.0f);
     g = clampf(g, 0.0f, 1.0f);
@@ -517,24 +518,63 @@ HKD void rgb_to_spectrum(const DTables& T, float r, float g, float b, float& c0,
     float yc = maxc == 1 ? b : (maxc == 2 ? r : g);
     int res = T.rgb2spec_res;
     float x = xc * (float)(res - 1) / z, y = yc * (float)(res - 1) / z;
-    int zi = 1;
-    for (int i = 1; i <= res - 1; ++i)
-        if (T.rgb2spec_scale[i - 1] < z) zi = i;
+    // zi = the largest i in 1 .. res-1 with scale[i-1] < z (1 when there is none): the reference's linear scan (rgb2spec.jl:118-124).
+    // The scale table is non-decreasing (hk_ctx_set_tables checks it), so the entries below z form a prefix: 6 probes, not 63.
+    int zi;
+    if (T.rgb2spec_sorted) {
+        int lo = 0, hi = res - 1;   // first j in [0, res-1) with !(scale[j] < z)
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (T.rgb2spec_scale[mid] < z)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        zi = lo < 1 ? 1 : lo;
+    } else {
+        zi = 1;
+        for (int i = 1; i <= res - 1; ++i)
+            if (T.rgb2spec_scale[i - 1] < z) zi = i;
+    }
     zi = zi < res - 1 ? zi : res - 1;
     int xi = (int)x + 1, yi = (int)y + 1;
     xi = xi < res - 1 ? xi : res - 1;
     yi = yi < res - 1 ? yi : res - 1;
     float dx = x - (float)(xi - 1), dy = y - (float)(yi - 1);
     float dz = (z - T.rgb2spec_scale[zi - 1]) / (T.rgb2spec_scale[zi] - T.rgb2spec_scale[zi - 1]);
-    size_t R = (size_t)res;
+    // the eight corners as float4 grid points (c0, c1, c2, -), x fastest (DTables::rgb2spec_points): 8 per-lane loads instead of 24
+    const size_t R = (size_t)res;
+    const float4* __restrict__ P = T.rgb2spec_points + (((size_t)(maxc - 1) * R + (size_t)(zi - 1)) * R + (size_t)(yi - 1)) * R + (size_t)(xi - 1);
     float out[3];
+    if (TWO_PLANES) {
+        // One z plane at a time (4 corners = 16 registers live, not 32): the second plane's address is made to depend on the first
+        // plane's result, otherwise the compiler hoists all eight loads.  Used by the Matte reflectance only: with all eight in
+        // flight k_shade<Matte> spills into its hot path (Cornell, which never comes here, +4 %); the other kinds run faster with
+        // the eight loads in flight (sky: k_shade -15 % against the two-plane form).
+        float pl[2][3];
+        unsigned plane = 0;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        auto A = [&](int zz, int yy, int xx) {
-            return T.rgb2spec_coeffs[(size_t)(maxc - 1) + 3 * ((size_t)(zz - 1) + R * ((size_t)(yy - 1) + R * ((size_t)(xx - 1) + R * (size_t)k)))];
-        };
-        out[k] = (1.0f - dz) * ((1.0f - dy) * ((1.0f - dx) * A(zi, yi, xi) + dx * A(zi, yi, xi + 1)) + dy * ((1.0f - dx) * A(zi, yi + 1, xi) + dx * A(zi, yi + 1, xi + 1))) +
-                 dz * ((1.0f - dy) * ((1.0f - dx) * A(zi + 1, yi, xi) + dx * A(zi + 1, yi, xi + 1)) + dy * ((1.0f - dx) * A(zi + 1, yi + 1, xi) + dx * A(zi + 1, yi + 1, xi + 1)));
+        for (int h = 0; h < 2; ++h) {
+            const float4 a00 = P[plane], a01 = P[plane + 1], a10 = P[plane + R], a11 = P[plane + R + 1];
+#define HK_R2S_LERP(F) ((1.0f - dy) * ((1.0f - dx) * a00.F + dx * a01.F) + dy * ((1.0f - dx) * a10.F + dx * a11.F))
+            pl[h][0] = HK_R2S_LERP(x);
+            pl[h][1] = HK_R2S_LERP(y);
+            pl[h][2] = HK_R2S_LERP(z);
+#undef HK_R2S_LERP
+            plane = (unsigned)(res * res);
+            if (h == 0) asm volatile("" : "+v"(plane) : "v"(pl[0][0]), "v"(pl[0][1]), "v"(pl[0][2]));
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) out[k] = (1.0f - dz) * pl[0][k] + dz * pl[1][k];
+    } else {
+        const float4 a000 = P[0], a001 = P[1], a010 = P[R], a011 = P[R + 1], a100 = P[R * R], a101 = P[R * R + 1], a110 = P[R * R + R], a111 = P[R * R + R + 1];
+#define HK_R2S_LERP(F)                                                                                                                  \
+    ((1.0f - dz) * ((1.0f - dy) * ((1.0f - dx) * a000.F + dx * a001.F) + dy * ((1.0f - dx) * a010.F + dx * a011.F)) +                    \
+     dz * ((1.0f - dy) * ((1.0f - dx) * a100.F + dx * a101.F) + dy * ((1.0f - dx) * a110.F + dx * a111.F)))
+        out[0] = HK_R2S_LERP(x);
+        out[1] = HK_R2S_LERP(y);
+        out[2] = HK_R2S_LERP(z);
+#undef HK_R2S_LERP
     }
     c0 = out[0];
     c1 = out[1];
@@ -562,24 +602,27 @@ HKD float sample_d65(float l) {  // uplift.jl:437-457
 HKD S4 d65_4(S4 l) { return s4(sample_d65(l.x), sample_d65(l.y), sample_d65(l.z), sample_d65(l.w)); }
 
 // the three uplifts, split into "coefficients" (host-baked or table lookup) and "evaluate"
+template <bool TWO_PLANES = false>
 HKD float4 coef_bounded(const DTables& T, float r, float g, float b) {  // uplift_rgb
     float c0, c1, c2;
-    rgb_to_spectrum(T, r, g, b, c0, c1, c2);
+    rgb_to_spectrum<TWO_PLANES>(T, r, g, b, c0, c1, c2);
     return make_float4(c0, c1, c2, 1.0f);
 }
+template <bool TWO_PLANES = false>
 HKD float4 coef_unbounded(const DTables& T, float r, float g, float b) {  // uplift_rgb_unbounded (Q5)
     float m = maxf(maxf(r, g), b);
     if (m <= 0.0f) return make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // scale 0 => zero spectrum
     float c0, c1, c2;
-    rgb_to_spectrum(T, r / m, g / m, b / m, c0, c1, c2);
+    rgb_to_spectrum<TWO_PLANES>(T, r / m, g / m, b / m, c0, c1, c2);
     return make_float4(c0, c1, c2, m / poly_max_value(c0, c1, c2));
 }
+template <bool TWO_PLANES = false>
 HKD float4 coef_illuminant(const DTables& T, float r, float g, float b) {  // rgb_to_spectral_sigmoid_illuminant
     float m = maxf(maxf(r, g), b);
     if (m <= 0.0f) return make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     float scale = 2.0f * m;
     float c0, c1, c2;
-    rgb_to_spectrum(T, r / scale, g / scale, b / scale, c0, c1, c2);
+    rgb_to_spectrum<TWO_PLANES>(T, r / scale, g / scale, b / scale, c0, c1, c2);
     return make_float4(c0, c1, c2, scale);
 }
 HKD S4 eval_bounded(float4 c, S4 l) { return poly_eval4(c, l); }
@@ -961,6 +1004,7 @@ HKD Surface surface_at(const DScene& sc, int prim, float bu, float bv, v3 ro, v3
 // materials: parameter fetch
 // ------------------------------------------------------------------------------------------------
 enum { UPLIFT_BOUNDED = 0, UPLIFT_UNBOUNDED = 1 };
+template <bool TWO_PLANES = false>
 HKD float4 rgb_param_coef(const DScene& sc, const DTables& T, const DSpectrumParam& p, const TexCtx& uv, int mode, bool clamp_lo) {
     if (p.tex < 0) return p.coef;
     float o[4] = {0, 0, 0, 1};
@@ -970,7 +1014,7 @@ HKD float4 rgb_param_coef(const DScene& sc, const DTables& T, const DSpectrumPar
         o[1] = clampf(o[1], 0.0f, INF_F);
         o[2] = clampf(o[2], 0.0f, INF_F);
     }
-    return mode == UPLIFT_BOUNDED ? coef_bounded(T, o[0], o[1], o[2]) : coef_unbounded(T, o[0], o[1], o[2]);
+    return mode == UPLIFT_BOUNDED ? coef_bounded<TWO_PLANES>(T, o[0], o[1], o[2]) : coef_unbounded<TWO_PLANES>(T, o[0], o[1], o[2]);
 }
 // alpha goes through eval_tex(ctx, ref, uv::Point2f) == _sample_texture_data: NEAREST texel by truncation
 // (textures/basic.jl:19-26; spectral-eval.jl:3882-3885), unlike shading, which is bilinear (quirk Q28)
@@ -1182,7 +1226,7 @@ namespace hkd {
 // hands it to both the next-event evaluation and the BSDF sample (the two would each run the four sigmoid evaluations — a
 // square root and a division per wavelength — on the same inputs).  Same operations, same order as the generic entry points.
 HKD S4 matte_kd(const DScene& sc, const DTables& T, const DMaterial& m, const TexCtx& uv, S4 lambda) {
-    return eval_bounded(rgb_param_coef(sc, T, m.rgb[0], uv, UPLIFT_BOUNDED, true), lambda);
+    return eval_bounded(rgb_param_coef<true>(sc, T, m.rgb[0], uv, UPLIFT_BOUNDED, true), lambda);
 }
 HKD S4 eval_matte_kd(S4 kd, v3 wo_w, v3 wi_w, v3 n, float& pdf) {  // spectral-eval.jl:371-398
     pdf = 0.0f;
@@ -1499,14 +1543,17 @@ struct LightSample {
     bool is_delta;
 };
 HKD S4 light_spectrum(const DLight& l, S4 lambda) { return eval_illuminant(l.coef, lambda); }
+// TWO_PLANES: see rgb_to_spectrum (true in k_shade<Matte>)
+template <bool TWO_PLANES = false>
 HKD S4 arealight_Le(const DScene& sc, const DTables& T, const DLight& l, v3 wo, v3 n, v2 uv, S4 lambda) {
     if (l.kind != HK_LIGHT_DIFFUSE_AREA) return s4(0.0f);
     if (!(l.flags & 1) && dot(wo, n) < 0.0f) return s4(0.0f);
     if (l.Le_tex < 0) return eval_bounded(l.coef, lambda);  // uplift_rgb(Le * scale), bounded (Q3)
     float o[4] = {0, 0, 0, 1};
     tex_bilinear(sc.textures[l.Le_tex], uv, o);
-    return eval_bounded(coef_bounded(T, o[0] * l.scale, o[1] * l.scale, o[2] * l.scale), lambda);
+    return eval_bounded(coef_bounded<TWO_PLANES>(T, o[0] * l.scale, o[1] * l.scale, o[2] * l.scale), lambda);
 }
+template <bool TWO_PLANES = false>
 HKD LightSample sample_light(const DScene& sc, const DTables& T, const DLight& l, v3 p, S4 lambda, v2 u) {
     LightSample s;
     s.Li = s4(0.0f);
@@ -1577,7 +1624,7 @@ HKD LightSample sample_light(const DScene& sc, const DTables& T, const DLight& l
             s.wi = wi;
             s.pdf = pdf;
             s.p_light = p + 1.0e6f * wi;
-            s.Li = eval_illuminant(coef_illuminant(T, t.x * l.Le_rgba[0], t.y * l.Le_rgba[1], t.z * l.Le_rgba[2]), lambda);
+            s.Li = eval_illuminant(coef_illuminant<TWO_PLANES>(T, t.x * l.Le_rgba[0], t.y * l.Le_rgba[1], t.z * l.Le_rgba[2]), lambda);
             return s;
         }
         case HK_LIGHT_DIFFUSE_AREA: {
@@ -1601,7 +1648,7 @@ HKD LightSample sample_light(const DScene& sc, const DTables& T, const DLight& l
             if (ct < 1e-6f) return s;
             float pdf = d2 / (ct * l.area);
             v2 uvs = mk2(b0 * l.uv[0] + b1 * l.uv[2] + b2 * l.uv[4], b0 * l.uv[1] + b1 * l.uv[3] + b2 * l.uv[5]);
-            S4 Le = arealight_Le(sc, T, l, mk3(-wi.x, -wi.y, -wi.z), ln, uvs, lambda);
+            S4 Le = arealight_Le<TWO_PLANES>(sc, T, l, mk3(-wi.x, -wi.y, -wi.z), ln, uvs, lambda);
             if (is_black(Le)) return s;
             s.Li = Le;
             s.wi = wi;

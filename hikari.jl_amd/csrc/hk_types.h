@@ -178,6 +178,8 @@ struct DTables {
     const float* rgb2spec_scale;
     const float* rgb2spec_coeffs;
     int rgb2spec_res;
+    const float4* rgb2spec_points;   // the same coefficients as float4 grid points (c0, c1, c2, 0) at [((maxc * res + z) * res + y) * res + x]: one load per corner
+    int rgb2spec_sorted;             // 1: rgb2spec_scale is non-decreasing (binary search for the z cell is then exact)
 };
 
 struct DFilter {

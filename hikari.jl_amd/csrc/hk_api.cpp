@@ -92,6 +92,9 @@ struct DevBuf {
 struct hk_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t aux = nullptr;            // second stream: the shadow rays of bounce d run beside the traversal of bounce d + 1
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int overlap = 1;                      // HK_OVERLAP=0 switches the second stream off
     int n_cu = 256;
     int waves_per_cu = 0;      // HK_WAVES_PER_CU: fixed number of wave segments per CU (0 = sized from the pass)
     int stat_rows = 8192;      // DStats rows, indexed by PHYSICAL wave: n_cu * 32 (8 waves x 4 SIMDs is the residency limit)
@@ -179,7 +182,8 @@ extern "C" int32_t hk_ctx_create(int32_t device_id, void* stream, hk_ctx** out) 
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     {
         if (const char* e = std::getenv("HK_WAVES_PER_CU")) c->waves_per_cu = std::atoi(e) > 0 ? std::atoi(e) : 0;
-        c->stat_rows = c->n_cu * 32;
+        c->stat_rows = c->n_cu * 32 * 2;   // second half: the kernels of the second stream (their waves have the same physical ids)
+        if (const char* e = std::getenv("HK_OVERLAP")) c->overlap = std::atoi(e) ? 1 : 0;
     }
     {
         std::vector<DStats> zero((size_t)c->stat_rows);
@@ -202,6 +206,9 @@ extern "C" int32_t hk_ctx_destroy(hk_ctx* c) {
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
     if (c->ev_end) (void)hipEventDestroy(c->ev_end);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->aux) (void)hipStreamDestroy(c->aux);
     delete c;
     return HK_OK;
 }
@@ -1386,9 +1393,26 @@ extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_
             timed(3, [&] { hk::launch_segment_lists(s, I->st, n, dd, qq); });
         };
         lists({{0, Q_RAY}});
+        // Two streams: k_shadow of bounce d touches only its shadow records and L; k_trace of bounce d + 1 touches neither.  The
+        // shadow launch goes to a second stream behind the shade kernels, the next traversal starts beside it, and the first stream
+        // waits for the shadows before anything that adds to L or rewrites shadow records (media tracking, escaped, shade).  The two
+        // fill each other's tails and stalls.  With per-kernel timing on (hk_stats_enable_counters bit 1) everything stays on one
+        // stream so that the class times add up.
+        // (surfaces only: beside the long shadow walks of a media scene the next traversal only competes — cloud -4.5 %; Cornell +-0, sky +1 %, many-light +2.4 %)
+        const bool overlap = c->overlap && !c->time_kernels && sc->d.n_lights > 0 && sc->d.n_media == 0;
+        if (overlap && !c->aux) {
+            HIP_TRY(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+        }
+        bool shadows_in_flight = false;
         for (int depth = 0; depth < I->p.max_depth; ++depth) {
             timed(0, [&] { hk::launch_trace(s, trace_blocks, I->st, sc->d, c->tables, fr, depth, dstats); });
             c->trace_launches++;
+            if (shadows_in_flight) {
+                HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
+                shadows_in_flight = false;
+            }
             int first_kind = 1;
             if (sc->d.n_media > 0) {
                 timed(4, [&] { hk::launch_medium(s, c->n_cu, I->st, sc->d, c->tables, fr, sob, depth, dstats); });
@@ -1407,10 +1431,18 @@ extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_
                 }
             lists({{depth, Q_SHADOW}, {depth + 1, Q_RAY}});
             if (sc->d.n_lights > 0) {
-                timed(1, [&] { hk::launch_shadow(s, trace_blocks, I->st, sc->d, c->tables, fr, depth, dstats); });
+                if (overlap) {
+                    HIP_TRY(hipEventRecord(c->ev_fork, s));
+                    HIP_TRY(hipStreamWaitEvent(c->aux, c->ev_fork, 0));
+                    hk::launch_shadow(c->aux, trace_blocks, I->st, sc->d, c->tables, fr, depth, dstats + c->stat_rows / 2);
+                    HIP_TRY(hipEventRecord(c->ev_join, c->aux));
+                    shadows_in_flight = true;
+                } else
+                    timed(1, [&] { hk::launch_shadow(s, trace_blocks, I->st, sc->d, c->tables, fr, depth, dstats); });
                 c->shadow_launches++;
             }
         }
+        if (shadows_in_flight) HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
         timed(3, [&] { hk::launch_film(s, I->st, fr, c->tables, film->accum, film->f64); });
         done += k;
     }

@@ -1301,8 +1301,8 @@ extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_
         // the deep rows serve few paths and fall back to hashing the sample digits.
         const long last_idx = (long)first_sample_idx + (long)(n_samples - 1) * sample_stride;
         if (n_samples >= 16 && sob.log2_spp >= 2 && sob.log2_spp <= 16 && (last_idx >> sob.log2_spp) == 0) {
-            const int base = sample_stride == 1 ? (first_sample_idx & ~3) : first_sample_idx;
-            const int count = (int)((((last_idx - base) / sample_stride + 1) + 3) & ~3L);
+            const int base = sample_stride == 1 ? (first_sample_idx & ~15) : first_sample_idx;
+            const int count = (int)((((last_idx - base) / sample_stride + 1) + 15) & ~15L);
             bool same = table_same && I->lo_base == base && I->lo_sample_stride == sample_stride && I->lo_count == count && I->lo_rows > 0;
             if (!same) {
                 double gb = 32.0;

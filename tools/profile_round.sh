@@ -12,6 +12,9 @@ if [ "$MODE" != "quick" ]; then
     timeout 900 python bench.py --config $c > $O/bench_${R}_$c.json 2> $O/bench_$c.err
   done
 fi
+# the profiled runs keep every kernel on one stream (HK_OVERLAP=0): a kernel trace of overlapping kernels charges each of them the
+# time it shared, and the per-kernel averages would no longer be comparable with the bench line's serial HIP-event replay
+export HK_OVERLAP=0
 prof() {  # name, config, extra bench args, counters...
   local name=$1 cfg=$2 extra=$3; shift 3
   local pmc=""; if [ $# -gt 0 ]; then pmc="--pmc $*"; fi
@@ -23,7 +26,7 @@ prof kernel_stats_cornell800 cornell ""
 prof kernel_stats_cloud1024 cloud "--warmup 1"
 prof kernel_stats_manylight1024 manylight "--warmup 1"
 prof kernel_stats_sky800 sky ""
-for cfg in cornell cloud manylight; do
+for cfg in cornell cloud manylight sky; do
   extra="--warmup 1"
   prof pmc_fetch_$cfg $cfg "$extra" FETCH_SIZE
   prof pmc_write_$cfg $cfg "$extra" WRITE_SIZE

@@ -1132,6 +1132,7 @@ int ensure_state(hk_integrator* I, int capacity, bool media, bool open_scene) {
     long W_want = ((long)(capacity + 63) / 64) / 16;
     if (W_want < 4L * n_cu) W_want = 4L * n_cu;
     if (W_want > cap_per_cu * n_cu) W_want = cap_per_cu * n_cu;
+    if (const char* e = std::getenv("HK_WAVES_PER_CU")) I->ctx->waves_per_cu = std::atoi(e) > 0 ? std::atoi(e) : 0;   // read per call: tests toggle it
     if (I->ctx->waves_per_cu > 0) W_want = (long)I->ctx->waves_per_cu * n_cu;
     W_want = (W_want + 3) / 4 * 4;
     I->st.dynamic_segments = (media || !open_scene) ? 1 : 0;
@@ -1399,6 +1400,7 @@ extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_
         // fill each other's tails and stalls.  With per-kernel timing on (hk_stats_enable_counters bit 1) everything stays on one
         // stream so that the class times add up.
         // (surfaces only: beside the long shadow walks of a media scene the next traversal only competes — cloud -4.5 %; Cornell +-0, sky +1 %, many-light +2.4 %)
+        if (const char* e = std::getenv("HK_OVERLAP")) c->overlap = std::atoi(e) ? 1 : 0;
         const bool overlap = c->overlap && !c->time_kernels && sc->d.n_lights > 0 && sc->d.n_media == 0;
         if (overlap && !c->aux) {
             HIP_TRY(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));

@@ -1857,47 +1857,91 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
 template <typename ACC>
 __global__ void __launch_bounds__(256) k_film(DPathState st, DFrame fr, DTables T, ACC* __restrict__ accum) {
     // One wave per 8x8 pixel tile = a contiguous run of 64 * S path slots.  The run is read 64 slots at a time (coalesced; the colour
-    // conversion runs on all lanes), the weighted colours go through LDS, and the lane that OWNS a pixel adds that pixel's entries one
-    // after the other: the sums are formed in sample order, as the reference forms them.
-    __shared__ float4 buf[4][64];
-    float4* mine = buf[threadIdx.x >> 6];
+    // conversion — twelve IEEE divisions and table reads per sample, the bulk of this kernel — runs on all lanes), the weighted
+    // colours go through LDS, and the entries of a pixel are added one after the other IN SAMPLE ORDER, as the reference adds them
+    // (so the film does not depend on the pass size): lanes 4p .. 4p+3 own the four channels of the p-th pixel met in the step.
+    __shared__ float buf[4][64 * 4];
+    float* mine = buf[threadIdx.x >> 6];
     const int lane = lane_id();
     const int S = fr.samples_in_pass;
     const int n_tiles = fr.n_pixels_padded >> 6;
     const size_t N = (size_t)fr.width * fr.height;
     const int n_waves = (int)(gridDim.x * (blockDim.x >> 6));
     for (int tile = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)); tile < n_tiles; tile += n_waves) {
-        int px, py;
-        bool inside;
-        slot_to_pixel(fr, tile * 64 + lane, px, py, inside);
-        const size_t p = inside ? (size_t)py * fr.width + px : 0;
-        ACC r = 0, g = 0, b = 0, w = 0;
-        if (inside) r = accum[3 * p], g = accum[3 * p + 1], b = accum[3 * p + 2], w = accum[3 * N + p];
         const size_t base = (size_t)tile * 64 * S;
-        const int lo = lane * S, hi = lo + S;   // this lane's pixel owns entries [lo, hi) of the run
-        for (int j = 0; j < 64 * S; j += 64) {
-            const size_t slot = base + j + lane;
-            // slots of film padding were never written by k_camera: whatever they hold is converted but never added
-            const v3 rgb = spectral_to_rgb_clamped(T, ld4(&st.L[slot]), ld4(&st.lambda_s[slot]), ld4(&st.pdf[slot]), fr.max_component_value);
-            const float fw = st.filter_w[slot];
-            mine[lane] = make_float4(fw * rgb.x, fw * rgb.y, fw * rgb.z, fw);
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            const int a = lo > j ? lo : j, e = hi < j + 64 ? hi : j + 64;
-            if (inside)
-                for (int t = a; t < e; ++t) {
-                    const float4 c = mine[t - j];
-                    r += (ACC)c.x;
-                    g += (ACC)c.y;
-                    b += (ACC)c.z;
-                    w += (ACC)c.w;
+        // pass sizes that tile the 64-slot steps (S a multiple of 64, or 4 / 8 / 16 / 32): whole pixels per step, one quad per pixel;
+        // any other S: one lane per pixel walks the steps.  Both add in sample order.
+        const int ch = lane & 3, quad = lane >> 2;
+        if (S >= 64 ? (S & 63) == 0 : (S >= 4 && (64 % S) == 0)) {
+            const int pix_per_step = S >= 64 ? 1 : 64 / S;        // pixels wholly inside one step (S < 64), or one pixel over S / 64 steps
+            const int steps_per_pix = S >= 64 ? S / 64 : 1;
+            for (int p0 = 0; p0 < 64; p0 += pix_per_step) {       // first pixel of the group handled together
+                ACC acc = 0;
+                bool inside = false;
+                size_t fp = 0;
+                if (quad < pix_per_step) {
+                    int px, py;
+                    slot_to_pixel(fr, tile * 64 + p0 + quad, px, py, inside);
+                    fp = inside ? (size_t)py * fr.width + px : 0;
+                    if (inside) acc = ch < 3 ? accum[3 * fp + ch] : accum[3 * N + fp];
                 }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        }
-        if (inside) {
-            accum[3 * p] = r;
-            accum[3 * p + 1] = g;
-            accum[3 * p + 2] = b;
-            accum[3 * N + p] = w;
+                for (int stp = 0; stp < steps_per_pix; ++stp) {
+                    const size_t slot = base + (size_t)p0 * S + (size_t)stp * 64 + lane;
+                    // slots of film padding were never written by k_camera: whatever they hold is converted but never added
+                    const v3 rgb = spectral_to_rgb_clamped(T, ld4(&st.L[slot]), ld4(&st.lambda_s[slot]), ld4(&st.pdf[slot]), fr.max_component_value);
+                    const float fw = st.filter_w[slot];
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                    mine[4 * lane + 0] = fw * rgb.x;
+                    mine[4 * lane + 1] = fw * rgb.y;
+                    mine[4 * lane + 2] = fw * rgb.z;
+                    mine[4 * lane + 3] = fw;
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                    if (quad < pix_per_step && inside) {
+                        const int first = S >= 64 ? 0 : quad * S, cnt = S >= 64 ? 64 : S;
+                        for (int t = 0; t < cnt; ++t) acc += (ACC)mine[4 * (first + t) + ch];
+                    }
+                }
+                if (quad < pix_per_step && inside) {
+                    if (ch < 3)
+                        accum[3 * fp + ch] = acc;
+                    else
+                        accum[3 * N + fp] = acc;
+                }
+            }
+        } else {
+            // general S: lane = pixel, every 64-slot step's entries of a pixel added by its lane (four channels in turn)
+            int px, py;
+            bool inside;
+            slot_to_pixel(fr, tile * 64 + lane, px, py, inside);
+            const size_t p = inside ? (size_t)py * fr.width + px : 0;
+            ACC r = 0, g = 0, b = 0, w = 0;
+            if (inside) r = accum[3 * p], g = accum[3 * p + 1], b = accum[3 * p + 2], w = accum[3 * N + p];
+            const int lo = lane * S, hi = lo + S;
+            for (int j = 0; j < 64 * S; j += 64) {
+                const size_t slot = base + j + lane;
+                const v3 rgb = spectral_to_rgb_clamped(T, ld4(&st.L[slot]), ld4(&st.lambda_s[slot]), ld4(&st.pdf[slot]), fr.max_component_value);
+                const float fw = st.filter_w[slot];
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                mine[4 * lane + 0] = fw * rgb.x;
+                mine[4 * lane + 1] = fw * rgb.y;
+                mine[4 * lane + 2] = fw * rgb.z;
+                mine[4 * lane + 3] = fw;
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                const int a = lo > j ? lo : j, e = hi < j + 64 ? hi : j + 64;
+                if (inside)
+                    for (int t = a; t < e; ++t) {
+                        r += (ACC)mine[4 * (t - j) + 0];
+                        g += (ACC)mine[4 * (t - j) + 1];
+                        b += (ACC)mine[4 * (t - j) + 2];
+                        w += (ACC)mine[4 * (t - j) + 3];
+                    }
+            }
+            if (inside) {
+                accum[3 * p] = r;
+                accum[3 * p + 1] = g;
+                accum[3 * p + 2] = b;
+                accum[3 * N + p] = w;
+            }
         }
     }
 }

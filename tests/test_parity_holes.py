@@ -653,3 +653,46 @@ def test_zsobol_sample_bit_table(hk, oracle, monkeypatch, first, n, stride, per_
     oacc, _ = osc.render(p, cam, w, h, n, first=first, stride=stride)
     rel_mse, frac = frame_metrics(fb, oracle.finalize(oacc, w, h))
     assert rel_mse <= 1e-5 and frac >= 0.995, (rel_mse, frac)
+
+
+@pytest.mark.parametrize("which", ["cornell", "sky", "slab"])
+def test_scheduling_is_result_neutral(hk, monkeypatch, which):
+    """How segments reach waves must not change a bit of the film: static stride vs tickets over the work lists, other segment counts
+    (a count that is no multiple of anything), the shadow kernels on the second stream or not.  Accumulators compared exactly."""
+    from hikari_jl_amd import scenes
+    w, h = 40, 36
+    if which == "cornell":
+        s, film, cam = scenes.cornell_box(w, h, light="area")
+        kw = dict(max_depth=6, samples=64)
+    elif which == "sky":
+        s, film, cam = scenes.sky_scene(w, h, env_res=32)
+        kw = dict(max_depth=6, samples=64)
+    else:
+        s, film, cam = scenes.slab_scene(w, h, hk.HomogeneousMedium(sigma_a=hk.RGBSpectrum(0.2), sigma_s=hk.RGBSpectrum(0.8, 0.7, 0.6), g=0.3))
+        kw = dict(max_depth=6, samples=64)
+
+    def run(env):
+        for k in ("HK_OVERLAP", "HK_DYNAMIC_SEGMENTS", "HK_WAVES_PER_CU"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        vp = hk.VolPath(**kw)
+        vp._ensure(film)
+        vp.clear()
+        vp.render_samples(s, film, cam, 20, first=1)
+        acc = vp.read_accumulators(film).copy()
+        vp.close()
+        return acc
+
+    ref = run({})
+    assert np.isfinite(ref).all() and ref.max() > 0
+    for env in ({"HK_OVERLAP": "0"}, {"HK_DYNAMIC_SEGMENTS": "0"}, {"HK_DYNAMIC_SEGMENTS": "1"}, {"HK_DYNAMIC_SEGMENTS": "1", "HK_WAVES_PER_CU": "7"},
+                {"HK_DYNAMIC_SEGMENTS": "0", "HK_WAVES_PER_CU": "5", "HK_OVERLAP": "1"}):
+        got = run(env)
+        assert np.array_equal(ref.view(np.uint32), got.view(np.uint32)), env
+    for k in ("HK_OVERLAP", "HK_DYNAMIC_SEGMENTS", "HK_WAVES_PER_CU"):
+        monkeypatch.delenv(k, raising=False)
+    # leave the context's sticky knobs at their defaults for the tests that follow
+    monkeypatch.setenv("HK_OVERLAP", "1")
+    monkeypatch.setenv("HK_WAVES_PER_CU", "0")
+    run({"HK_OVERLAP": "1", "HK_WAVES_PER_CU": "0"})

@@ -233,14 +233,15 @@ def main():
                 if k in u:
                     e[k] = u[k]
             hb, vi = e.get("hbm_frac_by_traffic"), e.get("valu_issue_frac")
+            # valu_issue_frac prices a wave64 VALU instruction at the data sheet's 2 cycles; measured on this chip (tools/valu_rate.hip,
+            # profiles/r02_valu_rate.txt) v_fma / v_mul / v_mov cost 2.3 - 2.9 and nearly everything else 4.2 - 4.4, so 0.25 - 0.45 in
+            # data-sheet units is a saturated issue port for these instruction mixes
             if hb is None or vi is None:
                 e["binding"] = "unprofiled on this workload"
             elif hb >= 0.5:
-                e["binding"] = "HBM traffic (%.0f %% of peak)" % (100 * hb)
-            elif vi >= 0.5:
-                e["binding"] = "VALU issue (%.0f %% of the issue cycles)" % (100 * vi)
+                e["binding"] = "HBM traffic (%.0f %% of the 8 TB/s peak, %.0f %% of the device-copy rate); VALU issue %.0f %% at 2 cycles per instruction" % (100 * hb, 100 * hb * HBM_PEAK_GBS / 5200.0, 100 * vi)
             else:
-                e["binding"] = "latency: HBM traffic at %.0f %% of peak, VALU issue >= %.0f %% of cycles at %.0f %% lane utilisation" % (100 * hb, 100 * vi, 100 * e.get("lane_util", 0))
+                e["binding"] = "instruction issue and latency: VALU issue %.0f %% of all cycles at 2 cycles per instruction (this mix costs ~4: profiles/r02_valu_rate.txt) with %.0f %% of the lanes active; HBM traffic %.0f %% of peak" % (100 * vi, 100 * e.get("lane_util", 0), 100 * hb)
             rooflines.append(e)
         # BVH nodes come from L1 / L2, not HBM: the SURVEY 8(d) byte formula is an upper bound of traversal's HBM need, not a ceiling
         for e in rooflines:

@@ -514,7 +514,7 @@ extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene**
     // ---- lights ----
     std::vector<DLight> dl(d->n_lights > 0 ? d->n_lights : 1);
     std::memset(dl.data(), 0, dl.size() * sizeof(DLight));
-    int has_escape = 0;
+    int has_escape = 0, textured_emitters = 0;
     for (int i = 0; i < d->n_lights; ++i) {
         const hk_light& l = d->lights[i];
         DLight& o = dl[i];
@@ -549,6 +549,7 @@ extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene**
                 o.cos_falloff_start = l.cos_falloff_start;
             }
             if (l.kind == HK_LIGHT_AMBIENT || l.kind == HK_LIGHT_ENVIRONMENT) has_escape = 1;
+            if (l.kind == HK_LIGHT_DIFFUSE_AREA && o.Le_tex >= 0) textured_emitters = 1;
             if (l.kind == HK_LIGHT_ENVIRONMENT) {  // scale::RGBSpectrum rides in Le_rgba, the map index in Le_tex
                 std::memcpy(o.Le_rgba, l.i_rgb, 16);
                 o.Le_tex = l.envmap;
@@ -841,6 +842,7 @@ extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene**
     D.envmaps = s->envmaps.as<DEnvMap>();
     D.n_envmaps = d->n_envmaps;
     D.has_escape_lights = has_escape;
+    D.simple_lights = (!has_escape && !textured_emitters) ? 1 : 0;
     D.all_opaque = all_opaque ? 1 : 0;
     D.bvh_depth = bvh.max_depth;
     *out = guard.release();

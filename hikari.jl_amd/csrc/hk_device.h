@@ -1543,17 +1543,19 @@ struct LightSample {
     bool is_delta;
 };
 HKD S4 light_spectrum(const DLight& l, S4 lambda) { return eval_illuminant(l.coef, lambda); }
-// TWO_PLANES: see rgb_to_spectrum (true in k_shade<Matte>)
-template <bool TWO_PLANES = false>
+// TWO_PLANES: see rgb_to_spectrum (true in k_shade<Matte>).  SIMPLE: the scene has no ambient / environment light and no textured
+// emitter (DScene::simple_lights): those branches are compiled out — k_shade<Matte> then spills 35 registers instead of 73 (Cornell -6 %)
+template <bool TWO_PLANES = false, bool SIMPLE = false>
 HKD S4 arealight_Le(const DScene& sc, const DTables& T, const DLight& l, v3 wo, v3 n, v2 uv, S4 lambda) {
     if (l.kind != HK_LIGHT_DIFFUSE_AREA) return s4(0.0f);
     if (!(l.flags & 1) && dot(wo, n) < 0.0f) return s4(0.0f);
     if (l.Le_tex < 0) return eval_bounded(l.coef, lambda);  // uplift_rgb(Le * scale), bounded (Q3)
+    if (SIMPLE) return s4(0.0f);   // no textured emitters in such a scene
     float o[4] = {0, 0, 0, 1};
     tex_bilinear(sc.textures[l.Le_tex], uv, o);
     return eval_bounded(coef_bounded<TWO_PLANES>(T, o[0] * l.scale, o[1] * l.scale, o[2] * l.scale), lambda);
 }
-template <bool TWO_PLANES = false>
+template <bool TWO_PLANES = false, bool SIMPLE = false>
 HKD LightSample sample_light(const DScene& sc, const DTables& T, const DLight& l, v3 p, S4 lambda, v2 u) {
     LightSample s;
     s.Li = s4(0.0f);
@@ -1601,6 +1603,7 @@ HKD LightSample sample_light(const DScene& sc, const DTables& T, const DLight& l
             return s;
         }
         case HK_LIGHT_AMBIENT: {
+            if (SIMPLE) return s;   // compiled out: the scene has none (DScene::simple_lights)
             float z = 1.0f - 2.0f * u.x;
             float r = sqrtf(maxf(0.0f, 1.0f - z * z));
             float phi = 2.0f * PI_F * u.y;
@@ -1614,6 +1617,7 @@ HKD LightSample sample_light(const DScene& sc, const DTables& T, const DLight& l
             return s;
         }
         case HK_LIGHT_ENVIRONMENT: {  // lights.jl:158-190
+            if (SIMPLE) return s;
             const DEnvMap& e = sc.envmaps[l.Le_tex];
             float map_pdf;
             v2 uv = dist2d_sample(e, u, map_pdf);
@@ -1648,7 +1652,7 @@ HKD LightSample sample_light(const DScene& sc, const DTables& T, const DLight& l
             if (ct < 1e-6f) return s;
             float pdf = d2 / (ct * l.area);
             v2 uvs = mk2(b0 * l.uv[0] + b1 * l.uv[2] + b2 * l.uv[4], b0 * l.uv[1] + b1 * l.uv[3] + b2 * l.uv[5]);
-            S4 Le = arealight_Le<TWO_PLANES>(sc, T, l, mk3(-wi.x, -wi.y, -wi.z), ln, uvs, lambda);
+            S4 Le = arealight_Le<TWO_PLANES, SIMPLE>(sc, T, l, mk3(-wi.x, -wi.y, -wi.z), ln, uvs, lambda);
             if (is_black(Le)) return s;
             s.Li = Le;
             s.wi = wi;

@@ -1188,7 +1188,7 @@ __global__ void __launch_bounds__(256) k_escaped(DPathState st, DScene sc, DTabl
 #define HK_SHADE_WAVES 3
 #endif
 // K8 for one flagged vertex (surface-eval.jl:147-220): L += beta * Le / MIS denominator.
-template <bool TWO_PLANES>
+template <bool TWO_PLANES, bool SIMPLE>
 HKD void shade_emission(DPathState& st, const DPathGen& g, bool ones, const DScene& sc, const DTables& T, uint32_t slot, unsigned& n_lnodes) {
     const float4 H = st.hit[slot];
     const float4 O = g.ray_o[slot], D = g.ray_d[slot];
@@ -1201,7 +1201,7 @@ HKD void shade_emission(DPathState& st, const DPathGen& g, bool ones, const DSce
     const v3 wo = -rd;
     const S4 lambda = ld4(&g.lambda[slot]);
     const DLight& light = sc.lights[meta.arealight - 1];
-    S4 Le = arealight_Le<TWO_PLANES>(sc, T, light, wo, sf.n, sf.uv, lambda);
+    S4 Le = arealight_Le<TWO_PLANES, SIMPLE>(sc, T, light, wo, sf.n, sf.uv, lambda);
     if (is_black(Le)) return;
     const S4 beta = ld_throughput(g.beta, slot, ones), r_u = ld_ru(g, slot, ones, st.compact != 0), r_l = ld_rl(g, slot, ones, st.compact != 0);
     const uint2 pmeta = g.meta[slot];
@@ -1233,7 +1233,8 @@ struct ShadeWaves {
 #ifndef HK_SHADE_MIN_WAVES
 #define HK_SHADE_MIN_WAVES 1
 #endif
-template <int KIND>
+// SIMPLE (instantiated for Matte): the scene has neither ambient / environment lights nor textured emitters (DScene::simple_lights)
+template <int KIND, bool SIMPLE = false>
 __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_per_eu(ShadeWaves<KIND>::value))) k_shade(DPathState st, DScene sc, DTables T, DFrame fr, DSobol sob, int depth, int first_kind, DStats* stats) {
     __shared__ uint32_t emit_list[4 * 128];   // per wave: slots of flagged (emissive-hit) vertices waiting for the dense K8 pass
     const int lane = lane_id();
@@ -1269,7 +1270,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             const int take = n_emit < 64 ? n_emit : 64;
-            if (lane < take) shade_emission<KIND == HK_MAT_MATTE>(st, g, ones, sc, T, elist[lane], n_lnodes);
+            if (lane < take) shade_emission<KIND == HK_MAT_MATTE, SIMPLE>(st, g, ones, sc, T, elist[lane], n_lnodes);
             const int rest = n_emit - take;
             const uint32_t moved = lane < rest ? elist[64 + lane] : 0u;
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -1386,7 +1387,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
                     // delta lights ignore the 2-D sample (lights.jl:39-131): draw it only for lights that use it
                     v2 u_light = mk2(0.0f, 0.0f);
                     if (sel.kind >= HK_LIGHT_AMBIENT) u_light = sobol_2d(sctx, base_dim + 3);
-                    LightSample ls = sample_light<KIND == HK_MAT_MATTE>(sc, T, sel, sf.pi, lambda, u_light);
+                    LightSample ls = sample_light<KIND == HK_MAT_MATTE, SIMPLE>(sc, T, sel, sf.pi, lambda, u_light);
                     if (ls.pdf > 0.0f && !is_black(ls.Li)) {
                         float bsdf_pdf;
                         S4 f = KIND == HK_MAT_MATTE ? eval_matte_kd(kd_matte, wo, ls.wi, sf.ns, bsdf_pdf)
@@ -2454,6 +2455,11 @@ void launch_shade(hipStream_t s, int n_cu, int kind, const DPathState& st, const
         const int blocks = cached_blocks<k_shade<K>>(256, n_cu, 8);                                                            \
         hipLaunchKernelGGL(k_shade<K>, dim3(clamp_blocks(blocks, st)), dim3(256), 0, s, st, sc, T, fr, sob, depth, first_kind, stats); \
     } break;
+    if (kind == HK_MAT_MATTE && sc.simple_lights) {
+        const int blocks = cached_blocks<k_shade<HK_MAT_MATTE, true>>(256, n_cu, 8);
+        hipLaunchKernelGGL((k_shade<HK_MAT_MATTE, true>), dim3(clamp_blocks(blocks, st)), dim3(256), 0, s, st, sc, T, fr, sob, depth, first_kind, stats);
+        return;
+    }
     switch (kind) {
         HK_SHADE_CASE(HK_MAT_MATTE)
         HK_SHADE_CASE(HK_MAT_MIRROR)

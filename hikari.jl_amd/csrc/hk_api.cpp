@@ -842,7 +842,7 @@ extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene**
     D.envmaps = s->envmaps.as<DEnvMap>();
     D.n_envmaps = d->n_envmaps;
     D.has_escape_lights = has_escape;
-    D.simple_lights = (!has_escape && !textured_emitters) ? 1 : 0;
+    D.simple_lights = (!has_escape && !textured_emitters && d->n_textures == 0) ? 1 : 0;
     D.all_opaque = all_opaque ? 1 : 0;
     D.bvh_depth = bvh.max_depth;
     *out = guard.release();

@@ -720,8 +720,10 @@ HKD void tex_bilinear(const DTexture& t, const TexCtx& tc, float out[4]) {
     }
     tex_bilinear(t, tc.uv, out);
 }
+// NO_TEX: the scene holds no texture at all (DScene::simple_lights): the lookup is compiled out
+template <bool NO_TEX = false>
 HKD float eval_f32(const DScene& sc, const DMaterial& m, int slot, const TexCtx& uv) {
-    if (m.ftex[slot] < 0) return m.f[slot];
+    if (NO_TEX || m.ftex[slot] < 0) return m.f[slot];
     float o[4] = {0, 0, 0, 0};
     tex_bilinear(sc.textures[m.ftex[slot]], uv, o);
     return o[0];
@@ -1004,9 +1006,9 @@ HKD Surface surface_at(const DScene& sc, int prim, float bu, float bv, v3 ro, v3
 // materials: parameter fetch
 // ------------------------------------------------------------------------------------------------
 enum { UPLIFT_BOUNDED = 0, UPLIFT_UNBOUNDED = 1 };
-template <bool TWO_PLANES = false>
+template <bool TWO_PLANES = false, bool NO_TEX = false>
 HKD float4 rgb_param_coef(const DScene& sc, const DTables& T, const DSpectrumParam& p, const TexCtx& uv, int mode, bool clamp_lo) {
-    if (p.tex < 0) return p.coef;
+    if (NO_TEX || p.tex < 0) return p.coef;
     float o[4] = {0, 0, 0, 1};
     tex_bilinear(sc.textures[p.tex], uv, o);
     if (clamp_lo) {  // clamp(kd_rgb): [0, Inf)
@@ -1225,8 +1227,9 @@ namespace hkd {
 // MatteMaterial with its reflectance spectrum already evaluated: k_shade evaluates kd = uplift(clamp(Kd))(lambda) ONCE per vertex and
 // hands it to both the next-event evaluation and the BSDF sample (the two would each run the four sigmoid evaluations — a
 // square root and a division per wavelength — on the same inputs).  Same operations, same order as the generic entry points.
+template <bool NO_TEX = false>
 HKD S4 matte_kd(const DScene& sc, const DTables& T, const DMaterial& m, const TexCtx& uv, S4 lambda) {
-    return eval_bounded(rgb_param_coef<true>(sc, T, m.rgb[0], uv, UPLIFT_BOUNDED, true), lambda);
+    return eval_bounded(rgb_param_coef<true, NO_TEX>(sc, T, m.rgb[0], uv, UPLIFT_BOUNDED, true), lambda);
 }
 HKD S4 eval_matte_kd(S4 kd, v3 wo_w, v3 wi_w, v3 n, float& pdf) {  // spectral-eval.jl:371-398
     pdf = 0.0f;
@@ -1238,10 +1241,11 @@ HKD S4 eval_matte_kd(S4 kd, v3 wo_w, v3 wi_w, v3 n, float& pdf) {  // spectral-e
     return kd / PI_F;
 }
 HKD BSDFSample sample_lambert(v3 wo, v3 n, v2 u, S4 f);
+template <bool NO_TEX = false>
 HKD BSDFSample sample_matte_kd(const DScene& sc, const DMaterial& m, S4 kd, v3 wo_w, v3 n, const TexCtx& uv, v2 u) {  // :42-101
     float wdn = dot(wo_w, n);
     if (fabsf(wdn) < 1e-6f) return invalid_sample();
-    float sigma = eval_f32(sc, m, 0, uv);
+    float sigma = eval_f32<NO_TEX>(sc, m, 0, uv);
     S4 f;
     if (sigma > 0.0f) {
         float rf = 1.0f - 0.5f * sigma / (sigma + 0.33f);
@@ -1543,8 +1547,8 @@ struct LightSample {
     bool is_delta;
 };
 HKD S4 light_spectrum(const DLight& l, S4 lambda) { return eval_illuminant(l.coef, lambda); }
-// TWO_PLANES: see rgb_to_spectrum (true in k_shade<Matte>).  SIMPLE: the scene has no ambient / environment light and no textured
-// emitter (DScene::simple_lights): those branches are compiled out — k_shade<Matte> then spills 35 registers instead of 73 (Cornell -6 %)
+// TWO_PLANES: see rgb_to_spectrum (true in k_shade<Matte>).  SIMPLE: the scene has no ambient / environment light and no texture
+// (DScene::simple_lights): those branches are compiled out — k_shade<Matte> then spills 29 registers instead of 73 (Cornell -10 %)
 template <bool TWO_PLANES = false, bool SIMPLE = false>
 HKD S4 arealight_Le(const DScene& sc, const DTables& T, const DLight& l, v3 wo, v3 n, v2 uv, S4 lambda) {
     if (l.kind != HK_LIGHT_DIFFUSE_AREA) return s4(0.0f);

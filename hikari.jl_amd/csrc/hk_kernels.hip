@@ -1233,7 +1233,7 @@ struct ShadeWaves {
 #ifndef HK_SHADE_MIN_WAVES
 #define HK_SHADE_MIN_WAVES 1
 #endif
-// SIMPLE (instantiated for Matte): the scene has neither ambient / environment lights nor textured emitters (DScene::simple_lights)
+// SIMPLE (instantiated for Matte): the scene has no ambient / environment light and no texture of any kind (DScene::simple_lights)
 template <int KIND, bool SIMPLE = false>
 __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_per_eu(ShadeWaves<KIND>::value))) k_shade(DPathState st, DScene sc, DTables T, DFrame fr, DSobol sob, int depth, int first_kind, DStats* stats) {
     __shared__ uint32_t emit_list[4 * 128];   // per wave: slots of flagged (emissive-hit) vertices waiting for the dense K8 pass
@@ -1323,7 +1323,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
             split_slot(fr, pslot, pix, k);
             sctx = sobol_ctx_slot(sob, T.sobol, fr.x0, fr.y0, fr.tiles_x, pix, k, fr.first_sample + k * fr.sample_stride);
 
-            if (KIND == HK_MAT_MATTE) kd_matte = matte_kd(sc, T, sc.materials[st.mat_id[slot] & ~HK_MAT_EMISSIVE_BIT], TexCtx(sf.uv, meta.prim_index, H.z, H.w), lambda);
+            if (KIND == HK_MAT_MATTE) kd_matte = matte_kd<SIMPLE>(sc, T, sc.materials[st.mat_id[slot] & ~HK_MAT_EMISSIVE_BIT], TexCtx(sf.uv, meta.prim_index, H.z, H.w), lambda);
 #ifdef HK_ABLATE
             // cost attribution by duplication (tools/ablate.md): stage HK_ABLATE runs a second time on laundered inputs, its result is
             // kept alive but unused; the k_shade time delta against the plain build is that stage's cost.  Never defined in the product.
@@ -1437,7 +1437,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
                 float uc = (KIND == HK_MAT_GLASS || KIND > HK_MAT_CONDUCTOR) && KIND != HK_MAT_FALLBACK ? sobol_1d(sctx, base_dim + 4) : 0.0f;
                 v2 u = (KIND == HK_MAT_MIRROR || KIND == HK_MAT_GLASS || KIND == HK_MAT_THIN_DIELECTRIC) ? mk2(0.0f, 0.0f) : sobol_2d(sctx, base_dim + 6);
                 bool regularize = fr.regularize && any_non_specular;
-                BSDFSample s = KIND == HK_MAT_MATTE ? sample_matte_kd(sc, mat, kd_matte, wo, sf.ns, TexCtx(sf.uv, meta.prim_index, H.z, H.w), u)
+                BSDFSample s = KIND == HK_MAT_MATTE ? sample_matte_kd<SIMPLE>(sc, mat, kd_matte, wo, sf.ns, TexCtx(sf.uv, meta.prim_index, H.z, H.w), u)
                                                     : sample_bsdf<KIND>(sc, T, mat, wo, sf.ns, TexCtx(sf.uv, meta.prim_index, H.z, H.w), lambda, u, uc, regularize);
                 if (s.pdf > 0.0f && !is_black(s.f)) {
                     float ct = fabsf(dot(s.wi, sf.ns));

@@ -168,7 +168,7 @@ struct DScene {
     const DEnvMap* envmaps;
     int n_envmaps;
     int has_escape_lights;      // any ambient / environment light
-    int simple_lights;          // no ambient / environment light and no textured emitter: k_shade<Matte, true> leaves those branches out
+    int simple_lights;          // no ambient / environment light and no texture of any kind: k_shade<Matte, true> leaves those branches out
     int all_opaque;             // no medium transitions and no alpha-tested surfaces
     int bvh_depth;              // deepest BVH level (bounds the traversal stack)
 };

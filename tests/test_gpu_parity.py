@@ -80,8 +80,12 @@ def test_camera_stage(hk, oracle, gpu_ctx):
     rec = cam.record()
     hk._lib.check(L.hk_test_camera(gpu_ctx.h, integ, C.byref(rec), 800, 800, n, _pi(px), _pi(py), _pi(si), out.ctypes.data_as(hk._abi.PF)), "hk_test_camera")
     L.hk_integrator_destroy(integ)
-    assert np.allclose(out[:, :4], ref[:, :4], rtol=0, atol=2e-3)            # lambda [nm]
-    assert np.allclose(out[:, 4:8], ref[:, 4:8], rtol=2e-5, atol=1e-9)       # pdf
+    # the sampler's atanh / cosh go through the hardware's log2 / exp2 / rcp (hk_device.h: atanh_sampler, cosh_sampler); against a
+    # float64 evaluation of the same formulas they must stay within 2.5e-4 nm (four float spacings at 540 nm) and 4e-6 relative
+    print("camera stage: max |d lambda| = %.3g nm, max rel d pdf = %.3g (GPU vs oracle/glibc)" % (
+        np.abs(out[:, :4] - ref[:, :4]).max(), (np.abs(out[:, 4:8] - ref[:, 4:8]) / np.maximum(ref[:, 4:8], 1e-12)).max()))
+    assert np.allclose(out[:, :4], ref[:, :4], rtol=0, atol=2.5e-4)          # lambda [nm]
+    assert np.allclose(out[:, 4:8], ref[:, 4:8], rtol=4e-6, atol=1e-9)       # pdf (follows the 2-spacing difference in lambda)
     assert ulp_diff(out[:, 8], ref[:, 8]).max() <= 2                          # filter weight
     assert np.array_equal(out[:, 9:12], ref[:, 9:12])                         # ray origin (no lens): exact
     assert ulp_diff(out[:, 12:15], ref[:, 12:15]).max() <= 2                  # ray direction

@@ -1849,13 +1849,23 @@ HKD float lcg_next(uint64_t& s) {
     return r < lim ? r : lim;
 }
 HKD S4 s4max0(S4 a) { return s4(maxf(a.x, 0.0f), maxf(a.y, 0.0f), maxf(a.z, 0.0f), maxf(a.w, 0.0f)); }
+// exp / log of the tracking loops through the hardware's exp2 / log2 (1 ulp each; the argument scaling adds ~|x| * 6e-8 relative):
+// the free-flight and transmittance arithmetic of a path is statistical anyway (its RNG is seeded from float bit patterns,
+// DESIGN.md §2), and ocml's expf / logf cost ~25 instructions per call in loops that run at a third of the lanes
+#ifndef HK_MEDIA_LIBM
+HKD float media_expf(float x) { return __builtin_amdgcn_exp2f(1.4426950408889634f * x); }
+HKD float media_logf(float x) { return 0.6931471805599453f * __builtin_amdgcn_logf(x); }
+#else
+HKD float media_expf(float x) { return expf(x); }
+HKD float media_logf(float x) { return logf(x); }
+#endif
 HKD S4 s4exp(S4 a) {
-    // grey media (all four wavelengths see the same sigma): one expf, bit-identical to four
+    // grey media (all four wavelengths see the same sigma): one exp, bit-identical to four
     if (a.x == a.y && a.x == a.z && a.x == a.w) {
-        float e = expf(a.x);
+        float e = media_expf(a.x);
         return s4(e, e, e, e);
     }
-    return s4(expf(a.x), expf(a.y), expf(a.z), expf(a.w));
+    return s4(media_expf(a.x), media_expf(a.y), media_expf(a.z), media_expf(a.w));
 }
 // a / y through one correctly-rounded reciprocal: each component within 1 ulp of the IEEE quotient, at a third of the
 // instructions (a full-precision f32 division is ~10 VALU ops on CDNA).  Used in the tracking loops only, whose paths cannot

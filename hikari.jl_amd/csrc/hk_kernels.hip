@@ -891,7 +891,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
                     } else {
                         ++k_in_seg;
                         float u = lcg_next(rng);
-                        pend_dt = -logf(maxf(1e-10f, 1.0f - u)) / sm0;
+                        pend_dt = -media_logf(maxf(1e-10f, 1.0f - u)) / sm0;
                         float ts = t + pend_dt;
                         if (ts >= seg1) {
                             float dr = seg1 - t;
@@ -1766,7 +1766,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
                         } else {
                             ++k_in_seg;
                             float u = pcg32_f32(rng);
-                            pend_dt = -logf(maxf(1e-10f, 1.0f - u)) / sm0;
+                            pend_dt = -media_logf(maxf(1e-10f, 1.0f - u)) / sm0;
                             float ts = t + pend_dt;
                             if (ts >= seg1) {
                                 float dr = seg1 - t;

@@ -696,3 +696,33 @@ def test_scheduling_is_result_neutral(hk, monkeypatch, which):
     monkeypatch.setenv("HK_OVERLAP", "1")
     monkeypatch.setenv("HK_WAVES_PER_CU", "0")
     run({"HK_OVERLAP": "1", "HK_WAVES_PER_CU": "0"})
+
+
+def test_medium_furnace_gain_q30(hk):
+    """The HIP path against the closed form of tests/test_independent_pins.py::test_medium_white_furnace_and_single_scatter: a
+    non-absorbing isotropic slab of optical thickness 1.5 inside a constant environment returns 1.387 times the environment (the
+    reference's double-counted direct light behind a specular medium boundary, quirk Q30) — the value of an independent float64
+    random walk, not of the oracle."""
+    from hikari_jl_amd import scenes
+    from hikari_jl_amd import geometry as G
+    R = hk.RGBSpectrum
+    w = h = 32
+
+    def frame(medium):
+        _, film, cam = scenes.slab_scene(w, h, medium)
+        s = hk.Scene()
+        if medium is not None:
+            s.push(G.rect3f((-2.5, -2.6, 1.0), (5.0, 5.2, 1.0)), hk.MediumInterface(hk.GlassMaterial(Kr=R(0.0), Kt=R(1.0), index=1.0), inside=medium, outside=None))
+        s.push(hk.EnvironmentLight(hk.EnvironmentMap(np.full((16, 16, 3), 6e-5, np.float32)), R(1.0, 0.9, 0.8)))
+        s.sync()
+        vp = hk.VolPath(max_depth=64, samples=256)
+        vp._ensure(film)
+        vp.clear()
+        vp.render_samples(s, film, cam, 256, first=1)
+        img = film.framebuffer.copy()
+        vp.close()
+        return img[h // 4: 3 * h // 4, w // 4: 3 * w // 4].mean(axis=(0, 1))
+
+    ref = frame(None)
+    gain = frame(hk.HomogeneousMedium(sigma_a=R(0.0), sigma_s=R(1.5), g=0.0)) / ref
+    assert np.allclose(gain, 1.387, rtol=0.012), gain

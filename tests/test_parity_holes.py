@@ -726,3 +726,26 @@ def test_medium_furnace_gain_q30(hk):
     ref = frame(None)
     gain = frame(hk.HomogeneousMedium(sigma_a=R(0.0), sigma_s=R(1.5), g=0.0)) / ref
     assert np.allclose(gain, 1.387, rtol=0.012), gain
+
+
+def test_surface_furnace_q31(hk):
+    """The HIP path on the closed emissive box of tests/test_independent_pins.py::test_surface_furnace_radiosity_closed_form: an
+    independent float64 random walk of the reference's estimator gives 1.3896 Le for rho = 0.3 (2.7 % below Le / (1 - rho): the
+    emission MIS evaluates the light-choice pmf at the hit point, quirk Q31) — the frame must land there, not on the oracle's word."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_independent_pins import _emissive_box
+
+    def mean(rho, spp):
+        s, film, cam = _emissive_box(hk, rho)
+        vp = hk.VolPath(max_depth=40, samples=4096, max_component_value=1e9)
+        vp._ensure(film)
+        vp.clear()
+        vp.render_samples(s, film, cam, spp, first=1)
+        img = film.framebuffer.copy()
+        vp.close()
+        return img.mean(axis=(0, 1))
+
+    base = mean(0.0, 256)
+    got = (mean(0.3, 512) / base).mean()
+    assert abs(got - 1.3896) < 0.006, got

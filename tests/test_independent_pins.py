@@ -937,3 +937,94 @@ def test_direct_light_against_lambert_form_factor(hk, oracle):
     want = rho * Le[None, :] * F[:, None]
     ratio = got[sel] / want[sel]
     assert abs(ratio.mean() - 1.0) < 0.01 and np.median(np.abs(ratio - 1.0)) < 0.04, (ratio.mean(), np.median(np.abs(ratio - 1.0)))
+
+
+# ---------------------------------------------------------------------------------------------------- specular chains, heterogeneous tracking
+def _emitter_view(hk, oracle, extra, spp=64, max_depth=24, wh=16, fov=6.0):
+    """narrow view along +z from the origin at a big emitter at z = 6, with `extra(scene)` objects in between -> mean RGB"""
+    from hikari_jl_amd import geometry as G
+    R = hk.RGBSpectrum
+    s = hk.Scene()
+    em = G.quad((-6, -6, 6), (-6, 6, 6), (6, 6, 6), (6, -6, 6), normal=(0, 0, -1))
+    s.push(em, hk.MediumInterface(hk.MatteMaterial(Kd=R(0.0)), emission=hk.Emissive(Le=R(0.2), scale=1.0, two_sided=True)))
+    extra(s)
+    s.sync()
+    cam = hk.PerspectiveCamera((0, 0, 0), (0, 0, 1), hk.Film((wh, wh)), fov=fov)
+    p = hk.integrator_params(max_depth=max_depth, samples=4096, max_component_value=1e9)
+    osc = oracle.OracleScene(s)
+    acc, _ = osc.render(p, cam, wh, wh, spp)
+    img = oracle.finalize(acc, wh, wh)
+    return img.mean(axis=(0, 1)).astype(np.float64), osc, s
+
+
+def test_specular_chains_closed_forms(hk, oracle):
+    """Specular bounces carry no MIS and no cosine (Q27): an emitter seen in a mirror is Kr Le, seen in two mirrors Kr^2 Le; seen through
+    a plane-parallel glass slab at normal incidence it is Le (1 - R) / (1 + R) with R = ((n - 1) / (n + 1))^2 — the incoherent sum over all
+    internal reflections, which the stochastic reflect / transmit choice of GlassMaterial must reproduce in expectation."""
+    from hikari_jl_amd import geometry as G
+    R = hk.RGBSpectrum
+    base, osc, _ = _emitter_view(hk, oracle, lambda s: None, spp=16)
+    osc.close()
+    assert base.min() > 0.01
+
+    # one and two mirrors: camera looks along +z at a 45-degree mirror that turns the view to +x ... use a periscope back to +z
+    def one_mirror(s):
+        # mirror in the plane z = 3 facing the camera: the camera sees the emitter BEHIND it (z = -6) reflected
+        s.push(G.quad((-2, -2, 3), (2, -2, 3), (2, 2, 3), (-2, 2, 3), normal=(0, 0, -1)), hk.MirrorMaterial(Kr=R(0.8)))
+        em2 = G.quad((-9, -9, -6), (9, -9, -6), (9, 9, -6), (-9, 9, -6), normal=(0, 0, 1))
+        s.push(em2, hk.MediumInterface(hk.MatteMaterial(Kd=R(0.0)), emission=hk.Emissive(Le=R(0.2), scale=1.0, two_sided=True)))
+
+    got, osc, _ = _emitter_view(hk, oracle, one_mirror, spp=16)
+    osc.close()
+    assert np.allclose(got / base, 0.8, rtol=2e-3), got / base
+
+    n = 1.5
+    Rf = ((n - 1) / (n + 1)) ** 2
+
+    def slab(s):
+        s.push(G.rect3f((-3, -3, 2.0), (6, 6, 0.5)), hk.GlassMaterial(Kr=R(1.0), Kt=R(1.0), index=n))
+
+    got, osc, _ = _emitter_view(hk, oracle, slab, spp=1024, max_depth=40)
+    osc.close()
+    assert np.allclose(got / base, (1 - Rf) / (1 + Rf), rtol=0.012), (got / base, (1 - Rf) / (1 + Rf))
+
+
+def test_heterogeneous_absorption_against_quadrature(hk, oracle):
+    """Delta tracking through a heterogeneous GridMedium and a NanoVDB tree (majorant-grid DDA, null collisions, media.jl:625-729,
+    delta-tracking.jl:79-453) against deterministic quadrature: a purely absorbing medium attenuates the emitter behind it by
+    exp(-integral sigma_a dt) along each view ray.  The density along the ray is read through the point sampler (whose values are
+    pinned bit for bit elsewhere); the tracking loop, the majorant segments and the collision probabilities are what is tested."""
+    from hikari_jl_amd import geometry as G
+    R = hk.RGBSpectrum
+    rng = np.random.default_rng(21)
+    dens = (0.2 + 1.6 * rng.random((12, 10, 14))).astype(np.float32)
+    dens[3:7, 2:6, 4:9] = 0.0                                          # an empty pocket: zero-majorant cells on the way
+    bounds = ((-1.0, -1.0, 2.0), (1.0, 1.0, 4.0))
+    base, osc, _ = _emitter_view(hk, oracle, lambda s: None, spp=16)
+    osc.close()
+    for make in (lambda: hk.GridMedium(dens, sigma_a=R(1.0), sigma_s=R(0.0), bounds=bounds),
+                 lambda: hk.NanoVDBMedium(dens, bounds=bounds, sigma_a=R(1.0), sigma_s=R(0.0), majorant_res=(5, 4, 6))):
+        med = make()
+
+        def box(s, med=med):
+            s.push(G.rect3f(bounds[0], tuple(np.subtract(bounds[1], bounds[0]))), hk.MediumInterface(hk.GlassMaterial(Kr=R(0.0), Kt=R(1.0), index=1.0), inside=med, outside=None))
+
+        got, osc, s = _emitter_view(hk, oracle, box, spp=512, fov=14.0)
+        # quadrature of sigma_a along 1500 of the camera's own rays (filter-weighted like the film)
+        pq = hk.integrator_params(max_depth=24, samples=4096, max_component_value=1e9)
+        camq = hk.PerspectiveCamera((0, 0, 0), (0, 0, 1), hk.Film((16, 16)), fov=14.0)
+        r2 = np.random.default_rng(5)
+        cs = oracle.camera_samples(pq, camq, 16, 16, r2.integers(1, 17, 1500).astype(np.int32), r2.integers(1, 17, 1500).astype(np.int32),
+                                   r2.integers(1, 500, 1500).astype(np.int32)).astype(np.float64)
+        fw, dirs = cs[:, 8], cs[:, 12:15]
+        ts = np.linspace(0.0, 7.0, 1401)
+        T = []
+        for dd in dirs:
+            P = (dd[None, :] * ts[:, None]).astype(np.float32)
+            inside = np.all((P > np.array(bounds[0])) & (P < np.array(bounds[1])), axis=1)
+            sig = osc.medium(0, 0, P, np.full((len(P), 4), 550.0, np.float32))[:, 0].astype(np.float64) * inside
+            T.append(np.exp(-float(((sig[1:] + sig[:-1]) * 0.5 * np.diff(ts)).sum())))
+        osc.close()
+        want = float((fw * np.array(T)).sum() / fw.sum())
+        assert 0.05 < want < 0.6
+        assert np.allclose(got / base, want, rtol=0.03), (type(med).__name__, got / base, want)

@@ -651,9 +651,39 @@ def test_medium_white_furnace_and_single_scatter(hk, oracle):
             mu = np.where(alive, 2.0 * rng.random(n) - 1.0, mu)
         return 1.0 + X.mean()
 
+    def walk_gain_hg(tau, g, n=400000, seed=2):
+        """the same for a Henyey-Greenstein phase function: the next-event sample is uniform over the sphere (p_l = 1 / 4 pi) and carries the
+        weight p_p / (p_l + p_p) with p_p the phase function towards it, times the transmittance to the slab's boundary in that direction"""
+        rng = np.random.default_rng(seed)
+        z, alive, X = np.zeros(n), np.ones(n, bool), np.zeros(n)
+        d = np.tile(np.array([0.0, 0.0, 1.0]), (n, 1))
+        hg = lambda mu: (1.0 - g * g) / (4.0 * np.pi * (1.0 + g * g - 2.0 * g * mu) ** 1.5)     # mu = cos between propagation directions
+        while alive.any():
+            z = np.where(alive, z - d[:, 2] * np.log(1.0 - rng.random(n)), z)
+            alive &= (z > 0) & (z < tau)
+            wz = 2.0 * rng.random(n) - 1.0
+            ph = 2.0 * np.pi * rng.random(n)
+            w = np.stack([np.sqrt(1 - wz * wz) * np.cos(ph), np.sqrt(1 - wz * wz) * np.sin(ph), wz], 1)
+            pp = hg((d * w).sum(1))
+            dist = np.where(wz > 0, (tau - z) / np.maximum(wz, 1e-12), z / np.maximum(-wz, 1e-12))
+            X += np.where(alive, pp / (1.0 / (4.0 * np.pi) + pp) * np.exp(-dist), 0.0)
+            # next direction ~ HG about d
+            xi = rng.random(n)
+            mu = (1.0 + g * g - ((1.0 - g * g) / (1.0 - g + 2.0 * g * xi)) ** 2) / (2.0 * g)
+            ph = 2.0 * np.pi * rng.random(n)
+            a = np.where(np.abs(d[:, [2]]) < 0.9, np.array([[0.0, 0.0, 1.0]]), np.array([[1.0, 0.0, 0.0]]))
+            t1 = np.cross(d, a)
+            t1 /= np.linalg.norm(t1, axis=1)[:, None]
+            t2 = np.cross(d, t1)
+            st = np.sqrt(np.maximum(0.0, 1.0 - mu * mu))
+            nd = st[:, None] * (np.cos(ph)[:, None] * t1 + np.sin(ph)[:, None] * t2) + mu[:, None] * d
+            d = np.where(alive[:, None], nd, d)
+        return 1.0 + X.mean()
+
     tau = 1.5
     expected = walk_gain(tau)
     assert abs(expected - 1.387) < 0.003
+    assert abs(walk_gain_hg(tau, 1e-4) - expected) < 0.004                       # the HG walk reduces to the isotropic one
     iso = hk.HomogeneousMedium(sigma_a=R(0.0), sigma_s=R(tau), g=0.0)              # slab thickness 1
     for ambient in (False, True):
         s0, cam = furnace(None, ambient)
@@ -665,9 +695,12 @@ def test_medium_white_furnace_and_single_scatter(hk, oracle):
     # forward-peaked phase function, heterogeneous density: no closed form here, but never below the furnace and never above twice it
     s0, cam = furnace(None)
     ref = mean(s0, cam, 8)
-    for med in (hk.HomogeneousMedium(sigma_a=R(0.0), sigma_s=R(4.0), g=0.7),
-                hk.GridMedium((0.2 + 0.8 * np.random.default_rng(3).random((6, 6, 6))).astype(np.float32), sigma_a=R(0.0), sigma_s=R(3.0), g=0.3,
-                              bounds=((-2.5, -2.6, 1.0), (2.5, 2.6, 2.0)))):
+    hg_med = hk.HomogeneousMedium(sigma_a=R(0.0), sigma_s=R(4.0), g=0.7)
+    s1, cam1 = furnace(hg_med)
+    gain = mean(s1, cam1, 256) / ref
+    assert np.allclose(gain, walk_gain_hg(4.0, 0.7), rtol=0.015), (gain, walk_gain_hg(4.0, 0.7))
+    for med in (hk.GridMedium((0.2 + 0.8 * np.random.default_rng(3).random((6, 6, 6))).astype(np.float32), sigma_a=R(0.0), sigma_s=R(3.0), g=0.3,
+                              bounds=((-2.5, -2.6, 1.0), (2.5, 2.6, 2.0))),):
         s1, cam1 = furnace(med)
         gain = mean(s1, cam1, 64) / ref
         assert np.all(gain > 1.0) and np.all(gain < 2.0), gain

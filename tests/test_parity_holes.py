@@ -749,3 +749,65 @@ def test_surface_furnace_q31(hk):
     base = mean(0.0, 256)
     got = (mean(0.3, 512) / base).mean()
     assert abs(got - 1.3896) < 0.006, got
+
+
+def test_specular_and_absorption_closed_forms_on_device(hk, oracle):
+    """The HIP path against the closed forms of tests/test_independent_pins.py directly (not through the oracle's frames): an emitter in
+    a mirror is Kr Le, through a glass slab (1 - R) / (1 + R) Le, behind a heterogeneous absorbing NanoVDB box exp(-integral sigma_a)."""
+    from hikari_jl_amd import geometry as G
+    R = hk.RGBSpectrum
+    wh = 16
+
+    def view(extra, spp, fov=6.0, max_depth=40):
+        s = hk.Scene()
+        em = G.quad((-6, -6, 6), (-6, 6, 6), (6, 6, 6), (6, -6, 6), normal=(0, 0, -1))
+        s.push(em, hk.MediumInterface(hk.MatteMaterial(Kd=R(0.0)), emission=hk.Emissive(Le=R(0.2), scale=1.0, two_sided=True)))
+        extra(s)
+        s.sync()
+        film = hk.Film((wh, wh))
+        cam = hk.PerspectiveCamera((0, 0, 0), (0, 0, 1), film, fov=fov)
+        vp = hk.VolPath(max_depth=max_depth, samples=4096, max_component_value=1e9)
+        vp._ensure(film)
+        vp.clear()
+        vp.render_samples(s, film, cam, spp, first=1)
+        m = film.framebuffer.mean(axis=(0, 1)).astype(np.float64)
+        vp.close()
+        return m, s
+
+    base, _ = view(lambda s: None, 64)
+
+    def mirror(s):
+        s.push(G.quad((-2, -2, 3), (2, -2, 3), (2, 2, 3), (-2, 2, 3), normal=(0, 0, -1)), hk.MirrorMaterial(Kr=R(0.8)))
+        em2 = G.quad((-9, -9, -6), (9, -9, -6), (9, 9, -6), (-9, 9, -6), normal=(0, 0, 1))
+        s.push(em2, hk.MediumInterface(hk.MatteMaterial(Kd=R(0.0)), emission=hk.Emissive(Le=R(0.2), scale=1.0, two_sided=True)))
+
+    got, _ = view(mirror, 64)
+    assert np.allclose(got / base, 0.8, rtol=2e-3), got / base
+    n = 1.5
+    Rf = ((n - 1) / (n + 1)) ** 2
+    got, _ = view(lambda s: s.push(G.rect3f((-3, -3, 2.0), (6, 6, 0.5)), hk.GlassMaterial(Kr=R(1.0), Kt=R(1.0), index=n)), 2048)
+    assert np.allclose(got / base, (1 - Rf) / (1 + Rf), rtol=0.008), (got / base, (1 - Rf) / (1 + Rf))
+
+    rng = np.random.default_rng(21)
+    dens = (0.2 + 1.6 * rng.random((12, 10, 14))).astype(np.float32)
+    dens[3:7, 2:6, 4:9] = 0.0
+    bounds = ((-1.0, -1.0, 2.0), (1.0, 1.0, 4.0))
+    med = hk.NanoVDBMedium(dens, bounds=bounds, sigma_a=R(1.0), sigma_s=R(0.0), majorant_res=(5, 4, 6))
+    got, s = view(lambda s: s.push(G.rect3f(bounds[0], (2.0, 2.0, 2.0)), hk.MediumInterface(hk.GlassMaterial(Kr=R(0.0), Kt=R(1.0), index=1.0), inside=med, outside=None)), 2048, fov=14.0)
+    osc = oracle.OracleScene(s)
+    pq = hk.integrator_params(max_depth=24, samples=4096, max_component_value=1e9)
+    camq = hk.PerspectiveCamera((0, 0, 0), (0, 0, 1), hk.Film((wh, wh)), fov=14.0)
+    r2 = np.random.default_rng(5)
+    cs = oracle.camera_samples(pq, camq, wh, wh, r2.integers(1, wh + 1, 1500).astype(np.int32), r2.integers(1, wh + 1, 1500).astype(np.int32),
+                               r2.integers(1, 500, 1500).astype(np.int32)).astype(np.float64)
+    fw, dirs = cs[:, 8], cs[:, 12:15]
+    ts = np.linspace(0.0, 7.0, 1401)
+    T = []
+    for dd in dirs:
+        P = (dd[None, :] * ts[:, None]).astype(np.float32)
+        inside = np.all((P > np.array(bounds[0])) & (P < np.array(bounds[1])), axis=1)
+        sig = osc.medium(0, 0, P, np.full((len(P), 4), 550.0, np.float32))[:, 0].astype(np.float64) * inside
+        T.append(np.exp(-float(((sig[1:] + sig[:-1]) * 0.5 * np.diff(ts)).sum())))
+    osc.close()
+    want = float((fw * np.array(T)).sum() / fw.sum())
+    assert np.allclose(got / base, want, rtol=0.02), (got / base, want)

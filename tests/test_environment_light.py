@@ -203,3 +203,50 @@ def test_sky_scene_frame_parity(hk, oracle, sun, analytic):
     assert abs(int(st.rays_closest) - int(ost.rays_closest)) <= 0.002 * ost.rays_closest + 8
     assert abs(int(st.rays_shadow) - int(ost.rays_shadow)) <= 0.002 * ost.rays_shadow + 8
     vp.close()
+
+
+@pytest.mark.gpu
+def test_sky_scene_bench_configuration(hk, oracle):
+    """Config 3 exactly as bench.py --config sky builds it — 512^2 equal-area environment map, default tessellation, depth 12 — first
+    against the oracle on a small film (same seed, strict), then at the bench's 800 x 800 through size-independent properties: finite,
+    the rays per path of the full frame equal those of the small one within 1 %, and two sample-index shards add up to the unsharded film."""
+    from hikari_jl_amd import scenes
+    from test_gpu_parity import frame_metrics
+    kw = dict(max_depth=12, samples=256)
+    w = h = 80
+    s, film, cam = scenes.sky_scene(w, h, env_res=512)
+    p = hk.integrator_params(**kw)
+    osc = oracle.OracleScene(s)
+    acc, ost = osc.render(p, cam, w, h, 4)
+    osc.close()
+    ref = oracle.finalize(acc, w, h)
+    vp = hk.VolPath(**kw)
+    vp._ensure(film)
+    vp.clear()
+    vp.reset_stats()
+    vp.render_samples(s, film, cam, 4, first=1)
+    st = vp.stats()
+    rel_mse, frac_ok = frame_metrics(film.framebuffer, ref)
+    assert rel_mse <= 1e-3 and frac_ok >= 0.99, (rel_mse, frac_ok)
+    assert abs(int(st.rays_closest) - int(ost.rays_closest)) <= 0.002 * ost.rays_closest + 8
+    small_rays_per_path = (int(st.rays_closest) + int(st.rays_shadow)) / (w * h * 4)
+    vp.close()
+
+    W = H = 800
+    s2, film2, cam2 = scenes.sky_scene(W, H, env_res=512)
+    vp = hk.VolPath(**kw)
+    vp._ensure(film2)
+    vp.clear()
+    vp.reset_stats()
+    vp.render_samples(s2, film2, cam2, 16, first=1)
+    st = vp.stats()
+    full = vp.read_accumulators(film2).copy()
+    assert np.isfinite(full).all() and full.max() > 0
+    rays_per_path = (int(st.rays_closest) + int(st.rays_shadow)) / (W * H * 16)
+    assert abs(rays_per_path / small_rays_per_path - 1.0) < 0.01, (rays_per_path, small_rays_per_path)
+    vp.clear()
+    vp.render_samples(s2, film2, cam2, 8, stride=2, first=1)
+    vp.render_samples(s2, film2, cam2, 8, stride=2, first=2)
+    both = vp.read_accumulators(film2)
+    assert np.allclose(both, full, rtol=2e-4, atol=1e-5)      # the same 16 samples per pixel, summed in another order
+    vp.close()

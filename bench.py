@@ -119,10 +119,29 @@ def main():
 
     # ---- the film reduce of N > 1: hk_comm over RCCL inside the library (the C-ABI's own exchange step) ----
     comm = None
+    comm_note = None
     if world > 1 and not single_device:
-        uid = [hk.Comm.unique_id() if rank == 0 else None]
+        # The builder's box has one GPU: this path has only ever run as a 1-rank communicator.  If the in-library communicator cannot
+        # be set up on every rank (or its first reduce fails, below), ALL ranks fall back to torch.distributed's reduce — the same
+        # RCCL ring on the same buffer — and the line says so, rather than the scaling run dying.
+        ok = 1
+        try:
+            uid = [hk.Comm.unique_id() if rank == 0 else None]
+        except Exception as e:           # noqa: BLE001
+            uid, ok, comm_note = [None], 0, "hk_comm_unique_id: %s" % e
         dist.broadcast_object_list(uid, src=0)        # the launcher's side channel for the 128-byte id
-        comm = hk.Comm.rank(vp._ctx, uid[0], rank, world)
+        if uid[0] is None:
+            ok = 0
+        if ok:
+            try:
+                comm = hk.Comm.rank(vp._ctx, uid[0], rank, world)
+            except Exception as e:       # noqa: BLE001
+                ok, comm_note = 0, "hk_comm_create_rank: %s" % e
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            comm = None
+            comm_note = comm_note or "another rank could not create its communicator"
 
     def reduce_films():
         if comm is not None:
@@ -140,7 +159,22 @@ def main():
         # untimed: RCCL sets up the reduce's channels on first use; and the cross-check of the in-library reduce against
         # torch.distributed's on the warm-up film (same inputs, same ring: identical sums)
         keep = accum.clone()
-        reduce_films()
+        if comm is not None:
+            ok = 1
+            try:
+                reduce_films()
+                vp.sync()
+            except Exception as e:       # noqa: BLE001
+                ok, comm_note = 0, "hk_film_reduce: %s" % e
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                comm = None
+                comm_note = comm_note or "hk_film_reduce failed on another rank"
+                accum.copy_(keep)
+                reduce_films()
+        else:
+            reduce_films()
         barrier()
         mine = accum.clone()
         accum.copy_(keep)
@@ -296,7 +330,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload,
                        "resolution": [W, H], "max_depth": DEPTH, "spp_per_step": SPP_PER_STEP, "spp_rendered": spp_done,
-                       "triangles": int(scene.desc.n_triangles), "lights": int(scene.desc.n_lights), "parallelism": "sample-index sharding x%d + in-library RCCL film reduce (hk_film_reduce)" % world,
+                       "triangles": int(scene.desc.n_triangles), "lights": int(scene.desc.n_lights), "parallelism": ("sample-index sharding x%d + in-library RCCL film reduce (hk_film_reduce)" % world) if (comm is not None or world == 1) else ("sample-index sharding x%d + %s" % (world, "gloo film reduce on one device (HK_BENCH_SINGLE_DEVICE test hook)" if single_device else "torch.distributed film reduce (in-library communicator unavailable: %s)" % comm_note)),
                        "reduce_matches_torch_distributed": reduce_check},
             "seconds_timed": round(elapsed_max, 4),
             "seconds_to_256spp": round(elapsed_max * FULL_SPP / spp_done * world, 4) if world == 1 else round(elapsed_max * (FULL_SPP / spp_done), 4),

@@ -1123,3 +1123,43 @@ def test_filter_samplers_against_quadrature(hk, oracle):
             scale = np.abs(F * np.abs(g(X, Y))).sum() * cell / (norm or 1.0)
             tol = 0.04 if flt.type in (hk._abi.HK_FILTER_MITCHELL, hk._abi.HK_FILTER_LANCZOS) else 0.015
             assert abs(got - want) < tol * scale, (type(flt).__name__, k, got, want)
+
+
+# ---------------------------------------------------------------------------------------------------- stochastic surface decisions
+def test_alpha_and_mix_fractions(hk, oracle):
+    """Two decisions taken by hashing float bit patterns (intersection.jl:233-252 alpha test; mix-material.jl:96-127 material choice): whatever
+    the hash, over many rays a surface of alpha a must let 1 - a of them through (an emitter behind a black cut-out shows (1 - a) Le), and
+    a MixMaterial of amount m must resolve to its second child for a fraction m of the points."""
+    from hikari_jl_amd import geometry as G
+    from hikari_jl_amd.materials import Texture
+    R = hk.RGBSpectrum
+    base, osc, _ = _emitter_view(hk, oracle, lambda s: None, spp=16)
+    osc.close()
+    for a in (0.25, 0.6):
+        tex = np.zeros((4, 4, 4), np.float32)
+        tex[..., 3] = a                                     # black, alpha a everywhere
+
+        def cutout(s, tex=tex):
+            s.push(G.quad((-2, -2, 3), (2, -2, 3), (2, 2, 3), (-2, 2, 3), normal=(0, 0, -1)), hk.MatteMaterial(Kd=Texture(tex)))
+
+        got, osc, _ = _emitter_view(hk, oracle, cutout, spp=256)
+        osc.close()
+        assert np.allclose(got / base, 1.0 - a, rtol=0.02), (a, got / base)
+
+    rng = np.random.default_rng(8)
+    n = 200000
+    p = (rng.random((n, 3)) * 2 - 1).astype(f32)
+    wo = _unit(rng.normal(size=(n, 3))).astype(f32)
+    uv = rng.random((n, 2), dtype=f32)
+    for m in (0.2, 0.5, 0.85):
+        s = hk.Scene()
+        mix = hk.MixMaterial((hk.MatteMaterial(Kd=R(0.8, 0.1, 0.1)), hk.MirrorMaterial(Kr=R(0.9))), amount=m)
+        s.push(G.quad((-1, -1, 0), (1, -1, 0), (1, 1, 0), (-1, 1, 0), normal=(0, 0, 1)), mix)
+        s.sync()
+        osc = oracle.OracleScene(s)
+        kinds = [s.desc.materials[i].kind for i in range(s.desc.n_materials)]
+        mi = kinds.index(hk._abi.HK_MAT_MIX)
+        res = osc.mix_resolve(mi, p, wo, uv)
+        osc.close()
+        second = np.array([kinds[i] == hk._abi.HK_MAT_MIRROR for i in res])
+        assert abs(second.mean() - m) < 0.005, (m, second.mean())

@@ -645,9 +645,12 @@ def test_zsobol_sample_bit_table(hk, oracle, monkeypatch, first, n, stride, per_
         return acc, fb
 
     acc_table, fb = run()
+    monkeypatch.setenv("HK_SOBOL_LO_GB", "0.0002")     # 200 kB: room for a handful of the 29 rows — the deeper dimensions hash their digits
+    acc_partial, _ = run()
     monkeypatch.setenv("HK_SOBOL_LO_GB", "0")
     acc_hashed, _ = run()
     assert np.array_equal(acc_table.view(np.uint32), acc_hashed.view(np.uint32))
+    assert np.array_equal(acc_partial.view(np.uint32), acc_hashed.view(np.uint32))
     osc = oracle.OracleScene(s)
     p = hk.integrator_params(max_depth=4, samples=spp_setting)
     oacc, _ = osc.render(p, cam, w, h, n, first=first, stride=stride)

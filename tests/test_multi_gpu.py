@@ -68,11 +68,12 @@ def test_tile_sharding_is_bit_exact(hk):
     (not a multiple of the 8x8 tile) with a medium in the scene (ticketed segments) and on Cornell (static segments)."""
     from hikari_jl_amd import distributed as hd
     from hikari_jl_amd import scenes
-    for which, (w, h) in (("cornell", (67, 45)), ("integration", (40, 36))):
+    # 16 samples per call: the call reads the sampler's sample-bit table (built per tile origin), 4: it hashes the digits
+    for which, (w, h), ns in (("cornell", (67, 45), 4), ("cornell", (67, 45), 16), ("integration", (40, 36), 4)):
         s, _, _ = (scenes.cornell_box(w, h, light="area") if which == "cornell" else scenes.integration_test_scene(w, h))
         film = hk.Film((w, h))
         cam = hk.PerspectiveCamera((0, 1, -3.5), (0, 1, 0), film, fov=40.0)
-        kw = dict(max_depth=5, samples=4)
+        kw = dict(max_depth=5, samples=ns)
         vp = hk.VolPath(**kw)
         vp(s, film, cam)
         whole = vp.read_accumulators(film)
@@ -89,7 +90,7 @@ def test_tile_sharding_is_bit_exact(hk):
                 v._ensure(f)
                 v.clear()
                 v.reset_stats()
-                v.render_samples(s, f, cam, 4, tile=tile, readback=False)
+                v.render_samples(s, f, cam, ns, tile=tile, readback=False)
                 part = v.read_accumulators(f)
                 x0, y0, x1, y1 = tile
                 m = np.zeros((h, w), bool)

@@ -1581,6 +1581,9 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_shadow(DPathState st, DScene
 }
 
 enum { SH_EMPTY = 0, SH_CAST = 1, SH_TRACK = 2 };
+#ifndef HK_SHADOW_FEED_ROUNDS
+#define HK_SHADOW_FEED_ROUNDS 3
+#endif
 #ifndef HK_SHADOW_TRACK_BATCH
 #define HK_SHADOW_TRACK_BATCH 4
 #endif
@@ -1612,6 +1615,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
     bool in_seg = false, after_inner = false, pending = false;
     float pend_dt = 0.0f;
     int k_in_seg = 0, segi = 0;
+    int feed_rounds = 0;
     for (;;) {
         // ---- refill ----
         const unsigned long long busy_m = __ballot(state != SH_EMPTY);
@@ -1725,6 +1729,17 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
                 }
             }
         }
+        // ---- short rays (one cast and done: shadow rays that start outside the medium, blocked ones) leave their lanes empty for the
+        //      whole tracking batch below, which is where the time goes: fetch and cast again, a few times, until the wave is mostly
+        //      tracking (the cloud's walk ran its collision rounds with 28 % of the lanes EMPTY although work was waiting) ----
+        if (MM != 0 && feed_rounds < HK_SHADOW_FEED_ROUNDS) {
+            const int waiting = __popcll(__ballot(state == SH_EMPTY)) + __popcll(__ballot(state == SH_CAST));
+            if (waiting >= HK_REFILL_MIN_IDLE && (cursor < n || more)) {
+                ++feed_rounds;
+                continue;
+            }
+        }
+        feed_rounds = 0;
         // ---- a few ratio-tracking rounds: cheap steps until a tentative collision is pending, then the collisions.  Lanes are
         //      served medium by medium so that the medium record is read through a wave-uniform index (scalar loads) ----
         if (MM != 0) {

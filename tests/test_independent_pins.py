@@ -214,6 +214,19 @@ def test_conductor_against_float64(hk, oracle):
     E = osc.bsdf(1, 6, wo, wi, ns, lam, u, uc)
     f, pdf = R.conductor_f(wo, wi, a, a, ge, gk)
     assert np.allclose(E[same, 0:4], f[same], rtol=1e-3, atol=1e-7) and np.allclose(E[same, 4], pdf[same], rtol=1e-3, atol=1e-7)
+    # regularisation (microfacet.jl:97-99, applied by sample_bsdf_spectral after a non-specular bounce): alpha < 0.3 becomes
+    # clamp(2 alpha, 0.1, 0.3) — Gold's 0.2 samples and evaluates as 0.3, the smooth conductor (alpha 0) as a rough one of 0.1
+    for mat, a_reg, ee, kk in ((6, 0.3, ge, gk), (5, 0.1, eta, k)):
+        S = osc.bsdf(0, mat, wo, wi, ns, lam, u, uc, regularize=True)
+        wm = R.tr_sample_wm(wo, u, a_reg, a_reg)
+        refl = -wo + 2 * (wo * wm).sum(-1, keepdims=True) * wm
+        ok = (S[:, 7] > 0) & (np.abs(wo[:, 2]) > 0.05) & (np.abs(S[:, 2]) > 0.05)
+        assert ok.mean() > 0.7 and (S[ok, 8] == 0).all()                       # no longer specular
+        close = np.abs(S[:, 0:3] - refl).max(axis=1) < 2e-3                     # (a handful of samples sit on sample_wm's binary32 knife edges)
+        assert close[ok].mean() > 0.998
+        ok &= close
+        f, pdf = R.conductor_f(wo, S[:, 0:3].astype(np.float64), a_reg, a_reg, ee, kk)
+        assert np.allclose(S[ok, 3:7], f[ok], rtol=4e-3, atol=1e-6) and np.allclose(S[ok, 7], pdf[ok], rtol=4e-3, atol=1e-6)
     osc.close()
 
 

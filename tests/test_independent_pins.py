@@ -712,6 +712,15 @@ def test_medium_white_furnace_and_single_scatter(hk, oracle):
     s1, cam1 = furnace(hg_med)
     gain = mean(s1, cam1, 256) / ref
     assert np.allclose(gain, walk_gain_hg(4.0, 0.7), rtol=0.015), (gain, walk_gain_hg(4.0, 0.7))
+    # heterogeneous, exactly: a plane-parallel medium whose density depends on depth only is the homogeneous slab in optical-depth
+    # coordinates, so a z-ramp of total optical thickness 1.5 must show the isotropic slab's factor (delta tracking through a majorant
+    # grid with very different cells, against the same closed-form walk)
+    nz = 16
+    ramp = np.tile((0.25 + 1.5 * (np.arange(nz) + 0.5) / nz)[None, None, :], (6, 6, 1)).astype(np.float32)      # mean 1
+    het = hk.GridMedium(ramp, sigma_a=R(0.0), sigma_s=R(tau), g=0.0, bounds=((-2.5, -2.6, 1.0), (2.5, 2.6, 2.0)))
+    s1, cam1 = furnace(het)
+    gain = mean(s1, cam1, 128) / ref
+    assert np.allclose(gain, expected, rtol=0.02), (gain, expected)
     for med in (hk.GridMedium((0.2 + 0.8 * np.random.default_rng(3).random((6, 6, 6))).astype(np.float32), sigma_a=R(0.0), sigma_s=R(3.0), g=0.3,
                               bounds=((-2.5, -2.6, 1.0), (2.5, 2.6, 2.0))),):
         s1, cam1 = furnace(med)

@@ -679,7 +679,7 @@ def test_medium_white_furnace_and_single_scatter(hk, oracle):
             w = np.stack([np.sqrt(1 - wz * wz) * np.cos(ph), np.sqrt(1 - wz * wz) * np.sin(ph), wz], 1)
             pp = hg((d * w).sum(1))
             dist = np.where(wz > 0, (tau - z) / np.maximum(wz, 1e-12), z / np.maximum(-wz, 1e-12))
-            X += np.where(alive, pp / (1.0 / (4.0 * np.pi) + pp) * np.exp(-dist), 0.0)
+            X += np.where(alive, pp / (1.0 / (4.0 * np.pi) + pp) * np.exp(-np.where(alive, dist, 0.0)), 0.0)
             # next direction ~ HG about d
             xi = rng.random(n)
             mu = (1.0 + g * g - ((1.0 - g * g) / (1.0 - g + 2.0 * g * xi)) ** 2) / (2.0 * g)
@@ -721,6 +721,53 @@ def test_medium_white_furnace_and_single_scatter(hk, oracle):
     s1, cam1 = furnace(het)
     gain = mean(s1, cam1, 128) / ref
     assert np.allclose(gain, expected, rtol=0.02), (gain, expected)
+    # NULL collisions change the factor (Q30 again): the shadow ray's ratio tracker multiplies T_ray and r_u by sigma_n / sigma_maj per
+    # majorant event, the sample is weighted T / (r_l + r_u), and E[T / (1 + r_u)] >= Tr / 2 -- so the doubly counted direct term grows
+    # with the slack of the majorant (tight: T in {0, 1} and the factor above).  The walk below is an independent simulation of exactly
+    # that estimator (delta tracking to real collisions, ratio tracking with the 0.05 / 0.75 roulette of intersection.jl:422-542 on the
+    # next-event ray) in a plane-parallel slab; the renderer goes through a NanoVDB tree under ONE global majorant cell.
+    def walk_gain_tracked(rho, sigma_bar, n=150000, seed=4):       # extinction sigma_bar * rho(z) <= sigma_bar over thickness 1
+        rng = np.random.default_rng(seed)
+        z, mu, alive, X = np.zeros(n), np.ones(n), np.ones(n, bool), np.zeros(n)
+        while alive.any():
+            seek = alive.copy()
+            while seek.any():
+                z = np.where(seek, z - mu * np.log(1.0 - rng.random(n)) / sigma_bar, z)
+                left = seek & ((z <= 0) | (z >= 1))
+                alive &= ~left
+                seek &= ~left
+                seek &= ~(seek & (rng.random(n) < rho(np.clip(z, 0, 1))))
+            wz = 2.0 * rng.random(n) - 1.0
+            T, ru, zc, go = np.ones(n), np.ones(n), z.copy(), alive.copy()
+            while go.any():
+                zc = np.where(go, zc - wz * np.log(1.0 - rng.random(n)) / sigma_bar, zc)
+                go &= (zc > 0) & (zc < 1)
+                keep = 1.0 - rho(np.clip(zc, 0, 1))
+                T, ru = np.where(go, T * keep, T), np.where(go, ru * keep, ru)
+                rr = go & (T / (1.0 + ru) < 0.05)
+                kill = rr & (rng.random(n) < 0.75)
+                T = np.where(kill, 0.0, np.where(rr, T / 0.25, T))
+                go &= T > 0.0
+            X += np.where(alive, T / (1.0 + ru), 0.0)
+            mu = np.where(alive, 2.0 * rng.random(n) - 1.0, mu)
+        return 1.0 + X.mean()
+
+    assert abs(walk_gain_tracked(lambda zz: np.ones_like(zz), tau) - expected) < 0.006        # tight majorant: the closed form again
+    nv_bounds = ((-2.5, -2.6, 1.0), (2.5, 2.6, 2.0))
+    spike = np.ones((16, 16, 16), np.float32)
+    spike[0, 0, 0] = 2.0                                                    # a corner voxel far from the probed pixels doubles the majorant
+    loose = hk.NanoVDBMedium(spike, bounds=nv_bounds, sigma_a=R(0.0), sigma_s=R(tau), g=0.0, majorant_res=(1, 1, 1))
+    s1, cam1 = furnace(loose)
+    gain = mean(s1, cam1, 128) / ref
+    want = walk_gain_tracked(lambda zz: np.full_like(zz, 0.5), 2.0 * tau)
+    assert 1.46 < want < 1.49 and np.allclose(gain, want, rtol=0.015), (gain, want)
+    vox = 0.25 + 1.5 * (np.arange(16) + 0.5) / 16                           # depth ramp through the tree: trilinear between voxel
+    ramp16 = np.tile(vox[None, None, :], (16, 16, 1)).astype(np.float32)    # centres, fading to the background 0 across the faces
+    het_nv = hk.NanoVDBMedium(ramp16, bounds=nv_bounds, sigma_a=R(0.0), sigma_s=R(tau), g=0.0, majorant_res=(1, 1, 1))
+    s1, cam1 = furnace(het_nv)
+    gain = mean(s1, cam1, 128) / ref
+    want = walk_gain_tracked(lambda zz: np.interp(zz * 16 - 0.5, np.arange(-1, 17), np.concatenate([[0.0], vox, [0.0]])) / vox.max(), tau * vox.max())
+    assert 1.43 < want < 1.47 and np.allclose(gain, want, rtol=0.015), (gain, want)
     for med in (hk.GridMedium((0.2 + 0.8 * np.random.default_rng(3).random((6, 6, 6))).astype(np.float32), sigma_a=R(0.0), sigma_s=R(3.0), g=0.3,
                               bounds=((-2.5, -2.6, 1.0), (2.5, 2.6, 2.0))),):
         s1, cam1 = furnace(med)

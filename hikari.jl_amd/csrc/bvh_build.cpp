@@ -187,6 +187,31 @@ void build_bvh(const float* positions, int n_tris, BVH& out) {
     Box box;
     out.root_ref = b.build(0, n_tris, 0, box);
     out.max_depth = b.max_depth_seen;
+    // Breadth-first renumbering: the recursion above emits nodes in pre-order; the traversal kernels keep the FIRST nodes of the
+    // array in LDS, and those should be the top levels of the tree (every ray visits them).  Indices are internal to the node
+    // array, so results do not change.
+    if (out.root_ref >= 0) {
+        const size_t n = out.nodes.size();
+        std::vector<int> order;
+        order.reserve(n);
+        std::vector<int> new_index(n, -1);
+        order.push_back(out.root_ref);
+        for (size_t head = 0; head < order.size(); ++head) {
+            const BVHNode& nd = out.nodes[order[head]];
+            if (nd.c0 >= 0) order.push_back(nd.c0);
+            if (nd.c1 >= 0) order.push_back(nd.c1);
+        }
+        for (size_t i = 0; i < order.size(); ++i) new_index[order[i]] = (int)i;
+        std::vector<BVHNode> sorted(order.size());
+        for (size_t i = 0; i < order.size(); ++i) {
+            BVHNode nd = out.nodes[order[i]];
+            if (nd.c0 >= 0) nd.c0 = new_index[nd.c0];
+            if (nd.c1 >= 0) nd.c1 = new_index[nd.c1];
+            sorted[i] = nd;
+        }
+        out.nodes.swap(sorted);
+        out.root_ref = 0;
+    }
     for (int k = 0; k < 3; ++k) {
         out.lo[k] = box.lo[k];
         out.hi[k] = box.hi[k];

@@ -865,9 +865,35 @@ typedef float hk_f2 __attribute__((ext_vector_type(2)));
 // One inner-node step of a lane: both child boxes (DNode: the (lo, hi) pair of an axis sits in adjacent words, so one packed fma
 // gives both plane distances), nearest hit child first, the other pushed.  Per-lane stack in LDS: entry e of lane l at
 // stack[e * 64 + l] (bank = lane => conflict-free).  Selects instead of a four-way branch: a divergent wave would walk every arm.
-HKD void node_step(const DScene& sc, const RaySlab& rs, float t_best, int* __restrict__ stack, int lane, int& cur, int& sp) {
-    const float4* np = reinterpret_cast<const float4*>(sc.nodes) + 4 * (size_t)cur;
-    const float4 A = np[0], B = np[1], C = np[2], D = np[3];
+// The first `nc` nodes (breadth-first order: the top of the tree) may sit in LDS, one array per 16-byte part of the node so that the
+// lanes of a wave, each at its own node, spread over all banks: part j of node i at box[j * NC + i], the child pair at child[i].
+// (LDS-qualified pointers, and an asm barrier in the LDS arm of node_step: left alone the compiler turns the two arms into a SELECT of
+// generic pointers and one flat load.)
+typedef float hk_f4v __attribute__((ext_vector_type(4)));
+typedef int hk_i2v __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) hk_f4v lds_float4;
+typedef __attribute__((address_space(3))) hk_i2v lds_int2;
+struct NodeCache {
+    const lds_float4* box;
+    const lds_int2* child;
+    int nc;
+};
+template <int NC = 0>
+HKD void node_step(const DScene& sc, const RaySlab& rs, float t_best, int* __restrict__ stack, int lane, int& cur, int& sp, const NodeCache& cache = NodeCache()) {
+    float4 A, B, C;
+    int c0, c1;
+    if (NC > 0 && cur < cache.nc) {
+        const hk_f4v a = cache.box[cur], b = cache.box[NC + cur], c = cache.box[2 * NC + cur];
+        const hk_i2v ch = cache.child[cur];
+        A = make_float4(a.x, a.y, a.z, a.w), B = make_float4(b.x, b.y, b.z, b.w), C = make_float4(c.x, c.y, c.z, c.w);
+        c0 = ch.x, c1 = ch.y;
+        asm volatile("" : "+v"(c0));
+    } else {
+        const float4* np = reinterpret_cast<const float4*>(sc.nodes) + 4 * (size_t)cur;
+        A = np[0], B = np[1], C = np[2];
+        const float4 D = np[3];
+        c0 = __float_as_int(D.x), c1 = __float_as_int(D.y);
+    }
     const hk_f2 IX = {rs.ix, rs.ix}, IY = {rs.iy, rs.iy}, IZ = {rs.iz, rs.iz}, OX = {rs.ox, rs.ox}, OY = {rs.oy, rs.oy}, OZ = {rs.oz, rs.oz};
     const hk_f2 x0 = __builtin_elementwise_fma((hk_f2){A.x, A.y}, IX, OX), y0 = __builtin_elementwise_fma((hk_f2){A.z, A.w}, IY, OY);
     const hk_f2 z0 = __builtin_elementwise_fma((hk_f2){B.x, B.y}, IZ, OZ), x1 = __builtin_elementwise_fma((hk_f2){B.z, B.w}, IX, OX);
@@ -878,7 +904,6 @@ HKD void node_step(const DScene& sc, const RaySlab& rs, float t_best, int* __res
     const float f1 = fminf(fminf(fmaxf(x1.x, x1.y), fmaxf(y1.x, y1.y)), fminf(fmaxf(z1.x, z1.y), t_best));
     const bool h0 = n0 <= fmaf(f0, 1.00003f, rs.eps3);
     const bool h1 = n1 <= fmaf(f1, 1.00003f, rs.eps3);
-    const int c0 = __float_as_int(D.x), c1 = __float_as_int(D.y);
     const bool both = h0 && h1, any = h0 || h1;
     const bool first0 = n0 <= n1;
     const int near_c = (both ? first0 : h0) ? c0 : c1;

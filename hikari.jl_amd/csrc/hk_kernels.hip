@@ -12,6 +12,7 @@
 // then k_film folds the S samples of each pixel into the film accumulators in sample order        [K12]
 // Queue sizes live in device memory (counters[depth][queue]); every kernel sizes itself from them.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include "hikari_mi355x.h"
 #include "hk_device.h"
@@ -30,7 +31,15 @@ struct WaveQ {
     uint32_t* base;
     int count;  // wave-uniform
 };
-__device__ __forceinline__ int global_wave() { return (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)); }
+// Wave index of the launch.  Everything that ties data to an XCD (static segment strides, ticket counters) assumes 4-wave blocks dealt
+// round-robin over the 8 XCDs: wave g runs on XCD (g / 4) % 8.  A 16-wave block (k_trace_lean with its node cache) numbers its
+// waves so that this still holds: it stands for the four 4-wave blocks vb = ((b / 8) * 4 + w / 4) * 8 + b % 8 (a bijection when
+// the grid is a multiple of 8 blocks, which one block per CU is).
+__device__ __forceinline__ int global_wave() {
+    const int w = (int)(threadIdx.x >> 6), b = (int)blockIdx.x;
+    if (blockDim.x == 1024 && (gridDim.x & 7) == 0) return ((((b >> 3) * 4 + (w >> 2)) * 8 + (b & 7)) << 2) + (w & 3);
+    return b * (int)(blockDim.x >> 6) + w;
+}
 __device__ __forceinline__ int physical_waves() { return (int)(gridDim.x * (blockDim.x >> 6)); }
 // A kernel is launched with as many physical waves as are resident for ITS register/LDS budget; each physical wave walks the
 // virtual wave segments.  Surface scenes walk them with a static stride (the grid is clamped to a divisor of W, see
@@ -539,8 +548,8 @@ HKD void lane_ray_start(LaneRay& r, const DScene& sc, v3 o, v3 d, float t_max) {
 }
 // one while-while round for the lanes with `active`: inner nodes until every such lane holds a leaf (or is done), then the leaves.
 // ANYHIT: the first accepted triangle ends the ray (cur = DONE, best.prim >= 0).
-template <bool ANYHIT, bool COUNT>
-HKD void lane_ray_round(LaneRay& r, bool active, const DScene& sc, int* __restrict__ stack, int lane, unsigned& n_nodes, unsigned& n_tris) {
+template <bool ANYHIT, bool COUNT, int NC = 0>
+HKD void lane_ray_round(LaneRay& r, bool active, const DScene& sc, int* __restrict__ stack, int lane, unsigned& n_nodes, unsigned& n_tris, const NodeCache& cache = NodeCache()) {
     const int DONE = (int)0x80000000;
     for (;;) {
         const unsigned long long in_nodes = __ballot(active && r.cur >= 0);
@@ -551,7 +560,7 @@ HKD void lane_ray_round(LaneRay& r, bool active, const DScene& sc, int* __restri
         if (__popcll(in_nodes) < __popcll(__ballot(active && r.cur < 0 && r.cur != DONE))) break;
         if (active && r.cur >= 0) {
             if (COUNT) ++n_nodes;
-            node_step(sc, r.rs, r.best.t, stack, lane, r.cur, r.sp);
+            node_step<NC>(sc, r.rs, r.best.t, stack, lane, r.cur, r.sp, cache);
         }
     }
     if (active && r.cur < 0 && r.cur != DONE) {
@@ -592,12 +601,33 @@ HKD void lane_ray_round(LaneRay& r, bool active, const DScene& sc, int* __restri
 
 enum { LR_EMPTY = 0, LR_ACTIVE = 1 };
 
+// Copies the first min(NC, sc.n_nodes) nodes into the block's LDS (see NodeCache) and waits for the whole block.
+template <int NC, int BLOCK>
+HKD NodeCache node_cache_fill(const DScene& sc, float4* __restrict__ box, int2* __restrict__ child) {
+    NodeCache c;
+    c.box = (const lds_float4*)box, c.child = (const lds_int2*)child;
+    c.nc = sc.n_nodes < NC ? sc.n_nodes : NC;
+    if (NC > 0) {
+        for (int i = threadIdx.x; i < c.nc; i += BLOCK) {
+            const float4* np = reinterpret_cast<const float4*>(sc.nodes) + 4 * (size_t)i;
+            const float4 D = np[3];
+            box[i] = np[0], box[NC + i] = np[1], box[2 * NC + i] = np[2];
+            child[i] = make_int2(__float_as_int(D.x), __float_as_int(D.y));
+        }
+        __syncthreads();
+    }
+    return c;
+}
+
 // STACK: LDS stack entries per lane.  The stack holds at most one entry per inner level, so a BVH of depth <= 16 (every scene
 // but the 10^6-triangle one) runs with half the LDS: 16 KB per block instead of 32, and LDS stops limiting residency.
-template <bool COUNT, int STACK>
-__global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace_lean(DPathState st, DScene sc, int depth, DStats* stats) {
-    __shared__ int lds_stack[(HK_TRACE_BLOCK / 64) * STACK * 64];
+template <bool COUNT, int STACK, int BLOCK = HK_TRACE_BLOCK, int NC = 0>
+__global__ void __launch_bounds__(BLOCK) k_trace_lean(DPathState st, DScene sc, int depth, DStats* stats) {
+    __shared__ int lds_stack[(BLOCK / 64) * STACK * 64];
+    __shared__ float4 lds_box[NC > 0 ? 3 * NC : 1];
+    __shared__ int2 lds_child[NC > 0 ? NC : 1];
     int* stack = lds_stack + (threadIdx.x >> 6) * (STACK * 64);
+    const NodeCache cache = node_cache_fill<NC, BLOCK>(sc, lds_box, lds_child);
     const int lane = lane_id();
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const int DONE = (int)0x80000000;
@@ -669,7 +699,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace_lean(DPathState st, DS
             cursor += want_n < avail ? want_n : (avail > 0 ? avail : 0);
             if (__ballot(state == LR_ACTIVE) == 0ull) break;
         }
-        lane_ray_round<false, COUNT>(r, state == LR_ACTIVE && r.cur != DONE, sc, stack, lane, n_nodes, n_tris);
+        lane_ray_round<false, COUNT, NC>(r, state == LR_ACTIVE && r.cur != DONE, sc, stack, lane, n_nodes, n_tris, cache);
     }
     wq_close(q_escaped, count_ptr(st, depth, Q_ESCAPED, gw));
     if (lane == 0) {
@@ -1514,10 +1544,13 @@ HKD void shadow_contribute(DPathState& st, uint32_t rec, S4 T_ray, S4 tr_u, S4 t
     }
 }
 
-template <bool COUNT, int STACK>
-__global__ void __launch_bounds__(HK_TRACE_BLOCK) k_shadow(DPathState st, DScene sc, int depth, DStats* stats) {
-    __shared__ int lds_stack[(HK_TRACE_BLOCK / 64) * STACK * 64];
+template <bool COUNT, int STACK, int BLOCK = HK_TRACE_BLOCK, int NC = 0>
+__global__ void __launch_bounds__(BLOCK) k_shadow(DPathState st, DScene sc, int depth, DStats* stats) {
+    __shared__ int lds_stack[(BLOCK / 64) * STACK * 64];
+    __shared__ float4 lds_box[NC > 0 ? 3 * NC : 1];
+    __shared__ int2 lds_child[NC > 0 ? NC : 1];
     int* stack = lds_stack + (threadIdx.x >> 6) * (STACK * 64);
+    const NodeCache cache = node_cache_fill<NC, BLOCK>(sc, lds_box, lds_child);
     const int lane = lane_id();
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const int DONE = (int)0x80000000;
@@ -1569,7 +1602,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_shadow(DPathState st, DScene
                 continue;
             }
         }
-        lane_ray_round<true, COUNT>(r, have && r.cur != DONE, sc, stack, lane, n_nodes, n_tris);
+        lane_ray_round<true, COUNT, NC>(r, have && r.cur != DONE, sc, stack, lane, n_nodes, n_tris, cache);
     }
     stats += global_wave();
     wave_add(&stats->rays_shadow, n_casts);
@@ -2349,8 +2382,16 @@ static int cached_blocks(int block, int n_cu, int cap_per_cu) {
 // Segments are walked with a static stride, so the number of physical waves must DIVIDE W or the last round runs with a
 // fraction of the waves (shade at W = 16/CU with 12 resident: 12 % slower than at W = 24): the largest divisor of the
 // 4-wave block count that is resident.
-static int clamp_blocks(int blocks, const DPathState& st) {
-    const int units = st.n_waves / 4;
+static int node_cache_mode() {   // HK_NODE_CACHE=0: the lean closest-hit kernel reads every node from global memory (A/B switch)
+    static int mode = -1;
+    if (mode < 0) {
+        const char* e = std::getenv("HK_NODE_CACHE");
+        mode = (e && std::atoi(e) == 0) ? 0 : 1;
+    }
+    return mode;
+}
+static int clamp_blocks(int blocks, const DPathState& st, int waves_per_block = 4) {
+    const int units = st.n_waves / waves_per_block;
     if (blocks >= units) return units;
     if (st.dynamic_segments) return blocks;
     int best = 1;
@@ -2369,20 +2410,30 @@ void launch_camera(hipStream_t s, int n_cu, const DPathState& st, const DFrame& 
 }
 void launch_trace(hipStream_t s, int n_cu, const DPathState& st, const DScene& sc, const DTables& T, const DFrame& fr, int depth, DStats* stats) {
     if (sc.all_opaque && sc.n_media == 0) {
-#define HK_LEAN_LAUNCH(K, C, S)                                                                                       \
-    {                                                                                                                 \
-        const int blocks = cached_blocks<K<C, S>>(HK_TRACE_BLOCK, n_cu, 8);                                         \
-        hipLaunchKernelGGL((K<C, S>), dim3(clamp_blocks(blocks, st)), dim3(HK_TRACE_BLOCK), 0, s, st, sc, depth, stats); \
+#define HK_LEAN_LAUNCH(K, C, S, B, NC)                                                                                         \
+    {                                                                                                                          \
+        const int blocks = cached_blocks<K<C, S, B, NC>>(B, n_cu, 8);                                                          \
+        hipLaunchKernelGGL((K<C, S, B, NC>), dim3(clamp_blocks(blocks, st, B / 64)), dim3(B), 0, s, st, sc, depth, stats);     \
     }
-#define HK_LEAN_DISPATCH(K)                                        \
-    if (sc.bvh_depth <= 16) {                                      \
-        if (fr.count_nodes) HK_LEAN_LAUNCH(K, true, 16)            \
-        else HK_LEAN_LAUNCH(K, false, 16)                          \
-    } else {                                                       \
-        if (fr.count_nodes) HK_LEAN_LAUNCH(K, true, HK_LDS_STACK)  \
-        else HK_LEAN_LAUNCH(K, false, HK_LDS_STACK)                \
+// k_trace_lean over a BVH of depth <= 16: ONE 1024-thread block per CU (the 4 waves per SIMD its registers allow anyway) whose LDS
+// holds the 16 stacks (64 KB) and the top 1536 nodes of the tree (84 KB) — all of the Cornell box, the upper levels of the others.
+// Measured (HK_NODE_CACHE=0 switches it off): trace -11 % in the Cornell box and the sky scene.  Not for the any-hit kernel (it
+// runs at 7 waves per SIMD, and the cache would cost it three of them: +3 %) and not for the 32-entry stacks of the 10^6-triangle
+// scene (512 nodes are a small part of its visits: +-1 %).
+#define HK_LEAN_DISPATCH(K, B16, NC16)                                           \
+    if (sc.bvh_depth <= 16) {                                                    \
+        if (node_cache_mode() != 0) {                                            \
+            if (fr.count_nodes) HK_LEAN_LAUNCH(K, true, 16, B16, NC16)           \
+            else HK_LEAN_LAUNCH(K, false, 16, B16, NC16)                         \
+        } else {                                                                 \
+            if (fr.count_nodes) HK_LEAN_LAUNCH(K, true, 16, HK_TRACE_BLOCK, 0)   \
+            else HK_LEAN_LAUNCH(K, false, 16, HK_TRACE_BLOCK, 0)                 \
+        }                                                                        \
+    } else {                                                                     \
+        if (fr.count_nodes) HK_LEAN_LAUNCH(K, true, HK_LDS_STACK, HK_TRACE_BLOCK, 0)   \
+        else HK_LEAN_LAUNCH(K, false, HK_LDS_STACK, HK_TRACE_BLOCK, 0)           \
     }
-        HK_LEAN_DISPATCH(k_trace_lean)
+        HK_LEAN_DISPATCH(k_trace_lean, 1024, 1536)
         return;
     }
     const int b0 = cached_blocks<k_trace<false>>(HK_TRACE_BLOCK, n_cu, 8), b1 = cached_blocks<k_trace<true>>(HK_TRACE_BLOCK, n_cu, 8);
@@ -2398,7 +2449,7 @@ static int media_mask_class(const DScene& sc) {
 }
 void launch_shadow(hipStream_t s, int n_cu, const DPathState& st, const DScene& sc, const DTables& T, const DFrame& fr, int depth, DStats* stats) {
     if (sc.all_opaque && sc.n_media == 0) {
-        HK_LEAN_DISPATCH(k_shadow)
+        HK_LEAN_DISPATCH(k_shadow, HK_TRACE_BLOCK, 0)
         return;
     }
 #define HK_SHADOW_LAUNCH(C, MM)                                                                                                        \

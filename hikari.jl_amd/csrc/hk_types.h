@@ -146,6 +146,8 @@ struct DScene {
     const float4* leaf_tris;    // 3 float4 per triangle in leaf order
     int root_ref;
     int n_tris;
+    int n_nodes;                // inner nodes, breadth-first: the first HK_NODE_CACHE of them are what the lean traversal kernels keep in LDS
+    int pad_nodes;
     const float* positions;     // [T][9]
     const float* normals;       // [T][9] or null
     const float* uvs;           // [T][6] or null

@@ -823,6 +823,7 @@ extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene**
     D.root_ref = bvh.root_ref;
     D.n_tris = T;
     D.n_nodes = (int)bvh.nodes.size();
+    D.pad_nodes = 0;
     D.positions = s->positions.as<float>();
     D.normals = d->normals ? s->normals.as<float>() : nullptr;
     D.uvs = d->uvs ? s->uvs.as<float>() : nullptr;

@@ -567,6 +567,29 @@ HKD void lane_ray_round(LaneRay& r, bool active, const DScene& sc, int* __restri
         int ref = ~r.cur;
         int first = ref >> 3, count = (ref & 7) + 1;
         bool stop = false;
+        if (!ANYHIT) {
+            // closest hit tests every triangle of the leaf, so the next one is fetched while this one is tested (trace -4 % in the
+            // Cornell box, -2 % elsewhere); the any-hit loop below usually stops early and is better off without (shadow +1 %)
+            const float4* tp = sc.leaf_tris + 3 * (size_t)first;
+            float4 T0 = tp[0], T1 = tp[1], T2 = tp[2];
+            for (int i = 0; i < count; ++i) {
+                float4 N0 = T0, N1 = T1, N2 = T2;
+                if (i + 1 < count) N0 = tp[3 * i + 3], N1 = tp[3 * i + 4], N2 = tp[3 * i + 5];
+                asm volatile("" ::"v"(T0.x), "v"(T0.y), "v"(T0.z), "v"(T0.w));
+                if (COUNT) ++n_tris;
+                float t, u, v;
+                if (intersect_triangle(r.o, r.d, r.t_max, mk3(T0.x, T0.y, T0.z), mk3(T1.x, T1.y, T1.z), mk3(T2.x, T2.y, T2.z), t, u, v)) {
+                    int prim = __float_as_int(T0.w);
+                    if (r.best.prim < 0 || t < r.best.t || (t == r.best.t && prim < r.best.prim)) {
+                        r.best.t = t;
+                        r.best.prim = prim;
+                        r.best.u = u;
+                        r.best.v = v;
+                    }
+                }
+                T0 = N0, T1 = N1, T2 = N2;
+            }
+        } else
         for (int i = 0; i < count && !stop; ++i) {
             const float4* tp = sc.leaf_tris + 3 * (size_t)(first + i);
             float4 T0 = tp[0], T1 = tp[1], T2 = tp[2];
@@ -2382,13 +2405,9 @@ static int cached_blocks(int block, int n_cu, int cap_per_cu) {
 // Segments are walked with a static stride, so the number of physical waves must DIVIDE W or the last round runs with a
 // fraction of the waves (shade at W = 16/CU with 12 resident: 12 % slower than at W = 24): the largest divisor of the
 // 4-wave block count that is resident.
-static int node_cache_mode() {   // HK_NODE_CACHE=0: the lean closest-hit kernel reads every node from global memory (A/B switch)
-    static int mode = -1;
-    if (mode < 0) {
-        const char* e = std::getenv("HK_NODE_CACHE");
-        mode = (e && std::atoi(e) == 0) ? 0 : 1;
-    }
-    return mode;
+static int node_cache_mode() {   // HK_NODE_CACHE=0: the lean closest-hit kernel reads every node from global memory (A/B switch, read per launch)
+    const char* e = std::getenv("HK_NODE_CACHE");
+    return (e && std::atoi(e) == 0) ? 0 : 1;
 }
 static int clamp_blocks(int blocks, const DPathState& st, int waves_per_block = 4) {
     const int units = st.n_waves / waves_per_block;

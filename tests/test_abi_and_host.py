@@ -228,3 +228,18 @@ def test_medium_presets_table_and_constructors(hk):
     rec = hk._abi.hk_medium()
     m.fill_record(rec, [])
     assert rec.kind == hk._abi.HK_MEDIUM_HOMOGENEOUS and rec.sigma_s[2] == f32(3.77) * f32(0.5)
+
+
+@pytest.mark.parametrize("n_tris", [1, 4, 5, 257, 1934, 60000])
+def test_bvh_builder_invariants(n_tris):
+    """bvh_build.cpp on the host alone (g++, no GPU): breadth-first node numbering — the first nodes of the array are the top of the tree,
+    which is what k_trace_lean's LDS node cache holds — every node and triangle referenced exactly once, leaves of <= 4 inside their
+    child box, depth within the traversal stack (tests/native/bvh_order_check.cpp)."""
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(tempfile.gettempdir(), "hk_bvh_order_check_%d" % os.getuid())
+    src = [os.path.join(root, "tests", "native", "bvh_order_check.cpp"), os.path.join(root, "hikari.jl_amd", "csrc", "bvh_build.cpp")]
+    if not os.path.exists(exe) or any(os.path.getmtime(f) > os.path.getmtime(exe) for f in src):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(root, "include"), "-I", os.path.join(root, "hikari.jl_amd", "csrc")] + src + ["-o", exe])
+    r = subprocess.run([exe, str(n_tris), "11"], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), (r.stdout, r.stderr)

@@ -661,7 +661,8 @@ def test_zsobol_sample_bit_table(hk, oracle, monkeypatch, first, n, stride, per_
 @pytest.mark.parametrize("which", ["cornell", "sky", "slab"])
 def test_scheduling_is_result_neutral(hk, monkeypatch, which):
     """How segments reach waves must not change a bit of the film: static stride vs tickets over the work lists, other segment counts
-    (a count that is no multiple of anything), the shadow kernels on the second stream or not.  Accumulators compared exactly."""
+    (a count that is no multiple of anything), the shadow kernels on the second stream or not, BVH nodes from LDS or from global memory.
+    Accumulators compared exactly."""
     from hikari_jl_amd import scenes
     w, h = 40, 36
     if which == "cornell":
@@ -675,7 +676,7 @@ def test_scheduling_is_result_neutral(hk, monkeypatch, which):
         kw = dict(max_depth=6, samples=64)
 
     def run(env):
-        for k in ("HK_OVERLAP", "HK_DYNAMIC_SEGMENTS", "HK_WAVES_PER_CU"):
+        for k in ("HK_OVERLAP", "HK_DYNAMIC_SEGMENTS", "HK_WAVES_PER_CU", "HK_NODE_CACHE"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -690,10 +691,10 @@ def test_scheduling_is_result_neutral(hk, monkeypatch, which):
     ref = run({})
     assert np.isfinite(ref).all() and ref.max() > 0
     for env in ({"HK_OVERLAP": "0"}, {"HK_DYNAMIC_SEGMENTS": "0"}, {"HK_DYNAMIC_SEGMENTS": "1"}, {"HK_DYNAMIC_SEGMENTS": "1", "HK_WAVES_PER_CU": "7"},
-                {"HK_DYNAMIC_SEGMENTS": "0", "HK_WAVES_PER_CU": "5", "HK_OVERLAP": "1"}):
+                {"HK_DYNAMIC_SEGMENTS": "0", "HK_WAVES_PER_CU": "5", "HK_OVERLAP": "1"}, {"HK_NODE_CACHE": "0"}, {"HK_NODE_CACHE": "0", "HK_DYNAMIC_SEGMENTS": "0"}):
         got = run(env)
         assert np.array_equal(ref.view(np.uint32), got.view(np.uint32)), env
-    for k in ("HK_OVERLAP", "HK_DYNAMIC_SEGMENTS", "HK_WAVES_PER_CU"):
+    for k in ("HK_OVERLAP", "HK_DYNAMIC_SEGMENTS", "HK_WAVES_PER_CU", "HK_NODE_CACHE"):
         monkeypatch.delenv(k, raising=False)
     # leave the context's sticky knobs at their defaults for the tests that follow
     monkeypatch.setenv("HK_OVERLAP", "1")
@@ -729,6 +730,17 @@ def test_medium_furnace_gain_q30(hk):
     ref = frame(None)
     gain = frame(hk.HomogeneousMedium(sigma_a=R(0.0), sigma_s=R(1.5), g=0.0)) / ref
     assert np.allclose(gain, 1.387, rtol=0.012), gain
+    # null collisions (same CPU test, walk_gain_tracked): the ratio-tracked shadow ray's T / (r_l + r_u) weight raises the factor with
+    # the slack of the majorant — 1.475 when one global majorant cell is twice the density (a corner voxel doubles it), 1.449 for a
+    # depth ramp through the NanoVDB tree under one global cell
+    nv_bounds = ((-2.5, -2.6, 1.0), (2.5, 2.6, 2.0))
+    spike = np.ones((16, 16, 16), np.float32)
+    spike[0, 0, 0] = 2.0
+    gain = frame(hk.NanoVDBMedium(spike, bounds=nv_bounds, sigma_a=R(0.0), sigma_s=R(1.5), g=0.0, majorant_res=(1, 1, 1))) / ref
+    assert np.allclose(gain, 1.475, rtol=0.012), gain
+    ramp = np.tile((0.25 + 1.5 * (np.arange(16) + 0.5) / 16)[None, None, :], (16, 16, 1)).astype(np.float32)
+    gain = frame(hk.NanoVDBMedium(ramp, bounds=nv_bounds, sigma_a=R(0.0), sigma_s=R(1.5), g=0.0, majorant_res=(1, 1, 1))) / ref
+    assert np.allclose(gain, 1.449, rtol=0.012), gain
 
 
 def test_surface_furnace_q31(hk):

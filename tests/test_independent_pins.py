@@ -1132,6 +1132,59 @@ def test_heterogeneous_absorption_against_quadrature(hk, oracle):
         assert np.allclose(got / base, want, rtol=0.03), (type(med).__name__, got / base, want)
 
 
+def _nested_media_scene(hk, sigma_outer, sigma_inner):
+    """a diffuse wall at z = 4 lit by a point light at (3, 0, 2); between wall and light, away from the camera's rays, an absorbing box
+    (medium A) that contains a second box (medium B, declared inside = B / outside = A): the shadow rays cross A, B, A"""
+    from hikari_jl_amd import geometry as G
+    R = hk.RGBSpectrum
+    s = hk.Scene()
+    s.push(G.quad((-1, -1, 4), (-1, 1, 4), (1, 1, 4), (1, -1, 4), normal=(0, 0, -1)), hk.MatteMaterial(Kd=R(0.6)))
+    if sigma_outer is not None:
+        A = hk.HomogeneousMedium(sigma_a=R(sigma_outer), sigma_s=R(0.0), g=0.0)
+        B = hk.HomogeneousMedium(sigma_a=R(sigma_inner), sigma_s=R(0.0), g=0.0)
+        s.push(G.rect3f((1.3, -1.5, 2.2), (1.4, 3.0, 1.4)), hk.MediumInterface(hk.GlassMaterial(Kr=R(0.0), Kt=R(1.0), index=1.0), inside=A, outside=None))
+        s.push(G.rect3f((1.7, -0.8, 2.6), (0.6, 1.6, 0.6)), hk.MediumInterface(hk.GlassMaterial(Kr=R(0.0), Kt=R(1.0), index=1.0), inside=B, outside=A))
+    s.push(hk.PointLight((3.0, 0.0, 2.0), R(5.0)))
+    s.sync()
+    return s, hk.PerspectiveCamera((0, 0, 0), (0, 0, 1), hk.Film((8, 8)), fov=1.0)
+
+
+def _nested_media_expected(sigma_outer, sigma_inner):
+    P, L = np.array([0.0, 0.0, 4.0]), np.array([3.0, 0.0, 2.0])        # the 1-degree view sees the wall at P only
+
+    def chord(lo, hi):
+        d = L - P
+        t0, t1 = 0.0, 1.0
+        for k in range(3):
+            if d[k] != 0.0:
+                a, b = (lo[k] - P[k]) / d[k], (hi[k] - P[k]) / d[k]
+                t0, t1 = max(t0, min(a, b)), min(t1, max(a, b))
+        return max(0.0, t1 - t0) * float(np.linalg.norm(d))
+
+    l_outer, l_inner = chord((1.3, -1.5, 2.2), (2.7, 1.5, 3.6)), chord((1.7, -0.8, 2.6), (2.3, 0.8, 3.2))
+    assert l_inner > 0.3 and l_outer > l_inner + 0.5
+    return float(np.exp(-sigma_outer * (l_outer - l_inner) - sigma_inner * l_inner))
+
+
+def test_nested_media_shadow_transmittance(hk, oracle):
+    """The shadow walk through NESTED medium transitions (intersection.jl:302-406: the current medium follows inside / outside of every
+    transition surface it crosses): direct light on a diffuse wall behind a box of medium A containing a box of medium B is attenuated
+    by exp(-sigma_A (l_A - l_B) - sigma_B l_B), chord lengths by float64 slab intersection.  Camera rays never touch the media."""
+    p = hk.integrator_params(max_depth=4, samples=2048, max_component_value=1e9)
+
+    def mean(scene, cam):
+        osc = oracle.OracleScene(scene)
+        acc, _ = osc.render(p, cam, 8, 8, 2048)
+        osc.close()
+        return oracle.finalize(acc, 8, 8).mean(axis=(0, 1))
+
+    base = mean(*_nested_media_scene(hk, None, None))
+    assert base.min() > 1e-3
+    for sa, sb in ((0.5, 2.0), (1.2, 0.3)):
+        got = mean(*_nested_media_scene(hk, sa, sb)) / base
+        assert np.allclose(got, _nested_media_expected(sa, sb), rtol=0.015), (sa, sb, got, _nested_media_expected(sa, sb))
+
+
 # ---------------------------------------------------------------------------------------------------- pixel filters: sampler vs function
 def test_filter_samplers_against_quadrature(hk, oracle):
     """filter.jl:228-300, 733-953: for every filter the importance sampler (closed form for Box / Triangle, the tabulated FilterSampler for

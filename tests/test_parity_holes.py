@@ -766,6 +766,30 @@ def test_surface_furnace_q31(hk):
     assert abs(got - 1.3896) < 0.006, got
 
 
+def test_nested_media_shadow_on_device(hk):
+    """The HIP shadow walk through nested medium transitions against the closed form of
+    tests/test_independent_pins.py::test_nested_media_shadow_transmittance (exp(-sigma_A (l_A - l_B) - sigma_B l_B))."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_independent_pins import _nested_media_scene, _nested_media_expected
+
+    def mean(sa, sb):
+        s, cam = _nested_media_scene(hk, sa, sb)
+        film = hk.Film((8, 8))
+        vp = hk.VolPath(max_depth=4, samples=2048, max_component_value=1e9)
+        vp._ensure(film)
+        vp.clear()
+        vp.render_samples(s, film, cam, 2048, first=1)
+        img = film.framebuffer.copy()
+        vp.close()
+        return img.mean(axis=(0, 1))
+
+    base = mean(None, None)
+    for sa, sb in ((0.5, 2.0), (1.2, 0.3)):
+        got = mean(sa, sb) / base
+        assert np.allclose(got, _nested_media_expected(sa, sb), rtol=0.015), (sa, sb, got)
+
+
 def test_specular_and_absorption_closed_forms_on_device(hk, oracle):
     """The HIP path against the closed forms of tests/test_independent_pins.py directly (not through the oracle's frames): an emitter in
     a mirror is Kr Le, through a glass slab (1 - R) / (1 + R) Le, behind a heterogeneous absorbing NanoVDB box exp(-integral sigma_a)."""

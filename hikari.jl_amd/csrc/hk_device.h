@@ -906,8 +906,9 @@ HKD void node_step(const DScene& sc, const RaySlab& rs, float t_best, int* __res
     const bool h1 = n1 <= fmaf(f1, 1.00003f, rs.eps3);
     const bool both = h0 && h1, any = h0 || h1;
     const bool first0 = n0 <= n1;
-    const int near_c = (both ? first0 : h0) ? c0 : c1;
-    if (both) stack[sp * 64 + lane] = first0 ? c1 : c0;
+    const bool pick0 = h0 & (!h1 | first0);   // and / or of lane masks (scalar): a select between two conditions would be done per lane, && would branch
+    const int near_c = pick0 ? c0 : c1;
+    if (both) stack[sp * 64 + lane] = pick0 ? c1 : c0;
     sp += both ? 1 : 0;
     const bool pop = !any && sp > 0;
     sp -= pop ? 1 : 0;

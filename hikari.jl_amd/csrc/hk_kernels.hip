@@ -551,13 +551,16 @@ HKD void lane_ray_start(LaneRay& r, const DScene& sc, v3 o, v3 d, float t_max) {
 template <bool ANYHIT, bool COUNT, int NC = 0>
 HKD void lane_ray_round(LaneRay& r, bool active, const DScene& sc, int* __restrict__ stack, int lane, unsigned& n_nodes, unsigned& n_tris, const NodeCache& cache = NodeCache()) {
     const int DONE = (int)0x80000000;
+    // ballots of ONE comparison each, combined as scalar masks: the ballot of a compound condition costs two VALU instructions
+    // (v_cndmask + v_cmp) on top of the comparisons, and this loop is bound by instruction issue
+    const unsigned long long act_m = __builtin_amdgcn_ballot_w64(active);
     for (;;) {
-        const unsigned long long in_nodes = __ballot(active && r.cur >= 0);
+        const unsigned long long in_nodes = act_m & __builtin_amdgcn_ballot_w64(r.cur >= 0);
         if (in_nodes == 0ull) break;
         // stragglers: once fewer lanes are still descending than are waiting with a leaf, test the leaves first — the descending
         // lanes keep their state and go on in the next round.  (Running the node loop until the LAST lane holds a leaf cost
         // half of the traversal time in the 10^6-triangle scene: trace 0.94 -> 0.46 s, shadow 0.30 -> 0.19 s.)
-        if (__popcll(in_nodes) < __popcll(__ballot(active && r.cur < 0 && r.cur != DONE))) break;
+        if (__builtin_popcountll(in_nodes) < __builtin_popcountll(act_m & __builtin_amdgcn_ballot_w64((unsigned)r.cur > 0x80000000u))) break;   // cur < 0 and not DONE
         if (active && r.cur >= 0) {
             if (COUNT) ++n_nodes;
             node_step<NC>(sc, r.rs, r.best.t, stack, lane, r.cur, r.sp, cache);

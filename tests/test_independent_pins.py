@@ -1183,6 +1183,22 @@ def test_nested_media_shadow_transmittance(hk, oracle):
     for sa, sb in ((0.5, 2.0), (1.2, 0.3)):
         got = mean(*_nested_media_scene(hk, sa, sb)) / base
         assert np.allclose(got, _nested_media_expected(sa, sb), rtol=0.015), (sa, sb, got, _nested_media_expected(sa, sb))
+    # the CAMERA path through the same nesting (delta tracking restarts in the medium the crossed surface declares): an emitter seen
+    # through box A (2 deep) that contains box B (0.7 deep)
+    from hikari_jl_amd import geometry as G
+    R = hk.RGBSpectrum
+    view0, osc, _ = _emitter_view(hk, oracle, lambda s: None, spp=16)
+    osc.close()
+    for sa, sb in ((0.4, 1.5), (0.9, 0.2)):
+        def boxes(s, sa=sa, sb=sb):
+            A = hk.HomogeneousMedium(sigma_a=R(sa), sigma_s=R(0.0), g=0.0)
+            B = hk.HomogeneousMedium(sigma_a=R(sb), sigma_s=R(0.0), g=0.0)
+            s.push(G.rect3f((-1.0, -1.0, 2.0), (2.0, 2.0, 2.0)), hk.MediumInterface(hk.GlassMaterial(Kr=R(0.0), Kt=R(1.0), index=1.0), inside=A, outside=None))
+            s.push(G.rect3f((-0.5, -0.5, 2.5), (1.0, 1.0, 0.7)), hk.MediumInterface(hk.GlassMaterial(Kr=R(0.0), Kt=R(1.0), index=1.0), inside=B, outside=A))
+        got, osc, _ = _emitter_view(hk, oracle, boxes, spp=1024)
+        osc.close()
+        want = np.exp(-sa * 1.3 - sb * 0.7)
+        assert np.allclose(got / view0, want, rtol=0.02), (sa, sb, got / view0, want)
 
 
 # ---------------------------------------------------------------------------------------------------- pixel filters: sampler vs function

@@ -2439,10 +2439,17 @@ void launch_trace(hipStream_t s, int n_cu, const DPathState& st, const DScene& s
     }
 // k_trace_lean over a BVH of depth <= 16: ONE 1024-thread block per CU (the 4 waves per SIMD its registers allow anyway) whose LDS
 // holds the 16 stacks (64 KB) and the top 1536 nodes of the tree (84 KB) — all of the Cornell box, the upper levels of the others.
-// Measured (HK_NODE_CACHE=0 switches it off): trace -11 % in the Cornell box and the sky scene.  Not for the any-hit kernel (it
-// runs at 7 waves per SIMD, and the cache would cost it three of them: +3 %) and not for the 32-entry stacks of the 10^6-triangle
-// scene (512 nodes are a small part of its visits: +-1 %).
-#define HK_LEAN_DISPATCH(K, B16, NC16)                                           \
+// Measured (HK_NODE_CACHE=0 switches it off): trace -11 % in the Cornell box and the sky scene; with the 32-entry stacks of the
+// 10^6-triangle scene 512 nodes are a small part of the visits (+-1 %: no cache there).
+// The any-hit kernel lives on residency (7 waves per SIMD on 16 KB of stacks; the big cache cost it three of them: +3 %), so it
+// gets the cache that FITS beside them: HK_SHADOW_NC16 nodes per 4-wave block.
+#ifndef HK_SHADOW_NC16
+#define HK_SHADOW_NC16 112
+#endif
+#ifndef HK_SHADOW_NC32
+#define HK_SHADOW_NC32 0
+#endif
+#define HK_LEAN_DISPATCH(K, B16, NC16, NC32)                                     \
     if (sc.bvh_depth <= 16) {                                                    \
         if (node_cache_mode() != 0) {                                            \
             if (fr.count_nodes) HK_LEAN_LAUNCH(K, true, 16, B16, NC16)           \
@@ -2452,10 +2459,15 @@ void launch_trace(hipStream_t s, int n_cu, const DPathState& st, const DScene& s
             else HK_LEAN_LAUNCH(K, false, 16, HK_TRACE_BLOCK, 0)                 \
         }                                                                        \
     } else {                                                                     \
-        if (fr.count_nodes) HK_LEAN_LAUNCH(K, true, HK_LDS_STACK, HK_TRACE_BLOCK, 0)   \
-        else HK_LEAN_LAUNCH(K, false, HK_LDS_STACK, HK_TRACE_BLOCK, 0)           \
+        if (node_cache_mode() != 0) {                                            \
+            if (fr.count_nodes) HK_LEAN_LAUNCH(K, true, HK_LDS_STACK, HK_TRACE_BLOCK, NC32)   \
+            else HK_LEAN_LAUNCH(K, false, HK_LDS_STACK, HK_TRACE_BLOCK, NC32)    \
+        } else {                                                                 \
+            if (fr.count_nodes) HK_LEAN_LAUNCH(K, true, HK_LDS_STACK, HK_TRACE_BLOCK, 0)   \
+            else HK_LEAN_LAUNCH(K, false, HK_LDS_STACK, HK_TRACE_BLOCK, 0)       \
+        }                                                                        \
     }
-        HK_LEAN_DISPATCH(k_trace_lean, 1024, 1536)
+        HK_LEAN_DISPATCH(k_trace_lean, 1024, 1536, 0)
         return;
     }
     const int b0 = cached_blocks<k_trace<false>>(HK_TRACE_BLOCK, n_cu, 8), b1 = cached_blocks<k_trace<true>>(HK_TRACE_BLOCK, n_cu, 8);
@@ -2471,7 +2483,7 @@ static int media_mask_class(const DScene& sc) {
 }
 void launch_shadow(hipStream_t s, int n_cu, const DPathState& st, const DScene& sc, const DTables& T, const DFrame& fr, int depth, DStats* stats) {
     if (sc.all_opaque && sc.n_media == 0) {
-        HK_LEAN_DISPATCH(k_shadow, HK_TRACE_BLOCK, 0)
+        HK_LEAN_DISPATCH(k_shadow, HK_TRACE_BLOCK, HK_SHADOW_NC16, HK_SHADOW_NC32)
         return;
     }
 #define HK_SHADOW_LAUNCH(C, MM)                                                                                                        \

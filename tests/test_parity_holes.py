@@ -702,6 +702,45 @@ def test_scheduling_is_result_neutral(hk, monkeypatch, which):
     run({"HK_OVERLAP": "1", "HK_WAVES_PER_CU": "0"})
 
 
+def test_node_cache_partial_tree(hk, gpu_ctx, oracle, monkeypatch):
+    """A tree LARGER than the LDS node cache but at most 16 deep: lanes at cached levels read LDS, lanes below read global memory, in
+    the same wave (k_trace_lean 1536 nodes, k_shadow 112).  The film must equal, bit for bit, the one rendered with HK_NODE_CACHE=0,
+    and agree with the oracle's frame."""
+    import ctypes as C
+    from hikari_jl_amd import geometry as G
+    R = hk.RGBSpectrum
+    w, h = 48, 40
+    s = hk.Scene()
+    s.push(G.sphere((0.0, 0.0, 3.0), 1.0, nvertices=64), hk.MatteMaterial(Kd=R(0.7, 0.5, 0.3)))
+    s.push(G.quad((-3, -1.0, 0.5), (-3, -1.0, 6), (3, -1.0, 6), (3, -1.0, 0.5), normal=(0, 1, 0)), hk.MatteMaterial(Kd=R(0.5)))
+    s.push(hk.PointLight((2.0, 3.0, 0.5), R(20.0)))
+    s.sync()
+    cam = hk.PerspectiveCamera((0, 0.3, 0), (0, 0, 3), hk.Film((w, h)), fov=50.0)
+    n_nodes, depth = C.c_int32(), C.c_int32()
+    hk._lib.lib().hk_scene_bvh_info(hk.scene_handle(gpu_ctx, s), C.byref(n_nodes), None, C.byref(depth))
+    assert n_nodes.value > 1536 and depth.value <= 16, (n_nodes.value, depth.value)
+
+    def run(cache):
+        monkeypatch.setenv("HK_NODE_CACHE", cache)
+        film = hk.Film((w, h))
+        vp = hk.VolPath(max_depth=5, samples=64)
+        vp._ensure(film)
+        vp.clear()
+        vp.render_samples(s, film, cam, 16, first=1)
+        acc, img = vp.read_accumulators(film).copy(), film.framebuffer.copy()
+        vp.close()
+        return acc, img
+
+    acc1, img1 = run("1")
+    acc0, _ = run("0")
+    monkeypatch.delenv("HK_NODE_CACHE", raising=False)
+    assert np.array_equal(acc0.view(np.uint32), acc1.view(np.uint32))
+    oacc, _ = oracle.OracleScene(s).render(hk.integrator_params(max_depth=5, samples=64), cam, w, h, 16)
+    ref = oracle.finalize(oacc, w, h)
+    rel_mse, frac = frame_metrics(img1, ref)
+    assert img1.max() > 0.05 and rel_mse <= 1e-3 and frac >= 0.99, (rel_mse, frac)
+
+
 def test_medium_furnace_gain_q30(hk):
     """The HIP path against the closed form of tests/test_independent_pins.py::test_medium_white_furnace_and_single_scatter: a
     non-absorbing isotropic slab of optical thickness 1.5 inside a constant environment returns 1.387 times the environment (the

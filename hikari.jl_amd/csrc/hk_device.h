@@ -877,6 +877,8 @@ struct NodeCache {
     const lds_float4* box;
     const lds_int2* child;
     int nc;
+    const lds_float4* tri;   // leaf triangles 0 .. nt-1 (media kernels: scenes of a few dozen triangles live in LDS entirely), part j of
+    int nt;                  // triangle i at tri[j * NT + i]
 };
 template <int NC = 0>
 HKD void node_step(const DScene& sc, const RaySlab& rs, float t_best, int* __restrict__ stack, int lane, int& cur, int& sp, const NodeCache& cache = NodeCache()) {
@@ -920,8 +922,9 @@ HKD void node_step(const DScene& sc, const RaySlab& rs, float t_best, int* __res
 // MODE 0: closest hit (ties on t -> smaller prim index).  MODE 1: shadow segment — returns as soon as an
 // opaque triangle is hit (any opaque hit zeroes the contribution, intersection.jl:378-379), otherwise
 // closest hit among the non-opaque ones.
-template <int MODE, bool COUNT>
-HKD HitRec traverse(const DScene& sc, v3 o, v3 d, float t_max, int* __restrict__ stack, int lane, unsigned& n_nodes, unsigned& n_tris, bool& opaque_hit) {
+template <int MODE, bool COUNT, int NC = 0, int NT = 0>
+HKD HitRec traverse(const DScene& sc, v3 o, v3 d, float t_max, int* __restrict__ stack, int lane, unsigned& n_nodes, unsigned& n_tris, bool& opaque_hit,
+                    const NodeCache& cache = NodeCache()) {
     HitRec best;
     best.t = t_max;
     best.prim = -1;
@@ -943,15 +946,22 @@ HKD HitRec traverse(const DScene& sc, v3 o, v3 d, float t_max, int* __restrict__
             if (__popcll(in_nodes) < __popcll(__ballot(cur < 0))) break;
             if (cur >= 0) {
                 if (COUNT) ++n_nodes;
-                node_step(sc, rs, best.t, stack, lane, cur, sp);
+                node_step<NC>(sc, rs, best.t, stack, lane, cur, sp, cache);
             }
         }
         if (cur < 0 && cur != DONE) {
             int ref = ~cur;
             int first = ref >> 3, count = (ref & 7) + 1;
             for (int i = 0; i < count; ++i) {
-                const float4* tp = sc.leaf_tris + 3 * (size_t)(first + i);
-                float4 T0 = tp[0], T1 = tp[1], T2 = tp[2];
+                float4 T0, T1, T2;
+                if (NT > 0 && first + i < cache.nt) {
+                    const hk_f4v a = cache.tri[first + i], b = cache.tri[NT + first + i], c = cache.tri[2 * NT + first + i];
+                    T0 = make_float4(a.x, a.y, a.z, a.w), T1 = make_float4(b.x, b.y, b.z, b.w), T2 = make_float4(c.x, c.y, c.z, c.w);
+                    asm volatile("" : "+v"(T0.x));   // keeps the arms apart (see NodeCache)
+                } else {
+                    const float4* tp = sc.leaf_tris + 3 * (size_t)(first + i);
+                    T0 = tp[0], T1 = tp[1], T2 = tp[2];
+                }
                 asm volatile("" ::"v"(T0.x), "v"(T0.y), "v"(T0.z), "v"(T0.w));   // issue the three loads together (see lane_ray_round)
                 if (COUNT) ++n_tris;
                 float t, u, v;

@@ -396,13 +396,54 @@ __global__ void __launch_bounds__(256) k_camera(DPathState st, DFrame fr, DTable
     }
 }
 
+// Copies the first min(NC, sc.n_nodes) nodes into the block's LDS (see NodeCache) and waits for the whole block.
+template <int NC, int BLOCK>
+HKD NodeCache node_cache_fill(const DScene& sc, float4* __restrict__ box, int2* __restrict__ child) {
+    NodeCache c;
+    c.box = (const lds_float4*)box, c.child = (const lds_int2*)child;
+    c.tri = nullptr, c.nt = 0;
+    c.nc = sc.n_nodes < NC ? sc.n_nodes : NC;
+    if (NC > 0) {
+        for (int i = threadIdx.x; i < c.nc; i += BLOCK) {
+            const float4* np = reinterpret_cast<const float4*>(sc.nodes) + 4 * (size_t)i;
+            const float4 D = np[3];
+            box[i] = np[0], box[NC + i] = np[1], box[2 * NC + i] = np[2];
+            child[i] = make_int2(__float_as_int(D.x), __float_as_int(D.y));
+        }
+        __syncthreads();
+    }
+    return c;
+}
+
+// The scenes of the media kernels are often a handful of boxes (the cloud config: 24 triangles, 7 nodes): k_trace keeps the first NC
+// nodes AND the first NT leaf triangles in LDS, so such a cast touches no global memory at all (cloud trace 87 -> 65 ms).  Not the
+// shadow walk: the same cache inside k_shadow_walk cost it 28 % (its registers are full: 168 at 3 waves per SIMD).
+#define HK_MEDIA_NC 64
+#define HK_MEDIA_NT 80    // 32 KB of stacks + 7.25 KB of cache: 4 blocks per CU, as without it
+template <int NC, int NT, int BLOCK>
+HKD NodeCache scene_cache_fill(const DScene& sc, float4* __restrict__ box, int2* __restrict__ child, float4* __restrict__ tri) {
+    NodeCache c = node_cache_fill<NC, BLOCK>(sc, box, child);
+    c.tri = (const lds_float4*)tri;
+    c.nt = sc.n_tris < NT ? sc.n_tris : NT;
+    for (int i = threadIdx.x; i < c.nt; i += BLOCK) {
+        const float4* tp = sc.leaf_tris + 3 * (size_t)i;
+        tri[i] = tp[0], tri[NT + i] = tp[1], tri[2 * NT + i] = tp[2];
+    }
+    __syncthreads();
+    return c;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // K3: closest-hit traversal + classification (intersection.jl:188-269).
 // ---------------------------------------------------------------------------------------------------
 template <bool COUNT>
 __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace(DPathState st, DScene sc, DTables T, DFrame fr, int depth, DStats* stats) {
     __shared__ int lds_stack[(HK_TRACE_BLOCK / 64) * HK_LDS_STACK * 64];
+    __shared__ float4 lds_box[3 * HK_MEDIA_NC];
+    __shared__ int2 lds_child[HK_MEDIA_NC];
+    __shared__ float4 lds_tri[3 * HK_MEDIA_NT];
     int* stack = lds_stack + (threadIdx.x >> 6) * (HK_LDS_STACK * 64);
+    const NodeCache cache = scene_cache_fill<HK_MEDIA_NC, HK_MEDIA_NT, HK_TRACE_BLOCK>(sc, lds_box, lds_child, lds_tri);
     const int lane = lane_id();
     unsigned n_nodes = 0, n_tris = 0, n_casts = 0, n_hits = 0;
     HK_FOR_EACH_WAVE_SEGMENT(gw, st, ticket_ptr(st, depth, TK_TRACE), depth, Q_RAY) {
@@ -427,7 +468,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace(DPathState st, DScene 
             float4 O = g.ray_o[slot], D = g.ray_d[slot];
             bool dummy;
             ++n_casts;
-            HitRec h = traverse<0, COUNT>(sc, mk3(O.x, O.y, O.z), mk3(D.x, D.y, D.z), O.w, stack, lane, n_nodes, n_tris, dummy);
+            HitRec h = traverse<0, COUNT, HK_MEDIA_NC, HK_MEDIA_NT>(sc, mk3(O.x, O.y, O.z), mk3(D.x, D.y, D.z), O.w, stack, lane, n_nodes, n_tris, dummy, cache);
             if (h.prim >= 0) {
                 ++n_hits;
                 st.hit[slot] = make_float4(h.t, __int_as_float(h.prim), h.u, h.v);
@@ -445,7 +486,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace(DPathState st, DScene 
             for (int it = 0; it < 16; ++it) {
                 bool dummy;
                 ++n_casts;
-                HitRec h = traverse<0, COUNT>(sc, ro, rd, it == 0 ? tmax : INF_F, stack, lane, n_nodes, n_tris, dummy);
+                HitRec h = traverse<0, COUNT, HK_MEDIA_NC, HK_MEDIA_NT>(sc, ro, rd, it == 0 ? tmax : INF_F, stack, lane, n_nodes, n_tris, dummy, cache);
                 if (h.prim < 0) {
                     kind = -2;
                     break;
@@ -626,24 +667,6 @@ HKD void lane_ray_round(LaneRay& r, bool active, const DScene& sc, int* __restri
 }
 
 enum { LR_EMPTY = 0, LR_ACTIVE = 1 };
-
-// Copies the first min(NC, sc.n_nodes) nodes into the block's LDS (see NodeCache) and waits for the whole block.
-template <int NC, int BLOCK>
-HKD NodeCache node_cache_fill(const DScene& sc, float4* __restrict__ box, int2* __restrict__ child) {
-    NodeCache c;
-    c.box = (const lds_float4*)box, c.child = (const lds_int2*)child;
-    c.nc = sc.n_nodes < NC ? sc.n_nodes : NC;
-    if (NC > 0) {
-        for (int i = threadIdx.x; i < c.nc; i += BLOCK) {
-            const float4* np = reinterpret_cast<const float4*>(sc.nodes) + 4 * (size_t)i;
-            const float4 D = np[3];
-            box[i] = np[0], box[NC + i] = np[1], box[2 * NC + i] = np[2];
-            child[i] = make_int2(__float_as_int(D.x), __float_as_int(D.y));
-        }
-        __syncthreads();
-    }
-    return c;
-}
 
 // STACK: LDS stack entries per lane.  The stack holds at most one entry per inner level, so a BVH of depth <= 16 (every scene
 // but the 10^6-triangle one) runs with half the LDS: 16 KB per block instead of 32, and LDS stops limiting residency.

@@ -1,27 +1,30 @@
 #!/usr/bin/env python3
-"""bench.py — Mrays/s of the VolPath hot path on BASELINE.json configs[1]:
-Cornell box (diffuse + area light), 800x800, depth 8, 256 spp, 1 x MI355X.
+"""bench.py — Mrays/s and seconds per converged frame of the VolPath hot path on BASELINE.json configs[1]:
+Cornell box (diffuse + area light), 800x800, depth 8, 256 spp, N x MI355X.
 
-A "step" is one wavefront pass of the hot path over one batch of synthetic input: SPP_PER_STEP (=256)
-samples of every pixel of the 800x800 frame carried through the 8-bounce loop (164 M paths in flight, ~72 GB
-of path state of the 288 GB of HBM: the deeper bounces of a pass only keep the chip busy when the pass starts
-with hundreds of paths per resident lane — 5.9 G rays/s at 32 spp per pass, 6.3 at 64, 6.45 at 128, 6.56 at
-256).  The default single step is exactly the 256-spp frame, so `seconds_to_256spp` is the timed region itself
-(--spp-per-step changes the batch; --steps defaults to 256 / spp-per-step).
+A "step" is ONE FRAME the way the reference's `integrator(scene, film, camera)` renders one: clear the film, FULL_SPP (= 256)
+samples of every pixel carried through the 8-bounce loop, and — on N > 1 GPUs — the ONE sum-reduce of the film accumulators onto
+rank 0 that finishes the frame.  On one GPU the frame is one wavefront pass (164 M paths in flight, ~72 GB of path state of the
+288 GB of HBM: the deeper bounces of a pass only keep the chip busy when the pass starts with hundreds of paths per resident lane —
+5.9 G rays/s at 32 spp per pass, 6.3 at 64, 6.45 at 128, 6.56 at 256).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1 without a launcher: starts the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-N > 1: one process per GPU; rank g renders sample indices g+1, g+1+N, ... (weak scaling: K steps each), then
-ONE RCCL sum-reduce of the film accumulators to rank 0 inside the timed region — the library's own hk_film_reduce
-(ncclReduce on the render stream; torch.distributed only carries the 128-byte communicator id and the final
-statistics, and its reduce serves as the untimed cross-check of the result).  value = rays of all ranks /
-max-over-ranks time.  The scene, BVH and film live in HBM before the timed region starts.
+N > 1: one process per GPU; rank g renders the sample indices g+1, g+1+N, ... of ALL pixels (ZSobol is a pure function of
+(pixel, sample index, dimension), so the union over ranks is exactly the one-GPU sample set).
+  --scaling strong (default: BASELINE.json's metric is the wall-clock to ONE 256-spp frame at 1/2/4/8 GPUs): the frame's 256
+      samples are split over the ranks, 256 / N each; `seconds_per_frame` is the measured time of a frame INCLUDING its reduce.
+  --scaling weak: every rank renders 256 spp (N x 256 in the reduced film).
+The reduce is the library's own hk_film_reduce (ncclReduce over xGMI on the render stream; torch.distributed only carries the
+128-byte communicator id and the final statistics, and its own reduce is the untimed cross-check of the result).
+value = rays of all ranks / max-over-ranks time of the K steps.  Scene, BVH and sampler tables live in HBM before the timed region
+starts; `cold_frame_seconds` is a frame that has to rebuild the sample-bit table first (a one-shot render of a new sample range).
 """
 import argparse
-import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -30,38 +33,142 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-W, H, DEPTH, SPP_PER_STEP, FULL_SPP = 800, 800, 8, 256, 256
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-S_NODE, B_TRI, B_HIT, B_RAY_IN, B_HIT_OUT = 64, 36, 96, 32, 16   # SURVEY.md §8(d) algorithmic bytes per cast
-S_STATE = 104                  # compact path state, read + written once per path vertex
+COMM_TIMEOUT_S = 180.0         # the collective communicator bring-up may not hang the run
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None, help="frames in the timed region (default 1; Cornell: 20)")
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="strong: the frame's samples are split over the ranks (the metric: wall-clock to one 256-spp frame); weak: every rank renders the full sample count")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-spp", type=int, default=0, help="samples per pixel of the CPU baseline sample (0 = about 15 s of work)")
+    ap.add_argument("--spp", type=int, default=None, help="samples per pixel of one frame (default: the config's — 256, many-light 512)")
+    ap.add_argument("--spp-per-pass", type=int, default=0, help="samples of every pixel in flight per wavefront pass (0 = the library's choice: up to 256)")
+    ap.add_argument("--config", default="cornell", choices=["cornell", "cloud", "sky", "manylight"],
+                    help="cornell = BASELINE configs[1] (the bench line); sky = configs[2] (glass sphere + gold slab + Hosek-Wilkie sun-sky, depth 12); "
+                         "cloud = configs[3] (BOMEX stand-in: worley-fbm NanoVDB cloud field, 1024x1024, depth 32); manylight = configs[4] stand-in "
+                         "(10^6 triangles, 5*10^4 area lights, 1024x1024, depth 8, 512 spp)")
+    return ap.parse_args(argv)
+
+
+def launch_ranks(args):
+    """`bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (this parent never touches HIP or
+    torch.cuda, and no child is ever re-exec'ed), wait for all of them and forward rank 0's JSON line.  A failing rank fails the run."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = b""
+    failed = None
+    deadline = time.time() + float(os.environ.get("HK_BENCH_LAUNCH_TIMEOUT", "3000"))
+    pending = set(range(args.gpus))
+    while pending and failed is None:
+        for r in sorted(pending):
+            p = procs[r]
+            if r == 0:
+                try:
+                    o, _ = p.communicate(timeout=0.2)
+                    out0 += o or b""
+                except subprocess.TimeoutExpired:
+                    continue
+            elif p.poll() is None:
+                continue
+            pending.discard(r)
+            if p.returncode != 0:
+                failed = (r, p.returncode)
+                break
+        if time.time() > deadline:
+            failed = (-1, "timeout")
+        time.sleep(0.05)
+    if failed is not None:
+        for p in procs:            # exactly the processes started above
+            if p.poll() is None:
+                p.kill()
+        sys.stderr.write("bench.py: rank %s failed (%s)\n" % failed)
+        sys.stdout.write(out0.decode(errors="replace"))
+        sys.exit(1)
+    sys.stdout.write(out0.decode(errors="replace"))
+    sys.stdout.flush()
+    sys.exit(0)
+
+
+def call_with_timeout(fn, seconds, what):
+    """Run a (collective) bring-up call in a thread: a rank that never returns must end the run, not hang it."""
+    import threading
+    box = {}
+
+    def run():
+        try:
+            box["value"] = fn()
+        except BaseException as e:          # noqa: BLE001
+            box["error"] = e
+    t = threading.Thread(target=run, daemon=True)
+    t.start()
+    t.join(seconds)
+    if t.is_alive():
+        sys.stderr.write("bench.py: %s did not return within %.0f s\n" % (what, seconds))
+        sys.stderr.flush()
+        os._exit(3)
+    if "error" in box:
+        raise box["error"]
+    return box.get("value")
+
+
+def build_workload(config, scenes):
+    """-> scene, film, camera, W, H, depth, spp per frame, workload text (BASELINE.json configs / SURVEY 8d)."""
+    if config == "cloud":
+        W, H, depth, spp = 1024, 1024, 32, 256
+        mres = int(os.environ.get("HK_CLOUD_MAJORANT", "64"))
+        scene, film, cam = scenes.bomex_scene(W, H, res=(256, 256, 128), fill=0.05, max_extinction=620.0, majorant_res=(mres, mres, mres))
+        workload = ("BOMEX stand-in (the LES data is not in the reference tree): generate_cloud_density's worley-fbm recipe (src/random.jl:149-206, "
+                    "pure noise) on 256x256x128, thresholded to 5 % fill, max extinction 620, NanoVDB + %d^3 majorant grid, sigma_a 0 / sigma_s 1 / g 0.877, "
+                    "scene of examples/bomex_cloud_example.jl:53-184 (index-matched glass cube 1.2, floor + two walls, Ambient + Directional), 1024x1024, "
+                    "VolPath depth 32" % mres)
+    elif config == "sky":
+        W, H, depth, spp = 800, 800, 12, 256
+        scene, film, cam = scenes.sky_scene(W, H, env_res=512)
+        workload = "README scene: glass sphere + Gold(roughness=0.01) slab + Hosek-Wilkie sun-sky (512^2 equal-area env map + SunLight), 800x800, VolPath depth 12"
+    elif config == "manylight":
+        W, H, depth, spp = 1024, 1024, 8, 512
+        scene, film, cam = scenes.many_light_scene(W, H)
+        workload = ("synthetic many-light barrel standing in for the absent CMS detector asset (10^6 triangles, ~5*10^4 area lights in the light BVH), "
+                    "1024x1024, VolPath depth 8")
+    else:
+        W, H, depth, spp = 800, 800, 8, 256
+        scene, film, cam = scenes.cornell_box(W, H, light="area")
+        workload = "Cornell box (diffuse + area light), 800x800, VolPath depth 8"
+    return scene, film, cam, W, H, depth, spp, workload
 
 
 def main():
-    global SPP_PER_STEP
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="default: the full 256-spp frame (256 / spp-per-step)")
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-spp", type=int, default=0, help="samples per pixel of the CPU baseline sample (0 = about 15 s of work)")
-    ap.add_argument("--spp-per-step", type=int, default=SPP_PER_STEP, help="samples of every pixel in flight per wavefront pass (one step)")
-    ap.add_argument("--config", default="cornell", choices=["cornell", "cloud", "sky", "manylight"],
-                    help="cornell = BASELINE configs[1] (the bench line); sky = configs[2] stand-in (glass sphere + gold slab + env map + sun, depth 12); "
-                         "cloud = configs[3] stand-in (synthetic NanoVDB cloud, 1024x1024, depth 32); manylight = configs[4] stand-in (10^6 triangles, "
-                         "5*10^4 area lights, 1024x1024, depth 8)")
-    args = ap.parse_args()
+    args = parse_args()
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and world_env is None:
+        launch_ranks(args)          # never returns
 
-    import numpy as np
+    import numpy as np              # noqa: F401
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(world_env or "1")
     # HK_BENCH_SINGLE_DEVICE=1 (test hook): every rank shares cuda:0 and the process group is gloo, so the N > 1 code path can be
     # exercised on a 1-GPU box.  The driver's runs never set it: one process per GPU over RCCL ("nccl").
     single_device = os.environ.get("HK_BENCH_SINGLE_DEVICE") == "1"
-    if args.gpus > 1 or world > 1:
+    if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("gloo" if single_device else "nccl", rank=rank, world_size=world)
@@ -73,43 +180,24 @@ def main():
     from hikari_jl_amd import distributed as hd
     from hikari_jl_amd import scenes
 
-    global W, H, DEPTH
-    SPP_PER_STEP = args.spp_per_step
+    scene, film, cam, W, H, DEPTH, FULL_SPP, workload = build_workload(args.config, scenes)
+    if args.spp:
+        FULL_SPP = args.spp
     if args.steps is None:
-        args.steps = max(FULL_SPP // SPP_PER_STEP, 1)
-    if args.config == "cloud":
-        W, H, DEPTH = 1024, 1024, 32
-        mres = int(os.environ.get("HK_CLOUD_MAJORANT", "32"))
-        scene, film, cam = scenes.cloud_scene(W, H, "nanovdb", res=(256, 256, 128), sigma_scale=620.0 / 4, majorant_res=(mres, mres, mres))
-        workload = "synthetic BOMEX-like NanoVDB cloud (256x256x128, delta tracking), 1024x1024, VolPath depth 32, %d spp per step" % SPP_PER_STEP
-    elif args.config == "sky":
-        W, H, DEPTH = 800, 800, 12
-        scene, film, cam = scenes.sky_scene(W, H, env_res=512)
-        workload = "README scene: glass sphere + Gold(roughness=0.01) slab + Hosek-Wilkie sun-sky (512^2 equal-area env map + SunLight), 800x800, VolPath depth 12, %d spp per step" % SPP_PER_STEP
-    elif args.config == "manylight":
-        W, H, DEPTH = 1024, 1024, 8
-        scene, film, cam = scenes.many_light_scene(W, H)
-        workload = "synthetic many-light barrel (10^6 triangles, ~5*10^4 area lights in the light BVH), 1024x1024, VolPath depth 8, %d spp per step" % SPP_PER_STEP
-    else:
-        scene, film, cam = scenes.cornell_box(W, H, light="area")
-        workload = "Cornell box (diffuse + area light), 800x800, VolPath depth 8, %d spp per step" % SPP_PER_STEP
+        args.steps = 20 if (args.config == "cornell" and FULL_SPP <= 256) else 1
+    strong = args.scaling == "strong"
+    # this rank's share of a frame: sample indices first, first + stride, ... (count of them)
+    first, my_spp, stride = hd.shard_samples(FULL_SPP, rank, world) if strong else (rank + 1, FULL_SPP, world)
+    frame_spp = FULL_SPP if strong else FULL_SPP * world
+    if single_device and args.spp_per_pass == 0:
+        args.spp_per_pass = max(1, min(my_spp, 64))     # several contexts share one device: bounded path state per rank
     n_pix = W * H
-    # film accumulators live in a torch tensor so torch.distributed (RCCL) can reduce them in place
+    # film accumulators live in a torch tensor so torch.distributed (RCCL) can reduce them in place (the cross-check)
     accum = torch.zeros(4 * n_pix, dtype=torch.float32, device="cuda")
     # `samples` only sizes the ZSobol index (log2 of max(samples, 4096)): cover every sample index this run touches
-    vp = hk.VolPath(max_depth=DEPTH, samples=max(FULL_SPP, SPP_PER_STEP * world), samples_per_pass=SPP_PER_STEP,
-                    device=local_rank)
+    vp = hk.VolPath(max_depth=DEPTH, samples=max(FULL_SPP * (1 if strong else world), 256), samples_per_pass=args.spp_per_pass, device=local_rank)
     vp.use_external_accumulators(accum.data_ptr())
     vp._ensure(film)
-    L = hk._lib.lib()
-
-    def run_steps(first_step, n_steps, readback=False):
-        # A step is one frame, the way the reference's `integrator(scene, film, camera)` renders one: clear the film, then
-        # SPP_PER_STEP samples per pixel — on this rank the sample indices (rank+1) + world*j, j < SPP_PER_STEP.  Every step
-        # renders the same sample indices (a frame loop), so the sampler tables built by the first frame serve the later ones.
-        for _ in range(n_steps):
-            vp.clear()
-            vp.render_samples(scene, film, cam, SPP_PER_STEP, stride=world, first=rank + 1, readback=readback)
 
     def barrier():
         if world > 1:
@@ -121,9 +209,9 @@ def main():
     comm = None
     comm_note = None
     if world > 1 and not single_device:
-        # The builder's box has one GPU: this path has only ever run as a 1-rank communicator.  If the in-library communicator cannot
-        # be set up on every rank (or its first reduce fails, below), ALL ranks fall back to torch.distributed's reduce — the same
-        # RCCL ring on the same buffer — and the line says so, rather than the scaling run dying.
+        # If the in-library communicator cannot be set up on every rank (or its first reduce fails, below), ALL ranks fall back to
+        # torch.distributed's reduce — the same RCCL ring on the same buffer — and the line says so.  The bring-up calls are
+        # collective: each runs under a timeout, and a rank that does not come back ends the run with a non-zero exit.
         ok = 1
         try:
             uid = [hk.Comm.unique_id() if rank == 0 else None]
@@ -134,7 +222,7 @@ def main():
             ok = 0
         if ok:
             try:
-                comm = hk.Comm.rank(vp._ctx, uid[0], rank, world)
+                comm = call_with_timeout(lambda: hk.Comm.rank(vp._ctx, uid[0], rank, world), COMM_TIMEOUT_S, "hk_comm_create_rank")
             except Exception as e:       # noqa: BLE001
                 ok, comm_note = 0, "hk_comm_create_rank: %s" % e
         flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
@@ -144,14 +232,27 @@ def main():
             comm_note = comm_note or "another rank could not create its communicator"
 
     def reduce_films():
+        if world == 1:
+            return
         if comm is not None:
             comm.reduce_films([vp], root=0)
-        else:                                         # HK_BENCH_SINGLE_DEVICE test hook: every rank shares cuda:0, gloo stages through the host
+        else:                                         # fallback / HK_BENCH_SINGLE_DEVICE test hook (gloo stages through the host)
+            vp.sync()
             hd.reduce_film(accum, root=0)
 
-    # ---- warmup (untimed): also uploads the scene / builds the BVH ----
+    def run_frames(n_frames, first_idx=first, reduce=True):
+        # One frame: clear the film, this rank's samples of every pixel, the reduce onto rank 0.  Every frame renders the same
+        # sample indices (a frame loop), so the sampler tables built by the first frame serve the later ones.
+        for _ in range(n_frames):
+            vp.clear()
+            if my_spp > 0:
+                vp.render_samples(scene, film, cam, my_spp, stride=stride, first=first_idx, readback=False)
+            if reduce:
+                reduce_films()
+
+    # ---- warmup (untimed): also uploads the scene / builds the BVH / allocates the path state ----
     t0 = time.time()
-    run_steps(0, max(args.warmup, 1) if args.warmup > 0 else 0)
+    run_frames(max(args.warmup, 1), reduce=False)
     barrier()
     setup_s = time.time() - t0
     reduce_check = None
@@ -162,8 +263,7 @@ def main():
         if comm is not None:
             ok = 1
             try:
-                reduce_films()
-                vp.sync()
+                call_with_timeout(lambda: (reduce_films(), vp.sync()), COMM_TIMEOUT_S, "the first hk_film_reduce")
             except Exception as e:       # noqa: BLE001
                 ok, comm_note = 0, "hk_film_reduce: %s" % e
             flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
@@ -182,70 +282,77 @@ def main():
         barrier()
         if rank == 0:
             reduce_check = bool(torch.allclose(mine, accum, rtol=1e-6, atol=1e-7))
+        del keep, mine
+    # ---- a cold frame (untimed for `value`): the sample-bit table of a NEW sample range is built inside it, as a one-shot
+    #      `integrator(scene, film, camera)` call pays it; path state and scene stay resident ----
+    shift = stride * ((FULL_SPP + stride - 1) // stride + 16)
+    barrier()
+    t0 = time.perf_counter()
+    run_frames(1, first_idx=first + shift)
+    barrier()
+    cold_s = time.perf_counter() - t0
+    run_frames(1, reduce=False)              # back to the bench's sample range (rebuilds its table, untimed)
     accum.zero_()
     vp.enable_counters(count_nodes=False, time_kernels=False)
     vp.reset_stats()
     barrier()
 
-    # ---- timed region: EXACTLY K steps + (N>1) the film reduce ----
+    # ---- timed region: EXACTLY K steps (frames), each with its reduce ----
     t0 = time.perf_counter()
-    run_steps(0, args.steps)
-    if world > 1:
-        reduce_films()
+    run_frames(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     st = vp.stats()
     rays_local = int(st.rays_closest) + int(st.rays_shadow)
     stat_dev = "cpu" if single_device else "cuda"
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=stat_dev)
+    tmax = torch.tensor([elapsed, cold_s], dtype=torch.float64, device=stat_dev)
     rays = torch.tensor([float(rays_local)], dtype=torch.float64, device=stat_dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
-    elapsed_max = float(tmax.item())
+    elapsed_max, cold_max = float(tmax[0].item()), float(tmax[1].item())
     total_rays = float(rays.item())
 
     result = None
     if rank == 0:
-        # ---- per-kernel-class times: an untimed replay of the same steps with HIP events around every launch, on the launch stream.
-        #      With the events on, the library keeps everything on one stream (the timed region above runs the shadow rays of bounce d
-        #      beside the traversal of bounce d + 1 on a second stream), so the class times add up to slightly MORE than the timed frame ----
+        # ---- per-kernel-class times: an untimed replay of the same frames (this rank's share) with HIP events around every launch,
+        #      on the launch stream.  With the events on, the library keeps everything on one stream (the timed region above runs the
+        #      shadow rays of bounce d beside the traversal of bounce d + 1 on a second stream), so the class times add up to slightly
+        #      MORE than the timed frame ----
         accum_timed = accum.clone()
         vp.enable_counters(count_nodes=False, time_kernels=True)
         vp.reset_stats()
-        run_steps(0, args.steps)
+        run_frames(args.steps, reduce=False)
         vp.sync()
         st = vp.stats()
-        accum.copy_(accum_timed)
-        # ---- roofline of the dominant kernel: counts from an instrumented (untimed) replay of the same steps ----
         timed = dict(trace=st.seconds_trace, shadow=st.seconds_shadow, shade=st.seconds_shade, media=st.seconds_media, other=st.seconds_other)
-        launches = dict(trace=int(st.trace_launches), shadow=int(st.shadow_launches), shade=int(st.shade_launches))
-        casts = dict(trace=int(st.rays_closest), shadow=int(st.rays_shadow))
-        vertices = int(st.path_vertices)
-        accum_keep = accum.clone()
+        launches = dict(trace=int(st.trace_launches), shadow=int(st.shadow_launches), shade=int(st.shade_launches), media=int(st.media_launches))
+        # ---- counts from an instrumented (untimed) replay of the same frames ----
         vp.enable_counters(count_nodes=True, time_kernels=False)
         vp.reset_stats()
-        run_steps(0, args.steps)
+        run_frames(args.steps, reduce=False)
         vp.sync()
         sc = vp.stats()
-        accum.copy_(accum_keep)
+        accum.copy_(accum_timed)
+        del accum_timed
         vp.enable_counters(False, False)
         # ---- per-kernel-class ceilings: ALGORITHMIC bytes from the counted replay (hk_stats.bytes_algorithmic_*) over the
-        #      HIP-event time of that class's launches in the timed region; PMC traffic / L2 hit rate / VALU issue / lane utilisation
-        #      from the rocprofv3 passes committed under profiles/ for the same workload (tools/profile_round.sh) ----
-        alg = dict(trace=int(sc.bytes_algorithmic_trace), shadow=int(sc.bytes_algorithmic_shadow), shade=int(sc.bytes_algorithmic_shade))
-        kname = {"trace": "k_trace", "shadow": "k_shadow", "shade": "k_shade"}
+        #      HIP-event time of that class's launches; PMC traffic / L2 hit rate / VALU issue / lane utilisation from the rocprofv3
+        #      passes committed under profiles/ for the same workload (tools/profile_round.sh) ----
+        alg = dict(trace=int(sc.bytes_algorithmic_trace), shadow=int(sc.bytes_algorithmic_shadow), shade=int(sc.bytes_algorithmic_shade),
+                   media=int(sc.bytes_algorithmic_media))
+        kname = {"trace": "k_trace", "shadow": "k_shadow", "shade": "k_shade", "media": "k_track+k_scatter"}
 
         def committed(stem):
             path = os.path.join(ROOT, "profiles", "%s_%s.json" % (stem, args.config))
-            try:
-                return json.load(open(path)) if SPP_PER_STEP == 256 else {}     # the PMC passes were taken at the default 256 spp per step
+            try:    # the PMC passes were taken on one GPU at the config's default frame
+                return json.load(open(path)) if (world == 1 and not args.spp and not args.spp_per_pass) else {}
             except (OSError, ValueError):
                 return {}
 
         pmc, util = committed("pmc_traffic"), committed("utilisation")
         rooflines = []
-        for cls in ("trace", "shadow", "shade"):
+        for cls in ("trace", "shadow", "shade", "media"):
             n_launch = max(launches[cls], 1)
             avg_s = timed[cls] / n_launch
             if timed[cls] <= 0:
@@ -254,15 +361,19 @@ def main():
             e = {"kernel": kname[cls], "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                  "algorithmic_bytes_per_launch": int(alg[cls] / n_launch), "avg_launch_ms": round(avg_s * 1e3, 4), "launches": n_launch,
                  "seconds": round(timed[cls], 4)}
-            t = pmc.get(kname[cls], {})
-            e["traffic"] = t.get("hbm_bytes_per_launch")
-            if e["traffic"]:
+            names = ["k_track", "k_scatter"] if cls == "media" else [kname[cls]]
+            tr = [pmc.get(k, {}) for k in names]
+            if all("hbm_bytes_per_launch" in t for t in tr):
                 # the PMC launches average over the same depths as the bench's (whole passes): traffic per launch is comparable
+                e["traffic"] = sum(t["hbm_bytes_per_launch"] * t.get("launches", 1) for t in tr) / max(sum(t.get("launches", 1) for t in tr), 1)
                 e["traffic_over_algorithmic"] = round(e["traffic"] / max(alg[cls] / n_launch, 1), 3)
                 e["hbm_frac_by_traffic"] = round(e["traffic"] / avg_s / 1e9 / HBM_PEAK_GBS, 4)
+            else:
+                e["traffic"] = None
+            t = tr[0]
             if "l2_hit_rate" in t:
                 e["l2_hit_rate"] = t["l2_hit_rate"]
-            u = util.get(kname[cls], {})
+            u = util.get(names[0], {})
             for k in ("valu_issue_frac", "lane_util", "wait_frac"):
                 if k in u:
                     e[k] = u[k]
@@ -274,14 +385,21 @@ def main():
                 e["binding"] = "unprofiled on this workload"
             elif hb >= 0.5:
                 e["binding"] = "HBM traffic (%.0f %% of the 8 TB/s peak, %.0f %% of the device-copy rate); VALU issue %.0f %% at 2 cycles per instruction" % (100 * hb, 100 * hb * HBM_PEAK_GBS / 5200.0, 100 * vi)
+            elif cls == "media" or (cls == "shadow" and int(sc.shadow_collisions) > 0):
+                e["binding"] = "latency of dependent loads (majorant cell -> tree / brick -> 8 taps): VALU issue %.0f %% at 2 cycles per instruction with %.0f %% of the lanes active; HBM traffic %.0f %% of peak" % (100 * vi, 100 * e.get("lane_util", 0), 100 * hb)
             else:
                 e["binding"] = "instruction issue and latency: VALU issue %.0f %% of all cycles at 2 cycles per instruction (this mix costs ~4: profiles/r02_valu_rate.txt) with %.0f %% of the lanes active; HBM traffic %.0f %% of peak" % (100 * vi, 100 * e.get("lane_util", 0), 100 * hb)
             rooflines.append(e)
-        # BVH nodes come from L1 / L2, not HBM: the SURVEY 8(d) byte formula is an upper bound of traversal's HBM need, not a ceiling
+        # BVH nodes come from LDS / L1 / L2, not HBM: the SURVEY 8(d) byte formula is an upper bound of traversal's HBM need, not a ceiling
         for e in rooflines:
             if e["kernel"] in ("k_trace", "k_shadow"):
                 e["note"] = "algorithmic bytes count every BVH node / triangle visit at full size; measured HBM traffic is the `traffic` field"
-        dom = max(("trace", "shadow", "shade"), key=lambda k: timed[k])
+            if e["kernel"] == "k_track+k_scatter":
+                e["units"] = {"collisions": int(sc.track_collisions), "dda_steps": int(sc.track_dda_steps), "scatter_vertices": int(sc.scatter_vertices),
+                              "bytes_per_collision": 84, "bytes_per_dda_step": 4}
+            if e["kernel"] == "k_shadow" and int(sc.shadow_collisions) > 0:
+                e["units"] = {"collisions": int(sc.shadow_collisions), "dda_steps": int(sc.shadow_dda_steps), "casts": int(sc.rays_shadow)}
+        dom = max((k for k in ("trace", "shadow", "shade", "media") if timed[k] > 0), key=lambda k: timed[k])
         # measured HBM ceiling of this box beside the nominal peak: device-to-device copy, read + write bytes
         a = torch.empty(1 << 28, dtype=torch.float32, device="cuda")    # 1 GiB
         b = torch.empty_like(a)
@@ -303,7 +421,7 @@ def main():
 
         # ---- CPU baseline: the oracle (a port, NOT Julia / KernelAbstractions.CPU()) on a bounded sample ----
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             import oracle
             oracle.build()
             oracle.set_threads(oracle.available_cores())     # affinity mask and cgroup quota, not the host's core count
@@ -319,26 +437,35 @@ def main():
             crays = int(ost.rays_closest) + int(ost.rays_shadow)
             cpu = {"value": round(crays / cdt / 1e6, 4), "unit": "Mrays/s", "cores": oracle.max_threads(), "kind": "port",
                    "sample": "%d spp of the same %dx%d depth-%d frame (%.1f s); CPU restatement of Hikari VolPath, not Julia" % (args.cpu_spp, W, H, DEPTH, cdt),
-                   "seconds_to_256spp_extrapolated": round(cdt * FULL_SPP / args.cpu_spp, 1)}
+                   "seconds_per_frame_extrapolated": round(cdt * FULL_SPP / args.cpu_spp, 1)}
             osc.close()
 
         value = total_rays / elapsed_max / 1e6
-        spp_done = SPP_PER_STEP * args.steps * world
+        per_frame = elapsed_max / max(args.steps, 1)
+        if comm is not None or world == 1:
+            par = "sample-index sharding x%d + in-library RCCL film reduce (hk_film_reduce)" % world
+        elif single_device:
+            par = "sample-index sharding x%d + gloo film reduce on one device (HK_BENCH_SINGLE_DEVICE test hook)" % world
+        else:
+            par = "sample-index sharding x%d + torch.distributed film reduce (in-library communicator unavailable: %s)" % (world, comm_note)
         result = {
             "metric": "Mrays/s", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed_max / max(args.steps, 1) * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(per_frame * 1e3, 4), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": workload,
-                       "resolution": [W, H], "max_depth": DEPTH, "spp_per_step": SPP_PER_STEP, "spp_rendered": spp_done,
-                       "triangles": int(scene.desc.n_triangles), "lights": int(scene.desc.n_lights), "parallelism": ("sample-index sharding x%d + in-library RCCL film reduce (hk_film_reduce)" % world) if (comm is not None or world == 1) else ("sample-index sharding x%d + %s" % (world, "gloo film reduce on one device (HK_BENCH_SINGLE_DEVICE test hook)" if single_device else "torch.distributed film reduce (in-library communicator unavailable: %s)" % comm_note)),
+            "config": {"workload": "%s, %d spp per frame (one step = one frame%s)" % (workload, frame_spp, "" if world == 1 else ", %d spp on each of %d GPUs" % (my_spp, world)),
+                       "resolution": [W, H], "max_depth": DEPTH, "spp_per_frame": frame_spp, "spp_per_rank": my_spp, "spp_per_pass": args.spp_per_pass or min(my_spp, 256),
+                       "triangles": int(scene.desc.n_triangles), "lights": int(scene.desc.n_lights), "parallelism": par,
                        "reduce_matches_torch_distributed": reduce_check},
             "seconds_timed": round(elapsed_max, 4),
-            "seconds_to_256spp": round(elapsed_max * FULL_SPP / spp_done * world, 4) if world == 1 else round(elapsed_max * (FULL_SPP / spp_done), 4),
+            "seconds_per_frame": round(per_frame, 4),
+            "seconds_to_256spp": round(per_frame * 256.0 / frame_spp, 4),
+            "cold_frame_seconds": round(cold_max, 4),
             "rays": {"closest": int(st.rays_closest), "shadow": int(st.rays_shadow), "total_all_ranks": int(total_rays), "medium_collisions": int(st.medium_collisions)},
             "setup_seconds": round(setup_s, 3),
             "roofline": roofline, "rooflines": rooflines, "cpu_baseline": cpu,
         }
         print(json.dumps(result))
+        sys.stdout.flush()
     if comm is not None:
         comm.close()
     if world > 1:

@@ -107,7 +107,8 @@ struct hk_ctx {
     // timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_events;   // class 0
     std::vector<std::pair<hipEvent_t, hipEvent_t>> class_events[5];  // 1 shadow, 2 shade, 3 other, 4 media
-    uint64_t shadow_launches = 0, shade_launches = 0;
+    uint64_t shadow_launches = 0, shade_launches = 0, media_launches = 0;
+    int nvdb_collisions = 0;              // a scene with a NanoVDB medium was rendered since the last hk_stats_reset (84 B per collision instead of 36)
     std::vector<hipEvent_t> event_pool;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool have_span = false;
@@ -1335,6 +1336,7 @@ extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_
             }
         }
     }
+    if (sc->d.media_mask & (1 << HK_MEDIUM_NANOVDB)) c->nvdb_collisions = 1;
     DCamera dc = make_camera(*cam);
     DStats* dstats = c->stats.as<DStats>();
     const int trace_blocks = c->n_cu, shade_blocks = c->n_cu, light_blocks = c->n_cu;  // launchers size the grid from residency
@@ -1422,6 +1424,7 @@ extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_
             int first_kind = 1;
             if (sc->d.n_media > 0) {
                 timed(4, [&] { hk::launch_medium(s, c->n_cu, I->st, sc->d, c->tables, fr, sob, depth, dstats); });
+                c->media_launches += 2;   // k_track + k_scatter
                 first_kind = 0;
             }
             if (sc->d.has_escape_lights)
@@ -1504,7 +1507,8 @@ extern "C" int32_t hk_stats_reset(hk_ctx* c) {
         v.clear();
     }
     c->seconds_trace = c->seconds_total = 0.0;
-    c->trace_launches = c->shadow_launches = c->shade_launches = 0;
+    c->trace_launches = c->shadow_launches = c->shade_launches = c->media_launches = 0;
+    c->nvdb_collisions = 0;
     c->have_span = false;
     return HK_OK;
 }
@@ -1527,6 +1531,11 @@ extern "C" int32_t hk_stats_get(hk_ctx* c, hk_stats* out) {
             h.light_nodes += r.light_nodes;
             h.sh_nodes += r.sh_nodes;
             h.sh_tris += r.sh_tris;
+            h.sh_collisions += r.sh_collisions;
+            h.dda_steps += r.dda_steps;
+            h.sh_dda_steps += r.sh_dda_steps;
+            h.scatter_vertices += r.scatter_vertices;
+            h.sc_light_nodes += r.sc_light_nodes;
 #ifdef HK_DEBUG_UTIL
             for (int k = 0; k < 16; ++k) h.dbg[k] += r.dbg[k];
 #endif
@@ -1553,8 +1562,13 @@ extern "C" int32_t hk_stats_get(hk_ctx* c, hk_stats* out) {
     out->tris_tested = h.tris;
     out->hits_accepted = h.hits;
     out->path_vertices = h.vertices;
-    out->medium_collisions = h.collisions;
-    out->light_bvh_nodes = h.light_nodes;
+    out->medium_collisions = h.collisions + h.sh_collisions;
+    out->track_collisions = h.collisions;
+    out->shadow_collisions = h.sh_collisions;
+    out->track_dda_steps = h.dda_steps;
+    out->shadow_dda_steps = h.sh_dda_steps;
+    out->scatter_vertices = h.scatter_vertices;
+    out->light_bvh_nodes = h.light_nodes + h.sc_light_nodes;
     out->seconds_trace = tr;
     out->seconds_total = total;
     out->trace_launches = c->trace_launches;
@@ -1566,6 +1580,7 @@ extern "C" int32_t hk_stats_get(hk_ctx* c, hk_stats* out) {
     out->tris_tested = h.tris + h.sh_tris;
     out->shadow_launches = c->shadow_launches;
     out->shade_launches = c->shade_launches;
+    out->media_launches = c->media_launches;
     double cls[5] = {0, 0, 0, 0, 0};
     for (int k = 1; k < 5; ++k)
         for (auto& e : c->class_events[k]) {
@@ -1581,6 +1596,13 @@ extern "C" int32_t hk_stats_get(hk_ctx* c, hk_stats* out) {
         out->bytes_algorithmic_trace = h.rays_closest * (32 + 16) + 64 * h.nodes + 36 * h.tris + 96 * hits_closest;
         out->bytes_algorithmic_shadow = h.rays_shadow * (32 + 16) + 64 * h.sh_nodes + 36 * h.sh_tris;
         out->bytes_algorithmic_shade = h.vertices * (2 * 104 + 64 + 96) + 60 * h.light_nodes;
+        // media: per collision 8 taps x 4 B + 4 B majorant = 36 B on a dense grid, 84 B through a NanoVDB tree (+ 8 B x 3
+        // levels x 2 leaves); per majorant cell entered (DDA step) 4 B; the delta-tracking kernel reads and rewrites the path state
+        // (2 x 104 B) once per tracked ray = per entry of the medium queue, which is what `track_rays` counts; a scattering vertex
+        // (K5 + K6) is a path vertex without a material record.
+        const uint64_t b_coll = c->nvdb_collisions ? 84 : 36;
+        out->bytes_algorithmic_media = h.collisions * b_coll + 4 * h.dda_steps + h.scatter_vertices * (2 * 104 + 96) + 60 * h.sc_light_nodes;
+        out->bytes_algorithmic_shadow += h.sh_collisions * b_coll + 4 * h.sh_dda_steps;
     }
     return HK_OK;
 }

@@ -804,7 +804,7 @@ template <int MM>
 __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_per_eu(HK_MEDIA_WAVES))) k_track(DPathState st, DScene sc, DTables T, DFrame fr, int depth, DStats* stats) {
     const int lane = lane_id();
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    unsigned n_coll = 0;
+    unsigned n_coll = 0, n_dda = 0;
     const DPathGen g = st.gen[depth & 1];   // throughput / scattering vertex are updated IN PLACE in the current generation
     const bool ones = depth == 0 && fr.implicit_ones;
     // The wave streams segment after segment (SegStream) WITHOUT draining its lanes in between: the collision count per path is so
@@ -959,6 +959,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
                             survived = true;  // ran out of segments with the path still alive
                         else {
                             ++segi;
+                            ++n_dda;
                             sm0 = sm.x;
                             if (sm0 >= 1e-10f) {
                                 t = seg0;
@@ -1068,6 +1069,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
     close_seg(seg[1]);
     stats += global_wave();
     wave_add(&stats->collisions, n_coll);
+    wave_add(&stats->dda_steps, n_dda);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1076,7 +1078,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
 // next-ray segments.
 // ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_scatter(DPathState st, DScene sc, DTables T, DFrame fr, DSobol sob, int depth, DStats* stats) {
-    unsigned n_lnodes = 0;
+    unsigned n_lnodes = 0, n_sv = 0;
     HK_FOR_EACH_WAVE_SEGMENT(gw, st, ticket_ptr(st, depth, TK_SCATTER), depth, Q_SCATTER) {
         const uint32_t* __restrict__ queue = st.scatter_q + (size_t)gw * st.wave_cap;
         const int n = *count_ptr(st, depth, Q_SCATTER, gw);
@@ -1093,6 +1095,7 @@ __global__ void __launch_bounds__(256) k_scatter(DPathState st, DScene sc, DTabl
             S4 shLd = s4(0.0f), shRu = s4(0.0f), shRl = s4(0.0f), lambda = s4(0.0f), beta = s4(0.0f), r_u = s4(0.0f), n_rl = s4(0.0f);
             uint32_t pslot = 0, nflags = 0;
             if (active) {
+                ++n_sv;
                 O = g.ray_o[slot];
                 const float4 D = g.ray_d[slot];
                 v3 sp = mk3(O.x, O.y, O.z), wo = mk3(-D.x, -D.y, -D.z);
@@ -1171,7 +1174,8 @@ __global__ void __launch_bounds__(256) k_scatter(DPathState st, DScene sc, DTabl
         }
     }
     stats += global_wave();
-    wave_add(&stats->light_nodes, n_lnodes);
+    wave_add(&stats->sc_light_nodes, n_lnodes);
+    wave_add(&stats->scatter_vertices, n_sv);
 }
 
 // K14: which medium is the camera in?  (intersection.jl:690-747)  One lane, result stays on the device.
@@ -1676,7 +1680,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
     int* stack = lds_stack + (threadIdx.x >> 6) * (HK_LDS_STACK * 64);
     const int lane = lane_id();
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    unsigned n_nodes = 0, n_tris = 0, n_casts = 0, n_hits = 0, n_coll = 0;
+    unsigned n_nodes = 0, n_tris = 0, n_casts = 0, n_hits = 0, n_coll = 0, n_dda = 0;
     HK_DBG_DECL
     SegStream stream = stream_open(st, ticket_ptr(st, depth, TK_SHADOW), true, depth, Q_SHADOW);
     uint32_t rec0 = 0;   // current segment's shadow records: entries rec0 .. rec0 + n - 1 (the wave streams segment after segment)
@@ -1851,6 +1855,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
                                 track_done = true;
                             else {
                                 ++segi;
+                                ++n_dda;
                                 sm0 = sm.x;
                                 if (sm0 >= 1e-10f) {
                                     t = seg0;
@@ -1941,7 +1946,8 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
     }
     stats += global_wave();
     HK_DBG_FLUSH(stats);
-    wave_add(&stats->collisions, n_coll);
+    wave_add(&stats->sh_collisions, n_coll);
+    wave_add(&stats->sh_dda_steps, n_dda);
     wave_add(&stats->rays_shadow, n_casts);
     wave_add(&stats->hits, n_hits);
     if (COUNT) {

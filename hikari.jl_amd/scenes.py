@@ -142,6 +142,77 @@ def cloud_scene(width=1024, height=1024, kind="nanovdb", res=(128, 128, 64), sig
     return s, film, cam
 
 
+def bomex_density(res=(256, 256, 128), fill=0.05, max_extinction=620.0, cache=True):
+    """Config 4's density field: the worley-fbm recipe of `generate_cloud_density` (src/random.jl:149-206, pure noise:
+    `sphere_falloff = false` — a cloud FIELD, not one cloud) on a 256 x 256 x 128 grid, the threshold set to the field's
+    (1 - fill) quantile so that `fill` (5 %) of the voxels are cloudy, scaled so that the densest voxel has extinction 620
+    (the BOMEX example's `extinction_scale` comment, examples/bomex_cloud_example.jl:50).  The LES data itself is not in the
+    reference tree (:22 points outside it).  The noise takes ~10 s of host time at full size, so the array is kept in the temp dir."""
+    import hashlib
+    import os
+    import tempfile
+    from . import noise
+    res = tuple(int(v) for v in res)
+    key = hashlib.sha1(repr(("bomex-v1", res, float(fill), float(max_extinction))).encode()).hexdigest()[:16]
+    path = os.path.join(tempfile.gettempdir(), "hikari_mi355x_cache", "bomex_%s.npy" % key)
+    if cache and os.path.isfile(path):
+        try:
+            d = np.load(path)
+            if d.shape == res and d.dtype == np.float32:
+                return d
+        except (OSError, ValueError):
+            pass
+    base, _ = noise.cloud_noise_base(res, scale=4.0, worley_weight=0.6)
+    thr = float(np.quantile(base, 1.0 - fill))
+    val = np.clip((base - thr) / (1.0 - thr), 0.0, 1.0)
+    d = (val * (max_extinction / max(float(val.max()), 1e-12))).astype(f32)
+    if cache:
+        try:
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            tmp = "%s.%d.tmp.npy" % (path, os.getpid())
+            np.save(tmp, d)
+            os.replace(tmp, path)
+        except OSError:
+            pass
+    return d
+
+
+def bomex_scene(width=1024, height=1024, res=(256, 256, 128), fill=0.05, max_extinction=620.0, majorant_res=(64, 64, 64), kind="nanovdb",
+                sigma_a=None, sigma_s=None, g=0.877):
+    """Config 4 (examples/bomex_cloud_example.jl:53-184 `example_bomex_disney_lighting`): `bomex_density` as a NanoVDB
+    medium (`build_nanovdb_from_dense`) in the cube 1.2 at (-0.6, 0.3, -0.6), sigma_a = 0, sigma_s = 1, g = 0.877, 64^3 majorant
+    grid; the cube's faces are index-matched glass (Kr = 0, Kt = 1, index = 1) with MediumInterface(inside = cloud); floor, red
+    left wall and green right wall, no ceiling / back wall; AmbientLight(.03,.07,.23) + DirectionalLight(2.6,2.5,2.3) along
+    (-.5826,-.766,-.2717); camera (0,1,-3.5) -> (0,.9,0), fov 40.  `sigma_a` / `sigma_s` / `g` default to the example's (0, 1, 0.877);
+    the tests also render an absorbing variant of the same field."""
+    from .lights import AmbientLight
+    from .media import GridMedium, NanoVDBMedium
+    dens = bomex_density(res, fill, max_extinction)
+    lo, hi = (-0.6, 0.3, -0.6), (0.6, 1.5, 0.6)
+    sigma_a = RGBSpectrum(0.0) if sigma_a is None else sigma_a
+    sigma_s = RGBSpectrum(1.0) if sigma_s is None else sigma_s
+    if kind == "nanovdb":
+        med = NanoVDBMedium(dens, bounds=(lo, hi), sigma_a=sigma_a, sigma_s=sigma_s, g=g, majorant_res=tuple(majorant_res))
+    else:
+        med = GridMedium(dens, sigma_a=sigma_a, sigma_s=sigma_s, g=g, bounds=(lo, hi), majorant_res=tuple(majorant_res))
+    white = MatteMaterial(Kd=RGBSpectrum(0.73, 0.73, 0.73))
+    red = MatteMaterial(Kd=RGBSpectrum(0.65, 0.05, 0.05))
+    green = MatteMaterial(Kd=RGBSpectrum(0.12, 0.45, 0.15))
+    box, half = 2.0, 1.0
+    s = Scene()
+    s.push(AmbientLight(RGBSpectrum(0.03, 0.07, 0.23)))
+    s.push(DirectionalLight(RGBSpectrum(2.6, 2.5, 2.3), (-0.5826, -0.766, -0.2717)))
+    s.push(G.rect3f((-half, 0, -half), (box, 0.01, box)), white)
+    s.push(G.rect3f((-half, 0, -half), (0.01, box, box)), red)
+    s.push(G.rect3f((half - 0.01, 0, -half), (0.01, box, box)), green)
+    iface = MediumInterface(GlassMaterial(Kr=RGBSpectrum(0.0), Kt=RGBSpectrum(1.0), index=1.0), inside=med, outside=None)
+    s.push(G.rect3f(lo, (1.2, 1.2, 1.2)), iface)
+    s.sync()
+    film = Film((width, height))
+    cam = PerspectiveCamera((0.0, 1.0, -3.5), (0.0, 0.9, 0.0), film, fov=40.0)
+    return s, film, cam
+
+
 def material_scene(width=64, height=64, material=None, light="both", thin_panel=False):
     """Cornell-like box whose sphere + tilted slab carry `material` (the kinds of Appendix A that the Cornell /
     integration scenes do not exercise: coated / thin / transmissive).  `thin_panel` hangs a single-sided-thin

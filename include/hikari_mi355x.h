@@ -298,6 +298,15 @@ typedef struct hk_stats {
        (material record) + 96 (light record) + 60 per light-BVH node.  The node / triangle terms need counter flag bit 0. */
     uint64_t bytes_algorithmic_trace, bytes_algorithmic_shadow, bytes_algorithmic_shade;
     double seconds_media;      /* HIP-event sum of the delta-tracking kernels (k_track + k_scatter); not part of seconds_other */
+    /* media class (84 B per collision through a NanoVDB tree / 36 B on a dense grid, 4 B per majorant cell entered).
+       medium_collisions above = track_collisions + shadow_collisions. */
+    uint64_t track_collisions, shadow_collisions;   /* tentative collisions of delta tracking (K4) / of the shadow rays' ratio tracking (K10) */
+    uint64_t track_dda_steps, shadow_dda_steps;     /* majorant cells entered by K4 / by K10 */
+    uint64_t scatter_vertices;                      /* real scattering events handed to K5 + K6 */
+    uint64_t media_launches;                        /* k_track + k_scatter launches */
+    /* collisions x 84|36 + 4 x DDA steps of K4, + (2 x 104 state + 96 light record) per scattering vertex of K5 + K6;
+       bytes_algorithmic_shadow likewise includes the shadow walk's collisions and DDA steps */
+    uint64_t bytes_algorithmic_media;
 } hk_stats;
 
 typedef struct hk_ctx hk_ctx;

@@ -137,3 +137,46 @@ def test_rccl_film_reduce_in_library(hk):
     assert L.hk_film_reduce(comm.h, films, 2, 0) == hk._abi.HK_ERR_INVALID
     comm.close()
     vp.close()
+
+
+def test_bench_launcher_propagates_a_failing_rank():
+    """`bench.py --gpus 2` without a launcher starts the two ranks itself.  Here (no GPU) both ranks fail at torch.cuda.set_device;
+    the parent must come back non-zero, name the rank, and leave no child behind."""
+    env = dict(os.environ, HK_BENCH_LAUNCH_TIMEOUT="240")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU: the ranks are meant to fail")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                       env=env, capture_output=True, timeout=600)
+    assert r.returncode != 0
+    assert b"failed" in r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_through_the_launcher(hk):
+    """The form the driver runs: `python bench.py --gpus 2` (no torchrun).  Both ranks share cuda:0 over gloo (HK_BENCH_SINGLE_DEVICE);
+    the parent forwards rank 0's line: n_gpus == 2, strong scaling (128 of the frame's 256 spp... here 8 of 16 per rank), the
+    reduced film equals torch.distributed's reduce, and the ray count is the one-GPU frame's."""
+    import json
+    env = dict(os.environ, HK_BENCH_SINGLE_DEVICE="1", HK_BENCH_LAUNCH_TIMEOUT="900")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--spp", "16"]
+    r2 = subprocess.run(base + ["--gpus", "2"], env=env, capture_output=True, timeout=1200)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    d2 = json.loads(r2.stdout.decode().strip().splitlines()[-1])
+    assert d2["n_gpus"] == 2 and d2["scaling"] == "strong"
+    assert d2["config"]["spp_per_frame"] == 16 and d2["config"]["spp_per_rank"] == 8
+    assert d2["config"]["reduce_matches_torch_distributed"] is True
+    r1 = subprocess.run(base + ["--gpus", "1"], env=dict(env, HK_BENCH_SINGLE_DEVICE="0"), capture_output=True, timeout=1200)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    d1 = json.loads(r1.stdout.decode().strip().splitlines()[-1])
+    assert d1["n_gpus"] == 1
+    # the two ranks together cast the rays of the one-GPU frame (same sample set; the hashed decisions do not depend on the sharding)
+    assert abs(d2["rays"]["total_all_ranks"] - d1["rays"]["total_all_ranks"]) <= 1e-3 * d1["rays"]["total_all_ranks"]
+    w = subprocess.run(base + ["--gpus", "2", "--scaling", "weak"], env=env, capture_output=True, timeout=1200)
+    assert w.returncode == 0, w.stderr[-3000:]
+    dw = json.loads(w.stdout.decode().strip().splitlines()[-1])
+    assert dw["scaling"] == "weak" and dw["config"]["spp_per_frame"] == 32 and dw["config"]["spp_per_rank"] == 16

@@ -387,8 +387,8 @@ def _media_scene(hk, which):
     if which == "nanovdb_small":
         s, _, _ = scenes.cloud_scene(16, 16, "nanovdb", res=(48, 48, 24))
         return s, (-0.6, 0.3, -0.6), (0.6, 1.5, 0.6)
-    assert which == "nanovdb_bench"            # BASELINE configs[3] stand-in exactly as bench.py builds it
-    s, _, _ = scenes.cloud_scene(16, 16, "nanovdb", res=(256, 256, 128), sigma_scale=620.0 / 4)
+    assert which == "nanovdb_bench"            # BASELINE configs[3] exactly as bench.py builds it (5 % fill, extinction 620, 64^3 majorant)
+    s, _, _ = scenes.bomex_scene(16, 16)
     return s, (-0.6, 0.3, -0.6), (0.6, 1.5, 0.6)
 
 
@@ -560,36 +560,35 @@ def test_full_size_many_light(hk, oracle):
 
 
 def test_full_size_cloud(hk, oracle):
-    """BASELINE configs[3] stand-in at FULL size exactly as bench.py builds it (256 x 256 x 128 NanoVDB, sigma scale 155, 1024^2,
-    depth 32), one sample per pixel: finite, non-negative, deterministic (film and collision counter), plus the ABSORBING-only
-    variant of the same grid — no scattering, so no re-seeding from direction bits — against the oracle on a 64 x 64
-    frame: strict tolerance and an identical collision count (delta tracking consumes the same RNG stream on both sides)."""
+    """BASELINE configs[3] at FULL size exactly as bench.py builds it (`scenes.bomex_scene`: 256 x 256 x 128 worley-fbm field at 5 %
+    fill, extinction up to 620, NanoVDB + 64^3 majorant, 1024^2, depth 32), one sample per pixel: finite, non-negative,
+    deterministic (film and collision counters), sample-sharded == unsharded.  Plus the ABSORBING-only variant of the same field — no
+    scattering, so no re-seeding from direction bits — against the oracle on a 64 x 64 frame: strict tolerance and
+    an identical collision count (delta tracking consumes the same RNG stream on both sides)."""
     from hikari_jl_amd import scenes
-    s, film, cam = scenes.cloud_scene(1024, 1024, "nanovdb", res=(256, 256, 128), sigma_scale=620.0 / 4)
-    vp = hk.VolPath(max_depth=32, samples=1)
+    s, film, cam = scenes.bomex_scene(1024, 1024)
+    vp = hk.VolPath(max_depth=32, samples=2)
     vp(s, film, cam)
     a = film.framebuffer.copy()
-    c1 = int(vp.stats().medium_collisions)
-    assert np.isfinite(a).all() and (a >= 0).all() and a.mean() > 0.01 and c1 > 10_000_000
+    acc = vp.read_accumulators(film)
+    st = vp.stats()
+    c1 = int(st.medium_collisions)
+    assert np.isfinite(a).all() and (a >= 0).all() and a.mean() > 0.01 and c1 > 1_000_000
+    assert int(st.track_collisions) + int(st.shadow_collisions) == c1 and int(st.track_dda_steps) > 0 and int(st.shadow_dda_steps) > 0
+    assert int(st.scatter_vertices) > 100_000 and int(st.bytes_algorithmic_media) >= 84 * int(st.track_collisions)
     vp(s, film, cam)
     assert np.array_equal(a, film.framebuffer) and int(vp.stats().medium_collisions) == c1
+    # the two samples rendered as two strided calls (two ranks' shares) add up to the same film, up to the order of the two fp32 adds
+    vp.clear()
+    vp.render_samples(s, film, cam, 1, stride=2, first=1, readback=False)
+    vp.render_samples(s, film, cam, 1, stride=2, first=2, readback=False)
+    acc2 = vp.read_accumulators(film)
+    assert np.allclose(acc, acc2, rtol=1e-6, atol=1e-7)
     vp.close()
-    from hikari_jl_amd import geometry as G
-    from hikari_jl_amd.media import NanoVDBMedium
-    dens = scenes.cloud_density((256, 256, 128)) * np.float32(620.0 / 4 / 10)      # optical depth of a few: the absorbing cloud stays see-through at its rim
-    lo, hi = (-0.6, 0.3, -0.6), (0.6, 1.5, 0.6)
-    med = NanoVDBMedium(dens, bounds=(lo, hi), sigma_a=hk.RGBSpectrum(0.9, 1.0, 1.2), sigma_s=hk.RGBSpectrum(0.0), g=0.0, majorant_res=(32, 32, 32))
-    s2 = hk.Scene()
-    s2.push(hk.AmbientLight(hk.RGBSpectrum(0.03, 0.07, 0.23)))
-    s2.push(hk.DirectionalLight(hk.RGBSpectrum(2.6, 2.5, 2.3), (-0.5826, -0.766, -0.2717)))
-    s2.push(G.rect3f((-4, -0.01, -4), (8, 0.01, 8)), hk.MatteMaterial(Kd=hk.RGBSpectrum(0.35, 0.33, 0.3)))
-    eps = 1e-3
-    s2.push(G.rect3f((lo[0] - eps, lo[1] - eps, lo[2] - eps), (1.2 + 2 * eps,) * 3),
-            hk.MediumInterface(hk.GlassMaterial(Kr=hk.RGBSpectrum(0.0), Kt=hk.RGBSpectrum(1.0), index=1.0), inside=med, outside=None))
-    s2.sync()
+    s2, _, _ = scenes.bomex_scene(64, 64, max_extinction=620.0 / 16, sigma_a=hk.RGBSpectrum(0.9, 1.0, 1.2), sigma_s=hk.RGBSpectrum(0.0), g=0.0)
     w = h = 64
     f2 = hk.Film((w, h))
-    cam2 = hk.PerspectiveCamera((0.0, 1.0, -3.2), (0.0, 0.85, 0.0), f2, fov=35.0)
+    cam2 = hk.PerspectiveCamera((0.0, 1.0, -3.5), (0.0, 0.9, 0.0), f2, fov=40.0)
     g, r, st, ost = _frame_both(hk, oracle, s2, cam2, w, h, max_depth=6, samples=8)
     rel_mse, frac = frame_metrics(g, r)
     assert rel_mse <= 1e-3 and frac >= 0.99, (rel_mse, frac)

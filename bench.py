@@ -133,7 +133,7 @@ def build_workload(config, scenes):
         mres = int(os.environ.get("HK_CLOUD_MAJORANT", "64"))
         scene, film, cam = scenes.bomex_scene(W, H, res=(256, 256, 128), fill=0.05, max_extinction=620.0, majorant_res=(mres, mres, mres))
         workload = ("BOMEX stand-in (the LES data is not in the reference tree): generate_cloud_density's worley-fbm recipe (src/random.jl:149-206, "
-                    "pure noise) on 256x256x128, thresholded to 5 % fill, max extinction 620, NanoVDB + %d^3 majorant grid, sigma_a 0 / sigma_s 1 / g 0.877, "
+                    "pure noise) on 256x256x128, thresholded to 5 %% fill, max extinction 620, NanoVDB + %d^3 majorant grid, sigma_a 0 / sigma_s 1 / g 0.877, "
                     "scene of examples/bomex_cloud_example.jl:53-184 (index-matched glass cube 1.2, floor + two walls, Ambient + Directional), 1024x1024, "
                     "VolPath depth 32" % mres)
     elif config == "sky":

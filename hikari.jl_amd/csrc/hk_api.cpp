@@ -786,18 +786,19 @@ extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene**
             HIP_TRY(tb->upload(table.data(), table.size() * sizeof(uint2)));
             o.nv_blocks = tb->as<uint2>();
             for (int k = 0; k < 3; ++k) o.nvb_dim[k] = (int)dim[k];
-            // dense bricks: every block of the table materialised (leaf values copied, constant blocks filled) so that the device
-            // fetches a voxel with ONE load at a computed address.  2 KB per block: taken when it fits HK_NVDB_DENSE_MB (default
-            // 4096 MB — 288 GB of HBM are there to be used; the bench cloud needs 47 MB), else the table + leaves path stays.
+            // dense bricks: every block of the table materialised (leaf values copied, constant blocks filled) WITH the first voxel
+            // plane of its +x / +y / +z neighbours (9^3 floats per block, z fastest), so that the device fetches the eight taps of a
+            // lookup from one brick at one computed address.  2.9 KB per block: taken when it fits HK_NVDB_DENSE_MB (default 4096 MB —
+            // 288 GB of HBM are there to be used; the bench cloud needs 67 MB), else the table + leaves path stays.
             {
                 size_t budget_mb = 4096;
                 if (const char* e = std::getenv("HK_NVDB_DENSE_MB")) budget_mb = (size_t)std::atol(e);
-                const size_t brick_bytes = (size_t)total * 512 * sizeof(float);
+                const size_t brick_bytes = (size_t)total * 729 * sizeof(float);
                 if (brick_bytes <= budget_mb * (size_t)(1 << 20)) {
-                    std::vector<float> bricks((size_t)total * 512);
+                    std::vector<float> plain((size_t)total * 512);
                     for (size_t b = 0; b < (size_t)total; ++b) {
                         const uint2 e = table[b];
-                        float* dst = bricks.data() + b * 512;
+                        float* dst = plain.data() + b * 512;
                         if (e.x == 0u) {
                             float v;
                             std::memcpy(&v, &e.y, 4);
@@ -805,6 +806,20 @@ extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene**
                         } else
                             for (int n = 0; n < 512; ++n) dst[n] = hknv::f32(m.nvdb_bytes, (long long)e.x + 96 + (long long)n * 4);
                     }
+                    auto voxel = [&](long long bx, long long by, long long bz, int x, int y, int z) -> float {   // (x, y, z) in 0 .. 8 relative to block (bx, by, bz)
+                        bx += x >> 3, by += y >> 3, bz += z >> 3;
+                        if (bx >= dim[0] || by >= dim[1] || bz >= dim[2]) return bg_probe;   // beyond the (background) margin
+                        return plain[((size_t)bz + (size_t)dim[2] * ((size_t)by + (size_t)dim[1] * (size_t)bx)) * 512 + (size_t)(((x & 7) << 6) | ((y & 7) << 3) | (z & 7))];
+                    };
+                    std::vector<float> bricks((size_t)total * 729);
+                    for (long long bx = 0; bx < dim[0]; ++bx)
+                        for (long long by = 0; by < dim[1]; ++by)
+                            for (long long bz = 0; bz < dim[2]; ++bz) {
+                                float* dst = bricks.data() + ((size_t)bz + (size_t)dim[2] * ((size_t)by + (size_t)dim[1] * (size_t)bx)) * 729;
+                                for (int x = 0; x < 9; ++x)
+                                    for (int y = 0; y < 9; ++y)
+                                        for (int z = 0; z < 9; ++z) dst[x * 81 + y * 9 + z] = voxel(bx, by, bz, x, y, z);
+                            }
                     DevBuf* bb = new DevBuf();
                     s->media_data.push_back(bb);
                     HIP_TRY(bb->upload(bricks.data(), brick_bytes));
@@ -1284,6 +1299,15 @@ extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_
     fr.max_component_value = I->p.max_component_value;
     fr.count_nodes = c->count_nodes;
     fr.implicit_ones = sc->d.n_media == 0 ? 1 : 0;
+    {   // loop shapes of the tracking state machines (measured defaults; read per call)
+        auto knob = [](const char* name, int dflt) {
+            const char* e = std::getenv(name);
+            const int v = e ? std::atoi(e) : dflt;
+            return v >= 1 && v <= 255 ? v : dflt;
+        };
+        fr.delta_advance = knob("HK_DELTA_ADVANCE", 4);
+        fr.walk_tune = knob("HK_SHADOW_TRACK_BATCH", 8) | (knob("HK_TRACK_ADVANCE", 4) << 8) | (knob("HK_SHADOW_FEED_ROUNDS", 3) << 16);
+    }
     DSobol sob = make_sobol(I->p, W, H);
     {   // pixel-digit table of the sampler: depends on film size, spp exponent and max_depth only
         const int rows = 4 + 5 * (I->p.max_depth + 1);

@@ -2096,6 +2096,7 @@ HKD void majorant_skip_zero(MajorantIter& it, const DMedium& m, int& segi) {
 // offset, or 0 and the block's constant tile / background value}.  On the device a voxel fetch is table entry -> leaf value:
 // two dependent loads instead of six, and no tree-walk code (and registers) in the tracking kernels.  Blocks outside the
 // table hold the background value (the upload checks that the margin does).  Values are those the walk returns.
+typedef float hk_f2u __attribute__((ext_vector_type(2), aligned(4)));
 struct NvBlock {
     uint32_t leaf_off;   // 1-based byte offset of the leaf node, 0 => constant `value` for the whole block
     float value;
@@ -2114,13 +2115,6 @@ HKD NvBlock nv_find_block(const DMedium& m, int kx, int ky, int kz) {  // block 
     return r;
 }
 HKD float nv_leaf_value(const DMedium& m, uint32_t leaf_off, int n_leaf) { return hknv::f32(m.nvdb, (long long)leaf_off + 96 + (long long)n_leaf * 4); }
-// voxel (x, y, z) through the dense bricks: one load at a computed address (background outside the table's extent)
-HKD float nv_brick_value(const DMedium& m, int x, int y, int z) {
-    const int bx = (x >> 3) - m.nvb_min[0], by = (y >> 3) - m.nvb_min[1], bz = (z >> 3) - m.nvb_min[2];
-    if ((unsigned)bx < (unsigned)m.nvb_dim[0] && (unsigned)by < (unsigned)m.nvb_dim[1] && (unsigned)bz < (unsigned)m.nvb_dim[2])
-        return m.nv_bricks[(((size_t)bz + (size_t)m.nvb_dim[2] * ((size_t)by + (size_t)m.nvb_dim[1] * (size_t)bx)) << 9) + (size_t)(((x & 7) << 6) | ((y & 7) << 3) | (z & 7))];
-    return m.nv_background;
-}
 HKD float sample_nanovdb_density(const DMedium& m, v3 p) {  // nanovdb.jl:400-469
     float px = p.x - m.vec[0], py = p.y - m.vec[1], pz = p.z - m.vec[2];
     float fxi = m.inv_mat[0] * px + m.inv_mat[1] * py + m.inv_mat[2] * pz;
@@ -2131,22 +2125,17 @@ HKD float sample_nanovdb_density(const DMedium& m, v3 p) {  // nanovdb.jl:400-46
     float fx = fxi - (float)ix, fy = fyi - (float)iy, fz = fzi - (float)iz;
     float v000, v001, v010, v011, v100, v101, v110, v111;
     if (m.nv_bricks) {
-        // dense bricks (the upload materialises them when the index bounding box is small enough): eight INDEPENDENT loads, no
-        // dependent table lookup in front of them.  Same voxel values as the tree walk.
-        if ((ix & 7) != 7 && (iy & 7) != 7 && (iz & 7) != 7) {
-            const int bx = (ix >> 3) - m.nvb_min[0], by = (iy >> 3) - m.nvb_min[1], bz = (iz >> 3) - m.nvb_min[2];
-            if ((unsigned)bx < (unsigned)m.nvb_dim[0] && (unsigned)by < (unsigned)m.nvb_dim[1] && (unsigned)bz < (unsigned)m.nvb_dim[2]) {
-                const float* b = m.nv_bricks + ((((size_t)bz + (size_t)m.nvb_dim[2] * ((size_t)by + (size_t)m.nvb_dim[1] * (size_t)bx)) << 9) +
-                                                (size_t)(((ix & 7) << 6) | ((iy & 7) << 3) | (iz & 7)));
-                v000 = b[0], v001 = b[1], v010 = b[8], v011 = b[9], v100 = b[64], v101 = b[65], v110 = b[72], v111 = b[73];
-            } else
-                v000 = v001 = v010 = v011 = v100 = v101 = v110 = v111 = m.nv_background;
-        } else {
-            v000 = nv_brick_value(m, ix, iy, iz), v001 = nv_brick_value(m, ix, iy, iz + 1);
-            v010 = nv_brick_value(m, ix, iy + 1, iz), v011 = nv_brick_value(m, ix, iy + 1, iz + 1);
-            v100 = nv_brick_value(m, ix + 1, iy, iz), v101 = nv_brick_value(m, ix + 1, iy, iz + 1);
-            v110 = nv_brick_value(m, ix + 1, iy + 1, iz), v111 = nv_brick_value(m, ix + 1, iy + 1, iz + 1);
-        }
+        // dense bricks WITH A HALO (the upload materialises them when the index bounding box is small enough): brick = the block's 8^3
+        // voxels plus the first plane of its +x / +y / +z neighbours, 9^3 floats, z fastest — the eight taps of ANY voxel are in the
+        // brick of its block: four 8-byte loads (4-byte aligned) at one computed address, no dependent table lookup, no second path
+        // for the 33 % of the voxels whose taps straddle two blocks.  Same voxel values as the tree walk.
+        const int bx = (ix >> 3) - m.nvb_min[0], by = (iy >> 3) - m.nvb_min[1], bz = (iz >> 3) - m.nvb_min[2];
+        if ((unsigned)bx < (unsigned)m.nvb_dim[0] && (unsigned)by < (unsigned)m.nvb_dim[1] && (unsigned)bz < (unsigned)m.nvb_dim[2]) {
+            const float* b = m.nv_bricks + ((size_t)(bz + m.nvb_dim[2] * (by + m.nvb_dim[1] * bx)) * 729u + (size_t)((ix & 7) * 81 + (iy & 7) * 9 + (iz & 7)));
+            const hk_f2u p00 = *(const hk_f2u*)(b), p01 = *(const hk_f2u*)(b + 9), p10 = *(const hk_f2u*)(b + 81), p11 = *(const hk_f2u*)(b + 90);
+            v000 = p00.x, v001 = p00.y, v010 = p01.x, v011 = p01.y, v100 = p10.x, v101 = p10.y, v110 = p11.x, v111 = p11.y;
+        } else   // the table's outermost blocks hold the background (checked at upload), so a base voxel outside it has background taps only
+            v000 = v001 = v010 = v011 = v100 = v101 = v110 = v111 = m.nv_background;
     } else if ((ix & 7) != 7 && (iy & 7) != 7 && (iz & 7) != 7) {
         // all eight taps in one 8^3 block (2 of 3 lookups): one table entry, eight independent leaf loads
         NvBlock c = nv_find_block(m, ix >> 3, iy >> 3, iz >> 3);

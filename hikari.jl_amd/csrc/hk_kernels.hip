@@ -946,15 +946,12 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
                 // ---- phase A: cheap steps (next majorant cell, free-flight sample, cell-boundary crossing) until every busy lane
                 //      either holds a tentative collision or has run out of segments ----
     #pragma unroll 1
-                for (int adv = 0; adv < HK_DELTA_ADVANCE; ++adv) {
+                for (int adv = 0; adv < fr.delta_advance; ++adv) {
                     const bool need = mine && state == TR_BUSY && !pending && !survived;
                     if (__ballot(need) == 0ull) break;
                     if (!need) continue;
                     if (!in_seg) {
                         float seg0;
-#if HK_SKIP_ZERO
-                        majorant_skip_zero<MM>(it, med, segi);   // empty cells: DDA steps only, no majorant fetch, no outer iteration
-#endif
                         if (segi >= 256 || !majorant_next<MM>(it, med, base_a + base_s, seg0, seg1, sm))
                             survived = true;  // ran out of segments with the path still alive
                         else {
@@ -1674,10 +1671,10 @@ enum { SH_EMPTY = 0, SH_CAST = 1, SH_TRACK = 2 };
 #define HK_SHADOW_TRACK_BATCH 4
 #endif
 
-template <bool COUNT, int MM>
-__global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TRACE_BLOCK), amdgpu_waves_per_eu(MM == 0 ? 4 : HK_MEDIA_WAVES))) k_shadow_walk(DPathState st, DScene sc, DTables T, int depth, DStats* stats) {
-    __shared__ int lds_stack[(HK_TRACE_BLOCK / 64) * HK_LDS_STACK * 64];
-    int* stack = lds_stack + (threadIdx.x >> 6) * (HK_LDS_STACK * 64);
+template <bool COUNT, int MM, int STACK = HK_LDS_STACK>
+__global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TRACE_BLOCK), amdgpu_waves_per_eu(MM == 0 ? 4 : (MM == 8 || MM == 2 || MM == 1) ? 3 : HK_MEDIA_WAVES))) k_shadow_walk(DPathState st, DScene sc, DTables T, int depth, int tune, DStats* stats) {
+    __shared__ int lds_stack[(HK_TRACE_BLOCK / 64) * STACK * 64];
+    int* stack = lds_stack + (threadIdx.x >> 6) * (STACK * 64);
     const int lane = lane_id();
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     unsigned n_nodes = 0, n_tris = 0, n_casts = 0, n_hits = 0, n_coll = 0, n_dda = 0;
@@ -1818,7 +1815,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
         // ---- short rays (one cast and done: shadow rays that start outside the medium, blocked ones) leave their lanes empty for the
         //      whole tracking batch below, which is where the time goes: fetch and cast again, a few times, until the wave is mostly
         //      tracking (the cloud's walk ran its collision rounds with 28 % of the lanes EMPTY although work was waiting) ----
-        if (MM != 0 && feed_rounds < HK_SHADOW_FEED_ROUNDS) {
+        if (MM != 0 && feed_rounds < ((tune >> 16) & 0xff)) {
             const int waiting = __popcll(__ballot(state == SH_EMPTY)) + __popcll(__ballot(state == SH_CAST));
             if (waiting >= HK_REFILL_MIN_IDLE && (cursor < n || more)) {
                 ++feed_rounds;
@@ -1835,20 +1832,17 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
                 const bool mine = state == SH_TRACK && medium == m_uniform;
                 const DMedium& med = sc.media[m_uniform];
 #pragma unroll 1
-                for (int batch = 0; batch < HK_SHADOW_TRACK_BATCH; ++batch) {
+                for (int batch = 0; batch < (tune & 0xff); ++batch) {
                     if (__ballot(mine && state == SH_TRACK) == 0ull) break;
                     bool track_done = false;
 #pragma unroll 1
-                    for (int adv = 0; adv < HK_TRACK_ADVANCE; ++adv) {
+                    for (int adv = 0; adv < ((tune >> 8) & 0xff); ++adv) {
                         const bool need = mine && state == SH_TRACK && !pending && !track_done;
                         if (__ballot(need) == 0ull) break;
                         HK_DBG(1, need);
                         if (!need) continue;
                         if (!in_seg) {
                             float seg0;
-#if HK_SKIP_ZERO
-                            if (!(after_inner && is_black(sT))) majorant_skip_zero<MM>(it, med, segi);   // empty cells: DDA steps only
-#endif
                             if (after_inner && is_black(sT))
                                 track_done = true;
                             else if (segi >= 256 || !majorant_next<MM>(it, med, base_a + base_s, seg0, seg1, sm))
@@ -2277,7 +2271,7 @@ __global__ void k_test_medium(DScene sc, DTables T, int mode, int medium_idx, in
             float t0, t1;
             S4 sm;
             for (;;) {
-                if (mode == 2) majorant_skip_zero<MM>(it, med, count);   // the tracking kernels' fast-forward over zero cells
+                if (mode == 2) majorant_skip_zero<MM>(it, med, count);   // fast-forward over zero cells (measured and not used by the kernels: DESIGN §5)
                 if (count >= 256 || !majorant_next<MM>(it, med, base_a + base_s, t0, t1, sm)) break;
                 // mode 1 records every segment, mode 2 the segments that survive the fast-forward (zero cells excluded)
                 if (kept < HK_TEST_MAJ_SEGS) r[1 + 3 * kept] = t0, r[2 + 3 * kept] = t1, r[3 + 3 * kept] = sm.x;
@@ -2516,9 +2510,12 @@ void launch_shadow(hipStream_t s, int n_cu, const DPathState& st, const DScene& 
         return;
     }
 #define HK_SHADOW_LAUNCH(C, MM)                                                                                                        \
-    {                                                                                                                                  \
+    if (sc.bvh_depth <= 16) {   /* 16-entry stacks: 16 KB per block beside the 32 KB zero-cell mask */                               \
+        const int blocks = cached_blocks<k_shadow_walk<C, MM, 16>>(HK_TRACE_BLOCK, n_cu, 8);                                         \
+        hipLaunchKernelGGL((k_shadow_walk<C, MM, 16>), dim3(clamp_blocks(blocks, st)), dim3(HK_TRACE_BLOCK), 0, s, st, sc, T, depth, fr.walk_tune, stats); \
+    } else {                                                                                                                           \
         const int blocks = cached_blocks<k_shadow_walk<C, MM>>(HK_TRACE_BLOCK, n_cu, 8);                                             \
-        hipLaunchKernelGGL((k_shadow_walk<C, MM>), dim3(clamp_blocks(blocks, st)), dim3(HK_TRACE_BLOCK), 0, s, st, sc, T, depth, stats); \
+        hipLaunchKernelGGL((k_shadow_walk<C, MM>), dim3(clamp_blocks(blocks, st)), dim3(HK_TRACE_BLOCK), 0, s, st, sc, T, depth, fr.walk_tune, stats); \
     }
 #define HK_SHADOW_MM(C)                                   \
     switch (sc.n_media > 0 ? media_mask_class(sc) : 0) {  \

@@ -125,8 +125,8 @@ struct DMedium {
     const unsigned char* nvdb;     // NanoVDB bytes (tree part)
     const uint2* nv_blocks;        // flattened tree over the index bbox: {leaf offset (1-based, 0 = constant block), value bits}
     int nvb_min[3], nvb_dim[3];    // block-coordinate origin / extent of nv_blocks ([bx][by][bz], bz fastest)
-    const float* nv_bricks;        // optional: every block of the table materialised as a dense 8^3 brick (512 floats, leaf order): a voxel
-                                   // fetch is then ONE load at a computed address instead of table entry -> leaf value (null: use nv_blocks)
+    const float* nv_bricks;        // optional: every block of the table materialised as a dense brick with a +1 halo (9^3 floats, z fastest): the 8
+                                   // taps of a lookup are four 8-byte loads at ONE computed address instead of table entry -> leaf value (null: use nv_blocks)
     float nv_background;           // value of every block outside the table
     long long root_off;            // 1-based like the reference
     int root_table_size;
@@ -297,4 +297,6 @@ struct DFrame {            // per-pass constants
     float max_component_value;
     int count_nodes;       // 1: accumulate node/triangle counters
     int implicit_ones;     // 1: scene without media: the depth-0 records do not store beta = r_u = r_l = 1
+    int delta_advance;     // k_track: cheap steps (next majorant cell / free-flight sample) per round before the pending collisions are evaluated (HK_DELTA_ADVANCE)
+    int walk_tune;         // k_shadow_walk: tracking batches per round | advance steps per batch << 8 | feed rounds << 16 (HK_SHADOW_TRACK_BATCH, HK_TRACK_ADVANCE, HK_SHADOW_FEED_ROUNDS)
 };

@@ -6,7 +6,7 @@ import os
 from . import _abi as A
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libhikari_mi355x.so")
+LIB_PATH = os.environ.get("HK_LIB_PATH") or os.path.join(_HERE, "csrc", "libhikari_mi355x.so")   # HK_LIB_PATH: A/B builds of the same library (tools/)
 _lib = None
 
 

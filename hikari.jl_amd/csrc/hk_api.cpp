@@ -834,6 +834,13 @@ extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene**
     D.n_media = d->n_media;
     D.media_mask = 0;
     for (int i = 0; i < d->n_media; ++i) D.media_mask |= 1 << d->media[i].kind;
+    D.all_grey = d->n_media == 1 ? 1 : 0;   // the GREY kernels read ONE medium record
+    for (int i = 0; i < d->n_media; ++i) {
+        const DMedium& dm = dmed[i];
+        const bool flat_a = dm.sigma_a.w == 0.0f || (dm.sigma_a.x == 0.0f && dm.sigma_a.y == 0.0f);
+        const bool flat_s = dm.sigma_s.w == 0.0f || (dm.sigma_s.x == 0.0f && dm.sigma_s.y == 0.0f);
+        if (!(flat_a && flat_s && (dm.kind == HK_MEDIUM_GRID || dm.kind == HK_MEDIUM_NANOVDB))) D.all_grey = 0;
+    }
     D.nodes = s->nodes.as<DNode>();
     D.leaf_tris = s->leaf_tris.as<float4>();
     D.root_ref = bvh.root_ref;
@@ -1141,14 +1148,14 @@ hipError_t alloc_arr(hk_integrator* I, T*& dst, size_t n) {
 // W virtual wave segments: every queue is split W ways and a segment is processed by one wave per kernel, so W is independent of each
 // kernel's residency.  Finer segments balance better, but every segment should keep >= 16 chunks (1024 paths) so its per-kind queues
 // fill whole waves: W = chunks / 16, capped per CU.  Measured on the four bench scenes (work lists + 64-way XCD-affine tickets):
-//   media                     tickets, 256 per CU   (cloud 2.21 -> 2.32 G rays/s against 96; the work per segment is wildly uneven)
+//   media                     tickets, 96 per CU    (round 3, the 5 %-fill cloud: 1.22 s per frame at 256, 1.14 at 96, 1.18 at 64; the round-2 blob cloud preferred 256)
 //   surfaces, closed scene    tickets, 192 per CU   (Cornell 7.19 -> 7.55, many-light 1.11 -> 1.19: trace -10 %, light-BVH shading -9 %)
 //   surfaces, open scene      static stride, 48 per CU   (sky: most paths escape after 1-2 vertices; finer segments only fragment
 //                             the per-kind queues: k_shade +7 % at 96, +15 % at 256, whichever way they are handed out)
 // HK_WAVES_PER_CU / HK_DYNAMIC_SEGMENTS override.  stats rows are indexed by PHYSICAL wave (ctx->stat_rows).
 int ensure_state(hk_integrator* I, int capacity, bool media, bool open_scene) {
     const int n_cu = I->ctx->n_cu;
-    const long cap_per_cu = media ? 256 : (open_scene ? 48 : 192);
+    const long cap_per_cu = media ? 96 : (open_scene ? 48 : 192);
     long W_want = ((long)(capacity + 63) / 64) / 16;
     if (W_want < 4L * n_cu) W_want = 4L * n_cu;
     if (W_want > cap_per_cu * n_cu) W_want = cap_per_cu * n_cu;
@@ -1158,7 +1165,7 @@ int ensure_state(hk_integrator* I, int capacity, bool media, bool open_scene) {
     I->st.dynamic_segments = (media || !open_scene) ? 1 : 0;
     if (const char* e = std::getenv("HK_DYNAMIC_SEGMENTS")) I->st.dynamic_segments = std::atoi(e) ? 1 : 0;
     I->st.compact = media ? 0 : 1;
-    if (I->st_capacity >= capacity && I->st_depth >= I->p.max_depth && I->st.n_waves == (int)W_want) return HK_OK;
+    if (I->st_capacity >= capacity && I->st_depth >= I->p.max_depth && I->st.n_waves == (int)W_want && (!(media && std::getenv("HK_WALK_SPLIT") && std::atoi(std::getenv("HK_WALK_SPLIT"))) || I->st.wq_a != nullptr)) return HK_OK;
     for (auto* b : I->bufs) delete b;
     I->bufs.clear();
     DPathState& s = I->st;
@@ -1191,6 +1198,16 @@ int ensure_state(hk_integrator* I, int capacity, bool media, bool open_scene) {
     HIP_TRY(alloc_arr(I, s.sh_ru, Q));
     HIP_TRY(alloc_arr(I, s.sh_rl, Q));
     HIP_TRY(alloc_arr(I, s.sh_slot, Q));
+    s.sh_T = nullptr, s.sh_aux = nullptr, s.sh_it = nullptr, s.wq_a = nullptr, s.wq_b = nullptr, s.wq_ctl = nullptr;
+    const char* split_env = std::getenv("HK_WALK_SPLIT");
+    if (media && split_env && std::atoi(split_env)) {   // the split shadow walk of grey media (92 B per record; off by default)
+        HIP_TRY(alloc_arr(I, s.sh_T, Q));
+        HIP_TRY(alloc_arr(I, s.sh_aux, Q));
+        HIP_TRY(alloc_arr(I, s.sh_it, 4 * Q));
+        HIP_TRY(alloc_arr(I, s.wq_a, Q + (4u << 20)));   // + the padding of the writers' last chunks (HK_GQ_CHUNK x resident waves)
+        HIP_TRY(alloc_arr(I, s.wq_b, Q + (4u << 20)));
+        HIP_TRY(alloc_arr(I, s.wq_ctl, (size_t)(I->p.max_depth + 2) * 11 * 4));
+    }
     HIP_TRY(alloc_arr(I, s.escaped_q, Q));
     HIP_TRY(alloc_arr(I, s.medium_q, Q));
     HIP_TRY(alloc_arr(I, s.scatter_q, Q));
@@ -1306,7 +1323,8 @@ extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_
             return v >= 1 && v <= 255 ? v : dflt;
         };
         fr.delta_advance = knob("HK_DELTA_ADVANCE", 4);
-        fr.walk_tune = knob("HK_SHADOW_TRACK_BATCH", 8) | (knob("HK_TRACK_ADVANCE", 4) << 8) | (knob("HK_SHADOW_FEED_ROUNDS", 3) << 16);
+        fr.refill_idle = knob("HK_TRACK_REFILL_IDLE", 24);
+        fr.walk_tune = knob("HK_SHADOW_TRACK_BATCH", 8) | (knob("HK_TRACK_ADVANCE", 4) << 8) | (knob("HK_SHADOW_FEED_ROUNDS", 3) << 16) | ((knob("HK_WALK_REFILL_IDLE", 16) & 63) << 24);
     }
     DSobol sob = make_sobol(I->p, W, H);
     {   // pixel-digit table of the sampler: depends on film size, spp exponent and max_depth only
@@ -1413,6 +1431,7 @@ extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_
         // queue sizes start every pass at zero: a depth at which no shade / scatter kernel runs (a triangle-free scene lit by an
         // environment map, say) must not see the ray / shadow counts an earlier render left behind
         HIP_TRY(hipMemsetAsync(I->st.counters, 0, (size_t)(I->st_depth + 2) * Q_COUNT * I->st.n_waves * sizeof(int), s));
+        if (I->st.wq_ctl) HIP_TRY(hipMemsetAsync(I->st.wq_ctl, 0, (size_t)(I->st_depth + 2) * 11 * 4 * sizeof(int), s));
         if (timed(3, [&] { hk::launch_camera(s, c->n_cu, I->st, fr, c->tables, I->filter, dc, sob, -1); }) != HK_OK) return fail(HK_ERR_DEVICE, "event record failed");
         // work lists: after every producer, the non-empty segments of the queues it filled (consumers never visit an empty segment)
         auto lists = [&](std::initializer_list<std::pair<int, int>> dq, bool kinds_of_depth = false, int kd = 0) {

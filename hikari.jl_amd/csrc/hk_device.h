@@ -2015,37 +2015,32 @@ HKD bool majorant_next(MajorantIter& it, const DMedium& m, S4 sigma_t, float& se
         return false;
     }
     if (HK_HAS_MEDIUM(MM, HK_MEDIUM_RGB_GRID) && m.kind == HK_MEDIUM_RGB_GRID) sigma_t = s4(1.0f);
-    float tx = it.next_t[0], ty = it.next_t[1], tz = it.next_t[2];
-    int axis = (tx < ty) ? ((tx < tz) ? 0 : 2) : ((ty < tz) ? 1 : 2);
-    float nt = axis == 0 ? tx : (axis == 1 ? ty : tz);
-    float stm = minf(nt, it.t_max);
+    // one DDA step without a branch (a divergent wave would walk all three axis arms, each behind its own exec-mask bookkeeping):
+    // the stepping axis is the one media.jl:676-690 picks, the crossing time of that axis advances by ONE addition as there
+    const float tx = it.next_t[0], ty = it.next_t[1], tz = it.next_t[2];
+    const bool lxy = tx < ty, lxz = tx < tz, lyz = ty < tz;
+    const bool a0 = lxy & lxz, a1 = (!lxy) & lyz;   // axis 0, axis 1, else axis 2
+    const float nt = a0 ? tx : (a1 ? ty : tz);
+    const float stm = minf(nt, it.t_max);
     const int rx = m.mres[0], ry = m.mres[1], rz = m.mres[2];
-    float rho = m.majorant[it.voxel[0] + rx * (it.voxel[1] + ry * it.voxel[2])];
+    const int vx = it.voxel[0], vy = it.voxel[1], vz = it.voxel[2];
+    const float rho = m.majorant[vx + rx * (vy + ry * vz)];
     seg_t_min = it.t_min;
     seg_t_max = stm;
     sigma_maj = sigma_t * rho;
-    it.t_min = stm;
-    bool out;
-    if (axis == 0) {
-        bool neg = it.mode & 0x100;
-        it.voxel[0] += neg ? -1 : 1;
-        it.next_t[0] += it.delta_t[0];
-        out = it.voxel[0] == (neg ? -1 : rx);
-    } else if (axis == 1) {
-        bool neg = it.mode & 0x200;
-        it.voxel[1] += neg ? -1 : 1;
-        it.next_t[1] += it.delta_t[1];
-        out = it.voxel[1] == (neg ? -1 : ry);
-    } else {
-        bool neg = it.mode & 0x400;
-        it.voxel[2] += neg ? -1 : 1;
-        it.next_t[2] += it.delta_t[2];
-        out = it.voxel[2] == (neg ? -1 : rz);
-    }
-    if (out) {
-        it.mode = 0;
-        it.t_min = it.t_max;
-    }
+    const bool neg = (it.mode & (a0 ? 0x100 : (a1 ? 0x200 : 0x400))) != 0;
+    const int v = (a0 ? vx : (a1 ? vy : vz)) + (neg ? -1 : 1);
+    const int lim = neg ? -1 : (a0 ? rx : (a1 ? ry : rz));
+    const float s = nt + (a0 ? it.delta_t[0] : (a1 ? it.delta_t[1] : it.delta_t[2]));
+    it.voxel[0] = a0 ? v : vx;
+    it.voxel[1] = a1 ? v : vy;
+    it.voxel[2] = (a0 | a1) ? vz : v;
+    it.next_t[0] = a0 ? s : tx;
+    it.next_t[1] = a1 ? s : ty;
+    it.next_t[2] = (a0 | a1) ? tz : s;
+    const bool out = v == lim;
+    it.mode = out ? 0 : it.mode;
+    it.t_min = out ? it.t_max : stm;
     return true;
 }
 
@@ -2252,4 +2247,18 @@ HKD MediumProps sample_point(const DTables& T, S4 lambda, const DMedium& m, S4 b
     mp.Le = s4(0.0f);
     return mp;
 }
+// density at p of a density-scaled medium (Grid / NanoVDB): what sample_point multiplies the medium's spectra with
+template <int MM>
+HKD float sample_density(const DMedium& m, v3 p) {
+    if (HK_HAS_MEDIUM(MM, HK_MEDIUM_GRID) && (m.kind == HK_MEDIUM_GRID || !HK_HAS_MEDIUM(MM, HK_MEDIUM_NANOVDB))) {
+        const float* M = m.r2m;
+        return sample_grid_density(m, mk3(M[0] * p.x + M[1] * p.y + M[2] * p.z + M[3], M[4] * p.x + M[5] * p.y + M[6] * p.z + M[7], M[8] * p.x + M[9] * p.y + M[10] * p.z + M[11]));
+    }
+    return sample_nanovdb_density(m, p);
+}
+// GREY media: sigma_a and sigma_s are flat spectra (sigmoid coefficients c0 = c1 = 0: what a grey RGB uplifts to, and what the
+// BOMEX example's RGBSpectrum(0) / RGBSpectrum(1) are) — the value is the same at every wavelength, bit for bit
+HKD float eval_flat(float4 c) { return c.w == 0.0f ? 0.0f : c.w * poly_eval(0.0f, 0.0f, c.z, 500.0f); }
+// average() of an S4 whose four components are all v, in average()'s own operation order
+HKD float average_flat(float v) { return (((v + v) + v) + v) / 4.0f; }
 }  // namespace hkd

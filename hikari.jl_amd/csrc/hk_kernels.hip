@@ -12,6 +12,7 @@
 // then k_film folds the S samples of each pixel into the film accumulators in sample order        [K12]
 // Queue sizes live in device memory (counters[depth][queue]); every kernel sizes itself from them.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <cstdlib>
 
 #include "hikari_mi355x.h"
@@ -800,8 +801,15 @@ struct TrackSeg {
     int esc, sca;                 // entries in the segment's escaped / scatter queues
     int kind_count[HK_MAX_KINDS]; // entries in its per-kind queues
 };
-template <int MM>
-__global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_per_eu(HK_MEDIA_WAVES))) k_track(DPathState st, DScene sc, DTables T, DFrame fr, int depth, DStats* stats) {
+// GREY (scenes whose media are all Grid / NanoVDB with flat sigma_a and sigma_s spectra — DScene::all_grey; the BOMEX example's cloud is
+// RGBSpectrum(0) / RGBSpectrum(1)): every ratio the tracker multiplies into beta and r_u is then a spectrum of four EQUAL components
+// divided by its own first component, i.e. 1 up to rounding — the general code multiplies by (1 +- 3 ulp) per collision, this
+// instantiation leaves beta and r_u alone (they stay in memory, not in registers), carries r_l's rescaling as one float, needs no
+// wavelengths and no exp at a cell boundary.  Every DECISION (free-flight distance, absorb / scatter / null, termination) is taken on
+// the same first-component arithmetic as in the general code, so the collision sequence of a path is identical.
+template <int MM, bool GREY = false>
+__global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_per_eu(GREY ? 3 : HK_MEDIA_WAVES))) k_track(DPathState st, DScene sc, DTables T, DFrame fr, int depth, DStats* stats, const DMedium* __restrict__ media) {
+    // `media` == sc.media: a restrict-qualified kernel argument, so the record of a wave-uniform medium index is read with scalar loads
     const int lane = lane_id();
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     unsigned n_coll = 0, n_dda = 0;
@@ -839,6 +847,8 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
         uint32_t slot = 0, pslot = 0;   // generation index of the lane's path; its path slot (pixel-sample id: where L lives)
         v3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 1), cur_o = mk3(0, 0, 0);
         S4 lambda = s4(0.0f), beta = s4(0.0f), r_u = s4(0.0f), r_l = s4(0.0f), base_a = s4(0.0f), base_s = s4(0.0f), base_Le = s4(0.0f), sm = s4(0.0f);
+        float a0 = 0.0f, s0 = 0.0f, rl_f = 1.0f;   // GREY: the flat sigma_a / sigma_s values, the factor r_l has picked up so far
+        bool dead_null = false;                    // GREY: beta or r_u is black (the general code notices at the first null collision / at the end)
         uint64_t rng = 0;
         MajorantIter it = exhausted_iter();
         float seg1 = 0.0f, sm0 = 0.0f, t = 0.0f;
@@ -847,7 +857,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
         int k_in_seg = 0, segi = 0, medium_idx = 0;
         for (;;) {
             const unsigned long long busy_m = __ballot(state == TR_BUSY);
-            if (busy_m == 0ull || (64 - __popcll(busy_m) >= HK_REFILL_MIN_IDLE && (cursor < n || more))) {
+            if (busy_m == 0ull || (64 - __popcll(busy_m) >= fr.refill_idle && (cursor < n || more))) {
                 // ---- route the finished paths into the queues of their own segment ----
 #pragma unroll
                 for (int tg = 0; tg < 2; ++tg) {
@@ -913,14 +923,23 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
                     const uint2 meta = g.meta[slot];
                     medium_idx = (int)(meta.x >> 16) - 1;
                     pslot = meta.y;
-                    const DMedium& med = sc.media[medium_idx];
-                    lambda = ld4(&g.lambda[slot]);
-                    beta = ld_throughput(g.beta, slot, ones);
-                    r_u = ld_throughput(g.r_u, slot, ones);
-                    r_l = ld_throughput(g.r_l, slot, ones);
-                    base_a = eval_scaled(med.sigma_a, lambda);
-                    base_s = eval_scaled(med.sigma_s, lambda);
-                    if (HK_HAS_MEDIUM(MM, HK_MEDIUM_HOMOGENEOUS)) base_Le = eval_scaled(med.Le, lambda);
+                    const DMedium& med = sc.n_media == 1 ? media[0] : media[medium_idx];
+                    if constexpr (GREY) {
+                        a0 = eval_flat(med.sigma_a);
+                        s0 = eval_flat(med.sigma_s);
+                        base_a = s4(a0);
+                        base_s = s4(s0);
+                        rl_f = 1.0f;
+                        dead_null = is_black(ld_throughput(g.beta, slot, ones)) || is_black(ld_throughput(g.r_u, slot, ones));
+                    } else {
+                        lambda = ld4(&g.lambda[slot]);
+                        beta = ld_throughput(g.beta, slot, ones);
+                        r_u = ld_throughput(g.r_u, slot, ones);
+                        r_l = ld_throughput(g.r_l, slot, ones);
+                        base_a = eval_scaled(med.sigma_a, lambda);
+                        base_s = eval_scaled(med.sigma_s, lambda);
+                        if (HK_HAS_MEDIUM(MM, HK_MEDIUM_HOMOGENEOUS)) base_Le = eval_scaled(med.Le, lambda);
+                    }
                     rng = lcg_init(ro, rd, t_max);
                     it = create_majorant_iterator<MM>(med, ro, rd, t_max);
                     in_seg = false;
@@ -942,7 +961,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
             while (todo) {
                 const int m_uniform = __builtin_amdgcn_readlane(medium_idx, __ffsll((long long)todo) - 1);
                 const bool mine = state == TR_BUSY && medium_idx == m_uniform;
-                const DMedium& med = sc.media[m_uniform];
+                const DMedium& med = media[m_uniform];
                 // ---- phase A: cheap steps (next majorant cell, free-flight sample, cell-boundary crossing) until every busy lane
                 //      either holds a tentative collision or has run out of segments ----
     #pragma unroll 1
@@ -973,13 +992,15 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
                         pend_dt = -media_logf(maxf(1e-10f, 1.0f - u)) / sm0;
                         float ts = t + pend_dt;
                         if (ts >= seg1) {
-                            float dr = seg1 - t;
-                            S4 Tm = s4exp((-dr) * sm);
-                            float T0 = Tm.x;
-                            if (T0 > 1e-10f) {
-                                beta = div4(beta * Tm, T0);
-                                r_u = div4(r_u * Tm, T0);
-                                r_l = div4(r_l * Tm, T0);
+                            if constexpr (!GREY) {   // GREY: T_maj / T_maj[1] = 1, nothing changes
+                                float dr = seg1 - t;
+                                S4 Tm = s4exp((-dr) * sm);
+                                float T0 = Tm.x;
+                                if (T0 > 1e-10f) {
+                                    beta = div4(beta * Tm, T0);
+                                    r_u = div4(r_u * Tm, T0);
+                                    r_l = div4(r_l * Tm, T0);
+                                }
                             }
                             in_seg = false;
                         } else
@@ -987,7 +1008,38 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
                     }
                 }
                 // ---- phase B: the tentative collisions (medium lookup, absorb / scatter / null) ----
-                if (mine && state == TR_BUSY && pending) {
+                if (GREY && mine && state == TR_BUSY && pending) {
+                    pending = false;
+                    const float dt = pend_dt;
+                    const float Tm0 = media_expf((-dt) * sm0);
+                    const v3 p = cur_o + rd * dt;
+                    ++n_coll;
+                    const float d = sample_density<MM>(med, p);
+                    const float sa = a0 * d, ss = s0 * d;
+                    const float p_absorb = sa / sm0, p_scatter = ss / sm0;
+                    const float ue = lcg_next(rng);
+                    if (ue < p_absorb) {
+                        state = TR_EMPTY;  // absorbed
+                    } else if (ue < p_absorb + p_scatter) {
+                        if (depth >= fr.max_depth)
+                            state = TR_EMPTY;
+                        else {   // beta and r_u are rescaled by sigma_s T_maj / (sigma_s T_maj)[1] = 1: they stay as they are in the record
+                            g.ray_o[slot] = make_float4(p.x, p.y, p.z, INF_F);  // the scattering vertex: k_scatter continues from here
+                            state = TR_SCATTER;
+                        }
+                    } else {
+                        const float sn0 = maxf(sm0 - sa - ss, 0.0f);
+                        const float pdf = Tm0 * sn0;
+                        if (pdf > 1e-10f) {
+                            rl_f = ((rl_f * Tm0) * sm0) * (1.0f / pdf);
+                            t = t + dt;
+                            cur_o = p;
+                            if (dead_null) state = TR_EMPTY;
+                        } else
+                            state = TR_EMPTY;
+                    }
+                }
+                if (!GREY && mine && state == TR_BUSY && pending) {
                     pending = false;
                     const float dt = pend_dt;
                     const float ts = t + dt;
@@ -1038,11 +1090,15 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
             }
             if (survived) {
                 state = TR_EMPTY;
-                if (!(is_black(beta) || is_black(r_u) || depth >= fr.max_depth)) {
+                if (!((GREY ? dead_null : (is_black(beta) || is_black(r_u))) || depth >= fr.max_depth)) {
                     // survived to t_max: hand the stored surface hit / the escape over with the updated throughput
-                    st4(&g.beta[slot], beta);
-                    st4(&g.r_u[slot], r_u);
-                    st4(&g.r_l[slot], r_l);
+                    if constexpr (GREY) {
+                        st4(&g.r_l[slot], ld_throughput(g.r_l, slot, ones) * rl_f);
+                    } else {
+                        st4(&g.beta[slot], beta);
+                        st4(&g.r_u[slot], r_u);
+                        st4(&g.r_l[slot], r_l);
+                    }
                     float4 H = st.hit[slot];
                     const int prim = __float_as_int(H.y);
                     if (prim < 0)
@@ -1578,6 +1634,12 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
 //                  together for all lanes that need one, and finished lanes pull the next shadow ray of the wave's queue.
 // ---------------------------------------------------------------------------------------------------
 // rec: index of the shadow record (segment * wave_cap + position in the segment's shadow queue)
+template <class W> HKD W wone();
+template <> HKD float wone<float>() { return 1.0f; }
+template <> HKD S4 wone<S4>() { return s4(1.0f); }
+HKD S4 wide(S4 v) { return v; }
+HKD S4 wide(float v) { return s4(v); }
+HKD bool is_black(float v) { return v == 0.0f; }
 template <bool COMPACT>
 HKD void shadow_contribute(DPathState& st, uint32_t rec, S4 T_ray, S4 tr_u, S4 tr_l) {
     if (is_black(T_ray)) return;
@@ -1663,6 +1725,9 @@ __global__ void __launch_bounds__(BLOCK) k_shadow(DPathState st, DScene sc, int 
     }
 }
 
+#ifndef HK_GREY_WALK_WAVES
+#define HK_GREY_WALK_WAVES 4
+#endif
 enum { SH_EMPTY = 0, SH_CAST = 1, SH_TRACK = 2 };
 #ifndef HK_SHADOW_FEED_ROUNDS
 #define HK_SHADOW_FEED_ROUNDS 3
@@ -1671,8 +1736,11 @@ enum { SH_EMPTY = 0, SH_CAST = 1, SH_TRACK = 2 };
 #define HK_SHADOW_TRACK_BATCH 4
 #endif
 
-template <bool COUNT, int MM, int STACK = HK_LDS_STACK>
-__global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TRACE_BLOCK), amdgpu_waves_per_eu(MM == 0 ? 4 : (MM == 8 || MM == 2 || MM == 1) ? 3 : HK_MEDIA_WAVES))) k_shadow_walk(DPathState st, DScene sc, DTables T, int depth, int tune, DStats* stats) {
+// GREY: see k_track — the transmittance ratios of a flat-spectrum medium have four equal components, so T_ray, r_u, r_l and the
+// per-segment ratio-tracking state are one float each (same operations, in the same order, as the general code performs on the
+// first component), no wavelengths are fetched, and a cell boundary costs nothing.
+template <bool COUNT, int MM, int STACK = HK_LDS_STACK, bool GREY = false>
+__global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TRACE_BLOCK), amdgpu_waves_per_eu(MM == 0 ? 4 : GREY ? HK_GREY_WALK_WAVES : (MM == 8 || MM == 2 || MM == 1) ? 3 : HK_MEDIA_WAVES))) k_shadow_walk(DPathState st, DScene sc, DTables T, int depth, int tune, DStats* stats, const DMedium* __restrict__ media) {
     __shared__ int lds_stack[(HK_TRACE_BLOCK / 64) * STACK * 64];
     int* stack = lds_stack + (threadIdx.x >> 6) * (STACK * 64);
     const int lane = lane_id();
@@ -1689,9 +1757,13 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
     float t_remaining = 0.0f, hit_t = 0.0f;
     int medium = -1, next_medium = -1, seg = 0;
     bool miss_case = false, transition = false;
-    S4 T_ray = s4(1.0f), tr_u = s4(1.0f), tr_l = s4(1.0f), lambda = s4(0.0f);
+    using W = typename std::conditional<GREY, float, S4>::type;   // a spectral weight: four wavelengths, or one value for all four
+    W T_ray = wone<W>(), tr_u = wone<W>(), tr_l = wone<W>();
+    S4 lambda = s4(0.0f);
     // ratio-tracking state of the current medium segment
-    S4 sT = s4(1.0f), su = s4(1.0f), sl = s4(1.0f), base_a = s4(0.0f), base_s = s4(0.0f), base_Le = s4(0.0f), sm = s4(0.0f);
+    W sT = wone<W>(), su = wone<W>(), sl = wone<W>();
+    S4 base_a = s4(0.0f), base_s = s4(0.0f), base_Le = s4(0.0f), sm = s4(0.0f);
+    float a0 = 0.0f, s0 = 0.0f;   // GREY: the flat sigma_a / sigma_s values
     MajorantIter it = exhausted_iter();
     PCG32 rng = PCG32{0ull, 0ull};
     float seg1 = 0.0f, sm0 = 0.0f, t = 0.0f;
@@ -1702,7 +1774,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
     for (;;) {
         // ---- refill ----
         const unsigned long long busy_m = __ballot(state != SH_EMPTY);
-        if (busy_m == 0ull || (64 - __popcll(busy_m) >= HK_REFILL_MIN_IDLE && (cursor < n || more))) {
+        if (busy_m == 0ull || (64 - __popcll(busy_m) >= (tune >> 24) && (cursor < n || more))) {
             while (more && cursor >= n) {   // this segment is used up: go on with the next one, the lanes in flight keep running
                 const int gw = stream_next(stream, st.n_waves);
                 if (gw >= st.n_waves) {
@@ -1723,10 +1795,10 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
                 dir = mk3(D.x, D.y, D.z);
                 t_remaining = O.w;
                 medium = __float_as_int(D.w);
-                T_ray = s4(1.0f);
-                tr_u = s4(1.0f);
-                tr_l = s4(1.0f);
-                if (MM != 0) lambda = ld4(&st.lambda_s[st.sh_slot[slot]]);
+                T_ray = wone<W>();
+                tr_u = wone<W>();
+                tr_l = wone<W>();
+                if (MM != 0 && !GREY) lambda = ld4(&st.lambda_s[st.sh_slot[slot]]);
                 seg = 0;
                 state = t_remaining < 1e-6f ? SH_EMPTY : SH_CAST;  // a degenerate ray is simply not visible
             }
@@ -1741,7 +1813,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
         {
             const unsigned long long cast_m = __ballot(state == SH_CAST);
             const unsigned long long track_m = __ballot(state == SH_TRACK);
-            if (cast_m != 0ull && (track_m == 0ull || __popcll(cast_m) >= HK_REFILL_MIN_IDLE)) {
+            if (cast_m != 0ull && (track_m == 0ull || __popcll(cast_m) >= ((tune >> 24) < 8 ? (tune >> 24) : 8))) {
                 HK_DBG(0, state == SH_CAST);
                 if (state == SH_CAST) {
                     bool opaque;
@@ -1780,13 +1852,20 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
                         state = SH_EMPTY;  // blocked
                     else if (MM != 0 && medium >= 0) {
                         // ratio tracking over [0, hit_t] of this segment (intersection.jl:326-336, 376-386)
-                        const DMedium& m = sc.media[medium];
-                        sT = s4(1.0f);
-                        su = s4(1.0f);
-                        sl = s4(1.0f);
-                        base_a = eval_scaled(m.sigma_a, lambda);
-                        base_s = eval_scaled(m.sigma_s, lambda);
-                        if (HK_HAS_MEDIUM(MM, HK_MEDIUM_HOMOGENEOUS)) base_Le = eval_scaled(m.Le, lambda);
+                        const DMedium& m = sc.n_media == 1 ? media[0] : media[medium];
+                        sT = wone<W>();
+                        su = wone<W>();
+                        sl = wone<W>();
+                        if constexpr (GREY) {
+                            a0 = eval_flat(m.sigma_a);
+                            s0 = eval_flat(m.sigma_s);
+                            base_a = s4(a0);
+                            base_s = s4(s0);
+                        } else {
+                            base_a = eval_scaled(m.sigma_a, lambda);
+                            base_s = eval_scaled(m.sigma_s, lambda);
+                            if (HK_HAS_MEDIUM(MM, HK_MEDIUM_HOMOGENEOUS)) base_Le = eval_scaled(m.Le, lambda);
+                        }
                         it = create_majorant_iterator<MM>(m, ro, dir, hit_t);
                         rng = pcg32_init(pbrt_hash(ro), pbrt_hash(dir));
                         in_seg = false;
@@ -1795,7 +1874,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
                         segi = 0;
                         state = SH_TRACK;
                     } else if (miss_case) {
-                        shadow_contribute<MM == 0>(st, slot, T_ray, tr_u, tr_l);
+                        shadow_contribute<MM == 0>(st, slot, wide(T_ray), wide(tr_u), wide(tr_l));
                         state = SH_EMPTY;
                     } else {
                         // step over the surface (no medium on this side)
@@ -1817,7 +1896,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
         //      tracking (the cloud's walk ran its collision rounds with 28 % of the lanes EMPTY although work was waiting) ----
         if (MM != 0 && feed_rounds < ((tune >> 16) & 0xff)) {
             const int waiting = __popcll(__ballot(state == SH_EMPTY)) + __popcll(__ballot(state == SH_CAST));
-            if (waiting >= HK_REFILL_MIN_IDLE && (cursor < n || more)) {
+            if (waiting >= (tune >> 24) && (cursor < n || more)) {
                 ++feed_rounds;
                 continue;
             }
@@ -1830,7 +1909,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
             while (todo) {
                 const int m_uniform = __builtin_amdgcn_readlane(medium, __ffsll((long long)todo) - 1);
                 const bool mine = state == SH_TRACK && medium == m_uniform;
-                const DMedium& med = sc.media[m_uniform];
+                const DMedium& med = media[m_uniform];
 #pragma unroll 1
                 for (int batch = 0; batch < (tune & 0xff); ++batch) {
                     if (__ballot(mine && state == SH_TRACK) == 0ull) break;
@@ -1867,13 +1946,15 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
                             pend_dt = -media_logf(maxf(1e-10f, 1.0f - u)) / sm0;
                             float ts = t + pend_dt;
                             if (ts >= seg1) {
-                                float dr = seg1 - t;
-                                S4 Tm = s4exp((-dr) * sm);
-                                float T0 = Tm.x;
-                                if (T0 > 1e-10f) {
-                                    sT = div4(sT * Tm, T0);
-                                    sl = div4(sl * Tm, T0);
-                                    su = div4(su * Tm, T0);
+                                if constexpr (!GREY) {   // GREY: T_maj / T_maj[1] = 1, nothing changes
+                                    float dr = seg1 - t;
+                                    S4 Tm = s4exp((-dr) * sm);
+                                    float T0 = Tm.x;
+                                    if (T0 > 1e-10f) {
+                                        sT = div4(sT * Tm, T0);
+                                        sl = div4(sl * Tm, T0);
+                                        su = div4(su * Tm, T0);
+                                    }
                                 }
                                 in_seg = false;
                                 after_inner = true;
@@ -1885,7 +1966,40 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
                     HK_DBG(3, state == SH_TRACK);
                     HK_DBG(4, state == SH_CAST);
                     HK_DBG(5, state == SH_EMPTY);
-                    if (mine && state == SH_TRACK && pending) {
+                    if (GREY && mine && state == SH_TRACK && pending) {
+                        if constexpr (GREY) {
+                            pending = false;
+                            const float dt = pend_dt;
+                            const float ts = t + dt;
+                            ++n_coll;
+                            const float d = sample_density<MM>(med, ro + dir * ts);
+                            const float sn0 = maxf(sm0 - a0 * d - s0 * d, 0.0f);
+                            const float Tm0 = media_expf((-dt) * sm0);
+                            const float pr = Tm0 * sm0;
+                            if (pr > 1e-10f) {
+                                const float inv = 1.0f / pr;
+                                sT = ((sT * Tm0) * sn0) * inv;
+                                sl = ((sl * Tm0) * sm0) * inv;
+                                su = ((su * Tm0) * sn0) * inv;
+                                const float est = sT * (1.0f / maxf(1e-10f, average_flat(sl + su)));
+                                if (est < 0.05f) {
+                                    float rr = pcg32_f32(rng);
+                                    if (rr < 0.75f) {
+                                        sT = 0.0f;
+                                        track_done = true;
+                                    } else
+                                        sT = sT / (1.0f - 0.75f);
+                                }
+                                if (sT == 0.0f) track_done = true;
+                                t = ts;
+                            } else {
+                                sT = 0.0f;
+                                track_done = true;
+                            }
+                        }
+                    }
+                    if (!GREY && mine && state == SH_TRACK && pending) {
+                      if constexpr (!GREY) {
                         pending = false;
                         const float dt = pend_dt;
                         const float ts = t + dt;
@@ -1914,12 +2028,13 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
                             track_done = true;
                         }
                     }
+                    }
                     if (track_done) {
                         T_ray = T_ray * sT;
                         tr_u = tr_u * su;
                         tr_l = tr_l * sl;
                         if (miss_case) {
-                            shadow_contribute<MM == 0>(st, slot, T_ray, tr_u, tr_l);
+                            shadow_contribute<MM == 0>(st, slot, wide(T_ray), wide(tr_u), wide(tr_l));
                             state = SH_EMPTY;
                         } else {
                             bool stop = false;
@@ -1948,6 +2063,404 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
         wave_add(&stats->sh_nodes, n_nodes);
         wave_add(&stats->sh_tris, n_tris);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K10 of a scene whose (single) medium is GREY, SPLIT in two kernels.  k_shadow_walk carries the registers of the
+// BVH traversal and of the ratio tracker together (128 VGPRs with spills at 4 waves per SIMD) and these loops are bound by instruction
+// issue at low residency; the two halves never need each other's state:
+//   k_walk_cast   one any-hit-style cast per record (LDS stacks + the scene's nodes and triangles in LDS, like k_trace), the surface
+//                 logic of intersection.jl:316-406; a ray that has to cross a medium is parked in its record and queued for
+//   k_walk_track  ratio tracking through the medium up to the surface found by the cast (intersection.jl:422-542): a flat state
+//                 machine without traversal state; a ray that goes on behind the surface is queued for the next cast round.
+// Rounds alternate cast(0), track(0), cast(1), ... on the host side (HK_WALK_ROUNDS casts: the reference walks <= 10 segments).
+// Round 0 streams the shadow records of the wave segments like k_shadow_walk; later rounds read GLOBAL index queues filled with one
+// atomic per wave and push: the order of the queue does not matter to the result, because a path slot receives at most one shadow
+// contribution per depth (one NEE sample per vertex) — no two records of a launch add to the same L.
+// In-flight state of a record: sh_o = (origin, t_remaining), sh_d = (direction, medium), sh_T = (T_ray, r_u, r_l, hit_t),
+// sh_aux = segments | miss << 8 | transition << 9 | (next medium + 1) << 16.
+// Same arithmetic per ray as k_shadow_walk<.., GREY = true>: films are bit-identical (tests: HK_WALK_SPLIT=0 against 1).
+// ---------------------------------------------------------------------------------------------------
+#define HK_WALK_ROUNDS 10
+HKD int* walk_ctl(const DPathState& st, int depth, int round) { return st.wq_ctl + (size_t)(depth * (HK_WALK_ROUNDS + 1) + round) * 4; }   // {count A, cursor A, count B, cursor B}
+// A global queue is written and read in wave-private CHUNKS: one atomic on the queue's count / cursor per chunk, not per push
+// (the first version paid one atomic per refill round and push — 90 M same-address atomics per frame: the tracking half alone took
+// longer than the whole unsplit walk).  A writer reserves HK_GQ_CHUNK entries at a time and pads what it leaves unused with
+// HK_GQ_NONE, which readers skip; a reader takes chunks sized to the queue (n / (8 x waves), 64 ... 4096 entries).
+#define HK_GQ_CHUNK 256
+#define HK_GQ_NONE 0xffffffffu
+struct GQOut {
+    uint32_t* q;
+    int* count;
+    int base, used, cap;
+};
+HKD GQOut gq_out_open(uint32_t* q, int* count) { return GQOut{q, count, 0, 0, 0}; }
+HKD void gq_out_pad(GQOut& o) {
+    for (int i = o.used + lane_id(); i < o.cap; i += 64) o.q[o.base + i] = HK_GQ_NONE;
+}
+HKD void gq_out_push(GQOut& o, uint32_t value, bool active) {   // called by the whole wave
+    const unsigned long long m = __ballot(active);
+    const int k = __popcll(m);
+    if (k == 0) return;
+    if (o.used + k > o.cap) {
+        gq_out_pad(o);
+        int b = 0;
+        if (lane_id() == 0) b = atomicAdd(o.count, HK_GQ_CHUNK);
+        o.base = __builtin_amdgcn_readfirstlane(b);
+        o.used = 0;
+        o.cap = HK_GQ_CHUNK;
+    }
+    if (active) o.q[o.base + o.used + __popcll(m & ((1ull << lane_id()) - 1ull))] = value;
+    o.used += k;
+}
+struct GQIn {
+    const uint32_t* q;
+    int* cursor;
+    int n, lo, hi, chunk;
+    bool more;
+};
+HKD GQIn gq_in_open(const uint32_t* q, int* cursor, int n) {
+    int chunk = (n / (8 * physical_waves()) + 63) & ~63;
+    chunk = chunk < 64 ? 64 : (chunk > 4096 ? 4096 : chunk);
+    return GQIn{q, cursor, n, 0, 0, chunk, n > 0};
+}
+// the next entries of the wave's chunk for the lanes with `want` (lane rank r gets entry lo + r); -> false once the queue is used up
+HKD bool gq_in_take(GQIn& in, bool want, uint32_t& value, bool& got) {
+    got = false;
+    while (in.lo >= in.hi && in.more) {
+        int b = 0;
+        if (lane_id() == 0) b = atomicAdd(in.cursor, in.chunk);
+        b = __builtin_amdgcn_readfirstlane(b);
+        if (b >= in.n)
+            in.more = false;
+        else {
+            in.lo = b;
+            in.hi = b + in.chunk < in.n ? b + in.chunk : in.n;
+        }
+    }
+    if (in.lo >= in.hi) return false;
+    const unsigned long long m = __ballot(want);
+    const int rank = __popcll(m & ((1ull << lane_id()) - 1ull));
+    const int avail = in.hi - in.lo, k = __popcll(m);
+    if (want && rank < avail) {
+        value = in.q[in.lo + rank];
+        got = value != HK_GQ_NONE;
+    }
+    in.lo += k < avail ? k : avail;
+    return true;
+}
+
+template <bool COUNT, int MM, int STACK>
+__global__ void __launch_bounds__(HK_TRACE_BLOCK) k_walk_cast(DPathState st, DScene sc, int depth, int round, DStats* stats, const DMedium* __restrict__ media) {
+    __shared__ int lds_stack[(HK_TRACE_BLOCK / 64) * STACK * 64];
+    __shared__ float4 lds_box[3 * HK_MEDIA_NC];
+    __shared__ int2 lds_child[HK_MEDIA_NC];
+    __shared__ float4 lds_tri[3 * HK_MEDIA_NT];
+    int* stack = lds_stack + (threadIdx.x >> 6) * (STACK * 64);
+    int* ctl = walk_ctl(st, depth, round);
+    if (round > 0 && ctl[0] == 0) return;   // nothing was queued for this round (uniform: before the block's barrier)
+    const NodeCache cache = scene_cache_fill<HK_MEDIA_NC, HK_MEDIA_NT, HK_TRACE_BLOCK>(sc, lds_box, lds_child, lds_tri);
+    const int lane = lane_id();
+    unsigned n_nodes = 0, n_tris = 0, n_casts = 0, n_hits = 0;
+    SegStream stream = stream_open(st, ticket_ptr(st, depth, TK_SHADOW), true, depth, Q_SHADOW);
+    uint32_t rec0 = 0;
+    int n = 0, cursor = 0;
+    GQIn in = gq_in_open(st.wq_a, &ctl[1], round > 0 ? ctl[0] : 0);
+    GQOut out = gq_out_open(st.wq_b, &ctl[2]);
+    for (;;) {
+        // ---- the next 64 records ----
+        uint32_t rec = 0;
+        bool have = false;
+        if (round == 0) {
+            if (cursor >= n) {
+                const int gw = stream_next(stream, st.n_waves);
+                if (gw >= st.n_waves) break;
+                rec0 = (uint32_t)gw * (uint32_t)st.wave_cap;
+                n = *count_ptr(st, depth, Q_SHADOW, gw);
+                cursor = 0;
+                continue;
+            }
+            have = cursor + lane < n;
+            rec = rec0 + (uint32_t)(cursor + lane);
+            cursor += 64;
+        } else if (!gq_in_take(in, true, rec, have))
+            break;
+        v3 ro = mk3(0, 0, 0), dir = mk3(0, 0, 1);
+        float t_remaining = 0.0f, T_ray = 1.0f, tr_u = 1.0f, tr_l = 1.0f;
+        int medium = -1, seg = 0;
+        if (have) {
+            const float4 O = st.sh_o[rec], D = st.sh_d[rec];
+            ro = mk3(O.x, O.y, O.z);
+            dir = mk3(D.x, D.y, D.z);
+            t_remaining = O.w;
+            medium = __float_as_int(D.w);
+            if (round > 0) {
+                const float4 Tq = st.sh_T[rec];
+                T_ray = Tq.x, tr_u = Tq.y, tr_l = Tq.z;
+                seg = (int)(st.sh_aux[rec] & 0xffu);
+            }
+        }
+        bool active = have && !(t_remaining < 1e-6f);   // a degenerate ray is simply not visible
+        // ---- casts; a ray that meets a surface outside every medium steps over it and casts again right here ----
+        while (__ballot(active) != 0ull) {
+            bool park = false;
+            if (active) {
+                bool opaque;
+                ++n_casts;
+                HitRec h = traverse<1, COUNT, HK_MEDIA_NC, HK_MEDIA_NT>(sc, ro, dir, t_remaining, stack, lane, n_nodes, n_tris, opaque, cache);
+                bool alive = true, miss_case = true, transition = false;
+                int next_medium = medium;
+                float hit_t = t_remaining;
+                if (h.prim >= 0) {
+                    ++n_hits;
+                    miss_case = false;
+                    hit_t = h.t;
+                    if (opaque)
+                        alive = false;
+                    else {
+                        DTriMeta meta = sc.meta[h.prim];
+                        DMediumInterface mi = sc.mis[meta.mi];
+                        v3 ng = geometric_normal(sc, h.prim);
+                        bool entering = dot(dir, ng) < 0.0f;
+                        transition = mi.inside != mi.outside;
+                        next_medium = transition ? (entering ? mi.inside : mi.outside) : medium;
+                        if (!transition) {
+                            float w = 1.0f - h.u - h.v;
+                            float alpha = surface_alpha(sc, mi.material, uv_at(sc, h.prim, w, h.u, h.v));
+                            bool pass = false;
+                            if (alpha < 1.0f) {
+                                PCG32 arng = pcg32_init(pbrt_hash(ro), pbrt_hash(dir));
+                                pass = pcg32_f32(arng) > alpha;
+                            }
+                            alive = pass;
+                        }
+                    }
+                }
+                if (!alive)
+                    active = false;  // blocked
+                else if (medium >= 0) {
+                    // ratio tracking over [0, hit_t] comes next: park the ray in its record
+                    st.sh_o[rec] = make_float4(ro.x, ro.y, ro.z, t_remaining);
+                    st.sh_d[rec] = make_float4(dir.x, dir.y, dir.z, __int_as_float(medium));
+                    st.sh_T[rec] = make_float4(T_ray, tr_u, tr_l, hit_t);
+                    st.sh_aux[rec] = (uint32_t)seg | (miss_case ? 0x100u : 0u) | (transition ? 0x200u : 0u) | ((uint32_t)(next_medium + 1) << 16);
+                    // the tracker's per-ray set-up (majorant iterator: three divisions per axis; two 64-bit hashes for the PCG32 seed) is
+                    // done HERE, where every lane of the wave has a ray, and handed over in the record: inside the tracking state
+                    // machine it ran on the ~25 lanes of a refill round and cost as much as five collisions
+                    const MajorantIter it = create_majorant_iterator<MM>(media[0], ro, dir, hit_t);
+                    const PCG32 rng = pcg32_init(pbrt_hash(ro), pbrt_hash(dir));
+                    float4* itp = st.sh_it + 4 * (size_t)rec;
+                    itp[0] = make_float4(it.next_t[0], it.next_t[1], it.next_t[2], it.t_min);
+                    itp[1] = make_float4(it.delta_t[0], it.delta_t[1], it.delta_t[2], it.t_max);
+                    itp[2] = make_float4(__int_as_float(it.voxel[0]), __int_as_float(it.voxel[1]), __int_as_float(it.voxel[2]), __int_as_float(it.mode));
+                    itp[3] = make_float4(__uint_as_float((uint32_t)rng.state), __uint_as_float((uint32_t)(rng.state >> 32)), __uint_as_float((uint32_t)rng.inc),
+                                         __uint_as_float((uint32_t)(rng.inc >> 32)));
+                    park = true;
+                    active = false;
+                } else if (miss_case) {
+                    shadow_contribute<false>(st, rec, s4(T_ray), s4(tr_u), s4(tr_l));
+                    active = false;
+                } else {
+                    // step over the surface (no medium on this side)
+                    bool stop = false;
+                    if (transition) {
+                        if (T_ray == 0.0f) stop = true;
+                        medium = next_medium;
+                    }
+                    ro = ro + dir * (hit_t + 1e-4f);
+                    t_remaining = t_remaining - hit_t - 1e-4f;
+                    ++seg;
+                    active = !(stop || seg >= 10 || t_remaining < 1e-6f);
+                }
+            }
+            gq_out_push(out, rec, park);
+        }
+    }
+    gq_out_pad(out);
+    stats += global_wave();
+    wave_add(&stats->rays_shadow, n_casts);
+    wave_add(&stats->hits, n_hits);
+    if (COUNT) {
+        wave_add(&stats->sh_nodes, n_nodes);
+        wave_add(&stats->sh_tris, n_tris);
+    }
+}
+
+#ifndef HK_WALK_TRACK_WAVES
+#define HK_WALK_TRACK_WAVES 5
+#endif
+template <int MM>
+__global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_per_eu(HK_WALK_TRACK_WAVES))) k_walk_track(DPathState st, DScene sc, int depth, int round, int tune, DStats* stats,
+                                                                                                                               const DMedium* __restrict__ media) {
+    int* ctl = walk_ctl(st, depth, round);
+    int* ctl_next = walk_ctl(st, depth, round + 1);
+    const int n = ctl[2];
+    if (n == 0) return;
+    const DMedium& med = media[0];   // GREY scenes hold one medium
+    const float a0 = eval_flat(med.sigma_a), s0 = eval_flat(med.sigma_s);
+    const S4 sigma_t = s4(a0 + s0);
+    const int refill_idle = tune >> 24, adv_rounds = (tune >> 8) & 0xff, batches = tune & 0xff;
+    unsigned n_coll = 0, n_dda = 0;
+    HK_DBG_DECL
+    GQIn in = gq_in_open(st.wq_b, &ctl[3], n);
+    GQOut out = gq_out_open(st.wq_a, &ctl_next[0]);
+    // per-lane state
+    bool busy = false, in_seg = false, pending = false;
+    uint32_t rec = 0;
+    v3 ro = mk3(0, 0, 0), dir = mk3(0, 0, 1);
+    float T_ray = 1.0f, tr_u = 1.0f, tr_l = 1.0f, hit_t = 0.0f, t_remaining = 0.0f;
+    float sT = 1.0f, su = 1.0f, sl = 1.0f, sm0 = 0.0f, seg1 = 0.0f, t = 0.0f, pend_dt = 0.0f;
+    uint32_t aux = 0;
+    int k_in_seg = 0, segi = 0;
+    MajorantIter it = exhausted_iter();
+    PCG32 rng = PCG32{0ull, 0ull};
+    for (;;) {
+        // ---- refill ----
+        const unsigned long long busy_m = __ballot(busy);
+        const bool can_refill = in.more || in.lo < in.hi;
+        if (busy_m == 0ull || (can_refill && 64 - __popcll(busy_m) >= refill_idle)) {
+            if (!can_refill) break;
+            uint32_t r_new = 0;
+            bool got = false;
+            gq_in_take(in, !busy, r_new, got);
+            HK_DBG(5, got);
+            if (got) {
+                rec = r_new;
+                const float4 O = st.sh_o[rec], D = st.sh_d[rec], Tq = st.sh_T[rec];
+                aux = st.sh_aux[rec];
+                ro = mk3(O.x, O.y, O.z);
+                dir = mk3(D.x, D.y, D.z);
+                t_remaining = O.w;
+                T_ray = Tq.x, tr_u = Tq.y, tr_l = Tq.z, hit_t = Tq.w;
+                sT = su = sl = 1.0f;
+                {   // iterator and RNG as k_walk_cast set them up
+                    const float4* itp = st.sh_it + 4 * (size_t)rec;
+                    const float4 I0 = itp[0], I1 = itp[1], I2 = itp[2], I3 = itp[3];
+                    it.next_t[0] = I0.x, it.next_t[1] = I0.y, it.next_t[2] = I0.z, it.t_min = I0.w;
+                    it.delta_t[0] = I1.x, it.delta_t[1] = I1.y, it.delta_t[2] = I1.z, it.t_max = I1.w;
+                    it.voxel[0] = __float_as_int(I2.x), it.voxel[1] = __float_as_int(I2.y), it.voxel[2] = __float_as_int(I2.z), it.mode = __float_as_int(I2.w);
+                    rng.state = (uint64_t)__float_as_uint(I3.x) | ((uint64_t)__float_as_uint(I3.y) << 32);
+                    rng.inc = (uint64_t)__float_as_uint(I3.z) | ((uint64_t)__float_as_uint(I3.w) << 32);
+                }
+                in_seg = false;
+                pending = false;
+                segi = 0;
+                busy = true;
+            }
+            if (__ballot(busy) == 0ull) {
+                if (!(in.more || in.lo < in.hi)) break;
+                continue;
+            }
+        }
+#pragma unroll 1
+        for (int batch = 0; batch < batches; ++batch) {
+            bool done = false;
+            // ---- cheap steps until a tentative collision is pending: next majorant cell; free-flight sample inside a cell ----
+#pragma unroll 1
+            for (int adv = 0; adv < adv_rounds; ++adv) {
+                const bool need = busy && !pending && !done;
+                if (__ballot(need) == 0ull) break;
+                HK_DBG(0, need);
+                HK_DBG(1, need && !in_seg);
+                HK_DBG(2, need && in_seg);
+                if (need && !in_seg) {
+                    float seg0;
+                    S4 sm;
+                    if (segi >= 256 || !majorant_next<MM>(it, med, sigma_t, seg0, seg1, sm))
+                        done = true;
+                    else {
+                        ++segi;
+                        ++n_dda;
+                        sm0 = sm.x;
+                        const bool enter = sm0 >= 1e-10f;
+                        t = enter ? seg0 : t;
+                        in_seg = enter;
+                        k_in_seg = enter ? 0 : k_in_seg;
+                    }
+                }
+                if (need && in_seg && !done) {   // in a cell with a non-zero majorant (also: just entered): the next tentative collision, or out through the cell's far side
+                    const bool over = k_in_seg >= 100;
+                    PCG32 r2 = rng;
+                    const float u = pcg32_f32(r2);
+                    rng = over ? rng : r2;
+                    k_in_seg += over ? 0 : 1;
+                    pend_dt = -media_logf(maxf(1e-10f, 1.0f - u)) / sm0;
+                    const bool leave = over || (t + pend_dt >= seg1);   // T_maj / T_maj[1] = 1 at the boundary: nothing else changes
+                    in_seg = !leave;
+                    pending = !leave;
+                }
+            }
+            // ---- the tentative collisions ----
+            HK_DBG(3, busy && pending);
+            HK_DBG(4, busy);
+            if (busy && pending) {
+                pending = false;
+                const float dt = pend_dt;
+                const float ts = t + dt;
+                ++n_coll;
+                const float d = sample_density<MM>(med, ro + dir * ts);
+                const float sn0 = maxf(sm0 - a0 * d - s0 * d, 0.0f);
+                const float Tm0 = media_expf((-dt) * sm0);
+                const float pr = Tm0 * sm0;
+                if (pr > 1e-10f) {
+                    const float inv = 1.0f / pr;
+                    sT = ((sT * Tm0) * sn0) * inv;
+                    sl = ((sl * Tm0) * sm0) * inv;
+                    su = ((su * Tm0) * sn0) * inv;
+                    const float est = sT * (1.0f / maxf(1e-10f, average_flat(sl + su)));
+                    if (est < 0.05f) {
+                        const float rr = pcg32_f32(rng);
+                        if (rr < 0.75f) {
+                            sT = 0.0f;
+                            done = true;
+                        } else
+                            sT = sT / (1.0f - 0.75f);
+                    }
+                    if (sT == 0.0f) done = true;
+                    t = ts;
+                } else {
+                    sT = 0.0f;
+                    done = true;
+                }
+            }
+            // ---- the end of this medium segment ----
+            bool requeue = false;
+            if (busy && done) {
+                busy = false;
+                T_ray = T_ray * sT;
+                tr_u = tr_u * su;
+                tr_l = tr_l * sl;
+                if (aux & 0x100u)   // the cast ended at the light: deliver
+                    shadow_contribute<false>(st, rec, s4(T_ray), s4(tr_u), s4(tr_l));
+                else {
+                    int seg = (int)(aux & 0xffu);
+                    int medium = 0;   // the ray was in the (only) medium
+                    bool stop = false;
+                    if (aux & 0x200u) {
+                        if (T_ray == 0.0f) stop = true;
+                        medium = (int)(aux >> 16) - 1;
+                    }
+                    ro = ro + dir * (hit_t + 1e-4f);
+                    t_remaining = t_remaining - hit_t - 1e-4f;
+                    ++seg;
+                    if (!(stop || seg >= 10 || t_remaining < 1e-6f)) {
+                        st.sh_o[rec] = make_float4(ro.x, ro.y, ro.z, t_remaining);
+                        st.sh_d[rec] = make_float4(dir.x, dir.y, dir.z, __int_as_float(medium));
+                        st.sh_T[rec] = make_float4(T_ray, tr_u, tr_l, 0.0f);
+                        st.sh_aux[rec] = (uint32_t)seg;
+                        requeue = true;
+                    }
+                }
+            }
+            gq_out_push(out, rec, requeue);
+            if (__ballot(busy) == 0ull) break;
+        }
+    }
+    gq_out_pad(out);
+    stats += global_wave();
+    HK_DBG_FLUSH(stats);
+    wave_add(&stats->sh_collisions, n_coll);
+    wave_add(&stats->sh_dda_steps, n_dda);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2499,23 +3012,55 @@ void launch_trace(hipStream_t s, int n_cu, const DPathState& st, const DScene& s
     else
         hipLaunchKernelGGL(k_trace<false>, dim3(clamp_blocks(b0, st)), dim3(HK_TRACE_BLOCK), 0, s, st, sc, T, fr, depth, stats);
 }
+static int grey_mode() {   // HK_GREY=0: flat-spectrum media run through the general tracking kernels (A/B switch, read per launch)
+    const char* e = std::getenv("HK_GREY");
+    return e ? std::atoi(e) : 1;
+}
 // media kernels are instantiated for a single medium kind or for all four (15)
 static int media_mask_class(const DScene& sc) {
     int m = sc.media_mask;
     return (m == 1 || m == 2 || m == 4 || m == 8) ? m : 15;
+}
+static int walk_split_mode() {   // HK_WALK_SPLIT=1: the grey medium's shadow walk runs as k_walk_cast / k_walk_track rounds instead of ONE k_shadow_walk<.., GREY>
+    const char* e = std::getenv("HK_WALK_SPLIT");   // (measured on the BOMEX stand-in: cast rounds 0.085 s + tracking rounds 0.45 s against 0.51 s unsplit — off by default)
+    return e ? std::atoi(e) : 0;
+}
+template <bool C, int MM>
+static void launch_walk_split(hipStream_t s, int n_cu, const DPathState& st, const DScene& sc, const DFrame& fr, int depth, DStats* stats) {
+    const int cb = clamp_blocks(cached_blocks<k_walk_cast<C, MM, 16>>(HK_TRACE_BLOCK, n_cu, 8), st);
+    const int tb = clamp_blocks(cached_blocks<k_walk_track<MM>>(256, n_cu, 8), st);
+    for (int round = 0; round < HK_WALK_ROUNDS; ++round) {
+        hipLaunchKernelGGL((k_walk_cast<C, MM, 16>), dim3(cb), dim3(HK_TRACE_BLOCK), 0, s, st, sc, depth, round, stats, sc.media);
+        hipLaunchKernelGGL((k_walk_track<MM>), dim3(tb), dim3(256), 0, s, st, sc, depth, round, fr.walk_tune, stats, sc.media);
+    }
 }
 void launch_shadow(hipStream_t s, int n_cu, const DPathState& st, const DScene& sc, const DTables& T, const DFrame& fr, int depth, DStats* stats) {
     if (sc.all_opaque && sc.n_media == 0) {
         HK_LEAN_DISPATCH(k_shadow, HK_TRACE_BLOCK, HK_SHADOW_NC16, HK_SHADOW_NC32)
         return;
     }
+    if (sc.all_grey && grey_mode() && walk_split_mode() && sc.bvh_depth <= 16 && st.wq_a != nullptr) {
+        const int mc = media_mask_class(sc);
+        if (mc == 8) {
+            if (fr.count_nodes) launch_walk_split<true, 8>(s, n_cu, st, sc, fr, depth, stats); else launch_walk_split<false, 8>(s, n_cu, st, sc, fr, depth, stats);
+            return;
+        }
+        if (mc == 2) {
+            if (fr.count_nodes) launch_walk_split<true, 2>(s, n_cu, st, sc, fr, depth, stats); else launch_walk_split<false, 2>(s, n_cu, st, sc, fr, depth, stats);
+            return;
+        }
+    }
 #define HK_SHADOW_LAUNCH(C, MM)                                                                                                        \
-    if (sc.bvh_depth <= 16) {   /* 16-entry stacks: 16 KB per block beside the 32 KB zero-cell mask */                               \
+    if (sc.bvh_depth <= 16 && (MM == 2 || MM == 8) && sc.all_grey && grey_mode()) {                                                  \
+        constexpr int M2 = (MM == 2 || MM == 8) ? MM : 8;                                                                              \
+        const int blocks = cached_blocks<k_shadow_walk<C, M2, 16, true>>(HK_TRACE_BLOCK, n_cu, 8);                                   \
+        hipLaunchKernelGGL((k_shadow_walk<C, M2, 16, true>), dim3(clamp_blocks(blocks, st)), dim3(HK_TRACE_BLOCK), 0, s, st, sc, T, depth, fr.walk_tune, stats, sc.media); \
+    } else if (sc.bvh_depth <= 16) {   /* 16-entry stacks: 16 KB per block */                                                       \
         const int blocks = cached_blocks<k_shadow_walk<C, MM, 16>>(HK_TRACE_BLOCK, n_cu, 8);                                         \
-        hipLaunchKernelGGL((k_shadow_walk<C, MM, 16>), dim3(clamp_blocks(blocks, st)), dim3(HK_TRACE_BLOCK), 0, s, st, sc, T, depth, fr.walk_tune, stats); \
+        hipLaunchKernelGGL((k_shadow_walk<C, MM, 16>), dim3(clamp_blocks(blocks, st)), dim3(HK_TRACE_BLOCK), 0, s, st, sc, T, depth, fr.walk_tune, stats, sc.media); \
     } else {                                                                                                                           \
         const int blocks = cached_blocks<k_shadow_walk<C, MM>>(HK_TRACE_BLOCK, n_cu, 8);                                             \
-        hipLaunchKernelGGL((k_shadow_walk<C, MM>), dim3(clamp_blocks(blocks, st)), dim3(HK_TRACE_BLOCK), 0, s, st, sc, T, depth, fr.walk_tune, stats); \
+        hipLaunchKernelGGL((k_shadow_walk<C, MM>), dim3(clamp_blocks(blocks, st)), dim3(HK_TRACE_BLOCK), 0, s, st, sc, T, depth, fr.walk_tune, stats, sc.media); \
     }
 #define HK_SHADOW_MM(C)                                   \
     switch (sc.n_media > 0 ? media_mask_class(sc) : 0) {  \
@@ -2550,16 +3095,18 @@ void launch_medium(hipStream_t s, int n_cu, const DPathState& st, const DScene& 
         const int d = depth, q = Q_MEDIUM;
         launch_segment_lists(s, st, 1, &d, &q);
     }
+#define COMMA ,
 #define HK_TRACK_LAUNCH(MM)                                                                                              \
     {                                                                                                                    \
         const int blocks = cached_blocks<k_track<MM>>(256, n_cu, 8);                                                   \
-        hipLaunchKernelGGL((k_track<MM>), dim3(clamp_blocks(blocks, st)), dim3(256), 0, s, st, sc, T, fr, depth, stats);   \
+        hipLaunchKernelGGL((k_track<MM>), dim3(clamp_blocks(blocks, st)), dim3(256), 0, s, st, sc, T, fr, depth, stats, sc.media);   \
     }
+    const bool grey = sc.all_grey && grey_mode();
     switch (media_mask_class(sc)) {
         case 1: HK_TRACK_LAUNCH(1) break;
-        case 2: HK_TRACK_LAUNCH(2) break;
+        case 2: if (grey) HK_TRACK_LAUNCH(2 COMMA true) else HK_TRACK_LAUNCH(2) break;
         case 4: HK_TRACK_LAUNCH(4) break;
-        case 8: HK_TRACK_LAUNCH(8) break;
+        case 8: if (grey) HK_TRACK_LAUNCH(8 COMMA true) else HK_TRACK_LAUNCH(8) break;
         default: HK_TRACK_LAUNCH(15) break;
     }
 #undef HK_TRACK_LAUNCH

@@ -173,6 +173,7 @@ struct DScene {
     int simple_lights;          // no ambient / environment light and no texture of any kind: k_shade<Matte, true> leaves those branches out
     int all_opaque;             // no medium transitions and no alpha-tested surfaces
     int bvh_depth;              // deepest BVH level (bounds the traversal stack)
+    int all_grey;               // every medium is a Grid / NanoVDB medium whose sigma_a and sigma_s are flat spectra (the GREY tracking kernels)
 };
 
 struct DTables {
@@ -258,6 +259,13 @@ struct DPathState {
     float4* sh_ru;
     float4* sh_rl;
     uint32_t* sh_slot;     // path slot whose L receives the contribution
+    // split shadow walk of grey media (k_walk_cast / k_walk_track; null when the scene has no medium): a ray's state between the two
+    float4* sh_T;          // T_ray, r_u, r_l (one value for all four wavelengths), hit_t of the pending medium segment
+    uint32_t* sh_aux;      // segments | miss << 8 | transition << 9 | (next medium + 1) << 16
+    float4* sh_it;         // 4 per record: the tracker's majorant iterator (next_t | t_min, delta_t | t_max, voxel | mode) and PCG32 state, set up by the cast
+    uint32_t* wq_a;        // global index queue: records that need a cast (rounds > 0)
+    uint32_t* wq_b;        // global index queue: records that need a tracking pass
+    int* wq_ctl;           // [depth][round][4]: count A, cursor A, count B, cursor B
     // index queues: entries are generation indices p of the current depth
     uint32_t* escaped_q;
     uint32_t* medium_q;    // rays that travel inside a medium (delta tracking before their surface hit is processed)
@@ -298,5 +306,6 @@ struct DFrame {            // per-pass constants
     int count_nodes;       // 1: accumulate node/triangle counters
     int implicit_ones;     // 1: scene without media: the depth-0 records do not store beta = r_u = r_l = 1
     int delta_advance;     // k_track: cheap steps (next majorant cell / free-flight sample) per round before the pending collisions are evaluated (HK_DELTA_ADVANCE)
-    int walk_tune;         // k_shadow_walk: tracking batches per round | advance steps per batch << 8 | feed rounds << 16 (HK_SHADOW_TRACK_BATCH, HK_TRACK_ADVANCE, HK_SHADOW_FEED_ROUNDS)
+    int refill_idle;       // k_track: idle lanes that trigger a refill round (HK_TRACK_REFILL_IDLE)
+    int walk_tune;         // k_shadow_walk: tracking batches per round | advance steps per batch << 8 | feed rounds << 16 | idle lanes that trigger a refill << 24 (HK_SHADOW_TRACK_BATCH, HK_TRACK_ADVANCE, HK_SHADOW_FEED_ROUNDS, HK_WALK_REFILL_IDLE)
 };

@@ -657,7 +657,7 @@ def test_zsobol_sample_bit_table(hk, oracle, monkeypatch, first, n, stride, per_
     assert rel_mse <= 1e-5 and frac >= 0.995, (rel_mse, frac)
 
 
-@pytest.mark.parametrize("which", ["cornell", "sky", "slab"])
+@pytest.mark.parametrize("which", ["cornell", "sky", "slab", "cloud"])
 def test_scheduling_is_result_neutral(hk, monkeypatch, which):
     """How segments reach waves must not change a bit of the film: static stride vs tickets over the work lists, other segment counts
     (a count that is no multiple of anything), the shadow kernels on the second stream or not, BVH nodes from LDS or from global memory.
@@ -670,12 +670,17 @@ def test_scheduling_is_result_neutral(hk, monkeypatch, which):
     elif which == "sky":
         s, film, cam = scenes.sky_scene(w, h, env_res=32)
         kw = dict(max_depth=6, samples=64)
+    elif which == "cloud":   # a GREY NanoVDB medium (flat sigma_a / sigma_s): the specialised tracking kernels and their loop-shape knobs
+        s, film, cam = scenes.cloud_scene(w, h, "nanovdb", res=(48, 48, 24))
+        kw = dict(max_depth=8, samples=64)
     else:
         s, film, cam = scenes.slab_scene(w, h, hk.HomogeneousMedium(sigma_a=hk.RGBSpectrum(0.2), sigma_s=hk.RGBSpectrum(0.8, 0.7, 0.6), g=0.3))
         kw = dict(max_depth=6, samples=64)
+    knobs = ("HK_OVERLAP", "HK_DYNAMIC_SEGMENTS", "HK_WAVES_PER_CU", "HK_NODE_CACHE", "HK_WALK_SPLIT", "HK_GREY", "HK_DELTA_ADVANCE", "HK_TRACK_ADVANCE",
+             "HK_SHADOW_TRACK_BATCH", "HK_SHADOW_FEED_ROUNDS", "HK_TRACK_REFILL_IDLE", "HK_WALK_REFILL_IDLE")
 
     def run(env):
-        for k in ("HK_OVERLAP", "HK_DYNAMIC_SEGMENTS", "HK_WAVES_PER_CU", "HK_NODE_CACHE"):
+        for k in knobs:
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -693,7 +698,23 @@ def test_scheduling_is_result_neutral(hk, monkeypatch, which):
                 {"HK_DYNAMIC_SEGMENTS": "0", "HK_WAVES_PER_CU": "5", "HK_OVERLAP": "1"}, {"HK_NODE_CACHE": "0"}, {"HK_NODE_CACHE": "0", "HK_DYNAMIC_SEGMENTS": "0"}):
         got = run(env)
         assert np.array_equal(ref.view(np.uint32), got.view(np.uint32)), env
-    for k in ("HK_OVERLAP", "HK_DYNAMIC_SEGMENTS", "HK_WAVES_PER_CU", "HK_NODE_CACHE"):
+    if which in ("slab", "cloud"):   # the shapes of the tracking loops (how many cheap steps per round, when idle lanes refill) are scheduling too
+        for env in ({"HK_DELTA_ADVANCE": "1", "HK_TRACK_REFILL_IDLE": "1"}, {"HK_DELTA_ADVANCE": "9", "HK_TRACK_REFILL_IDLE": "40"},
+                    {"HK_TRACK_ADVANCE": "1", "HK_SHADOW_TRACK_BATCH": "1", "HK_WALK_REFILL_IDLE": "1", "HK_SHADOW_FEED_ROUNDS": "1"},
+                    {"HK_TRACK_ADVANCE": "7", "HK_SHADOW_TRACK_BATCH": "3", "HK_WALK_REFILL_IDLE": "33", "HK_SHADOW_FEED_ROUNDS": "5"}):
+            got = run(env)
+            assert np.array_equal(ref.view(np.uint32), got.view(np.uint32)), env
+    if which == "cloud":
+        # the shadow walk split into cast and tracking kernels with global queues in between: the same arithmetic per ray
+        got = run({"HK_WALK_SPLIT": "1"})
+        assert np.array_equal(ref.view(np.uint32), got.view(np.uint32)), "HK_WALK_SPLIT"
+        got = run({"HK_WALK_SPLIT": "1", "HK_WAVES_PER_CU": "3", "HK_SHADOW_TRACK_BATCH": "2"})
+        assert np.array_equal(ref.view(np.uint32), got.view(np.uint32)), "HK_WALK_SPLIT, 3 segments per CU"
+        # the GREY kernels against the general ones: every decision is taken on the same arithmetic (identical paths), the weights
+        # differ by the roundings of x * (T / T[1]) that the GREY code does not perform
+        got = run({"HK_GREY": "0"})
+        assert np.allclose(ref, got, rtol=2e-5, atol=1e-7), float(np.abs(ref - got).max())
+    for k in knobs:
         monkeypatch.delenv(k, raising=False)
     # leave the context's sticky knobs at their defaults for the tests that follow
     monkeypatch.setenv("HK_OVERLAP", "1")

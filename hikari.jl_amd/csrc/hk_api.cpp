@@ -74,7 +74,9 @@ struct DevBuf {
         p = nullptr;
         bytes = n;
         if (n == 0) return hipSuccess;
-        return hipMalloc(&p, n);
+        const hipError_t e = hipMalloc(&p, n);
+        if (e != hipSuccess) p = nullptr, bytes = 0;
+        return e;
     }
     hipError_t upload(const void* src, size_t n) {
         hipError_t e = alloc(n ? n : 4);
@@ -1362,13 +1364,24 @@ extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_
                 int lo_rows = (int)(budget / per_row < (size_t)rows ? budget / per_row : (size_t)rows);
                 I->lo_rows = 0;
                 if (lo_rows > 0 && (size_t)fr.n_pixels_padded * count < 0xffffffffull) {
-                    if (I->sobol_lo.bytes < per_row * lo_rows || I->sobol_lo.bytes > 2 * per_row * lo_rows) HIP_TRY(I->sobol_lo.alloc(per_row * lo_rows));
-                    hk::launch_sobol_lo_table(c->stream, sob, fr, I->sobol_lo.as<uint16_t>(), lo_rows, base, sample_stride, count);
-                    HIP_TRY(hipGetLastError());
-                    I->lo_rows = lo_rows;
-                    I->lo_base = base;
-                    I->lo_sample_stride = sample_stride;
-                    I->lo_count = count;
+                    // the table is an optimisation: when its memory cannot be had (another context on the device took it since
+                    // hipMemGetInfo), the call renders with hashed digits instead of failing
+                    bool have_buf = true;
+                    if (I->sobol_lo.bytes < per_row * lo_rows || I->sobol_lo.bytes > 2 * per_row * lo_rows) {
+                        while (lo_rows > 0 && I->sobol_lo.alloc(per_row * lo_rows) != hipSuccess) {
+                            (void)hipGetLastError();
+                            lo_rows /= 2;
+                        }
+                        have_buf = lo_rows > 0;
+                    }
+                    if (have_buf) {
+                        hk::launch_sobol_lo_table(c->stream, sob, fr, I->sobol_lo.as<uint16_t>(), lo_rows, base, sample_stride, count);
+                        HIP_TRY(hipGetLastError());
+                        I->lo_rows = lo_rows;
+                        I->lo_base = base;
+                        I->lo_sample_stride = sample_stride;
+                        I->lo_count = count;
+                    }
                 }
             }
             if (I->lo_rows > 0) {
@@ -1434,15 +1447,15 @@ extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_
         if (I->st.wq_ctl) HIP_TRY(hipMemsetAsync(I->st.wq_ctl, 0, (size_t)(I->st_depth + 2) * 11 * 4 * sizeof(int), s));
         if (timed(3, [&] { hk::launch_camera(s, c->n_cu, I->st, fr, c->tables, I->filter, dc, sob, -1); }) != HK_OK) return fail(HK_ERR_DEVICE, "event record failed");
         // work lists: after every producer, the non-empty segments of the queues it filled (consumers never visit an empty segment)
-        auto lists = [&](std::initializer_list<std::pair<int, int>> dq, bool kinds_of_depth = false, int kd = 0) {
+        auto lists = [&](std::initializer_list<std::pair<int, int>> dq, bool kinds_of_depth = false, int kd = 0) -> int {
             int dd[HK_MAX_KINDS + 6], qq[HK_MAX_KINDS + 6], n = 0;
             for (auto& e : dq) dd[n] = e.first, qq[n] = e.second, ++n;
             if (kinds_of_depth)
                 for (int kind = 0; kind < HK_MAX_KINDS; ++kind)
                     if (sc->kinds_mask & (1u << kind)) dd[n] = kd, qq[n] = Q_MAT0 + kind, ++n;
-            timed(3, [&] { hk::launch_segment_lists(s, I->st, n, dd, qq); });
+            return timed(3, [&] { hk::launch_segment_lists(s, I->st, n, dd, qq); });
         };
-        lists({{0, Q_RAY}});
+        if (lists({{0, Q_RAY}}) != HK_OK) return fail(HK_ERR_DEVICE, "event record failed");
         // Two streams: k_shadow of bounce d touches only its shadow records and L; k_trace of bounce d + 1 touches neither.  The
         // shadow launch goes to a second stream behind the shade kernels, the next traversal starts beside it, and the first stream
         // waits for the shadows before anything that adds to L or rewrites shadow records (media tracking, escaped, shade).  The two
@@ -1457,8 +1470,17 @@ extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_
             HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
         }
         bool shadows_in_flight = false;
+        // whatever way this function is left while a shadow kernel runs on the second stream, the stream is joined first: the next
+        // render's memsets of tickets and counters on `s` must not race with it
+        struct AuxJoin {
+            hk_ctx* c;
+            const bool* in_flight;
+            ~AuxJoin() {
+                if (*in_flight && c->aux) (void)hipStreamSynchronize(c->aux);
+            }
+        } aux_join{c, &shadows_in_flight};
         for (int depth = 0; depth < I->p.max_depth; ++depth) {
-            timed(0, [&] { hk::launch_trace(s, trace_blocks, I->st, sc->d, c->tables, fr, depth, dstats); });
+            if (timed(0, [&] { hk::launch_trace(s, trace_blocks, I->st, sc->d, c->tables, fr, depth, dstats); }) != HK_OK) return fail(HK_ERR_DEVICE, "event record failed");
             c->trace_launches++;
             if (shadows_in_flight) {
                 HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
@@ -1466,22 +1488,23 @@ extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_
             }
             int first_kind = 1;
             if (sc->d.n_media > 0) {
-                timed(4, [&] { hk::launch_medium(s, c->n_cu, I->st, sc->d, c->tables, fr, sob, depth, dstats); });
+                if (timed(4, [&] { hk::launch_medium(s, c->n_cu, I->st, sc->d, c->tables, fr, sob, depth, dstats); }) != HK_OK) return fail(HK_ERR_DEVICE, "event record failed");
                 c->media_launches += 2;   // k_track + k_scatter
                 first_kind = 0;
             }
             if (sc->d.has_escape_lights)
-                lists({{depth, Q_ESCAPED}}, true, depth);
+                if (lists({{depth, Q_ESCAPED}}, true, depth) != HK_OK) return fail(HK_ERR_DEVICE, "event record failed");
             else
-                lists({}, true, depth);
-            if (sc->d.has_escape_lights) timed(3, [&] { hk::launch_escaped(s, light_blocks, I->st, sc->d, c->tables, fr, depth); });
+                if (lists({}, true, depth) != HK_OK) return fail(HK_ERR_DEVICE, "event record failed");
+            if (sc->d.has_escape_lights)
+                if (timed(3, [&] { hk::launch_escaped(s, light_blocks, I->st, sc->d, c->tables, fr, depth); }) != HK_OK) return fail(HK_ERR_DEVICE, "event record failed");
             for (int kind = 0; kind < HK_MAX_KINDS; ++kind)
                 if (sc->kinds_mask & (1u << kind)) {
-                    timed(2, [&] { hk::launch_shade(s, shade_blocks, kind, I->st, sc->d, c->tables, fr, sob, depth, first_kind, dstats); });
+                    if (timed(2, [&] { hk::launch_shade(s, shade_blocks, kind, I->st, sc->d, c->tables, fr, sob, depth, first_kind, dstats); }) != HK_OK) return fail(HK_ERR_DEVICE, "event record failed");
                     first_kind = 0;
                     c->shade_launches++;
                 }
-            lists({{depth, Q_SHADOW}, {depth + 1, Q_RAY}});
+            if (lists({{depth, Q_SHADOW}, {depth + 1, Q_RAY}}) != HK_OK) return fail(HK_ERR_DEVICE, "event record failed");
             if (sc->d.n_lights > 0) {
                 if (overlap) {
                     HIP_TRY(hipEventRecord(c->ev_fork, s));
@@ -1490,12 +1513,15 @@ extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_
                     HIP_TRY(hipEventRecord(c->ev_join, c->aux));
                     shadows_in_flight = true;
                 } else
-                    timed(1, [&] { hk::launch_shadow(s, trace_blocks, I->st, sc->d, c->tables, fr, depth, dstats); });
+                    if (timed(1, [&] { hk::launch_shadow(s, trace_blocks, I->st, sc->d, c->tables, fr, depth, dstats); }) != HK_OK) return fail(HK_ERR_DEVICE, "event record failed");
                 c->shadow_launches++;
             }
         }
-        if (shadows_in_flight) HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
-        timed(3, [&] { hk::launch_film(s, I->st, fr, c->tables, film->accum, film->f64); });
+        if (shadows_in_flight) {
+            HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
+            shadows_in_flight = false;
+        }
+        if (timed(3, [&] { hk::launch_film(s, I->st, fr, c->tables, film->accum, film->f64); }) != HK_OK) return fail(HK_ERR_DEVICE, "event record failed");
         done += k;
     }
     HIP_TRY(hipGetLastError());
@@ -1524,6 +1550,7 @@ extern "C" int32_t hk_sync(hk_ctx* c) {
     if (!c) return fail(HK_ERR_INVALID, "null ctx");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->aux) HIP_TRY(hipStreamSynchronize(c->aux));   // a render that failed half-way may have left a shadow kernel on the second stream
     return HK_OK;
 }
 extern "C" int32_t hk_stats_enable_counters(hk_ctx* c, int32_t flags) {
@@ -1965,11 +1992,22 @@ extern "C" int32_t hk_film_reduce(hk_comm* c, hk_film* const* films, int32_t n_f
     const size_t count = (size_t)4 * films[0]->width * films[0]->height;
     const int dtype = films[0]->f64 ? 8 : 7;   // ncclFloat64 : ncclFloat32
     if (n_films > 1) RCCL_TRY(r.GroupStart());
-    for (int i = 0; i < n_films; ++i) {
-        HIP_TRY(hipSetDevice(c->ctxs[i]->device));
+    // once the group is open it is ALWAYS closed: a return between GroupStart and GroupEnd would leave the process-wide RCCL group
+    // open and every later RCCL call queued behind it.  The first error is kept, the loop is left, GroupEnd runs, then the error returns.
+    int status = HK_OK;
+    for (int i = 0; i < n_films && status == HK_OK; ++i) {
+        const hipError_t he = hipSetDevice(c->ctxs[i]->device);
+        if (he != hipSuccess) {
+            status = fail(HK_ERR_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(he));
+            break;
+        }
         // in place: the root's accumulators receive the sum; ordered after the renders already enqueued on the context's stream
-        RCCL_TRY(r.Reduce(films[i]->accum, films[i]->accum, count, dtype, 0 /* ncclSum */, root, c->comms[i], c->ctxs[i]->stream));
+        const int rc = r.Reduce(films[i]->accum, films[i]->accum, count, dtype, 0 /* ncclSum */, root, c->comms[i], c->ctxs[i]->stream);
+        if (rc != 0) status = rccl_fail("ncclReduce", rc);
     }
-    if (n_films > 1) RCCL_TRY(r.GroupEnd());
-    return HK_OK;
+    if (n_films > 1) {
+        const int rc = r.GroupEnd();
+        if (rc != 0 && status == HK_OK) status = rccl_fail("ncclGroupEnd", rc);
+    }
+    return status;
 }

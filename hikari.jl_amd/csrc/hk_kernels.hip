@@ -182,6 +182,49 @@ __device__ __forceinline__ void ld_shadow_weights(const DPathState& st, size_t r
         rl = ld4(&st.sh_rl[rec]);
     }
 }
+// Streaming stores / loads of path and shadow records (written once, read once by a later kernel): marked non-temporal so that they
+// do not push the register-spill lines of the resident waves out of the L2s (HK_NT=0 at build time: plain accesses)
+#ifndef HK_NT
+#define HK_NT 1
+#endif
+typedef uint32_t hk_u2v __attribute__((ext_vector_type(2)));
+HKD void stream_st(float4* p, float4 v) {
+#if HK_NT
+    __builtin_nontemporal_store((hk_f4v){v.x, v.y, v.z, v.w}, (hk_f4v*)p);
+#else
+    *p = v;
+#endif
+}
+HKD void stream_st(float4* p, S4 v) { stream_st(p, make_float4(v.x, v.y, v.z, v.w)); }
+HKD void stream_st(uint2* p, uint2 v) {
+#if HK_NT
+    __builtin_nontemporal_store((hk_u2v){v.x, v.y}, (hk_u2v*)p);
+#else
+    *p = v;
+#endif
+}
+HKD void stream_st(float* p, float v) {
+#if HK_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+HKD void stream_st(uint32_t* p, uint32_t v) {
+#if HK_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+HKD float4 stream_ld(const float4* p) {
+#if HK_NT
+    const hk_f4v v = __builtin_nontemporal_load((const hk_f4v*)p);
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
 // dense append of a whole record: the position the pushing lanes get inside the segment (count + rank among the pushing lanes)
 struct WavePos {
     int count;  // wave-uniform: entries already in the segment
@@ -266,7 +309,9 @@ __global__ void __launch_bounds__(1024) k_segment_lists(DPathState st, SegQueues
     int* __restrict__ out = st.seg_list + (size_t)(d * Q_COUNT + q) * st.n_waves;
     const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
     const int share = (st.n_waves + HK_LIST_SPLIT - 1) / HK_LIST_SPLIT;
-    const int begin = (int)blockIdx.y * share, end = begin + share < st.n_waves ? begin + share : st.n_waves;
+    // both clamped: for small segment counts ceil(n / 8) * 7 can exceed n (n = 12: share 2, block 7 would start at 14 and count the NEXT
+    // queue's words into its prefix)
+    const int begin = (int)blockIdx.y * share < st.n_waves ? (int)blockIdx.y * share : st.n_waves, end = begin + share < st.n_waves ? begin + share : st.n_waves;
     // the non-empty segments before this block's share
     int mine = 0;
     for (int i = (int)threadIdx.x; i < begin; i += 1024) mine += cnt[i] != 0 ? 1 : 0;
@@ -376,9 +421,9 @@ __global__ void __launch_bounds__(256) k_camera(DPathState st, DFrame fr, DTable
             v3 ro, rd;
             float time;
             generate_ray(cam, pfilm, lens, time_u, ro, rd, time);
-            g0.ray_o[p] = make_float4(ro.x, ro.y, ro.z, INF_F);
-            g0.ray_d[p] = make_float4(rd.x, rd.y, rd.z, 0.0f);
-            st4(&g0.lambda[p], lambda);
+            stream_st(&g0.ray_o[p], make_float4(ro.x, ro.y, ro.z, INF_F));
+            stream_st(&g0.ray_d[p], make_float4(rd.x, rd.y, rd.z, 0.0f));
+            stream_st(&g0.lambda[p], lambda);
             // beta = r_u = r_l = 1 at depth 0 (volpath.jl:190-197): in scenes without media nothing changes them before the first
             // shading event, so they are not stored and the depth-0 readers substitute the constant (ld_throughput)
             if (!fr.implicit_ones) {
@@ -386,11 +431,11 @@ __global__ void __launch_bounds__(256) k_camera(DPathState st, DFrame fr, DTable
                 st4(&g0.r_u[p], s4(1.0f));
                 st4(&g0.r_l[p], s4(1.0f));
             }
-            g0.meta[p] = make_uint2((uint32_t)(*st.initial_medium + 1) << 16, (uint32_t)slot);
-            st4(&st.lambda_s[slot], lambda);
-            st4(&st.pdf[slot], pdf);
-            st4(&st.L[slot], s4(0.0f));
-            st.filter_w[slot] = fw;
+            stream_st(&g0.meta[p], make_uint2((uint32_t)(*st.initial_medium + 1) << 16, (uint32_t)slot));
+            stream_st(&st.lambda_s[slot], lambda);
+            stream_st(&st.pdf[slot], pdf);
+            stream_st(&st.L[slot], s4(0.0f));
+            stream_st(&st.filter_w[slot], fw);
         }
     }
     if (lane_id() == 0) *count_ptr(st, 0, Q_RAY, gw) = out.count;
@@ -713,8 +758,8 @@ __global__ void __launch_bounds__(BLOCK) k_trace_lean(DPathState st, DScene sc, 
                     }
                     kind = sc.materials[mat].kind;
                     if (kind == HK_MAT_MIX) kind = HK_MAT_FALLBACK;
-                    st.hit[slot] = make_float4(r.best.t, __int_as_float(r.best.prim), r.best.u, r.best.v);
-                    st.mat_id[slot] = mat | (hm.arealight > 0 ? HK_MAT_EMISSIVE_BIT : 0);
+                    stream_st(&st.hit[slot], make_float4(r.best.t, __int_as_float(r.best.prim), r.best.u, r.best.v));
+                    stream_st(reinterpret_cast<uint32_t*>(st.mat_id) + slot, (uint32_t)(mat | (hm.arealight > 0 ? HK_MAT_EMISSIVE_BIT : 0)));
                 }
                 state = LR_EMPTY;
             }
@@ -728,7 +773,7 @@ __global__ void __launch_bounds__(BLOCK) k_trace_lean(DPathState st, DScene sc, 
                 int cnt = 0;
 #pragma unroll
                 for (int kk = 0; kk < HK_MAX_KINDS; ++kk) cnt = (kk == k) ? kind_count[kk] : cnt;
-                if (mine) st.mat_q[((size_t)k * st.n_waves + gw) * st.wave_cap + cnt + __popcll(m & lt_mask)] = slot;
+                if (mine) stream_st(&st.mat_q[((size_t)k * st.n_waves + gw) * st.wave_cap + cnt + __popcll(m & lt_mask)], slot);
                 int add = __popcll(m);
 #pragma unroll
                 for (int kk = 0; kk < HK_MAX_KINDS; ++kk) kind_count[kk] += (kk == k) ? add : 0;
@@ -740,7 +785,7 @@ __global__ void __launch_bounds__(BLOCK) k_trace_lean(DPathState st, DScene sc, 
             const int rank = __popcll(want & lt_mask);
             if (state == LR_EMPTY && rank < avail) {
                 slot = seg + (uint32_t)(cursor + rank);
-                float4 O = g.ray_o[slot], D = g.ray_d[slot];
+                float4 O = stream_ld(&g.ray_o[slot]), D = stream_ld(&g.ray_d[slot]);
                 ++n_casts;
                 lane_ray_start(r, sc, mk3(O.x, O.y, O.z), mk3(D.x, D.y, D.z), O.w);
                 state = LR_ACTIVE;
@@ -1438,16 +1483,24 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
         S4 shLd = s4(0.0f), shRu = s4(0.0f), shRl = s4(0.0f);
         if (active) {
             ++n_vertices;
-            H = st.hit[slot];
-            float4 O = g.ray_o[slot], D = g.ray_d[slot];
+            H = stream_ld(&st.hit[slot]);
+            float4 O = stream_ld(&g.ray_o[slot]), D = stream_ld(&g.ray_d[slot]);
             v3 ro = mk3(O.x, O.y, O.z), rd = mk3(D.x, D.y, D.z);
             float t_hit = H.x;
             int prim = __float_as_int(H.y);
             sf = surface_at(sc, prim, H.z, H.w, ro, rd, t_hit);
             wo = -rd;
             meta = sc.meta[prim];
-            lambda = ld4(&g.lambda[slot]);
-            beta = ld_throughput(g.beta, slot, ones);
+            {
+                const float4 lv = stream_ld(&g.lambda[slot]);
+                lambda = s4(lv.x, lv.y, lv.z, lv.w);
+            }
+            if (ones)
+                beta = s4(1.0f);
+            else {
+                const float4 bv = stream_ld(&g.beta[slot]);
+                beta = s4(bv.x, bv.y, bv.z, bv.w);
+            }
             r_u = ld_ru(g, slot, ones, st.compact != 0);
             const uint2 pmeta = g.meta[slot];
             fl = pmeta.x;
@@ -1555,11 +1608,18 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
         {
             const size_t ps = seg + (size_t)wp_push(q_shadow, push_shadow);
             if (push_shadow) {
-                st.sh_o[ps] = shO;
-                st.sh_d[ps] = shD;
-                st4(&st.sh_Ld[ps], shLd);
-                st_shadow_weights(st, ps, shRu, shRl);
-                st.sh_slot[ps] = pslot;
+                stream_st(&st.sh_o[ps], shO);
+                stream_st(&st.sh_d[ps], shD);
+                stream_st(&st.sh_Ld[ps], shLd);
+                if (st.compact) {
+#if HK_NT
+                    __builtin_nontemporal_store((hk_f2){shRu.x, shRl.x}, (hk_f2*)(reinterpret_cast<float2*>(st.sh_ru) + ps));
+#else
+                    reinterpret_cast<float2*>(st.sh_ru)[ps] = make_float2(shRu.x, shRl.x);
+#endif
+                } else
+                    st_shadow_weights(st, ps, shRu, shRl);
+                stream_st(&st.sh_slot[ps], pslot);
             }
         }
         // ---- K11: BSDF sampling, throughput, Russian roulette, continuation ray ----
@@ -1606,12 +1666,15 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
         {   // the continuing path's record, whole, at its position in the next generation (r_u is unchanged by a surface event)
             const size_t pn = seg + (size_t)wp_push(q_next, push_ray);
             if (push_ray) {
-                gn.ray_o[pn] = nO;
-                gn.ray_d[pn] = nD;
-                st4(&gn.beta[pn], nb);
-                st_ru_rl(gn, pn, r_u, nrl, st.compact != 0);
-                st4(&gn.lambda[pn], lambda);
-                gn.meta[pn] = make_uint2(nflags, pslot);
+                stream_st(&gn.ray_o[pn], nO);
+                stream_st(&gn.ray_d[pn], nD);
+                stream_st(&gn.beta[pn], nb);
+                if (st.compact)
+                    stream_st(reinterpret_cast<float*>(gn.r_l) + pn, nrl.x);
+                else
+                    st_ru_rl(gn, pn, r_u, nrl, false);
+                stream_st(&gn.lambda[pn], lambda);
+                stream_st(&gn.meta[pn], make_uint2(nflags, pslot));
             }
         }
     }
@@ -1700,7 +1763,7 @@ __global__ void __launch_bounds__(BLOCK) k_shadow(DPathState st, DScene sc, int 
             const int rank = __popcll(want & lt_mask);
             if (!have && rank < avail) {
                 slot = seg + (uint32_t)(cursor + rank);
-                float4 O = st.sh_o[slot], D = st.sh_d[slot];
+                float4 O = stream_ld(&st.sh_o[slot]), D = stream_ld(&st.sh_d[slot]);
                 if (O.w >= 1e-6f) {   // a degenerate shadow ray is simply not visible
                     ++n_casts;
                     lane_ray_start(r, sc, mk3(O.x, O.y, O.z), mk3(D.x, D.y, D.z), O.w);

@@ -1492,12 +1492,11 @@ extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_
                 c->media_launches += 2;   // k_track + k_scatter
                 first_kind = 0;
             }
-            if (sc->d.has_escape_lights)
+            if (sc->d.has_escape_lights) {
                 if (lists({{depth, Q_ESCAPED}}, true, depth) != HK_OK) return fail(HK_ERR_DEVICE, "event record failed");
-            else
-                if (lists({}, true, depth) != HK_OK) return fail(HK_ERR_DEVICE, "event record failed");
-            if (sc->d.has_escape_lights)
                 if (timed(3, [&] { hk::launch_escaped(s, light_blocks, I->st, sc->d, c->tables, fr, depth); }) != HK_OK) return fail(HK_ERR_DEVICE, "event record failed");
+            } else if (lists({}, true, depth) != HK_OK)
+                return fail(HK_ERR_DEVICE, "event record failed");
             for (int kind = 0; kind < HK_MAX_KINDS; ++kind)
                 if (sc->kinds_mask & (1u << kind)) {
                     if (timed(2, [&] { hk::launch_shade(s, shade_blocks, kind, I->st, sc->d, c->tables, fr, sob, depth, first_kind, dstats); }) != HK_OK) return fail(HK_ERR_DEVICE, "event record failed");

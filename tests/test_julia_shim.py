@@ -157,3 +157,34 @@ def test_shim_defines_what_integration_md_promises():
             names = [n.strip() for n in m.group(1).split(",")]
             vals = re.findall(r"Int32\((\d+)\)", m.group(2))
             assert vals[names.index(const)] == val, const
+
+
+def test_flatten_scene_fills_every_descriptor_field():
+    """hk_scene_desc has 8 counts and 12 array pointers: flatten_scene's HkSceneDesc(...) call must name a Julia array for each of
+    them (a count and a pointer per array, in the header's order), and every one of those arrays must be built in the function."""
+    i = SRC.index("function flatten_scene(ctx::Ptr{Cvoid}, scene)")
+    body = SRC[i:SRC.index("\nend\n", i)]
+    j = body.index("HkSceneDesc(")
+    args = [a.strip() for a in _call_args(body, j + len("HkSceneDesc"))]
+    hdr = open(os.path.join(ROOT, "include", "hikari_mi355x.h")).read()
+    fields = re.findall(r"^\s+(?:int32_t|const [\w ]+\*)\s+(\w+);", hdr[hdr.index("typedef struct hk_scene_desc {"):hdr.index("} hk_scene_desc;")], re.M)
+    assert len(args) == len(fields) == 20
+    counts = {"n_triangles": "meta", "n_materials": "materials", "n_textures": "textures", "n_media_interfaces": "mis", "n_lights": "lights",
+              "n_envmaps": "envmaps", "n_media": "media", "n_spectra": "spectra"}
+    ptrs = {"positions": "pos", "normals": "nrm", "uvs": "uvs", "tangents": "tan", "meta": "meta", "materials": "materials", "textures": "textures",
+            "media_interfaces": "mis", "lights": "lights", "envmaps": "envmaps", "media": "media", "spectra": "spectra"}
+    for f, a in zip(fields, args):
+        want = "length(%s)" % counts[f] if f in counts else "p(%s)" % ptrs[f]
+        assert a == want, (f, a, want)
+    for arr in set(ptrs.values()):
+        assert re.search(r"\b%s\b\s*(=|,)" % arr, body[:j]), arr      # built (assigned) before the descriptor is
+
+
+def test_runtests_jl_covers_the_reference_integration_scene():
+    rt = open(os.path.join(ROOT, "julia", "test", "runtests.jl")).read()
+    for needle in ("Hikari.VolPath(samples=4, max_depth=5)", "HikariMI355X.MI355XVolPath(samples=4, max_depth=5)", "rel_mse(got, ref) <= 1f-3", "frac_within(got, ref) >= 0.99",
+                   "Hikari.render!(vp, scene, film, camera)", "PointLight(Point3f(0f0, 1.8f0, 0f0)"):
+        assert needle in rt, needle
+    # the shim defines what the script calls
+    for needle in ("MI355XVolPath(;", "function Base.close(vp::MI355XVolPath)", "function Hikari.clear!(vp::MI355XVolPath)"):
+        assert needle in SRC, needle

@@ -366,8 +366,12 @@ HKD uint64_t sobol_morton_base(const SobolCtx& c) {   // encode_morton2(px, py) 
 // The draws that miss the sample-bit table (rows beyond the table's budget, one-sample progressive calls, the point-wise test kernels)
 // hash the digits in line: moved out of line (noinline) the call made k_shade<0> 3 % and k_track 3 % slower (288 B of scratch for the
 // callee's frame) although it removes ~1600 static instructions from every path vertex.
+// TABLE_ONLY: the caller knows (from the host: DSobol::lo_rows against the rows a bounce reads) that both tables hold this draw for
+// every path of the launch — two loads, and none of the hashing code (and its registers) in the kernel.
+template <bool TABLE_ONLY = false>
 HKD uint64_t sobol_index(const SobolCtx& c, int dim) {
     const int row = sobol_row(dim);
+    if (TABLE_ONLY) return ((uint64_t)c.hi[(size_t)row * c.hi_stride].x << c.log2_spp) | (uint64_t)c.lo[(size_t)row * c.lo_row_stride];
     if (c.hi != nullptr && row >= 0 && row < c.hi_rows) {
         const uint2 e = c.hi[(size_t)row * c.hi_stride];
         if (row < c.lo_rows) return ((uint64_t)e.x << c.log2_spp) | (uint64_t)c.lo[(size_t)row * c.lo_row_stride];
@@ -375,13 +379,15 @@ HKD uint64_t sobol_index(const SobolCtx& c, int dim) {
     }
     return zsobol_sample_index(sobol_morton_base(c), dim, c.log2_spp, c.n_digits);
 }
+template <bool TABLE_ONLY = false>
 HKD float sobol_1d(const SobolCtx& c, int dim) {  // sobol.jl:269-282
-    uint64_t idx = sobol_index(c, dim);
+    uint64_t idx = sobol_index<TABLE_ONLY>(c, dim);
     uint32_t h = (uint32_t)zsobol_hash(dim + 1, c.seed);
     return sobol_sample(idx, 0, h, c.mats);
 }
+template <bool TABLE_ONLY = false>
 HKD v2 sobol_2d(const SobolCtx& c, int dim) {  // sobol.jl:290-309
-    uint64_t idx = sobol_index(c, dim);
+    uint64_t idx = sobol_index<TABLE_ONLY>(c, dim);
     uint64_t bits = zsobol_hash(dim + 2, c.seed);
     return mk2(sobol_sample(idx, 0, (uint32_t)bits, c.mats), sobol_sample(idx, 1, (uint32_t)(bits >> 32), c.mats));
 }

@@ -1417,7 +1417,10 @@ struct ShadeWaves {
 #define HK_SHADE_MIN_WAVES 1
 #endif
 // SIMPLE (instantiated for Matte): the scene has no ambient / environment light and no texture of any kind (DScene::simple_lights)
-template <int KIND, bool SIMPLE = false>
+// FT ("full tables"; Matte, Mirror, Glass, Conductor): every Sobol draw of this bounce is in the sampler's two tables for every path of the launch (the host
+// checks DSobol::lo_rows against the rows of this depth): the draws are two loads each and the digit-hashing fallback — three 64-bit
+// hash loops inlined at each of the five draw sites — is not in the kernel at all.
+template <int KIND, bool SIMPLE = false, bool FT = false>
 __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_per_eu(ShadeWaves<KIND>::value))) k_shade(DPathState st, DScene sc, DTables T, DFrame fr, DSobol sob, int depth, int first_kind, DStats* stats) {
     __shared__ uint32_t emit_list[4 * 128];   // per wave: slots of flagged (emissive-hit) vertices waiting for the dense K8 pass
     const int lane = lane_id();
@@ -1570,14 +1573,14 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
             // ---- K9: next-event estimation through the light BVH ----
             if (sc.n_lights > 0) {
                 const DMaterial& mat = sc.materials[st.mat_id[slot] & ~HK_MAT_EMISSIVE_BIT];
-                float light_select = sobol_1d(sctx, base_dim + 1);
+                float light_select = sobol_1d<FT>(sctx, base_dim + 1);
                 float light_pmf;
                 int light_idx = bvh_sample_light(sc, sf.pi, sf.ns, light_select, light_pmf, n_lnodes);
                 if (light_idx >= 1 && light_idx <= sc.n_lights && light_pmf > 0.0f) {
                     const DLight& sel = sc.lights[light_idx - 1];
                     // delta lights ignore the 2-D sample (lights.jl:39-131): draw it only for lights that use it
                     v2 u_light = mk2(0.0f, 0.0f);
-                    if (sel.kind >= HK_LIGHT_AMBIENT) u_light = sobol_2d(sctx, base_dim + 3);
+                    if (sel.kind >= HK_LIGHT_AMBIENT) u_light = sobol_2d<FT>(sctx, base_dim + 3);
                     LightSample ls = sample_light<KIND == HK_MAT_MATTE, SIMPLE>(sc, T, sel, sf.pi, lambda, u_light);
                     if (ls.pdf > 0.0f && !is_black(ls.Li)) {
                         float bsdf_pdf;
@@ -1632,8 +1635,8 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
                 const DMaterial& mat = sc.materials[st.mat_id[slot] & ~HK_MAT_EMISSIVE_BIT];
                 const DMediumInterface mi = sc.mis[meta.mi];
                 // the 1-D component sample is read only by BSDFs that choose a lobe (Glass and the layered kinds)
-                float uc = (KIND == HK_MAT_GLASS || KIND > HK_MAT_CONDUCTOR) && KIND != HK_MAT_FALLBACK ? sobol_1d(sctx, base_dim + 4) : 0.0f;
-                v2 u = (KIND == HK_MAT_MIRROR || KIND == HK_MAT_GLASS || KIND == HK_MAT_THIN_DIELECTRIC) ? mk2(0.0f, 0.0f) : sobol_2d(sctx, base_dim + 6);
+                float uc = (KIND == HK_MAT_GLASS || KIND > HK_MAT_CONDUCTOR) && KIND != HK_MAT_FALLBACK ? sobol_1d<FT>(sctx, base_dim + 4) : 0.0f;
+                v2 u = (KIND == HK_MAT_MIRROR || KIND == HK_MAT_GLASS || KIND == HK_MAT_THIN_DIELECTRIC) ? mk2(0.0f, 0.0f) : sobol_2d<FT>(sctx, base_dim + 6);
                 bool regularize = fr.regularize && any_non_specular;
                 BSDFSample s = KIND == HK_MAT_MATTE ? sample_matte_kd<SIMPLE>(sc, mat, kd_matte, wo, sf.ns, TexCtx(sf.uv, meta.prim_index, H.z, H.w), u)
                                                     : sample_bsdf<KIND>(sc, T, mat, wo, sf.ns, TexCtx(sf.uv, meta.prim_index, H.z, H.w), lambda, u, uc, regularize);
@@ -1643,7 +1646,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
                     nrl = s.is_specular ? r_u : r_u / s.pdf;
                     bool cont = true;
                     if (new_depth > 3) {  // russian_roulette_spectral, min_depth fixed at 3 (Q7)
-                        float rr = sobol_1d(sctx, base_dim + 7);
+                        float rr = sobol_1d<FT>(sctx, base_dim + 7);
                         float q = maxf(0.05f, 1.0f - max_component(nb));
                         if (rr < q)
                             cont = false;
@@ -3193,11 +3196,31 @@ void launch_shade(hipStream_t s, int n_cu, int kind, const DPathState& st, const
         const int blocks = cached_blocks<k_shade<K>>(256, n_cu, 8);                                                            \
         hipLaunchKernelGGL(k_shade<K>, dim3(clamp_blocks(blocks, st)), dim3(256), 0, s, st, sc, T, fr, sob, depth, first_kind, stats); \
     } break;
+    // both sampler tables hold every draw of this bounce (rows up to 9 + 5 depth: sobol_row) for every path of the pass: the table-only
+    // instantiation (HK_SOBOL_TABLE_ONLY=0: always the general one — A/B switch, read per launch)
+    const char* ft_env = std::getenv("HK_SOBOL_TABLE_ONLY");   // read per launch (A/B switch)
+    const bool ft = sob.hi_table != nullptr && sob.lo_table != nullptr && 9 + 5 * depth < sob.lo_rows && 9 + 5 * depth < sob.hi_rows && !(ft_env && std::atoi(ft_env) == 0);
     if (kind == HK_MAT_MATTE && sc.simple_lights) {
-        const int blocks = cached_blocks<k_shade<HK_MAT_MATTE, true>>(256, n_cu, 8);
-        hipLaunchKernelGGL((k_shade<HK_MAT_MATTE, true>), dim3(clamp_blocks(blocks, st)), dim3(256), 0, s, st, sc, T, fr, sob, depth, first_kind, stats);
+        if (ft) {
+            const int blocks = cached_blocks<k_shade<HK_MAT_MATTE, true, true>>(256, n_cu, 8);
+            hipLaunchKernelGGL((k_shade<HK_MAT_MATTE, true, true>), dim3(clamp_blocks(blocks, st)), dim3(256), 0, s, st, sc, T, fr, sob, depth, first_kind, stats);
+        } else {
+            const int blocks = cached_blocks<k_shade<HK_MAT_MATTE, true>>(256, n_cu, 8);
+            hipLaunchKernelGGL((k_shade<HK_MAT_MATTE, true>), dim3(clamp_blocks(blocks, st)), dim3(256), 0, s, st, sc, T, fr, sob, depth, first_kind, stats);
+        }
         return;
     }
+#define HK_SHADE_FT(K)                                                                                                                  \
+    if (kind == K && ft) {                                                                                                              \
+        const int blocks = cached_blocks<k_shade<K, false, true>>(256, n_cu, 8);                                                      \
+        hipLaunchKernelGGL((k_shade<K, false, true>), dim3(clamp_blocks(blocks, st)), dim3(256), 0, s, st, sc, T, fr, sob, depth, first_kind, stats); \
+        return;                                                                                                                         \
+    }
+    HK_SHADE_FT(HK_MAT_MATTE)
+    HK_SHADE_FT(HK_MAT_MIRROR)
+    HK_SHADE_FT(HK_MAT_GLASS)
+    HK_SHADE_FT(HK_MAT_CONDUCTOR)
+#undef HK_SHADE_FT
     switch (kind) {
         HK_SHADE_CASE(HK_MAT_MATTE)
         HK_SHADE_CASE(HK_MAT_MIRROR)

@@ -368,3 +368,102 @@ def test_nanovdb_file_round_trip(hk, oracle, tmp_path):
     m3 = hk.NanoVDBMedium.from_file(path, transform=R, majorant_res=(4, 4, 4))            # rotated: bounds = bbox of the rotated corners
     assert np.allclose(sorted(np.subtract(m3.bounds[1], m3.bounds[0])), sorted(np.subtract(m.bounds[1], m.bounds[0])), atol=1e-5)
     assert m3.majorant.max() > 0
+
+
+def test_procedural_noise_against_scalar_restatement(hk):
+    """hikari.jl_amd/noise.py evaluates the noise of src/random.jl on whole arrays (the BOMEX stand-in of BASELINE configs[3] is made
+    with it).  Here the same functions are written out voxel by voxel the way the Julia text reads (perlin3d :36-49, fbm3d :64-74,
+    worley3d :86-112, worley_fbm3d :119-129, generate_cloud_density :154-218) and compared point by point — the two forms share only
+    Ken Perlin's published permutation table."""
+    import math
+    from hikari_jl_amd import noise
+    P = [int(v) for v in noise._PERM]
+    perm = lambda i: P[i & 255]
+    fade = lambda t: t * t * t * (t * (t * 6 - 15) + 10)
+    lerp = lambda t, a, b: a + t * (b - a)
+
+    def grad(h, x, y, z):
+        h &= 15
+        u = x if h < 8 else y
+        v = y if h < 4 else (x if h in (12, 14) else z)
+        return (u if (h & 1) == 0 else -u) + (v if (h & 2) == 0 else -v)
+
+    def perlin(x, y, z):
+        X, Y, Z = math.floor(x) & 255, math.floor(y) & 255, math.floor(z) & 255
+        x, y, z = x - math.floor(x), y - math.floor(y), z - math.floor(z)
+        u, v, w = fade(x), fade(y), fade(z)
+        A, B = perm(X) + Y, perm(X + 1) + Y
+        AA, AB, BA, BB = perm(A) + Z, perm(A + 1) + Z, perm(B) + Z, perm(B + 1) + Z
+        return lerp(w, lerp(v, lerp(u, grad(perm(AA), x, y, z), grad(perm(BA), x - 1, y, z)), lerp(u, grad(perm(AB), x, y - 1, z), grad(perm(BB), x - 1, y - 1, z))),
+                    lerp(v, lerp(u, grad(perm(AA + 1), x, y, z - 1), grad(perm(BA + 1), x - 1, y, z - 1)),
+                         lerp(u, grad(perm(AB + 1), x, y - 1, z - 1), grad(perm(BB + 1), x - 1, y - 1, z - 1))))
+
+    def fbm(x, y, z, octaves=4, persistence=0.5):
+        total, f, a, m = 0.0, 1.0, 1.0, 0.0
+        for _ in range(octaves):
+            total += perlin(x * f, y * f, z * f) * a
+            m += a
+            a *= persistence
+            f *= 2.0
+        return total / m
+
+    def worley(x, y, z, seed=0):
+        xi, yi, zi = math.floor(x), math.floor(y), math.floor(z)
+        fx, fy, fz = x - xi, y - yi, z - zi
+        best = 10.0
+        for dz in (-1, 0, 1):
+            for dy in (-1, 0, 1):
+                for dx in (-1, 0, 1):
+                    h = perm(perm(perm((xi + dx + seed) & 255) + ((yi + dy) & 255)) + ((zi + dz) & 255))
+                    px, py, pz = dx + (h & 63) / 64.0, dy + ((h >> 2) & 63) / 64.0, dz + ((h >> 4) & 63) / 64.0
+                    best = min(best, math.sqrt((fx - px) ** 2 + (fy - py) ** 2 + (fz - pz) ** 2))
+        return best
+
+    def worley_fbm(x, y, z, octaves=3):
+        total, f, a, m = 0.0, 1.0, 1.0, 0.0
+        for i in range(1, octaves + 1):
+            total += worley(x * f, y * f, z * f, seed=i * 17) * a
+            m += a
+            a *= 0.5
+            f *= 2.0
+        return total / m
+
+    rng = np.random.default_rng(4)
+    pts = rng.random((200, 3)) * 40.0 - 7.0
+    assert np.allclose(noise.perlin3d(pts[:, 0], pts[:, 1], pts[:, 2]), [perlin(*p) for p in pts], rtol=0, atol=1e-12)
+    assert np.allclose(noise.fbm3d(pts[:, 0], pts[:, 1], pts[:, 2], octaves=3, persistence=0.55), [fbm(*p, octaves=3, persistence=0.55) for p in pts], atol=1e-12)
+    assert np.allclose(noise.worley3d(pts[:, 0], pts[:, 1], pts[:, 2], seed=17), [worley(*p, seed=17) for p in pts], atol=1e-12)
+    assert np.allclose(noise.worley_fbm3d(pts[:, 0], pts[:, 1], pts[:, 2]), [worley_fbm(*p) for p in pts], atol=1e-12)
+    assert -1.001 <= noise.perlin3d(pts[:, 0], pts[:, 1], pts[:, 2]).min() and noise.worley3d(pts[:, 0], pts[:, 1], pts[:, 2]).max() < 1.8
+
+    def cloud(res, scale=4.0, sphere_falloff=True, threshold=0.3, worley_weight=0.6, edge_sharpness=1.5, density_scale=3.0):
+        f32 = np.float32
+        out = np.zeros((res, res, res), np.float32)
+        for iz in range(1, res + 1):
+            for iy in range(1, res + 1):
+                for ix in range(1, res + 1):
+                    x, y, z = (float((f32(v) - f32(0.5)) / f32(res)) for v in (ix, iy, iz))
+                    dx, dy, dz = x - 0.5, y - 0.5, z - 0.5
+                    dist = math.sqrt(dx * dx + dy * dy + dz * dz)
+                    w = 1.0 - worley_fbm(x * scale * 0.8, y * scale * 0.8, z * scale * 0.8)
+                    billow = 1.0 - abs(fbm(x * scale * 1.5, y * scale * 1.5, z * scale * 1.5, octaves=4, persistence=0.55))
+                    base = worley_weight * w + (1.0 - worley_weight) * billow
+                    base += fbm(x * scale * 4.0 + 13.7, y * scale * 4.0 - 5.3, z * scale * 4.0 + 9.1, octaves=3) * 0.12
+                    val = min(max((base - threshold) / (1.0 - threshold), 0.0), 1.0)
+                    if not sphere_falloff:
+                        out[ix - 1, iy - 1, iz - 1] = val * density_scale
+                        continue
+                    er = float(f32(0.45)) * (1.0 + 0.15 * fbm(x * scale * 2.0 + 7.1, y * scale * 2.0, z * scale * 2.0 - 3.3, octaves=3))
+                    if dist < er:
+                        t = dist / er
+                        edge = min(max(1.0 - (t / (0.3 + 0.7 * base)) ** edge_sharpness, 0.0), 1.0)
+                        out[ix - 1, iy - 1, iz - 1] = val * edge * density_scale
+        return out
+
+    for kw in (dict(), dict(sphere_falloff=False, threshold=0.15, density_scale=3.5)):
+        assert np.allclose(noise.generate_cloud_density(7, **kw), cloud(7, **kw), rtol=1e-6, atol=1e-7), kw
+    # the bench's field: `fill` of the voxels are cloudy, the densest has the stated extinction, the array is cached and reproducible
+    from hikari_jl_amd import scenes
+    d = scenes.bomex_density((32, 32, 16), fill=0.05, max_extinction=620.0, cache=False)
+    assert d.shape == (32, 32, 16) and d.dtype == np.float32 and abs(d.max() - 620.0) < 1e-3 and abs((d > 0).mean() - 0.05) < 0.004
+    assert np.array_equal(d, scenes.bomex_density((32, 32, 16), fill=0.05, max_extinction=620.0, cache=False))

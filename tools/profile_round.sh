@@ -4,7 +4,7 @@
 # utilisation counters behind DESIGN.md's "what bounds the kernels".  Everything lands in gpurun_out/<round>/; the summaries
 # (text / json, no databases) are then copied into profiles/ by hand.
 #   tools/profile_round.sh r02 [quick]
-R=${1:-r02}; MODE=$2
+R=${1:-r03}; MODE=$2
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/$R; mkdir -p $O
 if [ "$MODE" != "quick" ]; then
@@ -37,6 +37,7 @@ for cfg in cornell cloud manylight sky; do
   prof sq_busy_$cfg $cfg "$extra" SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_SALU
   prof sq_mem_$cfg $cfg "$extra" SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_INST_ANY
   prof grbm_$cfg $cfg "$extra" GRBM_GUI_ACTIVE SQ_WAVES
+  python3 tools/pmc_utilisation.py $O $R $cfg > $O/utilisation_$cfg.json
 done
 find $O -name "*_results.db" -delete
 find $O -type d -empty -delete

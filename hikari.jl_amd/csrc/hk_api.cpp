@@ -1191,7 +1191,7 @@ int ensure_state(hk_integrator* I, int capacity, bool media, bool open_scene) {
     HIP_TRY(alloc_arr(I, s.hit, Q));
     HIP_TRY(alloc_arr(I, s.mat_id, Q));
     HIP_TRY(alloc_arr(I, s.lambda_s, P));
-    HIP_TRY(alloc_arr(I, s.pdf, P));
+    s.pdf = nullptr;   // recomputed from lambda_s by k_film
     HIP_TRY(alloc_arr(I, s.L, P));
     HIP_TRY(alloc_arr(I, s.filter_w, P));
     HIP_TRY(alloc_arr(I, s.sh_o, Q));

@@ -433,7 +433,6 @@ __global__ void __launch_bounds__(256) k_camera(DPathState st, DFrame fr, DTable
             }
             stream_st(&g0.meta[p], make_uint2((uint32_t)(*st.initial_medium + 1) << 16, (uint32_t)slot));
             stream_st(&st.lambda_s[slot], lambda);
-            stream_st(&st.pdf[slot], pdf);
             stream_st(&st.L[slot], s4(0.0f));
             stream_st(&st.filter_w[slot], fw);
         }
@@ -2533,6 +2532,9 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
 // K12: spectral -> RGB, firefly clamp, filter-weighted accumulation (volpath.jl:326-375).  The S samples of
 // a pixel are folded in sample order, so the fp32 sums equal the reference's sample-by-sample sums.
 // ---------------------------------------------------------------------------------------------------
+// The wavelength pdfs are a function of the wavelengths alone (sample_wavelengths_visible: pdf = visible_wavelengths_pdf(lambda), the
+// same expression on the same bits): the film kernel recomputes them instead of reading 16 B per sample that k_camera had to write.
+HKD S4 pdf_of(S4 l) { return s4(visible_wavelengths_pdf(l.x), visible_wavelengths_pdf(l.y), visible_wavelengths_pdf(l.z), visible_wavelengths_pdf(l.w)); }
 template <typename ACC>
 __global__ void __launch_bounds__(256) k_film(DPathState st, DFrame fr, DTables T, ACC* __restrict__ accum) {
     // One wave per 8x8 pixel tile = a contiguous run of 64 * S path slots.  The run is read 64 slots at a time (coalesced; the colour
@@ -2567,7 +2569,8 @@ __global__ void __launch_bounds__(256) k_film(DPathState st, DFrame fr, DTables 
                 for (int stp = 0; stp < steps_per_pix; ++stp) {
                     const size_t slot = base + (size_t)p0 * S + (size_t)stp * 64 + lane;
                     // slots of film padding were never written by k_camera: whatever they hold is converted but never added
-                    const v3 rgb = spectral_to_rgb_clamped(T, ld4(&st.L[slot]), ld4(&st.lambda_s[slot]), ld4(&st.pdf[slot]), fr.max_component_value);
+                    const S4 lam_ = ld4(&st.lambda_s[slot]);
+                    const v3 rgb = spectral_to_rgb_clamped(T, ld4(&st.L[slot]), lam_, pdf_of(lam_), fr.max_component_value);
                     const float fw = st.filter_w[slot];
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                     mine[4 * lane + 0] = fw * rgb.x;
@@ -2598,7 +2601,8 @@ __global__ void __launch_bounds__(256) k_film(DPathState st, DFrame fr, DTables 
             const int lo = lane * S, hi = lo + S;
             for (int j = 0; j < 64 * S; j += 64) {
                 const size_t slot = base + j + lane;
-                const v3 rgb = spectral_to_rgb_clamped(T, ld4(&st.L[slot]), ld4(&st.lambda_s[slot]), ld4(&st.pdf[slot]), fr.max_component_value);
+                const S4 lam_ = ld4(&st.lambda_s[slot]);
+                const v3 rgb = spectral_to_rgb_clamped(T, ld4(&st.L[slot]), lam_, pdf_of(lam_), fr.max_component_value);
                 const float fw = st.filter_w[slot];
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                 mine[4 * lane + 0] = fw * rgb.x;

@@ -249,7 +249,7 @@ struct DPathState {
     int* mat_id;           // per entry of the current generation: resolved material index of the hit (| HK_MAT_EMISSIVE_BIT)
     // per path slot: written once by the camera kernel, accumulated into (L) along the path, read by the film kernel
     float4* lambda_s;
-    float4* pdf;
+    float4* pdf;           // unused since round 3: the wavelength pdfs are recomputed from lambda_s by k_film (kept: ABI of the struct)
     float4* L;
     float* filter_w;
     // shadow records, dense in shadow-queue order (entry = segment * wave_cap + position in the segment's shadow queue)

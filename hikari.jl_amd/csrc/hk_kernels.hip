@@ -1028,6 +1028,10 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
                                 k_in_seg = 0;
                             }
                         }
+                    }
+                    // a lane that has just entered a cell draws its first free flight in the same round (same operations per path
+                    // in the same order; one round less per cell entered)
+                    if (!in_seg || survived) {
                     } else if (k_in_seg >= 1024) {
                         in_seg = false;
                     } else {
@@ -2002,6 +2006,8 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
                                 }
                             }
                             after_inner = false;
+                        }
+                        if (!in_seg || track_done) {   // (a lane that has just entered a cell goes on in the same round: see k_track)
                         } else if (k_in_seg >= 100) {
                             in_seg = false;
                             after_inner = true;

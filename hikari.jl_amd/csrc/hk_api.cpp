@@ -1324,9 +1324,9 @@ extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_
             const int v = e ? std::atoi(e) : dflt;
             return v >= 1 && v <= 255 ? v : dflt;
         };
-        fr.delta_advance = knob("HK_DELTA_ADVANCE", 4);
+        fr.delta_advance = knob("HK_DELTA_ADVANCE", 3);
         fr.refill_idle = knob("HK_TRACK_REFILL_IDLE", 24);
-        fr.walk_tune = knob("HK_SHADOW_TRACK_BATCH", 8) | (knob("HK_TRACK_ADVANCE", 4) << 8) | (knob("HK_SHADOW_FEED_ROUNDS", 3) << 16) | ((knob("HK_WALK_REFILL_IDLE", 16) & 63) << 24);
+        fr.walk_tune = knob("HK_SHADOW_TRACK_BATCH", 8) | (knob("HK_TRACK_ADVANCE", 2) << 8) | (knob("HK_SHADOW_FEED_ROUNDS", 3) << 16) | ((knob("HK_WALK_REFILL_IDLE", 16) & 63) << 24);
     }
     DSobol sob = make_sobol(I->p, W, H);
     {   // pixel-digit table of the sampler: depends on film size, spp exponent and max_depth only

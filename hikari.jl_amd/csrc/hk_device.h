@@ -2008,7 +2008,7 @@ template <int MM>
 HKD bool majorant_next(MajorantIter& it, const DMedium& m, S4 sigma_t, float& seg_t_min, float& seg_t_max, S4& sigma_maj) {  // media.jl:625-729
     const int mode = it.mode & 0xff;
     if (mode == 0) return false;
-    if (mode == 1) {
+    if (HK_HAS_MEDIUM(MM, HK_MEDIUM_HOMOGENEOUS) && mode == 1) {
         it.mode = 0;
         if (it.t_min >= it.t_max) return false;
         seg_t_min = it.t_min;
@@ -2037,7 +2037,8 @@ HKD bool majorant_next(MajorantIter& it, const DMedium& m, S4 sigma_t, float& se
     const bool neg = (it.mode & (a0 ? 0x100 : (a1 ? 0x200 : 0x400))) != 0;
     const int v = (a0 ? vx : (a1 ? vy : vz)) + (neg ? -1 : 1);
     const int lim = neg ? -1 : (a0 ? rx : (a1 ? ry : rz));
-    const float s = nt + (a0 ? it.delta_t[0] : (a1 ? it.delta_t[1] : it.delta_t[2]));
+    const float d0 = it.delta_t[0], d1 = it.delta_t[1], d2 = it.delta_t[2];   // (named: an indexed pick makes the compiler keep the array in LDS)
+    const float s = nt + (a0 ? d0 : (a1 ? d1 : d2));
     it.voxel[0] = a0 ? v : vx;
     it.voxel[1] = a1 ? v : vy;
     it.voxel[2] = (a0 | a1) ? vz : v;

@@ -1178,6 +1178,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
 // medium-scatter.jl:15-138) and phase-function sampling (medium-scatter.jl:148-216).  First writer of this depth's shadow /
 // next-ray segments.
 // ---------------------------------------------------------------------------------------------------
+template <bool FT>   // FT: this bounce's Sobol draws are table loads for every path (see k_shade)
 __global__ void __launch_bounds__(256) k_scatter(DPathState st, DScene sc, DTables T, DFrame fr, DSobol sob, int depth, DStats* stats) {
     unsigned n_lnodes = 0, n_sv = 0;
     HK_FOR_EACH_WAVE_SEGMENT(gw, st, ticket_ptr(st, depth, TK_SCATTER), depth, Q_SCATTER) {
@@ -1212,13 +1213,13 @@ __global__ void __launch_bounds__(256) k_scatter(DPathState st, DScene sc, DTabl
                 SobolCtx sctx = sobol_ctx_slot(sob, T.sobol, fr.x0, fr.y0, fr.tiles_x, pix, k, fr.first_sample + k * fr.sample_stride);
                 const int base_dim = 6 + 7 * depth;
                 if (sc.n_lights > 0) {
-                    float light_select = sobol_1d(sctx, base_dim + 1);
+                    float light_select = sobol_1d<FT>(sctx, base_dim + 1);
                     float light_pmf;
                     int light_idx = bvh_sample_light(sc, sp, mk3(0, 0, 0), light_select, light_pmf, n_lnodes);
                     if (light_idx >= 1 && light_idx <= sc.n_lights && light_pmf > 0.0f) {
                         const DLight& sel = sc.lights[light_idx - 1];
                         v2 u_light = mk2(0.0f, 0.0f);
-                        if (sel.kind >= HK_LIGHT_AMBIENT) u_light = sobol_2d(sctx, base_dim + 3);
+                        if (sel.kind >= HK_LIGHT_AMBIENT) u_light = sobol_2d<FT>(sctx, base_dim + 3);
                         LightSample ls = sample_light(sc, T, sel, sp, lambda, u_light);
                         if (ls.pdf > 0.0f && !is_black(ls.Li)) {
                             float phase_val = hg_p(sg, dot(wo, ls.wi));
@@ -1238,7 +1239,7 @@ __global__ void __launch_bounds__(256) k_scatter(DPathState st, DScene sc, DTabl
                 }
                 int new_depth = depth + 1;
                 if (new_depth < fr.max_depth) {
-                    v2 u = sobol_2d(sctx, base_dim + 6);
+                    v2 u = sobol_2d<FT>(sctx, base_dim + 6);
                     float ppdf;
                     v3 wi = sample_hg(sg, wo, u, ppdf);
                     if (ppdf > 0.0f) {
@@ -3190,8 +3191,14 @@ void launch_medium(hipStream_t s, int n_cu, const DPathState& st, const DScene& 
         const int d = depth, q = Q_SCATTER;
         launch_segment_lists(s, st, 1, &d, &q);
     }
-    const int sblocks = cached_blocks<k_scatter>(256, n_cu, 8);
-    hipLaunchKernelGGL(k_scatter, dim3(clamp_blocks(sblocks, st)), dim3(256), 0, s, st, sc, T, fr, sob, depth, stats);
+    const char* ft_env = std::getenv("HK_SOBOL_TABLE_ONLY");   // read per launch (A/B switch)
+    if (sob.hi_table != nullptr && sob.lo_table != nullptr && 9 + 5 * depth < sob.lo_rows && 9 + 5 * depth < sob.hi_rows && !(ft_env && std::atoi(ft_env) == 0)) {
+        const int sblocks = cached_blocks<k_scatter<true>>(256, n_cu, 8);
+        hipLaunchKernelGGL(k_scatter<true>, dim3(clamp_blocks(sblocks, st)), dim3(256), 0, s, st, sc, T, fr, sob, depth, stats);
+    } else {
+        const int sblocks = cached_blocks<k_scatter<false>>(256, n_cu, 8);
+        hipLaunchKernelGGL(k_scatter<false>, dim3(clamp_blocks(sblocks, st)), dim3(256), 0, s, st, sc, T, fr, sob, depth, stats);
+    }
 }
 void launch_detect_camera_medium(hipStream_t s, const DPathState& st, const DScene& sc, float x, float y, float z, DStats* stats) {
     hipLaunchKernelGGL(k_detect_camera_medium, dim3(1), dim3(64), 0, s, st, sc, x, y, z, stats);

@@ -696,11 +696,15 @@ HKD void tex_bilinear(const DTexture& t, v2 uv, float out[4]) {
     const float* p10 = t.data + ((size_t)(y0 - 1) + (size_t)h * (size_t)(x1 - 1)) * ch;
     const float* p01 = t.data + ((size_t)(y1 - 1) + (size_t)h * (size_t)(x0 - 1)) * ch;
     const float* p11 = t.data + ((size_t)(y1 - 1) + (size_t)h * (size_t)(x1 - 1)) * ch;
-    for (int c = 0; c < ch; ++c) {
-        float c0 = p00[c] * (1.0f - fx) + p10[c] * fx;
-        float c1 = p01[c] * (1.0f - fx) + p11[c] * fx;
-        out[c] = c0 * (1.0f - fy) + c1 * fy;
-    }
+    // channels is 1 or 4: a loop of four with the channel test inside unrolls to constant indices, so `out` stays in registers (a loop
+    // to a run-time bound made the compiler keep every caller's float[4] in LDS)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        if (c < ch) {
+            float c0 = p00[c] * (1.0f - fx) + p10[c] * fx;
+            float c1 = p01[c] * (1.0f - fx) + p11[c] * fx;
+            out[c] = c0 * (1.0f - fy) + c1 * fy;
+        }
 }
 // eval_tex(ctx, ref, uv::Point2f) == _sample_texture_data (textures/basic.jl:19-26): NEAREST texel by truncation
 HKD float eval_f32_nearest(const DScene& sc, const DMaterial& m, int slot, v2 uv) {
@@ -725,12 +729,16 @@ struct TexCtx {
 HKD void tex_bilinear(const DTexture& t, const TexCtx& tc, float out[4]) {
     if (t.pad == 1) {
         if (tc.face == 0u) {  // UV-only evaluation: gray placeholder RGBSpectrum(0.5f0)
-            for (int c = 0; c < t.channels; ++c) out[c] = c < 3 ? 0.5f : 1.0f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < t.channels) out[c] = c < 3 ? 0.5f : 1.0f;
             return;
         }
         const float* f = t.data + (size_t)(tc.face - 1u) * 3u * (size_t)t.channels;
         float w = 1.0f - tc.bu - tc.bv;
-        for (int c = 0; c < t.channels; ++c) out[c] = f[c] * w + f[t.channels + c] * tc.bu + f[2 * t.channels + c] * tc.bv;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < t.channels) out[c] = f[c] * w + f[t.channels + c] * tc.bu + f[2 * t.channels + c] * tc.bv;
         return;
     }
     tex_bilinear(t, tc.uv, out);

@@ -837,6 +837,9 @@ __global__ void __launch_bounds__(BLOCK) k_trace_lean(DPathState st, DScene sc, 
 #ifndef HK_SKIP_ZERO
 #define HK_SKIP_ZERO 0
 #endif
+#ifndef HK_GREY_TRACK_WAVES
+#define HK_GREY_TRACK_WAVES 4
+#endif
 enum { TR_BUSY = -101, TR_EMPTY = -100, TR_SCATTER = -3, TR_ESCAPED = -2 };  // >= 0: reached its surface hit of that material kind
 
 // One open output segment of k_track: the wave owns its count words while it is open.
@@ -852,7 +855,7 @@ struct TrackSeg {
 // wavelengths and no exp at a cell boundary.  Every DECISION (free-flight distance, absorb / scatter / null, termination) is taken on
 // the same first-component arithmetic as in the general code, so the collision sequence of a path is identical.
 template <int MM, bool GREY = false>
-__global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_per_eu(GREY ? 3 : HK_MEDIA_WAVES))) k_track(DPathState st, DScene sc, DTables T, DFrame fr, int depth, DStats* stats, const DMedium* __restrict__ media) {
+__global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_per_eu(GREY ? HK_GREY_TRACK_WAVES : HK_MEDIA_WAVES))) k_track(DPathState st, DScene sc, DTables T, DFrame fr, int depth, DStats* stats, const DMedium* __restrict__ media) {
     // `media` == sc.media: a restrict-qualified kernel argument, so the record of a wave-uniform medium index is read with scalar loads
     const int lane = lane_id();
     const unsigned long long lt_mask = (1ull << lane) - 1ull;

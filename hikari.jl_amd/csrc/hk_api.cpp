@@ -29,6 +29,8 @@ void launch_escaped(hipStream_t, int, const DPathState&, const DScene&, const DT
 void launch_medium(hipStream_t, int, const DPathState&, const DScene&, const DTables&, const DFrame&, const DSobol&, int, DStats*);
 void launch_detect_camera_medium(hipStream_t, const DPathState&, const DScene&, float, float, float, DStats*);
 void launch_shade(hipStream_t, int, int, const DPathState&, const DScene&, const DTables&, const DFrame&, const DSobol&, int, int, DStats*);
+bool preselect_lights(const DScene&, const DPathState&);
+void launch_light_select(hipStream_t, int, const DPathState&, const DScene&, const DTables&, const DFrame&, const DSobol&, int, uint32_t, DStats*);
 void launch_film(hipStream_t, const DPathState&, const DFrame&, const DTables&, void*, bool);
 void launch_segment_lists(hipStream_t, const DPathState&, int, const int*, const int*);
 void launch_finalize(hipStream_t, const void*, bool, float*, int, int);
@@ -1190,6 +1192,8 @@ int ensure_state(hk_integrator* I, int capacity, bool media, bool open_scene) {
     }
     HIP_TRY(alloc_arr(I, s.hit, Q));
     HIP_TRY(alloc_arr(I, s.mat_id, Q));
+    s.sel_light = nullptr;
+    if (!media) HIP_TRY(alloc_arr(I, s.sel_light, Q));   // k_light_select's results (8 B per entry)
     HIP_TRY(alloc_arr(I, s.lambda_s, P));
     s.pdf = nullptr;   // recomputed from lambda_s by k_film
     HIP_TRY(alloc_arr(I, s.L, P));
@@ -1497,6 +1501,11 @@ extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_
                 if (timed(3, [&] { hk::launch_escaped(s, light_blocks, I->st, sc->d, c->tables, fr, depth); }) != HK_OK) return fail(HK_ERR_DEVICE, "event record failed");
             } else if (lists({}, true, depth) != HK_OK)
                 return fail(HK_ERR_DEVICE, "event record failed");
+            // scenes with a deep light BVH: the next-event light of every shading vertex of this depth, chosen by a kernel of its own
+            // (per-lane descent with refill) — part of the shade class
+            if (sc->d.n_lights > 0 && hk::preselect_lights(sc->d, I->st)) {
+                if (timed(2, [&] { hk::launch_light_select(s, shade_blocks, I->st, sc->d, c->tables, fr, sob, depth, sc->kinds_mask, dstats); }) != HK_OK) return fail(HK_ERR_DEVICE, "event record failed");
+            }
             for (int kind = 0; kind < HK_MAX_KINDS; ++kind)
                 if (sc->kinds_mask & (1u << kind)) {
                     if (timed(2, [&] { hk::launch_shade(s, shade_blocks, kind, I->st, sc->d, c->tables, fr, sob, depth, first_kind, dstats); }) != HK_OK) return fail(HK_ERR_DEVICE, "event record failed");

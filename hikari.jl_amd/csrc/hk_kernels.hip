@@ -137,7 +137,7 @@ __device__ __forceinline__ SegStream stream_open(const DPathState& st, int* tick
 }
 __device__ __forceinline__ int stream_next(SegStream& s, int n_segments) { return seg_next(s, n_segments); }
 // ticket words: row = bounce depth (row max_depth + 1: camera / film), column = kernel
-enum { TK_TRACE = 0, TK_TRACK = 1, TK_SHADOW = 2, TK_ESCAPED = 3, TK_SCATTER = 4, TK_SHADE0 = 5, TK_CAMERA = 0, TK_FILM = 1 };
+enum { TK_TRACE = 0, TK_TRACK = 1, TK_SHADOW = 2, TK_ESCAPED = 3, TK_SCATTER = 4, TK_SHADE0 = 5, TK_SELECT = 1, TK_CAMERA = 0, TK_FILM = 1 };   // TK_SELECT shares TK_TRACK's column: k_light_select only runs in scenes without media
 __device__ __forceinline__ int* ticket_ptr(const DPathState& st, int row, int col) { return st.tickets + (size_t)(row * HK_TICKET_COLS + col) * (HK_TICKET_WAYS * HK_TICKET_STRIDE); }
 __device__ __forceinline__ WaveQ wq_open(uint32_t* q, const DPathState& st, int gw) { return WaveQ{q + (size_t)gw * st.wave_cap, 0}; }
 __device__ __forceinline__ void wq_push(WaveQ& q, uint32_t value, bool active) {
@@ -1371,6 +1371,144 @@ __global__ void __launch_bounds__(256) k_escaped(DPathState st, DScene sc, DTabl
 // Register budget: 512 VGPRs per SIMD lane => 3 waves/SIMD need <= 168, 4 need <= 128.  The simple kinds sit a few registers
 // above 168 without a hint; asking for 3 waves costs a handful of scratch spills and buys a third more latency hiding.
 // The walk kinds (coated diffuse / transmission) are far above: they keep the default.
+// ---------------------------------------------------------------------------------------------------
+// Light selection of K9 as its own kernel, for scenes with a deep light BVH (DScene::num_bvh_lights >= HK_PRESELECT_MIN, no media).
+// A descent of bvh_sample_light (bvh-light-sampler.jl:105-170) takes as many levels as the chosen light's leaf is deep — 12 to 25 in
+// the 5*10^4-light scene — and inside k_shade every lane of a wave waits for the deepest: 49 % of the lanes active.  Here each
+// lane is a little state machine (like the traversal kernels'): one level per round for the lanes that descend, finished lanes keep
+// their result until enough of them wait (HK_SELECT_MIN_IDLE = 24: 8 / 16 / 24 / 32 idle lanes give 0.78 / 0.72 / 0.69 / 0.70 s of shading per
+// 512-spp frame; computing the inputs in a dense pre-pass changed nothing), then write it and pull the next shading vertices of the segment — the
+// entries of its per-kind queues, one kind after the other.  Same arithmetic per vertex as the fused form: position and shading normal
+// from surface_at, the sample from dimension base + 1, node_importance in the same order; the result (light, pmf) goes to sel_light[entry].
+// ---------------------------------------------------------------------------------------------------
+#define HK_PRESELECT_MIN 64
+#ifndef HK_SELECT_MIN_IDLE
+#define HK_SELECT_MIN_IDLE 24
+#endif
+template <bool FT>
+__global__ void __launch_bounds__(256) k_light_select(DPathState st, DScene sc, DTables T, DFrame fr, DSobol sob, int depth, uint32_t kinds_mask, int min_idle, DStats* stats) {
+    const int lane = lane_id();
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    unsigned n_lnodes = 0;
+    const DPathGen g = st.gen[depth & 1];
+    const int base_dim = 6 + 7 * depth;
+    const int ninf = sc.num_infinite_lights, nbvh = sc.num_bvh_lights;
+    const bool has_bvh = nbvh > 0;
+    const float p_inf = (float)ninf / (float)(ninf + (has_bvh ? 1 : 0));
+    HK_FOR_EACH_WAVE_SEGMENT(gw, st, ticket_ptr(st, depth, TK_SELECT), depth, Q_RAY) {
+        int kind = -1, n = 0, cursor = 0;
+        const uint32_t* __restrict__ queue = st.mat_q;
+        bool more = true;
+        // per-lane descent state
+        bool busy = false, done = false;
+        uint32_t slot = 0, bits = 0, child = 0;
+        int ni = 1, res_light = 0, lvl = 0;
+        float ub = 0.0f, pmf = 0.0f, res_pmf = 0.0f;
+        v3 p = mk3(0, 0, 0), nn = mk3(0, 0, 1);
+        for (;;) {
+            const unsigned long long run_m = __ballot(busy && !done);
+            if (run_m == 0ull || (64 - __popcll(run_m) >= min_idle && (cursor < n || more))) {
+                if (busy && done) {
+                    st.sel_light[slot] = make_uint2((uint32_t)res_light, __float_as_uint(res_pmf));
+                    busy = false;
+                }
+                while (more && cursor >= n) {   // the next kind present in the scene that has entries in this segment
+                    ++kind;
+                    while (kind < HK_MAX_KINDS && !(kinds_mask & (1u << kind))) ++kind;
+                    if (kind >= HK_MAX_KINDS) {
+                        more = false;
+                        break;
+                    }
+                    queue = st.mat_q + ((size_t)kind * st.n_waves + gw) * st.wave_cap;
+                    n = *count_ptr(st, depth, Q_MAT0 + kind, gw);
+                    cursor = 0;
+                }
+                const unsigned long long want = __ballot(!busy);
+                const int avail = n - cursor;
+                const int rank = __popcll(want & lt_mask);
+                if (!busy && rank < avail) {
+                    slot = queue[cursor + rank];
+                    const float4 H = st.hit[slot], O = g.ray_o[slot], D = g.ray_d[slot];
+                    const Surface sf = surface_at(sc, __float_as_int(H.y), H.z, H.w, mk3(O.x, O.y, O.z), mk3(D.x, D.y, D.z), H.x);
+                    p = sf.pi;
+                    nn = sf.ns;
+                    int pix, k;
+                    split_slot(fr, g.meta[slot].y, pix, k);
+                    const SobolCtx sctx = sobol_ctx_slot(sob, T.sobol, fr.x0, fr.y0, fr.tiles_x, pix, k, fr.first_sample + k * fr.sample_stride);
+                    const float u = sobol_1d<FT>(sctx, base_dim + 1);
+                    // bvh_sample_light's prologue: the infinite lights, then the root
+                    busy = true;
+                    done = true;
+                    res_light = 0;
+                    res_pmf = 0.0f;
+                    if (ninf + nbvh > 0) {
+                        if (ninf > 0 && u < p_inf) {
+                            const float ur = u / p_inf;
+                            int idx = (int)floorf(ur * (float)ninf);
+                            idx = (idx < ninf - 1 ? idx : ninf - 1) + 1;
+                            res_pmf = p_inf / (float)ninf;
+                            res_light = sc.infinite_lights[idx - 1];
+                        } else if (has_bvh) {
+                            ub = ninf > 0 ? minf((u - p_inf) / (1.0f - p_inf), 0.99999994f) : minf(u, 0.99999994f);
+                            pmf = 1.0f - p_inf;
+                            ni = 1;
+                            const DLightNode root = load_light_node(sc.lnodes, 0);
+                            bits = root.bits, child = root.child1_or_light;
+                            lvl = 0;
+                            done = false;
+                        }
+                    }
+                }
+                const int want_n = __popcll(want);
+                cursor += want_n < avail ? want_n : (avail > 0 ? avail : 0);
+                if (__ballot(busy) == 0ull) {
+                    if (cursor >= n && !more) break;
+                    continue;
+                }
+            }
+            // ---- one level of the descent for the lanes that are on their way ----
+            if (busy && !done) {
+                if (lvl >= 64) {   // the reference gives up after 64 levels (bvh-light-sampler.jl:126)
+                    res_light = 0;
+                    res_pmf = 0.0f;
+                    done = true;
+                } else if (bits & 2u) {
+                    res_pmf = pmf;
+                    res_light = (int)child;
+                    done = true;
+                } else {
+                    ++lvl;
+                    const int c0i = ni + 1, c1i = (int)child;
+                    const DLightNode n0 = load_light_node(sc.lnodes, c0i - 1), n1 = load_light_node(sc.lnodes, c1i - 1);
+                    const float c0 = node_importance(n0, p, nn);
+                    const float c1 = node_importance(n1, p, nn);
+                    n_lnodes += 2;
+                    if (c0 == 0.0f && c1 == 0.0f) {
+                        res_light = 0;
+                        res_pmf = 0.0f;
+                        done = true;
+                    } else {
+                        const float p0 = c0 / (c0 + c1);
+                        if (ub < p0) {
+                            pmf *= p0;
+                            ub = ub / p0;
+                            ni = c0i;
+                            bits = n0.bits, child = n0.child1_or_light;
+                        } else {
+                            pmf *= (1.0f - p0);
+                            ub = (ub - p0) / (1.0f - p0);
+                            ni = c1i;
+                            bits = n1.bits, child = n1.child1_or_light;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    stats += global_wave();
+    wave_add(&stats->light_nodes, n_lnodes);
+}
+
 #ifndef HK_SHADE_WAVES_MATTE
 #define HK_SHADE_WAVES_MATTE 4
 #endif
@@ -1427,7 +1565,9 @@ struct ShadeWaves {
 // FT ("full tables"; Matte, Mirror, Glass, Conductor): every Sobol draw of this bounce is in the sampler's two tables for every path of the launch (the host
 // checks DSobol::lo_rows against the rows of this depth): the draws are two loads each and the digit-hashing fallback — three 64-bit
 // hash loops inlined at each of the five draw sites — is not in the kernel at all.
-template <int KIND, bool SIMPLE = false, bool FT = false>
+// PRE: the light of this vertex's next-event estimation was chosen by k_light_select (scenes with a deep light BVH): the descent —
+// three quarters of this kernel's time in the 5*10^4-light scene, run at 49 % lane utilisation because leaf depths differ — is not here.
+template <int KIND, bool SIMPLE = false, bool FT = false, bool PRE = false>
 __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_per_eu(ShadeWaves<KIND>::value))) k_shade(DPathState st, DScene sc, DTables T, DFrame fr, DSobol sob, int depth, int first_kind, DStats* stats) {
     __shared__ uint32_t emit_list[4 * 128];   // per wave: slots of flagged (emissive-hit) vertices waiting for the dense K8 pass
     const int lane = lane_id();
@@ -1580,9 +1720,16 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
             // ---- K9: next-event estimation through the light BVH ----
             if (sc.n_lights > 0) {
                 const DMaterial& mat = sc.materials[st.mat_id[slot] & ~HK_MAT_EMISSIVE_BIT];
-                float light_select = sobol_1d<FT>(sctx, base_dim + 1);
                 float light_pmf;
-                int light_idx = bvh_sample_light(sc, sf.pi, sf.ns, light_select, light_pmf, n_lnodes);
+                int light_idx;
+                if constexpr (PRE) {
+                    const uint2 pre = st.sel_light[slot];
+                    light_idx = (int)pre.x;
+                    light_pmf = __uint_as_float(pre.y);
+                } else {
+                    float light_select = sobol_1d<FT>(sctx, base_dim + 1);
+                    light_idx = bvh_sample_light(sc, sf.pi, sf.ns, light_select, light_pmf, n_lnodes);
+                }
                 if (light_idx >= 1 && light_idx <= sc.n_lights && light_pmf > 0.0f) {
                     const DLight& sel = sc.lights[light_idx - 1];
                     // delta lights ignore the 2-D sample (lights.jl:39-131): draw it only for lights that use it
@@ -3210,6 +3357,26 @@ void launch_escaped(hipStream_t s, int n_cu, const DPathState& st, const DScene&
     const int blocks = cached_blocks<k_escaped>(256, n_cu, 8);
     hipLaunchKernelGGL(k_escaped, dim3(clamp_blocks(blocks, st)), dim3(256), 0, s, st, sc, T, depth, fr.implicit_ones);
 }
+static bool sobol_tables_cover(const DSobol& sob, int depth) {
+    const char* ft_env = std::getenv("HK_SOBOL_TABLE_ONLY");   // read per launch (A/B switch)
+    return sob.hi_table != nullptr && sob.lo_table != nullptr && 9 + 5 * depth < sob.lo_rows && 9 + 5 * depth < sob.hi_rows && !(ft_env && std::atoi(ft_env) == 0);
+}
+// scenes whose next-event light is chosen by k_light_select before the shade kernels run (HK_PRESELECT=0: never)
+bool preselect_lights(const DScene& sc, const DPathState& st) {
+    const char* e = std::getenv("HK_PRESELECT");
+    return sc.n_media == 0 && sc.num_bvh_lights >= HK_PRESELECT_MIN && st.sel_light != nullptr && !(e && std::atoi(e) == 0);
+}
+void launch_light_select(hipStream_t s, int n_cu, const DPathState& st, const DScene& sc, const DTables& T, const DFrame& fr, const DSobol& sob, int depth, uint32_t kinds_mask, DStats* stats) {
+    int min_idle = HK_SELECT_MIN_IDLE;
+    if (const char* e = std::getenv("HK_SELECT_MIN_IDLE")) min_idle = std::atoi(e) >= 1 && std::atoi(e) <= 64 ? std::atoi(e) : min_idle;
+    if (sobol_tables_cover(sob, depth)) {
+        const int blocks = cached_blocks<k_light_select<true>>(256, n_cu, 8);
+        hipLaunchKernelGGL(k_light_select<true>, dim3(clamp_blocks(blocks, st)), dim3(256), 0, s, st, sc, T, fr, sob, depth, kinds_mask, min_idle, stats);
+    } else {
+        const int blocks = cached_blocks<k_light_select<false>>(256, n_cu, 8);
+        hipLaunchKernelGGL(k_light_select<false>, dim3(clamp_blocks(blocks, st)), dim3(256), 0, s, st, sc, T, fr, sob, depth, kinds_mask, min_idle, stats);
+    }
+}
 void launch_shade(hipStream_t s, int n_cu, int kind, const DPathState& st, const DScene& sc, const DTables& T, const DFrame& fr, const DSobol& sob, int depth, int first_kind, DStats* stats) {
 #define HK_SHADE_CASE(K)                                                                                                          \
     case K: {                                                                                                                     \
@@ -3218,8 +3385,25 @@ void launch_shade(hipStream_t s, int n_cu, int kind, const DPathState& st, const
     } break;
     // both sampler tables hold every draw of this bounce (rows up to 9 + 5 depth: sobol_row) for every path of the pass: the table-only
     // instantiation (HK_SOBOL_TABLE_ONLY=0: always the general one — A/B switch, read per launch)
-    const char* ft_env = std::getenv("HK_SOBOL_TABLE_ONLY");   // read per launch (A/B switch)
-    const bool ft = sob.hi_table != nullptr && sob.lo_table != nullptr && 9 + 5 * depth < sob.lo_rows && 9 + 5 * depth < sob.hi_rows && !(ft_env && std::atoi(ft_env) == 0);
+    const bool ft = sobol_tables_cover(sob, depth);
+    if (preselect_lights(sc, st)) {   // k_light_select has run for this depth: the instantiations without the light-BVH descent
+#define HK_SHADE_PRE(K)                                                                                                                 \
+    if (kind == K) {                                                                                                                    \
+        if (ft) {                                                                                                                       \
+            const int blocks = cached_blocks<k_shade<K, false, true, true>>(256, n_cu, 8);                                            \
+            hipLaunchKernelGGL((k_shade<K, false, true, true>), dim3(clamp_blocks(blocks, st)), dim3(256), 0, s, st, sc, T, fr, sob, depth, first_kind, stats); \
+        } else {                                                                                                                        \
+            const int blocks = cached_blocks<k_shade<K, false, false, true>>(256, n_cu, 8);                                           \
+            hipLaunchKernelGGL((k_shade<K, false, false, true>), dim3(clamp_blocks(blocks, st)), dim3(256), 0, s, st, sc, T, fr, sob, depth, first_kind, stats); \
+        }                                                                                                                               \
+        return;                                                                                                                         \
+    }
+        HK_SHADE_PRE(HK_MAT_MATTE)
+        HK_SHADE_PRE(HK_MAT_MIRROR)
+        HK_SHADE_PRE(HK_MAT_GLASS)
+        HK_SHADE_PRE(HK_MAT_CONDUCTOR)
+#undef HK_SHADE_PRE
+    }
     if (kind == HK_MAT_MATTE && sc.simple_lights) {
         if (ft) {
             const int blocks = cached_blocks<k_shade<HK_MAT_MATTE, true, true>>(256, n_cu, 8);

@@ -247,6 +247,7 @@ struct DPathState {
     DPathGen gen[2];       // gen[depth & 1]: the ray queue of that depth IS this array (no index queue)
     float4* hit;           // per entry of the current generation: t, prim(bits), u, v
     int* mat_id;           // per entry of the current generation: resolved material index of the hit (| HK_MAT_EMISSIVE_BIT)
+    uint2* sel_light;      // per entry of the current generation: the next-event light k_light_select chose (1-based index, pmf bits); scenes without media
     // per path slot: written once by the camera kernel, accumulated into (L) along the path, read by the film kernel
     float4* lambda_s;
     float4* pdf;           // unused since round 3: the wavelength pdfs are recomputed from lambda_s by k_film (kept: ABI of the struct)

@@ -657,6 +657,40 @@ def test_zsobol_sample_bit_table(hk, oracle, monkeypatch, first, n, stride, per_
     assert rel_mse <= 1e-5 and frac >= 0.995, (rel_mse, frac)
 
 
+def test_light_preselection_is_result_neutral(hk, monkeypatch):
+    """Scenes with a deep light BVH choose the next-event light in a kernel of its own (k_light_select: per-lane descent with refill)
+    before the shade kernels run.  Same arithmetic per vertex as the fused form: the film must be bit-identical with HK_PRESELECT=0,
+    at any refill threshold, with and without the table-only Sobol instantiations."""
+    from hikari_jl_amd import scenes
+    w, h = 40, 36
+    s, film, cam = scenes.many_light_scene(w, h, n_boxes=4000)      # ~2.4 k area lights: well above HK_PRESELECT_MIN
+    kw = dict(max_depth=5, samples=64)
+
+    def run(env):
+        for k in ("HK_PRESELECT", "HK_SELECT_MIN_IDLE", "HK_SOBOL_TABLE_ONLY"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        vp = hk.VolPath(**kw)
+        vp._ensure(film)
+        vp.clear()
+        vp.reset_stats()
+        vp.render_samples(s, film, cam, 20, first=1)
+        acc = vp.read_accumulators(film).copy()
+        nodes = int(vp.stats().light_bvh_nodes)
+        vp.close()
+        return acc, nodes
+
+    ref, nodes = run({"HK_PRESELECT": "0"})
+    assert np.isfinite(ref).all() and ref.max() > 0 and nodes > 0
+    for env in ({}, {"HK_SELECT_MIN_IDLE": "1"}, {"HK_SELECT_MIN_IDLE": "64"}, {"HK_SOBOL_TABLE_ONLY": "0"}, {"HK_SOBOL_TABLE_ONLY": "0", "HK_PRESELECT": "0"}):
+        got, n2 = run(env)
+        assert np.array_equal(ref.view(np.uint32), got.view(np.uint32)), env
+        assert n2 == nodes, (env, n2, nodes)                            # the same node evaluations, wherever they run
+    for k in ("HK_PRESELECT", "HK_SELECT_MIN_IDLE", "HK_SOBOL_TABLE_ONLY"):
+        monkeypatch.delenv(k, raising=False)
+
+
 @pytest.mark.parametrize("which", ["cornell", "sky", "slab", "cloud"])
 def test_scheduling_is_result_neutral(hk, monkeypatch, which):
     """How segments reach waves must not change a bit of the film: static stride vs tickets over the work lists, other segment counts

@@ -15,7 +15,7 @@ import json
 import re
 import sys
 
-FAMILIES = ["k_trace", "k_shade", "k_shadow", "k_camera", "k_film", "k_track", "k_scatter", "k_escaped"]
+FAMILIES = ["k_trace", "k_shade", "k_shadow", "k_camera", "k_film", "k_track", "k_scatter", "k_escaped", "k_light_select", "k_walk"]
 
 
 def family(name):

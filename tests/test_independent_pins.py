@@ -1608,3 +1608,241 @@ def test_nested_scattering_media_furnace(hk, oracle):
     want = 1.0 + X.mean()
     assert 1.3 < want < 1.8, want
     assert np.allclose(gain, want, rtol=0.02), (gain, want)
+
+
+# ---------------------------------------------------------------------------------------------------- CoatedConductor by formula
+def test_coated_conductor_sample_against_float64(hk, oracle):
+    """sample_bsdf_spectral(::CoatedConductorMaterial) (spectral-eval.jl:2877-3235) is closed-form — one Fresnel-weighted lobe pick, no
+    random walk (Q13) — so its four configurations can be written down in float64 from the text and compared sample by sample:
+      smooth coat / smooth metal:  uc < F_i: mirror, f = 1, pdf = 1;  else mirror, f = F_c(cos_t) T_in T_out tr / cos_o, pdf = 1 - F_i
+      smooth coat / rough metal:   else-branch: microfacet reflection INSIDE the coat (wo refracted by 1/eta), back out by Snell:
+                                   f = D F_c G / (4 cos cos) T_in T_out tr, pdf = (1 - F_i) D_wo(wm) / (4 |wo.wm|)
+      rough coat (either metal):   uc < F_i(wo.wm): reflection off the coat's microfacet, f = D G / (4 cos cos) (no Fresnel factor),
+                                   pdf = F_i D_wo / (4 |wo.wm|);  else the metal seen along the un-refracted directions
+    with F_c the complex Fresnel of (eta, k) / eta_coat, k = 2 sqrt(r) / sqrt(1 - r + 1e-6) and eta = 1 in reflectance mode, and
+    tr = albedo exp(-thickness / cos) per traversal when the coat holds a medium.  The oracle (and through it the HIP path:
+    hk_test_bsdf parity) must agree with these expressions."""
+    from test_layered_materials import MATERIAL_NAMES, palette_scene
+    osc = oracle.OracleScene(palette_scene(hk))
+    n = 6000
+    rng = np.random.default_rng(21)
+    wo = _dirs(rng, n, upper=True)
+    wo = wo[wo[:, 2] > 0.08][:4000]
+    n = wo.shape[0]
+    z = np.tile(np.array([[0, 0, 1]], f32), (n, 1))
+    lam = (360 + 470 * rng.random((n, 4))).astype(f32)
+    u = rng.random((n, 2)).astype(f32)
+    uc = rng.random(n).astype(f32)
+    wo64 = wo.astype(np.float64)
+    cos_o = wo64[:, 2]
+    ieta = 1.5
+    mirror = wo64 * np.array([-1.0, -1.0, 1.0])
+    e_rgb = oracle.uplift(1, np.tile([[0.2, 0.92, 1.1]], (n, 1)), lam).astype(np.float64) / ieta
+    k_rgb = oracle.uplift(1, np.tile([[3.9, 2.45, 2.14]], (n, 1)), lam).astype(np.float64) / ieta
+    alpha = lambda r: float(np.sqrt(f32(r)))
+
+    def snell_in(w):        # direction inside the coat, normalised the way the reference does it
+        s2 = np.maximum(0.0, 1 - w[:, 2] ** 2) / ieta ** 2
+        ct = np.sqrt(1 - s2)
+        v = np.stack([w[:, 0] / ieta, w[:, 1] / ieta, ct], 1)
+        return v / np.linalg.norm(v, axis=1, keepdims=True), ct
+
+    def check(name, want_wi, want_f, want_pdf, want_spec, sel, rtol=3e-3):
+        S = osc.bsdf(0, MATERIAL_NAMES.index(name), wo, wo, z, lam, u, uc).astype(np.float64)
+        ok = sel & (S[:, 7] > 0) & (np.abs(S[:, 2]) > 0.03)
+        assert ok.sum() > 0.3 * sel.sum(), (name, ok.sum(), sel.sum())
+        close = np.abs(S[:, 0:3] - want_wi).max(axis=1) < 2e-3          # (sample_wm's binary32 knife edges move a handful)
+        assert close[ok].mean() > 0.995, (name, close[ok].mean())
+        ok &= close
+        assert np.allclose(S[ok, 3:7], want_f[ok], rtol=rtol, atol=1e-6), (name, np.abs(S[ok, 3:7] / np.maximum(want_f[ok], 1e-12) - 1).max())
+        assert np.allclose(S[ok, 7], want_pdf[ok], rtol=rtol, atol=1e-6), name
+        assert (S[ok, 8] == (1.0 if want_spec else 0.0)).all(), name
+
+    # ---- smooth coat, smooth metal ----
+    F_i = R.fresnel_dielectric(cos_o, ieta)
+    refl = uc.astype(np.float64) < F_i
+    _, ct = snell_in(wo64)
+    F_c = R.fr_complex(ct[:, None], e_rgb, k_rgb)
+    T = (1 - F_i)[:, None]
+    f_t = F_c * T * T / cos_o[:, None]
+    check("cc_ss", mirror, np.where(refl[:, None], 1.0, f_t), np.where(refl, 1.0, 1 - F_i), True, np.abs(uc - F_i) > 1e-4)
+    # ---- smooth coat, rough metal (roughness 0.2) ----
+    a_c = alpha(0.2)
+    wo_c, ct = snell_in(wo64)
+    wm = R.tr_sample_wm(wo_c, u, a_c, a_c)
+    c = (wo_c * wm).sum(1)
+    wi_c = -wo_c + 2 * c[:, None] * wm
+    F_c = R.fr_complex(np.abs(c)[:, None], e_rgb, k_rgb)
+    f_c = (R.tr_d(wm, a_c, a_c) * R.tr_g(wo_c, wi_c, a_c, a_c) / (4 * np.abs(wo_c[:, 2]) * np.abs(wi_c[:, 2])))[:, None] * F_c
+    s2o = (wi_c[:, 0] ** 2 + wi_c[:, 1] ** 2) * ieta ** 2
+    co = np.sqrt(np.maximum(0.0, 1 - s2o))
+    wi_l = np.stack([wi_c[:, 0] * ieta, wi_c[:, 1] * ieta, co], 1)
+    wi_l /= np.linalg.norm(wi_l, axis=1, keepdims=True)
+    T_out = 1 - R.fresnel_dielectric(co, ieta)
+    f_t = f_c * (1 - F_i)[:, None] * T_out[:, None]
+    pdf_t = (1 - F_i) * R.tr_pdf(wo_c, wm, a_c, a_c) / (4 * np.abs(c))
+    valid = (c > 0) & (wi_c[:, 2] > 0) & (s2o < 1)
+    S = osc.bsdf(0, MATERIAL_NAMES.index("cc_sr"), wo, wo, z, lam, u, uc).astype(np.float64)
+    assert not S[~refl & ~valid & (np.abs(uc - F_i) > 1e-4), 7].any()                      # back-facing microfacet / total internal reflection: no sample
+    sel = (np.abs(uc - F_i) > 1e-4) & ~refl & valid
+    check("cc_sr", wi_l, f_t, pdf_t, False, sel)
+    check("cc_sr", mirror, np.ones((n, 4)), np.ones(n), True, (np.abs(uc - F_i) > 1e-4) & refl)
+    # ---- rough coat (roughness 0.2), smooth metal ----
+    a_i = alpha(0.2)
+    wm = R.tr_sample_wm(wo64, u, a_i, a_i)
+    c = (wo64 * wm).sum(1)
+    F_m = R.fresnel_dielectric(c, ieta)
+    refl_m = uc.astype(np.float64) < F_m
+    edge = np.abs(uc - F_m) > 1e-4
+    wi_r = -wo64 + 2 * c[:, None] * wm
+    pdf_m = R.tr_pdf(wo64, wm, a_i, a_i) / (4 * np.abs(c))
+    f_r = (R.tr_d(wm, a_i, a_i) * R.tr_g(wo64, wi_r, a_i, a_i) / (4 * np.abs(wi_r[:, 2]) * cos_o))[:, None] * np.ones((1, 4))
+    check("cc_rs", wi_r, f_r, F_m * pdf_m, False, edge & refl_m & (c > 0) & (wi_r[:, 2] > 0))
+    F_c = R.fr_complex(cos_o[:, None], e_rgb, k_rgb)
+    f_t = F_c * (1 - F_m)[:, None] * (1 - R.fresnel_dielectric(cos_o, ieta))[:, None] / cos_o[:, None]
+    check("cc_rs", mirror, f_t, (1 - F_m) * pdf_m, False, edge & ~refl_m & (c > 0))
+    # ---- rough coat (0.1), rough metal (0.3), reflectance mode, a medium in the coat (albedo 0.8, thickness 0.05) ----
+    a_i, a_c, thick = alpha(0.1), alpha(0.3), 0.05
+    r_sp = oracle.uplift(0, np.tile([[0.9, 0.6, 0.3]], (n, 1)), lam).astype(np.float64)
+    kk = 2 * np.sqrt(r_sp) / np.sqrt(np.maximum(1 - r_sp, 0.0) + 1e-6) / ieta
+    ee = np.ones_like(kk) / ieta
+    alb = oracle.uplift(0, np.tile([[0.8, 0.8, 0.8]], (n, 1)), lam).astype(np.float64)
+    wm = R.tr_sample_wm(wo64, u, a_i, a_i)
+    c = (wo64 * wm).sum(1)
+    F_m = R.fresnel_dielectric(c, ieta)
+    refl_m = uc.astype(np.float64) < F_m
+    edge = np.abs(uc - F_m) > 1e-4
+    wi_r = -wo64 + 2 * c[:, None] * wm
+    f_r = (R.tr_d(wm, a_i, a_i) * R.tr_g(wo64, wi_r, a_i, a_i) / (4 * np.abs(wi_r[:, 2]) * cos_o))[:, None] * np.ones((1, 4))
+    check("cc_rr", wi_r, f_r, F_m * R.tr_pdf(wo64, wm, a_i, a_i) / (4 * np.abs(c)), False, edge & refl_m & (c > 0) & (wi_r[:, 2] > 0))
+    wm_c = R.tr_sample_wm(wo64, u, a_c, a_c)
+    cc = (wo64 * wm_c).sum(1)
+    wi_t = -wo64 + 2 * cc[:, None] * wm_c
+    F_c = R.fr_complex(np.abs(cc)[:, None], ee, kk)
+    ci = np.abs(wi_t[:, 2])
+    f_c = (R.tr_d(wm_c, a_c, a_c) * R.tr_g(wo64, wi_t, a_c, a_c) / (4 * ci * cos_o))[:, None] * F_c
+    tr = (np.exp(-thick / cos_o) * np.exp(-thick / np.maximum(ci, 1e-9)))[:, None] * alb
+    f_t = f_c * (1 - F_m)[:, None] * (1 - R.fresnel_dielectric(ci, ieta))[:, None] * tr
+    pdf_t = (1 - F_m) * R.tr_pdf(wo64, wm_c, a_c, a_c) / (4 * np.abs(cc))
+    check("cc_rr", wi_t, f_t, pdf_t, False, edge & ~refl_m & (c > 0) & (cc > 0) & (wi_t[:, 2] > 0), rtol=5e-3)
+    osc.close()
+
+
+def test_coated_conductor_evaluate_against_float64(hk, oracle):
+    """evaluate_bsdf_spectral(::CoatedConductorMaterial) (spectral-eval.jl:3243-3420) by formula, on random direction pairs:
+      smooth / smooth: no non-delta part (0, 0);
+      smooth coat, rough metal: f = D_c F_c(|wo.wh|) G_c / (4 cos cos) T(wo) T(wi) tr,  pdf = T(wo) D_wo(wh) / (4 |wo.wh|) — the UN-refracted
+          directions evaluate the metal's lobe (the sampler refracts them: the two are not each other's density; reproduced as written);
+      rough coat: f = D_i F_i(|wo.wh|) G_i / (4 cos cos) + metal term T(wo) T(wi) tr, with the metal term F_c(cos_o) / cos_o and
+          "pdf" 1 for a smooth metal, the microfacet lobe otherwise;  pdf = F_i(cos_o) D_wo,i(wh) / (4 |wo.wh|) + T(wo) pdf_metal;
+      tr = albedo exp(-thickness / |wi_z|)^2 with a medium in the coat."""
+    from test_layered_materials import MATERIAL_NAMES, palette_scene
+    osc = oracle.OracleScene(palette_scene(hk))
+    rng = np.random.default_rng(22)
+    n = 6000
+    wo, wi = _dirs(rng, n, upper=True), _dirs(rng, n, upper=True)
+    keep = (wo[:, 2] > 0.06) & (wi[:, 2] > 0.06)
+    wo, wi = wo[keep], wi[keep]
+    n = wo.shape[0]
+    z = np.tile(np.array([[0, 0, 1]], f32), (n, 1))
+    lam = (360 + 470 * rng.random((n, 4))).astype(f32)
+    u0, uc0 = np.zeros((n, 2), f32), np.zeros(n, f32)
+    wo64, wi64 = wo.astype(np.float64), wi.astype(np.float64)
+    ieta = 1.5
+    e_rgb = oracle.uplift(1, np.tile([[0.2, 0.92, 1.1]], (n, 1)), lam).astype(np.float64) / ieta
+    k_rgb = oracle.uplift(1, np.tile([[3.9, 2.45, 2.14]], (n, 1)), lam).astype(np.float64) / ieta
+    alpha = lambda r: float(np.sqrt(f32(r)))
+    wh = wo64 + wi64
+    wh /= np.linalg.norm(wh, axis=1, keepdims=True)
+    coh = np.abs((wo64 * wh).sum(1))
+    co, ci = wo64[:, 2], wi64[:, 2]
+    T_o, T_i = 1 - R.fresnel_dielectric(co, ieta), 1 - R.fresnel_dielectric(ci, ieta)
+
+    def lobe(a, F):
+        return (R.tr_d(wh, a, a) * R.tr_g(wo64, wi64, a, a) / (4 * ci * co))[:, None] * F, R.tr_pdf(wo64, wh, a, a) / (4 * coh)
+
+    def got(name):
+        return osc.bsdf(1, MATERIAL_NAMES.index(name), wo, wi, z, lam, u0, uc0).astype(np.float64)
+
+    assert not got("cc_ss").any()
+    # smooth coat, rough metal
+    f_c, p_c = lobe(alpha(0.2), R.fr_complex(coh[:, None], e_rgb, k_rgb))
+    E = got("cc_sr")
+    assert np.allclose(E[:, 0:4], f_c * (T_o * T_i)[:, None], rtol=2e-3, atol=1e-7) and np.allclose(E[:, 4], T_o * p_c, rtol=2e-3, atol=1e-7)
+    # rough coat, smooth metal
+    a_i = alpha(0.2)
+    f_i, p_i = lobe(a_i, R.fresnel_dielectric(coh, ieta)[:, None] * np.ones((1, 4)))
+    f_m = R.fr_complex(co[:, None], e_rgb, k_rgb) / co[:, None]
+    E = got("cc_rs")
+    assert np.allclose(E[:, 0:4], f_i + f_m * (T_o * T_i)[:, None], rtol=2e-3, atol=1e-7)
+    assert np.allclose(E[:, 4], R.fresnel_dielectric(co, ieta) * p_i + T_o * 1.0, rtol=2e-3, atol=1e-7)
+    # rough coat, rough metal, reflectance mode, medium
+    a_i, a_c, thick = alpha(0.1), alpha(0.3), 0.05
+    r_sp = oracle.uplift(0, np.tile([[0.9, 0.6, 0.3]], (n, 1)), lam).astype(np.float64)
+    kk = 2 * np.sqrt(r_sp) / np.sqrt(np.maximum(1 - r_sp, 0.0) + 1e-6) / ieta
+    ee = np.ones_like(kk) / ieta
+    alb = oracle.uplift(0, np.tile([[0.8, 0.8, 0.8]], (n, 1)), lam).astype(np.float64)
+    f_i, p_i = lobe(a_i, R.fresnel_dielectric(coh, ieta)[:, None] * np.ones((1, 4)))
+    f_c, p_c = lobe(a_c, R.fr_complex(coh[:, None], ee, kk))
+    tr = (np.exp(-thick / ci) ** 2)[:, None] * alb
+    E = got("cc_rr")
+    assert np.allclose(E[:, 0:4], f_i + f_c * (T_o * T_i)[:, None] * tr, rtol=3e-3, atol=1e-7)
+    assert np.allclose(E[:, 4], R.fresnel_dielectric(co, ieta) * p_i + T_o * p_c, rtol=3e-3, atol=1e-7)
+    # opposite hemispheres: nothing
+    assert not osc.bsdf(1, MATERIAL_NAMES.index("cc_rr"), wo, (wi * np.array([1, 1, -1], f32)).astype(f32), z, lam, u0, uc0).any()
+    osc.close()
+
+
+def test_coated_diffuse_transmission_against_bruteforce_walk(hk, oracle):
+    """CoatedDiffuseTransmission (spectral-eval.jl:2341-2840: the LayeredBxDF walk over a DiffuseTransmission base) against photon
+    counting in float64: a smooth eta = 1.5 coat over a base that reflects r and transmits t diffusely (cosine lobes), slab attenuation
+    exp(-thickness / |cos|) per traversal as in the CoatedDiffuse case.  A photon that enters the coat bounces between the base
+    (up with r, OUT through the bottom with t) and the interface (Fresnel from below, total internal reflection included) until it
+    leaves.  The reference's sample() estimator (f |cos| / pdf of its non-specular samples, split by hemisphere) must reproduce both
+    the reflected and the transmitted fraction — with the radiance scaling of quirk Q29 on the reflected side only where evaluate() is
+    concerned; sample()'s own weights carry none, as for CoatedDiffuse."""
+    from hikari_jl_amd import geometry as G
+    Rr = hk.RGBSpectrum
+    m = hk.CoatedDiffuseTransmissionMaterial(reflectance=Rr(0.3, 0.2, 0.1), transmittance=Rr(0.4, 0.5, 0.6))      # smooth coat, no medium
+    s = hk.Scene()
+    s.push(G.quad((0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0)), m)
+    s.push(hk.PointLight((0, 3, 0), Rr(1.0)))
+    s.sync()
+    osc = oracle.OracleScene(s)
+    rng = np.random.default_rng(13)
+    lam = np.full((1, 4), 550.0, f32)
+    r = float(oracle.uplift(0, np.array([[0.3, 0.2, 0.1]], f32), lam)[0, 0])
+    t = float(oracle.uplift(0, np.array([[0.4, 0.5, 0.6]], f32), lam)[0, 0])
+    eta, thick = 1.5, 0.01
+    for cos_o in (0.9, 0.5):
+        wo1 = np.array([np.sqrt(1 - cos_o ** 2), 0, cos_o])
+        n = 400000
+        wo = np.tile(wo1.astype(f32), (n, 1))
+        z = np.tile(np.array([[0, 0, 1]], f32), (n, 1))
+        S = osc.bsdf(0, 0, wo, wo, z, np.tile(lam, (n, 1)), rng.random((n, 2)).astype(f32), rng.random(n).astype(f32)).astype(np.float64)
+        w = np.where((S[:, 7] > 0) & (S[:, 8] == 0), S[:, 3] * np.abs(S[:, 2]) / np.maximum(S[:, 7], 1e-30), 0.0)
+        up, dn = np.where(S[:, 2] > 0, w, 0.0), np.where(S[:, 2] < 0, w, 0.0)
+        # photon counting
+        m_ = 600000
+        alive = np.ones(m_, bool)
+        weight = np.ones(m_)
+        out_up, out_dn = np.zeros(m_), np.zeros(m_)
+        alive &= ~(rng.random(m_) < R.fresnel_dielectric(np.full(m_, cos_o), eta))          # mirrored off the coat: the specular lobe, not counted
+        weight *= np.exp(-thick / np.sqrt(1 - (1 - cos_o ** 2) / eta ** 2))
+        for _ in range(64):
+            if not alive.any():
+                break
+            out_dn[alive] += weight[alive] * t                        # through the base: gone
+            weight[alive] *= r                                        # back up, cosine distributed
+            c_up = np.sqrt(np.maximum(rng.random(m_), 1e-12))
+            weight[alive] *= np.exp(-thick / c_up[alive])
+            esc = alive & (rng.random(m_) >= R.fresnel_dielectric(-c_up, eta))
+            out_up[esc] = weight[esc]
+            alive &= ~esc
+            weight[alive] *= np.exp(-thick / c_up[alive])
+        R_phys, T_phys = out_up.mean(), out_dn.mean()
+        se = lambda a: a.std() / np.sqrt(a.size)
+        assert 0.05 < R_phys < 0.3 and 0.2 < T_phys < 0.6
+        assert abs(up.mean() - R_phys) < 4 * np.hypot(se(up), se(out_up)) + 0.04 * R_phys, (cos_o, up.mean(), R_phys)
+        assert abs(dn.mean() - T_phys) < 4 * np.hypot(se(dn), se(out_dn)) + 0.04 * T_phys, (cos_o, dn.mean(), T_phys)
+    osc.close()

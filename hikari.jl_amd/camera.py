@@ -22,6 +22,14 @@ class PerspectiveCamera:
         offset = G.translate((-x0, -y0, 0))
         raster_to_screen = (G.inv(offset) @ G.inv(inv_bounds) @ G.inv(resolution)).astype(f32)
         self.raster_to_camera = (G.inv(camera_to_screen) @ raster_to_screen).astype(f32)
+        # Raycore's look_at / perspective are not in the reference tree.  generate_ray's lens branch states their convention
+        # (perspective.jl:109: "Camera looks in -z, so d[3] < 0; negate to get positive t"), so the mirror builds that frame: pbrt's
+        # LookAt / Perspective with the camera's z axis reversed.  Negating the z column of camera_to_world and the z row of
+        # raster_to_camera leaves every pinhole ray bit-identical (two exact sign flips cancel); with a lens, t = -focal / d.z is
+        # now positive and the ray passes through the plane of focus in FRONT of the camera instead of behind it.
+        flip = np.diag(np.array([1, 1, -1, 1], dtype=f32))
+        self.camera_to_world = (self.camera_to_world @ flip).astype(f32)
+        self.raster_to_camera = (flip @ self.raster_to_camera).astype(f32)
         self.lens_radius, self.focal_distance = float(lens_radius), float(focal_distance)
         self.shutter_open, self.shutter_close = float(shutter_open), float(shutter_close)
         p_min = self._apply_point(self.raster_to_camera, (0, 0, 0))

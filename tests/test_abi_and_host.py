@@ -98,16 +98,19 @@ def test_camera_matches_reference_conventions(hk, oracle):
 
 
 def test_matrix_camera_equals_perspective_camera(hk, oracle):
-    """MatrixCamera (camera/matrix.jl) fed the view / projection a PerspectiveCamera is built from gives the same rays; a flipped
-    OpenGL view (camera looking along -z) turns them around."""
+    """MatrixCamera (camera/matrix.jl) fed the view / projection a PerspectiveCamera is built from gives the same rays.  The
+    PerspectiveCamera mirror keeps the camera looking along -z in its own space (perspective.jl:109), i.e. pbrt's matrices with the
+    z axis reversed: the two records differ by exactly those signs and the pinhole rays are bit-identical."""
     from hikari_jl_amd import geometry as G
     film = hk.Film((40, 30))
     pc = hk.PerspectiveCamera((1, 2, -5), (0, 0.5, 0), film, fov=35.0)
     view = G.look_at((1, 2, -5), (0, 0.5, 0), (0, 1, 0))
     proj = G.perspective(35.0, 0.01, 1000.0)
     mc = hk.MatrixCamera(view, proj, film)
-    assert np.allclose(mc.raster_to_camera, pc.raster_to_camera, rtol=1e-6, atol=1e-7)
-    assert np.allclose(mc.camera_to_world, pc.camera_to_world, rtol=1e-6, atol=1e-7)
+    flip = np.diag([1.0, 1.0, -1.0, 1.0]).astype(np.float32)
+    assert np.allclose(flip @ mc.raster_to_camera, pc.raster_to_camera, rtol=1e-6, atol=1e-7)
+    assert np.allclose(mc.camera_to_world @ flip, pc.camera_to_world, rtol=1e-6, atol=1e-7)
+    assert pc._apply_point(pc.raster_to_camera, (20, 15, 0))[2] < 0            # the camera looks along -z in camera space
     assert np.allclose(mc.dx_camera, pc.dx_camera, atol=1e-7) and mc.A > 0
     p = hk.integrator_params()
     rng = np.random.default_rng(4)

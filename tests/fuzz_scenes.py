@@ -95,7 +95,7 @@ def _medium(hk, rng, scattering, lo, hi):
                             g=g, bounds=(tuple(lo), tuple(hi)), majorant_res=mres)
 
 
-def random_scene(hk, seed, klass="closed"):
+def random_scene(hk, seed, klass="closed", size=None):
     """klass: "closed" (closed-form materials, no scattering media: strict parity), "absorbing" (adds absorbing / emitting media:
     strict), "walk" (LayeredBxDF kinds) or "scatter" (scattering media) — the last two compare statistically; "wild" /
     "wild_scatter": the closed / scatter vocabulary plus the awkward cases — a camera INSIDE a medium, a medium nested in a medium,
@@ -109,6 +109,8 @@ def random_scene(hk, seed, klass="closed"):
     if wild:
         klass = "scatter" if klass == "wild_scatter" else ("absorbing" if rng.random() < 0.5 else "closed")
     w, h = int(rng.integers(16, 49)), int(rng.integers(16, 49))
+    if size is not None:        # same scene, larger film: enough paths to fill every wave segment of the device several times over
+        w, h = size
     s = hk.Scene()
     desc = ["%dx%d" % (w, h)]
     mat = (lambda: walk_material(hk, rng) if rng.random() < 0.6 else closed_form_material(hk, rng)) if klass == "walk" else (lambda: closed_form_material(hk, rng))

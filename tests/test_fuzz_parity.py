@@ -2,7 +2,8 @@
 tuned — random geometry (boxes, spheres, quads, triangle soup, alpha cut-outs), every material kind incl. nested Mix and textures, every
 light kind, the four medium kinds behind index-matched or refracting boundaries, thin lens, all filters, odd film sizes, non-power-of-two
 sample counts, the three material_coherence values, both accumulator widths; the "wild" classes add a camera inside a medium, nested
-media, coplanar and zero-area triangles, swarms of small emitters, rotated environment maps, transforms, depth up to 13.
+media, coplanar and zero-area triangles, swarms of small emitters, rotated environment maps, transforms, depth up to 13.  Fourteen
+of the strict scenes are rendered at ~280^2 (up to 0.6 M paths per pass: every wave segment refilled several times).
 
 Strict classes ("closed": closed-form materials; "absorbing": plus absorbing / emitting media — no direction-seeded RNG anywhere): the
 frame bar of SURVEY §8(d), relMSE <= 1e-3 and >= 99 % of the pixels within 1e-2 relative L2 (at most 2 pixels where 1 % is less than
@@ -39,10 +40,15 @@ def test_fuzz_scenes_are_deterministic_and_finite(hk, oracle):
         assert np.isfinite(frames[0]).all() and (frames[0] >= 0).all(), (klass, seed, desc)
 
 
+LARGE = [("closed", 100 + i, (311, 257)) for i in range(4)] + [("absorbing", 100 + i, (256, 300)) for i in range(4)] + [("wild", 100 + i, (283, 277)) for i in range(6)]
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("klass,seed", STRICT)
-def test_fuzz_strict(hk, oracle, klass, seed):
-    s, film, cam, kw, desc = random_scene(hk, seed, klass)
+@pytest.mark.parametrize("klass,seed,size", [(k, i, None) for k, i in STRICT] + LARGE)
+def test_fuzz_strict(hk, oracle, klass, seed, size):
+    s, film, cam, kw, desc = random_scene(hk, seed, klass, size)
+    if size is not None:
+        kw["samples"] = min(kw["samples"], 8)
     w, h = film.width, film.height
     acc, ost = oracle.OracleScene(s).render(hk.integrator_params(**kw), cam, w, h, kw["samples"])
     ref = oracle.finalize(acc, w, h)

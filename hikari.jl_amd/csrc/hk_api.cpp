@@ -1189,7 +1189,11 @@ int ensure_state(hk_integrator* I, int capacity, bool media, bool open_scene) {
         HIP_TRY(alloc_arr(I, g.beta, Q));
         HIP_TRY(alloc_arr(I, g.r_u, Q));
         HIP_TRY(alloc_arr(I, g.r_l, Q));
+#if HK_LAMBDA_BY_SLOT
+        g.lambda = nullptr;
+#else
         HIP_TRY(alloc_arr(I, g.lambda, Q));
+#endif
         HIP_TRY(alloc_arr(I, g.meta, Q));
     }
     HIP_TRY(alloc_arr(I, s.hit, Q));

@@ -225,6 +225,25 @@ HKD float4 stream_ld(const float4* p) {
     return *p;
 #endif
 }
+// The four wavelengths of a path never change after the camera drew them (TerminateSecondary is not part of the reference's path), so
+// they are kept ONCE, by camera slot (lambda_s, which the film kernel needs anyway), instead of travelling with every generation
+// record: 16 B less to write per continuing vertex and per camera ray, the same 16 B to read (slots of a queue ascend, so the reads
+// stay nearly dense).  HK_LAMBDA_BY_SLOT=0 (hk_types.h) builds the round-2 layout (a copy in every generation) for A/B runs.
+// Measured (round 3): films bit-identical; k_camera -5 %, k_shade unchanged (it is not bound by its bytes alone: DESIGN.md §5), 5 GB less
+// path state at 164 M paths in flight.
+__device__ __forceinline__ S4 ld_lambda(const DPathState& st, const DPathGen& g, size_t p, uint32_t pslot) {
+#if HK_LAMBDA_BY_SLOT
+    const float4 v = stream_ld(&st.lambda_s[pslot]);
+#else
+    const float4 v = stream_ld(&g.lambda[p]);
+#endif
+    return s4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void st_lambda(const DPathGen& g, size_t p, S4 lambda) {
+#if !HK_LAMBDA_BY_SLOT
+    stream_st(&g.lambda[p], lambda);
+#endif
+}
 // dense append of a whole record: the position the pushing lanes get inside the segment (count + rank among the pushing lanes)
 struct WavePos {
     int count;  // wave-uniform: entries already in the segment
@@ -423,7 +442,7 @@ __global__ void __launch_bounds__(256) k_camera(DPathState st, DFrame fr, DTable
             generate_ray(cam, pfilm, lens, time_u, ro, rd, time);
             stream_st(&g0.ray_o[p], make_float4(ro.x, ro.y, ro.z, INF_F));
             stream_st(&g0.ray_d[p], make_float4(rd.x, rd.y, rd.z, 0.0f));
-            stream_st(&g0.lambda[p], lambda);
+            st_lambda(g0, p, lambda);
             // beta = r_u = r_l = 1 at depth 0 (volpath.jl:190-197): in scenes without media nothing changes them before the first
             // shading event, so they are not stored and the depth-0 readers substitute the constant (ld_throughput)
             if (!fr.implicit_ones) {
@@ -979,7 +998,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
                         rl_f = 1.0f;
                         dead_null = is_black(ld_throughput(g.beta, slot, ones)) || is_black(ld_throughput(g.r_u, slot, ones));
                     } else {
-                        lambda = ld4(&g.lambda[slot]);
+                        lambda = ld_lambda(st, g, slot, pslot);
                         beta = ld_throughput(g.beta, slot, ones);
                         r_u = ld_throughput(g.r_u, slot, ones);
                         r_l = ld_throughput(g.r_l, slot, ones);
@@ -1208,7 +1227,7 @@ __global__ void __launch_bounds__(256) k_scatter(DPathState st, DScene sc, DTabl
                 pslot = meta.y;
                 const int medium_idx = (int)(meta.x >> 16) - 1;
                 const float sg = sc.media[medium_idx].g;
-                lambda = ld4(&g.lambda[slot]);
+                lambda = ld_lambda(st, g, slot, pslot);
                 beta = ld4(&g.beta[slot]);
                 r_u = ld4(&g.r_u[slot]);
                 int pix, k;
@@ -1269,7 +1288,7 @@ __global__ void __launch_bounds__(256) k_scatter(DPathState st, DScene sc, DTabl
                 st4(&gn.beta[pn], beta);
                 st4(&gn.r_u[pn], r_u);
                 st4(&gn.r_l[pn], n_rl);
-                st4(&gn.lambda[pn], lambda);
+                st_lambda(gn, pn, lambda);
                 gn.meta[pn] = make_uint2(nflags, pslot);
             }
         }
@@ -1320,7 +1339,7 @@ __global__ void __launch_bounds__(256) k_escaped(DPathState st, DScene sc, DTabl
     const bool ones = depth == 0 && implicit_ones;
     for (int i = lane_id(); i < n; i += 64) {
         uint32_t slot = queue[i];
-        S4 lambda = ld4(&g.lambda[slot]);
+        S4 lambda = ld_lambda(st, g, slot, g.meta[slot].y);
         S4 Le = s4(0.0f);
         v3 rd = mk3(0, 0, 1);
         bool have_dir = false;
@@ -1527,12 +1546,12 @@ HKD void shade_emission(DPathState& st, const DPathGen& g, bool ones, const DSce
     if (meta.arealight <= 0) return;
     const Surface sf = surface_at(sc, prim, H.z, H.w, ro, rd, t_hit);
     const v3 wo = -rd;
-    const S4 lambda = ld4(&g.lambda[slot]);
+    const uint2 pmeta = g.meta[slot];
+    const S4 lambda = ld_lambda(st, g, slot, pmeta.y);
     const DLight& light = sc.lights[meta.arealight - 1];
     S4 Le = arealight_Le<TWO_PLANES, SIMPLE>(sc, T, light, wo, sf.n, sf.uv, lambda);
     if (is_black(Le)) return;
     const S4 beta = ld_throughput(g.beta, slot, ones), r_u = ld_ru(g, slot, ones, st.compact != 0), r_l = ld_rl(g, slot, ones, st.compact != 0);
-    const uint2 pmeta = g.meta[slot];
     const uint32_t fl = pmeta.x;
     const int pdepth = (int)(fl & 0xff);
     const bool specular_bounce = (fl >> 8) & 1u;
@@ -1641,10 +1660,8 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
             sf = surface_at(sc, prim, H.z, H.w, ro, rd, t_hit);
             wo = -rd;
             meta = sc.meta[prim];
-            {
-                const float4 lv = stream_ld(&g.lambda[slot]);
-                lambda = s4(lv.x, lv.y, lv.z, lv.w);
-            }
+            const uint2 pmeta = g.meta[slot];
+            lambda = ld_lambda(st, g, slot, pmeta.y);
             if (ones)
                 beta = s4(1.0f);
             else {
@@ -1652,7 +1669,6 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
                 beta = s4(bv.x, bv.y, bv.z, bv.w);
             }
             r_u = ld_ru(g, slot, ones, st.compact != 0);
-            const uint2 pmeta = g.meta[slot];
             fl = pmeta.x;
             pslot = pmeta.y;
             pdepth = (int)(fl & 0xff);
@@ -1830,7 +1846,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
                     stream_st(reinterpret_cast<float*>(gn.r_l) + pn, nrl.x);
                 else
                     st_ru_rl(gn, pn, r_u, nrl, false);
-                stream_st(&gn.lambda[pn], lambda);
+                st_lambda(gn, pn, lambda);
                 stream_st(&gn.meta[pn], make_uint2(nflags, pslot));
             }
         }

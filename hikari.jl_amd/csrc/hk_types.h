@@ -230,6 +230,10 @@ enum { Q_RAY = 0, Q_SHADOW = 1, Q_ESCAPED = 2, Q_MEDIUM = 3, Q_SCATTER = 4, Q_MA
 // continues a path (shade, scatter) writes the whole record at the path's position in the NEXT generation, so a bounce reads and
 // writes contiguous memory however few of the pass's paths are still alive (round 1 indexed these arrays by the fixed path slot:
 // deep bounces then used a fraction of every 128-byte line — 1.8x the touched bytes in k_shade, 2.8x in k_shadow).
+// 1: a path's wavelengths live once, by camera slot (DPathState::lambda_s); 0: every generation record carries a copy (DPathGen::lambda)
+#ifndef HK_LAMBDA_BY_SLOT
+#define HK_LAMBDA_BY_SLOT 1
+#endif
 struct DPathGen {
     float4* ray_o;         // o.xyz, t_max
     float4* ray_d;         // d.xyz, time

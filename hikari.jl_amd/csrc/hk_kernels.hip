@@ -633,6 +633,10 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace(DPathState st, DScene 
 #ifndef HK_TRACE_MIN_IDLE
 #define HK_TRACE_MIN_IDLE 24
 #endif
+// closest hit with the whole tree in LDS: the node loop of a round ends once A * (lanes still descending) < lanes waiting with a leaf
+#ifndef HK_LEAF_BREAK_A
+#define HK_LEAF_BREAK_A 2
+#endif
 struct LaneRay {   // per-lane traversal state
     v3 o, d;
     RaySlab rs;
@@ -654,23 +658,38 @@ HKD void lane_ray_start(LaneRay& r, const DScene& sc, v3 o, v3 d, float t_max) {
 // one while-while round for the lanes with `active`: inner nodes until every such lane holds a leaf (or is done), then the leaves.
 // ANYHIT: the first accepted triangle ends the ray (cur = DONE, best.prim >= 0).
 template <bool ANYHIT, bool COUNT, int NC = 0>
-HKD void lane_ray_round(LaneRay& r, bool active, const DScene& sc, int* __restrict__ stack, int lane, unsigned& n_nodes, unsigned& n_tris, const NodeCache& cache = NodeCache()) {
+HKD void lane_ray_round(LaneRay& r, bool active, const DScene& sc, int* __restrict__ stack, int lane, unsigned& n_nodes, unsigned& n_tris, const NodeCache& cache = NodeCache()
+#ifdef HK_DEBUG_UTIL
+                        , unsigned long long* dbg_ = nullptr
+#endif
+                        ) {
     const int DONE = (int)0x80000000;
     // ballots of ONE comparison each, combined as scalar masks: the ballot of a compound condition costs two VALU instructions
     // (v_cndmask + v_cmp) on top of the comparisons, and this loop is bound by instruction issue
     const unsigned long long act_m = __builtin_amdgcn_ballot_w64(active);
+    // The rule that ends the node loop weighs what a leaf costs against a node step.  With the WHOLE tree in LDS (closest hit in the
+    // Cornell box) a node step is cheap and the leaf phase — 46 % of the lanes under the 1 : 1 rule, up to four triangles each — is
+    // where the lane-slots go: the nodes run on until they are outnumbered 2 : 1 (trace -5 %, frame +1.7 %).  Trees that reach into
+    // global memory keep 1 : 1 (sky scene at 2 : 1: trace +1 %; 10^6 triangles: +3 %), and so does the any-hit kernel (+-0 either way).
+    const int break_a = (!ANYHIT && NC > 0 && sc.n_nodes <= NC) ? HK_LEAF_BREAK_A : 1;
     for (;;) {
         const unsigned long long in_nodes = act_m & __builtin_amdgcn_ballot_w64(r.cur >= 0);
         if (in_nodes == 0ull) break;
         // stragglers: once fewer lanes are still descending than are waiting with a leaf, test the leaves first — the descending
         // lanes keep their state and go on in the next round.  (Running the node loop until the LAST lane holds a leaf cost
         // half of the traversal time in the 10^6-triangle scene: trace 0.94 -> 0.46 s, shadow 0.30 -> 0.19 s.)
-        if (__builtin_popcountll(in_nodes) < __builtin_popcountll(act_m & __builtin_amdgcn_ballot_w64((unsigned)r.cur > 0x80000000u))) break;   // cur < 0 and not DONE
+        if (break_a * __builtin_popcountll(in_nodes) < __builtin_popcountll(act_m & __builtin_amdgcn_ballot_w64((unsigned)r.cur > 0x80000000u))) break;   // cur < 0 and not DONE
+#ifdef HK_DEBUG_UTIL
+        if (dbg_) HK_DBG(0, active && r.cur >= 0);          // node steps: lanes that descend
+#endif
         if (active && r.cur >= 0) {
             if (COUNT) ++n_nodes;
             node_step<NC>(sc, r.rs, r.best.t, stack, lane, r.cur, r.sp, cache);
         }
     }
+#ifdef HK_DEBUG_UTIL
+    if (dbg_) HK_DBG(1, active && r.cur < 0 && r.cur != DONE);   // leaf phase: lanes that hold a leaf
+#endif
     if (active && r.cur < 0 && r.cur != DONE) {
         int ref = ~r.cur;
         int first = ref >> 3, count = (ref & 7) + 1;
@@ -745,6 +764,7 @@ __global__ void __launch_bounds__(BLOCK) k_trace_lean(DPathState st, DScene sc, 
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const int DONE = (int)0x80000000;
     unsigned n_nodes = 0, n_tris = 0, n_casts = 0, n_hits = 0;
+    HK_DBG_DECL
     HK_FOR_EACH_WAVE_SEGMENT(gw, st, ticket_ptr(st, depth, TK_TRACE), depth, Q_RAY) {
     const DPathGen g = st.gen[depth & 1];
     const uint32_t seg = (uint32_t)gw * (uint32_t)st.wave_cap;   // the rays of this segment: entries seg .. seg + n - 1, read in order (no index queue)
@@ -812,7 +832,12 @@ __global__ void __launch_bounds__(BLOCK) k_trace_lean(DPathState st, DScene sc, 
             cursor += want_n < avail ? want_n : (avail > 0 ? avail : 0);
             if (__ballot(state == LR_ACTIVE) == 0ull) break;
         }
+#ifdef HK_DEBUG_UTIL
+        HK_DBG(2, state == LR_ACTIVE && r.cur != DONE);      // rounds: lanes with a ray in flight
+        lane_ray_round<false, COUNT, NC>(r, state == LR_ACTIVE && r.cur != DONE, sc, stack, lane, n_nodes, n_tris, cache, dbg_);
+#else
         lane_ray_round<false, COUNT, NC>(r, state == LR_ACTIVE && r.cur != DONE, sc, stack, lane, n_nodes, n_tris, cache);
+#endif
     }
     wq_close(q_escaped, count_ptr(st, depth, Q_ESCAPED, gw));
     if (lane == 0) {
@@ -828,6 +853,7 @@ __global__ void __launch_bounds__(BLOCK) k_trace_lean(DPathState st, DScene sc, 
         wave_add(&stats->nodes, n_nodes);
         wave_add(&stats->tris, n_tris);
     }
+    HK_DBG_FLUSH(stats);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -3,12 +3,12 @@
 # (FETCH_SIZE / WRITE_SIZE / L2 hit-miss in SEPARATE passes, as /opt/skills/guides/MI355X_MICROARCH.md prescribes) and the SQ / TA
 # utilisation counters behind DESIGN.md's "what bounds the kernels".  Everything lands in gpurun_out/<round>/; the summaries
 # (text / json, no databases) are then copied into profiles/ by hand.
-#   tools/profile_round.sh r02 [quick]
-R=${1:-r03}; MODE=$2
+#   tools/profile_round.sh r03 [quick|full] ["cornell sky cloud manylight"]     (third argument: only these configs)
+R=${1:-r03}; MODE=$2; CFGS=${3:-cornell sky cloud manylight}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/$R; mkdir -p $O
 if [ "$MODE" != "quick" ]; then
-  for c in cornell sky cloud manylight; do
+  for c in $CFGS; do
     timeout 900 python bench.py --config $c > $O/bench_${R}_$c.json 2> $O/bench_$c.err
   done
 fi
@@ -22,11 +22,15 @@ prof() {  # name, config, extra bench args, counters...
   timeout 900 rocprofv3 --kernel-trace $stats $pmc -d $O/$name -- python3 bench.py --config $cfg --no-cpu-baseline $extra > $O/$name.log 2>&1
   python3 tools/rocpd_summary.py $O/$name/*/*_results.db > $O/${R}_$name.txt 2>&1
 }
-prof kernel_stats_cornell800 cornell ""
-prof kernel_stats_cloud1024 cloud "--warmup 1"
-prof kernel_stats_manylight1024 manylight "--warmup 1"
-prof kernel_stats_sky800 sky ""
-for cfg in cornell cloud manylight sky; do
+for cfg in $CFGS; do
+  case $cfg in
+    cornell) prof kernel_stats_cornell800 cornell "" ;;
+    cloud) prof kernel_stats_cloud1024 cloud "--warmup 1" ;;
+    manylight) prof kernel_stats_manylight1024 manylight "--warmup 1" ;;
+    sky) prof kernel_stats_sky800 sky "" ;;
+  esac
+done
+for cfg in $CFGS; do
   extra="--warmup 1"
   prof pmc_fetch_$cfg $cfg "$extra" FETCH_SIZE
   prof pmc_write_$cfg $cfg "$extra" WRITE_SIZE

@@ -633,6 +633,13 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace(DPathState st, DScene 
 #ifndef HK_TRACE_MIN_IDLE
 #define HK_TRACE_MIN_IDLE 24
 #endif
+// leaf phases wait until this many lanes hold a leaf (0: never wait), as long as the kernel can still refill its idle lanes
+#ifndef HK_ANYHIT_LEAF_MIN
+#define HK_ANYHIT_LEAF_MIN 16
+#endif
+#ifndef HK_CLOSEST_LEAF_MIN
+#define HK_CLOSEST_LEAF_MIN 0
+#endif
 // closest hit with the whole tree in LDS: the node loop of a round ends once A * (lanes still descending) < lanes waiting with a leaf
 #ifndef HK_LEAF_BREAK_A
 #define HK_LEAF_BREAK_A 2
@@ -658,7 +665,8 @@ HKD void lane_ray_start(LaneRay& r, const DScene& sc, v3 o, v3 d, float t_max) {
 // one while-while round for the lanes with `active`: inner nodes until every such lane holds a leaf (or is done), then the leaves.
 // ANYHIT: the first accepted triangle ends the ray (cur = DONE, best.prim >= 0).
 template <bool ANYHIT, bool COUNT, int NC = 0>
-HKD void lane_ray_round(LaneRay& r, bool active, const DScene& sc, int* __restrict__ stack, int lane, unsigned& n_nodes, unsigned& n_tris, const NodeCache& cache = NodeCache()
+HKD void lane_ray_round(LaneRay& r, bool active, const DScene& sc, int* __restrict__ stack, int lane, unsigned& n_nodes, unsigned& n_tris, const NodeCache& cache = NodeCache(),
+                        bool may_wait = false
 #ifdef HK_DEBUG_UTIL
                         , unsigned long long* dbg_ = nullptr
 #endif
@@ -687,6 +695,15 @@ HKD void lane_ray_round(LaneRay& r, bool active, const DScene& sc, int* __restri
             node_step<NC>(sc, r.rs, r.best.t, stack, lane, r.cur, r.sp, cache);
         }
     }
+    // The leaf phase is the expensive half of a round (up to four triangles), and it used to run for however few lanes held a leaf: in the
+    // any-hit kernel, where most rays finish in the node loop without ever reaching one, 14 % of its lane-slots did work (HK_DEBUG_UTIL).
+    // While the caller can still refill (`may_wait`), the few leaf holders now keep their leaf and wait: the caller's refill brings new
+    // rays, and the leaves are tested once LEAF_MIN lanes hold one (Cornell: leaf phases 14 % -> 32 % full and 57 % fewer of them, k_shadow -5 %;
+    // 8 or 20 instead of 16: no better).  (After the node loop either nothing descends or fewer lanes descend
+    // than hold leaves: with fewer than LEAF_MIN <= 20 leaf holders at least 24 lanes are idle, so the refill is certain to happen.)
+    constexpr int LEAF_MIN = ANYHIT ? (NC > 0 ? HK_ANYHIT_LEAF_MIN : 0) : HK_CLOSEST_LEAF_MIN;   // the deep-tree instantiations (NC == 0: 10^6 triangles) lose 1 % by waiting
+    static_assert(LEAF_MIN == 0 || 64 - 2 * LEAF_MIN >= HK_TRACE_MIN_IDLE, "waiting leaf holders must leave enough idle lanes for the caller's refill to trigger");
+    if (LEAF_MIN > 0 && may_wait && __builtin_popcountll(act_m & __builtin_amdgcn_ballot_w64((unsigned)r.cur > 0x80000000u)) < LEAF_MIN) return;
 #ifdef HK_DEBUG_UTIL
     if (dbg_) HK_DBG(1, active && r.cur < 0 && r.cur != DONE);   // leaf phase: lanes that hold a leaf
 #endif
@@ -834,9 +851,9 @@ __global__ void __launch_bounds__(BLOCK) k_trace_lean(DPathState st, DScene sc, 
         }
 #ifdef HK_DEBUG_UTIL
         HK_DBG(2, state == LR_ACTIVE && r.cur != DONE);      // rounds: lanes with a ray in flight
-        lane_ray_round<false, COUNT, NC>(r, state == LR_ACTIVE && r.cur != DONE, sc, stack, lane, n_nodes, n_tris, cache, dbg_);
+        lane_ray_round<false, COUNT, NC>(r, state == LR_ACTIVE && r.cur != DONE, sc, stack, lane, n_nodes, n_tris, cache, cursor < n, dbg_);
 #else
-        lane_ray_round<false, COUNT, NC>(r, state == LR_ACTIVE && r.cur != DONE, sc, stack, lane, n_nodes, n_tris, cache);
+        lane_ray_round<false, COUNT, NC>(r, state == LR_ACTIVE && r.cur != DONE, sc, stack, lane, n_nodes, n_tris, cache, cursor < n);
 #endif
     }
     wq_close(q_escaped, count_ptr(st, depth, Q_ESCAPED, gw));
@@ -1929,6 +1946,7 @@ __global__ void __launch_bounds__(BLOCK) k_shadow(DPathState st, DScene sc, int 
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const int DONE = (int)0x80000000;
     unsigned n_nodes = 0, n_tris = 0, n_casts = 0, n_hits = 0;
+    HK_DBG_DECL
     SegStream stream = stream_open(st, ticket_ptr(st, depth, TK_SHADOW), false, depth, Q_SHADOW);
     uint32_t seg = 0;   // current segment's shadow records: entries seg .. seg + n - 1, streamed in order
     int n = 0, cursor = 0;
@@ -1976,9 +1994,15 @@ __global__ void __launch_bounds__(BLOCK) k_shadow(DPathState st, DScene sc, int 
                 continue;
             }
         }
-        lane_ray_round<true, COUNT, NC>(r, have && r.cur != DONE, sc, stack, lane, n_nodes, n_tris, cache);
+#ifdef HK_DEBUG_UTIL
+        HK_DBG(5, have && r.cur != DONE);      // rounds: lanes with a shadow ray in flight (probes 3 / 4: its node steps / leaf phases)
+        lane_ray_round<true, COUNT, NC>(r, have && r.cur != DONE, sc, stack, lane, n_nodes, n_tris, cache, cursor < n || more, dbg_ + 6);
+#else
+        lane_ray_round<true, COUNT, NC>(r, have && r.cur != DONE, sc, stack, lane, n_nodes, n_tris, cache, cursor < n || more);
+#endif
     }
     stats += global_wave();
+    HK_DBG_FLUSH(stats);
     wave_add(&stats->rays_shadow, n_casts);
     wave_add(&stats->hits, n_hits);
     if (COUNT) {

@@ -48,11 +48,16 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-spp", type=int, default=0, help="samples per pixel of the CPU baseline sample (0 = about 15 s of work)")
     ap.add_argument("--spp", type=int, default=None, help="samples per pixel of one frame (default: the config's — 256, many-light 512)")
     ap.add_argument("--spp-per-pass", type=int, default=0, help="samples of every pixel in flight per wavefront pass (0 = the library's choice: up to 256)")
-    ap.add_argument("--config", default="cornell", choices=["cornell", "cloud", "sky", "manylight"],
-                    help="cornell = BASELINE configs[1] (the bench line); sky = configs[2] (glass sphere + gold slab + Hosek-Wilkie sun-sky, depth 12); "
+    ap.add_argument("--config", default=None, choices=["cornell", "cloud", "sky", "manylight"],
+                    help="default: cornell as the bench line, then ONE warm frame each of cloud, sky and manylight appended as `configs` (one GPU only; "
+                         "--no-extra-configs leaves them out).  cornell = BASELINE configs[1] (the bench line); sky = configs[2] (glass sphere + gold slab + Hosek-Wilkie sun-sky, depth 12); "
                          "cloud = configs[3] (BOMEX stand-in: worley-fbm NanoVDB cloud field, 1024x1024, depth 32); manylight = configs[4] stand-in "
                          "(10^6 triangles, 5*10^4 area lights, 1024x1024, depth 8, 512 spp)")
-    return ap.parse_args(argv)
+    ap.add_argument("--no-extra-configs", action="store_true", help="the default run without the one-frame lines of cloud / sky / manylight")
+    args = ap.parse_args(argv)
+    args.extra_configs = args.config is None and not args.no_extra_configs and args.gpus == 1 and not args.spp and not args.spp_per_pass
+    args.config = args.config or "cornell"
+    return args
 
 
 def launch_ranks(args):
@@ -150,6 +155,147 @@ def build_workload(config, scenes):
         scene, film, cam = scenes.cornell_box(W, H, light="area")
         workload = "Cornell box (diffuse + area light), 800x800, VolPath depth 8"
     return scene, film, cam, W, H, depth, spp, workload
+
+
+VALU_CYCLES_THIS_MIX = 4.2     # profiles/r02_valu_rate.txt (tools/valu_rate.hip): compares, selects, integer ops, conversions cost 4.2 - 4.4 cycles
+                               # per wave64 instruction on a busy SIMD (v_fma / v_mul / v_mov 2.3 - 2.9): the price of the traversal kernels' mix
+N_SIMD = 1024                  # 256 CUs x 4 SIMDs
+KERNEL_OF_CLASS = {"trace": "k_trace", "shadow": "k_shadow", "shade": "k_shade", "media": "k_track+k_scatter"}
+
+
+def class_rooflines(config, timed, launches, sc, default_frame):
+    """One entry per hot kernel class.  IN-RUN: seconds / avg_launch_ms (HIP events on the launch stream) and the counted units behind
+    the SURVEY 8(d) algorithmic bytes.  FROM COMMITTED rocprofv3 PASSES of the same workload (named in `counters_from`): HBM traffic,
+    L2 hit rate, VALU / SALU instruction counts, lane utilisation.  Shading and media classes are priced against HBM; the BVH
+    traversal classes of surface scenes against instruction issue (their nodes come from LDS / L1 / L2: a byte ceiling says nothing)."""
+    alg = dict(trace=int(sc.bytes_algorithmic_trace), shadow=int(sc.bytes_algorithmic_shadow), shade=int(sc.bytes_algorithmic_shade),
+               media=int(sc.bytes_algorithmic_media))
+
+    def committed(stem):
+        rel = os.path.join("profiles", "%s_%s.json" % (stem, config))
+        try:    # the PMC passes were taken on one GPU at the config's default frame
+            return (json.load(open(os.path.join(ROOT, rel))), rel) if default_frame else ({}, None)
+        except (OSError, ValueError):
+            return {}, None
+
+    (pmc, pmc_file), (util, util_file) = committed("pmc_traffic"), committed("utilisation")
+    walk = int(sc.shadow_collisions) > 0
+    rooflines = []
+    for cls in ("trace", "shadow", "shade", "media"):
+        n_launch = max(launches[cls], 1)
+        avg_s = timed[cls] / n_launch
+        if timed[cls] <= 0:
+            continue
+        kernel = KERNEL_OF_CLASS[cls]
+        names = ["k_track", "k_scatter"] if cls == "media" else [kernel]
+        tr = [pmc.get(k, {}) for k in names]
+        u = util.get(names[0], {})
+        bytes_rate = alg[cls] / n_launch / avg_s / 1e9
+        e = {"kernel": kernel}
+        # instruction issue, re-priced on this run's launch time: the committed pass gives the wave-level instruction count per launch (a
+        # property of the workload) and the clock (its own cycles / its own duration); a wave64 VALU instruction of this mix holds a
+        # SIMD's issue port for VALU_CYCLES_THIS_MIX cycles
+        issue = None
+        if u.get("valu_inst_per_launch") and u.get("valu_issue_frac") and u.get("avg_launch_us"):
+            clock_hz = u["valu_inst_per_launch"] * 2.0 / (u["valu_issue_frac"] * N_SIMD) / (u["avg_launch_us"] * 1e-6)
+            issue = u["valu_inst_per_launch"] * VALU_CYCLES_THIS_MIX / (avg_s * clock_hz * N_SIMD)
+        traversal = cls in ("trace", "shadow") and not (cls == "shadow" and walk)
+        if traversal and issue is not None:
+            e.update({"bound": "valu_issue", "achieved": round(issue, 4), "peak": 1.0, "unit": "share of the SIMDs' VALU issue slots", "frac": round(issue, 4),
+                      "cycles_per_valu_instruction": VALU_CYCLES_THIS_MIX, "valu_instructions_per_launch": u["valu_inst_per_launch"],
+                      "algorithmic_bytes_per_launch": int(alg[cls] / n_launch), "algorithmic_gbs": round(bytes_rate, 2)})
+        else:
+            e.update({"bound": "hbm", "achieved": round(bytes_rate, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(bytes_rate / HBM_PEAK_GBS, 5),
+                      "algorithmic_bytes_per_launch": int(alg[cls] / n_launch)})
+            if issue is not None:
+                e["valu_issue_at_%.1f_cycles" % VALU_CYCLES_THIS_MIX] = round(issue, 4)
+        e.update({"avg_launch_ms": round(avg_s * 1e3, 4), "launches": n_launch, "seconds": round(timed[cls], 4)})
+        if all("hbm_bytes_per_launch" in t for t in tr):
+            # the PMC launches average over the same depths as the bench's (whole passes): traffic per launch is comparable
+            e["traffic"] = sum(t["hbm_bytes_per_launch"] * t.get("launches", 1) for t in tr) / max(sum(t.get("launches", 1) for t in tr), 1)
+            e["traffic_over_algorithmic"] = round(e["traffic"] / max(alg[cls] / n_launch, 1), 3)
+            e["hbm_frac_by_traffic"] = round(e["traffic"] / avg_s / 1e9 / HBM_PEAK_GBS, 4)
+        else:
+            e["traffic"] = None
+        if "l2_hit_rate" in tr[0]:
+            e["l2_hit_rate"] = tr[0]["l2_hit_rate"]
+        for k in ("valu_issue_frac", "lane_util", "wait_frac"):
+            if k in u:
+                e[k] = u[k]
+        if u.get("salu_per_launch") and u.get("valu_inst_per_launch"):
+            e["salu_over_valu"] = round(u["salu_per_launch"] / u["valu_inst_per_launch"], 3)
+        e["counters_from"] = [f for f in (pmc_file if e["traffic"] is not None else None, util_file if u else None) if f]
+        e["measured_in_run"] = ["avg_launch_ms", "seconds", "launches", "algorithmic_bytes_per_launch"]
+        hb, vi = e.get("hbm_frac_by_traffic"), e.get("valu_issue_frac")
+        # valu_issue_frac prices a wave64 VALU instruction at the data sheet's 2 cycles; measured on this chip (tools/valu_rate.hip,
+        # profiles/r02_valu_rate.txt) v_fma / v_mul / v_mov cost 2.3 - 2.9 and nearly everything else 4.2 - 4.4, so 0.25 - 0.45 in
+        # data-sheet units is a saturated issue port for these instruction mixes
+        if hb is None or vi is None:
+            e["binding"] = "unprofiled on this workload"
+        elif hb >= 0.5:
+            e["binding"] = "HBM traffic (%.0f %% of the 8 TB/s peak, %.0f %% of the device-copy rate); VALU issue %.0f %% at 2 cycles per instruction" % (100 * hb, 100 * hb * HBM_PEAK_GBS / 5200.0, 100 * vi)
+        elif cls == "media" or (cls == "shadow" and walk):
+            e["binding"] = "instruction issue (vector + scalar exec-mask instructions) at low lane utilisation: VALU issue %.0f %% at 2 cycles per instruction with %.0f %% of the lanes active; HBM traffic %.0f %% of peak" % (100 * vi, 100 * e.get("lane_util", 0), 100 * hb)
+        else:
+            e["binding"] = "instruction issue and latency: VALU issue %.0f %% of all cycles at 2 cycles per instruction (this mix costs ~4: profiles/r02_valu_rate.txt) with %.0f %% of the lanes active; HBM traffic %.0f %% of peak" % (100 * vi, 100 * e.get("lane_util", 0), 100 * hb)
+        # BVH nodes come from LDS / L1 / L2, not HBM: the SURVEY 8(d) byte formula is an upper bound of traversal's HBM need, not a ceiling
+        if traversal:
+            e["note"] = "algorithmic bytes count every BVH node / triangle visit at full size (SURVEY 8d); nodes are served from LDS / L1 / L2, measured HBM traffic is the `traffic` field"
+        if cls == "media":
+            e["units"] = {"collisions": int(sc.track_collisions), "dda_steps": int(sc.track_dda_steps), "scatter_vertices": int(sc.scatter_vertices),
+                          "bytes_per_collision": 84, "bytes_per_dda_step": 4}
+        if cls == "shadow" and walk:
+            e["units"] = {"collisions": int(sc.shadow_collisions), "dda_steps": int(sc.shadow_dda_steps), "casts": int(sc.rays_shadow)}
+        rooflines.append(e)
+    return rooflines
+
+
+def one_frame_line(hk, scenes, torch, config, device):
+    """ONE warm frame of another BASELINE.json config on this GPU, after the bench line's timed region: wall-clock seconds per frame,
+    Mrays/s and the per-class rooflines (same definitions as the bench line).  Three frames are rendered: a first one that uploads the
+    scene, builds the sampler tables and counts the units (untimed), the timed one, and a replay with HIP events around every launch."""
+    t_setup = time.perf_counter()
+    scene, film, cam, W, H, depth, spp, workload = build_workload(config, scenes)
+    accum = torch.zeros(4 * W * H, dtype=torch.float32, device="cuda")
+    vp = hk.VolPath(max_depth=depth, samples=max(spp, 256), device=device)
+    vp.use_external_accumulators(accum.data_ptr())
+    vp._ensure(film)
+
+    def frame():
+        vp.clear()
+        vp.render_samples(scene, film, cam, spp, stride=1, first=1, readback=False)
+        vp.sync()
+        torch.cuda.synchronize()
+
+    vp.enable_counters(count_nodes=True, time_kernels=False)
+    frame()
+    sc = vp.stats()
+    setup_s = time.perf_counter() - t_setup
+    vp.enable_counters(count_nodes=False, time_kernels=False)
+    vp.reset_stats()
+    t0 = time.perf_counter()
+    frame()
+    seconds = time.perf_counter() - t0
+    st = vp.stats()
+    rays = int(st.rays_closest) + int(st.rays_shadow)
+    vp.enable_counters(count_nodes=False, time_kernels=True)
+    vp.reset_stats()
+    frame()
+    tk = vp.stats()
+    timed = dict(trace=tk.seconds_trace, shadow=tk.seconds_shadow, shade=tk.seconds_shade, media=tk.seconds_media, other=tk.seconds_other)
+    launches = dict(trace=int(tk.trace_launches), shadow=int(tk.shadow_launches), shade=int(tk.shade_launches), media=int(tk.media_launches))
+    rooflines = class_rooflines(config, timed, launches, sc, True)
+    dom = max((k for k in ("trace", "shadow", "shade", "media") if timed[k] > 0), key=lambda k: timed[k])
+    line = {"config": config, "workload": "%s, %d spp per frame" % (workload, spp), "resolution": [W, H], "max_depth": depth, "spp_per_frame": spp,
+            "triangles": int(scene.desc.n_triangles), "lights": int(scene.desc.n_lights), "frames_timed": 1,
+            "seconds_per_frame": round(seconds, 4), "value": round(rays / seconds / 1e6, 2), "unit": "Mrays/s",
+            "rays": {"closest": int(st.rays_closest), "shadow": int(st.rays_shadow), "medium_collisions": int(st.medium_collisions)},
+            "kernel_seconds": {k: round(v, 4) for k, v in timed.items()}, "setup_seconds": round(setup_s, 2),
+            "roofline": next(e for e in rooflines if e["kernel"] == KERNEL_OF_CLASS[dom]), "rooflines": rooflines}
+    vp.close()
+    del accum
+    torch.cuda.empty_cache()
+    return line
 
 
 def main():
@@ -339,66 +485,8 @@ def main():
         # ---- per-kernel-class ceilings: ALGORITHMIC bytes from the counted replay (hk_stats.bytes_algorithmic_*) over the
         #      HIP-event time of that class's launches; PMC traffic / L2 hit rate / VALU issue / lane utilisation from the rocprofv3
         #      passes committed under profiles/ for the same workload (tools/profile_round.sh) ----
-        alg = dict(trace=int(sc.bytes_algorithmic_trace), shadow=int(sc.bytes_algorithmic_shadow), shade=int(sc.bytes_algorithmic_shade),
-                   media=int(sc.bytes_algorithmic_media))
-        kname = {"trace": "k_trace", "shadow": "k_shadow", "shade": "k_shade", "media": "k_track+k_scatter"}
-
-        def committed(stem):
-            path = os.path.join(ROOT, "profiles", "%s_%s.json" % (stem, args.config))
-            try:    # the PMC passes were taken on one GPU at the config's default frame
-                return json.load(open(path)) if (world == 1 and not args.spp and not args.spp_per_pass) else {}
-            except (OSError, ValueError):
-                return {}
-
-        pmc, util = committed("pmc_traffic"), committed("utilisation")
-        rooflines = []
-        for cls in ("trace", "shadow", "shade", "media"):
-            n_launch = max(launches[cls], 1)
-            avg_s = timed[cls] / n_launch
-            if timed[cls] <= 0:
-                continue
-            achieved = alg[cls] / n_launch / avg_s / 1e9
-            e = {"kernel": kname[cls], "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                 "algorithmic_bytes_per_launch": int(alg[cls] / n_launch), "avg_launch_ms": round(avg_s * 1e3, 4), "launches": n_launch,
-                 "seconds": round(timed[cls], 4)}
-            names = ["k_track", "k_scatter"] if cls == "media" else [kname[cls]]
-            tr = [pmc.get(k, {}) for k in names]
-            if all("hbm_bytes_per_launch" in t for t in tr):
-                # the PMC launches average over the same depths as the bench's (whole passes): traffic per launch is comparable
-                e["traffic"] = sum(t["hbm_bytes_per_launch"] * t.get("launches", 1) for t in tr) / max(sum(t.get("launches", 1) for t in tr), 1)
-                e["traffic_over_algorithmic"] = round(e["traffic"] / max(alg[cls] / n_launch, 1), 3)
-                e["hbm_frac_by_traffic"] = round(e["traffic"] / avg_s / 1e9 / HBM_PEAK_GBS, 4)
-            else:
-                e["traffic"] = None
-            t = tr[0]
-            if "l2_hit_rate" in t:
-                e["l2_hit_rate"] = t["l2_hit_rate"]
-            u = util.get(names[0], {})
-            for k in ("valu_issue_frac", "lane_util", "wait_frac"):
-                if k in u:
-                    e[k] = u[k]
-            hb, vi = e.get("hbm_frac_by_traffic"), e.get("valu_issue_frac")
-            # valu_issue_frac prices a wave64 VALU instruction at the data sheet's 2 cycles; measured on this chip (tools/valu_rate.hip,
-            # profiles/r02_valu_rate.txt) v_fma / v_mul / v_mov cost 2.3 - 2.9 and nearly everything else 4.2 - 4.4, so 0.25 - 0.45 in
-            # data-sheet units is a saturated issue port for these instruction mixes
-            if hb is None or vi is None:
-                e["binding"] = "unprofiled on this workload"
-            elif hb >= 0.5:
-                e["binding"] = "HBM traffic (%.0f %% of the 8 TB/s peak, %.0f %% of the device-copy rate); VALU issue %.0f %% at 2 cycles per instruction" % (100 * hb, 100 * hb * HBM_PEAK_GBS / 5200.0, 100 * vi)
-            elif cls == "media" or (cls == "shadow" and int(sc.shadow_collisions) > 0):
-                e["binding"] = "latency of dependent loads (majorant cell -> tree / brick -> 8 taps): VALU issue %.0f %% at 2 cycles per instruction with %.0f %% of the lanes active; HBM traffic %.0f %% of peak" % (100 * vi, 100 * e.get("lane_util", 0), 100 * hb)
-            else:
-                e["binding"] = "instruction issue and latency: VALU issue %.0f %% of all cycles at 2 cycles per instruction (this mix costs ~4: profiles/r02_valu_rate.txt) with %.0f %% of the lanes active; HBM traffic %.0f %% of peak" % (100 * vi, 100 * e.get("lane_util", 0), 100 * hb)
-            rooflines.append(e)
-        # BVH nodes come from LDS / L1 / L2, not HBM: the SURVEY 8(d) byte formula is an upper bound of traversal's HBM need, not a ceiling
-        for e in rooflines:
-            if e["kernel"] in ("k_trace", "k_shadow"):
-                e["note"] = "algorithmic bytes count every BVH node / triangle visit at full size; measured HBM traffic is the `traffic` field"
-            if e["kernel"] == "k_track+k_scatter":
-                e["units"] = {"collisions": int(sc.track_collisions), "dda_steps": int(sc.track_dda_steps), "scatter_vertices": int(sc.scatter_vertices),
-                              "bytes_per_collision": 84, "bytes_per_dda_step": 4}
-            if e["kernel"] == "k_shadow" and int(sc.shadow_collisions) > 0:
-                e["units"] = {"collisions": int(sc.shadow_collisions), "dda_steps": int(sc.shadow_dda_steps), "casts": int(sc.rays_shadow)}
+        default_frame = world == 1 and not args.spp and not args.spp_per_pass
+        rooflines = class_rooflines(args.config, timed, launches, sc, default_frame)
         dom = max((k for k in ("trace", "shadow", "shade", "media") if timed[k] > 0), key=lambda k: timed[k])
         # measured HBM ceiling of this box beside the nominal peak: device-to-device copy, read + write bytes
         a = torch.empty(1 << 28, dtype=torch.float32, device="cuda")    # 1 GiB
@@ -413,7 +501,7 @@ def main():
         torch.cuda.synchronize()
         copy_gbs = 10 * 2 * a.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del a, b
-        roofline = dict(next(e for e in rooflines if e["kernel"] == kname[dom]))
+        roofline = dict(next(e for e in rooflines if e["kernel"] == KERNEL_OF_CLASS[dom]))
         roofline.update({"measured_copy_gbs": round(copy_gbs, 1), "frac_of_measured_copy": round(roofline["achieved"] / copy_gbs, 5),
                          "nodes_per_cast": round(int(sc.trace_nodes) / max(int(sc.rays_closest), 1), 2),
                          "tris_per_cast": round(int(sc.trace_tris) / max(int(sc.rays_closest), 1), 2),
@@ -464,14 +552,25 @@ def main():
             "setup_seconds": round(setup_s, 3),
             "roofline": roofline, "rooflines": rooflines, "cpu_baseline": cpu,
         }
-        print(json.dumps(result))
-        sys.stdout.flush()
     if comm is not None:
         comm.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     vp.close()
+    if result is not None:
+        if args.extra_configs and world == 1:
+            # the other north_star targets, one warm frame each, driver-visible in the same line (headline fields above are untouched)
+            del accum
+            torch.cuda.empty_cache()
+            result["configs"] = []
+            for c in ("cloud", "sky", "manylight"):
+                try:
+                    result["configs"].append(one_frame_line(hk, scenes, torch, c, local_rank))
+                except Exception as e:           # noqa: BLE001
+                    result["configs"].append({"config": c, "error": "%s: %s" % (type(e).__name__, e)})
+        print(json.dumps(result))
+        sys.stdout.flush()
     return result
 
 

@@ -847,6 +847,7 @@ extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene**
         const bool flat_s = dm.sigma_s.w == 0.0f || (dm.sigma_s.x == 0.0f && dm.sigma_s.y == 0.0f);
         if (!(flat_a && flat_s && (dm.kind == HK_MEDIUM_GRID || dm.kind == HK_MEDIUM_NANOVDB))) D.all_grey = 0;
     }
+    D.grey_bricks = (D.all_grey && dmed[0].kind == HK_MEDIUM_NANOVDB && dmed[0].nv_bricks != nullptr) ? 1 : 0;
     D.nodes = s->nodes.as<DNode>();
     D.leaf_tris = s->leaf_tris.as<float4>();
     D.root_ref = bvh.root_ref;
@@ -1334,6 +1335,12 @@ extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_
             const int v = e ? std::atoi(e) : dflt;
             return v >= 1 && v <= 255 ? v : dflt;
         };
+        {   // collision rounds of k_track_flat wait for HK_TRACK_MIN_PENDING lanes, for at most HK_TRACK_EXTRA_ADVANCE further cheap steps (0 = never wait)
+            const char* e = std::getenv("HK_TRACK_MIN_PENDING");
+            const char* x = std::getenv("HK_TRACK_EXTRA_ADVANCE");
+            const int mp = e ? std::atoi(e) : 0, xa = x ? std::atoi(x) : 4;
+            fr.track_gate = (mp >= 0 && mp <= 64 ? mp : 0) | ((xa >= 0 && xa <= 255 ? xa : 4) << 8);
+        }
         fr.delta_advance = knob("HK_DELTA_ADVANCE", 3);
         fr.refill_idle = knob("HK_TRACK_REFILL_IDLE", 24);
         fr.walk_tune = knob("HK_SHADOW_TRACK_BATCH", 8) | (knob("HK_TRACK_ADVANCE", 2) << 8) | (knob("HK_SHADOW_FEED_ROUNDS", 3) << 16) | ((knob("HK_WALK_REFILL_IDLE", 16) & 63) << 24);

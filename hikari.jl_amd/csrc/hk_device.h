@@ -2125,6 +2125,8 @@ HKD NvBlock nv_find_block(const DMedium& m, int kx, int ky, int kz) {  // block 
     return r;
 }
 HKD float nv_leaf_value(const DMedium& m, uint32_t leaf_off, int n_leaf) { return hknv::f32(m.nvdb, (long long)leaf_off + 96 + (long long)n_leaf * 4); }
+// BRICKS_ONLY: the caller knows that the medium has dense bricks (DScene::grey_bricks), the tree-walk paths are not instantiated
+template <bool BRICKS_ONLY = false>
 HKD float sample_nanovdb_density(const DMedium& m, v3 p) {  // nanovdb.jl:400-469
     float px = p.x - m.vec[0], py = p.y - m.vec[1], pz = p.z - m.vec[2];
     float fxi = m.inv_mat[0] * px + m.inv_mat[1] * py + m.inv_mat[2] * pz;
@@ -2134,7 +2136,7 @@ HKD float sample_nanovdb_density(const DMedium& m, v3 p) {  // nanovdb.jl:400-46
     int ix = (int)flx, iy = (int)fly, iz = (int)flz;
     float fx = fxi - (float)ix, fy = fyi - (float)iy, fz = fzi - (float)iz;
     float v000, v001, v010, v011, v100, v101, v110, v111;
-    if (m.nv_bricks) {
+    if (BRICKS_ONLY || m.nv_bricks) {
         // dense bricks WITH A HALO (the upload materialises them when the index bounding box is small enough): brick = the block's 8^3
         // voxels plus the first plane of its +x / +y / +z neighbours, 9^3 floats, z fastest — the eight taps of ANY voxel are in the
         // brick of its block: four 8-byte loads (4-byte aligned) at one computed address, no dependent table lookup, no second path
@@ -2146,7 +2148,7 @@ HKD float sample_nanovdb_density(const DMedium& m, v3 p) {  // nanovdb.jl:400-46
             v000 = p00.x, v001 = p00.y, v010 = p01.x, v011 = p01.y, v100 = p10.x, v101 = p10.y, v110 = p11.x, v111 = p11.y;
         } else   // the table's outermost blocks hold the background (checked at upload), so a base voxel outside it has background taps only
             v000 = v001 = v010 = v011 = v100 = v101 = v110 = v111 = m.nv_background;
-    } else if ((ix & 7) != 7 && (iy & 7) != 7 && (iz & 7) != 7) {
+    } else if (!BRICKS_ONLY && (ix & 7) != 7 && (iy & 7) != 7 && (iz & 7) != 7) {
         // all eight taps in one 8^3 block (2 of 3 lookups): one table entry, eight independent leaf loads
         NvBlock c = nv_find_block(m, ix >> 3, iy >> 3, iz >> 3);
         if (c.leaf_off == 0u)
@@ -2162,6 +2164,8 @@ HKD float sample_nanovdb_density(const DMedium& m, v3 p) {  // nanovdb.jl:400-46
             v110 = nv_leaf_value(m, c.leaf_off, n + 72);
             v111 = nv_leaf_value(m, c.leaf_off, n + 73);
         }
+    } else if (BRICKS_ONLY) {
+        v000 = v001 = v010 = v011 = v100 = v101 = v110 = v111 = 0.0f;   // (not reached)
     } else {
         v000 = v001 = v010 = v011 = v100 = v101 = v110 = v111 = 0.0f;
 #pragma unroll 1
@@ -2263,13 +2267,13 @@ HKD MediumProps sample_point(const DTables& T, S4 lambda, const DMedium& m, S4 b
     return mp;
 }
 // density at p of a density-scaled medium (Grid / NanoVDB): what sample_point multiplies the medium's spectra with
-template <int MM>
+template <int MM, bool BRICKS_ONLY = false>
 HKD float sample_density(const DMedium& m, v3 p) {
     if (HK_HAS_MEDIUM(MM, HK_MEDIUM_GRID) && (m.kind == HK_MEDIUM_GRID || !HK_HAS_MEDIUM(MM, HK_MEDIUM_NANOVDB))) {
         const float* M = m.r2m;
         return sample_grid_density(m, mk3(M[0] * p.x + M[1] * p.y + M[2] * p.z + M[3], M[4] * p.x + M[5] * p.y + M[6] * p.z + M[7], M[8] * p.x + M[9] * p.y + M[10] * p.z + M[11]));
     }
-    return sample_nanovdb_density(m, p);
+    return sample_nanovdb_density<BRICKS_ONLY>(m, p);
 }
 // GREY media: sigma_a and sigma_s are flat spectra (sigmoid coefficients c0 = c1 = 0: what a grey RGB uplifts to, and what the
 // BOMEX example's RGBSpectrum(0) / RGBSpectrum(1) are) — the value is the same at every wavelength, bit for bit

@@ -1243,6 +1243,287 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
 }
 
 // ---------------------------------------------------------------------------------------------------
+// k_track_flat: K4 of a scene whose ONE medium is GREY (k_track<MM, true> above) — the same per-lane state machine, the same
+// arithmetic and RNG consumption per path (films bit-identical: tests + tools/ab_bitwise.py, HK_GREY_FLAT=0 runs the older kernel),
+// re-shaped for INSTRUCTION ISSUE.  On this chip a scalar instruction costs a SIMD about what a vector one does (tools/valu_rate.hip:
+// v_fma + s_add pair 6.4 cycles at 4 waves against 2.9 + 4.2 alone), and k_track issued as many scalar exec-mask instructions as
+// vector ones: every loop-carried `bool` (in_seg, pending, survived, dead_null, the iterator's liveness ...) lived in an SGPR pair
+// and every divergent assignment to it cost an andn2 / and / or triple PER NESTING LEVEL it crossed.  Here
+//   * the lane's flags are bits of ONE VGPR: a write under a divergent exec mask merges for free, a test is v_and + v_cmp;
+//   * the majorant iterator's mode / axis signs are three more bits of that word, its DDA step is straight-line code;
+//   * there is one medium (all_grey): no waterfall loop, its record's fields are read once into scalar registers before the loop;
+//   * BRICKS: the medium is a NanoVDB grid with dense halo bricks (DScene::grey_bricks) — the tree-walk paths of the lookup are
+//     not in the kernel;
+//   * the collision round can WAIT (fr.track_gate): when fewer than N lanes hold a tentative collision and others can still advance,
+//     the cheap-step loop goes on for a few more iterations (the rule of k_shadow's waiting leaf phases).
+// ---------------------------------------------------------------------------------------------------
+#ifndef HK_FLAT_TRACK_WAVES
+#define HK_FLAT_TRACK_WAVES 4
+#endif
+enum { TF_IN_SEG = 1, TF_PENDING = 2, TF_SURVIVED = 4, TF_DEAD_NULL = 8, TF_TAG = 16, TF_IT_LIVE = 32, TF_NEG0 = 0x100, TF_NEG1 = 0x200, TF_NEG2 = 0x400 };
+template <int MM, bool BRICKS>
+__global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_per_eu(HK_FLAT_TRACK_WAVES))) k_track_flat(DPathState st, DScene sc, DFrame fr, int depth, DStats* stats, const DMedium* __restrict__ media) {
+    const int lane = lane_id();
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    unsigned n_coll = 0, n_dda = 0;
+    HK_DBG_DECL
+    const DPathGen g = st.gen[depth & 1];
+    const bool ones = depth == 0 && fr.implicit_ones;
+    const DMedium& med = media[0];
+    const float a0 = eval_flat(med.sigma_a), s0 = eval_flat(med.sigma_s);
+    const float sig_t = a0 + s0;   // (base_a + base_s).x of the general code
+    const int mrx = med.mres[0], mry = med.mres[1], mrz = med.mres[2];
+    const float* __restrict__ maj = med.majorant;
+    const bool last_depth = depth >= fr.max_depth;
+    const int gate_min = fr.track_gate & 0xff, gate_cap = fr.delta_advance + ((fr.track_gate >> 8) & 0xff);
+    SegStream stream = stream_open(st, ticket_ptr(st, depth, TK_TRACK), true, depth, Q_MEDIUM);
+    TrackSeg seg[2];
+    seg[0].gw = seg[1].gw = -1;
+    int cur_tag = 0;
+    const uint32_t* __restrict__ queue = st.medium_q;
+    int n = 0, cursor = 0;
+    bool more = true;
+    auto open_seg = [&](TrackSeg& s, int gw) {
+        s.gw = gw;
+        s.esc = *count_ptr(st, depth, Q_ESCAPED, gw);
+        s.sca = 0;
+#pragma unroll
+        for (int k = 0; k < HK_MAX_KINDS; ++k) s.kind_count[k] = *count_ptr(st, depth, Q_MAT0 + k, gw);
+    };
+    auto close_seg = [&](TrackSeg& s) {
+        if (s.gw >= 0 && lane == 0) {
+            *count_ptr(st, depth, Q_SCATTER, s.gw) = s.sca;
+            *count_ptr(st, depth, Q_ESCAPED, s.gw) = s.esc;
+#pragma unroll
+            for (int k = 0; k < HK_MAX_KINDS; ++k) *count_ptr(st, depth, Q_MAT0 + k, s.gw) = s.kind_count[k];
+        }
+        s.gw = -1;
+    };
+    int state = TR_EMPTY, fl = 0;
+    uint32_t slot = 0;
+    v3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 1), cur_o = mk3(0, 0, 0);
+    float rl_f = 1.0f;
+    uint64_t rng = 0;
+    float it_tmin = 0.0f, it_tmax = 0.0f, nt0 = 0.0f, nt1 = 0.0f, nt2 = 0.0f, dl0 = 0.0f, dl1 = 0.0f, dl2 = 0.0f;
+    int vx = 0, vy = 0, vz = 0;
+    float seg1 = 0.0f, sm0 = 0.0f, t = 0.0f, pend_dt = 0.0f;
+    int k_in_seg = 0, segi = 0;
+    for (;;) {
+        const unsigned long long busy_m = __ballot(state == TR_BUSY);
+        if (busy_m == 0ull || (64 - __popcll(busy_m) >= fr.refill_idle && (cursor < n || more))) {
+            // ---- route the finished paths into the queues of their own segment ----
+            const int tag = (fl & TF_TAG) ? 1 : 0;
+#pragma unroll
+            for (int tg = 0; tg < 2; ++tg) {
+                TrackSeg& S = seg[tg];
+                const bool sel = tag == tg && state != TR_BUSY && state != TR_EMPTY;
+                if (__ballot(sel) == 0ull) continue;
+                const size_t base = (size_t)S.gw * st.wave_cap;
+                {
+                    const unsigned long long m = __ballot(sel && state == TR_SCATTER);
+                    if (sel && state == TR_SCATTER) st.scatter_q[base + S.sca + __popcll(m & lt_mask)] = slot;
+                    S.sca += __popcll(m);
+                }
+                {
+                    const unsigned long long m = __ballot(sel && state == TR_ESCAPED);
+                    if (sel && state == TR_ESCAPED) st.escaped_q[base + S.esc + __popcll(m & lt_mask)] = slot;
+                    S.esc += __popcll(m);
+                }
+                unsigned long long todo_k = __ballot(sel && state >= 0);
+                while (todo_k) {
+                    int src = __ffsll((long long)todo_k) - 1;
+                    const int k = __builtin_amdgcn_readlane(state, src);   // wave-uniform: counts stay in scalar registers
+                    bool mine = sel && state == k;
+                    unsigned long long m = __ballot(mine);
+                    int cnt = 0;
+#pragma unroll
+                    for (int kk = 0; kk < HK_MAX_KINDS; ++kk) cnt = (kk == k) ? S.kind_count[kk] : cnt;
+                    if (mine) st.mat_q[((size_t)k * st.n_waves + S.gw) * st.wave_cap + cnt + __popcll(m & lt_mask)] = slot;
+                    int add = __popcll(m);
+#pragma unroll
+                    for (int kk = 0; kk < HK_MAX_KINDS; ++kk) S.kind_count[kk] += (kk == k) ? add : 0;
+                    todo_k &= ~m;
+                }
+            }
+            if (state != TR_BUSY) state = TR_EMPTY;
+            // ---- the current segment is used up: open the next one in the other slot as soon as that slot's last lane is done ----
+            while (more && cursor >= n) {
+                const int other = cur_tag ^ 1;
+                const bool other_busy = __ballot(state == TR_BUSY && ((fl & TF_TAG) ? 1 : 0) == other) != 0ull;
+                if (other_busy) break;   // both slots hold lanes in flight: no third segment, the refill waits
+                if (other == 0) close_seg(seg[0]); else close_seg(seg[1]);
+                const int gw = stream_next(stream, st.n_waves);
+                if (gw >= st.n_waves) {
+                    more = false;
+                    break;
+                }
+                if (other == 0) open_seg(seg[0], gw); else open_seg(seg[1], gw);
+                cur_tag = other;
+                queue = st.medium_q + (size_t)gw * st.wave_cap;
+                n = *count_ptr(st, depth, Q_MEDIUM, gw);
+                cursor = 0;
+            }
+            // ---- refill idle lanes from the current segment's queue ----
+            const unsigned long long want = __ballot(state == TR_EMPTY);
+            const int avail = n - cursor;
+            const int rank = __popcll(want & lt_mask);
+            HK_DBG(5, state == TR_EMPTY && rank < avail);
+            if (state == TR_EMPTY && rank < avail) {
+                slot = queue[cursor + rank];
+                float4 O = g.ray_o[slot], D = g.ray_d[slot];
+                ro = mk3(O.x, O.y, O.z);
+                rd = mk3(D.x, D.y, D.z);
+                const float t_max = st.hit[slot].x;
+                const bool dead = is_black(ld_throughput(g.beta, slot, ones)) || is_black(ld_throughput(g.r_u, slot, ones));
+                rl_f = 1.0f;
+                rng = lcg_init(ro, rd, t_max);
+                const MajorantIter it = create_majorant_iterator<MM>(med, ro, rd, t_max);
+                it_tmin = it.t_min;
+                it_tmax = it.t_max;
+                nt0 = it.next_t[0], nt1 = it.next_t[1], nt2 = it.next_t[2];
+                dl0 = it.delta_t[0], dl1 = it.delta_t[1], dl2 = it.delta_t[2];
+                vx = it.voxel[0], vy = it.voxel[1], vz = it.voxel[2];
+                fl = (cur_tag ? TF_TAG : 0) | (dead ? TF_DEAD_NULL : 0) | ((it.mode & 0xff) == 2 ? TF_IT_LIVE : 0) | (it.mode & 0x700);
+                segi = 0;
+                state = TR_BUSY;
+            }
+            const int want_n = __popcll(want);
+            cursor += want_n < avail ? want_n : (avail > 0 ? avail : 0);
+            if (__ballot(state == TR_BUSY) == 0ull) {
+                if (cursor >= n && !more) break;
+                continue;
+            }
+        }
+        // ---- phase A: cheap steps (next majorant cell, free-flight sample) until the busy lanes hold a tentative collision or have
+        //      run out of cells.  fr.delta_advance iterations; then, while fewer than gate_min lanes hold a collision, up to gate_cap ----
+#pragma unroll 1
+        for (int adv = 0;; ++adv) {
+            const bool need = state == TR_BUSY && (fl & (TF_PENDING | TF_SURVIVED)) == 0;
+            if (__ballot(need) == 0ull) break;
+            if (adv >= fr.delta_advance) {
+                if (adv >= gate_cap) break;
+                if (__popcll(__ballot(state == TR_BUSY && (fl & TF_PENDING) != 0)) >= gate_min) break;
+            }
+            HK_DBG(0, need);
+            if (need) {
+                if ((fl & TF_IN_SEG) == 0) {
+                    HK_DBG(1, true);
+                    // majorant_next (media.jl:625-729) of a DDA iterator, straight-line
+                    if ((fl & TF_IT_LIVE) == 0 || segi >= 256 || it_tmin >= it_tmax)
+                        fl |= TF_SURVIVED;   // ran out of segments with the path still alive
+                    else {
+                        const bool lxy = nt0 < nt1, lxz = nt0 < nt2, lyz = nt1 < nt2;
+                        const bool ax0 = lxy & lxz, ax1 = (!lxy) & lyz;   // axis 0, axis 1, else axis 2
+                        const float nt = ax0 ? nt0 : (ax1 ? nt1 : nt2);
+                        const float stm = minf(nt, it_tmax);
+                        const float rho = maj[vx + mrx * (vy + mry * vz)];
+                        const float seg0 = it_tmin;
+                        seg1 = stm;
+                        const bool neg = (fl & (ax0 ? TF_NEG0 : (ax1 ? TF_NEG1 : TF_NEG2))) != 0;
+                        const int v = (ax0 ? vx : (ax1 ? vy : vz)) + (neg ? -1 : 1);
+                        const int lim = neg ? -1 : (ax0 ? mrx : (ax1 ? mry : mrz));
+                        const float s = nt + (ax0 ? dl0 : (ax1 ? dl1 : dl2));
+                        vx = ax0 ? v : vx;
+                        vy = ax1 ? v : vy;
+                        vz = (ax0 | ax1) ? vz : v;
+                        nt0 = ax0 ? s : nt0;
+                        nt1 = ax1 ? s : nt1;
+                        nt2 = (ax0 | ax1) ? nt2 : s;
+                        const bool out = v == lim;
+                        fl = out ? (fl & ~TF_IT_LIVE) : fl;
+                        it_tmin = out ? it_tmax : stm;
+                        ++segi;
+                        ++n_dda;
+                        sm0 = sig_t * rho;
+                        if (sm0 >= 1e-10f) {
+                            t = seg0;
+                            cur_o = ro + rd * t;
+                            fl |= TF_IN_SEG;
+                            k_in_seg = 0;
+                        }
+                    }
+                }
+                // a lane that has just entered a cell draws its first free flight in the same round
+                if ((fl & (TF_IN_SEG | TF_SURVIVED)) == TF_IN_SEG) {
+                    HK_DBG(2, true);
+                    if (k_in_seg >= 1024)
+                        fl &= ~TF_IN_SEG;
+                    else {
+                        ++k_in_seg;
+                        const float u = lcg_next(rng);
+                        pend_dt = -media_logf(maxf(1e-10f, 1.0f - u)) / sm0;
+                        const float ts = t + pend_dt;
+                        fl = ts >= seg1 ? (fl & ~TF_IN_SEG) : (fl | TF_PENDING);   // leaves the cell (T_maj / T_maj[1] = 1: nothing else changes) / tentative collision
+                    }
+                }
+            }
+        }
+        // ---- phase B: the tentative collisions (medium lookup, absorb / scatter / null) ----
+        HK_DBG(3, state == TR_BUSY && (fl & TF_PENDING) != 0);
+        HK_DBG(4, state == TR_BUSY);
+        if (state == TR_BUSY && (fl & TF_PENDING) != 0) {
+            fl &= ~TF_PENDING;
+            const float dt = pend_dt;
+            const float Tm0 = media_expf((-dt) * sm0);
+            const v3 p = cur_o + rd * dt;
+            ++n_coll;
+            const float d = sample_density<MM, BRICKS>(med, p);
+            const float sa = a0 * d, ss = s0 * d;
+            const float p_absorb = sa / sm0, p_scatter = ss / sm0;
+            const float ue = lcg_next(rng);
+            if (ue < p_absorb) {
+                state = TR_EMPTY;  // absorbed
+            } else if (ue < p_absorb + p_scatter) {
+                if (last_depth)
+                    state = TR_EMPTY;
+                else {   // beta and r_u are rescaled by sigma_s T_maj / (sigma_s T_maj)[1] = 1: they stay as they are in the record
+                    g.ray_o[slot] = make_float4(p.x, p.y, p.z, INF_F);  // the scattering vertex: k_scatter continues from here
+                    state = TR_SCATTER;
+                }
+            } else {
+                const float sn0 = maxf(sm0 - sa - ss, 0.0f);
+                const float pdf = Tm0 * sn0;
+                if (pdf > 1e-10f) {
+                    rl_f = ((rl_f * Tm0) * sm0) * (1.0f / pdf);
+                    t = t + dt;
+                    cur_o = p;
+                    if (fl & TF_DEAD_NULL) state = TR_EMPTY;
+                } else
+                    state = TR_EMPTY;
+            }
+        }
+        if (state == TR_BUSY && (fl & TF_SURVIVED) != 0) {
+            state = TR_EMPTY;
+            if (!((fl & TF_DEAD_NULL) != 0 || last_depth)) {
+                // survived to t_max: hand the stored surface hit / the escape over with the updated throughput
+                st4(&g.r_l[slot], ld_throughput(g.r_l, slot, ones) * rl_f);
+                float4 H = st.hit[slot];
+                const int prim = __float_as_int(H.y);
+                if (prim < 0)
+                    state = TR_ESCAPED;
+                else {
+                    const int mat_word = st.mat_id[slot];
+                    int mat = mat_word & ~HK_MAT_EMISSIVE_BIT;
+                    if (sc.materials[mat].kind == HK_MAT_MIX) {
+                        float w = 1.0f - H.z - H.w;
+                        mat = resolve_mix_material(sc, mat, ro + rd * H.x, -rd, uv_at(sc, prim, w, H.z, H.w));
+                        st.mat_id[slot] = mat | (mat_word & HK_MAT_EMISSIVE_BIT);
+                    }
+                    int kind = sc.materials[mat].kind;
+                    state = kind == HK_MAT_MIX ? HK_MAT_FALLBACK : kind;
+                }
+            }
+        }
+    }
+    close_seg(seg[0]);
+    close_seg(seg[1]);
+    stats += global_wave();
+    HK_DBG_FLUSH(stats);
+    wave_add(&stats->collisions, n_coll);
+    wave_add(&stats->dda_steps, n_dda);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // K5 + K6: direct lighting at a medium scattering vertex (light-BVH NEE with n = 0, HG evaluated with cos = wo.wi,
 // medium-scatter.jl:15-138) and phase-function sampling (medium-scatter.jl:148-216).  First writer of this depth's shadow /
 // next-ray segments.
@@ -3313,6 +3594,10 @@ static int grey_mode() {   // HK_GREY=0: flat-spectrum media run through the gen
     const char* e = std::getenv("HK_GREY");
     return e ? std::atoi(e) : 1;
 }
+static int grey_flat_mode() {   // HK_GREY_FLAT=0: grey media run through the round-3 GREY instantiations of k_track / k_shadow_walk (A/B switch, read per launch)
+    const char* e = std::getenv("HK_GREY_FLAT");
+    return e ? std::atoi(e) : 1;
+}
 // media kernels are instantiated for a single medium kind or for all four (15)
 static int media_mask_class(const DScene& sc) {
     int m = sc.media_mask;
@@ -3398,15 +3683,22 @@ void launch_medium(hipStream_t s, int n_cu, const DPathState& st, const DScene& 
         const int blocks = cached_blocks<k_track<MM>>(256, n_cu, 8);                                                   \
         hipLaunchKernelGGL((k_track<MM>), dim3(clamp_blocks(blocks, st)), dim3(256), 0, s, st, sc, T, fr, depth, stats, sc.media);   \
     }
+#define HK_TRACK_FLAT(MM, B)                                                                                             \
+    {                                                                                                                    \
+        const int blocks = cached_blocks<k_track_flat<MM, B>>(256, n_cu, 8);                                           \
+        hipLaunchKernelGGL((k_track_flat<MM, B>), dim3(clamp_blocks(blocks, st)), dim3(256), 0, s, st, sc, fr, depth, stats, sc.media);   \
+    }
     const bool grey = sc.all_grey && grey_mode();
+    const bool flat = grey && grey_flat_mode();
     switch (media_mask_class(sc)) {
         case 1: HK_TRACK_LAUNCH(1) break;
-        case 2: if (grey) HK_TRACK_LAUNCH(2 COMMA true) else HK_TRACK_LAUNCH(2) break;
+        case 2: if (flat) HK_TRACK_FLAT(2, false) else if (grey) HK_TRACK_LAUNCH(2 COMMA true) else HK_TRACK_LAUNCH(2) break;
         case 4: HK_TRACK_LAUNCH(4) break;
-        case 8: if (grey) HK_TRACK_LAUNCH(8 COMMA true) else HK_TRACK_LAUNCH(8) break;
+        case 8: if (flat && sc.grey_bricks) HK_TRACK_FLAT(8, true) else if (flat) HK_TRACK_FLAT(8, false) else if (grey) HK_TRACK_LAUNCH(8 COMMA true) else HK_TRACK_LAUNCH(8) break;
         default: HK_TRACK_LAUNCH(15) break;
     }
 #undef HK_TRACK_LAUNCH
+#undef HK_TRACK_FLAT
     {
         const int d = depth, q = Q_SCATTER;
         launch_segment_lists(s, st, 1, &d, &q);

@@ -174,6 +174,7 @@ struct DScene {
     int all_opaque;             // no medium transitions and no alpha-tested surfaces
     int bvh_depth;              // deepest BVH level (bounds the traversal stack)
     int all_grey;               // every medium is a Grid / NanoVDB medium whose sigma_a and sigma_s are flat spectra (the GREY tracking kernels)
+    int grey_bricks;            // all_grey and the one medium is a NanoVDB grid with dense halo bricks (DMedium::nv_bricks): tracking kernels without the tree walk
 };
 
 struct DTables {
@@ -310,6 +311,7 @@ struct DFrame {            // per-pass constants
     float max_component_value;
     int count_nodes;       // 1: accumulate node/triangle counters
     int implicit_ones;     // 1: scene without media: the depth-0 records do not store beta = r_u = r_l = 1
+    int track_gate;        // k_track_flat: collision rounds wait until this many lanes hold a tentative collision | cap on the extra cheap steps << 8 (HK_TRACK_MIN_PENDING, HK_TRACK_EXTRA_ADVANCE)
     int delta_advance;     // k_track: cheap steps (next majorant cell / free-flight sample) per round before the pending collisions are evaluated (HK_DELTA_ADVANCE)
     int refill_idle;       // k_track: idle lanes that trigger a refill round (HK_TRACK_REFILL_IDLE)
     int walk_tune;         // k_shadow_walk: tracking batches per round | advance steps per batch << 8 | feed rounds << 16 | idle lanes that trigger a refill << 24 (HK_SHADOW_TRACK_BATCH, HK_TRACK_ADVANCE, HK_SHADOW_FEED_ROUNDS, HK_WALK_REFILL_IDLE)

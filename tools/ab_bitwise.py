@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Film accumulators of a few small scenes under two builds of the library (HK_LIB_PATH), compared bit for bit: for changes that
-only re-schedule work (loop shapes, kernel splits).   python tools/ab_bitwise.py <libA.so> <libB.so>"""
+only re-schedule work (loop shapes, kernel splits).   python tools/ab_bitwise.py <specA> <specB>
+A spec is a library path, or comma-separated VAR=value settings (the shipped library under those environment variables), or both
+joined by commas: "HK_GREY_FLAT=0", "hikari.jl_amd/csrc/libx.so,HK_GREY=0"."""
 import os
 import subprocess
 import sys
@@ -35,7 +37,14 @@ def main(lib_a, lib_b):
     outs = []
     for i, lib in enumerate((lib_a, lib_b)):
         path = "/tmp/ab_bitwise_%d.npz" % i
-        subprocess.check_call([sys.executable, "-c", CHILD % {"root": ROOT}, path], env=dict(os.environ, HK_LIB_PATH=os.path.abspath(lib)))
+        env = dict(os.environ)
+        for part in lib.split(","):
+            if "=" in part:
+                k, v = part.split("=", 1)
+                env[k] = v
+            elif part and part != "-":
+                env["HK_LIB_PATH"] = os.path.abspath(part)
+        subprocess.check_call([sys.executable, "-c", CHILD % {"root": ROOT}, path], env=env)
         outs.append(np.load(path))
     ok = True
     for k in outs[0].files:

@@ -847,6 +847,7 @@ extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene**
         const bool flat_s = dm.sigma_s.w == 0.0f || (dm.sigma_s.x == 0.0f && dm.sigma_s.y == 0.0f);
         if (!(flat_a && flat_s && (dm.kind == HK_MEDIUM_GRID || dm.kind == HK_MEDIUM_NANOVDB))) D.all_grey = 0;
     }
+    D.grey_pool = (D.all_grey && D.n_media == 1 && dmed[0].mres[0] <= 1024 && dmed[0].mres[1] <= 1024 && dmed[0].mres[2] <= 1024) ? 1 : 0;
     D.grey_bricks = (D.all_grey && dmed[0].kind == HK_MEDIUM_NANOVDB && dmed[0].nv_bricks != nullptr) ? 1 : 0;
     D.nodes = s->nodes.as<DNode>();
     D.leaf_tris = s->leaf_tris.as<float4>();

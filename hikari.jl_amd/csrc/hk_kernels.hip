@@ -1524,6 +1524,339 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
 }
 
 // ---------------------------------------------------------------------------------------------------
+// k_track_pool: k_track_flat with DENSE set-up and DENSE routing through a per-wave pool in LDS.  A camera / bounce ray lives 2.7
+// collisions and 7.7 majorant cells, so half of k_track's instructions were the per-ray set-up (queue entry, ray record, LCG seed,
+// majorant iterator: 18 IEEE divisions) and the routing of the finished paths — both executed for the ~25 idle lanes that triggered a
+// refill, with every instruction paid for 64.  Here
+//   * SET-UP runs for 64 queue entries at once, whenever the pool is empty and a lane is free, and writes 64 ready-to-track states
+//     (19 words each) to the wave's pool;
+//   * a lane whose path ends takes the next state from the pool IN THE SAME ROUND (19 LDS reads) — no lane waits for a refill round;
+//   * a finished path leaves (slot, destination key, r_l factor) in a 128-entry ring in LDS; the ring is ROUTED 64 entries at a time:
+//     the r_l update, the hit / material classification of the survivors (Mix resolve included) and the ballot compaction into the
+//     segment's queues all run on full waves;
+//   * the two open segments' count words live in LDS, not in 28 scalar registers.
+// Same arithmetic and RNG consumption per path as k_track<MM, true> (films bit-identical: tools/ab_bitwise.py; HK_TRACK_POOL=0 runs
+// k_track_flat).  Only the ORDER of a segment's queue entries differs, which no result depends on (test_scheduling_is_result_neutral).
+// ---------------------------------------------------------------------------------------------------
+enum { TP_SLOT = 0, TP_RO = 1, TP_RD = 4, TP_RNG = 7, TP_TMIN = 9, TP_TMAX = 10, TP_NT = 11, TP_DL = 14, TP_VOX = 17, TP_FL = 18, TP_FIELDS = 19, TP_RING = 128,
+       TP_WAVE_INTS = TP_FIELDS * 64 + 3 * TP_RING + 32, TP_SURVIVED = 15 };
+HKD void wave_lds_fence() {   // orders this wave's LDS writes before its later LDS reads by OTHER lanes (the hardware executes a wave's LDS instructions in order)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <int MM, bool BRICKS>
+__global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_per_eu(HK_FLAT_TRACK_WAVES))) k_track_pool(DPathState st, DScene sc, DFrame fr, int depth, DStats* stats, const DMedium* __restrict__ media) {
+    __shared__ int lds_all[4 * TP_WAVE_INTS];
+    int* const pool = lds_all + (threadIdx.x >> 6) * TP_WAVE_INTS;   // [field][64]
+    int* const ring = pool + TP_FIELDS * 64;                          // [slot | key | r_l factor][TP_RING]
+    int* const segc = ring + 3 * TP_RING;                             // [tag][16]: entries in the segment's escaped, scatter and per-kind queues
+    const int lane = lane_id();
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    unsigned n_coll = 0, n_dda = 0;
+    HK_DBG_DECL
+    const DPathGen g = st.gen[depth & 1];
+    const bool ones = depth == 0 && fr.implicit_ones;
+    const DMedium& med = media[0];
+    const float a0 = eval_flat(med.sigma_a), s0 = eval_flat(med.sigma_s);
+    const float sig_t = a0 + s0;   // (base_a + base_s).x of the general code
+    const int mrx = med.mres[0], mry = med.mres[1], mrz = med.mres[2];
+    const float* __restrict__ maj = med.majorant;
+    const bool last_depth = depth >= fr.max_depth;
+    SegStream stream = stream_open(st, ticket_ptr(st, depth, TK_TRACK), true, depth, Q_MEDIUM);
+    int gw0 = -1, gw1 = -1;   // the two open segments (tag 0 / 1)
+    int cur_tag = 0;
+    const uint32_t* __restrict__ queue = st.medium_q;
+    int n = 0, cursor = 0;
+    bool more = true;
+    int pool_n = 0, res_head = 0, res_n = 0;   // wave-uniform
+    bool drain = false;                         // route the whole ring, not only full chunks
+    auto open_seg = [&](int tag, int gw) {
+        if (lane < 2 + HK_MAX_KINDS) segc[tag * 16 + lane] = lane == 1 ? 0 : *count_ptr(st, depth, lane == 0 ? Q_ESCAPED : Q_MAT0 + lane - 2, gw);
+        if (tag == 0) gw0 = gw; else gw1 = gw;
+    };
+    auto close_seg = [&](int tag) {
+        const int gw = tag == 0 ? gw0 : gw1;
+        if (gw >= 0 && lane < 2 + HK_MAX_KINDS) *count_ptr(st, depth, lane == 0 ? Q_ESCAPED : (lane == 1 ? Q_SCATTER : Q_MAT0 + lane - 2), gw) = segc[tag * 16 + lane];
+        if (tag == 0) gw0 = -1; else gw1 = -1;
+    };
+    // route the first cnt (<= 64) entries of the ring: r_l update and classification of the survivors, then ballot compaction per destination
+    auto route = [&](int cnt) {
+        wave_lds_fence();
+        const bool have = lane < cnt;
+        const int p = (res_head + lane) & (TP_RING - 1);
+        uint32_t rslot = 0;
+        int key = -1;
+        if (have) {
+            rslot = (uint32_t)ring[p];
+            key = ring[TP_RING + p];
+        }
+        HK_DBG(6, have);
+        if (have && (key & 15) == TP_SURVIVED) {
+            // survived to t_max: hand the stored surface hit / the escape over with the updated throughput
+            const float rl = __int_as_float(ring[2 * TP_RING + p]);
+            st4(&g.r_l[rslot], ld_throughput(g.r_l, rslot, ones) * rl);
+            const float4 H = st.hit[rslot];
+            const int prim = __float_as_int(H.y);
+            int cls = 0;
+            if (prim >= 0) {
+                const int mat_word = st.mat_id[rslot];
+                int mat = mat_word & ~HK_MAT_EMISSIVE_BIT;
+                if (sc.materials[mat].kind == HK_MAT_MIX) {
+                    const float4 O = g.ray_o[rslot], D = g.ray_d[rslot];
+                    const v3 o = mk3(O.x, O.y, O.z), d = mk3(D.x, D.y, D.z);
+                    const float w = 1.0f - H.z - H.w;
+                    mat = resolve_mix_material(sc, mat, o + d * H.x, -d, uv_at(sc, prim, w, H.z, H.w));
+                    st.mat_id[rslot] = mat | (mat_word & HK_MAT_EMISSIVE_BIT);
+                }
+                const int kind = sc.materials[mat].kind;
+                cls = 2 + (kind == HK_MAT_MIX ? HK_MAT_FALLBACK : kind);
+            }
+            key = (key & 16) | cls;
+        }
+        res_head = (res_head + cnt) & (TP_RING - 1);
+        res_n -= cnt;
+        unsigned long long todo = __ballot(have);
+        while (todo) {
+            const int k = __builtin_amdgcn_readlane(key, __ffsll((long long)todo) - 1);   // wave-uniform destination
+            const unsigned long long m = __ballot(key == k);
+            const int base = __builtin_amdgcn_readfirstlane(segc[k]);
+            const int gw = (k & 16) ? gw1 : gw0, cls = k & 15;
+            uint32_t* __restrict__ q = cls == 0 ? st.escaped_q + (size_t)gw * st.wave_cap
+                                     : cls == 1 ? st.scatter_q + (size_t)gw * st.wave_cap
+                                                : st.mat_q + ((size_t)(cls - 2) * st.n_waves + gw) * st.wave_cap;
+            if (key == k) q[base + __popcll(m & lt_mask)] = rslot;
+            if (lane == 0) segc[k] = base + __popcll(m);
+            todo &= ~m;
+        }
+        wave_lds_fence();
+    };
+    int state = TR_EMPTY, fl = 0;
+    uint32_t slot = 0;
+    v3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 1), cur_o = mk3(0, 0, 0);
+    float rl_f = 1.0f;
+    uint64_t rng = 0;
+    float it_tmin = 0.0f, it_tmax = 0.0f, nt0 = 0.0f, nt1 = 0.0f, nt2 = 0.0f, dl0 = 0.0f, dl1 = 0.0f, dl2 = 0.0f;
+    int vx = 0, vy = 0, vz = 0;
+    float seg1 = 0.0f, sm0 = 0.0f, t = 0.0f, pend_dt = 0.0f;
+    int k_in_seg = 0, segi = 0;
+    for (;;) {
+        // ---- finished paths leave their result in the ring ----
+        {
+            const bool fin = state != TR_BUSY && state != TR_EMPTY;
+            const unsigned long long m = __ballot(fin);
+            if (m != 0ull) {
+                if (fin) {
+                    const int p = (res_head + res_n + __popcll(m & lt_mask)) & (TP_RING - 1);
+                    ring[p] = (int)slot;
+                    ring[TP_RING + p] = ((fl & TF_TAG) ? 16 : 0) | (state == TR_SCATTER ? 1 : TP_SURVIVED);   // (survivors are classified when routed)
+                    ring[2 * TP_RING + p] = __float_as_int(rl_f);
+                    state = TR_EMPTY;
+                }
+                res_n += __popcll(m);
+            }
+        }
+        // full chunks of the ring are routed at once; all of it before a segment is retired and at the end (ONE call site: the routing
+        // code with its Mix resolve is long)
+        while (res_n >= (drain ? 1 : 64)) route(res_n < 64 ? res_n : 64);
+        drain = false;
+        unsigned long long free_m = __ballot(state == TR_EMPTY);
+        // ---- the pool is empty and a lane is free: set up the next 64 entries of the segment's queue ----
+        if (free_m != 0ull && pool_n == 0 && (cursor < n || more)) {
+            while (more && cursor >= n) {
+                // the current segment is used up: open the next one in the other slot as soon as that slot's last lane is done
+                const int other = cur_tag ^ 1;
+                const bool other_busy = __ballot(state == TR_BUSY && ((fl & TF_TAG) ? 1 : 0) == other) != 0ull;
+                if (other_busy) break;   // both slots hold lanes in flight: no third segment, the set-up waits
+                if (res_n > 0) {         // its last results are still in the ring
+                    drain = true;
+                    break;
+                }
+                close_seg(other);
+                const int gw = stream_next(stream, st.n_waves);
+                if (gw >= st.n_waves) {
+                    more = false;
+                    break;
+                }
+                open_seg(other, gw);
+                cur_tag = other;
+                queue = st.medium_q + (size_t)gw * st.wave_cap;
+                n = *count_ptr(st, depth, Q_MEDIUM, gw);
+                cursor = 0;
+            }
+            if (drain) continue;
+            const int avail = n - cursor;
+            const int take = avail < 64 ? avail : 64;
+            HK_DBG(5, lane < take);
+            if (lane < take) {
+                const uint32_t s_new = queue[cursor + lane];
+                const float4 O = g.ray_o[s_new], D = g.ray_d[s_new];
+                const v3 o = mk3(O.x, O.y, O.z), d = mk3(D.x, D.y, D.z);
+                const float t_max = st.hit[s_new].x;
+                const bool dead = is_black(ld_throughput(g.beta, s_new, ones)) || is_black(ld_throughput(g.r_u, s_new, ones));
+                const uint64_t r = lcg_init(o, d, t_max);
+                const MajorantIter it = create_majorant_iterator<MM>(med, o, d, t_max);
+                int* e = pool + lane;
+                e[TP_SLOT * 64] = (int)s_new;
+                e[(TP_RO + 0) * 64] = __float_as_int(o.x);
+                e[(TP_RO + 1) * 64] = __float_as_int(o.y);
+                e[(TP_RO + 2) * 64] = __float_as_int(o.z);
+                e[(TP_RD + 0) * 64] = __float_as_int(d.x);
+                e[(TP_RD + 1) * 64] = __float_as_int(d.y);
+                e[(TP_RD + 2) * 64] = __float_as_int(d.z);
+                e[(TP_RNG + 0) * 64] = (int)(uint32_t)r;
+                e[(TP_RNG + 1) * 64] = (int)(uint32_t)(r >> 32);
+                e[TP_TMIN * 64] = __float_as_int(it.t_min);
+                e[TP_TMAX * 64] = __float_as_int(it.t_max);
+                e[(TP_NT + 0) * 64] = __float_as_int(it.next_t[0]);
+                e[(TP_NT + 1) * 64] = __float_as_int(it.next_t[1]);
+                e[(TP_NT + 2) * 64] = __float_as_int(it.next_t[2]);
+                e[(TP_DL + 0) * 64] = __float_as_int(it.delta_t[0]);
+                e[(TP_DL + 1) * 64] = __float_as_int(it.delta_t[1]);
+                e[(TP_DL + 2) * 64] = __float_as_int(it.delta_t[2]);
+                e[TP_VOX * 64] = (it.mode & 0xff) == 2 ? (it.voxel[0] | (it.voxel[1] << 10) | (it.voxel[2] << 20)) : 0;
+                e[TP_FL * 64] = (cur_tag ? TF_TAG : 0) | (dead ? TF_DEAD_NULL : 0) | ((it.mode & 0xff) == 2 ? TF_IT_LIVE : 0) | (it.mode & 0x700);
+            }
+            pool_n = take > 0 ? take : 0;
+            cursor += pool_n;
+            wave_lds_fence();
+        }
+        // ---- free lanes take a ready state from the pool ----
+        if (free_m != 0ull && pool_n > 0) {
+            const int rank = __popcll(free_m & lt_mask);
+            if (state == TR_EMPTY && rank < pool_n) {
+                const int* e = pool + (pool_n - 1 - rank);
+                slot = (uint32_t)e[TP_SLOT * 64];
+                ro = mk3(__int_as_float(e[(TP_RO + 0) * 64]), __int_as_float(e[(TP_RO + 1) * 64]), __int_as_float(e[(TP_RO + 2) * 64]));
+                rd = mk3(__int_as_float(e[(TP_RD + 0) * 64]), __int_as_float(e[(TP_RD + 1) * 64]), __int_as_float(e[(TP_RD + 2) * 64]));
+                rng = (uint64_t)(uint32_t)e[(TP_RNG + 0) * 64] | ((uint64_t)(uint32_t)e[(TP_RNG + 1) * 64] << 32);
+                it_tmin = __int_as_float(e[TP_TMIN * 64]);
+                it_tmax = __int_as_float(e[TP_TMAX * 64]);
+                nt0 = __int_as_float(e[(TP_NT + 0) * 64]), nt1 = __int_as_float(e[(TP_NT + 1) * 64]), nt2 = __int_as_float(e[(TP_NT + 2) * 64]);
+                dl0 = __int_as_float(e[(TP_DL + 0) * 64]), dl1 = __int_as_float(e[(TP_DL + 1) * 64]), dl2 = __int_as_float(e[(TP_DL + 2) * 64]);
+                const int vox = e[TP_VOX * 64];
+                vx = vox & 1023, vy = (vox >> 10) & 1023, vz = vox >> 20;
+                fl = e[TP_FL * 64];
+                rl_f = 1.0f;
+                segi = 0;
+                state = TR_BUSY;
+            }
+            const int free_n = __popcll(free_m);
+            pool_n -= free_n < pool_n ? free_n : pool_n;
+            wave_lds_fence();
+        }
+        if (__ballot(state == TR_BUSY) == 0ull) {
+            if (pool_n == 0 && cursor >= n && !more) {
+                if (res_n == 0) break;
+                drain = true;
+            }
+            continue;
+        }
+        // ---- phase A: cheap steps (next majorant cell, free-flight sample) until the busy lanes hold a tentative collision or have
+        //      run out of cells ----
+#pragma unroll 1
+        for (int adv = 0; adv < fr.delta_advance; ++adv) {
+            const bool need = state == TR_BUSY && (fl & (TF_PENDING | TF_SURVIVED)) == 0;
+            if (__ballot(need) == 0ull) break;
+            HK_DBG(0, need);
+            if (need) {
+                if ((fl & TF_IN_SEG) == 0) {
+                    HK_DBG(1, true);
+                    // majorant_next (media.jl:625-729) of a DDA iterator, straight-line
+                    if ((fl & TF_IT_LIVE) == 0 || segi >= 256 || it_tmin >= it_tmax)
+                        fl |= TF_SURVIVED;   // ran out of segments with the path still alive
+                    else {
+                        const bool lxy = nt0 < nt1, lxz = nt0 < nt2, lyz = nt1 < nt2;
+                        const bool ax0 = lxy & lxz, ax1 = (!lxy) & lyz;   // axis 0, axis 1, else axis 2
+                        const float nt = ax0 ? nt0 : (ax1 ? nt1 : nt2);
+                        const float stm = minf(nt, it_tmax);
+                        const float rho = maj[vx + mrx * (vy + mry * vz)];
+                        const float seg0 = it_tmin;
+                        seg1 = stm;
+                        const bool neg = (fl & (ax0 ? TF_NEG0 : (ax1 ? TF_NEG1 : TF_NEG2))) != 0;
+                        const int v = (ax0 ? vx : (ax1 ? vy : vz)) + (neg ? -1 : 1);
+                        const int lim = neg ? -1 : (ax0 ? mrx : (ax1 ? mry : mrz));
+                        const float s = nt + (ax0 ? dl0 : (ax1 ? dl1 : dl2));
+                        vx = ax0 ? v : vx;
+                        vy = ax1 ? v : vy;
+                        vz = (ax0 | ax1) ? vz : v;
+                        nt0 = ax0 ? s : nt0;
+                        nt1 = ax1 ? s : nt1;
+                        nt2 = (ax0 | ax1) ? nt2 : s;
+                        const bool out = v == lim;
+                        fl = out ? (fl & ~TF_IT_LIVE) : fl;
+                        it_tmin = out ? it_tmax : stm;
+                        ++segi;
+                        ++n_dda;
+                        sm0 = sig_t * rho;
+                        if (sm0 >= 1e-10f) {
+                            t = seg0;
+                            cur_o = ro + rd * t;
+                            fl |= TF_IN_SEG;
+                            k_in_seg = 0;
+                        }
+                    }
+                }
+                // a lane that has just entered a cell draws its first free flight in the same round
+                if ((fl & (TF_IN_SEG | TF_SURVIVED)) == TF_IN_SEG) {
+                    HK_DBG(2, true);
+                    if (k_in_seg >= 1024)
+                        fl &= ~TF_IN_SEG;
+                    else {
+                        ++k_in_seg;
+                        const float u = lcg_next(rng);
+                        pend_dt = -media_logf(maxf(1e-10f, 1.0f - u)) / sm0;
+                        const float ts = t + pend_dt;
+                        fl = ts >= seg1 ? (fl & ~TF_IN_SEG) : (fl | TF_PENDING);   // leaves the cell (T_maj / T_maj[1] = 1: nothing else changes) / tentative collision
+                    }
+                }
+            }
+        }
+        // ---- phase B: the tentative collisions (medium lookup, absorb / scatter / null) ----
+        HK_DBG(3, state == TR_BUSY && (fl & TF_PENDING) != 0);
+        HK_DBG(4, state == TR_BUSY);
+        if (state == TR_BUSY && (fl & TF_PENDING) != 0) {
+            fl &= ~TF_PENDING;
+            const float dt = pend_dt;
+            const float Tm0 = media_expf((-dt) * sm0);
+            const v3 p = cur_o + rd * dt;
+            ++n_coll;
+            const float d = sample_density<MM, BRICKS>(med, p);
+            const float sa = a0 * d, ss = s0 * d;
+            const float p_absorb = sa / sm0, p_scatter = ss / sm0;
+            const float ue = lcg_next(rng);
+            if (ue < p_absorb) {
+                state = TR_EMPTY;  // absorbed
+            } else if (ue < p_absorb + p_scatter) {
+                if (last_depth)
+                    state = TR_EMPTY;
+                else {   // beta and r_u are rescaled by sigma_s T_maj / (sigma_s T_maj)[1] = 1: they stay as they are in the record
+                    g.ray_o[slot] = make_float4(p.x, p.y, p.z, INF_F);  // the scattering vertex: k_scatter continues from here
+                    state = TR_SCATTER;
+                }
+            } else {
+                const float sn0 = maxf(sm0 - sa - ss, 0.0f);
+                const float pdf = Tm0 * sn0;
+                if (pdf > 1e-10f) {
+                    rl_f = ((rl_f * Tm0) * sm0) * (1.0f / pdf);
+                    t = t + dt;
+                    cur_o = p;
+                    if (fl & TF_DEAD_NULL) state = TR_EMPTY;
+                } else
+                    state = TR_EMPTY;
+            }
+        }
+        if (state == TR_BUSY && (fl & TF_SURVIVED) != 0) state = ((fl & TF_DEAD_NULL) != 0 || last_depth) ? TR_EMPTY : TP_SURVIVED;
+    }
+    close_seg(0);
+    close_seg(1);
+    stats += global_wave();
+    HK_DBG_FLUSH(stats);
+    wave_add(&stats->collisions, n_coll);
+    wave_add(&stats->dda_steps, n_dda);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // K5 + K6: direct lighting at a medium scattering vertex (light-BVH NEE with n = 0, HG evaluated with cos = wo.wi,
 // medium-scatter.jl:15-138) and phase-function sampling (medium-scatter.jl:148-216).  First writer of this depth's shadow /
 // next-ray segments.
@@ -3598,6 +3931,10 @@ static int grey_flat_mode() {   // HK_GREY_FLAT=0: grey media run through the ro
     const char* e = std::getenv("HK_GREY_FLAT");
     return e ? std::atoi(e) : 1;
 }
+static int track_pool_mode() {   // HK_TRACK_POOL=0: k_track_flat instead of k_track_pool (A/B switch, read per launch)
+    const char* e = std::getenv("HK_TRACK_POOL");
+    return e ? std::atoi(e) : 1;
+}
 // media kernels are instantiated for a single medium kind or for all four (15)
 static int media_mask_class(const DScene& sc) {
     int m = sc.media_mask;
@@ -3684,12 +4021,16 @@ void launch_medium(hipStream_t s, int n_cu, const DPathState& st, const DScene& 
         hipLaunchKernelGGL((k_track<MM>), dim3(clamp_blocks(blocks, st)), dim3(256), 0, s, st, sc, T, fr, depth, stats, sc.media);   \
     }
 #define HK_TRACK_FLAT(MM, B)                                                                                             \
-    {                                                                                                                    \
+    if (pool) {                                                                                                          \
+        const int blocks = cached_blocks<k_track_pool<MM, B>>(256, n_cu, 8);                                           \
+        hipLaunchKernelGGL((k_track_pool<MM, B>), dim3(clamp_blocks(blocks, st)), dim3(256), 0, s, st, sc, fr, depth, stats, sc.media);   \
+    } else {                                                                                                             \
         const int blocks = cached_blocks<k_track_flat<MM, B>>(256, n_cu, 8);                                           \
         hipLaunchKernelGGL((k_track_flat<MM, B>), dim3(clamp_blocks(blocks, st)), dim3(256), 0, s, st, sc, fr, depth, stats, sc.media);   \
     }
     const bool grey = sc.all_grey && grey_mode();
     const bool flat = grey && grey_flat_mode();
+    const bool pool = flat && track_pool_mode() && sc.grey_pool;
     switch (media_mask_class(sc)) {
         case 1: HK_TRACK_LAUNCH(1) break;
         case 2: if (flat) HK_TRACK_FLAT(2, false) else if (grey) HK_TRACK_LAUNCH(2 COMMA true) else HK_TRACK_LAUNCH(2) break;

@@ -174,6 +174,7 @@ struct DScene {
     int all_opaque;             // no medium transitions and no alpha-tested surfaces
     int bvh_depth;              // deepest BVH level (bounds the traversal stack)
     int all_grey;               // every medium is a Grid / NanoVDB medium whose sigma_a and sigma_s are flat spectra (the GREY tracking kernels)
+    int grey_pool;              // all_grey, ONE medium, majorant grid <= 1024 cells per axis (k_track_pool packs the cell index in one word)
     int grey_bricks;            // all_grey and the one medium is a NanoVDB grid with dense halo bricks (DMedium::nv_bricks): tracking kernels without the tree walk
 };
 

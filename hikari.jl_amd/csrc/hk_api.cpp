@@ -1629,11 +1629,11 @@ extern "C" int32_t hk_stats_get(hk_ctx* c, hk_stats* out) {
             h.scatter_vertices += r.scatter_vertices;
             h.sc_light_nodes += r.sc_light_nodes;
 #ifdef HK_DEBUG_UTIL
-            for (int k = 0; k < 16; ++k) h.dbg[k] += r.dbg[k];
+            for (int k = 0; k < 32; ++k) h.dbg[k] += r.dbg[k];
 #endif
         }
 #ifdef HK_DEBUG_UTIL
-        for (int k = 0; k < 8; ++k)
+        for (int k = 0; k < 16; ++k)
             if (h.dbg[2 * k]) std::fprintf(stderr, "HK_DEBUG_UTIL[%d]: %.3f of %llu lane-slots\n", k, (double)h.dbg[2 * k + 1] / (double)h.dbg[2 * k], h.dbg[2 * k]);
 #endif
     }

@@ -260,9 +260,9 @@ __device__ __forceinline__ void wq_close(const WaveQ& q, int* cnt) {
 }
 
 #ifdef HK_DEBUG_UTIL
-#define HK_DBG_DECL unsigned long long dbg_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define HK_DBG_DECL unsigned long long dbg_[32] = {0};
 #define HK_DBG(i, active) do { dbg_[2 * (i)] += 64; dbg_[2 * (i) + 1] += __popcll(__ballot(active)); } while (0)
-#define HK_DBG_FLUSH(stats) do { if (lane_id() == 0) for (int k_ = 0; k_ < 16; ++k_) (stats)->dbg[k_] += dbg_[k_]; } while (0)
+#define HK_DBG_FLUSH(stats) do { if (lane_id() == 0) for (int k_ = 0; k_ < 32; ++k_) (stats)->dbg[k_] += dbg_[k_]; } while (0)
 #else
 #define HK_DBG_DECL
 #define HK_DBG(i, active) do { } while (0)
@@ -2972,6 +2972,357 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
 }
 
 // ---------------------------------------------------------------------------------------------------
+// k_walk_pool: K10 of a scene whose ONE medium is GREY (k_shadow_walk<.., GREY = true> above; same arithmetic and RNG consumption per
+// shadow ray, films bit-identical: tools/ab_bitwise.py, HK_WALK_POOL=0 runs the older kernel), with the two halves of a walk taken apart
+// INSIDE the wave (the split into two kernels lost to the traffic and the random order of its hand-over queues):
+//   * CAST PHASE, dense: whenever the wave's pool is empty and a lane is free, ALL 64 lanes cast — lanes that hold a ray waiting for its
+//     next segment cast that one, every other lane (tracking or idle) the next shadow record of the stream — then run the surface logic
+//     of intersection.jl:316-406 and, for the rays that have a stretch of medium in front of them, the set-up of the ratio tracker
+//     (majorant iterator: 18 IEEE divisions; PCG seed: two 64-bit Murmur hashes).  What goes on is written to the POOL in LDS
+//     (26 words per ray, CAP entries; a phase takes no more rays than the pool has room for).  In k_shadow_walk this code ran for
+//     the 16 - 25 lanes that happened to be idle, and the tracking rounds ran with 46 % of the lanes waiting for it.
+//     STACK / CAP: 16-entry traversal stacks and 48 pool entries are 36 KB of LDS per 4-wave block, four blocks per CU (8-entry stacks
+//     and 64 pool entries for the example's shallow BVH measured the same: 0.305 against 0.308 s).
+//   * TRACKING ROUNDS: a lane whose stretch ends takes the next ready ray from the pool in the same round (26 LDS reads); lane
+//     flags in one VGPR, straight-line DDA step (see k_track_flat).
+// ---------------------------------------------------------------------------------------------------
+enum { WP_SLOT = 0, WP_RO = 1, WP_DIR = 4, WP_TREM = 7, WP_HIT = 8, WP_T = 9, WP_U = 10, WP_L = 11, WP_TMIN = 12, WP_TMAX = 13, WP_NT = 14, WP_DL = 17, WP_VOX = 20, WP_RNG = 21,
+       WP_FL = 25, WP_FIELDS = 26 };
+enum { WF_IN_SEG = 1, WF_PENDING = 2, WF_DONE = 4, WF_AFTER_INNER = 8, WF_IT_LIVE = 32, WF_NEG0 = 0x100, WF_NEG1 = 0x200, WF_NEG2 = 0x400, WF_MISS = 0x1000, WF_TRANSITION = 0x2000,
+       WF_NEXT_MEDIUM = 0x4000, WF_MEDIUM = 0x8000, WF_SEG_SHIFT = 16, WF_SEG_MASK = 0xf0000, WF_CAST = 0x100000 };
+#ifndef HK_WALK_POOL_WAVES
+#define HK_WALK_POOL_WAVES 4
+#endif
+template <bool COUNT, int MM, bool BRICKS, int STACK, int CAP>
+__global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TRACE_BLOCK), amdgpu_waves_per_eu(HK_WALK_POOL_WAVES))) k_walk_pool(DPathState st, DScene sc, int depth, int tune, DStats* stats, const DMedium* __restrict__ media) {
+    constexpr int WAVE_INTS = WP_FIELDS * CAP + STACK * 64;
+    __shared__ int lds_all[(HK_TRACE_BLOCK / 64) * WAVE_INTS];
+    int* const pool = lds_all + (threadIdx.x >> 6) * WAVE_INTS;   // [field][CAP]
+    int* const stack = pool + WP_FIELDS * CAP;
+    const int lane = lane_id();
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    unsigned n_nodes = 0, n_tris = 0, n_casts = 0, n_hits = 0, n_coll = 0, n_dda = 0;
+    HK_DBG_DECL
+    const DMedium& med = media[0];
+    const float a0 = eval_flat(med.sigma_a), s0 = eval_flat(med.sigma_s);
+    const float sig_t = a0 + s0;
+    const int mrx = med.mres[0], mry = med.mres[1], mrz = med.mres[2];
+    const float* __restrict__ maj = med.majorant;
+    const int adv_n = (tune >> 8) & 0xff;
+    SegStream stream = stream_open(st, ticket_ptr(st, depth, TK_SHADOW), true, depth, Q_SHADOW);
+    uint32_t rec0 = 0;   // current segment's shadow records: entries rec0 .. rec0 + n - 1 (the wave streams segment after segment)
+    int n = 0, cursor = 0;
+    bool more = true;
+    int pool_n = 0;      // wave-uniform
+    int state = SH_EMPTY, fl = 0;
+    uint32_t slot = 0;
+    v3 ro = mk3(0, 0, 0), dir = mk3(0, 0, 1);
+    float t_remaining = 0.0f, hit_t = 0.0f;
+    float T_ray = 1.0f, tr_u = 1.0f, tr_l = 1.0f, sT = 1.0f, su = 1.0f, sl = 1.0f;
+    float it_tmin = 0.0f, it_tmax = 0.0f, nt0 = 0.0f, nt1 = 0.0f, nt2 = 0.0f, dl0 = 0.0f, dl1 = 0.0f, dl2 = 0.0f;
+    int vx = 0, vy = 0, vz = 0;
+    PCG32 rng = PCG32{0ull, 0ull};
+    float seg1 = 0.0f, sm0 = 0.0f, t = 0.0f, pend_dt = 0.0f;
+    int k_in_seg = 0, segi = 0;
+    for (;;) {
+        const unsigned long long track_m = __ballot(state == SH_TRACK);
+        // ---- cast phase: the pool is empty and a lane is free (or every lane waits for a cast: then with the room the pool has left) ----
+        const unsigned long long cast_m = __ballot(state == SH_CAST);
+        if (~track_m != 0ull && (pool_n == 0 || (track_m | cast_m) == ~0ull && track_m == 0ull)) {
+            const int room = CAP - pool_n;
+            bool own = state == SH_CAST && __popcll(cast_m & lt_mask) < room;
+            const unsigned long long own_m = __ballot(own);
+            const unsigned long long others_m = ~cast_m;   // idle and tracking lanes cast a fresh record
+            while (more && cursor >= n) {   // this segment is used up: go on with the next one
+                const int gw = stream_next(stream, st.n_waves);
+                if (gw >= st.n_waves) {
+                    more = false;
+                    break;
+                }
+                rec0 = (uint32_t)gw * (uint32_t)st.wave_cap;
+                n = *count_ptr(st, depth, Q_SHADOW, gw);
+                cursor = 0;
+            }
+            int avail = n - cursor > 0 ? n - cursor : 0;
+            if (own_m == 0ull && avail == 0) {
+                if (track_m == 0ull && pool_n == 0) break;   // nothing in flight, nothing left
+            } else {
+                // the ray of this lane for the phase: its own waiting one, or the next record of the stream
+                const int room_fresh = room - __popcll(own_m);
+                avail = avail < room_fresh ? avail : room_fresh;
+                const int rank = __popcll(others_m & lt_mask);
+                const bool fresh = (others_m >> lane & 1ull) != 0ull && rank < avail;
+                uint32_t c_slot = slot;
+                v3 c_ro = ro, c_dir = dir;
+                float c_trem = t_remaining, c_T = T_ray, c_u = tr_u, c_l = tr_l;
+                int c_fl = fl & (WF_MEDIUM | WF_SEG_MASK);
+                if (fresh) {
+                    c_slot = rec0 + (uint32_t)(cursor + rank);
+                    const float4 O = st.sh_o[c_slot], D = st.sh_d[c_slot];
+                    c_ro = mk3(O.x, O.y, O.z);
+                    c_dir = mk3(D.x, D.y, D.z);
+                    c_trem = O.w;
+                    c_T = c_u = c_l = 1.0f;
+                    c_fl = __float_as_int(D.w) >= 0 ? WF_MEDIUM : 0;
+                }
+                {
+                    const int others = __popcll(others_m);
+                    cursor += others < avail ? others : avail;
+                }
+                if (own) state = SH_EMPTY;   // (the ray lives in c_* now and comes back through the pool)
+                const bool active = own || (fresh && !(c_trem < 1e-6f));   // a degenerate ray is simply not visible
+                int out = 0;   // 0: the ray ended here, 1: goes on (ready to track, or waiting for another cast: WF_CAST)
+                float c_hit = 0.0f;
+                MajorantIter it = exhausted_iter();
+                PCG32 c_rng = PCG32{0ull, 0ull};
+                HK_DBG(8, active);
+                if (active) {
+                    bool opaque;
+                    ++n_casts;
+                    const HitRec h = traverse<1, COUNT>(sc, c_ro, c_dir, c_trem, stack, lane, n_nodes, n_tris, opaque);
+                    bool alive = true, miss_case = true, transition = false;
+                    int next_medium = -1;
+                    c_hit = c_trem;
+                    if (h.prim >= 0) {
+                        ++n_hits;
+                        miss_case = false;
+                        c_hit = h.t;
+                        if (opaque)
+                            alive = false;
+                        else {
+                            const DTriMeta meta = sc.meta[h.prim];
+                            const DMediumInterface mi = sc.mis[meta.mi];
+                            const v3 ng = geometric_normal(sc, h.prim);
+                            const bool entering = dot(c_dir, ng) < 0.0f;
+                            transition = mi.inside != mi.outside;
+                            next_medium = transition ? (entering ? mi.inside : mi.outside) : ((c_fl & WF_MEDIUM) ? 0 : -1);
+                            if (!transition) {
+                                const float w = 1.0f - h.u - h.v;
+                                const float alpha = surface_alpha(sc, mi.material, uv_at(sc, h.prim, w, h.u, h.v));
+                                bool pass = false;
+                                if (alpha < 1.0f) {
+                                    PCG32 arng = pcg32_init(pbrt_hash(c_ro), pbrt_hash(c_dir));
+                                    pass = pcg32_f32(arng) > alpha;
+                                }
+                                alive = pass;
+                            }
+                        }
+                    }
+                    if (!alive) {
+                        // blocked
+                    } else if (c_fl & WF_MEDIUM) {
+                        // ratio tracking over [0, c_hit] of this segment (intersection.jl:326-336, 376-386): set up here, run in the tracking rounds
+                        it = create_majorant_iterator<MM>(med, c_ro, c_dir, c_hit);
+                        c_rng = pcg32_init(pbrt_hash(c_ro), pbrt_hash(c_dir));
+                        c_fl |= (miss_case ? WF_MISS : 0) | (transition ? WF_TRANSITION : 0) | (next_medium >= 0 ? WF_NEXT_MEDIUM : 0) | ((it.mode & 0xff) == 2 ? WF_IT_LIVE : 0) | (it.mode & 0x700);
+                        out = 1;
+                    } else if (miss_case) {
+                        shadow_contribute<false>(st, c_slot, s4(c_T), s4(c_u), s4(c_l));
+                    } else {
+                        // step over the surface (no medium on this side)
+                        const bool stop = transition && c_T == 0.0f;
+                        if (transition) c_fl = (c_fl & ~WF_MEDIUM) | (next_medium >= 0 ? WF_MEDIUM : 0);
+                        c_ro = c_ro + c_dir * (c_hit + 1e-4f);
+                        c_trem = c_trem - c_hit - 1e-4f;
+                        const int seg = ((c_fl & WF_SEG_MASK) >> WF_SEG_SHIFT) + 1;
+                        c_fl = (c_fl & ~WF_SEG_MASK) | (seg << WF_SEG_SHIFT) | WF_CAST;
+                        out = (stop || seg >= 10 || c_trem < 1e-6f) ? 0 : 1;
+                    }
+                }
+                // ---- what goes on, to the pool ----
+                const unsigned long long out_m = __ballot(out != 0);
+                HK_DBG(9, out != 0);
+                if (out != 0) {
+                    int* e = pool + pool_n + __popcll(out_m & lt_mask);
+                    e[WP_SLOT * CAP] = (int)c_slot;
+                    e[(WP_RO + 0) * CAP] = __float_as_int(c_ro.x);
+                    e[(WP_RO + 1) * CAP] = __float_as_int(c_ro.y);
+                    e[(WP_RO + 2) * CAP] = __float_as_int(c_ro.z);
+                    e[(WP_DIR + 0) * CAP] = __float_as_int(c_dir.x);
+                    e[(WP_DIR + 1) * CAP] = __float_as_int(c_dir.y);
+                    e[(WP_DIR + 2) * CAP] = __float_as_int(c_dir.z);
+                    e[WP_TREM * CAP] = __float_as_int(c_trem);
+                    e[WP_HIT * CAP] = __float_as_int(c_hit);
+                    e[WP_T * CAP] = __float_as_int(c_T);
+                    e[WP_U * CAP] = __float_as_int(c_u);
+                    e[WP_L * CAP] = __float_as_int(c_l);
+                    e[WP_TMIN * CAP] = __float_as_int(it.t_min);
+                    e[WP_TMAX * CAP] = __float_as_int(it.t_max);
+                    e[(WP_NT + 0) * CAP] = __float_as_int(it.next_t[0]);
+                    e[(WP_NT + 1) * CAP] = __float_as_int(it.next_t[1]);
+                    e[(WP_NT + 2) * CAP] = __float_as_int(it.next_t[2]);
+                    e[(WP_DL + 0) * CAP] = __float_as_int(it.delta_t[0]);
+                    e[(WP_DL + 1) * CAP] = __float_as_int(it.delta_t[1]);
+                    e[(WP_DL + 2) * CAP] = __float_as_int(it.delta_t[2]);
+                    e[WP_VOX * CAP] = (c_fl & WF_IT_LIVE) ? (it.voxel[0] | (it.voxel[1] << 10) | (it.voxel[2] << 20)) : 0;
+                    e[(WP_RNG + 0) * CAP] = (int)(uint32_t)c_rng.state;
+                    e[(WP_RNG + 1) * CAP] = (int)(uint32_t)(c_rng.state >> 32);
+                    e[(WP_RNG + 2) * CAP] = (int)(uint32_t)c_rng.inc;
+                    e[(WP_RNG + 3) * CAP] = (int)(uint32_t)(c_rng.inc >> 32);
+                    e[WP_FL * CAP] = c_fl;
+                }
+                pool_n += __popcll(out_m);
+                wave_lds_fence();
+            }
+        }
+        // ---- free lanes take a ray from the pool ----
+        {
+            const unsigned long long free_m = __ballot(state == SH_EMPTY);
+            if (free_m != 0ull && pool_n > 0) {
+                const int rank = __popcll(free_m & lt_mask);
+                if (state == SH_EMPTY && rank < pool_n) {
+                    const int* e = pool + (pool_n - 1 - rank);
+                    slot = (uint32_t)e[WP_SLOT * CAP];
+                    ro = mk3(__int_as_float(e[(WP_RO + 0) * CAP]), __int_as_float(e[(WP_RO + 1) * CAP]), __int_as_float(e[(WP_RO + 2) * CAP]));
+                    dir = mk3(__int_as_float(e[(WP_DIR + 0) * CAP]), __int_as_float(e[(WP_DIR + 1) * CAP]), __int_as_float(e[(WP_DIR + 2) * CAP]));
+                    t_remaining = __int_as_float(e[WP_TREM * CAP]);
+                    hit_t = __int_as_float(e[WP_HIT * CAP]);
+                    T_ray = __int_as_float(e[WP_T * CAP]);
+                    tr_u = __int_as_float(e[WP_U * CAP]);
+                    tr_l = __int_as_float(e[WP_L * CAP]);
+                    it_tmin = __int_as_float(e[WP_TMIN * CAP]);
+                    it_tmax = __int_as_float(e[WP_TMAX * CAP]);
+                    nt0 = __int_as_float(e[(WP_NT + 0) * CAP]), nt1 = __int_as_float(e[(WP_NT + 1) * CAP]), nt2 = __int_as_float(e[(WP_NT + 2) * CAP]);
+                    dl0 = __int_as_float(e[(WP_DL + 0) * CAP]), dl1 = __int_as_float(e[(WP_DL + 1) * CAP]), dl2 = __int_as_float(e[(WP_DL + 2) * CAP]);
+                    const int vox = e[WP_VOX * CAP];
+                    vx = vox & 1023, vy = (vox >> 10) & 1023, vz = vox >> 20;
+                    rng.state = (uint64_t)(uint32_t)e[(WP_RNG + 0) * CAP] | ((uint64_t)(uint32_t)e[(WP_RNG + 1) * CAP] << 32);
+                    rng.inc = (uint64_t)(uint32_t)e[(WP_RNG + 2) * CAP] | ((uint64_t)(uint32_t)e[(WP_RNG + 3) * CAP] << 32);
+                    fl = e[WP_FL * CAP];
+                    sT = su = sl = 1.0f;
+                    segi = 0;
+                    state = (fl & WF_CAST) ? SH_CAST : SH_TRACK;
+                    fl &= ~WF_CAST;
+                }
+                const int free_n = __popcll(free_m);
+                pool_n -= free_n < pool_n ? free_n : pool_n;
+                wave_lds_fence();
+            }
+        }
+        if (__ballot(state == SH_TRACK) == 0ull) continue;   // (the cast phase above ends the kernel when nothing is left)
+        // ---- phase A: cheap steps (next majorant cell, free-flight sample) ----
+#pragma unroll 1
+        for (int adv = 0; adv < adv_n; ++adv) {
+            const bool need = state == SH_TRACK && (fl & (WF_PENDING | WF_DONE)) == 0;
+            if (__ballot(need) == 0ull) break;
+            HK_DBG(10, need);
+            if (need) {
+                if ((fl & WF_IN_SEG) == 0) {
+                    if (((fl & WF_AFTER_INNER) != 0 && sT == 0.0f) || segi >= 256 || (fl & WF_IT_LIVE) == 0 || it_tmin >= it_tmax)
+                        fl |= WF_DONE;
+                    else {
+                        // majorant_next (media.jl:625-729) of a DDA iterator, straight-line
+                        const bool lxy = nt0 < nt1, lxz = nt0 < nt2, lyz = nt1 < nt2;
+                        const bool ax0 = lxy & lxz, ax1 = (!lxy) & lyz;   // axis 0, axis 1, else axis 2
+                        const float nt = ax0 ? nt0 : (ax1 ? nt1 : nt2);
+                        const float stm = minf(nt, it_tmax);
+                        const float rho = maj[vx + mrx * (vy + mry * vz)];
+                        const float seg0 = it_tmin;
+                        seg1 = stm;
+                        const bool neg = (fl & (ax0 ? WF_NEG0 : (ax1 ? WF_NEG1 : WF_NEG2))) != 0;
+                        const int v = (ax0 ? vx : (ax1 ? vy : vz)) + (neg ? -1 : 1);
+                        const int lim = neg ? -1 : (ax0 ? mrx : (ax1 ? mry : mrz));
+                        const float s = nt + (ax0 ? dl0 : (ax1 ? dl1 : dl2));
+                        vx = ax0 ? v : vx;
+                        vy = ax1 ? v : vy;
+                        vz = (ax0 | ax1) ? vz : v;
+                        nt0 = ax0 ? s : nt0;
+                        nt1 = ax1 ? s : nt1;
+                        nt2 = (ax0 | ax1) ? nt2 : s;
+                        const bool out_of_grid = v == lim;
+                        fl = out_of_grid ? (fl & ~WF_IT_LIVE) : fl;
+                        it_tmin = out_of_grid ? it_tmax : stm;
+                        ++segi;
+                        ++n_dda;
+                        sm0 = sig_t * rho;
+                        if (sm0 >= 1e-10f) {
+                            t = seg0;
+                            fl |= WF_IN_SEG;
+                            k_in_seg = 0;
+                        }
+                    }
+                    fl &= ~WF_AFTER_INNER;
+                }
+                // a lane that has just entered a cell draws its first free flight in the same round
+                if ((fl & (WF_IN_SEG | WF_DONE)) == WF_IN_SEG) {
+                    if (k_in_seg >= 100)
+                        fl = (fl & ~WF_IN_SEG) | WF_AFTER_INNER;
+                    else {
+                        ++k_in_seg;
+                        const float u = pcg32_f32(rng);
+                        pend_dt = -media_logf(maxf(1e-10f, 1.0f - u)) / sm0;
+                        const float ts = t + pend_dt;
+                        fl = ts >= seg1 ? ((fl & ~WF_IN_SEG) | WF_AFTER_INNER) : (fl | WF_PENDING);   // leaves the cell (T_maj / T_maj[1] = 1: nothing else changes) / tentative collision
+                    }
+                }
+            }
+        }
+        // ---- phase B: the tentative collisions ----
+        HK_DBG(11, state == SH_TRACK && (fl & WF_PENDING) != 0);
+        HK_DBG(12, state == SH_TRACK);
+        HK_DBG(13, state == SH_CAST);
+        if (state == SH_TRACK && (fl & WF_PENDING) != 0) {
+            fl &= ~WF_PENDING;
+            const float dt = pend_dt;
+            const float ts = t + dt;
+            ++n_coll;
+            const float d = sample_density<MM, BRICKS>(med, ro + dir * ts);
+            const float sn0 = maxf(sm0 - a0 * d - s0 * d, 0.0f);
+            const float Tm0 = media_expf((-dt) * sm0);
+            const float pr = Tm0 * sm0;
+            if (pr > 1e-10f) {
+                const float inv = 1.0f / pr;
+                sT = ((sT * Tm0) * sn0) * inv;
+                sl = ((sl * Tm0) * sm0) * inv;
+                su = ((su * Tm0) * sn0) * inv;
+                const float est = sT * (1.0f / maxf(1e-10f, average_flat(sl + su)));
+                if (est < 0.05f) {
+                    const float rr = pcg32_f32(rng);
+                    if (rr < 0.75f) {
+                        sT = 0.0f;
+                        fl |= WF_DONE;
+                    } else
+                        sT = sT / (1.0f - 0.75f);
+                }
+                if (sT == 0.0f) fl |= WF_DONE;
+                t = ts;
+            } else {
+                sT = 0.0f;
+                fl |= WF_DONE;
+            }
+        }
+        // ---- the end of a stretch of medium: contribute (the ray reached its light), or wait for the cast behind the surface ----
+        if (state == SH_TRACK && (fl & WF_DONE) != 0) {
+            T_ray = T_ray * sT;
+            tr_u = tr_u * su;
+            tr_l = tr_l * sl;
+            if (fl & WF_MISS) {
+                shadow_contribute<false>(st, slot, s4(T_ray), s4(tr_u), s4(tr_l));
+                state = SH_EMPTY;
+            } else {
+                const bool stop = (fl & WF_TRANSITION) != 0 && T_ray == 0.0f;
+                const int medium_bit = (fl & WF_TRANSITION) ? ((fl & WF_NEXT_MEDIUM) ? WF_MEDIUM : 0) : WF_MEDIUM;
+                ro = ro + dir * (hit_t + 1e-4f);
+                t_remaining = t_remaining - hit_t - 1e-4f;
+                const int seg = ((fl & WF_SEG_MASK) >> WF_SEG_SHIFT) + 1;
+                fl = medium_bit | (seg << WF_SEG_SHIFT);
+                state = (stop || seg >= 10 || t_remaining < 1e-6f) ? SH_EMPTY : SH_CAST;
+            }
+        }
+    }
+    stats += global_wave();
+    HK_DBG_FLUSH(stats);
+    wave_add(&stats->sh_collisions, n_coll);
+    wave_add(&stats->sh_dda_steps, n_dda);
+    wave_add(&stats->rays_shadow, n_casts);
+    wave_add(&stats->hits, n_hits);
+    if (COUNT) {
+        wave_add(&stats->sh_nodes, n_nodes);
+        wave_add(&stats->sh_tris, n_tris);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // K10 of a scene whose (single) medium is GREY, SPLIT in two kernels.  k_shadow_walk carries the registers of the
 // BVH traversal and of the ratio tracker together (128 VGPRs with spills at 4 waves per SIMD) and these loops are bound by instruction
 // issue at low residency; the two halves never need each other's state:
@@ -3931,6 +4282,10 @@ static int grey_flat_mode() {   // HK_GREY_FLAT=0: grey media run through the ro
     const char* e = std::getenv("HK_GREY_FLAT");
     return e ? std::atoi(e) : 1;
 }
+static int walk_pool_mode() {   // HK_WALK_POOL=0: k_shadow_walk<.., GREY> instead of k_walk_pool (A/B switch, read per launch)
+    const char* e = std::getenv("HK_WALK_POOL");
+    return e ? std::atoi(e) : 1;
+}
 static int track_pool_mode() {   // HK_TRACK_POOL=0: k_track_flat instead of k_track_pool (A/B switch, read per launch)
     const char* e = std::getenv("HK_TRACK_POOL");
     return e ? std::atoi(e) : 1;
@@ -3970,7 +4325,16 @@ void launch_shadow(hipStream_t s, int n_cu, const DPathState& st, const DScene& 
         }
     }
 #define HK_SHADOW_LAUNCH(C, MM)                                                                                                        \
-    if (sc.bvh_depth <= 16 && (MM == 2 || MM == 8) && sc.all_grey && grey_mode()) {                                                  \
+    if (sc.bvh_depth <= 16 && (MM == 2 || MM == 8) && sc.grey_pool && grey_mode() && grey_flat_mode() && walk_pool_mode()) {         \
+        constexpr int M2 = (MM == 2 || MM == 8) ? MM : 8;                                                                              \
+        if (M2 == 8 && sc.grey_bricks) {                                                                                        \
+            const int blocks = cached_blocks<k_walk_pool<C, 8, true, 16, 48>>(HK_TRACE_BLOCK, n_cu, 8);                              \
+            hipLaunchKernelGGL((k_walk_pool<C, 8, true, 16, 48>), dim3(clamp_blocks(blocks, st)), dim3(HK_TRACE_BLOCK), 0, s, st, sc, depth, fr.walk_tune, stats, sc.media); \
+        } else {                                                                                                                       \
+            const int blocks = cached_blocks<k_walk_pool<C, M2, false, 16, 48>>(HK_TRACE_BLOCK, n_cu, 8);                            \
+            hipLaunchKernelGGL((k_walk_pool<C, M2, false, 16, 48>), dim3(clamp_blocks(blocks, st)), dim3(HK_TRACE_BLOCK), 0, s, st, sc, depth, fr.walk_tune, stats, sc.media); \
+        }                                                                                                                              \
+    } else if (sc.bvh_depth <= 16 && (MM == 2 || MM == 8) && sc.all_grey && grey_mode()) {                                           \
         constexpr int M2 = (MM == 2 || MM == 8) ? MM : 8;                                                                              \
         const int blocks = cached_blocks<k_shadow_walk<C, M2, 16, true>>(HK_TRACE_BLOCK, n_cu, 8);                                   \
         hipLaunchKernelGGL((k_shadow_walk<C, M2, 16, true>), dim3(clamp_blocks(blocks, st)), dim3(HK_TRACE_BLOCK), 0, s, st, sc, T, depth, fr.walk_tune, stats, sc.media); \

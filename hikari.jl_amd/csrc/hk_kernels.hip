@@ -3013,7 +3013,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
     uint32_t rec0 = 0;   // current segment's shadow records: entries rec0 .. rec0 + n - 1 (the wave streams segment after segment)
     int n = 0, cursor = 0;
     bool more = true;
-    int pool_n = 0;      // wave-uniform
+    int track_n = 0, cast_n = 0;   // wave-uniform: ready rays at pool[0 .. track_n), rays waiting for a cast at pool[CAP - cast_n .. CAP)
     int state = SH_EMPTY, fl = 0;
     uint32_t slot = 0;
     v3 ro = mk3(0, 0, 0), dir = mk3(0, 0, 1);
@@ -3026,13 +3026,10 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
     int k_in_seg = 0, segi = 0;
     for (;;) {
         const unsigned long long track_m = __ballot(state == SH_TRACK);
-        // ---- cast phase: the pool is empty and a lane is free (or every lane waits for a cast: then with the room the pool has left) ----
-        const unsigned long long cast_m = __ballot(state == SH_CAST);
-        if (~track_m != 0ull && (pool_n == 0 || (track_m | cast_m) == ~0ull && track_m == 0ull)) {
-            const int room = CAP - pool_n;
-            bool own = state == SH_CAST && __popcll(cast_m & lt_mask) < room;
-            const unsigned long long own_m = __ballot(own);
-            const unsigned long long others_m = ~cast_m;   // idle and tracking lanes cast a fresh record
+        // ---- cast phase: no ready ray is left in the pool and a lane is not tracking (or every lane holds a waiting ray) ----
+        const bool own = state == SH_CAST;   // (a lane keeps a waiting ray itself only when the pool had no room for it)
+        const unsigned long long own_m = __ballot(own);
+        if (~track_m != 0ull && (track_n == 0 || own_m == ~0ull)) {
             while (more && cursor >= n) {   // this segment is used up: go on with the next one
                 const int gw = stream_next(stream, st.n_waves);
                 if (gw >= st.n_waves) {
@@ -3043,21 +3040,36 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
                 n = *count_ptr(st, depth, Q_SHADOW, gw);
                 cursor = 0;
             }
-            int avail = n - cursor > 0 ? n - cursor : 0;
-            if (own_m == 0ull && avail == 0) {
-                if (track_m == 0ull && pool_n == 0) break;   // nothing in flight, nothing left
+            // the rays of the phase: the lanes' own waiting ones, then the pool's waiting ones, then the next records of the stream — as
+            // many of those as the pool could take back (every ray leaves at most one entry behind)
+            const int n_other = 64 - __popcll(own_m);
+            const int c_take = cast_n < n_other ? cast_n : n_other;
+            int f_take = n - cursor > 0 ? n - cursor : 0;
+            f_take = f_take < n_other - c_take ? f_take : n_other - c_take;
+            f_take = f_take < CAP - track_n - cast_n ? f_take : CAP - track_n - cast_n;
+            if (own_m == 0ull && c_take == 0 && f_take == 0) {
+                if (track_m == 0ull) break;   // nothing in flight, nothing left
             } else {
-                // the ray of this lane for the phase: its own waiting one, or the next record of the stream
-                const int room_fresh = room - __popcll(own_m);
-                avail = avail < room_fresh ? avail : room_fresh;
-                const int rank = __popcll(others_m & lt_mask);
-                const bool fresh = (others_m >> lane & 1ull) != 0ull && rank < avail;
+                const int rank = __popcll(~own_m & lt_mask);
+                const bool from_pool = !own && rank < c_take;
+                const bool fresh = !own && !from_pool && rank - c_take < f_take;
                 uint32_t c_slot = slot;
                 v3 c_ro = ro, c_dir = dir;
                 float c_trem = t_remaining, c_T = T_ray, c_u = tr_u, c_l = tr_l;
                 int c_fl = fl & (WF_MEDIUM | WF_SEG_MASK);
+                if (from_pool) {
+                    const int* e = pool + (CAP - cast_n + rank);
+                    c_slot = (uint32_t)e[WP_SLOT * CAP];
+                    c_ro = mk3(__int_as_float(e[(WP_RO + 0) * CAP]), __int_as_float(e[(WP_RO + 1) * CAP]), __int_as_float(e[(WP_RO + 2) * CAP]));
+                    c_dir = mk3(__int_as_float(e[(WP_DIR + 0) * CAP]), __int_as_float(e[(WP_DIR + 1) * CAP]), __int_as_float(e[(WP_DIR + 2) * CAP]));
+                    c_trem = __int_as_float(e[WP_TREM * CAP]);
+                    c_T = __int_as_float(e[WP_T * CAP]);
+                    c_u = __int_as_float(e[WP_U * CAP]);
+                    c_l = __int_as_float(e[WP_L * CAP]);
+                    c_fl = e[WP_FL * CAP] & (WF_MEDIUM | WF_SEG_MASK);
+                }
                 if (fresh) {
-                    c_slot = rec0 + (uint32_t)(cursor + rank);
+                    c_slot = rec0 + (uint32_t)(cursor + rank - c_take);
                     const float4 O = st.sh_o[c_slot], D = st.sh_d[c_slot];
                     c_ro = mk3(O.x, O.y, O.z);
                     c_dir = mk3(D.x, D.y, D.z);
@@ -3065,13 +3077,11 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
                     c_T = c_u = c_l = 1.0f;
                     c_fl = __float_as_int(D.w) >= 0 ? WF_MEDIUM : 0;
                 }
-                {
-                    const int others = __popcll(others_m);
-                    cursor += others < avail ? others : avail;
-                }
-                if (own) state = SH_EMPTY;   // (the ray lives in c_* now and comes back through the pool)
-                const bool active = own || (fresh && !(c_trem < 1e-6f));   // a degenerate ray is simply not visible
-                int out = 0;   // 0: the ray ended here, 1: goes on (ready to track, or waiting for another cast: WF_CAST)
+                cast_n -= c_take;
+                cursor += f_take;
+                wave_lds_fence();
+                const bool active = own || from_pool || (fresh && !(c_trem < 1e-6f));   // a degenerate ray is simply not visible
+                int out = 0;   // 0: the ray ended here, 1: ready to track, 2: waits for another cast
                 float c_hit = 0.0f;
                 MajorantIter it = exhausted_iter();
                 PCG32 c_rng = PCG32{0ull, 0ull};
@@ -3125,15 +3135,32 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
                         c_ro = c_ro + c_dir * (c_hit + 1e-4f);
                         c_trem = c_trem - c_hit - 1e-4f;
                         const int seg = ((c_fl & WF_SEG_MASK) >> WF_SEG_SHIFT) + 1;
-                        c_fl = (c_fl & ~WF_SEG_MASK) | (seg << WF_SEG_SHIFT) | WF_CAST;
-                        out = (stop || seg >= 10 || c_trem < 1e-6f) ? 0 : 1;
+                        c_fl = (c_fl & ~WF_SEG_MASK) | (seg << WF_SEG_SHIFT);
+                        out = (stop || seg >= 10 || c_trem < 1e-6f) ? 0 : 2;
                     }
                 }
-                // ---- what goes on, to the pool ----
-                const unsigned long long out_m = __ballot(out != 0);
-                HK_DBG(9, out != 0);
-                if (out != 0) {
-                    int* e = pool + pool_n + __popcll(out_m & lt_mask);
+                HK_DBG(9, out == 1);
+                const int c_vox = (c_fl & WF_IT_LIVE) ? (it.voxel[0] | (it.voxel[1] << 10) | (it.voxel[2] << 20)) : 0;
+                // ---- a lane's own ray stays with the lane ----
+                if (own) {
+                    slot = c_slot;
+                    ro = c_ro, dir = c_dir;
+                    t_remaining = c_trem, hit_t = c_hit;
+                    T_ray = c_T, tr_u = c_u, tr_l = c_l;
+                    it_tmin = it.t_min, it_tmax = it.t_max;
+                    nt0 = it.next_t[0], nt1 = it.next_t[1], nt2 = it.next_t[2];
+                    dl0 = it.delta_t[0], dl1 = it.delta_t[1], dl2 = it.delta_t[2];
+                    vx = c_vox & 1023, vy = (c_vox >> 10) & 1023, vz = c_vox >> 20;
+                    rng = c_rng;
+                    fl = c_fl;
+                    sT = su = sl = 1.0f;
+                    segi = 0;
+                    state = out == 1 ? SH_TRACK : (out == 2 ? SH_CAST : SH_EMPTY);
+                }
+                // ---- the others' rays go to the pool: ready ones from the bottom, waiting ones from the top ----
+                const unsigned long long ready_m = __ballot(!own && out == 1), wait_m = __ballot(!own && out == 2);
+                if (!own && out != 0) {
+                    int* e = pool + (out == 1 ? track_n + __popcll(ready_m & lt_mask) : CAP - 1 - cast_n - __popcll(wait_m & lt_mask));
                     e[WP_SLOT * CAP] = (int)c_slot;
                     e[(WP_RO + 0) * CAP] = __float_as_int(c_ro.x);
                     e[(WP_RO + 1) * CAP] = __float_as_int(c_ro.y);
@@ -3142,36 +3169,39 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
                     e[(WP_DIR + 1) * CAP] = __float_as_int(c_dir.y);
                     e[(WP_DIR + 2) * CAP] = __float_as_int(c_dir.z);
                     e[WP_TREM * CAP] = __float_as_int(c_trem);
-                    e[WP_HIT * CAP] = __float_as_int(c_hit);
                     e[WP_T * CAP] = __float_as_int(c_T);
                     e[WP_U * CAP] = __float_as_int(c_u);
                     e[WP_L * CAP] = __float_as_int(c_l);
-                    e[WP_TMIN * CAP] = __float_as_int(it.t_min);
-                    e[WP_TMAX * CAP] = __float_as_int(it.t_max);
-                    e[(WP_NT + 0) * CAP] = __float_as_int(it.next_t[0]);
-                    e[(WP_NT + 1) * CAP] = __float_as_int(it.next_t[1]);
-                    e[(WP_NT + 2) * CAP] = __float_as_int(it.next_t[2]);
-                    e[(WP_DL + 0) * CAP] = __float_as_int(it.delta_t[0]);
-                    e[(WP_DL + 1) * CAP] = __float_as_int(it.delta_t[1]);
-                    e[(WP_DL + 2) * CAP] = __float_as_int(it.delta_t[2]);
-                    e[WP_VOX * CAP] = (c_fl & WF_IT_LIVE) ? (it.voxel[0] | (it.voxel[1] << 10) | (it.voxel[2] << 20)) : 0;
-                    e[(WP_RNG + 0) * CAP] = (int)(uint32_t)c_rng.state;
-                    e[(WP_RNG + 1) * CAP] = (int)(uint32_t)(c_rng.state >> 32);
-                    e[(WP_RNG + 2) * CAP] = (int)(uint32_t)c_rng.inc;
-                    e[(WP_RNG + 3) * CAP] = (int)(uint32_t)(c_rng.inc >> 32);
                     e[WP_FL * CAP] = c_fl;
+                    if (out == 1) {
+                        e[WP_HIT * CAP] = __float_as_int(c_hit);
+                        e[WP_TMIN * CAP] = __float_as_int(it.t_min);
+                        e[WP_TMAX * CAP] = __float_as_int(it.t_max);
+                        e[(WP_NT + 0) * CAP] = __float_as_int(it.next_t[0]);
+                        e[(WP_NT + 1) * CAP] = __float_as_int(it.next_t[1]);
+                        e[(WP_NT + 2) * CAP] = __float_as_int(it.next_t[2]);
+                        e[(WP_DL + 0) * CAP] = __float_as_int(it.delta_t[0]);
+                        e[(WP_DL + 1) * CAP] = __float_as_int(it.delta_t[1]);
+                        e[(WP_DL + 2) * CAP] = __float_as_int(it.delta_t[2]);
+                        e[WP_VOX * CAP] = c_vox;
+                        e[(WP_RNG + 0) * CAP] = (int)(uint32_t)c_rng.state;
+                        e[(WP_RNG + 1) * CAP] = (int)(uint32_t)(c_rng.state >> 32);
+                        e[(WP_RNG + 2) * CAP] = (int)(uint32_t)c_rng.inc;
+                        e[(WP_RNG + 3) * CAP] = (int)(uint32_t)(c_rng.inc >> 32);
+                    }
                 }
-                pool_n += __popcll(out_m);
+                track_n += __popcll(ready_m);
+                cast_n += __popcll(wait_m);
                 wave_lds_fence();
             }
         }
-        // ---- free lanes take a ray from the pool ----
+        // ---- free lanes take a ready ray from the pool ----
         {
             const unsigned long long free_m = __ballot(state == SH_EMPTY);
-            if (free_m != 0ull && pool_n > 0) {
+            if (free_m != 0ull && track_n > 0) {
                 const int rank = __popcll(free_m & lt_mask);
-                if (state == SH_EMPTY && rank < pool_n) {
-                    const int* e = pool + (pool_n - 1 - rank);
+                if (state == SH_EMPTY && rank < track_n) {
+                    const int* e = pool + (track_n - 1 - rank);
                     slot = (uint32_t)e[WP_SLOT * CAP];
                     ro = mk3(__int_as_float(e[(WP_RO + 0) * CAP]), __int_as_float(e[(WP_RO + 1) * CAP]), __int_as_float(e[(WP_RO + 2) * CAP]));
                     dir = mk3(__int_as_float(e[(WP_DIR + 0) * CAP]), __int_as_float(e[(WP_DIR + 1) * CAP]), __int_as_float(e[(WP_DIR + 2) * CAP]));
@@ -3191,11 +3221,10 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
                     fl = e[WP_FL * CAP];
                     sT = su = sl = 1.0f;
                     segi = 0;
-                    state = (fl & WF_CAST) ? SH_CAST : SH_TRACK;
-                    fl &= ~WF_CAST;
+                    state = SH_TRACK;
                 }
                 const int free_n = __popcll(free_m);
-                pool_n -= free_n < pool_n ? free_n : pool_n;
+                track_n -= free_n < track_n ? free_n : track_n;
                 wave_lds_fence();
             }
         }
@@ -3291,22 +3320,53 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
                 fl |= WF_DONE;
             }
         }
-        // ---- the end of a stretch of medium: contribute (the ray reached its light), or wait for the cast behind the surface ----
-        if (state == SH_TRACK && (fl & WF_DONE) != 0) {
-            T_ray = T_ray * sT;
-            tr_u = tr_u * su;
-            tr_l = tr_l * sl;
-            if (fl & WF_MISS) {
-                shadow_contribute<false>(st, slot, s4(T_ray), s4(tr_u), s4(tr_l));
-                state = SH_EMPTY;
-            } else {
-                const bool stop = (fl & WF_TRANSITION) != 0 && T_ray == 0.0f;
-                const int medium_bit = (fl & WF_TRANSITION) ? ((fl & WF_NEXT_MEDIUM) ? WF_MEDIUM : 0) : WF_MEDIUM;
-                ro = ro + dir * (hit_t + 1e-4f);
-                t_remaining = t_remaining - hit_t - 1e-4f;
-                const int seg = ((fl & WF_SEG_MASK) >> WF_SEG_SHIFT) + 1;
-                fl = medium_bit | (seg << WF_SEG_SHIFT);
-                state = (stop || seg >= 10 || t_remaining < 1e-6f) ? SH_EMPTY : SH_CAST;
+        // ---- the end of a stretch of medium: contribute (the ray reached its light), or leave the ray in the pool for the cast behind the surface ----
+        {
+            const bool fin = state == SH_TRACK && (fl & WF_DONE) != 0;
+            const unsigned long long fin_m = __ballot(fin);
+            if (fin_m != 0ull) {
+                bool goes_on = false;
+                if (fin) {
+                    T_ray = T_ray * sT;
+                    tr_u = tr_u * su;
+                    tr_l = tr_l * sl;
+                    state = SH_EMPTY;
+                    if (fl & WF_MISS)
+                        shadow_contribute<false>(st, slot, s4(T_ray), s4(tr_u), s4(tr_l));
+                    else {
+                        const bool stop = (fl & WF_TRANSITION) != 0 && T_ray == 0.0f;
+                        const int medium_bit = (fl & WF_TRANSITION) ? ((fl & WF_NEXT_MEDIUM) ? WF_MEDIUM : 0) : WF_MEDIUM;
+                        ro = ro + dir * (hit_t + 1e-4f);
+                        t_remaining = t_remaining - hit_t - 1e-4f;
+                        const int seg = ((fl & WF_SEG_MASK) >> WF_SEG_SHIFT) + 1;
+                        fl = medium_bit | (seg << WF_SEG_SHIFT);
+                        goes_on = !(stop || seg >= 10 || t_remaining < 1e-6f);
+                    }
+                }
+                const unsigned long long on_m = __ballot(goes_on);
+                if (on_m != 0ull) {
+                    const int room = CAP - track_n - cast_n;
+                    const int r = __popcll(on_m & lt_mask);
+                    if (goes_on && r < room) {
+                        int* e = pool + (CAP - 1 - cast_n - r);
+                        e[WP_SLOT * CAP] = (int)slot;
+                        e[(WP_RO + 0) * CAP] = __float_as_int(ro.x);
+                        e[(WP_RO + 1) * CAP] = __float_as_int(ro.y);
+                        e[(WP_RO + 2) * CAP] = __float_as_int(ro.z);
+                        e[(WP_DIR + 0) * CAP] = __float_as_int(dir.x);
+                        e[(WP_DIR + 1) * CAP] = __float_as_int(dir.y);
+                        e[(WP_DIR + 2) * CAP] = __float_as_int(dir.z);
+                        e[WP_TREM * CAP] = __float_as_int(t_remaining);
+                        e[WP_T * CAP] = __float_as_int(T_ray);
+                        e[WP_U * CAP] = __float_as_int(tr_u);
+                        e[WP_L * CAP] = __float_as_int(tr_l);
+                        e[WP_FL * CAP] = fl;
+                    } else if (goes_on)
+                        state = SH_CAST;   // no room: the lane keeps the ray until the next cast phase
+                    const int pushed = __popcll(on_m);
+                    cast_n += pushed < room ? pushed : room;
+                    wave_lds_fence();
+                }
             }
         }
     }

@@ -1539,7 +1539,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
 // k_track_flat).  Only the ORDER of a segment's queue entries differs, which no result depends on (test_scheduling_is_result_neutral).
 // ---------------------------------------------------------------------------------------------------
 enum { TP_SLOT = 0, TP_RO = 1, TP_RD = 4, TP_RNG = 7, TP_TMIN = 9, TP_TMAX = 10, TP_NT = 11, TP_DL = 14, TP_VOX = 17, TP_FL = 18, TP_FIELDS = 19, TP_RING = 128,
-       TP_WAVE_INTS = TP_FIELDS * 64 + 3 * TP_RING + 32, TP_SURVIVED = 15 };
+       TP_TAGS = 4, TP_TAG_SHIFT = 12, TP_WAVE_INTS = TP_FIELDS * 64 + 3 * TP_RING + 16 * TP_TAGS, TP_SURVIVED = 14 };
 HKD void wave_lds_fence() {   // orders this wave's LDS writes before its later LDS reads by OTHER lanes (the hardware executes a wave's LDS instructions in order)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -1550,7 +1550,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
     __shared__ int lds_all[4 * TP_WAVE_INTS];
     int* const pool = lds_all + (threadIdx.x >> 6) * TP_WAVE_INTS;   // [field][64]
     int* const ring = pool + TP_FIELDS * 64;                          // [slot | key | r_l factor][TP_RING]
-    int* const segc = ring + 3 * TP_RING;                             // [tag][16]: entries in the segment's escaped, scatter and per-kind queues
+    int* const segc = ring + 3 * TP_RING;                             // [tag][16]: entries in the segment's escaped, scatter and per-kind queues; [15] = the segment
     const int lane = lane_id();
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     unsigned n_coll = 0, n_dda = 0;
@@ -1564,8 +1564,9 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
     const float* __restrict__ maj = med.majorant;
     const bool last_depth = depth >= fr.max_depth;
     SegStream stream = stream_open(st, ticket_ptr(st, depth, TK_TRACK), true, depth, Q_MEDIUM);
-    int gw0 = -1, gw1 = -1;   // the two open segments (tag 0 / 1)
-    int cur_tag = 0;
+    int cur_tag = 0;          // up to TP_TAGS segments are open at a time (a path's tag: bits TP_TAG_SHIFT.. of its flag word): the wave goes on
+                              // with the next segment while the last paths of the previous ones are still in flight
+    if (lane < TP_TAGS) segc[lane * 16 + 15] = -1;
     const uint32_t* __restrict__ queue = st.medium_q;
     int n = 0, cursor = 0;
     bool more = true;
@@ -1573,12 +1574,12 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
     bool drain = false;                         // route the whole ring, not only full chunks
     auto open_seg = [&](int tag, int gw) {
         if (lane < 2 + HK_MAX_KINDS) segc[tag * 16 + lane] = lane == 1 ? 0 : *count_ptr(st, depth, lane == 0 ? Q_ESCAPED : Q_MAT0 + lane - 2, gw);
-        if (tag == 0) gw0 = gw; else gw1 = gw;
+        if (lane == 15) segc[tag * 16 + 15] = gw;
     };
     auto close_seg = [&](int tag) {
-        const int gw = tag == 0 ? gw0 : gw1;
+        const int gw = __builtin_amdgcn_readfirstlane(segc[tag * 16 + 15]);
         if (gw >= 0 && lane < 2 + HK_MAX_KINDS) *count_ptr(st, depth, lane == 0 ? Q_ESCAPED : (lane == 1 ? Q_SCATTER : Q_MAT0 + lane - 2), gw) = segc[tag * 16 + lane];
-        if (tag == 0) gw0 = -1; else gw1 = -1;
+        if (lane == 15) segc[tag * 16 + 15] = -1;
     };
     // route the first cnt (<= 64) entries of the ring: r_l update and classification of the survivors, then ballot compaction per destination
     auto route = [&](int cnt) {
@@ -1612,7 +1613,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
                 const int kind = sc.materials[mat].kind;
                 cls = 2 + (kind == HK_MAT_MIX ? HK_MAT_FALLBACK : kind);
             }
-            key = (key & 16) | cls;
+            key = (key & ~15) | cls;
         }
         res_head = (res_head + cnt) & (TP_RING - 1);
         res_n -= cnt;
@@ -1621,7 +1622,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
             const int k = __builtin_amdgcn_readlane(key, __ffsll((long long)todo) - 1);   // wave-uniform destination
             const unsigned long long m = __ballot(key == k);
             const int base = __builtin_amdgcn_readfirstlane(segc[k]);
-            const int gw = (k & 16) ? gw1 : gw0, cls = k & 15;
+            const int gw = __builtin_amdgcn_readfirstlane(segc[(k & ~15) + 15]), cls = k & 15;
             uint32_t* __restrict__ q = cls == 0 ? st.escaped_q + (size_t)gw * st.wave_cap
                                      : cls == 1 ? st.scatter_q + (size_t)gw * st.wave_cap
                                                 : st.mat_q + ((size_t)(cls - 2) * st.n_waves + gw) * st.wave_cap;
@@ -1649,7 +1650,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
                 if (fin) {
                     const int p = (res_head + res_n + __popcll(m & lt_mask)) & (TP_RING - 1);
                     ring[p] = (int)slot;
-                    ring[TP_RING + p] = ((fl & TF_TAG) ? 16 : 0) | (state == TR_SCATTER ? 1 : TP_SURVIVED);   // (survivors are classified when routed)
+                    ring[TP_RING + p] = (((fl >> TP_TAG_SHIFT) & (TP_TAGS - 1)) << 4) | (state == TR_SCATTER ? 1 : TP_SURVIVED);   // (survivors are classified when routed)
                     ring[2 * TP_RING + p] = __float_as_int(rl_f);
                     state = TR_EMPTY;
                 }
@@ -1664,10 +1665,10 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
         // ---- the pool is empty and a lane is free: set up the next 64 entries of the segment's queue ----
         if (free_m != 0ull && pool_n == 0 && (cursor < n || more)) {
             while (more && cursor >= n) {
-                // the current segment is used up: open the next one in the other slot as soon as that slot's last lane is done
-                const int other = cur_tag ^ 1;
-                const bool other_busy = __ballot(state == TR_BUSY && ((fl & TF_TAG) ? 1 : 0) == other) != 0ull;
-                if (other_busy) break;   // both slots hold lanes in flight: no third segment, the set-up waits
+                // the current segment is used up: open the next one in the oldest slot as soon as that slot's last lane is done
+                const int other = (cur_tag + 1) & (TP_TAGS - 1);
+                const bool other_busy = __ballot(state == TR_BUSY && ((fl >> TP_TAG_SHIFT) & (TP_TAGS - 1)) == other) != 0ull;
+                if (other_busy) break;   // every slot holds lanes in flight: the set-up waits
                 if (res_n > 0) {         // its last results are still in the ring
                     drain = true;
                     break;
@@ -1687,7 +1688,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
             if (drain) continue;
             const int avail = n - cursor;
             const int take = avail < 64 ? avail : 64;
-            HK_DBG(5, lane < take);
+            if (take > 0) HK_DBG(5, lane < take);
             if (lane < take) {
                 const uint32_t s_new = queue[cursor + lane];
                 const float4 O = g.ray_o[s_new], D = g.ray_d[s_new];
@@ -1715,7 +1716,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
                 e[(TP_DL + 1) * 64] = __float_as_int(it.delta_t[1]);
                 e[(TP_DL + 2) * 64] = __float_as_int(it.delta_t[2]);
                 e[TP_VOX * 64] = (it.mode & 0xff) == 2 ? (it.voxel[0] | (it.voxel[1] << 10) | (it.voxel[2] << 20)) : 0;
-                e[TP_FL * 64] = (cur_tag ? TF_TAG : 0) | (dead ? TF_DEAD_NULL : 0) | ((it.mode & 0xff) == 2 ? TF_IT_LIVE : 0) | (it.mode & 0x700);
+                e[TP_FL * 64] = (cur_tag << TP_TAG_SHIFT) | (dead ? TF_DEAD_NULL : 0) | ((it.mode & 0xff) == 2 ? TF_IT_LIVE : 0) | (it.mode & 0x700);
             }
             pool_n = take > 0 ? take : 0;
             cursor += pool_n;
@@ -1848,8 +1849,8 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
         }
         if (state == TR_BUSY && (fl & TF_SURVIVED) != 0) state = ((fl & TF_DEAD_NULL) != 0 || last_depth) ? TR_EMPTY : TP_SURVIVED;
     }
-    close_seg(0);
-    close_seg(1);
+#pragma unroll
+    for (int tg = 0; tg < TP_TAGS; ++tg) close_seg(tg);
     stats += global_wave();
     HK_DBG_FLUSH(stats);
     wave_add(&stats->collisions, n_coll);
@@ -2993,12 +2994,22 @@ enum { WF_IN_SEG = 1, WF_PENDING = 2, WF_DONE = 4, WF_AFTER_INNER = 8, WF_IT_LIV
 #ifndef HK_WALK_POOL_WAVES
 #define HK_WALK_POOL_WAVES 4
 #endif
+#ifndef HK_WALK_POOL_NC
+#define HK_WALK_POOL_NC 16
+#define HK_WALK_POOL_NT 32
+#endif
 template <bool COUNT, int MM, bool BRICKS, int STACK, int CAP>
 __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TRACE_BLOCK), amdgpu_waves_per_eu(HK_WALK_POOL_WAVES))) k_walk_pool(DPathState st, DScene sc, int depth, int tune, DStats* stats, const DMedium* __restrict__ media) {
     constexpr int WAVE_INTS = WP_FIELDS * CAP + STACK * 64;
     __shared__ int lds_all[(HK_TRACE_BLOCK / 64) * WAVE_INTS];
     int* const pool = lds_all + (threadIdx.x >> 6) * WAVE_INTS;   // [field][CAP]
     int* const stack = pool + WP_FIELDS * CAP;
+    // the shallow-BVH instantiation (a cloud in a box: a few dozen triangles) casts from LDS: nodes and leaf triangles, 2.5 KB per block
+    constexpr int NC = STACK <= 8 ? HK_WALK_POOL_NC : 0, NT = STACK <= 8 ? HK_WALK_POOL_NT : 0;
+    __shared__ float4 lds_box[NC > 0 ? 3 * NC : 1];
+    __shared__ int2 lds_child[NC > 0 ? NC : 1];
+    __shared__ float4 lds_tri[NT > 0 ? 3 * NT : 1];
+    const NodeCache cache = NC > 0 ? scene_cache_fill<NC, NT, HK_TRACE_BLOCK>(sc, lds_box, lds_child, lds_tri) : NodeCache();
     const int lane = lane_id();
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     unsigned n_nodes = 0, n_tris = 0, n_casts = 0, n_hits = 0, n_coll = 0, n_dda = 0;
@@ -3030,30 +3041,45 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
         const bool own = state == SH_CAST;   // (a lane keeps a waiting ray itself only when the pool had no room for it)
         const unsigned long long own_m = __ballot(own);
         if (~track_m != 0ull && (track_n == 0 || own_m == ~0ull)) {
-            while (more && cursor >= n) {   // this segment is used up: go on with the next one
-                const int gw = stream_next(stream, st.n_waves);
-                if (gw >= st.n_waves) {
-                    more = false;
-                    break;
-                }
-                rec0 = (uint32_t)gw * (uint32_t)st.wave_cap;
-                n = *count_ptr(st, depth, Q_SHADOW, gw);
-                cursor = 0;
-            }
             // the rays of the phase: the lanes' own waiting ones, then the pool's waiting ones, then the next records of the stream — as
-            // many of those as the pool could take back (every ray leaves at most one entry behind)
+            // many of those as the pool could take back (every ray leaves at most one entry behind); the records may come from several
+            // segments (the deep bounces' segments hold a few dozen records each)
             const int n_other = 64 - __popcll(own_m);
             const int c_take = cast_n < n_other ? cast_n : n_other;
-            int f_take = n - cursor > 0 ? n - cursor : 0;
-            f_take = f_take < n_other - c_take ? f_take : n_other - c_take;
-            f_take = f_take < CAP - track_n - cast_n ? f_take : CAP - track_n - cast_n;
+            const int rank = __popcll(~own_m & lt_mask);
+            const bool from_pool = !own && rank < c_take;
+            bool fresh = false;
+            uint32_t c_slot = slot;
+            int f_take = 0;
+            {
+                int want = n_other - c_take < CAP - track_n - cast_n ? n_other - c_take : CAP - track_n - cast_n;
+                while (want > 0) {
+                    while (more && cursor >= n) {   // this segment is used up: go on with the next one
+                        const int gw = stream_next(stream, st.n_waves);
+                        if (gw >= st.n_waves) {
+                            more = false;
+                            break;
+                        }
+                        rec0 = (uint32_t)gw * (uint32_t)st.wave_cap;
+                        n = *count_ptr(st, depth, Q_SHADOW, gw);
+                        cursor = 0;
+                    }
+                    const int avail = n - cursor;
+                    if (avail <= 0) break;
+                    const int take = avail < want ? avail : want;
+                    const int r = rank - c_take - f_take;
+                    if (!own && r >= 0 && r < take) {
+                        fresh = true;
+                        c_slot = rec0 + (uint32_t)(cursor + r);
+                    }
+                    cursor += take;
+                    f_take += take;
+                    want -= take;
+                }
+            }
             if (own_m == 0ull && c_take == 0 && f_take == 0) {
                 if (track_m == 0ull) break;   // nothing in flight, nothing left
             } else {
-                const int rank = __popcll(~own_m & lt_mask);
-                const bool from_pool = !own && rank < c_take;
-                const bool fresh = !own && !from_pool && rank - c_take < f_take;
-                uint32_t c_slot = slot;
                 v3 c_ro = ro, c_dir = dir;
                 float c_trem = t_remaining, c_T = T_ray, c_u = tr_u, c_l = tr_l;
                 int c_fl = fl & (WF_MEDIUM | WF_SEG_MASK);
@@ -3069,7 +3095,6 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
                     c_fl = e[WP_FL * CAP] & (WF_MEDIUM | WF_SEG_MASK);
                 }
                 if (fresh) {
-                    c_slot = rec0 + (uint32_t)(cursor + rank - c_take);
                     const float4 O = st.sh_o[c_slot], D = st.sh_d[c_slot];
                     c_ro = mk3(O.x, O.y, O.z);
                     c_dir = mk3(D.x, D.y, D.z);
@@ -3078,7 +3103,6 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
                     c_fl = __float_as_int(D.w) >= 0 ? WF_MEDIUM : 0;
                 }
                 cast_n -= c_take;
-                cursor += f_take;
                 wave_lds_fence();
                 const bool active = own || from_pool || (fresh && !(c_trem < 1e-6f));   // a degenerate ray is simply not visible
                 int out = 0;   // 0: the ray ended here, 1: ready to track, 2: waits for another cast
@@ -3089,7 +3113,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
                 if (active) {
                     bool opaque;
                     ++n_casts;
-                    const HitRec h = traverse<1, COUNT>(sc, c_ro, c_dir, c_trem, stack, lane, n_nodes, n_tris, opaque);
+                    const HitRec h = traverse<1, COUNT, NC, NT>(sc, c_ro, c_dir, c_trem, stack, lane, n_nodes, n_tris, opaque, cache);
                     bool alive = true, miss_case = true, transition = false;
                     int next_medium = -1;
                     c_hit = c_trem;
@@ -4387,12 +4411,15 @@ void launch_shadow(hipStream_t s, int n_cu, const DPathState& st, const DScene& 
 #define HK_SHADOW_LAUNCH(C, MM)                                                                                                        \
     if (sc.bvh_depth <= 16 && (MM == 2 || MM == 8) && sc.grey_pool && grey_mode() && grey_flat_mode() && walk_pool_mode()) {         \
         constexpr int M2 = (MM == 2 || MM == 8) ? MM : 8;                                                                              \
-        if (M2 == 8 && sc.grey_bricks) {                                                                                        \
-            const int blocks = cached_blocks<k_walk_pool<C, 8, true, 16, 48>>(HK_TRACE_BLOCK, n_cu, 8);                              \
-            hipLaunchKernelGGL((k_walk_pool<C, 8, true, 16, 48>), dim3(clamp_blocks(blocks, st)), dim3(HK_TRACE_BLOCK), 0, s, st, sc, depth, fr.walk_tune, stats, sc.media); \
+        if (M2 == 8 && sc.grey_bricks && sc.bvh_depth <= 8 && walk_pool_mode() == 1) {                                                 \
+            const int blocks = cached_blocks<k_walk_pool<C, 8, true, 8, 64>>(HK_TRACE_BLOCK, n_cu, 8);                                 \
+            hipLaunchKernelGGL((k_walk_pool<C, 8, true, 8, 64>), dim3(clamp_blocks(blocks, st)), dim3(HK_TRACE_BLOCK), 0, s, st, sc, depth, fr.walk_tune, stats, sc.media); \
+        } else if (M2 == 8 && sc.grey_bricks) {                                                                                        \
+            const int blocks = cached_blocks<k_walk_pool<C, 8, true, 16, 56>>(HK_TRACE_BLOCK, n_cu, 8);                                \
+            hipLaunchKernelGGL((k_walk_pool<C, 8, true, 16, 56>), dim3(clamp_blocks(blocks, st)), dim3(HK_TRACE_BLOCK), 0, s, st, sc, depth, fr.walk_tune, stats, sc.media); \
         } else {                                                                                                                       \
-            const int blocks = cached_blocks<k_walk_pool<C, M2, false, 16, 48>>(HK_TRACE_BLOCK, n_cu, 8);                            \
-            hipLaunchKernelGGL((k_walk_pool<C, M2, false, 16, 48>), dim3(clamp_blocks(blocks, st)), dim3(HK_TRACE_BLOCK), 0, s, st, sc, depth, fr.walk_tune, stats, sc.media); \
+            const int blocks = cached_blocks<k_walk_pool<C, M2, false, 16, 56>>(HK_TRACE_BLOCK, n_cu, 8);                              \
+            hipLaunchKernelGGL((k_walk_pool<C, M2, false, 16, 56>), dim3(clamp_blocks(blocks, st)), dim3(HK_TRACE_BLOCK), 0, s, st, sc, depth, fr.walk_tune, stats, sc.media); \
         }                                                                                                                              \
     } else if (sc.bvh_depth <= 16 && (MM == 2 || MM == 8) && sc.all_grey && grey_mode()) {                                           \
         constexpr int M2 = (MM == 2 || MM == 8) ? MM : 8;                                                                              \

@@ -160,7 +160,7 @@ struct hk_integrator {
     // path state (the reference's VolPathState, volpath-state.jl:29-181)
     DPathState st{};
     std::vector<DevBuf*> bufs;
-    int st_capacity = 0, st_depth = 0;
+    int st_capacity = 0, st_depth = 0, st_media = -1;   // what the retained path state was allocated for
     DevBuf sobol_table;  // DSobol::hi_table
     int sobol_rows = 0, sobol_stride = 0, sobol_log2 = -1, sobol_digits = -1, sobol_x0 = -1, sobol_y0 = -1, sobol_tiles_x = -1;
     DevBuf sobol_lo;     // DSobol::lo_table
@@ -1173,7 +1173,11 @@ int ensure_state(hk_integrator* I, int capacity, bool media, bool open_scene) {
     I->st.dynamic_segments = (media || !open_scene) ? 1 : 0;
     if (const char* e = std::getenv("HK_DYNAMIC_SEGMENTS")) I->st.dynamic_segments = std::atoi(e) ? 1 : 0;
     I->st.compact = media ? 0 : 1;
-    if (I->st_capacity >= capacity && I->st_depth >= I->p.max_depth && I->st.n_waves == (int)W_want && (!(media && std::getenv("HK_WALK_SPLIT") && std::atoi(std::getenv("HK_WALK_SPLIT"))) || I->st.wq_a != nullptr)) return HK_OK;
+    const char* split_env = std::getenv("HK_WALK_SPLIT");
+    const bool want_split = media && split_env && std::atoi(split_env);
+    // the retained state must be of the same flavour: a state allocated for a scene with media has no sel_light (k_light_select would
+    // silently not run in a later scene without media), one allocated without HK_WALK_SPLIT has no hand-over queues
+    if (I->st_capacity >= capacity && I->st_depth >= I->p.max_depth && I->st.n_waves == (int)W_want && I->st_media == (media ? 1 : 0) && (!want_split || I->st.wq_a != nullptr)) return HK_OK;
     for (auto* b : I->bufs) delete b;
     I->bufs.clear();
     DPathState& s = I->st;
@@ -1213,13 +1217,15 @@ int ensure_state(hk_integrator* I, int capacity, bool media, bool open_scene) {
     HIP_TRY(alloc_arr(I, s.sh_rl, Q));
     HIP_TRY(alloc_arr(I, s.sh_slot, Q));
     s.sh_T = nullptr, s.sh_aux = nullptr, s.sh_it = nullptr, s.wq_a = nullptr, s.wq_b = nullptr, s.wq_ctl = nullptr;
-    const char* split_env = std::getenv("HK_WALK_SPLIT");
-    if (media && split_env && std::atoi(split_env)) {   // the split shadow walk of grey media (92 B per record; off by default)
+    if (want_split) {   // the split shadow walk of grey media (92 B per record; off by default)
         HIP_TRY(alloc_arr(I, s.sh_T, Q));
         HIP_TRY(alloc_arr(I, s.sh_aux, Q));
         HIP_TRY(alloc_arr(I, s.sh_it, 4 * Q));
-        HIP_TRY(alloc_arr(I, s.wq_a, Q + (4u << 20)));   // + the padding of the writers' last chunks (HK_GQ_CHUNK x resident waves)
-        HIP_TRY(alloc_arr(I, s.wq_b, Q + (4u << 20)));
+        // worst case of gq_out_push: a chunk of 256 entries is closed (padded) as soon as the next push of up to 64 does not fit, so 193
+        // pushes can use up 256 entries, plus one open chunk per resident wave (at most 32 waves per CU)
+        const size_t wq_n = (Q / 193 + 1) * 256 + (size_t)256 * 32 * (size_t)n_cu;
+        HIP_TRY(alloc_arr(I, s.wq_a, wq_n));
+        HIP_TRY(alloc_arr(I, s.wq_b, wq_n));
         HIP_TRY(alloc_arr(I, s.wq_ctl, (size_t)(I->p.max_depth + 2) * 11 * 4));
     }
     HIP_TRY(alloc_arr(I, s.escaped_q, Q));
@@ -1237,6 +1243,7 @@ int ensure_state(hk_integrator* I, int capacity, bool media, bool open_scene) {
     HIP_TRY(alloc_arr(I, s.seg_list_n, (size_t)(I->p.max_depth + 2) * Q_COUNT));
     I->st_capacity = capacity;
     I->st_depth = I->p.max_depth;
+    I->st_media = media ? 1 : 0;
     return HK_OK;
 }
 int ceil_log2(long v) {
@@ -1344,7 +1351,7 @@ extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_
         }
         fr.delta_advance = knob("HK_DELTA_ADVANCE", 3);
         fr.refill_idle = knob("HK_TRACK_REFILL_IDLE", 24);
-        fr.walk_tune = knob("HK_SHADOW_TRACK_BATCH", 8) | (knob("HK_TRACK_ADVANCE", 2) << 8) | (knob("HK_SHADOW_FEED_ROUNDS", 3) << 16) | ((knob("HK_WALK_REFILL_IDLE", 16) & 63) << 24);
+        fr.walk_tune = knob("HK_SHADOW_TRACK_BATCH", 8) | (knob("HK_TRACK_ADVANCE", 2) << 8) | (knob("HK_SHADOW_FEED_ROUNDS", 3) << 16) | ((knob("HK_WALK_REFILL_IDLE", 16) > 63 ? 63 : knob("HK_WALK_REFILL_IDLE", 16)) << 24);
     }
     DSobol sob = make_sobol(I->p, W, H);
     {   // pixel-digit table of the sampler: depends on film size, spp exponent and max_depth only

@@ -691,7 +691,7 @@ def test_light_preselection_is_result_neutral(hk, monkeypatch):
         monkeypatch.delenv(k, raising=False)
 
 
-@pytest.mark.parametrize("which", ["cornell", "sky", "slab", "cloud"])
+@pytest.mark.parametrize("which", ["cornell", "sky", "slab", "cloud", "cloud_grid"])
 def test_scheduling_is_result_neutral(hk, monkeypatch, which):
     """How segments reach waves must not change a bit of the film: static stride vs tickets over the work lists, other segment counts
     (a count that is no multiple of anything), the shadow kernels on the second stream or not, BVH nodes from LDS or from global memory.
@@ -707,11 +707,14 @@ def test_scheduling_is_result_neutral(hk, monkeypatch, which):
     elif which == "cloud":   # a GREY NanoVDB medium (flat sigma_a / sigma_s): the specialised tracking kernels and their loop-shape knobs
         s, film, cam = scenes.cloud_scene(w, h, "nanovdb", res=(48, 48, 24))
         kw = dict(max_depth=8, samples=64)
+    elif which == "cloud_grid":   # the same field as a dense GridMedium: the pool kernels without the NanoVDB bricks
+        s, film, cam = scenes.cloud_scene(w, h, "grid", res=(48, 48, 24))
+        kw = dict(max_depth=8, samples=64)
     else:
         s, film, cam = scenes.slab_scene(w, h, hk.HomogeneousMedium(sigma_a=hk.RGBSpectrum(0.2), sigma_s=hk.RGBSpectrum(0.8, 0.7, 0.6), g=0.3))
         kw = dict(max_depth=6, samples=64)
     knobs = ("HK_OVERLAP", "HK_DYNAMIC_SEGMENTS", "HK_WAVES_PER_CU", "HK_NODE_CACHE", "HK_WALK_SPLIT", "HK_GREY", "HK_DELTA_ADVANCE", "HK_TRACK_ADVANCE",
-             "HK_SHADOW_TRACK_BATCH", "HK_SHADOW_FEED_ROUNDS", "HK_TRACK_REFILL_IDLE", "HK_WALK_REFILL_IDLE")
+             "HK_SHADOW_TRACK_BATCH", "HK_SHADOW_FEED_ROUNDS", "HK_TRACK_REFILL_IDLE", "HK_WALK_REFILL_IDLE", "HK_GREY_FLAT", "HK_TRACK_POOL", "HK_WALK_POOL")
 
     def run(env):
         for k in knobs:
@@ -732,10 +735,18 @@ def test_scheduling_is_result_neutral(hk, monkeypatch, which):
                 {"HK_DYNAMIC_SEGMENTS": "0", "HK_WAVES_PER_CU": "5", "HK_OVERLAP": "1"}, {"HK_NODE_CACHE": "0"}, {"HK_NODE_CACHE": "0", "HK_DYNAMIC_SEGMENTS": "0"}):
         got = run(env)
         assert np.array_equal(ref.view(np.uint32), got.view(np.uint32)), env
-    if which in ("slab", "cloud"):   # the shapes of the tracking loops (how many cheap steps per round, when idle lanes refill) are scheduling too
+    if which in ("slab", "cloud", "cloud_grid"):   # the shapes of the tracking loops (how many cheap steps per round, when idle lanes refill) are scheduling too
         for env in ({"HK_DELTA_ADVANCE": "1", "HK_TRACK_REFILL_IDLE": "1"}, {"HK_DELTA_ADVANCE": "9", "HK_TRACK_REFILL_IDLE": "40"},
                     {"HK_TRACK_ADVANCE": "1", "HK_SHADOW_TRACK_BATCH": "1", "HK_WALK_REFILL_IDLE": "1", "HK_SHADOW_FEED_ROUNDS": "1"},
                     {"HK_TRACK_ADVANCE": "7", "HK_SHADOW_TRACK_BATCH": "3", "HK_WALK_REFILL_IDLE": "33", "HK_SHADOW_FEED_ROUNDS": "5"}):
+            got = run(env)
+            assert np.array_equal(ref.view(np.uint32), got.view(np.uint32)), env
+    if which in ("cloud", "cloud_grid"):
+        # round 4: the tracking kernels with a per-wave ray pool in LDS (dense set-up / cast phases) against the per-lane refill kernels
+        # they replace — k_track_pool / k_track_flat / k_track<GREY>, k_walk_pool (both pool sizes) / k_shadow_walk<GREY> — and under
+        # odd segment counts (segments that end inside a phase, several segments per phase)
+        for env in ({"HK_TRACK_POOL": "0"}, {"HK_WALK_POOL": "0"}, {"HK_WALK_POOL": "2"}, {"HK_GREY_FLAT": "0"}, {"HK_TRACK_POOL": "0", "HK_WALK_POOL": "0", "HK_WAVES_PER_CU": "3"},
+                    {"HK_WAVES_PER_CU": "3"}, {"HK_WAVES_PER_CU": "29", "HK_DELTA_ADVANCE": "1", "HK_TRACK_ADVANCE": "1"}, {"HK_WALK_POOL": "2", "HK_WAVES_PER_CU": "1"}, {"HK_WAVES_PER_CU": "0"}):   # (the segment count is sticky in the context: back to the default)
             got = run(env)
             assert np.array_equal(ref.view(np.uint32), got.view(np.uint32)), env
     if which == "cloud":

@@ -188,6 +188,8 @@ def class_rooflines(config, timed, launches, sc, default_frame):
             continue
         kernel = KERNEL_OF_CLASS[cls]
         names = ["k_track", "k_scatter"] if cls == "media" else [kernel]
+        if cls == "shadow" and walk and ("k_walk" in pmc or "k_walk" in util):
+            names = ["k_walk"]      # the pooled shadow walk of a grey medium (k_walk_pool) is its own kernel family in the profiles
         tr = [pmc.get(k, {}) for k in names]
         u = util.get(names[0], {})
         bytes_rate = alg[cls] / n_launch / avg_s / 1e9
@@ -268,6 +270,7 @@ def one_frame_line(hk, scenes, torch, config, device):
         torch.cuda.synchronize()
 
     vp.enable_counters(count_nodes=True, time_kernels=False)
+    vp.reset_stats()             # (the statistics belong to the device context, which the bench line's frames have used)
     frame()
     sc = vp.stats()
     setup_s = time.perf_counter() - t_setup

@@ -1563,6 +1563,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
     const int mrx = med.mres[0], mry = med.mres[1], mrz = med.mres[2];
     const float* __restrict__ maj = med.majorant;
     const bool last_depth = depth >= fr.max_depth;
+    const int gate_min = fr.track_gate & 0xff, gate_cap = fr.delta_advance + ((fr.track_gate >> 8) & 0xff);
     SegStream stream = stream_open(st, ticket_ptr(st, depth, TK_TRACK), true, depth, Q_MEDIUM);
     int cur_tag = 0;          // up to TP_TAGS segments are open at a time (a path's tag: bits TP_TAG_SHIFT.. of its flag word): the wave goes on
                               // with the next segment while the last paths of the previous ones are still in flight
@@ -1756,9 +1757,13 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
         // ---- phase A: cheap steps (next majorant cell, free-flight sample) until the busy lanes hold a tentative collision or have
         //      run out of cells ----
 #pragma unroll 1
-        for (int adv = 0; adv < fr.delta_advance; ++adv) {
+        for (int adv = 0;; ++adv) {
             const bool need = state == TR_BUSY && (fl & (TF_PENDING | TF_SURVIVED)) == 0;
             if (__ballot(need) == 0ull) break;
+            if (adv >= fr.delta_advance) {
+                if (adv >= gate_cap) break;
+                if (__popcll(__ballot(state == TR_BUSY && (fl & TF_PENDING) != 0)) >= gate_min) break;
+            }
             HK_DBG(0, need);
             if (need) {
                 if ((fl & TF_IN_SEG) == 0) {
@@ -2999,7 +3004,7 @@ enum { WF_IN_SEG = 1, WF_PENDING = 2, WF_DONE = 4, WF_AFTER_INNER = 8, WF_IT_LIV
 #define HK_WALK_POOL_NT 32
 #endif
 template <bool COUNT, int MM, bool BRICKS, int STACK, int CAP>
-__global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TRACE_BLOCK), amdgpu_waves_per_eu(HK_WALK_POOL_WAVES))) k_walk_pool(DPathState st, DScene sc, int depth, int tune, DStats* stats, const DMedium* __restrict__ media) {
+__global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TRACE_BLOCK), amdgpu_waves_per_eu(HK_WALK_POOL_WAVES))) k_walk_pool(DPathState st, DScene sc, int depth, int tune, int gate, DStats* stats, const DMedium* __restrict__ media) {
     constexpr int WAVE_INTS = WP_FIELDS * CAP + STACK * 64;
     __shared__ int lds_all[(HK_TRACE_BLOCK / 64) * WAVE_INTS];
     int* const pool = lds_all + (threadIdx.x >> 6) * WAVE_INTS;   // [field][CAP]
@@ -3020,6 +3025,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
     const int mrx = med.mres[0], mry = med.mres[1], mrz = med.mres[2];
     const float* __restrict__ maj = med.majorant;
     const int adv_n = (tune >> 8) & 0xff;
+    const int gate_min = gate & 0xff, gate_cap = adv_n + ((gate >> 8) & 0xff);   // a collision round waits for gate_min pending lanes, for at most gate_cap cheap steps
     SegStream stream = stream_open(st, ticket_ptr(st, depth, TK_SHADOW), true, depth, Q_SHADOW);
     uint32_t rec0 = 0;   // current segment's shadow records: entries rec0 .. rec0 + n - 1 (the wave streams segment after segment)
     int n = 0, cursor = 0;
@@ -3255,9 +3261,13 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
         if (__ballot(state == SH_TRACK) == 0ull) continue;   // (the cast phase above ends the kernel when nothing is left)
         // ---- phase A: cheap steps (next majorant cell, free-flight sample) ----
 #pragma unroll 1
-        for (int adv = 0; adv < adv_n; ++adv) {
+        for (int adv = 0;; ++adv) {
             const bool need = state == SH_TRACK && (fl & (WF_PENDING | WF_DONE)) == 0;
             if (__ballot(need) == 0ull) break;
+            if (adv >= adv_n) {
+                if (adv >= gate_cap) break;
+                if (__popcll(__ballot(state == SH_TRACK && (fl & WF_PENDING) != 0)) >= gate_min) break;
+            }
             HK_DBG(10, need);
             if (need) {
                 if ((fl & WF_IN_SEG) == 0) {
@@ -4413,13 +4423,13 @@ void launch_shadow(hipStream_t s, int n_cu, const DPathState& st, const DScene& 
         constexpr int M2 = (MM == 2 || MM == 8) ? MM : 8;                                                                              \
         if (M2 == 8 && sc.grey_bricks && sc.bvh_depth <= 8 && walk_pool_mode() == 1) {                                                 \
             const int blocks = cached_blocks<k_walk_pool<C, 8, true, 8, 64>>(HK_TRACE_BLOCK, n_cu, 8);                                 \
-            hipLaunchKernelGGL((k_walk_pool<C, 8, true, 8, 64>), dim3(clamp_blocks(blocks, st)), dim3(HK_TRACE_BLOCK), 0, s, st, sc, depth, fr.walk_tune, stats, sc.media); \
+            hipLaunchKernelGGL((k_walk_pool<C, 8, true, 8, 64>), dim3(clamp_blocks(blocks, st)), dim3(HK_TRACE_BLOCK), 0, s, st, sc, depth, fr.walk_tune, fr.track_gate, stats, sc.media); \
         } else if (M2 == 8 && sc.grey_bricks) {                                                                                        \
             const int blocks = cached_blocks<k_walk_pool<C, 8, true, 16, 56>>(HK_TRACE_BLOCK, n_cu, 8);                                \
-            hipLaunchKernelGGL((k_walk_pool<C, 8, true, 16, 56>), dim3(clamp_blocks(blocks, st)), dim3(HK_TRACE_BLOCK), 0, s, st, sc, depth, fr.walk_tune, stats, sc.media); \
+            hipLaunchKernelGGL((k_walk_pool<C, 8, true, 16, 56>), dim3(clamp_blocks(blocks, st)), dim3(HK_TRACE_BLOCK), 0, s, st, sc, depth, fr.walk_tune, fr.track_gate, stats, sc.media); \
         } else {                                                                                                                       \
             const int blocks = cached_blocks<k_walk_pool<C, M2, false, 16, 56>>(HK_TRACE_BLOCK, n_cu, 8);                              \
-            hipLaunchKernelGGL((k_walk_pool<C, M2, false, 16, 56>), dim3(clamp_blocks(blocks, st)), dim3(HK_TRACE_BLOCK), 0, s, st, sc, depth, fr.walk_tune, stats, sc.media); \
+            hipLaunchKernelGGL((k_walk_pool<C, M2, false, 16, 56>), dim3(clamp_blocks(blocks, st)), dim3(HK_TRACE_BLOCK), 0, s, st, sc, depth, fr.walk_tune, fr.track_gate, stats, sc.media); \
         }                                                                                                                              \
     } else if (sc.bvh_depth <= 16 && (MM == 2 || MM == 8) && sc.all_grey && grey_mode()) {                                           \
         constexpr int M2 = (MM == 2 || MM == 8) ? MM : 8;                                                                              \

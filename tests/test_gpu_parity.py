@@ -6,6 +6,8 @@ import ctypes as C
 import numpy as np
 import pytest
 
+import ulp_bounds
+
 pytestmark = pytest.mark.gpu
 
 
@@ -84,6 +86,10 @@ def test_camera_stage(hk, oracle, gpu_ctx):
     # float64 evaluation of the same formulas they must stay within 2.5e-4 nm (four float spacings at 540 nm) and 4e-6 relative
     print("camera stage: max |d lambda| = %.3g nm, max rel d pdf = %.3g (GPU vs oracle/glibc)" % (
         np.abs(out[:, :4] - ref[:, :4]).max(), (np.abs(out[:, 4:8] - ref[:, 4:8]) / np.maximum(ref[:, 4:8], 1e-12)).max()))
+    ulp_bounds.check("camera/lambda", out[:, :4], ref[:, :4], floor=1.0)
+    ulp_bounds.check("camera/lambda_pdf", out[:, 4:8], ref[:, 4:8], floor=1e-6)
+    ulp_bounds.check("camera/filter_weight", out[:, 8], ref[:, 8], floor=1e-6)
+    ulp_bounds.check("camera/ray_direction", out[:, 12:15], ref[:, 12:15], floor=1e-3)
     assert np.allclose(out[:, :4], ref[:, :4], rtol=0, atol=2.5e-4)          # lambda [nm]
     assert np.allclose(out[:, 4:8], ref[:, 4:8], rtol=4e-6, atol=1e-9)       # pdf (follows the 2-spacing difference in lambda)
     assert ulp_diff(out[:, 8], ref[:, 8]).max() <= 2                          # filter weight
@@ -175,6 +181,9 @@ def test_light_bvh_parity(hk, oracle, gpu_ctx):
     assert same.mean() > 0.999                                                # a 1-ulp node difference may flip a knife-edge choice
     assert np.allclose(gpmf[same], rpmf[same], rtol=2e-5, atol=0)
     assert np.allclose(gq, rq, rtol=2e-5, atol=1e-12)
+    # achieved accuracy against its recorded bound (the pmf is a product of up to ~8 importance ratios, each a quotient of sums)
+    ulp_bounds.check("light_bvh/pmf_of_choice", gpmf[same], rpmf[same], floor=1e-12)
+    ulp_bounds.check("light_bvh/pmf_of_query", gq, rq, floor=1e-12)
     assert len(set(gl.tolist())) > 20
 
 

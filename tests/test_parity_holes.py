@@ -17,6 +17,8 @@ import ctypes as C
 import numpy as np
 import pytest
 
+import ulp_bounds
+
 pytestmark = pytest.mark.gpu
 f32 = np.float32
 
@@ -89,6 +91,8 @@ def test_simple_bsdf_pointwise_parity(hk, oracle, gpu_ctx, name):
             assert close.mean() >= 0.9995, (name, mode, reg, close.mean())
             if name in ("matte", "matte_sigma", "mirror"):          # no transcendental beyond sin/cos of the disk map
                 assert close.all() and ulp_diff(out[:, 3:8], ref[:, 3:8]).max() <= 4
+            # what is achieved on the rows where both sides took the same lobe, against its recorded bound (tests/ulp_bounds.py)
+            ulp_bounds.check("bsdf_simple/%s/mode%d/reg%d" % (name, mode, int(reg)), out, ref, floor=1e-3, rows=close)
     osc.close()
 
 

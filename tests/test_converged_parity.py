@@ -18,36 +18,61 @@ pytestmark = pytest.mark.gpu
 N_ORACLE, N_GPU, BATCHES = 4096, 16384, 16
 
 
-def converged_pair(hk, oracle, s, cam, w, h, **kw):
-    kw = dict(kw, samples=N_ORACLE + N_GPU)          # one ZSobol index width for both sides
+_ORACLE_FRAMES = {}     # the oracle's batches of a scene are rendered once per session (cases that differ only in a device switch share them)
+
+
+def oracle_batches(hk, oracle, s, cam, w, h, kw, n_oracle=N_ORACLE, batches=BATCHES, key=None):
+    if key is not None and key in _ORACLE_FRAMES:
+        return _ORACLE_FRAMES[key]
     p = hk.integrator_params(**kw)
     osc = oracle.OracleScene(s)
-    per = N_ORACLE // BATCHES
-    frames = np.stack([oracle.finalize(osc.render(p, cam, w, h, per, first=1 + b * per)[0], w, h) for b in range(BATCHES)])
+    per = n_oracle // batches
+    frames = np.stack([oracle.finalize(osc.render(p, cam, w, h, per, first=1 + b * per)[0], w, h) for b in range(batches)])
     osc.close()
+    if key is not None:
+        _ORACLE_FRAMES[key] = frames
+    return frames
+
+
+def converged_pair(hk, oracle, s, cam, w, h, n_oracle=N_ORACLE, n_gpu=N_GPU, batches=BATCHES, key=None, **kw):
+    kw = dict(kw, samples=n_oracle + n_gpu)          # one ZSobol index width for both sides
+    frames = oracle_batches(hk, oracle, s, cam, w, h, kw, n_oracle, batches, key)
     film = hk.Film((w, h))
     vp = hk.VolPath(**kw)
     vp._ensure(film)
     vp.clear()
-    vp.render_samples(s, film, cam, N_GPU, first=N_ORACLE + 1)
+    vp.render_samples(s, film, cam, n_gpu, first=n_oracle + 1)
     G = film.framebuffer.copy()
     vp.close()
     return frames, G
 
 
-def check_converged(name, frames, G):
+def check_converged(name, frames, G, n_oracle=N_ORACLE, n_gpu=N_GPU, mean_tol=0.005, robust=False):
     assert np.isfinite(G).all() and (G >= 0).all()
+    batches = frames.shape[0]
     A = frames.mean(axis=0)
-    seA = frames.std(axis=0, ddof=1) / np.sqrt(BATCHES)
-    widen = 1.0 + N_ORACLE / N_GPU
+    seA = frames.std(axis=0, ddof=1) / np.sqrt(batches)
+    widen = 1.0 + n_oracle / n_gpu
     for c in range(3):
         bm = frames[..., c].mean(axis=(1, 2))                       # channel mean per batch
-        se_mean = bm.std(ddof=1) / np.sqrt(BATCHES) * np.sqrt(widen)
+        se_mean = bm.std(ddof=1) / np.sqrt(batches) * np.sqrt(widen)
         a, g = A[..., c].mean(), G[..., c].mean()
-        assert abs(g - a) <= 0.005 * a + 4.0 * se_mean + 1e-6, (name, c, g, a, se_mean)
+        assert abs(g - a) <= mean_tol * a + 4.0 * se_mean + 1e-6, (name, c, g, a, se_mean)
     z = (G - A) / np.sqrt(seA ** 2 * widen + (1e-4 * (A + 1e-3)) ** 2)
-    assert float(np.mean(z ** 2)) <= 1.8, (name, float(np.mean(z ** 2)))
-    assert float(np.mean(np.abs(z) > 6.0)) <= 0.005, (name, float(np.mean(np.abs(z) > 6.0)))
+    # the variance estimate from B batches is itself noisy: E z^2 = (B - 1) / (B - 3) (15/13 at 16 batches, 7/5 at 8); bound = 1.56 x that
+    if robust:
+        # random scenes (point / spot lights through glass and mirrors): a pixel's batches may all miss a rare bright path that the other
+        # side's four-times-larger sample catches — the MEAN of z^2 is then one firefly.  The median of z^2 (0.51 for 8 batches, t_7^2)
+        # does not see fireflies and still moves to ~1.3 when every pixel is shifted by one standard error; tails: |z| > 6 on <= 6 %
+        # (measured: up to 4.7 % in sun-lit media scenes behind glass, where the median and the channel means hold)
+        lit = A.sum(axis=2) > 0
+        if lit.sum() >= 16:
+            assert float(np.median((z ** 2)[lit])) <= 1.0, (name, float(np.median((z ** 2)[lit])))
+            assert float(np.mean(np.abs(z[lit]) > 6.0)) <= 0.06, (name, float(np.mean(np.abs(z[lit]) > 6.0)))
+        return
+    z2_bound = 1.56 * (batches - 1.0) / (batches - 3.0)
+    assert float(np.mean(z ** 2)) <= z2_bound, (name, float(np.mean(z ** 2)), z2_bound)
+    assert float(np.mean(np.abs(z) > 6.0)) <= 0.005 * 16.0 / batches, (name, float(np.mean(np.abs(z) > 6.0)))
 
 
 MEDIA = [("integration", 4), ("slab_homogeneous", 6), ("slab_grid", 6), ("slab_rgbgrid", 6), ("textured", 5), ("cloud_nanovdb", 12), ("cloud_grid", 12)]
@@ -60,7 +85,7 @@ def test_media_converged_parity(hk, oracle, name, depth):
     from test_gpu_parity import _scene
     w = h = 24
     s, _, cam = _scene(name, w, h)
-    frames, G = converged_pair(hk, oracle, s, cam, w, h, max_depth=depth)
+    frames, G = converged_pair(hk, oracle, s, cam, w, h, key=name if name.startswith("cloud") else None, max_depth=depth)
     check_converged(name, frames, G)
 
 
@@ -77,10 +102,32 @@ def test_layered_converged_parity(hk, oracle, name):
     check_converged(name, frames, G)
 
 
-def test_bomex_crop_converged_parity(hk, oracle):
-    """The bench's own cloud (scenes.bomex_scene: 5 % fill, extinction 620, 64^3 majorant, g = 0.877, depth 32) on a 24 x 24 film."""
+GREY_SWITCHES = [{}, {"HK_GREY": "0"}, {"HK_TRACK_POOL": "0", "HK_WALK_POOL": "0"}]
+
+
+@pytest.mark.parametrize("env", GREY_SWITCHES, ids=["pool", "general", "grey_flat"])
+def test_bomex_crop_converged_parity(hk, oracle, monkeypatch, env):
+    """The bench's own cloud (scenes.bomex_scene: 5 % fill, extinction 620, 64^3 majorant, g = 0.877, depth 32) on a 24 x 24 film, through
+    the kernels the bench runs (k_track_pool / k_walk_pool), through the GENERAL tracking kernels (HK_GREY=0: they perform the
+    (1 +- 3 ulp) ratio multiplications of the oracle that the GREY kernels drop) and through the per-lane-refill GREY kernels."""
     from hikari_jl_amd import scenes
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     w = h = 24
     s, _, cam = scenes.bomex_scene(w, h)
-    frames, G = converged_pair(hk, oracle, s, cam, w, h, max_depth=32)
-    check_converged("bomex", frames, G)
+    frames, G = converged_pair(hk, oracle, s, cam, w, h, key="bomex", max_depth=32)
+    check_converged("bomex %s" % env, frames, G)
+
+
+@pytest.mark.parametrize("name", ["cloud_nanovdb", "cloud_grid"])
+@pytest.mark.parametrize("env", GREY_SWITCHES[1:], ids=["general", "grey_flat"])
+def test_grey_media_through_the_general_kernels(hk, oracle, monkeypatch, name, env):
+    """test_media_converged_parity's two GREY clouds (NanoVDB, dense grid) with the GREY specialisation switched off / the pool kernels
+    switched off: every tracking kernel family that can render a flat-spectrum medium is held to the same converged bar."""
+    from test_gpu_parity import _scene
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    w = h = 24
+    s, _, cam = _scene(name, w, h)
+    frames, G = converged_pair(hk, oracle, s, cam, w, h, key=name, max_depth=12)
+    check_converged("%s %s" % (name, env), frames, G)

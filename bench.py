@@ -33,6 +33,8 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+PROGRESSIVE_CALLS = 64         # --progressive
+READBACK_PASS = True
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 COMM_TIMEOUT_S = 180.0         # the collective communicator bring-up may not hang the run
 
@@ -53,10 +55,16 @@ def parse_args(argv=None):
                          "--no-extra-configs leaves them out).  cornell = BASELINE configs[1] (the bench line); sky = configs[2] (glass sphere + gold slab + Hosek-Wilkie sun-sky, depth 12); "
                          "cloud = configs[3] (BOMEX stand-in: worley-fbm NanoVDB cloud field, 1024x1024, depth 32); manylight = configs[4] stand-in "
                          "(10^6 triangles, 5*10^4 area lights, 1024x1024, depth 8, 512 spp)")
+    ap.add_argument("--progressive", type=int, default=64, help="calls of the ONE-SAMPLE-PER-CALL path (render!: hk_render(first = i, n = 1), what an interactive "
+                                                                 "viewer drives) measured after the timed region and reported as `progressive` (0 = skip)")
+    ap.add_argument("--no-readback-pass", action="store_true", help="--progressive without the second pass that reads the frame back after every call (kernel traces)")
     ap.add_argument("--no-extra-configs", action="store_true", help="the default run without the one-frame lines of cloud / sky / manylight")
     args = ap.parse_args(argv)
     args.extra_configs = args.config is None and not args.no_extra_configs and args.gpus == 1 and not args.spp and not args.spp_per_pass
     args.config = args.config or "cornell"
+    global PROGRESSIVE_CALLS, READBACK_PASS
+    PROGRESSIVE_CALLS = max(args.progressive, 0)
+    READBACK_PASS = not args.no_readback_pass
     return args
 
 
@@ -252,6 +260,39 @@ def class_rooflines(config, timed, launches, sc, default_frame):
     return rooflines
 
 
+def progressive_line(vp, scene, film, cam, calls, frame_spp, seconds_per_frame, torch):
+    """The reference's interactive path: render!(vp, scene, film, camera) = ONE sample of every pixel per call (volpath.jl:445-450, 471-474),
+    here hk_render(first = i, n = 1) for i = 1 .. calls on a cleared film, (a) back to back and (b) each followed by hk_film_read_rgb (the
+    frame an interactive viewer shows: finalize kernel + the device-to-host copy of the RGB frame).  `vs_frame_sample` = time per call over
+    the time per sample of the config's full frame (the 256-spp pass has ~100 paths per resident lane in flight, a 1-spp call has < 1)."""
+    submit = [0.0]
+
+    def run(readback):
+        vp.clear()
+        film.iteration_index = 0
+        vp.reset_stats()
+        vp.sync()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(calls):
+            vp.render_samples(scene, film, cam, 1, first=i + 1, readback=readback)
+        submit[0] = time.perf_counter() - t0
+        vp.sync()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        st = vp.stats()
+        return dt, int(st.rays_closest) + int(st.rays_shadow)
+
+    run(False)                       # untimed: the one-sample pass's path state / tables
+    dt, rays = run(False)
+    host_ms = submit[0] / calls * 1e3
+    dt_rb = run(True)[0] if READBACK_PASS else float("nan")
+    per_sample = seconds_per_frame / max(frame_spp, 1)
+    return {"calls": calls, "ms_per_call": round(dt / calls * 1e3, 4), "value": round(rays / dt / 1e6, 2), "unit": "Mrays/s",
+            "host_ms_per_call": round(host_ms, 4), "ms_per_call_with_readback": round(dt_rb / calls * 1e3, 4), "ms_per_sample_of_the_full_frame": round(per_sample * 1e3, 4),
+            "vs_frame_sample": round(dt / calls / per_sample, 3)}
+
+
 def one_frame_line(hk, scenes, torch, config, device):
     """ONE warm frame of another BASELINE.json config on this GPU, after the bench line's timed region: wall-clock seconds per frame,
     Mrays/s and the per-class rooflines (same definitions as the bench line).  Three frames are rendered: a first one that uploads the
@@ -295,6 +336,8 @@ def one_frame_line(hk, scenes, torch, config, device):
             "rays": {"closest": int(st.rays_closest), "shadow": int(st.rays_shadow), "medium_collisions": int(st.medium_collisions)},
             "kernel_seconds": {k: round(v, 4) for k, v in timed.items()}, "setup_seconds": round(setup_s, 2),
             "roofline": next(e for e in rooflines if e["kernel"] == KERNEL_OF_CLASS[dom]), "rooflines": rooflines}
+    if PROGRESSIVE_CALLS > 0:
+        line["progressive"] = progressive_line(vp, scene, film, cam, min(PROGRESSIVE_CALLS, 32), spp, seconds, torch)
     vp.close()
     del accum
     torch.cuda.empty_cache()
@@ -555,6 +598,8 @@ def main():
             "setup_seconds": round(setup_s, 3),
             "roofline": roofline, "rooflines": rooflines, "cpu_baseline": cpu,
         }
+        if world == 1 and args.progressive > 0 and not args.spp_per_pass:
+            result["progressive"] = progressive_line(vp, scene, film, cam, args.progressive, frame_spp, per_frame, torch)
     if comm is not None:
         comm.close()
     if world > 1:

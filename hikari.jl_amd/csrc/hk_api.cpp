@@ -119,7 +119,36 @@ struct hk_ctx {
     double seconds_trace = 0.0, seconds_total = 0.0;
     uint64_t trace_launches = 0;
     DStats host_stats{};
+    // PIPELINED SMALL PASSES.  A one-sample call (the reference's render!, volpath.jl:445-450: what an interactive viewer drives) puts
+    // < 1 path per resident lane in flight: its ~45 launches are each bound by the latency of ONE wave's chunk (50 - 90 us at any
+    // path count, profiles/r04_progressive_timeline.txt), the chip idles.  Such calls are independent of each other (another sample
+    // index of the same scene), so consecutive small calls go to HK_PIPELINE (default 4) LANES in turn — a stream, a path-state set
+    // and a statistics block each — and run beside each other; only the film kernels are chained (sums in call order: the film stays
+    // bit-identical to the sequential one).  Whatever reads or rewrites film / state / scene on the context's stream joins the
+    // lanes first (join_lanes).
+    struct Lane {
+        hipStream_t stream = nullptr;
+        hipEvent_t done = nullptr;
+        DevBuf stats;
+    };
+    enum { MAX_LANES = 16 };
+    Lane lanes[MAX_LANES];        // (created on first use)
+    int next_lane = 0;
+    bool lanes_dirty = false;     // a lane holds work the context's stream has not waited for
+    bool film_chain = false;      // ev_film marks the last film kernel of a lane
+    hipEvent_t ev_main = nullptr, ev_film = nullptr;
 };
+
+// the context's stream waits for everything the lanes were given (cheap when nothing is pending)
+static int join_lanes(hk_ctx* c) {
+    if (!c || !c->lanes_dirty) return HK_OK;
+    for (auto& l : c->lanes)
+        if (l.done) HIP_TRY(hipStreamWaitEvent(c->stream, l.done, 0));
+    c->lanes_dirty = false;
+    c->film_chain = false;
+    if (c->have_span) HIP_TRY(hipEventRecord(c->ev_end, c->stream));
+    return HK_OK;
+}
 
 struct hk_scene {
     hk_ctx* ctx = nullptr;
@@ -165,8 +194,24 @@ struct hk_integrator {
     int sobol_rows = 0, sobol_stride = 0, sobol_log2 = -1, sobol_digits = -1, sobol_x0 = -1, sobol_y0 = -1, sobol_tiles_x = -1;
     DevBuf sobol_lo;     // DSobol::lo_table
     int lo_rows = 0, lo_base = -1, lo_sample_stride = -1, lo_count = 0;
+    // the path-state sets of the context's lanes (pipelined small passes); a render on lane l swaps set l in for the duration of the call
+    struct StateSet {
+        DPathState st{};
+        std::vector<DevBuf*> bufs;
+        int st_capacity = 0, st_depth = 0, st_media = -1;
+    };
+    std::vector<StateSet> lane_sets;
+    void swap_set(StateSet& o) {
+        std::swap(st, o.st);
+        std::swap(bufs, o.bufs);
+        std::swap(st_capacity, o.st_capacity);
+        std::swap(st_depth, o.st_depth);
+        std::swap(st_media, o.st_media);
+    }
     ~hk_integrator() {
         for (auto* b : bufs) delete b;
+        for (auto& ls : lane_sets)
+            for (auto* b : ls.bufs) delete b;
     }
 };
 
@@ -203,7 +248,15 @@ extern "C" int32_t hk_ctx_create(int32_t device_id, void* stream, hk_ctx** out) 
 extern "C" int32_t hk_ctx_destroy(hk_ctx* c) {
     if (!c) return HK_OK;
     (void)hipSetDevice(c->device);
+    (void)join_lanes(c);
     (void)hipStreamSynchronize(c->stream);
+    for (auto& l : c->lanes) {
+        if (l.stream) (void)hipStreamSynchronize(l.stream);
+        if (l.done) (void)hipEventDestroy(l.done);
+        if (l.stream) (void)hipStreamDestroy(l.stream);
+    }
+    if (c->ev_main) (void)hipEventDestroy(c->ev_main);
+    if (c->ev_film) (void)hipEventDestroy(c->ev_film);
     for (auto& e : c->trace_events) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
@@ -884,6 +937,7 @@ extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene**
 extern "C" int32_t hk_scene_destroy(hk_scene* s) {
     if (s) {
         (void)hipSetDevice(s->ctx->device);
+        (void)join_lanes(s->ctx);
         (void)hipStreamSynchronize(s->ctx->stream);
         delete s;
     }
@@ -1025,6 +1079,7 @@ extern "C" int32_t hk_integrator_create(hk_ctx* c, const hk_integrator_params* p
 extern "C" int32_t hk_integrator_destroy(hk_integrator* I) {
     if (I) {
         (void)hipSetDevice(I->ctx->device);
+        (void)join_lanes(I->ctx);
         (void)hipStreamSynchronize(I->ctx->stream);
         delete I;
     }
@@ -1054,6 +1109,7 @@ extern "C" int32_t hk_film_create(hk_ctx* c, int32_t w, int32_t h, int32_t f64, 
 extern "C" int32_t hk_film_destroy(hk_film* f) {
     if (f) {
         (void)hipSetDevice(f->ctx->device);
+        (void)join_lanes(f->ctx);
         (void)hipStreamSynchronize(f->ctx->stream);
         delete f;
     }
@@ -1062,6 +1118,7 @@ extern "C" int32_t hk_film_destroy(hk_film* f) {
 extern "C" int32_t hk_film_clear(hk_film* f) {
     if (!f) return fail(HK_ERR_INVALID, "null film");
     HIP_TRY(hipSetDevice(f->ctx->device));
+    if (int e = join_lanes(f->ctx)) return e;
     HIP_TRY(hipMemsetAsync(f->accum, 0, (size_t)4 * f->width * f->height * (f->f64 ? 8 : 4), f->ctx->stream));
     return HK_OK;
 }
@@ -1069,6 +1126,7 @@ extern "C" void* hk_film_accum_device_ptr(hk_film* f) { return f ? f->accum : nu
 extern "C" int32_t hk_film_read_accum(hk_ctx* c, hk_film* f, void* out) {
     if (!c || !f || !out) return fail(HK_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
+    if (int e = join_lanes(c)) return e;
     HIP_TRY(hipMemcpyAsync(out, f->accum, (size_t)4 * f->width * f->height * (f->f64 ? 8 : 4), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return HK_OK;
@@ -1077,6 +1135,7 @@ extern "C" int32_t hk_film_read_rgb(hk_ctx* c, hk_film* f, float* out) {
     if (!c || !f || !out) return fail(HK_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
     size_t bytes = (size_t)3 * f->width * f->height * 4;
+    if (int e = join_lanes(c)) return e;
     if (f->readback.bytes != bytes) HIP_TRY(f->readback.alloc(bytes));
     hk::launch_finalize(c->stream, f->accum, f->f64, f->readback.as<float>(), f->width, f->height);
     HIP_TRY(hipGetLastError());
@@ -1103,6 +1162,7 @@ extern "C" int32_t hk_film_postprocess(hk_ctx* c, hk_film* f, const hk_postproce
     if (P->tonemap < HK_TONEMAP_NONE || P->tonemap > HK_TONEMAP_FILMIC) return fail(HK_ERR_INVALID, "unknown tonemap");
     HIP_TRY(hipSetDevice(c->device));
     size_t bytes = (size_t)3 * f->width * f->height * 4;
+    if (int e = join_lanes(c)) return e;
     if (f->readback.bytes != bytes) HIP_TRY(f->readback.alloc(bytes));
     hk::launch_finalize(c->stream, f->accum, f->f64, f->readback.as<float>(), f->width, f->height);
     DevBuf out;
@@ -1161,7 +1221,7 @@ hipError_t alloc_arr(hk_integrator* I, T*& dst, size_t n) {
 //   surfaces, open scene      static stride, 48 per CU   (sky: most paths escape after 1-2 vertices; finer segments only fragment
 //                             the per-kind queues: k_shade +7 % at 96, +15 % at 256, whichever way they are handed out)
 // HK_WAVES_PER_CU / HK_DYNAMIC_SEGMENTS override.  stats rows are indexed by PHYSICAL wave (ctx->stat_rows).
-int ensure_state(hk_integrator* I, int capacity, bool media, bool open_scene) {
+int ensure_state(hk_integrator* I, int capacity, bool media, bool open_scene, hipStream_t users = nullptr) {
     const int n_cu = I->ctx->n_cu;
     const long cap_per_cu = media ? 96 : (open_scene ? 48 : 192);
     long W_want = ((long)(capacity + 63) / 64) / 16;
@@ -1178,6 +1238,7 @@ int ensure_state(hk_integrator* I, int capacity, bool media, bool open_scene) {
     // the retained state must be of the same flavour: a state allocated for a scene with media has no sel_light (k_light_select would
     // silently not run in a later scene without media), one allocated without HK_WALK_SPLIT has no hand-over queues
     if (I->st_capacity >= capacity && I->st_depth >= I->p.max_depth && I->st.n_waves == (int)W_want && I->st_media == (media ? 1 : 0) && (!want_split || I->st.wq_a != nullptr)) return HK_OK;
+    if (users) HIP_TRY(hipStreamSynchronize(users));   // (a lane's set: its last call may still be running)
     for (auto* b : I->bufs) delete b;
     I->bufs.clear();
     DPathState& s = I->st;
@@ -1329,7 +1390,43 @@ extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_
     }
     if (S > n_samples) S = n_samples;
     if ((long)S * fr.n_pixels_padded > 0x3fffffffL) return fail(HK_ERR_INVALID, "pass too large");
-    int st = ensure_state(I, S * fr.n_pixels_padded, sc->d.n_media > 0, sc->d.has_escape_lights != 0);
+    // a small one-pass call goes to the next LANE (hk_ctx::Lane): it runs beside the small calls before and after it
+    int lane_idx = -1;
+    {
+        int n_lanes = 4;
+        long max_paths = 8L << 20;
+        if (const char* e = std::getenv("HK_PIPELINE")) n_lanes = std::atoi(e) >= 1 && std::atoi(e) <= 16 ? std::atoi(e) : n_lanes;
+        if (const char* e = std::getenv("HK_PIPELINE_MAX_PATHS_M")) max_paths = std::atol(e) > 0 ? std::atol(e) << 20 : max_paths;
+        if (n_lanes > 1 && !c->time_kernels && n_samples <= S && (long)S * fr.n_pixels_padded <= max_paths) {
+            if ((int)I->lane_sets.size() < (int)hk_ctx::MAX_LANES) I->lane_sets.resize(hk_ctx::MAX_LANES);
+            lane_idx = c->next_lane % n_lanes;
+            c->next_lane = (lane_idx + 1) % n_lanes;
+            hk_ctx::Lane& L = c->lanes[lane_idx];
+            if (!L.stream) {
+                HIP_TRY(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
+                std::vector<DStats> zero((size_t)c->stat_rows);
+                std::memset(zero.data(), 0, zero.size() * sizeof(DStats));
+                HIP_TRY(L.stats.upload(zero.data(), zero.size() * sizeof(DStats)));
+            }
+            if (!c->ev_main) {
+                HIP_TRY(hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&c->ev_film, hipEventDisableTiming));
+            }
+        } else if (int e = join_lanes(c))
+            return e;
+    }
+    const bool piped = lane_idx >= 0;
+    // the lane's path-state set stands in for the integrator's own for the duration of this call
+    struct SetGuard {
+        hk_integrator* I;
+        hk_integrator::StateSet* ls;
+        ~SetGuard() {
+            if (ls) I->swap_set(*ls);
+        }
+    } set_guard{I, piped ? &I->lane_sets[lane_idx] : nullptr};
+    if (piped) I->swap_set(I->lane_sets[lane_idx]);
+    int st = ensure_state(I, S * fr.n_pixels_padded, sc->d.n_media > 0, sc->d.has_escape_lights != 0, piped ? c->lanes[lane_idx].stream : nullptr);
     if (st != HK_OK) return st;
     fr.sample_stride = sample_stride;
     fr.max_depth = I->p.max_depth;
@@ -1359,6 +1456,10 @@ extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_
         const bool table_same = !(I->sobol_rows != rows || I->sobol_stride != fr.n_pixels_padded || I->sobol_log2 != sob.log2_spp || I->sobol_digits != sob.n_base4_digits ||
                                   I->sobol_x0 != x0 || I->sobol_y0 != y0 || I->sobol_tiles_x != fr.tiles_x);
         if (!table_same) {
+            if (c->lanes_dirty) {   // lanes may still read the table that is about to be replaced
+                if (int e = join_lanes(c)) return e;
+                HIP_TRY(hipStreamSynchronize(c->stream));
+            }
             HIP_TRY(I->sobol_table.alloc((size_t)rows * fr.n_pixels_padded * sizeof(uint2)));
             hk::launch_sobol_table(c->stream, sob, fr, I->sobol_table.as<uint2>(), rows);
             HIP_TRY(hipGetLastError());
@@ -1421,6 +1522,12 @@ extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_
     DStats* dstats = c->stats.as<DStats>();
     const int trace_blocks = c->n_cu, shade_blocks = c->n_cu, light_blocks = c->n_cu;  // launchers size the grid from residency
     hipStream_t s = c->stream;
+    if (piped) {   // behind everything the context's stream holds so far (scene upload, film clear, sampler tables), beside the other lanes
+        HIP_TRY(hipEventRecord(c->ev_main, c->stream));
+        s = c->lanes[lane_idx].stream;
+        HIP_TRY(hipStreamWaitEvent(s, c->ev_main, 0));
+        dstats = c->lanes[lane_idx].stats.as<DStats>();
+    }
     if (!c->have_span) {
         HIP_TRY(hipEventRecord(c->ev_begin, s));
         c->have_span = true;
@@ -1488,7 +1595,7 @@ extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_
         // stream so that the class times add up.
         // (surfaces only: beside the long shadow walks of a media scene the next traversal only competes — cloud -4.5 %; Cornell +-0, sky +1 %, many-light +2.4 %)
         if (const char* e = std::getenv("HK_OVERLAP")) c->overlap = std::atoi(e) ? 1 : 0;
-        const bool overlap = c->overlap && !c->time_kernels && sc->d.n_lights > 0 && sc->d.n_media == 0;
+        const bool overlap = c->overlap && !c->time_kernels && sc->d.n_lights > 0 && sc->d.n_media == 0 && !piped;
         if (overlap && !c->aux) {
             HIP_TRY(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
             HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -1550,11 +1657,20 @@ extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_
             HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
             shadows_in_flight = false;
         }
+        if (piped && c->film_chain) HIP_TRY(hipStreamWaitEvent(s, c->ev_film, 0));   // the film sums in call order
         if (timed(3, [&] { hk::launch_film(s, I->st, fr, c->tables, film->accum, film->f64); }) != HK_OK) return fail(HK_ERR_DEVICE, "event record failed");
+        if (piped) {
+            HIP_TRY(hipEventRecord(c->ev_film, s));
+            c->film_chain = true;
+        }
         done += k;
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(c->ev_end, s));
+    if (piped) {
+        HIP_TRY(hipEventRecord(c->lanes[lane_idx].done, s));
+        c->lanes_dirty = true;
+    } else
+        HIP_TRY(hipEventRecord(c->ev_end, s));
     return HK_OK;
 }
 
@@ -1578,6 +1694,7 @@ extern "C" int32_t hk_film_fill_aux(hk_ctx* c, hk_scene* sc, const hk_camera* ca
 extern "C" int32_t hk_sync(hk_ctx* c) {
     if (!c) return fail(HK_ERR_INVALID, "null ctx");
     HIP_TRY(hipSetDevice(c->device));
+    if (int e = join_lanes(c)) return e;
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->aux) HIP_TRY(hipStreamSynchronize(c->aux));   // a render that failed half-way may have left a shadow kernel on the second stream
     return HK_OK;
@@ -1591,8 +1708,11 @@ extern "C" int32_t hk_stats_enable_counters(hk_ctx* c, int32_t flags) {
 extern "C" int32_t hk_stats_reset(hk_ctx* c) {
     if (!c) return fail(HK_ERR_INVALID, "null ctx");
     HIP_TRY(hipSetDevice(c->device));
+    if (int e = join_lanes(c)) return e;
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemset(c->stats.p, 0, (size_t)c->stat_rows * sizeof(DStats)));
+    for (auto& l : c->lanes)
+        if (l.stats.p) HIP_TRY(hipMemset(l.stats.p, 0, (size_t)c->stat_rows * sizeof(DStats)));
     for (auto& e : c->trace_events) {
         c->event_pool.push_back(e.first);
         c->event_pool.push_back(e.second);
@@ -1614,11 +1734,18 @@ extern "C" int32_t hk_stats_reset(hk_ctx* c) {
 extern "C" int32_t hk_stats_get(hk_ctx* c, hk_stats* out) {
     if (!c || !out) return fail(HK_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
+    if (int e = join_lanes(c)) return e;
     HIP_TRY(hipStreamSynchronize(c->stream));
     DStats h{};
     {
-        std::vector<DStats> rows((size_t)c->stat_rows);
-        HIP_TRY(hipMemcpy(rows.data(), c->stats.p, rows.size() * sizeof(DStats), hipMemcpyDeviceToHost));
+        std::vector<DStats> rows((size_t)c->stat_rows * (1 + hk_ctx::MAX_LANES));
+        HIP_TRY(hipMemcpy(rows.data(), c->stats.p, (size_t)c->stat_rows * sizeof(DStats), hipMemcpyDeviceToHost));
+        for (size_t l = 0; l < (size_t)hk_ctx::MAX_LANES; ++l) {
+            if (c->lanes[l].stats.p)
+                HIP_TRY(hipMemcpy(rows.data() + (l + 1) * (size_t)c->stat_rows, c->lanes[l].stats.p, (size_t)c->stat_rows * sizeof(DStats), hipMemcpyDeviceToHost));
+            else
+                std::memset(rows.data() + (l + 1) * (size_t)c->stat_rows, 0, (size_t)c->stat_rows * sizeof(DStats));
+        }
         for (const DStats& r : rows) {
             h.rays_closest += r.rays_closest;
             h.rays_shadow += r.rays_shadow;
@@ -2031,6 +2158,10 @@ extern "C" int32_t hk_film_reduce(hk_comm* c, hk_film* const* films, int32_t n_f
             break;
         }
         // in place: the root's accumulators receive the sum; ordered after the renders already enqueued on the context's stream
+        if (join_lanes(c->ctxs[i]) != HK_OK) {
+            status = HK_ERR_DEVICE;
+            break;
+        }
         const int rc = r.Reduce(films[i]->accum, films[i]->accum, count, dtype, 0 /* ncclSum */, root, c->comms[i], c->ctxs[i]->stream);
         if (rc != 0) status = rccl_fail("ncclReduce", rc);
     }

@@ -403,6 +403,63 @@ def test_progressive_and_sharded_rendering(hk):
     vp2.close()
 
 
+@pytest.mark.parametrize("which", ["cornell", "cloud", "sky"])
+def test_progressive_calls_pipeline_bit_equal(hk, monkeypatch, which):
+    """64 one-sample calls (render!, volpath.jl:445-450) with no read-back in between run PIPELINED on the library's lanes (hk_ctx::Lane:
+    consecutive small calls beside each other, film kernels chained in call order): the accumulators equal, bit for bit, those of the same
+    calls run one after the other (HK_PIPELINE=1), of the one-shot 64-sample frame, and of a mix of call sizes; statistics add up; a clear
+    in the middle is ordered behind the calls before it."""
+    from hikari_jl_amd import scenes
+    w, h, n = 40, 36, 64
+    if which == "cornell":
+        s, film, cam = scenes.cornell_box(w, h, light="area")
+        depth = 6
+    elif which == "cloud":
+        s, film, cam = scenes.cloud_scene(w, h, "nanovdb", res=(48, 48, 24))
+        depth = 8
+    else:
+        s, film, cam = scenes.sky_scene(w, h, env_res=32)
+        depth = 6
+
+    def run(env, plan):
+        monkeypatch.delenv("HK_PIPELINE", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        vp = hk.VolPath(max_depth=depth, samples=n)
+        vp._ensure(film)
+        vp.clear()
+        vp.reset_stats()
+        first = 1
+        for k in plan:
+            vp.render_samples(s, film, cam, k, first=first, readback=False)
+            first += k
+        acc = vp.read_accumulators(film).copy()
+        st = vp.stats()
+        vp.close()
+        # (a scene with media casts one extra ray per CALL: the camera-medium detection, intersection.jl:690-747)
+        return acc, (int(st.rays_closest) - (len(plan) if which == "cloud" else 0), int(st.rays_shadow), int(st.medium_collisions), int(st.path_vertices))
+
+    ref, rays = run({"HK_PIPELINE": "1"}, [1] * n)
+    assert np.isfinite(ref).all() and ref.max() > 0
+    for env, plan in (({}, [1] * n), ({"HK_PIPELINE": "7"}, [1] * n), ({}, [n]), ({"HK_PIPELINE": "2"}, [1, 2, 1, 28, 1, 1, 30]), ({}, [3] * 20 + [4])):
+        got, r2 = run(env, plan)
+        assert np.array_equal(ref.view(np.uint32), got.view(np.uint32)), (env, plan[:4])
+        assert r2 == rays, (env, r2, rays)
+    # a clear between pipelined calls: what is rendered before it is gone, what comes after it is all there
+    monkeypatch.delenv("HK_PIPELINE", raising=False)
+    vp = hk.VolPath(max_depth=depth, samples=n)
+    vp._ensure(film)
+    vp.clear()
+    for i in range(8):
+        vp.render_samples(s, film, cam, 1, first=100 + i, readback=False)
+    vp.clear()
+    for i in range(n):
+        vp.render_samples(s, film, cam, 1, first=i + 1, readback=False)
+    got = vp.read_accumulators(film).copy()
+    vp.close()
+    assert np.array_equal(ref.view(np.uint32), got.view(np.uint32))
+
+
 def test_converged_image_within_mc_variance(hk, oracle):
     """SURVEY 8(d) converged-image check: a 256-spp GPU frame of sample indices the oracle never saw (1025..1280) against the
     oracle's 1024-spp frame (indices 1..1024).  Both estimate the same image, so their relMSE is var/256 + var/1024; var/256 is

@@ -1730,6 +1730,19 @@ HKD LightSample sample_light(const DScene& sc, const DTables& T, const DLight& l
 // ---- light BVH (lights/bvh-light-sampler.jl:58-232, light-bounds.jl:96-109,177-182) ----
 HKD float cos_sub_clamped(float sA, float cA, float sB, float cB) { return cA > cB ? 1.0f : cA * cB + sA * sB; }
 HKD float sin_sub_clamped(float sA, float cA, float sB, float cB) { return cA > cB ? 0.0f : sA * cB - cA * sB; }
+// sqrtf(x) for x == 0 or 2^-96 <= x < 2^32, bit for bit: the compiler's correctly rounded square root (hardware v_sqrt_f32 within 1 ulp,
+// then the neighbour whose residual has the right sign) WITHOUT the range scaling for tiny arguments and the class check for inf / nan
+// that the general expansion carries — 11 vector instructions instead of 16 and three of its five hazard s_nops.  The arguments below
+// are max(0, 1 - c^2) and 1 - r^2 / d^2 of cosines in [-1, 1]: 0 or at least 2^-24.  Exhaustively equal to sqrtf on the whole domain
+// (tools/sqrt_exact.hip; tests/test_gpu_parity.py::test_light_bvh_parity holds the pmf at 0 ulp from the oracle).
+HKD float sqrt_unit(float x) {
+    float s = __builtin_amdgcn_sqrtf(x);
+    const float dn = __uint_as_float(__float_as_uint(s) - 1u), up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float e_dn = __builtin_fmaf(-dn, s, x), e_up = __builtin_fmaf(-up, s, x);
+    s = 0.0f >= e_dn ? dn : s;
+    s = 0.0f < e_up ? up : s;
+    return x != x ? x : s;   // (a NaN comes back as it came, as from the general expansion: p on a node's centre)
+}
 HKD float node_importance(const DLightNode& nd, v3 p, v3 n) {
     if (nd.phi == 0.0f) return 0.0f;
     v3 pc = mk3(nd.centre[0], nd.centre[1], nd.centre[2]);
@@ -1739,9 +1752,9 @@ HKD float node_importance(const DLightNode& nd, v3 p, v3 n) {
     v3 wi = normalize(dp);
     float cw = dot(mk3(nd.w[0], nd.w[1], nd.w[2]), wi);
     if (nd.bits & 1u) cw = fabsf(cw);
-    float sw = sqrtf(maxf(0.0f, 1.0f - cw * cw));
-    float cb = dd < nd.r2 ? -1.0f : sqrtf(maxf(0.0f, 1.0f - nd.r2 / dd));
-    float sb = sqrtf(maxf(0.0f, 1.0f - cb * cb));
+    float sw = sqrt_unit(maxf(0.0f, 1.0f - cw * cw));
+    float cb = dd < nd.r2 ? -1.0f : sqrt_unit(maxf(0.0f, 1.0f - nd.r2 / dd));
+    float sb = sqrt_unit(maxf(0.0f, 1.0f - cb * cb));
     float so = nd.sin_o;
     float cx = cos_sub_clamped(sw, cw, so, nd.cos_o);
     float sx = sin_sub_clamped(sw, cw, so, nd.cos_o);
@@ -1750,7 +1763,7 @@ HKD float node_importance(const DLightNode& nd, v3 p, v3 n) {
     float imp = nd.phi * cp / d2;
     if (!is_zero(n)) {
         float ci = fabsf(dot(wi, n));
-        float si = sqrtf(maxf(0.0f, 1.0f - ci * ci));
+        float si = sqrt_unit(maxf(0.0f, 1.0f - ci * ci));
         imp *= cos_sub_clamped(si, ci, sb, cb);
     }
     return maxf(imp, 0.0f);

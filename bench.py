@@ -160,8 +160,11 @@ def build_workload(config, scenes):
                     "1024x1024, VolPath depth 8")
     else:
         W, H, depth, spp = 800, 800, 8, 256
-        scene, film, cam = scenes.cornell_box(W, H, light="area")
-        workload = "Cornell box (diffuse + area light), 800x800, VolPath depth 8"
+        objects = os.environ.get("HK_BENCH_CORNELL_OBJECTS", "two_spheres")
+        scene, film, cam = scenes.cornell_box(W, H, light="area", objects=objects)
+        workload = ("Cornell box (diffuse + area light; %s, %d triangles), 800x800, VolPath depth 8"
+                    % ("two matte spheres tessellated at 32: SURVEY 8(d)" if objects == "two_spheres" else "one tessellated sphere + one box: the rounds 1-3 scene",
+                       int(scene.desc.n_triangles)))
     return scene, film, cam, W, H, depth, spp, workload
 
 

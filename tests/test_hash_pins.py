@@ -5,6 +5,7 @@ fractions, tests/test_independent_pins.py::test_alpha_and_mix_fractions):
   * the stochastic alpha test        pcg32_init(pbrt_hash(o), pbrt_hash(d))      integrators/volpath/intersection.jl:233-252 (camera / bounce rays),
                                      first pcg32_uniform_f32 > alpha                                          :390-396 (shadow rays)
   * their ingredients                MurmurHash64A, pbrt_hash(Vec3f / Point3f), PCG32   materials/spectral-eval.jl:575-636, 700-716, 745-813
+  * the ZSobol sampler               Morton index, digit permutations, FastOwen scramble   sampler/sobol.jl:17-323 (every per-pixel comparison rests on it)
 
 restated below in PURE PYTHON INTEGERS (arbitrary precision, masked to 64 bits by hand — nothing is shared with oracle/ or the HIP
 library, not even the overflow behaviour of a machine word) from the text of those reference lines, and compared BIT FOR BIT:
@@ -105,6 +106,86 @@ def mix_hash_float(p, wo, key) -> np.float32:
     return f32(h & 0xFFFFFFFF) * f32(2.0 ** -32)
 
 
+# ZSobol (sampler/sobol.jl:17-323): the sampler every per-pixel comparison rests on — integers only as well
+M32 = (1 << 32) - 1
+PERMUTATIONS_4WAY = ((0, 1, 2, 3), (0, 1, 3, 2), (0, 2, 1, 3), (0, 2, 3, 1), (0, 3, 2, 1), (0, 3, 1, 2), (1, 0, 2, 3), (1, 0, 3, 2), (1, 2, 0, 3), (1, 2, 3, 0), (1, 3, 2, 0),
+                     (1, 3, 0, 2), (2, 1, 0, 3), (2, 1, 3, 0), (2, 0, 1, 3), (2, 0, 3, 1), (2, 3, 0, 1), (2, 3, 1, 0), (3, 1, 2, 0), (3, 1, 0, 2), (3, 2, 1, 0), (3, 2, 0, 1),
+                     (3, 0, 2, 1), (3, 0, 1, 2))          # sobol.jl:159-184 (pbrt-v4 samplers.h)
+
+
+def mix_bits64(v: int) -> int:                            # spectral-eval.jl:641-648
+    v ^= v >> 31
+    v = (v * 0x7FB5D329728EA185) & M64
+    v ^= v >> 27
+    v = (v * 0x81DADEF4BC2DD44D) & M64
+    v ^= v >> 33
+    return v
+
+
+def spread_bits(x: int) -> int:                           # left_shift2, sobol.jl:42-50
+    x &= 0xFFFFFFFF
+    x = (x ^ (x << 16)) & 0x0000FFFF0000FFFF
+    x = (x ^ (x << 8)) & 0x00FF00FF00FF00FF
+    x = (x ^ (x << 4)) & 0x0F0F0F0F0F0F0F0F
+    x = (x ^ (x << 2)) & 0x3333333333333333
+    x = (x ^ (x << 1)) & 0x5555555555555555
+    return x
+
+
+def bitreverse32(v: int) -> int:
+    return int("{:032b}".format(v)[::-1], 2)
+
+
+def fast_owen_scramble(v: int, seed: int) -> int:         # sobol.jl:73-81
+    v = bitreverse32(v)
+    v ^= (v * 0x3D20ADEA) & M32
+    v = (v + seed) & M32
+    v = (v * ((seed >> 16) | 1)) & M32
+    v ^= (v * 0x05526C56) & M32
+    v ^= (v * 0x53A22864) & M32
+    return bitreverse32(v)
+
+
+def zsobol_params(spp: int, width: int, height: int):     # compute_zsobol_params, sobol.jl:316-322
+    log2_spp = (max(1, spp) - 1).bit_length()
+    res_log2 = (max(width, height) - 1).bit_length()
+    return log2_spp, res_log2 + (log2_spp + 1) // 2
+
+
+def zsobol_sample_index(morton: int, dim: int, log2_spp: int, n_digits: int) -> int:     # sobol.jl:211-262
+    odd = log2_spp & 1
+    index = 0
+    for i in range(n_digits - 1, odd - 1, -1):            # (the reference runs 32 masked iterations; those below `last_digit` contribute nothing)
+        shift = max(0, 2 * i - odd)
+        digit = (morton >> shift) & 3
+        higher = morton >> (shift + 2)
+        p = (mix_bits64(higher ^ ((0x55555555 * dim) & M64)) >> 24) % 24
+        index |= PERMUTATIONS_4WAY[p][digit] << shift
+    if odd:
+        index |= ((morton & 1) ^ (mix_bits64((morton >> 1) ^ ((0x55555555 * dim) & M64)) & 1))
+    return index
+
+
+def sobol_sample(a: int, dimension: int, seed: int, matrices) -> np.float32:             # sobol.jl:100-126
+    v = 0
+    for bit in range(52):
+        if (a >> bit) & 1:
+            v ^= int(matrices[dimension * 52 + bit])
+    v = fast_owen_scramble(v, seed)
+    f = f32(v) * f32(2.3283064365386963e-10)
+    lim = f32(1.0) - np.finfo(f32).eps
+    return f if f < lim else lim
+
+
+def zsobol(px, py, sample_idx, dim, log2_spp, n_digits, seed, matrices, two=False):      # sobol.jl:274-311
+    morton = ((((spread_bits(py) << 1) | spread_bits(px)) << log2_spp) | sample_idx) & M64
+    index = zsobol_sample_index(morton, dim, log2_spp, n_digits)
+    h = murmur64a(struct.pack("<iI", dim + (2 if two else 1), seed), 0)      # Hash(dimension AFTER the increment, seed)
+    if two:
+        return sobol_sample(index, 0, h & M32, matrices), sobol_sample(index, 1, h >> 32, matrices)
+    return sobol_sample(index, 0, h & M32, matrices)
+
+
 def _unit(v):
     return (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(f32)
 
@@ -141,6 +222,29 @@ def test_murmur_and_pcg_restated_in_integers(oracle):
         seq, seed = int(rng.integers(0, 1 << 63)) * 2 + int(rng.integers(0, 2)), int(rng.integers(0, 1 << 63)) * 2 + int(rng.integers(0, 2))
         L.hko_pcg32(C.c_uint64(seq), C.c_uint64(seed), 1, 1, u32.ctypes.data_as(C.POINTER(C.c_uint32)), _pf(fl))
         assert fl[0].view(np.uint32) == np.asarray(pcg32_first_float(seq, seed), f32).view(np.uint32), (seq, seed)
+
+
+@pytest.mark.parametrize("width,height,spp", [(800, 800, 256), (64, 48, 16), (1024, 1024, 8), (33, 70, 4096), (16, 16, 1)])
+def test_zsobol_restated_in_integers(hk, oracle, width, height, spp):
+    """ZSobolSampler (Morton index, base-4 digit permutations hashed from the higher digits, FastOwen scrambling; power-of-4 and
+    odd-power-of-2 sample counts): 4 000 random (pixel, sample index, dimension) draws per film / sample-count combination, 1-D and 2-D,
+    the oracle's float bit for bit."""
+    mats = hk.tables.load()["sobol"]
+    rng = np.random.default_rng(403 + width)
+    n = 4000
+    px = rng.integers(1, width + 1, n).astype(np.int32)
+    py = rng.integers(1, height + 1, n).astype(np.int32)
+    eff = max(spp, 4096)                                      # render! sizes the index for at least 4 096 samples (volpath.jl:474-479)
+    si = rng.integers(1, min(eff, 1 << 14) + 1, n).astype(np.int32)
+    dim = rng.integers(0, 110, n).astype(np.int32)
+    seed = 0
+    o1, o2 = oracle.sobol(width, height, eff, seed, px, py, si, dim)
+    log2_spp, n_digits = zsobol_params(eff, width, height)
+    for i in range(n):
+        a = zsobol(int(px[i]), int(py[i]), int(si[i]), int(dim[i]), log2_spp, n_digits, seed, mats)
+        b0, b1 = zsobol(int(px[i]), int(py[i]), int(si[i]), int(dim[i]), log2_spp, n_digits, seed, mats, two=True)
+        assert np.asarray(a, f32).view(np.uint32) == o1[i].view(np.uint32), (i, a, o1[i])
+        assert np.asarray(b0, f32).view(np.uint32) == o2[i, 0].view(np.uint32) and np.asarray(b1, f32).view(np.uint32) == o2[i, 1].view(np.uint32), (i, b0, b1, o2[i])
 
 
 def _mix_scene(hk, amount):

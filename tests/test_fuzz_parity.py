@@ -79,7 +79,7 @@ def test_fuzz_strict(hk, oracle, klass, seed, size):
 def test_fuzz_converged(hk, oracle, klass, seed):
     """The statistical classes at the bar of tests/test_converged_parity.py, at reduced size: a 16 x 16 film, the oracle's 512 spp in 8
     batches against 2 048 OTHER spp on the device — channel means within 1 % + 4 standard errors, per-pixel z-scores with the median
-    square of 8-batch variance estimates (fireflies make the mean useless here) and |z| > 6 on at most 6 % of the lit pixel channels.  (test_fuzz_statistical below keeps the 64-spp comparison at the scenes' own sizes for a
+    square of 8-batch variance estimates (fireflies make the mean useless here) and |z| > 6 on at most 15 % of the lit pixel channels.  (test_fuzz_statistical below keeps the 64-spp comparison at the scenes' own sizes for a
     third of the seeds: wave segments that refill, odd film shapes.)"""
     from test_converged_parity import check_converged, converged_pair
     s, film, cam, kw, desc = random_scene(hk, seed, klass, (16, 16))

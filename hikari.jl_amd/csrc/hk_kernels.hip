@@ -4341,6 +4341,9 @@ void launch_trace(hipStream_t s, int n_cu, const DPathState& st, const DScene& s
 #ifndef HK_SHADOW_NC32
 #define HK_SHADOW_NC32 0
 #endif
+#ifndef HK_TRACE_NC32
+#define HK_TRACE_NC32 128   // 10^6-triangle scene: trace -1.3 % (256 nodes cost a block per CU: +15 %)
+#endif
 #define HK_LEAN_DISPATCH(K, B16, NC16, NC32)                                     \
     if (sc.bvh_depth <= 16) {                                                    \
         if (node_cache_mode() != 0) {                                            \
@@ -4359,7 +4362,7 @@ void launch_trace(hipStream_t s, int n_cu, const DPathState& st, const DScene& s
             else HK_LEAN_LAUNCH(K, false, HK_LDS_STACK, HK_TRACE_BLOCK, 0)       \
         }                                                                        \
     }
-        HK_LEAN_DISPATCH(k_trace_lean, 1024, 1536, 0)
+        HK_LEAN_DISPATCH(k_trace_lean, 1024, 1536, HK_TRACE_NC32)
         return;
     }
     const int b0 = cached_blocks<k_trace<false>>(HK_TRACE_BLOCK, n_cu, 8), b1 = cached_blocks<k_trace<true>>(HK_TRACE_BLOCK, n_cu, 8);

@@ -1,0 +1,725 @@
+"""K1 - K13 of the VolPath integrator for OPAQUE MATTE surfaces under DIFFUSE AREA LIGHTS (the Cornell box of BASELINE.json configs[1]),
+restated in float32 NumPy straight from the reference's Julia text — a second per-pixel source for the wavefront control flow
+(VERDICT r3 item 2b).  Nothing here is shared with oracle/ or the HIP library: no BVH (every ray is tested against every triangle, in
+float64), no work queues (arrays over all paths of one sample index with an `alive` mask), its own ZSobol, light BVH, uplift, film.
+
+    integrators/volpath/volpath.jl:123-205 (camera rays), :214-270 (the seven draws of a bounce), :330-420 (film), :445-636 (the loop)
+    integrators/volpath/surface-eval.jl:147-219 (emission + its MIS weight), :235-330 (next-event estimation), :395-505 (BSDF sample, roulette)
+    integrators/volpath/intersection.jl:13-182 (surface geometry), :303-420, :564-600 (shadow rays without media)
+    integrators/physical-wavefront/lights.jl:235-290 (triangle light sample), :535-600 (the direct-lighting record)
+    integrators/physical-wavefront/material-dispatch.jl:263-287 (roulette)
+    lights/bvh-light-sampler.jl:58-230 (importance, sample, pmf), :239-447 (SAH build); lights/light-bounds.jl (cones, bounds, triangle bounds)
+    lights/diffuse-area.jl:54-64; materials/spectral-eval.jl:43-100, 372-397 (Matte), :3514-3533 (frame); sampler/sampling.jl:5-33
+    sampler/sobol.jl (ZSobol); spectral/spectral.jl:192-249 (wavelengths); spectral/rgb2spec.jl:17-36, 83-167 (uplift); spectral/color.jl:364-440, 572-579
+    camera/perspective.jl:95-128 on the two matrices of the C-ABI's hk_camera record; filter.jl:58-64 (box filter)
+
+Inputs are the records of the C-ABI (hk_scene_desc, hk_camera, hk_integrator_params) and the shared DATA tables (Sobol matrices, CIE,
+rgb2spec).  Used by tests/test_control_flow_pin.py only."""
+import struct
+
+import numpy as np
+
+f32 = np.float32
+PI = f32(np.pi)
+M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def F(x):
+    return np.asarray(x, f32)
+
+
+# ---------------------------------------------------------------------------------------------------- ZSobol, vectorised over paths
+def _u64(x):
+    return np.asarray(x).astype(np.uint64)
+
+
+def mix_bits(v):
+    with np.errstate(over="ignore"):
+        v = v ^ (v >> np.uint64(31))
+        v = v * np.uint64(0x7FB5D329728EA185)
+        v = v ^ (v >> np.uint64(27))
+        v = v * np.uint64(0x81DADEF4BC2DD44D)
+        v = v ^ (v >> np.uint64(33))
+    return v
+
+
+def spread_bits(x):
+    x = _u64(x) & np.uint64(0xFFFFFFFF)
+    for s, m in ((16, 0x0000FFFF0000FFFF), (8, 0x00FF00FF00FF00FF), (4, 0x0F0F0F0F0F0F0F0F), (2, 0x3333333333333333), (1, 0x5555555555555555)):
+        x = (x ^ (x << np.uint64(s))) & np.uint64(m)
+    return x
+
+
+PERM = np.array([(0, 1, 2, 3), (0, 1, 3, 2), (0, 2, 1, 3), (0, 2, 3, 1), (0, 3, 2, 1), (0, 3, 1, 2), (1, 0, 2, 3), (1, 0, 3, 2), (1, 2, 0, 3), (1, 2, 3, 0), (1, 3, 2, 0),
+                 (1, 3, 0, 2), (2, 1, 0, 3), (2, 1, 3, 0), (2, 0, 1, 3), (2, 0, 3, 1), (2, 3, 0, 1), (2, 3, 1, 0), (3, 1, 2, 0), (3, 1, 0, 2), (3, 2, 1, 0), (3, 2, 0, 1),
+                 (3, 0, 2, 1), (3, 0, 1, 2)], np.uint64)
+
+
+def bitreverse32(v):
+    v = _u64(v)
+    r = np.zeros_like(v)
+    for i in range(32):
+        r |= ((v >> np.uint64(i)) & np.uint64(1)) << np.uint64(31 - i)
+    return r
+
+
+def fast_owen(v, seed):
+    m = np.uint64(0xFFFFFFFF)
+    seed = np.uint64(seed)
+    with np.errstate(over="ignore"):
+        v = bitreverse32(v)
+        v = v ^ ((v * np.uint64(0x3D20ADEA)) & m)
+        v = (v + seed) & m
+        v = (v * ((seed >> np.uint64(16)) | np.uint64(1))) & m
+        v = v ^ ((v * np.uint64(0x05526C56)) & m)
+        v = v ^ ((v * np.uint64(0x53A22864)) & m)
+    return bitreverse32(v)
+
+
+def murmur64a(data: bytes, seed: int = 0) -> int:
+    m, r, mask = 0xC6A4A7935BD1E995, 47, (1 << 64) - 1
+    h = (seed ^ (len(data) * m)) & mask
+    for i in range(len(data) // 8):
+        k = int.from_bytes(data[8 * i:8 * i + 8], "little")
+        k = (k * m) & mask
+        k ^= k >> r
+        k = (k * m) & mask
+        h = ((h ^ k) * m) & mask
+    tail = data[8 * (len(data) // 8):]
+    if tail:
+        h = ((h ^ int.from_bytes(tail, "little")) * m) & mask
+    h ^= h >> r
+    h = (h * m) & mask
+    return h ^ (h >> r)
+
+
+class ZSobol:
+    def __init__(self, matrices, width, height, spp, seed=0):
+        self.m = np.asarray(matrices, np.uint64)
+        self.log2_spp = (max(1, spp) - 1).bit_length()
+        self.n_digits = (max(width, height) - 1).bit_length() + (self.log2_spp + 1) // 2
+        self.seed = seed
+
+    def _index(self, px, py, sample_idx, dim):
+        morton = (((spread_bits(py) << np.uint64(1)) | spread_bits(px)) << np.uint64(self.log2_spp)) | np.uint64(sample_idx)
+        odd = self.log2_spp & 1
+        key = np.uint64((0x55555555 * dim) & 0xFFFFFFFFFFFFFFFF)
+        index = np.zeros_like(morton)
+        for i in range(self.n_digits - 1, odd - 1, -1):
+            shift = np.uint64(max(0, 2 * i - odd))
+            digit = (morton >> shift) & np.uint64(3)
+            p = (mix_bits((morton >> (shift + np.uint64(2))) ^ key) >> np.uint64(24)) % np.uint64(24)
+            index |= PERM[p.astype(np.int64), digit.astype(np.int64)] << shift
+        if odd:
+            index |= (morton & np.uint64(1)) ^ (mix_bits((morton >> np.uint64(1)) ^ key) & np.uint64(1))
+        return index
+
+    def _sample(self, index, dimension, h):
+        v = np.zeros_like(index)
+        for bit in range(52):
+            v ^= np.where(((index >> np.uint64(bit)) & np.uint64(1)) != 0, self.m[dimension * 52 + bit], np.uint64(0))
+        v = fast_owen(v, h)
+        x = v.astype(f32) * f32(2.3283064365386963e-10)
+        return np.minimum(x, f32(1.0) - np.finfo(f32).eps)
+
+    def d1(self, px, py, sample_idx, dim):
+        h = murmur64a(struct.pack("<iI", dim + 1, self.seed))
+        return self._sample(self._index(px, py, sample_idx, dim), 0, h & 0xFFFFFFFF)
+
+    def d2(self, px, py, sample_idx, dim):
+        h = murmur64a(struct.pack("<iI", dim + 2, self.seed))
+        idx = self._index(px, py, sample_idx, dim)
+        return self._sample(idx, 0, h & 0xFFFFFFFF), self._sample(idx, 1, h >> 32)
+
+
+# ---------------------------------------------------------------------------------------------------- small vector helpers (float32)
+def dot(a, b):
+    return a[..., 0] * b[..., 0] + a[..., 1] * b[..., 1] + a[..., 2] * b[..., 2]
+
+
+def cross(a, b):
+    return np.stack([a[..., 1] * b[..., 2] - a[..., 2] * b[..., 1], a[..., 2] * b[..., 0] - a[..., 0] * b[..., 2], a[..., 0] * b[..., 1] - a[..., 1] * b[..., 0]], -1)
+
+
+def normalize(v):
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return v / np.sqrt(dot(v, v))[..., None]
+
+
+def average(s):
+    return (s[..., 0] + s[..., 1] + s[..., 2] + s[..., 3]) / f32(4)
+
+
+def is_black(s):
+    return np.all(s == 0, axis=-1)
+
+
+# ---------------------------------------------------------------------------------------------------- spectra
+def sigmoid(x):
+    with np.errstate(over="ignore", invalid="ignore"):
+        r = f32(0.5) + x / (f32(2) * np.sqrt(f32(1) + x * x))
+    return np.where(np.isinf(x), np.where(x > 0, f32(1), f32(0)), r).astype(f32)
+
+
+class Tables:
+    def __init__(self, t):
+        self.res = int(t["res"])
+        self.scale = F(t["scale"])
+        self.coeffs = F(t["coeffs"]).reshape((3, self.res, self.res, self.res, 3), order="F")     # [maxc, z, y, x, coeff], column-major
+        self.cie = [F(c) for c in t["cie"]]
+        self.sobol = t["sobol"]
+
+    def rgb_to_poly(self, rgb):
+        """rgb_to_spectrum (rgb2spec.jl:83-167) of ONE colour -> (c0, c1, c2)"""
+        r, g, b = [f32(min(max(float(c), 0.0), 1.0)) for c in rgb]
+        if r == g and g == b:
+            if 0 < r < 1:
+                c2 = (r - f32(0.5)) / np.sqrt(r * (f32(1) - r))
+            else:
+                c2 = f32(-1e10) if r <= 0 else f32(1e10)
+            return f32(0), f32(0), f32(c2)
+        maxc = (0 if r > b else 2) if r > g else (1 if g > b else 2)
+        z = (r, g, b)[maxc]
+        xc = (g, b, r)[maxc]
+        yc = (b, r, g)[maxc]
+        res = self.res
+        x = xc * f32(res - 1) / z
+        y = yc * f32(res - 1) / z
+        zi = 0
+        for i in range(res - 1):
+            if self.scale[i] < z:
+                zi = i
+        zi = min(zi, res - 2)
+        xi = min(int(x), res - 2)
+        yi = min(int(y), res - 2)
+        dx, dy = x - f32(xi), y - f32(yi)
+        dz = (z - self.scale[zi]) / (self.scale[zi + 1] - self.scale[zi])
+        out = []
+        one = f32(1)
+        for c in range(3):
+            co = self.coeffs[maxc, :, :, :, c]
+            v = (one - dz) * ((one - dy) * ((one - dx) * co[zi, yi, xi] + dx * co[zi, yi, xi + 1]) + dy * ((one - dx) * co[zi, yi + 1, xi] + dx * co[zi, yi + 1, xi + 1])) + \
+                dz * ((one - dy) * ((one - dx) * co[zi + 1, yi, xi] + dx * co[zi + 1, yi, xi + 1]) + dy * ((one - dx) * co[zi + 1, yi + 1, xi] + dx * co[zi + 1, yi + 1, xi + 1]))
+            out.append(f32(v))
+        return tuple(out)
+
+
+def eval_poly(poly, lam):
+    """poly: [..., 3] coefficients per path, lam [..., 4] -> sigmoid(c0 l^2 + c1 l + c2)"""
+    c0, c1, c2 = poly[..., 0:1], poly[..., 1:2], poly[..., 2:3]
+    return sigmoid(c0 * lam * lam + c1 * lam + c2)
+
+
+def sample_wavelengths(u):
+    """sample_wavelengths_visible (spectral.jl:192-249)"""
+    def inv(v):
+        return f32(538.0) - f32(138.888889) * np.arctanh(f32(0.85691062) - f32(1.82750197) * v)
+
+    def pdf(lam):
+        x = f32(0.0072) * (lam - f32(538.0))
+        c = np.cosh(x)
+        return np.where((lam < 360) | (lam > 830), f32(0), f32(0.0039398042) / (c * c)).astype(f32)
+
+    us = [u]
+    for off in (0.25, 0.5, 0.75):
+        v = u + f32(off)
+        us.append(np.where(v >= 1, v - f32(1), v).astype(f32))
+    lam = np.stack([inv(v) for v in us], -1).astype(f32)
+    return lam, pdf(lam)
+
+
+# ---------------------------------------------------------------------------------------------------- the light BVH (host build + walks)
+class LB:
+    def __init__(self, lo, hi, w, phi, cos_o, cos_e, two_sided):
+        self.lo, self.hi, self.w, self.phi, self.cos_o, self.cos_e, self.two_sided = F(lo), F(hi), F(w), f32(phi), f32(cos_o), f32(cos_e), bool(two_sided)
+
+    def centroid(self):
+        return (self.lo + self.hi) * f32(0.5)
+
+
+def _angle_between(a, b):
+    if dot(a, b) < 0:
+        return PI - f32(2) * np.arcsin(np.clip(np.sqrt(dot(a + b, a + b)) * f32(0.5), -1, 1).astype(f32))
+    return f32(2) * np.arcsin(np.clip(np.sqrt(dot(b - a, b - a)) * f32(0.5), -1, 1).astype(f32))
+
+
+def _cone_union(wa, ca, wb, cb):
+    if ca == np.inf:
+        return wb, cb
+    if cb == np.inf:
+        return wa, ca
+    ta, tb = np.arccos(np.clip(ca, -1, 1)).astype(f32), np.arccos(np.clip(cb, -1, 1)).astype(f32)
+    td = f32(_angle_between(wa, wb))
+    if min(td + tb, PI) <= ta:
+        return wa, ca
+    if min(td + ta, PI) <= tb:
+        return wb, cb
+    to = (ta + td + tb) * f32(0.5)
+    if to >= PI:
+        return F([0, 0, 1]), f32(-1)
+    tr = to - ta
+    wr = cross(wa, wb)
+    if dot(wr, wr) == 0:
+        return F([0, 0, 1]), f32(-1)
+    axis = normalize(wr)
+    s, c = np.sin(tr).astype(f32), np.cos(tr).astype(f32)
+    w = wa * c + cross(axis, wa) * s + axis * dot(axis, wa) * (f32(1) - c)
+    return normalize(w), np.cos(to).astype(f32)
+
+
+def lb_union(a, b):
+    if a is None or a.phi == 0:
+        return b
+    if b is None or b.phi == 0:
+        return a
+    w, c = _cone_union(a.w, a.cos_o, b.w, b.cos_o)
+    return LB(np.minimum(a.lo, b.lo), np.maximum(a.hi, b.hi), w, a.phi + b.phi, c, min(a.cos_e, b.cos_e), a.two_sided or b.two_sided)
+
+
+def _cost(lb, lo, hi, dim):
+    to = np.arccos(np.clip(lb.cos_o, -1, 1)).astype(f32)
+    te = np.arccos(np.clip(lb.cos_e, -1, 1)).astype(f32)
+    tw = min(to + te, PI)
+    so = np.sqrt(max(f32(0), f32(1) - lb.cos_o * lb.cos_o))
+    m_omega = f32(2) * PI * (f32(1) - lb.cos_o) + PI / f32(2) * (f32(2) * tw * so - np.cos(to - f32(2) * tw).astype(f32) - f32(2) * to * so + lb.cos_o)
+    d = hi - lo
+    kr = d.max() / d[dim] if d[dim] > 1e-10 else d.max() / f32(1e-10)
+    area = f32(2) * (d[0] * d[1] + d[0] * d[2] + d[1] * d[2])
+    return lb.phi * m_omega * kr * area
+
+
+class LightBVH:
+    """nodes as parallel arrays; child0 of an interior node is the next node, child1 is stored (bvh-light-sampler.jl:338-447)"""
+
+    def __init__(self, lights):
+        self.lights = lights
+        self.nodes = []                       # (LB, child1_or_light, is_leaf)
+        self.trail = {}
+        items = [(i + 1, lb) for i, lb in enumerate(lights) if lb is not None and lb.phi > 0]
+        self.n = len(items)
+        if items:
+            self._build(items, 0, len(items) - 1, 0, 0)
+        nd = self.nodes
+        self.lo = F([n[0].lo for n in nd])
+        self.hi = F([n[0].hi for n in nd])
+        self.w = F([n[0].w for n in nd])
+        self.phi = F([n[0].phi for n in nd])
+        self.cos_o = F([n[0].cos_o for n in nd])
+        self.cos_e = F([n[0].cos_e for n in nd])
+        self.two = np.array([n[0].two_sided for n in nd])
+        self.child = np.array([n[1] for n in nd], np.int64)
+        self.leaf = np.array([n[2] for n in nd])
+
+    def _bucket(self, lb, clo, chi, dim):
+        ext = chi[dim] - clo[dim]
+        o = (lb.centroid()[dim] - clo[dim]) / ext if ext > 0 else f32(0)
+        return int(min(max(int(np.floor(f32(12) * o)), 0), 11))
+
+    def _build(self, items, start, stop, trail, depth):
+        if start == stop:
+            idx, lb = items[start]
+            self.nodes.append((lb, idx, True))
+            self.trail[idx] = trail
+            return lb
+        overall = items[start][1]
+        clo = chi = items[start][1].centroid()
+        for i in range(start + 1, stop + 1):
+            overall = lb_union(overall, items[i][1])
+            c = items[i][1].centroid()
+            clo, chi = np.minimum(clo, c), np.maximum(chi, c)
+        best = (np.inf, -1, -1)
+        for dim in range(3):
+            if chi[dim] - clo[dim] <= 0:
+                continue
+            bb, cnt = [None] * 12, [0] * 12
+            for i in range(start, stop + 1):
+                b = self._bucket(items[i][1], clo, chi, dim)
+                bb[b] = lb_union(bb[b], items[i][1])
+                cnt[b] += 1
+            for split in range(11):
+                below = above = None
+                nb = na = 0
+                for b in range(split + 1):
+                    below = lb_union(below, bb[b])
+                    nb += cnt[b]
+                for b in range(split + 1, 12):
+                    above = lb_union(above, bb[b])
+                    na += cnt[b]
+                if nb == 0 or na == 0:
+                    continue
+                cost = _cost(below, overall.lo, overall.hi, dim) + _cost(above, overall.lo, overall.hi, dim)
+                if cost < best[0]:
+                    best = (cost, dim, split)
+        count = stop - start + 1
+        if best[1] >= 0:
+            pivot = start
+            for i in range(start, stop + 1):
+                if self._bucket(items[i][1], clo, chi, best[1]) <= best[2]:
+                    items[pivot], items[i] = items[i], items[pivot]
+                    pivot += 1
+            mid = start + count // 2 if (pivot == start or pivot > stop) else pivot - 1
+        else:
+            mid = start + count // 2 - 1
+        mid = min(max(mid, start), stop - 1)
+        me = len(self.nodes)
+        self.nodes.append(None)
+        lb0 = self._build(items, start, mid, trail, depth + 1)
+        child1 = len(self.nodes)
+        lb1 = self._build(items, mid + 1, stop, trail | (1 << depth), depth + 1)
+        merged = lb_union(lb0, lb1)
+        self.nodes[me] = (merged, child1, False)
+        return merged
+
+    def importance(self, k, p, n):
+        """node_importance (bvh-light-sampler.jl:58-94) of node k (array of node indices) for points p, normals n"""
+        lo, hi = self.lo[k], self.hi[k]
+        pc = (lo + hi) * f32(0.5)
+        dp = p - pc
+        d2 = dot(dp, dp)
+        diag = hi - lo
+        d2 = np.maximum(d2, np.sqrt(dot(diag, diag)) * f32(0.5))
+        wi = normalize(dp)
+        cw = dot(self.w[k], wi)
+        cw = np.where(self.two[k], np.abs(cw), cw)
+        sw = np.sqrt(np.maximum(f32(0), f32(1) - cw * cw))
+        # bound_subtended_directions (light-bounds.jl:96-109)
+        r2 = dot(hi - pc, hi - pc)
+        dd = dot(p - pc, p - pc)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            cb = np.where(dd < r2, f32(-1), np.sqrt(np.maximum(f32(0), f32(1) - r2 / dd))).astype(f32)
+        sb = np.sqrt(np.maximum(f32(0), f32(1) - cb * cb))
+        co = self.cos_o[k]
+        so = np.sqrt(np.maximum(f32(0), f32(1) - co * co))
+        cx = np.where(cw > co, f32(1), cw * co + sw * so)
+        sx = np.where(cw > co, f32(0), sw * co - cw * so)
+        cp = np.where(cx > cb, f32(1), cx * cb + sx * sb)
+        imp = self.phi[k] * cp / d2
+        has_n = np.any(n != 0, axis=-1)
+        ci = np.abs(dot(wi, n))
+        si = np.sqrt(np.maximum(f32(0), f32(1) - ci * ci))
+        imp = np.where(has_n, imp * np.where(ci > cb, f32(1), ci * cb + si * sb), imp)
+        imp = np.maximum(imp, f32(0))
+        return np.where((self.phi[k] == 0) | (cp <= self.cos_e[k]), f32(0), imp).astype(f32)
+
+    def sample(self, p, n, u):
+        """bvh_sample_light without infinite lights -> (1-based light index or 0, pmf)"""
+        N = p.shape[0]
+        light = np.zeros(N, np.int64)
+        pmf_out = np.zeros(N, f32)
+        if self.n == 0:
+            return light, pmf_out
+        ub = np.minimum(u, f32(0.99999994))
+        pmf = np.ones(N, f32)
+        node = np.zeros(N, np.int64)
+        run = np.ones(N, bool)
+        for _ in range(64):
+            at_leaf = run & self.leaf[node]
+            light[at_leaf] = self.child[node[at_leaf]]
+            pmf_out[at_leaf] = pmf[at_leaf]
+            run &= ~at_leaf
+            if not run.any():
+                break
+            c0i, c1i = node + 1, self.child[node]
+            c0i = np.where(run, c0i, 0)
+            c1i = np.where(run, c1i, 0)
+            c0, c1 = self.importance(c0i, p, n), self.importance(c1i, p, n)
+            dead = run & (c0 == 0) & (c1 == 0)
+            run &= ~dead
+            with np.errstate(divide="ignore", invalid="ignore"):
+                p0 = c0 / (c0 + c1)
+                left = ub < p0
+                pmf = np.where(run, np.where(left, pmf * p0, pmf * (f32(1) - p0)), pmf).astype(f32)
+                ub = np.where(run, np.where(left, ub / p0, (ub - p0) / (f32(1) - p0)), ub).astype(f32)
+            node = np.where(run, np.where(left, c0i, c1i), node)
+        return light, pmf_out
+
+    def pmf(self, p, n, light_idx):
+        """bvh_pmf by bit trail (light_idx: array of 1-based indices, all bounded lights)"""
+        N = p.shape[0]
+        pm = np.ones(N, f32)
+        out = np.zeros(N, f32)
+        node = np.zeros(N, np.int64)
+        trail = np.array([self.trail.get(int(i), 0) for i in light_idx], np.int64)
+        run = np.ones(N, bool)
+        for _ in range(64):
+            at_leaf = run & self.leaf[node]
+            out[at_leaf] = pm[at_leaf]
+            run &= ~at_leaf
+            if not run.any():
+                break
+            c0i, c1i = np.where(run, node + 1, 0), np.where(run, self.child[node], 0)
+            c0, c1 = self.importance(c0i, p, n), self.importance(c1i, p, n)
+            s = c0 + c1
+            dead = run & (s <= 0)
+            run &= ~dead
+            right = (trail & 1) == 1
+            with np.errstate(divide="ignore", invalid="ignore"):
+                pm = np.where(run, np.where(right, pm * (c1 / s), pm * (c0 / s)), pm).astype(f32)
+            node = np.where(run, np.where(right, c1i, c0i), node)
+            trail >>= 1
+        return out
+
+
+# ---------------------------------------------------------------------------------------------------- the scene, from the C-ABI records
+class SceneNP:
+    def __init__(self, desc, tables):
+        T = int(desc.n_triangles)
+        self.P = np.ctypeslib.as_array(desc.positions, shape=(T * 9,)).reshape(T, 3, 3).astype(f32)
+        self.Nrm = np.ctypeslib.as_array(desc.normals, shape=(T * 9,)).reshape(T, 3, 3).astype(f32)
+        self.mi = np.array([desc.meta[i].medium_interface_idx for i in range(T)], np.int64)
+        self.arealight = np.array([desc.meta[i].arealight_flat_idx_1based for i in range(T)], np.int64)
+        mats = [desc.materials[i] for i in range(desc.n_materials)]
+        assert all(m.kind == 0 for m in mats), "matte only"
+        assert all(m.rgb[0].tex < 0 for m in mats), "constant Kd only"
+        self.kd_poly = F([tables.rgb_to_poly([min(max(m.rgb[0].c[k], 0.0), 1.0) for k in range(3)]) for m in mats])
+        self.mat_of_mi = np.array([desc.media_interfaces[i].material for i in range(desc.n_media_interfaces)], np.int64)
+        self.lights = [desc.lights[i] for i in range(desc.n_lights)]
+        assert all(l.kind == 6 for l in self.lights), "diffuse area lights only"
+        self.lv = F([[l.v[k] for k in range(9)] for l in self.lights]).reshape(-1, 3, 3)
+        self.ln = F([[l.normal[k] for k in range(3)] for l in self.lights])
+        self.larea = F([l.area for l in self.lights])
+        self.ltwo = np.array([bool(l.two_sided) for l in self.lights])
+        le_rgb = [[f32(l.Le.c[k]) * f32(l.scale) for k in range(3)] for l in self.lights]
+        self.le_poly = F([tables.rgb_to_poly(c) for c in le_rgb])
+        bounds = []
+        for i, l in enumerate(self.lights):
+            lum = f32(0.212671) * f32(l.Le.c[0]) + f32(0.715160) * f32(l.Le.c[1]) + f32(0.072169) * f32(l.Le.c[2])
+            phi = PI * f32(2.0 if l.two_sided else 1.0) * f32(l.area) * f32(l.scale) * lum
+            bounds.append(LB(self.lv[i].min(0), self.lv[i].max(0), self.ln[i], phi, 1.0, f32(np.cos(np.pi / 2)), l.two_sided))
+        self.bvh = LightBVH(bounds)
+        # triangle set-up for the brute-force intersection (float64)
+        self.v0 = self.P[:, 0].astype(np.float64)
+        self.e1 = (self.P[:, 1] - self.P[:, 0]).astype(np.float64)
+        self.e2 = (self.P[:, 2] - self.P[:, 0]).astype(np.float64)
+        e1f, e2f = self.P[:, 1] - self.P[:, 0], self.P[:, 2] - self.P[:, 0]
+        self.ng = normalize(cross(e1f, e2f))
+        self.tri_area = (f32(0.5) * np.sqrt(dot(cross(e1f, e2f), cross(e1f, e2f)))).astype(f32)
+
+    def intersect(self, o, d, tmax):
+        """closest hit of rays (o, d) [N, 3] (float32) with t in (0, tmax): Moeller-Trumbore in float64 over all triangles"""
+        o, d = o.astype(np.float64)[:, None, :], d.astype(np.float64)[:, None, :]
+        pv = np.cross(d, self.e2[None])
+        det = np.einsum("ntk,ntk->nt", np.broadcast_to(self.e1[None], pv.shape), pv)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            inv = 1.0 / det
+            tv = o - self.v0[None]
+            u = np.einsum("ntk,ntk->nt", tv, pv) * inv
+            qv = np.cross(tv, self.e1[None])
+            v = np.einsum("ntk,ntk->nt", np.broadcast_to(d, qv.shape), qv) * inv
+            t = np.einsum("ntk,ntk->nt", np.broadcast_to(self.e2[None], qv.shape), qv) * inv
+        ok = (np.abs(det) > 0) & (u >= 0) & (v >= 0) & (u + v <= 1) & (t > 0) & (t < tmax[:, None])
+        t = np.where(ok, t, np.inf)
+        prim = t.argmin(1)
+        idx = np.arange(t.shape[0])
+        hit = np.isfinite(t[idx, prim])
+        return hit, prim, t[idx, prim], u[idx, prim], v[idx, prim]
+
+    def occluded(self, o, d, tmax):
+        hit, _, _, _, _ = self.intersect(o, d, tmax)
+        return hit
+
+
+# ---------------------------------------------------------------------------------------------------- K1 - K13
+def apply_point(m, p):
+    x = m[0, 0] * p[..., 0] + m[0, 1] * p[..., 1] + m[0, 2] * p[..., 2] + m[0, 3]
+    y = m[1, 0] * p[..., 0] + m[1, 1] * p[..., 1] + m[1, 2] * p[..., 2] + m[1, 3]
+    z = m[2, 0] * p[..., 0] + m[2, 1] * p[..., 1] + m[2, 2] * p[..., 2] + m[2, 3]
+    w = m[3, 0] * p[..., 0] + m[3, 1] * p[..., 1] + m[3, 2] * p[..., 2] + m[3, 3]
+    out = np.stack([x, y, z], -1)
+    return np.where((w == 1)[..., None], out, out / w[..., None]).astype(f32)
+
+
+def apply_vector(m, v):
+    return np.stack([m[r, 0] * v[..., 0] + m[r, 1] * v[..., 1] + m[r, 2] * v[..., 2] for r in range(3)], -1).astype(f32)
+
+
+def cosine_hemisphere(u0, u1):
+    ox, oy = f32(2) * u0 - f32(1), f32(2) * u1 - f32(1)
+    sx, sy = ox + f32(1e-10), oy + f32(1e-10)
+    xl = np.abs(ox) > np.abs(oy)
+    r = np.where(xl, ox, oy)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        th = np.where(xl, (oy / sx) * PI / f32(4), PI / f32(2) - (ox / sy) * PI / f32(4)).astype(f32)
+    dx, dy = r * np.cos(th), r * np.sin(th)
+    z = np.sqrt(np.maximum(f32(0), f32(1) - dx * dx - dy * dy))
+    return np.stack([dx, dy, z], -1).astype(f32)
+
+
+def coordinate_system(n):
+    a = np.abs(n[..., 0]) > np.abs(n[..., 1])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ia = f32(1) / np.sqrt(n[..., 0] * n[..., 0] + n[..., 2] * n[..., 2])
+        ib = f32(1) / np.sqrt(n[..., 1] * n[..., 1] + n[..., 2] * n[..., 2])
+        zero = np.zeros_like(ia)
+        t = np.where(a[..., None], np.stack([n[..., 2] * ia, zero, -n[..., 0] * ia], -1), np.stack([zero, n[..., 2] * ib, -n[..., 1] * ib], -1)).astype(f32)
+    return t, cross(n, t)
+
+
+def render(desc, cam_rec, tables_dict, width, height, n_samples, max_depth, max_component_value=10.0, filter_radius=(0.5, 0.5), first=1, sobol_spp=None):
+    """-> framebuffer [height, width, 3] (row py - 1, column px - 1), the weighted sums and the weights"""
+    tb = Tables(tables_dict)
+    sc = SceneNP(desc, tb)
+    zs = ZSobol(tb.sobol, width, height, max(sobol_spp or n_samples, 4096), 0)
+    r2c = F(list(cam_rec.raster_to_camera)).reshape(4, 4)
+    c2w = F(list(cam_rec.camera_to_world)).reshape(4, 4)
+    assert cam_rec.lens_radius == 0
+    N = width * height
+    idx0 = np.arange(N)
+    px = (idx0 % width + 1).astype(np.int64)
+    py = (idx0 // width + 1).astype(np.int64)
+    rgb_sum = np.zeros((N, 3), f32)
+    w_sum = np.zeros(N, f32)
+    for sidx in range(first, first + n_samples):
+        # ---- K1 (volpath.jl:123-205): dims 1 (wavelength), 3 (jitter), 4 (time), 6 (lens) ----
+        wl_u = zs.d1(px, py, sidx, 1)
+        jx, jy = zs.d2(px, py, sidx, 3)
+        fx = (f32(1) - jx) * f32(-filter_radius[0]) + jx * f32(filter_radius[0])          # box filter: lerp(-r, r, u), weight 1
+        fy = (f32(1) - jy) * f32(-filter_radius[1]) + jy * f32(filter_radius[1])
+        fw = np.ones(N, f32)
+        lam, lpdf = sample_wavelengths(wl_u)
+        pf = np.stack([px.astype(f32) + f32(0.5) + fx, f32(height) - py.astype(f32) + f32(1) + f32(0.5) + fy, np.zeros(N, f32)], -1)
+        d = normalize(apply_point(r2c, pf))
+        ro = np.broadcast_to(apply_point(c2w, np.zeros((1, 3), f32)), (N, 3)).astype(f32)
+        rd = normalize(apply_vector(c2w, d))
+        beta, r_u, r_l = np.ones((N, 4), f32), np.ones((N, 4), f32), np.ones((N, 4), f32)
+        L = np.zeros((N, 4), f32)
+        alive = np.ones(N, bool)
+        for depth in range(max_depth):
+            if not alive.any():
+                break
+            base = 6 + 7 * depth
+            A = np.nonzero(alive)[0]
+            apx, apy = px[A], py[A]
+            d_uc = zs.d1(apx, apy, sidx, base + 1)
+            d_u0, d_u1 = zs.d2(apx, apy, sidx, base + 3)
+            i_u0, i_u1 = zs.d2(apx, apy, sidx, base + 6)
+            i_rr = zs.d1(apx, apy, sidx, base + 7)
+            o, dd = ro[A], rd[A]
+            hit, prim, t, bu, bv = sc.intersect(o, dd, np.full(len(A), np.inf))
+            alive[A[~hit]] = False                                   # escaped: no infinite lights in this scene
+            A, o, dd, prim, t, bu, bv = A[hit], o[hit], dd[hit], prim[hit], t[hit].astype(f32), bu[hit].astype(f32), bv[hit].astype(f32)
+            d_uc, d_u0, d_u1, i_u0, i_u1, i_rr = d_uc[hit], d_u0[hit], d_u1[hit], i_u0[hit], i_u1[hit], i_rr[hit]
+            if len(A) == 0:
+                break
+            bw = f32(1) - bu - bv
+            pi = (o + dd * t[:, None]).astype(f32)
+            n = sc.ng[prim]
+            nrm = sc.Nrm[prim]
+            ns_i = normalize(bw[:, None] * nrm[:, 0] + bu[:, None] * nrm[:, 1] + bv[:, None] * nrm[:, 2])
+            ns = np.where(np.isnan(nrm[:, :, 0]).any(1)[:, None], n, ns_i).astype(f32)
+            n = np.where((dot(n, ns) < 0)[:, None], -n, n)
+            wo = -dd
+            b, ru, rl, lm = beta[A], r_u[A], r_l[A], lam[A]
+            # ---- K8 (surface-eval.jl:147-219): emission of the triangle that was hit ----
+            em = sc.arealight[prim] > 0
+            if em.any():
+                E = np.nonzero(em)[0]
+                li = sc.arealight[prim[E]] - 1
+                Le = eval_poly(sc.le_poly[li], lm[E])
+                Le = np.where(((~sc.ltwo[li]) & (dot(wo[E], n[E]) < 0))[:, None], f32(0), Le).astype(f32)
+                contrib = b[E] * Le
+                if depth == 0:
+                    fin = contrib / average(ru[E])[:, None]
+                else:
+                    choice = sc.bvh.pmf(pi[E], n[E], li + 1)
+                    cos_t = np.abs(dot(n[E], normalize(dd[E])))
+                    with np.errstate(divide="ignore", invalid="ignore"):
+                        pdf_li = (t[E] * t[E]) / (cos_t * sc.tri_area[prim[E]])
+                    light_pdf = np.where((cos_t > 0) & (sc.tri_area[prim[E]] > 0), choice * pdf_li, f32(0)).astype(f32)
+                    rl_e = rl[E] * light_pdf[:, None]
+                    den = average(ru[E] + rl_e)
+                    with np.errstate(divide="ignore", invalid="ignore"):
+                        fin = np.where((den > f32(1e-10))[:, None], contrib / den[:, None], contrib / average(ru[E])[:, None])
+                fin = np.where(is_black(Le)[:, None], f32(0), fin).astype(f32)
+                L[A[E]] += fin
+            kd = eval_poly(sc.kd_poly[sc.mat_of_mi[sc.mi[prim]]], lm)
+            # ---- K9 (surface-eval.jl:235-330, lights.jl:235-290, 535-600): one light sample, shadow ray ----
+            lidx, lpmf = sc.bvh.sample(pi, ns, d_uc)
+            ok = (lidx >= 1) & (lpmf > 0)
+            li = np.maximum(lidx - 1, 0)
+            lt = d_u0 < d_u1
+            b0 = np.where(lt, d_u0 / f32(2), d_u0 - d_u1 / f32(2)).astype(f32)
+            b1 = np.where(lt, d_u1 - d_u0 / f32(2), d_u1 / f32(2)).astype(f32)
+            b2 = f32(1) - b0 - b1
+            pl = (b0[:, None] * sc.lv[li, 0] + b1[:, None] * sc.lv[li, 1] + b2[:, None] * sc.lv[li, 2]).astype(f32)
+            to_l = pl - pi
+            dsq = dot(to_l, to_l)
+            dist = np.sqrt(dsq)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                wi = (to_l / dist[:, None]).astype(f32)
+                cos_l = np.abs(dot(sc.ln[li], -wi))
+                lpdf_sa = dsq / (cos_l * sc.larea[li])
+            Li = eval_poly(sc.le_poly[li], lm)
+            Li = np.where(((~sc.ltwo[li]) & (dot(-wi, sc.ln[li]) < 0))[:, None], f32(0), Li).astype(f32)
+            ok &= (dsq >= f32(1e-12)) & (cos_l >= f32(1e-6)) & ~is_black(Li) & (lpdf_sa > 0)
+            ci, co = dot(wi, ns), dot(wo, ns)
+            bs_ok = ~(ci * co < 0) & ~(np.abs(ci) < f32(1e-6))
+            f = kd / PI
+            bs_pdf = np.abs(ci) / PI
+            f = np.where(bs_ok[:, None], f, f32(0)).astype(f32)
+            Ld = b * f * Li * np.abs(dot(wi, ns))[:, None]
+            ok &= ~is_black(f) & ~is_black(Ld)
+            off = f32(1e-4) * ns
+            so = np.where((dot(wi, ns) > 0)[:, None], pi + off, pi - off).astype(f32)
+            tl = pl - so
+            tmax = np.sqrt(dot(tl, tl)) - f32(1e-3)
+            ru_s = ru * bs_pdf[:, None]
+            rl_s = ru * lpdf_sa[:, None] * lpmf[:, None]
+            if ok.any():
+                K = np.nonzero(ok)[0]
+                vis = ~sc.occluded(so[K], wi[K], tmax[K].astype(np.float64)) & ~(tmax[K] < f32(1e-6))
+                den = average(ru_s[K] + rl_s[K])
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    add = np.where((vis & (den > f32(1e-10)))[:, None], Ld[K] / den[:, None], f32(0)).astype(f32)
+                L[A[K]] += add
+            # ---- K11 (surface-eval.jl:395-505): cosine sample, throughput, roulette, the next ray ----
+            new_depth = depth + 1
+            if new_depth >= max_depth:
+                alive[A] = False
+                break
+            wdn = dot(wo, ns)
+            lw = cosine_hemisphere(i_u0, i_u1)
+            cos_th = lw[:, 2].copy()
+            valid = ~(np.abs(wdn) < f32(1e-6)) & ~(cos_th < f32(1e-6))
+            lw[:, 2] = np.where(wdn < 0, -lw[:, 2], lw[:, 2])
+            tg, bt = coordinate_system(ns)
+            wi2 = normalize((tg * lw[:, 0:1] + bt * lw[:, 1:2] + ns * lw[:, 2:3]).astype(f32))
+            f2 = kd * (f32(1) / PI)
+            pdf2 = cos_th / PI
+            valid &= (pdf2 > 0) & ~is_black(f2)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                nb = (b * f2 * np.abs(dot(wi2, ns))[:, None] / pdf2[:, None]).astype(f32)
+                nrl = (ru / pdf2[:, None]).astype(f32)
+            if new_depth > 3:
+                q = np.maximum(f32(0.05), f32(1) - nb.max(1))
+                valid &= ~(i_rr < q)
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    nb = (nb * (f32(1) / (f32(1) - q))[:, None]).astype(f32)
+            o2 = (pi + np.where((dot(wi2, n) > 0)[:, None], n, -n) * f32(0.0001)).astype(f32)
+            alive[A[~valid]] = False
+            V = A[valid]
+            ro[V], rd[V], beta[V], r_l[V] = o2[valid], wi2[valid], nb[valid], nrl[valid]
+        # ---- K12 (volpath.jl:330-380): spectral -> XYZ -> linear sRGB, clamp, filter-weighted sums ----
+        offs = np.round(lam).astype(np.int64) - 360
+        inside = (offs >= 0) & (offs < 471)
+        oc = np.clip(offs, 0, 470)
+        xyz = np.zeros((N, 3), f32)
+        for i in range(4):
+            nz = lpdf[:, i] != 0
+            with np.errstate(divide="ignore", invalid="ignore"):
+                for c in range(3):
+                    cmf = np.where(inside[:, i], tb.cie[c][oc[:, i]], f32(0))
+                    xyz[:, c] += np.where(nz, cmf * L[:, i] / lpdf[:, i], f32(0)).astype(f32)
+        xyz *= f32(0.25)
+        X, Y, Z = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+        rgb = np.stack([f32(3.2404542) * X - f32(1.5371385) * Y - f32(0.4985314) * Z, f32(-0.9692660) * X + f32(1.8760108) * Y + f32(0.0415560) * Z,
+                        f32(0.0556434) * X - f32(0.2040259) * Y + f32(1.0572252) * Z], -1).astype(f32)
+        rgb = np.maximum(f32(0), rgb)
+        m = rgb.max(1)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            rgb = np.where((m > f32(max_component_value))[:, None], rgb * (f32(max_component_value) / m)[:, None], rgb).astype(f32)
+        rgb_sum += fw[:, None] * rgb
+        w_sum += fw
+    with np.errstate(divide="ignore", invalid="ignore"):
+        img = np.where((w_sum > 0)[:, None], rgb_sum * (f32(1) / w_sum)[:, None], f32(0)).astype(f32)
+    return img.reshape(height, width, 3), rgb_sum, w_sum

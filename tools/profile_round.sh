@@ -8,6 +8,8 @@ R=${1:-r03}; MODE=$2; CFGS=${3:-cornell sky cloud manylight}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/$R; mkdir -p $O
 if [ "$MODE" != "quick" ]; then
+  # the line the driver records (Cornell + one warm frame of every other config + the one-sample-per-call path), then one line per config
+  timeout 1200 python bench.py > $O/bench_${R}_default.json 2> $O/bench_default.err
   for c in $CFGS; do
     timeout 900 python bench.py --config $c > $O/bench_${R}_$c.json 2> $O/bench_$c.err
   done

@@ -21,7 +21,7 @@ prof() {  # name, config, extra bench args, counters...
   local name=$1 cfg=$2 extra=$3; shift 3
   local pmc=""; if [ $# -gt 0 ]; then pmc="--pmc $*"; fi
   local stats="--stats"; if [ $# -gt 0 ]; then stats=""; fi
-  timeout 900 rocprofv3 --kernel-trace $stats $pmc -d $O/$name -- python3 bench.py --config $cfg --no-cpu-baseline $extra > $O/$name.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace $stats $pmc -d $O/$name -- python3 bench.py --config $cfg --no-cpu-baseline --progressive 0 $extra > $O/$name.log 2>&1
   python3 tools/rocpd_summary.py $O/$name/*/*_results.db > $O/${R}_$name.txt 2>&1
 }
 for cfg in $CFGS; do

@@ -308,6 +308,7 @@ def one_frame_line(hk, scenes, torch, config, device):
     scene, builds the sampler tables and counts the units, a second untimed one, the timed one, and a replay with HIP events around
     every launch."""
     t_setup = time.perf_counter()
+    free_b, total_b = torch.cuda.mem_get_info()
     scene, film, cam, W, H, depth, spp, workload = build_workload(config, scenes)
     accum = torch.zeros(4 * W * H, dtype=torch.float32, device="cuda")
     vp = hk.VolPath(max_depth=depth, samples=max(spp, 256), device=device)
@@ -342,7 +343,7 @@ def one_frame_line(hk, scenes, torch, config, device):
     rooflines = class_rooflines(config, timed, launches, sc, True)      # (no committed counter passes for the two-spheres variant: in-run fields only)
     dom = max((k for k in ("trace", "shadow", "shade", "media") if timed[k] > 0), key=lambda k: timed[k])
     line = {"config": config, "workload": "%s, %d spp per frame" % (workload, spp), "resolution": [W, H], "max_depth": depth, "spp_per_frame": spp,
-            "triangles": int(scene.desc.n_triangles), "lights": int(scene.desc.n_lights), "frames_timed": 1,
+            "triangles": int(scene.desc.n_triangles), "lights": int(scene.desc.n_lights), "frames_timed": 1, "free_hbm_gb_before": round(free_b / 1e9, 1),
             "seconds_per_frame": round(seconds, 4), "value": round(rays / seconds / 1e6, 2), "unit": "Mrays/s",
             "rays": {"closest": int(st.rays_closest), "shadow": int(st.rays_shadow), "medium_collisions": int(st.medium_collisions)},
             "kernel_seconds": {k: round(v, 4) for k, v in timed.items()}, "setup_seconds": round(setup_s, 2),

@@ -152,8 +152,7 @@ static int join_lanes(hk_ctx* c) {
 
 struct hk_scene {
     hk_ctx* ctx = nullptr;
-    DevBuf nodes, leaf_tris, positions, normals, uvs, tangents, meta, materials, textures, spectra, mis, lights, lnodes, ltop, trails, infinite;
-    int n_ltop = 0;
+    DevBuf nodes, leaf_tris, positions, normals, uvs, tangents, meta, materials, textures, spectra, mis, lights, lnodes, trails, infinite;
     std::vector<DevBuf*> tex_data;
     std::vector<DevBuf*> spec_data;
     std::vector<DevBuf*> media_data;
@@ -652,36 +651,8 @@ extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene**
             o.sin_o = std::sqrt(om > 0.0f ? (float)om : 0.0f);
             o.bits = n.bits;
             o.child1_or_light = n.child1_or_light;
-            o.pad[0] = 0xFFFFFFFFu;
-            o.pad[1] = (uint32_t)i + 1u;
         }
         HIP_TRY(s->lnodes.upload(tmp.data(), tmp.size() * sizeof(DLightNode)));
-        {   // the top of the tree, breadth-first, whole levels while they fit HK_LTOP_N (the nodes array itself is depth-first: child0 = next)
-            std::vector<uint32_t> order, level;
-            if (!s->lbvh.nodes.empty()) level.push_back(0);
-            while (!level.empty() && order.size() + level.size() <= (size_t)HK_LTOP_N) {
-                std::vector<uint32_t> next;
-                for (uint32_t i : level) {
-                    order.push_back(i);
-                    if (!(tmp[i].bits & 2u)) {
-                        next.push_back(i + 1);
-                        next.push_back(tmp[i].child1_or_light - 1);
-                    }
-                }
-                level.swap(next);
-            }
-            std::vector<uint32_t> pos(tmp.size(), 0xFFFFu);
-            for (size_t t = 0; t < order.size(); ++t) pos[order[t]] = (uint32_t)t;
-            std::vector<DLightNode> top(order.size() ? order.size() : 1);
-            std::memset(top.data(), 0, top.size() * sizeof(DLightNode));
-            for (size_t t = 0; t < order.size(); ++t) {
-                top[t] = tmp[order[t]];
-                const DLightNode& n = tmp[order[t]];
-                top[t].pad[0] = (n.bits & 2u) ? 0xFFFFFFFFu : (pos[order[t] + 1] | (pos[n.child1_or_light - 1] << 16));
-            }
-            HIP_TRY(s->ltop.upload(top.data(), top.size() * sizeof(DLightNode)));
-            s->n_ltop = (int)order.size();
-        }
         std::vector<uint32_t> tr = s->lbvh.bit_trails;
         if (tr.empty()) tr.resize(1);
         HIP_TRY(s->trails.upload(tr.data(), tr.size() * 4));
@@ -950,8 +921,6 @@ extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene**
     D.n_lights = d->n_lights;
     D.n_materials = d->n_materials;
     D.lnodes = s->lnodes.as<DLightNode>();
-    D.ltop = s->ltop.as<DLightNode>();
-    D.n_ltop = s->n_ltop;
     D.bit_trails = s->trails.as<uint32_t>();
     D.infinite_lights = s->infinite.as<int>();
     D.num_bvh_lights = s->lbvh.num_bvh;

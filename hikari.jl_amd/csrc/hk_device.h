@@ -1780,19 +1780,7 @@ HKD DLightNode load_light_node(const DLightNode* __restrict__ nodes, int idx0) {
     n.r2 = b.x, n.w[0] = b.y, n.w[1] = b.z, n.w[2] = b.w;
     n.phi = c.x, n.cos_o = c.y, n.cos_e = c.z, n.sin_o = c.w;
     n.bits = __float_as_uint(d.x), n.child1_or_light = __float_as_uint(d.y);
-    n.pad[0] = __float_as_uint(d.z), n.pad[1] = __float_as_uint(d.w);
-    return n;
-}
-// the same record from k_light_select's LDS copy of the tree's top (one array per 16-byte part: 64 lanes at 64 nodes spread over the banks)
-HKD DLightNode load_light_node_lds(const lds_float4* __restrict__ top, uint32_t t) {
-    const hk_f4v a = top[t], b = top[HK_LTOP_N + t], c = top[2 * HK_LTOP_N + t], d = top[3 * HK_LTOP_N + t];
-    DLightNode n;
-    n.centre[0] = a.x, n.centre[1] = a.y, n.centre[2] = a.z, n.half_diag = a.w;
-    n.r2 = b.x, n.w[0] = b.y, n.w[1] = b.z, n.w[2] = b.w;
-    n.phi = c.x, n.cos_o = c.y, n.cos_e = c.z, n.sin_o = c.w;
-    n.bits = __float_as_uint(d.x), n.child1_or_light = __float_as_uint(d.y);
-    n.pad[0] = __float_as_uint(d.z), n.pad[1] = __float_as_uint(d.w);
-    asm volatile("" : "+v"(n.bits));   // keeps this arm a DS load (see NodeCache: merged with the global arm it becomes one flat load)
+    n.pad[0] = n.pad[1] = 0u;
     return n;
 }
 HKD int bvh_sample_light(const DScene& sc, v3 p, v3 n, float u, float& pmf_out, unsigned& visited) {

@@ -2072,16 +2072,7 @@ __global__ void __launch_bounds__(256) k_escaped(DPathState st, DScene sc, DTabl
 #define HK_SELECT_MIN_IDLE 24
 #endif
 template <bool FT>
-__global__ void __launch_bounds__(256) k_light_select(DPathState st, DScene sc, DTables T, DFrame fr, DSobol sob, int depth, uint32_t kinds_mask, int min_idle, int use_top, DStats* stats) {
-    // the top levels of the light BVH (every vertex walks them) in LDS: the descent waits for two 64-byte node loads per level
-    __shared__ float4 lds_top[4 * HK_LTOP_N];
-    const int n_top = use_top ? sc.n_ltop : 0;
-    for (int i = threadIdx.x; i < n_top; i += 256) {
-        const float4* q = reinterpret_cast<const float4*>(sc.ltop + i);
-        lds_top[i] = q[0], lds_top[HK_LTOP_N + i] = q[1], lds_top[2 * HK_LTOP_N + i] = q[2], lds_top[3 * HK_LTOP_N + i] = q[3];
-    }
-    __syncthreads();
-    const lds_float4* const top = (const lds_float4*)lds_top;
+__global__ void __launch_bounds__(256) k_light_select(DPathState st, DScene sc, DTables T, DFrame fr, DSobol sob, int depth, uint32_t kinds_mask, int min_idle, DStats* stats) {
     const int lane = lane_id();
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     unsigned n_lnodes = 0;
@@ -2096,7 +2087,7 @@ __global__ void __launch_bounds__(256) k_light_select(DPathState st, DScene sc, 
         bool more = true;
         // per-lane descent state
         bool busy = false, done = false;
-        uint32_t slot = 0, bits = 0, child = 0, trefs = 0xFFFFFFFFu;   // trefs: where the current node's children are in the LDS copy
+        uint32_t slot = 0, bits = 0, child = 0;
         int ni = 1, res_light = 0, lvl = 0;
         float ub = 0.0f, pmf = 0.0f, res_pmf = 0.0f;
         v3 p = mk3(0, 0, 0), nn = mk3(0, 0, 1);
@@ -2149,7 +2140,6 @@ __global__ void __launch_bounds__(256) k_light_select(DPathState st, DScene sc, 
                             ni = 1;
                             const DLightNode root = load_light_node(sc.lnodes, 0);
                             bits = root.bits, child = root.child1_or_light;
-                            trefs = n_top > 0 ? __float_as_uint(lds_top[3 * HK_LTOP_N].z) : 0xFFFFFFFFu;
                             lvl = 0;
                             done = false;
                         }
@@ -2175,10 +2165,7 @@ __global__ void __launch_bounds__(256) k_light_select(DPathState st, DScene sc, 
                 } else {
                     ++lvl;
                     const int c0i = ni + 1, c1i = (int)child;
-                    const uint32_t t0 = trefs & 0xFFFFu, t1 = trefs >> 16;
-                    DLightNode n0, n1;
-                    if (t0 != 0xFFFFu) n0 = load_light_node_lds(top, t0); else n0 = load_light_node(sc.lnodes, c0i - 1);
-                    if (t1 != 0xFFFFu) n1 = load_light_node_lds(top, t1); else n1 = load_light_node(sc.lnodes, c1i - 1);
+                    const DLightNode n0 = load_light_node(sc.lnodes, c0i - 1), n1 = load_light_node(sc.lnodes, c1i - 1);
                     const float c0 = node_importance(n0, p, nn);
                     const float c1 = node_importance(n1, p, nn);
                     n_lnodes += 2;
@@ -2192,12 +2179,12 @@ __global__ void __launch_bounds__(256) k_light_select(DPathState st, DScene sc, 
                             pmf *= p0;
                             ub = ub / p0;
                             ni = c0i;
-                            bits = n0.bits, child = n0.child1_or_light, trefs = n0.pad[0];
+                            bits = n0.bits, child = n0.child1_or_light;
                         } else {
                             pmf *= (1.0f - p0);
                             ub = (ub - p0) / (1.0f - p0);
                             ni = c1i;
-                            bits = n1.bits, child = n1.child1_or_light, trefs = n1.pad[0];
+                            bits = n1.bits, child = n1.child1_or_light;
                         }
                     }
                 }
@@ -4549,14 +4536,12 @@ bool preselect_lights(const DScene& sc, const DPathState& st) {
 void launch_light_select(hipStream_t s, int n_cu, const DPathState& st, const DScene& sc, const DTables& T, const DFrame& fr, const DSobol& sob, int depth, uint32_t kinds_mask, DStats* stats) {
     int min_idle = HK_SELECT_MIN_IDLE;
     if (const char* e = std::getenv("HK_SELECT_MIN_IDLE")) min_idle = std::atoi(e) >= 1 && std::atoi(e) <= 64 ? std::atoi(e) : min_idle;
-    int use_top = 1;   // HK_LIGHT_TOP=0: every node of the light BVH from global memory (A/B switch, read per launch)
-    if (const char* e = std::getenv("HK_LIGHT_TOP")) use_top = std::atoi(e) ? 1 : 0;
     if (sobol_tables_cover(sob, depth)) {
         const int blocks = cached_blocks<k_light_select<true>>(256, n_cu, 8);
-        hipLaunchKernelGGL(k_light_select<true>, dim3(clamp_blocks(blocks, st)), dim3(256), 0, s, st, sc, T, fr, sob, depth, kinds_mask, min_idle, use_top, stats);
+        hipLaunchKernelGGL(k_light_select<true>, dim3(clamp_blocks(blocks, st)), dim3(256), 0, s, st, sc, T, fr, sob, depth, kinds_mask, min_idle, stats);
     } else {
         const int blocks = cached_blocks<k_light_select<false>>(256, n_cu, 8);
-        hipLaunchKernelGGL(k_light_select<false>, dim3(clamp_blocks(blocks, st)), dim3(256), 0, s, st, sc, T, fr, sob, depth, kinds_mask, min_idle, use_top, stats);
+        hipLaunchKernelGGL(k_light_select<false>, dim3(clamp_blocks(blocks, st)), dim3(256), 0, s, st, sc, T, fr, sob, depth, kinds_mask, min_idle, stats);
     }
 }
 void launch_shade(hipStream_t s, int n_cu, int kind, const DPathState& st, const DScene& sc, const DTables& T, const DFrame& fr, const DSobol& sob, int depth, int first_kind, DStats* stats) {

@@ -104,9 +104,8 @@ struct DLightNode {
     float phi, cos_o, cos_e, sin_o;
     uint32_t bits;              // bit0 two_sided, bit1 is_leaf
     uint32_t child1_or_light;   // 1-based
-    uint32_t pad[2];            // [0]: positions of child0 | child1 << 16 in DScene::ltop (0xffff: not there); [1]: this node's 1-based index in DScene::lnodes
+    uint32_t pad[2];
 };
-#define HK_LTOP_N 512            // nodes of the light BVH's top levels that k_light_select keeps in LDS (32 KB per block)
 
 struct DMedium {
     int kind;
@@ -162,8 +161,6 @@ struct DScene {
     int n_lights;
     int n_materials;
     const DLightNode* lnodes;
-    const DLightNode* ltop;     // the top levels of the light BVH, breadth-first (whole levels, <= HK_LTOP_N nodes): k_light_select's LDS copy
-    int n_ltop;
     const uint32_t* bit_trails;
     const int* infinite_lights;
     int num_bvh_lights, num_infinite_lights;

@@ -671,7 +671,7 @@ def test_light_preselection_is_result_neutral(hk, monkeypatch):
     kw = dict(max_depth=5, samples=64)
 
     def run(env):
-        for k in ("HK_PRESELECT", "HK_SELECT_MIN_IDLE", "HK_SOBOL_TABLE_ONLY", "HK_LIGHT_TOP"):
+        for k in ("HK_PRESELECT", "HK_SELECT_MIN_IDLE", "HK_SOBOL_TABLE_ONLY"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -687,12 +687,11 @@ def test_light_preselection_is_result_neutral(hk, monkeypatch):
 
     ref, nodes = run({"HK_PRESELECT": "0"})
     assert np.isfinite(ref).all() and ref.max() > 0 and nodes > 0
-    for env in ({}, {"HK_SELECT_MIN_IDLE": "1"}, {"HK_SELECT_MIN_IDLE": "64"}, {"HK_SOBOL_TABLE_ONLY": "0"}, {"HK_SOBOL_TABLE_ONLY": "0", "HK_PRESELECT": "0"},
-                {"HK_LIGHT_TOP": "0"}, {"HK_LIGHT_TOP": "0", "HK_SELECT_MIN_IDLE": "7"}):     # (the top of the light BVH from LDS or from global memory)
+    for env in ({}, {"HK_SELECT_MIN_IDLE": "1"}, {"HK_SELECT_MIN_IDLE": "64"}, {"HK_SOBOL_TABLE_ONLY": "0"}, {"HK_SOBOL_TABLE_ONLY": "0", "HK_PRESELECT": "0"}):
         got, n2 = run(env)
         assert np.array_equal(ref.view(np.uint32), got.view(np.uint32)), env
         assert n2 == nodes, (env, n2, nodes)                            # the same node evaluations, wherever they run
-    for k in ("HK_PRESELECT", "HK_SELECT_MIN_IDLE", "HK_SOBOL_TABLE_ONLY", "HK_LIGHT_TOP"):
+    for k in ("HK_PRESELECT", "HK_SELECT_MIN_IDLE", "HK_SOBOL_TABLE_ONLY"):
         monkeypatch.delenv(k, raising=False)
 
 

@@ -1305,6 +1305,9 @@ int ensure_state(hk_integrator* I, int capacity, bool media, bool open_scene, hi
     I->st_capacity = capacity;
     I->st_depth = I->p.max_depth;
     I->st_media = media ? 1 : 0;
+    if (std::getenv("HK_DEBUG_ALLOC"))
+        std::fprintf(stderr, "HK_DEBUG_ALLOC capacity %d Q %zu: ray_o %p ray_d %p beta %p hit %p sh_o %p L %p medium_q %p mat_q %p counters %p\n", capacity, Q, (void*)s.gen[0].ray_o,
+                     (void*)s.gen[0].ray_d, (void*)s.gen[0].beta, (void*)s.hit, (void*)s.sh_o, (void*)s.L, (void*)s.medium_q, (void*)s.mat_q, (void*)s.counters);
     return HK_OK;
 }
 int ceil_log2(long v) {
@@ -1408,8 +1411,8 @@ extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_
             lane_idx = c->next_lane % n_lanes;
             c->next_lane = (lane_idx + 1) % n_lanes;
             hk_ctx::Lane& L = c->lanes[lane_idx];
-            if (!L.stream) {
-                HIP_TRY(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+            if (!L.stream) HIP_TRY(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+            if (!L.done) {
                 HIP_TRY(hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
                 std::vector<DStats> zero((size_t)c->stat_rows);
                 std::memset(zero.data(), 0, zero.size() * sizeof(DStats));
@@ -1419,8 +1422,9 @@ extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_
                 HIP_TRY(hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming));
                 HIP_TRY(hipEventCreateWithFlags(&c->ev_film, hipEventDisableTiming));
             }
-        } else if (int e = join_lanes(c))
-            return e;
+        } else {
+            if (int e = join_lanes(c)) return e;
+        }
     }
     const bool piped = lane_idx >= 0;
     // the lane's path-state set stands in for the integrator's own for the duration of this call

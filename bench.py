@@ -18,10 +18,10 @@ N > 1: one process per GPU; rank g renders the sample indices g+1, g+1+N, ... of
   --scaling weak: every rank renders 256 spp (N x 256 in the reduced film).
 The reduce is the library's own hk_film_reduce (ncclReduce over xGMI on the render stream; torch.distributed only carries the
 128-byte communicator id and the final statistics, and its own reduce is the untimed cross-check of the result).
-On ONE GPU the default run then renders one warm frame of every other BASELINE.json config (`configs`: the two-spheres Cornell, the cloud,
-the sky, the many-light scene — each with its rooflines) and, LAST, measures the one-sample-per-call path of every config (`progressive`:
-hk_render(first = i, n = 1), what an interactive viewer drives; small calls come after all full frames because a process that has rendered
-a small pass runs later full-size cloud frames 7 % slower — measured, not understood: see the comment in main()).
+On ONE GPU the default run then reports every other BASELINE.json config (`configs`: the two-spheres Cornell, the cloud, the sky, the
+many-light scene — seconds per frame, Mrays/s, class times, rooflines, the one-sample-per-call path), each measured by `bench.py --config X`
+in a child process of its own (the cloud frame has two speeds, decided when a process allocates its path state: DESIGN.md §5), and, last,
+the one-sample-per-call path of the bench scene (`progressive`: hk_render(first = i, n = 1), what an interactive viewer drives).
 value = rays of all ranks / max-over-ranks time of the K steps.  Scene, BVH and sampler tables live in HBM before the timed region
 starts; `cold_frame_seconds` is a frame that has to rebuild the sample-bit table first (a one-shot render of a new sample range).
 """
@@ -371,6 +371,26 @@ def progressive_of(hk, torch, device, scene, film, cam, depth, spp, seconds, cal
         vp.close()
 
 
+def child_config_line(config, progressive_calls):
+    """`bench.py --config <config>` in a child process (one warm frame timed, its class times, rooflines and one-sample-per-call path):
+    the fields of its JSON line that a `configs` entry carries."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--config", config, "--steps", "1", "--warmup", "2", "--no-cpu-baseline",
+           "--progressive", str(progressive_calls)]
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE"):
+        env.pop(k, None)
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    if out.returncode != 0:
+        raise RuntimeError("exit code %d: %s" % (out.returncode, out.stderr.decode(errors="replace")[-300:]))
+    d = json.loads(out.stdout.decode().strip().splitlines()[-1])
+    cfg = d["config"]
+    return {"config": config, "workload": cfg["workload"], "resolution": cfg["resolution"], "max_depth": cfg["max_depth"], "spp_per_frame": cfg["spp_per_frame"],
+            "triangles": cfg["triangles"], "lights": cfg["lights"], "frames_timed": d["steps"], "seconds_per_frame": d["seconds_per_frame"],
+            "cold_frame_seconds": d["cold_frame_seconds"], "value": d["value"], "unit": d["unit"], "rays": d["rays"],
+            "kernel_seconds": d["roofline"]["kernel_seconds"], "setup_seconds": d["setup_seconds"], "roofline": d["roofline"], "rooflines": d["rooflines"],
+            "progressive": d.get("progressive"), "measured_in": "a process of its own (bench.py --config %s)" % config}
+
+
 def main():
     args = parse_args()
     world_env = os.environ.get("WORLD_SIZE")
@@ -633,35 +653,37 @@ def main():
     vp.close()
     if result is not None:
         if args.extra_configs and world == 1:
-            # the other north_star targets, one warm frame each, driver-visible in the same line (headline fields above are untouched)
+            # the other north_star targets, driver-visible in the same line (headline fields above are untouched).  Each config is
+            # measured by `bench.py --config X` in a PROCESS OF ITS OWN — a child started here once this process has given its device
+            # memory back, never an exec of this one — exactly what `tools/profile_round.sh` does for the committed profiles: the cloud
+            # frame has two speeds (0.639 s / 0.683 s, decided when a process allocates the path state: DESIGN.md §5 "two speeds"), and
+            # a process that has already rendered other configs or small passes reliably draws the slow one.  If a child cannot be
+            # run, the config is measured in this process instead (`measured_in` says which).
             del accum
             torch.cuda.empty_cache()
             result["configs"] = []
-            for c in os.environ.get("HK_BENCH_EXTRAS", "cloud,sky,manylight,cornell_two_spheres").split(","):
+            for c in os.environ.get("HK_BENCH_EXTRAS", "cornell_two_spheres,cloud,sky,manylight").split(","):
+                line = None
                 try:
-                    result["configs"].append(one_frame_line(hk, scenes, torch, c, local_rank))
+                    line = child_config_line(c, min(args.progressive, 32))
                 except Exception as e:           # noqa: BLE001
-                    result["configs"].append({"config": c, "error": "%s: %s" % (type(e).__name__, e)})
-        # ---- the one-sample-per-call path, AFTER every full frame of the run.  Measured (round 4): the cloud frame has two
-        #      speeds, 0.639 s and 0.683 s (its tracking kernels 7 - 9 % slower), fixed for the life of a path-state ALLOCATION: the same device
-        #      scene rendered by a new integrator can switch from one to the other.  A process that has rendered a small pass (or the
-        #      two-spheres Cornell frames) before gets the slow one every time, a fresh process mostly the fast one; the library's own state is
-        #      not involved (a new context changes nothing) — physical placement of the path-state arrays is the suspect.  Hence the order:
-        #      cloud first, small calls last ----
+                    sys.stderr.write("bench.py: %s in its own process failed (%s: %s); measuring it in this process\n" % (c, type(e).__name__, e))
+                if line is None:
+                    try:
+                        line = one_frame_line(hk, scenes, torch, c, local_rank)
+                        inp = line.pop("_progressive_inputs", None)
+                        if inp is not None and args.progressive > 0:
+                            line["progressive"] = progressive_of(hk, torch, local_rank, *inp, calls=min(args.progressive, 32))
+                        line["measured_in"] = "the bench line's process"
+                    except Exception as e:       # noqa: BLE001
+                        line = {"config": c, "error": "%s: %s" % (type(e).__name__, e)}
+                result["configs"].append(line)
         if world == 1 and args.progressive > 0 and not args.spp_per_pass:
+            # the one-sample-per-call path of the bench scene, after every full frame this process renders
             try:
                 result["progressive"] = progressive_of(hk, torch, local_rank, scene, film, cam, DEPTH, frame_spp, per_frame, args.progressive)
             except Exception as e:               # noqa: BLE001
                 result["progressive"] = {"error": "%s: %s" % (type(e).__name__, e)}
-            for line in result.get("configs", []):
-                inp = line.pop("_progressive_inputs", None)
-                if inp is not None:
-                    try:
-                        line["progressive"] = progressive_of(hk, torch, local_rank, *inp, calls=min(args.progressive, 32))
-                    except Exception as e:       # noqa: BLE001
-                        line["progressive"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        for line in result.get("configs", []):
-            line.pop("_progressive_inputs", None)
         print(json.dumps(result))
         sys.stdout.flush()
     return result

@@ -190,6 +190,9 @@ struct hk_integrator {
     DPathState st{};
     std::vector<DevBuf*> bufs;
     int st_capacity = 0, st_depth = 0, st_media = -1;   // what the retained path state was allocated for
+    int slab_mode = 0;         // 0: one allocation per array; 1: measuring the slab; 2: carving it
+    void* slab_base = nullptr;
+    size_t slab_off = 0;
     DevBuf sobol_table;  // DSobol::hi_table
     int sobol_rows = 0, sobol_stride = 0, sobol_log2 = -1, sobol_digits = -1, sobol_x0 = -1, sobol_y0 = -1, sobol_tiles_x = -1;
     DevBuf sobol_lo;     // DSobol::lo_table
@@ -1205,8 +1208,15 @@ extern "C" int32_t hk_denoise(hk_ctx* c, const hk_denoise_params* P, int32_t w, 
 
 // ---- path state -----------------------------------------------------------------------------------------
 namespace {
+// HK_STATE_SLAB=1 (experiment, DESIGN.md §5 "two speeds"): the path-state arrays are carved from ONE allocation instead of ~40
 template <class T>
 hipError_t alloc_arr(hk_integrator* I, T*& dst, size_t n) {
+    if (I->slab_mode != 0) {
+        const size_t bytes = (n * sizeof(T) + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+        dst = I->slab_mode == 2 ? reinterpret_cast<T*>(static_cast<char*>(I->slab_base) + I->slab_off) : nullptr;
+        I->slab_off += bytes;
+        return hipSuccess;
+    }
     DevBuf* b = new DevBuf();
     I->bufs.push_back(b);
     hipError_t e = b->alloc(n * sizeof(T));
@@ -1249,59 +1259,83 @@ int ensure_state(hk_integrator* I, int capacity, bool media, bool open_scene, hi
     s.n_waves = W;
     s.wave_cap = ((chunks + W - 1) / W) * 64;
     const size_t Q = (size_t)W * s.wave_cap;
-    for (int gidx = 0; gidx < 2; ++gidx) {   // two generations of path records in queue order (DPathGen)
-        DPathGen& g = s.gen[gidx];
-        HIP_TRY(alloc_arr(I, g.ray_o, Q));
-        HIP_TRY(alloc_arr(I, g.ray_d, Q));
-        HIP_TRY(alloc_arr(I, g.beta, Q));
-        HIP_TRY(alloc_arr(I, g.r_u, Q));
-        HIP_TRY(alloc_arr(I, g.r_l, Q));
-#if HK_LAMBDA_BY_SLOT
-        g.lambda = nullptr;
-#else
-        HIP_TRY(alloc_arr(I, g.lambda, Q));
-#endif
-        HIP_TRY(alloc_arr(I, g.meta, Q));
-    }
-    HIP_TRY(alloc_arr(I, s.hit, Q));
-    HIP_TRY(alloc_arr(I, s.mat_id, Q));
-    s.sel_light = nullptr;
-    if (!media) HIP_TRY(alloc_arr(I, s.sel_light, Q));   // k_light_select's results (8 B per entry)
-    HIP_TRY(alloc_arr(I, s.lambda_s, P));
-    s.pdf = nullptr;   // recomputed from lambda_s by k_film
-    HIP_TRY(alloc_arr(I, s.L, P));
-    HIP_TRY(alloc_arr(I, s.filter_w, P));
-    HIP_TRY(alloc_arr(I, s.sh_o, Q));
-    HIP_TRY(alloc_arr(I, s.sh_d, Q));
-    HIP_TRY(alloc_arr(I, s.sh_Ld, Q));
-    HIP_TRY(alloc_arr(I, s.sh_ru, Q));
-    HIP_TRY(alloc_arr(I, s.sh_rl, Q));
-    HIP_TRY(alloc_arr(I, s.sh_slot, Q));
-    s.sh_T = nullptr, s.sh_aux = nullptr, s.sh_it = nullptr, s.wq_a = nullptr, s.wq_b = nullptr, s.wq_ctl = nullptr;
-    if (want_split) {   // the split shadow walk of grey media (92 B per record; off by default)
-        HIP_TRY(alloc_arr(I, s.sh_T, Q));
-        HIP_TRY(alloc_arr(I, s.sh_aux, Q));
-        HIP_TRY(alloc_arr(I, s.sh_it, 4 * Q));
-        // worst case of gq_out_push: a chunk of 256 entries is closed (padded) as soon as the next push of up to 64 does not fit, so 193
-        // pushes can use up 256 entries, plus one open chunk per resident wave (at most 32 waves per CU)
-        const size_t wq_n = (Q / 193 + 1) * 256 + (size_t)256 * 32 * (size_t)n_cu;
-        HIP_TRY(alloc_arr(I, s.wq_a, wq_n));
-        HIP_TRY(alloc_arr(I, s.wq_b, wq_n));
-        HIP_TRY(alloc_arr(I, s.wq_ctl, (size_t)(I->p.max_depth + 2) * 11 * 4));
-    }
-    HIP_TRY(alloc_arr(I, s.escaped_q, Q));
-    HIP_TRY(alloc_arr(I, s.medium_q, Q));
-    HIP_TRY(alloc_arr(I, s.scatter_q, Q));
-    s.ticket_rows = I->p.max_depth + 2;
-    HIP_TRY(alloc_arr(I, s.tickets, (size_t)s.ticket_rows * HK_TICKET_COLS * HK_TICKET_WAYS * HK_TICKET_STRIDE));
-    HIP_TRY(alloc_arr(I, s.initial_medium, 1));
-    HIP_TRY(hipMemset(s.initial_medium, 0xff, sizeof(int)));
-    HIP_TRY(alloc_arr(I, s.mat_q, Q * HK_MAX_KINDS));
-    size_t nc = (size_t)(I->p.max_depth + 2) * Q_COUNT * W;
-    HIP_TRY(alloc_arr(I, s.counters, nc));
-    HIP_TRY(hipMemset(s.counters, 0, nc * sizeof(int)));
-    HIP_TRY(alloc_arr(I, s.seg_list, nc));
-    HIP_TRY(alloc_arr(I, s.seg_list_n, (size_t)(I->p.max_depth + 2) * Q_COUNT));
+    auto layout = [&]() -> int {
+        for (int gidx = 0; gidx < 2; ++gidx) {   // two generations of path records in queue order (DPathGen)
+            DPathGen& g = s.gen[gidx];
+            HIP_TRY(alloc_arr(I, g.ray_o, Q));
+            HIP_TRY(alloc_arr(I, g.ray_d, Q));
+            HIP_TRY(alloc_arr(I, g.beta, Q));
+            HIP_TRY(alloc_arr(I, g.r_u, Q));
+            HIP_TRY(alloc_arr(I, g.r_l, Q));
+    #if HK_LAMBDA_BY_SLOT
+            g.lambda = nullptr;
+    #else
+            HIP_TRY(alloc_arr(I, g.lambda, Q));
+    #endif
+            HIP_TRY(alloc_arr(I, g.meta, Q));
+        }
+        HIP_TRY(alloc_arr(I, s.hit, Q));
+        HIP_TRY(alloc_arr(I, s.mat_id, Q));
+        s.sel_light = nullptr;
+        if (!media) HIP_TRY(alloc_arr(I, s.sel_light, Q));   // k_light_select's results (8 B per entry)
+        HIP_TRY(alloc_arr(I, s.lambda_s, P));
+        s.pdf = nullptr;   // recomputed from lambda_s by k_film
+        HIP_TRY(alloc_arr(I, s.L, P));
+        HIP_TRY(alloc_arr(I, s.filter_w, P));
+        HIP_TRY(alloc_arr(I, s.sh_o, Q));
+        HIP_TRY(alloc_arr(I, s.sh_d, Q));
+        HIP_TRY(alloc_arr(I, s.sh_Ld, Q));
+        HIP_TRY(alloc_arr(I, s.sh_ru, Q));
+        HIP_TRY(alloc_arr(I, s.sh_rl, Q));
+        HIP_TRY(alloc_arr(I, s.sh_slot, Q));
+        s.sh_T = nullptr, s.sh_aux = nullptr, s.sh_it = nullptr, s.wq_a = nullptr, s.wq_b = nullptr, s.wq_ctl = nullptr;
+        if (want_split) {   // the split shadow walk of grey media (92 B per record; off by default)
+            HIP_TRY(alloc_arr(I, s.sh_T, Q));
+            HIP_TRY(alloc_arr(I, s.sh_aux, Q));
+            HIP_TRY(alloc_arr(I, s.sh_it, 4 * Q));
+            // worst case of gq_out_push: a chunk of 256 entries is closed (padded) as soon as the next push of up to 64 does not fit, so 193
+            // pushes can use up 256 entries, plus one open chunk per resident wave (at most 32 waves per CU)
+            const size_t wq_n = (Q / 193 + 1) * 256 + (size_t)256 * 32 * (size_t)n_cu;
+            HIP_TRY(alloc_arr(I, s.wq_a, wq_n));
+            HIP_TRY(alloc_arr(I, s.wq_b, wq_n));
+            HIP_TRY(alloc_arr(I, s.wq_ctl, (size_t)(I->p.max_depth + 2) * 11 * 4));
+        }
+        HIP_TRY(alloc_arr(I, s.escaped_q, Q));
+        HIP_TRY(alloc_arr(I, s.medium_q, Q));
+        HIP_TRY(alloc_arr(I, s.scatter_q, Q));
+        s.ticket_rows = I->p.max_depth + 2;
+        HIP_TRY(alloc_arr(I, s.tickets, (size_t)s.ticket_rows * HK_TICKET_COLS * HK_TICKET_WAYS * HK_TICKET_STRIDE));
+        HIP_TRY(alloc_arr(I, s.initial_medium, 1));
+        if (I->slab_mode != 1) HIP_TRY(hipMemset(s.initial_medium, 0xff, sizeof(int)));
+        HIP_TRY(alloc_arr(I, s.mat_q, Q * HK_MAX_KINDS));
+        size_t nc = (size_t)(I->p.max_depth + 2) * Q_COUNT * W;
+        HIP_TRY(alloc_arr(I, s.counters, nc));
+        if (I->slab_mode != 1) HIP_TRY(hipMemset(s.counters, 0, nc * sizeof(int)));
+        HIP_TRY(alloc_arr(I, s.seg_list, nc));
+        HIP_TRY(alloc_arr(I, s.seg_list_n, (size_t)(I->p.max_depth + 2) * Q_COUNT));
+        return HK_OK;
+    };
+    const char* slab_env = std::getenv("HK_STATE_SLAB");
+    if (slab_env && std::atoi(slab_env)) {
+        I->slab_mode = 1, I->slab_off = 0;
+        if (int e = layout()) {
+            I->slab_mode = 0;
+            return e;
+        }
+        DevBuf* slab = new DevBuf();
+        I->bufs.push_back(slab);
+        const hipError_t he = slab->alloc(I->slab_off);
+        if (he != hipSuccess) {
+            I->slab_mode = 0;
+            return fail(HK_ERR_DEVICE, "path-state slab allocation failed");
+        }
+        I->slab_base = slab->p;
+        I->slab_mode = 2, I->slab_off = 0;
+        const int e = layout();
+        I->slab_mode = 0;
+        if (e) return e;
+    } else if (int e = layout())
+        return e;
     I->st_capacity = capacity;
     I->st_depth = I->p.max_depth;
     I->st_media = media ? 1 : 0;

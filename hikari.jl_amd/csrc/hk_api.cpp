@@ -276,6 +276,10 @@ extern "C" int32_t hk_ctx_destroy(hk_ctx* c) {
 extern "C" int32_t hk_ctx_set_tables(hk_ctx* c, const hk_tables* t) {
     if (!c || !t || !t->sobol_matrices || t->sobol_count < 104 || !t->cie_x || !t->rgb2spec_coeffs) return fail(HK_ERR_INVALID, "bad tables");
     HIP_TRY(hipSetDevice(c->device));
+    if (c->lanes_dirty) {   // renders in flight on the lanes read the tables that are about to be replaced
+        if (int e = join_lanes(c)) return e;
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
     HIP_TRY(c->sobol.upload(t->sobol_matrices, 104 * sizeof(uint32_t)));  // only Sobol dims 0,1 are ever read
     std::vector<float> cie(3 * 471);
     std::memcpy(&cie[0], t->cie_x, 471 * 4);

@@ -1247,6 +1247,22 @@ int ensure_state(hk_integrator* I, int capacity, bool media, bool open_scene, hi
     I->st.dynamic_segments = (media || !open_scene) ? 1 : 0;
     if (const char* e = std::getenv("HK_DYNAMIC_SEGMENTS")) I->st.dynamic_segments = std::atoi(e) ? 1 : 0;
     I->st.compact = media ? 0 : 1;
+    {   // a SMALL pass (at most 16 chunks for each of 4 waves per CU: a one-sample call at 800^2) hands segment g to wave g of every launch
+        // (static stride where a grid is smaller): the 17 k_segment_lists launches of a call and the ticket round trips go, and the segment
+        // count no longer has to stay below every kernel's residency, so it can be as fine as the latency of one wave's chunk wants it —
+        // HK_SMALL_PASS_WAVES per CU.  HK_SMALL_PASS=0: lists and tickets as ever.
+        const char* e = std::getenv("HK_SMALL_PASS");
+        const bool small = W_want <= 4L * n_cu && !(e && std::atoi(e) == 0) && std::getenv("HK_DYNAMIC_SEGMENTS") == nullptr;   // (an explicit HK_DYNAMIC_SEGMENTS keeps lists / tickets: the tests' small films)
+        I->st.small_pass = small ? 1 : 0;
+        if (small) {
+            I->st.dynamic_segments = 0;
+            const char* w = std::getenv("HK_SMALL_PASS_WAVES");
+            long per_cu = w && std::atoi(w) > 0 ? std::atoi(w) : (media ? 4 : 8);   // (800^2, one sample per call, 8 lanes: Cornell 0.99 / 0.89 / 1.03 / 1.30 ms per call at 4 / 8 / 16 / 32, cloud 12.6 / 13.8 / 17.9 / 19.6)
+            const long chunks = ((long)capacity + 63) / 64;
+            while (per_cu > 4 && per_cu * n_cu > chunks) per_cu /= 2;   // (no segment without a chunk)
+            if (I->ctx->waves_per_cu <= 0) W_want = (per_cu * n_cu + 3) / 4 * 4;
+        }
+    }
     const char* split_env = std::getenv("HK_WALK_SPLIT");
     const bool want_split = media && split_env && std::atoi(split_env);
     // the retained state must be of the same flavour: a state allocated for a scene with media has no sel_light (k_light_select would
@@ -1633,6 +1649,7 @@ extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_
             if (kinds_of_depth)
                 for (int kind = 0; kind < HK_MAX_KINDS; ++kind)
                     if (sc->kinds_mask & (1u << kind)) dd[n] = kd, qq[n] = Q_MAT0 + kind, ++n;
+            if (I->st.small_pass) return HK_OK;
             return timed(3, [&] { hk::launch_segment_lists(s, I->st, n, dd, qq); });
         };
         if (lists({{0, Q_RAY}}) != HK_OK) return fail(HK_ERR_DEVICE, "event record failed");

@@ -85,8 +85,10 @@ __device__ __forceinline__ const int* seg_list_ptr(const DPathState& st, int dep
 __device__ __forceinline__ SegTickets seg_open(const DPathState& st, int* cnt, bool dynamic, int depth, int q) {
     SegTickets it;
     it.cnt = cnt;
-    it.list = depth >= 0 ? seg_list_ptr(st, depth, q) : nullptr;
-    it.n = depth >= 0 ? st.seg_list_n[depth * Q_COUNT + q] : st.n_waves;
+    const bool lists = depth >= 0 && st.small_pass == 0;
+    it.list = lists ? seg_list_ptr(st, depth, q) : nullptr;
+    it.n = lists ? st.seg_list_n[depth * Q_COUNT + q] : st.n_waves;
+    if (st.small_pass) dynamic = false;
     it.k0 = global_wave() & (HK_TICKET_WAYS - 1);
     it.pos = global_wave();
     it.step = dynamic ? 0 : physical_waves();

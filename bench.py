@@ -595,7 +595,7 @@ def main():
         copy_gbs = 10 * 2 * a.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del a, b
         roofline = dict(next(e for e in rooflines if e["kernel"] == KERNEL_OF_CLASS[dom]))
-        roofline.update({"measured_copy_gbs": round(copy_gbs, 1), "frac_of_measured_copy": round(roofline["achieved"] / copy_gbs, 5),
+        roofline.update({"measured_copy_gbs": round(copy_gbs, 1), "frac_of_measured_copy": round(roofline["achieved"] / copy_gbs, 5) if roofline.get("bound") == "hbm" and roofline.get("achieved") else None,
                          "nodes_per_cast": round(int(sc.trace_nodes) / max(int(sc.rays_closest), 1), 2),
                          "tris_per_cast": round(int(sc.trace_tris) / max(int(sc.rays_closest), 1), 2),
                          "kernel_seconds": {k: round(v, 4) for k, v in timed.items()}})

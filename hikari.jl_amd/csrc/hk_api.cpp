@@ -190,6 +190,7 @@ struct hk_integrator {
     DPathState st{};
     std::vector<DevBuf*> bufs;
     int st_capacity = 0, st_depth = 0, st_media = -1;   // what the retained path state was allocated for
+    bool mid_pass = false;                              // the current pass is a mid-size one of a closed scene (ensure_state): static stride, one stream
     int slab_mode = 0;         // 0: one allocation per array; 1: measuring the slab; 2: carving it
     void* slab_base = nullptr;
     size_t slab_off = 0;
@@ -1235,16 +1236,25 @@ hipError_t alloc_arr(hk_integrator* I, T*& dst, size_t n) {
 //   surfaces, open scene      static stride, 48 per CU   (sky: most paths escape after 1-2 vertices; finer segments only fragment
 //                             the per-kind queues: k_shade +7 % at 96, +15 % at 256, whichever way they are handed out)
 // HK_WAVES_PER_CU / HK_DYNAMIC_SEGMENTS override.  stats rows are indexed by PHYSICAL wave (ctx->stat_rows).
-int ensure_state(hk_integrator* I, int capacity, bool media, bool open_scene, hipStream_t users = nullptr) {
+int ensure_state(hk_integrator* I, int capacity, bool media, bool open_scene, bool small_scene, hipStream_t users = nullptr) {
     const int n_cu = I->ctx->n_cu;
-    const long cap_per_cu = media ? 96 : (open_scene ? 48 : 192);
+    // a closed scene's pass of at most HK_MID_PASS_PATHS_M (32) million paths — a rank's share of a frame under 8-way strong scaling —
+    // behaves like the open scene WHEN THE SCENE IS SMALL (BVH depth <= 16, the Cornell box): the deep bounces hold a few dozen rays per
+    // segment and every visit costs a chunk's latency, so fewer segments and the static stride win (800^2 x 32 spp: 16.3 -> 14.4 ms per
+    // frame; x 64: 27.9 -> 27.2; x 128 and x 256 prefer the tickets).  The 10^6-triangle scene's rays are too uneven for a static stride
+    // at any size (1024^2 x 32 spp: 115 -> 128 ms).
+    long mid_paths = 32L << 20;
+    if (const char* e = std::getenv("HK_MID_PASS_PATHS_M")) mid_paths = std::atol(e) >= 0 ? std::atol(e) << 20 : mid_paths;
+    const bool mid = !media && !open_scene && small_scene && (long)capacity <= mid_paths;
+    I->mid_pass = mid;
+    const long cap_per_cu = media ? 96 : ((open_scene || mid) ? 48 : 192);
     long W_want = ((long)(capacity + 63) / 64) / 16;
     if (W_want < 4L * n_cu) W_want = 4L * n_cu;
     if (W_want > cap_per_cu * n_cu) W_want = cap_per_cu * n_cu;
     if (const char* e = std::getenv("HK_WAVES_PER_CU")) I->ctx->waves_per_cu = std::atoi(e) > 0 ? std::atoi(e) : 0;   // read per call: tests toggle it
     if (I->ctx->waves_per_cu > 0) W_want = (long)I->ctx->waves_per_cu * n_cu;
     W_want = (W_want + 3) / 4 * 4;
-    I->st.dynamic_segments = (media || !open_scene) ? 1 : 0;
+    I->st.dynamic_segments = (media || (!open_scene && !mid)) ? 1 : 0;
     if (const char* e = std::getenv("HK_DYNAMIC_SEGMENTS")) I->st.dynamic_segments = std::atoi(e) ? 1 : 0;
     I->st.compact = media ? 0 : 1;
     {   // a SMALL pass (at most 16 chunks for each of 4 waves per CU: a one-sample call at 800^2) hands segment g to wave g of every launch
@@ -1490,7 +1500,7 @@ extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_
         }
     } set_guard{I, piped ? &I->lane_sets[lane_idx] : nullptr};
     if (piped) I->swap_set(I->lane_sets[lane_idx]);
-    int st = ensure_state(I, S * fr.n_pixels_padded, sc->d.n_media > 0, sc->d.has_escape_lights != 0, piped ? c->lanes[lane_idx].stream : nullptr);
+    int st = ensure_state(I, S * fr.n_pixels_padded, sc->d.n_media > 0, sc->d.has_escape_lights != 0, sc->d.bvh_depth <= 16, piped ? c->lanes[lane_idx].stream : nullptr);
     if (st != HK_OK) return st;
     fr.sample_stride = sample_stride;
     fr.max_depth = I->p.max_depth;
@@ -1660,7 +1670,7 @@ extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_
         // stream so that the class times add up.
         // (surfaces only: beside the long shadow walks of a media scene the next traversal only competes — cloud -4.5 %; Cornell +-0, sky +1 %, many-light +2.4 %)
         if (const char* e = std::getenv("HK_OVERLAP")) c->overlap = std::atoi(e) ? 1 : 0;
-        const bool overlap = c->overlap && !c->time_kernels && sc->d.n_lights > 0 && sc->d.n_media == 0 && !piped;
+        const bool overlap = c->overlap && !c->time_kernels && sc->d.n_lights > 0 && sc->d.n_media == 0 && !piped && !I->mid_pass;   // (a mid-size pass: the two streams only get in each other's way, 800^2 x 32 spp -4 %)
         if (overlap && !c->aux) {
             HIP_TRY(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
             HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));

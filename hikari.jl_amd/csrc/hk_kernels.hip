@@ -58,6 +58,9 @@ __device__ __forceinline__ int physical_waves() { return (int)(gridDim.x * (bloc
 // launch that visits all W segments pays a count-word round trip (plus a ticket) per empty one.  After every producer the host
 // launches k_segment_lists, which writes, per queue, the ascending list of its non-empty segments and their number; consumers
 // iterate over the list — statically (entry w, w + waves, ...) or by ticket — and never see an empty segment.
+#ifndef HK_TICKET_REFRESH
+#define HK_TICKET_REFRESH 0   // see seg_next
+#endif
 struct SegTickets {
     int* cnt;                   // HK_TICKET_WAYS (= 64: one per lane) counters, HK_TICKET_STRIDE ints apart
     unsigned long long alive;   // counters not yet seen exhausted (wave-uniform)
@@ -121,7 +124,16 @@ __device__ __forceinline__ int seg_next(SegTickets& it, int n_segments) {   // -
         t = __builtin_amdgcn_readfirstlane(t);
         it.k0 = k;
         if (t < per_k) return seg_entry(it, k + t * HK_TICKET_WAYS);
-        it.alive &= ~(1ull << k);   // counters only grow: exhausted once, exhausted for good
+        // counters only grow: exhausted once, exhausted for good.  At the end of a launch every wave finds that out one failed atomic at
+        // a time (up to 63 serial round trips).  HK_TICKET_REFRESH=1 re-reads all 64 counters with one parallel load after a failure
+        // instead: the deep bounces of a 32-spp Cornell frame lose 20 - 30 us per launch, the 256-spp frame and the many-light frame gain
+        // 0.5 %, but the 64 extra line reads per wave get in the way of the remaining atomics where launches are short and many — the
+        // cloud frame +3.6 %, Cornell at 64 spp +3 % — so it stays off (round 4, interleaved on one box).
+#if HK_TICKET_REFRESH
+        const int v = __hip_atomic_load(it.cnt + lane_id() * HK_TICKET_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        it.alive &= __ballot(v < seg_per_way(it.n, lane_id()));
+#endif
+        it.alive &= ~(1ull << k);
     }
     return n_segments;
 }

@@ -507,6 +507,15 @@ def test_full_size_properties(hk):
     assert np.allclose(w, w[0], rtol=1e-2) and w[0] > 0
     st = vp.stats()
     assert st.rays_closest >= 4 * 640000
+    # a pass this size of a small closed scene takes the static stride on one stream (hk_api.cpp ensure_state, "mid"); the tickets and
+    # the second stream of a full-size pass must give the same film, bit for bit
+    import os
+    os.environ["HK_MID_PASS_PATHS_M"] = "0"
+    try:
+        vp(s, film, cam)
+    finally:
+        del os.environ["HK_MID_PASS_PATHS_M"]
+    assert np.array_equal(a, film.framebuffer)
     vp.close()
 
 

@@ -266,7 +266,7 @@ def class_rooflines(config, timed, launches, sc, default_frame):
             e["note"] = "algorithmic bytes count every BVH node / triangle visit at full size (SURVEY 8d); nodes are served from LDS / L1 / L2, measured HBM traffic is the `traffic` field"
         if cls == "media":
             e["units"] = {"collisions": int(sc.track_collisions), "dda_steps": int(sc.track_dda_steps), "scatter_vertices": int(sc.scatter_vertices),
-                          "bytes_per_collision": 84, "bytes_per_dda_step": 4}
+                          "bytes_per_collision": {"nanovdb_scene": 84, "grid_scene": 36}, "bytes_per_dda_step": 4}   # (hk_stats prices each scene's collisions by its own media)
         if cls == "shadow" and walk:
             e["units"] = {"collisions": int(sc.shadow_collisions), "dda_steps": int(sc.shadow_dda_steps), "casts": int(sc.rays_shadow)}
         rooflines.append(e)

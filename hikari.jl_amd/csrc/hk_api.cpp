@@ -112,7 +112,6 @@ struct hk_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_events;   // class 0
     std::vector<std::pair<hipEvent_t, hipEvent_t>> class_events[5];  // 1 shadow, 2 shade, 3 other, 4 media
     uint64_t shadow_launches = 0, shade_launches = 0, media_launches = 0;
-    int nvdb_collisions = 0;              // a scene with a NanoVDB medium was rendered since the last hk_stats_reset (84 B per collision instead of 36)
     std::vector<hipEvent_t> event_pool;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool have_span = false;
@@ -1591,7 +1590,6 @@ extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_
             }
         }
     }
-    if (sc->d.media_mask & (1 << HK_MEDIUM_NANOVDB)) c->nvdb_collisions = 1;
     DCamera dc = make_camera(*cam);
     DStats* dstats = c->stats.as<DStats>();
     const int trace_blocks = c->n_cu, shade_blocks = c->n_cu, light_blocks = c->n_cu;  // launchers size the grid from residency
@@ -1802,7 +1800,6 @@ extern "C" int32_t hk_stats_reset(hk_ctx* c) {
     }
     c->seconds_trace = c->seconds_total = 0.0;
     c->trace_launches = c->shadow_launches = c->shade_launches = c->media_launches = 0;
-    c->nvdb_collisions = 0;
     c->have_span = false;
     return HK_OK;
 }
@@ -1833,6 +1830,8 @@ extern "C" int32_t hk_stats_get(hk_ctx* c, hk_stats* out) {
             h.sh_nodes += r.sh_nodes;
             h.sh_tris += r.sh_tris;
             h.sh_collisions += r.sh_collisions;
+            h.nvdb_collisions += r.nvdb_collisions;
+            h.sh_nvdb_collisions += r.sh_nvdb_collisions;
             h.dda_steps += r.dda_steps;
             h.sh_dda_steps += r.sh_dda_steps;
             h.scatter_vertices += r.scatter_vertices;
@@ -1901,9 +1900,10 @@ extern "C" int32_t hk_stats_get(hk_ctx* c, hk_stats* out) {
         // levels x 2 leaves); per majorant cell entered (DDA step) 4 B; the delta-tracking kernel reads and rewrites the path state
         // (2 x 104 B) once per tracked ray = per entry of the medium queue, which is what `track_rays` counts; a scattering vertex
         // (K5 + K6) is a path vertex without a material record.
-        const uint64_t b_coll = c->nvdb_collisions ? 84 : 36;
-        out->bytes_algorithmic_media = h.collisions * b_coll + 4 * h.dda_steps + h.scatter_vertices * (2 * 104 + 96) + 60 * h.sc_light_nodes;
-        out->bytes_algorithmic_shadow += h.sh_collisions * b_coll + 4 * h.sh_dda_steps;
+        // The kernels count the collisions of NanoVDB scenes apart (DStats::nvdb_collisions), so a context that renders grid and NanoVDB
+        // scenes in one statistics window charges each its own price.
+        out->bytes_algorithmic_media = h.collisions * 36 + h.nvdb_collisions * (84 - 36) + 4 * h.dda_steps + h.scatter_vertices * (2 * 104 + 96) + 60 * h.sc_light_nodes;
+        out->bytes_algorithmic_shadow += h.sh_collisions * 36 + h.sh_nvdb_collisions * (84 - 36) + 4 * h.sh_dda_steps;
     }
     return HK_OK;
 }

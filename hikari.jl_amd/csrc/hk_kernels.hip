@@ -1253,6 +1253,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
     close_seg(seg[1]);
     stats += global_wave();
     wave_add(&stats->collisions, n_coll);
+    wave_add(&stats->nvdb_collisions, (sc.media_mask >> HK_MEDIUM_NANOVDB) & 1 ? n_coll : 0u);   // (priced per scene: SURVEY 8d charges the NanoVDB tree walk)
     wave_add(&stats->dda_steps, n_dda);
 }
 
@@ -1534,6 +1535,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
     stats += global_wave();
     HK_DBG_FLUSH(stats);
     wave_add(&stats->collisions, n_coll);
+    wave_add(&stats->nvdb_collisions, (sc.media_mask >> HK_MEDIUM_NANOVDB) & 1 ? n_coll : 0u);   // (priced per scene: SURVEY 8d charges the NanoVDB tree walk)
     wave_add(&stats->dda_steps, n_dda);
 }
 
@@ -1873,6 +1875,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
     stats += global_wave();
     HK_DBG_FLUSH(stats);
     wave_add(&stats->collisions, n_coll);
+    wave_add(&stats->nvdb_collisions, (sc.media_mask >> HK_MEDIUM_NANOVDB) & 1 ? n_coll : 0u);   // (priced per scene: SURVEY 8d charges the NanoVDB tree walk)
     wave_add(&stats->dda_steps, n_dda);
 }
 
@@ -2567,6 +2570,9 @@ HKD void shadow_contribute(DPathState& st, uint32_t rec, S4 T_ray, S4 tr_u, S4 t
     if (den > 1e-10f) {
         S4 fin = ld4(&st.sh_Ld[rec]) * T_ray / den;
         if (!is_black(fin)) {
+            // (this read-modify-write of one path's 16 B costs k_shadow a quarter of its time in the Cornell box — 15.4 -> 11.4 ms per
+            // frame without it; float atomics: 47 ms; non-temporal loads of the records around it, or the path slot read with the ray and
+            // weights / Ld / L loaded together (one memory round trip instead of four): +-0 — it is the traffic, not the latency)
             const uint32_t pslot = st.sh_slot[rec];
             st4(&st.L[pslot], ld4(&st.L[pslot]) + fin);
         }
@@ -2982,6 +2988,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
     stats += global_wave();
     HK_DBG_FLUSH(stats);
     wave_add(&stats->sh_collisions, n_coll);
+    wave_add(&stats->sh_nvdb_collisions, (sc.media_mask >> HK_MEDIUM_NANOVDB) & 1 ? n_coll : 0u);
     wave_add(&stats->sh_dda_steps, n_dda);
     wave_add(&stats->rays_shadow, n_casts);
     wave_add(&stats->hits, n_hits);
@@ -3421,6 +3428,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
     stats += global_wave();
     HK_DBG_FLUSH(stats);
     wave_add(&stats->sh_collisions, n_coll);
+    wave_add(&stats->sh_nvdb_collisions, (sc.media_mask >> HK_MEDIUM_NANOVDB) & 1 ? n_coll : 0u);
     wave_add(&stats->sh_dda_steps, n_dda);
     wave_add(&stats->rays_shadow, n_casts);
     wave_add(&stats->hits, n_hits);
@@ -3825,6 +3833,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
     stats += global_wave();
     HK_DBG_FLUSH(stats);
     wave_add(&stats->sh_collisions, n_coll);
+    wave_add(&stats->sh_nvdb_collisions, (sc.media_mask >> HK_MEDIUM_NANOVDB) & 1 ? n_coll : 0u);
     wave_add(&stats->sh_dda_steps, n_dda);
 }
 
@@ -4536,7 +4545,7 @@ void launch_detect_camera_medium(hipStream_t s, const DPathState& st, const DSce
 }
 void launch_escaped(hipStream_t s, int n_cu, const DPathState& st, const DScene& sc, const DTables& T, const DFrame& fr, int depth) {
     const int blocks = cached_blocks<k_escaped>(256, n_cu, 8);
-    hipLaunchKernelGGL(k_escaped, dim3(clamp_blocks(blocks, st)), dim3(256), 0, s, st, sc, T, depth, fr.implicit_ones);
+    hipLaunchKernelGGL(k_escaped, dim3(clamp_blocks(blocks, st)), dim3(256), 0, s, st, sc, T, depth, fr.implicit_ones);   // (one wave per segment instead of the resident stride: +-0, sky)
 }
 static bool sobol_tables_cover(const DSobol& sob, int depth) {
     const char* ft_env = std::getenv("HK_SOBOL_TABLE_ONLY");   // read per launch (A/B switch)

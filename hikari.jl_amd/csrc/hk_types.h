@@ -294,6 +294,7 @@ struct DPathState {
 
 struct DStats {
     unsigned long long rays_closest, rays_shadow, nodes, tris, hits, vertices, collisions, light_nodes, sh_nodes, sh_tris;
+    unsigned long long nvdb_collisions, sh_nvdb_collisions;   // the part of collisions / sh_collisions counted while a scene with a NanoVDB medium was rendered
     unsigned long long sh_collisions, dda_steps, sh_dda_steps, scatter_vertices, sc_light_nodes;   // ratio-tracking collisions of the shadow walk; majorant cells entered (delta / ratio tracking); K5+K6 vertices
 #ifdef HK_DEBUG_UTIL   // lane-utilisation bookkeeping of the media state machines (debug builds only: scratch/util_debug.sh)
     unsigned long long dbg[32];

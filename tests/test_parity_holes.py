@@ -563,6 +563,37 @@ def test_full_size_many_light(hk, oracle):
     assert abs(int(st.rays_closest) - int(ost.rays_closest)) <= 0.002 * ost.rays_closest + 4
 
 
+def test_collision_bytes_priced_per_scene(hk):
+    """hk_stats' algorithmic bytes charge 36 B per collision in a dense grid and 84 B through a NanoVDB tree.  One
+    integrator — one statistics window — that renders a grid scene and then a NanoVDB scene must charge each scene's collisions
+    their own price: the bytes add up to those of the two scenes rendered alone (a per-context "a NanoVDB scene was seen" flag
+    would charge the grid's collisions 84 B as well)."""
+    from hikari_jl_amd import scenes
+    kw = dict(res=(32, 32, 16), sigma_scale=20.0, majorant_res=(8, 8, 8))
+    sg, fg, cg = scenes.cloud_scene(48, 40, kind="grid", **kw)
+    sn, fn, cn = scenes.cloud_scene(48, 40, kind="nanovdb", **kw)
+    vp = hk.VolPath(max_depth=6, samples=2)
+    vp(sg, fg, cg)
+    g = vp.stats()
+    bg, bsg, cgl = int(g.bytes_algorithmic_media), int(g.bytes_algorithmic_shadow), int(g.track_collisions)
+    assert cgl > 1000 and int(g.shadow_collisions) > 100
+    vp.reset_stats()
+    vp(sn, fn, cn)
+    n = vp.stats()
+    bn, bsn = int(n.bytes_algorithmic_media), int(n.bytes_algorithmic_shadow)
+    assert int(n.track_collisions) > 1000
+    assert bn >= 84 * int(n.track_collisions) and bsn >= 84 * int(n.shadow_collisions)
+    vp.reset_stats()                                      # (VolPath.__call__ resets the statistics: render_samples does not)
+    fg.iteration_index = fn.iteration_index = 0           # (the same two samples as above)
+    vp.clear()
+    vp.render_samples(sg, fg, cg, 2)
+    vp.clear()
+    vp.render_samples(sn, fn, cn, 2)
+    both = vp.stats()
+    assert int(both.bytes_algorithmic_media) == bg + bn and int(both.bytes_algorithmic_shadow) == bsg + bsn
+    vp.close()
+
+
 def test_full_size_cloud(hk, oracle):
     """BASELINE configs[3] at FULL size exactly as bench.py builds it (`scenes.bomex_scene`: 256 x 256 x 128 worley-fbm field at 5 %
     fill, extinction up to 620, NanoVDB + 64^3 majorant, 1024^2, depth 32), one sample per pixel: finite, non-negative,

@@ -1237,12 +1237,12 @@ hipError_t alloc_arr(hk_integrator* I, T*& dst, size_t n) {
 // HK_WAVES_PER_CU / HK_DYNAMIC_SEGMENTS override.  stats rows are indexed by PHYSICAL wave (ctx->stat_rows).
 int ensure_state(hk_integrator* I, int capacity, bool media, bool open_scene, bool small_scene, hipStream_t users = nullptr) {
     const int n_cu = I->ctx->n_cu;
-    // a closed scene's pass of at most HK_MID_PASS_PATHS_M (32) million paths — a rank's share of a frame under 8-way strong scaling —
+    // a closed scene's pass of at most HK_MID_PASS_PATHS_M (48) million paths — a rank's share of a frame under 8-way strong scaling —
     // behaves like the open scene WHEN THE SCENE IS SMALL (BVH depth <= 16, the Cornell box): the deep bounces hold a few dozen rays per
     // segment and every visit costs a chunk's latency, so fewer segments and the static stride win (800^2 x 32 spp: 16.3 -> 14.4 ms per
-    // frame; x 64: 27.9 -> 27.2; x 128 and x 256 prefer the tickets).  The 10^6-triangle scene's rays are too uneven for a static stride
+    // frame; x 64: 29.1 -> 27.8; x 128 and x 256 prefer the tickets).  The 10^6-triangle scene's rays are too uneven for a static stride
     // at any size (1024^2 x 32 spp: 115 -> 128 ms).
-    long mid_paths = 32L << 20;
+    long mid_paths = 48L << 20;
     if (const char* e = std::getenv("HK_MID_PASS_PATHS_M")) mid_paths = std::atol(e) >= 0 ? std::atol(e) << 20 : mid_paths;
     const bool mid = !media && !open_scene && small_scene && (long)capacity <= mid_paths;
     I->mid_pass = mid;

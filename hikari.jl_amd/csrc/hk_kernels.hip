@@ -69,6 +69,7 @@ struct SegTickets {
     int n;                      // entries to hand out
     int pos, step;              // static mode: next entry of this wave, stride (step == 0: ticket mode)
     unsigned long long own;     // ticket mode: the counters whose segments the static stride would give to this wave's XCD
+    bool share;                 // ticket mode: exhausted counters are published in one shared word (seg_next)
 };
 // Static stride: block b runs on XCD b % 8 and its wave w takes the list entries 4b + w, 4b + w + waves, ...: the records one kernel
 // writes are read by the next kernel from the SAME XCD's L2 while they are still there (the per-XCD L2s do not share).  Tickets keep
@@ -97,6 +98,7 @@ __device__ __forceinline__ SegTickets seg_open(const DPathState& st, int* cnt, b
     it.step = dynamic ? 0 : physical_waves();
     it.alive = 0ull;
     it.own = 0ull;
+    it.share = st.ticket_share != 0;
     if (dynamic) {
         it.own = xcd_counters();
         const int lane = lane_id();
@@ -128,11 +130,20 @@ __device__ __forceinline__ int seg_next(SegTickets& it, int n_segments) {   // -
         // a time (up to 63 serial round trips).  HK_TICKET_REFRESH=1 re-reads all 64 counters with one parallel load after a failure
         // instead: the deep bounces of a 32-spp Cornell frame lose 20 - 30 us per launch, the 256-spp frame and the many-light frame gain
         // 0.5 %, but the 64 extra line reads per wave get in the way of the remaining atomics where launches are short and many — the
-        // cloud frame +3.6 %, Cornell at 64 spp +3 % — so it stays off (round 4, interleaved on one box).
+        // cloud frame +3.6 %, Cornell at 64 spp +3 % — so it stays off (round 4, interleaved on one box).  What does pay where launches are
+        // short and many is ONE shared word of "exhausted" bits per ticket (DPathState::ticket_share, scenes with media): cloud frame
+        // -1.8 % (644 -> 633 ms, three interleaved pairs), Cornell / sky / many-light +-0.3 %.
 #if HK_TICKET_REFRESH
         const int v = __hip_atomic_load(it.cnt + lane_id() * HK_TICKET_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         it.alive &= __ballot(v < seg_per_way(it.n, lane_id()));
 #endif
+        if (it.share) {   // one shared word per ticket (the unused second 128-B half of counter 0's 256 bytes): a wave that finds counter k
+                          // exhausted says so and learns, with the same atomic, what the others have found
+            unsigned long long m = 0ull;
+            if (lane_id() == 0) m = __hip_atomic_fetch_or(reinterpret_cast<unsigned long long*>(it.cnt + 32), 1ull << k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)m), hi = __builtin_amdgcn_readfirstlane((unsigned)(m >> 32));
+            it.alive &= ~(((unsigned long long)hi << 32) | lo);
+        }
         it.alive &= ~(1ull << k);
     }
     return n_segments;

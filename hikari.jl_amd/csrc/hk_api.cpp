@@ -1256,7 +1256,7 @@ int ensure_state(hk_integrator* I, int capacity, bool media, bool open_scene, bo
     I->st.dynamic_segments = (media || (!open_scene && !mid)) ? 1 : 0;
     if (const char* e = std::getenv("HK_DYNAMIC_SEGMENTS")) I->st.dynamic_segments = std::atoi(e) ? 1 : 0;
     I->st.compact = media ? 0 : 1;
-    I->st.ticket_share = media ? 1 : 0;
+    I->st.ticket_share = 1;
     if (const char* e = std::getenv("HK_TICKET_SHARE")) I->st.ticket_share = std::atoi(e) ? 1 : 0;
     {   // a SMALL pass (at most 16 chunks for each of 4 waves per CU: a one-sample call at 800^2) hands segment g to wave g of every launch
         // (static stride where a grid is smaller): the 17 k_segment_lists launches of a call and the ticket round trips go, and the segment

@@ -61,6 +61,9 @@ __device__ __forceinline__ int physical_waves() { return (int)(gridDim.x * (bloc
 #ifndef HK_TICKET_REFRESH
 #define HK_TICKET_REFRESH 0   // see seg_next
 #endif
+#ifndef HK_TICKET_OPEN_SHARED
+#define HK_TICKET_OPEN_SHARED 1
+#endif
 struct SegTickets {
     int* cnt;                   // HK_TICKET_WAYS (= 64: one per lane) counters, HK_TICKET_STRIDE ints apart
     unsigned long long alive;   // counters not yet seen exhausted (wave-uniform)
@@ -102,8 +105,17 @@ __device__ __forceinline__ SegTickets seg_open(const DPathState& st, int* cnt, b
     if (dynamic) {
         it.own = xcd_counters();
         const int lane = lane_id();
-        const int v = __hip_atomic_load(cnt + lane * HK_TICKET_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        it.alive = __ballot(v < seg_per_way(it.n, lane));
+#if HK_TICKET_OPEN_SHARED
+        if (it.share) {   // the shared word says which counters are used up: one 8-byte read instead of 64 lines per wave and launch
+            const unsigned long long m = __hip_atomic_load(reinterpret_cast<unsigned long long*>(cnt + 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)m), hi = __builtin_amdgcn_readfirstlane((unsigned)(m >> 32));
+            it.alive = __ballot(0 < seg_per_way(it.n, lane)) & ~(((unsigned long long)hi << 32) | lo);
+        } else
+#endif
+        {
+            const int v = __hip_atomic_load(cnt + lane * HK_TICKET_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            it.alive = __ballot(v < seg_per_way(it.n, lane));
+        }
     }
     return it;
 }
@@ -131,8 +143,9 @@ __device__ __forceinline__ int seg_next(SegTickets& it, int n_segments) {   // -
         // instead: the deep bounces of a 32-spp Cornell frame lose 20 - 30 us per launch, the 256-spp frame and the many-light frame gain
         // 0.5 %, but the 64 extra line reads per wave get in the way of the remaining atomics where launches are short and many — the
         // cloud frame +3.6 %, Cornell at 64 spp +3 % — so it stays off (round 4, interleaved on one box).  What does pay where launches are
-        // short and many is ONE shared word of "exhausted" bits per ticket (DPathState::ticket_share, scenes with media): cloud frame
-        // -1.8 % (644 -> 633 ms, three interleaved pairs), Cornell / sky / many-light +-0.3 %.
+        // short and many is ONE shared word of "exhausted" bits per ticket (DPathState::ticket_share): cloud frame -1.8 % (644 -> 633 ms,
+        // three interleaved pairs); with seg_open reading that word instead of the 64 counters another -0.4 %, Cornell -0.5 %,
+        // many-light -0.3 %.
 #if HK_TICKET_REFRESH
         const int v = __hip_atomic_load(it.cnt + lane_id() * HK_TICKET_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         it.alive &= __ballot(v < seg_per_way(it.n, lane_id()));

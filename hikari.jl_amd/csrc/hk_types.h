@@ -286,7 +286,7 @@ struct DPathState {
     int* seg_list_n;       // [depth][queue]: their number
     int dynamic_segments;  // 1: every kernel draws its segments from the tickets (scenes with media); 0: static stride
     int small_pass;        // 1: a pass of at most one segment per resident wave (a one-sample call): wave g takes segment g — no work lists, no tickets
-    int ticket_share;      // 1: waves publish exhausted ticket counters in one shared word per ticket (scenes with media: many short launches; HK_TICKET_SHARE)
+    int ticket_share;      // 1: waves publish exhausted ticket counters in one shared word per ticket and read it when they open one (HK_TICKET_SHARE=0: off)
     // 1 (scenes without media): r_u is 1 on every path and the four components of r_l are equal (r_l = r_u / pdf of a scalar pdf,
     // only media rescale them per wavelength) — r_u is not stored, r_l is one float per record (the float4 array's memory, read as
     // float), and a shadow record carries its two MIS weights as one float2 in sh_ru.  Same arithmetic on the broadcast values.

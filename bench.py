@@ -20,7 +20,7 @@ The reduce is the library's own hk_film_reduce (ncclReduce over xGMI on the rend
 128-byte communicator id and the final statistics, and its own reduce is the untimed cross-check of the result).
 On ONE GPU the default run then reports every other BASELINE.json config (`configs`: the two-spheres Cornell, the cloud, the sky, the
 many-light scene — seconds per frame, Mrays/s, class times, rooflines, the one-sample-per-call path), each measured by `bench.py --config X`
-in a child process of its own (the cloud frame has two speeds, decided when a process allocates its path state: DESIGN.md §5), and, last,
+in a child process of its own (a process that has used a second stream keeps slower launches for good: DESIGN.md §5 "two speeds"), and, last,
 the one-sample-per-call path of the bench scene (`progressive`: hk_render(first = i, n = 1), what an interactive viewer drives).
 value = rays of all ranks / max-over-ranks time of the K steps.  Scene, BVH and sampler tables live in HBM before the timed region
 starts; `cold_frame_seconds` is a frame that has to rebuild the sample-bit table first (a one-shot render of a new sample range).
@@ -656,8 +656,9 @@ def main():
             # the other north_star targets, driver-visible in the same line (headline fields above are untouched).  Each config is
             # measured by `bench.py --config X` in a PROCESS OF ITS OWN — a child started here once this process has given its device
             # memory back, never an exec of this one — exactly what `tools/profile_round.sh` does for the committed profiles: the cloud
-            # frame has two speeds (0.639 s / 0.683 s, decided when a process allocates the path state: DESIGN.md §5 "two speeds"), and
-            # a process that has already rendered other configs or small passes reliably draws the slow one.  If a child cannot be
+            # frame has two speeds (0.630 s / 0.683 s: once a process has launched on a second stream of its own, every kernel takes
+            # 50 - 120 us longer for good — DESIGN.md §5 "two speeds"), and a process that has rendered the many-light config or a
+            # run of small calls before is in the slow one.  If a child cannot be
             # run, the config is measured in this process instead (`measured_in` says which).
             del accum
             torch.cuda.empty_cache()

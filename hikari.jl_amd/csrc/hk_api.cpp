@@ -65,19 +65,111 @@ static int fail(int code, const std::string& msg) {
     } while (0)
 
 namespace {
+// PATH-STATE SLABS outlive the integrator that asked for them: the ~40 arrays of a path state are carved from one allocation, and a slab
+// that is let go is kept (per device, up to HK_STATE_CACHE_GB = 128 in total, the smallest ones dropped first) for the next path state
+// that fits it.  Two reasons, both measured on the cloud config (DESIGN.md §5 "two speeds"): allocating 84 GB takes 0.7 - 4 s, and where
+// the driver places a LATER big allocation decides whether the gather-heavy kernels run 7 - 9 % slower for the life of that integrator.
+// Everything cached is given back when a hipMalloc fails (then retried) and when a context of that device is destroyed.
+struct SlabCache {
+    struct Entry {
+        void* p;
+        size_t bytes;
+        int dev;
+    };
+    std::mutex m;
+    std::vector<Entry> free_list;
+    size_t cap() const {
+        long gb = 128;
+        if (const char* e = std::getenv("HK_STATE_CACHE_GB")) gb = std::atol(e) >= 0 ? std::atol(e) : gb;
+        return (size_t)gb << 30;
+    }
+    size_t total(int dev) {
+        std::lock_guard<std::mutex> g(m);
+        size_t t = 0;
+        for (const Entry& e : free_list) t += e.dev == dev ? e.bytes : 0;
+        return t;
+    }
+    void* take(int dev, size_t need, size_t& got) {   // the smallest slab that holds `need` without being more than twice as large
+        std::lock_guard<std::mutex> g(m);
+        int best = -1;
+        for (int i = 0; i < (int)free_list.size(); ++i) {
+            const Entry& e = free_list[i];
+            if (e.dev == dev && e.bytes >= need && e.bytes <= 2 * need + ((size_t)64 << 20) && (best < 0 || e.bytes < free_list[best].bytes)) best = i;
+        }
+        if (best < 0) return nullptr;
+        void* p = free_list[best].p;
+        got = free_list[best].bytes;
+        free_list.erase(free_list.begin() + best);
+        return p;
+    }
+    void give(int dev, void* p, size_t bytes) {
+        std::vector<void*> drop;
+        {
+            std::lock_guard<std::mutex> g(m);
+            free_list.push_back(Entry{p, bytes, dev});
+            size_t t = 0;
+            for (const Entry& e : free_list) t += e.bytes;
+            const size_t limit = cap();
+            while (!free_list.empty() && (t > limit || free_list.size() > 8)) {   // the smallest goes first: the big ones are the expensive ones
+                int k = 0;
+                for (int i = 1; i < (int)free_list.size(); ++i)
+                    if (free_list[i].bytes < free_list[k].bytes) k = i;
+                t -= free_list[k].bytes;
+                drop.push_back(free_list[k].p);
+                free_list.erase(free_list.begin() + k);
+            }
+        }
+        for (void* q : drop) (void)hipFree(q);
+    }
+    void trim(int dev) {   // dev < 0: every device
+        std::vector<void*> drop;
+        {
+            std::lock_guard<std::mutex> g(m);
+            for (int i = (int)free_list.size() - 1; i >= 0; --i)
+                if (dev < 0 || free_list[i].dev == dev) {
+                    drop.push_back(free_list[i].p);
+                    free_list.erase(free_list.begin() + i);
+                }
+        }
+        for (void* q : drop) (void)hipFree(q);
+    }
+};
+SlabCache g_slabs;
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
-    ~DevBuf() {
-        if (p) (void)hipFree(p);
+    int slab_dev = -1;   // >= 0: a path-state slab of that device (goes back to g_slabs, not to the driver)
+    void release() {
+        if (p && slab_dev >= 0) {
+            (void)hipDeviceSynchronize();   // (hipFree would have waited for the kernels that still use it)
+            g_slabs.give(slab_dev, p, bytes);
+        } else if (p)
+            (void)hipFree(p);
+        p = nullptr, bytes = 0, slab_dev = -1;
     }
+    ~DevBuf() { release(); }
     hipError_t alloc(size_t n) {
-        if (p) (void)hipFree(p);
-        p = nullptr;
+        release();
         bytes = n;
         if (n == 0) return hipSuccess;
-        const hipError_t e = hipMalloc(&p, n);
+        hipError_t e = hipMalloc(&p, n);
+        if (e != hipSuccess) {   // the cached slabs are memory too
+            (void)hipGetLastError();
+            g_slabs.trim(-1);
+            e = hipMalloc(&p, n);
+        }
         if (e != hipSuccess) p = nullptr, bytes = 0;
+        return e;
+    }
+    hipError_t alloc_slab(int dev, size_t n) {   // a cached slab that fits, or a new one
+        release();
+        size_t got = 0;
+        if (void* q = g_slabs.take(dev, n, got)) {
+            p = q, bytes = got, slab_dev = dev;
+            return hipSuccess;
+        }
+        const hipError_t e = alloc(n);
+        if (e == hipSuccess) slab_dev = dev;
         return e;
     }
     hipError_t upload(const void* src, size_t n) {
@@ -98,7 +190,8 @@ struct hk_ctx {
     hipStream_t stream = nullptr;
     hipStream_t aux = nullptr;            // second stream: the shadow rays of bounce d run beside the traversal of bounce d + 1
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    int overlap = 1;                      // HK_OVERLAP=0 switches the second stream off
+    int overlap = -1;                     // the shadow kernels on a second stream: -1 auto (scenes with a deep BVH), HK_OVERLAP=0 / 1 never / always
+    int small_streak = 0;                 // consecutive small one-pass render calls so far (the lanes start after HK_PIPELINE_AFTER of them)
     int n_cu = 256;
     int waves_per_cu = 0;      // HK_WAVES_PER_CU: fixed number of wave segments per CU (0 = sized from the pass)
     int stat_rows = 8192;      // DStats rows, indexed by PHYSICAL wave: n_cu * 32 (8 waves x 4 SIMDs is the residency limit)
@@ -237,6 +330,7 @@ extern "C" int32_t hk_ctx_create(int32_t device_id, void* stream, hk_ctx** out) 
         if (const char* e = std::getenv("HK_WAVES_PER_CU")) c->waves_per_cu = std::atoi(e) > 0 ? std::atoi(e) : 0;
         c->stat_rows = c->n_cu * 32 * 2;   // second half: the kernels of the second stream (their waves have the same physical ids)
         if (const char* e = std::getenv("HK_OVERLAP")) c->overlap = std::atoi(e) ? 1 : 0;
+        else c->overlap = -1;
     }
     {
         std::vector<DStats> zero((size_t)c->stat_rows);
@@ -270,6 +364,7 @@ extern "C" int32_t hk_ctx_destroy(hk_ctx* c) {
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->aux) (void)hipStreamDestroy(c->aux);
+    g_slabs.trim(c->device);
     delete c;
     return HK_OK;
 }
@@ -1212,7 +1307,7 @@ extern "C" int32_t hk_denoise(hk_ctx* c, const hk_denoise_params* P, int32_t w, 
 
 // ---- path state -----------------------------------------------------------------------------------------
 namespace {
-// HK_STATE_SLAB=1 (experiment, DESIGN.md §5 "two speeds"): the path-state arrays are carved from ONE allocation instead of ~40
+// the path-state arrays are carved from ONE allocation (a slab: see SlabCache) instead of ~40; HK_STATE_SLAB=0: one allocation each
 template <class T>
 hipError_t alloc_arr(hk_integrator* I, T*& dst, size_t n) {
     if (I->slab_mode != 0) {
@@ -1346,8 +1441,8 @@ int ensure_state(hk_integrator* I, int capacity, bool media, bool open_scene, bo
         HIP_TRY(alloc_arr(I, s.seg_list_n, (size_t)(I->p.max_depth + 2) * Q_COUNT));
         return HK_OK;
     };
-    const char* slab_env = std::getenv("HK_STATE_SLAB");
-    if (slab_env && std::atoi(slab_env)) {
+    const char* slab_env = std::getenv("HK_STATE_SLAB");   // (0: one allocation per array, nothing cached)
+    if (!(slab_env && std::atoi(slab_env) == 0)) {
         I->slab_mode = 1, I->slab_off = 0;
         if (int e = layout()) {
             I->slab_mode = 0;
@@ -1355,7 +1450,7 @@ int ensure_state(hk_integrator* I, int capacity, bool media, bool open_scene, bo
         }
         DevBuf* slab = new DevBuf();
         I->bufs.push_back(slab);
-        const hipError_t he = slab->alloc(I->slab_off);
+        const hipError_t he = slab->alloc_slab(I->ctx->device, I->slab_off);
         if (he != hipSuccess) {
             I->slab_mode = 0;
             return fail(HK_ERR_DEVICE, "path-state slab allocation failed");
@@ -1453,8 +1548,10 @@ extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_
         if (S < 1) S = 1;
         if (S > 256) S = 256;
         size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            free_b += g_slabs.total(c->device);   // (cached path-state slabs are given back when an allocation needs them)
             while (S > 1 && (size_t)S * fr.n_pixels_padded * 440 > free_b / 2) S /= 2;
+        }
     }
     if (S > n_samples) S = n_samples;
     if ((long)S * fr.n_pixels_padded > 0x3fffffffL) return fail(HK_ERR_INVALID, "pass too large");
@@ -1471,7 +1568,14 @@ extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_
             const long by_memory = (8L << 30) / (440L * (long)S * fr.n_pixels_padded);
             if (n_lanes > by_memory) n_lanes = by_memory < 1 ? 1 : (int)by_memory;
         }
-        if (n_lanes > 1 && !c->time_kernels && n_samples <= S && (long)S * fr.n_pixels_padded <= max_paths) {
+        // (the lanes are streams of their own — see the note on the second hardware queue at `overlap` below — so one small call, or a
+        // handful, does not start them: only a run of HK_PIPELINE_AFTER = 4 small calls in a row does, i.e. a progressive viewer)
+        const bool small_call = n_samples <= S && (long)S * fr.n_pixels_padded <= max_paths;
+        int after = 4;
+        if (const char* e = std::getenv("HK_PIPELINE_AFTER")) after = std::atoi(e) >= 0 ? std::atoi(e) : after;
+        c->small_streak = small_call ? c->small_streak + 1 : 0;
+        const bool lanes_started = c->ev_main != nullptr;
+        if (n_lanes > 1 && !c->time_kernels && small_call && (lanes_started || c->small_streak > after)) {
             if ((int)I->lane_sets.size() < (int)hk_ctx::MAX_LANES) I->lane_sets.resize(hk_ctx::MAX_LANES);
             lane_idx = c->next_lane % n_lanes;
             c->next_lane = (lane_idx + 1) % n_lanes;
@@ -1670,7 +1774,15 @@ extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_
         // stream so that the class times add up.
         // (surfaces only: beside the long shadow walks of a media scene the next traversal only competes — cloud -4.5 %; Cornell +-0, sky +1 %, many-light +2.4 %)
         if (const char* e = std::getenv("HK_OVERLAP")) c->overlap = std::atoi(e) ? 1 : 0;
-        const bool overlap = c->overlap && !c->time_kernels && sc->d.n_lights > 0 && sc->d.n_media == 0 && !piped && !I->mid_pass;   // (a mid-size pass: the two streams only get in each other's way, 800^2 x 32 spp -4 %)
+        else c->overlap = -1;
+        // A SECOND HARDWARE QUEUE IS NOT FREE ON THIS CHIP: from the moment a process has used a second stream of its own, every kernel of
+        // every stream takes 50 - 120 us longer (the completion of one and the start of the next, with or without events between the
+        // streams, whatever their flags and priorities; GPU_MAX_HW_QUEUES=1 makes it go away, and so does never creating the stream) —
+        // the "two speeds" of DESIGN.md §5: 8 % of a cloud frame (330 launches), 1 - 4 % of a Cornell frame.  The shadow launch on a
+        // second stream repays that only where launches are long: the 10^6-triangle scene (+2.9 %); Cornell and sky +-0.1 % with
+        // outliers of +4 %.  So: automatic for deep BVHs only, and never in a mid-size pass (800^2 x 32 spp: -4 %).
+        const bool want_overlap = c->overlap < 0 ? sc->d.bvh_depth > 16 : c->overlap != 0;
+        const bool overlap = want_overlap && !c->time_kernels && sc->d.n_lights > 0 && sc->d.n_media == 0 && !piped && (!I->mid_pass || c->overlap == 1);   // (an explicit HK_OVERLAP=1 is obeyed: the tests' small films)
         if (overlap && !c->aux) {
             HIP_TRY(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
             HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));

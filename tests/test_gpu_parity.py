@@ -423,6 +423,7 @@ def test_progressive_calls_pipeline_bit_equal(hk, monkeypatch, which):
 
     def run(env, plan):
         monkeypatch.delenv("HK_PIPELINE", raising=False)
+        monkeypatch.setenv("HK_PIPELINE_AFTER", "0")     # (the lanes start with the first small call, not after a run of four)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         vp = hk.VolPath(max_depth=depth, samples=n)
@@ -441,12 +442,13 @@ def test_progressive_calls_pipeline_bit_equal(hk, monkeypatch, which):
 
     ref, rays = run({"HK_PIPELINE": "1"}, [1] * n)
     assert np.isfinite(ref).all() and ref.max() > 0
-    for env, plan in (({}, [1] * n), ({"HK_PIPELINE": "7"}, [1] * n), ({}, [n]), ({"HK_PIPELINE": "2"}, [1, 2, 1, 28, 1, 1, 30]), ({}, [3] * 20 + [4])):
+    for env, plan in (({}, [1] * n), ({"HK_PIPELINE": "7"}, [1] * n), ({}, [n]), ({"HK_PIPELINE": "2"}, [1, 2, 1, 28, 1, 1, 30]), ({}, [3] * 20 + [4]), ({"HK_PIPELINE_AFTER": "4"}, [1] * n)):
         got, r2 = run(env, plan)
         assert np.array_equal(ref.view(np.uint32), got.view(np.uint32)), (env, plan[:4])
         assert r2 == rays, (env, r2, rays)
     # a clear between pipelined calls: what is rendered before it is gone, what comes after it is all there
     monkeypatch.delenv("HK_PIPELINE", raising=False)
+    monkeypatch.setenv("HK_PIPELINE_AFTER", "0")
     vp = hk.VolPath(max_depth=depth, samples=n)
     vp._ensure(film)
     vp.clear()

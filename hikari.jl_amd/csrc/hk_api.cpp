@@ -226,14 +226,28 @@ struct hk_ctx {
     enum { MAX_LANES = 16 };
     Lane lanes[MAX_LANES];        // (created on first use)
     int next_lane = 0;
+    // SMALL RENDER CALLS ARE BATCHED (hk_render_tile): consecutive one-pass calls that continue each other — same scene, integrator, film,
+    // camera, pixel range and stride, sample indices following on — are only noted here and rendered as ONE pass when something looks
+    // (flush_pending: every entry point that reads or rewrites film / statistics / scene / integrator, hk_sync, a call that does not fit)
+    struct Pending {
+        bool active = false;
+        hk_scene* sc = nullptr;
+        hk_integrator* I = nullptr;
+        hk_film* film = nullptr;
+        hk_camera cam{};
+        int first = 0, n = 0, stride = 1, x0 = 0, y0 = 0, x1 = 0, y1 = 0, calls = 0;
+    } pending;
     bool lanes_dirty = false;     // a lane holds work the context's stream has not waited for
     bool film_chain = false;      // ev_film marks the last film kernel of a lane
     hipEvent_t ev_main = nullptr, ev_film = nullptr;
 };
 
 // the context's stream waits for everything the lanes were given (cheap when nothing is pending)
+static int flush_pending(hk_ctx* c);
 static int join_lanes(hk_ctx* c) {
-    if (!c || !c->lanes_dirty) return HK_OK;
+    if (!c) return HK_OK;
+    if (int e = flush_pending(c)) return e;
+    if (!c->lanes_dirty) return HK_OK;
     for (auto& l : c->lanes)
         if (l.done) HIP_TRY(hipStreamWaitEvent(c->stream, l.done, 0));
     c->lanes_dirty = false;
@@ -1224,7 +1238,10 @@ extern "C" int32_t hk_film_clear(hk_film* f) {
     HIP_TRY(hipMemsetAsync(f->accum, 0, (size_t)4 * f->width * f->height * (f->f64 ? 8 : 4), f->ctx->stream));
     return HK_OK;
 }
-extern "C" void* hk_film_accum_device_ptr(hk_film* f) { return f ? f->accum : nullptr; }
+extern "C" void* hk_film_accum_device_ptr(hk_film* f) {
+    if (f) (void)flush_pending(f->ctx);   // (whoever asks for the pointer is about to look: the noted calls are enqueued first)
+    return f ? f->accum : nullptr;
+}
 extern "C" int32_t hk_film_read_accum(hk_ctx* c, hk_film* f, void* out) {
     if (!c || !f || !out) return fail(HK_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
@@ -1517,6 +1534,14 @@ extern "C" int32_t hk_render(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_film*
     return hk_render_tile(c, sc, I, film, cam, first_sample_idx, n_samples, sample_stride, 0, 0, film->width, film->height);
 }
 
+static int render_tile_now(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_film* film, const hk_camera* cam, int32_t first_sample_idx, int32_t n_samples,
+                           int32_t sample_stride, int32_t x0, int32_t y0, int32_t x1, int32_t y1);
+static int flush_pending(hk_ctx* c) {
+    if (!c || !c->pending.active) return HK_OK;
+    hk_ctx::Pending p = c->pending;
+    c->pending.active = false;
+    return render_tile_now(c, p.sc, p.I, p.film, &p.cam, p.first, p.n, p.stride, p.x0, p.y0, p.x1, p.y1);
+}
 extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_film* film, const hk_camera* cam, int32_t first_sample_idx, int32_t n_samples,
                                   int32_t sample_stride, int32_t x0, int32_t y0, int32_t x1, int32_t y1) {
     if (!c || !sc || !I || !film || !cam) return fail(HK_ERR_INVALID, "null argument");
@@ -1527,6 +1552,36 @@ extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_
     if (sc->ctx != c || I->ctx != c || film->ctx != c) return fail(HK_ERR_INVALID, "scene / integrator / film belong to another context");
     if (film->f64 != (I->p.accumulate_f64 != 0)) return fail(HK_ERR_INVALID, "film / integrator accumulation type mismatch");
     if (n_samples == 0) return HK_OK;
+    // A small call (a one-sample `render!`: < 1 path per resident lane, 26 launches of 26 - 100 us whatever they hold) is worth a seventh
+    // of its time as part of a larger pass, and the film does not depend on the pass size (k_film adds in sample order).  So a small call
+    // is only NOTED; calls that continue it grow the note; the pass is rendered when the note holds HK_BATCH_PATHS_M (32) million paths,
+    // when a call comes that does not continue it, or when anything looks at the result (flush_pending).  Rendering is asynchronous
+    // either way: a device error of a deferred pass is reported by the call that flushes it.  HK_BATCH_PATHS_M=0: every call at once.
+    {
+        long batch_paths = 32L << 20, small_paths = 8L << 20;
+        if (const char* e = std::getenv("HK_BATCH_PATHS_M")) batch_paths = std::atol(e) >= 0 ? std::atol(e) << 20 : batch_paths;
+        if (const char* e = std::getenv("HK_PIPELINE_MAX_PATHS_M")) small_paths = std::atol(e) > 0 ? std::atol(e) << 20 : small_paths;
+        const long px = (long)((x1 - x0 + 7) / 8) * ((y1 - y0 + 7) / 8) * 64;
+        hk_ctx::Pending& p = c->pending;
+        const bool small = batch_paths > 0 && !c->time_kernels && (long)n_samples * px <= small_paths && I->p.samples_per_pass <= 0;
+        if (p.active && small && p.sc == sc && p.I == I && p.film == film && std::memcmp(&p.cam, cam, sizeof(hk_camera)) == 0 && p.stride == sample_stride && p.x0 == x0 &&
+            p.y0 == y0 && p.x1 == x1 && p.y1 == y1 && (long)p.first + (long)p.n * p.stride == first_sample_idx && (long)(p.n + n_samples) * px <= batch_paths) {
+            p.n += n_samples;
+            p.calls += 1;
+            return HK_OK;
+        }
+        if (int e = flush_pending(c)) return e;
+        if (small) {
+            p.active = true;
+            p.sc = sc, p.I = I, p.film = film, p.cam = *cam;
+            p.first = first_sample_idx, p.n = n_samples, p.stride = sample_stride, p.x0 = x0, p.y0 = y0, p.x1 = x1, p.y1 = y1, p.calls = 1;
+            return HK_OK;
+        }
+    }
+    return render_tile_now(c, sc, I, film, cam, first_sample_idx, n_samples, sample_stride, x0, y0, x1, y1);
+}
+static int render_tile_now(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_film* film, const hk_camera* cam, int32_t first_sample_idx, int32_t n_samples,
+                           int32_t sample_stride, int32_t x0, int32_t y0, int32_t x1, int32_t y1) {
     HIP_TRY(hipSetDevice(c->device));
     const int W = film->width, H = film->height;
     DFrame fr{};
@@ -1560,7 +1615,7 @@ extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_
     {
         // measured (Cornell 800^2, one sample per call, ms per call): 1 lane 2.47, 2 lanes 1.69, 4 lanes 1.66, 8 lanes 1.36, 16 lanes 1.21;
         // the lanes' path-state sets together stay below 8 GB (440 B per path)
-        int n_lanes = 8;
+        int n_lanes = 1;   // (off since small calls are batched — HK_PIPELINE = 2 .. 16 turns the lanes on for calls that cannot be: a read-back between them)
         long max_paths = 8L << 20;
         if (const char* e = std::getenv("HK_PIPELINE")) n_lanes = std::atoi(e) >= 1 && std::atoi(e) <= 16 ? std::atoi(e) : n_lanes;
         if (const char* e = std::getenv("HK_PIPELINE_MAX_PATHS_M")) max_paths = std::atol(e) > 0 ? std::atol(e) << 20 : max_paths;
@@ -1888,6 +1943,7 @@ extern "C" int32_t hk_sync(hk_ctx* c) {
 }
 extern "C" int32_t hk_stats_enable_counters(hk_ctx* c, int32_t flags) {
     if (!c) return fail(HK_ERR_INVALID, "null ctx");
+    if (int e = join_lanes(c)) return e;   // (noted small calls are rendered under the flags they were made with)
     c->count_nodes = (flags & 1) ? 1 : 0;
     c->time_kernels = (flags & 2) ? 1 : 0;
     return HK_OK;

@@ -405,10 +405,11 @@ def test_progressive_and_sharded_rendering(hk):
 
 @pytest.mark.parametrize("which", ["cornell", "cloud", "sky"])
 def test_progressive_calls_pipeline_bit_equal(hk, monkeypatch, which):
-    """64 one-sample calls (render!, volpath.jl:445-450) with no read-back in between run PIPELINED on the library's lanes (hk_ctx::Lane:
-    consecutive small calls beside each other, film kernels chained in call order): the accumulators equal, bit for bit, those of the same
-    calls run one after the other (HK_PIPELINE=1), of the one-shot 64-sample frame, and of a mix of call sizes; statistics add up; a clear
-    in the middle is ordered behind the calls before it."""
+    """64 one-sample calls (render!, volpath.jl:445-450) with no read-back in between are BATCHED (hk_render_tile notes small calls that
+    continue each other and renders them as one pass when something looks) or, with HK_BATCH_PATHS_M=0 and HK_PIPELINE > 1, run PIPELINED on
+    the library's lanes (hk_ctx::Lane: consecutive small calls beside each other, film kernels chained in call order): the accumulators
+    equal, bit for bit, those of the same calls rendered at once, one after the other, of the one-shot 64-sample frame, and of a mix of
+    call sizes; statistics add up; a clear in the middle is ordered behind the calls before it."""
     from hikari_jl_amd import scenes
     w, h, n = 40, 36, 64
     if which == "cornell":
@@ -423,6 +424,7 @@ def test_progressive_calls_pipeline_bit_equal(hk, monkeypatch, which):
 
     def run(env, plan):
         monkeypatch.delenv("HK_PIPELINE", raising=False)
+        monkeypatch.delenv("HK_BATCH_PATHS_M", raising=False)
         monkeypatch.setenv("HK_PIPELINE_AFTER", "0")     # (the lanes start with the first small call, not after a run of four)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -437,29 +439,41 @@ def test_progressive_calls_pipeline_bit_equal(hk, monkeypatch, which):
         acc = vp.read_accumulators(film).copy()
         st = vp.stats()
         vp.close()
-        # (a scene with media casts one extra ray per CALL: the camera-medium detection, intersection.jl:690-747)
-        return acc, (int(st.rays_closest) - (len(plan) if which == "cloud" else 0), int(st.rays_shadow), int(st.medium_collisions), int(st.path_vertices))
+        # (a scene with media casts one extra ray per rendered PASS: the camera-medium detection, intersection.jl:690-747 — one per call
+        # when every call is rendered at once, fewer when small calls are batched: then the closest-hit count is left out)
+        batched = env.get("HK_BATCH_PATHS_M", "32") != "0"
+        closest = -1 if (which == "cloud" and batched) else int(st.rays_closest) - (len(plan) if which == "cloud" else 0)
+        return acc, (closest, int(st.rays_shadow), int(st.medium_collisions), int(st.path_vertices))
 
-    ref, rays = run({"HK_PIPELINE": "1"}, [1] * n)
+    off = {"HK_BATCH_PATHS_M": "0"}                       # every call rendered at once, one after the other: the reference
+    ref, rays = run({**off, "HK_PIPELINE": "1"}, [1] * n)
     assert np.isfinite(ref).all() and ref.max() > 0
-    for env, plan in (({}, [1] * n), ({"HK_PIPELINE": "7"}, [1] * n), ({}, [n]), ({"HK_PIPELINE": "2"}, [1, 2, 1, 28, 1, 1, 30]), ({}, [3] * 20 + [4]), ({"HK_PIPELINE_AFTER": "4"}, [1] * n)):
+    for env, plan in (({}, [1] * n), ({}, [1, 2, 1, 28, 1, 1, 30]), ({"HK_BATCH_PATHS_M": "1"}, [1] * n), ({}, [n]),      # small calls batched (the default)
+                      ({**off, "HK_PIPELINE": "7"}, [1] * n), ({**off, "HK_PIPELINE": "2"}, [1, 2, 1, 28, 1, 1, 30]), ({**off, "HK_PIPELINE": "8"}, [3] * 20 + [4]),
+                      ({**off, "HK_PIPELINE": "8", "HK_PIPELINE_AFTER": "4"}, [1] * n)):                                   # ... or run beside each other on lanes
         got, r2 = run(env, plan)
         assert np.array_equal(ref.view(np.uint32), got.view(np.uint32)), (env, plan[:4])
-        assert r2 == rays, (env, r2, rays)
+        assert r2[1:] == rays[1:] and (r2[0] < 0 or r2[0] == rays[0]), (env, r2, rays)
     # a clear between pipelined calls: what is rendered before it is gone, what comes after it is all there
+    for env in ({}, {**off, "HK_PIPELINE": "8"}):
+        monkeypatch.delenv("HK_PIPELINE", raising=False)
+        monkeypatch.delenv("HK_BATCH_PATHS_M", raising=False)
+        monkeypatch.setenv("HK_PIPELINE_AFTER", "0")
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        vp = hk.VolPath(max_depth=depth, samples=n)
+        vp._ensure(film)
+        vp.clear()
+        for i in range(8):
+            vp.render_samples(s, film, cam, 1, first=100 + i, readback=False)
+        vp.clear()
+        for i in range(n):
+            vp.render_samples(s, film, cam, 1, first=i + 1, readback=False)
+        got = vp.read_accumulators(film).copy()
+        vp.close()
+        assert np.array_equal(ref.view(np.uint32), got.view(np.uint32)), env
     monkeypatch.delenv("HK_PIPELINE", raising=False)
-    monkeypatch.setenv("HK_PIPELINE_AFTER", "0")
-    vp = hk.VolPath(max_depth=depth, samples=n)
-    vp._ensure(film)
-    vp.clear()
-    for i in range(8):
-        vp.render_samples(s, film, cam, 1, first=100 + i, readback=False)
-    vp.clear()
-    for i in range(n):
-        vp.render_samples(s, film, cam, 1, first=i + 1, readback=False)
-    got = vp.read_accumulators(film).copy()
-    vp.close()
-    assert np.array_equal(ref.view(np.uint32), got.view(np.uint32))
+    monkeypatch.delenv("HK_BATCH_PATHS_M", raising=False)
 
 
 def test_converged_image_within_mc_variance(hk, oracle):

@@ -18,10 +18,10 @@ N > 1: one process per GPU; rank g renders the sample indices g+1, g+1+N, ... of
   --scaling weak: every rank renders 256 spp (N x 256 in the reduced film).
 The reduce is the library's own hk_film_reduce (ncclReduce over xGMI on the render stream; torch.distributed only carries the
 128-byte communicator id and the final statistics, and its own reduce is the untimed cross-check of the result).
-On ONE GPU the default run then reports every other BASELINE.json config (`configs`: the two-spheres Cornell, the cloud, the sky, the
+On ONE GPU the default run also reports every other BASELINE.json config (`configs`: the two-spheres Cornell, the cloud, the sky, the
 many-light scene — seconds per frame, Mrays/s, class times, rooflines, the one-sample-per-call path), each measured by `bench.py --config X`
-in a child process of its own (a process that has used a second stream keeps slower launches for good: DESIGN.md §5 "two speeds"), and, last,
-the one-sample-per-call path of the bench scene (`progressive`: hk_render(first = i, n = 1), what an interactive viewer drives).
+in a child process of its own BEFORE this process touches the GPU (a second busy hardware queue on the device makes every kernel
+launch 50 - 120 us longer: DESIGN.md §5 "two speeds"), and, last, the one-sample-per-call path of the bench scene (`progressive`: hk_render(first = i, n = 1), what an interactive viewer drives).
 value = rays of all ranks / max-over-ranks time of the K steps.  Scene, BVH and sampler tables live in HBM before the timed region
 starts; `cold_frame_seconds` is a frame that has to rebuild the sample-bit table first (a one-shot render of a new sample range).
 """
@@ -400,7 +400,7 @@ def child_config_line(config, progressive_calls):
             "triangles": cfg["triangles"], "lights": cfg["lights"], "frames_timed": d["steps"], "seconds_per_frame": d["seconds_per_frame"],
             "cold_frame_seconds": d["cold_frame_seconds"], "value": d["value"], "unit": d["unit"], "rays": d["rays"],
             "kernel_seconds": d["roofline"]["kernel_seconds"], "setup_seconds": d["setup_seconds"], "roofline": d["roofline"], "rooflines": d["rooflines"],
-            "progressive": d.get("progressive"), "measured_in": "a process of its own (bench.py --config %s)" % config}
+            "progressive": d.get("progressive"), "measured_in": "a process of its own (bench.py --config %s), before this process touched the GPU" % config}
 
 
 def main():
@@ -408,6 +408,20 @@ def main():
     world_env = os.environ.get("WORLD_SIZE")
     if args.gpus > 1 and world_env is None:
         launch_ranks(args)          # never returns
+
+    # The other north_star targets (`configs` of the line) are measured FIRST, each by `bench.py --config X` in a child process, while this
+    # process has not touched the GPU yet.  Measured AFTER this process's own frames, timed replays and copies — the parent alive with
+    # whatever queues those left it — the children's cloud frame came out at 0.680 s instead of 0.629 s and the many-light frame at
+    # 1.54 s instead of 1.43 s: the per-launch cost of a second hardware queue (DESIGN.md §5 "two speeds") does not stop at the process
+    # boundary (a process that only holds an idle context has no such effect).  Children that fail are measured in this process after
+    # the bench line's own frames (`measured_in` says which).
+    pre_configs = {}
+    if args.extra_configs and int(world_env or "1") == 1:
+        for c in os.environ.get("HK_BENCH_EXTRAS", "cornell_two_spheres,cloud,sky,manylight").split(","):
+            try:
+                pre_configs[c] = child_config_line(c, min(args.progressive, 32))
+            except Exception as e:               # noqa: BLE001
+                sys.stderr.write("bench.py: %s in its own process failed (%s: %s); it will be measured in this process\n" % (c, type(e).__name__, e))
 
     import numpy as np              # noqa: F401
     import torch
@@ -665,22 +679,13 @@ def main():
     vp.close()
     if result is not None:
         if args.extra_configs and world == 1:
-            # the other north_star targets, driver-visible in the same line (headline fields above are untouched).  Each config is
-            # measured by `bench.py --config X` in a PROCESS OF ITS OWN — a child started here once this process has given its device
-            # memory back, never an exec of this one — exactly what `tools/profile_round.sh` does for the committed profiles: the cloud
-            # frame has two speeds (0.630 s / 0.683 s: once a process has launched on a second stream of its own, every kernel takes
-            # 50 - 120 us longer for good — DESIGN.md §5 "two speeds"), and a process that has rendered the many-light config or a
-            # run of small calls before is in the slow one.  If a child cannot be
-            # run, the config is measured in this process instead (`measured_in` says which).
+            # the other north_star targets, driver-visible in the same line (headline fields above are untouched): measured at the top of
+            # main(), each in a process of its own; one whose child failed is measured here, in this process
             del accum
             torch.cuda.empty_cache()
             result["configs"] = []
             for c in os.environ.get("HK_BENCH_EXTRAS", "cornell_two_spheres,cloud,sky,manylight").split(","):
-                line = None
-                try:
-                    line = child_config_line(c, min(args.progressive, 32))
-                except Exception as e:           # noqa: BLE001
-                    sys.stderr.write("bench.py: %s in its own process failed (%s: %s); measuring it in this process\n" % (c, type(e).__name__, e))
+                line = pre_configs.get(c)
                 if line is None:
                     try:
                         line = one_frame_line(hk, scenes, torch, c, local_rank)

@@ -17,7 +17,8 @@ N > 1: one process per GPU; rank g renders the sample indices g+1, g+1+N, ... of
       samples are split over the ranks, 256 / N each; `seconds_per_frame` is the measured time of a frame INCLUDING its reduce.
   --scaling weak: every rank renders 256 spp (N x 256 in the reduced film).
 The reduce is the library's own hk_film_reduce (ncclReduce over xGMI on the render stream; torch.distributed only carries the
-128-byte communicator id and the final statistics, and its own reduce is the untimed cross-check of the result).
+128-byte communicator id, the barriers and the final statistics — over a gloo group on CPU tensors, so that no second stream exists in
+the process while frames are timed — and its own RCCL reduce is the cross-check of the result, run after the timed region).
 On ONE GPU the default run also reports every other BASELINE.json config (`configs`: the two-spheres Cornell, the cloud, the sky, the
 many-light scene — seconds per frame, Mrays/s, class times, rooflines, the one-sample-per-call path), each measured by `bench.py --config X`
 in a child process of its own BEFORE this process touches the GPU (a second busy hardware queue on the device makes every kernel
@@ -437,6 +438,17 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("gloo" if single_device else "nccl", rank=rank, world_size=world)
+    # Host-side coordination (barriers, flags, the final statistics, the 128-byte communicator id) travels over gloo on CPU tensors, never
+    # over the NCCL process group: its first collective would give this process a stream — a hardware queue — of its own, and from then
+    # on every kernel launch of the frames costs 50 - 120 us more (DESIGN.md §5 "two speeds").  torch.distributed's RCCL reduce is only
+    # used for the cross-check of the in-library reduce, after the timed region (or as the fallback when the in-library one is unavailable).
+    coord = dist.new_group(backend="gloo") if (world > 1 and not single_device) else None
+
+    def host_all_reduce(values, op):
+        t = torch.tensor(values, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=op, group=coord)
+        return [float(x) for x in t]
     if single_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -466,7 +478,7 @@ def main():
 
     def barrier():
         if world > 1:
-            dist.barrier()
+            dist.barrier(group=coord)
         vp.sync()
         torch.cuda.synchronize()
 
@@ -482,7 +494,7 @@ def main():
             uid = [hk.Comm.unique_id() if rank == 0 else None]
         except Exception as e:           # noqa: BLE001
             uid, ok, comm_note = [None], 0, "hk_comm_unique_id: %s" % e
-        dist.broadcast_object_list(uid, src=0)        # the launcher's side channel for the 128-byte id
+        dist.broadcast_object_list(uid, src=0, group=coord)        # the launcher's side channel for the 128-byte id
         if uid[0] is None:
             ok = 0
         if ok:
@@ -490,9 +502,7 @@ def main():
                 comm = call_with_timeout(lambda: hk.Comm.rank(vp._ctx, uid[0], rank, world), COMM_TIMEOUT_S, "hk_comm_create_rank")
             except Exception as e:       # noqa: BLE001
                 ok, comm_note = 0, "hk_comm_create_rank: %s" % e
-        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
+        if int(host_all_reduce([ok], dist.ReduceOp.MIN)[0]) == 0:
             comm = None
             comm_note = comm_note or "another rank could not create its communicator"
 
@@ -522,8 +532,9 @@ def main():
     setup_s = time.time() - t0
     reduce_check = None
     if world > 1:
-        # untimed: RCCL sets up the reduce's channels on first use; and the cross-check of the in-library reduce against
-        # torch.distributed's on the warm-up film (same inputs, same ring: identical sums)
+        # untimed: RCCL sets up the reduce's channels on first use.  The warm-up film before and after the in-library reduce is kept
+        # for the cross-check against torch.distributed's reduce (same inputs, same ring: identical sums), which runs AFTER the timed
+        # region (see `coord` above)
         keep = accum.clone()
         if comm is not None:
             ok = 1
@@ -531,9 +542,7 @@ def main():
                 call_with_timeout(lambda: (reduce_films(), vp.sync()), COMM_TIMEOUT_S, "the first hk_film_reduce")
             except Exception as e:       # noqa: BLE001
                 ok, comm_note = 0, "hk_film_reduce: %s" % e
-            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 0:
+            if int(host_all_reduce([ok], dist.ReduceOp.MIN)[0]) == 0:
                 comm = None
                 comm_note = comm_note or "hk_film_reduce failed on another rank"
                 accum.copy_(keep)
@@ -542,12 +551,6 @@ def main():
             reduce_films()
         barrier()
         mine = accum.clone()
-        accum.copy_(keep)
-        hd.reduce_film(accum, root=0)
-        barrier()
-        if rank == 0:
-            reduce_check = bool(torch.allclose(mine, accum, rtol=1e-6, atol=1e-7))
-        del keep, mine
     # ---- a cold frame (untimed for `value`): the sample-bit table of a NEW sample range is built inside it, as a one-shot
     #      `integrator(scene, film, camera)` call pays it; path state and scene stay resident ----
     shift = stride * ((FULL_SPP + stride - 1) // stride + 16)
@@ -569,14 +572,18 @@ def main():
     elapsed = time.perf_counter() - t0
     st = vp.stats()
     rays_local = int(st.rays_closest) + int(st.rays_shadow)
-    stat_dev = "cpu" if single_device else "cuda"
-    tmax = torch.tensor([elapsed, cold_s], dtype=torch.float64, device=stat_dev)
-    rays = torch.tensor([float(rays_local)], dtype=torch.float64, device=stat_dev)
+    elapsed_max, cold_max = host_all_reduce([elapsed, cold_s], dist.ReduceOp.MAX) if world > 1 else (elapsed, cold_s)
+    total_rays = host_all_reduce([float(rays_local)], dist.ReduceOp.SUM)[0] if world > 1 else float(rays_local)
     if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(rays, op=dist.ReduceOp.SUM)
-    elapsed_max, cold_max = float(tmax[0].item()), float(tmax[1].item())
-    total_rays = float(rays.item())
+        # the cross-check of the in-library reduce (untimed, after the timed region): torch.distributed's reduce of the same warm-up film
+        last = accum.clone()
+        accum.copy_(keep)
+        hd.reduce_film(accum, root=0)
+        barrier()
+        if rank == 0:
+            reduce_check = bool(torch.allclose(mine, accum, rtol=1e-6, atol=1e-7))
+        accum.copy_(last)           # (the film of the timed frames, as the replays below expect it)
+        del keep, mine, last
 
     result = None
     if rank == 0:

@@ -1377,6 +1377,8 @@ int ensure_state(hk_integrator* I, int capacity, bool media, bool open_scene, bo
         const char* e = std::getenv("HK_SMALL_PASS");
         const bool small = W_want <= 4L * n_cu && !(e && std::atoi(e) == 0) && std::getenv("HK_DYNAMIC_SEGMENTS") == nullptr;   // (an explicit HK_DYNAMIC_SEGMENTS keeps lists / tickets: the tests' small films)
         I->st.small_pass = small ? 1 : 0;
+        if (mid && I->st.dynamic_segments == 0 && !(e && std::atoi(e) == 0) && !(std::getenv("HK_MID_LISTS") && std::atoi(std::getenv("HK_MID_LISTS"))))
+            I->st.small_pass = 1;   // a mid-size pass of a closed scene: its 48 segments per CU all hold paths down to the last bounce — the work lists (17 launches) list everything
         if (small) {
             I->st.dynamic_segments = 0;
             const char* w = std::getenv("HK_SMALL_PASS_WAVES");

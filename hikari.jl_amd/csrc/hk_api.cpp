@@ -385,6 +385,7 @@ extern "C" int32_t hk_ctx_destroy(hk_ctx* c) {
 extern "C" int32_t hk_ctx_set_tables(hk_ctx* c, const hk_tables* t) {
     if (!c || !t || !t->sobol_matrices || t->sobol_count < 104 || !t->cie_x || !t->rgb2spec_coeffs) return fail(HK_ERR_INVALID, "bad tables");
     HIP_TRY(hipSetDevice(c->device));
+    if (int e = flush_pending(c)) return e;   // (noted small calls are rendered with the tables they were made under)
     if (c->lanes_dirty) {   // renders in flight on the lanes read the tables that are about to be replaced
         if (int e = join_lanes(c)) return e;
         HIP_TRY(hipStreamSynchronize(c->stream));

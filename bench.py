@@ -442,13 +442,19 @@ def main():
     # over the NCCL process group: its first collective would give this process a stream — a hardware queue — of its own, and from then
     # on every kernel launch of the frames costs 50 - 120 us more (DESIGN.md §5 "two speeds").  torch.distributed's RCCL reduce is only
     # used for the cross-check of the in-library reduce, after the timed region (or as the fallback when the in-library one is unavailable).
-    coord = dist.new_group(backend="gloo") if (world > 1 and not single_device) else None
+    coord, coord_on_device = None, False
+    if world > 1 and not single_device:
+        try:
+            coord = dist.new_group(backend="gloo")
+        except Exception as e:                   # noqa: BLE001  (no gloo transport on this node: coordinate over the NCCL group after all)
+            sys.stderr.write("bench.py: no gloo group (%s: %s); coordinating over the NCCL process group\n" % (type(e).__name__, e))
+            coord, coord_on_device = None, True
 
     def host_all_reduce(values, op):
-        t = torch.tensor(values, dtype=torch.float64)
+        t = torch.tensor(values, dtype=torch.float64, device="cuda" if coord_on_device else "cpu")
         if world > 1:
             dist.all_reduce(t, op=op, group=coord)
-        return [float(x) for x in t]
+        return [float(x) for x in t.cpu()]
     if single_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)

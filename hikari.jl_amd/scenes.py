@@ -41,8 +41,8 @@ def cornell_box(width=800, height=800, light="area", spheres=True, tess=32, obje
     green = MatteMaterial(Kd=RGBSpectrum(0.12, 0.45, 0.15))
     box, half = 2.0, 1.0
     s = Scene()
-    if light == "point":
-        s.push(PointLight((0, 1.8, 0), RGBSpectrum(15.0)))
+    if light in ("point", "both"):
+        s.push(PointLight((0, 1.8, 0) if light == "point" else (0.5, 1.6, -0.4), RGBSpectrum(15.0) if light == "point" else RGBSpectrum(6.0, 5.0, 3.0)))
     s.push(G.rect3f((-half, 0, -half), (box, 0.01, box)), white)             # floor
     s.push(G.rect3f((-half, box - 0.01, -half), (box, 0.01, box)), white)    # ceiling
     s.push(G.rect3f((-half, 0, half - 0.01), (box, box, 0.01)), white)       # back
@@ -54,7 +54,7 @@ def cornell_box(width=800, height=800, light="area", spheres=True, tess=32, obje
             s.push(G.sphere((0.4, 0.35, 0.0), 0.3, tess), white)
         else:
             s.push(G.rect3f((0.15, 0.0, -0.1), (0.5, 0.6, 0.5)), white)
-    if light == "area":
+    if light in ("area", "both"):
         y = 1.98
         q = G.quad((-0.25, y, -0.25), (0.25, y, -0.25), (0.25, y, 0.25), (-0.25, y, 0.25), normal=(0, -1, 0))
         s.push(q, MediumInterface(MatteMaterial(Kd=RGBSpectrum(0.0)), emission=Emissive(Le=RGBSpectrum(1.0), scale=1.0, two_sided=False)))

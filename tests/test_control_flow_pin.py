@@ -1,5 +1,5 @@
 """The wavefront control flow, per pixel, from a second source: tests/ref_volpath_np.py restates K1 - K13 for opaque
-matte surfaces under diffuse area lights in float32 NumPy from the Julia text (own ZSobol, own light BVH, brute-force float64
+matte / mirror / glass surfaces under diffuse area lights and point lights in float32 NumPy from the Julia text (own ZSobol, own light BVH, brute-force float64
 intersection, no queues) and is compared PIXEL BY PIXEL with the oracle's frame of the Cornell box of BASELINE.json configs[1]: the same
 sample indices, the same path per (pixel, sample) — a wrong MIS weight, a wrong dimension of a Sobol draw, a roulette applied one bounce
 early, a light pmf taken at the wrong point would move every pixel.  What may differ: roundings (the restatement intersects in float64,
@@ -41,6 +41,23 @@ def test_cornell_frame_per_pixel_against_the_numpy_restatement(hk, oracle, objec
     assert abs(img.mean() / ref.mean() - 1.0) < 1e-3
 
 
+@pytest.mark.parametrize("light,depth,spp", [("point", 5, 4), ("both", 6, 4)])
+def test_point_light_per_pixel_against_the_numpy_restatement(hk, oracle, light, depth, spp):
+    """A POINT light in the box, alone and beside the area light: a delta light in the light BVH (a point as bounds, a cone of the whole
+    sphere: light-bounds.jl:234-246), its intensity uplifted as an illuminant (polynomial of rgb / 2 max times D65, uplift.jl:515-540),
+    Li = scale I / r^2 with pdf 1, and next-event estimation WITHOUT the BSDF's pdf in the MIS weight (lights.jl:583-589) — while the area
+    light beside it keeps its MIS and its pmf in the same tree."""
+    from hikari_jl_amd import scenes
+    w = h = 32
+    s, film, cam = scenes.cornell_box(w, h, light=light)
+    ref, img = _both(hk, oracle, s, cam, w, h, spp, depth)
+    assert ref.shape == img.shape and np.isfinite(img).all() and ref.max() > 0
+    rel = np.sqrt(((img - ref) ** 2).sum(axis=2)) / (np.sqrt((ref ** 2).sum(axis=2)) + 1e-6)
+    print("%s: pixels within 2e-4: %.4f, within 1e-2: %.4f, worst %.3g, mean ratio %.6f" % (light, (rel <= 2e-4).mean(), (rel <= 1e-2).mean(), rel.max(), img.mean() / ref.mean()))
+    assert (rel <= 2e-4).mean() >= 0.99 and (rel <= 1e-2).mean() >= 0.995
+    assert abs(img.mean() / ref.mean() - 1.0) < 1e-3
+
+
 @pytest.mark.parametrize("which", ["mirror", "glass"])
 def test_specular_objects_per_pixel_against_the_numpy_restatement(hk, oracle, which):
     """The box with a sphere and a slab of MirrorMaterial / GlassMaterial(index 1.5) under the area light, depth 7: the delta lobes
@@ -58,12 +75,13 @@ def test_specular_objects_per_pixel_against_the_numpy_restatement(hk, oracle, wh
 
 
 @pytest.mark.gpu
-def test_device_frame_per_pixel_against_the_numpy_restatement(hk):
-    """The same comparison for the HIP path: the device's Cornell frame (sphere + box, depth 5, 4 spp, box filter) against the NumPy
-    restatement, pixel by pixel — no oracle in between."""
+@pytest.mark.parametrize("light", ["area", "both"])
+def test_device_frame_per_pixel_against_the_numpy_restatement(hk, light):
+    """The same comparison for the HIP path: the device's Cornell frame (sphere + box, depth 5, 4 spp, box filter; under the area light,
+    and under the area light and a point light) against the NumPy restatement, pixel by pixel — no oracle in between."""
     from hikari_jl_amd import scenes
     w = h = 32
-    s, film, cam = scenes.cornell_box(w, h, light="area")
+    s, film, cam = scenes.cornell_box(w, h, light=light)
     vp = hk.VolPath(max_depth=5, samples=4, filter=hk.BoxFilter())
     vp(s, film, cam)
     dev = film.framebuffer.copy()

@@ -41,7 +41,9 @@ def cornell_box(width=800, height=800, light="area", spheres=True, tess=32, obje
     green = MatteMaterial(Kd=RGBSpectrum(0.12, 0.45, 0.15))
     box, half = 2.0, 1.0
     s = Scene()
-    if light in ("point", "both"):
+    if light in ("dir", "all"):      # into the open front of the box, downwards
+        s.push(DirectionalLight(RGBSpectrum(2.0, 1.9, 1.6), (0.25, -0.45, 1.0)))
+    if light in ("point", "both", "all"):
         s.push(PointLight((0, 1.8, 0) if light == "point" else (0.5, 1.6, -0.4), RGBSpectrum(15.0) if light == "point" else RGBSpectrum(6.0, 5.0, 3.0)))
     s.push(G.rect3f((-half, 0, -half), (box, 0.01, box)), white)             # floor
     s.push(G.rect3f((-half, box - 0.01, -half), (box, 0.01, box)), white)    # ceiling
@@ -54,7 +56,7 @@ def cornell_box(width=800, height=800, light="area", spheres=True, tess=32, obje
             s.push(G.sphere((0.4, 0.35, 0.0), 0.3, tess), white)
         else:
             s.push(G.rect3f((0.15, 0.0, -0.1), (0.5, 0.6, 0.5)), white)
-    if light in ("area", "both"):
+    if light in ("area", "both", "all"):
         y = 1.98
         q = G.quad((-0.25, y, -0.25), (0.25, y, -0.25), (0.25, y, 0.25), (-0.25, y, 0.25), normal=(0, -1, 0))
         s.push(q, MediumInterface(MatteMaterial(Kd=RGBSpectrum(0.0)), emission=Emissive(Le=RGBSpectrum(1.0), scale=1.0, two_sided=False)))

@@ -1,4 +1,4 @@
-"""K1 - K13 of the VolPath integrator for OPAQUE MATTE, MIRROR and GLASS surfaces under DIFFUSE AREA LIGHTS and POINT LIGHTS (the Cornell box of BASELINE.json configs[1]),
+"""K1 - K13 of the VolPath integrator for OPAQUE MATTE, MIRROR and GLASS surfaces under DIFFUSE AREA LIGHTS, POINT LIGHTS and DIRECTIONAL LIGHTS (the Cornell box of BASELINE.json configs[1]),
 restated in float32 NumPy straight from the reference's Julia text — a second per-pixel source for the wavefront control flow
 (VERDICT r3 item 2b).  Nothing here is shared with oracle/ or the HIP library: no BVH (every ray is tested against every triangle, in
 float64), no work queues (arrays over all paths of one sample index with an `alive` mask), its own ZSobol, light BVH, uplift, film.
@@ -6,7 +6,7 @@ float64), no work queues (arrays over all paths of one sample index with an `ali
     integrators/volpath/volpath.jl:123-205 (camera rays), :214-270 (the seven draws of a bounce), :330-420 (film), :445-636 (the loop)
     integrators/volpath/surface-eval.jl:147-219 (emission + its MIS weight), :235-330 (next-event estimation), :395-505 (BSDF sample, roulette)
     integrators/volpath/intersection.jl:13-182 (surface geometry), :303-420, :564-600 (shadow rays without media)
-    integrators/physical-wavefront/lights.jl:39-58 (point light sample), :235-290 (triangle light sample), :535-600 (the direct-lighting record)
+    integrators/physical-wavefront/lights.jl:39-58 (point light sample), :108-125 (directional), :235-290 (triangle light sample), :535-600 (the direct-lighting record)
     spectral/uplift.jl:412-457 (D65 table and lookup), :515-540 (RGB as an illuminant); lights/light-bounds.jl:234-246 (point light bounds)
     integrators/physical-wavefront/material-dispatch.jl:263-287 (roulette)
     lights/bvh-light-sampler.jl:58-230 (importance, sample, pmf), :239-447 (SAH build); lights/light-bounds.jl (cones, bounds, triangle bounds)
@@ -327,6 +327,7 @@ class LightBVH:
         self.nodes = []                       # (LB, child1_or_light, is_leaf)
         self.trail = {}
         items = [(i + 1, lb) for i, lb in enumerate(lights) if lb is not None and lb.phi > 0]
+        self.inf = np.array([i + 1 for i, lb in enumerate(lights) if lb is None], np.int64)     # lights without bounds (bvh-light-sampler.jl:298-310)
         self.n = len(items)
         if items:
             self._build(items, 0, len(items) - 1, 0, 0)
@@ -433,16 +434,27 @@ class LightBVH:
         return np.where((self.phi[k] == 0) | (cp <= self.cos_e[k]), f32(0), imp).astype(f32)
 
     def sample(self, p, n, u):
-        """bvh_sample_light without infinite lights -> (1-based light index or 0, pmf)"""
+        """bvh_sample_light (bvh-light-sampler.jl:105-170) -> (1-based light index or 0, pmf)"""
         N = p.shape[0]
         light = np.zeros(N, np.int64)
         pmf_out = np.zeros(N, f32)
+        ninf = len(self.inf)
+        if ninf + self.n == 0:
+            return light, pmf_out
+        p_inf = f32(ninf) / f32(ninf + (1 if self.n > 0 else 0))
+        run = np.ones(N, bool)
+        if ninf > 0:                          # the infinite lights share p_inf uniformly
+            take = u < p_inf
+            ur = u / p_inf
+            k = np.minimum(np.floor(ur * f32(ninf)).astype(np.int64), ninf - 1)
+            light[take] = self.inf[k[take]]
+            pmf_out[take] = p_inf / f32(ninf)
+            run &= ~take
         if self.n == 0:
             return light, pmf_out
-        ub = np.minimum(u, f32(0.99999994))
-        pmf = np.ones(N, f32)
+        ub = np.minimum((u - p_inf) / (f32(1) - p_inf), f32(0.99999994)).astype(f32) if ninf > 0 else np.minimum(u, f32(0.99999994))
+        pmf = np.full(N, f32(1) - p_inf, f32)
         node = np.zeros(N, np.int64)
-        run = np.ones(N, bool)
         for _ in range(64):
             at_leaf = run & self.leaf[node]
             light[at_leaf] = self.child[node[at_leaf]]
@@ -465,9 +477,10 @@ class LightBVH:
         return light, pmf_out
 
     def pmf(self, p, n, light_idx):
-        """bvh_pmf by bit trail (light_idx: array of 1-based indices, all bounded lights)"""
+        """bvh_pmf by bit trail (bvh-light-sampler.jl:184-232; light_idx: array of 1-based indices of BOUNDED lights)"""
         N = p.shape[0]
-        pm = np.ones(N, f32)
+        ninf = len(self.inf)
+        pm = np.full(N, f32(1) - f32(ninf) / f32(ninf + 1), f32)
         out = np.zeros(N, f32)
         node = np.zeros(N, np.int64)
         trail = np.array([self.trail.get(int(i), 0) for i in light_idx], np.int64)
@@ -509,7 +522,8 @@ class SceneNP:
         self.ior = F([m.f[0].v if m.kind == 2 else 1.0 for m in mats])
         self.mat_of_mi = np.array([desc.media_interfaces[i].material for i in range(desc.n_media_interfaces)], np.int64)
         self.lights = [desc.lights[i] for i in range(desc.n_lights)]
-        assert all(l.kind in (0, 6) for l in self.lights), "point lights and diffuse area lights only"
+        assert all(l.kind in (0, 2, 6) for l in self.lights), "point, directional and diffuse area lights only"
+        self.ldir = F([[l.direction[k] for k in range(3)] for l in self.lights])
         self.lkind = np.array([l.kind for l in self.lights], np.int64)
         self.lv = F([[l.v[k] for k in range(9)] for l in self.lights]).reshape(-1, 3, 3)
         self.ln = F([[l.normal[k] for k in range(3)] for l in self.lights])
@@ -525,9 +539,9 @@ class SceneNP:
         for i, l in enumerate(self.lights):
             rgb = [f32(l.i_rgb[k]) for k in range(3)]
             m = max(rgb)
-            if l.kind == 0:
+            if l.kind in (0, 2):
                 assert l.spectrum_kind == 0, "RGB intensity (uplifted per wavelength), not a baked illuminant"
-            if l.kind == 0 and m > 0:
+            if l.kind in (0, 2) and m > 0:
                 sc2 = f32(2) * m
                 self.li_scale2[i] = sc2
                 li_poly.append(tables.rgb_to_poly([c / sc2 for c in rgb]))
@@ -536,6 +550,9 @@ class SceneNP:
         self.li_poly = F(li_poly)
         bounds = []
         for i, l in enumerate(self.lights):
+            if l.kind == 2:      # no bounds: an infinite light of the sampler (light-bounds.jl:231)
+                bounds.append(None)
+                continue
             if l.kind == 0:      # light-bounds.jl:234-246
                 lum = f32(0.212671) * f32(l.i_rgb[0]) + f32(0.715160) * f32(l.i_rgb[1]) + f32(0.072169) * f32(l.i_rgb[2])
                 phi = f32(4) * PI * f32(l.scale) * lum
@@ -733,6 +750,17 @@ def render(desc, cam_rec, tables_dict, width, height, n_samples, max_depth, max_
                 Li = np.where(is_pt[:, None], Li_p, Li).astype(f32)
                 lpdf_sa = np.where(is_pt, f32(1), lpdf_sa).astype(f32)
                 area_ok = np.where(is_pt, pt_ok, area_ok)
+            # a directional light (lights.jl:108-125): wi against its direction, p_light 10^6 away, Li = scale * I(lambda), pdf 1, a delta light
+            is_dir = sc.lkind[li] == 2
+            if is_dir.any():
+                wi_d = (-sc.ldir[li]).astype(f32)
+                Li_d = (sc.lscale[li][:, None] * eval_illuminant(sc.li_scale2[li], sc.li_poly[li], lm)).astype(f32)
+                pl = np.where(is_dir[:, None], (pi + f32(1.0e6) * wi_d).astype(f32), pl).astype(f32)
+                wi = np.where(is_dir[:, None], wi_d, wi).astype(f32)
+                Li = np.where(is_dir[:, None], Li_d, Li).astype(f32)
+                lpdf_sa = np.where(is_dir, f32(1), lpdf_sa).astype(f32)
+                area_ok = np.where(is_dir, ~is_black(Li_d), area_ok)
+                is_pt = is_pt | is_dir                                                  # (delta lights, for the MIS weight below)
             ok &= area_ok
             ci, co = dot(wi, ns), dot(wo, ns)
             bs_ok = ~(ci * co < 0) & ~(np.abs(ci) < f32(1e-6)) & (kind == 0)     # (Mirror / Glass evaluate to zero: spectral-eval.jl:399-413)

@@ -8,7 +8,7 @@ f32 = np.float32
 from . import geometry as G
 from .camera import PerspectiveCamera
 from .film import Film
-from .lights import DirectionalLight, PointLight, SpotLight
+from .lights import AmbientLight, DirectionalLight, PointLight, SpotLight
 from .materials import (ConductorMaterial, Emissive, GlassMaterial, MatteMaterial, MediumInterface, MirrorMaterial,
                         RGBSpectrum)
 from .scene import Scene
@@ -41,6 +41,8 @@ def cornell_box(width=800, height=800, light="area", spheres=True, tess=32, obje
     green = MatteMaterial(Kd=RGBSpectrum(0.12, 0.45, 0.15))
     box, half = 2.0, 1.0
     s = Scene()
+    if light in ("ambient", "all"):
+        s.push(AmbientLight(RGBSpectrum(0.5, 0.6, 0.9)))
     if light in ("spot", "all"):     # from the front top left onto the objects, 25 degree cone with a soft edge from 15
         s.push(SpotLight((-0.7, 1.7, -0.8), (0.1, 0.3, 0.1), RGBSpectrum(20.0, 18.0, 14.0), 25.0, 15.0))
     if light in ("dir", "all"):      # into the open front of the box, downwards

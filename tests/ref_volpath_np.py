@@ -1,4 +1,4 @@
-"""K1 - K13 of the VolPath integrator for OPAQUE MATTE, MIRROR and GLASS surfaces under DIFFUSE AREA, POINT, SPOT and DIRECTIONAL LIGHTS (the Cornell box of BASELINE.json configs[1]),
+"""K1 - K13 of the VolPath integrator for OPAQUE MATTE, MIRROR and GLASS surfaces under DIFFUSE AREA, POINT, SPOT, DIRECTIONAL and AMBIENT LIGHTS (the Cornell box of BASELINE.json configs[1]),
 restated in float32 NumPy straight from the reference's Julia text — a second per-pixel source for the wavefront control flow
 (VERDICT r3 item 2b).  Nothing here is shared with oracle/ or the HIP library: no BVH (every ray is tested against every triangle, in
 float64), no work queues (arrays over all paths of one sample index with an `alive` mask), its own ZSobol, light BVH, uplift, film.
@@ -6,7 +6,7 @@ float64), no work queues (arrays over all paths of one sample index with an `ali
     integrators/volpath/volpath.jl:123-205 (camera rays), :214-270 (the seven draws of a bounce), :330-420 (film), :445-636 (the loop)
     integrators/volpath/surface-eval.jl:147-219 (emission + its MIS weight), :235-330 (next-event estimation), :395-505 (BSDF sample, roulette)
     integrators/volpath/intersection.jl:13-182 (surface geometry), :303-420, :564-600 (shadow rays without media)
-    integrators/physical-wavefront/lights.jl:39-58 (point light sample), :66-100 (spot), :108-125 (directional), :235-290 (triangle light sample), :535-600 (the direct-lighting record)
+    integrators/physical-wavefront/lights.jl:39-58 (point light sample), :66-100 (spot), :108-125 (directional), :199-221, :423-448 (ambient: sampled, and met by an escaped ray), :235-290 (triangle light sample), :535-600 (the direct-lighting record)
     spectral/uplift.jl:412-457 (D65 table and lookup), :515-540 (RGB as an illuminant); lights/light-bounds.jl:234-246 (point light bounds)
     integrators/physical-wavefront/material-dispatch.jl:263-287 (roulette)
     lights/bvh-light-sampler.jl:58-230 (importance, sample, pmf), :239-447 (SAH build); lights/light-bounds.jl (cones, bounds, triangle bounds)
@@ -522,7 +522,7 @@ class SceneNP:
         self.ior = F([m.f[0].v if m.kind == 2 else 1.0 for m in mats])
         self.mat_of_mi = np.array([desc.media_interfaces[i].material for i in range(desc.n_media_interfaces)], np.int64)
         self.lights = [desc.lights[i] for i in range(desc.n_lights)]
-        assert all(l.kind in (0, 1, 2, 6) for l in self.lights), "point, spot, directional and diffuse area lights only"
+        assert all(l.kind in (0, 1, 2, 4, 6) for l in self.lights), "point, spot, directional, ambient and diffuse area lights only"
         self.lw2l = F([[l.world_to_light[k] for k in range(16)] for l in self.lights]).reshape(-1, 4, 4)
         self.lcos_tot = F([l.cos_total_width for l in self.lights])
         self.lcos_fall = F([l.cos_falloff_start for l in self.lights])
@@ -542,9 +542,9 @@ class SceneNP:
         for i, l in enumerate(self.lights):
             rgb = [f32(l.i_rgb[k]) for k in range(3)]
             m = max(rgb)
-            if l.kind in (0, 1, 2):
+            if l.kind in (0, 1, 2, 4):
                 assert l.spectrum_kind == 0, "RGB intensity (uplifted per wavelength), not a baked illuminant"
-            if l.kind in (0, 1, 2) and m > 0:
+            if l.kind in (0, 1, 2, 4) and m > 0:
                 sc2 = f32(2) * m
                 self.li_scale2[i] = sc2
                 li_poly.append(tables.rgb_to_poly([c / sc2 for c in rgb]))
@@ -553,7 +553,7 @@ class SceneNP:
         self.li_poly = F(li_poly)
         bounds = []
         for i, l in enumerate(self.lights):
-            if l.kind == 2:      # no bounds: an infinite light of the sampler (light-bounds.jl:231)
+            if l.kind in (2, 4):      # no bounds: an infinite light of the sampler (light-bounds.jl:231)
                 bounds.append(None)
                 continue
             if l.kind == 1:      # light-bounds.jl:248-272: a point, the cone of the spot
@@ -686,7 +686,25 @@ def render(desc, cam_rec, tables_dict, width, height, n_samples, max_depth, max_
             i_rr = zs.d1(apx, apy, sidx, base + 7)
             o, dd = ro[A], rd[A]
             hit, prim, t, bu, bv = sc.intersect(o, dd, np.full(len(A), np.inf))
-            alive[A[~hit]] = False                                   # escaped: no infinite lights in this scene
+            # ---- K7 (intersection.jl:622-668): an escaped ray collects the ambient lights; only an environment map has a pdf, so the MIS
+            #      weight of this "light hit" is 1 / average(r_u) on every path ----
+            amb = np.nonzero(sc.lkind == 4)[0]
+            if len(amb) and (~hit).any():
+                E = np.nonzero(~hit)[0]
+                Le = np.zeros((len(E), 4), f32)
+                for k in amb:
+                    kk = np.full(len(E), k)
+                    Le = (Le + sc.lscale[kk][:, None] * eval_illuminant(sc.li_scale2[kk], sc.li_poly[kk], lam[A[E]])).astype(f32)
+                contrib = beta[A[E]] * Le
+                ru_e, rl_e = r_u[A[E]], r_l[A[E]]
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    plain = contrib / average(ru_e)[:, None]
+                    light_pdf = f32(0)                                          # compute_env_light_pdf: environment maps only (lights.jl:452-467)
+                    den = average(ru_e + rl_e * (f32(1) / f32(len(sc.lights))) * light_pdf)
+                    mis = np.where((den > f32(1e-10))[:, None], contrib / den[:, None], plain)
+                fin = plain if depth == 0 else np.where(spec[A[E]][:, None], plain, mis)
+                L[A[E]] += np.where(is_black(contrib)[:, None], f32(0), fin).astype(f32)
+            alive[A[~hit]] = False
             A, o, dd, prim, t, bu, bv = A[hit], o[hit], dd[hit], prim[hit], t[hit].astype(f32), bu[hit].astype(f32), bv[hit].astype(f32)
             d_uc, d_u0, d_u1, i_uc, i_u0, i_u1, i_rr = d_uc[hit], d_u0[hit], d_u1[hit], i_uc[hit], i_u0[hit], i_u1[hit], i_rr[hit]
             if len(A) == 0:
@@ -787,6 +805,19 @@ def render(desc, cam_rec, tables_dict, width, height, n_samples, max_depth, max_
                 lpdf_sa = np.where(is_dir, f32(1), lpdf_sa).astype(f32)
                 area_ok = np.where(is_dir, ~is_black(Li_d), area_ok)
                 is_pt = is_pt | is_dir                                                  # (delta lights, for the MIS weight below)
+            # an ambient light (lights.jl:199-221): a uniform direction of the sphere, pdf 1 / 4 pi, NOT a delta light
+            is_amb = sc.lkind[li] == 4
+            if is_amb.any():
+                z = f32(1) - f32(2) * d_u0
+                r = np.sqrt(np.maximum(f32(0), f32(1) - z * z))
+                phi = f32(2) * PI * d_u1
+                wi_a = np.stack([r * np.cos(phi).astype(f32), r * np.sin(phi).astype(f32), z], -1).astype(f32)
+                Li_a = (sc.lscale[li][:, None] * eval_illuminant(sc.li_scale2[li], sc.li_poly[li], lm)).astype(f32)
+                pl = np.where(is_amb[:, None], (pi + f32(1.0e6) * wi_a).astype(f32), pl).astype(f32)
+                wi = np.where(is_amb[:, None], wi_a, wi).astype(f32)
+                Li = np.where(is_amb[:, None], Li_a, Li).astype(f32)
+                lpdf_sa = np.where(is_amb, f32(1) / (f32(4) * PI), lpdf_sa).astype(f32)
+                area_ok = np.where(is_amb, ~is_black(Li_a), area_ok)
             ok &= area_ok
             ci, co = dot(wi, ns), dot(wo, ns)
             bs_ok = ~(ci * co < 0) & ~(np.abs(ci) < f32(1e-6)) & (kind == 0)     # (Mirror / Glass evaluate to zero: spectral-eval.jl:399-413)

@@ -1,5 +1,5 @@
 """The wavefront control flow, per pixel, from a second source: tests/ref_volpath_np.py restates K1 - K13 for opaque
-matte / mirror / glass surfaces under diffuse area, point, spot and directional lights in float32 NumPy from the Julia text (own ZSobol, own light BVH, brute-force float64
+matte / mirror / glass surfaces under diffuse area, point, spot, directional and ambient lights in float32 NumPy from the Julia text (own ZSobol, own light BVH, brute-force float64
 intersection, no queues) and is compared PIXEL BY PIXEL with the oracle's frame of the Cornell box of BASELINE.json configs[1]: the same
 sample indices, the same path per (pixel, sample) — a wrong MIS weight, a wrong dimension of a Sobol draw, a roulette applied one bounce
 early, a light pmf taken at the wrong point would move every pixel.  What may differ: roundings (the restatement intersects in float64,
@@ -41,7 +41,7 @@ def test_cornell_frame_per_pixel_against_the_numpy_restatement(hk, oracle, objec
     assert abs(img.mean() / ref.mean() - 1.0) < 1e-3
 
 
-@pytest.mark.parametrize("light,depth,spp", [("point", 5, 4), ("both", 6, 4), ("dir", 4, 4), ("spot", 5, 4), ("all", 6, 4)])
+@pytest.mark.parametrize("light,depth,spp", [("point", 5, 4), ("both", 6, 4), ("dir", 4, 4), ("spot", 5, 4), ("ambient", 5, 4), ("all", 6, 4)])
 def test_delta_lights_per_pixel_against_the_numpy_restatement(hk, oracle, light, depth, spp):
     """A POINT light in the box, alone and beside the area light: a delta light in the light BVH (a point as bounds, a cone of the whole
     sphere: light-bounds.jl:234-246), its intensity uplifted as an illuminant (polynomial of rgb / 2 max times D65, uplift.jl:515-540),
@@ -51,7 +51,10 @@ def test_delta_lights_per_pixel_against_the_numpy_restatement(hk, oracle, light,
     random number remapped for the tree, every tree pmf (next-event estimation and the MIS weight of emission that is hit) scaled by
     1 - p_inf (bvh-light-sampler.jl:105-232); wi against its direction, the shadow ray 10^6 long (lights.jl:108-125).  And a SPOT light
     ("spot"; also part of "all"): -wi taken to the light's frame, nothing outside the cone, the fourth-power edge between the two cosines
-    (lights.jl:66-100), its bounds a point with the cone of the spot (light-bounds.jl:248-272)."""
+    (lights.jl:66-100), its bounds a point with the cone of the spot (light-bounds.jl:248-272).  And an AMBIENT light ("ambient"; part of
+    "all"): an infinite light that is NOT a delta light — a uniform direction of the sphere with pdf 1 / 4 pi and the BSDF's pdf in the MIS
+    weight (lights.jl:199-221) — and the one kind an ESCAPED ray meets (K7, intersection.jl:622-668: its radiance over average(r_u), or
+    over average(r_u + r_l / n_lights * 0) after a non-specular bounce: only an environment map has a pdf there)."""
     from hikari_jl_amd import scenes
     w = h = 32
     s, film, cam = scenes.cornell_box(w, h, light=light)
@@ -83,7 +86,7 @@ def test_specular_objects_per_pixel_against_the_numpy_restatement(hk, oracle, wh
 @pytest.mark.parametrize("light", ["area", "all"])
 def test_device_frame_per_pixel_against_the_numpy_restatement(hk, light):
     """The same comparison for the HIP path: the device's Cornell frame (sphere + box, depth 5, 4 spp, box filter; under the area light,
-    and under area + point + spot + directional light) against the NumPy restatement, pixel by pixel — no oracle in between."""
+    and under area + point + spot + directional + ambient light) against the NumPy restatement, pixel by pixel — no oracle in between."""
     from hikari_jl_amd import scenes
     w = h = 32
     s, film, cam = scenes.cornell_box(w, h, light=light)

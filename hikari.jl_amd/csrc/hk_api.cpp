@@ -141,7 +141,11 @@ struct DevBuf {
     int slab_dev = -1;   // >= 0: a path-state slab of that device (goes back to g_slabs, not to the driver)
     void release() {
         if (p && slab_dev >= 0) {
-            (void)hipDeviceSynchronize();   // (hipFree would have waited for the kernels that still use it)
+            int cur = -1;   // (hipFree would have waited for the kernels that still use it: wait for the slab's own device)
+            (void)hipGetDevice(&cur);
+            if (cur != slab_dev) (void)hipSetDevice(slab_dev);
+            (void)hipDeviceSynchronize();
+            if (cur >= 0 && cur != slab_dev) (void)hipSetDevice(cur);
             g_slabs.give(slab_dev, p, bytes);
         } else if (p)
             (void)hipFree(p);

@@ -392,7 +392,7 @@ def child_config_line(config, progressive_calls):
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE"):
         env.pop(k, None)
-    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     if out.returncode != 0:
         raise RuntimeError("exit code %d: %s" % (out.returncode, out.stderr.decode(errors="replace")[-300:]))
     d = json.loads(out.stdout.decode().strip().splitlines()[-1])

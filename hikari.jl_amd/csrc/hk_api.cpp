@@ -29,6 +29,7 @@ void launch_escaped(hipStream_t, int, const DPathState&, const DScene&, const DT
 void launch_medium(hipStream_t, int, const DPathState&, const DScene&, const DTables&, const DFrame&, const DSobol&, int, DStats*);
 void launch_detect_camera_medium(hipStream_t, const DPathState&, const DScene&, float, float, float, DStats*);
 void launch_shade(hipStream_t, int, int, const DPathState&, const DScene&, const DTables&, const DFrame&, const DSobol&, int, int, DStats*);
+bool grey_compact_ok(const DScene&);
 bool preselect_lights(const DScene&, const DPathState&);
 void launch_light_select(hipStream_t, int, const DPathState&, const DScene&, const DTables&, const DFrame&, const DSobol&, int, uint32_t, DStats*);
 void launch_film(hipStream_t, const DPathState&, const DFrame&, const DTables&, void*, bool);
@@ -1352,7 +1353,7 @@ hipError_t alloc_arr(hk_integrator* I, T*& dst, size_t n) {
 //   surfaces, open scene      static stride, 48 per CU   (sky: most paths escape after 1-2 vertices; finer segments only fragment
 //                             the per-kind queues: k_shade +7 % at 96, +15 % at 256, whichever way they are handed out)
 // HK_WAVES_PER_CU / HK_DYNAMIC_SEGMENTS override.  stats rows are indexed by PHYSICAL wave (ctx->stat_rows).
-int ensure_state(hk_integrator* I, int capacity, bool media, bool open_scene, bool small_scene, hipStream_t users = nullptr) {
+int ensure_state(hk_integrator* I, int capacity, bool media, bool open_scene, bool small_scene, bool grey_compact, hipStream_t users = nullptr) {
     const int n_cu = I->ctx->n_cu;
     // a closed scene's pass of at most HK_MID_PASS_PATHS_M (48) million paths — a rank's share of a frame under 8-way strong scaling —
     // behaves like the open scene WHEN THE SCENE IS SMALL (BVH depth <= 16, the Cornell box): the deep bounces hold a few dozen rays per
@@ -1372,7 +1373,7 @@ int ensure_state(hk_integrator* I, int capacity, bool media, bool open_scene, bo
     W_want = (W_want + 3) / 4 * 4;
     I->st.dynamic_segments = (media || (!open_scene && !mid)) ? 1 : 0;
     if (const char* e = std::getenv("HK_DYNAMIC_SEGMENTS")) I->st.dynamic_segments = std::atoi(e) ? 1 : 0;
-    I->st.compact = media ? 0 : 1;
+    I->st.compact = media ? (grey_compact ? 1 : 0) : 1;
     I->st.ticket_share = 1;
     if (const char* e = std::getenv("HK_TICKET_SHARE")) I->st.ticket_share = std::atoi(e) ? 1 : 0;
     {   // a SMALL pass (at most 16 chunks for each of 4 waves per CU: a one-sample call at 800^2) hands segment g to wave g of every launch
@@ -1667,7 +1668,7 @@ static int render_tile_now(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_film* f
         }
     } set_guard{I, piped ? &I->lane_sets[lane_idx] : nullptr};
     if (piped) I->swap_set(I->lane_sets[lane_idx]);
-    int st = ensure_state(I, S * fr.n_pixels_padded, sc->d.n_media > 0, sc->d.has_escape_lights != 0, sc->d.bvh_depth <= 16, piped ? c->lanes[lane_idx].stream : nullptr);
+    int st = ensure_state(I, S * fr.n_pixels_padded, sc->d.n_media > 0, sc->d.has_escape_lights != 0, sc->d.bvh_depth <= 16, sc->d.n_media > 0 && hk::grey_compact_ok(sc->d), piped ? c->lanes[lane_idx].stream : nullptr);
     if (st != HK_OK) return st;
     fr.sample_stride = sample_stride;
     fr.max_depth = I->p.max_depth;

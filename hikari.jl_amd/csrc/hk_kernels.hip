@@ -200,6 +200,12 @@ __device__ __forceinline__ void st_ru_rl(const DPathGen& g, size_t p, S4 r_u, S4
         st4(&g.r_l[p], r_l);
     }
 }
+__device__ __forceinline__ void mul_rl(const DPathGen& g, size_t p, bool ones, float f, bool compact) {   // r_l[p] *= f
+    if (compact)
+        reinterpret_cast<float*>(g.r_l)[p] = (ones ? 1.0f : reinterpret_cast<const float*>(g.r_l)[p]) * f;
+    else
+        st4(&g.r_l[p], ld_throughput(g.r_l, p, ones) * f);
+}
 __device__ __forceinline__ void st_shadow_weights(const DPathState& st, size_t rec, S4 ru, S4 rl) {
     if (st.compact)
         reinterpret_cast<float2*>(st.sh_ru)[rec] = make_float2(ru.x, rl.x);
@@ -485,8 +491,7 @@ __global__ void __launch_bounds__(256) k_camera(DPathState st, DFrame fr, DTable
             // shading event, so they are not stored and the depth-0 readers substitute the constant (ld_throughput)
             if (!fr.implicit_ones) {
                 st4(&g0.beta[p], s4(1.0f));
-                st4(&g0.r_u[p], s4(1.0f));
-                st4(&g0.r_l[p], s4(1.0f));
+                st_ru_rl(g0, p, s4(1.0f), s4(1.0f), st.compact != 0);
             }
             stream_st(&g0.meta[p], make_uint2((uint32_t)(*st.initial_medium + 1) << 16, (uint32_t)slot));
             stream_st(&st.lambda_s[slot], lambda);
@@ -1637,7 +1642,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
         if (have && (key & 15) == TP_SURVIVED) {
             // survived to t_max: hand the stored surface hit / the escape over with the updated throughput
             const float rl = __int_as_float(ring[2 * TP_RING + p]);
-            st4(&g.r_l[rslot], ld_throughput(g.r_l, rslot, ones) * rl);
+            mul_rl(g, rslot, ones, rl, st.compact != 0);
             const float4 H = st.hit[rslot];
             const int prim = __float_as_int(H.y);
             int cls = 0;
@@ -1735,7 +1740,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
                 const float4 O = g.ray_o[s_new], D = g.ray_d[s_new];
                 const v3 o = mk3(O.x, O.y, O.z), d = mk3(D.x, D.y, D.z);
                 const float t_max = st.hit[s_new].x;
-                const bool dead = is_black(ld_throughput(g.beta, s_new, ones)) || is_black(ld_throughput(g.r_u, s_new, ones));
+                const bool dead = is_black(ld_throughput(g.beta, s_new, ones)) || is_black(ld_ru(g, s_new, ones, st.compact != 0));
                 const uint64_t r = lcg_init(o, d, t_max);
                 const MajorantIter it = create_majorant_iterator<MM>(med, o, d, t_max);
                 int* e = pool + lane;
@@ -1937,7 +1942,7 @@ __global__ void __launch_bounds__(256) k_scatter(DPathState st, DScene sc, DTabl
                 const float sg = sc.media[medium_idx].g;
                 lambda = ld_lambda(st, g, slot, pslot);
                 beta = ld4(&g.beta[slot]);
-                r_u = ld4(&g.r_u[slot]);
+                r_u = ld_ru(g, slot, false, st.compact != 0);
                 int pix, k;
                 split_slot(fr, pslot, pix, k);
                 SobolCtx sctx = sobol_ctx_slot(sob, T.sobol, fr.x0, fr.y0, fr.tiles_x, pix, k, fr.first_sample + k * fr.sample_stride);
@@ -1985,8 +1990,7 @@ __global__ void __launch_bounds__(256) k_scatter(DPathState st, DScene sc, DTabl
                 st.sh_o[ps] = shO;
                 st.sh_d[ps] = shD;
                 st4(&st.sh_Ld[ps], shLd);
-                st4(&st.sh_ru[ps], shRu);
-                st4(&st.sh_rl[ps], shRl);
+                st_shadow_weights(st, ps, shRu, shRl);
                 st.sh_slot[ps] = pslot;
             }
             const size_t pn = seg + (size_t)wp_push(q_next, push_ray);
@@ -1994,8 +1998,7 @@ __global__ void __launch_bounds__(256) k_scatter(DPathState st, DScene sc, DTabl
                 gn.ray_o[pn] = O;
                 gn.ray_d[pn] = nD;
                 st4(&gn.beta[pn], beta);
-                st4(&gn.r_u[pn], r_u);
-                st4(&gn.r_l[pn], n_rl);
+                st_ru_rl(gn, pn, r_u, n_rl, st.compact != 0);
                 st_lambda(gn, pn, lambda);
                 gn.meta[pn] = make_uint2(nflags, pslot);
             }
@@ -2603,6 +2606,14 @@ HKD void shadow_contribute(DPathState& st, uint32_t rec, S4 T_ray, S4 tr_u, S4 t
     }
 }
 
+// the layout of the shadow weights is a run-time fact where grey media may or may not use the compact records (k_walk_pool)
+HKD void shadow_contribute_rt(DPathState& st, uint32_t rec, S4 T_ray, S4 tr_u, S4 tr_l) {
+    if (st.compact)
+        shadow_contribute<true>(st, rec, T_ray, tr_u, tr_l);
+    else
+        shadow_contribute<false>(st, rec, T_ray, tr_u, tr_l);
+}
+
 template <bool COUNT, int STACK, int BLOCK = HK_TRACE_BLOCK, int NC = 0>
 __global__ void __launch_bounds__(BLOCK) k_shadow(DPathState st, DScene sc, int depth, DStats* stats) {
     __shared__ int lds_stack[(BLOCK / 64) * STACK * 64];
@@ -3202,7 +3213,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
                         c_fl |= (miss_case ? WF_MISS : 0) | (transition ? WF_TRANSITION : 0) | (next_medium >= 0 ? WF_NEXT_MEDIUM : 0) | ((it.mode & 0xff) == 2 ? WF_IT_LIVE : 0) | (it.mode & 0x700);
                         out = 1;
                     } else if (miss_case) {
-                        shadow_contribute<false>(st, c_slot, s4(c_T), s4(c_u), s4(c_l));
+                        shadow_contribute_rt(st, c_slot, s4(c_T), s4(c_u), s4(c_l));
                     } else {
                         // step over the surface (no medium on this side)
                         const bool stop = transition && c_T == 0.0f;
@@ -3411,7 +3422,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(HK_TRACE_BLOCK, HK_TR
                     tr_l = tr_l * sl;
                     state = SH_EMPTY;
                     if (fl & WF_MISS)
-                        shadow_contribute<false>(st, slot, s4(T_ray), s4(tr_u), s4(tr_l));
+                        shadow_contribute_rt(st, slot, s4(T_ray), s4(tr_u), s4(tr_l));
                     else {
                         const bool stop = (fl & WF_TRANSITION) != 0 && T_ray == 0.0f;
                         const int medium_bit = (fl & WF_TRANSITION) ? ((fl & WF_NEXT_MEDIUM) ? WF_MEDIUM : 0) : WF_MEDIUM;
@@ -4451,6 +4462,16 @@ static void launch_walk_split(hipStream_t s, int n_cu, const DPathState& st, con
         hipLaunchKernelGGL((k_walk_cast<C, MM, 16>), dim3(cb), dim3(HK_TRACE_BLOCK), 0, s, st, sc, depth, round, stats, sc.media);
         hipLaunchKernelGGL((k_walk_track<MM>), dim3(tb), dim3(256), 0, s, st, sc, depth, round, fr.walk_tune, stats, sc.media);
     }
+}
+// The compact records (r_u == 1 not stored, r_l one float: DPathState::compact) also hold in a scene whose one medium is grey AND runs
+// through the pool kernels (k_track_pool / k_walk_pool, the only media kernels that know the compact layout): r_u is never touched
+// there and every factor of r_l is a scalar.  HK_GREY_COMPACT=0: the full records.
+bool grey_compact_ok(const DScene& sc) {
+    const char* e = std::getenv("HK_GREY_COMPACT");
+    if (e && std::atoi(e) == 0) return false;
+    const int mc = sc.n_media > 0 ? media_mask_class(sc) : 0;
+    return sc.n_media == 1 && sc.all_grey && sc.grey_pool && (mc == 2 || mc == 8) && sc.bvh_depth <= 16 && grey_mode() && grey_flat_mode() && track_pool_mode() && walk_pool_mode() &&
+           !walk_split_mode();
 }
 void launch_shadow(hipStream_t s, int n_cu, const DPathState& st, const DScene& sc, const DTables& T, const DFrame& fr, int depth, DStats* stats) {
     if (sc.all_opaque && sc.n_media == 0) {

@@ -749,7 +749,7 @@ def test_scheduling_is_result_neutral(hk, monkeypatch, which):
         s, film, cam = scenes.slab_scene(w, h, hk.HomogeneousMedium(sigma_a=hk.RGBSpectrum(0.2), sigma_s=hk.RGBSpectrum(0.8, 0.7, 0.6), g=0.3))
         kw = dict(max_depth=6, samples=64)
     knobs = ("HK_OVERLAP", "HK_DYNAMIC_SEGMENTS", "HK_WAVES_PER_CU", "HK_NODE_CACHE", "HK_WALK_SPLIT", "HK_GREY", "HK_DELTA_ADVANCE", "HK_TRACK_ADVANCE",
-             "HK_SHADOW_TRACK_BATCH", "HK_SHADOW_FEED_ROUNDS", "HK_TRACK_REFILL_IDLE", "HK_WALK_REFILL_IDLE", "HK_GREY_FLAT", "HK_TRACK_POOL", "HK_WALK_POOL", "HK_SMALL_PASS", "HK_SMALL_PASS_WAVES", "HK_TICKET_SHARE")
+             "HK_SHADOW_TRACK_BATCH", "HK_SHADOW_FEED_ROUNDS", "HK_TRACK_REFILL_IDLE", "HK_WALK_REFILL_IDLE", "HK_GREY_FLAT", "HK_TRACK_POOL", "HK_WALK_POOL", "HK_SMALL_PASS", "HK_SMALL_PASS_WAVES", "HK_TICKET_SHARE", "HK_GREY_COMPACT")
 
     def run(env):
         for k in knobs:
@@ -782,7 +782,8 @@ def test_scheduling_is_result_neutral(hk, monkeypatch, which):
         # round 4: the tracking kernels with a per-wave ray pool in LDS (dense set-up / cast phases) against the per-lane refill kernels
         # they replace — k_track_pool / k_track_flat / k_track<GREY>, k_walk_pool (both pool sizes) / k_shadow_walk<GREY> — and under
         # odd segment counts (segments that end inside a phase, several segments per phase)
-        for env in ({"HK_TRACK_POOL": "0"}, {"HK_WALK_POOL": "0"}, {"HK_WALK_POOL": "2"}, {"HK_GREY_FLAT": "0"}, {"HK_TRACK_POOL": "0", "HK_WALK_POOL": "0", "HK_WAVES_PER_CU": "3"},
+        for env in ({"HK_GREY_COMPACT": "0"}, {"HK_GREY_COMPACT": "0", "HK_WAVES_PER_CU": "5"},      # (the pool kernels on the full records: r_u stored, r_l four floats)
+                    {"HK_TRACK_POOL": "0"}, {"HK_WALK_POOL": "0"}, {"HK_WALK_POOL": "2"}, {"HK_GREY_FLAT": "0"}, {"HK_TRACK_POOL": "0", "HK_WALK_POOL": "0", "HK_WAVES_PER_CU": "3"},
                     {"HK_WAVES_PER_CU": "3"}, {"HK_WAVES_PER_CU": "29", "HK_DELTA_ADVANCE": "1", "HK_TRACK_ADVANCE": "1"}, {"HK_WALK_POOL": "2", "HK_WAVES_PER_CU": "1"}, {"HK_WAVES_PER_CU": "0"}):   # (the segment count is sticky in the context: back to the default)
             got = run(env)
             assert np.array_equal(ref.view(np.uint32), got.view(np.uint32)), env

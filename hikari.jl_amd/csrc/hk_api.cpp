@@ -1562,11 +1562,11 @@ extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_
     if (n_samples == 0) return HK_OK;
     // A small call (a one-sample `render!`: < 1 path per resident lane, 26 launches of 26 - 100 us whatever they hold) is worth a seventh
     // of its time as part of a larger pass, and the film does not depend on the pass size (k_film adds in sample order).  So a small call
-    // is only NOTED; calls that continue it grow the note; the pass is rendered when the note holds HK_BATCH_PATHS_M (32) million paths,
+    // is only NOTED; calls that continue it grow the note; the pass is rendered when the note holds HK_BATCH_PATHS_M (64) million paths,
     // when a call comes that does not continue it, or when anything looks at the result (flush_pending).  Rendering is asynchronous
     // either way: a device error of a deferred pass is reported by the call that flushes it.  HK_BATCH_PATHS_M=0: every call at once.
     {
-        long batch_paths = 32L << 20, small_paths = 8L << 20;
+        long batch_paths = 64L << 20, small_paths = 8L << 20;   // (Cornell 800^2, 64 one-sample calls: 0.49 / 0.46 / 0.45 ms per call at 32 / 48 / 64 M, cloud 3.8 / 3.7 / 2.8)
         if (const char* e = std::getenv("HK_BATCH_PATHS_M")) batch_paths = std::atol(e) >= 0 ? std::atol(e) << 20 : batch_paths;
         if (const char* e = std::getenv("HK_PIPELINE_MAX_PATHS_M")) small_paths = std::atol(e) > 0 ? std::atol(e) << 20 : small_paths;
         const long px = (long)((x1 - x0 + 7) / 8) * ((y1 - y0 + 7) / 8) * 64;

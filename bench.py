@@ -64,6 +64,7 @@ def parse_args(argv=None):
                                                                  "viewer drives) measured after the timed region and reported as `progressive` (0 = skip)")
     ap.add_argument("--no-readback-pass", action="store_true", help="--progressive without the second pass that reads the frame back after every call (kernel traces)")
     ap.add_argument("--no-extra-configs", action="store_true", help="the default run without the one-frame lines of cloud / sky / manylight")
+    ap.add_argument("--detail-file", default=None, help="where the full record goes (default: bench_detail.json in the working directory); stdout carries the compact line only")
     args = ap.parse_args(argv)
     args.extra_configs = args.config is None and not args.no_extra_configs and args.gpus == 1 and not args.spp and not args.spp_per_pass
     args.config = args.config or "cornell"
@@ -274,6 +275,88 @@ def class_rooflines(config, timed, launches, sc, default_frame):
     return rooflines
 
 
+LINE_LIMIT = 3500              # the driver keeps the last ~8 000 characters of stdout: the ONE JSON line stays well inside them
+
+
+def _clip(text, n):
+    text = str(text)
+    return text if len(text) <= n else text[:n - 3] + "..."
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def compact_line(result, limit=LINE_LIMIT, detail_file="bench_detail.json"):
+    """The ONE stdout line: the contract's headline fields + `roofline` + `cpu_baseline` + one short entry per other BASELINE.json config
+    + the one-sample-per-call figures, at most `limit` characters.  Everything else the run measured (per-class `rooflines`, unit counts,
+    notes) is in `detail_file` and on stderr."""
+    head = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    line = {k: result.get(k) for k in head}
+    cfg = dict(result.get("config") or {})
+    cfg["workload"] = _clip(cfg.get("workload", ""), 200)
+    if "parallelism" in cfg:
+        cfg["parallelism"] = _clip(cfg["parallelism"], 90)
+    line["config"] = cfg
+    for k in ("seconds_per_frame", "seconds_to_256spp", "cold_frame_seconds"):
+        if k in result:
+            line[k] = result[k]
+    r = result.get("roofline") or {}
+    line["roofline"] = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
+    line["roofline"].update(_pick(r, ("kernel", "avg_launch_ms", "launches", "algorithmic_bytes_per_launch", "hbm_frac_by_traffic",
+                                      "traffic_over_algorithmic", "lane_util", "measured_copy_gbs", "kernel_seconds")))
+    cpu = result.get("cpu_baseline")
+    line["cpu_baseline"] = None if cpu is None else dict(_pick(cpu, ("value", "unit", "cores", "kind", "seconds_per_frame_extrapolated")),
+                                                           sample=_clip(cpu.get("sample", ""), 110))
+    if result.get("configs") is not None:
+        line["configs"] = []
+        for c in result["configs"]:
+            e = _pick(c, ("config", "seconds_per_frame", "value", "unit", "frames_timed", "warmup_frames", "error"))
+            if "workload" in c:
+                e["workload"] = _clip(c["workload"], 120)
+            if isinstance(c.get("roofline"), dict):
+                e["roofline"] = _pick(c["roofline"], ("kernel", "bound", "frac", "hbm_frac_by_traffic", "lane_util", "avg_launch_ms"))
+            if isinstance(c.get("kernel_seconds"), dict):
+                e["kernel_seconds"] = c["kernel_seconds"]
+            if isinstance(c.get("progressive"), dict):
+                e["progressive"] = _pick(c["progressive"], ("ms_per_call", "ms_per_call_with_readback", "vs_frame_sample"))
+            line["configs"].append(e)
+    if isinstance(result.get("progressive"), dict):
+        line["progressive"] = _pick(result["progressive"], ("calls", "ms_per_call", "ms_per_call_with_readback", "ms_per_call_batched_no_readback",
+                                                            "ms_per_sample_of_the_full_frame", "vs_frame_sample", "vs_frame_sample_with_readback", "error"))
+    line["detail"] = detail_file
+    # whatever a future field adds, the line never outgrows the driver: shed the least important parts first
+    shed = [lambda: [c.pop("kernel_seconds", None) for c in line.get("configs", [])],
+            lambda: [c.pop("progressive", None) for c in line.get("configs", [])],
+            lambda: line["roofline"].pop("kernel_seconds", None),
+            lambda: [c.pop("workload", None) for c in line.get("configs", [])],
+            lambda: line["config"].update(workload=_clip(line["config"]["workload"], 100)),
+            lambda: line.pop("configs", None),
+            lambda: line.pop("progressive", None)]
+    for drop in shed:
+        if len(json.dumps(line)) <= limit:
+            break
+        drop()
+    return line
+
+
+def emit(result, detail_path=None):
+    """Full record -> bench_detail.json (working directory) and stderr; the compact line -> stdout, the only stdout line of the run."""
+    detail_path = detail_path or os.path.join(os.getcwd(), "bench_detail.json")
+    full = json.dumps(result)
+    try:
+        with open(detail_path, "w") as f:
+            f.write(full + "\n")
+    except OSError as e:
+        sys.stderr.write("bench.py: could not write %s (%s)\n" % (detail_path, e))
+    sys.stderr.write("bench.py detail: " + full + "\n")
+    sys.stderr.flush()
+    text = json.dumps(compact_line(result, detail_file=os.path.basename(detail_path)))
+    assert len(text) <= LINE_LIMIT, len(text)
+    print(text)
+    sys.stdout.flush()
+
+
 def progressive_line(vp, scene, film, cam, calls, frame_spp, seconds_per_frame, torch):
     """The reference's interactive path: render!(vp, scene, film, camera) = ONE sample of every pixel per call (volpath.jl:445-450, 471-474),
     here hk_render(first = i, n = 1) for i = 1 .. calls on a cleared film, (a) back to back and (b) each followed by hk_film_read_rgb (the
@@ -312,11 +395,14 @@ def progressive_line(vp, scene, film, cam, calls, frame_spp, seconds_per_frame, 
             os.environ["HK_BATCH_PATHS_M"] = prev
     dt_rb = run(True)[0] if READBACK_PASS else float("nan")     # (a read-back after every call: nothing to batch)
     per_sample = seconds_per_frame / max(frame_spp, 1)
-    return {"calls": calls, "ms_per_call": round(dt / calls * 1e3, 4), "value": round(rays / dt / 1e6, 2), "unit": "Mrays/s",
-            "host_ms_per_call": round(host_ms, 4), "ms_per_call_each_rendered_at_once": round(dt_each / calls * 1e3, 4),
-            "ms_per_call_with_readback": round(dt_rb / calls * 1e3, 4), "ms_per_sample_of_the_full_frame": round(per_sample * 1e3, 4),
-            "vs_frame_sample": round(dt / calls / per_sample, 3),
-            "note": "calls without a read-back in between are batched by the library (HK_BATCH_PATHS_M); `each_rendered_at_once` is the same loop with batching off"}
+    # `ms_per_call` is what ONE render! call costs a caller that wants its sample rendered now (batching off, no read-back);
+    # `..._with_readback` adds the frame an interactive viewer shows after every call; the batched figure is a 64-spp pass in disguise
+    return {"calls": calls, "ms_per_call": round(dt_each / calls * 1e3, 4), "ms_per_call_with_readback": round(dt_rb / calls * 1e3, 4),
+            "ms_per_call_batched_no_readback": round(dt / calls * 1e3, 4), "value_batched": round(rays / dt / 1e6, 2), "unit": "Mrays/s",
+            "host_ms_per_call_batched": round(host_ms, 4), "ms_per_sample_of_the_full_frame": round(per_sample * 1e3, 4),
+            "vs_frame_sample": round(dt_each / calls / per_sample, 3), "vs_frame_sample_with_readback": round(dt_rb / calls / per_sample, 3),
+            "vs_frame_sample_batched": round(dt / calls / per_sample, 3),
+            "note": "calls without a read-back in between are batched by the library (HK_BATCH_PATHS_M); `ms_per_call` is the loop with batching off"}
 
 
 def one_frame_line(hk, scenes, torch, config, device):
@@ -361,7 +447,7 @@ def one_frame_line(hk, scenes, torch, config, device):
     dom = max((k for k in ("trace", "shadow", "shade", "media") if timed[k] > 0), key=lambda k: timed[k])
     line = {"config": config, "workload": "%s, %d spp per frame" % (workload, spp), "resolution": [W, H], "max_depth": depth, "spp_per_frame": spp,
             "triangles": int(scene.desc.n_triangles), "lights": int(scene.desc.n_lights), "frames_timed": 1, "free_hbm_gb_before": round(free_b / 1e9, 1),
-            "seconds_per_frame": round(seconds, 4), "value": round(rays / seconds / 1e6, 2), "unit": "Mrays/s",
+            "warmup_frames": 2, "seconds_per_frame": round(seconds, 4), "value": round(rays / seconds / 1e6, 2), "unit": "Mrays/s",
             "rays": {"closest": int(st.rays_closest), "shadow": int(st.rays_shadow), "medium_collisions": int(st.medium_collisions)},
             "kernel_seconds": {k: round(v, 4) for k, v in timed.items()}, "setup_seconds": round(setup_s, 2),
             "roofline": next(e for e in rooflines if e["kernel"] == KERNEL_OF_CLASS[dom]), "rooflines": rooflines}
@@ -387,21 +473,31 @@ def progressive_of(hk, torch, device, scene, film, cam, depth, spp, seconds, cal
 def child_config_line(config, progressive_calls):
     """`bench.py --config <config>` in a child process (one warm frame timed, its class times, rooflines and one-sample-per-call path):
     the fields of its JSON line that a `configs` entry carries."""
+    import tempfile
+    fd, detail = tempfile.mkstemp(prefix="hk_bench_%s_" % config, suffix=".json")
+    os.close(fd)
     cmd = [sys.executable, os.path.abspath(__file__), "--config", config, "--steps", "1", "--warmup", "2", "--no-cpu-baseline",
-           "--progressive", str(progressive_calls)]
+           "--progressive", str(progressive_calls), "--detail-file", detail]
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE"):
         env.pop(k, None)
-    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
-    if out.returncode != 0:
-        raise RuntimeError("exit code %d: %s" % (out.returncode, out.stderr.decode(errors="replace")[-300:]))
-    d = json.loads(out.stdout.decode().strip().splitlines()[-1])
+    try:
+        out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        if out.returncode != 0:
+            raise RuntimeError("exit code %d: %s" % (out.returncode, out.stderr.decode(errors="replace")[-300:]))
+        with open(detail) as f:
+            d = json.load(f)
+    finally:
+        try:
+            os.unlink(detail)
+        except OSError:
+            pass
     cfg = d["config"]
     return {"config": config, "workload": cfg["workload"], "resolution": cfg["resolution"], "max_depth": cfg["max_depth"], "spp_per_frame": cfg["spp_per_frame"],
-            "triangles": cfg["triangles"], "lights": cfg["lights"], "frames_timed": d["steps"], "seconds_per_frame": d["seconds_per_frame"],
+            "triangles": cfg["triangles"], "lights": cfg["lights"], "frames_timed": d["steps"], "warmup_frames": d["warmup"], "seconds_per_frame": d["seconds_per_frame"],
             "cold_frame_seconds": d["cold_frame_seconds"], "value": d["value"], "unit": d["unit"], "rays": d["rays"],
             "kernel_seconds": d["roofline"]["kernel_seconds"], "setup_seconds": d["setup_seconds"], "roofline": d["roofline"], "rooflines": d["rooflines"],
-            "progressive": d.get("progressive"), "measured_in": "a process of its own (bench.py --config %s), before this process touched the GPU" % config}
+            "progressive": d.get("progressive"), "measured_in": "a process of its own (bench.py --config %s --steps 1 --warmup 2), before this process touched the GPU" % config}
 
 
 def main():
@@ -715,8 +811,7 @@ def main():
                 result["progressive"] = progressive_of(hk, torch, local_rank, scene, film, cam, DEPTH, frame_spp, per_frame, args.progressive)
             except Exception as e:               # noqa: BLE001
                 result["progressive"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        print(json.dumps(result))
-        sys.stdout.flush()
+        emit(result, args.detail_file)
     return result
 
 

@@ -1,0 +1,76 @@
+"""bench.py's ONE stdout line must fit the driver's window (a 26 KB line left BENCH_r04.json.parsed = null).
+
+The shape comes from a real run (profiles/bench_r04_default.json: the headline + four `configs` with per-class `rooflines` + five
+`progressive` blocks); `compact_line` has to carry the contract's fields, `roofline`, `cpu_baseline` and one entry per other config in
+at most 3 500 characters, and the last 4 000 characters of stdout have to parse as JSON on their own."""
+import contextlib
+import io
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import bench
+    return bench
+
+
+def _round4_record():
+    with open(os.path.join(ROOT, "profiles", "bench_r04_default.json")) as f:
+        return json.load(f)
+
+
+def test_compact_line_fits_and_keeps_the_contract():
+    bench = _bench()
+    d = _round4_record()
+    assert len(json.dumps(d)) > 20000                      # the record that did not parse
+    line = bench.compact_line(d)
+    text = json.dumps(line)
+    assert len(text) < 3500
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["value"] == d["value"] and line["ms_per_step"] == d["ms_per_step"]
+    assert "workload" in line["config"] and "model" not in line["config"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in line["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in line["cpu_baseline"], k
+    names = [c["config"] for c in line["configs"]]
+    assert names == ["cornell_two_spheres", "cloud", "sky", "manylight"]
+    for c in line["configs"]:
+        assert c["seconds_per_frame"] > 0 and c["value"] > 0
+        assert {"kernel", "bound", "frac"} <= set(c["roofline"])
+    assert "ms_per_call" in line["progressive"] and "ms_per_call_with_readback" in line["progressive"]
+
+
+def test_compact_line_sheds_before_it_overflows():
+    bench = _bench()
+    d = _round4_record()
+    d["config"]["workload"] = "x" * 5000
+    d["configs"] = d["configs"] * 6                        # 24 entries: more than the window could ever hold at full width
+    for c in d["configs"]:
+        c["workload"] = "y" * 900
+    text = json.dumps(bench.compact_line(d))
+    assert len(text) <= 3500
+    line = json.loads(text)
+    assert line["roofline"]["frac"] == d["roofline"]["frac"] and line["cpu_baseline"]["value"] == d["cpu_baseline"]["value"]
+
+
+def test_emit_prints_one_line_the_driver_can_parse(tmp_path):
+    bench = _bench()
+    d = _round4_record()
+    out, err = io.StringIO(), io.StringIO()
+    detail = tmp_path / "bench_detail.json"
+    with contextlib.redirect_stdout(out), contextlib.redirect_stderr(err):
+        bench.emit(d, str(detail))
+    stdout = out.getvalue()
+    assert stdout.count("\n") == 1 and stdout.endswith("\n")
+    parsed = json.loads(stdout[-4000:])                    # what survives in the driver's tail
+    assert parsed["metric"] == "Mrays/s" and parsed["detail"] == "bench_detail.json"
+    full = json.loads(detail.read_text())
+    assert full["rooflines"] == d["rooflines"] and len(full["configs"]) == 4

@@ -319,10 +319,10 @@ def compact_line(result, limit=LINE_LIMIT, detail_file="bench_detail.json"):
             if isinstance(c.get("kernel_seconds"), dict):
                 e["kernel_seconds"] = c["kernel_seconds"]
             if isinstance(c.get("progressive"), dict):
-                e["progressive"] = _pick(c["progressive"], ("ms_per_call", "ms_per_call_with_readback", "vs_frame_sample"))
+                e["progressive"] = _pick(c["progressive"], ("ms_per_call", "ms_per_call_with_readback", "ms_per_call_pipelined_readback", "vs_frame_sample"))
             line["configs"].append(e)
     if isinstance(result.get("progressive"), dict):
-        line["progressive"] = _pick(result["progressive"], ("calls", "ms_per_call", "ms_per_call_with_readback", "ms_per_call_batched_no_readback",
+        line["progressive"] = _pick(result["progressive"], ("calls", "ms_per_call", "ms_per_call_with_readback", "ms_per_call_pipelined_readback", "ms_per_call_batched_no_readback",
                                                             "ms_per_sample_of_the_full_frame", "vs_frame_sample", "vs_frame_sample_with_readback", "error"))
     line["detail"] = detail_file
     # whatever a future field adds, the line never outgrows the driver: shed the least important parts first
@@ -374,6 +374,8 @@ def progressive_line(vp, scene, film, cam, calls, frame_spp, seconds_per_frame, 
         for i in range(calls):
             vp.render_samples(scene, film, cam, 1, first=i + 1, readback=readback)
         submit[0] = time.perf_counter() - t0
+        if readback == "pipelined":
+            vp.finish_pipelined(film)            # the last call's frame
         vp.sync()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
@@ -383,26 +385,28 @@ def progressive_line(vp, scene, film, cam, calls, frame_spp, seconds_per_frame, 
     run(False)                       # untimed: the one-sample pass's path state / tables
     dt, rays = run(False)            # the library's default: small calls that continue each other are noted and rendered as one pass (hk_render_tile)
     host_ms = submit[0] / calls * 1e3
-    prev = os.environ.get("HK_BATCH_PATHS_M")
-    os.environ["HK_BATCH_PATHS_M"] = "0"     # every call rendered at once (read per call by the library)
-    try:
+    with vp._ctx.options(HK_BATCH_PATHS_M=0):    # every call rendered at once
         run(False)
         dt_each = run(False)[0]
-    finally:
-        if prev is None:
-            del os.environ["HK_BATCH_PATHS_M"]
-        else:
-            os.environ["HK_BATCH_PATHS_M"] = prev
-    dt_rb = run(True)[0] if READBACK_PASS else float("nan")     # (a read-back after every call: nothing to batch)
+    # a read-back after every call (nothing to batch): "view" = hk_film_read_rgb into ONE host buffer, which the library pins after the second
+    # call; "pipelined" = hk_film_read_rgb_async / hk_film_read_wait, the frame shown lags one call and the GPU never waits for the host
+    dt_rb = dt_pipe = float("nan")
+    if READBACK_PASS:
+        run("view")
+        dt_rb = run("view")[0]
+        run("pipelined")
+        dt_pipe = run("pipelined")[0]
     per_sample = seconds_per_frame / max(frame_spp, 1)
     # `ms_per_call` is what ONE render! call costs a caller that wants its sample rendered now (batching off, no read-back);
     # `..._with_readback` adds the frame an interactive viewer shows after every call; the batched figure is a 64-spp pass in disguise
     return {"calls": calls, "ms_per_call": round(dt_each / calls * 1e3, 4), "ms_per_call_with_readback": round(dt_rb / calls * 1e3, 4),
+            "ms_per_call_pipelined_readback": round(dt_pipe / calls * 1e3, 4),
             "ms_per_call_batched_no_readback": round(dt / calls * 1e3, 4), "value_batched": round(rays / dt / 1e6, 2), "unit": "Mrays/s",
             "host_ms_per_call_batched": round(host_ms, 4), "ms_per_sample_of_the_full_frame": round(per_sample * 1e3, 4),
             "vs_frame_sample": round(dt_each / calls / per_sample, 3), "vs_frame_sample_with_readback": round(dt_rb / calls / per_sample, 3),
-            "vs_frame_sample_batched": round(dt / calls / per_sample, 3),
-            "note": "calls without a read-back in between are batched by the library (HK_BATCH_PATHS_M); `ms_per_call` is the loop with batching off"}
+            "vs_frame_sample_pipelined_readback": round(dt_pipe / calls / per_sample, 3), "vs_frame_sample_batched": round(dt / calls / per_sample, 3),
+            "note": "calls without a read-back in between are batched by the library (HK_BATCH_PATHS_M); `ms_per_call` is the loop with batching off; "
+                    "with_readback = hk_film_read_rgb after every call, pipelined = hk_film_read_rgb_async + hk_film_read_wait (frame shown one call late)"}
 
 
 def one_frame_line(hk, scenes, torch, config, device):

@@ -137,4 +137,5 @@ EXPORTED_SYMBOLS = [
     "hk_test_light_bvh", "hk_test_bsdf", "hk_film_postprocess", "hk_film_fill_aux", "hk_postprocess", "hk_test_light", "hk_scene_bvh_info", "hk_scene_light_bvh_copy",
     "hk_denoise", "hk_test_mix", "hk_test_medium", "hk_test_trace_lean",
     "hk_render_tile", "hk_comm_create", "hk_comm_unique_id", "hk_comm_create_rank", "hk_comm_destroy", "hk_film_reduce",
+    "hk_ctx_set_option", "hk_ctx_get_option", "hk_trim_cache", "hk_flush", "hk_film_read_rgb_async", "hk_film_read_wait",
 ]

@@ -32,6 +32,12 @@ def lib():
         "hk_ctx_destroy": ([vp], i32),
         "hk_last_error": ([], C.c_char_p),
         "hk_ctx_set_tables": ([vp, C.POINTER(A.hk_tables)], i32),
+        "hk_ctx_set_option": ([vp, C.c_char_p, C.c_char_p], i32),
+        "hk_ctx_get_option": ([vp, C.c_char_p, C.c_char_p, i32], i32),
+        "hk_trim_cache": ([vp], i32),
+        "hk_flush": ([vp], i32),
+        "hk_film_read_rgb_async": ([vp, vp], i32),
+        "hk_film_read_wait": ([vp, vp, PF, C.POINTER(PF)], i32),
         "hk_scene_create": ([vp, C.POINTER(A.hk_scene_desc), C.POINTER(vp)], i32),
         "hk_scene_destroy": ([vp], i32),
         "hk_integrator_create": ([vp, C.POINTER(A.hk_integrator_params), C.POINTER(vp)], i32),

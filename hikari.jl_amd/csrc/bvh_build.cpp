@@ -176,14 +176,14 @@ struct Builder {
 };
 }  // namespace
 
-void build_bvh(const float* positions, int n_tris, BVH& out) {
+void build_bvh(const float* positions, int n_tris, BVH& out, int leaf_size) {
     out.nodes.clear();
     out.leaf_prims.clear();
     out.max_depth = 0;
     out.root_ref = ~0;  // empty leaf marker handled by n_tris == 0
     if (n_tris <= 0) return;
     Builder b(positions, n_tris, out);
-    if (const char* e = std::getenv("HK_BVH_LEAF")) b.LEAF = std::atoi(e) >= 1 && std::atoi(e) <= 8 ? std::atoi(e) : 4;
+    b.LEAF = leaf_size >= 1 && leaf_size <= 8 ? leaf_size : 4;   // (HK_BVH_LEAF, resolved by the caller from its context's knobs)
     Box box;
     out.root_ref = b.build(0, n_tris, 0, box);
     out.max_depth = b.max_depth_seen;

@@ -18,7 +18,7 @@ struct BVH {
     int max_depth = 0;
     float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
 };
-void build_bvh(const float* positions, int n_tris, BVH& out);
+void build_bvh(const float* positions, int n_tris, BVH& out, int leaf_size = 4);   // leaf_size: triangles per leaf, 1 .. 8
 
 // Light BVH (lights/bvh-light-sampler.jl:283-466).  Node = 16 floats/uints as uploaded to the device.
 struct LightBVHNodeH {

@@ -14,6 +14,7 @@
 
 #include <dlfcn.h>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "bvh_build.h"
@@ -59,6 +60,39 @@ static int fail(int code, const std::string& msg) {
     g_err = msg;
     return code;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// RUN-TIME KNOBS.  The library never calls getenv on a render path: hk_ctx_create copies the HK_* variables it knows from the
+// environment ONCE into the context, hk_ctx_set_option changes one afterwards, and the code asks hk::knob("HK_X") — a lookup in the
+// table of the context whose entry point is running on this thread (KnobScope).  A host that setenv()s beside a render is harmless.
+// ---------------------------------------------------------------------------------------------------
+namespace hk {
+struct Knobs {
+    std::unordered_map<std::string, std::string> kv;
+};
+static thread_local const Knobs* tl_knobs = nullptr;
+const char* knob(const char* name) {
+    if (!tl_knobs) return nullptr;
+    auto it = tl_knobs->kv.find(name);
+    return it == tl_knobs->kv.end() ? nullptr : it->second.c_str();
+}
+static const char* const KNOB_NAMES[] = {
+    "HK_BATCH_PATHS_M", "HK_BVH_LEAF", "HK_DEBUG_ALLOC", "HK_DELTA_ADVANCE", "HK_DYNAMIC_SEGMENTS", "HK_GREY", "HK_GREY_COMPACT", "HK_GREY_FLAT", "HK_MAX_PATHS_M",
+    "HK_MID_LISTS", "HK_MID_PASS_PATHS_M", "HK_NODE_CACHE", "HK_NVDB_DENSE_MB", "HK_OVERLAP", "HK_PIPELINE", "HK_PIPELINE_AFTER", "HK_PIPELINE_MAX_PATHS_M", "HK_PRESELECT",
+    "HK_SELECT_MIN_IDLE", "HK_SHADOW_FEED_ROUNDS", "HK_SHADOW_TRACK_BATCH", "HK_SMALL_PASS", "HK_SMALL_PASS_WAVES", "HK_SOBOL_LO_GB", "HK_SOBOL_TABLE_ONLY",
+    "HK_STATE_CACHE_GB", "HK_STATE_SLAB", "HK_TICKET_SHARE", "HK_TRACK_ADVANCE", "HK_TRACK_EXTRA_ADVANCE", "HK_TRACK_MIN_PENDING", "HK_TRACK_POOL", "HK_TRACK_REFILL_IDLE",
+    "HK_WALK_POOL", "HK_WALK_REFILL_IDLE", "HK_WALK_SPLIT", "HK_WAVES_PER_CU", "HK_READBACK_PIN", "HK_DEFER_EXTERNAL"};
+static bool known_knob(const char* name) {
+    for (const char* k : KNOB_NAMES)
+        if (std::strcmp(k, name) == 0) return true;
+    return false;
+}
+}  // namespace hk
+struct KnobScope {   // the knobs of `k` answer hk::knob on this thread until the scope ends (entry points nest: the outer one is restored)
+    const hk::Knobs* prev;
+    explicit KnobScope(const hk::Knobs* k) : prev(hk::tl_knobs) { hk::tl_knobs = k; }
+    ~KnobScope() { hk::tl_knobs = prev; }
+};
 #define HIP_TRY(expr)                                                                                          \
     do {                                                                                                       \
         hipError_t e_ = (expr);                                                                                \
@@ -79,11 +113,8 @@ struct SlabCache {
     };
     std::mutex m;
     std::vector<Entry> free_list;
-    size_t cap() const {
-        long gb = 128;
-        if (const char* e = std::getenv("HK_STATE_CACHE_GB")) gb = std::atol(e) >= 0 ? std::atol(e) : gb;
-        return (size_t)gb << 30;
-    }
+    size_t cap_bytes = (size_t)128 << 30;   // HK_STATE_CACHE_GB (process-wide: the last context created / option set decides)
+    size_t cap() const { return cap_bytes; }
     size_t total(int dev) {
         std::lock_guard<std::mutex> g(m);
         size_t t = 0;
@@ -142,11 +173,8 @@ struct DevBuf {
     int slab_dev = -1;   // >= 0: a path-state slab of that device (goes back to g_slabs, not to the driver)
     void release() {
         if (p && slab_dev >= 0) {
-            int cur = -1;   // (hipFree would have waited for the kernels that still use it: wait for the slab's own device)
-            (void)hipGetDevice(&cur);
-            if (cur != slab_dev) (void)hipSetDevice(slab_dev);
-            (void)hipDeviceSynchronize();
-            if (cur >= 0 && cur != slab_dev) (void)hipSetDevice(cur);
+            // hipFree would have waited for the kernels that still use the memory; a slab goes back to the cache instead, so its OWNER
+            // waits first — for the streams of its own context only (quiesce), not for every stream of the host application
             g_slabs.give(slab_dev, p, bytes);
         } else if (p)
             (void)hipFree(p);
@@ -192,6 +220,8 @@ struct DevBuf {
 
 struct hk_ctx {
     int device = 0;
+    hk::Knobs knobs;                      // HK_* as of hk_ctx_create, then hk_ctx_set_option
+    bool own_stream_order = true;         // false: the caller handed hk_ctx_create a stream of its own and may order work after a render with stream / event calls
     hipStream_t stream = nullptr;
     hipStream_t aux = nullptr;            // second stream: the shadow rays of bounce d run beside the traversal of bounce d + 1
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -247,6 +277,14 @@ struct hk_ctx {
     hipEvent_t ev_main = nullptr, ev_film = nullptr;
 };
 
+// every stream this context has launched on is idle afterwards (before path-state memory changes hands); other streams of the process are not touched
+static void quiesce(hk_ctx* c) {
+    if (!c) return;
+    (void)hipStreamSynchronize(c->stream);
+    if (c->aux) (void)hipStreamSynchronize(c->aux);
+    for (auto& l : c->lanes)
+        if (l.stream) (void)hipStreamSynchronize(l.stream);
+}
 // the context's stream waits for everything the lanes were given (cheap when nothing is pending)
 static int flush_pending(hk_ctx* c);
 static int join_lanes(hk_ctx* c) {
@@ -289,7 +327,16 @@ struct hk_film {
     bool f64 = false;
     DevBuf own;
     void* accum = nullptr;  // device
+    bool external = false;  // the caller owns `accum` (and may read it behind stream / event ordering of its own)
     DevBuf readback;
+    // hk_film_read_rgb / _async: the finalized frame lands in PINNED host memory (two buffers in turn), or straight in the caller's
+    // buffer once that has been seen twice in a row and could be registered (HK_READBACK_PIN=0: never)
+    float* staging[2] = {nullptr, nullptr};
+    int staging_next = 0, staging_last = -1;   // which buffer the next async read fills / the last one filled
+    bool read_in_flight = false;
+    hipEvent_t ev_read = nullptr;
+    void* last_out = nullptr;       // the caller's buffer of the previous synchronous read
+    void* pinned_user = nullptr;    // ... registered with the driver (hipHostRegister) — the copy goes there directly
 };
 
 struct hk_integrator {
@@ -345,11 +392,17 @@ extern "C" int32_t hk_ctx_create(int32_t device_id, void* stream, hk_ctx** out) 
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device_id));
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    c->own_stream_order = stream == nullptr;
+    for (const char* name : hk::KNOB_NAMES)   // the ONLY place the library reads the environment (std::getenv below: nowhere else)
+        if (const char* e = std::getenv(name)) c->knobs.kv[name] = e;
+    KnobScope knobs(&c->knobs);
     {
-        if (const char* e = std::getenv("HK_WAVES_PER_CU")) c->waves_per_cu = std::atoi(e) > 0 ? std::atoi(e) : 0;
+        if (const char* e = hk::knob("HK_WAVES_PER_CU")) c->waves_per_cu = std::atoi(e) > 0 ? std::atoi(e) : 0;
         c->stat_rows = c->n_cu * 32 * 2;   // second half: the kernels of the second stream (their waves have the same physical ids)
-        if (const char* e = std::getenv("HK_OVERLAP")) c->overlap = std::atoi(e) ? 1 : 0;
+        if (const char* e = hk::knob("HK_OVERLAP")) c->overlap = std::atoi(e) ? 1 : 0;
         else c->overlap = -1;
+        if (const char* e = hk::knob("HK_STATE_CACHE_GB"))
+            if (std::atol(e) >= 0) g_slabs.cap_bytes = (size_t)std::atol(e) << 30;
     }
     {
         std::vector<DStats> zero((size_t)c->stat_rows);
@@ -364,8 +417,8 @@ extern "C" int32_t hk_ctx_create(int32_t device_id, void* stream, hk_ctx** out) 
 extern "C" int32_t hk_ctx_destroy(hk_ctx* c) {
     if (!c) return HK_OK;
     (void)hipSetDevice(c->device);
-    (void)join_lanes(c);
-    (void)hipStreamSynchronize(c->stream);
+    int status = join_lanes(c);
+    if (hipStreamSynchronize(c->stream) != hipSuccess && status == HK_OK) status = fail(HK_ERR_DEVICE, "hk_ctx_destroy: the context's stream reports an error");
     for (auto& l : c->lanes) {
         if (l.stream) (void)hipStreamSynchronize(l.stream);
         if (l.done) (void)hipEventDestroy(l.done);
@@ -385,6 +438,38 @@ extern "C" int32_t hk_ctx_destroy(hk_ctx* c) {
     if (c->aux) (void)hipStreamDestroy(c->aux);
     g_slabs.trim(c->device);
     delete c;
+    return status;
+}
+extern "C" int32_t hk_ctx_set_option(hk_ctx* c, const char* name, const char* value) {
+    if (!c || !name) return fail(HK_ERR_INVALID, "null argument");
+    if (!hk::known_knob(name)) return fail(HK_ERR_INVALID, std::string("unknown option ") + name);
+    HIP_TRY(hipSetDevice(c->device));
+    if (int e = join_lanes(c)) return e;   // calls that were only noted are rendered under the options they were made with
+    if (value) c->knobs.kv[name] = value;
+    else c->knobs.kv.erase(name);
+    if (std::strcmp(name, "HK_STATE_CACHE_GB") == 0) {
+        g_slabs.cap_bytes = (size_t)(value && std::atol(value) >= 0 ? std::atol(value) : 128) << 30;
+        if (g_slabs.cap_bytes == 0) g_slabs.trim(c->device);
+    }
+    return HK_OK;
+}
+extern "C" int32_t hk_ctx_get_option(hk_ctx* c, const char* name, char* out, int32_t out_bytes) {
+    if (!c || !name || (out_bytes > 0 && !out)) return fail(HK_ERR_INVALID, "null argument");
+    if (!hk::known_knob(name)) return fail(HK_ERR_INVALID, std::string("unknown option ") + name);
+    auto it = c->knobs.kv.find(name);
+    if (it == c->knobs.kv.end()) return -1;   // unset: the built-in default applies
+    if (out_bytes > 0) std::snprintf(out, (size_t)out_bytes, "%s", it->second.c_str());
+    return (int32_t)it->second.size();
+}
+extern "C" int32_t hk_flush(hk_ctx* c) {
+    if (!c) return fail(HK_ERR_INVALID, "null ctx");
+    HIP_TRY(hipSetDevice(c->device));
+    return join_lanes(c);   // noted calls are enqueued on the context's stream (and the lanes joined): stream-ordered from here on
+}
+extern "C" int32_t hk_trim_cache(hk_ctx* c) {
+    if (!c) return fail(HK_ERR_INVALID, "null ctx");
+    HIP_TRY(hipSetDevice(c->device));
+    g_slabs.trim(c->device);
     return HK_OK;
 }
 extern "C" int32_t hk_ctx_set_tables(hk_ctx* c, const hk_tables* t) {
@@ -542,6 +627,7 @@ std::string validate_desc(const hk_scene_desc& d) {
 extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene** out) {
     if (!c || !d || !out) return fail(HK_ERR_INVALID, "null argument");
     if (!c->have_tables) return fail(HK_ERR_INVALID, "hk_ctx_set_tables must be called first");
+    KnobScope knobs(&c->knobs);
     if (d->n_envmaps > 0 && !d->envmaps) return fail(HK_ERR_INVALID, "n_envmaps > 0 but envmaps is null");
     for (int i = 0; i < d->n_lights; ++i)
         if (d->lights[i].kind == HK_LIGHT_ENVIRONMENT && (d->lights[i].envmap < 0 || d->lights[i].envmap >= d->n_envmaps))
@@ -576,7 +662,10 @@ extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene**
     }
     // ---- BVH ----
     hk::BVH bvh;
-    hk::build_bvh(d->positions, T, bvh);
+    {
+        const char* leaf = hk::knob("HK_BVH_LEAF");
+        hk::build_bvh(d->positions, T, bvh, leaf ? std::atoi(leaf) : 4);
+    }
     s->bvh_nodes = (int)bvh.nodes.size();
     s->bvh_leaf_tris = (int)bvh.leaf_prims.size();
     s->bvh_depth = bvh.max_depth;
@@ -973,7 +1062,7 @@ extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene**
             // 288 GB of HBM are there to be used; the bench cloud needs 67 MB), else the table + leaves path stays.
             {
                 size_t budget_mb = 4096;
-                if (const char* e = std::getenv("HK_NVDB_DENSE_MB")) budget_mb = (size_t)std::atol(e);
+                if (const char* e = hk::knob("HK_NVDB_DENSE_MB")) budget_mb = (size_t)std::atol(e);
                 const size_t brick_bytes = (size_t)total * 729 * sizeof(float);
                 if (brick_bytes <= budget_mb * (size_t)(1 << 20)) {
                     std::vector<float> plain((size_t)total * 512);
@@ -1057,13 +1146,14 @@ extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene**
     return HK_OK;
 }
 extern "C" int32_t hk_scene_destroy(hk_scene* s) {
+    int status = HK_OK;   // the object goes either way; a device error of a pass that was still noted / in flight is reported (hk_last_error)
     if (s) {
         (void)hipSetDevice(s->ctx->device);
-        (void)join_lanes(s->ctx);
-        (void)hipStreamSynchronize(s->ctx->stream);
+        status = join_lanes(s->ctx);
+        if (hipStreamSynchronize(s->ctx->stream) != hipSuccess && status == HK_OK) status = fail(HK_ERR_DEVICE, "hk_scene_destroy: the context's stream reports an error");
         delete s;
     }
-    return HK_OK;
+    return status;
 }
 extern "C" int32_t hk_scene_bvh_info(hk_scene* s, int32_t* n_nodes, int32_t* n_leaf_tris, int32_t* max_depth) {
     if (!s) return fail(HK_ERR_INVALID, "null scene");
@@ -1199,13 +1289,15 @@ extern "C" int32_t hk_integrator_create(hk_ctx* c, const hk_integrator_params* p
     return HK_OK;
 }
 extern "C" int32_t hk_integrator_destroy(hk_integrator* I) {
+    int status = HK_OK;   // the object goes either way; a device error of a pass that was still noted / in flight is reported (hk_last_error)
     if (I) {
         (void)hipSetDevice(I->ctx->device);
-        (void)join_lanes(I->ctx);
-        (void)hipStreamSynchronize(I->ctx->stream);
+        status = join_lanes(I->ctx);
+        if (hipStreamSynchronize(I->ctx->stream) != hipSuccess && status == HK_OK) status = fail(HK_ERR_DEVICE, "hk_integrator_destroy: the context's stream reports an error");
+        quiesce(I->ctx);
         delete I;
     }
-    return HK_OK;
+    return status;
 }
 
 // ---- film ---------------------------------------------------------------------------------------------
@@ -1218,6 +1310,7 @@ extern "C" int32_t hk_film_create(hk_ctx* c, int32_t w, int32_t h, int32_t f64, 
     f->height = h;
     f->f64 = f64 != 0;
     size_t bytes = (size_t)4 * w * h * (f64 ? 8 : 4);
+    f->external = external != nullptr;
     if (external)
         f->accum = external;
     else {
@@ -1229,13 +1322,18 @@ extern "C" int32_t hk_film_create(hk_ctx* c, int32_t w, int32_t h, int32_t f64, 
     return HK_OK;
 }
 extern "C" int32_t hk_film_destroy(hk_film* f) {
+    int status = HK_OK;   // the object goes either way; a device error of a pass that was still noted / in flight is reported (hk_last_error)
     if (f) {
         (void)hipSetDevice(f->ctx->device);
-        (void)join_lanes(f->ctx);
-        (void)hipStreamSynchronize(f->ctx->stream);
+        status = join_lanes(f->ctx);
+        if (hipStreamSynchronize(f->ctx->stream) != hipSuccess && status == HK_OK) status = fail(HK_ERR_DEVICE, "hk_film_destroy: the context's stream reports an error");
+        if (f->pinned_user) (void)hipHostUnregister(f->pinned_user);
+        for (auto& st : f->staging)
+            if (st) (void)hipHostFree(st);
+        if (f->ev_read) (void)hipEventDestroy(f->ev_read);
         delete f;
     }
-    return HK_OK;
+    return status;
 }
 extern "C" int32_t hk_film_clear(hk_film* f) {
     if (!f) return fail(HK_ERR_INVALID, "null film");
@@ -1256,16 +1354,75 @@ extern "C" int32_t hk_film_read_accum(hk_ctx* c, hk_film* f, void* out) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     return HK_OK;
 }
-extern "C" int32_t hk_film_read_rgb(hk_ctx* c, hk_film* f, float* out) {
-    if (!c || !f || !out) return fail(HK_ERR_INVALID, "null argument");
-    HIP_TRY(hipSetDevice(c->device));
-    size_t bytes = (size_t)3 * f->width * f->height * 4;
+// K13 + the device-to-host copy of the frame.  A pageable destination made this the most expensive part of an interactive viewer's loop
+// (round 4: 3.7 ms of a 5.3-ms one-sample call at 800^2 — the runtime stages a pageable copy through small pinned buffers and the
+// stream waits for each).  Now the frame lands in PINNED memory: the film's own staging buffers (two, in turn), or the caller's
+// buffer itself once the same pointer has come twice in a row and hipHostRegister accepted it (a viewer reads into ONE framebuffer).
+static int enqueue_frame_read(hk_ctx* c, hk_film* f, float* direct) {
+    const size_t bytes = (size_t)3 * f->width * f->height * 4;
     if (int e = join_lanes(c)) return e;
     if (f->readback.bytes != bytes) HIP_TRY(f->readback.alloc(bytes));
+    if (!f->ev_read) HIP_TRY(hipEventCreateWithFlags(&f->ev_read, hipEventDisableTiming));
+    float* dst = direct;
+    if (!dst) {
+        const int k = f->staging_next;
+        if (!f->staging[k]) HIP_TRY(hipHostMalloc((void**)&f->staging[k], bytes, hipHostMallocDefault));
+        dst = f->staging[k];
+        f->staging_last = k;
+        f->staging_next = k ^ 1;
+    }
     hk::launch_finalize(c->stream, f->accum, f->f64, f->readback.as<float>(), f->width, f->height);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(out, f->readback.p, bytes, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpyAsync(dst, f->readback.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipEventRecord(f->ev_read, c->stream));
+    return HK_OK;
+}
+extern "C" int32_t hk_film_read_rgb(hk_ctx* c, hk_film* f, float* out) {
+    if (!c || !f || !out) return fail(HK_ERR_INVALID, "null argument");
+    if (f->ctx != c) return fail(HK_ERR_INVALID, "film belongs to another context");
+    HIP_TRY(hipSetDevice(c->device));
+    KnobScope knobs(&c->knobs);
+    const size_t bytes = (size_t)3 * f->width * f->height * 4;
+    if (f->read_in_flight) {   // an asynchronous read nobody waited for: its staging buffer is simply overtaken
+        HIP_TRY(hipEventSynchronize(f->ev_read));
+        f->read_in_flight = false;
+    }
+    const char* pin = hk::knob("HK_READBACK_PIN");
+    if (f->pinned_user != out && f->last_out == out && !(pin && std::atoi(pin) == 0)) {
+        if (f->pinned_user) (void)hipHostUnregister(f->pinned_user);
+        f->pinned_user = hipHostRegister(out, bytes, hipHostRegisterDefault) == hipSuccess ? out : nullptr;
+        (void)hipGetLastError();
+    } else if (f->pinned_user && f->pinned_user != out) {
+        (void)hipHostUnregister(f->pinned_user);
+        f->pinned_user = nullptr;
+    }
+    f->last_out = out;
+    const bool direct = f->pinned_user == out;
+    if (int e = enqueue_frame_read(c, f, direct ? out : nullptr)) return e;
+    HIP_TRY(hipEventSynchronize(f->ev_read));
+    if (!direct) std::memcpy(out, f->staging[f->staging_last], bytes);
+    return HK_OK;
+}
+extern "C" int32_t hk_film_read_rgb_async(hk_ctx* c, hk_film* f) {
+    if (!c || !f) return fail(HK_ERR_INVALID, "null argument");
+    if (f->ctx != c) return fail(HK_ERR_INVALID, "film belongs to another context");
+    HIP_TRY(hipSetDevice(c->device));
+    KnobScope knobs(&c->knobs);
+    if (f->read_in_flight) HIP_TRY(hipEventSynchronize(f->ev_read));   // (two buffers: the one about to be refilled is the one BEFORE the last)
+    if (int e = enqueue_frame_read(c, f, nullptr)) return e;
+    f->read_in_flight = true;
+    return HK_OK;
+}
+extern "C" int32_t hk_film_read_wait(hk_ctx* c, hk_film* f, float* out, const float** frame) {
+    if (!c || !f) return fail(HK_ERR_INVALID, "null argument");
+    if (f->ctx != c) return fail(HK_ERR_INVALID, "film belongs to another context");
+    if (f->staging_last < 0 || !f->ev_read) return fail(HK_ERR_INVALID, "hk_film_read_wait without hk_film_read_rgb_async");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventSynchronize(f->ev_read));
+    f->read_in_flight = false;
+    const float* src = f->staging[f->staging_last];
+    if (out) std::memcpy(out, src, (size_t)3 * f->width * f->height * 4);
+    if (frame) *frame = src;
     return HK_OK;
 }
 
@@ -1361,45 +1518,46 @@ int ensure_state(hk_integrator* I, int capacity, bool media, bool open_scene, bo
     // frame; x 64: 29.1 -> 27.8; x 128 and x 256 prefer the tickets).  The 10^6-triangle scene's rays are too uneven for a static stride
     // at any size (1024^2 x 32 spp: 115 -> 128 ms).
     long mid_paths = 48L << 20;
-    if (const char* e = std::getenv("HK_MID_PASS_PATHS_M")) mid_paths = std::atol(e) >= 0 ? std::atol(e) << 20 : mid_paths;
+    if (const char* e = hk::knob("HK_MID_PASS_PATHS_M")) mid_paths = std::atol(e) >= 0 ? std::atol(e) << 20 : mid_paths;
     const bool mid = !media && !open_scene && small_scene && (long)capacity <= mid_paths;
     I->mid_pass = mid;
     const long cap_per_cu = media ? 96 : ((open_scene || mid) ? 48 : 192);
     long W_want = ((long)(capacity + 63) / 64) / 16;
     if (W_want < 4L * n_cu) W_want = 4L * n_cu;
     if (W_want > cap_per_cu * n_cu) W_want = cap_per_cu * n_cu;
-    if (const char* e = std::getenv("HK_WAVES_PER_CU")) I->ctx->waves_per_cu = std::atoi(e) > 0 ? std::atoi(e) : 0;   // read per call: tests toggle it
+    if (const char* e = hk::knob("HK_WAVES_PER_CU")) I->ctx->waves_per_cu = std::atoi(e) > 0 ? std::atoi(e) : 0;   // read per call: tests toggle it
     if (I->ctx->waves_per_cu > 0) W_want = (long)I->ctx->waves_per_cu * n_cu;
     W_want = (W_want + 3) / 4 * 4;
     I->st.dynamic_segments = (media || (!open_scene && !mid)) ? 1 : 0;
-    if (const char* e = std::getenv("HK_DYNAMIC_SEGMENTS")) I->st.dynamic_segments = std::atoi(e) ? 1 : 0;
+    if (const char* e = hk::knob("HK_DYNAMIC_SEGMENTS")) I->st.dynamic_segments = std::atoi(e) ? 1 : 0;
     I->st.compact = media ? (grey_compact ? 1 : 0) : 1;
     I->st.ticket_share = 1;
-    if (const char* e = std::getenv("HK_TICKET_SHARE")) I->st.ticket_share = std::atoi(e) ? 1 : 0;
+    if (const char* e = hk::knob("HK_TICKET_SHARE")) I->st.ticket_share = std::atoi(e) ? 1 : 0;
     {   // a SMALL pass (at most 16 chunks for each of 4 waves per CU: a one-sample call at 800^2) hands segment g to wave g of every launch
         // (static stride where a grid is smaller): the 17 k_segment_lists launches of a call and the ticket round trips go, and the segment
         // count no longer has to stay below every kernel's residency, so it can be as fine as the latency of one wave's chunk wants it —
         // HK_SMALL_PASS_WAVES per CU.  HK_SMALL_PASS=0: lists and tickets as ever.
-        const char* e = std::getenv("HK_SMALL_PASS");
-        const bool small = W_want <= 4L * n_cu && !(e && std::atoi(e) == 0) && std::getenv("HK_DYNAMIC_SEGMENTS") == nullptr;   // (an explicit HK_DYNAMIC_SEGMENTS keeps lists / tickets: the tests' small films)
+        const char* e = hk::knob("HK_SMALL_PASS");
+        const bool small = W_want <= 4L * n_cu && !(e && std::atoi(e) == 0) && hk::knob("HK_DYNAMIC_SEGMENTS") == nullptr;   // (an explicit HK_DYNAMIC_SEGMENTS keeps lists / tickets: the tests' small films)
         I->st.small_pass = small ? 1 : 0;
-        if (mid && I->st.dynamic_segments == 0 && !(e && std::atoi(e) == 0) && !(std::getenv("HK_MID_LISTS") && std::atoi(std::getenv("HK_MID_LISTS"))))
+        if (mid && I->st.dynamic_segments == 0 && !(e && std::atoi(e) == 0) && !(hk::knob("HK_MID_LISTS") && std::atoi(hk::knob("HK_MID_LISTS"))))
             I->st.small_pass = 1;   // a mid-size pass of a closed scene: its 48 segments per CU all hold paths down to the last bounce — the work lists (17 launches) list everything
         if (small) {
             I->st.dynamic_segments = 0;
-            const char* w = std::getenv("HK_SMALL_PASS_WAVES");
+            const char* w = hk::knob("HK_SMALL_PASS_WAVES");
             long per_cu = w && std::atoi(w) > 0 ? std::atoi(w) : (media ? 4 : 8);   // (800^2, one sample per call, 8 lanes: Cornell 0.99 / 0.89 / 1.03 / 1.30 ms per call at 4 / 8 / 16 / 32, cloud 12.6 / 13.8 / 17.9 / 19.6)
             const long chunks = ((long)capacity + 63) / 64;
             while (per_cu > 4 && per_cu * n_cu > chunks) per_cu /= 2;   // (no segment without a chunk)
             if (I->ctx->waves_per_cu <= 0) W_want = (per_cu * n_cu + 3) / 4 * 4;
         }
     }
-    const char* split_env = std::getenv("HK_WALK_SPLIT");
+    const char* split_env = hk::knob("HK_WALK_SPLIT");
     const bool want_split = media && split_env && std::atoi(split_env);
     // the retained state must be of the same flavour: a state allocated for a scene with media has no sel_light (k_light_select would
     // silently not run in a later scene without media), one allocated without HK_WALK_SPLIT has no hand-over queues
     if (I->st_capacity >= capacity && I->st_depth >= I->p.max_depth && I->st.n_waves == (int)W_want && I->st_media == (media ? 1 : 0) && (!want_split || I->st.wq_a != nullptr)) return HK_OK;
     if (users) HIP_TRY(hipStreamSynchronize(users));   // (a lane's set: its last call may still be running)
+    if (!I->bufs.empty()) quiesce(I->ctx);             // the arrays about to be let go (a cached slab is handed on without a device-wide wait)
     for (auto* b : I->bufs) delete b;
     I->bufs.clear();
     DPathState& s = I->st;
@@ -1466,7 +1624,7 @@ int ensure_state(hk_integrator* I, int capacity, bool media, bool open_scene, bo
         HIP_TRY(alloc_arr(I, s.seg_list_n, (size_t)(I->p.max_depth + 2) * Q_COUNT));
         return HK_OK;
     };
-    const char* slab_env = std::getenv("HK_STATE_SLAB");   // (0: one allocation per array, nothing cached)
+    const char* slab_env = hk::knob("HK_STATE_SLAB");   // (0: one allocation per array, nothing cached)
     if (!(slab_env && std::atoi(slab_env) == 0)) {
         I->slab_mode = 1, I->slab_off = 0;
         if (int e = layout()) {
@@ -1490,7 +1648,7 @@ int ensure_state(hk_integrator* I, int capacity, bool media, bool open_scene, bo
     I->st_capacity = capacity;
     I->st_depth = I->p.max_depth;
     I->st_media = media ? 1 : 0;
-    if (std::getenv("HK_DEBUG_ALLOC"))
+    if (hk::knob("HK_DEBUG_ALLOC"))
         std::fprintf(stderr, "HK_DEBUG_ALLOC capacity %d Q %zu: ray_o %p ray_d %p beta %p hit %p sh_o %p L %p medium_q %p mat_q %p counters %p\n", capacity, Q, (void*)s.gen[0].ray_o,
                      (void*)s.gen[0].ray_d, (void*)s.gen[0].beta, (void*)s.hit, (void*)s.sh_o, (void*)s.L, (void*)s.medium_q, (void*)s.mat_q, (void*)s.counters);
     return HK_OK;
@@ -1560,6 +1718,7 @@ extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_
     if (sc->ctx != c || I->ctx != c || film->ctx != c) return fail(HK_ERR_INVALID, "scene / integrator / film belong to another context");
     if (film->f64 != (I->p.accumulate_f64 != 0)) return fail(HK_ERR_INVALID, "film / integrator accumulation type mismatch");
     if (n_samples == 0) return HK_OK;
+    KnobScope knobs(&c->knobs);
     // A small call (a one-sample `render!`: < 1 path per resident lane, 26 launches of 26 - 100 us whatever they hold) is worth a seventh
     // of its time as part of a larger pass, and the film does not depend on the pass size (k_film adds in sample order).  So a small call
     // is only NOTED; calls that continue it grow the note; the pass is rendered when the note holds HK_BATCH_PATHS_M (64) million paths,
@@ -1567,11 +1726,15 @@ extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_
     // either way: a device error of a deferred pass is reported by the call that flushes it.  HK_BATCH_PATHS_M=0: every call at once.
     {
         long batch_paths = 64L << 20, small_paths = 8L << 20;   // (Cornell 800^2, 64 one-sample calls: 0.49 / 0.46 / 0.45 ms per call at 32 / 48 / 64 M, cloud 3.8 / 3.7 / 2.8)
-        if (const char* e = std::getenv("HK_BATCH_PATHS_M")) batch_paths = std::atol(e) >= 0 ? std::atol(e) << 20 : batch_paths;
-        if (const char* e = std::getenv("HK_PIPELINE_MAX_PATHS_M")) small_paths = std::atol(e) > 0 ? std::atol(e) << 20 : small_paths;
+        if (const char* e = hk::knob("HK_BATCH_PATHS_M")) batch_paths = std::atol(e) >= 0 ? std::atol(e) << 20 : batch_paths;
+        if (const char* e = hk::knob("HK_PIPELINE_MAX_PATHS_M")) small_paths = std::atol(e) > 0 ? std::atol(e) << 20 : small_paths;
         const long px = (long)((x1 - x0 + 7) / 8) * ((y1 - y0 + 7) / 8) * 64;
         hk_ctx::Pending& p = c->pending;
-        const bool small = batch_paths > 0 && !c->time_kernels && (long)n_samples * px <= small_paths && I->p.samples_per_pass <= 0;
+        // A caller that owns the stream or the accumulators may order its own work behind this call with stream / event calls the library
+        // never sees (torch.cuda.synchronize(), a reduce of the accumulators): its calls are enqueued at once.  HK_DEFER_EXTERNAL=1: batched all the same.
+        const char* de = hk::knob("HK_DEFER_EXTERNAL");
+        const bool visible_order = (c->own_stream_order && !film->external) || (de && std::atoi(de));
+        const bool small = batch_paths > 0 && visible_order && !c->time_kernels && (long)n_samples * px <= small_paths && I->p.samples_per_pass <= 0;
         if (p.active && small && p.sc == sc && p.I == I && p.film == film && std::memcmp(&p.cam, cam, sizeof(hk_camera)) == 0 && p.stride == sample_stride && p.x0 == x0 &&
             p.y0 == y0 && p.x1 == x1 && p.y1 == y1 && (long)p.first + (long)p.n * p.stride == first_sample_idx && (long)(p.n + n_samples) * px <= batch_paths) {
             p.n += n_samples;
@@ -1591,6 +1754,7 @@ extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_
 static int render_tile_now(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_film* film, const hk_camera* cam, int32_t first_sample_idx, int32_t n_samples,
                            int32_t sample_stride, int32_t x0, int32_t y0, int32_t x1, int32_t y1) {
     HIP_TRY(hipSetDevice(c->device));
+    KnobScope knobs(&c->knobs);   // (flush_pending reaches this from every entry point)
     const int W = film->width, H = film->height;
     DFrame fr{};
     fr.width = W;
@@ -1606,7 +1770,7 @@ static int render_tile_now(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_film* f
         // rays/s at 32 spp per pass, 6.3 at 64, 6.45 at 128, 6.56 at 256); path state is ~440 B per path, i.e. up to ~80 GB of the
         // 288 GB of HBM, halved until it fits in half of the free memory.  HK_MAX_PATHS_M overrides the cap (millions of paths).
         long max_paths = 192L << 20;
-        if (const char* e = std::getenv("HK_MAX_PATHS_M")) max_paths = std::atol(e) > 0 ? std::atol(e) << 20 : max_paths;
+        if (const char* e = hk::knob("HK_MAX_PATHS_M")) max_paths = std::atol(e) > 0 ? std::atol(e) << 20 : max_paths;
         S = (int)(max_paths / fr.n_pixels_padded);
         if (S < 1) S = 1;
         if (S > 256) S = 256;
@@ -1625,8 +1789,8 @@ static int render_tile_now(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_film* f
         // the lanes' path-state sets together stay below 8 GB (440 B per path)
         int n_lanes = 1;   // (off since small calls are batched — HK_PIPELINE = 2 .. 16 turns the lanes on for calls that cannot be: a read-back between them)
         long max_paths = 8L << 20;
-        if (const char* e = std::getenv("HK_PIPELINE")) n_lanes = std::atoi(e) >= 1 && std::atoi(e) <= 16 ? std::atoi(e) : n_lanes;
-        if (const char* e = std::getenv("HK_PIPELINE_MAX_PATHS_M")) max_paths = std::atol(e) > 0 ? std::atol(e) << 20 : max_paths;
+        if (const char* e = hk::knob("HK_PIPELINE")) n_lanes = std::atoi(e) >= 1 && std::atoi(e) <= 16 ? std::atoi(e) : n_lanes;
+        if (const char* e = hk::knob("HK_PIPELINE_MAX_PATHS_M")) max_paths = std::atol(e) > 0 ? std::atol(e) << 20 : max_paths;
         {
             const long by_memory = (8L << 30) / (440L * (long)S * fr.n_pixels_padded);
             if (n_lanes > by_memory) n_lanes = by_memory < 1 ? 1 : (int)by_memory;
@@ -1635,7 +1799,7 @@ static int render_tile_now(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_film* f
         // handful, does not start them: only a run of HK_PIPELINE_AFTER = 4 small calls in a row does, i.e. a progressive viewer)
         const bool small_call = n_samples <= S && (long)S * fr.n_pixels_padded <= max_paths;
         int after = 4;
-        if (const char* e = std::getenv("HK_PIPELINE_AFTER")) after = std::atoi(e) >= 0 ? std::atoi(e) : after;
+        if (const char* e = hk::knob("HK_PIPELINE_AFTER")) after = std::atoi(e) >= 0 ? std::atoi(e) : after;
         c->small_streak = small_call ? c->small_streak + 1 : 0;
         const bool lanes_started = c->ev_main != nullptr;
         if (n_lanes > 1 && !c->time_kernels && small_call && (lanes_started || c->small_streak > after)) {
@@ -1678,13 +1842,13 @@ static int render_tile_now(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_film* f
     fr.implicit_ones = sc->d.n_media == 0 ? 1 : 0;
     {   // loop shapes of the tracking state machines (measured defaults; read per call)
         auto knob = [](const char* name, int dflt) {
-            const char* e = std::getenv(name);
+            const char* e = hk::knob(name);
             const int v = e ? std::atoi(e) : dflt;
             return v >= 1 && v <= 255 ? v : dflt;
         };
         {   // collision rounds of k_track_flat wait for HK_TRACK_MIN_PENDING lanes, for at most HK_TRACK_EXTRA_ADVANCE further cheap steps (0 = never wait)
-            const char* e = std::getenv("HK_TRACK_MIN_PENDING");
-            const char* x = std::getenv("HK_TRACK_EXTRA_ADVANCE");
+            const char* e = hk::knob("HK_TRACK_MIN_PENDING");
+            const char* x = hk::knob("HK_TRACK_EXTRA_ADVANCE");
             const int mp = e ? std::atoi(e) : 0, xa = x ? std::atoi(x) : 4;
             fr.track_gate = (mp >= 0 && mp <= 64 ? mp : 0) | ((xa >= 0 && xa <= 255 ? xa : 4) << 8);
         }
@@ -1723,8 +1887,12 @@ static int render_tile_now(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_film* f
             const int count = (int)((((last_idx - base) / sample_stride + 1) + 15) & ~15L);
             bool same = table_same && I->lo_base == base && I->lo_sample_stride == sample_stride && I->lo_count == count && I->lo_rows > 0;
             if (!same) {
+                if (c->lanes_dirty) {   // lanes may still draw from the table that is rebuilt in the same buffer (as for the hi table above)
+                    if (int e = join_lanes(c)) return e;
+                    HIP_TRY(hipStreamSynchronize(c->stream));
+                }
                 double gb = 32.0;
-                if (const char* e = std::getenv("HK_SOBOL_LO_GB")) gb = std::atof(e);
+                if (const char* e = hk::knob("HK_SOBOL_LO_GB")) gb = std::atof(e);
                 size_t budget = (size_t)(gb * 1e9), free_b = 0, total_b = 0;
                 // the buffer of the previous table is reused when it is large enough (another sample range of the same film)
                 if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (free_b + I->sobol_lo.bytes) / 4 < budget) budget = (free_b + I->sobol_lo.bytes) / 4;
@@ -1836,7 +2004,7 @@ static int render_tile_now(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_film* f
         // fill each other's tails and stalls.  With per-kernel timing on (hk_stats_enable_counters bit 1) everything stays on one
         // stream so that the class times add up.
         // (surfaces only: beside the long shadow walks of a media scene the next traversal only competes — cloud -4.5 %; Cornell +-0, sky +1 %, many-light +2.4 %)
-        if (const char* e = std::getenv("HK_OVERLAP")) c->overlap = std::atoi(e) ? 1 : 0;
+        if (const char* e = hk::knob("HK_OVERLAP")) c->overlap = std::atoi(e) ? 1 : 0;
         else c->overlap = -1;
         // A SECOND HARDWARE QUEUE IS NOT FREE ON THIS CHIP: from the moment a process has used a second stream of its own, every kernel of
         // every stream takes 50 - 120 us longer (the completion of one and the start of the next, with or without events between the
@@ -1988,14 +2156,13 @@ extern "C" int32_t hk_stats_get(hk_ctx* c, hk_stats* out) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     DStats h{};
     {
-        std::vector<DStats> rows((size_t)c->stat_rows * (1 + hk_ctx::MAX_LANES));
-        HIP_TRY(hipMemcpy(rows.data(), c->stats.p, (size_t)c->stat_rows * sizeof(DStats), hipMemcpyDeviceToHost));
-        for (size_t l = 0; l < (size_t)hk_ctx::MAX_LANES; ++l) {
-            if (c->lanes[l].stats.p)
-                HIP_TRY(hipMemcpy(rows.data() + (l + 1) * (size_t)c->stat_rows, c->lanes[l].stats.p, (size_t)c->stat_rows * sizeof(DStats), hipMemcpyDeviceToHost));
-            else
-                std::memset(rows.data() + (l + 1) * (size_t)c->stat_rows, 0, (size_t)c->stat_rows * sizeof(DStats));
-        }
+        // the context's own block + the blocks of the lanes that exist (none unless HK_PIPELINE > 1 has ever started them)
+        std::vector<const void*> blocks{c->stats.p};
+        for (const auto& l : c->lanes)
+            if (l.stats.p) blocks.push_back(l.stats.p);
+        std::vector<DStats> rows((size_t)c->stat_rows * blocks.size());
+        for (size_t b = 0; b < blocks.size(); ++b)
+            HIP_TRY(hipMemcpy(rows.data() + b * (size_t)c->stat_rows, blocks[b], (size_t)c->stat_rows * sizeof(DStats), hipMemcpyDeviceToHost));
         for (const DStats& r : rows) {
             h.rays_closest += r.rays_closest;
             h.rays_shadow += r.rays_shadow;
@@ -2108,6 +2275,7 @@ extern "C" int32_t hk_trace_closest(hk_ctx* c, hk_scene* sc, int32_t n, const fl
                                     float* out_uv2) {
     if (!c || !sc || n < 0) return fail(HK_ERR_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
+    KnobScope knobs(&c->knobs);
     Tmp t;
     float *o = t.up(o3, 3 * (size_t)n), *d = t.up(d3, 3 * (size_t)n), *tm = t.up(tmax, n);
     float* ot = t.up<float>(nullptr, n);
@@ -2249,6 +2417,7 @@ extern "C" int32_t hk_test_trace_lean(hk_ctx* c, hk_scene* sc, int32_t anyhit, i
                                       float* out_uv2) {
     if (!c || !sc || !o3 || !d3 || !tmax || !out_t || !out_prim || !out_uv2) return fail(HK_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
+    KnobScope knobs(&c->knobs);
     Tmp t;
     float *o = t.up(o3, 3 * (size_t)n), *d = t.up(d3, 3 * (size_t)n), *tm = t.up(tmax, (size_t)n);
     float *ot = t.up<float>(nullptr, (size_t)n), *ouv = t.up<float>(nullptr, 2 * (size_t)n);

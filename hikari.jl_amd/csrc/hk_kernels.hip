@@ -4358,8 +4358,8 @@ static int cached_blocks(int block, int n_cu, int cap_per_cu) {
 // Segments are walked with a static stride, so the number of physical waves must DIVIDE W or the last round runs with a
 // fraction of the waves (shade at W = 16/CU with 12 resident: 12 % slower than at W = 24): the largest divisor of the
 // 4-wave block count that is resident.
-static int node_cache_mode() {   // HK_NODE_CACHE=0: the lean closest-hit kernel reads every node from global memory (A/B switch, read per launch)
-    const char* e = std::getenv("HK_NODE_CACHE");
+static int node_cache_mode() {   // HK_NODE_CACHE=0: the lean closest-hit kernel reads every node from global memory (A/B switch, looked up per launch in the context's knob table)
+    const char* e = hk::knob("HK_NODE_CACHE");
     return (e && std::atoi(e) == 0) ? 0 : 1;
 }
 static int clamp_blocks(int blocks, const DPathState& st, int waves_per_block = 4) {
@@ -4429,20 +4429,20 @@ void launch_trace(hipStream_t s, int n_cu, const DPathState& st, const DScene& s
     else
         hipLaunchKernelGGL(k_trace<false>, dim3(clamp_blocks(b0, st)), dim3(HK_TRACE_BLOCK), 0, s, st, sc, T, fr, depth, stats);
 }
-static int grey_mode() {   // HK_GREY=0: flat-spectrum media run through the general tracking kernels (A/B switch, read per launch)
-    const char* e = std::getenv("HK_GREY");
+static int grey_mode() {   // HK_GREY=0: flat-spectrum media run through the general tracking kernels (A/B switch, looked up per launch in the context's knob table)
+    const char* e = hk::knob("HK_GREY");
     return e ? std::atoi(e) : 1;
 }
-static int grey_flat_mode() {   // HK_GREY_FLAT=0: grey media run through the round-3 GREY instantiations of k_track / k_shadow_walk (A/B switch, read per launch)
-    const char* e = std::getenv("HK_GREY_FLAT");
+static int grey_flat_mode() {   // HK_GREY_FLAT=0: grey media run through the round-3 GREY instantiations of k_track / k_shadow_walk (A/B switch, looked up per launch in the context's knob table)
+    const char* e = hk::knob("HK_GREY_FLAT");
     return e ? std::atoi(e) : 1;
 }
-static int walk_pool_mode() {   // HK_WALK_POOL=0: k_shadow_walk<.., GREY> instead of k_walk_pool (A/B switch, read per launch)
-    const char* e = std::getenv("HK_WALK_POOL");
+static int walk_pool_mode() {   // HK_WALK_POOL=0: k_shadow_walk<.., GREY> instead of k_walk_pool (A/B switch, looked up per launch in the context's knob table)
+    const char* e = hk::knob("HK_WALK_POOL");
     return e ? std::atoi(e) : 1;
 }
-static int track_pool_mode() {   // HK_TRACK_POOL=0: k_track_flat instead of k_track_pool (A/B switch, read per launch)
-    const char* e = std::getenv("HK_TRACK_POOL");
+static int track_pool_mode() {   // HK_TRACK_POOL=0: k_track_flat instead of k_track_pool (A/B switch, looked up per launch in the context's knob table)
+    const char* e = hk::knob("HK_TRACK_POOL");
     return e ? std::atoi(e) : 1;
 }
 // media kernels are instantiated for a single medium kind or for all four (15)
@@ -4451,7 +4451,7 @@ static int media_mask_class(const DScene& sc) {
     return (m == 1 || m == 2 || m == 4 || m == 8) ? m : 15;
 }
 static int walk_split_mode() {   // HK_WALK_SPLIT=1: the grey medium's shadow walk runs as k_walk_cast / k_walk_track rounds instead of ONE k_shadow_walk<.., GREY>
-    const char* e = std::getenv("HK_WALK_SPLIT");   // (measured on the BOMEX stand-in: cast rounds 0.085 s + tracking rounds 0.45 s against 0.51 s unsplit — off by default)
+    const char* e = hk::knob("HK_WALK_SPLIT");   // (measured on the BOMEX stand-in: cast rounds 0.085 s + tracking rounds 0.45 s against 0.51 s unsplit — off by default)
     return e ? std::atoi(e) : 0;
 }
 template <bool C, int MM>
@@ -4467,7 +4467,7 @@ static void launch_walk_split(hipStream_t s, int n_cu, const DPathState& st, con
 // through the pool kernels (k_track_pool / k_walk_pool, the only media kernels that know the compact layout): r_u is never touched
 // there and every factor of r_l is a scalar.  HK_GREY_COMPACT=0: the full records.
 bool grey_compact_ok(const DScene& sc) {
-    const char* e = std::getenv("HK_GREY_COMPACT");
+    const char* e = hk::knob("HK_GREY_COMPACT");
     if (e && std::atoi(e) == 0) return false;
     const int mc = sc.n_media > 0 ? media_mask_class(sc) : 0;
     return sc.n_media == 1 && sc.all_grey && sc.grey_pool && (mc == 2 || mc == 8) && sc.bvh_depth <= 16 && grey_mode() && grey_flat_mode() && track_pool_mode() && walk_pool_mode() &&
@@ -4576,7 +4576,7 @@ void launch_medium(hipStream_t s, int n_cu, const DPathState& st, const DScene& 
         const int d = depth, q = Q_SCATTER;
         launch_segment_lists(s, st, 1, &d, &q);
     }
-    const char* ft_env = std::getenv("HK_SOBOL_TABLE_ONLY");   // read per launch (A/B switch)
+    const char* ft_env = hk::knob("HK_SOBOL_TABLE_ONLY");   // looked up per launch in the context's knob table (A/B switch)
     if (sob.hi_table != nullptr && sob.lo_table != nullptr && 9 + 5 * depth < sob.lo_rows && 9 + 5 * depth < sob.hi_rows && !(ft_env && std::atoi(ft_env) == 0)) {
         const int sblocks = cached_blocks<k_scatter<true>>(256, n_cu, 8);
         hipLaunchKernelGGL(k_scatter<true>, dim3(clamp_blocks(sblocks, st)), dim3(256), 0, s, st, sc, T, fr, sob, depth, stats);
@@ -4593,17 +4593,17 @@ void launch_escaped(hipStream_t s, int n_cu, const DPathState& st, const DScene&
     hipLaunchKernelGGL(k_escaped, dim3(clamp_blocks(blocks, st)), dim3(256), 0, s, st, sc, T, depth, fr.implicit_ones);   // (one wave per segment instead of the resident stride: +-0, sky)
 }
 static bool sobol_tables_cover(const DSobol& sob, int depth) {
-    const char* ft_env = std::getenv("HK_SOBOL_TABLE_ONLY");   // read per launch (A/B switch)
+    const char* ft_env = hk::knob("HK_SOBOL_TABLE_ONLY");   // looked up per launch in the context's knob table (A/B switch)
     return sob.hi_table != nullptr && sob.lo_table != nullptr && 9 + 5 * depth < sob.lo_rows && 9 + 5 * depth < sob.hi_rows && !(ft_env && std::atoi(ft_env) == 0);
 }
 // scenes whose next-event light is chosen by k_light_select before the shade kernels run (HK_PRESELECT=0: never)
 bool preselect_lights(const DScene& sc, const DPathState& st) {
-    const char* e = std::getenv("HK_PRESELECT");
+    const char* e = hk::knob("HK_PRESELECT");
     return sc.n_media == 0 && sc.num_bvh_lights >= HK_PRESELECT_MIN && st.sel_light != nullptr && !(e && std::atoi(e) == 0);
 }
 void launch_light_select(hipStream_t s, int n_cu, const DPathState& st, const DScene& sc, const DTables& T, const DFrame& fr, const DSobol& sob, int depth, uint32_t kinds_mask, DStats* stats) {
     int min_idle = HK_SELECT_MIN_IDLE;
-    if (const char* e = std::getenv("HK_SELECT_MIN_IDLE")) min_idle = std::atoi(e) >= 1 && std::atoi(e) <= 64 ? std::atoi(e) : min_idle;
+    if (const char* e = hk::knob("HK_SELECT_MIN_IDLE")) min_idle = std::atoi(e) >= 1 && std::atoi(e) <= 64 ? std::atoi(e) : min_idle;
     if (sobol_tables_cover(sob, depth)) {
         const int blocks = cached_blocks<k_light_select<true>>(256, n_cu, 8);
         hipLaunchKernelGGL(k_light_select<true>, dim3(clamp_blocks(blocks, st)), dim3(256), 0, s, st, sc, T, fr, sob, depth, kinds_mask, min_idle, stats);
@@ -4619,7 +4619,7 @@ void launch_shade(hipStream_t s, int n_cu, int kind, const DPathState& st, const
         hipLaunchKernelGGL(k_shade<K>, dim3(clamp_blocks(blocks, st)), dim3(256), 0, s, st, sc, T, fr, sob, depth, first_kind, stats); \
     } break;
     // both sampler tables hold every draw of this bounce (rows up to 9 + 5 depth: sobol_row) for every path of the pass: the table-only
-    // instantiation (HK_SOBOL_TABLE_ONLY=0: always the general one — A/B switch, read per launch)
+    // instantiation (HK_SOBOL_TABLE_ONLY=0: always the general one — A/B switch, looked up per launch in the context's knob table)
     const bool ft = sobol_tables_cover(sob, depth);
     if (preselect_lights(sc, st)) {   // k_light_select has run for this depth: the instantiations without the light-BVH descent
 #define HK_SHADE_PRE(K)                                                                                                                 \

@@ -11,6 +11,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Run-time knobs (hk_api.cpp): the value of HK_<name> in the table of the context whose entry point runs on this thread, or nullptr.
+// The environment is read once, by hk_ctx_create; hk_ctx_set_option changes a knob afterwards.
+namespace hk {
+const char* knob(const char* name);
+}
+
 #define HK_TICKET_COLS 16       // kernels per bounce that draw segment tickets (5 + HK_MAX_KINDS)
 #define HK_TICKET_WAYS 64       // counters one ticket is split into: one per lane of a wave
 #define HK_TICKET_STRIDE 64     // ints between two counters of a ticket: one 256-byte line each

@@ -80,6 +80,43 @@ class Context:
             cls._by_device[device] = Context(device)
         return cls._by_device[device]
 
+    # -- tuning knobs (hk_ctx_set_option): the library reads HK_* from the environment once, when the context is created --
+    def set_option(self, name, value):
+        """value None: back to the built-in default"""
+        v = None if value is None else str(value).encode()
+        _lib.check(_lib.lib().hk_ctx_set_option(self.h, name.encode(), v), "hk_ctx_set_option(%s)" % name)
+
+    def get_option(self, name):
+        buf = C.create_string_buffer(256)
+        n = _lib.lib().hk_ctx_get_option(self.h, name.encode(), buf, 256)
+        return None if n < 0 else buf.value.decode()
+
+    def options(self, **kv):
+        """with ctx.options(HK_GREY=0, HK_WAVES_PER_CU=3): ... — the knobs are restored on exit"""
+        return _Options(self, kv)
+
+    def flush(self):
+        _lib.check(_lib.lib().hk_flush(self.h), "hk_flush")
+
+    def trim_cache(self):
+        _lib.check(_lib.lib().hk_trim_cache(self.h), "hk_trim_cache")
+
+
+class _Options:
+    def __init__(self, ctx, kv):
+        self.ctx, self.kv, self.saved = ctx, kv, {}
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            self.saved[k] = self.ctx.get_option(k)
+            self.ctx.set_option(k, v)
+        return self.ctx
+
+    def __exit__(self, *exc):
+        for k, v in self.saved.items():
+            self.ctx.set_option(k, v)
+        return False
+
 
 def scene_handle(ctx, scene):
     d = scene.desc
@@ -144,6 +181,8 @@ class VolPath:
         self._integ = None
         self._film = None      # (hk_film handle, w, h)
         self._external_accum = None
+        self._readback = None  # the one host buffer hk_film_read_rgb fills (a stable pointer: the library pins it)
+        self._read_pending = False
 
     # -- lazily created device state (the reference's `vp.state`, volpath.jl:463-482) --
     def _ensure(self, film):
@@ -156,6 +195,7 @@ class VolPath:
         if self._film is None or self._film[1:] != (film.width, film.height):
             if self._film is not None:
                 L.hk_film_destroy(self._film[0])
+                self._read_pending = False
             h = C.c_void_p()
             ext = C.c_void_p(self._external_accum) if self._external_accum else None
             _lib.check(L.hk_film_create(self._ctx.h, film.width, film.height, self.params.accumulate_f64, ext, C.byref(h)), "hk_film_create")
@@ -185,17 +225,51 @@ class VolPath:
             _lib.check(L.hk_render_tile(self._ctx.h, sh, self._integ, self._film[0], C.byref(cam), int(first), int(n_samples), int(stride),
                                         *[int(v) for v in tile]), "hk_render_tile")
         film.iteration_index = first + (n_samples - 1) * stride
-        if readback:
-            self.read_framebuffer(film)
+        if readback == "pipelined":
+            # the frame an interactive viewer shows, one call behind: this call's samples are handed to the GPU, the frame of the PREVIOUS
+            # call (its copy was enqueued then) is waited for while they render, then this call's copy is enqueued behind them
+            _lib.check(L.hk_flush(self._ctx.h), "hk_flush")
+            if self._read_pending:
+                self._frame_from_pinned(film)
+            _lib.check(L.hk_film_read_rgb_async(self._ctx.h, self._film[0]), "hk_film_read_rgb_async")
+            self._read_pending = True
+        elif readback:
+            self.read_framebuffer(film, view=(readback == "view"))
 
     def render(self, scene, film, camera):
         """render!(vp, scene, film, camera): one sample, progressive (volpath.jl:445-450)."""
         self.render_samples(scene, film, camera, 1)
 
-    def read_framebuffer(self, film):
-        out = np.empty((film.width, film.height, 3), dtype=np.float32)  # Julia [h,w] column-major == C [w][h]
-        _lib.check(_lib.lib().hk_film_read_rgb(self._ctx.h, self._film[0], out.ctypes.data_as(A.PF)), "hk_film_read_rgb")
-        film.framebuffer[...] = np.transpose(out, (1, 0, 2))
+    def read_framebuffer(self, film, view=False):
+        """film.framebuffer <- K13 of the accumulators.  The library writes Julia's [h, w] column-major matrix, i.e. C [w][h]: by default
+        it is copied (transposed) into film.framebuffer; view=True makes film.framebuffer a transposed VIEW of the integrator's one
+        read-back buffer instead — no host copy, and the library copies straight into that buffer once it has seen it twice
+        (include/hikari_mi355x.h: hk_film_read_rgb) — valid until the next read."""
+        self._read_pending = False
+        rb = self._readback
+        if rb is None or rb.shape != (film.width, film.height, 3):
+            rb = self._readback = np.empty((film.width, film.height, 3), dtype=np.float32)
+        _lib.check(_lib.lib().hk_film_read_rgb(self._ctx.h, self._film[0], rb.ctypes.data_as(A.PF)), "hk_film_read_rgb")
+        if view:
+            film.framebuffer = np.transpose(rb, (1, 0, 2))
+        else:
+            if not film.framebuffer.flags.writeable or film.framebuffer.base is rb:
+                film.framebuffer = np.empty((film.height, film.width, 3), dtype=np.float32)
+            film.framebuffer[...] = np.transpose(rb, (1, 0, 2))
+
+    def _frame_from_pinned(self, film):
+        """hk_film_read_wait: film.framebuffer becomes a view of the film's pinned staging buffer holding the last asynchronous read"""
+        ptr = A.PF()
+        _lib.check(_lib.lib().hk_film_read_wait(self._ctx.h, self._film[0], None, C.byref(ptr)), "hk_film_read_wait")
+        frame = np.ctypeslib.as_array(ptr, shape=(film.width, film.height, 3))
+        film.framebuffer = np.transpose(frame, (1, 0, 2))
+        self._read_pending = False
+
+    def finish_pipelined(self, film):
+        """after a loop of render_samples(..., readback="pipelined"): the frame of the LAST call"""
+        if self._read_pending:
+            self._frame_from_pinned(film)
+            film.framebuffer = film.framebuffer.copy()      # (the pinned buffer belongs to the film)
 
     def read_accumulators(self, film):
         n = film.width * film.height
@@ -231,11 +305,15 @@ class VolPath:
     def sync(self):
         _lib.check(_lib.lib().hk_sync(self._ctx.h), "hk_sync")
 
-    def close(self):
+    def close(self, trim_cache=False):
+        """trim_cache: also give the path-state slab (kept by the library for the next integrator: up to HK_STATE_CACHE_GB) back to the driver"""
         L = _lib.lib()
         if self._film is not None:
             L.hk_film_destroy(self._film[0])
             self._film = None
+        self._readback, self._read_pending = None, False
         if self._integ is not None:
             L.hk_integrator_destroy(self._integ)
             self._integ = None
+        if trim_cache and self._ctx is not None:
+            self._ctx.trim_cache()

@@ -320,6 +320,17 @@ int32_t hk_ctx_create(int32_t device_id, void* stream, hk_ctx** out);
 int32_t hk_ctx_destroy(hk_ctx* ctx);
 const char* hk_last_error(void);
 int32_t hk_ctx_set_tables(hk_ctx* ctx, const hk_tables* tables);
+/* Tuning knobs (the HK_* table of INTEGRATION.md).  The library reads the environment ONCE, in hk_ctx_create — never on a render
+ * path — and keeps the values in the context; hk_ctx_set_option changes one afterwards (value NULL: back to the built-in default).
+ * Calls that were only noted (see hk_render) are rendered first, under the options they were made with.  Unknown names are
+ * HK_ERR_INVALID.  hk_ctx_get_option: length of the value (copied to `out`, NUL-terminated, at most out_bytes), -1 when unset.
+ * There is no reference counterpart: Hikari's knobs are keyword arguments of VolPath(...) (volpath.jl:55-106), carried here by
+ * hk_integrator_params. */
+int32_t hk_ctx_set_option(hk_ctx* ctx, const char* name, const char* value);
+int32_t hk_ctx_get_option(hk_ctx* ctx, const char* name, char* out, int32_t out_bytes);
+/* Gives the path-state slabs this process keeps cached for `ctx`'s device back to the driver (a destroyed integrator's path
+ * state — up to HK_STATE_CACHE_GB = 128 in total — is otherwise kept for the next one: allocating 84 GB takes seconds). */
+int32_t hk_trim_cache(hk_ctx* ctx);
 
 /* Scene: copies the description, builds the BVH + light BVH on the host, uploads. */
 int32_t hk_scene_create(hk_ctx* ctx, const hk_scene_desc* desc, hk_scene** out);
@@ -337,7 +348,20 @@ int32_t hk_film_clear(hk_film* film); /* clear!(vp), volpath.jl:108-113 */
 
 /* Render samples first_sample_idx .. first_sample_idx+n_samples-1 (1-based like
  * film.iteration_index, volpath.jl:488-489) with stride `sample_stride` (1 on a single GPU; G when
- * G GPUs shard by sample index) on top of the current accumulators.  Asynchronous on ctx's stream. */
+ * G GPUs shard by sample index) on top of the current accumulators.
+ *
+ * ORDERING CONTRACT.  The call returns before the samples are rendered.
+ *   - A call of more than 8 M paths (HK_PIPELINE_MAX_PATHS_M), a call on a context that was created on a CALLER'S stream, and a call
+ *     into a film with EXTERNAL accumulators are enqueued on ctx's stream before the call returns: whatever the caller orders behind
+ *     that stream (events, a collective on the accumulators, torch.cuda.synchronize()) sees the samples.
+ *   - A SMALL call (a one-sample `render!`, volpath.jl:445-450) on a context with the default stream and a library-owned film may only
+ *     be NOTED: calls that continue each other (same scene / integrator / film / camera / pixel range / stride, sample indices
+ *     following on) are rendered as ONE pass — bit-identical film, a seventh of the time — when the note reaches HK_BATCH_PATHS_M
+ *     (64 M paths), when a call comes that does not continue it, or when anything looks: hk_flush, hk_sync, every hk_film_* / hk_stats_* /
+ *     hk_*_destroy / hk_ctx_set_option entry point.  hk_flush enqueues the noted calls without waiting for them.
+ *     HK_BATCH_PATHS_M=0 (hk_ctx_set_option) turns the noting off.
+ * Argument errors are reported by the call itself; a device error of a deferred pass by the call that flushes it — also by the
+ * destroy entry points, which still destroy their object. */
 int32_t hk_render(hk_ctx* ctx, hk_scene* scene, hk_integrator* integ, hk_film* film, const hk_camera* cam,
                   int32_t first_sample_idx, int32_t n_samples, int32_t sample_stride);
 
@@ -369,10 +393,25 @@ int32_t hk_film_reduce(hk_comm* comm, hk_film* const* films, int32_t n_films, in
 /* K13 finalize (volpath.jl:384-417): writes rgb/weight as Julia Matrix{RGB{Float32}}[height,width]
  * (`out_hw3` = 3 floats per pixel, column-major over (py,px)) into host memory; synchronises. */
 int32_t hk_film_read_rgb(hk_ctx* ctx, hk_film* film, float* out_hw3);
+/* The same frame without stopping the GPU for the copy — what an interactive viewer wants between two render! calls
+ * (volpath.jl:617-633 writes the frame after EVERY sample):
+ *   hk_film_read_rgb_async   enqueues K13 + the copy of the frame into PINNED host memory owned by the film (two buffers, used in
+ *                            turn) behind everything rendered so far, and returns at once — the next hk_render may follow;
+ *   hk_film_read_wait        waits for the LAST hk_film_read_rgb_async of the film only (not for renders enqueued after it), then
+ *                            copies the frame to out_hw3 (may be NULL) and / or returns the pinned buffer itself in *frame (may be
+ *                            NULL; valid until the second-next hk_film_read_rgb_async of this film).
+ * hk_film_read_rgb itself goes through the same pinned buffers; when it is given the SAME destination twice in a row it registers that
+ * buffer with the driver (hipHostRegister; unregistered when another pointer comes or the film is destroyed) and copies straight into
+ * it from then on.  HK_READBACK_PIN=0: never register caller memory. */
+int32_t hk_film_read_rgb_async(hk_ctx* ctx, hk_film* film);
+int32_t hk_film_read_wait(hk_ctx* ctx, hk_film* film, float* out_hw3, const float** frame);
 /* raw accumulators (host copy): 4*N floats (or doubles). */
 int32_t hk_film_read_accum(hk_ctx* ctx, hk_film* film, void* out);
 void* hk_film_accum_device_ptr(hk_film* film);
 
+/* hk_flush: every render call made so far is enqueued on ctx's stream (noted small calls are rendered now); does not wait.
+ * hk_sync: hk_flush + waits until the stream is idle. */
+int32_t hk_flush(hk_ctx* ctx);
 int32_t hk_sync(hk_ctx* ctx);
 int32_t hk_stats_get(hk_ctx* ctx, hk_stats* out);
 int32_t hk_stats_reset(hk_ctx* ctx);

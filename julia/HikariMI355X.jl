@@ -162,6 +162,10 @@ mutable struct MI355XVolPath <: Integrator
     comm::Ptr{Cvoid}
     scene_id::UInt
     film_size::Tuple{Int,Int}
+    display::Symbol            # what `render!` does with film.framebuffer after its sample: :every, :pipelined, :manual (see MI355XVolPath)
+    display_every::Int         # ... and every how many calls
+    calls_since_display::Int
+    read_pending::Bool         # an hk_film_read_rgb_async nobody has waited for yet
 end
 
 rowmajor(m) = ntuple(i -> Float32(m[(i - 1) ÷ 4 + 1, (i - 1) % 4 + 1]), 16)
@@ -174,12 +178,24 @@ rgba(s::Hikari.RGBSpectrum) = (s.c[1], s.c[2], s.c[3], s.c[4])
                   max_component_value=10f0, filter=GaussianFilter(), accumulation_eltype=Float32, devices=0:0)
 
 Same keywords and defaults as `Hikari.VolPath` (volpath.jl:75-101) plus `devices`: the GPUs of this node that share a frame
-(sample-index sharding + one RCCL reduce of the film inside the library, SURVEY 8e).
+(sample-index sharding + one RCCL reduce of the film inside the library, SURVEY 8e), and how `render!` — ONE sample per call, what
+RayMakie's interactive loop drives (volpath.jl:445-450) — keeps `film.framebuffer` (host memory here; a device array in the reference):
+
+  * `display = :every` (default), `display_every = k`: the frame is read back after every k-th call (`hk_film_read_rgb`: K13 + a copy into
+    `film.framebuffer`, which the library pins once it has seen it twice).  With k = 1 `film.framebuffer` is current after every call,
+    exactly like the reference; calls that are not followed by a read-back are only NOTED by the library and rendered as one pass with the
+    next read-back (bit-identical film, up to 7x less time per sample) — k = 4 … 16 is what a viewer at 60 Hz wants.
+  * `display = :pipelined`: after call i `film.framebuffer` holds the frame of call i − 1; the copy of frame i is in flight while call
+    i + 1 renders (`hk_film_read_rgb_async` / `hk_film_read_wait`), so the GPU never waits for the host.  `sync_display!(vp, film)` brings
+    the last frame in.
+  * `display = :manual`: `render!` never reads back; call `sync_display!(vp, film)` when a frame is wanted (an offline loop).
+The functor `vp(scene, film, camera)` always returns with the finished frame in place.
 """
 function MI355XVolPath(; max_depth::Int = 8, samples::Int = 64, russian_roulette_depth::Int = 3, regularize::Bool = true,
                        material_coherence::Symbol = :none, max_component_value::Real = 10f0,
                        filter = Hikari.GaussianFilter(), accumulation_eltype::DataType = Float32,
-                       devices = 0:0)
+                       devices = 0:0, display::Symbol = :every, display_every::Int = 1)
+    @assert display in (:every, :pipelined, :manual) && display_every >= 1
     @assert material_coherence in (:none, :sorted, :per_type)          # volpath.jl:85
     @assert accumulation_eltype in (Float32, Float64)                 # volpath.jl:86
     fp = Hikari.GPUFilterParams(filter)                                # filter.jl:574-604
@@ -187,7 +203,7 @@ function MI355XVolPath(; max_depth::Int = 8, samples::Int = 64, russian_roulette
                            Float32(max_component_value), fp.filter_type, (fp.radius[1], fp.radius[2]), fp.param1, fp.param2,
                            accumulation_eltype === Float64, UInt32(0), 0)
     devs = [DeviceState(Int(d), C_NULL, C_NULL, C_NULL, C_NULL) for d in devices]
-    MI355XVolPath(p, samples, devs, C_NULL, UInt(0), (0, 0))
+    MI355XVolPath(p, samples, devs, C_NULL, UInt(0), (0, 0), display, display_every, 0, false)
 end
 
 function ensure_ctx!(vp::MI355XVolPath)
@@ -520,7 +536,7 @@ end
 # ---------------------------------------------------------------------------------------------------------------------------
 # render! / functor / clear! / close  (volpath.jl:445-670, 108-113; Hikari.jl:47)
 # ---------------------------------------------------------------------------------------------------------------------------
-function render_samples!(vp::MI355XVolPath, scene, film::Hikari.Film, camera, n::Int)
+function render_samples!(vp::MI355XVolPath, scene, film::Hikari.Film, camera, n::Int; display::Symbol = :every)
     ensure_ctx!(vp)
     h, w = size(film.framebuffer)
     G = length(vp.devs)
@@ -563,11 +579,39 @@ function render_samples!(vp::MI355XVolPath, scene, film::Hikari.Film, camera, n:
         end
     end
     fb = film.framebuffer                               # Matrix{RGB{Float32}}[h, w]: exactly hk_film_read_rgb's layout
+    if display === :every
+        vp.read_pending = false
+        GC.@preserve fb check(ccall((:hk_film_read_rgb, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float32}), root.ctx, root.film, Ptr{Float32}(pointer(fb))), "hk_film_read_rgb")
+    elseif display === :pipelined
+        # this call's samples go to the GPU now; the frame of the PREVIOUS call is collected while they render; then this call's copy is enqueued
+        check(ccall((:hk_flush, LIB), Int32, (Ptr{Cvoid},), root.ctx), "hk_flush")
+        if vp.read_pending
+            GC.@preserve fb check(ccall((:hk_film_read_wait, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float32}, Ptr{Ptr{Float32}}), root.ctx, root.film, Ptr{Float32}(pointer(fb)), C_NULL), "hk_film_read_wait")
+        end
+        check(ccall((:hk_film_read_rgb_async, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), root.ctx, root.film), "hk_film_read_rgb_async")
+        vp.read_pending = true
+    end                                                 # :skip — the call is only noted (hk_render's ordering contract); the next read-back renders it
+    nothing
+end
+
+"film.framebuffer <- the frame of everything rendered so far (after `display = :pipelined` / `:manual` loops, or between displayed calls)"
+function sync_display!(vp::MI355XVolPath, film::Hikari.Film)
+    root = vp.devs[1]
+    (root.ctx == C_NULL || root.film == C_NULL) && return nothing
+    fb = film.framebuffer
+    vp.read_pending = false
+    vp.calls_since_display = 0
     GC.@preserve fb check(ccall((:hk_film_read_rgb, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float32}), root.ctx, root.film, Ptr{Float32}(pointer(fb))), "hk_film_read_rgb")
     nothing
 end
 
-Hikari.render!(vp::MI355XVolPath, scene::Hikari.AbstractScene, film::Hikari.Film, camera::Hikari.Camera) = render_samples!(vp, scene, film, camera, 1)
+function Hikari.render!(vp::MI355XVolPath, scene::Hikari.AbstractScene, film::Hikari.Film, camera::Hikari.Camera)
+    vp.calls_since_display += 1
+    due = vp.display !== :manual && vp.calls_since_display >= vp.display_every
+    due && (vp.calls_since_display = 0)
+    # multi-device frames reduce (and look) in every call: batching is a one-device matter
+    render_samples!(vp, scene, film, camera, 1; display = !due && length(vp.devs) == 1 ? :skip : (vp.display === :pipelined && due ? :pipelined : :every))
+end
 
 function Hikari.clear!(vp::MI355XVolPath)
     for d in vp.devs
@@ -578,12 +622,14 @@ end
 function (vp::MI355XVolPath)(scene::Hikari.AbstractScene, film::Hikari.Film, camera::Hikari.Camera)
     film.iteration_index[] = Int32(0)
     Hikari.clear!(vp)
+    vp.calls_since_display = 0
     render_samples!(vp, scene, film, camera, Int(vp.samples_per_pixel))
     copyto!(film.postprocess, film.framebuffer)          # the functor returns film.postprocess (volpath.jl:669): linear HDR until postprocess! runs
     return film.postprocess
 end
 
 function Base.close(vp::MI355XVolPath)
+    vp.read_pending = false
     vp.comm != C_NULL && ccall((:hk_comm_destroy, LIB), Int32, (Ptr{Cvoid},), vp.comm)
     vp.comm = C_NULL
     for d in vp.devs

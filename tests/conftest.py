@@ -30,3 +30,31 @@ def oracle():
 def gpu_ctx(hk):
     """hk_ctx on cuda:0; fails loudly (never falls back) when the HIP library is missing."""
     return hk.Context.get(0)
+
+
+class _Knobs:
+    """Tuning knobs of the device context for the duration of one test (hk_ctx_set_option — the library reads HK_* from the environment
+    only once, in hk_ctx_create).  setenv / delenv mirror pytest's monkeypatch; everything is restored at teardown."""
+
+    def __init__(self, ctx):
+        self.ctx, self.saved = ctx, {}
+
+    def setenv(self, name, value):
+        self.saved.setdefault(name, self.ctx.get_option(name))
+        self.ctx.set_option(name, value)
+
+    def delenv(self, name, raising=False):
+        self.saved.setdefault(name, self.ctx.get_option(name))
+        self.ctx.set_option(name, None)
+
+    def restore(self):
+        for name, value in self.saved.items():
+            self.ctx.set_option(name, value)
+        self.saved.clear()
+
+
+@pytest.fixture
+def knobs(gpu_ctx):
+    k = _Knobs(gpu_ctx)
+    yield k
+    k.restore()

@@ -83,19 +83,20 @@ def test_specular_objects_per_pixel_against_the_numpy_restatement(hk, oracle, wh
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("light", ["area", "all"])
-def test_device_frame_per_pixel_against_the_numpy_restatement(hk, light):
+@pytest.mark.parametrize("light,objects,depth,spp", [("area", "sphere_box", 5, 4), ("all", "sphere_box", 5, 4), ("area", "two_spheres", 4, 2)])
+def test_device_frame_per_pixel_against_the_numpy_restatement(hk, light, objects, depth, spp):
     """The same comparison for the HIP path: the device's Cornell frame (sphere + box, depth 5, 4 spp, box filter; under the area light,
-    and under area + point + spot + directional + ambient light) against the NumPy restatement, pixel by pixel — no oracle in between."""
+    and under area + point + spot + directional + ambient light; and SURVEY 8(d)'s two tessellated spheres — 3 782 triangles, the BVH that
+    mixes LDS-cached and global nodes in one traversal) against the NumPy restatement, pixel by pixel — no oracle in between."""
     from hikari_jl_amd import scenes
     w = h = 32
-    s, film, cam = scenes.cornell_box(w, h, light=light)
-    vp = hk.VolPath(max_depth=5, samples=4, filter=hk.BoxFilter())
+    s, film, cam = scenes.cornell_box(w, h, light=light, objects=objects)
+    vp = hk.VolPath(max_depth=depth, samples=spp, filter=hk.BoxFilter())
     vp(s, film, cam)
     dev = film.framebuffer.copy()
     mcv = float(vp.params.max_component_value)
     vp.close()
-    img, _, _ = R.render(s.desc, cam.record(), hk.tables.load(), w, h, 4, 5, max_component_value=mcv, sobol_spp=4)
+    img, _, _ = R.render(s.desc, cam.record(), hk.tables.load(), w, h, spp, depth, max_component_value=mcv, sobol_spp=spp)
     rel = np.sqrt(((img - dev) ** 2).sum(axis=2)) / (np.sqrt((dev ** 2).sum(axis=2)) + 1e-6)
     print("device vs restatement: within 2e-4: %.4f, within 1e-2: %.4f, worst %.3g" % ((rel <= 2e-4).mean(), (rel <= 1e-2).mean(), rel.max()))
     assert (rel <= 2e-4).mean() >= 0.99 and (rel <= 1e-2).mean() >= 0.995

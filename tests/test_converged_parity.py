@@ -107,13 +107,13 @@ GREY_SWITCHES = [{}, {"HK_GREY": "0"}, {"HK_TRACK_POOL": "0", "HK_WALK_POOL": "0
 
 
 @pytest.mark.parametrize("env", GREY_SWITCHES, ids=["pool", "general", "grey_flat"])
-def test_bomex_crop_converged_parity(hk, oracle, monkeypatch, env):
+def test_bomex_crop_converged_parity(hk, oracle, knobs, env):
     """The bench's own cloud (scenes.bomex_scene: 5 % fill, extinction 620, 64^3 majorant, g = 0.877, depth 32) on a 24 x 24 film, through
     the kernels the bench runs (k_track_pool / k_walk_pool), through the GENERAL tracking kernels (HK_GREY=0: they perform the
     (1 +- 3 ulp) ratio multiplications of the oracle that the GREY kernels drop) and through the per-lane-refill GREY kernels."""
     from hikari_jl_amd import scenes
     for k, v in env.items():
-        monkeypatch.setenv(k, v)
+        knobs.setenv(k, v)
     w = h = 24
     s, _, cam = scenes.bomex_scene(w, h)
     frames, G = converged_pair(hk, oracle, s, cam, w, h, key="bomex", max_depth=32)
@@ -122,12 +122,12 @@ def test_bomex_crop_converged_parity(hk, oracle, monkeypatch, env):
 
 @pytest.mark.parametrize("name", ["cloud_nanovdb", "cloud_grid"])
 @pytest.mark.parametrize("env", GREY_SWITCHES[1:], ids=["general", "grey_flat"])
-def test_grey_media_through_the_general_kernels(hk, oracle, monkeypatch, name, env):
+def test_grey_media_through_the_general_kernels(hk, oracle, knobs, name, env):
     """test_media_converged_parity's two GREY clouds (NanoVDB, dense grid) with the GREY specialisation switched off / the pool kernels
     switched off: every tracking kernel family that can render a flat-spectrum medium is held to the same converged bar."""
     from test_gpu_parity import _scene
     for k, v in env.items():
-        monkeypatch.setenv(k, v)
+        knobs.setenv(k, v)
     w = h = 24
     s, _, cam = _scene(name, w, h)
     frames, G = converged_pair(hk, oracle, s, cam, w, h, key=name, max_depth=12)

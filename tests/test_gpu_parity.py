@@ -191,6 +191,7 @@ FRAME_CASES = [
     ("single", dict(max_depth=4, samples=16), (80, 60)),
     ("cornell_area", dict(max_depth=8, samples=8), (96, 96)),
     ("cornell_point", dict(max_depth=5, samples=8), (64, 64)),
+    ("cornell_two_spheres", dict(max_depth=8, samples=8), (64, 64)),   # SURVEY 8(d)'s own Cornell geometry (3 782 triangles: the BVH no longer fits the LDS node cache whole)
     ("integration_nofog", dict(max_depth=5, samples=4), (64, 64)),
     ("many_light", dict(max_depth=4, samples=4), (64, 64)),   # config 5 in miniature: 48 k triangles, ~2.5 k area lights in the light BVH
     ("textured", dict(max_depth=1, samples=8), (64, 64)),   # deeper: alpha tests / coated walks re-seed from ray bits -> statistical case below
@@ -223,6 +224,8 @@ def _scene(name, w, h):
         return scenes.cornell_box(w, h, light="area")
     if name == "cornell_point":
         return scenes.cornell_box(w, h, light="point")
+    if name == "cornell_two_spheres":
+        return scenes.cornell_box(w, h, light="area", objects="two_spheres")
     if name == "integration_nofog":
         return scenes.integration_test_scene(w, h, with_fog=False)
     if name == "textured":
@@ -404,7 +407,7 @@ def test_progressive_and_sharded_rendering(hk):
 
 
 @pytest.mark.parametrize("which", ["cornell", "cloud", "sky"])
-def test_progressive_calls_pipeline_bit_equal(hk, monkeypatch, which):
+def test_progressive_calls_pipeline_bit_equal(hk, knobs, which):
     """64 one-sample calls (render!, volpath.jl:445-450) with no read-back in between are BATCHED (hk_render_tile notes small calls that
     continue each other and renders them as one pass when something looks) or, with HK_BATCH_PATHS_M=0 and HK_PIPELINE > 1, run PIPELINED on
     the library's lanes (hk_ctx::Lane: consecutive small calls beside each other, film kernels chained in call order): the accumulators
@@ -423,11 +426,11 @@ def test_progressive_calls_pipeline_bit_equal(hk, monkeypatch, which):
         depth = 6
 
     def run(env, plan):
-        monkeypatch.delenv("HK_PIPELINE", raising=False)
-        monkeypatch.delenv("HK_BATCH_PATHS_M", raising=False)
-        monkeypatch.setenv("HK_PIPELINE_AFTER", "0")     # (the lanes start with the first small call, not after a run of four)
+        knobs.delenv("HK_PIPELINE", raising=False)
+        knobs.delenv("HK_BATCH_PATHS_M", raising=False)
+        knobs.setenv("HK_PIPELINE_AFTER", "0")     # (the lanes start with the first small call, not after a run of four)
         for k, v in env.items():
-            monkeypatch.setenv(k, v)
+            knobs.setenv(k, v)
         vp = hk.VolPath(max_depth=depth, samples=n)
         vp._ensure(film)
         vp.clear()
@@ -456,11 +459,11 @@ def test_progressive_calls_pipeline_bit_equal(hk, monkeypatch, which):
         assert r2[1:] == rays[1:] and (r2[0] < 0 or r2[0] == rays[0]), (env, r2, rays)
     # a clear between pipelined calls: what is rendered before it is gone, what comes after it is all there
     for env in ({}, {**off, "HK_PIPELINE": "8"}):
-        monkeypatch.delenv("HK_PIPELINE", raising=False)
-        monkeypatch.delenv("HK_BATCH_PATHS_M", raising=False)
-        monkeypatch.setenv("HK_PIPELINE_AFTER", "0")
+        knobs.delenv("HK_PIPELINE", raising=False)
+        knobs.delenv("HK_BATCH_PATHS_M", raising=False)
+        knobs.setenv("HK_PIPELINE_AFTER", "0")
         for k, v in env.items():
-            monkeypatch.setenv(k, v)
+            knobs.setenv(k, v)
         vp = hk.VolPath(max_depth=depth, samples=n)
         vp._ensure(film)
         vp.clear()
@@ -472,8 +475,134 @@ def test_progressive_calls_pipeline_bit_equal(hk, monkeypatch, which):
         got = vp.read_accumulators(film).copy()
         vp.close()
         assert np.array_equal(ref.view(np.uint32), got.view(np.uint32)), env
-    monkeypatch.delenv("HK_PIPELINE", raising=False)
-    monkeypatch.delenv("HK_BATCH_PATHS_M", raising=False)
+    knobs.delenv("HK_PIPELINE", raising=False)
+    knobs.delenv("HK_BATCH_PATHS_M", raising=False)
+
+
+def test_readback_every_call_and_pipelined(hk, knobs):
+    """What an interactive viewer does (volpath.jl:617-633 writes the frame after every sample): one-sample calls, each followed by the
+    frame.  hk_film_read_rgb through the pinned path (the same host buffer every time: registered from the second call on) and the
+    hk_film_read_rgb_async / hk_film_read_wait pair (frame i while call i + 1 renders) must hand out, bit for bit, the frames of the
+    plain loop 'render one sample, read the frame into fresh memory'; with HK_READBACK_PIN=0 too."""
+    from hikari_jl_amd import scenes
+    w, h, n = 40, 36, 12
+    s, film, cam = scenes.cornell_box(w, h, light="area")
+
+    def loop(mode, pin=None):
+        if pin is not None:
+            knobs.setenv("HK_READBACK_PIN", pin)
+        vp = hk.VolPath(max_depth=5, samples=n)
+        vp._ensure(film)
+        vp.clear()
+        frames = []
+        for i in range(n):
+            vp.render_samples(s, film, cam, 1, first=i + 1, readback=mode)
+            if mode == "fresh":
+                vp._readback = None                      # a new destination every call: never pinned
+                vp.read_framebuffer(film)
+            frames.append(np.array(film.framebuffer, copy=True))
+        if mode == "pipelined":
+            vp.finish_pipelined(film)
+            frames.append(np.array(film.framebuffer, copy=True))
+        acc = vp.read_accumulators(film).copy()
+        vp.close()
+        knobs.delenv("HK_READBACK_PIN")
+        return frames, acc
+
+    ref, acc_ref = loop("fresh")
+    assert np.isfinite(ref[-1]).all() and ref[-1].max() > 0 and not np.array_equal(ref[0], ref[-1])
+    for mode, pin in (("view", None), ("view", "0"), (True, None)):
+        got, acc = loop(mode, pin)
+        assert np.array_equal(acc.view(np.uint32), acc_ref.view(np.uint32)), (mode, pin)
+        for i in range(n):
+            assert np.array_equal(got[i].view(np.uint32), ref[i].view(np.uint32)), (mode, pin, i)
+    got, acc = loop("pipelined")
+    assert np.array_equal(acc.view(np.uint32), acc_ref.view(np.uint32))
+    for i in range(1, n + 1):        # after call i the film shows frame i - 1; finish_pipelined brings the last one in
+        assert np.array_equal(got[i].view(np.uint32), ref[i - 1].view(np.uint32)), i
+
+
+def test_lane_pipeline_rebuilds_the_sample_bit_table_behind_the_lanes(hk, knobs):
+    """with HK_PIPELINE >= 2 and batching off, consecutive small calls of >= 16 samples each rebuild the sample-bit
+    table in the SAME buffer; a lane may still be drawing from the old one.  [16, 16, 16, 16] at samples = 256 must equal the same
+    calls rendered one after the other, bit for bit, and repeatedly."""
+    from hikari_jl_amd import scenes
+    w, h = 48, 40
+    s, film, cam = scenes.cornell_box(w, h, light="area")
+
+    def run(env, plan):
+        for k in ("HK_PIPELINE", "HK_BATCH_PATHS_M", "HK_PIPELINE_AFTER"):
+            knobs.delenv(k)
+        for k, v in env.items():
+            knobs.setenv(k, v)
+        vp = hk.VolPath(max_depth=6, samples=256)
+        vp._ensure(film)
+        vp.clear()
+        first = 1
+        for k in plan:
+            vp.render_samples(s, film, cam, k, first=first, readback=False)
+            first += k
+        acc = vp.read_accumulators(film).copy()
+        vp.close()
+        return acc
+
+    plan = [16, 16, 16, 16, 32, 16]
+    ref = run({"HK_BATCH_PATHS_M": "0", "HK_PIPELINE": "1"}, plan)
+    for rep in range(3):
+        for lanes in ("2", "4"):
+            got = run({"HK_BATCH_PATHS_M": "0", "HK_PIPELINE": lanes, "HK_PIPELINE_AFTER": "0"}, plan)
+            assert np.array_equal(ref.view(np.uint32), got.view(np.uint32)), (rep, lanes)
+    for k in ("HK_PIPELINE", "HK_BATCH_PATHS_M", "HK_PIPELINE_AFTER"):
+        knobs.delenv(k)
+
+
+def test_small_calls_into_external_accumulators_are_stream_ordered(hk):
+    """hk_render's ordering contract: a film with EXTERNAL accumulators (a torch tensor the host reduces) is never only noted — after
+    the call, work the caller orders behind the stream (torch.cuda.synchronize()) sees the samples without any hk_* call in between."""
+    import torch
+    from hikari_jl_amd import scenes
+    w, h = 32, 32
+    s, film, cam = scenes.cornell_box(w, h, light="area")
+    accum = torch.zeros(4 * w * h, dtype=torch.float32, device="cuda")
+    vp = hk.VolPath(max_depth=4, samples=4)
+    vp.use_external_accumulators(accum.data_ptr())
+    vp._ensure(film)
+    vp.clear()
+    vp.sync()
+    for i in range(4):
+        vp.render_samples(s, film, cam, 1, first=i + 1, readback=False)
+    torch.cuda.synchronize()
+    seen = accum.cpu().numpy().copy()
+    assert seen[3 * w * h:].min() > 0                    # every pixel has its four samples' filter weights
+    assert np.array_equal(seen.view(np.uint32), vp.read_accumulators(film).view(np.uint32))
+    vp.close()
+    own = hk.VolPath(max_depth=4, samples=4)             # the same calls into a library-owned film (batched): identical sums
+    own._ensure(film)
+    own.clear()
+    for i in range(4):
+        own.render_samples(s, film, cam, 1, first=i + 1, readback=False)
+    assert np.array_equal(seen.view(np.uint32), own.read_accumulators(film).view(np.uint32))
+    own.close()
+
+
+def test_context_options(hk, gpu_ctx, monkeypatch):
+    """hk_ctx_set_option / hk_ctx_get_option: knobs live in the context; the environment is read by hk_ctx_create only."""
+    L = hk._lib.lib()
+    assert L.hk_ctx_set_option(gpu_ctx.h, b"HK_NO_SUCH_KNOB", b"1") == hk._abi.HK_ERR_INVALID and b"unknown option" in L.hk_last_error()
+    assert L.hk_ctx_set_option(gpu_ctx.h, None, b"1") == hk._abi.HK_ERR_INVALID
+    before = gpu_ctx.get_option("HK_WAVES_PER_CU")
+    monkeypatch.setenv("HK_WAVES_PER_CU", "7")           # after the context exists: not seen
+    assert gpu_ctx.get_option("HK_WAVES_PER_CU") == before
+    with gpu_ctx.options(HK_WAVES_PER_CU=5):
+        assert gpu_ctx.get_option("HK_WAVES_PER_CU") == "5"
+    assert gpu_ctx.get_option("HK_WAVES_PER_CU") == before
+    fresh = hk.Context(0)                                # a new context picks the environment up once
+    try:
+        assert fresh.get_option("HK_WAVES_PER_CU") == "7"
+    finally:
+        L.hk_ctx_destroy(fresh.h)
+    gpu_ctx.flush()
+    gpu_ctx.trim_cache()
 
 
 def test_converged_image_within_mc_variance(hk, oracle):
@@ -525,12 +654,8 @@ def test_full_size_properties(hk):
     assert st.rays_closest >= 4 * 640000
     # a pass this size of a small closed scene takes the static stride on one stream (hk_api.cpp ensure_state, "mid"); the tickets and
     # the second stream of a full-size pass must give the same film, bit for bit
-    import os
-    os.environ["HK_MID_PASS_PATHS_M"] = "0"
-    try:
+    with hk.Context.get(0).options(HK_MID_PASS_PATHS_M=0):
         vp(s, film, cam)
-    finally:
-        del os.environ["HK_MID_PASS_PATHS_M"]
     assert np.array_equal(a, film.framebuffer)
     vp.close()
 

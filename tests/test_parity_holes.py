@@ -454,7 +454,7 @@ def test_medium_pointwise_bit_exact(hk, oracle, gpu_ctx, which):
 
 
 # ---------------------------------------------------------------------------------------------------- a11: the lean traversal
-@pytest.mark.parametrize("which", ["cornell", "many_light_full"])
+@pytest.mark.parametrize("which", ["cornell", "cornell_two_spheres", "many_light_full"])
 def test_lean_traversal_parity(hk, oracle, gpu_ctx, which):
     """The traversal the bench path runs — lane_ray_round (while-while rounds, straggler exit, per-lane refill) with the LDS stack
     the BVH depth selects — against the oracle's closest hit: (t, prim, bary) bit-exact on 1 M rays; any-hit mode: occluded
@@ -462,8 +462,10 @@ def test_lean_traversal_parity(hk, oracle, gpu_ctx, which):
     that primitive or lies behind the closest one).  `many_light_full` is the 10^6-triangle scene of BASELINE configs[4]: the only
     BVH deeper than 16 levels, i.e. the only user of the 32-entry-stack instantiations."""
     from hikari_jl_amd import scenes
-    if which == "cornell":
-        s, _, _ = scenes.cornell_box(64, 64)
+    if which.startswith("cornell"):
+        # `cornell_two_spheres` is SURVEY 8(d)'s own geometry (3 782 triangles): its BVH does not fit the 1 536-node LDS cache whole, so
+        # one traversal mixes cached and global nodes
+        s, _, _ = scenes.cornell_box(64, 64) if which == "cornell" else scenes.cornell_box(64, 64, light="area", objects="two_spheres")
         lo, hi = np.array([-1.2, -0.2, -1.2]), np.array([1.2, 2.2, 1.2])
     else:
         s, _, _ = scenes.many_light_scene(64, 64)
@@ -480,7 +482,7 @@ def test_lean_traversal_parity(hk, oracle, gpu_ctx, which):
     d[:1000] = np.array([0, -1, 0], f32)
     d[1000:2000] = np.array([1, 0, 0], f32)
     tmax = np.full(n, np.inf, f32)
-    tmax[::5] = (rng.random(len(tmax[::5])) * (2.0 if which == "cornell" else 6.0)).astype(f32)
+    tmax[::5] = (rng.random(len(tmax[::5])) * (2.0 if which.startswith("cornell") else 6.0)).astype(f32)
     tmax[7::97] = 0.0
     osc = oracle.OracleScene(s)
     rt, rp, ruv = osc.trace(o, d, tmax)
@@ -658,7 +660,7 @@ def test_zsobol_pixel_table_all_index_widths(hk, oracle, spp_setting):
 
 
 @pytest.mark.parametrize("first,n,stride,per_pass,spp_setting", [(1, 16, 1, 0, 64), (3, 21, 1, 8, 64), (2, 17, 3, 5, 64), (1, 20, 1, 0, 8192), (6, 16, 2, 0, 40000)])
-def test_zsobol_sample_bit_table(hk, oracle, monkeypatch, first, n, stride, per_pass, spp_setting):
+def test_zsobol_sample_bit_table(hk, oracle, knobs, first, n, stride, per_pass, spp_setting):
     """A call that renders >= 16 samples reads the permuted sample bits from a table (k_sobol_lo_table, DSobol::lo_table) instead of
     hashing the remaining base-4 digits.  The table must not change a single bit: the accumulators of the same call with the table
     switched off (HK_SOBOL_LO_GB=0) are compared exactly — over aligned and unaligned first samples, strides, several passes per
@@ -679,9 +681,9 @@ def test_zsobol_sample_bit_table(hk, oracle, monkeypatch, first, n, stride, per_
         return acc, fb
 
     acc_table, fb = run()
-    monkeypatch.setenv("HK_SOBOL_LO_GB", "0.0002")     # 200 kB: room for a handful of the 29 rows — the deeper dimensions hash their digits
+    knobs.setenv("HK_SOBOL_LO_GB", "0.0002")     # 200 kB: room for a handful of the 29 rows — the deeper dimensions hash their digits
     acc_partial, _ = run()
-    monkeypatch.setenv("HK_SOBOL_LO_GB", "0")
+    knobs.setenv("HK_SOBOL_LO_GB", "0")
     acc_hashed, _ = run()
     assert np.array_equal(acc_table.view(np.uint32), acc_hashed.view(np.uint32))
     assert np.array_equal(acc_partial.view(np.uint32), acc_hashed.view(np.uint32))
@@ -692,7 +694,7 @@ def test_zsobol_sample_bit_table(hk, oracle, monkeypatch, first, n, stride, per_
     assert rel_mse <= 1e-5 and frac >= 0.995, (rel_mse, frac)
 
 
-def test_light_preselection_is_result_neutral(hk, monkeypatch):
+def test_light_preselection_is_result_neutral(hk, knobs):
     """Scenes with a deep light BVH choose the next-event light in a kernel of its own (k_light_select: per-lane descent with refill)
     before the shade kernels run.  Same arithmetic per vertex as the fused form: the film must be bit-identical with HK_PRESELECT=0,
     at any refill threshold, with and without the table-only Sobol instantiations."""
@@ -703,9 +705,9 @@ def test_light_preselection_is_result_neutral(hk, monkeypatch):
 
     def run(env):
         for k in ("HK_PRESELECT", "HK_SELECT_MIN_IDLE", "HK_SOBOL_TABLE_ONLY"):
-            monkeypatch.delenv(k, raising=False)
+            knobs.delenv(k, raising=False)
         for k, v in env.items():
-            monkeypatch.setenv(k, v)
+            knobs.setenv(k, v)
         vp = hk.VolPath(**kw)
         vp._ensure(film)
         vp.clear()
@@ -723,11 +725,11 @@ def test_light_preselection_is_result_neutral(hk, monkeypatch):
         assert np.array_equal(ref.view(np.uint32), got.view(np.uint32)), env
         assert n2 == nodes, (env, n2, nodes)                            # the same node evaluations, wherever they run
     for k in ("HK_PRESELECT", "HK_SELECT_MIN_IDLE", "HK_SOBOL_TABLE_ONLY"):
-        monkeypatch.delenv(k, raising=False)
+        knobs.delenv(k, raising=False)
 
 
 @pytest.mark.parametrize("which", ["cornell", "sky", "slab", "cloud", "cloud_grid"])
-def test_scheduling_is_result_neutral(hk, monkeypatch, which):
+def test_scheduling_is_result_neutral(hk, knobs, which):
     """How segments reach waves must not change a bit of the film: static stride vs tickets over the work lists, other segment counts
     (a count that is no multiple of anything), the shadow kernels on the second stream or not, BVH nodes from LDS or from global memory.
     Accumulators compared exactly."""
@@ -753,9 +755,9 @@ def test_scheduling_is_result_neutral(hk, monkeypatch, which):
 
     def run(env):
         for k in knobs:
-            monkeypatch.delenv(k, raising=False)
+            knobs.delenv(k, raising=False)
         for k, v in env.items():
-            monkeypatch.setenv(k, v)
+            knobs.setenv(k, v)
         vp = hk.VolPath(**kw)
         vp._ensure(film)
         vp.clear()
@@ -798,14 +800,14 @@ def test_scheduling_is_result_neutral(hk, monkeypatch, which):
         got = run({"HK_GREY": "0"})
         assert np.allclose(ref, got, rtol=2e-5, atol=1e-7), float(np.abs(ref - got).max())
     for k in knobs:
-        monkeypatch.delenv(k, raising=False)
+        knobs.delenv(k, raising=False)
     # leave the context's sticky knobs at their defaults for the tests that follow
-    monkeypatch.setenv("HK_OVERLAP", "1")
-    monkeypatch.setenv("HK_WAVES_PER_CU", "0")
+    knobs.setenv("HK_OVERLAP", "1")
+    knobs.setenv("HK_WAVES_PER_CU", "0")
     run({"HK_OVERLAP": "1", "HK_WAVES_PER_CU": "0"})
 
 
-def test_node_cache_partial_tree(hk, gpu_ctx, oracle, monkeypatch):
+def test_node_cache_partial_tree(hk, gpu_ctx, oracle, knobs):
     """A tree LARGER than the LDS node cache but at most 16 deep: lanes at cached levels read LDS, lanes below read global memory, in
     the same wave (k_trace_lean 1536 nodes, k_shadow 112).  The film must equal, bit for bit, the one rendered with HK_NODE_CACHE=0,
     and agree with the oracle's frame."""
@@ -824,7 +826,7 @@ def test_node_cache_partial_tree(hk, gpu_ctx, oracle, monkeypatch):
     assert n_nodes.value > 1536 and depth.value <= 16, (n_nodes.value, depth.value)
 
     def run(cache):
-        monkeypatch.setenv("HK_NODE_CACHE", cache)
+        knobs.setenv("HK_NODE_CACHE", cache)
         film = hk.Film((w, h))
         vp = hk.VolPath(max_depth=5, samples=64)
         vp._ensure(film)
@@ -836,7 +838,7 @@ def test_node_cache_partial_tree(hk, gpu_ctx, oracle, monkeypatch):
 
     acc1, img1 = run("1")
     acc0, _ = run("0")
-    monkeypatch.delenv("HK_NODE_CACHE", raising=False)
+    knobs.delenv("HK_NODE_CACHE", raising=False)
     assert np.array_equal(acc0.view(np.uint32), acc1.view(np.uint32))
     oacc, _ = oracle.OracleScene(s).render(hk.integrator_params(max_depth=5, samples=64), cam, w, h, 16)
     ref = oracle.finalize(oacc, w, h)

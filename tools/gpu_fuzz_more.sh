@@ -8,7 +8,7 @@ import numpy as np, hikari_jl_amd as hk, oracle
 import test_fuzz_parity as T
 first, count = $1, $2
 bad = 0
-for klass, fn in (("closed", T.test_fuzz_strict), ("absorbing", T.test_fuzz_strict), ("wild", T.test_fuzz_strict), ("walk", T.test_fuzz_statistical), ("scatter", T.test_fuzz_statistical), ("wild_scatter", T.test_fuzz_statistical)):
+for klass, fn in (("closed", T.test_fuzz_strict), ("absorbing", T.test_fuzz_strict), ("wild", T.test_fuzz_strict), ("walk", T.test_fuzz_converged), ("scatter", T.test_fuzz_converged), ("wild_scatter", T.test_fuzz_converged)):
     for seed in range(first, first + count):
         try:
             if fn is T.test_fuzz_strict:

@@ -81,7 +81,7 @@ static const char* const KNOB_NAMES[] = {
     "HK_MID_LISTS", "HK_MID_PASS_PATHS_M", "HK_NODE_CACHE", "HK_NVDB_DENSE_MB", "HK_OVERLAP", "HK_PIPELINE", "HK_PIPELINE_AFTER", "HK_PIPELINE_MAX_PATHS_M", "HK_PRESELECT",
     "HK_SELECT_MIN_IDLE", "HK_SHADOW_FEED_ROUNDS", "HK_SHADOW_TRACK_BATCH", "HK_SMALL_PASS", "HK_SMALL_PASS_WAVES", "HK_SOBOL_LO_GB", "HK_SOBOL_TABLE_ONLY",
     "HK_STATE_CACHE_GB", "HK_STATE_SLAB", "HK_TICKET_SHARE", "HK_TRACK_ADVANCE", "HK_TRACK_EXTRA_ADVANCE", "HK_TRACK_MIN_PENDING", "HK_TRACK_POOL", "HK_TRACK_REFILL_IDLE",
-    "HK_WALK_POOL", "HK_WALK_REFILL_IDLE", "HK_WALK_SPLIT", "HK_WAVES_PER_CU", "HK_READBACK_PIN", "HK_DEFER_EXTERNAL"};
+    "HK_WALK_POOL", "HK_WALK_REFILL_IDLE", "HK_WALK_SPLIT", "HK_WAVES_PER_CU", "HK_READBACK_PIN", "HK_DEFER_EXTERNAL", "HK_SELECT_POOL"};
 static bool known_knob(const char* name) {
     for (const char* k : KNOB_NAMES)
         if (std::strcmp(k, name) == 0) return true;
@@ -862,6 +862,28 @@ extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene**
             o.sin_o = std::sqrt(om > 0.0f ? (float)om : 0.0f);
             o.bits = n.bits;
             o.child1_or_light = n.child1_or_light;
+        }
+        // SIBLING-PAIR ORDER on the device.  The host tree is in the reference's order (bvh-light-sampler.jl:26-46: child 0 = index + 1,
+        // child 1 stored), in which the two children a descent evaluates at every level lie in two unrelated 64-B lines.  The device
+        // walks entry 0 = root, entry 1 = unused, then the children of every inner node as ONE 128-B aligned pair (2k, 2k + 1), pairs in
+        // breadth-first order (the top of the tree is contiguous); an inner node's `child1_or_light` is the entry of its child 0.  Same
+        // nodes, same arithmetic per node, one line per level instead of two; hk_scene_light_bvh_copy still hands out the host order.
+        if (!s->lbvh.nodes.empty()) {
+            std::vector<DLightNode> pairs(2);
+            std::memset(pairs.data(), 0, 2 * sizeof(DLightNode));
+            pairs[0] = tmp[0];
+            std::vector<std::pair<uint32_t, uint32_t>> todo{{0u, 0u}};   // (host index, device entry) of inner nodes whose children are not placed yet
+            for (size_t q = 0; q < todo.size(); ++q) {
+                const uint32_t hi = todo[q].first, de = todo[q].second;
+                if (tmp[hi].bits & 2u) continue;
+                const uint32_t h0 = hi + 1, h1 = tmp[hi].child1_or_light - 1, base = (uint32_t)pairs.size();
+                pairs.push_back(tmp[h0]);
+                pairs.push_back(tmp[h1]);
+                pairs[de].child1_or_light = base;
+                todo.emplace_back(h0, base);
+                todo.emplace_back(h1, base + 1);
+            }
+            tmp.swap(pairs);
         }
         HIP_TRY(s->lnodes.upload(tmp.data(), tmp.size() * sizeof(DLightNode)));
         std::vector<uint32_t> tr = s->lbvh.bit_trails;

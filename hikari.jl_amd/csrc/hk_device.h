@@ -1799,7 +1799,6 @@ HKD int bvh_sample_light(const DScene& sc, v3 p, v3 n, float u, float& pmf_out, 
     if (!has_bvh) return 0;
     float ub = ninf > 0 ? minf((u - p_inf) / (1.0f - p_inf), 0.99999994f) : minf(u, 0.99999994f);
     float pmf = 1.0f - p_inf;
-    int ni = 1;
     uint32_t bits, child;
     {
         const DLightNode root = load_light_node(sc.lnodes, 0);
@@ -1810,8 +1809,7 @@ HKD int bvh_sample_light(const DScene& sc, v3 p, v3 n, float u, float& pmf_out, 
             pmf_out = pmf;
             return (int)child;
         }
-        int c0i = ni + 1, c1i = (int)child;
-        const DLightNode n0 = load_light_node(sc.lnodes, c0i - 1), n1 = load_light_node(sc.lnodes, c1i - 1);
+        const DLightNode n0 = load_light_node(sc.lnodes, (int)child), n1 = load_light_node(sc.lnodes, (int)child + 1);   // the sibling pair: one 128-B line
         float c0 = node_importance(n0, p, n);
         float c1 = node_importance(n1, p, n);
         visited += 2;
@@ -1820,12 +1818,10 @@ HKD int bvh_sample_light(const DScene& sc, v3 p, v3 n, float u, float& pmf_out, 
         if (ub < p0) {
             pmf *= p0;
             ub = ub / p0;
-            ni = c0i;
             bits = n0.bits, child = n0.child1_or_light;
         } else {
             pmf *= (1.0f - p0);
             ub = (ub - p0) / (1.0f - p0);
-            ni = c1i;
             bits = n1.bits, child = n1.child1_or_light;
         }
     }
@@ -1842,7 +1838,6 @@ HKD float bvh_pmf(const DScene& sc, v3 p, v3 n, int light_1based, unsigned& visi
     if (!has_bvh) return 0.0f;
     float p_inf = (float)sc.num_infinite_lights / (float)(sc.num_infinite_lights + 1);
     float pm = 1.0f - p_inf;
-    int ni = 1;
     uint32_t bits, child;
     {
         const DLightNode root = load_light_node(sc.lnodes, 0);
@@ -1850,8 +1845,7 @@ HKD float bvh_pmf(const DScene& sc, v3 p, v3 n, int light_1based, unsigned& visi
     }
     for (int it = 0; it < 64; ++it) {
         if (bits & 2u) return pm;
-        int c0i = ni + 1, c1i = (int)child;
-        const DLightNode n0 = load_light_node(sc.lnodes, c0i - 1), n1 = load_light_node(sc.lnodes, c1i - 1);
+        const DLightNode n0 = load_light_node(sc.lnodes, (int)child), n1 = load_light_node(sc.lnodes, (int)child + 1);
         float c0 = node_importance(n0, p, n);
         float c1 = node_importance(n1, p, n);
         visited += 2;
@@ -1859,11 +1853,9 @@ HKD float bvh_pmf(const DScene& sc, v3 p, v3 n, int light_1based, unsigned& visi
         if (sum <= 0.0f) return 0.0f;
         if ((trail & 1u) == 0u) {
             pm *= c0 / sum;
-            ni = c0i;
             bits = n0.bits, child = n0.child1_or_light;
         } else {
             pm *= c1 / sum;
-            ni = c1i;
             bits = n1.bits, child = n1.child1_or_light;
         }
         trail >>= 1;

@@ -39,6 +39,7 @@ struct WaveQ {
 __device__ __forceinline__ int global_wave() {
     const int w = (int)(threadIdx.x >> 6), b = (int)blockIdx.x;
     if (blockDim.x == 1024 && (gridDim.x & 7) == 0) return ((((b >> 3) * 4 + (w >> 2)) * 8 + (b & 7)) << 2) + (w & 3);
+    if (blockDim.x == 512 && (gridDim.x & 7) == 0) return ((((b >> 3) * 2 + (w >> 2)) * 8 + (b & 7)) << 2) + (w & 3);   // an 8-wave block (k_light_select_pool): two such 4-wave blocks
     return b * (int)(blockDim.x >> 6) + w;
 }
 __device__ __forceinline__ int physical_waves() { return (int)(gridDim.x * (blockDim.x >> 6)); }
@@ -2208,8 +2209,7 @@ __global__ void __launch_bounds__(256) k_light_select(DPathState st, DScene sc, 
                     done = true;
                 } else {
                     ++lvl;
-                    const int c0i = ni + 1, c1i = (int)child;
-                    const DLightNode n0 = load_light_node(sc.lnodes, c0i - 1), n1 = load_light_node(sc.lnodes, c1i - 1);
+                    const DLightNode n0 = load_light_node(sc.lnodes, (int)child), n1 = load_light_node(sc.lnodes, (int)child + 1);
                     const float c0 = node_importance(n0, p, nn);
                     const float c1 = node_importance(n1, p, nn);
                     n_lnodes += 2;
@@ -2222,16 +2222,229 @@ __global__ void __launch_bounds__(256) k_light_select(DPathState st, DScene sc, 
                         if (ub < p0) {
                             pmf *= p0;
                             ub = ub / p0;
-                            ni = c0i;
                             bits = n0.bits, child = n0.child1_or_light;
                         } else {
                             pmf *= (1.0f - p0);
                             ub = (ub - p0) / (1.0f - p0);
-                            ni = c1i;
                             bits = n1.bits, child = n1.child1_or_light;
                         }
                     }
                 }
+            }
+        }
+    }
+    stats += global_wave();
+    wave_add(&stats->light_nodes, n_lnodes);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_light_select re-shaped around a per-wave POOL in LDS (round 5; the round-4 re-shape of the cloud's tracking kernels carried over).
+// The per-lane-refill kernel above ran its descent rounds 70 % full: finished lanes waited for 24 of their kind, and the per-vertex
+// SET-UP (hit record, surface_at, the Sobol draw, the infinite-light prologue) ran for those ~25 lanes only.  Here
+//   * the set-up runs for 64 queue entries AT ONCE whenever the pool is empty and a lane is free; vertices that need a descent leave
+//     (entry, p, n, u_bvh) — 8 words — in the pool, the others (an infinite light chosen, no tree) are answered on the spot;
+//   * a lane whose descent reaches its leaf writes sel_light[entry] and takes the next vertex from the pool IN THE SAME ROUND;
+//   * results are indexed by entry, nothing is left behind in a segment: the wave streams segment after segment and kind after kind
+//     (SegStream) and drains its lanes once, at the end of the launch.
+// Arithmetic per vertex is that of bvh_sample_light, operation for operation (test_light_bvh_parity: pmf at 0 ulp;
+// test_light_preselection_is_result_neutral: film bit-identical with the fused form and with the kernel above, HK_SELECT_POOL=0).
+// ---------------------------------------------------------------------------------------------------
+//   * desynchronised lanes each fetch their own 128-B pair every round — 64 different lines per load instruction, where the batches of
+//     the kernel above still shared the top of the tree: the first pooled version issued 20 % fewer VALU instructions at 84 % lane
+//     utilisation (67 %) and was SLOWER, waiting 51 % of its wave-cycles for memory (16 %).  So the top NTOP entries of the tree — the
+//     first 9 levels in the pair order, half of an average descent — live in the block's LDS (one array per 16-byte part of a node, as
+//     in NodeCache), in 8-wave blocks so that three of them fit a CU beside their pools.
+#ifndef HK_SELECT_NTOP
+#define HK_SELECT_NTOP 512
+#endif
+#ifndef HK_SELECT_BLOCK
+#define HK_SELECT_BLOCK 512
+#endif
+template <int NTOP>
+HKD DLightNode lds_light_node(const lds_float4* top, int i) {
+    const hk_f4v a = top[i], b = top[NTOP + i], c = top[2 * NTOP + i], d = top[3 * NTOP + i];
+    DLightNode n;
+    n.centre[0] = a.x, n.centre[1] = a.y, n.centre[2] = a.z, n.half_diag = a.w;
+    n.r2 = b.x, n.w[0] = b.y, n.w[1] = b.z, n.w[2] = b.w;
+    n.phi = c.x, n.cos_o = c.y, n.cos_e = c.z, n.sin_o = c.w;
+    n.bits = __float_as_uint(d.x), n.child1_or_light = __float_as_uint(d.y);
+    n.pad[0] = n.pad[1] = 0u;
+    return n;
+}
+#ifndef HK_SELECT_WAVES
+#define HK_SELECT_WAVES 6   // three 8-wave blocks per CU: 80 VGPRs
+#endif
+template <bool FT, int BLOCK = HK_SELECT_BLOCK, int NTOP = HK_SELECT_NTOP>
+__global__ void __attribute__((amdgpu_flat_work_group_size(BLOCK, BLOCK), amdgpu_waves_per_eu(HK_SELECT_WAVES))) k_light_select_pool(DPathState st, DScene sc, DTables T, DFrame fr, DSobol sob, int depth, uint32_t kinds_mask, DStats* stats) {
+    __shared__ uint32_t lds_pool[BLOCK / 64][8][64];   // [wave of the block][field][entry] (bit patterns): lane i reads entry head + rank(i) — consecutive words, no bank conflict
+    __shared__ float4 lds_top[NTOP > 0 ? 4 * NTOP : 1];
+    uint32_t (*pool)[64] = lds_pool[threadIdx.x >> 6];
+    const lds_float4* top = (const lds_float4*)lds_top;
+    const int n_top = NTOP > 0 ? (2 * sc.num_bvh_lights < NTOP ? 2 * sc.num_bvh_lights : NTOP) : 0;   // the tree of n lights has 2 n entries (entry 1 unused)
+    if (NTOP > 0) {
+        for (int i = threadIdx.x; i < n_top; i += BLOCK) {
+            const float4* q = reinterpret_cast<const float4*>(sc.lnodes + i);
+            lds_top[i] = q[0], lds_top[NTOP + i] = q[1], lds_top[2 * NTOP + i] = q[2], lds_top[3 * NTOP + i] = q[3];
+        }
+        __syncthreads();
+    }
+    const int lane = lane_id();
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    unsigned n_lnodes = 0;
+    const DPathGen g = st.gen[depth & 1];
+    const int base_dim = 6 + 7 * depth;
+    const int ninf = sc.num_infinite_lights, nbvh = sc.num_bvh_lights;
+    const bool has_bvh = nbvh > 0;
+    const float p_inf = (float)ninf / (float)(ninf + (has_bvh ? 1 : 0));
+    uint32_t root_bits = 2u, root_child = 0u;
+    if (has_bvh) {
+        const DLightNode root = load_light_node(sc.lnodes, 0);
+        root_bits = __builtin_amdgcn_readfirstlane(root.bits), root_child = __builtin_amdgcn_readfirstlane(root.child1_or_light);
+    }
+    SegStream stream = stream_open(st, ticket_ptr(st, depth, TK_SELECT), false, depth, Q_RAY);
+    int gw = -1, kind = HK_MAX_KINDS, n = 0, cursor = 0;   // the input: entries cursor .. n - 1 of `queue`, the per-kind queue of segment gw
+    const uint32_t* __restrict__ queue = st.mat_q;
+    bool more = true;
+    int pool_n = 0, pool_head = 0;
+    // per-lane descent
+    bool busy = false;
+    uint32_t slot = 0, bits = 0, child = 0;
+    int lvl = 0;
+    float ub = 0.0f, pmf = 0.0f;
+    v3 p = mk3(0, 0, 0), nn = mk3(0, 0, 1);
+    for (;;) {
+        const unsigned long long free_m = __ballot(!busy);
+        if (free_m != 0ull) {
+            if (pool_head == pool_n && more) {
+                // ---- the next (up to 64) entries of the input ----
+                while (more && cursor >= n) {
+                    ++kind;
+                    while (kind < HK_MAX_KINDS && !(kinds_mask & (1u << kind))) ++kind;
+                    if (kind >= HK_MAX_KINDS) {   // this segment's kinds are used up: the next segment
+                        gw = stream_next(stream, st.n_waves);
+                        if (gw >= st.n_waves) {
+                            more = false;
+                            break;
+                        }
+                        kind = -1;
+                        continue;
+                    }
+                    queue = st.mat_q + ((size_t)kind * st.n_waves + gw) * st.wave_cap;
+                    n = *count_ptr(st, depth, Q_MAT0 + kind, gw);
+                    cursor = 0;
+                }
+                pool_n = pool_head = 0;
+                if (more) {
+                    const int take = n - cursor < 64 ? n - cursor : 64;
+                    bool descend = false;
+                    uint32_t e = 0;
+                    float u_b = 0.0f;
+                    v3 sp = mk3(0, 0, 0), sn = mk3(0, 0, 1);
+                    if (lane < take) {
+                        e = queue[cursor + lane];
+                        const float4 H = st.hit[e], O = g.ray_o[e], D = g.ray_d[e];
+                        const Surface sf = surface_at(sc, __float_as_int(H.y), H.z, H.w, mk3(O.x, O.y, O.z), mk3(D.x, D.y, D.z), H.x);
+                        sp = sf.pi;
+                        sn = sf.ns;
+                        int pix, k;
+                        split_slot(fr, g.meta[e].y, pix, k);
+                        const SobolCtx sctx = sobol_ctx_slot(sob, T.sobol, fr.x0, fr.y0, fr.tiles_x, pix, k, fr.first_sample + k * fr.sample_stride);
+                        const float u = sobol_1d<FT>(sctx, base_dim + 1);
+                        // bvh_sample_light's prologue: the infinite lights, then the root
+                        int res_light = 0;
+                        float res_pmf = 0.0f;
+                        if (ninf + nbvh > 0) {
+                            if (ninf > 0 && u < p_inf) {
+                                const float ur = u / p_inf;
+                                int idx = (int)floorf(ur * (float)ninf);
+                                idx = (idx < ninf - 1 ? idx : ninf - 1) + 1;
+                                res_pmf = p_inf / (float)ninf;
+                                res_light = sc.infinite_lights[idx - 1];
+                            } else if (has_bvh) {
+                                u_b = ninf > 0 ? minf((u - p_inf) / (1.0f - p_inf), 0.99999994f) : minf(u, 0.99999994f);
+                                if (root_bits & 2u) {   // a tree of one light
+                                    res_pmf = 1.0f - p_inf;
+                                    res_light = (int)root_child;
+                                } else
+                                    descend = true;
+                            }
+                        }
+                        if (!descend) st.sel_light[e] = make_uint2((uint32_t)res_light, __float_as_uint(res_pmf));
+                    }
+                    cursor += take;
+                    const unsigned long long dm = __ballot(descend);
+                    if (descend) {
+                        const int at = __popcll(dm & lt_mask);
+                        pool[0][at] = e;
+                        pool[1][at] = __float_as_uint(sp.x), pool[2][at] = __float_as_uint(sp.y), pool[3][at] = __float_as_uint(sp.z);
+                        pool[4][at] = __float_as_uint(sn.x), pool[5][at] = __float_as_uint(sn.y), pool[6][at] = __float_as_uint(sn.z);
+                        pool[7][at] = __float_as_uint(u_b);
+                    }
+                    pool_n = __popcll(dm);
+                    __builtin_amdgcn_wave_barrier();   // (the pool belongs to this wave alone: LDS operations of one wave complete in order)
+                }
+            }
+            const int avail = pool_n - pool_head;
+            if (avail > 0) {
+                const int rank = __popcll(free_m & lt_mask);
+                if (!busy && rank < avail) {
+                    const int at = pool_head + rank;
+                    slot = pool[0][at];
+                    p = mk3(__uint_as_float(pool[1][at]), __uint_as_float(pool[2][at]), __uint_as_float(pool[3][at]));
+                    nn = mk3(__uint_as_float(pool[4][at]), __uint_as_float(pool[5][at]), __uint_as_float(pool[6][at]));
+                    ub = __uint_as_float(pool[7][at]);
+                    pmf = 1.0f - p_inf;
+                    bits = root_bits, child = root_child;
+                    lvl = 0;
+                    busy = true;
+                }
+                const int free_n = __popcll(free_m);
+                pool_head += free_n < avail ? free_n : avail;
+            }
+            if (__ballot(busy) == 0ull) {
+                if (!more && pool_head == pool_n) break;
+                continue;
+            }
+        }
+        // ---- one level of the descent for every lane that is on its way (a lane that took a vertex above starts at once) ----
+        if (busy) {
+            int res_light = -1;
+            float res_pmf = 0.0f;
+            if (lvl >= 64) {   // the reference gives up after 64 levels (bvh-light-sampler.jl:126)
+                res_light = 0;
+            } else {
+                ++lvl;
+                DLightNode n0, n1;
+                if (NTOP > 0 && (int)child + 1 < n_top) {
+                    n0 = lds_light_node<NTOP>(top, (int)child), n1 = lds_light_node<NTOP>(top, (int)child + 1);
+                    asm volatile("" : "+v"(n0.bits));   // (keeps the two arms apart: a select of generic pointers would become one flat load)
+                } else
+                    n0 = load_light_node(sc.lnodes, (int)child), n1 = load_light_node(sc.lnodes, (int)child + 1);
+                const float c0 = node_importance(n0, p, nn);
+                const float c1 = node_importance(n1, p, nn);
+                n_lnodes += 2;
+                if (c0 == 0.0f && c1 == 0.0f) {
+                    res_light = 0;
+                } else {
+                    const float p0 = c0 / (c0 + c1);
+                    if (ub < p0) {
+                        pmf *= p0;
+                        ub = ub / p0;
+                        bits = n0.bits, child = n0.child1_or_light;
+                    } else {
+                        pmf *= (1.0f - p0);
+                        ub = (ub - p0) / (1.0f - p0);
+                        bits = n1.bits, child = n1.child1_or_light;
+                    }
+                    if ((bits & 2u) && lvl < 64) {   // the chosen child is a leaf: its light, with the pmf of the way down (a leaf 64 levels down is never looked at: bvh-light-sampler.jl:126)
+                        res_light = (int)child;
+                        res_pmf = pmf;
+                    }
+                }
+            }
+            if (res_light >= 0) {
+                st.sel_light[slot] = make_uint2((uint32_t)res_light, __float_as_uint(res_pmf));
+                busy = false;
             }
         }
     }
@@ -4604,6 +4817,17 @@ bool preselect_lights(const DScene& sc, const DPathState& st) {
 void launch_light_select(hipStream_t s, int n_cu, const DPathState& st, const DScene& sc, const DTables& T, const DFrame& fr, const DSobol& sob, int depth, uint32_t kinds_mask, DStats* stats) {
     int min_idle = HK_SELECT_MIN_IDLE;
     if (const char* e = hk::knob("HK_SELECT_MIN_IDLE")) min_idle = std::atoi(e) >= 1 && std::atoi(e) <= 64 ? std::atoi(e) : min_idle;
+    const char* pe = hk::knob("HK_SELECT_POOL");   // 0: the per-lane-refill kernel of round 4 (A/B switch; films bit-identical)
+    if (!(pe && std::atoi(pe) == 0)) {
+        if (sobol_tables_cover(sob, depth)) {
+            const int blocks = cached_blocks<k_light_select_pool<true>>(HK_SELECT_BLOCK, n_cu, 8);
+            hipLaunchKernelGGL(k_light_select_pool<true>, dim3(clamp_blocks(blocks, st, HK_SELECT_BLOCK / 64)), dim3(HK_SELECT_BLOCK), 0, s, st, sc, T, fr, sob, depth, kinds_mask, stats);
+        } else {
+            const int blocks = cached_blocks<k_light_select_pool<false>>(HK_SELECT_BLOCK, n_cu, 8);
+            hipLaunchKernelGGL(k_light_select_pool<false>, dim3(clamp_blocks(blocks, st, HK_SELECT_BLOCK / 64)), dim3(HK_SELECT_BLOCK), 0, s, st, sc, T, fr, sob, depth, kinds_mask, stats);
+        }
+        return;
+    }
     if (sobol_tables_cover(sob, depth)) {
         const int blocks = cached_blocks<k_light_select<true>>(256, n_cu, 8);
         hipLaunchKernelGGL(k_light_select<true>, dim3(clamp_blocks(blocks, st)), dim3(256), 0, s, st, sc, T, fr, sob, depth, kinds_mask, min_idle, stats);

@@ -109,7 +109,7 @@ struct DLightNode {
     float w[3];
     float phi, cos_o, cos_e, sin_o;
     uint32_t bits;              // bit0 two_sided, bit1 is_leaf
-    uint32_t child1_or_light;   // 1-based
+    uint32_t child1_or_light;   // leaf: light index, 1-based; inner node: ENTRY of its child 0 — child 1 is the next entry, the pair shares one 128-B line (sibling-pair order, hk_api.cpp)
     uint32_t pad[2];
 };
 

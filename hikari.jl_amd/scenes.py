@@ -30,12 +30,13 @@ def single_triangle(width=800, height=600):
     return s, film, cam
 
 
-def cornell_box(width=800, height=800, light="area", spheres=True, tess=32, objects="sphere_box"):
+def cornell_box(width=800, height=800, light="area", spheres=True, tess=32, objects="sphere_box", object_material=None):
     """Config 2: Cornell box, diffuse + area light: box 2x2x2 from 0.01-thick slabs, white .73,
     left red (.65,.05,.05), right green (.12,.45,.15), two matte objects, 0.5x0.5 quad light at y=1.98 facing -y
     with Emissive(Le=1, scale=1, two_sided=false); camera (0,1,-3.5)->(0,1,0), fov 40.
     objects = "sphere_box" (rounds 1-3: one sphere tessellated at `tess` + one box, 1 934 triangles) or "two_spheres" (the two
-    spheres of test/volpath_integration.jl:58-62, both tessellated at `tess`: SURVEY 8(d)'s "~4 k triangles")."""
+    spheres of test/volpath_integration.jl:58-62, both tessellated at `tess`: SURVEY 8(d)'s "~4 k triangles").  object_material: the
+    material of the first sphere instead of white matte (the per-pixel pins put a rough conductor there)."""
     white = MatteMaterial(Kd=RGBSpectrum(0.73, 0.73, 0.73))
     red = MatteMaterial(Kd=RGBSpectrum(0.65, 0.05, 0.05))
     green = MatteMaterial(Kd=RGBSpectrum(0.12, 0.45, 0.15))
@@ -55,7 +56,7 @@ def cornell_box(width=800, height=800, light="area", spheres=True, tess=32, obje
     s.push(G.rect3f((-half, 0, -half), (0.01, box, box)), red)               # left
     s.push(G.rect3f((half - 0.01, 0, -half), (0.01, box, box)), green)       # right
     if spheres:
-        s.push(G.sphere((-0.4, 0.4, 0.0), 0.35, tess), white)
+        s.push(G.sphere((-0.4, 0.4, 0.0), 0.35, tess), object_material if object_material is not None else white)
         if objects == "two_spheres":
             s.push(G.sphere((0.4, 0.35, 0.0), 0.3, tess), white)
         else:

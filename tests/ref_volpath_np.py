@@ -513,13 +513,39 @@ class SceneNP:
         self.mi = np.array([desc.meta[i].medium_interface_idx for i in range(T)], np.int64)
         self.arealight = np.array([desc.meta[i].arealight_flat_idx_1based for i in range(T)], np.int64)
         mats = [desc.materials[i] for i in range(desc.n_materials)]
-        assert all(m.kind in (0, 1, 2) for m in mats), "Matte, Mirror, Glass only"
+        assert all(m.kind in (0, 1, 2, 3) for m in mats), "Matte, Mirror, Glass, Conductor only"
         assert all(m.rgb[0].tex < 0 and m.rgb[1].tex < 0 and m.f[0].tex < 0 for m in mats), "constant parameters only"
         self.kind = np.array([m.kind for m in mats], np.int64)
+        # Conductor (uber-material.jl:378-426): roughness -> alpha = sqrt(roughness) when remap_roughness (reflection/microfacet.jl:83-85),
+        # eta / k as measured PiecewiseLinearSpectrum records of the scene description
+        self.alpha = np.zeros(len(mats), f32)
+        self.eta_pl, self.k_pl = {}, {}
+        for i, m in enumerate(mats):
+            if m.kind != 3:
+                continue
+            assert m.spectrum[0] >= 0 and m.spectrum[1] >= 0, "conductor eta / k as PiecewiseLinearSpectrum (the metal presets)"
+            r = f32(m.f[0].v)
+            self.alpha[i] = np.sqrt(r) if (m.flags & 1) else r
+            for store, si in ((self.eta_pl, m.spectrum[0]), (self.k_pl, m.spectrum[1])):
+                sp = desc.spectra[si]
+                store[i] = (np.ctypeslib.as_array(sp.lambdas, shape=(sp.n,)).astype(f32).copy(), np.ctypeslib.as_array(sp.values, shape=(sp.n,)).astype(f32).copy())
         # Matte clamps Kd to [0, 1] (spectral-eval.jl:63); Mirror / Glass pass Kr / Kt to uplift_rgb as they are (it clamps inside)
         self.kd_poly = F([tables.rgb_to_poly([m.rgb[0].c[k] for k in range(3)]) for m in mats])       # Kd, or Kr
         self.kt_poly = F([tables.rgb_to_poly([m.rgb[1].c[k] for k in range(3)]) for m in mats])
         self.ior = F([m.f[0].v if m.kind == 2 else 1.0 for m in mats])
+        self._rest(desc, tables)
+
+    def conductor_ior(self, mat, lam):
+        """eta, k [N, 4] of the conductor materials among `mat` (rows of other kinds: 1, 0)"""
+        eta, k = np.ones(lam.shape, f32), np.zeros(lam.shape, f32)
+        for i in self.eta_pl:
+            sel = mat == i
+            if sel.any():
+                eta[sel] = pl_sample(*self.eta_pl[i], lam[sel])
+                k[sel] = pl_sample(*self.k_pl[i], lam[sel])
+        return eta, k
+
+    def _rest(self, desc, tables):
         self.mat_of_mi = np.array([desc.media_interfaces[i].material for i in range(desc.n_media_interfaces)], np.int64)
         self.lights = [desc.lights[i] for i in range(desc.n_lights)]
         assert all(l.kind in (0, 1, 2, 4, 6) for l in self.lights), "point, spot, directional, ambient and diffuse area lights only"
@@ -607,6 +633,195 @@ class SceneNP:
         return hit
 
 
+# ---------------------------------------------------------------------------------------------------- rough / smooth Conductor
+def pl_sample(lams, vals, lam):
+    """PiecewiseLinearSpectrum at wavelengths lam [N, 4] (spectral/piecewise-linear.jl:11-31): end values outside, the interval found by
+    bisection with lambdas[mid] <= lam, t = (lam - l_lo) / (l_hi - l_lo), v_lo (1 - t) + v_hi t"""
+    lams, vals = F(lams), F(vals)
+    n = len(lams)
+    lo = np.clip(np.searchsorted(lams, lam, side="right") - 1, 0, n - 2)        # the last index with lambdas[lo] <= lam
+    hi = lo + 1
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t = ((lam - lams[lo]) / (lams[hi] - lams[lo])).astype(f32)
+    v = (vals[lo] * (f32(1) - t) + vals[hi] * t).astype(f32)
+    v = np.where(lam <= lams[0], vals[0], v)
+    return np.where(lam >= lams[-1], vals[-1], v).astype(f32)
+
+
+def fr_complex(cos_i, eta, k):
+    """materials/spectral-eval.jl:3667-3745, operation for operation, on float32 arrays (cos_i [N, 1] against eta, k [N, 4])"""
+    with np.errstate(divide="ignore", invalid="ignore"):
+        c = np.clip(cos_i, f32(0), f32(1)).astype(f32)
+        s2i = f32(1) - c * c
+        eta2, k2 = eta * eta, k * k
+        e_re, e_im = eta2 - k2, f32(2) * eta * k
+        den = e_re * e_re + e_im * e_im
+        s2t_re = s2i * e_re / den
+        s2t_im = -s2i * e_im / den
+        c2t_re, c2t_im = f32(1) - s2t_re, -s2t_im
+        mag = np.sqrt(c2t_re * c2t_re + c2t_im * c2t_im)
+        ct_re = np.sqrt(f32(0.5) * (mag + c2t_re))
+        ct_im = c2t_im / (f32(2) * ct_re)
+        ct_im = np.where(ct_re == 0, np.sqrt(f32(0.5) * mag), ct_im)
+        ec_re, ec_im = eta * c, k * c
+        np_re, np_im = ec_re - ct_re, ec_im - ct_im
+        dp_re, dp_im = ec_re + ct_re, ec_im + ct_im
+        dp2 = dp_re * dp_re + dp_im * dp_im
+        rp_re = (np_re * dp_re + np_im * dp_im) / dp2
+        rp_im = (np_im * dp_re - np_re * dp_im) / dp2
+        et_re = eta * ct_re - k * ct_im
+        et_im = eta * ct_im + k * ct_re
+        ns_re, ns_im = c - et_re, -et_im
+        ds_re, ds_im = c + et_re, et_im
+        ds2 = ds_re * ds_re + ds_im * ds_im
+        rs_re = (ns_re * ds_re + ns_im * ds_im) / ds2
+        rs_im = (ns_im * ds_re - ns_re * ds_im) / ds2
+        return (((rp_re * rp_re + rp_im * rp_im) + (rs_re * rs_re + rs_im * rs_im)) * f32(0.5)).astype(f32)
+
+
+def _cos2(w):
+    return w[..., 2] * w[..., 2]
+
+
+def _sin2(w):
+    return np.maximum(f32(0), f32(1) - _cos2(w))
+
+
+def _tan2(w):
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return (_sin2(w) / _cos2(w)).astype(f32)
+
+
+def _cos_phi(w):
+    st = np.sqrt(_sin2(w))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return np.where(st == 0, f32(1), np.clip(w[..., 0] / st, f32(-1), f32(1))).astype(f32)
+
+
+def _sin_phi(w):
+    st = np.sqrt(_sin2(w))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return np.where(st == 0, f32(0), np.clip(w[..., 1] / st, f32(-1), f32(1))).astype(f32)
+
+
+def tr_d(wm, a):
+    """trowbridge_reitz_d (spectral-eval.jl:3776-3785), isotropic alpha"""
+    t2 = _tan2(wm)
+    c4 = _cos2(wm) * _cos2(wm)
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        cp, sp = _cos_phi(wm) / a, _sin_phi(wm) / a
+        e = t2 * (cp * cp + sp * sp)
+        ope = f32(1) + e
+        d = f32(1) / (PI * a * a * c4 * (ope * ope))
+    return np.where(np.isinf(t2) | (c4 < f32(1e-16)), f32(0), d).astype(f32)
+
+
+def tr_lambda(w, a):
+    t2 = _tan2(w)
+    with np.errstate(invalid="ignore", over="ignore"):
+        ca, sa = _cos_phi(w) * a, _sin_phi(w) * a
+        a2 = ca * ca + sa * sa
+        lam = (np.sqrt(f32(1) + a2 * t2) - f32(1)) * f32(0.5)
+    return np.where(np.isinf(t2), f32(0), lam).astype(f32)
+
+
+def tr_pdf(w, wm, a):
+    """trowbridge_reitz_pdf = G1(w) / |cos w| * D(wm) * |w . wm|"""
+    with np.errstate(divide="ignore", invalid="ignore"):
+        g1 = f32(1) / (f32(1) + tr_lambda(w, a))
+        return (g1 / np.abs(w[..., 2]) * tr_d(wm, a) * np.abs(dot(w, wm))).astype(f32)
+
+
+def tr_sample_wm(w, u0, u1, a):
+    """trowbridge_reitz_sample_wm (spectral-eval.jl:3833-3861): visible normals, polar disk sampling"""
+    wh = normalize(np.stack([a * w[..., 0], a * w[..., 1], w[..., 2]], -1).astype(f32))
+    wh = np.where((wh[..., 2] < 0)[..., None], -wh, wh)
+    z = np.zeros_like(wh)
+    z[..., 2] = 1
+    with np.errstate(invalid="ignore", divide="ignore"):
+        t1n = normalize(cross(z, wh))
+    x = np.zeros_like(wh)
+    x[..., 0] = 1
+    t1 = np.where((wh[..., 2] < f32(0.99999))[..., None], t1n, x).astype(f32)
+    t2 = cross(wh, t1)
+    r = np.sqrt(u0)
+    phi = f32(2) * PI * u1
+    px_ = (r * np.cos(phi).astype(f32)).astype(f32)
+    py_ = (r * np.sin(phi).astype(f32)).astype(f32)
+    h = np.sqrt(f32(1) - px_ * px_)
+    tt = f32(0.5) * (f32(1) + wh[..., 2])
+    py_ = ((f32(1) - tt) * h + tt * py_).astype(f32)                                  # lerp(h, p_y, t) = (1 - t) h + t p_y (spectrum.jl:33)
+    pz = np.sqrt(np.maximum(f32(0), f32(1) - px_ * px_ - py_ * py_))
+    nh = (px_[..., None] * t1 + py_[..., None] * t2 + pz[..., None] * wh).astype(f32)
+    return normalize(np.stack([a * nh[..., 0], a * nh[..., 1], np.maximum(f32(1e-6), nh[..., 2])], -1).astype(f32))
+
+
+def _to_local(v, n, tg, bt):
+    return np.stack([dot(v, tg), dot(v, bt), dot(v, n)], -1).astype(f32)
+
+
+def _to_world(v, n, tg, bt):
+    return (tg * v[..., 0:1] + bt * v[..., 1:2] + n * v[..., 2:3]).astype(f32)
+
+
+def _alpha_final(a):
+    """the clamp both entry points apply: a distribution that is not effectively smooth (max alpha >= 1e-3) has alpha >= 1e-4"""
+    return np.where(a < f32(1e-3), a, np.maximum(a, f32(1e-4))).astype(f32)
+
+
+def conductor_eval(wo_w, wi_w, n, alpha, eta, k):
+    """evaluate_bsdf_spectral(::ConductorMaterial) (spectral-eval.jl:415-486): -> f [N, 4], pdf [N]; NO regularisation on this side"""
+    tg, bt = coordinate_system(n)
+    wo, wi = _to_local(wo_w, n, tg, bt), _to_local(wi_w, n, tg, bt)
+    a = _alpha_final(alpha)
+    ok = (wo[..., 2] * wi[..., 2] > 0) & ~(a < f32(1e-3))
+    co, ci = np.abs(wo[..., 2]), np.abs(wi[..., 2])
+    ok &= ~((ci == 0) | (co == 0))
+    wm = (wi + wo).astype(f32)
+    ok &= ~(dot(wm, wm) == 0)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        wm = normalize(wm)
+        Fr = fr_complex(np.abs(dot(wo, wm))[:, None], eta, k)
+        D = tr_d(wm, a)
+        G = (f32(1) / (f32(1) + tr_lambda(wo, a) + tr_lambda(wi, a))).astype(f32)
+        f = (D[:, None] * Fr * G[:, None] / (f32(4) * ci * co)[:, None]).astype(f32)
+        wmp = np.where((wm[..., 2] < 0)[..., None], -wm, wm)                          # face_forward(wm, (0, 0, 1))
+        pdf = (tr_pdf(wo, wmp, a) / (f32(4) * np.abs(dot(wo, wmp)))).astype(f32)
+    return np.where(ok[:, None], f, f32(0)).astype(f32), np.where(ok, pdf, f32(0)).astype(f32)
+
+
+def conductor_sample(wo_w, n, alpha, regularize, eta, k, u0, u1):
+    """sample_bsdf_spectral(::ConductorMaterial) (spectral-eval.jl:223-318): -> wi (world), f, pdf, is_specular, valid.
+    `regularize` [N] bool: alpha < 0.3 becomes clamp(2 alpha, 0.1, 0.3) (reflection/microfacet.jl:97-99) — on the sampling side only"""
+    tg, bt = coordinate_system(n)
+    wo = _to_local(wo_w, n, tg, bt)
+    valid = ~(wo[..., 2] == 0)
+    a = np.where(regularize & (alpha < f32(0.3)), np.clip(f32(2) * alpha, f32(0.1), f32(0.3)), alpha).astype(f32)
+    a = _alpha_final(a)
+    smooth = a < f32(1e-3)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        # smooth: the mirror direction, f = F / |cos|, pdf 1, a specular sample
+        wi_s = np.stack([-wo[..., 0], -wo[..., 1], wo[..., 2]], -1).astype(f32)
+        ci_s = np.abs(wi_s[..., 2])
+        f_s = (fr_complex(ci_s[:, None], eta, k) / ci_s[:, None]).astype(f32)
+        # rough: a visible normal, the reflection about it
+        wm = tr_sample_wm(wo, u0, u1, np.where(smooth, f32(1), a).astype(f32))
+        wi_r = (-wo + f32(2) * dot(wo, wm)[:, None] * wm).astype(f32)
+        ok_r = wo[..., 2] * wi_r[..., 2] > 0
+        pdf_r = (tr_pdf(wo, wm, a) / (f32(4) * np.abs(dot(wo, wm)))).astype(f32)
+        co, ci = np.abs(wo[..., 2]), np.abs(wi_r[..., 2])
+        ok_r &= ~((ci == 0) | (co == 0))
+        Fr = fr_complex(np.abs(dot(wo, wm))[:, None], eta, k)
+        D = tr_d(wm, a)
+        G = (f32(1) / (f32(1) + tr_lambda(wo, a) + tr_lambda(wi_r, a))).astype(f32)
+        f_r = (D[:, None] * Fr * G[:, None] / (f32(4) * ci * co)[:, None]).astype(f32)
+    wi = np.where(smooth[:, None], wi_s, wi_r).astype(f32)
+    f = np.where(smooth[:, None], f_s, f_r).astype(f32)
+    pdf = np.where(smooth, f32(1), pdf_r).astype(f32)
+    valid &= smooth | ok_r
+    return _to_world(wi, n, tg, bt), f, pdf, smooth, valid
+
+
 # ---------------------------------------------------------------------------------------------------- K1 - K13
 def apply_point(m, p):
     x = m[0, 0] * p[..., 0] + m[0, 1] * p[..., 1] + m[0, 2] * p[..., 2] + m[0, 3]
@@ -643,7 +858,8 @@ def coordinate_system(n):
     return t, cross(n, t)
 
 
-def render(desc, cam_rec, tables_dict, width, height, n_samples, max_depth, max_component_value=10.0, filter_radius=(0.5, 0.5), first=1, sobol_spp=None):
+def render(desc, cam_rec, tables_dict, width, height, n_samples, max_depth, max_component_value=10.0, filter_radius=(0.5, 0.5), first=1, sobol_spp=None,
+           regularize=True):
     """-> framebuffer [height, width, 3] (row py - 1, column px - 1), the weighted sums and the weights"""
     tb = Tables(tables_dict)
     sc = SceneNP(desc, tb)
@@ -673,6 +889,7 @@ def render(desc, cam_rec, tables_dict, width, height, n_samples, max_depth, max_
         L = np.zeros((N, 4), f32)
         alive = np.ones(N, bool)
         spec = np.zeros(N, bool)                                     # the last bounce was specular (no MIS for emission found after it)
+        anyns = np.zeros(N, bool)                                    # any_non_specular_bounces so far (surface-eval.jl:425, 503): roughens near-specular lobes
         for depth in range(max_depth):
             if not alive.any():
                 break
@@ -824,6 +1041,12 @@ def render(desc, cam_rec, tables_dict, width, height, n_samples, max_depth, max_
             f = kd / PI
             bs_pdf = np.abs(ci) / PI
             f = np.where(bs_ok[:, None], f, f32(0)).astype(f32)
+            is_cond = kind == 3
+            if is_cond.any():                                                    # a Conductor: the rough lobe evaluates, the smooth one is zero (spectral-eval.jl:415-486)
+                eta_c, k_c = sc.conductor_ior(mat, lm)
+                f_c, pdf_c = conductor_eval(wo, wi, ns, sc.alpha[mat], eta_c, k_c)
+                f = np.where(is_cond[:, None], f_c, f).astype(f32)
+                bs_pdf = np.where(is_cond, pdf_c, bs_pdf).astype(f32)
             Ld = b * f * Li * np.abs(dot(wi, ns))[:, None]
             ok &= ~is_black(f) & ~is_black(Ld)
             off = f32(1e-4) * ns
@@ -853,7 +1076,7 @@ def render(desc, cam_rec, tables_dict, width, height, n_samples, max_depth, max_
             wi2 = normalize((tg * lw[:, 0:1] + bt * lw[:, 1:2] + ns * lw[:, 2:3]).astype(f32))
             f2 = kd * (f32(1) / PI)
             pdf2 = cos_th / PI
-            is_spec = kind != 0
+            is_spec = (kind == 1) | (kind == 2)
             if is_spec.any():
                 # Mirror (spectral-eval.jl:108-131) and Glass (:139-198): delta lobes, f = Kr or Kt, pdf = 1
                 n_or = np.where((wdn < 0)[:, None], -ns, ns)
@@ -882,6 +1105,16 @@ def render(desc, cam_rec, tables_dict, width, height, n_samples, max_depth, max_
                 f2 = np.where(is_spec[:, None], f_s, f2).astype(f32)
                 pdf2 = np.where(is_spec, f32(1), pdf2).astype(f32)
                 valid = np.where(kind == 1, m_valid, np.where(kind == 2, True, valid))
+            if is_cond.any():
+                # Conductor (spectral-eval.jl:223-318): a visible normal of the Trowbridge-Reitz distribution, regularised once the path has
+                # had a non-specular bounce; the effectively smooth one is a mirror with f = F / cos
+                reg = anyns[A] & bool(regularize)
+                wi_c, f_c, pdf_c, smooth_c, valid_c = conductor_sample(wo, ns, sc.alpha[mat], reg, eta_c, k_c, i_u0, i_u1)
+                wi2 = np.where(is_cond[:, None], wi_c, wi2).astype(f32)
+                f2 = np.where(is_cond[:, None], f_c, f2).astype(f32)
+                pdf2 = np.where(is_cond, pdf_c, pdf2).astype(f32)
+                is_spec = np.where(is_cond, smooth_c, is_spec)
+                valid = np.where(is_cond, valid_c, valid)
             valid &= (pdf2 > 0) & ~is_black(f2)
             with np.errstate(divide="ignore", invalid="ignore"):
                 nb = np.where(is_spec[:, None], b * f2, b * f2 * np.abs(dot(wi2, ns))[:, None] / pdf2[:, None]).astype(f32)
@@ -896,6 +1129,7 @@ def render(desc, cam_rec, tables_dict, width, height, n_samples, max_depth, max_
             V = A[valid]
             ro[V], rd[V], beta[V], r_l[V] = o2[valid], wi2[valid], nb[valid], nrl[valid]
             spec[V] = is_spec[valid]
+            anyns[V] |= ~is_spec[valid]
         # ---- K12 (volpath.jl:330-380): spectral -> XYZ -> linear sRGB, clamp, filter-weighted sums ----
         offs = np.round(lam).astype(np.int64) - 360
         inside = (offs >= 0) & (offs < 471)

@@ -556,33 +556,49 @@ def test_lane_pipeline_rebuilds_the_sample_bit_table_behind_the_lanes(hk, knobs)
         knobs.delenv(k)
 
 
-def test_small_calls_into_external_accumulators_are_stream_ordered(hk):
+_EXTERNAL_ACCUM_SCRIPT = r"""
+import sys
+import numpy as np
+import torch                                             # first: torch brings its own HIP runtime, which has to be the one the process initialises
+sys.path[:0] = [%r, %r]
+import hikari_jl_amd as hk
+from hikari_jl_amd import scenes
+w, h = 32, 32
+s, film, cam = scenes.cornell_box(w, h, light="area")
+accum = torch.zeros(4 * w * h, dtype=torch.float32, device="cuda")
+vp = hk.VolPath(max_depth=4, samples=4)
+vp.use_external_accumulators(accum.data_ptr())
+vp._ensure(film)
+vp.clear()
+vp.sync()
+for i in range(4):
+    vp.render_samples(s, film, cam, 1, first=i + 1, readback=False)
+torch.cuda.synchronize()                                 # no hk_* call in between: the caller's own ordering
+seen = accum.cpu().numpy().copy()
+assert seen[3 * w * h:].min() > 0, "a pixel is missing samples"
+assert np.array_equal(seen.view(np.uint32), vp.read_accumulators(film).view(np.uint32))
+vp.close()
+own = hk.VolPath(max_depth=4, samples=4)                 # the same calls into a library-owned film (batched): identical sums
+own._ensure(film)
+own.clear()
+for i in range(4):
+    own.render_samples(s, film, cam, 1, first=i + 1, readback=False)
+assert np.array_equal(seen.view(np.uint32), own.read_accumulators(film).view(np.uint32))
+own.close()
+print("external accumulators ok")
+"""
+
+
+def test_small_calls_into_external_accumulators_are_stream_ordered():
     """hk_render's ordering contract: a film with EXTERNAL accumulators (a torch tensor the host reduces) is never only noted — after
-    the call, work the caller orders behind the stream (torch.cuda.synchronize()) sees the samples without any hk_* call in between."""
-    import torch
-    from hikari_jl_amd import scenes
-    w, h = 32, 32
-    s, film, cam = scenes.cornell_box(w, h, light="area")
-    accum = torch.zeros(4 * w * h, dtype=torch.float32, device="cuda")
-    vp = hk.VolPath(max_depth=4, samples=4)
-    vp.use_external_accumulators(accum.data_ptr())
-    vp._ensure(film)
-    vp.clear()
-    vp.sync()
-    for i in range(4):
-        vp.render_samples(s, film, cam, 1, first=i + 1, readback=False)
-    torch.cuda.synchronize()
-    seen = accum.cpu().numpy().copy()
-    assert seen[3 * w * h:].min() > 0                    # every pixel has its four samples' filter weights
-    assert np.array_equal(seen.view(np.uint32), vp.read_accumulators(film).view(np.uint32))
-    vp.close()
-    own = hk.VolPath(max_depth=4, samples=4)             # the same calls into a library-owned film (batched): identical sums
-    own._ensure(film)
-    own.clear()
-    for i in range(4):
-        own.render_samples(s, film, cam, 1, first=i + 1, readback=False)
-    assert np.array_equal(seen.view(np.uint32), own.read_accumulators(film).view(np.uint32))
-    own.close()
+    the call, work the caller orders behind the stream (torch.cuda.synchronize()) sees the samples without any hk_* call in between.
+    (A process of its own: torch has to initialise the GPU before the library does, as in bench.py.)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", _EXTERNAL_ACCUM_SCRIPT % (root, os.path.join(root, "oracle"))], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "external accumulators ok" in out.stdout, out.stderr[-2000:]
 
 
 def test_context_options(hk, gpu_ctx, monkeypatch):

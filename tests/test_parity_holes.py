@@ -697,14 +697,17 @@ def test_zsobol_sample_bit_table(hk, oracle, knobs, first, n, stride, per_pass, 
 def test_light_preselection_is_result_neutral(hk, knobs):
     """Scenes with a deep light BVH choose the next-event light in a kernel of its own (k_light_select: per-lane descent with refill)
     before the shade kernels run.  Same arithmetic per vertex as the fused form: the film must be bit-identical with HK_PRESELECT=0,
-    at any refill threshold, with and without the table-only Sobol instantiations."""
+    through the pooled kernel (k_light_select_pool, the default since round 5) and the per-lane-refill one (HK_SELECT_POOL=0) at any
+    refill threshold, with static and ticketed segments, with and without the table-only Sobol instantiations."""
     from hikari_jl_amd import scenes
     w, h = 40, 36
     s, film, cam = scenes.many_light_scene(w, h, n_boxes=4000)      # ~2.4 k area lights: well above HK_PRESELECT_MIN
     kw = dict(max_depth=5, samples=64)
 
+    names = ("HK_PRESELECT", "HK_SELECT_MIN_IDLE", "HK_SOBOL_TABLE_ONLY", "HK_SELECT_POOL", "HK_DYNAMIC_SEGMENTS", "HK_WAVES_PER_CU", "HK_SMALL_PASS")
+
     def run(env):
-        for k in ("HK_PRESELECT", "HK_SELECT_MIN_IDLE", "HK_SOBOL_TABLE_ONLY"):
+        for k in names:
             knobs.delenv(k, raising=False)
         for k, v in env.items():
             knobs.setenv(k, v)
@@ -720,11 +723,14 @@ def test_light_preselection_is_result_neutral(hk, knobs):
 
     ref, nodes = run({"HK_PRESELECT": "0"})
     assert np.isfinite(ref).all() and ref.max() > 0 and nodes > 0
-    for env in ({}, {"HK_SELECT_MIN_IDLE": "1"}, {"HK_SELECT_MIN_IDLE": "64"}, {"HK_SOBOL_TABLE_ONLY": "0"}, {"HK_SOBOL_TABLE_ONLY": "0", "HK_PRESELECT": "0"}):
+    old = {"HK_SELECT_POOL": "0"}
+    for env in ({}, {"HK_SOBOL_TABLE_ONLY": "0"}, {"HK_DYNAMIC_SEGMENTS": "1"}, {"HK_DYNAMIC_SEGMENTS": "0", "HK_WAVES_PER_CU": "5"}, {"HK_DYNAMIC_SEGMENTS": "1", "HK_WAVES_PER_CU": "3"},
+                {"HK_SMALL_PASS": "0"}, old, {**old, "HK_SELECT_MIN_IDLE": "1"}, {**old, "HK_SELECT_MIN_IDLE": "64"}, {**old, "HK_SOBOL_TABLE_ONLY": "0"},
+                {"HK_SOBOL_TABLE_ONLY": "0", "HK_PRESELECT": "0"}):
         got, n2 = run(env)
         assert np.array_equal(ref.view(np.uint32), got.view(np.uint32)), env
         assert n2 == nodes, (env, n2, nodes)                            # the same node evaluations, wherever they run
-    for k in ("HK_PRESELECT", "HK_SELECT_MIN_IDLE", "HK_SOBOL_TABLE_ONLY"):
+    for k in names:
         knobs.delenv(k, raising=False)
 
 
@@ -750,11 +756,11 @@ def test_scheduling_is_result_neutral(hk, knobs, which):
     else:
         s, film, cam = scenes.slab_scene(w, h, hk.HomogeneousMedium(sigma_a=hk.RGBSpectrum(0.2), sigma_s=hk.RGBSpectrum(0.8, 0.7, 0.6), g=0.3))
         kw = dict(max_depth=6, samples=64)
-    knobs = ("HK_OVERLAP", "HK_DYNAMIC_SEGMENTS", "HK_WAVES_PER_CU", "HK_NODE_CACHE", "HK_WALK_SPLIT", "HK_GREY", "HK_DELTA_ADVANCE", "HK_TRACK_ADVANCE",
+    names = ("HK_OVERLAP", "HK_DYNAMIC_SEGMENTS", "HK_WAVES_PER_CU", "HK_NODE_CACHE", "HK_WALK_SPLIT", "HK_GREY", "HK_DELTA_ADVANCE", "HK_TRACK_ADVANCE",
              "HK_SHADOW_TRACK_BATCH", "HK_SHADOW_FEED_ROUNDS", "HK_TRACK_REFILL_IDLE", "HK_WALK_REFILL_IDLE", "HK_GREY_FLAT", "HK_TRACK_POOL", "HK_WALK_POOL", "HK_SMALL_PASS", "HK_SMALL_PASS_WAVES", "HK_TICKET_SHARE", "HK_GREY_COMPACT")
 
     def run(env):
-        for k in knobs:
+        for k in names:
             knobs.delenv(k, raising=False)
         for k, v in env.items():
             knobs.setenv(k, v)
@@ -799,7 +805,7 @@ def test_scheduling_is_result_neutral(hk, knobs, which):
         # differ by the roundings of x * (T / T[1]) that the GREY code does not perform
         got = run({"HK_GREY": "0"})
         assert np.allclose(ref, got, rtol=2e-5, atol=1e-7), float(np.abs(ref - got).max())
-    for k in knobs:
+    for k in names:
         knobs.delenv(k, raising=False)
     # leave the context's sticky knobs at their defaults for the tests that follow
     knobs.setenv("HK_OVERLAP", "1")

@@ -2253,12 +2253,12 @@ __global__ void __launch_bounds__(256) k_light_select(DPathState st, DScene sc, 
 //     the kernel above still shared the top of the tree: the first pooled version issued 20 % fewer VALU instructions at 84 % lane
 //     utilisation (67 %) and was SLOWER, waiting 51 % of its wave-cycles for memory (16 %).  So the top NTOP entries of the tree — the
 //     first 9 levels in the pair order, half of an average descent — live in the block's LDS (one array per 16-byte part of a node, as
-//     in NodeCache), in 8-wave blocks so that three of them fit a CU beside their pools.
+//     in NodeCache).
 #ifndef HK_SELECT_NTOP
 #define HK_SELECT_NTOP 512
 #endif
 #ifndef HK_SELECT_BLOCK
-#define HK_SELECT_BLOCK 512
+#define HK_SELECT_BLOCK 256
 #endif
 template <int NTOP>
 HKD DLightNode lds_light_node(const lds_float4* top, int i) {
@@ -2272,8 +2272,9 @@ HKD DLightNode lds_light_node(const lds_float4* top, int i) {
     return n;
 }
 #ifndef HK_SELECT_WAVES
-#define HK_SELECT_WAVES 6   // three 8-wave blocks per CU: 80 VGPRs
-#endif
+#define HK_SELECT_WAVES 4   // 40 KB of LDS per 4-wave block: four blocks per CU.  Measured (many-light frame, shade class, interleaved on one box):
+#endif                      // per-lane refill 0.680 s; pool without the top cache 0.759; 256 / 512 / 4 waves 0.613; 512 / 512 / 6 waves (80 VGPRs, spills) 0.650;
+                            // 512 / 512 / 4 waves 0.617; one 1024-thread block with the top 1024 entries 0.610
 template <bool FT, int BLOCK = HK_SELECT_BLOCK, int NTOP = HK_SELECT_NTOP>
 __global__ void __attribute__((amdgpu_flat_work_group_size(BLOCK, BLOCK), amdgpu_waves_per_eu(HK_SELECT_WAVES))) k_light_select_pool(DPathState st, DScene sc, DTables T, DFrame fr, DSobol sob, int depth, uint32_t kinds_mask, DStats* stats) {
     __shared__ uint32_t lds_pool[BLOCK / 64][8][64];   // [wave of the block][field][entry] (bit patterns): lane i reads entry head + rank(i) — consecutive words, no bank conflict

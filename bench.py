@@ -179,7 +179,17 @@ def build_workload(config, scenes):
 VALU_CYCLES_THIS_MIX = 4.2     # profiles/r02_valu_rate.txt (tools/valu_rate.hip): compares, selects, integer ops, conversions cost 4.2 - 4.4 cycles
                                # per wave64 instruction on a busy SIMD (v_fma / v_mul / v_mov 2.3 - 2.9): the price of the traversal kernels' mix
 N_SIMD = 1024                  # 256 CUs x 4 SIMDs
-KERNEL_OF_CLASS = {"trace": "k_trace", "shadow": "k_shadow", "shade": "k_shade", "media": "k_track+k_scatter"}
+KERNEL_OF_CLASS = {"trace": "k_trace", "shadow": "k_shadow", "shade": "k_shade", "media": "k_track+k_scatter", "select": "k_light_select"}
+CLASSES = ("trace", "shadow", "shade", "media", "select")
+
+
+def class_times(st):
+    """hk_stats -> seconds and launches per kernel class.  `select` — the next-event light of every vertex chosen by a kernel of its own in
+    scenes with a deep light BVH — is part of K9 and of hk_stats.seconds_shade; here it is a class of its own and `shade` is the rest."""
+    sel = float(st.seconds_select)
+    timed = dict(trace=st.seconds_trace, shadow=st.seconds_shadow, shade=max(st.seconds_shade - sel, 0.0), media=st.seconds_media, select=sel, other=st.seconds_other)
+    launches = dict(trace=int(st.trace_launches), shadow=int(st.shadow_launches), shade=int(st.shade_launches), media=int(st.media_launches), select=int(st.select_launches))
+    return timed, launches
 
 
 def class_rooflines(config, timed, launches, sc, default_frame):
@@ -188,7 +198,10 @@ def class_rooflines(config, timed, launches, sc, default_frame):
     L2 hit rate, VALU / SALU instruction counts, lane utilisation.  Shading and media classes are priced against HBM; the BVH
     traversal classes of surface scenes against instruction issue (their nodes come from LDS / L1 / L2: a byte ceiling says nothing)."""
     alg = dict(trace=int(sc.bytes_algorithmic_trace), shadow=int(sc.bytes_algorithmic_shadow), shade=int(sc.bytes_algorithmic_shade),
-               media=int(sc.bytes_algorithmic_media))
+               media=int(sc.bytes_algorithmic_media), select=0)
+    if timed.get("select", 0) > 0:      # SURVEY 8(d) charges 60 B per light-BVH node visited: those visits happen in the selection kernel
+        alg["select"] = min(60 * int(sc.light_bvh_nodes), alg["shade"])
+        alg["shade"] -= alg["select"]
 
     def committed(stem):
         rel = os.path.join("profiles", "%s_%s.json" % (stem, config))
@@ -200,10 +213,10 @@ def class_rooflines(config, timed, launches, sc, default_frame):
     (pmc, pmc_file), (util, util_file) = committed("pmc_traffic"), committed("utilisation")
     walk = int(sc.shadow_collisions) > 0
     rooflines = []
-    for cls in ("trace", "shadow", "shade", "media"):
-        n_launch = max(launches[cls], 1)
-        avg_s = timed[cls] / n_launch
-        if timed[cls] <= 0:
+    for cls in CLASSES:
+        n_launch = max(launches.get(cls, 0), 1)
+        avg_s = timed.get(cls, 0.0) / n_launch
+        if timed.get(cls, 0.0) <= 0:
             continue
         kernel = KERNEL_OF_CLASS[cls]
         names = ["k_track", "k_scatter"] if cls == "media" else [kernel]
@@ -220,7 +233,9 @@ def class_rooflines(config, timed, launches, sc, default_frame):
         if u.get("valu_inst_per_launch") and u.get("valu_issue_frac") and u.get("avg_launch_us"):
             clock_hz = u["valu_inst_per_launch"] * 2.0 / (u["valu_issue_frac"] * N_SIMD) / (u["avg_launch_us"] * 1e-6)
             issue = u["valu_inst_per_launch"] * VALU_CYCLES_THIS_MIX / (avg_s * clock_hz * N_SIMD)
-        traversal = cls in ("trace", "shadow") and not (cls == "shadow" and walk)
+        # the light selection walks a tree whose nodes come from LDS / L2 like the traversal kernels' (the 60 B per node of SURVEY 8d are an
+        # upper bound of its HBM need): priced against instruction issue, as they are
+        traversal = cls == "select" or (cls in ("trace", "shadow") and not (cls == "shadow" and walk))
         if traversal and issue is None:
             # no committed counter pass for this workload: the ceiling that binds a traversal kernel cannot be priced from this run alone
             e.update({"bound": "valu_issue", "achieved": None, "peak": 1.0, "unit": "share of the SIMDs' VALU issue slots", "frac": None,
@@ -304,7 +319,7 @@ def compact_line(result, limit=LINE_LIMIT, detail_file="bench_detail.json"):
     r = result.get("roofline") or {}
     line["roofline"] = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
     line["roofline"].update(_pick(r, ("kernel", "avg_launch_ms", "launches", "algorithmic_bytes_per_launch", "hbm_frac_by_traffic",
-                                      "traffic_over_algorithmic", "lane_util", "measured_copy_gbs", "kernel_seconds")))
+                                      "traffic_over_algorithmic", "traffic_frac_of_measured_copy", "lane_util", "measured_copy_gbs", "kernel_seconds")))
     cpu = result.get("cpu_baseline")
     line["cpu_baseline"] = None if cpu is None else dict(_pick(cpu, ("value", "unit", "cores", "kind", "seconds_per_frame_extrapolated")),
                                                            sample=_clip(cpu.get("sample", ""), 110))
@@ -445,10 +460,9 @@ def one_frame_line(hk, scenes, torch, config, device):
     vp.reset_stats()
     frame()
     tk = vp.stats()
-    timed = dict(trace=tk.seconds_trace, shadow=tk.seconds_shadow, shade=tk.seconds_shade, media=tk.seconds_media, other=tk.seconds_other)
-    launches = dict(trace=int(tk.trace_launches), shadow=int(tk.shadow_launches), shade=int(tk.shade_launches), media=int(tk.media_launches))
+    timed, launches = class_times(tk)
     rooflines = class_rooflines(config, timed, launches, sc, True)      # (no committed counter passes for the two-spheres variant: in-run fields only)
-    dom = max((k for k in ("trace", "shadow", "shade", "media") if timed[k] > 0), key=lambda k: timed[k])
+    dom = max((k for k in CLASSES if timed[k] > 0), key=lambda k: timed[k])
     line = {"config": config, "workload": "%s, %d spp per frame" % (workload, spp), "resolution": [W, H], "max_depth": depth, "spp_per_frame": spp,
             "triangles": int(scene.desc.n_triangles), "lights": int(scene.desc.n_lights), "frames_timed": 1, "free_hbm_gb_before": round(free_b / 1e9, 1),
             "warmup_frames": 2, "seconds_per_frame": round(seconds, 4), "value": round(rays / seconds / 1e6, 2), "unit": "Mrays/s",
@@ -703,8 +717,7 @@ def main():
         run_frames(args.steps, reduce=False)
         vp.sync()
         st = vp.stats()
-        timed = dict(trace=st.seconds_trace, shadow=st.seconds_shadow, shade=st.seconds_shade, media=st.seconds_media, other=st.seconds_other)
-        launches = dict(trace=int(st.trace_launches), shadow=int(st.shadow_launches), shade=int(st.shade_launches), media=int(st.media_launches))
+        timed, launches = class_times(st)
         # ---- counts from an instrumented (untimed) replay of the same frames ----
         vp.enable_counters(count_nodes=True, time_kernels=False)
         vp.reset_stats()
@@ -719,7 +732,7 @@ def main():
         #      passes committed under profiles/ for the same workload (tools/profile_round.sh) ----
         default_frame = world == 1 and not args.spp and not args.spp_per_pass
         rooflines = class_rooflines(args.config, timed, launches, sc, default_frame)
-        dom = max((k for k in ("trace", "shadow", "shade", "media") if timed[k] > 0), key=lambda k: timed[k])
+        dom = max((k for k in CLASSES if timed[k] > 0), key=lambda k: timed[k])
         # measured HBM ceiling of this box beside the nominal peak: device-to-device copy, read + write bytes
         a = torch.empty(1 << 28, dtype=torch.float32, device="cuda")    # 1 GiB
         b = torch.empty_like(a)
@@ -734,7 +747,7 @@ def main():
         copy_gbs = 10 * 2 * a.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del a, b
         roofline = dict(next(e for e in rooflines if e["kernel"] == KERNEL_OF_CLASS[dom]))
-        roofline.update({"measured_copy_gbs": round(copy_gbs, 1), "frac_of_measured_copy": round(roofline["achieved"] / copy_gbs, 5) if roofline.get("bound") == "hbm" and roofline.get("achieved") else None,
+        roofline.update({"measured_copy_gbs": round(copy_gbs, 1), "traffic_frac_of_measured_copy": round(roofline["hbm_frac_by_traffic"] * HBM_PEAK_GBS / copy_gbs, 4) if roofline.get("hbm_frac_by_traffic") else None,   # (measured bytes over the measured ceiling: never above 1; `frac` prices SURVEY 8d's algorithmic bytes, which exceed what the compact records move)
                          "nodes_per_cast": round(int(sc.trace_nodes) / max(int(sc.rays_closest), 1), 2),
                          "tris_per_cast": round(int(sc.trace_tris) / max(int(sc.rays_closest), 1), 2),
                          "kernel_seconds": {k: round(v, 4) for k, v in timed.items()}})

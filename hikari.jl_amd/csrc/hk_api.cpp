@@ -238,8 +238,8 @@ struct hk_ctx {
     int count_nodes = 0, time_kernels = 0;
     // timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_events;   // class 0
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> class_events[5];  // 1 shadow, 2 shade, 3 other, 4 media
-    uint64_t shadow_launches = 0, shade_launches = 0, media_launches = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> class_events[6];  // 1 shadow, 2 shade, 3 other, 4 media, 5 light selection (reported inside the shade class AND on its own)
+    uint64_t shadow_launches = 0, shade_launches = 0, media_launches = 0, select_launches = 0;
     std::vector<hipEvent_t> event_pool;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool have_span = false;
@@ -2072,7 +2072,8 @@ static int render_tile_now(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_film* f
             // scenes with a deep light BVH: the next-event light of every shading vertex of this depth, chosen by a kernel of its own
             // (per-lane descent with refill) — part of the shade class
             if (sc->d.n_lights > 0 && hk::preselect_lights(sc->d, I->st)) {
-                if (timed(2, [&] { hk::launch_light_select(s, shade_blocks, I->st, sc->d, c->tables, fr, sob, depth, sc->kinds_mask, dstats); }) != HK_OK) return fail(HK_ERR_DEVICE, "event record failed");
+                if (timed(5, [&] { hk::launch_light_select(s, shade_blocks, I->st, sc->d, c->tables, fr, sob, depth, sc->kinds_mask, dstats); }) != HK_OK) return fail(HK_ERR_DEVICE, "event record failed");
+                c->select_launches++;
             }
             for (int kind = 0; kind < HK_MAX_KINDS; ++kind)
                 if (sc->kinds_mask & (1u << kind)) {
@@ -2167,7 +2168,7 @@ extern "C" int32_t hk_stats_reset(hk_ctx* c) {
         v.clear();
     }
     c->seconds_trace = c->seconds_total = 0.0;
-    c->trace_launches = c->shadow_launches = c->shade_launches = c->media_launches = 0;
+    c->trace_launches = c->shadow_launches = c->shade_launches = c->media_launches = c->select_launches = 0;
     c->have_span = false;
     return HK_OK;
 }
@@ -2248,16 +2249,18 @@ extern "C" int32_t hk_stats_get(hk_ctx* c, hk_stats* out) {
     out->shadow_launches = c->shadow_launches;
     out->shade_launches = c->shade_launches;
     out->media_launches = c->media_launches;
-    double cls[5] = {0, 0, 0, 0, 0};
-    for (int k = 1; k < 5; ++k)
+    double cls[6] = {0, 0, 0, 0, 0, 0};
+    for (int k = 1; k < 6; ++k)
         for (auto& e : c->class_events[k]) {
             float ms = 0.0f;
             if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) cls[k] += ms * 1e-3;
         }
     out->seconds_shadow = cls[1];
-    out->seconds_shade = cls[2];
+    out->seconds_shade = cls[2] + cls[5];   // (the light selection of a deep light BVH is part of K9: inside the shade class, and on its own below)
     out->seconds_other = cls[3];
     out->seconds_media = cls[4];
+    out->seconds_select = cls[5];
+    out->select_launches = c->select_launches;
     {   // SURVEY 8(d) algorithmic bytes over the counted units
         const uint64_t hits_closest = h.hits < h.rays_closest ? h.hits : h.rays_closest;   // shading attributes are fetched once per accepted closest hit
         out->bytes_algorithmic_trace = h.rays_closest * (32 + 16) + 64 * h.nodes + 36 * h.tris + 96 * hits_closest;

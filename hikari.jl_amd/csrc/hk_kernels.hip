@@ -688,12 +688,29 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace(DPathState st, DScene 
 #ifndef HK_LEAF_BREAK_A
 #define HK_LEAF_BREAK_A 2
 #endif
+// POSTPONED LEAVES (round 5; Aila & Laine's "speculative traversal").  A lane that reaches a leaf while its stack still holds nodes does
+// not wait for the wave's next leaf phase: it keeps the leaf in `pend` and goes on descending from the popped node; only a lane that
+// reaches a SECOND leaf (or has nothing left to descend) waits.  Node steps and leaf phases both run fuller; the price is one leaf's
+// worth of stale t_best (a few more nodes visited).  The hit does not depend on the order in which leaves are tested (closest hit:
+// minimum of (t, prim); any hit: whether one exists), so films are bit-identical (test_lean_traversal_parity, ab_bitwise.py).
+// MEASURED AND SWITCHED OFF (interleaved on one box, films bit-identical): the stale t_best costs more node visits than the fuller phases
+// return — Cornell trace +1.5 %, shadow +5 %; 10^6 triangles trace +7 %, shadow +4 %; sky trace +10 %.
+#ifndef HK_POSTPONE_CLOSEST
+#define HK_POSTPONE_CLOSEST 0
+#endif
+#ifndef HK_POSTPONE_ANYHIT
+#define HK_POSTPONE_ANYHIT 0
+#endif
+#ifndef HK_NODE_UNROLL
+#define HK_NODE_UNROLL 3   // node steps per evaluation of the node loop's exit rule (ballots, popcounts, the branch): 1 / 2 / 3 steps — Cornell trace 32.8 / 32.0 / 31.6 ms,
+#endif                     // 10^6 triangles 0.531 / 0.518 / 0.517 s (interleaved on one box, films bit-identical); lanes that reach a leaf sit out the rest of the group
 struct LaneRay {   // per-lane traversal state
     v3 o, d;
     RaySlab rs;
     float t_max;
     HitRec best;
     int cur, sp;
+    int pend;   // a postponed leaf reference, or DONE (0x80000000) for none; cur == DONE implies pend == DONE
 };
 HKD void lane_ray_start(LaneRay& r, const DScene& sc, v3 o, v3 d, float t_max) {
     r.o = o;
@@ -705,10 +722,11 @@ HKD void lane_ray_start(LaneRay& r, const DScene& sc, v3 o, v3 d, float t_max) {
     r.rs = ray_slab(o, d);
     r.sp = 0;
     r.cur = sc.n_tris == 0 ? (int)0x80000000 : sc.root_ref;
+    r.pend = (int)0x80000000;
 }
 // one while-while round for the lanes with `active`: inner nodes until every such lane holds a leaf (or is done), then the leaves.
 // ANYHIT: the first accepted triangle ends the ray (cur = DONE, best.prim >= 0).
-template <bool ANYHIT, bool COUNT, int NC = 0>
+template <bool ANYHIT, bool COUNT, int NC = 0, bool POSTPONE = (ANYHIT ? HK_POSTPONE_ANYHIT != 0 : HK_POSTPONE_CLOSEST != 0)>
 HKD void lane_ray_round(LaneRay& r, bool active, const DScene& sc, int* __restrict__ stack, int lane, unsigned& n_nodes, unsigned& n_tris, const NodeCache& cache = NodeCache(),
                         bool may_wait = false
 #ifdef HK_DEBUG_UTIL
@@ -738,9 +756,25 @@ HKD void lane_ray_round(LaneRay& r, bool active, const DScene& sc, int* __restri
 #ifdef HK_DEBUG_UTIL
         if (dbg_) HK_DBG(0, active && r.cur >= 0);          // node steps: lanes that descend
 #endif
+#pragma unroll
+        for (int rep = 1; rep < HK_NODE_UNROLL; ++rep)
+            if (active && r.cur >= 0) {
+                if (COUNT) ++n_nodes;
+                node_step<NC>(sc, r.rs, r.best.t, stack, lane, r.cur, r.sp, cache);
+            }
         if (active && r.cur >= 0) {
             if (COUNT) ++n_nodes;
             node_step<NC>(sc, r.rs, r.best.t, stack, lane, r.cur, r.sp, cache);
+            if (POSTPONE) {
+                if (r.cur == DONE) {   // nothing left to descend: the postponed leaf (if any) is what is left of this ray
+                    r.cur = r.pend;
+                    r.pend = DONE;
+                } else if (r.cur < 0 && r.pend == DONE && r.sp > 0) {   // a first leaf, and more to descend: postpone it
+                    r.pend = r.cur;
+                    --r.sp;
+                    r.cur = stack[r.sp * 64 + lane];
+                }
+            }
         }
     }
     // The leaf phase is the expensive half of a round (up to four triangles), and it used to run for however few lanes held a leaf: in the
@@ -751,12 +785,15 @@ HKD void lane_ray_round(LaneRay& r, bool active, const DScene& sc, int* __restri
     // than hold leaves: with fewer than LEAF_MIN <= 20 leaf holders at least 24 lanes are idle, so the refill is certain to happen.)
     constexpr int LEAF_MIN = ANYHIT ? (NC > 0 ? HK_ANYHIT_LEAF_MIN : 0) : HK_CLOSEST_LEAF_MIN;   // the deep-tree instantiations (NC == 0: 10^6 triangles) lose 1 % by waiting
     static_assert(LEAF_MIN == 0 || 64 - 2 * LEAF_MIN >= HK_TRACE_MIN_IDLE, "waiting leaf holders must leave enough idle lanes for the caller's refill to trigger");
+    // (with postponed leaves the wait only looks at the lanes that are STUCK with a leaf in `cur`: the descending ones take their
+    // postponed leaf along)
     if (LEAF_MIN > 0 && may_wait && __builtin_popcountll(act_m & __builtin_amdgcn_ballot_w64((unsigned)r.cur > 0x80000000u)) < LEAF_MIN) return;
+    const bool has_pend = POSTPONE && r.pend != DONE;
 #ifdef HK_DEBUG_UTIL
-    if (dbg_) HK_DBG(1, active && r.cur < 0 && r.cur != DONE);   // leaf phase: lanes that hold a leaf
+    if (dbg_) HK_DBG(1, active && (has_pend || (r.cur < 0 && r.cur != DONE)));   // leaf phase: lanes that hold a leaf
 #endif
-    if (active && r.cur < 0 && r.cur != DONE) {
-        int ref = ~r.cur;
+    if (active && (has_pend || (r.cur < 0 && r.cur != DONE))) {
+        int ref = ~(has_pend ? r.pend : r.cur);
         int first = ref >> 3, count = (ref & 7) + 1;
         bool stop = false;
         if (!ANYHIT) {
@@ -804,8 +841,11 @@ HKD void lane_ray_round(LaneRay& r, bool active, const DScene& sc, int* __restri
                 }
             }
         }
-        if (stop)
+        if (stop) {
             r.cur = DONE;
+            if (POSTPONE) r.pend = DONE;
+        } else if (has_pend)
+            r.pend = DONE;   // (cur — a node to descend, or a second leaf for the next phase — stays)
         else if (r.sp > 0) {
             --r.sp;
             r.cur = stack[r.sp * 64 + lane];
@@ -842,7 +882,7 @@ __global__ void __launch_bounds__(BLOCK) k_trace_lean(DPathState st, DScene sc, 
     int state = LR_EMPTY;
     uint32_t slot = 0;
     LaneRay r;
-    r.cur = DONE;
+    r.cur = r.pend = DONE;
     for (;;) {
         const unsigned long long run_m = __ballot(state == LR_ACTIVE && r.cur != DONE);
         if (run_m == 0ull || (64 - __popcll(run_m) >= HK_TRACE_MIN_IDLE && cursor < n)) {
@@ -2847,7 +2887,7 @@ __global__ void __launch_bounds__(BLOCK) k_shadow(DPathState st, DScene sc, int 
     bool have = false;
     uint32_t slot = 0;
     LaneRay r;
-    r.cur = DONE;
+    r.cur = r.pend = DONE;
     for (;;) {
         const unsigned long long run_m = __ballot(have && r.cur != DONE);
         if (run_m == 0ull || (64 - __popcll(run_m) >= HK_TRACE_MIN_IDLE && (cursor < n || more))) {
@@ -4442,7 +4482,7 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_test_trace_lean(DScene sc, i
     bool have = false;
     int idx = 0;
     LaneRay r;
-    r.cur = DONE;
+    r.cur = r.pend = DONE;
     for (;;) {
         const unsigned long long run_m = __ballot(have && r.cur != DONE);
         if (run_m == 0ull || (64 - __popcll(run_m) >= HK_TRACE_MIN_IDLE && cursor < count)) {

@@ -307,6 +307,10 @@ typedef struct hk_stats {
     /* collisions x 84|36 + 4 x DDA steps of K4, + (2 x 104 state + 96 light record) per scattering vertex of K5 + K6;
        bytes_algorithmic_shadow likewise includes the shadow walk's collisions and DDA steps */
     uint64_t bytes_algorithmic_media;
+    /* the part of seconds_shade spent choosing the next-event light in a kernel of its own (scenes with a deep light BVH: k_light_select*),
+       and its launches (not part of shade_launches) */
+    double seconds_select;
+    uint64_t select_launches;
 } hk_stats;
 
 typedef struct hk_ctx hk_ctx;

@@ -822,6 +822,239 @@ def conductor_sample(wo_w, n, alpha, regularize, eta, k, u0, u1):
     return _to_world(wi, n, tg, bt), f, pdf, smooth, valid
 
 
+# ---------------------------------------------------------------------------------------------------- a homogeneous medium (K4 - K6, K10, K14)
+# Scalar code, one path at a time: the random streams of the trackers are seeded by HASHES OF FLOAT BIT PATTERNS (delta-tracking.jl:28-45,
+# intersection.jl:455), so every intermediate that reaches a ray origin or direction has to be the correctly rounded binary32 value — log,
+# exp, sin and cos go through float64 and are rounded once (glibc's and Julia's float32 functions are correctly rounded in all but a few
+# arguments per million).
+def _f(x):
+    return f32(x)
+
+
+def _log32(x):
+    return f32(np.log(np.float64(x)))
+
+
+def _exp32(x):
+    return f32(np.exp(np.float64(x)))
+
+
+def _bits(x):
+    return int(np.asarray(x, f32).view(np.uint32))
+
+
+M64I = (1 << 64) - 1
+
+
+def _mix_bits_int(v):
+    v ^= v >> 31
+    v = (v * 0x7FB5D329728EA185) & M64I
+    v ^= v >> 27
+    v = (v * 0x81DADEF4BC2DD44D) & M64I
+    v ^= v >> 33
+    return v
+
+
+def lcg_init(o, d, t_max):
+    """delta-tracking.jl:28-45"""
+    ox, oy, oz, tm = _bits(o[0]), _bits(o[1]), _bits(o[2]), _bits(t_max)
+    dx, dy, dz = _bits(d[0]), _bits(d[1]), _bits(d[2])
+    s1 = _mix_bits_int((ox ^ (oy << 16) ^ (oz << 32) ^ tm) & M64I)
+    s2 = _mix_bits_int((dx ^ (dy << 16) ^ (dz << 32)) & M64I)
+    return s1 ^ s2
+
+
+def lcg_next(state):
+    """delta-tracking.jl:53-58: the upper 32 bits as a float32 times 2^-32, at most 1 - eps"""
+    state = (state * 0x5DEECE66D + 11) & M64I
+    r = f32(np.float32(state >> 32) * f32(2.3283064365386963e-10))
+    return state, min(r, f32(1) - f32(np.finfo(f32).eps))          # ONE_MINUS_EPSILON = 1 - eps(Float32) = 1 - 2^-23 (sampler/stratified.jl:72)
+
+
+def pbrt_hash3(v):
+    return murmur64a(struct.pack("<3f", float(v[0]), float(v[1]), float(v[2])), 0)
+
+
+class PCG32:
+    """pcg32_init(seq, seed) / pcg32_uniform_f32 (spectral-eval.jl:745-813)"""
+    MULT = 0x5851F42D4C957F2D
+
+    def __init__(self, seq, seed):
+        self.inc = ((seq << 1) | 1) & M64I
+        self.state = 0
+        self.u32()
+        self.state = (self.state + seed) & M64I
+        self.u32()
+
+    def u32(self):
+        old = self.state
+        self.state = (old * self.MULT + self.inc) & M64I
+        xs = (((old >> 18) ^ old) >> 27) & 0xFFFFFFFF
+        rot = old >> 59
+        return ((xs >> rot) | (xs << ((-rot) & 31))) & 0xFFFFFFFF
+
+    def f32(self):
+        return min(f32(np.float32(self.u32()) * f32(2.3283064365386963e-10)), f32(1) - f32(np.finfo(f32).eps))
+
+
+def hg_p(g, ct):
+    """media.jl:36-40"""
+    g, ct = f32(g), f32(ct)
+    g2 = g * g
+    den = f32(1) + g2 - f32(2) * g * ct
+    return f32((f32(1) - g2) / (f32(4) * PI * den * np.sqrt(den)))
+
+
+def sample_hg(g, wo, u0, u1):
+    """media.jl:51-72 -> wi, pdf"""
+    g = f32(g)
+    if abs(g) < f32(1e-3):
+        ct = f32(1) - f32(2) * u0
+    else:
+        g2 = g * g
+        sq = (f32(1) - g2) / (f32(1) - g + f32(2) * g * u0)
+        ct = f32(np.clip((f32(1) + g2 - sq * sq) / (f32(2) * g), f32(-1), f32(1)))
+    st = f32(np.sqrt(max(f32(0), f32(1) - ct * ct)))
+    phi = f32(f32(2) * PI * u1)
+    t1, t2 = coordinate_system(F(-wo)[None])
+    t1, t2 = t1[0], t2[0]
+    cphi, sphi = f32(np.cos(np.float64(phi))), f32(np.sin(np.float64(phi)))
+    wi = (st * cphi * t1 + st * sphi * t2 + ct * F(-wo)).astype(f32)
+    wi = normalize(wi[None])[0]
+    return wi, hg_p(g, ct)
+
+
+class MediumNP:
+    """HomogeneousMedium (media.jl:762-830): sigma_a, sigma_s, Le uplifted UNBOUNDED per wavelength (uplift.jl:286-308: the polynomial of
+    rgb / max, times max / max_value(polynomial)), majorant = sigma_a + sigma_s along the whole ray"""
+
+    def __init__(self, rec, tables):
+        assert rec.kind == 0, "homogeneous media only"
+        self.g = f32(rec.g)
+        self.rgb = {k: [f32(getattr(rec, k)[i]) for i in range(3)] for k in ("sigma_a", "sigma_s", "Le")}
+        self.tb = tables
+        self.poly = {}
+        for k, rgb in self.rgb.items():
+            m = max(rgb)
+            if m <= 0:
+                self.poly[k] = None
+                continue
+            c = tables.rgb_to_poly([f32(v / m) for v in rgb])
+            c = F(c)
+
+            def at(lam, c=c):
+                return f32(sigmoid(f32(c[0] * f32(lam) * f32(lam) + c[1] * f32(lam) + c[2])))
+            mv = max(at(f32(360)), at(f32(830)))
+            if c[0] != 0:
+                lc = f32(-c[1] / (f32(2) * c[0]))
+                if f32(360) <= lc <= f32(830):
+                    mv = max(mv, at(lc))
+            self.poly[k] = (c, f32(m / mv))
+
+    def spectrum(self, k, lam):
+        if self.poly[k] is None:
+            return np.zeros(4, f32)
+        c, scale = self.poly[k]
+        return (scale * eval_poly(c[None], F(lam)[None])[0]).astype(f32)
+
+
+def track_medium(md, o, d, t_max, lam, beta, r_u, r_l, depth, max_depth):
+    """sample_medium_interaction! for a HomogeneousMedium (delta-tracking.jl:154-240, 304-453): ONE majorant segment [0, t_max].
+    -> (kind, beta, r_u, r_l, p, Le_add): kind 'absorb' | 'scatter' | 'dropped' (scatter at the depth limit) | 'survive'"""
+    sa, ss, Le = md.spectrum("sigma_a", lam), md.spectrum("sigma_s", lam), md.spectrum("Le", lam)
+    smaj = (sa + ss).astype(f32)
+    s0 = smaj[0]
+    add = np.zeros(4, f32)
+    if not (f32(0) < t_max) or s0 < f32(1e-10):       # (iterator mode 0: no segment; an empty medium passes the ray on)
+        return "survive", beta, r_u, r_l, None, add
+    rng = lcg_init(o, d, t_max)
+    t = f32(0)
+    ray_o = (F(o) + F(d) * t).astype(f32)
+    for _ in range(1024):
+        rng, u = lcg_next(rng)
+        dt = f32(-_log32(max(f32(1e-10), f32(1) - u)) / s0)
+        ts = f32(t + dt)
+        if ts >= t_max:
+            Tm = np.array([_exp32(-(f32(t_max - t)) * x) for x in smaj], f32)
+            if Tm[0] > f32(1e-10):
+                beta = (beta * Tm / Tm[0]).astype(f32)
+                r_u = (r_u * Tm / Tm[0]).astype(f32)
+                r_l = (r_l * Tm / Tm[0]).astype(f32)
+            return "survive", beta, r_u, r_l, None, add
+        Tm = np.array([_exp32(-dt * x) for x in smaj], f32)
+        p = (ray_o + F(d) * dt).astype(f32)
+        if not is_black(Le[None])[0] and depth < max_depth:
+            pr = f32(s0 * Tm[0])
+            if pr > f32(1e-10):
+                r_e = (r_u * smaj * Tm / pr).astype(f32)
+                if not is_black(r_e[None])[0]:
+                    add = (add + beta * sa * Tm * Le / (pr * average(r_e[None])[0])).astype(f32)
+        p_a, p_s = f32(sa[0] / s0), f32(ss[0] / s0)
+        rng, ue = lcg_next(rng)
+        if ue < p_a:
+            return "absorb", np.zeros(4, f32), r_u, r_l, None, add
+        if ue < f32(p_a + p_s):
+            if depth >= max_depth:
+                return "dropped", beta, r_u, r_l, None, add
+            pdf = f32(Tm[0] * ss[0])
+            if pdf > f32(1e-10):
+                beta = (beta * Tm * ss / pdf).astype(f32)
+                r_u = (r_u * Tm * ss / pdf).astype(f32)
+            return "scatter", beta, r_u, r_l, p, add
+        sn = np.maximum(smaj - sa - ss, f32(0)).astype(f32)
+        pdf = f32(Tm[0] * sn[0])
+        if not pdf > f32(1e-10):
+            return "absorb", np.zeros(4, f32), r_u, r_l, None, add
+        beta = (beta * Tm * sn / pdf).astype(f32)
+        r_u = (r_u * Tm * sn / pdf).astype(f32)
+        r_l = (r_l * Tm * smaj / pdf).astype(f32)
+        t, ray_o = ts, p
+        if is_black(beta[None])[0] or is_black(r_u[None])[0]:
+            return "absorb", beta, r_u, r_l, None, add
+    return "survive", beta, r_u, r_l, None, add
+
+
+def ratio_tracking(md, o, d, t_max, lam):
+    """_ratio_tracking_dda for a HomogeneousMedium (intersection.jl:446-542): PCG32 seeded by the hashes of origin and direction"""
+    one = np.ones(4, f32)
+    T, ru, rl = one.copy(), one.copy(), one.copy()
+    sa, ss = md.spectrum("sigma_a", lam), md.spectrum("sigma_s", lam)
+    smaj = (sa + ss).astype(f32)
+    s0 = smaj[0]
+    if not (f32(0) < t_max) or s0 < f32(1e-10):
+        return T, ru, rl
+    rng = PCG32(pbrt_hash3(o), pbrt_hash3(d))
+    t = f32(0)
+    for _ in range(100):
+        u = rng.f32()
+        dt = f32(-_log32(max(f32(1e-10), f32(1) - u)) / s0)
+        ts = f32(t + dt)
+        if ts >= t_max:
+            Tm = np.array([_exp32(-(f32(t_max - t)) * x) for x in smaj], f32)
+            if Tm[0] > f32(1e-10):
+                T, rl, ru = (T * Tm / Tm[0]).astype(f32), (rl * Tm / Tm[0]).astype(f32), (ru * Tm / Tm[0]).astype(f32)
+            break
+        sn = np.maximum(smaj - sa - ss, f32(0)).astype(f32)
+        Tm = np.array([_exp32(-dt * x) for x in smaj], f32)
+        pr = f32(Tm[0] * s0)
+        if pr > f32(1e-10):
+            T = (T * Tm * sn / pr).astype(f32)
+            rl = (rl * Tm * smaj / pr).astype(f32)
+            ru = (ru * Tm * sn / pr).astype(f32)
+        else:
+            return np.zeros(4, f32), ru, rl
+        with np.errstate(divide="ignore", invalid="ignore"):
+            est = T / max(f32(1e-10), average((rl + ru)[None])[0])
+        if est.max() < f32(0.05):
+            if rng.f32() < f32(0.75):
+                return np.zeros(4, f32), ru, rl
+            T = (T / (f32(1) - f32(0.75))).astype(f32)
+        if is_black(T[None])[0]:
+            return T, ru, rl
+        t = ts
+    return T, ru, rl
+
+
 # ---------------------------------------------------------------------------------------------------- K1 - K13
 def apply_point(m, p):
     x = m[0, 0] * p[..., 0] + m[0, 1] * p[..., 1] + m[0, 2] * p[..., 2] + m[0, 3]
@@ -856,6 +1089,79 @@ def coordinate_system(n):
         zero = np.zeros_like(ia)
         t = np.where(a[..., None], np.stack([n[..., 2] * ia, zero, -n[..., 0] * ia], -1), np.stack([zero, n[..., 2] * ib, -n[..., 1] * ib], -1)).astype(f32)
     return t, cross(n, t)
+
+
+def sample_light_np(sc, li, pi, lm, d_u0, d_u1):
+    """sample_light_spectral for the light indices li (0-based) at the points pi (lights.jl:39-125, 199-290): -> p_light, wi, Li, pdf (solid
+    angle; 1 for delta lights), valid, is_delta"""
+    lt = d_u0 < d_u1
+    b0 = np.where(lt, d_u0 / f32(2), d_u0 - d_u1 / f32(2)).astype(f32)
+    b1 = np.where(lt, d_u1 - d_u0 / f32(2), d_u1 / f32(2)).astype(f32)
+    b2 = f32(1) - b0 - b1
+    pl = (b0[:, None] * sc.lv[li, 0] + b1[:, None] * sc.lv[li, 1] + b2[:, None] * sc.lv[li, 2]).astype(f32)
+    to_l = pl - pi
+    dsq = dot(to_l, to_l)
+    dist = np.sqrt(dsq)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        wi = (to_l / dist[:, None]).astype(f32)
+        cos_l = np.abs(dot(sc.ln[li], -wi))
+        lpdf_sa = dsq / (cos_l * sc.larea[li])
+    Li = eval_poly(sc.le_poly[li], lm)
+    Li = np.where(((~sc.ltwo[li]) & (dot(-wi, sc.ln[li]) < 0))[:, None], f32(0), Li).astype(f32)
+    area_ok = (dsq >= f32(1e-12)) & (cos_l >= f32(1e-6)) & ~is_black(Li) & (lpdf_sa > 0)
+    # a point light (lights.jl:39-58): wi towards it, Li = scale * I(lambda) / r^2, pdf 1, a delta light
+    is_pt = (sc.lkind[li] == 0) | (sc.lkind[li] == 1)
+    if is_pt.any():
+        to_p = sc.lpos[li] - pi
+        dsq_p = dot(to_p, to_p)
+        dist_p = np.sqrt(dsq_p)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            wi_p = (to_p / dist_p[:, None]).astype(f32)
+            Li_p = ((sc.lscale[li][:, None] * eval_illuminant(sc.li_scale2[li], sc.li_poly[li], lm)).astype(f32) / dsq_p[:, None]).astype(f32)
+        # a spot light (lights.jl:66-100): -wi in the light's frame, nothing outside the cone, a smooth fourth-power edge
+        is_spot = sc.lkind[li] == 1
+        m = sc.lw2l[li]
+        mw = -wi_p
+        wl = normalize(np.stack([m[:, 0, 0] * mw[:, 0] + m[:, 0, 1] * mw[:, 1] + m[:, 0, 2] * mw[:, 2],
+                                 m[:, 1, 0] * mw[:, 0] + m[:, 1, 1] * mw[:, 1] + m[:, 1, 2] * mw[:, 2],
+                                 m[:, 2, 0] * mw[:, 0] + m[:, 2, 1] * mw[:, 1] + m[:, 2, 2] * mw[:, 2]], -1).astype(f32))
+        ct = wl[:, 2]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            delta = ((ct - sc.lcos_tot[li]) / (sc.lcos_fall[li] - sc.lcos_tot[li])).astype(f32)
+            fall = np.where(ct >= sc.lcos_fall[li], f32(1), delta * delta * delta * delta).astype(f32)
+            Li_s = (((sc.lscale[li][:, None] * eval_illuminant(sc.li_scale2[li], sc.li_poly[li], lm)).astype(f32) * fall[:, None]).astype(f32) / dsq_p[:, None]).astype(f32)
+        Li_p = np.where(is_spot[:, None], Li_s, Li_p).astype(f32)
+        pt_ok = ~(dist_p < f32(1e-6)) & ~is_black(Li_p) & ~(is_spot & (ct < sc.lcos_tot[li]))
+        pl = np.where(is_pt[:, None], sc.lpos[li], pl).astype(f32)
+        wi = np.where(is_pt[:, None], wi_p, wi).astype(f32)
+        Li = np.where(is_pt[:, None], Li_p, Li).astype(f32)
+        lpdf_sa = np.where(is_pt, f32(1), lpdf_sa).astype(f32)
+        area_ok = np.where(is_pt, pt_ok, area_ok)
+    # a directional light (lights.jl:108-125): wi against its direction, p_light 10^6 away, Li = scale * I(lambda), pdf 1, a delta light
+    is_dir = sc.lkind[li] == 2
+    if is_dir.any():
+        wi_d = (-sc.ldir[li]).astype(f32)
+        Li_d = (sc.lscale[li][:, None] * eval_illuminant(sc.li_scale2[li], sc.li_poly[li], lm)).astype(f32)
+        pl = np.where(is_dir[:, None], (pi + f32(1.0e6) * wi_d).astype(f32), pl).astype(f32)
+        wi = np.where(is_dir[:, None], wi_d, wi).astype(f32)
+        Li = np.where(is_dir[:, None], Li_d, Li).astype(f32)
+        lpdf_sa = np.where(is_dir, f32(1), lpdf_sa).astype(f32)
+        area_ok = np.where(is_dir, ~is_black(Li_d), area_ok)
+        is_pt = is_pt | is_dir                                                  # (delta lights, for the MIS weight below)
+    # an ambient light (lights.jl:199-221): a uniform direction of the sphere, pdf 1 / 4 pi, NOT a delta light
+    is_amb = sc.lkind[li] == 4
+    if is_amb.any():
+        z = f32(1) - f32(2) * d_u0
+        r = np.sqrt(np.maximum(f32(0), f32(1) - z * z))
+        phi = f32(2) * PI * d_u1
+        wi_a = np.stack([r * np.cos(phi).astype(f32), r * np.sin(phi).astype(f32), z], -1).astype(f32)
+        Li_a = (sc.lscale[li][:, None] * eval_illuminant(sc.li_scale2[li], sc.li_poly[li], lm)).astype(f32)
+        pl = np.where(is_amb[:, None], (pi + f32(1.0e6) * wi_a).astype(f32), pl).astype(f32)
+        wi = np.where(is_amb[:, None], wi_a, wi).astype(f32)
+        Li = np.where(is_amb[:, None], Li_a, Li).astype(f32)
+        lpdf_sa = np.where(is_amb, f32(1) / (f32(4) * PI), lpdf_sa).astype(f32)
+        area_ok = np.where(is_amb, ~is_black(Li_a), area_ok)
+    return pl, wi, Li, lpdf_sa, area_ok, is_pt
 
 
 def render(desc, cam_rec, tables_dict, width, height, n_samples, max_depth, max_component_value=10.0, filter_radius=(0.5, 0.5), first=1, sobol_spp=None,
@@ -968,73 +1274,7 @@ def render(desc, cam_rec, tables_dict, width, height, n_samples, max_depth, max_
             lidx, lpmf = sc.bvh.sample(pi, ns, d_uc)
             ok = (lidx >= 1) & (lpmf > 0)
             li = np.maximum(lidx - 1, 0)
-            lt = d_u0 < d_u1
-            b0 = np.where(lt, d_u0 / f32(2), d_u0 - d_u1 / f32(2)).astype(f32)
-            b1 = np.where(lt, d_u1 - d_u0 / f32(2), d_u1 / f32(2)).astype(f32)
-            b2 = f32(1) - b0 - b1
-            pl = (b0[:, None] * sc.lv[li, 0] + b1[:, None] * sc.lv[li, 1] + b2[:, None] * sc.lv[li, 2]).astype(f32)
-            to_l = pl - pi
-            dsq = dot(to_l, to_l)
-            dist = np.sqrt(dsq)
-            with np.errstate(divide="ignore", invalid="ignore"):
-                wi = (to_l / dist[:, None]).astype(f32)
-                cos_l = np.abs(dot(sc.ln[li], -wi))
-                lpdf_sa = dsq / (cos_l * sc.larea[li])
-            Li = eval_poly(sc.le_poly[li], lm)
-            Li = np.where(((~sc.ltwo[li]) & (dot(-wi, sc.ln[li]) < 0))[:, None], f32(0), Li).astype(f32)
-            area_ok = (dsq >= f32(1e-12)) & (cos_l >= f32(1e-6)) & ~is_black(Li) & (lpdf_sa > 0)
-            # a point light (lights.jl:39-58): wi towards it, Li = scale * I(lambda) / r^2, pdf 1, a delta light
-            is_pt = (sc.lkind[li] == 0) | (sc.lkind[li] == 1)
-            if is_pt.any():
-                to_p = sc.lpos[li] - pi
-                dsq_p = dot(to_p, to_p)
-                dist_p = np.sqrt(dsq_p)
-                with np.errstate(divide="ignore", invalid="ignore"):
-                    wi_p = (to_p / dist_p[:, None]).astype(f32)
-                    Li_p = ((sc.lscale[li][:, None] * eval_illuminant(sc.li_scale2[li], sc.li_poly[li], lm)).astype(f32) / dsq_p[:, None]).astype(f32)
-                # a spot light (lights.jl:66-100): -wi in the light's frame, nothing outside the cone, a smooth fourth-power edge
-                is_spot = sc.lkind[li] == 1
-                m = sc.lw2l[li]
-                mw = -wi_p
-                wl = normalize(np.stack([m[:, 0, 0] * mw[:, 0] + m[:, 0, 1] * mw[:, 1] + m[:, 0, 2] * mw[:, 2],
-                                         m[:, 1, 0] * mw[:, 0] + m[:, 1, 1] * mw[:, 1] + m[:, 1, 2] * mw[:, 2],
-                                         m[:, 2, 0] * mw[:, 0] + m[:, 2, 1] * mw[:, 1] + m[:, 2, 2] * mw[:, 2]], -1).astype(f32))
-                ct = wl[:, 2]
-                with np.errstate(divide="ignore", invalid="ignore"):
-                    delta = ((ct - sc.lcos_tot[li]) / (sc.lcos_fall[li] - sc.lcos_tot[li])).astype(f32)
-                    fall = np.where(ct >= sc.lcos_fall[li], f32(1), delta * delta * delta * delta).astype(f32)
-                    Li_s = (((sc.lscale[li][:, None] * eval_illuminant(sc.li_scale2[li], sc.li_poly[li], lm)).astype(f32) * fall[:, None]).astype(f32) / dsq_p[:, None]).astype(f32)
-                Li_p = np.where(is_spot[:, None], Li_s, Li_p).astype(f32)
-                pt_ok = ~(dist_p < f32(1e-6)) & ~is_black(Li_p) & ~(is_spot & (ct < sc.lcos_tot[li]))
-                pl = np.where(is_pt[:, None], sc.lpos[li], pl).astype(f32)
-                wi = np.where(is_pt[:, None], wi_p, wi).astype(f32)
-                Li = np.where(is_pt[:, None], Li_p, Li).astype(f32)
-                lpdf_sa = np.where(is_pt, f32(1), lpdf_sa).astype(f32)
-                area_ok = np.where(is_pt, pt_ok, area_ok)
-            # a directional light (lights.jl:108-125): wi against its direction, p_light 10^6 away, Li = scale * I(lambda), pdf 1, a delta light
-            is_dir = sc.lkind[li] == 2
-            if is_dir.any():
-                wi_d = (-sc.ldir[li]).astype(f32)
-                Li_d = (sc.lscale[li][:, None] * eval_illuminant(sc.li_scale2[li], sc.li_poly[li], lm)).astype(f32)
-                pl = np.where(is_dir[:, None], (pi + f32(1.0e6) * wi_d).astype(f32), pl).astype(f32)
-                wi = np.where(is_dir[:, None], wi_d, wi).astype(f32)
-                Li = np.where(is_dir[:, None], Li_d, Li).astype(f32)
-                lpdf_sa = np.where(is_dir, f32(1), lpdf_sa).astype(f32)
-                area_ok = np.where(is_dir, ~is_black(Li_d), area_ok)
-                is_pt = is_pt | is_dir                                                  # (delta lights, for the MIS weight below)
-            # an ambient light (lights.jl:199-221): a uniform direction of the sphere, pdf 1 / 4 pi, NOT a delta light
-            is_amb = sc.lkind[li] == 4
-            if is_amb.any():
-                z = f32(1) - f32(2) * d_u0
-                r = np.sqrt(np.maximum(f32(0), f32(1) - z * z))
-                phi = f32(2) * PI * d_u1
-                wi_a = np.stack([r * np.cos(phi).astype(f32), r * np.sin(phi).astype(f32), z], -1).astype(f32)
-                Li_a = (sc.lscale[li][:, None] * eval_illuminant(sc.li_scale2[li], sc.li_poly[li], lm)).astype(f32)
-                pl = np.where(is_amb[:, None], (pi + f32(1.0e6) * wi_a).astype(f32), pl).astype(f32)
-                wi = np.where(is_amb[:, None], wi_a, wi).astype(f32)
-                Li = np.where(is_amb[:, None], Li_a, Li).astype(f32)
-                lpdf_sa = np.where(is_amb, f32(1) / (f32(4) * PI), lpdf_sa).astype(f32)
-                area_ok = np.where(is_amb, ~is_black(Li_a), area_ok)
+            pl, wi, Li, lpdf_sa, area_ok, is_pt = sample_light_np(sc, li, pi, lm, d_u0, d_u1)
             ok &= area_ok
             ci, co = dot(wi, ns), dot(wo, ns)
             bs_ok = ~(ci * co < 0) & ~(np.abs(ci) < f32(1e-6)) & (kind == 0)     # (Mirror / Glass evaluate to zero: spectral-eval.jl:399-413)

@@ -313,7 +313,7 @@ def compact_line(result, limit=LINE_LIMIT, detail_file="bench_detail.json"):
     if "parallelism" in cfg:
         cfg["parallelism"] = _clip(cfg["parallelism"], 90)
     line["config"] = cfg
-    for k in ("seconds_per_frame", "seconds_to_256spp", "cold_frame_seconds"):
+    for k in ("seconds_per_frame", "seconds_to_256spp", "cold_frame_seconds", "rays"):
         if k in result:
             line[k] = result[k]
     r = result.get("roofline") or {}
@@ -341,7 +341,8 @@ def compact_line(result, limit=LINE_LIMIT, detail_file="bench_detail.json"):
                                                             "ms_per_sample_of_the_full_frame", "vs_frame_sample", "vs_frame_sample_with_readback", "error"))
     line["detail"] = detail_file
     # whatever a future field adds, the line never outgrows the driver: shed the least important parts first
-    shed = [lambda: [c.pop("kernel_seconds", None) for c in line.get("configs", [])],
+    shed = [lambda: line.pop("rays", None),
+            lambda: [c.pop("kernel_seconds", None) for c in line.get("configs", [])],
             lambda: [c.pop("progressive", None) for c in line.get("configs", [])],
             lambda: line["roofline"].pop("kernel_seconds", None),
             lambda: [c.pop("workload", None) for c in line.get("configs", [])],

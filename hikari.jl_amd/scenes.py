@@ -98,15 +98,22 @@ def integration_test_scene(width=64, height=64, with_fog=True):
     return s, film, cam
 
 
-def slab_scene(width=32, height=32, medium=None, thickness=1.0):
+def slab_scene(width=32, height=32, medium=None, thickness=1.0, inner_emitter=False):
     """Closed-form check scene: the camera looks through a slab of `medium` (index-matched
-    interface: GlassMaterial(Kr=0, Kt=1, index=1)) at a large two-sided emitter; pixel ~ Le * exp(-sigma_t * d)."""
+    interface: GlassMaterial(Kr=0, Kt=1, index=1)) at a large two-sided emitter; pixel ~ Le * exp(-sigma_t * d).
+    inner_emitter: a two-sided emitter INSIDE the medium (the same medium on both of its sides) — the one place where a ray
+    scattered by the phase function meets emission without a specular vertex in between, i.e. where r_l = r_u / phase_pdf is used."""
     s = Scene()
     emitter = G.quad((-4, -4, 3), (4, -4, 3), (4, 4, 3), (-4, 4, 3), normal=(0, 0, -1))
     s.push(emitter, MediumInterface(MatteMaterial(Kd=RGBSpectrum(0.0)), emission=Emissive(Le=RGBSpectrum(0.5), scale=1.0, two_sided=True)))
     if medium is not None:
         iface = MediumInterface(GlassMaterial(Kr=RGBSpectrum(0.0), Kt=RGBSpectrum(1.0), index=1.0), inside=medium, outside=None)
         s.push(G.rect3f((-2.5, -2.6, 1.0), (5.0, 5.2, thickness)), iface)
+        if inner_emitter:
+            z = 1.0 + 0.55 * thickness
+            inner = G.quad((-1.3, -1.1, z), (1.1, -1.1, z), (1.1, 1.2, z), (-1.3, 1.2, z), normal=(0, 0, -1))
+            s.push(inner, MediumInterface(MatteMaterial(Kd=RGBSpectrum(0.0)), inside=medium, outside=medium,
+                                          emission=Emissive(Le=RGBSpectrum(1.0, 0.8, 0.6), scale=1.0, two_sided=True)))
     s.sync()
     film = Film((width, height))
     cam = PerspectiveCamera((0, 0, -2), (0, 0, 1), film, fov=20.0)

@@ -1370,6 +1370,77 @@ int32_t hko_mix_resolve(hko_scene* s, int32_t mat_idx, int32_t n, const float* p
 
 // Point-wise media: mode 0 = sample_point -> out[13] = sigma_a4, sigma_s4, Le4, g (through the NanoVDB TREE WALK, nanovdb.jl:315-388);
 // mode 1 = create_majorant_iterator + ray_majorant_next -> out[49] = segment count (<= 256), (t_min, t_max, sigma_maj[1]) of the first 16
+// K4 + K5 + K6 of n caller-supplied rays through the oracle's OWN stage code (process_media_stage above, nothing restated): ray i is
+// pixel i + 1 of an n-pixel state whose Sobol draws (direct_uc, direct_u, indirect_u) the caller supplies.  in[i] = o3, d3, t_max (inf: the
+// ray meets no surface), lambda4, beta4, r_u4, r_l4 (23 floats); out[i] (56 floats) = fate (0 ended, 1 reached its surface, 2 escaped),
+// beta4, r_u4, r_l4 of a survivor, L4 added to the pixel by medium emission; continuation ray: valid, o3, d3, beta4, r_u4, r_l4; shadow
+// ray: valid, o3, d3, t_max, Ld4, r_u4, r_l4.  Test entry: the per-ray pins of tests/test_control_flow_pin.py.
+int32_t hko_media_stage(hko_scene* s, int32_t medium_idx, int32_t depth, int32_t max_depth, int32_t n, const float* in23, const float* direct_uc, const float* direct_u2,
+                        const float* indirect_u2, float* out56) {
+    Scene& sc = s->sc;
+    if (medium_idx < 0 || medium_idx >= sc.desc.n_media) return -1;
+    RenderState st;
+    st.width = n, st.height = 1;
+    st.pixel_L.assign(4 * (size_t)n, 0.0f);
+    st.s_direct_uc.assign(direct_uc, direct_uc + n);
+    st.s_direct_u.resize(n);
+    st.s_indirect_u.resize(n);
+    for (int i = 0; i < n; ++i) st.s_direct_u[i] = V2(direct_u2[2 * i], direct_u2[2 * i + 1]), st.s_indirect_u[i] = V2(indirect_u2[2 * i], indirect_u2[2 * i + 1]);
+    RawVec<RayItem> rays;
+    std::vector<uint8_t> kind(n, 3);
+    std::vector<MediumSampleItem> ms(n);
+    RawBuf<HitItem> hits(n);
+    RawBuf<EscapedItem> escaped(n);
+    RawVec<RayItem> next_rays;
+    RawVec<ShadowItem> shadows;
+    for (int i = 0; i < n; ++i) {
+        const float* r = in23 + 23 * (size_t)i;
+        MediumSampleItem& m = ms[i];
+        m.o = V3(r[0], r[1], r[2]), m.d = V3(r[3], r[4], r[5]);
+        m.time = 0.0f, m.t_max = r[6];
+        m.depth = depth;
+        for (int k = 0; k < 4; ++k) m.lambda.lambda[k] = r[7 + k], m.lambda.pdf[k] = 1.0f;
+        m.pixel_index = i + 1;
+        m.beta = Spec(r[11], r[12], r[13], r[14]), m.r_u = Spec(r[15], r[16], r[17], r[18]), m.r_l = Spec(r[19], r[20], r[21], r[22]);
+        m.eta_scale = 1.0f, m.specular_bounce = false, m.any_non_specular = false;
+        m.medium = medium_idx;
+        m.has_surface_hit = std::isfinite(r[6]);
+    }
+    hk_integrator_params ip{};
+    ip.max_depth = max_depth;
+#if defined(_OPENMP)
+    std::vector<Counters> cnts((size_t)omp_get_max_threads());
+#else
+    std::vector<Counters> cnts(1);
+#endif
+    process_media_stage(sc, st, rays, kind, ms, hits, escaped, next_rays, shadows, ip, cnts, depth);
+    for (size_t k = 0; k < 56 * (size_t)n; ++k) out56[k] = 0.0f;
+    for (int i = 0; i < n; ++i) {
+        float* o = out56 + 56 * (size_t)i;
+        o[0] = (float)kind[i];
+        const Spec *b = nullptr, *u = nullptr, *l = nullptr;
+        if (kind[i] == 1) b = &hits[i].beta, u = &hits[i].r_u, l = &hits[i].r_l;
+        if (kind[i] == 2) b = &escaped[i].beta, u = &escaped[i].r_u, l = &escaped[i].r_l;
+        if (b)
+            for (int k = 0; k < 4; ++k) o[1 + k] = (*b)[k], o[5 + k] = (*u)[k], o[9 + k] = (*l)[k];
+        for (int k = 0; k < 4; ++k) o[13 + k] = st.pixel_L[4 * (size_t)i + k];
+    }
+    for (size_t j = 0; j < next_rays.size(); ++j) {
+        const RayItem& r = next_rays[j];
+        float* o = out56 + 56 * (size_t)(r.pixel_index - 1) + 17;
+        o[0] = 1.0f;
+        o[1] = r.o.x, o[2] = r.o.y, o[3] = r.o.z, o[4] = r.d.x, o[5] = r.d.y, o[6] = r.d.z;
+        for (int k = 0; k < 4; ++k) o[7 + k] = r.beta[k], o[11 + k] = r.r_u[k], o[15 + k] = r.r_l[k];
+    }
+    for (size_t j = 0; j < shadows.size(); ++j) {
+        const ShadowItem& r = shadows[j];
+        float* o = out56 + 56 * (size_t)(r.pixel_index - 1) + 36;
+        o[0] = 1.0f;
+        o[1] = r.o.x, o[2] = r.o.y, o[3] = r.o.z, o[4] = r.d.x, o[5] = r.d.y, o[6] = r.d.z, o[7] = r.t_max;
+        for (int k = 0; k < 4; ++k) o[8 + k] = r.Ld[k], o[12 + k] = r.r_u[k], o[16 + k] = r.r_l[k];
+    }
+    return 0;
+}
 int32_t hko_medium(hko_scene* s, int32_t mode, int32_t medium_idx, int32_t n, const float* a3, const float* b3, const float* tmax, const float* lambda, float* out) {
     Scene& sc = s->sc;
 #pragma omp parallel for schedule(static)
@@ -1377,7 +1448,16 @@ int32_t hko_medium(hko_scene* s, int32_t mode, int32_t medium_idx, int32_t n, co
         Wavelengths w;
         for (int k = 0; k < 4; ++k) w.lambda[k] = lambda[4 * i + k], w.pdf[k] = 1.0f;
         V3 a(a3[3 * i], a3[3 * i + 1], a3[3 * i + 2]);
-        if (mode == 0) {
+        if (mode == 2) {
+            // the whole shadow walk of ONE ray (trace_shadow_transmittance above: intersection.jl:302-542) starting in medium `medium_idx`
+            // (-1: vacuum): -> T_ray[4], r_u[4], r_l[4], visible.  Test entry: the per-ray pin of tests/test_control_flow_pin.py.
+            Spec T, ru, rl;
+            Counters cnt{};
+            const bool vis = trace_shadow_transmittance(sc, a, V3(b3[3 * i], b3[3 * i + 1], b3[3 * i + 2]), tmax[i], w, medium_idx, T, ru, rl, cnt);
+            float* r = out + 13 * (size_t)i;
+            for (int k = 0; k < 4; ++k) r[k] = T[k], r[4 + k] = ru[k], r[8 + k] = rl[k];
+            r[12] = vis ? 1.0f : 0.0f;
+        } else if (mode == 0) {
             MediumProperties mp = sample_point(sc.media, medium_idx, a, w);
             float* r = out + 13 * (size_t)i;
             for (int k = 0; k < 4; ++k) r[k] = mp.sigma_a[k], r[4 + k] = mp.sigma_s[k], r[8 + k] = mp.Le[k];

@@ -200,14 +200,29 @@ class OracleScene:
 
     def medium(self, mode, medium_idx, a, lam, b=None, tmax=None):
         """mode 0: sample_point(medium, p = a, lambda) -> [n, 13] = sigma_a4, sigma_s4, Le4, g;
-        mode 1: majorant segments along (o = a, d = b, tmax) -> [n, 49] = count, (t_min, t_max, sigma_maj[1]) x 16"""
+        mode 1: majorant segments along (o = a, d = b, tmax) -> [n, 49] = count, (t_min, t_max, sigma_maj[1]) x 16;
+        mode 2: the shadow walk of the ray (o = a, d = b, tmax) that starts in medium `medium_idx` (-1: vacuum) -> [n, 13] = T_ray4, r_u4, r_l4, visible"""
         n = a.shape[0]
         a = np.ascontiguousarray(a, np.float32)
         lam = np.ascontiguousarray(lam, np.float32)
         b = np.ascontiguousarray(b if b is not None else np.zeros((n, 3)), np.float32)
         tmax = np.ascontiguousarray(tmax if tmax is not None else np.zeros(n), np.float32)
-        out = np.zeros((n, 13 if mode == 0 else 49), np.float32)
+        out = np.zeros((n, 49 if mode == 1 else 13), np.float32)
         lib().hko_medium(self.h, mode, medium_idx, n, _pf(a), _pf(b), _pf(tmax), _pf(lam), _pf(out))
+        return out
+
+    def media_stage(self, medium_idx, depth, max_depth, rays23, direct_uc, direct_u, indirect_u):
+        """K4 + K5 + K6 of caller-supplied rays through the oracle's own stage code -> [n, 56] (hko_media_stage in hko_render.cpp)"""
+        rays23 = np.ascontiguousarray(rays23, np.float32)
+        n = rays23.shape[0]
+        a = [np.ascontiguousarray(x, np.float32) for x in (direct_uc, direct_u, indirect_u)]
+        out = np.zeros((n, 56), np.float32)
+        L = lib()
+        L.hko_media_stage.restype = C.c_int32
+        PF = C.POINTER(C.c_float)
+        L.hko_media_stage.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, PF, PF, PF, PF, PF]
+        pf = lambda x: x.ctypes.data_as(PF)     # noqa: E731
+        assert L.hko_media_stage(self.h, medium_idx, depth, max_depth, n, pf(rays23), *[pf(x) for x in a], pf(out)) == 0
         return out
 
     def node_importance(self, node_idx, p, n):

@@ -21,6 +21,7 @@ import struct
 import numpy as np
 
 f32 = np.float32
+SABOTAGE = False
 PI = f32(np.pi)
 M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
 
@@ -547,6 +548,9 @@ class SceneNP:
 
     def _rest(self, desc, tables):
         self.mat_of_mi = np.array([desc.media_interfaces[i].material for i in range(desc.n_media_interfaces)], np.int64)
+        self.mi_inside = np.array([desc.media_interfaces[i].inside for i in range(desc.n_media_interfaces)], np.int64)      # -1: vacuum
+        self.mi_outside = np.array([desc.media_interfaces[i].outside for i in range(desc.n_media_interfaces)], np.int64)
+        self.media = [MediumNP(desc.media[i], tables) for i in range(desc.n_media)]
         self.lights = [desc.lights[i] for i in range(desc.n_lights)]
         assert all(l.kind in (0, 1, 2, 4, 6) for l in self.lights), "point, spot, directional, ambient and diffuse area lights only"
         self.lw2l = F([[l.world_to_light[k] for k in range(16)] for l in self.lights]).reshape(-1, 4, 4)
@@ -624,6 +628,29 @@ class SceneNP:
         ok = (np.abs(det) > 0) & (u >= 0) & (v >= 0) & (u + v <= 1) & (t > 0) & (t < tmax[:, None])
         t = np.where(ok, t, np.inf)
         prim = t.argmin(1)
+        idx = np.arange(t.shape[0])
+        hit = np.isfinite(t[idx, prim])
+        return hit, prim, t[idx, prim], u[idx, prim], v[idx, prim]
+
+    def intersect32(self, o, d, tmax):
+        """The same query in BINARY32, operation for operation as DESIGN.md section 3 defines the build's intersection arithmetic (Moeller-
+        Trumbore on (v0, e1, e2), no FMA: p = d x e2; det = e1 . p; inv = 1 / det; s = o - v0; u = (s . p) inv; q = s x e1; v = (d . q) inv;
+        t = (e2 . q) inv; accept 0 < t < t_max; ties to the smaller triangle index).  Where a later decision HASHES the bits of a hit point
+        (the trackers' seeds) the distance has to be this value, not the float64 one."""
+        v0, e1, e2 = self.P[:, 0][None], (self.P[:, 1] - self.P[:, 0])[None], (self.P[:, 2] - self.P[:, 0])[None]
+        o, d = F(o)[:, None, :], F(d)[:, None, :]
+        with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+            pv = cross(np.broadcast_to(d, (o.shape[0],) + e2.shape[1:]), np.broadcast_to(e2, (o.shape[0],) + e2.shape[1:])).astype(f32)
+            det = dot(np.broadcast_to(e1, pv.shape), pv).astype(f32)
+            inv = (f32(1) / det).astype(f32)
+            sv = (o - v0).astype(f32)
+            u = (dot(sv, pv) * inv).astype(f32)
+            qv = cross(sv, np.broadcast_to(e1, sv.shape)).astype(f32)
+            v = (dot(np.broadcast_to(d, qv.shape), qv) * inv).astype(f32)
+            t = (dot(np.broadcast_to(e2, qv.shape), qv) * inv).astype(f32)
+            ok = (det != 0) & (u >= 0) & ~(u > 1) & (v >= 0) & ~(u + v > 1) & (t > 0) & (t < F(tmax)[:, None])
+        t = np.where(ok, t, np.inf).astype(f32)
+        prim = t.argmin(1)                       # (argmin returns the FIRST minimum: the smaller triangle index on a tie)
         idx = np.arange(t.shape[0])
         hit = np.isfinite(t[idx, prim])
         return hit, prim, t[idx, prim], u[idx, prim], v[idx, prim]
@@ -1091,6 +1118,92 @@ def coordinate_system(n):
     return t, cross(n, t)
 
 
+def media_vertex(sc, medium, o, d, t_max, lam, beta, r_u, r_l, depth, max_depth, d_uc, d_u, i_u):
+    """K4 + K5 + K6 of ONE ray inside medium `medium` (delta-tracking.jl:154-453, medium-scatter.jl:15-198) with the bounce's Sobol draws
+    d_uc (light choice), d_u (light sample), i_u (phase sample) -> dict: kind ('survive' | 'absorb' | 'dropped' | 'scatter'), the path's
+    beta / r_u / r_l afterwards, `add` (medium emission for the pixel), `shadow` = (o, d, t_max, Ld, r_u, r_l) of the scattering vertex's
+    next-event estimation or None, `cont` = (o, d, r_l) of the continuation ray or None (beta and r_u stay: phase / pdf = 1)."""
+    md = sc.media[medium]
+    kind, b_, ru_, rl_, sp, add = track_medium(md, o, d, t_max, lam, beta, r_u, r_l, depth, max_depth)
+    out = {"kind": kind, "beta": b_, "r_u": ru_, "r_l": rl_, "add": add, "shadow": None, "cont": None}
+    if kind != "scatter":
+        return out
+    wo_m = (-F(d)).astype(f32)
+    # ---- K5 (medium-scatter.jl:15-118): one light through the tree WITHOUT a normal, the phase function as the BSDF ----
+    if len(sc.lights) >= 1:
+        lidx, lpmf = sc.bvh.sample(sp[None], np.zeros((1, 3), f32), F([d_uc]))
+        if lidx[0] >= 1 and lpmf[0] > 0:
+            pl, wi_l, Li_l, lpdf_sa, l_ok, l_delta = sample_light_np(sc, np.array([lidx[0] - 1]), sp[None], F(lam)[None], F([d_u[0]]), F([d_u[1]]))
+            if l_ok[0] and lpdf_sa[0] > 0 and not is_black(Li_l)[0]:
+                ph = hg_p(md.g, dot(wo_m[None], wi_l)[0])
+                if ph > 0:
+                    Ld = (b_ * ph * Li_l[0]).astype(f32)
+                    ru_s = (ru_ * (f32(0) if l_delta[0] else ph)).astype(f32)
+                    rl_s = (ru_ * f32(lpdf_sa[0] * lpmf[0])).astype(f32)
+                    tl = (pl[0] - sp).astype(f32)
+                    tmax_s = f32(np.sqrt(dot(tl[None], tl[None])[0]) - f32(0.001)) if l_delta[0] else f32(1.0e6)
+                    out["shadow"] = (sp, wi_l[0], tmax_s, Ld, ru_s, rl_s)
+    # ---- K6 (medium-scatter.jl:139-198): the next direction from the phase function; beta stays, r_l = r_u / pdf ----
+    if depth + 1 >= max_depth:
+        return out
+    wi_p, pdf_p = sample_hg(md.g, wo_m, f32(i_u[0]), f32(i_u[1]))
+    if pdf_p > 0:
+        out["cont"] = (sp, wi_p, (ru_ / pdf_p).astype(f32) if not SABOTAGE else ru_)
+    return out
+
+
+def camera_medium(sc, cam_pos):
+    """K14 (intersection.jl:690-735): a ray from the camera along (1, 1, 1) / sqrt 3; the first medium-transition surface it meets tells
+    which medium the camera is in; other surfaces are stepped over (<= 16); nothing met: vacuum"""
+    d = F([0.57735027, 0.57735027, 0.57735027])
+    o = F(cam_pos)
+    for _ in range(16):
+        hit, prim, t, _, _ = sc.intersect32(o[None], d[None], np.full(1, np.inf, f32))
+        if not hit[0]:
+            return -1
+        mi = sc.mi[prim[0]]
+        n = sc.ng[prim[0]]
+        if sc.mi_inside[mi] != sc.mi_outside[mi]:
+            return int(sc.mi_outside[mi] if dot((-d)[None], n[None])[0] > 0 else sc.mi_inside[mi])
+        pi = (o + d * f32(t[0])).astype(f32)
+        off = n if dot(d[None], n[None])[0] > 0 else -n
+        o = (pi + off * f32(1e-4)).astype(f32)
+    return -1
+
+
+def trace_shadow(sc, origin, direction, t_max, lam, medium):
+    """trace_shadow_transmittance (intersection.jl:303-406) for opaque surfaces (alpha 1) and homogeneous media: <= 10 closest-hit segments,
+    ratio tracking through the current medium up to every medium-transition surface -> T_ray, r_u, r_l, visible"""
+    one = np.ones(4, f32)
+    T, ru, rl = one.copy(), one.copy(), one.copy()
+    cur, ro, trem = int(medium), F(origin), f32(t_max)
+    d = F(direction)
+    for _ in range(10):
+        if trem < f32(1e-6):
+            break
+        hit, prim, t, _, _ = sc.intersect32(ro[None], d[None], np.array([trem], f32))
+        if not hit[0]:
+            if cur >= 0:
+                sT, sru, srl = ratio_tracking(sc.media[cur], ro, d, trem, lam)
+                T, ru, rl = (T * sT).astype(f32), (ru * sru).astype(f32), (rl * srl).astype(f32)
+            return T, ru, rl, True
+        th = f32(t[0])
+        mi = sc.mi[prim[0]]
+        n = sc.ng[prim[0]]
+        entering = dot(d[None], n[None])[0] < 0
+        if sc.mi_inside[mi] == sc.mi_outside[mi]:
+            return np.zeros(4, f32), one, one, False                 # an opaque surface (every material here has alpha 1)
+        if cur >= 0:
+            sT, sru, srl = ratio_tracking(sc.media[cur], ro, d, th, lam)
+            T, ru, rl = (T * sT).astype(f32), (ru * sru).astype(f32), (rl * srl).astype(f32)
+        if is_black(T[None])[0]:
+            return T, ru, rl, True
+        cur = int(sc.mi_inside[mi] if entering else sc.mi_outside[mi])
+        ro = (ro + d * f32(th + f32(1e-4))).astype(f32)
+        trem = f32(f32(trem - th) - f32(1e-4))
+    return np.zeros(4, f32), one, one, False
+
+
 def sample_light_np(sc, li, pi, lm, d_u0, d_u1):
     """sample_light_spectral for the light indices li (0-based) at the points pi (lights.jl:39-125, 199-290): -> p_light, wi, Li, pdf (solid
     angle; 1 for delta lights), valid, is_delta"""
@@ -1179,6 +1292,8 @@ def render(desc, cam_rec, tables_dict, width, height, n_samples, max_depth, max_
     py = (idx0 // width + 1).astype(np.int64)
     rgb_sum = np.zeros((N, 3), f32)
     w_sum = np.zeros(N, f32)
+    has_media = len(sc.media) > 0
+    cam_med = camera_medium(sc, apply_point(c2w, np.zeros((1, 3), f32))[0]) if has_media else -1
     for sidx in range(first, first + n_samples):
         # ---- K1 (volpath.jl:123-205): dims 1 (wavelength), 3 (jitter), 4 (time), 6 (lens) ----
         wl_u = zs.d1(px, py, sidx, 1)
@@ -1196,6 +1311,7 @@ def render(desc, cam_rec, tables_dict, width, height, n_samples, max_depth, max_
         alive = np.ones(N, bool)
         spec = np.zeros(N, bool)                                     # the last bounce was specular (no MIS for emission found after it)
         anyns = np.zeros(N, bool)                                    # any_non_specular_bounces so far (surface-eval.jl:425, 503): roughens near-specular lobes
+        med = np.full(N, cam_med, np.int64)                          # the medium the path's current ray travels in (-1: vacuum)
         for depth in range(max_depth):
             if not alive.any():
                 break
@@ -1209,11 +1325,36 @@ def render(desc, cam_rec, tables_dict, width, height, n_samples, max_depth, max_
             i_rr = zs.d1(apx, apy, sidx, base + 7)
             o, dd = ro[A], rd[A]
             hit, prim, t, bu, bv = sc.intersect(o, dd, np.full(len(A), np.inf))
+            esc, surf = ~hit, hit
+            pending = []                                             # shadow rays of this depth's SCATTERING vertices (traced with the surfaces' below)
+            if has_media and (med[A] >= 0).any():
+                # ---- K4 (delta-tracking.jl:154-453): a ray inside a medium is tracked up to the surface it would hit (one cast, no alpha
+                #      test: intersection.jl:198-221); absorbed, scattered (K5 + K6) or passed on to the surface / escape handling ----
+                scat, gone = np.zeros(len(A), bool), np.zeros(len(A), bool)
+                for j in np.nonzero(med[A] >= 0)[0]:
+                    a = A[j]
+                    tm = f32(t[j]) if hit[j] else f32(np.inf)
+                    v = media_vertex(sc, int(med[a]), o[j], dd[j], tm, lam[a], beta[a], r_u[a], r_l[a], depth, max_depth, d_uc[j], (d_u0[j], d_u1[j]), (i_u0[j], i_u1[j]))
+                    L[a] += v["add"]
+                    beta[a], r_u[a], r_l[a] = v["beta"], v["r_u"], v["r_l"]
+                    if v["shadow"] is not None:
+                        pending.append((a,) + v["shadow"] + (int(med[a]),))
+                    if v["kind"] == "survive":
+                        gone[j] = bool(is_black(v["beta"][None])[0] or is_black(v["r_u"][None])[0])
+                        continue
+                    scat[j] = v["kind"] == "scatter"
+                    if v["cont"] is None:
+                        gone[j] = True
+                        continue
+                    ro[a], rd[a], r_l[a] = v["cont"]
+                    spec[a], anyns[a] = False, True
+                alive[A[gone]] = False
+                esc, surf = ~hit & ~scat & ~gone, hit & ~scat & ~gone
             # ---- K7 (intersection.jl:622-668): an escaped ray collects the ambient lights; only an environment map has a pdf, so the MIS
             #      weight of this "light hit" is 1 / average(r_u) on every path ----
             amb = np.nonzero(sc.lkind == 4)[0]
-            if len(amb) and (~hit).any():
-                E = np.nonzero(~hit)[0]
+            if len(amb) and esc.any():
+                E = np.nonzero(esc)[0]
                 Le = np.zeros((len(E), 4), f32)
                 for k in amb:
                     kk = np.full(len(E), k)
@@ -1227,10 +1368,13 @@ def render(desc, cam_rec, tables_dict, width, height, n_samples, max_depth, max_
                     mis = np.where((den > f32(1e-10))[:, None], contrib / den[:, None], plain)
                 fin = plain if depth == 0 else np.where(spec[A[E]][:, None], plain, mis)
                 L[A[E]] += np.where(is_black(contrib)[:, None], f32(0), fin).astype(f32)
-            alive[A[~hit]] = False
+            alive[A[esc]] = False
+            hit = surf
             A, o, dd, prim, t, bu, bv = A[hit], o[hit], dd[hit], prim[hit], t[hit].astype(f32), bu[hit].astype(f32), bv[hit].astype(f32)
             d_uc, d_u0, d_u1, i_uc, i_u0, i_u1, i_rr = d_uc[hit], d_u0[hit], d_u1[hit], i_uc[hit], i_u0[hit], i_u1[hit], i_rr[hit]
             if len(A) == 0:
+                if has_media:
+                    continue        # (no surface hit at this depth: the reference traces no shadow rays either — volpath.jl:568-607 — the scattered paths go on)
                 break
             bw = f32(1) - bu - bv
             pi = (o + dd * t[:, None]).astype(f32)
@@ -1295,7 +1439,20 @@ def render(desc, cam_rec, tables_dict, width, height, n_samples, max_depth, max_
             tmax = np.sqrt(dot(tl, tl)) - f32(1e-3)
             ru_s = ru * np.where(is_pt, f32(0), bs_pdf)[:, None]                 # (a delta light: no BSDF sampling could have found it, lights.jl:583-589)
             rl_s = ru * lpdf_sa[:, None] * lpmf[:, None]
-            if ok.any():
+            if has_media:
+                # ---- K10 with media (intersection.jl:303-420, 564-600): every shadow ray of this depth — the scattering vertices' and the
+                #      surfaces' — walks through medium-transition surfaces with ratio tracking; Ld T / average(r_u T_u + r_l T_l) ----
+                for k in np.nonzero(ok)[0]:
+                    pending.append((A[k], so[k], wi[k], tmax[k], Ld[k], ru_s[k], rl_s[k], int(med[A[k]])))
+                for a, s_o, s_d, s_t, s_Ld, s_ru, s_rl, s_med in pending:
+                    T_ray, t_u, t_l, visible = trace_shadow(sc, s_o, s_d, s_t, lam[a], s_med)
+                    if visible and not is_black(T_ray[None])[0]:
+                        den = average((s_ru * t_u + s_rl * t_l)[None])[0]
+                        if den > f32(1e-10):
+                            fin = (s_Ld * T_ray / den).astype(f32)
+                            if not is_black(fin[None])[0]:
+                                L[a] += fin
+            elif ok.any():
                 K = np.nonzero(ok)[0]
                 vis = ~sc.occluded(so[K], wi[K], tmax[K].astype(np.float64)) & ~(tmax[K] < f32(1e-6))
                 den = average(ru_s[K] + rl_s[K])
@@ -1370,6 +1527,11 @@ def render(desc, cam_rec, tables_dict, width, height, n_samples, max_depth, max_
             ro[V], rd[V], beta[V], r_l[V] = o2[valid], wi2[valid], nb[valid], nrl[valid]
             spec[V] = is_spec[valid]
             anyns[V] |= ~is_spec[valid]
+            if has_media:            # the medium behind a medium-transition surface, by the side of the GEOMETRIC normal the new ray leaves on (surface-eval.jl:465-474)
+                mi_v = sc.mi[prim[valid]]
+                trans = sc.mi_inside[mi_v] != sc.mi_outside[mi_v]
+                out_side = dot(wi2[valid], n[valid]) > 0
+                med[V] = np.where(trans, np.where(out_side, sc.mi_outside[mi_v], sc.mi_inside[mi_v]), med[V])
         # ---- K12 (volpath.jl:330-380): spectral -> XYZ -> linear sRGB, clamp, filter-weighted sums ----
         offs = np.round(lam).astype(np.int64) - 360
         inside = (offs >= 0) & (offs < 471)

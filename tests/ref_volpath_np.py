@@ -1,4 +1,5 @@
-"""K1 - K13 of the VolPath integrator for OPAQUE MATTE, MIRROR and GLASS surfaces under DIFFUSE AREA, POINT, SPOT, DIRECTIONAL and AMBIENT LIGHTS (the Cornell box of BASELINE.json configs[1]),
+"""K1 - K14 of the VolPath integrator for OPAQUE MATTE, MIRROR, GLASS and CONDUCTOR (smooth and Trowbridge-Reitz) surfaces and a HOMOGENEOUS MEDIUM behind
+medium-transition surfaces (round 5: delta tracking, phase-function scattering, shadow rays with ratio tracking, the camera's medium) under DIFFUSE AREA, POINT, SPOT, DIRECTIONAL and AMBIENT LIGHTS (the Cornell box of BASELINE.json configs[1]),
 restated in float32 NumPy straight from the reference's Julia text — a second per-pixel source for the wavefront control flow
 (VERDICT r3 item 2b).  Nothing here is shared with oracle/ or the HIP library: no BVH (every ray is tested against every triangle, in
 float64), no work queues (arrays over all paths of one sample index with an `alive` mask), its own ZSobol, light BVH, uplift, film.
@@ -21,7 +22,7 @@ import struct
 import numpy as np
 
 f32 = np.float32
-SABOTAGE = False
+SABOTAGE = False      # (tests of the tests: True drops the division in r_l = r_u / phase_pdf — the per-ray pin must notice)
 PI = f32(np.pi)
 M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
 

@@ -112,7 +112,9 @@ def test_homogeneous_medium_against_the_numpy_restatement(hk, oracle, which):
     implementations that differ by one rounding anywhere upstream of a medium boundary draw different (equally valid) streams: a
     per-pixel comparison of single samples is impossible by construction.  What is compared is the CONVERGED estimate: 256 spp on an
     8 x 8 film in 8 batches each side, channel means within 1 % + 4 standard errors, per-pixel z-scores from the batch variances.
-    A wrong MIS weight (r_l after the phase sample, the light pdf of a scattering vertex, the T_maj ratios) biases exactly these means."""
+    This is the END-TO-END check of the restated control flow (which medium a ray is in, who traces which shadow ray, what a survivor
+    carries to its surface); it is blind to some weights — dropping the division in r_l = r_u / phase_pdf moves these means by 0.1 % —
+    which is what the two per-ray tests below are for."""
     from hikari_jl_amd import scenes
     w = h = 8
     if which == "scattering":

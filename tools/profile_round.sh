@@ -9,9 +9,9 @@ cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/$R; mkdir -p $O
 if [ "$MODE" != "quick" ]; then
   # the line the driver records (Cornell + one warm frame of every other config + the one-sample-per-call path), then one line per config
-  timeout 1200 python bench.py > $O/bench_${R}_default.json 2> $O/bench_default.err
+  timeout 1200 python bench.py --detail-file $O/bench_${R}_default_detail.json > $O/bench_${R}_default.json 2> $O/bench_default.err
   for c in $CFGS; do
-    timeout 900 python bench.py --config $c > $O/bench_${R}_$c.json 2> $O/bench_$c.err
+    timeout 900 python bench.py --config $c --detail-file $O/bench_${R}_${c}_detail.json > $O/bench_${R}_$c.json 2> $O/bench_$c.err
   done
 fi
 # the profiled runs keep every kernel on one stream (HK_OVERLAP=0): a kernel trace of overlapping kernels charges each of them the

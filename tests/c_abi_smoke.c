@@ -33,6 +33,11 @@ typedef int32_t (*hk_render_t)(hk_ctx*, hk_scene*, hk_integrator*, hk_film*, con
 typedef int32_t (*hk_film_read_rgb_t)(hk_ctx*, hk_film*, float*);
 typedef int32_t (*hk_film_read_accum_t)(hk_ctx*, hk_film*, void*);
 typedef int32_t (*hk_stats_get_t)(hk_ctx*, hk_stats*);
+typedef int32_t (*hk_ctx_set_option_t)(hk_ctx*, const char*, const char*);
+typedef int32_t (*hk_ctx_get_option_t)(hk_ctx*, const char*, char*, int32_t);
+typedef int32_t (*hk_flush_t)(hk_ctx*);
+typedef int32_t (*hk_film_read_rgb_async_t)(hk_ctx*, hk_film*);
+typedef int32_t (*hk_film_read_wait_t)(hk_ctx*, hk_film*, float*, const float**);
 
 static void* slurp(const char* dir, const char* name, size_t want_bytes) {
     char path[1024];
@@ -76,6 +81,7 @@ int main(int argc, char** argv) {
     LOAD(hk_ctx_create) LOAD(hk_ctx_destroy) LOAD(hk_last_error) LOAD(hk_ctx_set_tables) LOAD(hk_scene_create) LOAD(hk_scene_destroy)
     LOAD(hk_integrator_create) LOAD(hk_integrator_destroy) LOAD(hk_film_create) LOAD(hk_film_destroy) LOAD(hk_film_clear) LOAD(hk_render)
     LOAD(hk_film_read_rgb) LOAD(hk_film_read_accum) LOAD(hk_stats_get)
+    LOAD(hk_ctx_set_option) LOAD(hk_ctx_get_option) LOAD(hk_flush) LOAD(hk_film_read_rgb_async) LOAD(hk_film_read_wait)
 
     hk_ctx* ctx = NULL;
     if (hk_ctx_create_p(0, NULL, &ctx) != HK_OK) {
@@ -177,6 +183,30 @@ int main(int argc, char** argv) {
     printf("c_abi_smoke ok: %d x %d, %d spp, rays %llu + %llu\n", W, H, spp, (unsigned long long)st.rays_closest, (unsigned long long)st.rays_shadow);
     /* error behaviour: bad arguments are status codes with a message, never a crash */
     if (hk_render_p(ctx, scene, integ, film, &cam, 0, 1, 1) != HK_ERR_INVALID || !hk_last_error_p()[0]) return 1;
+    /* knobs live in the context (the environment is read once, by hk_ctx_create): set, read back, reset; unknown names are refused */
+    {
+        char buf[16];
+        if (hk_ctx_set_option_p(ctx, "HK_BATCH_PATHS_M", "0") != HK_OK || hk_ctx_get_option_p(ctx, "HK_BATCH_PATHS_M", buf, 16) != 1 || buf[0] != '0') return 1;
+        if (hk_ctx_set_option_p(ctx, "HK_BATCH_PATHS_M", NULL) != HK_OK || hk_ctx_get_option_p(ctx, "HK_BATCH_PATHS_M", buf, 16) != -1) return 1;
+        if (hk_ctx_set_option_p(ctx, "HK_NOT_A_KNOB", "1") != HK_ERR_INVALID) return 1;
+    }
+    /* the interactive loop of a viewer: one more sample per call, the frame of call i - 1 collected while call i renders; the last frame
+       through the pair equals a synchronous read of the same film */
+    {
+        const float* frame = NULL;
+        float* rgb2 = (float*)malloc((size_t)W * H * 3 * 4);
+        for (int i = 0; i < 3; ++i) {
+            if (hk_render_p(ctx, scene, integ, film, &cam, spp + 1 + i, 1, 1) != HK_OK || hk_flush_p(ctx) != HK_OK) return 1;
+            if (i > 0 && hk_film_read_wait_p(ctx, film, NULL, &frame) != HK_OK) return 1;
+            if (hk_film_read_rgb_async_p(ctx, film) != HK_OK) return 1;
+        }
+        if (hk_film_read_wait_p(ctx, film, NULL, &frame) != HK_OK || !frame) return 1;
+        if (hk_film_read_rgb_p(ctx, film, rgb2) != HK_OK || memcmp(frame, rgb2, (size_t)W * H * 3 * 4) != 0) {
+            fprintf(stderr, "asynchronous and synchronous frame differ\n");
+            return 1;
+        }
+        free(rgb2);
+    }
     hk_film_destroy_p(film);
     hk_integrator_destroy_p(integ);
     hk_scene_destroy_p(scene);

@@ -156,7 +156,16 @@ def test_integrator_film_and_render_arguments(hk, gpu_ctx):
     out = np.empty((24, 24, 3), np.float32)
     assert L.hk_film_read_rgb(gpu_ctx.h, f32film, None) == A.HK_ERR_INVALID
     assert L.hk_film_read_rgb(gpu_ctx.h, None, out.ctypes.data_as(A.PF)) == A.HK_ERR_INVALID
+    # the asynchronous pair: waiting without a read in flight is an error with a message; null handles are refused; a wait may ask for neither copy nor pointer
+    assert L.hk_film_read_wait(gpu_ctx.h, f64film, None, None) == A.HK_ERR_INVALID and b"hk_film_read_rgb_async" in L.hk_last_error()
+    assert L.hk_film_read_rgb_async(gpu_ctx.h, None) == A.HK_ERR_INVALID and L.hk_film_read_rgb_async(None, f32film) == A.HK_ERR_INVALID
     assert L.hk_film_read_rgb(gpu_ctx.h, f32film, out.ctypes.data_as(A.PF)) == 0 and np.isfinite(out).all() and out.mean() > 0
+    assert L.hk_film_read_rgb_async(gpu_ctx.h, f32film) == 0 and L.hk_film_read_wait(gpu_ctx.h, f32film, None, None) == 0
+    out2, ptr = np.empty_like(out), A.PF()
+    assert L.hk_film_read_rgb_async(gpu_ctx.h, f32film) == 0 and L.hk_film_read_wait(gpu_ctx.h, f32film, out2.ctypes.data_as(A.PF), C.byref(ptr)) == 0
+    assert np.array_equal(out2, out) and np.array_equal(np.ctypeslib.as_array(ptr, shape=out.shape), out)
+    assert L.hk_flush(None) == A.HK_ERR_INVALID and L.hk_trim_cache(None) == A.HK_ERR_INVALID and L.hk_flush(gpu_ctx.h) == 0
+    assert L.hk_ctx_get_option(gpu_ctx.h, b"HK_NOT_A_KNOB", None, 0) == A.HK_ERR_INVALID
     # point-wise entry points
     z = np.zeros((4, 4), np.float32)
     PF = A.PF

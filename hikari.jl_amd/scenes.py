@@ -354,11 +354,12 @@ def _boxes_mesh(centers, half, angle):
     return P, N
 
 
-def many_light_scene(width=1024, height=1024, n_boxes=83334, emissive_frac=0.05, seed=1):
+def many_light_scene(width=1024, height=1024, n_boxes=83334, emissive_frac=0.05, seed=1, box_scale=1.0):
     """Config 5 stand-in: ~10^6 triangles as boxes in concentric barrel layers around the z axis, 5 % of the boxes
     emissive with a random Le in [0.2, 1] per face (=> ~5*10^4 DiffuseAreaLights in the light BVH), the rest matte / conductor.
     Per-face emission colours come through the reference's own mechanism: a textured Emissive is point-sampled at each face's
-    centroid uv (scene-mesh.jl:49), so every face of the emissive mesh carries a uv that selects one texel."""
+    centroid uv (scene-mesh.jl:49), so every face of the emissive mesh carries a uv that selects one texel.  box_scale > 1: the same
+    layout with larger boxes — a small case of a few hundred boxes that still fills the frame (the per-pixel pin of the tests)."""
     from .geometry import Mesh
     from .materials import Texture
     rng = np.random.default_rng(seed)
@@ -368,7 +369,7 @@ def many_light_scene(width=1024, height=1024, n_boxes=83334, emissive_frac=0.05,
     phi = rng.random(n_boxes) * 2 * np.pi
     zpos = (rng.random(n_boxes) * 2 - 1) * 6.0
     centers = np.stack([radius * np.cos(phi), radius * np.sin(phi), zpos], axis=1)
-    half = 0.012 + 0.03 * rng.random((n_boxes, 3))
+    half = (0.012 + 0.03 * rng.random((n_boxes, 3))) * box_scale
     P, N = _boxes_mesh(centers, half, rng.random(n_boxes) * np.pi)
     group = rng.random(n_boxes)
     em = group < emissive_frac

@@ -271,10 +271,17 @@ class LB:
         return (self.lo + self.hi) * f32(0.5)
 
 
+def _r32(fn, x):
+    """a transcendental of a binary32 number, correctly rounded to binary32 (evaluated in binary64): the light BVH's build decides between
+    splits whose costs tie to the last bits (the cost uses the PARENT's area for both sides, bvh-light-sampler.jl:256-258, so only the cones
+    tell splits apart), and a few-ulp vectorised float32 arcsin would send it down another tree than libm's"""
+    return f32(fn(np.float64(x)))
+
+
 def _angle_between(a, b):
     if dot(a, b) < 0:
-        return PI - f32(2) * np.arcsin(np.clip(np.sqrt(dot(a + b, a + b)) * f32(0.5), -1, 1).astype(f32))
-    return f32(2) * np.arcsin(np.clip(np.sqrt(dot(b - a, b - a)) * f32(0.5), -1, 1).astype(f32))
+        return PI - f32(2) * _r32(np.arcsin, np.clip(np.sqrt(dot(a + b, a + b)) * f32(0.5), -1, 1))
+    return f32(2) * _r32(np.arcsin, np.clip(np.sqrt(dot(b - a, b - a)) * f32(0.5), -1, 1))
 
 
 def _cone_union(wa, ca, wb, cb):
@@ -282,7 +289,7 @@ def _cone_union(wa, ca, wb, cb):
         return wb, cb
     if cb == np.inf:
         return wa, ca
-    ta, tb = np.arccos(np.clip(ca, -1, 1)).astype(f32), np.arccos(np.clip(cb, -1, 1)).astype(f32)
+    ta, tb = _r32(np.arccos, np.clip(ca, -1, 1)), _r32(np.arccos, np.clip(cb, -1, 1))
     td = f32(_angle_between(wa, wb))
     if min(td + tb, PI) <= ta:
         return wa, ca
@@ -296,9 +303,9 @@ def _cone_union(wa, ca, wb, cb):
     if dot(wr, wr) == 0:
         return F([0, 0, 1]), f32(-1)
     axis = normalize(wr)
-    s, c = np.sin(tr).astype(f32), np.cos(tr).astype(f32)
+    s, c = _r32(np.sin, tr), _r32(np.cos, tr)
     w = wa * c + cross(axis, wa) * s + axis * dot(axis, wa) * (f32(1) - c)
-    return normalize(w), np.cos(to).astype(f32)
+    return normalize(w), _r32(np.cos, to)
 
 
 def lb_union(a, b):
@@ -311,11 +318,11 @@ def lb_union(a, b):
 
 
 def _cost(lb, lo, hi, dim):
-    to = np.arccos(np.clip(lb.cos_o, -1, 1)).astype(f32)
-    te = np.arccos(np.clip(lb.cos_e, -1, 1)).astype(f32)
+    to = _r32(np.arccos, np.clip(lb.cos_o, -1, 1))
+    te = _r32(np.arccos, np.clip(lb.cos_e, -1, 1))
     tw = min(to + te, PI)
     so = np.sqrt(max(f32(0), f32(1) - lb.cos_o * lb.cos_o))
-    m_omega = f32(2) * PI * (f32(1) - lb.cos_o) + PI / f32(2) * (f32(2) * tw * so - np.cos(to - f32(2) * tw).astype(f32) - f32(2) * to * so + lb.cos_o)
+    m_omega = f32(2) * PI * (f32(1) - lb.cos_o) + PI / f32(2) * (f32(2) * tw * so - _r32(np.cos, to - f32(2) * tw) - f32(2) * to * so + lb.cos_o)
     d = hi - lo
     kr = d.max() / d[dim] if d[dim] > 1e-10 else d.max() / f32(1e-10)
     area = f32(2) * (d[0] * d[1] + d[0] * d[2] + d[1] * d[2])
@@ -344,6 +351,19 @@ class LightBVH:
         self.two = np.array([n[0].two_sided for n in nd])
         self.child = np.array([n[1] for n in nd], np.int64)
         self.leaf = np.array([n[2] for n in nd])
+
+    def adopt(self, nodes16, trails):
+        """take another builder's TREE (rows of 16 floats: lo, hi, w, phi, cos_o, cos_e, two_sided, child1 (1-based) or light, is_leaf; and the
+        per-light bit trails) and keep this class's walks: the build is ill-conditioned where cones of opposite faces are merged — the axis
+        of the union turns about a x b, and for a = -b that cross product is rounding noise — so two correct builders may differ in a few
+        subtrees (test_many_light_tree_and_frame_against_the_numpy_restatement counts them); the walks are compared on one tree"""
+        nd = np.asarray(nodes16, f32)
+        self.lo, self.hi, self.w = nd[:, 0:3].copy(), nd[:, 3:6].copy(), nd[:, 6:9].copy()
+        self.phi, self.cos_o, self.cos_e = nd[:, 9].copy(), nd[:, 10].copy(), nd[:, 11].copy()
+        self.two = nd[:, 12] > 0
+        self.leaf = nd[:, 14] > 0
+        self.child = np.where(self.leaf, nd[:, 13], nd[:, 13] - 1).astype(np.int64)
+        self.trail = {i + 1: int(t) for i, t in enumerate(trails)}
 
     def _bucket(self, lb, clo, chi, dim):
         ext = chi[dim] - clo[dim]
@@ -400,7 +420,7 @@ class LightBVH:
         self.nodes.append(None)
         lb0 = self._build(items, start, mid, trail, depth + 1)
         child1 = len(self.nodes)
-        lb1 = self._build(items, mid + 1, stop, trail | (1 << depth), depth + 1)
+        lb1 = self._build(items, mid + 1, stop, trail | ((1 << depth) & 0xFFFFFFFF), depth + 1)     # UInt32(1) << depth is 0 from depth 32 on: the trail loses those turns
         merged = lb_union(lb0, lb1)
         self.nodes[me] = (merged, child1, False)
         return merged
@@ -526,12 +546,15 @@ class SceneNP:
         for i, m in enumerate(mats):
             if m.kind != 3:
                 continue
-            assert m.spectrum[0] >= 0 and m.spectrum[1] >= 0, "conductor eta / k as PiecewiseLinearSpectrum (the metal presets)"
             r = f32(m.f[0].v)
             self.alpha[i] = np.sqrt(r) if (m.flags & 1) else r
-            for store, si in ((self.eta_pl, m.spectrum[0]), (self.k_pl, m.spectrum[1])):
-                sp = desc.spectra[si]
-                store[i] = (np.ctypeslib.as_array(sp.lambdas, shape=(sp.n,)).astype(f32).copy(), np.ctypeslib.as_array(sp.values, shape=(sp.n,)).astype(f32).copy())
+            for store, si, rgb in ((self.eta_pl, m.spectrum[0], m.rgb[0]), (self.k_pl, m.spectrum[1], m.rgb[1])):
+                if si >= 0:      # a measured PiecewiseLinearSpectrum (the metal presets)
+                    sp = desc.spectra[si]
+                    store[i] = ("pl", np.ctypeslib.as_array(sp.lambdas, shape=(sp.n,)).astype(f32).copy(), np.ctypeslib.as_array(sp.values, shape=(sp.n,)).astype(f32).copy())
+                else:            # an RGB value: uplifted UNBOUNDED per wavelength (eval_ior_spectral, spectral-eval.jl:207-210; uplift.jl:286-308)
+                    assert rgb.tex < 0
+                    store[i] = ("rgb", unbounded_poly(tables, [f32(rgb.c[k]) for k in range(3)]))
         # Matte clamps Kd to [0, 1] (spectral-eval.jl:63); Mirror / Glass pass Kr / Kt to uplift_rgb as they are (it clamps inside)
         self.kd_poly = F([tables.rgb_to_poly([m.rgb[0].c[k] for k in range(3)]) for m in mats])       # Kd, or Kr
         self.kt_poly = F([tables.rgb_to_poly([m.rgb[1].c[k] for k in range(3)]) for m in mats])
@@ -544,8 +567,8 @@ class SceneNP:
         for i in self.eta_pl:
             sel = mat == i
             if sel.any():
-                eta[sel] = pl_sample(*self.eta_pl[i], lam[sel])
-                k[sel] = pl_sample(*self.k_pl[i], lam[sel])
+                for out, rec in ((eta, self.eta_pl[i]), (k, self.k_pl[i])):
+                    out[sel] = pl_sample(rec[1], rec[2], lam[sel]) if rec[0] == "pl" else unbounded_eval(rec[1], lam[sel])
         return eta, k
 
     def _rest(self, desc, tables):
@@ -620,23 +643,38 @@ class SceneNP:
         self.tri_area = (f32(0.5) * np.sqrt(dot(cross(e1f, e2f), cross(e1f, e2f)))).astype(f32)
 
     def intersect(self, o, d, tmax):
-        """closest hit of rays (o, d) [N, 3] (float32) with t in (0, tmax): Moeller-Trumbore in float64 over all triangles"""
-        o, d = o.astype(np.float64)[:, None, :], d.astype(np.float64)[:, None, :]
-        pv = np.cross(d, self.e2[None])
-        det = np.einsum("ntk,ntk->nt", np.broadcast_to(self.e1[None], pv.shape), pv)
-        with np.errstate(divide="ignore", invalid="ignore"):
-            inv = 1.0 / det
-            tv = o - self.v0[None]
-            u = np.einsum("ntk,ntk->nt", tv, pv) * inv
-            qv = np.cross(tv, self.e1[None])
-            v = np.einsum("ntk,ntk->nt", np.broadcast_to(d, qv.shape), qv) * inv
-            t = np.einsum("ntk,ntk->nt", np.broadcast_to(self.e2[None], qv.shape), qv) * inv
-        ok = (np.abs(det) > 0) & (u >= 0) & (v >= 0) & (u + v <= 1) & (t > 0) & (t < tmax[:, None])
-        t = np.where(ok, t, np.inf)
-        prim = t.argmin(1)
-        idx = np.arange(t.shape[0])
-        hit = np.isfinite(t[idx, prim])
-        return hit, prim, t[idx, prim], u[idx, prim], v[idx, prim]
+        """closest hit of rays (o, d) [N, 3] (float32) with t in (0, tmax): Moeller-Trumbore in float64 over all triangles (component planes
+        [rays of a block, triangles], blocks sized to stay in cache)"""
+        N, T = o.shape[0], self.v0.shape[0]
+        o64, d64, tmax = o.astype(np.float64), d.astype(np.float64), np.asarray(tmax, np.float64)
+        hit, prim = np.zeros(N, bool), np.zeros(N, np.int64)
+        tt, uu, vv = np.full(N, np.inf), np.zeros(N), np.zeros(N)
+        if T == 0 or N == 0:
+            return hit, prim, tt, uu, vv
+        if getattr(self, "_planes", None) is None:
+            self._planes = [np.ascontiguousarray(a[:, k])[None, :] for a in (self.v0, self.e1, self.e2) for k in range(3)]
+        v0x, v0y, v0z, e1x, e1y, e1z, e2x, e2y, e2z = self._planes
+        step = max(1, (1 << 18) // T)
+        for lo in range(0, N, step):
+            sl = slice(lo, min(lo + step, N))
+            ox, oy, oz = (o64[sl, k][:, None] for k in range(3))
+            dx, dy, dz = (d64[sl, k][:, None] for k in range(3))
+            px, py, pz = dy * e2z - dz * e2y, dz * e2x - dx * e2z, dx * e2y - dy * e2x
+            det = e1x * px + e1y * py + e1z * pz
+            with np.errstate(divide="ignore", invalid="ignore"):
+                inv = 1.0 / det
+                sx, sy, sz = ox - v0x, oy - v0y, oz - v0z
+                u = (sx * px + sy * py + sz * pz) * inv
+                qx, qy, qz = sy * e1z - sz * e1y, sz * e1x - sx * e1z, sx * e1y - sy * e1x
+                v = (dx * qx + dy * qy + dz * qz) * inv
+                t = (e2x * qx + e2y * qy + e2z * qz) * inv
+                ok = (np.abs(det) > 0) & (u >= 0) & (v >= 0) & (u + v <= 1) & (t > 0) & (t < tmax[sl, None])
+            t = np.where(ok, t, np.inf)
+            k = t.argmin(1)
+            idx = np.arange(t.shape[0])
+            tt[sl], uu[sl], vv[sl], prim[sl] = t[idx, k], u[idx, k], v[idx, k], k
+        hit = np.isfinite(tt)
+        return hit, prim, tt, uu, vv
 
     def intersect32(self, o, d, tmax):
         """The same query in BINARY32, operation for operation as DESIGN.md section 3 defines the build's intersection arithmetic (Moeller-
@@ -664,6 +702,31 @@ class SceneNP:
     def occluded(self, o, d, tmax):
         hit, _, _, _, _ = self.intersect(o, d, tmax)
         return hit
+
+
+def unbounded_poly(tables, rgb):
+    """uplift_rgb_unbounded of one colour (uplift.jl:286-308): the polynomial of rgb / max and the factor max / max_value(polynomial)
+    (rgb2spec.jl:39-53: the larger end point, or the critical point of the parabola inside [360, 830]) -> (coefficients, scale) or None"""
+    m = max(rgb)
+    if m <= 0:
+        return None
+    c = F(tables.rgb_to_poly([f32(v / m) for v in rgb]))
+
+    def at(lam):
+        return f32(sigmoid(f32(c[0] * f32(lam) * f32(lam) + c[1] * f32(lam) + c[2])))
+    mv = max(at(f32(360)), at(f32(830)))
+    if c[0] != 0:
+        lc = f32(-c[1] / (f32(2) * c[0]))
+        if f32(360) <= lc <= f32(830):
+            mv = max(mv, at(lc))
+    return c, f32(m / mv)
+
+
+def unbounded_eval(rec, lam):
+    if rec is None:
+        return np.zeros(np.shape(lam), f32)
+    c, scale = rec
+    return (scale * eval_poly(np.broadcast_to(c, np.shape(lam)[:-1] + (3,)), F(lam))).astype(f32)
 
 
 # ---------------------------------------------------------------------------------------------------- rough / smooth Conductor
@@ -966,29 +1029,10 @@ class MediumNP:
         self.g = f32(rec.g)
         self.rgb = {k: [f32(getattr(rec, k)[i]) for i in range(3)] for k in ("sigma_a", "sigma_s", "Le")}
         self.tb = tables
-        self.poly = {}
-        for k, rgb in self.rgb.items():
-            m = max(rgb)
-            if m <= 0:
-                self.poly[k] = None
-                continue
-            c = tables.rgb_to_poly([f32(v / m) for v in rgb])
-            c = F(c)
-
-            def at(lam, c=c):
-                return f32(sigmoid(f32(c[0] * f32(lam) * f32(lam) + c[1] * f32(lam) + c[2])))
-            mv = max(at(f32(360)), at(f32(830)))
-            if c[0] != 0:
-                lc = f32(-c[1] / (f32(2) * c[0]))
-                if f32(360) <= lc <= f32(830):
-                    mv = max(mv, at(lc))
-            self.poly[k] = (c, f32(m / mv))
+        self.poly = {k: unbounded_poly(tables, rgb) for k, rgb in self.rgb.items()}
 
     def spectrum(self, k, lam):
-        if self.poly[k] is None:
-            return np.zeros(4, f32)
-        c, scale = self.poly[k]
-        return (scale * eval_poly(c[None], F(lam)[None])[0]).astype(f32)
+        return unbounded_eval(self.poly[k], F(lam)[None])[0]
 
 
 def track_medium(md, o, d, t_max, lam, beta, r_u, r_l, depth, max_depth):
@@ -1427,10 +1471,10 @@ def sample_light_np(sc, li, pi, lm, d_u0, d_u1):
 
 
 def render(desc, cam_rec, tables_dict, width, height, n_samples, max_depth, max_component_value=10.0, filter_radius=(0.5, 0.5), first=1, sobol_spp=None,
-           regularize=True):
+           regularize=True, scene=None):
     """-> framebuffer [height, width, 3] (row py - 1, column px - 1), the weighted sums and the weights"""
     tb = Tables(tables_dict)
-    sc = SceneNP(desc, tb)
+    sc = scene if scene is not None else SceneNP(desc, tb)
     zs = ZSobol(tb.sobol, width, height, max(sobol_spp or n_samples, 4096), 0)
     r2c = F(list(cam_rec.raster_to_camera)).reshape(4, 4)
     c2w = F(list(cam_rec.camera_to_world)).reshape(4, 4)

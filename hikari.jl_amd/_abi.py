@@ -125,7 +125,8 @@ class hk_stats(C.Structure):
                 ("bytes_algorithmic_shadow", C.c_uint64), ("bytes_algorithmic_shade", C.c_uint64), ("seconds_media", C.c_double),
                 ("track_collisions", C.c_uint64), ("shadow_collisions", C.c_uint64), ("track_dda_steps", C.c_uint64),
                 ("shadow_dda_steps", C.c_uint64), ("scatter_vertices", C.c_uint64), ("media_launches", C.c_uint64),
-                ("bytes_algorithmic_media", C.c_uint64), ("seconds_select", C.c_double), ("select_launches", C.c_uint64)]
+                ("bytes_algorithmic_media", C.c_uint64), ("seconds_select", C.c_double), ("select_launches", C.c_uint64),
+                ("fused_passes", C.c_uint64)]
 
 
 # every symbol include/hikari_mi355x.h declares (tests check the built library exports all of them)

@@ -32,6 +32,7 @@ void launch_detect_camera_medium(hipStream_t, const DPathState&, const DScene&, 
 void launch_shade(hipStream_t, int, int, const DPathState&, const DScene&, const DTables&, const DFrame&, const DSobol&, int, int, DStats*);
 bool grey_compact_ok(const DScene&);
 bool preselect_lights(const DScene&, const DPathState&);
+bool launch_small_pass(hipStream_t, int, const DPathState&, const DScene&, const DTables&, const DFrame&, const DFilter&, const DCamera&, const DSobol&, int, uint32_t, DStats*);
 void launch_light_select(hipStream_t, int, const DPathState&, const DScene&, const DTables&, const DFrame&, const DSobol&, int, uint32_t, DStats*);
 void launch_film(hipStream_t, const DPathState&, const DFrame&, const DTables&, void*, bool);
 void launch_segment_lists(hipStream_t, const DPathState&, int, const int*, const int*);
@@ -81,7 +82,7 @@ static const char* const KNOB_NAMES[] = {
     "HK_MID_LISTS", "HK_MID_PASS_PATHS_M", "HK_NODE_CACHE", "HK_NVDB_DENSE_MB", "HK_OVERLAP", "HK_PIPELINE", "HK_PIPELINE_AFTER", "HK_PIPELINE_MAX_PATHS_M", "HK_PRESELECT",
     "HK_SELECT_MIN_IDLE", "HK_SHADOW_FEED_ROUNDS", "HK_SHADOW_TRACK_BATCH", "HK_SMALL_PASS", "HK_SMALL_PASS_WAVES", "HK_SOBOL_LO_GB", "HK_SOBOL_TABLE_ONLY",
     "HK_STATE_CACHE_GB", "HK_STATE_SLAB", "HK_TICKET_SHARE", "HK_TRACK_ADVANCE", "HK_TRACK_EXTRA_ADVANCE", "HK_TRACK_MIN_PENDING", "HK_TRACK_POOL", "HK_TRACK_REFILL_IDLE",
-    "HK_WALK_POOL", "HK_WALK_REFILL_IDLE", "HK_WALK_SPLIT", "HK_WAVES_PER_CU", "HK_READBACK_PIN", "HK_DEFER_EXTERNAL", "HK_SELECT_POOL"};
+    "HK_WALK_POOL", "HK_WALK_REFILL_IDLE", "HK_WALK_SPLIT", "HK_WAVES_PER_CU", "HK_READBACK_PIN", "HK_DEFER_EXTERNAL", "HK_SELECT_POOL", "HK_SMALL_PASS_FUSED"};
 static bool known_knob(const char* name) {
     for (const char* k : KNOB_NAMES)
         if (std::strcmp(k, name) == 0) return true;
@@ -236,6 +237,7 @@ struct hk_ctx {
     std::vector<float> h_r2s_scale, h_r2s_coeffs;
     hk::RGB2Spec r2s_host;
     int count_nodes = 0, time_kernels = 0;
+    unsigned long long fused_passes = 0;   // passes rendered by k_small_pass (one launch)
     // timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_events;   // class 0
     std::vector<std::pair<hipEvent_t, hipEvent_t>> class_events[6];  // 1 shadow, 2 shade, 3 other, 4 media, 5 light selection (reported inside the shade class AND on its own)
@@ -1567,7 +1569,14 @@ int ensure_state(hk_integrator* I, int capacity, bool media, bool open_scene, bo
         if (small) {
             I->st.dynamic_segments = 0;
             const char* w = hk::knob("HK_SMALL_PASS_WAVES");
-            long per_cu = w && std::atoi(w) > 0 ? std::atoi(w) : (media ? 4 : 8);   // (800^2, one sample per call, 8 lanes: Cornell 0.99 / 0.89 / 1.03 / 1.30 ms per call at 4 / 8 / 16 / 32, cloud 12.6 / 13.8 / 17.9 / 19.6)
+            // (800^2, one sample per call.  Eight calls in flight on eight lanes (HK_PIPELINE): Cornell 0.99 / 0.89 / 1.03 / 1.30 ms per call at
+            // 4 / 8 / 16 / 32 segments per CU, cloud 12.6 / 13.8 / 17.9 / 19.6.  ONE call at a time — the default since small calls are batched,
+            // and what a caller that looks at every frame gets: Cornell 2.04 / 1.53 / 1.41 / 1.34 / 1.59 / 1.63 ms at 4 / 8 / 12 / 16 / 20 / 32,
+            // cloud 29.8 / 26.0 / 25.4 at 4 / 8 / 16, 10^6 triangles 11.0 / 10.9 / 12.1 at 8 / 16 / 32, sky 2.32 / 2.39 / 2.49: one segment per
+            // resident wave — 16 waves per CU is what k_trace_lean's 16-wave block and k_shade's 128 registers hold, and at 8 the 1024-thread
+            // trace blocks covered half of the CUs.  An OPEN surface scene keeps 8: its deep bounces are empty and its glass / conductor
+            // shade kernels hold fewer than 16 waves per CU.)
+            long per_cu = w && std::atoi(w) > 0 ? std::atoi(w) : (users ? (media ? 4 : 8) : ((open_scene && !media) ? 8 : 16));
             const long chunks = ((long)capacity + 63) / 64;
             while (per_cu > 4 && per_cu * n_cu > chunks) per_cu /= 2;   // (no segment without a chunk)
             if (I->ctx->waves_per_cu <= 0) W_want = (per_cu * n_cu + 3) / 4 * 4;
@@ -2008,6 +2017,10 @@ static int render_tile_now(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_film* f
         // environment map, say) must not see the ray / shadow counts an earlier render left behind
         HIP_TRY(hipMemsetAsync(I->st.counters, 0, (size_t)(I->st_depth + 2) * Q_COUNT * I->st.n_waves * sizeof(int), s));
         if (I->st.wq_ctl) HIP_TRY(hipMemsetAsync(I->st.wq_ctl, 0, (size_t)(I->st_depth + 2) * 11 * 4 * sizeof(int), s));
+        // a small pass of a closed all-matte scene: camera rays and every bounce in ONE launch (k_small_pass), then the film
+        const bool fused = !c->time_kernels && !piped && hk::launch_small_pass(s, c->n_cu, I->st, sc->d, c->tables, fr, I->filter, dc, sob, I->p.max_depth, sc->kinds_mask, dstats);
+        if (fused) c->fused_passes++;
+        if (!fused) {
         if (timed(3, [&] { hk::launch_camera(s, c->n_cu, I->st, fr, c->tables, I->filter, dc, sob, -1); }) != HK_OK) return fail(HK_ERR_DEVICE, "event record failed");
         // work lists: after every producer, the non-empty segments of the queues it filled (consumers never visit an empty segment)
         auto lists = [&](std::initializer_list<std::pair<int, int>> dq, bool kinds_of_depth = false, int kd = 0) -> int {
@@ -2098,6 +2111,7 @@ static int render_tile_now(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_film* f
             HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
             shadows_in_flight = false;
         }
+        }   // !fused
         if (piped && c->film_chain) HIP_TRY(hipStreamWaitEvent(s, c->ev_film, 0));   // the film sums in call order
         if (timed(3, [&] { hk::launch_film(s, I->st, fr, c->tables, film->accum, film->f64); }) != HK_OK) return fail(HK_ERR_DEVICE, "event record failed");
         if (piped) {
@@ -2169,6 +2183,7 @@ extern "C" int32_t hk_stats_reset(hk_ctx* c) {
     }
     c->seconds_trace = c->seconds_total = 0.0;
     c->trace_launches = c->shadow_launches = c->shade_launches = c->media_launches = c->select_launches = 0;
+    c->fused_passes = 0;
     c->have_span = false;
     return HK_OK;
 }
@@ -2261,6 +2276,7 @@ extern "C" int32_t hk_stats_get(hk_ctx* c, hk_stats* out) {
     out->seconds_media = cls[4];
     out->seconds_select = cls[5];
     out->select_launches = c->select_launches;
+    out->fused_passes = c->fused_passes;
     {   // SURVEY 8(d) algorithmic bytes over the counted units
         const uint64_t hits_closest = h.hits < h.rays_closest ? h.hits : h.rays_closest;   // shading attributes are fetched once per accepted closest hit
         out->bytes_algorithmic_trace = h.rays_closest * (32 + 16) + 64 * h.nodes + 36 * h.tris + 96 * hits_closest;

@@ -166,6 +166,24 @@ __device__ __forceinline__ int seg_next(SegTickets& it, int n_segments) {   // -
 #define HK_FOR_EACH_WAVE_SEGMENT(gw, st, ticket, depth, q)                                                        \
     for (SegTickets gw##_t = seg_open(st, ticket, (st).dynamic_segments != 0, depth, q); gw##_t.cnt; gw##_t.cnt = nullptr) \
         for (int gw = seg_next(gw##_t, (st).n_waves); gw < (st).n_waves; gw = seg_next(gw##_t, (st).n_waves))
+// the same loop over a prepared source (seg_open's result, or seg_single: the stage bodies are shared with k_small_pass)
+#define HK_FOR_EACH_SEGMENT_FROM(gw, st, tickets)                                                                  \
+    for (SegTickets gw##_t = (tickets); gw##_t.cnt; gw##_t.cnt = nullptr)                                         \
+        for (int gw = seg_next(gw##_t, (st).n_waves); gw < (st).n_waves; gw = seg_next(gw##_t, (st).n_waves))
+// exactly the segment g (static mode: the counter pointer only says "open")
+__device__ __forceinline__ SegTickets seg_single(const DPathState& st, int g) {
+    SegTickets it;
+    it.cnt = st.tickets;
+    it.alive = 0ull;
+    it.k0 = 0;
+    it.list = nullptr;
+    it.n = g + 1;
+    it.pos = g;
+    it.step = 1 << 30;
+    it.own = 0ull;
+    it.share = false;
+    return it;
+}
 // A kernel whose lanes leave nothing behind in their segment (the shadow kernels: results go to L[slot]) does not have to drain its
 // lanes at the end of every segment: it asks for one segment after another and the per-lane refill simply continues with the next
 // segment's entries.  The only drain left is the one at the end of the launch (the shadow walk of the cloud config ran a third of
@@ -446,11 +464,11 @@ __global__ void __launch_bounds__(256) k_sobol_lo_table(DSobol sob, DFrame fr, u
 // ---------------------------------------------------------------------------------------------------
 // K1: camera rays (volpath.jl:125-205).  One thread per path slot of the pass.
 // ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_camera(DPathState st, DFrame fr, DTables T, DFilter flt, DCamera cam, DSobol sob, int initial_medium) {
+__device__ __forceinline__ void camera_body(const DPathState& st, const DFrame& fr, const DTables& T, const DFilter& flt, const DCamera& cam, const DSobol& sob, const SegTickets& src) {
     const int total = fr.n_pixels_padded * fr.samples_in_pass;
     const int n_chunks = total >> 6;
     const DPathGen g0 = st.gen[0];
-    HK_FOR_EACH_WAVE_SEGMENT(gw, st, ticket_ptr(st, st.ticket_rows - 1, TK_CAMERA), -1, 0) {
+    HK_FOR_EACH_SEGMENT_FROM(gw, st, src) {
     WavePos out{0};
     const size_t seg = (size_t)gw * st.wave_cap;
     // wave w generates chunks w, w+W, w+2W, ... (64 consecutive slots = samples of one pixel, or of 64 / S pixels; interleaved across waves for load balance)
@@ -502,6 +520,9 @@ __global__ void __launch_bounds__(256) k_camera(DPathState st, DFrame fr, DTable
     }
     if (lane_id() == 0) *count_ptr(st, 0, Q_RAY, gw) = out.count;
     }
+}
+__global__ void __launch_bounds__(256) k_camera(DPathState st, DFrame fr, DTables T, DFilter flt, DCamera cam, DSobol sob, int initial_medium) {
+    camera_body(st, fr, T, flt, cam, sob, seg_open(st, ticket_ptr(st, st.ticket_rows - 1, TK_CAMERA), st.dynamic_segments != 0, -1, 0));
 }
 
 // Copies the first min(NC, sc.n_nodes) nodes into the block's LDS (see NodeCache) and waits for the whole block.
@@ -792,6 +813,18 @@ HKD void lane_ray_round(LaneRay& r, bool active, const DScene& sc, int* __restri
 #ifdef HK_DEBUG_UTIL
     if (dbg_) HK_DBG(1, active && (has_pend || (r.cur < 0 && r.cur != DONE)));   // leaf phase: lanes that hold a leaf
 #endif
+#ifdef HK_DEBUG_UTIL
+    if (dbg_) {   // triangle iterations of the leaf phase: the wave runs max(count) of them, sum(count) lane-slots work (probe 6: closest hit, 7: any hit — an upper bound there)
+        const bool holds = active && (has_pend || (r.cur < 0 && r.cur != DONE));
+        int c = holds ? ((~(has_pend ? r.pend : r.cur)) & 7) + 1 : 0, mx = c, sm = c;
+        for (int off = 32; off > 0; off >>= 1) {
+            mx = max(mx, __shfl_xor(mx, off));
+            sm += __shfl_xor(sm, off);
+        }
+        dbg_[ANYHIT ? 8 : 12] += 64ull * (unsigned)mx;
+        dbg_[ANYHIT ? 9 : 13] += (unsigned)sm;
+    }
+#endif
     if (active && (has_pend || (r.cur < 0 && r.cur != DONE))) {
         int ref = ~(has_pend ? r.pend : r.cur);
         int first = ref >> 3, count = (ref & 7) + 1;
@@ -858,19 +891,14 @@ enum { LR_EMPTY = 0, LR_ACTIVE = 1 };
 
 // STACK: LDS stack entries per lane.  The stack holds at most one entry per inner level, so a BVH of depth <= 16 (every scene
 // but the 10^6-triangle one) runs with half the LDS: 16 KB per block instead of 32, and LDS stops limiting residency.
-template <bool COUNT, int STACK, int BLOCK = HK_TRACE_BLOCK, int NC = 0>
-__global__ void __launch_bounds__(BLOCK) k_trace_lean(DPathState st, DScene sc, int depth, DStats* stats) {
-    __shared__ int lds_stack[(BLOCK / 64) * STACK * 64];
-    __shared__ float4 lds_box[NC > 0 ? 3 * NC : 1];
-    __shared__ int2 lds_child[NC > 0 ? NC : 1];
-    int* stack = lds_stack + (threadIdx.x >> 6) * (STACK * 64);
-    const NodeCache cache = node_cache_fill<NC, BLOCK>(sc, lds_box, lds_child);
+template <bool COUNT, int NC>
+__device__ __forceinline__ void trace_lean_body(const DPathState& st, const DScene& sc, int depth, DStats* stats, const SegTickets& src, int* __restrict__ stack, const NodeCache& cache) {
     const int lane = lane_id();
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const int DONE = (int)0x80000000;
     unsigned n_nodes = 0, n_tris = 0, n_casts = 0, n_hits = 0;
     HK_DBG_DECL
-    HK_FOR_EACH_WAVE_SEGMENT(gw, st, ticket_ptr(st, depth, TK_TRACE), depth, Q_RAY) {
+    HK_FOR_EACH_SEGMENT_FROM(gw, st, src) {
     const DPathGen g = st.gen[depth & 1];
     const uint32_t seg = (uint32_t)gw * (uint32_t)st.wave_cap;   // the rays of this segment: entries seg .. seg + n - 1, read in order (no index queue)
     const int n = *count_ptr(st, depth, Q_RAY, gw);
@@ -887,6 +915,7 @@ __global__ void __launch_bounds__(BLOCK) k_trace_lean(DPathState st, DScene sc, 
         const unsigned long long run_m = __ballot(state == LR_ACTIVE && r.cur != DONE);
         if (run_m == 0ull || (64 - __popcll(run_m) >= HK_TRACE_MIN_IDLE && cursor < n)) {
             // ---- flush: classify the finished rays, push them to the escaped / material-kind queues ----
+            HK_DBG(8, state == LR_ACTIVE && r.cur == DONE);   // flushes: lanes that deliver a finished ray
             int kind = -1;
             if (state == LR_ACTIVE && r.cur == DONE) {
                 if (r.best.prim < 0)
@@ -959,6 +988,15 @@ __global__ void __launch_bounds__(BLOCK) k_trace_lean(DPathState st, DScene sc, 
         wave_add(&stats->tris, n_tris);
     }
     HK_DBG_FLUSH(stats);
+}
+template <bool COUNT, int STACK, int BLOCK = HK_TRACE_BLOCK, int NC = 0>
+__global__ void __launch_bounds__(BLOCK) k_trace_lean(DPathState st, DScene sc, int depth, DStats* stats) {
+    __shared__ int lds_stack[(BLOCK / 64) * STACK * 64];
+    __shared__ float4 lds_box[NC > 0 ? 3 * NC : 1];
+    __shared__ int2 lds_child[NC > 0 ? NC : 1];
+    int* stack = lds_stack + (threadIdx.x >> 6) * (STACK * 64);
+    const NodeCache cache = node_cache_fill<NC, BLOCK>(sc, lds_box, lds_child);
+    trace_lean_body<COUNT, NC>(st, sc, depth, stats, seg_open(st, ticket_ptr(st, depth, TK_TRACE), st.dynamic_segments != 0, depth, Q_RAY), stack, cache);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2501,7 +2539,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(BLOCK, BLOCK), amdgpu
 #endif
 // K8 for one flagged vertex (surface-eval.jl:147-220): L += beta * Le / MIS denominator.
 template <bool TWO_PLANES, bool SIMPLE>
-HKD void shade_emission(DPathState& st, const DPathGen& g, bool ones, const DScene& sc, const DTables& T, uint32_t slot, unsigned& n_lnodes) {
+HKD void shade_emission(const DPathState& st, const DPathGen& g, bool ones, const DScene& sc, const DTables& T, uint32_t slot, unsigned& n_lnodes) {
     const float4 H = st.hit[slot];
     const float4 O = g.ray_o[slot], D = g.ray_d[slot];
     const v3 ro = mk3(O.x, O.y, O.z), rd = mk3(D.x, D.y, D.z);
@@ -2551,12 +2589,12 @@ struct ShadeWaves {
 // hash loops inlined at each of the five draw sites — is not in the kernel at all.
 // PRE: the light of this vertex's next-event estimation was chosen by k_light_select (scenes with a deep light BVH): the descent —
 // three quarters of this kernel's time in the 5*10^4-light scene, run at 49 % lane utilisation because leaf depths differ — is not here.
-template <int KIND, bool SIMPLE = false, bool FT = false, bool PRE = false>
-__global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_per_eu(ShadeWaves<KIND>::value))) k_shade(DPathState st, DScene sc, DTables T, DFrame fr, DSobol sob, int depth, int first_kind, DStats* stats) {
-    __shared__ uint32_t emit_list[4 * 128];   // per wave: slots of flagged (emissive-hit) vertices waiting for the dense K8 pass
+template <int KIND, bool SIMPLE, bool FT, bool PRE>
+__device__ __forceinline__ void shade_body(const DPathState& st, const DScene& sc, const DTables& T, const DFrame& fr, const DSobol& sob, int depth, int first_kind, DStats* stats, const SegTickets& src,
+                                           uint32_t* __restrict__ elist) {   // elist: this wave's 128 LDS words (slots of flagged — emissive-hit — vertices waiting for the dense K8 pass)
     const int lane = lane_id();
     unsigned n_vertices = 0, n_lnodes = 0;
-    HK_FOR_EACH_WAVE_SEGMENT(gw, st, ticket_ptr(st, depth, TK_SHADE0 + KIND), depth, Q_MAT0 + KIND) {
+    HK_FOR_EACH_SEGMENT_FROM(gw, st, src) {
     const uint32_t* __restrict__ queue = st.mat_q + ((size_t)KIND * st.n_waves + gw) * st.wave_cap;
     const int n = *count_ptr(st, depth, Q_MAT0 + KIND, gw);
     const DPathGen g = st.gen[depth & 1], gn = st.gen[(depth + 1) & 1];
@@ -2573,7 +2611,6 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
     //      inline in the main pass, a wave walks the light BVH (bvh_pmf, ~2 log2 n node evaluations) whenever ANY of its 64
     //      vertices sits on an emitter: with 5 % emissive faces that is 96 % of the waves at 5 % lane utilisation. ----
     {
-        uint32_t* elist = emit_list + (threadIdx.x >> 6) * 128;
         int n_emit = 0;
         for (int base = 0; base < n || n_emit > 0; base += 64) {
             if (base < n) {
@@ -2825,6 +2862,12 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
     wave_add(&stats->vertices, n_vertices);
     wave_add(&stats->light_nodes, n_lnodes);
 }
+template <int KIND, bool SIMPLE = false, bool FT = false, bool PRE = false>
+__global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_per_eu(ShadeWaves<KIND>::value))) k_shade(DPathState st, DScene sc, DTables T, DFrame fr, DSobol sob, int depth, int first_kind, DStats* stats) {
+    __shared__ uint32_t emit_list[4 * 128];
+    shade_body<KIND, SIMPLE, FT, PRE>(st, sc, T, fr, sob, depth, first_kind, stats, seg_open(st, ticket_ptr(st, depth, TK_SHADE0 + KIND), st.dynamic_segments != 0, depth, Q_MAT0 + KIND),
+                                      emit_list + (threadIdx.x >> 6) * 128);
+}
 
 // ---------------------------------------------------------------------------------------------------
 // K10: shadow rays (intersection.jl:302-406, 565-600).
@@ -2842,7 +2885,7 @@ HKD S4 wide(S4 v) { return v; }
 HKD S4 wide(float v) { return s4(v); }
 HKD bool is_black(float v) { return v == 0.0f; }
 template <bool COMPACT>
-HKD void shadow_contribute(DPathState& st, uint32_t rec, S4 T_ray, S4 tr_u, S4 tr_l) {
+HKD void shadow_contribute(const DPathState& st, uint32_t rec, S4 T_ray, S4 tr_u, S4 tr_l) {
     if (is_black(T_ray)) return;
     S4 w_u, w_l;
     ld_shadow_weights<COMPACT>(st, rec, w_u, w_l);
@@ -2861,26 +2904,20 @@ HKD void shadow_contribute(DPathState& st, uint32_t rec, S4 T_ray, S4 tr_u, S4 t
 }
 
 // the layout of the shadow weights is a run-time fact where grey media may or may not use the compact records (k_walk_pool)
-HKD void shadow_contribute_rt(DPathState& st, uint32_t rec, S4 T_ray, S4 tr_u, S4 tr_l) {
+HKD void shadow_contribute_rt(const DPathState& st, uint32_t rec, S4 T_ray, S4 tr_u, S4 tr_l) {
     if (st.compact)
         shadow_contribute<true>(st, rec, T_ray, tr_u, tr_l);
     else
         shadow_contribute<false>(st, rec, T_ray, tr_u, tr_l);
 }
 
-template <bool COUNT, int STACK, int BLOCK = HK_TRACE_BLOCK, int NC = 0>
-__global__ void __launch_bounds__(BLOCK) k_shadow(DPathState st, DScene sc, int depth, DStats* stats) {
-    __shared__ int lds_stack[(BLOCK / 64) * STACK * 64];
-    __shared__ float4 lds_box[NC > 0 ? 3 * NC : 1];
-    __shared__ int2 lds_child[NC > 0 ? NC : 1];
-    int* stack = lds_stack + (threadIdx.x >> 6) * (STACK * 64);
-    const NodeCache cache = node_cache_fill<NC, BLOCK>(sc, lds_box, lds_child);
+template <bool COUNT, int NC>
+__device__ __forceinline__ void shadow_body(const DPathState& st, const DScene& sc, int depth, DStats* stats, SegStream stream, int* __restrict__ stack, const NodeCache& cache) {
     const int lane = lane_id();
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const int DONE = (int)0x80000000;
     unsigned n_nodes = 0, n_tris = 0, n_casts = 0, n_hits = 0;
     HK_DBG_DECL
-    SegStream stream = stream_open(st, ticket_ptr(st, depth, TK_SHADOW), false, depth, Q_SHADOW);
     uint32_t seg = 0;   // current segment's shadow records: entries seg .. seg + n - 1, streamed in order
     int n = 0, cursor = 0;
     bool more = true;
@@ -2941,6 +2978,57 @@ __global__ void __launch_bounds__(BLOCK) k_shadow(DPathState st, DScene sc, int 
     if (COUNT) {
         wave_add(&stats->sh_nodes, n_nodes);
         wave_add(&stats->sh_tris, n_tris);
+    }
+}
+template <bool COUNT, int STACK, int BLOCK = HK_TRACE_BLOCK, int NC = 0>
+__global__ void __launch_bounds__(BLOCK) k_shadow(DPathState st, DScene sc, int depth, DStats* stats) {
+    __shared__ int lds_stack[(BLOCK / 64) * STACK * 64];
+    __shared__ float4 lds_box[NC > 0 ? 3 * NC : 1];
+    __shared__ int2 lds_child[NC > 0 ? NC : 1];
+    int* stack = lds_stack + (threadIdx.x >> 6) * (STACK * 64);
+    const NodeCache cache = node_cache_fill<NC, BLOCK>(sc, lds_box, lds_child);
+    shadow_body<COUNT, NC>(st, sc, depth, stats, stream_open(st, ticket_ptr(st, depth, TK_SHADOW), false, depth, Q_SHADOW), stack, cache);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// A SMALL pass as ONE launch (the reference's interactive call: one sample of every pixel, volpath.jl:445-450).  A path never leaves the
+// segment that generated its camera ray, so K1 and every bounce's K2 / K8 - K9 / K10 of a segment depend on nothing outside it: the wave
+// that owns the segment runs all of them, stage after stage, without waiting for any other wave.  As launches, the 26 kernels of such a
+// call each ran at the latency of one wave's chunks PLUS the wait for the slowest wave of the stage; here a wave's stages follow each
+// other directly.  The stage bodies are the standalone kernels' (camera_body, trace_lean_body, shade_body, shadow_body: same arithmetic,
+// same order, same queues — films bit-identical), the block is k_trace_lean's (16 waves: the stacks and the top of the tree in LDS).
+// Hand-over between stages goes through the segment's global arrays: written and read by the SAME wave, so completing the stores
+// (workgroup-scope release / acquire: s_waitcnt; a CU's vector L1 is write-through and coherent with its own stores) is all it takes.
+// For: all-opaque scenes without media, escape lights or light preselection whose only material kind is Matte under simple lights
+// (launch_small_pass says which; everything else keeps the launches).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void stage_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+template <int NC>
+__global__ void __attribute__((amdgpu_flat_work_group_size(1024, 1024), amdgpu_waves_per_eu(4))) k_small_pass(DPathState st, DScene sc, DTables T, DFrame fr, DFilter flt, DCamera cam, DSobol sob, int max_depth,
+                                                                                                                int shadows, DStats* stats) {
+    constexpr int STACK = 16, BLOCK = 1024;
+    __shared__ int lds_stack[(BLOCK / 64) * STACK * 64];
+    __shared__ float4 lds_box[3 * NC];
+    __shared__ int2 lds_child[NC];
+    __shared__ uint32_t emit_list[(BLOCK / 64) * 128];
+    int* stack = lds_stack + (threadIdx.x >> 6) * (STACK * 64);
+    uint32_t* elist = emit_list + (threadIdx.x >> 6) * 128;
+    const NodeCache cache = node_cache_fill<NC, BLOCK>(sc, lds_box, lds_child);
+    for (int g = global_wave(); g < st.n_waves; g += physical_waves()) {
+        camera_body(st, fr, T, flt, cam, sob, seg_single(st, g));
+        for (int depth = 0; depth < max_depth; ++depth) {
+            stage_fence();
+            trace_lean_body<false, NC>(st, sc, depth, stats, seg_single(st, g), stack, cache);
+            stage_fence();
+            shade_body<HK_MAT_MATTE, true, false, false>(st, sc, T, fr, sob, depth, 1, stats, seg_single(st, g), elist);
+            if (shadows) {
+                stage_fence();
+                shadow_body<false, NC>(st, sc, depth, stats, seg_single(st, g), stack, cache);
+            }
+        }
     }
 }
 
@@ -4941,6 +5029,24 @@ void launch_shade(hipStream_t s, int n_cu, int kind, const DPathState& st, const
         } break;
     }
 #undef HK_SHADE_CASE
+}
+// k_small_pass: the whole pass of a small call in one launch.  -> false when this scene / pass is not its case (the caller launches the stages)
+#ifndef HK_SMALL_PASS_NC
+#define HK_SMALL_PASS_NC 1536
+#endif
+bool launch_small_pass(hipStream_t s, int n_cu, const DPathState& st, const DScene& sc, const DTables& T, const DFrame& fr, const DFilter& flt, const DCamera& cam, const DSobol& sob, int max_depth,
+                       uint32_t kinds_mask, DStats* stats) {
+    const char* e = hk::knob("HK_SMALL_PASS_FUSED");   // 0: the stages as launches (A/B switch; films bit-identical)
+    if (e && std::atoi(e) == 0) return false;
+    if (!st.small_pass || st.dynamic_segments || !(sc.all_opaque && sc.n_media == 0) || sc.bvh_depth > 16 || sc.has_escape_lights || fr.count_nodes) return false;
+    if (kinds_mask != (1u << HK_MAT_MATTE) || !sc.simple_lights || preselect_lights(sc, st) || node_cache_mode() == 0) return false;
+    for (int depth = 0; depth < max_depth; ++depth)
+        if (sobol_tables_cover(sob, depth)) return false;
+    int blocks = cached_blocks<k_small_pass<HK_SMALL_PASS_NC>>(1024, n_cu, 1);
+    if (blocks * 16 > st.n_waves) blocks = st.n_waves / 16;
+    if (blocks < 1) return false;
+    hipLaunchKernelGGL((k_small_pass<HK_SMALL_PASS_NC>), dim3(blocks), dim3(1024), 0, s, st, sc, T, fr, flt, cam, sob, max_depth, sc.n_lights > 0 ? 1 : 0, stats);
+    return true;
 }
 void launch_film(hipStream_t s, const DPathState& st, const DFrame& fr, const DTables& T, void* accum, bool f64) {
     int g = grid_for(fr.n_pixels_padded >> 6, 4, 4096);   // one wave per 8x8 tile

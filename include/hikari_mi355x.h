@@ -311,6 +311,9 @@ typedef struct hk_stats {
        and its launches (not part of shade_launches) */
     double seconds_select;
     uint64_t select_launches;
+    /* passes rendered as ONE launch (k_small_pass: camera rays and every bounce of a small pass of a closed all-matte scene; the film
+       kernel follows).  Their stages are not counted in *_launches. */
+    uint64_t fused_passes;
 } hk_stats;
 
 typedef struct hk_ctx hk_ctx;

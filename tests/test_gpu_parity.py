@@ -772,4 +772,65 @@ def test_full_size_media_properties(hk):
     assert np.isfinite(a).all() and (a >= 0).all() and a.mean() > 0.01 and c1 > 1_000_000
     vp(s, film, cam)
     assert np.array_equal(a, film.framebuffer) and int(vp.stats().medium_collisions) == c1
-    vp.close()
+    vp.close()@pytest.mark.gpu
+def test_small_pass_in_one_launch(hk, knobs):
+    """k_small_pass: a small pass of a closed all-matte scene — the reference's interactive call, one sample of every pixel (volpath.jl:445-450)
+    — is ONE launch in which the wave that owns a segment runs the camera rays and every bounce's trace / shade / shadow stage of that
+    segment (a path never leaves its segment).  The accumulators must equal, bit for bit, those of the same calls rendered as launches
+    (HK_SMALL_PASS_FUSED=0), for one-sample calls and for a 24-sample pass, with an odd segment count too; hk_stats says which way was
+    taken; and scenes that are not its case (escape lights, a non-matte kind, media) keep the launches."""
+    from hikari_jl_amd import scenes
+    w, h = 72, 56
+
+    def run(scene, cam, film, env, plan, depth=7):
+        for k in ("HK_SMALL_PASS_FUSED", "HK_WAVES_PER_CU", "HK_SMALL_PASS_WAVES"):
+            knobs.delenv(k, raising=False)
+        knobs.setenv("HK_BATCH_PATHS_M", "0")              # every call rendered at once
+        for k, v in env.items():
+            knobs.setenv(k, v)
+        vp = hk.VolPath(max_depth=depth, samples=64)
+        vp._ensure(film)
+        vp.clear()
+        vp.reset_stats()
+        first = 1
+        for k in plan:
+            vp.render_samples(scene, film, cam, k, first=first, readback=False)
+            first += k
+        acc = vp.read_accumulators(film).copy()
+        st = vp.stats()
+        vp.close()
+        return acc, st
+
+    for objects in ("sphere_box", "two_spheres"):
+        s, film, cam = scenes.cornell_box(w, h, light="area", objects=objects)
+        for plan in ([1] * 6, [24], [1, 3, 1]):
+            ref, st0 = run(s, cam, film, {"HK_SMALL_PASS_FUSED": "0"}, plan)
+            assert int(st0.fused_passes) == 0 and int(st0.trace_launches) == 7 * len(plan)
+            assert np.isfinite(ref).all() and ref.max() > 0
+            for env in ({}, {"HK_SMALL_PASS_WAVES": "4"}, {"HK_WAVES_PER_CU": "3"}):
+                got, st1 = run(s, cam, film, env, plan)
+                if max(plan) == 1:                         # (larger passes have their Sobol draws in tables — k_shade's table-only instantiation — and keep the launches)
+                    assert int(st1.fused_passes) == len(plan) and int(st1.trace_launches) == 0, (env, plan)
+                assert int(st1.fused_passes) * 7 + int(st1.trace_launches) == 7 * len(plan)
+                assert np.array_equal(ref.view(np.uint32), got.view(np.uint32)), (objects, env, plan)
+                assert (int(st1.rays_closest), int(st1.rays_shadow), int(st1.hits_accepted), int(st1.path_vertices)) == \
+                       (int(st0.rays_closest), int(st0.rays_shadow), int(st0.hits_accepted), int(st0.path_vertices))
+    # not its case: an open scene (escape lights, several kinds), a conductor in the box, a point light only (still matte: fused), a medium
+    s, film, cam = scenes.sky_scene(w, h, env_res=32)
+    assert int(run(s, cam, film, {}, [1, 1])[1].fused_passes) == 0
+    s, film, cam = scenes.cornell_box(w, h, light="area", object_material=hk.ConductorMaterial(roughness=0.2))
+    assert int(run(s, cam, film, {}, [1, 1])[1].fused_passes) == 0
+    s, film, cam = scenes.cornell_box(w, h, light="point")
+    ref, st0 = run(s, cam, film, {"HK_SMALL_PASS_FUSED": "0"}, [1, 1])
+    got, st1 = run(s, cam, film, {}, [1, 1])
+    assert int(st1.fused_passes) == 2 and np.array_equal(ref.view(np.uint32), got.view(np.uint32))
+    s, film, cam = scenes.cloud_scene(w, h, "grid", res=(24, 24, 12))
+    assert int(run(s, cam, film, {}, [1, 1], depth=5)[1].fused_passes) == 0
+    for k in ("HK_SMALL_PASS_FUSED", "HK_WAVES_PER_CU", "HK_SMALL_PASS_WAVES", "HK_BATCH_PATHS_M"):
+        knobs.delenv(k, raising=False)
+    knobs.setenv("HK_WAVES_PER_CU", "0")                   # (sticky in the context: back to the default)
+    s, film, cam = scenes.cornell_box(w, h, light="area")
+    run(s, cam, film, {"HK_WAVES_PER_CU": "0"}, [1])
+
+
+

@@ -653,7 +653,7 @@ def test_medium_white_furnace_and_single_scatter(hk, oracle):
         s2.sync()
         return s2, cam
 
-    def walk_gain(tau, n=400000, seed=1):      # 1 + E[sum over collisions 1/4 (E2(z) + E2(tau - z))], normal incidence, isotropic scattering
+    def walk_gain(tau, n=200000, seed=1):      # 1 + E[sum over collisions 1/4 (E2(z) + E2(tau - z))], normal incidence, isotropic scattering
         rng = np.random.default_rng(seed)
         z, mu, alive, X = np.zeros(n), np.ones(n), np.ones(n, bool), np.zeros(n)
         while alive.any():
@@ -664,7 +664,7 @@ def test_medium_white_furnace_and_single_scatter(hk, oracle):
             mu = np.where(alive, 2.0 * rng.random(n) - 1.0, mu)
         return 1.0 + X.mean()
 
-    def walk_gain_hg(tau, g, n=400000, seed=2):
+    def walk_gain_hg(tau, g, n=200000, seed=2):
         """the same for a Henyey-Greenstein phase function: the next-event sample is uniform over the sphere (p_l = 1 / 4 pi) and carries the
         weight p_p / (p_l + p_p) with p_p the phase function towards it, times the transmittance to the slab's boundary in that direction"""
         rng = np.random.default_rng(seed)

@@ -32,7 +32,8 @@ void launch_detect_camera_medium(hipStream_t, const DPathState&, const DScene&, 
 void launch_shade(hipStream_t, int, int, const DPathState&, const DScene&, const DTables&, const DFrame&, const DSobol&, int, int, DStats*);
 bool grey_compact_ok(const DScene&);
 bool preselect_lights(const DScene&, const DPathState&);
-bool launch_small_pass(hipStream_t, int, const DPathState&, const DScene&, const DTables&, const DFrame&, const DFilter&, const DCamera&, const DSobol&, int, uint32_t, DStats*);
+bool small_pass_fusable(const DScene&, uint32_t);
+bool launch_small_pass(hipStream_t, int, const DPathState&, const DScene&, const DTables&, const DFrame&, const DFilter&, const DCamera&, const DSobol&, int, uint32_t, DStats*, bool, void*, int);
 void launch_light_select(hipStream_t, int, const DPathState&, const DScene&, const DTables&, const DFrame&, const DSobol&, int, uint32_t, DStats*);
 void launch_film(hipStream_t, const DPathState&, const DFrame&, const DTables&, void*, bool);
 void launch_segment_lists(hipStream_t, const DPathState&, int, const int*, const int*);
@@ -82,7 +83,7 @@ static const char* const KNOB_NAMES[] = {
     "HK_MID_LISTS", "HK_MID_PASS_PATHS_M", "HK_NODE_CACHE", "HK_NVDB_DENSE_MB", "HK_OVERLAP", "HK_PIPELINE", "HK_PIPELINE_AFTER", "HK_PIPELINE_MAX_PATHS_M", "HK_PRESELECT",
     "HK_SELECT_MIN_IDLE", "HK_SHADOW_FEED_ROUNDS", "HK_SHADOW_TRACK_BATCH", "HK_SMALL_PASS", "HK_SMALL_PASS_WAVES", "HK_SOBOL_LO_GB", "HK_SOBOL_TABLE_ONLY",
     "HK_STATE_CACHE_GB", "HK_STATE_SLAB", "HK_TICKET_SHARE", "HK_TRACK_ADVANCE", "HK_TRACK_EXTRA_ADVANCE", "HK_TRACK_MIN_PENDING", "HK_TRACK_POOL", "HK_TRACK_REFILL_IDLE",
-    "HK_WALK_POOL", "HK_WALK_REFILL_IDLE", "HK_WALK_SPLIT", "HK_WAVES_PER_CU", "HK_READBACK_PIN", "HK_DEFER_EXTERNAL", "HK_SELECT_POOL", "HK_SMALL_PASS_FUSED"};
+    "HK_WALK_POOL", "HK_WALK_REFILL_IDLE", "HK_WALK_SPLIT", "HK_WAVES_PER_CU", "HK_READBACK_PIN", "HK_DEFER_EXTERNAL", "HK_SELECT_POOL", "HK_SMALL_PASS_FUSED", "HK_SMALL_PASS_MERGED"};
 static bool known_knob(const char* name) {
     for (const char* k : KNOB_NAMES)
         if (std::strcmp(k, name) == 0) return true;
@@ -1534,7 +1535,7 @@ hipError_t alloc_arr(hk_integrator* I, T*& dst, size_t n) {
 //   surfaces, open scene      static stride, 48 per CU   (sky: most paths escape after 1-2 vertices; finer segments only fragment
 //                             the per-kind queues: k_shade +7 % at 96, +15 % at 256, whichever way they are handed out)
 // HK_WAVES_PER_CU / HK_DYNAMIC_SEGMENTS override.  stats rows are indexed by PHYSICAL wave (ctx->stat_rows).
-int ensure_state(hk_integrator* I, int capacity, bool media, bool open_scene, bool small_scene, bool grey_compact, hipStream_t users = nullptr) {
+int ensure_state(hk_integrator* I, int capacity, bool media, bool open_scene, bool small_scene, bool grey_compact, hipStream_t users = nullptr, bool fusable = false) {
     const int n_cu = I->ctx->n_cu;
     // a closed scene's pass of at most HK_MID_PASS_PATHS_M (48) million paths — a rank's share of a frame under 8-way strong scaling —
     // behaves like the open scene WHEN THE SCENE IS SMALL (BVH depth <= 16, the Cornell box): the deep bounces hold a few dozen rays per
@@ -1576,7 +1577,8 @@ int ensure_state(hk_integrator* I, int capacity, bool media, bool open_scene, bo
             // resident wave — 16 waves per CU is what k_trace_lean's 16-wave block and k_shade's 128 registers hold, and at 8 the 1024-thread
             // trace blocks covered half of the CUs.  An OPEN surface scene keeps 8: its deep bounces are empty and its glass / conductor
             // shade kernels hold fewer than 16 waves per CU.)
-            long per_cu = w && std::atoi(w) > 0 ? std::atoi(w) : (users ? (media ? 4 : 8) : ((open_scene && !media) ? 8 : 16));
+            // k_small_pass (`fusable`: the whole pass in one launch) likes 8: 1.05 ms against 1.14 at 16 — fuller chunks, no spills at two waves per SIMD.
+            long per_cu = w && std::atoi(w) > 0 ? std::atoi(w) : (users ? (media ? 4 : 8) : (((open_scene && !media) || fusable) ? 8 : 16));
             const long chunks = ((long)capacity + 63) / 64;
             while (per_cu > 4 && per_cu * n_cu > chunks) per_cu /= 2;   // (no segment without a chunk)
             if (I->ctx->waves_per_cu <= 0) W_want = (per_cu * n_cu + 3) / 4 * 4;
@@ -1863,7 +1865,8 @@ static int render_tile_now(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_film* f
         }
     } set_guard{I, piped ? &I->lane_sets[lane_idx] : nullptr};
     if (piped) I->swap_set(I->lane_sets[lane_idx]);
-    int st = ensure_state(I, S * fr.n_pixels_padded, sc->d.n_media > 0, sc->d.has_escape_lights != 0, sc->d.bvh_depth <= 16, sc->d.n_media > 0 && hk::grey_compact_ok(sc->d), piped ? c->lanes[lane_idx].stream : nullptr);
+    int st = ensure_state(I, S * fr.n_pixels_padded, sc->d.n_media > 0, sc->d.has_escape_lights != 0, sc->d.bvh_depth <= 16, sc->d.n_media > 0 && hk::grey_compact_ok(sc->d), piped ? c->lanes[lane_idx].stream : nullptr,
+                          !piped && !c->time_kernels && !c->count_nodes && hk::small_pass_fusable(sc->d, sc->kinds_mask));
     if (st != HK_OK) return st;
     fr.sample_stride = sample_stride;
     fr.max_depth = I->p.max_depth;
@@ -2012,14 +2015,22 @@ static int render_tile_now(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_film* f
             }
             return HK_OK;
         };
+        // a small pass of a closed all-matte scene: camera rays and every bounce in ONE launch (k_small_pass), then the film.  It takes no
+        // tickets, and every queue size it reads was written before by the same wave: the three clears below are not for it.
+        const bool fused = !c->time_kernels && !piped && hk::launch_small_pass(s, c->n_cu, I->st, sc->d, c->tables, fr, I->filter, dc, sob, I->p.max_depth, sc->kinds_mask, dstats, true, nullptr, 0);
+        if (!fused) {
         HIP_TRY(hipMemsetAsync(I->st.tickets, 0, (size_t)I->st.ticket_rows * HK_TICKET_COLS * HK_TICKET_WAYS * HK_TICKET_STRIDE * sizeof(int), s));
         // queue sizes start every pass at zero: a depth at which no shade / scatter kernel runs (a triangle-free scene lit by an
         // environment map, say) must not see the ray / shadow counts an earlier render left behind
         HIP_TRY(hipMemsetAsync(I->st.counters, 0, (size_t)(I->st_depth + 2) * Q_COUNT * I->st.n_waves * sizeof(int), s));
         if (I->st.wq_ctl) HIP_TRY(hipMemsetAsync(I->st.wq_ctl, 0, (size_t)(I->st_depth + 2) * 11 * 4 * sizeof(int), s));
-        // a small pass of a closed all-matte scene: camera rays and every bounce in ONE launch (k_small_pass), then the film
-        const bool fused = !c->time_kernels && !piped && hk::launch_small_pass(s, c->n_cu, I->st, sc->d, c->tables, fr, I->filter, dc, sob, I->p.max_depth, sc->kinds_mask, dstats);
-        if (fused) c->fused_passes++;
+        }
+        bool film_inline = false;
+        if (fused) {
+            film_inline = fr.samples_in_pass == 1;   // a one-sample pass adds its paths to the film itself
+            (void)hk::launch_small_pass(s, c->n_cu, I->st, sc->d, c->tables, fr, I->filter, dc, sob, I->p.max_depth, sc->kinds_mask, dstats, false, film->accum, film_inline ? (film->f64 ? 2 : 1) : 0);
+            c->fused_passes++;
+        }
         if (!fused) {
         if (timed(3, [&] { hk::launch_camera(s, c->n_cu, I->st, fr, c->tables, I->filter, dc, sob, -1); }) != HK_OK) return fail(HK_ERR_DEVICE, "event record failed");
         // work lists: after every producer, the non-empty segments of the queues it filled (consumers never visit an empty segment)
@@ -2113,7 +2124,7 @@ static int render_tile_now(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_film* f
         }
         }   // !fused
         if (piped && c->film_chain) HIP_TRY(hipStreamWaitEvent(s, c->ev_film, 0));   // the film sums in call order
-        if (timed(3, [&] { hk::launch_film(s, I->st, fr, c->tables, film->accum, film->f64); }) != HK_OK) return fail(HK_ERR_DEVICE, "event record failed");
+        if (!film_inline && timed(3, [&] { hk::launch_film(s, I->st, fr, c->tables, film->accum, film->f64); }) != HK_OK) return fail(HK_ERR_DEVICE, "event record failed");
         if (piped) {
             HIP_TRY(hipEventRecord(c->ev_film, s));
             c->film_chain = true;

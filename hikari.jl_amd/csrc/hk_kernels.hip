@@ -732,6 +732,7 @@ struct LaneRay {   // per-lane traversal state
     HitRec best;
     int cur, sp;
     int pend;   // a postponed leaf reference, or DONE (0x80000000) for none; cur == DONE implies pend == DONE
+    bool any;   // lane_ray_round<.., MIXED>: this lane's ray is an any-hit (shadow) ray among closest-hit rays (trace_shadow_body)
 };
 HKD void lane_ray_start(LaneRay& r, const DScene& sc, v3 o, v3 d, float t_max) {
     r.o = o;
@@ -744,10 +745,13 @@ HKD void lane_ray_start(LaneRay& r, const DScene& sc, v3 o, v3 d, float t_max) {
     r.sp = 0;
     r.cur = sc.n_tris == 0 ? (int)0x80000000 : sc.root_ref;
     r.pend = (int)0x80000000;
+    r.any = false;
 }
 // one while-while round for the lanes with `active`: inner nodes until every such lane holds a leaf (or is done), then the leaves.
 // ANYHIT: the first accepted triangle ends the ray (cur = DONE, best.prim >= 0).
-template <bool ANYHIT, bool COUNT, int NC = 0, bool POSTPONE = (ANYHIT ? HK_POSTPONE_ANYHIT != 0 : HK_POSTPONE_CLOSEST != 0)>
+// MIXED (with ANYHIT = false): closest-hit and any-hit rays share the wave, LaneRay::any says which a lane holds; the round's rules are the
+// closest-hit kernel's, a lane's leaf test is its own kind's.
+template <bool ANYHIT, bool COUNT, int NC = 0, bool POSTPONE = (ANYHIT ? HK_POSTPONE_ANYHIT != 0 : HK_POSTPONE_CLOSEST != 0), bool MIXED = false>
 HKD void lane_ray_round(LaneRay& r, bool active, const DScene& sc, int* __restrict__ stack, int lane, unsigned& n_nodes, unsigned& n_tris, const NodeCache& cache = NodeCache(),
                         bool may_wait = false
 #ifdef HK_DEBUG_UTIL
@@ -829,7 +833,7 @@ HKD void lane_ray_round(LaneRay& r, bool active, const DScene& sc, int* __restri
         int ref = ~(has_pend ? r.pend : r.cur);
         int first = ref >> 3, count = (ref & 7) + 1;
         bool stop = false;
-        if (!ANYHIT) {
+        if (!ANYHIT && !MIXED) {
             // closest hit tests every triangle of the leaf, so the next one is fetched while this one is tested (trace -4 % in the
             // Cornell box, -2 % elsewhere); the any-hit loop below usually stops early and is better off without (shadow +1 %)
             const float4* tp = sc.leaf_tris + 3 * (size_t)first;
@@ -862,7 +866,7 @@ HKD void lane_ray_round(LaneRay& r, bool active, const DScene& sc, int* __restri
             float t, u, v;
             if (intersect_triangle(r.o, r.d, r.t_max, mk3(T0.x, T0.y, T0.z), mk3(T1.x, T1.y, T1.z), mk3(T2.x, T2.y, T2.z), t, u, v)) {
                 int prim = __float_as_int(T0.w);
-                if (ANYHIT) {
+                if (MIXED ? r.any : ANYHIT) {
                     r.best.t = t;
                     r.best.prim = prim;
                     stop = true;
@@ -2121,8 +2125,8 @@ __global__ void __launch_bounds__(64) k_detect_camera_medium(DPathState st, DSce
 // ---------------------------------------------------------------------------------------------------
 // K7: escaped rays (intersection.jl:622-678; lights.jl:408-467).  MIS uses 1/num_lights (Q6).
 // ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_escaped(DPathState st, DScene sc, DTables T, int depth, int implicit_ones) {
-    HK_FOR_EACH_WAVE_SEGMENT(gw, st, ticket_ptr(st, depth, TK_ESCAPED), depth, Q_ESCAPED) {
+__device__ __forceinline__ void escaped_body(const DPathState& st, const DScene& sc, const DTables& T, int depth, int implicit_ones, const SegTickets& src) {
+    HK_FOR_EACH_SEGMENT_FROM(gw, st, src) {
     const uint32_t* __restrict__ queue = st.escaped_q + (size_t)gw * st.wave_cap;
     const int n = *count_ptr(st, depth, Q_ESCAPED, gw);
     const DPathGen g = st.gen[depth & 1];
@@ -2172,6 +2176,9 @@ __global__ void __launch_bounds__(256) k_escaped(DPathState st, DScene sc, DTabl
         st4(&st.L[meta.y], ld4(&st.L[meta.y]) + fin);
     }
     }
+}
+__global__ void __launch_bounds__(256) k_escaped(DPathState st, DScene sc, DTables T, int depth, int implicit_ones) {
+    escaped_body(st, sc, T, depth, implicit_ones, seg_open(st, ticket_ptr(st, depth, TK_ESCAPED), st.dynamic_segments != 0, depth, Q_ESCAPED));
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2990,6 +2997,121 @@ __global__ void __launch_bounds__(BLOCK) k_shadow(DPathState st, DScene sc, int 
     shadow_body<COUNT, NC>(st, sc, depth, stats, stream_open(st, ticket_ptr(st, depth, TK_SHADOW), false, depth, Q_SHADOW), stack, cache);
 }
 
+// K10 of bounce `depth` and K2 of bounce `depth + 1` of ONE segment in one per-lane-refill loop (k_small_pass): after the shade stage
+// the segment's shadow rays and its next generation of rays are both there and depend on nothing but it, so idle lanes take whichever is
+// left (shadow records first) and the wave keeps twice the rays in flight — one drain instead of two, fuller rounds.  Per ray nothing
+// changes: an any-hit ray ends at its first accepted triangle and delivers its contribution (shadow_body), a closest-hit ray is routed
+// as trace_lean_body routes it; a path's L sees the same additions in the same order (its shadow ray of this bounce, then whatever
+// bounce depth + 1 adds in the NEXT stage).
+template <int NC>
+__device__ __forceinline__ void trace_shadow_body(const DPathState& st, const DScene& sc, int depth, DStats* stats, int gw, int* __restrict__ stack, const NodeCache& cache) {
+    const int lane = lane_id();
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const int DONE = (int)0x80000000;
+    unsigned n_nodes = 0, n_tris = 0, n_casts = 0, n_hits = 0, n_sh_casts = 0;
+    const int dt = depth + 1;
+    const DPathGen g = st.gen[dt & 1];
+    const uint32_t seg = (uint32_t)gw * (uint32_t)st.wave_cap;
+    const int n_ray = *count_ptr(st, dt, Q_RAY, gw), n_sh = *count_ptr(st, depth, Q_SHADOW, gw);
+    WaveQ q_escaped = wq_open(st.escaped_q, st, gw);
+    int kind_count[HK_MAX_KINDS];
+#pragma unroll
+    for (int k = 0; k < HK_MAX_KINDS; ++k) kind_count[k] = 0;
+    int cur_ray = 0, cur_sh = 0;
+    int state = LR_EMPTY;
+    uint32_t slot = 0;
+    LaneRay r;
+    r.cur = r.pend = DONE;
+    r.any = false;
+    for (;;) {
+        const unsigned long long run_m = __ballot(state == LR_ACTIVE && r.cur != DONE);
+        if (run_m == 0ull || (64 - __popcll(run_m) >= HK_TRACE_MIN_IDLE && (cur_ray < n_ray || cur_sh < n_sh))) {
+            int kind = -1;
+            if (state == LR_ACTIVE && r.cur == DONE) {
+                if (r.any) {   // a shadow ray: unoccluded, it delivers its contribution
+                    if (r.best.prim < 0)
+                        shadow_contribute<true>(st, slot, s4(1.0f), s4(1.0f), s4(1.0f));
+                    else
+                        ++n_hits;
+                } else if (r.best.prim < 0)
+                    kind = -2;
+                else {
+                    ++n_hits;
+                    const DTriMeta hm = sc.meta[r.best.prim];
+                    int mat = sc.mis[hm.mi].material;
+                    if (sc.materials[mat].kind == HK_MAT_MIX) {
+                        float w = 1.0f - r.best.u - r.best.v;
+                        mat = resolve_mix_material(sc, mat, r.o + r.d * r.best.t, -r.d, uv_at(sc, r.best.prim, w, r.best.u, r.best.v));
+                    }
+                    kind = sc.materials[mat].kind;
+                    if (kind == HK_MAT_MIX) kind = HK_MAT_FALLBACK;
+                    stream_st(&st.hit[slot], make_float4(r.best.t, __int_as_float(r.best.prim), r.best.u, r.best.v));
+                    stream_st(reinterpret_cast<uint32_t*>(st.mat_id) + slot, (uint32_t)(mat | (hm.arealight > 0 ? HK_MAT_EMISSIVE_BIT : 0)));
+                }
+                state = LR_EMPTY;
+            }
+            wq_push(q_escaped, slot, kind == -2);
+            unsigned long long pending = __ballot(kind >= 0);
+            while (pending) {
+                int src = __ffsll((long long)pending) - 1;
+                const int k = __builtin_amdgcn_readlane(kind, src);
+                bool mine = kind == k;
+                unsigned long long m = __ballot(mine);
+                int cnt = 0;
+#pragma unroll
+                for (int kk = 0; kk < HK_MAX_KINDS; ++kk) cnt = (kk == k) ? kind_count[kk] : cnt;
+                if (mine) stream_st(&st.mat_q[((size_t)k * st.n_waves + gw) * st.wave_cap + cnt + __popcll(m & lt_mask)], slot);
+                int add = __popcll(m);
+#pragma unroll
+                for (int kk = 0; kk < HK_MAX_KINDS; ++kk) kind_count[kk] += (kk == k) ? add : 0;
+                pending &= ~m;
+            }
+            // ---- refill: the shadow records first, then the rays of the next bounce ----
+            const unsigned long long want = __ballot(state == LR_EMPTY);
+            const int avail_sh = n_sh - cur_sh, avail_ray = n_ray - cur_ray;
+            const int rank = __popcll(want & lt_mask);
+            if (state == LR_EMPTY) {
+                if (rank < avail_sh) {
+                    slot = seg + (uint32_t)(cur_sh + rank);
+                    float4 O = stream_ld(&st.sh_o[slot]), D = stream_ld(&st.sh_d[slot]);
+                    if (O.w >= 1e-6f) {   // a degenerate shadow ray is simply not visible
+                        ++n_sh_casts;
+                        lane_ray_start(r, sc, mk3(O.x, O.y, O.z), mk3(D.x, D.y, D.z), O.w);
+                        r.any = true;
+                        state = LR_ACTIVE;
+                    }
+                } else if (rank - avail_sh < avail_ray) {
+                    slot = seg + (uint32_t)(cur_ray + rank - avail_sh);
+                    float4 O = stream_ld(&g.ray_o[slot]), D = stream_ld(&g.ray_d[slot]);
+                    ++n_casts;
+                    lane_ray_start(r, sc, mk3(O.x, O.y, O.z), mk3(D.x, D.y, D.z), O.w);
+                    state = LR_ACTIVE;
+                }
+            }
+            const int want_n = __popcll(want);
+            const int take_sh = want_n < avail_sh ? want_n : avail_sh;
+            const int rest = want_n - take_sh;
+            cur_sh += take_sh;
+            cur_ray += rest < avail_ray ? rest : avail_ray;
+            if (__ballot(state == LR_ACTIVE) == 0ull) {
+                if (cur_ray >= n_ray && cur_sh >= n_sh) break;
+                continue;   // (only degenerate shadow rays were drawn: draw again)
+            }
+        }
+        lane_ray_round<false, false, NC, false, true>(r, state == LR_ACTIVE && r.cur != DONE, sc, stack, lane, n_nodes, n_tris, cache, cur_ray < n_ray || cur_sh < n_sh);
+    }
+    wq_close(q_escaped, count_ptr(st, dt, Q_ESCAPED, gw));
+    if (lane == 0) {
+        *count_ptr(st, dt, Q_MEDIUM, gw) = 0;
+#pragma unroll
+        for (int k = 0; k < HK_MAX_KINDS; ++k) *count_ptr(st, dt, Q_MAT0 + k, gw) = kind_count[k];
+    }
+    stats += global_wave();
+    wave_add(&stats->rays_closest, n_casts);
+    wave_add(&stats->rays_shadow, n_sh_casts);
+    wave_add(&stats->hits, n_hits);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // A SMALL pass as ONE launch (the reference's interactive call: one sample of every pixel, volpath.jl:445-450).  A path never leaves the
 // segment that generated its camera ray, so K1 and every bounce's K2 / K8 - K9 / K10 of a segment depend on nothing outside it: the wave
@@ -3002,14 +3124,18 @@ __global__ void __launch_bounds__(BLOCK) k_shadow(DPathState st, DScene sc, int 
 // For: all-opaque scenes without media, escape lights or light preselection whose only material kind is Matte under simple lights
 // (launch_small_pass says which; everything else keeps the launches).
 // ---------------------------------------------------------------------------------------------------
+template <typename ACC>
+__device__ __forceinline__ void film_tile(const DPathState& st, const DFrame& fr, const DTables& T, ACC* __restrict__ accum, float* __restrict__ mine, int tile);
 __device__ __forceinline__ void stage_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
-template <int NC>
-__global__ void __attribute__((amdgpu_flat_work_group_size(1024, 1024), amdgpu_waves_per_eu(4))) k_small_pass(DPathState st, DScene sc, DTables T, DFrame fr, DFilter flt, DCamera cam, DSobol sob, int max_depth,
-                                                                                                                int shadows, DStats* stats) {
-    constexpr int STACK = 16, BLOCK = 1024;
+// GENERAL: the kinds with a light-weight shade body — Matte (under any lights), Mirror, Glass, Conductor — whichever the scene has, and K7 for
+// escape lights (escaped_body); two waves per SIMD (512-thread blocks and below), where the union of their registers fits.
+template <int NC, int BLOCK, bool GENERAL = false>
+__global__ void __attribute__((amdgpu_flat_work_group_size(BLOCK, BLOCK), amdgpu_waves_per_eu(BLOCK / 256))) k_small_pass(DPathState st, DScene sc, DTables T, DFrame fr, DFilter flt, DCamera cam, DSobol sob,
+                                                                                                                            int max_depth, int shadows, int merged, void* accum, int film_mode, uint32_t kinds_mask, DStats* stats) {
+    constexpr int STACK = 16;
     __shared__ int lds_stack[(BLOCK / 64) * STACK * 64];
     __shared__ float4 lds_box[3 * NC];
     __shared__ int2 lds_child[NC];
@@ -3017,19 +3143,72 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(1024, 1024), amdgpu_w
     int* stack = lds_stack + (threadIdx.x >> 6) * (STACK * 64);
     uint32_t* elist = emit_list + (threadIdx.x >> 6) * 128;
     const NodeCache cache = node_cache_fill<NC, BLOCK>(sc, lds_box, lds_child);
+#ifdef HK_DEBUG_UTIL   // cycles per wave and stage (probes 10 - 13: camera, trace, shade, shadow — "x of y": average cycles of a wave's stage calls / 64)
+    unsigned long long t_stage[4] = {0, 0, 0, 0}, n_stage[4] = {0, 0, 0, 0};
+#define HK_STAGE_T(i, call) do { const unsigned long long t0_ = __builtin_readcyclecounter(); call; t_stage[i] += __builtin_readcyclecounter() - t0_; n_stage[i] += 64; } while (0)
+#else
+#define HK_STAGE_T(i, call) call
+#endif
     for (int g = global_wave(); g < st.n_waves; g += physical_waves()) {
-        camera_body(st, fr, T, flt, cam, sob, seg_single(st, g));
+        HK_STAGE_T(0, camera_body(st, fr, T, flt, cam, sob, seg_single(st, g)));
+        stage_fence();
+        HK_STAGE_T(1, (trace_lean_body<false, NC>(st, sc, 0, stats, seg_single(st, g), stack, cache)));
         for (int depth = 0; depth < max_depth; ++depth) {
             stage_fence();
-            trace_lean_body<false, NC>(st, sc, depth, stats, seg_single(st, g), stack, cache);
+            if (!GENERAL)
+                HK_STAGE_T(2, (shade_body<HK_MAT_MATTE, true, false, false>(st, sc, T, fr, sob, depth, 1, stats, seg_single(st, g), elist)));
+            else {
+                if (sc.has_escape_lights) escaped_body(st, sc, T, depth, fr.implicit_ones, seg_single(st, g));
+                int first_kind = 1;   // the kinds in ascending order, each continuing the shadow / next-ray queues of the one before (as the launches do)
+#define HK_SMALL_KIND(K, S)                                                                                                                   \
+    if (kinds_mask & (1u << K)) {                                                                                                             \
+        if (!first_kind) stage_fence();                                                                                                       \
+        HK_STAGE_T(2, (shade_body<K, S, false, false>(st, sc, T, fr, sob, depth, first_kind, stats, seg_single(st, g), elist)));            \
+        first_kind = 0;                                                                                                                       \
+    }
+                if (sc.simple_lights) {
+                    HK_SMALL_KIND(HK_MAT_MATTE, true)
+                } else {
+                    HK_SMALL_KIND(HK_MAT_MATTE, false)
+                }
+                HK_SMALL_KIND(HK_MAT_MIRROR, false)
+                HK_SMALL_KIND(HK_MAT_GLASS, false)
+                HK_SMALL_KIND(HK_MAT_CONDUCTOR, false)
+#undef HK_SMALL_KIND
+            }
             stage_fence();
-            shade_body<HK_MAT_MATTE, true, false, false>(st, sc, T, fr, sob, depth, 1, stats, seg_single(st, g), elist);
-            if (shadows) {
-                stage_fence();
-                shadow_body<false, NC>(st, sc, depth, stats, seg_single(st, g), stack, cache);
+            // the shadow rays of this bounce and the rays of the next one, together (trace_shadow_body)
+            if (depth + 1 < max_depth) {
+                if (shadows && merged)
+                    HK_STAGE_T(3, (trace_shadow_body<NC>(st, sc, depth, stats, g, stack, cache)));
+                else {
+                    if (shadows) HK_STAGE_T(3, (shadow_body<false, NC>(st, sc, depth, stats, seg_single(st, g), stack, cache)));
+                    HK_STAGE_T(1, (trace_lean_body<false, NC>(st, sc, depth + 1, stats, seg_single(st, g), stack, cache)));
+                }
+            } else if (shadows)
+                HK_STAGE_T(3, (shadow_body<false, NC>(st, sc, depth, stats, seg_single(st, g), stack, cache)));
+        }
+        // K12 for a one-sample pass: chunk c of the camera IS tile c, and this segment's chunks are g, g + W, ... — the wave adds its own
+        // paths to the film (film_tile: k_film's arithmetic; the traversal stacks are free now: 256 of their floats stage the colours)
+        if (film_mode) {
+            stage_fence();
+            const int n_tiles = fr.n_pixels_padded >> 6;
+            for (int tile = g; tile < n_tiles; tile += st.n_waves) {
+                if (film_mode == 2)
+                    film_tile<double>(st, fr, T, (double*)accum, reinterpret_cast<float*>(stack), tile);
+                else
+                    film_tile<float>(st, fr, T, (float*)accum, reinterpret_cast<float*>(stack), tile);
             }
         }
     }
+#ifdef HK_DEBUG_UTIL
+    if (lane_id() == 0)
+        for (int i = 0; i < 4; ++i) {
+            (stats + global_wave())->dbg[20 + 2 * i] += n_stage[i];
+            (stats + global_wave())->dbg[21 + 2 * i] += t_stage[i];
+        }
+#endif
+#undef HK_STAGE_T
 }
 
 #ifndef HK_GREY_WALK_WAVES
@@ -4221,20 +4400,16 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
 // The wavelength pdfs are a function of the wavelengths alone (sample_wavelengths_visible: pdf = visible_wavelengths_pdf(lambda), the
 // same expression on the same bits): the film kernel recomputes them instead of reading 16 B per sample that k_camera had to write.
 HKD S4 pdf_of(S4 l) { return s4(visible_wavelengths_pdf(l.x), visible_wavelengths_pdf(l.y), visible_wavelengths_pdf(l.z), visible_wavelengths_pdf(l.w)); }
+// One 8x8 pixel tile = a contiguous run of 64 * S path slots, by one wave.  The run is read 64 slots at a time (coalesced; the colour
+// conversion — twelve IEEE divisions and table reads per sample, the bulk of this kernel — runs on all lanes), the weighted
+// colours go through LDS (`mine`: 256 floats of the wave), and the entries of a pixel are added one after the other IN SAMPLE ORDER, as
+// the reference adds them (so the film does not depend on the pass size): lanes 4p .. 4p+3 own the four channels of the p-th pixel met
+// in the step.
 template <typename ACC>
-__global__ void __launch_bounds__(256) k_film(DPathState st, DFrame fr, DTables T, ACC* __restrict__ accum) {
-    // One wave per 8x8 pixel tile = a contiguous run of 64 * S path slots.  The run is read 64 slots at a time (coalesced; the colour
-    // conversion — twelve IEEE divisions and table reads per sample, the bulk of this kernel — runs on all lanes), the weighted
-    // colours go through LDS, and the entries of a pixel are added one after the other IN SAMPLE ORDER, as the reference adds them
-    // (so the film does not depend on the pass size): lanes 4p .. 4p+3 own the four channels of the p-th pixel met in the step.
-    __shared__ float buf[4][64 * 4];
-    float* mine = buf[threadIdx.x >> 6];
+__device__ __forceinline__ void film_tile(const DPathState& st, const DFrame& fr, const DTables& T, ACC* __restrict__ accum, float* __restrict__ mine, int tile) {
     const int lane = lane_id();
     const int S = fr.samples_in_pass;
-    const int n_tiles = fr.n_pixels_padded >> 6;
     const size_t N = (size_t)fr.width * fr.height;
-    const int n_waves = (int)(gridDim.x * (blockDim.x >> 6));
-    for (int tile = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)); tile < n_tiles; tile += n_waves) {
         const size_t base = (size_t)tile * 64 * S;
         // pass sizes that tile the 64-slot steps (S a multiple of 64, or 4 / 8 / 16 / 32): whole pixels per step, one quad per pixel;
         // any other S: one lane per pixel walks the steps.  Both add in sample order.
@@ -4312,7 +4487,14 @@ __global__ void __launch_bounds__(256) k_film(DPathState st, DFrame fr, DTables 
                 accum[3 * N + p] = w;
             }
         }
-    }
+}
+template <typename ACC>
+__global__ void __launch_bounds__(256) k_film(DPathState st, DFrame fr, DTables T, ACC* __restrict__ accum) {
+    __shared__ float buf[4][64 * 4];
+    float* mine = buf[threadIdx.x >> 6];
+    const int n_tiles = fr.n_pixels_padded >> 6;
+    const int n_waves = (int)(gridDim.x * (blockDim.x >> 6));
+    for (int tile = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)); tile < n_tiles; tile += n_waves) film_tile<ACC>(st, fr, T, accum, mine, tile);
 }
 
 // K13 (volpath.jl:384-417): out = Julia Matrix{RGB{Float32}}[height,width] column-major
@@ -5034,18 +5216,47 @@ void launch_shade(hipStream_t s, int n_cu, int kind, const DPathState& st, const
 #ifndef HK_SMALL_PASS_NC
 #define HK_SMALL_PASS_NC 1536
 #endif
+// the scenes k_small_pass is instantiated for (the pass itself must be a small one: launch_small_pass): -> 0 none, 1 the all-matte closed
+// scene under simple lights, 2 the general instantiation (Matte / Mirror / Glass / Conductor, escape lights)
+static int small_pass_class(const DScene& sc, uint32_t kinds_mask) {
+    const char* e = hk::knob("HK_SMALL_PASS_FUSED");   // 0: the stages as launches, 1: only the all-matte instantiation (A/B switch; films bit-identical)
+    const int mode = e ? std::atoi(e) : 2;
+    if (mode == 0) return 0;
+    if (!(sc.all_opaque && sc.n_media == 0 && sc.bvh_depth <= 16 && sc.num_bvh_lights < HK_PRESELECT_MIN && node_cache_mode() != 0)) return 0;
+    if (kinds_mask == (1u << HK_MAT_MATTE) && sc.simple_lights && !sc.has_escape_lights) return 1;
+    const uint32_t light_kinds = (1u << HK_MAT_MATTE) | (1u << HK_MAT_MIRROR) | (1u << HK_MAT_GLASS) | (1u << HK_MAT_CONDUCTOR);
+    return (mode >= 2 && kinds_mask != 0 && (kinds_mask & ~light_kinds) == 0) ? 2 : 0;
+}
+bool small_pass_fusable(const DScene& sc, uint32_t kinds_mask) { return small_pass_class(sc, kinds_mask) != 0; }
 bool launch_small_pass(hipStream_t s, int n_cu, const DPathState& st, const DScene& sc, const DTables& T, const DFrame& fr, const DFilter& flt, const DCamera& cam, const DSobol& sob, int max_depth,
-                       uint32_t kinds_mask, DStats* stats) {
-    const char* e = hk::knob("HK_SMALL_PASS_FUSED");   // 0: the stages as launches (A/B switch; films bit-identical)
-    if (e && std::atoi(e) == 0) return false;
-    if (!st.small_pass || st.dynamic_segments || !(sc.all_opaque && sc.n_media == 0) || sc.bvh_depth > 16 || sc.has_escape_lights || fr.count_nodes) return false;
-    if (kinds_mask != (1u << HK_MAT_MATTE) || !sc.simple_lights || preselect_lights(sc, st) || node_cache_mode() == 0) return false;
+                       uint32_t kinds_mask, DStats* stats, bool dry, void* accum, int film_mode) {   // dry: only say whether this pass would be launched; film_mode: 0 the caller launches k_film, 1 / 2: float / double accumulators, added inside (one-sample passes)
+    const int cls = small_pass_class(sc, kinds_mask);
+    if (cls == 0 || !st.small_pass || st.dynamic_segments || fr.count_nodes || preselect_lights(sc, st)) return false;
     for (int depth = 0; depth < max_depth; ++depth)
         if (sobol_tables_cover(sob, depth)) return false;
-    int blocks = cached_blocks<k_small_pass<HK_SMALL_PASS_NC>>(1024, n_cu, 1);
-    if (blocks * 16 > st.n_waves) blocks = st.n_waves / 16;
-    if (blocks < 1) return false;
-    hipLaunchKernelGGL((k_small_pass<HK_SMALL_PASS_NC>), dim3(blocks), dim3(1024), 0, s, st, sc, T, fr, flt, cam, sob, max_depth, sc.n_lights > 0 ? 1 : 0, stats);
+    // one block per CU (its LDS: 16-entry stacks, the top of the tree, the emission lists) of as many waves as the pass has segments per CU
+    const char* me = hk::knob("HK_SMALL_PASS_MERGED");   // 0: shadow rays and the next bounce's rays as two stages (A/B switch; films bit-identical)
+    const int merged = (me && std::atoi(me) == 0) ? 0 : 1;
+#define HK_SMALL_PASS_LAUNCH(B, G)                                                                                                                          \
+    {                                                                                                                                                       \
+        int blocks = cached_blocks<k_small_pass<HK_SMALL_PASS_NC, B, G>>(B, n_cu, 1);                                                                       \
+        if (blocks * (B / 64) > st.n_waves) blocks = st.n_waves / (B / 64);                                                                                 \
+        if (blocks < 1) return false;                                                                                                                       \
+        if (!dry) hipLaunchKernelGGL((k_small_pass<HK_SMALL_PASS_NC, B, G>), dim3(blocks), dim3(B), 0, s, st, sc, T, fr, flt, cam, sob, max_depth, sc.n_lights > 0 ? 1 : 0, merged, accum, film_mode, kinds_mask, stats); \
+    }
+    // (Cornell 800^2, one sample per call: 1.42 / 1.05 / 1.14 ms at 4 / 8 / 16 segments per CU — 256- / 512- / 1024-thread blocks; a 768-thread
+    // block for 12: 1.55.  Eight waves per CU hold 312 paths each: chunks stay fuller down the bounces than with 156, and at two waves per
+    // SIMD nothing spills.)
+    if (cls == 2) {   // the general instantiation wants its registers: two waves per SIMD at most
+        if (st.n_waves > 8 * n_cu) return false;
+        if (st.n_waves > 4 * n_cu) HK_SMALL_PASS_LAUNCH(512, true)
+        else HK_SMALL_PASS_LAUNCH(256, true)
+        return true;
+    }
+    if (st.n_waves > 8 * n_cu) HK_SMALL_PASS_LAUNCH(1024, false)
+    else if (st.n_waves > 4 * n_cu) HK_SMALL_PASS_LAUNCH(512, false)
+    else HK_SMALL_PASS_LAUNCH(256, false)
+#undef HK_SMALL_PASS_LAUNCH
     return true;
 }
 void launch_film(hipStream_t s, const DPathState& st, const DFrame& fr, const DTables& T, void* accum, bool f64) {

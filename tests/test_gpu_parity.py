@@ -778,17 +778,19 @@ def test_small_pass_in_one_launch(hk, knobs):
     — is ONE launch in which the wave that owns a segment runs the camera rays and every bounce's trace / shade / shadow stage of that
     segment (a path never leaves its segment).  The accumulators must equal, bit for bit, those of the same calls rendered as launches
     (HK_SMALL_PASS_FUSED=0), for one-sample calls and for a 24-sample pass, with an odd segment count too; hk_stats says which way was
-    taken; and scenes that are not its case (escape lights, a non-matte kind, media) keep the launches."""
+    taken; scenes with Mirror / Glass / Conductor surfaces or escape lights take the GENERAL instantiation, and scenes that are not its
+    case (a layered kind, media) keep the launches.  Inside it the shadow rays of a bounce
+    and the rays of the next one share one refill loop (trace_shadow_body; HK_SMALL_PASS_MERGED=0: two stages)."""
     from hikari_jl_amd import scenes
     w, h = 72, 56
 
-    def run(scene, cam, film, env, plan, depth=7):
-        for k in ("HK_SMALL_PASS_FUSED", "HK_WAVES_PER_CU", "HK_SMALL_PASS_WAVES"):
+    def run(scene, cam, film, env, plan, depth=7, eltype="Float32"):
+        for k in ("HK_SMALL_PASS_FUSED", "HK_WAVES_PER_CU", "HK_SMALL_PASS_WAVES", "HK_SMALL_PASS_MERGED"):
             knobs.delenv(k, raising=False)
         knobs.setenv("HK_BATCH_PATHS_M", "0")              # every call rendered at once
         for k, v in env.items():
             knobs.setenv(k, v)
-        vp = hk.VolPath(max_depth=depth, samples=64)
+        vp = hk.VolPath(max_depth=depth, samples=64, accumulation_eltype=eltype)
         vp._ensure(film)
         vp.clear()
         vp.reset_stats()
@@ -807,7 +809,7 @@ def test_small_pass_in_one_launch(hk, knobs):
             ref, st0 = run(s, cam, film, {"HK_SMALL_PASS_FUSED": "0"}, plan)
             assert int(st0.fused_passes) == 0 and int(st0.trace_launches) == 7 * len(plan)
             assert np.isfinite(ref).all() and ref.max() > 0
-            for env in ({}, {"HK_SMALL_PASS_WAVES": "4"}, {"HK_WAVES_PER_CU": "3"}):
+            for env in ({}, {"HK_SMALL_PASS_WAVES": "4"}, {"HK_SMALL_PASS_WAVES": "16"}, {"HK_WAVES_PER_CU": "3"}, {"HK_SMALL_PASS_MERGED": "0"}, {"HK_SMALL_PASS_MERGED": "0", "HK_SMALL_PASS_WAVES": "16"}):      # (256- / 512- / 1024-thread blocks of k_small_pass, an odd segment count)
                 got, st1 = run(s, cam, film, env, plan)
                 if max(plan) == 1:                         # (larger passes have their Sobol draws in tables — k_shade's table-only instantiation — and keep the launches)
                     assert int(st1.fused_passes) == len(plan) and int(st1.trace_launches) == 0, (env, plan)
@@ -815,18 +817,43 @@ def test_small_pass_in_one_launch(hk, knobs):
                 assert np.array_equal(ref.view(np.uint32), got.view(np.uint32)), (objects, env, plan)
                 assert (int(st1.rays_closest), int(st1.rays_shadow), int(st1.hits_accepted), int(st1.path_vertices)) == \
                        (int(st0.rays_closest), int(st0.rays_shadow), int(st0.hits_accepted), int(st0.path_vertices))
-    # not its case: an open scene (escape lights, several kinds), a conductor in the box, a point light only (still matte: fused), a medium
-    s, film, cam = scenes.sky_scene(w, h, env_res=32)
-    assert int(run(s, cam, film, {}, [1, 1])[1].fused_passes) == 0
-    s, film, cam = scenes.cornell_box(w, h, light="area", object_material=hk.ConductorMaterial(roughness=0.2))
-    assert int(run(s, cam, film, {}, [1, 1])[1].fused_passes) == 0
-    s, film, cam = scenes.cornell_box(w, h, light="point")
+    # a Float64 film (the one-sample pass adds its paths to the film inside the launch: film_tile<double>)
+    s, film, cam = scenes.cornell_box(w, h, light="area")
+    ref, st0 = run(s, cam, film, {"HK_SMALL_PASS_FUSED": "0"}, [1] * 5, eltype="Float64")
+    got, st1 = run(s, cam, film, {}, [1] * 5, eltype="Float64")
+    assert ref.dtype == np.float64 and int(st1.fused_passes) == 5 and int(st0.fused_passes) == 0 and np.array_equal(ref.view(np.uint64), got.view(np.uint64))
+    # the GENERAL instantiation (Matte under any lights, Mirror, Glass, Conductor; K7 for escape lights): the sky scene (glass sphere, gold
+    # slab, environment map + sun), the box with a rough conductor / a glass / a mirror object, every light kind at once
+    R = hk.RGBSpectrum
+    cases = [scenes.sky_scene(w, h, env_res=32),
+             scenes.cornell_box(w, h, light="area", object_material=hk.ConductorMaterial(roughness=0.2)),
+             scenes.cornell_box(w, h, light="all", object_material=hk.GlassMaterial(Kr=R(1.0), Kt=R(1.0), index=1.5)),
+             scenes.cornell_box(w, h, light="both", object_material=hk.MirrorMaterial(Kr=R(0.9)))]
+    for s, film, cam in cases:
+        for plan in ([1] * 4, [2, 1]):
+            ref, st0 = run(s, cam, film, {"HK_SMALL_PASS_FUSED": "0"}, plan)
+            assert int(st0.fused_passes) == 0 and np.isfinite(ref).all() and ref.max() > 0
+            for env in ({}, {"HK_SMALL_PASS_WAVES": "4"}, {"HK_SMALL_PASS_MERGED": "0"}):
+                got, st1 = run(s, cam, film, env, plan)
+                if max(plan) == 1:
+                    assert int(st1.fused_passes) == len(plan), (env, plan)
+                assert np.array_equal(ref.view(np.uint32), got.view(np.uint32)), (env, plan)
+                assert (int(st1.rays_closest), int(st1.rays_shadow), int(st1.hits_accepted), int(st1.path_vertices)) == \
+                       (int(st0.rays_closest), int(st0.rays_shadow), int(st0.hits_accepted), int(st0.path_vertices))
+            # HK_SMALL_PASS_FUSED=1: only the all-matte instantiation; 16 segments per CU: the general one does not fit four waves per SIMD
+            assert int(run(s, cam, film, {"HK_SMALL_PASS_FUSED": "1"}, plan)[1].fused_passes) == 0
+            got, st1 = run(s, cam, film, {"HK_SMALL_PASS_WAVES": "16"}, plan)
+            assert np.array_equal(ref.view(np.uint32), got.view(np.uint32))
+    s, film, cam = scenes.cornell_box(w, h, light="point")          # a point light only: still the all-matte case
     ref, st0 = run(s, cam, film, {"HK_SMALL_PASS_FUSED": "0"}, [1, 1])
-    got, st1 = run(s, cam, film, {}, [1, 1])
+    got, st1 = run(s, cam, film, {"HK_SMALL_PASS_FUSED": "1"}, [1, 1])
     assert int(st1.fused_passes) == 2 and np.array_equal(ref.view(np.uint32), got.view(np.uint32))
+    # not its case: a layered kind, a medium
+    s, film, cam = scenes.cornell_box(w, h, light="area", object_material=hk.CoatedDiffuseMaterial())
+    assert int(run(s, cam, film, {}, [1, 1])[1].fused_passes) == 0
     s, film, cam = scenes.cloud_scene(w, h, "grid", res=(24, 24, 12))
     assert int(run(s, cam, film, {}, [1, 1], depth=5)[1].fused_passes) == 0
-    for k in ("HK_SMALL_PASS_FUSED", "HK_WAVES_PER_CU", "HK_SMALL_PASS_WAVES", "HK_BATCH_PATHS_M"):
+    for k in ("HK_SMALL_PASS_FUSED", "HK_WAVES_PER_CU", "HK_SMALL_PASS_WAVES", "HK_SMALL_PASS_MERGED", "HK_BATCH_PATHS_M"):
         knobs.delenv(k, raising=False)
     knobs.setenv("HK_WAVES_PER_CU", "0")                   # (sticky in the context: back to the default)
     s, film, cam = scenes.cornell_box(w, h, light="area")

@@ -3132,10 +3132,11 @@ __device__ __forceinline__ void stage_fence() {
 }
 // GENERAL: the kinds with a light-weight shade body — Matte (under any lights), Mirror, Glass, Conductor — whichever the scene has, and K7 for
 // escape lights (escaped_body); two waves per SIMD (512-thread blocks and below), where the union of their registers fits.
-template <int NC, int BLOCK, bool GENERAL = false>
+// STACK = 32: trees deeper than 16 levels (the 10^6-triangle scene; its next-event light comes from the shade body's own descent of the
+// light BVH — what k_light_select would have chosen, test_light_preselection_is_result_neutral).
+template <int NC, int BLOCK, bool GENERAL = false, int STACK = 16>
 __global__ void __attribute__((amdgpu_flat_work_group_size(BLOCK, BLOCK), amdgpu_waves_per_eu(BLOCK / 256))) k_small_pass(DPathState st, DScene sc, DTables T, DFrame fr, DFilter flt, DCamera cam, DSobol sob,
                                                                                                                             int max_depth, int shadows, int merged, void* accum, int film_mode, uint32_t kinds_mask, DStats* stats) {
-    constexpr int STACK = 16;
     __shared__ int lds_stack[(BLOCK / 64) * STACK * 64];
     __shared__ float4 lds_box[3 * NC];
     __shared__ int2 lds_child[NC];
@@ -5222,8 +5223,8 @@ static int small_pass_class(const DScene& sc, uint32_t kinds_mask) {
     const char* e = hk::knob("HK_SMALL_PASS_FUSED");   // 0: the stages as launches, 1: only the all-matte instantiation (A/B switch; films bit-identical)
     const int mode = e ? std::atoi(e) : 2;
     if (mode == 0) return 0;
-    if (!(sc.all_opaque && sc.n_media == 0 && sc.bvh_depth <= 16 && sc.num_bvh_lights < HK_PRESELECT_MIN && node_cache_mode() != 0)) return 0;
-    if (kinds_mask == (1u << HK_MAT_MATTE) && sc.simple_lights && !sc.has_escape_lights) return 1;
+    if (!(sc.all_opaque && sc.n_media == 0 && sc.bvh_depth <= HK_LDS_STACK && node_cache_mode() != 0)) return 0;
+    if (kinds_mask == (1u << HK_MAT_MATTE) && sc.simple_lights && !sc.has_escape_lights && sc.bvh_depth <= 16 && sc.num_bvh_lights < HK_PRESELECT_MIN) return 1;
     const uint32_t light_kinds = (1u << HK_MAT_MATTE) | (1u << HK_MAT_MIRROR) | (1u << HK_MAT_GLASS) | (1u << HK_MAT_CONDUCTOR);
     return (mode >= 2 && kinds_mask != 0 && (kinds_mask & ~light_kinds) == 0) ? 2 : 0;
 }
@@ -5231,25 +5232,28 @@ bool small_pass_fusable(const DScene& sc, uint32_t kinds_mask) { return small_pa
 bool launch_small_pass(hipStream_t s, int n_cu, const DPathState& st, const DScene& sc, const DTables& T, const DFrame& fr, const DFilter& flt, const DCamera& cam, const DSobol& sob, int max_depth,
                        uint32_t kinds_mask, DStats* stats, bool dry, void* accum, int film_mode) {   // dry: only say whether this pass would be launched; film_mode: 0 the caller launches k_film, 1 / 2: float / double accumulators, added inside (one-sample passes)
     const int cls = small_pass_class(sc, kinds_mask);
-    if (cls == 0 || !st.small_pass || st.dynamic_segments || fr.count_nodes || preselect_lights(sc, st)) return false;
+    if (cls == 0 || !st.small_pass || st.dynamic_segments || fr.count_nodes) return false;
     for (int depth = 0; depth < max_depth; ++depth)
         if (sobol_tables_cover(sob, depth)) return false;
     // one block per CU (its LDS: 16-entry stacks, the top of the tree, the emission lists) of as many waves as the pass has segments per CU
     const char* me = hk::knob("HK_SMALL_PASS_MERGED");   // 0: shadow rays and the next bounce's rays as two stages (A/B switch; films bit-identical)
     const int merged = (me && std::atoi(me) == 0) ? 0 : 1;
-#define HK_SMALL_PASS_LAUNCH(B, G)                                                                                                                          \
+#define HK_SMALL_PASS_LAUNCH(B, G, ...)                                                                                                                     \
     {                                                                                                                                                       \
-        int blocks = cached_blocks<k_small_pass<HK_SMALL_PASS_NC, B, G>>(B, n_cu, 1);                                                                       \
+        int blocks = cached_blocks<k_small_pass<HK_SMALL_PASS_NC, B, G, ##__VA_ARGS__>>(B, n_cu, 1);                                                        \
         if (blocks * (B / 64) > st.n_waves) blocks = st.n_waves / (B / 64);                                                                                 \
         if (blocks < 1) return false;                                                                                                                       \
-        if (!dry) hipLaunchKernelGGL((k_small_pass<HK_SMALL_PASS_NC, B, G>), dim3(blocks), dim3(B), 0, s, st, sc, T, fr, flt, cam, sob, max_depth, sc.n_lights > 0 ? 1 : 0, merged, accum, film_mode, kinds_mask, stats); \
+        if (!dry) hipLaunchKernelGGL((k_small_pass<HK_SMALL_PASS_NC, B, G, ##__VA_ARGS__>), dim3(blocks), dim3(B), 0, s, st, sc, T, fr, flt, cam, sob, max_depth, sc.n_lights > 0 ? 1 : 0, merged, accum, film_mode, kinds_mask, stats); \
     }
     // (Cornell 800^2, one sample per call: 1.42 / 1.05 / 1.14 ms at 4 / 8 / 16 segments per CU — 256- / 512- / 1024-thread blocks; a 768-thread
     // block for 12: 1.55.  Eight waves per CU hold 312 paths each: chunks stay fuller down the bounces than with 156, and at two waves per
     // SIMD nothing spills.)
     if (cls == 2) {   // the general instantiation wants its registers: two waves per SIMD at most
         if (st.n_waves > 8 * n_cu) return false;
-        if (st.n_waves > 4 * n_cu) HK_SMALL_PASS_LAUNCH(512, true)
+        if (sc.bvh_depth > 16) {
+            if (st.n_waves > 4 * n_cu) HK_SMALL_PASS_LAUNCH(512, true, HK_LDS_STACK)
+            else HK_SMALL_PASS_LAUNCH(256, true, HK_LDS_STACK)
+        } else if (st.n_waves > 4 * n_cu) HK_SMALL_PASS_LAUNCH(512, true)
         else HK_SMALL_PASS_LAUNCH(256, true)
         return true;
     }

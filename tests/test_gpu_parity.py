@@ -829,6 +829,10 @@ def test_small_pass_in_one_launch(hk, knobs):
              scenes.cornell_box(w, h, light="area", object_material=hk.ConductorMaterial(roughness=0.2)),
              scenes.cornell_box(w, h, light="all", object_material=hk.GlassMaterial(Kr=R(1.0), Kt=R(1.0), index=1.5)),
              scenes.cornell_box(w, h, light="both", object_material=hk.MirrorMaterial(Kr=R(0.9)))]
+    # ... and the many-light barrel: >= 64 lights in the light BVH (the launches choose the next-event light in k_light_select; inside
+    # k_small_pass the shade body descends itself), once with a tree of at most 16 levels and once deeper (32-entry stacks)
+    cases.append(scenes.many_light_scene(w, h, n_boxes=500, emissive_frac=0.25, box_scale=8.0))
+    cases.append(scenes.many_light_scene(w, h, n_boxes=20000, emissive_frac=0.05, box_scale=2.0))
     for s, film, cam in cases:
         for plan in ([1] * 4, [2, 1]):
             ref, st0 = run(s, cam, film, {"HK_SMALL_PASS_FUSED": "0"}, plan)

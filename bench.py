@@ -340,7 +340,7 @@ def compact_line(result, limit=LINE_LIMIT, detail_file="bench_detail.json"):
                 e["progressive"] = _pick(c["progressive"], ("ms_per_call", "ms_per_call_with_readback", "ms_per_call_pipelined_readback", "vs_frame_sample"))
             line["configs"].append(e)
     if isinstance(result.get("progressive"), dict):
-        line["progressive"] = _pick(result["progressive"], ("calls", "ms_per_call", "ms_per_call_with_readback", "ms_per_call_pipelined_readback", "ms_per_call_batched_no_readback",
+        line["progressive"] = _pick(result["progressive"], ("calls", "one_launch_per_call", "ms_per_call", "ms_per_call_with_readback", "ms_per_call_pipelined_readback", "ms_per_call_batched_no_readback",
                                                             "ms_per_sample_of_the_full_frame", "vs_frame_sample", "vs_frame_sample_with_readback", "error"))
     line["detail"] = detail_file
     # whatever a future field adds, the line never outgrows the driver: shed the least important parts first
@@ -382,6 +382,7 @@ def progressive_line(vp, scene, film, cam, calls, frame_spp, seconds_per_frame, 
     frame an interactive viewer shows: finalize kernel + the device-to-host copy of the RGB frame).  `vs_frame_sample` = time per call over
     the time per sample of the config's full frame (the 256-spp pass has ~100 paths per resident lane in flight, a 1-spp call has < 1)."""
     submit = [0.0]
+    fused = [0]
 
     def run(readback):
         vp.clear()
@@ -399,6 +400,7 @@ def progressive_line(vp, scene, film, cam, calls, frame_spp, seconds_per_frame, 
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         st = vp.stats()
+        fused[0] = int(st.fused_passes)
         return dt, int(st.rays_closest) + int(st.rays_shadow)
 
     run(False)                       # untimed: the one-sample pass's path state / tables
@@ -407,6 +409,7 @@ def progressive_line(vp, scene, film, cam, calls, frame_spp, seconds_per_frame, 
     with vp._ctx.options(HK_BATCH_PATHS_M=0):    # every call rendered at once
         run(False)
         dt_each = run(False)[0]
+        one_launch = fused[0] == calls        # k_small_pass: camera rays, every bounce and the film update of a call in ONE launch (hk_stats.fused_passes)
     # a read-back after every call (nothing to batch): "view" = hk_film_read_rgb into ONE host buffer, which the library pins after the second
     # call; "pipelined" = hk_film_read_rgb_async / hk_film_read_wait, the frame shown lags one call and the GPU never waits for the host
     dt_rb = dt_pipe = float("nan")
@@ -418,7 +421,7 @@ def progressive_line(vp, scene, film, cam, calls, frame_spp, seconds_per_frame, 
     per_sample = seconds_per_frame / max(frame_spp, 1)
     # `ms_per_call` is what ONE render! call costs a caller that wants its sample rendered now (batching off, no read-back);
     # `..._with_readback` adds the frame an interactive viewer shows after every call; the batched figure is a 64-spp pass in disguise
-    return {"calls": calls, "ms_per_call": round(dt_each / calls * 1e3, 4), "ms_per_call_with_readback": round(dt_rb / calls * 1e3, 4),
+    return {"calls": calls, "one_launch_per_call": bool(one_launch), "ms_per_call": round(dt_each / calls * 1e3, 4), "ms_per_call_with_readback": round(dt_rb / calls * 1e3, 4),
             "ms_per_call_pipelined_readback": round(dt_pipe / calls * 1e3, 4),
             "ms_per_call_batched_no_readback": round(dt / calls * 1e3, 4), "value_batched": round(rays / dt / 1e6, 2), "unit": "Mrays/s",
             "host_ms_per_call_batched": round(host_ms, 4), "ms_per_sample_of_the_full_frame": round(per_sample * 1e3, 4),

@@ -5233,6 +5233,9 @@ bool launch_small_pass(hipStream_t s, int n_cu, const DPathState& st, const DSce
                        uint32_t kinds_mask, DStats* stats, bool dry, void* accum, int film_mode) {   // dry: only say whether this pass would be launched; film_mode: 0 the caller launches k_film, 1 / 2: float / double accumulators, added inside (one-sample passes)
     const int cls = small_pass_class(sc, kinds_mask);
     if (cls == 0 || !st.small_pass || st.dynamic_segments || fr.count_nodes) return false;
+    // a SMALL pass in ensure_state's sense (at most 16 chunks for each of 4 waves per CU), not the mid-size pass that shares its static
+    // segments: with 25 chunks per stage the launches' higher residency wins (800^2 x 32 spp without sampler tables: 14.8 ms as launches, 17.2 here)
+    if (((long)st.capacity + 63) / 64 / 16 > 4L * n_cu) return false;
     for (int depth = 0; depth < max_depth; ++depth)
         if (sobol_tables_cover(sob, depth)) return false;
     // one block per CU (its LDS: 16-entry stacks, the top of the tree, the emission lists) of as many waves as the pass has segments per CU

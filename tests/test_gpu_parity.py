@@ -772,7 +772,9 @@ def test_full_size_media_properties(hk):
     assert np.isfinite(a).all() and (a >= 0).all() and a.mean() > 0.01 and c1 > 1_000_000
     vp(s, film, cam)
     assert np.array_equal(a, film.framebuffer) and int(vp.stats().medium_collisions) == c1
-    vp.close()@pytest.mark.gpu
+    vp.close()
+
+
 def test_small_pass_in_one_launch(hk, knobs):
     """k_small_pass: a small pass of a closed all-matte scene — the reference's interactive call, one sample of every pixel (volpath.jl:445-450)
     — is ONE launch in which the wave that owns a segment runs the camera rays and every bounce's trace / shade / shadow stage of that
@@ -862,6 +864,3 @@ def test_small_pass_in_one_launch(hk, knobs):
     knobs.setenv("HK_WAVES_PER_CU", "0")                   # (sticky in the context: back to the default)
     s, film, cam = scenes.cornell_box(w, h, light="area")
     run(s, cam, film, {"HK_WAVES_PER_CU": "0"}, [1])
-
-
-

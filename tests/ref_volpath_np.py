@@ -537,8 +537,19 @@ class SceneNP:
         self.arealight = np.array([desc.meta[i].arealight_flat_idx_1based for i in range(T)], np.int64)
         mats = [desc.materials[i] for i in range(desc.n_materials)]
         assert all(m.kind in (0, 1, 2, 3) for m in mats), "Matte, Mirror, Glass, Conductor only"
-        assert all(m.rgb[0].tex < 0 and m.rgb[1].tex < 0 and m.f[0].tex < 0 for m in mats), "constant parameters only"
+        assert all((m.rgb[0].tex < 0 or m.kind == 0) and m.rgb[1].tex < 0 and m.f[0].tex < 0 for m in mats), "constant parameters only (but a Matte's Kd may be an image texture)"
         self.kind = np.array([m.kind for m in mats], np.int64)
+        # image textures (Raycore TextureRef -> a Matrix [h, w] of RGB; the description stores it column-major with the channels innermost)
+        self.kd_tex = np.array([m.rgb[0].tex if m.kind == 0 else -1 for m in mats], np.int64)
+        self.textures = {}
+        for ti in set(int(x) for x in self.kd_tex if x >= 0):
+            tx = desc.textures[ti]
+            assert tx.kind == 0 and tx.channels >= 3, "image textures only"
+            self.textures[ti] = np.ctypeslib.as_array(tx.data, shape=(tx.width * tx.height * tx.channels,)).astype(f32).reshape(tx.width, tx.height, tx.channels).transpose(1, 0, 2).copy()
+        if desc.uvs:
+            self.uv = np.ctypeslib.as_array(desc.uvs, shape=(T * 6,)).reshape(T, 3, 2).astype(f32)
+        else:      # a mesh without texture coordinates: (0, 0), (1, 0), (1, 1) per triangle
+            self.uv = np.broadcast_to(F([[0, 0], [1, 0], [1, 1]]), (T, 3, 2)).astype(f32)
         # Conductor (uber-material.jl:378-426): roughness -> alpha = sqrt(roughness) when remap_roughness (reflection/microfacet.jl:83-85),
         # eta / k as measured PiecewiseLinearSpectrum records of the scene description
         self.alpha = np.zeros(len(mats), f32)
@@ -560,6 +571,39 @@ class SceneNP:
         self.kt_poly = F([tables.rgb_to_poly([m.rgb[1].c[k] for k in range(3)]) for m in mats])
         self.ior = F([m.f[0].v if m.kind == 2 else 1.0 for m in mats])
         self._rest(desc, tables)
+
+    def tex_bilinear(self, ti, uv):
+        """_sample_texture_bilinear (textures/texture-ref.jl:151-186) of image ti at uv [N, 2] -> [N, channels]: the (1 - v, u) flip, pixel
+        coordinates u (w - 1) + 1, the four neighbours clamped to the image, c0 (1 - fx) + c1 fx in x, then the same in y"""
+        img = self.textures[ti]
+        h, w = img.shape[0], img.shape[1]
+        a0, a1 = (f32(1) - uv[:, 1]).astype(f32), uv[:, 0]
+        px = (a1 * f32(w - 1) + f32(1)).astype(f32)
+        py = (a0 * f32(h - 1) + f32(1)).astype(f32)
+        fx0, fy0 = np.floor(px), np.floor(py)
+        x0, y0 = fx0.astype(np.int64), fy0.astype(np.int64)
+        x1, y1 = x0 + 1, y0 + 1
+        x0, x1 = np.clip(x0, 1, w) - 1, np.clip(x1, 1, w) - 1
+        y0, y1 = np.clip(y0, 1, h) - 1, np.clip(y1, 1, h) - 1
+        fx, fy = (px - fx0).astype(f32)[:, None], (py - fy0).astype(f32)[:, None]
+        c0 = (img[y0, x0] * (f32(1) - fx) + img[y0, x1] * fx).astype(f32)
+        c1 = (img[y1, x0] * (f32(1) - fx) + img[y1, x1] * fx).astype(f32)
+        return (c0 * (f32(1) - fy) + c1 * fy).astype(f32)
+
+    def kd_polys(self, mat, prim, bw, bu, bv):
+        """the reflectance polynomials of the hit materials [N, 3]: a constant Kd's, or — a textured Matte — those of the bilinear texel at
+        the hit's uv (compute_uv_barycentric, physical-wavefront/intersection.jl:181-194: w uv0 + u uv1 + v uv2; Kd clamped to [0, 1] before
+        the uplift, spectral-eval.jl:57-63)"""
+        out = self.kd_poly[mat].copy()
+        tx = self.kd_tex[mat]
+        for ti in set(int(x) for x in tx if x >= 0):
+            sel = np.nonzero(tx == ti)[0]
+            uvs = self.uv[prim[sel]]
+            uv = (bw[sel, None] * uvs[:, 0] + bu[sel, None] * uvs[:, 1] + bv[sel, None] * uvs[:, 2]).astype(f32)
+            rgb = self.tex_bilinear(ti, uv)
+            for j, c in zip(sel, rgb):
+                out[j] = self.tables.rgb_to_poly([float(c[0]), float(c[1]), float(c[2])])
+        return out
 
     def conductor_ior(self, mat, lam):
         """eta, k [N, 4] of the conductor materials among `mat` (rows of other kinds: 1, 0)"""
@@ -1610,7 +1654,7 @@ def render(desc, cam_rec, tables_dict, width, height, n_samples, max_depth, max_
                 L[A[E]] += fin
             mat = sc.mat_of_mi[sc.mi[prim]]
             kind = sc.kind[mat]
-            kd = eval_poly(sc.kd_poly[mat], lm)                      # Kd of a matte surface, Kr of a mirror / glass
+            kd = eval_poly(sc.kd_polys(mat, prim, bw, bu, bv), lm)   # Kd of a matte surface (constant or an image texture), Kr of a mirror / glass
             kt = eval_poly(sc.kt_poly[mat], lm)
             # ---- K9 (surface-eval.jl:235-330, lights.jl:235-290, 535-600): one light sample, shadow ray ----
             lidx, lpmf = sc.bvh.sample(pi, ns, d_uc)

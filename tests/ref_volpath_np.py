@@ -1064,119 +1064,265 @@ def sample_hg(g, wo, u0, u1):
     return wi, hg_p(g, ct)
 
 
+def _floor_i(x):
+    return int(np.floor(np.float64(f32(x))))
+
+
 class MediumNP:
     """HomogeneousMedium (media.jl:762-830): sigma_a, sigma_s, Le uplifted UNBOUNDED per wavelength (uplift.jl:286-308: the polynomial of
-    rgb / max, times max / max_value(polynomial)), majorant = sigma_a + sigma_s along the whole ray"""
+    rgb / max, times max / max_value(polynomial)), majorant = sigma_a + sigma_s along the whole ray.
+    GridMedium (media.jl:873-935, 1459-1760): a density grid [nx, ny, nz] sampled trilinearly at cell centres inside `bounds` of medium
+    space, sigma_a / sigma_s scaled by it, no emission; majorants per cell of a coarse grid (the maximum density over the voxels a cell
+    covers), walked by a DDA along the ray (create_dda_iterator / dda_next: pbrt-v4's DDAMajorantIterator)."""
 
     def __init__(self, rec, tables):
-        assert rec.kind == 0, "homogeneous media only"
+        assert rec.kind in (0, 1), "homogeneous and grid media only"
+        self.kind = int(rec.kind)
         self.g = f32(rec.g)
         self.rgb = {k: [f32(getattr(rec, k)[i]) for i in range(3)] for k in ("sigma_a", "sigma_s", "Le")}
         self.tb = tables
         self.poly = {k: unbounded_poly(tables, rgb) for k, rgb in self.rgb.items()}
+        if self.kind == 1:
+            nx, ny, nz = [int(rec.res[i]) for i in range(3)]
+            self.res = (nx, ny, nz)
+            self.density = np.ctypeslib.as_array(rec.density, shape=(nx * ny * nz,)).astype(f32).reshape(nz, ny, nx).transpose(2, 1, 0).copy()      # [x, y, z] as in Julia
+            self.lo, self.hi = F([rec.bounds_min[i] for i in range(3)]), F([rec.bounds_max[i] for i in range(3)])
+            self.r2m = F([rec.render_to_medium[i] for i in range(16)]).reshape(4, 4)
+            self.mres = tuple(int(rec.majorant_res[i]) for i in range(3))
+            self.majorant = self.build_majorant()
+            given = np.ctypeslib.as_array(rec.majorant, shape=(self.mres[0] * self.mres[1] * self.mres[2],)).astype(f32).reshape(self.mres[2], self.mres[1], self.mres[0]).transpose(2, 1, 0)
+            assert np.array_equal(self.majorant, given), "the description's majorant grid is not build_majorant_grid(density)"
+
+    def build_majorant(self):
+        """build_majorant_grid (media.jl:1459-1496): cell i of an axis covers the density indices max(1, floor(i n / r) + 1) .. min(n, ceil((i + 1) n / r))"""
+        nx, ny, nz = self.res
+        rx, ry, rz = self.mres
+        out = np.zeros((rx, ry, rz), f32)
+
+        def rng_(i, n, r):
+            return max(1, int(np.floor(i * n / r)) + 1), min(n, int(np.ceil((i + 1) * n / r)))
+        for iz in range(rz):
+            z0, z1 = rng_(iz, nz, rz)
+            for iy in range(ry):
+                y0, y1 = rng_(iy, ny, ry)
+                for ix in range(rx):
+                    x0, x1 = rng_(ix, nx, rx)
+                    blk = self.density[x0 - 1:x1, y0 - 1:y1, z0 - 1:z1]
+                    out[ix, iy, iz] = max(f32(0), blk.max()) if blk.size else f32(0)
+        return out
 
     def spectrum(self, k, lam):
         return unbounded_eval(self.poly[k], F(lam)[None])[0]
 
+    def to_medium(self, v, point):
+        M = self.r2m
+        x, y, z = f32(v[0]), f32(v[1]), f32(v[2])
+        out = [f32(f32(f32(M[i, 0] * x) + f32(M[i, 1] * y)) + f32(M[i, 2] * z)) for i in range(3)]
+        if point:
+            out = [f32(out[i] + M[i, 3]) for i in range(3)]
+        return F(out)
+
+    def sample_density(self, pm):
+        """sample_density (media.jl:1544-1595): trilinear over cell centres, p n + 1/2 in 1-based indices, clamped to [1, n - 1]"""
+        pn = ((pm - self.lo) / (self.hi - self.lo)).astype(f32)
+        if (pn < 0).any() or (pn > 1).any():
+            return f32(0)
+        n = self.res
+        g = [f32(pn[i] * f32(n[i]) + f32(0.5)) for i in range(3)]
+        i0 = [min(max(_floor_i(g[i]), 1), n[i] - 1) for i in range(3)]
+        fr = [f32(min(max(f32(g[i] - f32(i0[i])), f32(0)), f32(1))) for i in range(3)]
+        D = self.density
+        ix, iy, iz = i0[0] - 1, i0[1] - 1, i0[2] - 1
+        fx, fy, fz = fr
+        fx1, fy1 = f32(f32(1) - fx), f32(f32(1) - fy)
+        d00 = f32(f32(D[ix, iy, iz] * fx1) + f32(D[ix + 1, iy, iz] * fx))
+        d10 = f32(f32(D[ix, iy + 1, iz] * fx1) + f32(D[ix + 1, iy + 1, iz] * fx))
+        d01 = f32(f32(D[ix, iy, iz + 1] * fx1) + f32(D[ix + 1, iy, iz + 1] * fx))
+        d11 = f32(f32(D[ix, iy + 1, iz + 1] * fx1) + f32(D[ix + 1, iy + 1, iz + 1] * fx))
+        d0 = f32(f32(d00 * fy1) + f32(d10 * fy))
+        d1 = f32(f32(d01 * fy1) + f32(d11 * fy))
+        return f32(f32(d0 * f32(f32(1) - fz)) + f32(d1 * fz))
+
+    def point(self, p, lam):
+        """sample_point -> (sigma_a, sigma_s, Le) [4] at render-space p (media.jl:781-793, 1597-1622)"""
+        sa, ss = self.spectrum("sigma_a", lam), self.spectrum("sigma_s", lam)
+        if self.kind == 0:
+            return sa, ss, self.spectrum("Le", lam)
+        dn = self.sample_density(self.to_medium(p, True))
+        return (sa * dn).astype(f32), (ss * dn).astype(f32), np.zeros(4, f32)
+
+    def segments(self, o, d, t_max, lam):
+        """the majorant segments (t_min, t_max, sigma_maj [4]) a ray meets, in order (at most 256 are consumed)"""
+        sa, ss = self.spectrum("sigma_a", lam), self.spectrum("sigma_s", lam)
+        st = (sa + ss).astype(f32)
+        if self.kind == 0:          # HomogeneousMajorantIterator: one segment [0, t_max] (media.jl:132-170)
+            if f32(0) < f32(t_max):
+                yield f32(0), f32(t_max), st
+            return
+        ro, rd = self.to_medium(o, True), self.to_medium(d, False)
+        if f32(f32(f32(rd[0] * rd[0]) + f32(rd[1] * rd[1])) + f32(rd[2] * rd[2])) < f32(1e-20):
+            return
+        # ray_bounds_intersect (media.jl:1700-1740)
+        t0s, t1s = [], []
+        for k in range(3):
+            with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+                inv = f32(f32(1) / rd[k]) if abs(rd[k]) > f32(1e-10) else (f32(np.inf) if rd[k] >= 0 else f32(-np.inf))
+                a, b_ = f32(f32(self.lo[k] - ro[k]) * inv), f32(f32(self.hi[k] - ro[k]) * inv)
+            if a > b_:
+                a, b_ = b_, a
+            t0s.append(a)
+            t1s.append(b_)
+        t_enter, t_exit = max(max(t0s[0], t0s[1]), t0s[2]), min(min(t1s[0], t1s[1]), t1s[2])
+        t_enter, t_exit = max(t_enter, f32(0)), min(t_exit, f32(t_max))
+        if not t_enter < t_exit:
+            return
+        # create_dda_iterator (media.jl:268-395)
+        res = self.mres
+        diag = (self.hi - self.lo).astype(f32)
+        go = [f32(f32(ro[k] - self.lo[k]) / diag[k]) for k in range(3)]
+        gd = [f32(rd[k] * (f32(f32(1) / diag[k]) if abs(diag[k]) > f32(1e-10) else f32(0))) for k in range(3)]
+        gi = [f32(go[k] + f32(gd[k] * t_enter)) for k in range(3)]
+        vox = [min(max(_floor_i(f32(gi[k] * f32(res[k]))), 0), res[k] - 1) for k in range(3)]
+        delta = [f32(f32(1) / f32(abs(gd[k]) * f32(res[k]))) if abs(gd[k]) > f32(1e-10) else f32(np.inf) for k in range(3)]
+        nxt, step, limit = [], [], []
+        for k in range(3):
+            if gd[k] >= 0:
+                pos = f32(f32(vox[k] + 1) / f32(res[k]))
+                nxt.append(f32(t_enter + f32(f32(pos - gi[k]) / gd[k])) if gd[k] > f32(1e-10) else f32(np.inf))
+                step.append(1)
+                limit.append(res[k])
+            else:
+                pos = f32(f32(vox[k]) / f32(res[k]))
+                nxt.append(f32(t_enter + f32(f32(pos - gi[k]) / gd[k])) if gd[k] < f32(-1e-10) else f32(np.inf))
+                step.append(-1)
+                limit.append(-1)
+        t_min = t_enter
+        axis_of = (2, 1, 2, 1, 2, 2, 0, 0)      # cmpToAxis of pbrt-v4 (media.jl:425-443)
+        while t_min < t_exit:
+            bits = (4 if nxt[0] < nxt[1] else 0) + (2 if nxt[0] < nxt[2] else 0) + (1 if nxt[1] < nxt[2] else 0)
+            ax = axis_of[bits]
+            t_vox = min(t_exit, nxt[ax])
+            yield t_min, t_vox, (st * self.majorant[vox[0], vox[1], vox[2]]).astype(f32)
+            t_min = t_vox
+            vox[ax] += step[ax]
+            if vox[ax] == limit[ax] or nxt[ax] > t_exit:
+                t_min = t_exit
+            nxt[ax] = f32(nxt[ax] + delta[ax])
+
 
 def track_medium(md, o, d, t_max, lam, beta, r_u, r_l, depth, max_depth):
-    """sample_medium_interaction! for a HomogeneousMedium (delta-tracking.jl:154-240, 304-453): ONE majorant segment [0, t_max].
-    -> (kind, beta, r_u, r_l, p, Le_add): kind 'absorb' | 'scatter' | 'dropped' (scatter at the depth limit) | 'survive'"""
-    sa, ss, Le = md.spectrum("sigma_a", lam), md.spectrum("sigma_s", lam), md.spectrum("Le", lam)
-    smaj = (sa + ss).astype(f32)
-    s0 = smaj[0]
+    """sample_medium_interaction! (delta-tracking.jl:154-453): the majorant segments of the ray in turn (one for a HomogeneousMedium, the
+    DDA's cells for a GridMedium; at most 256), exponential steps by the LCG inside each, the medium's coefficients at every tentative
+    collision.  -> (kind, beta, r_u, r_l, p, Le_add): kind 'absorb' | 'scatter' | 'dropped' (scatter at the depth limit) | 'survive'"""
     add = np.zeros(4, f32)
-    if not (f32(0) < t_max) or s0 < f32(1e-10):       # (iterator mode 0: no segment; an empty medium passes the ray on)
-        return "survive", beta, r_u, r_l, None, add
     rng = lcg_init(o, d, t_max)
-    t = f32(0)
-    ray_o = (F(o) + F(d) * t).astype(f32)
-    for _ in range(1024):
-        rng, u = lcg_next(rng)
-        dt = f32(-_log32(max(f32(1e-10), f32(1) - u)) / s0)
-        ts = f32(t + dt)
-        if ts >= t_max:
-            Tm = np.array([_exp32(-(f32(t_max - t)) * x) for x in smaj], f32)
-            if Tm[0] > f32(1e-10):
-                beta = (beta * Tm / Tm[0]).astype(f32)
-                r_u = (r_u * Tm / Tm[0]).astype(f32)
-                r_l = (r_l * Tm / Tm[0]).astype(f32)
-            return "survive", beta, r_u, r_l, None, add
-        Tm = np.array([_exp32(-dt * x) for x in smaj], f32)
-        p = (ray_o + F(d) * dt).astype(f32)
-        if not is_black(Le[None])[0] and depth < max_depth:
-            pr = f32(s0 * Tm[0])
-            if pr > f32(1e-10):
-                r_e = (r_u * smaj * Tm / pr).astype(f32)
-                if not is_black(r_e[None])[0]:
-                    add = (add + beta * sa * Tm * Le / (pr * average(r_e[None])[0])).astype(f32)
-        p_a, p_s = f32(sa[0] / s0), f32(ss[0] / s0)
-        rng, ue = lcg_next(rng)
-        if ue < p_a:
-            return "absorb", np.zeros(4, f32), r_u, r_l, None, add
-        if ue < f32(p_a + p_s):
-            if depth >= max_depth:
-                return "dropped", beta, r_u, r_l, None, add
-            pdf = f32(Tm[0] * ss[0])
-            if pdf > f32(1e-10):
-                beta = (beta * Tm * ss / pdf).astype(f32)
-                r_u = (r_u * Tm * ss / pdf).astype(f32)
-            return "scatter", beta, r_u, r_l, p, add
-        sn = np.maximum(smaj - sa - ss, f32(0)).astype(f32)
-        pdf = f32(Tm[0] * sn[0])
-        if not pdf > f32(1e-10):
-            return "absorb", np.zeros(4, f32), r_u, r_l, None, add
-        beta = (beta * Tm * sn / pdf).astype(f32)
-        r_u = (r_u * Tm * sn / pdf).astype(f32)
-        r_l = (r_l * Tm * smaj / pdf).astype(f32)
-        t, ray_o = ts, p
-        if is_black(beta[None])[0] or is_black(r_u[None])[0]:
-            return "absorb", beta, r_u, r_l, None, add
+    n_seg = 0
+    for t0, t1, smaj in md.segments(o, d, t_max, lam):
+        n_seg += 1
+        if n_seg > 256:
+            break
+        s0 = smaj[0]
+        if s0 < f32(1e-10):               # an empty cell: the ray passes
+            continue
+        t = f32(t0)
+        ray_o = (F(o) + F(d) * t).astype(f32)
+        ended = False
+        for _ in range(1024):
+            rng, u = lcg_next(rng)
+            dt = f32(-_log32(max(f32(1e-10), f32(1) - u)) / s0)
+            ts = f32(t + dt)
+            if ts >= t1:
+                Tm = np.array([_exp32(-(f32(t1 - t)) * x) for x in smaj], f32)
+                if Tm[0] > f32(1e-10):
+                    beta = (beta * Tm / Tm[0]).astype(f32)
+                    r_u = (r_u * Tm / Tm[0]).astype(f32)
+                    r_l = (r_l * Tm / Tm[0]).astype(f32)
+                ended = True
+                break
+            Tm = np.array([_exp32(-dt * x) for x in smaj], f32)
+            p = (ray_o + F(d) * dt).astype(f32)
+            sa, ss, Le = md.point(p, lam)
+            if not is_black(Le[None])[0] and depth < max_depth:
+                pr = f32(s0 * Tm[0])
+                if pr > f32(1e-10):
+                    r_e = (r_u * smaj * Tm / pr).astype(f32)
+                    if not is_black(r_e[None])[0]:
+                        add = (add + beta * sa * Tm * Le / (pr * average(r_e[None])[0])).astype(f32)
+            p_a, p_s = f32(sa[0] / s0), f32(ss[0] / s0)
+            rng, ue = lcg_next(rng)
+            if ue < p_a:
+                return "absorb", np.zeros(4, f32), r_u, r_l, None, add
+            if ue < f32(p_a + p_s):
+                if depth >= max_depth:
+                    return "dropped", beta, r_u, r_l, None, add
+                pdf = f32(Tm[0] * ss[0])
+                if pdf > f32(1e-10):
+                    beta = (beta * Tm * ss / pdf).astype(f32)
+                    r_u = (r_u * Tm * ss / pdf).astype(f32)
+                return "scatter", beta, r_u, r_l, p, add
+            sn = np.maximum(smaj - sa - ss, f32(0)).astype(f32)
+            pdf = f32(Tm[0] * sn[0])
+            if not pdf > f32(1e-10):
+                return "absorb", np.zeros(4, f32), r_u, r_l, None, add
+            beta = (beta * Tm * sn / pdf).astype(f32)
+            r_u = (r_u * Tm * sn / pdf).astype(f32)
+            r_l = (r_l * Tm * smaj / pdf).astype(f32)
+            t, ray_o = ts, p
+            if is_black(beta[None])[0] or is_black(r_u[None])[0]:
+                return "absorb", beta, r_u, r_l, None, add
+        if not ended:
+            pass                          # (1 024 tentative collisions inside one segment: on to the next one)
     return "survive", beta, r_u, r_l, None, add
 
 
 def ratio_tracking(md, o, d, t_max, lam):
-    """_ratio_tracking_dda for a HomogeneousMedium (intersection.jl:446-542): PCG32 seeded by the hashes of origin and direction"""
+    """_ratio_tracking_dda (intersection.jl:446-542): the ray's majorant segments in turn (<= 256; one for a HomogeneousMedium), at most 100
+    exponential steps in each, the medium's coefficients at origin + dir t of every step; PCG32 seeded by the hashes of origin and direction"""
     one = np.ones(4, f32)
     T, ru, rl = one.copy(), one.copy(), one.copy()
-    sa, ss = md.spectrum("sigma_a", lam), md.spectrum("sigma_s", lam)
-    smaj = (sa + ss).astype(f32)
-    s0 = smaj[0]
-    if not (f32(0) < t_max) or s0 < f32(1e-10):
-        return T, ru, rl
     rng = PCG32(pbrt_hash3(o), pbrt_hash3(d))
-    t = f32(0)
-    for _ in range(100):
-        u = rng.f32()
-        dt = f32(-_log32(max(f32(1e-10), f32(1) - u)) / s0)
-        ts = f32(t + dt)
-        if ts >= t_max:
-            Tm = np.array([_exp32(-(f32(t_max - t)) * x) for x in smaj], f32)
-            if Tm[0] > f32(1e-10):
-                T, rl, ru = (T * Tm / Tm[0]).astype(f32), (rl * Tm / Tm[0]).astype(f32), (ru * Tm / Tm[0]).astype(f32)
+    n_seg = 0
+    for t0, t1, smaj in md.segments(o, d, t_max, lam):
+        n_seg += 1
+        if n_seg > 256:
             break
-        sn = np.maximum(smaj - sa - ss, f32(0)).astype(f32)
-        Tm = np.array([_exp32(-dt * x) for x in smaj], f32)
-        pr = f32(Tm[0] * s0)
-        if pr > f32(1e-10):
-            T = (T * Tm * sn / pr).astype(f32)
-            rl = (rl * Tm * smaj / pr).astype(f32)
-            ru = (ru * Tm * sn / pr).astype(f32)
-        else:
-            return np.zeros(4, f32), ru, rl
-        with np.errstate(divide="ignore", invalid="ignore"):
-            est = T / max(f32(1e-10), average((rl + ru)[None])[0])
-        if est.max() < f32(0.05):
-            if rng.f32() < f32(0.75):
+        s0 = smaj[0]
+        if s0 < f32(1e-10):
+            continue
+        t = f32(t0)
+        for _ in range(100):
+            u = rng.f32()
+            dt = f32(-_log32(max(f32(1e-10), f32(1) - u)) / s0)
+            ts = f32(t + dt)
+            if ts >= t1:
+                Tm = np.array([_exp32(-(f32(t1 - t)) * x) for x in smaj], f32)
+                if Tm[0] > f32(1e-10):
+                    T, rl, ru = (T * Tm / Tm[0]).astype(f32), (rl * Tm / Tm[0]).astype(f32), (ru * Tm / Tm[0]).astype(f32)
+                break
+            pp = (F(o) + F(d) * ts).astype(f32)
+            sa, ss, _ = md.point(pp, lam)
+            sn = np.maximum(smaj - sa - ss, f32(0)).astype(f32)
+            Tm = np.array([_exp32(-dt * x) for x in smaj], f32)
+            pr = f32(Tm[0] * s0)
+            if pr > f32(1e-10):
+                T = (T * Tm * sn / pr).astype(f32)
+                rl = (rl * Tm * smaj / pr).astype(f32)
+                ru = (ru * Tm * sn / pr).astype(f32)
+            else:
                 return np.zeros(4, f32), ru, rl
-            T = (T / (f32(1) - f32(0.75))).astype(f32)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                est = T / max(f32(1e-10), average((rl + ru)[None])[0])
+            if est.max() < f32(0.05):
+                if rng.f32() < f32(0.75):
+                    return np.zeros(4, f32), ru, rl
+                T = (T / (f32(1) - f32(0.75))).astype(f32)
+            if is_black(T[None])[0]:
+                return T, ru, rl
+            t = ts
         if is_black(T[None])[0]:
-            return T, ru, rl
-        t = ts
+            break
     return T, ru, rl
 
-
-# ---------------------------------------------------------------------------------------------------- the environment light
 def equal_area_sphere_to_square(d):
     """textures/environment_map.jl:78-129 (Clarberg's mapping, the polynomial atan), float32, d [N, 3] -> u, v in [0, 1]"""
     x, y, z = np.abs(d[:, 0]), np.abs(d[:, 1]), np.abs(d[:, 2])

@@ -102,7 +102,7 @@ def test_conductor_per_pixel_against_the_numpy_restatement(hk, oracle, metal, ro
     assert abs(img.mean() / ref.mean() - 1.0) < 5e-3
 
 
-@pytest.mark.parametrize("which", ["scattering", "absorbing"])
+@pytest.mark.parametrize("which", ["scattering", "absorbing", "grid"])
 def test_homogeneous_medium_against_the_numpy_restatement(hk, oracle, which):
     """K4 - K6, K10 and K14 have a second source: a HomogeneousMedium behind an index-matched boundary, restated in
     tests/ref_volpath_np.py from delta-tracking.jl:28-58, 154-453 (the LCG seeded by ray bits, absorption / real / null collisions,
@@ -120,6 +120,11 @@ def test_homogeneous_medium_against_the_numpy_restatement(hk, oracle, which):
     if which == "scattering":
         med = hk.HomogeneousMedium(sigma_a=hk.RGBSpectrum(0.2, 0.3, 0.1), sigma_s=hk.RGBSpectrum(0.8, 0.6, 0.9), Le=hk.RGBSpectrum(0.05, 0.0, 0.0), g=0.4)
         depth, batches, per = 6, 8, 32
+    elif which == "grid":      # a HETEROGENEOUS medium end to end: the DDA over the majorant cells and the trilinear density inside the restated loop
+        gr = np.random.default_rng(8)
+        dens = (gr.random((10, 8, 6)) ** 2 * 2.5).astype(np.float32)
+        med = hk.GridMedium(dens, sigma_a=hk.RGBSpectrum(0.15, 0.2, 0.1), sigma_s=hk.RGBSpectrum(1.2, 1.0, 1.4), g=0.35, bounds=((-2.5, -2.6, 1.0), (2.5, 2.6, 2.0)), majorant_res=(4, 3, 5))
+        depth, batches, per = 6, 8, 24
     else:
         med = hk.HomogeneousMedium(sigma_a=hk.RGBSpectrum(0.7, 0.9, 1.2), sigma_s=hk.RGBSpectrum(0.0), Le=hk.RGBSpectrum(0.0))
         depth, batches, per = 4, 8, 16
@@ -149,16 +154,25 @@ def test_homogeneous_medium_against_the_numpy_restatement(hk, oracle, which):
     assert (np.abs(z[lit]) > 4).mean() <= 0.03 and np.abs(z[lit]).max() < 8.0
 
 
-def test_shadow_walk_per_ray_against_the_numpy_restatement(hk, oracle):
+@pytest.mark.parametrize("which", ["homogeneous", "grid"])
+def test_shadow_walk_per_ray_against_the_numpy_restatement(hk, oracle, which):
     """K10 ray by ray, bit for bit: the oracle's trace_shadow_transmittance (its test entry hko_medium mode 2) against
     ref_volpath_np.trace_shadow on the SAME rays — the <= 10-segment walk through medium-transition surfaces, the medium on either side
     by the geometric normal, ratio tracking in a homogeneous medium with PCG32 seeded by pbrt_hash(origin), pbrt_hash(direction)
     (MurmurHash64A of the float bits), Russian roulette of the transmittance estimate, the three running products T_ray / r_u / r_l.
     Same inputs, so the hashed seeds agree and the comparison is exact: every visibility decision equal, every zero equal, the products
     within 4 ulp (float32 exp / log of glibc against correctly rounded ones) on all but a few rays per thousand whose tracker crosses
-    a segment end on a rounding."""
+    a segment end on a rounding.  "grid": the same walk through a HETEROGENEOUS GridMedium (10 x 8 x 6 voxels, 4 x 3 x 5 majorant cells):
+    ratio tracking cell by cell along the DDA (_ratio_tracking_dda, intersection.jl:446-542), one PCG32 stream across the cells, the
+    trilinear density at origin + dir t of every step."""
     from hikari_jl_amd import scenes
-    med = hk.HomogeneousMedium(sigma_a=hk.RGBSpectrum(0.2, 0.3, 0.1), sigma_s=hk.RGBSpectrum(0.8, 0.6, 0.9), Le=hk.RGBSpectrum(0.0), g=0.4)
+    if which == "homogeneous":
+        med = hk.HomogeneousMedium(sigma_a=hk.RGBSpectrum(0.2, 0.3, 0.1), sigma_s=hk.RGBSpectrum(0.8, 0.6, 0.9), Le=hk.RGBSpectrum(0.0), g=0.4)
+    else:
+        gr = np.random.default_rng(8)
+        dens = (gr.random((10, 8, 6)) ** 2 * 2.5).astype(np.float32)
+        dens[:3, :, :2] = 0.0
+        med = hk.GridMedium(dens, sigma_a=hk.RGBSpectrum(0.3, 0.4, 0.2), sigma_s=hk.RGBSpectrum(1.2, 1.0, 1.4), g=0.35, bounds=((-2.5, -2.6, 1.0), (2.5, 2.6, 2.0)), majorant_res=(4, 3, 5))
     s, _, _ = scenes.slab_scene(16, 16, med, inner_emitter=True)
     tb = R.Tables(hk.tables.load())
     sc = R.SceneNP(s.desc, tb)
@@ -182,7 +196,7 @@ def test_shadow_walk_per_ray_against_the_numpy_restatement(hk, oracle):
         T, ru, rl, vis = R.trace_shadow(sc, o[i], d[i], tmax[i], lam[i], 0 if inside[i] else -1)
         got[i] = np.concatenate([T, ru, rl, [1.0 if vis else 0.0]])
     # (a homogeneous medium's majorant is its extinction: the first component of T_ray is 0 or 1, the others carry the spectral ratios)
-    assert 0.2 < ref[:, 12].mean() < 0.95 and (ref[:, 0] == 0).mean() > 0.1 and ((ref[:, 1] > 0) & (ref[:, 1] != 1)).mean() > 0.05
+    assert 0.2 < ref[:, 12].mean() < 0.95 and (ref[:, 0] == 0).mean() > (0.1 if which == "homogeneous" else 0.03) and ((ref[:, 1] > 0) & (ref[:, 1] != 1)).mean() > 0.05
     assert np.array_equal(got[:, 12], ref[:, 12])                                        # visible / blocked: every ray
     ulp = np.abs(got[:, :12].view(np.int32).astype(np.int64) - ref[:, :12].view(np.int32).astype(np.int64))
     same = (ulp <= 4).all(axis=1)
@@ -190,7 +204,8 @@ def test_shadow_walk_per_ray_against_the_numpy_restatement(hk, oracle):
     assert same.mean() >= 0.99
 
 
-def test_media_stage_per_ray_against_the_numpy_restatement(hk, oracle):
+@pytest.mark.parametrize("which", ["homogeneous", "grid", "grid_rotated"])
+def test_media_stage_per_ray_against_the_numpy_restatement(hk, oracle, which):
     """K4 + K5 + K6 ray by ray: the oracle's own stage code (process_media_stage, reached through its test entry hko_media_stage — nothing
     restated on that side) against ref_volpath_np.media_vertex on the SAME rays, throughputs, weights and Sobol draws.  Same ray bits, so
     both sides seed the LCG alike (delta-tracking.jl:28-58) and the comparison is exact: the FATE of every ray (absorbed / dropped at the
@@ -199,9 +214,25 @@ def test_media_stage_per_ray_against_the_numpy_restatement(hk, oracle):
     r_l = r_u / phase_pdf — medium-scatter.jl:172-198) and the shadow ray of its next-event estimation (Ld = beta * phase * Li, r_u * phase
     pdf, r_u * light pdf * pmf of the light tree walked WITHOUT a normal, t_max 10^6 for an area light — :15-118); and the emission a
     tentative collision adds to the pixel (delta-tracking.jl:371-381).  A wrong r_l after a phase sample, which the converged test above
-    cannot see (measured: dropping the division changes its means by 0.1 %), fails here on every scattered ray."""
+    cannot see (measured: dropping the division changes its means by 0.1 %), fails here on every scattered ray.
+    "grid": a HETEROGENEOUS medium — BASELINE configs[3]'s kind — through the same comparison: a GridMedium of 10 x 8 x 6 voxels under a
+    4 x 3 x 5 majorant grid (cells that do not divide the voxels), i.e. the DDA over the majorant cells (create_dda_iterator / dda_next,
+    media.jl:268-500), the tracking state carried from cell to cell with ONE LCG stream, the trilinear density at every tentative collision
+    (sample_density, :1544-1595) and the majorant grid itself (build_majorant_grid, :1459-1496: rebuilt from the text and compared with the
+    scene description's); "grid_rotated": the same with a medium-to-render transform (rays and points taken to medium space)."""
     from hikari_jl_amd import scenes
-    med = hk.HomogeneousMedium(sigma_a=hk.RGBSpectrum(0.2, 0.3, 0.1), sigma_s=hk.RGBSpectrum(0.8, 0.6, 0.9), Le=hk.RGBSpectrum(0.05, 0.02, 0.0), g=0.4)
+    if which == "homogeneous":
+        med = hk.HomogeneousMedium(sigma_a=hk.RGBSpectrum(0.2, 0.3, 0.1), sigma_s=hk.RGBSpectrum(0.8, 0.6, 0.9), Le=hk.RGBSpectrum(0.05, 0.02, 0.0), g=0.4)
+    else:
+        gr = np.random.default_rng(8)
+        dens = (gr.random((10, 8, 6)) ** 2 * 2.5).astype(np.float32)
+        dens[:3, :, :2] = 0.0                                         # empty majorant cells on the way
+        xf = None
+        if which == "grid_rotated":
+            c, sn = np.cos(0.3), np.sin(0.3)
+            xf = np.array([[c, -sn, 0, 0.2], [sn, c, 0, -0.1], [0, 0, 1, 0.05], [0, 0, 0, 1]], np.float32)
+        med = hk.GridMedium(dens, sigma_a=hk.RGBSpectrum(0.3, 0.4, 0.2), sigma_s=hk.RGBSpectrum(1.2, 1.0, 1.4), g=0.35, bounds=((-2.5, -2.6, 1.0), (2.5, 2.6, 2.0)),
+                            transform=xf, majorant_res=(4, 3, 5))
     s, _, _ = scenes.slab_scene(16, 16, med, inner_emitter=True)
     sc = R.SceneNP(s.desc, R.Tables(hk.tables.load()))
     rng = np.random.default_rng(5)
@@ -217,7 +248,9 @@ def test_media_stage_per_ray_against_the_numpy_restatement(hk, oracle):
     ref = osc.media_stage(0, depth, max_depth, np.concatenate([o, d, tmax[:, None], lam, beta, ru, rl], 1), duc, du, iu)
     last = osc.media_stage(0, max_depth - 1, max_depth, np.concatenate([o, d, tmax[:, None], lam, beta, ru, rl], 1)[:50], duc[:50], du[:50], iu[:50])
     osc.close()
-    assert (ref[:, 0] == 1).sum() > 30 and ref[:, 17].sum() > 100 and ref[:, 36].sum() > 100      # (an unbounded ray through a homogeneous medium never escapes)
+    assert (ref[:, 0] == 1).sum() > 30 and ref[:, 17].sum() > (100 if which == "homogeneous" else 60) and ref[:, 36].sum() > (100 if which == "homogeneous" else 60)      # (an unbounded ray through a homogeneous medium never escapes)
+    if which != "homogeneous":
+        assert (ref[:, 0] == 2).sum() > 10                          # unbounded rays that leave the grid's bounds escape
     assert last[:, 17].sum() == 0                                   # at the depth limit nothing continues (K6: new_depth >= max_depth)
 
     def close(a, b):

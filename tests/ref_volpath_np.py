@@ -1076,7 +1076,7 @@ class MediumNP:
     covers), walked by a DDA along the ray (create_dda_iterator / dda_next: pbrt-v4's DDAMajorantIterator)."""
 
     def __init__(self, rec, tables):
-        assert rec.kind in (0, 1), "homogeneous and grid media only"
+        assert rec.kind in (0, 1, 3), "homogeneous, grid and NanoVDB media only"
         self.kind = int(rec.kind)
         self.g = f32(rec.g)
         self.rgb = {k: [f32(getattr(rec, k)[i]) for i in range(3)] for k in ("sigma_a", "sigma_s", "Le")}
@@ -1092,6 +1092,102 @@ class MediumNP:
             self.majorant = self.build_majorant()
             given = np.ctypeslib.as_array(rec.majorant, shape=(self.mres[0] * self.mres[1] * self.mres[2],)).astype(f32).reshape(self.mres[2], self.mres[1], self.mres[0]).transpose(2, 1, 0)
             assert np.array_equal(self.majorant, given), "the description's majorant grid is not build_majorant_grid(density)"
+
+        if self.kind == 3:
+            # NanoVDBMedium (nanovdb.jl:160-200): the grid's bytes as they are, byte offsets 1-based as the reference keeps them
+            self.buf = np.ctypeslib.as_array(rec.nvdb_bytes, shape=(int(rec.nvdb_size),)).copy()
+            self.root_off, self.root_n = int(rec.root_offset_1based), int(rec.root_table_size)
+            self.inv_mat = [f32(rec.inv_mat[i]) for i in range(9)]
+            self.vec = [f32(rec.vec[i]) for i in range(3)]
+            self.imin = [int(rec.index_bbox_min[i]) for i in range(3)]
+            self.imax = [int(rec.index_bbox_max[i]) for i in range(3)]
+            self.lo, self.hi = F([rec.bounds_min[i] for i in range(3)]), F([rec.bounds_max[i] for i in range(3)])
+            self.mres = tuple(int(rec.majorant_res[i]) for i in range(3))
+            self._vox = {}
+            self.majorant = self.build_majorant_nvdb()
+            given = np.ctypeslib.as_array(rec.majorant, shape=(self.mres[0] * self.mres[1] * self.mres[2],)).astype(f32).reshape(self.mres[2], self.mres[1], self.mres[0]).transpose(2, 1, 0)
+            assert np.array_equal(self.majorant, given), "the description's majorant grid is not build_nanovdb_majorant_grid(tree)"
+
+    # ---- NanoVDB (nanovdb.jl:230-475): Tree::getValue over the byte buffer, world -> index, the trilinear sampler ----
+    def _rd(self, off1, dt):
+        return np.frombuffer(self.buf, dt, 1, off1 - 1)[0]
+
+    def nvdb_value(self, i, j, k):
+        """nanovdb_get_value (nanovdb.jl:296-386): root tile by key (linear search) -> upper node 32^3 -> lower node 16^3 -> leaf 8^3; a tile
+        without a child holds a constant; child offsets are relative to the parent node"""
+        key3 = (i, j, k)
+        if key3 in self._vox:
+            return self._vox[key3]
+        u = [v & 0xFFFFFFFF for v in (i, j, k)]
+        key = ((u[2] >> 12) & 0x1fffff) | (((u[1] >> 12) & 0x1fffff) << 21) | (((u[0] >> 12) & 0x1fffff) << 42)
+        tile = None
+        for t in range(self.root_n):
+            off = self.root_off + 64 + t * 32
+            if int(self._rd(off, np.uint64)) == key:
+                tile = off
+                break
+        if tile is None:
+            val = f32(self._rd(self.root_off + 28, np.float32))
+        else:
+            child = int(self._rd(tile + 8, np.int64))
+            if child == 0:
+                val = f32(self._rd(tile + 20, np.float32))
+            else:
+                up = self.root_off + child
+                n_up = (((u[0] >> 7) & 31) << 10) | (((u[1] >> 7) & 31) << 5) | ((u[2] >> 7) & 31)
+                if not (self.buf[up + 4128 - 1 + (n_up >> 3)] >> (n_up & 7)) & 1:
+                    val = f32(self._rd(up + 8256 + n_up * 8, np.float32))
+                else:
+                    lw = up + int(self._rd(up + 8256 + n_up * 8, np.int64))
+                    n_lw = (((u[0] >> 3) & 15) << 8) | (((u[1] >> 3) & 15) << 4) | ((u[2] >> 3) & 15)
+                    if not (self.buf[lw + 544 - 1 + (n_lw >> 3)] >> (n_lw & 7)) & 1:
+                        val = f32(self._rd(lw + 1088 + n_lw * 8, np.float32))
+                    else:
+                        leaf = lw + int(self._rd(lw + 1088 + n_lw * 8, np.int64))
+                        n_lf = ((i & 7) << 6) | ((j & 7) << 3) | (k & 7)
+                        val = f32(self._rd(leaf + 96 + n_lf * 4, np.float32))
+        self._vox[key3] = val
+        return val
+
+    def world_to_index(self, p):
+        q = [f32(p[k] - self.vec[k]) for k in range(3)]
+        m = self.inv_mat
+        return [f32(f32(f32(m[3 * r] * q[0]) + f32(m[3 * r + 1] * q[1])) + f32(m[3 * r + 2] * q[2])) for r in range(3)]
+
+    def nvdb_density(self, p):
+        """sample_nanovdb_density (nanovdb.jl:424-470): trilinear over the eight voxels around the index-space point, z first, then y, then x"""
+        pi = self.world_to_index(p)
+        i0 = [_floor_i(pi[k]) for k in range(3)]
+        fx, fy, fz = [f32(pi[k] - f32(i0[k])) for k in range(3)]
+        v = [[[self.nvdb_value(i0[0] + a, i0[1] + b_, i0[2] + c) for c in (0, 1)] for b_ in (0, 1)] for a in (0, 1)]
+        fx1, fy1, fz1 = f32(f32(1) - fx), f32(f32(1) - fy), f32(f32(1) - fz)
+        vz = [[f32(f32(v[a][b_][0] * fz1) + f32(v[a][b_][1] * fz)) for b_ in (0, 1)] for a in (0, 1)]
+        vy = [f32(f32(vz[a][0] * fy1) + f32(vz[a][1] * fy)) for a in (0, 1)]
+        return f32(f32(vy[0] * fx1) + f32(vy[1] * fx))
+
+    def build_majorant_nvdb(self):
+        """build_nanovdb_majorant_grid (nanovdb.jl:1174-1233): per cell of the world-space grid, the maximum voxel over the cell's index range
+        widened by one voxel (the trilinear filter's reach), clipped to the index bounding box"""
+        rx, ry, rz = self.mres
+        out = np.zeros((rx, ry, rz), f32)
+        diag = (self.hi - self.lo).astype(f32)
+        res = (rx, ry, rz)
+
+        def corner(c):
+            return F([f32(self.lo[k] + f32(f32(diag[k] * f32(c[k])) / f32(res[k]))) for k in range(3)])
+        for iz in range(rz):
+            for iy in range(ry):
+                for ix in range(rx):
+                    a, b_ = self.world_to_index(corner((ix, iy, iz))), self.world_to_index(corner((ix + 1, iy + 1, iz + 1)))
+                    r0 = [max(_floor_i(f32(min(a[k], b_[k]) - f32(1))), self.imin[k]) for k in range(3)]
+                    r1 = [min(int(np.ceil(np.float64(f32(max(a[k], b_[k]) + f32(1))))), self.imax[k]) for k in range(3)]
+                    mv = f32(0)
+                    for z in range(r0[2], r1[2] + 1):
+                        for y in range(r0[1], r1[1] + 1):
+                            for x in range(r0[0], r1[0] + 1):
+                                mv = max(mv, self.nvdb_value(x, y, z))
+                    out[ix, iy, iz] = mv
+        return out
 
     def build_majorant(self):
         """build_majorant_grid (media.jl:1459-1496): cell i of an axis covers the density indices max(1, floor(i n / r) + 1) .. min(n, ceil((i + 1) n / r))"""
@@ -1148,7 +1244,7 @@ class MediumNP:
         sa, ss = self.spectrum("sigma_a", lam), self.spectrum("sigma_s", lam)
         if self.kind == 0:
             return sa, ss, self.spectrum("Le", lam)
-        dn = self.sample_density(self.to_medium(p, True))
+        dn = self.nvdb_density(F(p)) if self.kind == 3 else self.sample_density(self.to_medium(p, True))
         return (sa * dn).astype(f32), (ss * dn).astype(f32), np.zeros(4, f32)
 
     def segments(self, o, d, t_max, lam):
@@ -1159,9 +1255,12 @@ class MediumNP:
             if f32(0) < f32(t_max):
                 yield f32(0), f32(t_max), st
             return
-        ro, rd = self.to_medium(o, True), self.to_medium(d, False)
-        if f32(f32(f32(rd[0] * rd[0]) + f32(rd[1] * rd[1])) + f32(rd[2] * rd[2])) < f32(1e-20):
-            return
+        if self.kind == 3:          # NanoVDBMedium: the majorant grid lives in world (render) space (nanovdb.jl:509-543)
+            ro, rd = F(o), F(d)
+        else:
+            ro, rd = self.to_medium(o, True), self.to_medium(d, False)
+            if f32(f32(f32(rd[0] * rd[0]) + f32(rd[1] * rd[1])) + f32(rd[2] * rd[2])) < f32(1e-20):
+                return
         # ray_bounds_intersect (media.jl:1700-1740)
         t0s, t1s = [], []
         for k in range(3):

@@ -154,7 +154,7 @@ def test_homogeneous_medium_against_the_numpy_restatement(hk, oracle, which):
     assert (np.abs(z[lit]) > 4).mean() <= 0.03 and np.abs(z[lit]).max() < 8.0
 
 
-@pytest.mark.parametrize("which", ["homogeneous", "grid"])
+@pytest.mark.parametrize("which", ["homogeneous", "grid", "nanovdb"])
 def test_shadow_walk_per_ray_against_the_numpy_restatement(hk, oracle, which):
     """K10 ray by ray, bit for bit: the oracle's trace_shadow_transmittance (its test entry hko_medium mode 2) against
     ref_volpath_np.trace_shadow on the SAME rays — the <= 10-segment walk through medium-transition surfaces, the medium on either side
@@ -172,7 +172,13 @@ def test_shadow_walk_per_ray_against_the_numpy_restatement(hk, oracle, which):
         gr = np.random.default_rng(8)
         dens = (gr.random((10, 8, 6)) ** 2 * 2.5).astype(np.float32)
         dens[:3, :, :2] = 0.0
-        med = hk.GridMedium(dens, sigma_a=hk.RGBSpectrum(0.3, 0.4, 0.2), sigma_s=hk.RGBSpectrum(1.2, 1.0, 1.4), g=0.35, bounds=((-2.5, -2.6, 1.0), (2.5, 2.6, 2.0)), majorant_res=(4, 3, 5))
+        if which == "nanovdb":     # (24 x 17 x 11 voxels: leaves of 8^3 that are partly empty, several leaves along every axis)
+            big = (gr.random((24, 17, 11)) ** 2 * 2.5).astype(np.float32)
+            big[:7, :, :4] = 0.0
+            med = hk.NanoVDBMedium(big, bounds=((-2.5, -2.6, 1.0), (2.5, 2.6, 2.0)), sigma_a=hk.RGBSpectrum(0.3, 0.4, 0.2),
+                                   sigma_s=hk.RGBSpectrum(1.2, 1.0, 1.4), g=0.35, majorant_res=(4, 3, 5))
+        else:
+            med = hk.GridMedium(dens, sigma_a=hk.RGBSpectrum(0.3, 0.4, 0.2), sigma_s=hk.RGBSpectrum(1.2, 1.0, 1.4), g=0.35, bounds=((-2.5, -2.6, 1.0), (2.5, 2.6, 2.0)), majorant_res=(4, 3, 5))
     s, _, _ = scenes.slab_scene(16, 16, med, inner_emitter=True)
     tb = R.Tables(hk.tables.load())
     sc = R.SceneNP(s.desc, tb)
@@ -204,7 +210,7 @@ def test_shadow_walk_per_ray_against_the_numpy_restatement(hk, oracle, which):
     assert same.mean() >= 0.99
 
 
-@pytest.mark.parametrize("which", ["homogeneous", "grid", "grid_rotated"])
+@pytest.mark.parametrize("which", ["homogeneous", "grid", "grid_rotated", "nanovdb"])
 def test_media_stage_per_ray_against_the_numpy_restatement(hk, oracle, which):
     """K4 + K5 + K6 ray by ray: the oracle's own stage code (process_media_stage, reached through its test entry hko_media_stage — nothing
     restated on that side) against ref_volpath_np.media_vertex on the SAME rays, throughputs, weights and Sobol draws.  Same ray bits, so
@@ -231,8 +237,15 @@ def test_media_stage_per_ray_against_the_numpy_restatement(hk, oracle, which):
         if which == "grid_rotated":
             c, sn = np.cos(0.3), np.sin(0.3)
             xf = np.array([[c, -sn, 0, 0.2], [sn, c, 0, -0.1], [0, 0, 1, 0.05], [0, 0, 0, 1]], np.float32)
-        med = hk.GridMedium(dens, sigma_a=hk.RGBSpectrum(0.3, 0.4, 0.2), sigma_s=hk.RGBSpectrum(1.2, 1.0, 1.4), g=0.35, bounds=((-2.5, -2.6, 1.0), (2.5, 2.6, 2.0)),
-                            transform=xf, majorant_res=(4, 3, 5))
+        if which == "nanovdb":     # BASELINE configs[3]'s medium: the NanoVDB tree decoded from its bytes (nanovdb.jl:296-386), the index-space
+            # trilinear sampler (:424-470), the world-space majorant grid rebuilt from the tree (:1174-1233) — all restated in MediumNP
+            big = (gr.random((24, 17, 11)) ** 2 * 2.5).astype(np.float32)      # (leaves of 8^3 that are partly empty, a second and third leaf along the axes)
+            big[:7, :, :4] = 0.0
+            med = hk.NanoVDBMedium(big, bounds=((-2.5, -2.6, 1.0), (2.5, 2.6, 2.0)), sigma_a=hk.RGBSpectrum(0.3, 0.4, 0.2),
+                                   sigma_s=hk.RGBSpectrum(1.2, 1.0, 1.4), g=0.35, majorant_res=(4, 3, 5))
+        else:
+            med = hk.GridMedium(dens, sigma_a=hk.RGBSpectrum(0.3, 0.4, 0.2), sigma_s=hk.RGBSpectrum(1.2, 1.0, 1.4), g=0.35, bounds=((-2.5, -2.6, 1.0), (2.5, 2.6, 2.0)),
+                                transform=xf, majorant_res=(4, 3, 5))
     s, _, _ = scenes.slab_scene(16, 16, med, inner_emitter=True)
     sc = R.SceneNP(s.desc, R.Tables(hk.tables.load()))
     rng = np.random.default_rng(5)
@@ -511,3 +524,69 @@ def test_device_textured_matte_per_pixel_against_the_numpy_restatement(hk):
     print("device vs restatement (textured room): within 2e-4: %.4f, within 1e-2: %.4f, worst %.3g" % ((rel <= 2e-4).mean(), (rel <= 1e-2).mean(), rel.max()))
     assert (rel <= 2e-4).mean() >= 0.99 and (rel <= 1e-2).mean() >= 0.995
     assert abs(img.mean() / dev.mean() - 1.0) < 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["grid", "grid_rotated", "nanovdb"])
+def test_device_media_points_and_segments_against_the_numpy_restatement(hk, gpu_ctx, which):
+    """The HIP path's heterogeneous media against the NumPy restatement directly (no oracle in between): sample_point — the trilinear
+    density of a GridMedium, the NanoVDB tree decoded from its bytes and its index-space sampler, the unbounded uplift of sigma_a / sigma_s —
+    at 3 000 points, and the majorant segments a ray meets (ray to medium space, ray / bounds, the DDA over the majorant cells with the
+    grid the restatement REBUILT from the density / the tree) for 600 rays: segment count, and t_min / t_max / sigma_maj of the first 16."""
+    import ctypes as C
+    from hikari_jl_amd import scenes
+    gr = np.random.default_rng(8)
+    bounds = ((-2.5, -2.6, 1.0), (2.5, 2.6, 2.0))
+    kw = dict(sigma_a=hk.RGBSpectrum(0.3, 0.4, 0.2), sigma_s=hk.RGBSpectrum(1.2, 1.0, 1.4), g=0.35, majorant_res=(4, 3, 5))
+    if which == "nanovdb":
+        big = (gr.random((24, 17, 11)) ** 2 * 2.5).astype(np.float32)
+        big[:7, :, :4] = 0.0
+        med = hk.NanoVDBMedium(big, bounds=bounds, **kw)
+    else:
+        dens = (gr.random((10, 8, 6)) ** 2 * 2.5).astype(np.float32)
+        dens[:3, :, :2] = 0.0
+        xf = None
+        if which == "grid_rotated":
+            c, sn = np.cos(0.3), np.sin(0.3)
+            xf = np.array([[c, -sn, 0, 0.2], [sn, c, 0, -0.1], [0, 0, 1, 0.05], [0, 0, 0, 1]], np.float32)
+        med = hk.GridMedium(dens, bounds=bounds, transform=xf, **kw)
+    s, _, _ = scenes.slab_scene(16, 16, med)
+    md = R.SceneNP(s.desc, R.Tables(hk.tables.load())).media[0]
+    sh = hk.scene_handle(gpu_ctx, s)
+    L = hk._lib.lib()
+    PF = hk._abi.PF
+    pf = lambda a: a.ctypes.data_as(PF)
+    rng = np.random.default_rng(21)
+    n = 3000
+    p = (rng.random((n, 3)) * np.array([5.6, 5.8, 1.3]) + np.array([-2.8, -2.9, 0.85])).astype(np.float32)
+    lam = (380 + 420 * rng.random((n, 4))).astype(np.float32)
+    out = np.zeros((n, 13), np.float32)
+    hk._lib.check(L.hk_test_medium(gpu_ctx.h, sh, 0, 0, n, pf(p), None, None, pf(lam), pf(out)), "hk_test_medium")
+    mine = np.array([np.concatenate(md.point(p[i], lam[i])[:2]) for i in range(n)]).astype(np.float32)
+    ulp = np.abs(out[:, :8].view(np.int32).astype(np.int64) - mine.view(np.int32).astype(np.int64))
+    print("device vs restatement (%s): sample_point max %d ulp over %d points, %.2f of them inside the medium" % (which, ulp.max(), n, (mine[:, 0] > 0).mean()))
+    assert (mine[:, 0] > 0).mean() > 0.4 and ulp.max() <= 2                      # (the device's uplift runs the hardware exp: 2 ulp)
+    m = 600
+    o = (rng.random((m, 3)) * np.array([7.0, 7.0, 3.0]) + np.array([-3.5, -3.5, 0.0])).astype(np.float32)
+    tgt = (rng.random((m, 3)) * np.array([5.0, 5.2, 1.0]) + np.array([-2.5, -2.6, 1.0])).astype(np.float32)
+    d = tgt - o
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    d[:40] = np.array([0, 0, 1], np.float32)
+    tmax = np.where(rng.random(m) < 0.3, rng.random(m) * 3.0, np.inf).astype(np.float32)
+    outm = np.zeros((m, 49), np.float32)
+    hk._lib.check(L.hk_test_medium(gpu_ctx.h, sh, 1, 0, m, pf(o), pf(d), pf(tmax), pf(lam[:m]), pf(outm)), "hk_test_medium")
+    bad = 0
+    for i in range(m):
+        segs = []
+        for t0, t1, smaj in md.segments(o[i], d[i], tmax[i], lam[i]):
+            segs.append((t0, t1, smaj[0]))
+            if len(segs) >= 256:
+                break
+        ok = int(outm[i, 0]) == len(segs)
+        got = outm[i, 1:].reshape(16, 3)[:min(len(segs), 16)]
+        want = np.array(segs[:16], np.float32).reshape(-1, 3)
+        if ok and len(want):
+            ok = bool((np.abs(got.view(np.int32).astype(np.int64) - want.view(np.int32).astype(np.int64)) <= 2).all())
+        bad += 0 if ok else 1
+    print("device vs restatement (%s): majorant segments of %d rays, %d differ; up to %d segments per ray" % (which, m, bad, int(outm[:, 0].max())))
+    assert outm[:, 0].max() >= 4 and bad == 0

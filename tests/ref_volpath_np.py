@@ -1076,8 +1076,8 @@ class MediumNP:
     covers), walked by a DDA along the ray (create_dda_iterator / dda_next: pbrt-v4's DDAMajorantIterator)."""
 
     def __init__(self, rec, tables):
-        assert rec.kind in (0, 1, 3), "homogeneous, grid and NanoVDB media only"
         self.kind = int(rec.kind)
+        assert self.kind in (0, 1, 2, 3)
         self.g = f32(rec.g)
         self.rgb = {k: [f32(getattr(rec, k)[i]) for i in range(3)] for k in ("sigma_a", "sigma_s", "Le")}
         self.tb = tables
@@ -1093,6 +1093,25 @@ class MediumNP:
             given = np.ctypeslib.as_array(rec.majorant, shape=(self.mres[0] * self.mres[1] * self.mres[2],)).astype(f32).reshape(self.mres[2], self.mres[1], self.mres[0]).transpose(2, 1, 0)
             assert np.array_equal(self.majorant, given), "the description's majorant grid is not build_majorant_grid(density)"
 
+        if self.kind == 2:
+            # RGBGridMedium (media.jl:1002-1435): sigma_a / sigma_s / Le as RGB voxels (an absent sigma grid reads 1, an absent Le grid 0), uplifted
+            # unbounded AT THE POINT and scaled by sigma_scale / Le_scale; the majorant grid holds sigma_scale (max sigma_a component + max
+            # sigma_s component) per cell and the iterator runs with sigma_t = 1
+            nx, ny, nz = [int(rec.res[i]) for i in range(3)]
+            self.res = (nx, ny, nz)
+
+            def rgb_grid(ptr):
+                if not ptr:
+                    return None
+                return np.ctypeslib.as_array(ptr, shape=(nx * ny * nz * 4,)).astype(f32).reshape(nz, ny, nx, 4).transpose(2, 1, 0, 3)[..., :3].copy()
+            self.ga, self.gs, self.gl = rgb_grid(rec.sigma_a_grid), rgb_grid(rec.sigma_s_grid), rgb_grid(rec.Le_grid)
+            self.sigma_scale, self.Le_scale = f32(rec.sigma_scale), f32(rec.Le_scale)
+            self.lo, self.hi = F([rec.bounds_min[i] for i in range(3)]), F([rec.bounds_max[i] for i in range(3)])
+            self.r2m = F([rec.render_to_medium[i] for i in range(16)]).reshape(4, 4)
+            self.mres = tuple(int(rec.majorant_res[i]) for i in range(3))
+            self.majorant = self.build_majorant_rgb()
+            given = np.ctypeslib.as_array(rec.majorant, shape=(self.mres[0] * self.mres[1] * self.mres[2],)).astype(f32).reshape(self.mres[2], self.mres[1], self.mres[0]).transpose(2, 1, 0)
+            assert np.array_equal(self.majorant, given), "the description's majorant grid is not build_rgb_majorant_grid(grids)"
         if self.kind == 3:
             # NanoVDBMedium (nanovdb.jl:160-200): the grid's bytes as they are, byte offsets 1-based as the reference keeps them
             self.buf = np.ctypeslib.as_array(rec.nvdb_bytes, shape=(int(rec.nvdb_size),)).copy()
@@ -1189,6 +1208,45 @@ class MediumNP:
                     out[ix, iy, iz] = mv
         return out
 
+    def build_majorant_rgb(self):
+        """build_rgb_majorant_grid (media.jl:1123-1183)"""
+        nx, ny, nz = self.res
+        rx, ry, rz = self.mres
+        out = np.zeros((rx, ry, rz), f32)
+        ma = self.ga.max(axis=3) if self.ga is not None else None
+        ms = self.gs.max(axis=3) if self.gs is not None else None
+
+        def rng_(i, n, r):
+            return max(1, int(np.floor(i * n / r)) + 1), min(n, int(np.ceil((i + 1) * n / r)))
+        for iz in range(rz):
+            z0, z1 = rng_(iz, nz, rz)
+            for iy in range(ry):
+                y0, y1 = rng_(iy, ny, ry)
+                for ix in range(rx):
+                    x0, x1 = rng_(ix, nx, rx)
+                    va = f32(1) if ma is None else max(f32(0), ma[x0 - 1:x1, y0 - 1:y1, z0 - 1:z1].max())
+                    vs = f32(1) if ms is None else max(f32(0), ms[x0 - 1:x1, y0 - 1:y1, z0 - 1:z1].max())
+                    out[ix, iy, iz] = f32(self.sigma_scale * f32(va + vs))
+        return out
+
+    def sample_rgb(self, grid, pn):
+        """_sample_rgb_grid (media.jl:1279-1326): the GridMedium's trilinear lookup, per channel"""
+        if (pn < 0).any() or (pn > 1).any():
+            return np.zeros(3, f32)
+        n = self.res
+        g = [f32(pn[i] * f32(n[i]) + f32(0.5)) for i in range(3)]
+        i0 = [min(max(_floor_i(g[i]), 1), n[i] - 1) for i in range(3)]
+        fx, fy, fz = [f32(min(max(f32(g[i] - f32(i0[i])), f32(0)), f32(1))) for i in range(3)]
+        ix, iy, iz = i0[0] - 1, i0[1] - 1, i0[2] - 1
+        fx1, fy1 = f32(f32(1) - fx), f32(f32(1) - fy)
+        c00 = (grid[ix, iy, iz] * fx1).astype(f32) + (grid[ix + 1, iy, iz] * fx).astype(f32)
+        c10 = (grid[ix, iy + 1, iz] * fx1).astype(f32) + (grid[ix + 1, iy + 1, iz] * fx).astype(f32)
+        c01 = (grid[ix, iy, iz + 1] * fx1).astype(f32) + (grid[ix + 1, iy, iz + 1] * fx).astype(f32)
+        c11 = (grid[ix, iy + 1, iz + 1] * fx1).astype(f32) + (grid[ix + 1, iy + 1, iz + 1] * fx).astype(f32)
+        c0 = (c00.astype(f32) * fy1).astype(f32) + (c10.astype(f32) * fy).astype(f32)
+        c1 = (c01.astype(f32) * fy1).astype(f32) + (c11.astype(f32) * fy).astype(f32)
+        return ((c0.astype(f32) * f32(f32(1) - fz)).astype(f32) + (c1.astype(f32) * fz).astype(f32)).astype(f32)
+
     def build_majorant(self):
         """build_majorant_grid (media.jl:1459-1496): cell i of an axis covers the density indices max(1, floor(i n / r) + 1) .. min(n, ceil((i + 1) n / r))"""
         nx, ny, nz = self.res
@@ -1241,6 +1299,18 @@ class MediumNP:
 
     def point(self, p, lam):
         """sample_point -> (sigma_a, sigma_s, Le) [4] at render-space p (media.jl:781-793, 1597-1622)"""
+        if self.kind == 2:
+            pm = self.to_medium(p, True)
+            pn = ((pm - self.lo) / (self.hi - self.lo)).astype(f32)
+            one = np.ones(3, f32)
+            ra = one if self.ga is None else self.sample_rgb(self.ga, pn)
+            rs = one if self.gs is None else self.sample_rgb(self.gs, pn)
+            up = lambda rgb: unbounded_eval(unbounded_poly(self.tb, [f32(c) for c in rgb]), F(lam)[None])[0]
+            sa, ss = (up(ra) * self.sigma_scale).astype(f32), (up(rs) * self.sigma_scale).astype(f32)
+            Le = np.zeros(4, f32)
+            if self.gl is not None and self.Le_scale > 0:
+                Le = (up(self.sample_rgb(self.gl, pn)) * self.Le_scale).astype(f32)
+            return sa, ss, Le
         sa, ss = self.spectrum("sigma_a", lam), self.spectrum("sigma_s", lam)
         if self.kind == 0:
             return sa, ss, self.spectrum("Le", lam)
@@ -1249,8 +1319,11 @@ class MediumNP:
 
     def segments(self, o, d, t_max, lam):
         """the majorant segments (t_min, t_max, sigma_maj [4]) a ray meets, in order (at most 256 are consumed)"""
-        sa, ss = self.spectrum("sigma_a", lam), self.spectrum("sigma_s", lam)
-        st = (sa + ss).astype(f32)
+        if self.kind == 2:          # (the scale is baked into the majorant grid: sigma_t = 1, media.jl:1410-1412)
+            st = np.ones(4, f32)
+        else:
+            sa, ss = self.spectrum("sigma_a", lam), self.spectrum("sigma_s", lam)
+            st = (sa + ss).astype(f32)
         if self.kind == 0:          # HomogeneousMajorantIterator: one segment [0, t_max] (media.jl:132-170)
             if f32(0) < f32(t_max):
                 yield f32(0), f32(t_max), st

@@ -536,7 +536,7 @@ class SceneNP:
         self.mi = np.array([desc.meta[i].medium_interface_idx for i in range(T)], np.int64)
         self.arealight = np.array([desc.meta[i].arealight_flat_idx_1based for i in range(T)], np.int64)
         mats = [desc.materials[i] for i in range(desc.n_materials)]
-        assert all(m.kind in (0, 1, 2, 3) for m in mats), "Matte, Mirror, Glass, Conductor only"
+        assert all(m.kind in (0, 1, 2, 3, 5, 6) for m in mats), "Matte, Mirror, Glass, Conductor, ThinDielectric, DiffuseTransmission only"
         assert all((m.rgb[0].tex < 0 or m.kind == 0) and m.rgb[1].tex < 0 and m.f[0].tex < 0 for m in mats), "constant parameters only (but a Matte's Kd may be an image texture)"
         self.kind = np.array([m.kind for m in mats], np.int64)
         # image textures (Raycore TextureRef -> a Matrix [h, w] of RGB; the description stores it column-major with the channels innermost)
@@ -569,7 +569,19 @@ class SceneNP:
         # Matte clamps Kd to [0, 1] (spectral-eval.jl:63); Mirror / Glass pass Kr / Kt to uplift_rgb as they are (it clamps inside)
         self.kd_poly = F([tables.rgb_to_poly([m.rgb[0].c[k] for k in range(3)]) for m in mats])       # Kd, or Kr
         self.kt_poly = F([tables.rgb_to_poly([m.rgb[1].c[k] for k in range(3)]) for m in mats])
-        self.ior = F([m.f[0].v if m.kind == 2 else 1.0 for m in mats])
+        self.ior = F([m.f[0].v if m.kind in (2, 5) else 1.0 for m in mats])      # Glass index, ThinDielectric eta
+        # DiffuseTransmission (spectral-eval.jl:2083-2215): reflectance and transmittance times scale, clamped to [0, 1]; the lobe is chosen
+        # by the larger components
+        self.dt_r_poly, self.dt_t_poly = np.zeros((len(mats), 3), f32), np.zeros((len(mats), 3), f32)
+        self.dt_pr, self.dt_pt = np.zeros(len(mats), f32), np.zeros(len(mats), f32)
+        for i, m in enumerate(mats):
+            if m.kind != 6:
+                continue
+            sc_ = f32(m.f[0].v)
+            rr = [min(max(f32(f32(m.rgb[0].c[k]) * sc_), f32(0)), f32(1)) for k in range(3)]
+            tt = [min(max(f32(f32(m.rgb[1].c[k]) * sc_), f32(0)), f32(1)) for k in range(3)]
+            self.dt_r_poly[i], self.dt_t_poly[i] = tables.rgb_to_poly(rr), tables.rgb_to_poly(tt)
+            self.dt_pr[i], self.dt_pt[i] = max(rr), max(tt)
         self._rest(desc, tables)
 
     def tex_bilinear(self, ti, uv):
@@ -1985,6 +1997,16 @@ def render(desc, cam_rec, tables_dict, width, height, n_samples, max_depth, max_
             f = kd / PI
             bs_pdf = np.abs(ci) / PI
             f = np.where(bs_ok[:, None], f, f32(0)).astype(f32)
+            is_dt = kind == 6
+            if is_dt.any():                                                      # DiffuseTransmission evaluates on both sides (spectral-eval.jl:2172-2215); ThinDielectric (5) is zero
+                same = (ci * co) > 0
+                prt = (sc.dt_pr[mat] + sc.dt_pt[mat]).astype(f32)
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    f_dt = np.where(same[:, None], eval_poly(sc.dt_r_poly[mat], lm), eval_poly(sc.dt_t_poly[mat], lm)) * (f32(1) / PI)
+                    pdf_dt = (np.where(same, sc.dt_pr[mat] / prt, sc.dt_pt[mat] / prt) * np.abs(ci) / PI).astype(f32)
+                dt_ok = ~(np.abs(ci) < f32(1e-6)) & ~(prt < f32(1e-10))
+                f = np.where(is_dt[:, None], np.where(dt_ok[:, None], f_dt, f32(0)), f).astype(f32)
+                bs_pdf = np.where(is_dt, np.where(dt_ok, pdf_dt, f32(0)), bs_pdf).astype(f32)
             is_cond = kind == 3
             if is_cond.any():                                                    # a Conductor: the rough lobe evaluates, the smooth one is zero (spectral-eval.jl:415-486)
                 eta_c, k_c = sc.conductor_ior(mat, lm)
@@ -2062,6 +2084,51 @@ def render(desc, cam_rec, tables_dict, width, height, n_samples, max_depth, max_
                 f2 = np.where(is_spec[:, None], f_s, f2).astype(f32)
                 pdf2 = np.where(is_spec, f32(1), pdf2).astype(f32)
                 valid = np.where(kind == 1, m_valid, np.where(kind == 2, True, valid))
+            is_td = kind == 5
+            if is_td.any():
+                # ThinDielectric (spectral-eval.jl:1975-2037): R0 of one interface, R = R0 + T0^2 R0 / (1 - R0^2) for the slab, reflection with
+                # probability R — f = R / |cos| — or straight through, f = T / |cos|; a delta lobe (beta *= f)
+                tg5, bt5 = coordinate_system(ns)
+                wl = np.stack([dot(wo, tg5), dot(wo, bt5), wdn], -1).astype(f32)
+                c5 = np.abs(wl[:, 2])
+                eta5 = sc.ior[mat]
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    cc = np.clip(c5, f32(-1), f32(1))
+                    s2t5 = (f32(1) - cc * cc) / (eta5 * eta5)
+                    ct5 = np.sqrt(f32(1) - s2t5)
+                    rp = (eta5 * cc - ct5) / (eta5 * cc + ct5)
+                    rs_ = (cc - eta5 * ct5) / (cc + eta5 * ct5)
+                    R0 = np.where(s2t5 >= 1, f32(1), f32(0.5) * (rp * rp + rs_ * rs_)).astype(f32)
+                    T0 = (f32(1) - R0).astype(f32)
+                    Rr = np.where(R0 < 1, R0 + T0 * T0 * R0 / (f32(1) - R0 * R0), R0).astype(f32)
+                    Tt = (f32(1) - Rr).astype(f32)
+                    prob_r = (Rr / (Rr + Tt)).astype(f32)
+                    refl5 = normalize((tg5 * (-wl[:, 0:1]) + bt5 * (-wl[:, 1:2]) + ns * wl[:, 2:3]).astype(f32))
+                    take_r = i_uc < prob_r
+                    f5 = np.where(take_r, Rr / np.abs(wl[:, 2]), Tt / c5).astype(f32)
+                wi2 = np.where(is_td[:, None], np.where(take_r[:, None], refl5, -wo), wi2).astype(f32)
+                f2 = np.where(is_td[:, None], f5[:, None] * np.ones((1, 4), f32), f2).astype(f32)
+                pdf2 = np.where(is_td, np.where(take_r, prob_r, f32(1) - prob_r), pdf2).astype(f32)
+                is_spec = is_spec | is_td
+                valid = np.where(is_td, ~(np.abs(wdn) < f32(1e-6)) & ~(Rr + Tt < f32(1e-10)), valid)
+            if is_dt.any():
+                # DiffuseTransmission (spectral-eval.jl:2083-2165): the cosine lobe on wo's side with probability pr / (pr + pt), on the other side otherwise
+                prt = (sc.dt_pr[mat] + sc.dt_pt[mat]).astype(f32)
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    prob_r6 = (sc.dt_pr[mat] / prt).astype(f32)
+                take_r6 = i_uc < prob_r6
+                lw6 = cosine_hemisphere(i_u0, i_u1)
+                flip = np.where(take_r6, wdn < 0, wdn > 0)
+                lw6[:, 2] = np.where(flip, -lw6[:, 2], lw6[:, 2])
+                c6 = np.abs(lw6[:, 2])
+                tg6, bt6 = coordinate_system(ns)
+                wi6 = normalize((tg6 * lw6[:, 0:1] + bt6 * lw6[:, 1:2] + ns * lw6[:, 2:3]).astype(f32))
+                f6 = np.where(take_r6[:, None], eval_poly(sc.dt_r_poly[mat], lm), eval_poly(sc.dt_t_poly[mat], lm)) * (f32(1) / PI)
+                pdf6 = (np.where(take_r6, prob_r6, f32(1) - prob_r6) * c6 / PI).astype(f32)
+                wi2 = np.where(is_dt[:, None], wi6, wi2).astype(f32)
+                f2 = np.where(is_dt[:, None], f6, f2).astype(f32)
+                pdf2 = np.where(is_dt, pdf6, pdf2).astype(f32)
+                valid = np.where(is_dt, ~(np.abs(wdn) < f32(1e-6)) & ~(prt < f32(1e-10)) & ~(c6 < f32(1e-6)), valid)
             if is_cond.any():
                 # Conductor (spectral-eval.jl:223-318): a visible normal of the Trowbridge-Reitz distribution, regularised once the path has
                 # had a non-specular bounce; the effectively smooth one is a mirror with f = F / cos

@@ -611,3 +611,52 @@ def test_device_media_points_and_segments_against_the_numpy_restatement(hk, gpu_
         bad += 0 if ok else 1
     print("device vs restatement (%s): majorant segments of %d rays, %d differ; up to %d segments per ray" % (which, m, bad, int(outm[:, 0].max())))
     assert outm[:, 0].max() >= 4 and bad == 0
+
+
+def _thin_and_translucent_box(hk, scenes, w, h, light):
+    """the Cornell box with a ThinDielectric pane and a DiffuseTransmission sheet standing in it (both two-sided in effect: light reaches
+    the walls behind them by transmission), the sphere kept matte"""
+    from hikari_jl_amd import geometry as G
+    R = hk.RGBSpectrum
+    s, film, cam = scenes.cornell_box(w, h, light=light, spheres=False)
+    s.push(G.quad((-0.7, 0.0, 0.35), (-0.05, 0.0, 0.05), (-0.05, 1.3, 0.05), (-0.7, 1.3, 0.35)), hk.ThinDielectricMaterial(eta=1.45))
+    s.push(G.quad((0.1, 0.0, 0.0), (0.75, 0.0, 0.3), (0.75, 1.1, 0.3), (0.1, 1.1, 0.0)),
+           hk.DiffuseTransmissionMaterial(reflectance=R(0.5, 0.35, 0.2), transmittance=R(0.3, 0.5, 0.7), scale=1.3))
+    s.push(G.sphere((0.0, 0.3, 0.55), 0.3, 10), hk.MatteMaterial(Kd=R(0.6)))
+    s.sync()
+    return s, film, cam
+
+
+@pytest.mark.parametrize("light,depth,spp", [("area", 6, 4), ("both", 5, 4)])
+def test_thin_dielectric_and_diffuse_transmission_per_pixel_against_the_numpy_restatement(hk, oracle, light, depth, spp):
+    """Two more material kinds inside the loop: ThinDielectric (spectral-eval.jl:1975-2037: slab reflectance R0 + T0^2 R0 / (1 - R0^2), the
+    lobe chosen by the bounce's 1-D sample, f = R / |cos| or T / |cos| with beta *= f as the reference has it) and DiffuseTransmission
+    (:2083-2215: reflectance / transmittance times scale, clamped; the side chosen by the larger components; evaluated on BOTH sides in
+    next-event estimation, with the lobe probability in the pdf that enters the MIS weights)."""
+    from hikari_jl_amd import scenes
+    w = h = 32
+    s, film, cam = _thin_and_translucent_box(hk, scenes, w, h, light)
+    ref, img = _both(hk, oracle, s, cam, w, h, spp, depth)
+    assert np.isfinite(img).all() and ref.max() > 0
+    rel = np.sqrt(((img - ref) ** 2).sum(axis=2)) / (np.sqrt((ref ** 2).sum(axis=2)) + 1e-6)
+    print("pixels within 2e-4: %.4f, within 1e-2: %.4f, worst %.3g, mean ratio %.6f" % ((rel <= 2e-4).mean(), (rel <= 1e-2).mean(), rel.max(), img.mean() / ref.mean()))
+    assert (rel <= 2e-4).mean() >= 0.99 and (rel <= 1e-2).mean() >= 0.995
+    assert abs(img.mean() / ref.mean() - 1.0) < 1e-3
+
+
+@pytest.mark.gpu
+def test_device_thin_dielectric_and_diffuse_transmission_against_the_numpy_restatement(hk):
+    """the HIP path's frame of that box against the NumPy restatement — no oracle in between"""
+    from hikari_jl_amd import scenes
+    w = h = 32
+    s, film, cam = _thin_and_translucent_box(hk, scenes, w, h, "both")
+    vp = hk.VolPath(max_depth=5, samples=4, filter=hk.BoxFilter())
+    vp(s, film, cam)
+    dev = film.framebuffer.copy()
+    mcv = float(vp.params.max_component_value)
+    vp.close()
+    img, _, _ = R.render(s.desc, cam.record(), hk.tables.load(), w, h, 4, 5, max_component_value=mcv, sobol_spp=4)
+    rel = np.sqrt(((img - dev) ** 2).sum(axis=2)) / (np.sqrt((dev ** 2).sum(axis=2)) + 1e-6)
+    print("device vs restatement (thin dielectric + diffuse transmission): within 2e-4: %.4f, within 1e-2: %.4f, worst %.3g" % ((rel <= 2e-4).mean(), (rel <= 1e-2).mean(), rel.max()))
+    assert (rel <= 2e-4).mean() >= 0.99 and (rel <= 1e-2).mean() >= 0.995
+    assert abs(img.mean() / dev.mean() - 1.0) < 1e-3

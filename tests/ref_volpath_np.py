@@ -537,15 +537,30 @@ class SceneNP:
         self.arealight = np.array([desc.meta[i].arealight_flat_idx_1based for i in range(T)], np.int64)
         mats = [desc.materials[i] for i in range(desc.n_materials)]
         assert all(m.kind in (0, 1, 2, 3, 5, 6) for m in mats), "Matte, Mirror, Glass, Conductor, ThinDielectric, DiffuseTransmission only"
-        assert all((m.rgb[0].tex < 0 or m.kind == 0) and m.rgb[1].tex < 0 and m.f[0].tex < 0 for m in mats), "constant parameters only (but a Matte's Kd may be an image texture)"
+        # parameters that may be TEXTURES (eval_tex, textures/texture-ref.jl:40-80, 222-243): Matte Kd and sigma, Mirror Kr, Glass Kr / Kt,
+        # Conductor roughness — an image (bilinear at the hit's uv) or a VertexColorTexture (the face's three colours by the hit's barycentrics);
+        # everything else must be constant
+        self.mats = mats
+        for m in mats:
+            ok_rgb = {0: (0,), 1: (0,), 2: (0, 1)}.get(m.kind, ())
+            ok_f = {0: (0,), 3: (0,)}.get(m.kind, ())
+            assert all(m.rgb[k].tex < 0 or k in ok_rgb for k in range(4)) and all(m.f[k].tex < 0 or k in ok_f for k in range(8)), "a textured parameter the restatement does not read"
         self.kind = np.array([m.kind for m in mats], np.int64)
-        # image textures (Raycore TextureRef -> a Matrix [h, w] of RGB; the description stores it column-major with the channels innermost)
-        self.kd_tex = np.array([m.rgb[0].tex if m.kind == 0 else -1 for m in mats], np.int64)
-        self.textures = {}
-        for ti in set(int(x) for x in self.kd_tex if x >= 0):
+        self.kd_tex = np.array([m.rgb[0].tex if m.kind in (0, 1, 2) else -1 for m in mats], np.int64)
+        self.kt_tex = np.array([m.rgb[1].tex if m.kind == 2 else -1 for m in mats], np.int64)
+        self.f0_tex = np.array([m.f[0].tex if m.kind in (0, 3) else -1 for m in mats], np.int64)
+        self.f0 = F([m.f[0].v for m in mats])
+        self.remap = np.array([bool(m.flags & 1) for m in mats])
+        self.face = np.array([desc.meta[i].primitive_index for i in range(T)], np.int64)          # the triangle's face index within its mesh (1-based)
+        self.textures, self.tex_kind = {}, {}
+        for ti in set(int(x) for arr in (self.kd_tex, self.kt_tex, self.f0_tex) for x in arr if x >= 0):
             tx = desc.textures[ti]
-            assert tx.kind == 0 and tx.channels >= 3, "image textures only"
-            self.textures[ti] = np.ctypeslib.as_array(tx.data, shape=(tx.width * tx.height * tx.channels,)).astype(f32).reshape(tx.width, tx.height, tx.channels).transpose(1, 0, 2).copy()
+            self.tex_kind[ti] = int(tx.kind)
+            if tx.kind == 0:       # an image: Matrix [h, w], column-major with the channels innermost
+                self.textures[ti] = np.ctypeslib.as_array(tx.data, shape=(tx.width * tx.height * tx.channels,)).astype(f32).reshape(tx.width, tx.height, tx.channels).transpose(1, 0, 2).copy()
+            else:                  # vertex colours: [face][vertex][channel]
+                assert tx.height == 3
+                self.textures[ti] = np.ctypeslib.as_array(tx.data, shape=(tx.width * 3 * tx.channels,)).astype(f32).reshape(tx.width, 3, tx.channels).copy()
         if desc.uvs:
             self.uv = np.ctypeslib.as_array(desc.uvs, shape=(T * 6,)).reshape(T, 3, 2).astype(f32)
         else:      # a mesh without texture coordinates: (0, 0), (1, 0), (1, 1) per triangle
@@ -602,20 +617,34 @@ class SceneNP:
         c1 = (img[y1, x0] * (f32(1) - fx) + img[y1, x1] * fx).astype(f32)
         return (c0 * (f32(1) - fy) + c1 * fy).astype(f32)
 
-    def kd_polys(self, mat, prim, bw, bu, bv):
-        """the reflectance polynomials of the hit materials [N, 3]: a constant Kd's, or — a textured Matte — those of the bilinear texel at
-        the hit's uv (compute_uv_barycentric, physical-wavefront/intersection.jl:181-194: w uv0 + u uv1 + v uv2; Kd clamped to [0, 1] before
-        the uplift, spectral-eval.jl:57-63)"""
-        out = self.kd_poly[mat].copy()
-        tx = self.kd_tex[mat]
+    def tex_at(self, ti, prim, bw, bu, bv):
+        """eval_tex(ctx, texture, tfc) of texture ti at hits -> [N, channels]"""
+        if self.tex_kind[ti] == 0:
+            uvs = self.uv[prim]
+            uv = (bw[:, None] * uvs[:, 0] + bu[:, None] * uvs[:, 1] + bv[:, None] * uvs[:, 2]).astype(f32)        # compute_uv_barycentric (physical-wavefront/intersection.jl:181-194)
+            return self.tex_bilinear(ti, uv)
+        fc = self.textures[ti][self.face[prim] - 1]                 # VertexColorTexture (texture-ref.jl:230-235): data[1, fi] b1 + data[2, fi] b2 + data[3, fi] b3, b = (w, u, v)
+        return ((fc[:, 0] * bw[:, None]).astype(f32) + (fc[:, 1] * bu[:, None]).astype(f32) + (fc[:, 2] * bv[:, None]).astype(f32)).astype(f32)
+
+    def _polys(self, base, tex, mat, prim, bw, bu, bv):
+        out = base[mat].copy()
+        tx = tex[mat]
         for ti in set(int(x) for x in tx if x >= 0):
             sel = np.nonzero(tx == ti)[0]
-            uvs = self.uv[prim[sel]]
-            uv = (bw[sel, None] * uvs[:, 0] + bu[sel, None] * uvs[:, 1] + bv[sel, None] * uvs[:, 2]).astype(f32)
-            rgb = self.tex_bilinear(ti, uv)
+            rgb = self.tex_at(ti, prim[sel], bw[sel], bu[sel], bv[sel])
             for j, c in zip(sel, rgb):
-                out[j] = self.tables.rgb_to_poly([float(c[0]), float(c[1]), float(c[2])])
+                out[j] = self.tables.rgb_to_poly([float(c[0]), float(c[1]), float(c[2])])      # (rgb_to_poly clamps to [0, 1]: Matte clamps Kd, uplift_rgb the others)
         return out
+
+    def hit_params(self, mat, prim, bw, bu, bv):
+        """the materials' parameters AT the hits: reflectance polynomials kd [N, 3] (Matte Kd, Mirror / Glass Kr) and kt (Glass Kt), f0 [N]
+        (Matte sigma, Glass index, ThinDielectric eta, Conductor roughness) — constants, or textures evaluated per hit"""
+        f0 = self.f0[mat].copy()
+        tx = self.f0_tex[mat]
+        for ti in set(int(x) for x in tx if x >= 0):
+            sel = np.nonzero(tx == ti)[0]
+            f0[sel] = self.tex_at(ti, prim[sel], bw[sel], bu[sel], bv[sel])[:, 0]
+        return self._polys(self.kd_poly, self.kd_tex, mat, prim, bw, bu, bv), self._polys(self.kt_poly, self.kt_tex, mat, prim, bw, bu, bv), f0
 
     def conductor_ior(self, mat, lam):
         """eta, k [N, 4] of the conductor materials among `mat` (rows of other kinds: 1, 0)"""
@@ -1984,8 +2013,11 @@ def render(desc, cam_rec, tables_dict, width, height, n_samples, max_depth, max_
                 L[A[E]] += fin
             mat = sc.mat_of_mi[sc.mi[prim]]
             kind = sc.kind[mat]
-            kd = eval_poly(sc.kd_polys(mat, prim, bw, bu, bv), lm)   # Kd of a matte surface (constant or an image texture), Kr of a mirror / glass
-            kt = eval_poly(sc.kt_poly[mat], lm)
+            kd_p, kt_p, f0 = sc.hit_params(mat, prim, bw, bu, bv)
+            kd = eval_poly(kd_p, lm)                                 # Kd of a matte surface, Kr of a mirror / glass — constants or textures at the hit
+            kt = eval_poly(kt_p, lm)
+            with np.errstate(invalid="ignore"):
+                alpha_h = np.where(sc.remap[mat], np.sqrt(np.maximum(f0, f32(0))), f0).astype(f32)      # Conductor: alpha = sqrt(roughness) when remap_roughness
             # ---- K9 (surface-eval.jl:235-330, lights.jl:235-290, 535-600): one light sample, shadow ray ----
             lidx, lpmf = sc.bvh.sample(pi, ns, d_uc)
             ok = (lidx >= 1) & (lpmf > 0)
@@ -2010,7 +2042,7 @@ def render(desc, cam_rec, tables_dict, width, height, n_samples, max_depth, max_
             is_cond = kind == 3
             if is_cond.any():                                                    # a Conductor: the rough lobe evaluates, the smooth one is zero (spectral-eval.jl:415-486)
                 eta_c, k_c = sc.conductor_ior(mat, lm)
-                f_c, pdf_c = conductor_eval(wo, wi, ns, sc.alpha[mat], eta_c, k_c)
+                f_c, pdf_c = conductor_eval(wo, wi, ns, alpha_h, eta_c, k_c)
                 f = np.where(is_cond[:, None], f_c, f).astype(f32)
                 bs_pdf = np.where(is_cond, pdf_c, bs_pdf).astype(f32)
             Ld = b * f * Li * np.abs(dot(wi, ns))[:, None]
@@ -2053,7 +2085,9 @@ def render(desc, cam_rec, tables_dict, width, height, n_samples, max_depth, max_
             lw[:, 2] = np.where(wdn < 0, -lw[:, 2], lw[:, 2])
             tg, bt = coordinate_system(ns)
             wi2 = normalize((tg * lw[:, 0:1] + bt * lw[:, 1:2] + ns * lw[:, 2:3]).astype(f32))
-            f2 = kd * (f32(1) / PI)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                rough_f = np.where((kind == 0) & (f0 > 0), f32(1) - f32(0.5) * f0 / (f0 + f32(0.33)), f32(1)).astype(f32)      # Matte sigma > 0: the SAMPLED lobe is scaled
+            f2 = np.where((rough_f != 1)[:, None], kd * (rough_f / PI)[:, None], kd * (f32(1) / PI)).astype(f32)               # (spectral-eval.jl:88-96; the evaluation stays Kd / pi, :372-396)
             pdf2 = cos_th / PI
             is_spec = (kind == 1) | (kind == 2)
             if is_spec.any():
@@ -2062,7 +2096,7 @@ def render(desc, cam_rec, tables_dict, width, height, n_samples, max_depth, max_
                 refl = (-wo + f32(2) * dot(wo, n_or)[:, None] * n_or).astype(f32)
                 m_valid = ~(np.abs(wdn) < f32(1e-6))
                 cos_o = np.abs(wdn)
-                ior = sc.ior[mat]
+                ior = np.where(kind == 2, f0, f32(1)).astype(f32)
                 ior = np.where(ior == 0, f32(1), ior)
                 with np.errstate(divide="ignore", invalid="ignore"):
                     eta = np.where(wdn > 0, ior, f32(1) / ior).astype(f32)
@@ -2091,7 +2125,7 @@ def render(desc, cam_rec, tables_dict, width, height, n_samples, max_depth, max_
                 tg5, bt5 = coordinate_system(ns)
                 wl = np.stack([dot(wo, tg5), dot(wo, bt5), wdn], -1).astype(f32)
                 c5 = np.abs(wl[:, 2])
-                eta5 = sc.ior[mat]
+                eta5 = f0
                 with np.errstate(divide="ignore", invalid="ignore"):
                     cc = np.clip(c5, f32(-1), f32(1))
                     s2t5 = (f32(1) - cc * cc) / (eta5 * eta5)
@@ -2133,7 +2167,7 @@ def render(desc, cam_rec, tables_dict, width, height, n_samples, max_depth, max_
                 # Conductor (spectral-eval.jl:223-318): a visible normal of the Trowbridge-Reitz distribution, regularised once the path has
                 # had a non-specular bounce; the effectively smooth one is a mirror with f = F / cos
                 reg = anyns[A] & bool(regularize)
-                wi_c, f_c, pdf_c, smooth_c, valid_c = conductor_sample(wo, ns, sc.alpha[mat], reg, eta_c, k_c, i_u0, i_u1)
+                wi_c, f_c, pdf_c, smooth_c, valid_c = conductor_sample(wo, ns, alpha_h, reg, eta_c, k_c, i_u0, i_u1)
                 wi2 = np.where(is_cond[:, None], wi_c, wi2).astype(f32)
                 f2 = np.where(is_cond[:, None], f_c, f2).astype(f32)
                 pdf2 = np.where(is_cond, pdf_c, pdf2).astype(f32)

@@ -484,7 +484,7 @@ def test_device_many_light_frame_against_the_numpy_restatement(hk, gpu_ctx):
     assert abs(img.mean() / dev.mean() - 1.0) < 1e-3
 
 
-def _textured_room(hk, w, h):
+def _textured_room(hk, w, h, full=False):
     """a room whose floor, back wall and sphere carry image textures of different, non-square sizes (a transposed or flipped lookup shows),
     under an area light and a point light"""
     from hikari_jl_amd import geometry as G
@@ -499,6 +499,15 @@ def _textured_room(hk, w, h):
     s.push(G.quad((1, 0, -1), (1, 2, -1), (1, 2, 1), (1, 0, 1), normal=(-1, 0, 0)), hk.MatteMaterial(Kd=R(0.2, 0.6, 0.25)))
     s.push(G.quad((-1, 2, -1), (-1, 2, 1), (1, 2, 1), (1, 2, -1), normal=(0, -1, 0)), hk.MatteMaterial(Kd=R(0.75)))
     s.push(G.sphere((0.25, 0.45, 0.1), 0.45, 12), hk.MatteMaterial(Kd=Texture(smooth(8, 4))))
+    if full:      # every textured parameter the restatement reads: sigma (a float image), vertex colours, Kr, Kt, a conductor's roughness
+        from hikari_jl_amd.materials import VertexColorTexture
+        sig = (30.0 * rng.random((4, 3))).astype(np.float32)
+        s.push(G.quad((-0.95, 0.02, 0.2), (-0.4, 0.02, 0.2), (-0.4, 0.02, 0.9), (-0.95, 0.02, 0.9), normal=(0, 1, 0)), hk.MatteMaterial(Kd=Texture(smooth(3, 3)), sigma=Texture(sig)))
+        panel = G.rect3f((-0.9, 0.9, -0.95), (0.6, 0.7, 0.05))
+        s.push(panel, hk.MatteMaterial(Kd=VertexColorTexture((0.2 + 0.7 * rng.random((panel.n_faces, 3, 3))).astype(np.float32))))
+        s.push(G.quad((0.55, 0.6, -0.9), (0.95, 0.6, -0.6), (0.95, 1.5, -0.6), (0.55, 1.5, -0.9)), hk.MirrorMaterial(Kr=Texture(smooth(4, 4))))
+        s.push(G.sphere((-0.45, 0.3, -0.3), 0.3, 10), hk.GlassMaterial(Kr=Texture(smooth(2, 3)), Kt=Texture(smooth(3, 2)), index=1.5))
+        s.push(G.sphere((0.65, 0.25, 0.6), 0.25, 10), hk.ConductorMaterial(eta=R(0.2, 0.92, 1.1), k=R(3.9, 2.45, 2.14), roughness=Texture((0.05 + 0.5 * rng.random((5, 4))).astype(np.float32))))
     s.push(G.quad((-0.3, 1.98, -0.3), (0.3, 1.98, -0.3), (0.3, 1.98, 0.3), (-0.3, 1.98, 0.3), normal=(0, -1, 0)),
            hk.MediumInterface(hk.MatteMaterial(Kd=R(0.0)), emission=hk.Emissive(Le=R(1.0, 0.9, 0.8), scale=12.0)))
     s.push(hk.PointLight((-0.6, 1.2, 0.6), R(2.0, 2.5, 3.0)))
@@ -508,13 +517,14 @@ def _textured_room(hk, w, h):
     return s, film, cam
 
 
-def test_textured_matte_per_pixel_against_the_numpy_restatement(hk, oracle):
+@pytest.mark.parametrize("full", [False, True])
+def test_textured_matte_per_pixel_against_the_numpy_restatement(hk, oracle, full):
     """TEXTURES inside the loop: a Matte's Kd from an image at the hit's uv — the barycentric uv (physical-wavefront/intersection.jl:181-194),
     the bilinear lookup with its (1 - v, u) flip and clamped neighbours (textures/texture-ref.jl:151-186), Kd clamped and uplifted per
     vertex (spectral-eval.jl:57-63) — for next-event estimation and for the sampled bounce alike."""
     w = h = 32
-    s, film, cam = _textured_room(hk, w, h)
-    ref, img = _both(hk, oracle, s, cam, w, h, 4, 5)
+    s, film, cam = _textured_room(hk, w, h, full)     # full: + a sigma image (the SAMPLED lobe scaled, the evaluated one not: spectral-eval.jl:88-96 against
+    ref, img = _both(hk, oracle, s, cam, w, h, 4, 5)  # :372-396), a VertexColorTexture (texture-ref.jl:230-235), textured Kr / Kt / conductor roughness
     assert np.isfinite(img).all() and ref.max() > 0
     rel = np.sqrt(((img - ref) ** 2).sum(axis=2)) / (np.sqrt((ref ** 2).sum(axis=2)) + 1e-6)
     print("pixels within 2e-4: %.4f, within 1e-2: %.4f, worst %.3g, mean ratio %.6f" % ((rel <= 2e-4).mean(), (rel <= 1e-2).mean(), rel.max(), img.mean() / ref.mean()))
@@ -526,7 +536,7 @@ def test_textured_matte_per_pixel_against_the_numpy_restatement(hk, oracle):
 def test_device_textured_matte_per_pixel_against_the_numpy_restatement(hk):
     """the HIP path's frame of the textured room against the NumPy restatement — no oracle in between"""
     w = h = 32
-    s, film, cam = _textured_room(hk, w, h)
+    s, film, cam = _textured_room(hk, w, h, True)
     vp = hk.VolPath(max_depth=5, samples=4, filter=hk.BoxFilter())
     vp(s, film, cam)
     dev = film.framebuffer.copy()

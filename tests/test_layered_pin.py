@@ -1,0 +1,88 @@
+"""CoatedDiffuseMaterial from a second source ("a wrong r_l after ... a CoatedDiffuse bounce"): tests/ref_layered_np.py
+restates pbrt-v4's LayeredBxDF as the reference ports it (materials/spectral-eval.jl:815-1940) in scalar float32 NumPy and is compared
+POINT BY POINT with the oracle's sample_bsdf_spectral / evaluate_bsdf_spectral on identical (wo, wi, n, lambda, u, uc).  The random walks
+draw from a PCG32 seeded by hashes of the float bits of their inputs, so identical inputs give the same walk on both sides and the
+comparison is exact up to the roundings of float32 transcendentals — except where such a rounding flips a branch of the walk (a
+reflection / transmission choice, a roulette): those samples differ wholesale and are counted."""
+import numpy as np
+import pytest
+
+import ref_layered_np as LN
+import ref_volpath_np as R
+
+
+def _unit(v):
+    return (v / np.linalg.norm(v, axis=-1, keepdims=True)).astype(np.float32)
+
+
+CASES = {
+    # name: (kwargs of CoatedDiffuseMaterial, regularize)
+    "smooth_no_medium": (dict(reflectance=(0.7, 0.4, 0.2), u_roughness=0.0, v_roughness=0.0, thickness=0.02, eta=1.5), False),
+    "rough": (dict(reflectance=(0.5, 0.6, 0.3), u_roughness=0.25, v_roughness=0.25, thickness=0.05, eta=1.4), False),
+    "rough_aniso_medium": (dict(reflectance=(0.6, 0.5, 0.5), u_roughness=0.3, v_roughness=0.1, thickness=0.3, eta=1.5, albedo=(0.7, 0.8, 0.6), g=0.4, max_depth=12, n_samples=2), False),
+    "smooth_medium_regularized": (dict(reflectance=(0.3, 0.5, 0.7), u_roughness=0.0005, v_roughness=0.0005, thickness=0.2, eta=1.6, albedo=(0.5, 0.5, 0.9), g=-0.3, remap_roughness=False), True),
+}
+
+
+def _params(hk, kw, lam, tables):
+    rgb = lambda c: np.array(c if np.ndim(c) else (c, c, c), np.float32)
+    refl = R.eval_poly(R.F(tables.rgb_to_poly(list(rgb(kw["reflectance"]))))[None], lam[None])[0]
+    alb_rgb = rgb(kw.get("albedo", 0.0))
+    albedo = R.eval_poly(R.F(tables.rgb_to_poly(list(alb_rgb)))[None], lam[None])[0]
+    remap = kw.get("remap_roughness", True)
+    al = lambda r: np.float32(np.sqrt(np.float32(r))) if remap else np.float32(r)
+    return LN.Coated(refl, albedo, bool((alb_rgb != 0).any()), al(kw.get("u_roughness", 0.0)), al(kw.get("v_roughness", 0.0)), kw.get("eta", 1.5), kw.get("thickness", 0.01),
+                     kw.get("g", 0.0), kw.get("max_depth", 10), kw.get("n_samples", 1))
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_coated_diffuse_point_wise_against_the_numpy_restatement(hk, oracle, name):
+    from hikari_jl_amd import geometry as G
+    kw, regularize = CASES[name]
+    Rg = hk.RGBSpectrum
+    mk = dict(kw)
+    for k in ("reflectance", "albedo"):
+        if k in mk:
+            mk[k] = Rg(*mk[k])
+    s = hk.Scene()
+    s.push(G.quad((-1, 0, -1), (1, 0, -1), (1, 0, 1), (-1, 0, 1), normal=(0, 1, 0)), hk.CoatedDiffuseMaterial(**mk))
+    s.push(hk.PointLight((0, 2, 0), Rg(1.0)))
+    s.sync()
+    tables = R.Tables(hk.tables.load())
+    rng = np.random.default_rng(hash(name) % 1000)
+    n = 160
+    ns = _unit(rng.normal(size=(n, 3)))
+    wo = _unit(rng.normal(size=(n, 3)))
+    wi = _unit(rng.normal(size=(n, 3)))
+    lam = (380 + 420 * rng.random((n, 4))).astype(np.float32)
+    u = rng.random((n, 2)).astype(np.float32)
+    uc = rng.random(n).astype(np.float32)
+    osc = oracle.OracleScene(s)
+    smp = osc.bsdf(0, 0, wo, wi, ns, lam, u, uc, regularize=regularize)
+    evl = osc.bsdf(1, 0, wo, wi, ns, lam, u, uc)
+    osc.close()
+
+    def close(a, b, rt):
+        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        return bool(np.all(np.abs(a - b) <= rt * np.maximum(np.abs(a), np.abs(b)) + 1e-12))
+
+    bad_s = bad_e = n_valid = n_spec = 0
+    for i in range(n):
+        P = _params(hk, kw, lam[i], tables)
+        got = LN.coated_sample(P, wo[i], ns[i], (u[i, 0], u[i, 1]), uc[i], regularize)
+        r = smp[i]
+        valid_ref = r[7] > 0 and np.any(r[3:7] != 0)
+        if got is None:
+            ok = not valid_ref
+        else:
+            w2, f2, p2, sp2, eta2 = got
+            n_valid += 1
+            n_spec += bool(sp2)
+            ok = bool(valid_ref) and close(w2, r[0:3], 2e-5) and close(f2, r[3:7], 2e-4) and close([p2], r[7:8], 2e-4) and bool(sp2) == bool(r[8]) and close([eta2], r[9:10], 1e-6)
+        bad_s += 0 if ok else 1
+        f3, p3 = LN.coated_eval(P, wo[i], wi[i], ns[i])
+        e = evl[i]
+        bad_e += 0 if (close(f3, e[0:4], 5e-4) and close([p3], e[4:5], 5e-4)) else 1
+    print("%s: %d samples (%d valid, %d specular paths), %d differ; %d evaluations, %d differ" % (name, n, n_valid, n_spec, bad_s, n, bad_e))
+    assert n_valid >= n // 3
+    assert bad_s <= max(2, n // 50) and bad_e <= max(2, n // 50)

@@ -86,3 +86,60 @@ def test_coated_diffuse_point_wise_against_the_numpy_restatement(hk, oracle, nam
     print("%s: %d samples (%d valid, %d specular paths), %d differ; %d evaluations, %d differ" % (name, n, n_valid, n_spec, bad_s, n, bad_e))
     assert n_valid >= n // 3
     assert bad_s <= max(2, n // 50) and bad_e <= max(2, n // 50)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(CASES))
+def test_device_coated_diffuse_point_wise_against_the_numpy_restatement(hk, gpu_ctx, name):
+    """The HIP BSDF (hk_test_bsdf through the C-ABI) against the NumPy restatement directly — no oracle in between.  The device's log / exp /
+    sin / cos are the hardware's (1 - 2 ulp): a few more walks take another branch than on the CPU."""
+    from hikari_jl_amd import geometry as G
+    kw, regularize = CASES[name]
+    Rg = hk.RGBSpectrum
+    mk = dict(kw)
+    for k in ("reflectance", "albedo"):
+        if k in mk:
+            mk[k] = Rg(*mk[k])
+    s = hk.Scene()
+    s.push(G.quad((-1, 0, -1), (1, 0, -1), (1, 0, 1), (-1, 0, 1), normal=(0, 1, 0)), hk.CoatedDiffuseMaterial(**mk))
+    s.push(hk.PointLight((0, 2, 0), Rg(1.0)))
+    s.sync()
+    tables = R.Tables(hk.tables.load())
+    rng = np.random.default_rng(hash(name) % 1000 + 7)
+    n = 160
+    ns = _unit(rng.normal(size=(n, 3)))
+    wo = _unit(rng.normal(size=(n, 3)))
+    wi = _unit(rng.normal(size=(n, 3)))
+    lam = (380 + 420 * rng.random((n, 4))).astype(np.float32)
+    u = rng.random((n, 2)).astype(np.float32)
+    uc = rng.random(n).astype(np.float32)
+    sh = hk.scene_handle(gpu_ctx, s)
+    L = hk._lib.lib()
+    PF = hk._abi.PF
+    outs = []
+    for mode, reg in ((0, regularize), (1, False)):
+        out = np.zeros((n, 10), np.float32)
+        hk._lib.check(L.hk_test_bsdf(gpu_ctx.h, sh, mode, 0, 1 if reg else 0, n, *[a.ctypes.data_as(PF) for a in (wo, wi, ns, lam, u, uc, out)]), "hk_test_bsdf")
+        outs.append(out)
+    smp, evl = outs
+
+    def close(a, b, rt):
+        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        return bool(np.all(np.abs(a - b) <= rt * np.maximum(np.abs(a), np.abs(b)) + 1e-12))
+
+    bad_s = bad_e = 0
+    for i in range(n):
+        P = _params(hk, kw, lam[i], tables)
+        got = LN.coated_sample(P, wo[i], ns[i], (u[i, 0], u[i, 1]), uc[i], regularize)
+        r = smp[i]
+        valid_dev = r[7] > 0 and np.any(r[3:7] != 0)
+        if got is None:
+            ok = not valid_dev
+        else:
+            w2, f2, p2, sp2, eta2 = got
+            ok = bool(valid_dev) and close(w2, r[0:3], 5e-5) and close(f2, r[3:7], 1e-3) and close([p2], r[7:8], 1e-3) and bool(sp2) == bool(r[8]) and close([eta2], r[9:10], 1e-6)
+        bad_s += 0 if ok else 1
+        f3, p3 = LN.coated_eval(P, wo[i], wi[i], ns[i])
+        bad_e += 0 if (close(f3, evl[i][0:4], 2e-3) and close([p3], evl[i][4:5], 2e-3)) else 1
+    print("device vs restatement (coated diffuse, %s): %d samples, %d differ; %d evaluations, %d differ" % (name, n, bad_s, n, bad_e))
+    assert bad_s <= n // 16 and bad_e <= n // 16

@@ -5251,8 +5251,10 @@ bool launch_small_pass(hipStream_t s, int n_cu, const DPathState& st, const DSce
     // (Cornell 800^2, one sample per call: 1.42 / 1.05 / 1.14 ms at 4 / 8 / 16 segments per CU — 256- / 512- / 1024-thread blocks; a 768-thread
     // block for 12: 1.55.  Eight waves per CU hold 312 paths each: chunks stay fuller down the bounces than with 156, and at two waves per
     // SIMD nothing spills.)
-    if (cls == 2) {   // the general instantiation wants its registers: two waves per SIMD at most
-        if (st.n_waves > 8 * n_cu) return false;
+    // two waves per SIMD at most: at 16 segments per CU (1 024-thread blocks, 128 registers) the matte instantiation spilled 372 B per lane
+    // and lost to 8 (1.14 ms against 1.05), the general one does not fit at all — such a pass keeps the launches
+    if (st.n_waves > 8 * n_cu) return false;
+    if (cls == 2) {
         if (sc.bvh_depth > 16) {
             if (st.n_waves > 4 * n_cu) HK_SMALL_PASS_LAUNCH(512, true, HK_LDS_STACK)
             else HK_SMALL_PASS_LAUNCH(256, true, HK_LDS_STACK)
@@ -5260,8 +5262,7 @@ bool launch_small_pass(hipStream_t s, int n_cu, const DPathState& st, const DSce
         else HK_SMALL_PASS_LAUNCH(256, true)
         return true;
     }
-    if (st.n_waves > 8 * n_cu) HK_SMALL_PASS_LAUNCH(1024, false)
-    else if (st.n_waves > 4 * n_cu) HK_SMALL_PASS_LAUNCH(512, false)
+    if (st.n_waves > 4 * n_cu) HK_SMALL_PASS_LAUNCH(512, false)
     else HK_SMALL_PASS_LAUNCH(256, false)
 #undef HK_SMALL_PASS_LAUNCH
     return true;

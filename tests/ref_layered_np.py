@@ -301,6 +301,82 @@ def pdf_diffuse(wo, wi):
     return f32(abs(wi[2]) / PI) if same_hemisphere(wo, wi) else f32(0)
 
 
+class DiffuseBottom:
+    """CoatedDiffuse's base: the Lambertian interface above (sample_diffuse_interface / eval_ / pdf_, :1144-1199)"""
+
+    def __init__(self, refl):
+        self.refl = np.asarray(refl, np.float32)
+
+    def sample(self, wo, u, uc, flags):
+        return sample_diffuse(wo, u, self.refl, flags)
+
+    def eval(self, wo, wi):
+        return eval_diffuse(wo, wi, self.refl)
+
+    def pdf(self, wo, wi):
+        return pdf_diffuse(wo, wi)
+
+    # the draws pdf_layered_bsdf takes for its two base samples (:1893-1894, :1912-1913)
+    def draw_rs(self, rng):
+        return (rng.f32(), rng.f32()), f32(0)
+
+    def draw_wis(self, rng):
+        return (rng.f32(), rng.f32()), f32(0)
+
+
+class DiffuseTransmissionBottom:
+    """CoatedDiffuseTransmission's base (sample_ / eval_ / pdf_diffuse_transmission_bottom, :2257-2335): a Lambertian lobe on wo's side with
+    probability pr / (pr + pt), one on the other side otherwise (pr, pt: the largest components of the clamped reflectance / transmittance)"""
+
+    def __init__(self, refl, trans, pr, pt):
+        self.refl, self.trans, self.pr, self.pt = np.asarray(refl, np.float32), np.asarray(trans, np.float32), f32(pr), f32(pt)
+
+    def sample(self, wo, u, uc, flags):
+        pr = self.pr if flags & REFL else f32(0)
+        pt = self.pt if flags & TRANS else f32(0)
+        if f32(pr + pt) < f32(1e-10):
+            return S()
+        prob_r = f32(pr / f32(pr + pt))
+        wi = cosine_hemisphere(np.array([u[0]], np.float32), np.array([u[1]], np.float32))[0]
+        if uc < prob_r:
+            if wo[2] < 0:
+                wi = V(wi[0], wi[1], -wi[2])
+            c = abs(wi[2])
+            if c < f32(1e-6):
+                return S()
+            return S((self.refl * f32(f32(1) / PI)).astype(np.float32), wi, f32(f32(prob_r * c) / PI), True, False, 1.0, True)
+        if wo[2] > 0:
+            wi = V(wi[0], wi[1], -wi[2])
+        c = abs(wi[2])
+        if c < f32(1e-6):
+            return S()
+        return S((self.trans * f32(f32(1) / PI)).astype(np.float32), wi, f32(f32(f32(f32(1) - prob_r) * c) / PI), False, False, 1.0, True)
+
+    def eval(self, wo, wi):
+        if f32(self.pr + self.pt) < f32(1e-10):
+            return np.zeros(4, np.float32), f32(0)
+        c = abs(wi[2])
+        if same_hemisphere(wo, wi):
+            return (self.refl * f32(f32(1) / PI)).astype(np.float32), f32(f32(f32(self.pr / f32(self.pr + self.pt)) * c) / PI)
+        return (self.trans * f32(f32(1) / PI)).astype(np.float32), f32(f32(f32(self.pt / f32(self.pr + self.pt)) * c) / PI)
+
+    def pdf(self, wo, wi):
+        if f32(self.pr + self.pt) < f32(1e-10):
+            return f32(0)
+        c = abs(wi[2])
+        share = f32(self.pr / f32(self.pr + self.pt)) if same_hemisphere(wo, wi) else f32(self.pt / f32(self.pr + self.pt))
+        return f32(f32(share * c) / PI)
+
+    # pdf_layered_bsdf_dt draws u5, u6, uc3 for its base reflection sample and uc2, u3, u4 for the exit sample (:2790-2792, :2812-2814)
+    def draw_rs(self, rng):
+        u = (rng.f32(), rng.f32())
+        return u, rng.f32()
+
+    def draw_wis(self, rng):
+        uc = rng.f32()
+        return (rng.f32(), rng.f32()), uc
+
+
 def power_heuristic(fp, gp):
     f2, g2 = f32(fp * fp), f32(gp * gp)
     return f32(0) if f32(f2 + g2) == 0 else f32(f2 / f32(f2 + g2))
@@ -345,8 +421,9 @@ class Coated:
     """the evaluated parameters of one CoatedDiffuseMaterial at one wavelength set: refl / albedo [4] (uplifted), alpha_x / alpha_y (after
     roughness_to_alpha when remapped), eta, thickness (>= eps), g (clamped to +-0.99), has_medium, max_depth, n_samples"""
 
-    def __init__(self, refl, albedo, has_medium, ax, ay, eta, thickness, g, max_depth, n_samples):
+    def __init__(self, refl, albedo, has_medium, ax, ay, eta, thickness, g, max_depth, n_samples, bottom=None):
         self.refl, self.albedo, self.has_medium = np.asarray(refl, np.float32), np.asarray(albedo, np.float32), bool(has_medium)
+        self.bottom = bottom if bottom is not None else DiffuseBottom(refl)      # (CoatedDiffuseTransmission: a DiffuseTransmissionBottom — the walks are the same text, :2341-2840)
         self.ax, self.ay, self.eta = f32(ax), f32(ay), f32(eta)
         self.thickness = max(f32(thickness), EPS)
         self.g = min(max(f32(g), f32(-0.99)), f32(0.99))
@@ -424,7 +501,7 @@ def coated_sample(P, wo, n, u, uc, regularize=False):
             at_bottom = z == 0
             uc2, u2 = rng.f32(), None
             u2 = (rng.f32(), rng.f32())
-            bi = sample_diffuse(-w, u2, P.refl, ALL) if at_bottom else sample_dielectric(-w, uc2, u2, ax, ay, P.eta, ALL)
+            bi = P.bottom.sample(-w, u2, uc2, ALL) if at_bottom else sample_dielectric(-w, uc2, u2, ax, ay, P.eta, ALL)
             if (not bi.valid) or bi.pdf == 0 or bi.wi[2] == 0:
                 return None
             f = (f * bi.f).astype(np.float32)
@@ -456,12 +533,12 @@ def coated_pdf(P, wo, wi):
                 wis = sample_dielectric(wi, uc2, u2, ax, ay, eta, TRANS)
                 if wos.valid and wos.pdf > 0 and wis.valid and wis.pdf > 0:
                     if smooth:
-                        total = f32(total + pdf_diffuse(-wos.wi, -wis.wi))
+                        total = f32(total + P.bottom.pdf(-wos.wi, -wis.wi))
                     else:
-                        u3 = (rng.f32(), rng.f32())
-                        rs = sample_diffuse(-wos.wi, u3, P.refl, ALL)
+                        u3, uc3 = P.bottom.draw_rs(rng)
+                        rs = P.bottom.sample(-wos.wi, u3, uc3, ALL)
                         if rs.valid and rs.pdf > 0:
-                            r_pdf = pdf_diffuse(-wos.wi, -wis.wi)
+                            r_pdf = P.bottom.pdf(-wos.wi, -wis.wi)
                             total = f32(total + f32(power_heuristic(wis.pdf, r_pdf) * r_pdf))
                             t_pdf = pdf_dielectric(-rs.wi, wi, ax, ay, eta)
                             total = f32(total + f32(power_heuristic(rs.pdf, t_pdf) * t_pdf))
@@ -470,14 +547,14 @@ def coated_pdf(P, wo, wi):
                 wos = sample_dielectric(wo, uc1, u1, ax, ay, eta, TRANS)
                 if (not wos.valid) or wos.pdf == 0 or wos.refl:
                     continue
-                u2 = (rng.f32(), rng.f32())
-                wis = sample_diffuse(wi, u2, P.refl, TRANS)
+                u2, uc2 = P.bottom.draw_wis(rng)
+                wis = P.bottom.sample(wi, u2, uc2, TRANS)
                 if (not wis.valid) or wis.pdf == 0 or wis.refl:
                     continue
                 if smooth:
-                    total = f32(total + pdf_diffuse(-wos.wi, wi))
+                    total = f32(total + P.bottom.pdf(-wos.wi, wi))
                 else:
-                    total = f32(total + f32(f32(pdf_dielectric(wo, -wis.wi, ax, ay, eta) + pdf_diffuse(-wos.wi, wi)) / f32(2)))
+                    total = f32(total + f32(f32(pdf_dielectric(wo, -wis.wi, ax, ay, eta) + P.bottom.pdf(-wos.wi, wi)) / f32(2)))
     est = f32(total / ns)
     # lerp(0.9f0, 1 / 4 pi, est) with the reference's OWN lerp(v1, v2, t) = (1 - t) v1 + t v2 (spectrum.jl:33): the estimate is the interpolation
     # PARAMETER between 0.9 and 1 / 4 pi — pbrt-v4 mixes the other way round (Lerp(0.9, 1 / 4 pi, estimate)); the reference is what is restated
@@ -511,7 +588,7 @@ def coated_eval(P, wo, wi, n):
             if (not wos.valid) or wos.pdf == 0 or wos.wi[2] == 0:
                 continue
             uc, u = rng.f32(), (rng.f32(), rng.f32())
-            wis = sample_diffuse(wil, u, P.refl, TRANS) if exit_bottom else sample_dielectric(wil, uc, u, ax, ay, eta, TRANS)
+            wis = P.bottom.sample(wil, u, uc, TRANS) if exit_bottom else sample_dielectric(wil, uc, u, ax, ay, eta, TRANS)
             if (not wis.valid) or wis.pdf == 0 or wis.wi[2] == 0:
                 continue
             beta = (wos.f * abs(wos.wi[2]) / wos.pdf).astype(np.float32)
@@ -543,7 +620,7 @@ def coated_eval(P, wo, wi, n):
                         w, z = wi_p, zp
                         if (z < exit_z and w[2] > 0) or (z > exit_z and w[2] < 0):
                             if exit_bottom:
-                                fe, epdf = eval_diffuse(-w, wil, P.refl)
+                                fe, epdf = P.bottom.eval(-w, wil)
                             else:
                                 if not smooth:
                                     fv, _ = eval_dielectric(-w, wil, ax, ay, eta)
@@ -559,7 +636,7 @@ def coated_eval(P, wo, wi, n):
                     beta = (beta * layer_tr(th, w)).astype(np.float32)
                 if z == exit_z:
                     uc, u = rng.f32(), (rng.f32(), rng.f32())
-                    bs = sample_diffuse(-w, u, P.refl, REFL) if exit_bottom else sample_dielectric(-w, uc, u, ax, ay, eta, REFL)
+                    bs = P.bottom.sample(-w, u, uc, REFL) if exit_bottom else sample_dielectric(-w, uc, u, ax, ay, eta, REFL)
                     if (not bs.valid) or bs.pdf == 0 or bs.wi[2] == 0:
                         break
                     beta = (beta * bs.f * abs(bs.wi[2]) / bs.pdf).astype(np.float32)
@@ -571,29 +648,29 @@ def coated_eval(P, wo, wi, n):
                             fv, _ = eval_dielectric(-w, -wis.wi, ax, ay, eta)
                             fn = s4(fv)
                         else:
-                            fn, _ = eval_diffuse(-w, -wis.wi, P.refl)
+                            fn, _ = P.bottom.eval(-w, -wis.wi)
                         if mx(fn) > 0:
                             wt = f32(1)
                             if (not exit_bottom) or (not smooth):
-                                npdf = pdf_dielectric(-w, -wis.wi, ax, ay, eta) if z == th else pdf_diffuse(-w, -wis.wi)
+                                npdf = pdf_dielectric(-w, -wis.wi, ax, ay, eta) if z == th else P.bottom.pdf(-w, -wis.wi)
                                 wt = power_heuristic(wis.pdf, npdf)
                             res = (res + beta * fn * abs(wis.wi[2]) * wt * layer_tr(th, wis.wi) * wis.f / wis.pdf).astype(np.float32)
                     uc, u = rng.f32(), (rng.f32(), rng.f32())
-                    bs = sample_dielectric(-w, uc, u, ax, ay, eta, REFL) if z == th else sample_diffuse(-w, u, P.refl, REFL)
+                    bs = sample_dielectric(-w, uc, u, ax, ay, eta, REFL) if z == th else P.bottom.sample(-w, u, uc, REFL)
                     if (not bs.valid) or bs.pdf == 0 or bs.wi[2] == 0:
                         break
                     beta = (beta * bs.f * abs(bs.wi[2]) / bs.pdf).astype(np.float32)
                     w = bs.wi
                     if (not smooth) or exit_bottom:
                         if exit_bottom:
-                            f3, _ = eval_diffuse(-w, wil, P.refl)
+                            f3, _ = P.bottom.eval(-w, wil)
                         else:
                             fv, _ = eval_dielectric(-w, wil, ax, ay, eta)
                             f3 = s4(fv)
                         if mx(f3) > 0:
                             wt3 = f32(1)
                             if not non_exit_spec:
-                                e3 = pdf_diffuse(-w, wil) if exit_bottom else pdf_dielectric(-w, wil, ax, ay, eta, TRANS)
+                                e3 = P.bottom.pdf(-w, wil) if exit_bottom else pdf_dielectric(-w, wil, ax, ay, eta, TRANS)
                                 wt3 = power_heuristic(bs.pdf, e3)
                             res = (res + beta * layer_tr(th, bs.wi) * f3 * wt3).astype(np.float32)
     res = (res / ns).astype(np.float32)

@@ -1,4 +1,4 @@
-"""CoatedDiffuseMaterial from a second source ("a wrong r_l after ... a CoatedDiffuse bounce"): tests/ref_layered_np.py
+"""CoatedDiffuseMaterial and CoatedDiffuseTransmissionMaterial from a second source ("a wrong r_l after ... a CoatedDiffuse bounce"): tests/ref_layered_np.py
 restates pbrt-v4's LayeredBxDF as the reference ports it (materials/spectral-eval.jl:815-1940) in scalar float32 NumPy and is compared
 POINT BY POINT with the oracle's sample_bsdf_spectral / evaluate_bsdf_spectral on identical (wo, wi, n, lambda, u, uc).  The random walks
 draw from a PCG32 seeded by hashes of the float bits of their inputs, so identical inputs give the same walk on both sides and the
@@ -24,7 +24,26 @@ CASES = {
 }
 
 
+CDT_CASES = {
+    "cdt_smooth": (dict(reflectance=(0.5, 0.3, 0.2), transmittance=(0.3, 0.5, 0.6), u_roughness=0.0, v_roughness=0.0, thickness=0.05, eta=1.5), False),
+    "cdt_rough_medium": (dict(reflectance=(0.6, 0.6, 0.4), transmittance=(0.2, 0.3, 0.7), u_roughness=0.2, v_roughness=0.35, thickness=0.25, eta=1.45, albedo=(0.8, 0.6, 0.7), g=0.3,
+                              max_depth=12, n_samples=2), False),
+    "cdt_regularized": (dict(reflectance=(1.4, 0.2, 0.1), transmittance=(0.05, 0.9, 0.3), u_roughness=0.01, v_roughness=0.01, thickness=0.1, eta=1.6), True),
+}
+CASES.update(CDT_CASES)
+
+
 def _params(hk, kw, lam, tables):
+    if "transmittance" in kw:      # CoatedDiffuseTransmission: reflectance / transmittance clamped to [0, 1], the base's lobe chosen by their largest components
+        cl = lambda c: np.clip(np.array(c, np.float32), 0, 1)
+        rr, tt = cl(kw["reflectance"]), cl(kw["transmittance"])
+        up = lambda c: R.eval_poly(R.F(tables.rgb_to_poly([float(x) for x in c]))[None], lam[None])[0]
+        alb_rgb = np.array(kw.get("albedo", (0.0, 0.0, 0.0)), np.float32)
+        remap = kw.get("remap_roughness", True)
+        al = lambda r: np.float32(np.sqrt(np.float32(r))) if remap else np.float32(r)
+        refl, trans = up(rr), up(tt)
+        return LN.Coated(refl, up(alb_rgb), bool((alb_rgb != 0).any()), al(kw.get("u_roughness", 0.0)), al(kw.get("v_roughness", 0.0)), kw.get("eta", 1.5), kw.get("thickness", 0.01),
+                         kw.get("g", 0.0), kw.get("max_depth", 10), kw.get("n_samples", 1), bottom=LN.DiffuseTransmissionBottom(refl, trans, rr.max(), tt.max()))
     rgb = lambda c: np.array(c if np.ndim(c) else (c, c, c), np.float32)
     refl = R.eval_poly(R.F(tables.rgb_to_poly(list(rgb(kw["reflectance"]))))[None], lam[None])[0]
     alb_rgb = rgb(kw.get("albedo", 0.0))
@@ -41,15 +60,15 @@ def test_coated_diffuse_point_wise_against_the_numpy_restatement(hk, oracle, nam
     kw, regularize = CASES[name]
     Rg = hk.RGBSpectrum
     mk = dict(kw)
-    for k in ("reflectance", "albedo"):
+    for k in ("reflectance", "albedo", "transmittance"):
         if k in mk:
             mk[k] = Rg(*mk[k])
     s = hk.Scene()
-    s.push(G.quad((-1, 0, -1), (1, 0, -1), (1, 0, 1), (-1, 0, 1), normal=(0, 1, 0)), hk.CoatedDiffuseMaterial(**mk))
+    s.push(G.quad((-1, 0, -1), (1, 0, -1), (1, 0, 1), (-1, 0, 1), normal=(0, 1, 0)), (hk.CoatedDiffuseTransmissionMaterial if "transmittance" in mk else hk.CoatedDiffuseMaterial)(**mk))
     s.push(hk.PointLight((0, 2, 0), Rg(1.0)))
     s.sync()
     tables = R.Tables(hk.tables.load())
-    rng = np.random.default_rng(hash(name) % 1000)
+    rng = np.random.default_rng(sum(name.encode()))
     n = 160
     ns = _unit(rng.normal(size=(n, 3)))
     wo = _unit(rng.normal(size=(n, 3)))
@@ -97,15 +116,15 @@ def test_device_coated_diffuse_point_wise_against_the_numpy_restatement(hk, gpu_
     kw, regularize = CASES[name]
     Rg = hk.RGBSpectrum
     mk = dict(kw)
-    for k in ("reflectance", "albedo"):
+    for k in ("reflectance", "albedo", "transmittance"):
         if k in mk:
             mk[k] = Rg(*mk[k])
     s = hk.Scene()
-    s.push(G.quad((-1, 0, -1), (1, 0, -1), (1, 0, 1), (-1, 0, 1), normal=(0, 1, 0)), hk.CoatedDiffuseMaterial(**mk))
+    s.push(G.quad((-1, 0, -1), (1, 0, -1), (1, 0, 1), (-1, 0, 1), normal=(0, 1, 0)), (hk.CoatedDiffuseTransmissionMaterial if "transmittance" in mk else hk.CoatedDiffuseMaterial)(**mk))
     s.push(hk.PointLight((0, 2, 0), Rg(1.0)))
     s.sync()
     tables = R.Tables(hk.tables.load())
-    rng = np.random.default_rng(hash(name) % 1000 + 7)
+    rng = np.random.default_rng(sum(name.encode()) + 7)
     n = 160
     ns = _unit(rng.normal(size=(n, 3)))
     wo = _unit(rng.normal(size=(n, 3)))

@@ -675,3 +675,191 @@ def coated_eval(P, wo, wi, n):
                             res = (res + beta * layer_tr(th, bs.wi) * f3 * wt3).astype(np.float32)
     res = (res / ns).astype(np.float32)
     return res, coated_pdf(P, wol, wil)
+
+
+# ---------------------------------------------------------------------------------------------------- CoatedConductor (spectral-eval.jl:2877-3425)
+# NOT a random walk in the reference: an analytic composition of the dielectric coating and the conductor base, case by case
+# (smooth / rough coating x smooth / rough conductor).  Deterministic, no hashes.
+class CoatedCond:
+    """parameters at one wavelength set: interface eta (0 -> 1) and alphas, conductor alphas, conductor eta / k [4] ALREADY divided by the
+    interface eta (:2933-2935), thickness (>= eps), albedo [4], has_medium"""
+
+    def __init__(self, ieta, iax, iay, cax, cay, ce, ck, thickness, albedo, has_medium):
+        self.ieta = f32(1) if f32(ieta) == 0 else f32(ieta)
+        self.iax, self.iay, self.cax, self.cay = f32(iax), f32(iay), f32(cax), f32(cay)
+        self.ce, self.ck = (np.asarray(ce, np.float32) / self.ieta).astype(np.float32), (np.asarray(ck, np.float32) / self.ieta).astype(np.float32)
+        self.thickness = max(f32(thickness), EPS)
+        self.albedo, self.has_medium = np.asarray(albedo, np.float32), bool(has_medium)
+
+
+def _frc(c, P):
+    from ref_volpath_np import fr_complex
+    return fr_complex(np.array([[f32(c)]], np.float32), P.ce[None], P.ck[None])[0]
+
+
+def cc_sample(P, wo, n, u, uc, regularize=False):
+    """sample_bsdf_spectral(::CoatedConductorMaterial) -> None, or (wi world, f [4], pdf, is_specular)"""
+    wo, n = np.asarray(wo, np.float32), np.asarray(n, np.float32)
+    wdn = dot(wo, n)
+    if abs(wdn) < f32(1e-6):
+        return None
+    iax, iay, cax, cay = P.iax, P.iay, P.cax, P.cay
+    if regularize:
+        iax, iay, cax, cay = regularize_alpha(iax), regularize_alpha(iay), regularize_alpha(cax), regularize_alpha(cay)
+    ieta, th = P.ieta, P.thickness
+    tg, bt = _frame(n)
+    wl = V(dot(wo, tg), dot(wo, bt), wdn)
+    flip = wl[2] < 0
+    if flip:
+        wl = -wl
+    co = abs(wl[2])
+
+    def world(w):
+        w = -w if flip else w
+        return normalize((tg * w[0] + bt * w[1] + n * w[2]).astype(np.float32))
+    i_smooth, c_smooth = tr_smooth(iax, iay), tr_smooth(cax, cay)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        if i_smooth:
+            Fi = fresnel(co, ieta)
+            if uc < Fi:
+                return world(V(-wl[0], -wl[1], wl[2])), s4(1.0), f32(1), True
+            s2t = f32(max(f32(0), f32(f32(1) - f32(co * co))) / f32(ieta * ieta))
+            if s2t >= 1:
+                return None
+            ct_in = f32(np.sqrt(f32(f32(1) - s2t)))
+            if c_smooth:
+                wb = normalize(V(f32(-wl[0] / ieta), f32(-wl[1] / ieta), ct_in))
+                Fc = _frc(ct_in, P)
+                s2o = f32(max(f32(0), f32(f32(1) - f32(wb[2] * wb[2]))) * f32(ieta * ieta))
+                if s2o >= 1:
+                    return None
+                c_out = f32(np.sqrt(f32(f32(1) - s2o)))
+                T_in, T_out = f32(f32(1) - Fi), f32(f32(1) - fresnel(c_out, ieta))
+                if P.has_medium:
+                    tr = layer_tr(th, V(0, 0, ct_in))
+                    ltr = (f32(tr * tr) * P.albedo).astype(np.float32)
+                else:
+                    ltr = s4(1.0)
+                f = (Fc * T_in * T_out * ltr / co).astype(np.float32)
+                return world(V(-wl[0], -wl[1], wl[2])), f, f32(f32(1) - Fi), True
+            woc = normalize(V(f32(wl[0] / ieta), f32(wl[1] / ieta), ct_in))
+            cax, cay = max(cax, f32(1e-4)), max(cay, f32(1e-4))
+            wm = tr_sample_wm(woc, u, cax, cay)
+            com = dot(woc, wm)
+            if com < 0:
+                return None
+            wic = ((-woc).astype(np.float32) + (f32(f32(2) * com) * wm).astype(np.float32)).astype(np.float32)
+            if wic[2] < 0:
+                return None
+            Fc = _frc(abs(com), P)
+            fc = (f32(tr_d(wm, cax, cay)) * Fc * tr_g(woc, wic, cax, cay) / f32(f32(f32(4) * abs(woc[2])) * abs(wic[2]))).astype(np.float32)
+            s2o = f32(f32(f32(wic[0] * wic[0]) + f32(wic[1] * wic[1])) * f32(ieta * ieta))
+            if s2o >= 1:
+                return None
+            c_out = f32(np.sqrt(f32(f32(1) - s2o)))
+            T_in, T_out = f32(f32(1) - Fi), f32(f32(1) - fresnel(c_out, ieta))
+            if P.has_medium:
+                ltr = (f32(layer_tr(th, V(0, 0, ct_in)) * layer_tr(th, V(0, 0, wic[2]))) * P.albedo).astype(np.float32)
+            else:
+                ltr = s4(1.0)
+            wil = normalize(V(f32(wic[0] * ieta), f32(wic[1] * ieta), c_out))
+            f = (fc * T_in * T_out * ltr).astype(np.float32)
+            pdf = f32(f32(f32(1) - Fi) * f32(tr_pdf(woc, wm, cax, cay) / f32(f32(4) * abs(com))))
+            return world(wil), f, pdf, False
+        # rough coating
+        iax, iay = max(iax, f32(1e-4)), max(iay, f32(1e-4))
+        wm = tr_sample_wm(wl, u, iax, iay)
+        com = dot(wl, wm)
+        if com < 0:
+            return None
+        Fi = fresnel(com, ieta)
+        if uc < Fi:
+            wil = ((-wl).astype(np.float32) + (f32(f32(2) * com) * wm).astype(np.float32)).astype(np.float32)
+            if f32(wil[2] * wl[2]) < 0:
+                return None
+            fv = f32(f32(tr_d(wm, iax, iay) * tr_g(wl, wil, iax, iay)) / f32(f32(f32(4) * abs(wil[2])) * abs(wl[2])))
+            pdf = f32(f32(Fi * tr_pdf(wl, wm, iax, iay)) / f32(f32(4) * abs(com)))
+            return world(wil), s4(fv), pdf, False
+        T_in = f32(f32(1) - Fi)
+        lc = V(-wl[0], -wl[1], wl[2])
+        if c_smooth:
+            cb = abs(lc[2])
+            Fc = _frc(cb, P)
+            T_out = f32(f32(1) - fresnel(cb, ieta))
+            if P.has_medium:
+                tr = layer_tr(th, lc)
+                ltr = (f32(tr * tr) * P.albedo).astype(np.float32)
+            else:
+                ltr = s4(1.0)
+            f = (Fc * T_in * T_out * ltr / co).astype(np.float32)
+            pdf = f32(f32(f32(f32(1) - Fi) * tr_pdf(wl, wm, iax, iay)) / f32(f32(4) * abs(com)))
+            return world(lc), f, pdf, False
+        cax, cay = max(cax, f32(1e-4)), max(cay, f32(1e-4))
+        wmc = tr_sample_wm(wl, u, cax, cay)
+        comc = dot(wl, wmc)
+        if comc < 0:
+            return None
+        wil = ((-wl).astype(np.float32) + (f32(f32(2) * comc) * wmc).astype(np.float32)).astype(np.float32)
+        if f32(wil[2] * wl[2]) < 0:
+            return None
+        Fc = _frc(abs(comc), P)
+        ci, c_o = abs(wil[2]), abs(wl[2])
+        fc = (f32(tr_d(wmc, cax, cay)) * Fc * tr_g(wl, wil, cax, cay) / f32(f32(f32(4) * ci) * c_o)).astype(np.float32)
+        T_out = f32(f32(1) - fresnel(ci, ieta))
+        if P.has_medium:
+            ltr = (f32(layer_tr(th, V(0, 0, c_o)) * layer_tr(th, wil)) * P.albedo).astype(np.float32)
+        else:
+            ltr = s4(1.0)
+        f = (fc * T_in * T_out * ltr).astype(np.float32)
+        pdf = f32(f32(f32(f32(1) - Fi) * tr_pdf(wl, wmc, cax, cay)) / f32(f32(4) * abs(comc)))
+        return world(wil), f, pdf, False
+
+
+def cc_eval(P, wo, wi, n):
+    """evaluate_bsdf_spectral(::CoatedConductorMaterial) (:3243-3412) -> (f [4], pdf)"""
+    wo, wi, n = np.asarray(wo, np.float32), np.asarray(wi, np.float32), np.asarray(n, np.float32)
+    zero = (np.zeros(4, np.float32), f32(0))
+    ci, co = dot(wi, n), dot(wo, n)
+    if f32(ci * co) < 0:
+        return zero
+    if abs(ci) < f32(1e-6) or abs(co) < f32(1e-6):
+        return zero
+    iax, iay, cax, cay, ieta, th = P.iax, P.iay, P.cax, P.cay, P.ieta, P.thickness
+    tg, bt = _frame(n)
+    wol, wil = V(dot(wo, tg), dot(wo, bt), co), V(dot(wi, tg), dot(wi, bt), ci)
+    if wol[2] < 0:
+        wol, wil = -wol, -wil
+    i_smooth, c_smooth = tr_smooth(iax, iay), tr_smooth(cax, cay)
+    if i_smooth and c_smooth:
+        return zero
+    with np.errstate(divide="ignore", invalid="ignore"):
+        wh = normalize((wol + wil).astype(np.float32))
+        if wh[2] < 0:
+            wh = -wh
+        coh = dot(wol, wh)
+        F_wh, F_o, F_i = fresnel(abs(coh), ieta), fresnel(abs(wol[2]), ieta), fresnel(abs(wil[2]), ieta)
+        T_o, T_i = f32(f32(1) - F_o), f32(f32(1) - F_i)
+        if P.has_medium:
+            tr = layer_tr(th, wil)
+            ltr = (f32(tr * tr) * P.albedo).astype(np.float32)
+        else:
+            ltr = s4(1.0)
+        den = f32(f32(f32(4) * abs(wil[2])) * abs(wol[2]))
+        if i_smooth:
+            cax, cay = max(cax, f32(1e-4)), max(cay, f32(1e-4))
+            fc = (f32(tr_d(wh, cax, cay)) * _frc(abs(coh), P) * tr_g(wol, wil, cax, cay) / den).astype(np.float32)
+            f = (fc * T_o * T_i * ltr).astype(np.float32)
+            pdf = f32(f32(T_o * tr_pdf(wol, wh, cax, cay)) / f32(f32(4) * abs(coh)))
+            return f, pdf
+        iax, iay = max(iax, f32(1e-4)), max(iay, f32(1e-4))
+        f_int = f32(f32(f32(tr_d(wh, iax, iay) * F_wh) * tr_g(wol, wil, iax, iay)) / den)
+        if c_smooth:
+            fc = (_frc(abs(wol[2]), P) / abs(wol[2])).astype(np.float32)
+            pdf_c = f32(1)
+        else:
+            cax, cay = max(cax, f32(1e-4)), max(cay, f32(1e-4))
+            fc = (f32(tr_d(wh, cax, cay)) * _frc(abs(coh), P) * tr_g(wol, wil, cax, cay) / den).astype(np.float32)
+            pdf_c = f32(tr_pdf(wol, wh, cax, cay) / f32(f32(4) * abs(coh)))
+        f = (s4(f_int) + (fc * T_o * T_i * ltr).astype(np.float32)).astype(np.float32)
+        pdf_i = f32(f32(F_o * tr_pdf(wol, wh, iax, iay)) / f32(f32(4) * abs(coh)))
+        return f, f32(pdf_i + f32(T_o * pdf_c))

@@ -536,7 +536,7 @@ class SceneNP:
         self.mi = np.array([desc.meta[i].medium_interface_idx for i in range(T)], np.int64)
         self.arealight = np.array([desc.meta[i].arealight_flat_idx_1based for i in range(T)], np.int64)
         mats = [desc.materials[i] for i in range(desc.n_materials)]
-        assert all(m.kind in (0, 1, 2, 3, 5, 6) for m in mats), "Matte, Mirror, Glass, Conductor, ThinDielectric, DiffuseTransmission only"
+        assert all(m.kind in (0, 1, 2, 3, 5, 6, 8) for m in mats), "Matte, Mirror, Glass, Conductor, ThinDielectric, DiffuseTransmission, CoatedConductor only"
         # parameters that may be TEXTURES (eval_tex, textures/texture-ref.jl:40-80, 222-243): Matte Kd and sigma, Mirror Kr, Glass Kr / Kt,
         # Conductor roughness — an image (bilinear at the hit's uv) or a VertexColorTexture (the face's three colours by the hit's barycentrics);
         # everything else must be constant
@@ -597,7 +597,34 @@ class SceneNP:
             tt = [min(max(f32(f32(m.rgb[1].c[k]) * sc_), f32(0)), f32(1)) for k in range(3)]
             self.dt_r_poly[i], self.dt_t_poly[i] = tables.rgb_to_poly(rr), tables.rgb_to_poly(tt)
             self.dt_pr[i], self.dt_pt[i] = max(rr), max(tt)
+        # CoatedConductor (spectral-eval.jl:2877-3412; the reference's analytic composition — deterministic, so it can live in this loop):
+        # constant parameters, RGB eta / k (flag bit 1: USE_ETA_K) or the reflectance mode; evaluated per hit by ref_layered_np
+        self.cc = {}
+        for i, m in enumerate(mats):
+            if m.kind != 8:
+                continue
+            assert all(m.rgb[k].tex < 0 for k in range(4)) and all(m.f[k].tex < 0 for k in range(7)) and m.spectrum[0] < 0 and m.spectrum[1] < 0
+            remap = bool(m.flags & 1)
+            al = (lambda r: f32(np.sqrt(f32(r)))) if remap else (lambda r: f32(r))
+            self.cc[i] = dict(use_eta_k=bool(m.flags & 2), eta=[f32(m.rgb[0].c[k]) for k in range(3)], k=[f32(m.rgb[1].c[k]) for k in range(3)],
+                              refl=[f32(m.rgb[2].c[k]) for k in range(3)], albedo=[f32(m.rgb[3].c[k]) for k in range(3)],
+                              iax=al(m.f[0].v), iay=al(m.f[1].v), ieta=f32(m.f[2].v), cax=al(m.f[3].v), cay=al(m.f[4].v), thickness=f32(m.f[5].v))
         self._rest(desc, tables)
+
+    def coated_conductor(self, mat, lam):
+        """the CoatedCond parameters of material `mat` at the wavelengths lam [4]"""
+        import ref_layered_np as LN
+        c = self.cc[int(mat)]
+        up = lambda rgb: eval_poly(F(self.tables.rgb_to_poly([float(x) for x in rgb]))[None], F(lam)[None])[0]
+        if c["use_eta_k"]:
+            ce = unbounded_eval(unbounded_poly(self.tables, c["eta"]), F(lam)[None])[0]
+            ck = unbounded_eval(unbounded_poly(self.tables, c["k"]), F(lam)[None])[0]
+        else:
+            r = up([min(max(x, f32(0)), f32(0.9999)) for x in c["refl"]])
+            ce = np.ones(4, f32)
+            ck = (f32(2) * np.sqrt(r) / np.sqrt(np.maximum(f32(1) - r, f32(0)) + f32(1e-6))).astype(f32)
+        alb = c["albedo"]
+        return LN.CoatedCond(c["ieta"], c["iax"], c["iay"], c["cax"], c["cay"], ce, ck, c["thickness"], up(alb), any(x != 0 for x in alb))
 
     def tex_bilinear(self, ti, uv):
         """_sample_texture_bilinear (textures/texture-ref.jl:151-186) of image ti at uv [N, 2] -> [N, channels]: the (1 - v, u) flip, pixel
@@ -2039,6 +2066,14 @@ def render(desc, cam_rec, tables_dict, width, height, n_samples, max_depth, max_
                 dt_ok = ~(np.abs(ci) < f32(1e-6)) & ~(prt < f32(1e-10))
                 f = np.where(is_dt[:, None], np.where(dt_ok[:, None], f_dt, f32(0)), f).astype(f32)
                 bs_pdf = np.where(is_dt, np.where(dt_ok, pdf_dt, f32(0)), bs_pdf).astype(f32)
+            is_cc = kind == 8
+            cc_par = {}
+            if is_cc.any():                                                      # a CoatedConductor: ref_layered_np.cc_eval per hit
+                import ref_layered_np as LN
+                for j in np.nonzero(is_cc)[0]:
+                    cc_par[j] = sc.coated_conductor(mat[j], lm[j])
+                    f_j, p_j = LN.cc_eval(cc_par[j], wo[j], wi[j], ns[j])
+                    f[j], bs_pdf[j] = f_j, p_j
             is_cond = kind == 3
             if is_cond.any():                                                    # a Conductor: the rough lobe evaluates, the smooth one is zero (spectral-eval.jl:415-486)
                 eta_c, k_c = sc.conductor_ior(mat, lm)
@@ -2163,6 +2198,14 @@ def render(desc, cam_rec, tables_dict, width, height, n_samples, max_depth, max_
                 f2 = np.where(is_dt[:, None], f6, f2).astype(f32)
                 pdf2 = np.where(is_dt, pdf6, pdf2).astype(f32)
                 valid = np.where(is_dt, ~(np.abs(wdn) < f32(1e-6)) & ~(prt < f32(1e-10)) & ~(c6 < f32(1e-6)), valid)
+            if is_cc.any():
+                for j in np.nonzero(is_cc)[0]:
+                    got = LN.cc_sample(cc_par[j], wo[j], ns[j], (i_u0[j], i_u1[j]), i_uc[j], bool(anyns[A][j]) and bool(regularize))
+                    if got is None:
+                        valid[j], pdf2[j] = False, f32(0)
+                        continue
+                    wi2[j], f2[j], pdf2[j], is_spec[j] = got[0], got[1], got[2], got[3]
+                    valid[j] = True
             if is_cond.any():
                 # Conductor (spectral-eval.jl:223-318): a visible normal of the Trowbridge-Reitz distribution, regularised once the path has
                 # had a non-specular bounce; the effectively smooth one is a mirror with f = F / cos

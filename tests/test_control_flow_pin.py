@@ -670,3 +670,47 @@ def test_device_thin_dielectric_and_diffuse_transmission_against_the_numpy_resta
     print("device vs restatement (thin dielectric + diffuse transmission): within 2e-4: %.4f, within 1e-2: %.4f, worst %.3g" % ((rel <= 2e-4).mean(), (rel <= 1e-2).mean(), rel.max()))
     assert (rel <= 2e-4).mean() >= 0.99 and (rel <= 1e-2).mean() >= 0.995
     assert abs(img.mean() / dev.mean() - 1.0) < 1e-3
+
+
+@pytest.mark.parametrize("which", ["rough_rough", "smooth_rough_reflectance"])
+def test_coated_conductor_per_pixel_against_the_numpy_restatement(hk, oracle, which):
+    """A LAYERED kind inside the loop: the reference's CoatedConductor is an analytic composition of coating and base (spectral-eval.jl:
+    2877-3412; no random walk, no hashed seeds), so its bounce can be followed per pixel — next-event estimation through cc_eval with the
+    pdf that enters the MIS weights, the sampled bounce through cc_sample (r_l = r_u / pdf after it), regularised once the path has had
+    a non-specular bounce.  (CoatedDiffuse and CoatedDiffuseTransmission ARE hashed walks: point-wise only, tests/test_layered_pin.py.)"""
+    from hikari_jl_amd import scenes
+    R_ = hk.RGBSpectrum
+    w = h = 32
+    if which == "rough_rough":
+        mat = hk.CoatedConductorMaterial(interface_u_roughness=0.1, interface_v_roughness=0.1, interface_eta=1.5, conductor_u_roughness=0.2, conductor_v_roughness=0.2,
+                                         albedo=R_(0.7, 0.8, 0.9), thickness=0.05)
+    else:
+        mat = hk.CoatedConductorMaterial(interface_eta=1.45, conductor_u_roughness=0.15, conductor_v_roughness=0.3, reflectance=R_(0.9, 0.6, 0.3))
+    s, film, cam = scenes.cornell_box(w, h, light="both", object_material=mat)
+    ref, img = _both(hk, oracle, s, cam, w, h, 4, 6)
+    assert np.isfinite(img).all() and ref.max() > 0
+    rel = np.sqrt(((img - ref) ** 2).sum(axis=2)) / (np.sqrt((ref ** 2).sum(axis=2)) + 1e-6)
+    print("pixels within 2e-4: %.4f, within 1e-2: %.4f, worst %.3g, mean ratio %.6f" % ((rel <= 2e-4).mean(), (rel <= 1e-2).mean(), rel.max(), img.mean() / ref.mean()))
+    assert (rel <= 2e-4).mean() >= 0.99 and (rel <= 1e-2).mean() >= 0.995
+    assert abs(img.mean() / ref.mean() - 1.0) < 1e-3
+
+
+@pytest.mark.gpu
+def test_device_coated_conductor_per_pixel_against_the_numpy_restatement(hk):
+    """the HIP path's frame of the box with a rough-on-rough CoatedConductor object against the NumPy restatement — no oracle in between"""
+    from hikari_jl_amd import scenes
+    R_ = hk.RGBSpectrum
+    w = h = 32
+    mat = hk.CoatedConductorMaterial(interface_u_roughness=0.1, interface_v_roughness=0.1, interface_eta=1.5, conductor_u_roughness=0.2, conductor_v_roughness=0.2,
+                                     albedo=R_(0.7, 0.8, 0.9), thickness=0.05)
+    s, film, cam = scenes.cornell_box(w, h, light="both", object_material=mat)
+    vp = hk.VolPath(max_depth=6, samples=4, filter=hk.BoxFilter())
+    vp(s, film, cam)
+    dev = film.framebuffer.copy()
+    mcv = float(vp.params.max_component_value)
+    vp.close()
+    img, _, _ = R.render(s.desc, cam.record(), hk.tables.load(), w, h, 4, 6, max_component_value=mcv, sobol_spp=4)
+    rel = np.sqrt(((img - dev) ** 2).sum(axis=2)) / (np.sqrt((dev ** 2).sum(axis=2)) + 1e-6)
+    print("device vs restatement (coated conductor in the box): within 2e-4: %.4f, within 1e-2: %.4f, worst %.3g" % ((rel <= 2e-4).mean(), (rel <= 1e-2).mean(), rel.max()))
+    assert (rel <= 2e-4).mean() >= 0.99 and (rel <= 1e-2).mean() >= 0.995
+    assert abs(img.mean() / dev.mean() - 1.0) < 1e-3

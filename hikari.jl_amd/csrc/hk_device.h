@@ -1491,7 +1491,10 @@ HKD S4 eval_bsdf(const DScene& sc, const DTables& T, const DMaterial& m, v3 wo_w
 // ------------------------------------------------------------------------------------------------
 HKD v2 equal_area_sphere_to_square(v3 d) {
     float x = fabsf(d.x), y = fabsf(d.y), z = fabsf(d.z);
-    float r = sqrtf(1.0f - z);
+    // quirk Q35: the reference takes sqrt(1 - |z|) bare (environment_map.jl:82; pbrt-v4 has SafeSqrt there) and a NORMALISED direction can
+    // carry |z| = 1 + 2^-23: a DomainError on its CPU path, NaN -> an undefined texel index on a GPU backend.  Where the reference is defined
+    // (|z| <= 1) max(0, .) changes nothing; beyond, the pole's texel is read (what pbrt does) instead of a NaN that would stay in the pixel.
+    float r = sqrtf(maxf(0.0f, 1.0f - z));
     float a = maxf(x, y);
     float b = a == 0.0f ? 0.0f : minf(x, y) / a;
     const float t1 = 0.406758566246788489601959989e-5f, t2 = 0.636226545274016134946890922156f, t3 = 0.61572017898280213493197203466e-2f,

@@ -116,7 +116,9 @@ inline float eval_tex(const TextureSet& ts, const hk_tex_f32& f, const TexCtx& u
 //   Distribution2D sample_continuous / pdf           src/sampler/sampling.jl:264-361
 inline V2 equal_area_sphere_to_square(V3 d) {
     float x = std::fabs(d.x), y = std::fabs(d.y), z = std::fabs(d.z);
-    float r = std::sqrt(1.0f - z);
+    // quirk Q35: sqrt(1 - |z|) of a direction whose |z| is 1 + 2^-23 after normalisation is undefined in the reference
+    // (DomainError on the CPU, NaN on a GPU backend); max(0, .) is the identity wherever the reference is defined
+    float r = std::sqrt(maxf(0.0f, 1.0f - z));
     float a = maxf(x, y);
     float b = a == 0.0f ? 0.0f : minf(x, y) / a;
     const float t1 = 0.406758566246788489601959989e-5f, t2 = 0.636226545274016134946890922156f, t3 = 0.61572017898280213493197203466e-2f,

@@ -1566,7 +1566,7 @@ def ratio_tracking(md, o, d, t_max, lam):
 def equal_area_sphere_to_square(d):
     """textures/environment_map.jl:78-129 (Clarberg's mapping, the polynomial atan), float32, d [N, 3] -> u, v in [0, 1]"""
     x, y, z = np.abs(d[:, 0]), np.abs(d[:, 1]), np.abs(d[:, 2])
-    r = np.sqrt(f32(1) - z)
+    r = np.sqrt(np.maximum(f32(0), f32(1) - z))      # (quirk Q35: a normalised direction may carry |z| = 1 + 2^-23; the reference takes the bare sqrt and is undefined there)
     a = np.maximum(x, y)
     with np.errstate(divide="ignore", invalid="ignore"):
         b = np.where(a == 0, f32(0), np.minimum(x, y) / a).astype(f32)

@@ -168,6 +168,7 @@ def test_environment_light_pointwise_parity(hk, oracle, gpu_ctx):
     u[200:400, 1] = 0.0
     u[400:600] = np.float32(1.0 - 2 ** -24)
     d[:6] = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], np.float32)   # poles / seams
+    d[6:8] = np.array([[0, 0, 1 + 2.0 ** -23], [0, 0, -(1 + 2.0 ** -23)]], np.float32)                      # quirk Q35: |z| one ulp above 1
     sh = hk.scene_handle(gpu_ctx, s)
     L = hk._lib.lib()
     PF = hk._abi.PF

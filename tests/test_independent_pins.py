@@ -306,6 +306,14 @@ def test_equal_area_mapping(oracle):
     assert np.allclose(np.linalg.norm(dirs, axis=1), 1, atol=2e-6) and abs((dirs[:, 2] ** 2).mean() - 1 / 3) < 5e-3
     octant = (dirs[:, 0] > 0) * 4 + (dirs[:, 1] > 0) * 2 + (dirs[:, 2] > 0)
     assert np.abs(np.bincount(octant, minlength=8) / n - 0.125).max() < 5e-3
+    # quirk Q35: a direction normalised in float32 may carry |z| = 1 + 2^-23, where the reference's bare sqrt(1 - |z|) is undefined;
+    # oracle and restatement return the pole's square coordinates (pbrt's SafeSqrt) instead of NaN
+    over = np.array([[0, 0, 1 + 2.0 ** -23], [0, 0, -(1 + 2.0 ** -23)], [2.0 ** -13, 0, 1 + 2.0 ** -23]], f32)
+    pole = np.array([[0, 0, 1], [0, 0, -1], [2.0 ** -13, 0, 1]], f32)
+    got, want = oracle.equal_area(np.zeros((3, 2), f32), over)[:, 3:5], oracle.equal_area(np.zeros((3, 2), f32), pole)[:, 3:5]
+    assert np.isfinite(got).all() and np.array_equal(got, want)
+    import ref_volpath_np as RV
+    assert np.isfinite(np.stack(RV.equal_area_sphere_to_square(over))).all()
 
 
 def test_distribution2d_against_float64(hk, oracle):

@@ -79,7 +79,7 @@ const char* knob(const char* name) {
     return it == tl_knobs->kv.end() ? nullptr : it->second.c_str();
 }
 static const char* const KNOB_NAMES[] = {
-    "HK_BATCH_PATHS_M", "HK_BVH_LEAF", "HK_DEBUG_ALLOC", "HK_DELTA_ADVANCE", "HK_DYNAMIC_SEGMENTS", "HK_GREY", "HK_GREY_COMPACT", "HK_GREY_FLAT", "HK_MAX_PATHS_M",
+    "HK_BATCH_PATHS_M", "HK_BVH_LEAF", "HK_QNODES", "HK_DEBUG_ALLOC", "HK_DELTA_ADVANCE", "HK_DYNAMIC_SEGMENTS", "HK_GREY", "HK_GREY_COMPACT", "HK_GREY_FLAT", "HK_MAX_PATHS_M",
     "HK_MID_LISTS", "HK_MID_PASS_PATHS_M", "HK_NODE_CACHE", "HK_NVDB_DENSE_MB", "HK_OVERLAP", "HK_PIPELINE", "HK_PIPELINE_AFTER", "HK_PIPELINE_MAX_PATHS_M", "HK_PRESELECT",
     "HK_SELECT_MIN_IDLE", "HK_SHADOW_FEED_ROUNDS", "HK_SHADOW_TRACK_BATCH", "HK_SMALL_PASS", "HK_SMALL_PASS_WAVES", "HK_SOBOL_LO_GB", "HK_SOBOL_TABLE_ONLY",
     "HK_STATE_CACHE_GB", "HK_STATE_SLAB", "HK_TICKET_SHARE", "HK_TRACK_ADVANCE", "HK_TRACK_EXTRA_ADVANCE", "HK_TRACK_MIN_PENDING", "HK_TRACK_POOL", "HK_TRACK_REFILL_IDLE",
@@ -304,7 +304,7 @@ static int join_lanes(hk_ctx* c) {
 
 struct hk_scene {
     hk_ctx* ctx = nullptr;
-    DevBuf nodes, leaf_tris, positions, normals, uvs, tangents, meta, materials, textures, spectra, mis, lights, lnodes, trails, infinite;
+    DevBuf nodes, qnodes, leaf_tris, positions, normals, uvs, tangents, meta, materials, textures, spectra, mis, lights, lnodes, trails, infinite;
     std::vector<DevBuf*> tex_data;
     std::vector<DevBuf*> spec_data;
     std::vector<DevBuf*> media_data;
@@ -700,6 +700,45 @@ extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene**
         lt[3 * i + 2] = make_float4(p[6] - p[0], p[7] - p[1], p[8] - p[2], 0.0f);  // e2 = v2 - v0
     }
     HIP_TRY(s->nodes.upload(dn.data(), dn.size() * sizeof(DNode)));
+    // ---- quantised copy of a deep tree (DQNode, hk_types.h): 16-bit planes on a grid over the root box, lo rounded down and hi rounded
+    //      up with one more cell of margin; read by the lean traversal kernels' deep-tree instantiations (HK_QNODES=0: off) ----
+    float q_base[3] = {0, 0, 0}, q_cell[3] = {1, 1, 1};
+    bool have_qnodes = false;
+    {
+        const char* qk = hk::knob("HK_QNODES");
+        if (bvh.max_depth > 16 && !bvh.nodes.empty() && (!qk || std::atoi(qk) != 0)) {
+            for (int k = 0; k < 3; ++k) {
+                const double ext = (double)bvh.hi[k] - (double)bvh.lo[k];
+                q_cell[k] = (float)std::max(ext / 65527.0, 1e-30);
+                q_base[k] = (float)((double)bvh.lo[k] - 3.0 * (double)q_cell[k]);
+            }
+            std::vector<DQNode> qn(bvh.nodes.size());
+            auto quant = [&](float v, int axis, bool upper) -> uint32_t {
+                if (!std::isfinite(v)) return upper ? 0u : 65535u;   // an empty box stays empty (lo > hi)
+                const double g = ((double)v - (double)q_base[axis]) / (double)q_cell[axis];
+                const double q = upper ? std::ceil(g) + 1.0 : std::floor(g) - 1.0;
+                return (uint32_t)std::min(std::max(q, 0.0), 65535.0);
+            };
+            bool ok = true;
+            for (size_t i = 0; i < bvh.nodes.size(); ++i) {
+                const hk::BVHNode& n = bvh.nodes[i];
+                for (int c = 0; c < 2; ++c)
+                    for (int k = 0; k < 3; ++k) {
+                        const float lo = c ? n.lo1[k] : n.lo0[k], hi = c ? n.hi1[k] : n.hi0[k];
+                        const uint32_t ql = quant(lo, k, false), qh = quant(hi, k, true);
+                        // the grid must contain the box with its margin (a box outside the root's bounds would be clipped: never for a child of the root)
+                        if (std::isfinite(lo) && std::isfinite(hi) && ((double)q_base[k] + ql * (double)q_cell[k] > lo || (double)q_base[k] + qh * (double)q_cell[k] < hi)) ok = false;
+                        qn[i].w[3 * c + k] = ql | (qh << 16);
+                    }
+                qn[i].c0 = n.c0;
+                qn[i].c1 = n.c1;
+            }
+            if (ok) {
+                HIP_TRY(s->qnodes.upload(qn.data(), qn.size() * sizeof(DQNode)));
+                have_qnodes = true;
+            }
+        }
+    }
     HIP_TRY(s->leaf_tris.upload(lt.data(), lt.size() * sizeof(float4)));
     HIP_TRY(s->positions.upload(d->positions, (size_t)T * 9 * 4));
     if (d->normals) HIP_TRY(s->normals.upload(d->normals, (size_t)T * 9 * 4));
@@ -1139,6 +1178,8 @@ extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene**
     D.grey_pool = (D.all_grey && D.n_media == 1 && dmed[0].mres[0] <= 1024 && dmed[0].mres[1] <= 1024 && dmed[0].mres[2] <= 1024) ? 1 : 0;
     D.grey_bricks = (D.all_grey && dmed[0].kind == HK_MEDIUM_NANOVDB && dmed[0].nv_bricks != nullptr) ? 1 : 0;
     D.nodes = s->nodes.as<DNode>();
+    D.qnodes = have_qnodes ? s->qnodes.as<DQNode>() : nullptr;
+    for (int k = 0; k < 3; ++k) D.q_base[k] = q_base[k], D.q_cell[k] = q_cell[k];
     D.leaf_tris = s->leaf_tris.as<float4>();
     D.root_ref = bvh.root_ref;
     D.n_tris = T;

@@ -875,6 +875,15 @@ HKD RaySlab ray_slab(v3 o, v3 d) {
     r.eps3 = 3.0f * (2.4e-7f * fmaxf(fmaxf(fabsf(r.ix) < 1e30f ? fabsf(r.ox) : 0.0f, fabsf(r.iy) < 1e30f ? fabsf(r.oy) : 0.0f), fabsf(r.iz) < 1e30f ? fabsf(r.oz) : 0.0f));
     return r;
 }
+// the same ray against QUANTISED nodes (DQNode): planes are grid coordinates q with plane = base + q * cell, so
+// t = plane * i + o' = q * (cell * i) + (base * i + o') — the slab of a ray in grid space, one fma per plane as before.  (The rounding of
+// the two folded constants moves a plane by ~1e-7 of the scene's size; the boxes carry a whole grid cell, 1.5e-5 of it, of margin.)
+HKD RaySlab ray_slab_grid(const DScene& sc, v3 o, v3 d) {
+    RaySlab r = ray_slab(o, d);
+    r.ox = fmaf(sc.q_base[0], r.ix, r.ox), r.oy = fmaf(sc.q_base[1], r.iy, r.oy), r.oz = fmaf(sc.q_base[2], r.iz, r.oz);
+    r.ix *= sc.q_cell[0], r.iy *= sc.q_cell[1], r.iz *= sc.q_cell[2];
+    return r;
+}
 typedef float hk_f2 __attribute__((ext_vector_type(2)));
 // One inner-node step of a lane: both child boxes (DNode: the (lo, hi) pair of an axis sits in adjacent words, so one packed fma
 // gives both plane distances), nearest hit child first, the other pushed.  Per-lane stack in LDS: entry e of lane l at
@@ -894,11 +903,18 @@ struct NodeCache {
     const lds_float4* tri;   // leaf triangles 0 .. nt-1 (media kernels: scenes of a few dozen triangles live in LDS entirely), part j of
     int nt;                  // triangle i at tri[j * NT + i]
 };
-template <int NC = 0>
+template <int NC = 0, bool QN = false>
 HKD void node_step(const DScene& sc, const RaySlab& rs, float t_best, int* __restrict__ stack, int lane, int& cur, int& sp, const NodeCache& cache = NodeCache()) {
     float4 A, B, C;
     int c0, c1;
-    if (NC > 0 && cur < cache.nc) {
+    if (QN && !(NC > 0 && cur < cache.nc)) {   // quantised node: two 16-B loads, planes in grid coordinates (rs is the ray's slab in grid space; the LDS copies hold grid coordinates too)
+        const uint4* qp = reinterpret_cast<const uint4*>(sc.qnodes) + 2 * (size_t)cur;
+        const uint4 P = qp[0], Q = qp[1];
+        A = make_float4((float)(P.x & 0xffffu), (float)(P.x >> 16), (float)(P.y & 0xffffu), (float)(P.y >> 16));
+        B = make_float4((float)(P.z & 0xffffu), (float)(P.z >> 16), (float)(P.w & 0xffffu), (float)(P.w >> 16));
+        C = make_float4((float)(Q.x & 0xffffu), (float)(Q.x >> 16), (float)(Q.y & 0xffffu), (float)(Q.y >> 16));
+        c0 = (int)Q.z, c1 = (int)Q.w;
+    } else if (NC > 0 && cur < cache.nc) {
         const hk_f4v a = cache.box[cur], b = cache.box[NC + cur], c = cache.box[2 * NC + cur];
         const hk_i2v ch = cache.child[cur];
         A = make_float4(a.x, a.y, a.z, a.w), B = make_float4(b.x, b.y, b.z, b.w), C = make_float4(c.x, c.y, c.z, c.w);

@@ -526,7 +526,7 @@ __global__ void __launch_bounds__(256) k_camera(DPathState st, DFrame fr, DTable
 }
 
 // Copies the first min(NC, sc.n_nodes) nodes into the block's LDS (see NodeCache) and waits for the whole block.
-template <int NC, int BLOCK>
+template <int NC, int BLOCK, bool QN = false>
 HKD NodeCache node_cache_fill(const DScene& sc, float4* __restrict__ box, int2* __restrict__ child) {
     NodeCache c;
     c.box = (const lds_float4*)box, c.child = (const lds_int2*)child;
@@ -534,6 +534,15 @@ HKD NodeCache node_cache_fill(const DScene& sc, float4* __restrict__ box, int2* 
     c.nc = sc.n_nodes < NC ? sc.n_nodes : NC;
     if (NC > 0) {
         for (int i = threadIdx.x; i < c.nc; i += BLOCK) {
+            if (QN) {   // quantised tree: the LDS copy holds the grid coordinates as floats (node_step's arithmetic is the same for both arms)
+                const uint4* qp = reinterpret_cast<const uint4*>(sc.qnodes) + 2 * (size_t)i;
+                const uint4 P = qp[0], Q = qp[1];
+                box[i] = make_float4((float)(P.x & 0xffffu), (float)(P.x >> 16), (float)(P.y & 0xffffu), (float)(P.y >> 16));
+                box[NC + i] = make_float4((float)(P.z & 0xffffu), (float)(P.z >> 16), (float)(P.w & 0xffffu), (float)(P.w >> 16));
+                box[2 * NC + i] = make_float4((float)(Q.x & 0xffffu), (float)(Q.x >> 16), (float)(Q.y & 0xffffu), (float)(Q.y >> 16));
+                child[i] = make_int2((int)Q.z, (int)Q.w);
+                continue;
+            }
             const float4* np = reinterpret_cast<const float4*>(sc.nodes) + 4 * (size_t)i;
             const float4 D = np[3];
             box[i] = np[0], box[NC + i] = np[1], box[2 * NC + i] = np[2];
@@ -734,6 +743,7 @@ struct LaneRay {   // per-lane traversal state
     int pend;   // a postponed leaf reference, or DONE (0x80000000) for none; cur == DONE implies pend == DONE
     bool any;   // lane_ray_round<.., MIXED>: this lane's ray is an any-hit (shadow) ray among closest-hit rays (trace_shadow_body)
 };
+template <bool QN = false>
 HKD void lane_ray_start(LaneRay& r, const DScene& sc, v3 o, v3 d, float t_max) {
     r.o = o;
     r.d = d;
@@ -741,7 +751,7 @@ HKD void lane_ray_start(LaneRay& r, const DScene& sc, v3 o, v3 d, float t_max) {
     r.best.t = t_max;
     r.best.prim = -1;
     r.best.u = r.best.v = 0.0f;
-    r.rs = ray_slab(o, d);
+    r.rs = QN ? ray_slab_grid(sc, o, d) : ray_slab(o, d);
     r.sp = 0;
     r.cur = sc.n_tris == 0 ? (int)0x80000000 : sc.root_ref;
     r.pend = (int)0x80000000;
@@ -751,7 +761,7 @@ HKD void lane_ray_start(LaneRay& r, const DScene& sc, v3 o, v3 d, float t_max) {
 // ANYHIT: the first accepted triangle ends the ray (cur = DONE, best.prim >= 0).
 // MIXED (with ANYHIT = false): closest-hit and any-hit rays share the wave, LaneRay::any says which a lane holds; the round's rules are the
 // closest-hit kernel's, a lane's leaf test is its own kind's.
-template <bool ANYHIT, bool COUNT, int NC = 0, bool POSTPONE = (ANYHIT ? HK_POSTPONE_ANYHIT != 0 : HK_POSTPONE_CLOSEST != 0), bool MIXED = false>
+template <bool ANYHIT, bool COUNT, int NC = 0, bool POSTPONE = (ANYHIT ? HK_POSTPONE_ANYHIT != 0 : HK_POSTPONE_CLOSEST != 0), bool MIXED = false, bool QN = false>
 HKD void lane_ray_round(LaneRay& r, bool active, const DScene& sc, int* __restrict__ stack, int lane, unsigned& n_nodes, unsigned& n_tris, const NodeCache& cache = NodeCache(),
                         bool may_wait = false
 #ifdef HK_DEBUG_UTIL
@@ -785,11 +795,11 @@ HKD void lane_ray_round(LaneRay& r, bool active, const DScene& sc, int* __restri
         for (int rep = 1; rep < HK_NODE_UNROLL; ++rep)
             if (active && r.cur >= 0) {
                 if (COUNT) ++n_nodes;
-                node_step<NC>(sc, r.rs, r.best.t, stack, lane, r.cur, r.sp, cache);
+                node_step<NC, QN>(sc, r.rs, r.best.t, stack, lane, r.cur, r.sp, cache);
             }
         if (active && r.cur >= 0) {
             if (COUNT) ++n_nodes;
-            node_step<NC>(sc, r.rs, r.best.t, stack, lane, r.cur, r.sp, cache);
+            node_step<NC, QN>(sc, r.rs, r.best.t, stack, lane, r.cur, r.sp, cache);
             if (POSTPONE) {
                 if (r.cur == DONE) {   // nothing left to descend: the postponed leaf (if any) is what is left of this ray
                     r.cur = r.pend;
@@ -895,7 +905,7 @@ enum { LR_EMPTY = 0, LR_ACTIVE = 1 };
 
 // STACK: LDS stack entries per lane.  The stack holds at most one entry per inner level, so a BVH of depth <= 16 (every scene
 // but the 10^6-triangle one) runs with half the LDS: 16 KB per block instead of 32, and LDS stops limiting residency.
-template <bool COUNT, int NC>
+template <bool COUNT, int NC, bool QN = false>
 __device__ __forceinline__ void trace_lean_body(const DPathState& st, const DScene& sc, int depth, DStats* stats, const SegTickets& src, int* __restrict__ stack, const NodeCache& cache) {
     const int lane = lane_id();
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -963,7 +973,7 @@ __device__ __forceinline__ void trace_lean_body(const DPathState& st, const DSce
                 slot = seg + (uint32_t)(cursor + rank);
                 float4 O = stream_ld(&g.ray_o[slot]), D = stream_ld(&g.ray_d[slot]);
                 ++n_casts;
-                lane_ray_start(r, sc, mk3(O.x, O.y, O.z), mk3(D.x, D.y, D.z), O.w);
+                lane_ray_start<QN>(r, sc, mk3(O.x, O.y, O.z), mk3(D.x, D.y, D.z), O.w);
                 state = LR_ACTIVE;
             }
             const int want_n = __popcll(want);
@@ -972,9 +982,9 @@ __device__ __forceinline__ void trace_lean_body(const DPathState& st, const DSce
         }
 #ifdef HK_DEBUG_UTIL
         HK_DBG(2, state == LR_ACTIVE && r.cur != DONE);      // rounds: lanes with a ray in flight
-        lane_ray_round<false, COUNT, NC>(r, state == LR_ACTIVE && r.cur != DONE, sc, stack, lane, n_nodes, n_tris, cache, cursor < n, dbg_);
+        lane_ray_round<false, COUNT, NC, HK_POSTPONE_CLOSEST != 0, false, QN>(r, state == LR_ACTIVE && r.cur != DONE, sc, stack, lane, n_nodes, n_tris, cache, cursor < n, dbg_);
 #else
-        lane_ray_round<false, COUNT, NC>(r, state == LR_ACTIVE && r.cur != DONE, sc, stack, lane, n_nodes, n_tris, cache, cursor < n);
+        lane_ray_round<false, COUNT, NC, HK_POSTPONE_CLOSEST != 0, false, QN>(r, state == LR_ACTIVE && r.cur != DONE, sc, stack, lane, n_nodes, n_tris, cache, cursor < n);
 #endif
     }
     wq_close(q_escaped, count_ptr(st, depth, Q_ESCAPED, gw));
@@ -993,14 +1003,14 @@ __device__ __forceinline__ void trace_lean_body(const DPathState& st, const DSce
     }
     HK_DBG_FLUSH(stats);
 }
-template <bool COUNT, int STACK, int BLOCK = HK_TRACE_BLOCK, int NC = 0>
+template <bool COUNT, int STACK, int BLOCK = HK_TRACE_BLOCK, int NC = 0, bool QN = false>
 __global__ void __launch_bounds__(BLOCK) k_trace_lean(DPathState st, DScene sc, int depth, DStats* stats) {
     __shared__ int lds_stack[(BLOCK / 64) * STACK * 64];
     __shared__ float4 lds_box[NC > 0 ? 3 * NC : 1];
     __shared__ int2 lds_child[NC > 0 ? NC : 1];
     int* stack = lds_stack + (threadIdx.x >> 6) * (STACK * 64);
-    const NodeCache cache = node_cache_fill<NC, BLOCK>(sc, lds_box, lds_child);
-    trace_lean_body<COUNT, NC>(st, sc, depth, stats, seg_open(st, ticket_ptr(st, depth, TK_TRACE), st.dynamic_segments != 0, depth, Q_RAY), stack, cache);
+    const NodeCache cache = node_cache_fill<NC, BLOCK, QN>(sc, lds_box, lds_child);
+    trace_lean_body<COUNT, NC, QN>(st, sc, depth, stats, seg_open(st, ticket_ptr(st, depth, TK_TRACE), st.dynamic_segments != 0, depth, Q_RAY), stack, cache);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2918,7 +2928,7 @@ HKD void shadow_contribute_rt(const DPathState& st, uint32_t rec, S4 T_ray, S4 t
         shadow_contribute<false>(st, rec, T_ray, tr_u, tr_l);
 }
 
-template <bool COUNT, int NC>
+template <bool COUNT, int NC, bool QN = false>
 __device__ __forceinline__ void shadow_body(const DPathState& st, const DScene& sc, int depth, DStats* stats, SegStream stream, int* __restrict__ stack, const NodeCache& cache) {
     const int lane = lane_id();
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -2960,7 +2970,7 @@ __device__ __forceinline__ void shadow_body(const DPathState& st, const DScene& 
                 float4 O = stream_ld(&st.sh_o[slot]), D = stream_ld(&st.sh_d[slot]);
                 if (O.w >= 1e-6f) {   // a degenerate shadow ray is simply not visible
                     ++n_casts;
-                    lane_ray_start(r, sc, mk3(O.x, O.y, O.z), mk3(D.x, D.y, D.z), O.w);
+                    lane_ray_start<QN>(r, sc, mk3(O.x, O.y, O.z), mk3(D.x, D.y, D.z), O.w);
                     have = true;
                 }
             }
@@ -2973,9 +2983,9 @@ __device__ __forceinline__ void shadow_body(const DPathState& st, const DScene& 
         }
 #ifdef HK_DEBUG_UTIL
         HK_DBG(5, have && r.cur != DONE);      // rounds: lanes with a shadow ray in flight (probes 3 / 4: its node steps / leaf phases)
-        lane_ray_round<true, COUNT, NC>(r, have && r.cur != DONE, sc, stack, lane, n_nodes, n_tris, cache, cursor < n || more, dbg_ + 6);
+        lane_ray_round<true, COUNT, NC, HK_POSTPONE_ANYHIT != 0, false, QN>(r, have && r.cur != DONE, sc, stack, lane, n_nodes, n_tris, cache, cursor < n || more, dbg_ + 6);
 #else
-        lane_ray_round<true, COUNT, NC>(r, have && r.cur != DONE, sc, stack, lane, n_nodes, n_tris, cache, cursor < n || more);
+        lane_ray_round<true, COUNT, NC, HK_POSTPONE_ANYHIT != 0, false, QN>(r, have && r.cur != DONE, sc, stack, lane, n_nodes, n_tris, cache, cursor < n || more);
 #endif
     }
     stats += global_wave();
@@ -2987,14 +2997,14 @@ __device__ __forceinline__ void shadow_body(const DPathState& st, const DScene& 
         wave_add(&stats->sh_tris, n_tris);
     }
 }
-template <bool COUNT, int STACK, int BLOCK = HK_TRACE_BLOCK, int NC = 0>
+template <bool COUNT, int STACK, int BLOCK = HK_TRACE_BLOCK, int NC = 0, bool QN = false>
 __global__ void __launch_bounds__(BLOCK) k_shadow(DPathState st, DScene sc, int depth, DStats* stats) {
     __shared__ int lds_stack[(BLOCK / 64) * STACK * 64];
     __shared__ float4 lds_box[NC > 0 ? 3 * NC : 1];
     __shared__ int2 lds_child[NC > 0 ? NC : 1];
     int* stack = lds_stack + (threadIdx.x >> 6) * (STACK * 64);
-    const NodeCache cache = node_cache_fill<NC, BLOCK>(sc, lds_box, lds_child);
-    shadow_body<COUNT, NC>(st, sc, depth, stats, stream_open(st, ticket_ptr(st, depth, TK_SHADOW), false, depth, Q_SHADOW), stack, cache);
+    const NodeCache cache = node_cache_fill<NC, BLOCK, QN>(sc, lds_box, lds_child);
+    shadow_body<COUNT, NC, QN>(st, sc, depth, stats, stream_open(st, ticket_ptr(st, depth, TK_SHADOW), false, depth, Q_SHADOW), stack, cache);
 }
 
 // K10 of bounce `depth` and K2 of bounce `depth + 1` of ONE segment in one per-lane-refill loop (k_small_pass): after the shade stage
@@ -4737,7 +4747,7 @@ __global__ void k_test_medium(DScene sc, DTables T, int mode, int medium_idx, in
 // The traversal of the surfaces-only bench path: lane_ray_round (while-while rounds, straggler exit, LDS stack of STACK entries)
 // driven by the same per-lane refill as k_trace_lean / k_shadow, over a plain ray array.  Every wave owns a contiguous range of
 // rays.  ANYHIT = the shadow kernel's first-accepted-hit mode (out_prim >= 0 <=> occluded).
-template <bool ANYHIT, int STACK>
+template <bool ANYHIT, int STACK, bool QN = false>
 __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_test_trace_lean(DScene sc, int n, const float* o3, const float* d3, const float* tmax, float* out_t, int* out_prim, float* out_uv) {
     __shared__ int lds_stack[(HK_TRACE_BLOCK / 64) * STACK * 64];
     int* stack = lds_stack + (threadIdx.x >> 6) * (STACK * 64);
@@ -4769,14 +4779,14 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_test_trace_lean(DScene sc, i
             const int rank = __popcll(want & lt_mask);
             if (!have && rank < avail) {
                 idx = first + cursor + rank;
-                lane_ray_start(r, sc, mk3(o3[3 * idx], o3[3 * idx + 1], o3[3 * idx + 2]), mk3(d3[3 * idx], d3[3 * idx + 1], d3[3 * idx + 2]), tmax[idx]);
+                lane_ray_start<QN>(r, sc, mk3(o3[3 * idx], o3[3 * idx + 1], o3[3 * idx + 2]), mk3(d3[3 * idx], d3[3 * idx + 1], d3[3 * idx + 2]), tmax[idx]);
                 have = true;
             }
             const int want_n = __popcll(want);
             cursor += want_n < avail ? want_n : (avail > 0 ? avail : 0);
             if (__ballot(have) == 0ull) break;
         }
-        lane_ray_round<ANYHIT, false>(r, have && r.cur != DONE, sc, stack, lane, n_nodes, n_tris);
+        lane_ray_round<ANYHIT, false, 0, (ANYHIT ? HK_POSTPONE_ANYHIT != 0 : HK_POSTPONE_CLOSEST != 0), false, QN>(r, have && r.cur != DONE, sc, stack, lane, n_nodes, n_tris);
     }
 }
 
@@ -4912,6 +4922,11 @@ void launch_trace(hipStream_t s, int n_cu, const DPathState& st, const DScene& s
         const int blocks = cached_blocks<K<C, S, B, NC>>(B, n_cu, 8);                                                          \
         hipLaunchKernelGGL((K<C, S, B, NC>), dim3(clamp_blocks(blocks, st, B / 64)), dim3(B), 0, s, st, sc, depth, stats);     \
     }
+#define HK_LEAN_LAUNCH_QN(K, C, S, B, NC)   /* the quantised nodes of a deep tree (DScene::qnodes) */                            \
+    {                                                                                                                          \
+        const int blocks = cached_blocks<K<C, S, B, NC, true>>(B, n_cu, 8);                                                    \
+        hipLaunchKernelGGL((K<C, S, B, NC, true>), dim3(clamp_blocks(blocks, st, B / 64)), dim3(B), 0, s, st, sc, depth, stats); \
+    }
 // k_trace_lean over a BVH of depth <= 16: ONE 1024-thread block per CU (the 4 waves per SIMD its registers allow anyway) whose LDS
 // holds the 16 stacks (64 KB) and the top 1536 nodes of the tree (84 KB) — all of the Cornell box, the upper levels of the others.
 // Measured (HK_NODE_CACHE=0 switches it off): trace -11 % in the Cornell box and the sky scene; with the 32-entry stacks of the
@@ -4936,6 +4951,9 @@ void launch_trace(hipStream_t s, int n_cu, const DPathState& st, const DScene& s
             if (fr.count_nodes) HK_LEAN_LAUNCH(K, true, 16, HK_TRACE_BLOCK, 0)   \
             else HK_LEAN_LAUNCH(K, false, 16, HK_TRACE_BLOCK, 0)                 \
         }                                                                        \
+    } else if (sc.qnodes != nullptr) {                                           \
+        if (fr.count_nodes) HK_LEAN_LAUNCH_QN(K, true, HK_LDS_STACK, HK_TRACE_BLOCK, NC32)    \
+        else HK_LEAN_LAUNCH_QN(K, false, HK_LDS_STACK, HK_TRACE_BLOCK, NC32)     \
     } else {                                                                     \
         if (node_cache_mode() != 0) {                                            \
             if (fr.count_nodes) HK_LEAN_LAUNCH(K, true, HK_LDS_STACK, HK_TRACE_BLOCK, NC32)   \
@@ -5368,6 +5386,9 @@ void launch_test_trace_lean(hipStream_t s, int n_cu, const DScene& sc, int anyhi
 #define HK_TL_LAUNCH(A, S) hipLaunchKernelGGL((k_test_trace_lean<A, S>), dim3(blocks), dim3(HK_TRACE_BLOCK), 0, s, sc, n, o, d, tmax, t, prim, uv)
     if (sc.bvh_depth <= 16) {
         if (anyhit) HK_TL_LAUNCH(true, 16); else HK_TL_LAUNCH(false, 16);
+    } else if (sc.qnodes != nullptr) {   // the kernels' own choice for a deep tree: its quantised nodes
+        if (anyhit) hipLaunchKernelGGL((k_test_trace_lean<true, HK_LDS_STACK, true>), dim3(blocks), dim3(HK_TRACE_BLOCK), 0, s, sc, n, o, d, tmax, t, prim, uv);
+        else hipLaunchKernelGGL((k_test_trace_lean<false, HK_LDS_STACK, true>), dim3(blocks), dim3(HK_TRACE_BLOCK), 0, s, sc, n, o, d, tmax, t, prim, uv);
     } else {
         if (anyhit) HK_TL_LAUNCH(true, HK_LDS_STACK); else HK_TL_LAUNCH(false, HK_LDS_STACK);
     }

@@ -147,8 +147,20 @@ struct DTriMeta {
     uint32_t mi, prim_index, arealight;
 };
 
+// QUANTISED NODES (trees deeper than 16 levels; round 5).  The deep-tree traversal kernels are bound by the number of 16-B loads a
+// node step issues per lane (each one a line look-up in the CU's vector cache: DESIGN.md section 5) — a 64-B node is four of them.  A
+// DQNode is two: the twelve box planes as 16-bit coordinates on a grid over the scene's bounds (lo rounded down, hi rounded up, one
+// more cell of margin), the same child references.  Boxes only grow, so every leaf the float tree reaches is reached; hits come from the
+// same triangle tests, and ties on t are broken by triangle index, not by visiting order: results are those of the float tree.
+struct DQNode {
+    uint32_t w[6];   // (lo | hi << 16) per axis pair, in DNode's order: c0 x, c0 y, c0 z, c1 x, c1 y, c1 z
+    int c0, c1;
+};
+
 struct DScene {
     const DNode* nodes;
+    const DQNode* qnodes;       // null unless the tree is deeper than 16 levels (and HK_QNODES != 0)
+    float q_base[3], q_cell[3]; // plane = q_base + q * q_cell
     const float4* leaf_tris;    // 3 float4 per triangle in leaf order
     int root_ref;
     int n_tris;

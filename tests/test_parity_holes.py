@@ -734,6 +734,62 @@ def test_light_preselection_is_result_neutral(hk, knobs):
         knobs.delenv(k, raising=False)
 
 
+def test_quantised_nodes_are_result_neutral(hk, knobs, gpu_ctx):
+    """Trees deeper than 16 levels are traversed through DQNode (16-bit planes on a grid over the scene's bounds, boxes only ever larger
+    than the float ones: hk_types.h) by the lean kernels.  A scene created with HK_QNODES=0 keeps the float nodes: films (accumulators,
+    bit for bit), ray counts and a 300 k-ray closest-hit / any-hit table are the same — what the boxes prune differs, what the triangle
+    tests find does not (ties on t go to the smaller triangle index, whatever the visiting order)."""
+    from hikari_jl_amd import scenes
+    L = hk._lib.lib()
+    w, h = 48, 40
+    kw = dict(max_depth=5, samples=8)
+
+    def run(env):
+        knobs.delenv("HK_QNODES", raising=False)
+        knobs.setenv("HK_SMALL_PASS_FUSED", "0")                                     # (a film this small would be ONE k_small_pass launch, which reads the float nodes: the stages as launches)
+        for k, v in env.items():
+            knobs.setenv(k, v)
+        s, film, cam = scenes.many_light_scene(w, h, n_boxes=12000, seed=5, box_scale=2.5)        # 144 k triangles; a fresh Scene object: the knob is read when its device scene is built
+        sh = hk.scene_handle(gpu_ctx, s)
+        depth = C.c_int32()
+        L.hk_scene_bvh_info(sh, None, None, C.byref(depth))
+        assert depth.value > 16, depth.value
+        vp = hk.VolPath(**kw)
+        vp._ensure(film)
+        vp.clear()
+        vp.reset_stats()
+        vp.render_samples(s, film, cam, 8, first=1)
+        acc = vp.read_accumulators(film).copy()
+        st = vp.stats()
+        assert int(st.fused_passes) == 0
+        rays = (int(st.rays_closest), int(st.rays_shadow), int(st.path_vertices))
+        vp.close()
+        rng = np.random.default_rng(11)
+        n = 300_000
+        o = (rng.random((n, 3)) * 14 - 7).astype(f32)
+        d = _unit(rng.normal(size=(n, 3)))
+        d[:500] = np.array([0, 0, 1], f32)
+        tmax = np.full(n, np.inf, f32)
+        tmax[::3] = (rng.random(len(tmax[::3])) * 6.0).astype(f32)
+        out = []
+        for anyhit in (0, 1):
+            t, pr, uv = np.empty(n, f32), np.empty(n, np.int32), np.empty((n, 2), f32)
+            hk._lib.check(L.hk_test_trace_lean(gpu_ctx.h, sh, anyhit, n, _pf(hk, o), _pf(hk, d), _pf(hk, tmax), _pf(hk, t), _pi(pr), _pf(hk, uv)), "hk_test_trace_lean")
+            out.append((t, pr, uv))
+        return acc, rays, out
+
+    ref, rays0, tab0 = run({"HK_QNODES": "0"})
+    got, rays1, tab1 = run({})
+    knobs.delenv("HK_QNODES", raising=False)
+    knobs.delenv("HK_SMALL_PASS_FUSED", raising=False)
+    assert np.isfinite(ref).all() and ref.max() > 0
+    assert np.array_equal(ref.view(np.uint32), got.view(np.uint32)) and rays0 == rays1
+    (t0, p0, u0), (t1, p1, u1) = tab0[0], tab1[0]
+    assert np.array_equal(p0, p1) and np.array_equal(t0.view(np.uint32), t1.view(np.uint32)) and np.array_equal(u0.view(np.uint32), u1.view(np.uint32))
+    assert 0.01 < (p0 >= 0).mean() < 0.999, (p0 >= 0).mean()
+    assert np.array_equal(tab0[1][1] >= 0, tab1[1][1] >= 0)                         # any hit: the same rays are occluded
+
+
 @pytest.mark.parametrize("which", ["cornell", "sky", "slab", "cloud", "cloud_grid"])
 def test_scheduling_is_result_neutral(hk, knobs, which):
     """How segments reach waves must not change a bit of the film: static stride vs tickets over the work lists, other segment counts

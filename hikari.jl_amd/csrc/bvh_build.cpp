@@ -1,7 +1,7 @@
 // bvh_build.cpp — host-side BVH2 builder for the traversal kernels.
 //
 // Replaces what the reference gets from Raycore's TLAS/BVH (src/scene.jl:120-149 `sync!`, call sites
-// src/integrators/volpath/intersection.jl:200,225,323,703).  Binned SAH (16 bins), leaves of <= 4
+// src/integrators/volpath/intersection.jl:200,225,323,703).  Binned SAH (32 bins; 16 until round 5), leaves of <= 4
 // triangles, depth bounded so a per-lane stack of HK_LDS_STACK entries can never overflow: a split
 // is only taken if both children can still be finished by median splits inside the depth budget.
 // Output layout: DNode (64 B, both child boxes inline) + leaf-ordered 48-B triangles.
@@ -57,7 +57,8 @@ struct Builder {
     BVH& out;
     int max_depth_seen = 0;
     int LEAF = 4;
-    static constexpr int NBINS = 16;
+    static constexpr int MAXBINS = 64;
+    int NBINS = 16;
     static constexpr int DEPTH_BUDGET = 30;  // < HK_LDS_STACK
 
     Builder(const float* p, int n, BVH& o) : pos(p), out(o) {
@@ -96,8 +97,8 @@ struct Builder {
         for (int axis = 0; axis < 3; ++axis) {
             float ext = cb.hi[axis] - cb.lo[axis];
             if (!(ext > 0)) continue;
-            Box bins[NBINS];
-            int cnt[NBINS] = {0};
+            Box bins[MAXBINS];
+            int cnt[MAXBINS] = {0};
             for (auto& b : bins) b.reset();
             float scale = NBINS / ext;
             for (int i = first; i < first + count; ++i) {
@@ -106,8 +107,8 @@ struct Builder {
                 bins[b].grow(tb[idx[i]]);
                 cnt[b]++;
             }
-            float right_area[NBINS];
-            int right_cnt[NBINS];
+            float right_area[MAXBINS];
+            int right_cnt[MAXBINS];
             Box acc;
             acc.reset();
             int c = 0;
@@ -176,14 +177,15 @@ struct Builder {
 };
 }  // namespace
 
-void build_bvh(const float* positions, int n_tris, BVH& out, int leaf_size) {
+void build_bvh(const float* positions, int n_tris, BVH& out, int leaf_size, int bins) {
     out.nodes.clear();
     out.leaf_prims.clear();
     out.max_depth = 0;
     out.root_ref = ~0;  // empty leaf marker handled by n_tris == 0
     if (n_tris <= 0) return;
     Builder b(positions, n_tris, out);
-    b.LEAF = leaf_size >= 1 && leaf_size <= 8 ? leaf_size : 4;   // (HK_BVH_LEAF, resolved by the caller from its context's knobs)
+    b.LEAF = leaf_size >= 1 && leaf_size <= 8 ? leaf_size : 4;
+    b.NBINS = std::min(std::max(bins, 4), (int)Builder::MAXBINS);   // (HK_BVH_BINS)   // (HK_BVH_LEAF, resolved by the caller from its context's knobs)
     Box box;
     out.root_ref = b.build(0, n_tris, 0, box);
     out.max_depth = b.max_depth_seen;

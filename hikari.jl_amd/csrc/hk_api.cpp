@@ -79,7 +79,7 @@ const char* knob(const char* name) {
     return it == tl_knobs->kv.end() ? nullptr : it->second.c_str();
 }
 static const char* const KNOB_NAMES[] = {
-    "HK_BATCH_PATHS_M", "HK_BVH_LEAF", "HK_QNODES", "HK_DEBUG_ALLOC", "HK_DELTA_ADVANCE", "HK_DYNAMIC_SEGMENTS", "HK_GREY", "HK_GREY_COMPACT", "HK_GREY_FLAT", "HK_MAX_PATHS_M",
+    "HK_BATCH_PATHS_M", "HK_BVH_LEAF", "HK_BVH_BINS", "HK_QNODES", "HK_DEBUG_ALLOC", "HK_DELTA_ADVANCE", "HK_DYNAMIC_SEGMENTS", "HK_GREY", "HK_GREY_COMPACT", "HK_GREY_FLAT", "HK_MAX_PATHS_M",
     "HK_MID_LISTS", "HK_MID_PASS_PATHS_M", "HK_NODE_CACHE", "HK_NVDB_DENSE_MB", "HK_OVERLAP", "HK_PIPELINE", "HK_PIPELINE_AFTER", "HK_PIPELINE_MAX_PATHS_M", "HK_PRESELECT",
     "HK_SELECT_MIN_IDLE", "HK_SHADOW_FEED_ROUNDS", "HK_SHADOW_TRACK_BATCH", "HK_SMALL_PASS", "HK_SMALL_PASS_WAVES", "HK_SOBOL_LO_GB", "HK_SOBOL_TABLE_ONLY",
     "HK_STATE_CACHE_GB", "HK_STATE_SLAB", "HK_TICKET_SHARE", "HK_TRACK_ADVANCE", "HK_TRACK_EXTRA_ADVANCE", "HK_TRACK_MIN_PENDING", "HK_TRACK_POOL", "HK_TRACK_REFILL_IDLE",
@@ -667,7 +667,8 @@ extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene**
     hk::BVH bvh;
     {
         const char* leaf = hk::knob("HK_BVH_LEAF");
-        hk::build_bvh(d->positions, T, bvh, leaf ? std::atoi(leaf) : 4);
+        const char* bins = hk::knob("HK_BVH_BINS");
+        hk::build_bvh(d->positions, T, bvh, leaf ? std::atoi(leaf) : 4, bins ? std::atoi(bins) : 32);
     }
     s->bvh_nodes = (int)bvh.nodes.size();
     s->bvh_leaf_tris = (int)bvh.leaf_prims.size();

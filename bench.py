@@ -19,7 +19,7 @@ N > 1: one process per GPU; rank g renders the sample indices g+1, g+1+N, ... of
 The reduce is the library's own hk_film_reduce (ncclReduce over xGMI on the render stream; torch.distributed only carries the
 128-byte communicator id, the barriers and the final statistics — over a gloo group on CPU tensors, so that no second stream exists in
 the process while frames are timed — and its own RCCL reduce is the cross-check of the result, run after the timed region).
-On ONE GPU the default run also reports every other BASELINE.json config (`configs`: the two-spheres Cornell, the cloud, the sky, the
+On ONE GPU the default run also reports every other BASELINE.json config (`configs`: the rounds 1-5 Cornell variant, the cloud, the sky, the
 many-light scene — seconds per frame, Mrays/s, class times, rooflines, the one-sample-per-call path), each measured by `bench.py --config X`
 in a child process of its own BEFORE this process touches the GPU (a second busy hardware queue on the device makes every kernel
 launch 50 - 120 us longer: DESIGN.md §5 "two speeds"), and, last, the one-sample-per-call path of the bench scene (`progressive`: hk_render(first = i, n = 1), what an interactive viewer drives).
@@ -55,9 +55,10 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-spp", type=int, default=0, help="samples per pixel of the CPU baseline sample (0 = about 15 s of work)")
     ap.add_argument("--spp", type=int, default=None, help="samples per pixel of one frame (default: the config's — 256, many-light 512)")
     ap.add_argument("--spp-per-pass", type=int, default=0, help="samples of every pixel in flight per wavefront pass (0 = the library's choice: up to 256)")
-    ap.add_argument("--config", default=None, choices=["cornell", "cornell_two_spheres", "cloud", "sky", "manylight"],
-                    help="default: cornell as the bench line, then ONE warm frame each of cloud, sky and manylight appended as `configs` (one GPU only; "
-                         "--no-extra-configs leaves them out).  cornell = BASELINE configs[1] (the bench line); sky = configs[2] (glass sphere + gold slab + Hosek-Wilkie sun-sky, depth 12); "
+    ap.add_argument("--config", default=None, choices=["cornell", "cornell_sphere_box", "cornell_two_spheres", "cloud", "sky", "manylight"],
+                    help="default: cornell as the bench line, then ONE warm frame each of cornell_sphere_box, cloud, sky and manylight appended as `configs` (one GPU only; "
+                         "--no-extra-configs leaves them out).  cornell = BASELINE configs[1] as SURVEY 8(d) specifies it: two tessellated spheres, 3 782 triangles (cornell_two_spheres: the same); "
+                         "cornell_sphere_box = the bench scene of rounds 1-5 (one sphere + one box); sky = configs[2] (glass sphere + gold slab + Hosek-Wilkie sun-sky, depth 12); "
                          "cloud = configs[3] (BOMEX stand-in: worley-fbm NanoVDB cloud field, 1024x1024, depth 32); manylight = configs[4] stand-in "
                          "(10^6 triangles, 5*10^4 area lights, 1024x1024, depth 8, 512 spp)")
     ap.add_argument("--progressive", type=int, default=64, help="calls of the ONE-SAMPLE-PER-CALL path (render!: hk_render(first = i, n = 1), what an interactive "
@@ -166,20 +167,21 @@ def build_workload(config, scenes):
                     "1024x1024, VolPath depth 8")
     else:
         W, H, depth, spp = 800, 800, 8, 256
-        # rounds 1-3 benchmarked one sphere + one box (1 934 triangles); SURVEY 8(d) describes two tessellated spheres (3 782).  The bench
-        # line keeps the scene of the earlier rounds (comparable numbers); the default run appends the other as `cornell_two_spheres`
-        objects = os.environ.get("HK_BENCH_CORNELL_OBJECTS", "two_spheres" if config == "cornell_two_spheres" else "sphere_box")
+        # "two matte boxes/spheres tessellated at 32" (test/volpath_integration.jl:58-62) — the bench line since round 6.
+        # Rounds 1-5 led with one sphere + one box (1 934 triangles): still measured, as the `cornell_sphere_box` entry of `configs`.
+        objects = os.environ.get("HK_BENCH_CORNELL_OBJECTS", "sphere_box" if config == "cornell_sphere_box" else "two_spheres")
         scene, film, cam = scenes.cornell_box(W, H, light="area", objects=objects)
         workload = ("Cornell box (diffuse + area light; %s, %d triangles), 800x800, VolPath depth 8"
-                    % ("two matte spheres tessellated at 32: SURVEY 8(d)" if objects == "two_spheres" else "one tessellated sphere + one box: the rounds 1-3 scene",
+                    % ("two matte spheres tessellated at 32: SURVEY 8(d)" if objects == "two_spheres" else "one tessellated sphere + one box: the rounds 1-5 scene",
                        int(scene.desc.n_triangles)))
     return scene, film, cam, W, H, depth, spp, workload
 
 
-VALU_CYCLES_THIS_MIX = 4.2     # profiles/r02_valu_rate.txt (tools/valu_rate.hip): compares, selects, integer ops, conversions cost 4.2 - 4.4 cycles
-                               # per wave64 instruction on a busy SIMD (v_fma / v_mul / v_mov 2.3 - 2.9): the price of the traversal kernels' mix
-VALU_CYCLES_FMA_MIX = 2.6      # ... and v_fma / v_mul / v_mov 2.3 - 2.9: the price of the light selection, whose node_importance is multiplies, adds and their
-                               # Newton steps (correctly rounded divisions and square roots expand to v_fma chains): 4.2 there would report a share above 1
+VALU_CYCLES = 2.0              # data sheet: a wave64 VALU instruction holds a SIMD's issue port for 2 cycles.  ONE rule for every kernel: the
+                               # issue-bound classes report valu_issue (instructions x 2 cycles over the SIMD-cycles of the launch), lane_util (active lanes per
+                               # issued instruction) and their product — the share of the chip's lane-slots that did useful work — as `frac`.  Rounds 2-5 priced
+                               # these kernels at a per-kernel 4.2 / 2.6 cycles per instruction (tools/valu_rate.hip: what this mix costs on a busy SIMD): a ceiling
+                               # chosen so that the fraction stayed below 1 — gone.
 N_SIMD = 1024                  # 256 CUs x 4 SIMDs
 KERNEL_OF_CLASS = {"trace": "k_trace", "shadow": "k_shadow", "shade": "k_shade", "media": "k_track+k_scatter", "select": "k_light_select"}
 CLASSES = ("trace", "shadow", "shade", "media", "select")
@@ -228,30 +230,29 @@ def class_rooflines(config, timed, launches, sc, default_frame):
         u = util.get(names[0], {})
         bytes_rate = alg[cls] / n_launch / avg_s / 1e9
         e = {"kernel": kernel}
-        # instruction issue, re-priced on this run's launch time: the committed pass gives the wave-level instruction count per launch (a
-        # property of the workload) and the clock (its own cycles / its own duration); a wave64 VALU instruction of this mix holds a
-        # SIMD's issue port for VALU_CYCLES_THIS_MIX cycles
+        # instruction issue, re-priced on this run's launch time: the committed pass gives the wave-level VALU instruction count per launch
+        # (a property of the workload), the clock (its own cycles / its own duration) and the lane utilisation
         issue = None
-        cycles = VALU_CYCLES_FMA_MIX if cls == "select" else VALU_CYCLES_THIS_MIX
         if u.get("valu_inst_per_launch") and u.get("valu_issue_frac") and u.get("avg_launch_us"):
-            clock_hz = u["valu_inst_per_launch"] * 2.0 / (u["valu_issue_frac"] * N_SIMD) / (u["avg_launch_us"] * 1e-6)
-            issue = u["valu_inst_per_launch"] * cycles / (avg_s * clock_hz * N_SIMD)
+            clock_hz = u["valu_inst_per_launch"] * VALU_CYCLES / (u["valu_issue_frac"] * N_SIMD) / (u["avg_launch_us"] * 1e-6)
+            issue = u["valu_inst_per_launch"] * VALU_CYCLES / (avg_s * clock_hz * N_SIMD)
+        useful = issue * u["lane_util"] if (issue is not None and u.get("lane_util")) else None
         # the light selection walks a tree whose nodes come from LDS / L2 like the traversal kernels' (the 60 B per node of SURVEY 8d are an
         # upper bound of its HBM need): priced against instruction issue, as they are
         traversal = cls == "select" or (cls in ("trace", "shadow") and not (cls == "shadow" and walk))
-        if traversal and issue is None:
+        if traversal and useful is None:
             # no committed counter pass for this workload: the ceiling that binds a traversal kernel cannot be priced from this run alone
-            e.update({"bound": "valu_issue", "achieved": None, "peak": 1.0, "unit": "share of the SIMDs' VALU issue slots", "frac": None,
+            e.update({"bound": "valu_issue", "achieved": None, "peak": 1.0, "unit": "share of the chip's VALU lane-slots doing useful work", "frac": None,
                       "algorithmic_bytes_per_launch": int(alg[cls] / n_launch), "algorithmic_gbs": round(bytes_rate, 2)})
         elif traversal:
-            e.update({"bound": "valu_issue", "achieved": round(issue, 4), "peak": 1.0, "unit": "share of the SIMDs' VALU issue slots", "frac": round(issue, 4),
-                      "cycles_per_valu_instruction": cycles, "valu_instructions_per_launch": u["valu_inst_per_launch"],
+            e.update({"bound": "valu_issue", "achieved": round(useful, 4), "peak": 1.0, "unit": "share of the chip's VALU lane-slots doing useful work", "frac": round(useful, 4),
+                      "valu_issue_in_run": round(issue, 4), "cycles_per_valu_instruction": VALU_CYCLES, "valu_instructions_per_launch": u["valu_inst_per_launch"],
                       "algorithmic_bytes_per_launch": int(alg[cls] / n_launch), "algorithmic_gbs": round(bytes_rate, 2)})
         else:
             e.update({"bound": "hbm", "achieved": round(bytes_rate, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(bytes_rate / HBM_PEAK_GBS, 5),
                       "algorithmic_bytes_per_launch": int(alg[cls] / n_launch)})
-            if issue is not None and issue <= 1.0:      # (an informational second ceiling; a mix cheaper than 4.2 cycles per instruction would price above 1: left out then)
-                e["valu_issue_at_%.1f_cycles" % VALU_CYCLES_THIS_MIX] = round(issue, 4)
+            if useful is not None:
+                e["useful_lane_issue"] = round(useful, 4)
         e.update({"avg_launch_ms": round(avg_s * 1e3, 4), "launches": n_launch, "seconds": round(timed[cls], 4)})
         if all("hbm_bytes_per_launch" in t for t in tr):
             # the PMC launches average over the same depths as the bench's (whole passes): traffic per launch is comparable
@@ -270,17 +271,13 @@ def class_rooflines(config, timed, launches, sc, default_frame):
         e["counters_from"] = [f for f in (pmc_file if e["traffic"] is not None else None, util_file if u else None) if f]
         e["measured_in_run"] = ["avg_launch_ms", "seconds", "launches", "algorithmic_bytes_per_launch"]
         hb, vi = e.get("hbm_frac_by_traffic"), e.get("valu_issue_frac")
-        # valu_issue_frac prices a wave64 VALU instruction at the data sheet's 2 cycles; measured on this chip (tools/valu_rate.hip,
-        # profiles/r02_valu_rate.txt) v_fma / v_mul / v_mov cost 2.3 - 2.9 and nearly everything else 4.2 - 4.4, so 0.25 - 0.45 in
-        # data-sheet units is a saturated issue port for these instruction mixes
         if hb is None or vi is None:
             e["binding"] = "unprofiled on this workload"
         elif hb >= 0.5:
-            e["binding"] = "HBM traffic (%.0f %% of the 8 TB/s peak, %.0f %% of the device-copy rate); VALU issue %.0f %% at 2 cycles per instruction" % (100 * hb, 100 * hb * HBM_PEAK_GBS / 5200.0, 100 * vi)
-        elif cls == "media" or (cls == "shadow" and walk):
-            e["binding"] = "instruction issue (vector + scalar exec-mask instructions) at low lane utilisation: VALU issue %.0f %% at 2 cycles per instruction with %.0f %% of the lanes active; HBM traffic %.0f %% of peak" % (100 * vi, 100 * e.get("lane_util", 0), 100 * hb)
+            e["binding"] = "HBM traffic (%.0f %% of the 8 TB/s peak, %.0f %% of the device-copy rate); VALU issue %.0f %% of the SIMD cycles" % (100 * hb, 100 * hb * HBM_PEAK_GBS / 5200.0, 100 * vi)
         else:
-            e["binding"] = "instruction issue and latency: VALU issue %.0f %% of all cycles at 2 cycles per instruction (this mix costs ~4: profiles/r02_valu_rate.txt) with %.0f %% of the lanes active; HBM traffic %.0f %% of peak" % (100 * vi, 100 * e.get("lane_util", 0), 100 * hb)
+            e["binding"] = "instruction issue and latency: VALU issue %.0f %% of the SIMD cycles (2 cycles per instruction) with %.0f %% of the lanes active = %.0f %% useful lane-slots; HBM traffic %.0f %% of peak" % (
+                100 * vi, 100 * e.get("lane_util", 0), 100 * vi * e.get("lane_util", 0), 100 * hb)
         # BVH nodes come from LDS / L1 / L2, not HBM: the SURVEY 8(d) byte formula is an upper bound of traversal's HBM need, not a ceiling
         if traversal:
             e["note"] = "algorithmic bytes count every BVH node / triangle visit at full size (SURVEY 8d); nodes are served from LDS / L1 / L2, measured HBM traffic is the `traffic` field"
@@ -326,10 +323,14 @@ def compact_line(result, limit=LINE_LIMIT, detail_file="bench_detail.json"):
     cpu = result.get("cpu_baseline")
     line["cpu_baseline"] = None if cpu is None else dict(_pick(cpu, ("value", "unit", "cores", "kind", "seconds_per_frame_extrapolated")),
                                                            sample=_clip(cpu.get("sample", ""), 110))
+    if isinstance(result.get("frame_check"), dict):
+        line["frame_check"] = {k: v for k, v in result["frame_check"].items() if k != "tolerance"}
     if result.get("configs") is not None:
         line["configs"] = []
         for c in result["configs"]:
             e = _pick(c, ("config", "seconds_per_frame", "value", "unit", "frames_timed", "warmup_frames", "error"))
+            if isinstance(c.get("frame_check"), dict):
+                e["frame_ok"] = bool(c["frame_check"].get("ok"))
             if "workload" in c:
                 e["workload"] = _clip(c["workload"], 120)
             if isinstance(c.get("roofline"), dict):
@@ -436,6 +437,7 @@ def one_frame_line(hk, scenes, torch, config, device):
     Mrays/s and the per-class rooflines (same definitions as the bench line).  Four frames are rendered: a first one that uploads the
     scene, builds the sampler tables and counts the units, a second untimed one, the timed one, and a replay with HIP events around
     every launch."""
+    import numpy as np
     t_setup = time.perf_counter()
     free_b, total_b = torch.cuda.mem_get_info()
     scene, film, cam, W, H, depth, spp, workload = build_workload(config, scenes)
@@ -463,6 +465,9 @@ def one_frame_line(hk, scenes, torch, config, device):
     seconds = time.perf_counter() - t0
     st = vp.stats()
     rays = int(st.rays_closest) + int(st.rays_shadow)
+    acc_np = accum.detach().cpu().numpy()
+    frame_check = {"finite": bool(np.isfinite(acc_np).all() and (acc_np[:3 * W * H] >= 0).all()), "mean_rgb_sum": round(float(acc_np[:3 * W * H].mean()), 6)}
+    frame_check["ok"] = frame_check["finite"] and frame_check["mean_rgb_sum"] > 0
     vp.enable_counters(count_nodes=False, time_kernels=True)
     vp.reset_stats()
     frame()
@@ -475,7 +480,7 @@ def one_frame_line(hk, scenes, torch, config, device):
             "warmup_frames": 2, "seconds_per_frame": round(seconds, 4), "value": round(rays / seconds / 1e6, 2), "unit": "Mrays/s",
             "rays": {"closest": int(st.rays_closest), "shadow": int(st.rays_shadow), "medium_collisions": int(st.medium_collisions)},
             "kernel_seconds": {k: round(v, 4) for k, v in timed.items()}, "setup_seconds": round(setup_s, 2),
-            "roofline": next(e for e in rooflines if e["kernel"] == KERNEL_OF_CLASS[dom]), "rooflines": rooflines}
+            "roofline": next(e for e in rooflines if e["kernel"] == KERNEL_OF_CLASS[dom]), "rooflines": rooflines, "frame_check": frame_check}
     vp.enable_counters(count_nodes=False, time_kernels=False)
     vp.close()
     del accum
@@ -522,7 +527,7 @@ def child_config_line(config, progressive_calls):
             "triangles": cfg["triangles"], "lights": cfg["lights"], "frames_timed": d["steps"], "warmup_frames": d["warmup"], "seconds_per_frame": d["seconds_per_frame"],
             "cold_frame_seconds": d["cold_frame_seconds"], "value": d["value"], "unit": d["unit"], "rays": d["rays"],
             "kernel_seconds": d["roofline"]["kernel_seconds"], "setup_seconds": d["setup_seconds"], "roofline": d["roofline"], "rooflines": d["rooflines"],
-            "progressive": d.get("progressive"), "measured_in": "a process of its own (bench.py --config %s --steps 1 --warmup 2), before this process touched the GPU" % config}
+            "progressive": d.get("progressive"), "frame_check": d.get("frame_check"), "measured_in": "a process of its own (bench.py --config %s --steps 1 --warmup 2), before this process touched the GPU" % config}
 
 
 def main():
@@ -539,7 +544,7 @@ def main():
     # the bench line's own frames (`measured_in` says which).
     pre_configs = {}
     if args.extra_configs and int(world_env or "1") == 1:
-        for c in os.environ.get("HK_BENCH_EXTRAS", "cornell_two_spheres,cloud,sky,manylight").split(","):
+        for c in os.environ.get("HK_BENCH_EXTRAS", "cornell_sphere_box,cloud,sky,manylight").split(","):
             try:
                 pre_configs[c] = child_config_line(c, min(args.progressive, 32))
             except Exception as e:               # noqa: BLE001
@@ -588,7 +593,7 @@ def main():
     if args.spp:
         FULL_SPP = args.spp
     if args.steps is None:
-        args.steps = 20 if (args.config == "cornell" and FULL_SPP <= 256) else 1
+        args.steps = 20 if (args.config.startswith("cornell") and FULL_SPP <= 256) else 1
     strong = args.scaling == "strong"
     # this rank's share of a frame: sample indices first, first + stride, ... (count of them)
     first, my_spp, stride = hd.shard_samples(FULL_SPP, rank, world) if strong else (rank + 1, FULL_SPP, world)
@@ -772,13 +777,47 @@ def main():
             if args.cpu_spp <= 0:                             # auto: about 15 s of CPU work
                 args.cpu_spp = max(1, min(32, int(15.0 / max(time.perf_counter() - c0, 1e-3))))
             c0 = time.perf_counter()
-            _, ost = osc.render(p, cam, W, H, args.cpu_spp)
+            oracle_acc, ost = osc.render(p, cam, W, H, args.cpu_spp)       # (kept: the timed film is checked against this image below)
             cdt = time.perf_counter() - c0
             crays = int(ost.rays_closest) + int(ost.rays_shadow)
             cpu = {"value": round(crays / cdt / 1e6, 4), "unit": "Mrays/s", "cores": oracle.max_threads(), "kind": "port",
                    "sample": "%d spp of the same %dx%d depth-%d frame (%.1f s); CPU restatement of Hikari VolPath, not Julia" % (args.cpu_spp, W, H, DEPTH, cdt),
                    "seconds_per_frame_extrapolated": round(cdt * FULL_SPP / args.cpu_spp, 1)}
             osc.close()
+
+        # ---- the film the timed region rendered is LOOKED AT: finite, and against the oracle image of the CPU leg —
+        #      (a) the timed frame itself (FULL_SPP samples) vs the oracle's cpu_spp samples of the same frame: two estimates of one image,
+        #      relMSE ~ var / cpu_spp + var / FULL_SPP, mean ratio within 2 %; (b) the SAME cpu_spp sample indices rendered once more on the
+        #      GPU (untimed, a few ms) vs the oracle under SURVEY 8(d)'s frame tolerance: relMSE <= 1e-3 and >= 99 % of the pixels within
+        #      1e-2 relative L2.  Anything else ends the run with a non-zero exit code AFTER the line is printed.
+        timed_acc = accum.detach().cpu().numpy().copy()
+        n_px = W * H
+        frame_check = {"finite": bool(np.isfinite(timed_acc).all() and (timed_acc[:3 * n_px] >= 0).all()),
+                       "mean_weight_per_pixel": round(float(timed_acc[3 * n_px:].mean()), 4), "mean_rgb_sum": round(float(timed_acc[:3 * n_px].mean()), 6)}
+        frame_check["ok"] = frame_check["finite"] and frame_check["mean_rgb_sum"] > 0
+        if cpu is not None and world == 1:
+            def rel_mse(a, b):
+                return float(np.mean((a - b) ** 2 / (b ** 2 + 1e-3)))
+            ref_img = oracle.finalize(oracle_acc, W, H)
+            img = oracle.finalize(timed_acc, W, H)                      # (K13 on the host: rgb / weight; the checker's finalize is three divisions per pixel)
+            keep = accum.clone()
+            vp.clear()
+            vp.render_samples(scene, film, cam, args.cpu_spp, stride=1, first=1, readback=False)
+            vp.sync()
+            torch.cuda.synchronize()
+            same = oracle.finalize(accum.detach().cpu().numpy().copy(), W, H)
+            accum.copy_(keep)
+            del keep
+            d = np.sqrt(((same - ref_img) ** 2).sum(axis=2)) / np.maximum(np.sqrt((ref_img ** 2).sum(axis=2)), 1e-6)
+            frame_check.update({
+                "oracle_spp": args.cpu_spp,
+                "rel_mse_vs_oracle_%dspp" % args.cpu_spp: round(rel_mse(img, ref_img), 6),
+                "mean_ratio": round(float(img.mean() / max(ref_img.mean(), 1e-12)), 5),
+                "same_samples_rel_mse": float("%.3g" % rel_mse(same, ref_img)),
+                "same_samples_frac_pixels_within_1e-2": round(float((d <= 1e-2).mean()), 5),
+                "tolerance": "SURVEY 8(d): relMSE <= 1e-3 and >= 99 % of the pixels within 1e-2 (same samples); mean ratio within 2 % (timed film)"})
+            frame_check["ok"] = bool(frame_check["finite"] and abs(frame_check["mean_ratio"] - 1.0) <= 0.02 and
+                                     frame_check["same_samples_rel_mse"] <= 1e-3 and frame_check["same_samples_frac_pixels_within_1e-2"] >= 0.99)
 
         value = total_rays / elapsed_max / 1e6
         per_frame = elapsed_max / max(args.steps, 1)
@@ -802,7 +841,7 @@ def main():
             "cold_frame_seconds": round(cold_max, 4),
             "rays": {"closest": int(st.rays_closest), "shadow": int(st.rays_shadow), "total_all_ranks": int(total_rays), "medium_collisions": int(st.medium_collisions)},
             "setup_seconds": round(setup_s, 3),
-            "roofline": roofline, "rooflines": rooflines, "cpu_baseline": cpu,
+            "roofline": roofline, "rooflines": rooflines, "cpu_baseline": cpu, "frame_check": frame_check,
         }
     if comm is not None:
         comm.close()
@@ -817,7 +856,7 @@ def main():
             del accum
             torch.cuda.empty_cache()
             result["configs"] = []
-            for c in os.environ.get("HK_BENCH_EXTRAS", "cornell_two_spheres,cloud,sky,manylight").split(","):
+            for c in os.environ.get("HK_BENCH_EXTRAS", "cornell_sphere_box,cloud,sky,manylight").split(","):
                 line = pre_configs.get(c)
                 if line is None:
                     try:
@@ -836,6 +875,11 @@ def main():
             except Exception as e:               # noqa: BLE001
                 result["progressive"] = {"error": "%s: %s" % (type(e).__name__, e)}
         emit(result, args.detail_file)
+        bad = [] if result["frame_check"].get("ok") else [args.config]
+        bad += [c.get("config") for c in result.get("configs") or [] if isinstance(c.get("frame_check"), dict) and not c["frame_check"].get("ok")]
+        if bad:
+            sys.stderr.write("bench.py: FRAME CHECK FAILED for %s (see frame_check in the line / detail file)\n" % ", ".join(str(b) for b in bad))
+            sys.exit(4)
     return result
 
 

@@ -8,6 +8,7 @@ PF = C.POINTER(C.c_float)
 
 HK_OK = 0
 HK_ERR_INVALID, HK_ERR_DEVICE, HK_ERR_UNSUPPORTED = -1, -2, -3
+HK_UNSET = -100       # hk_ctx_get_option: the knob has no value (not an error)
 
 (HK_MAT_MATTE, HK_MAT_MIRROR, HK_MAT_GLASS, HK_MAT_CONDUCTOR, HK_MAT_COATED_DIFFUSE, HK_MAT_THIN_DIELECTRIC,
  HK_MAT_DIFFUSE_TRANSMISSION, HK_MAT_COATED_DIFFUSE_TRANSMISSION, HK_MAT_COATED_CONDUCTOR, HK_MAT_MIX,
@@ -139,4 +140,5 @@ EXPORTED_SYMBOLS = [
     "hk_denoise", "hk_test_mix", "hk_test_medium", "hk_test_trace_lean",
     "hk_render_tile", "hk_comm_create", "hk_comm_unique_id", "hk_comm_create_rank", "hk_comm_destroy", "hk_film_reduce",
     "hk_ctx_set_option", "hk_ctx_get_option", "hk_trim_cache", "hk_flush", "hk_film_read_rgb_async", "hk_film_read_wait",
+    "hk_film_pin_host", "hk_film_unpin_host",
 ]

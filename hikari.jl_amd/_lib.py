@@ -38,6 +38,8 @@ def lib():
         "hk_flush": ([vp], i32),
         "hk_film_read_rgb_async": ([vp, vp], i32),
         "hk_film_read_wait": ([vp, vp, PF, C.POINTER(PF)], i32),
+        "hk_film_pin_host": ([vp, PF], i32),
+        "hk_film_unpin_host": ([vp], i32),
         "hk_scene_create": ([vp, C.POINTER(A.hk_scene_desc), C.POINTER(vp)], i32),
         "hk_scene_destroy": ([vp], i32),
         "hk_integrator_create": ([vp, C.POINTER(A.hk_integrator_params), C.POINTER(vp)], i32),

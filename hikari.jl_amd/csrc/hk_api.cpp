@@ -83,7 +83,7 @@ static const char* const KNOB_NAMES[] = {
     "HK_MID_LISTS", "HK_MID_PASS_PATHS_M", "HK_NODE_CACHE", "HK_NVDB_DENSE_MB", "HK_OVERLAP", "HK_PIPELINE", "HK_PIPELINE_AFTER", "HK_PIPELINE_MAX_PATHS_M", "HK_PRESELECT",
     "HK_SELECT_MIN_IDLE", "HK_SHADOW_FEED_ROUNDS", "HK_SHADOW_TRACK_BATCH", "HK_SMALL_PASS", "HK_SMALL_PASS_WAVES", "HK_SOBOL_LO_GB", "HK_SOBOL_TABLE_ONLY",
     "HK_STATE_CACHE_GB", "HK_STATE_SLAB", "HK_TICKET_SHARE", "HK_TRACK_ADVANCE", "HK_TRACK_EXTRA_ADVANCE", "HK_TRACK_MIN_PENDING", "HK_TRACK_POOL", "HK_TRACK_REFILL_IDLE",
-    "HK_WALK_POOL", "HK_WALK_REFILL_IDLE", "HK_WALK_SPLIT", "HK_WAVES_PER_CU", "HK_READBACK_PIN", "HK_DEFER_EXTERNAL", "HK_SELECT_POOL", "HK_SMALL_PASS_FUSED", "HK_SMALL_PASS_MERGED"};
+    "HK_WALK_POOL", "HK_WALK_REFILL_IDLE", "HK_WALK_SPLIT", "HK_WAVES_PER_CU", "HK_READBACK_PIN", "HK_DEFER_EXTERNAL", "HK_SELECT_POOL", "HK_SMALL_PASS_FUSED", "HK_SMALL_PASS_MERGED", "HK_FILM_LANES"};
 static bool known_knob(const char* name) {
     for (const char* k : KNOB_NAMES)
         if (std::strcmp(k, name) == 0) return true;
@@ -331,15 +331,18 @@ struct hk_film {
     DevBuf own;
     void* accum = nullptr;  // device
     bool external = false;  // the caller owns `accum` (and may read it behind stream / event ordering of its own)
+    bool exposed = false;   // hk_film_accum_device_ptr handed the accumulators out: the caller may keep the pointer, so calls into this film are never only noted
     DevBuf readback;
     // hk_film_read_rgb / _async: the finalized frame lands in PINNED host memory (two buffers in turn), or straight in the caller's
-    // buffer once that has been seen twice in a row and could be registered (HK_READBACK_PIN=0: never)
+    // buffer when the caller named it with hk_film_pin_host (HK_READBACK_PIN=1: also a pointer that has come twice in a row)
     float* staging[2] = {nullptr, nullptr};
     int staging_next = 0, staging_last = -1;   // which buffer the next async read fills / the last one filled
     bool read_in_flight = false;
     hipEvent_t ev_read = nullptr;
     void* last_out = nullptr;       // the caller's buffer of the previous synchronous read
     void* pinned_user = nullptr;    // ... registered with the driver (hipHostRegister) — the copy goes there directly
+    bool pinned_explicit = false;   // registered by hk_film_pin_host (stays until hk_film_unpin_host / hk_film_destroy)
+    void* pin_failed = nullptr;     // HK_READBACK_PIN=1: the pointer whose registration the driver refused (not retried every frame)
 };
 
 struct hk_integrator {
@@ -460,7 +463,10 @@ extern "C" int32_t hk_ctx_get_option(hk_ctx* c, const char* name, char* out, int
     if (!c || !name || (out_bytes > 0 && !out)) return fail(HK_ERR_INVALID, "null argument");
     if (!hk::known_knob(name)) return fail(HK_ERR_INVALID, std::string("unknown option ") + name);
     auto it = c->knobs.kv.find(name);
-    if (it == c->knobs.kv.end()) return -1;   // unset: the built-in default applies
+    if (it == c->knobs.kv.end()) {   // unset: the built-in default applies — HK_UNSET, not an error code (HK_ERR_INVALID is -1: a typo must not read as "default")
+        if (out_bytes > 0) out[0] = 0;
+        return HK_UNSET;
+    }
     if (out_bytes > 0) std::snprintf(out, (size_t)out_bytes, "%s", it->second.c_str());
     return (int32_t)it->second.size();
 }
@@ -1412,7 +1418,10 @@ extern "C" int32_t hk_film_clear(hk_film* f) {
     return HK_OK;
 }
 extern "C" void* hk_film_accum_device_ptr(hk_film* f) {
-    if (f) (void)flush_pending(f->ctx);   // (whoever asks for the pointer is about to look: the noted calls are enqueued first)
+    if (f) {
+        (void)flush_pending(f->ctx);   // (whoever asks for the pointer is about to look: the noted calls are enqueued first)
+        f->exposed = true;             // ... and may keep it: from now on calls into this film are enqueued at once (hk_render: ORDERING CONTRACT)
+    }
     return f ? f->accum : nullptr;
 }
 extern "C" int32_t hk_film_read_accum(hk_ctx* c, hk_film* f, void* out) {
@@ -1456,20 +1465,55 @@ extern "C" int32_t hk_film_read_rgb(hk_ctx* c, hk_film* f, float* out) {
         HIP_TRY(hipEventSynchronize(f->ev_read));
         f->read_in_flight = false;
     }
+    // Caller memory is registered with the driver only on request (the library cannot know when a buffer it registered by
+    // itself is freed — a C host that mallocs a frame buffer per frame gets the same address back, and the copy would go through a
+    // stale registration): hk_film_pin_host names the buffer, or HK_READBACK_PIN=1 brings back "the same pointer twice in a row".
+    // A registration that failed is remembered for that pointer and not tried again on every frame.
     const char* pin = hk::knob("HK_READBACK_PIN");
-    if (f->pinned_user != out && f->last_out == out && !(pin && std::atoi(pin) == 0)) {
-        if (f->pinned_user) (void)hipHostUnregister(f->pinned_user);
-        f->pinned_user = hipHostRegister(out, bytes, hipHostRegisterDefault) == hipSuccess ? out : nullptr;
-        (void)hipGetLastError();
-    } else if (f->pinned_user && f->pinned_user != out) {
-        (void)hipHostUnregister(f->pinned_user);
-        f->pinned_user = nullptr;
+    if (!f->pinned_explicit) {
+        if (pin && std::atoi(pin) == 1 && f->pinned_user != out && f->last_out == out && f->pin_failed != out) {
+            if (f->pinned_user) (void)hipHostUnregister(f->pinned_user);
+            f->pinned_user = hipHostRegister(out, bytes, hipHostRegisterDefault) == hipSuccess ? out : nullptr;
+            if (!f->pinned_user) f->pin_failed = out;
+            (void)hipGetLastError();
+        } else if (f->pinned_user && f->pinned_user != out) {
+            (void)hipHostUnregister(f->pinned_user);
+            f->pinned_user = nullptr;
+        }
     }
     f->last_out = out;
     const bool direct = f->pinned_user == out;
     if (int e = enqueue_frame_read(c, f, direct ? out : nullptr)) return e;
     HIP_TRY(hipEventSynchronize(f->ev_read));
     if (!direct) std::memcpy(out, f->staging[f->staging_last], bytes);
+    return HK_OK;
+}
+extern "C" int32_t hk_film_pin_host(hk_film* f, float* host_hw3) {
+    if (!f || !host_hw3) return fail(HK_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(f->ctx->device));
+    if (f->read_in_flight) {
+        HIP_TRY(hipEventSynchronize(f->ev_read));
+        f->read_in_flight = false;
+    }
+    if (f->pinned_user == host_hw3 && f->pinned_explicit) return HK_OK;
+    if (f->pinned_user) (void)hipHostUnregister(f->pinned_user);
+    f->pinned_user = nullptr, f->pinned_explicit = false;
+    if (hipHostRegister(host_hw3, (size_t)3 * f->width * f->height * 4, hipHostRegisterDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(HK_ERR_DEVICE, "hk_film_pin_host: hipHostRegister refused the buffer");
+    }
+    f->pinned_user = host_hw3, f->pinned_explicit = true;
+    return HK_OK;
+}
+extern "C" int32_t hk_film_unpin_host(hk_film* f) {
+    if (!f) return fail(HK_ERR_INVALID, "null film");
+    HIP_TRY(hipSetDevice(f->ctx->device));
+    if (f->read_in_flight) {
+        HIP_TRY(hipEventSynchronize(f->ev_read));
+        f->read_in_flight = false;
+    }
+    if (f->pinned_user) (void)hipHostUnregister(f->pinned_user);
+    f->pinned_user = nullptr, f->pinned_explicit = false, f->last_out = nullptr;
     return HK_OK;
 }
 extern "C" int32_t hk_film_read_rgb_async(hk_ctx* c, hk_film* f) {
@@ -1594,7 +1638,10 @@ int ensure_state(hk_integrator* I, int capacity, bool media, bool open_scene, bo
     long W_want = ((long)(capacity + 63) / 64) / 16;
     if (W_want < 4L * n_cu) W_want = 4L * n_cu;
     if (W_want > cap_per_cu * n_cu) W_want = cap_per_cu * n_cu;
-    if (const char* e = hk::knob("HK_WAVES_PER_CU")) I->ctx->waves_per_cu = std::atoi(e) > 0 ? std::atoi(e) : 0;   // read per call: tests toggle it
+    {   // read per call (tests toggle it); an unset knob is the built-in policy again — not the last forced count
+        const char* e = hk::knob("HK_WAVES_PER_CU");
+        I->ctx->waves_per_cu = e && std::atoi(e) > 0 ? std::atoi(e) : 0;
+    }
     if (I->ctx->waves_per_cu > 0) W_want = (long)I->ctx->waves_per_cu * n_cu;
     W_want = (W_want + 3) / 4 * 4;
     I->st.dynamic_segments = (media || (!open_scene && !mid)) ? 1 : 0;
@@ -1810,7 +1857,7 @@ extern "C" int32_t hk_render_tile(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_
         // A caller that owns the stream or the accumulators may order its own work behind this call with stream / event calls the library
         // never sees (torch.cuda.synchronize(), a reduce of the accumulators): its calls are enqueued at once.  HK_DEFER_EXTERNAL=1: batched all the same.
         const char* de = hk::knob("HK_DEFER_EXTERNAL");
-        const bool visible_order = (c->own_stream_order && !film->external) || (de && std::atoi(de));
+        const bool visible_order = (c->own_stream_order && !film->external && !film->exposed) || (de && std::atoi(de));
         const bool small = batch_paths > 0 && visible_order && !c->time_kernels && (long)n_samples * px <= small_paths && I->p.samples_per_pass <= 0;
         if (p.active && small && p.sc == sc && p.I == I && p.film == film && std::memcmp(&p.cam, cam, sizeof(hk_camera)) == 0 && p.stride == sample_stride && p.x0 == x0 &&
             p.y0 == y0 && p.x1 == x1 && p.y1 == y1 && (long)p.first + (long)p.n * p.stride == first_sample_idx && (long)(p.n + n_samples) * px <= batch_paths) {
@@ -1910,7 +1957,9 @@ static int render_tile_now(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_film* f
     } set_guard{I, piped ? &I->lane_sets[lane_idx] : nullptr};
     if (piped) I->swap_set(I->lane_sets[lane_idx]);
     int st = ensure_state(I, S * fr.n_pixels_padded, sc->d.n_media > 0, sc->d.has_escape_lights != 0, sc->d.bvh_depth <= 16, sc->d.n_media > 0 && hk::grey_compact_ok(sc->d), piped ? c->lanes[lane_idx].stream : nullptr,
-                          !piped && !c->time_kernels && !c->count_nodes && hk::small_pass_fusable(sc->d, sc->kinds_mask));
+                          // (the predicate of launch_small_pass, as far as it is known here: a call of >= 16 samples draws from the sample-bit table
+                          // and keeps the launches — those want 16 segments per CU, not k_small_pass's 8)
+                          !piped && !c->time_kernels && !c->count_nodes && n_samples < 16 && hk::small_pass_fusable(sc->d, sc->kinds_mask));
     if (st != HK_OK) return st;
     fr.sample_stride = sample_stride;
     fr.max_depth = I->p.max_depth;

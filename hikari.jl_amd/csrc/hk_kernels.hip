@@ -4508,6 +4508,94 @@ __global__ void __launch_bounds__(256) k_film(DPathState st, DFrame fr, DTables 
     for (int tile = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)); tile < n_tiles; tile += n_waves) film_tile<ACC>(st, fr, T, accum, mine, tile);
 }
 
+// K12 with ONE LANE PER PIXEL (round 6).  k_film above reads a tile's slots 64 at a time — the 64 samples of ONE pixel — converts them on
+// all lanes and lets the four lanes of that pixel add the 64 entries from LDS one after the other: every 64-slot step is a chain of
+// load -> convert -> LDS -> 64 dependent adds with nothing else of the wave in flight (3.1 ms for the 5.9 GB of a 164 M-path pass:
+// 1.9 TB/s).  Here lane l of a wave owns pixel l of the tile and streams through ITS S consecutive slots, eight at a time (one 128-B
+// line of L and of lambda_s, 32 B of filter weights per step and lane), converts them and adds them to its own four accumulators in
+// sample order — the same fp32 (or fp64) sums, 64 independent chains per wave instead of one.  The colour-matching functions sit in
+// LDS as one (x, y, z) record per nanometre: one LDS read per wavelength instead of three table gathers through the vector cache.
+// Films bit-identical to k_film's (HK_FILM_LANES=0: the old kernel; tests/test_gpu_parity.py::test_film_kernels_agree).
+HKD v3 spectral_to_rgb_clamped_lds(const float4* __restrict__ cie4, S4 L, S4 lambda, S4 pdf, float max_component_value) {   // spectral_to_rgb_clamped with the table in LDS
+    v3 sum = mk3(0.0f, 0.0f, 0.0f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float p = at(pdf, i);
+        if (p != 0.0f) {
+            const float l = at(lambda, i), Li = at(L, i);
+            const int off = (int)rintf(l) - 360;
+            v3 cmf = mk3(0.0f, 0.0f, 0.0f);
+            if (off >= 0 && off < 471) {
+                const float4 c = cie4[off];
+                cmf = mk3(c.x, c.y, c.z);
+            }
+            sum = sum + (cmf * Li) / p;
+        }
+    }
+    const v3 xyz = sum * 0.25f;
+    const float X = xyz.x, Y = xyz.y, Z = xyz.z;
+    v3 rgb = mk3(3.2404542f * X - 1.5371385f * Y - 0.4985314f * Z, -0.9692660f * X + 1.8760108f * Y + 0.0415560f * Z,
+                 0.0556434f * X - 0.2040259f * Y + 1.0572252f * Z);
+    rgb = mk3(maxf(0.0f, rgb.x), maxf(0.0f, rgb.y), maxf(0.0f, rgb.z));
+    const float m = maxf(maxf(rgb.x, rgb.y), rgb.z);
+    if (m > max_component_value) rgb = rgb * (max_component_value / m);
+    return rgb;
+}
+template <typename ACC>
+__global__ void __launch_bounds__(256) k_film_lanes(DPathState st, DFrame fr, DTables T, ACC* __restrict__ accum) {
+    __shared__ float4 cie4[471];
+    for (int i = (int)threadIdx.x; i < 471; i += 256) cie4[i] = make_float4(T.cie[i], T.cie[471 + i], T.cie[942 + i], 0.0f);
+    __syncthreads();
+    const int lane = lane_id();
+    const int S = fr.samples_in_pass;
+    const size_t N = (size_t)fr.width * fr.height;
+    const int n_tiles = fr.n_pixels_padded >> 6;
+    const int n_waves = (int)(gridDim.x * (blockDim.x >> 6));
+    for (int tile = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)); tile < n_tiles; tile += n_waves) {
+        int px, py;
+        bool inside;
+        slot_to_pixel(fr, tile * 64 + lane, px, py, inside);
+        if (!inside) continue;   // (film padding: its slots were never written)
+        const size_t p = (size_t)py * fr.width + px;
+        ACC r = accum[3 * p], g = accum[3 * p + 1], b = accum[3 * p + 2], w = accum[3 * N + p];
+        const size_t base = ((size_t)tile * 64 + (size_t)lane) * (size_t)S;
+        int k = 0;
+        if ((S & 7) == 0) {
+            for (; k < S; k += 8) {
+                float4 Lv[8], lv[8];
+                float fwv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) Lv[j] = stream_ld(&st.L[base + k + j]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) lv[j] = stream_ld(&st.lambda_s[base + k + j]);
+                {
+                    const float4 f0 = stream_ld(reinterpret_cast<const float4*>(st.filter_w + base + k)), f1 = stream_ld(reinterpret_cast<const float4*>(st.filter_w + base + k) + 1);
+                    fwv[0] = f0.x, fwv[1] = f0.y, fwv[2] = f0.z, fwv[3] = f0.w, fwv[4] = f1.x, fwv[5] = f1.y, fwv[6] = f1.z, fwv[7] = f1.w;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const S4 lam_ = s4(lv[j].x, lv[j].y, lv[j].z, lv[j].w);
+                    const v3 rgb = spectral_to_rgb_clamped_lds(cie4, s4(Lv[j].x, Lv[j].y, Lv[j].z, Lv[j].w), lam_, pdf_of(lam_), fr.max_component_value);
+                    const float fw = fwv[j];
+                    const float cr = fw * rgb.x, cg = fw * rgb.y, cb = fw * rgb.z;
+                    r += (ACC)cr, g += (ACC)cg, b += (ACC)cb, w += (ACC)fw;
+                }
+            }
+        }
+        for (; k < S; ++k) {
+            const S4 lam_ = ld4(&st.lambda_s[base + k]);
+            const v3 rgb = spectral_to_rgb_clamped_lds(cie4, ld4(&st.L[base + k]), lam_, pdf_of(lam_), fr.max_component_value);
+            const float fw = st.filter_w[base + k];
+            const float cr = fw * rgb.x, cg = fw * rgb.y, cb = fw * rgb.z;
+            r += (ACC)cr, g += (ACC)cg, b += (ACC)cb, w += (ACC)fw;
+        }
+        accum[3 * p] = r;
+        accum[3 * p + 1] = g;
+        accum[3 * p + 2] = b;
+        accum[3 * N + p] = w;
+    }
+}
+
 // K13 (volpath.jl:384-417): out = Julia Matrix{RGB{Float32}}[height,width] column-major
 template <typename ACC>
 __global__ void k_finalize(const ACC* __restrict__ accum, float* __restrict__ out, int width, int height) {
@@ -4952,8 +5040,13 @@ void launch_trace(hipStream_t s, int n_cu, const DPathState& st, const DScene& s
             else HK_LEAN_LAUNCH(K, false, 16, HK_TRACE_BLOCK, 0)                 \
         }                                                                        \
     } else if (sc.qnodes != nullptr) {                                           \
-        if (fr.count_nodes) HK_LEAN_LAUNCH_QN(K, true, HK_LDS_STACK, HK_TRACE_BLOCK, NC32)    \
-        else HK_LEAN_LAUNCH_QN(K, false, HK_LDS_STACK, HK_TRACE_BLOCK, NC32)     \
+        if (node_cache_mode() != 0) {                                            \
+            if (fr.count_nodes) HK_LEAN_LAUNCH_QN(K, true, HK_LDS_STACK, HK_TRACE_BLOCK, NC32)    \
+            else HK_LEAN_LAUNCH_QN(K, false, HK_LDS_STACK, HK_TRACE_BLOCK, NC32) \
+        } else {   /* HK_NODE_CACHE=0 is honoured for the quantised tree too */ \
+            if (fr.count_nodes) HK_LEAN_LAUNCH_QN(K, true, HK_LDS_STACK, HK_TRACE_BLOCK, 0)   \
+            else HK_LEAN_LAUNCH_QN(K, false, HK_LDS_STACK, HK_TRACE_BLOCK, 0)    \
+        }                                                                        \
     } else {                                                                     \
         if (node_cache_mode() != 0) {                                            \
             if (fr.count_nodes) HK_LEAN_LAUNCH(K, true, HK_LDS_STACK, HK_TRACE_BLOCK, NC32)   \
@@ -5287,6 +5380,14 @@ bool launch_small_pass(hipStream_t s, int n_cu, const DPathState& st, const DSce
 }
 void launch_film(hipStream_t s, const DPathState& st, const DFrame& fr, const DTables& T, void* accum, bool f64) {
     int g = grid_for(fr.n_pixels_padded >> 6, 4, 4096);   // one wave per 8x8 tile
+    const char* fl = hk::knob("HK_FILM_LANES");           // 0: k_film (a pixel's samples added by four lanes from LDS; A/B switch, films bit-identical)
+    if (!(fl && std::atoi(fl) == 0)) {
+        if (f64)
+            hipLaunchKernelGGL(k_film_lanes<double>, dim3(g), dim3(256), 0, s, st, fr, T, (double*)accum);
+        else
+            hipLaunchKernelGGL(k_film_lanes<float>, dim3(g), dim3(256), 0, s, st, fr, T, (float*)accum);
+        return;
+    }
     if (f64)
         hipLaunchKernelGGL(k_film<double>, dim3(g), dim3(256), 0, s, st, fr, T, (double*)accum);
     else

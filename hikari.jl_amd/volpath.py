@@ -89,7 +89,10 @@ class Context:
     def get_option(self, name):
         buf = C.create_string_buffer(256)
         n = _lib.lib().hk_ctx_get_option(self.h, name.encode(), buf, 256)
-        return None if n < 0 else buf.value.decode()
+        if n == A.HK_UNSET:
+            return None                  # no value: the built-in default applies
+        _lib.check(min(n, 0), "hk_ctx_get_option(%s)" % name)      # an unknown name raises (it used to read as "default")
+        return buf.value.decode()
 
     def options(self, **kv):
         """with ctx.options(HK_GREY=0, HK_WAVES_PER_CU=3): ... — the knobs are restored on exit"""
@@ -181,7 +184,8 @@ class VolPath:
         self._integ = None
         self._film = None      # (hk_film handle, w, h)
         self._external_accum = None
-        self._readback = None  # the one host buffer hk_film_read_rgb fills (a stable pointer: the library pins it)
+        self._readback = None  # the one host buffer hk_film_read_rgb fills (a stable pointer: read_framebuffer(view=True) pins it)
+        self._pinned = None    # the film handle `_readback` is registered with (hk_film_pin_host)
         self._read_pending = False
 
     # -- lazily created device state (the reference's `vp.state`, volpath.jl:463-482) --
@@ -194,8 +198,9 @@ class VolPath:
             _lib.check(L.hk_integrator_create(self._ctx.h, C.byref(self.params), C.byref(self._integ)), "hk_integrator_create")
         if self._film is None or self._film[1:] != (film.width, film.height):
             if self._film is not None:
-                L.hk_film_destroy(self._film[0])
+                L.hk_film_destroy(self._film[0])       # (unregisters a pinned read-back buffer)
                 self._read_pending = False
+                self._pinned = None
             h = C.c_void_p()
             ext = C.c_void_p(self._external_accum) if self._external_accum else None
             _lib.check(L.hk_film_create(self._ctx.h, film.width, film.height, self.params.accumulate_f64, ext, C.byref(h)), "hk_film_create")
@@ -249,6 +254,12 @@ class VolPath:
         rb = self._readback
         if rb is None or rb.shape != (film.width, film.height, 3):
             rb = self._readback = np.empty((film.width, film.height, 3), dtype=np.float32)
+            self._pinned = None
+        if view and self._pinned is not self._film[0]:
+            # a viewer's loop: this integrator owns `rb` for as long as the film lives, so the library may copy straight into it
+            # (hk_film_pin_host; a refusal of the driver is not an error — the read then goes through the film's staging buffers)
+            if _lib.lib().hk_film_pin_host(self._film[0], rb.ctypes.data_as(A.PF)) == A.HK_OK:
+                self._pinned = self._film[0]
         _lib.check(_lib.lib().hk_film_read_rgb(self._ctx.h, self._film[0], rb.ctypes.data_as(A.PF)), "hk_film_read_rgb")
         if view:
             film.framebuffer = np.transpose(rb, (1, 0, 2))
@@ -311,7 +322,7 @@ class VolPath:
         if self._film is not None:
             L.hk_film_destroy(self._film[0])
             self._film = None
-        self._readback, self._read_pending = None, False
+        self._readback, self._read_pending, self._pinned = None, False, None
         if self._integ is not None:
             L.hk_integrator_destroy(self._integ)
             self._integ = None

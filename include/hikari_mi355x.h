@@ -33,6 +33,7 @@ extern "C" {
 #define HK_ERR_INVALID -1
 #define HK_ERR_DEVICE -2
 #define HK_ERR_UNSUPPORTED -3
+#define HK_UNSET -100 /* hk_ctx_get_option: the knob has no value (distinct from every error code) */
 
 /* ---------------------------------------------------------------------------------------------
  * Textures (reference: textures/texture-ref.jl:151-186 bilinear fetch with the (1-v, u) flip).
@@ -330,7 +331,8 @@ int32_t hk_ctx_set_tables(hk_ctx* ctx, const hk_tables* tables);
 /* Tuning knobs (the HK_* table of INTEGRATION.md).  The library reads the environment ONCE, in hk_ctx_create — never on a render
  * path — and keeps the values in the context; hk_ctx_set_option changes one afterwards (value NULL: back to the built-in default).
  * Calls that were only noted (see hk_render) are rendered first, under the options they were made with.  Unknown names are
- * HK_ERR_INVALID.  hk_ctx_get_option: length of the value (copied to `out`, NUL-terminated, at most out_bytes), -1 when unset.
+ * HK_ERR_INVALID.  hk_ctx_get_option: length of the value (copied to `out`, NUL-terminated, at most out_bytes); HK_UNSET — not an error:
+ * the built-in default applies, `out` becomes the empty string — when the knob has no value.
  * There is no reference counterpart: Hikari's knobs are keyword arguments of VolPath(...) (volpath.jl:55-106), carried here by
  * hk_integrator_params. */
 int32_t hk_ctx_set_option(hk_ctx* ctx, const char* name, const char* value);
@@ -359,7 +361,7 @@ int32_t hk_film_clear(hk_film* film); /* clear!(vp), volpath.jl:108-113 */
  *
  * ORDERING CONTRACT.  The call returns before the samples are rendered.
  *   - A call of more than 8 M paths (HK_PIPELINE_MAX_PATHS_M), a call on a context that was created on a CALLER'S stream, and a call
- *     into a film with EXTERNAL accumulators are enqueued on ctx's stream before the call returns: whatever the caller orders behind
+ *     into a film with EXTERNAL accumulators — or one whose accumulators hk_film_accum_device_ptr has handed out — are enqueued on ctx's stream before the call returns: whatever the caller orders behind
  *     that stream (events, a collective on the accumulators, torch.cuda.synchronize()) sees the samples.
  *   - A SMALL call (a one-sample `render!`, volpath.jl:445-450) on a context with the default stream and a library-owned film may only
  *     be NOTED: calls that continue each other (same scene / integrator / film / camera / pixel range / stride, sample indices
@@ -407,13 +409,19 @@ int32_t hk_film_read_rgb(hk_ctx* ctx, hk_film* film, float* out_hw3);
  *   hk_film_read_wait        waits for the LAST hk_film_read_rgb_async of the film only (not for renders enqueued after it), then
  *                            copies the frame to out_hw3 (may be NULL) and / or returns the pinned buffer itself in *frame (may be
  *                            NULL; valid until the second-next hk_film_read_rgb_async of this film).
- * hk_film_read_rgb itself goes through the same pinned buffers; when it is given the SAME destination twice in a row it registers that
- * buffer with the driver (hipHostRegister; unregistered when another pointer comes or the film is destroyed) and copies straight into
- * it from then on.  HK_READBACK_PIN=0: never register caller memory. */
+ * hk_film_read_rgb itself goes through the same pinned buffers and a memcpy.  A viewer that reads every frame into ONE buffer can
+ * spare the memcpy: hk_film_pin_host registers that buffer (3 * width * height floats) with the driver (hipHostRegister) and
+ * hk_film_read_rgb copies straight into it whenever it is the destination; the caller keeps the buffer alive until hk_film_unpin_host
+ * or hk_film_destroy.  The library never registers caller memory on its own (it cannot know when such a buffer is freed), unless
+ * HK_READBACK_PIN=1 asks for round 5's behaviour: the same destination twice in a row is registered. */
 int32_t hk_film_read_rgb_async(hk_ctx* ctx, hk_film* film);
 int32_t hk_film_read_wait(hk_ctx* ctx, hk_film* film, float* out_hw3, const float** frame);
+int32_t hk_film_pin_host(hk_film* film, float* host_hw3);
+int32_t hk_film_unpin_host(hk_film* film);
 /* raw accumulators (host copy): 4*N floats (or doubles). */
 int32_t hk_film_read_accum(hk_ctx* ctx, hk_film* film, void* out);
+/* the accumulators on the device.  Noted calls are enqueued first, and because the caller may KEEP the pointer (a reduce, an event of
+ * its own behind ctx's stream), every later hk_render into this film is enqueued before it returns — as for external accumulators. */
 void* hk_film_accum_device_ptr(hk_film* film);
 
 /* hk_flush: every render call made so far is enqueued on ctx's stream (noted small calls are rendered now); does not wait.

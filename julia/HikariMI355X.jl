@@ -166,6 +166,7 @@ mutable struct MI355XVolPath <: Integrator
     display_every::Int         # ... and every how many calls
     calls_since_display::Int
     read_pending::Bool         # an hk_film_read_rgb_async nobody has waited for yet
+    pinned_fb::Any             # the framebuffer registered with hk_film_pin_host (held here so that it outlives the registration), or nothing
 end
 
 rowmajor(m) = ntuple(i -> Float32(m[(i - 1) ÷ 4 + 1, (i - 1) % 4 + 1]), 16)
@@ -182,7 +183,7 @@ Same keywords and defaults as `Hikari.VolPath` (volpath.jl:75-101) plus `devices
 RayMakie's interactive loop drives (volpath.jl:445-450) — keeps `film.framebuffer` (host memory here; a device array in the reference):
 
   * `display = :every` (default), `display_every = k`: the frame is read back after every k-th call (`hk_film_read_rgb`: K13 + a copy into
-    `film.framebuffer`, which the library pins once it has seen it twice).  With k = 1 `film.framebuffer` is current after every call,
+    `film.framebuffer`, which the shim registers with `hk_film_pin_host` and keeps alive).  With k = 1 `film.framebuffer` is current after every call,
     exactly like the reference; calls that are not followed by a read-back are only NOTED by the library and rendered as one pass with the
     next read-back (bit-identical film, up to 7x less time per sample) — k = 4 … 16 is what a viewer at 60 Hz wants.
   * `display = :pipelined`: after call i `film.framebuffer` holds the frame of call i − 1; the copy of frame i is in flight while call
@@ -203,7 +204,7 @@ function MI355XVolPath(; max_depth::Int = 8, samples::Int = 64, russian_roulette
                            Float32(max_component_value), fp.filter_type, (fp.radius[1], fp.radius[2]), fp.param1, fp.param2,
                            accumulation_eltype === Float64, UInt32(0), 0)
     devs = [DeviceState(Int(d), C_NULL, C_NULL, C_NULL, C_NULL) for d in devices]
-    MI355XVolPath(p, samples, devs, C_NULL, UInt(0), (0, 0), display, display_every, 0, false)
+    MI355XVolPath(p, samples, devs, C_NULL, UInt(0), (0, 0), display, display_every, 0, false, nothing)
 end
 
 function ensure_ctx!(vp::MI355XVolPath)
@@ -541,6 +542,7 @@ function render_samples!(vp::MI355XVolPath, scene, film::Hikari.Film, camera, n:
     h, w = size(film.framebuffer)
     G = length(vp.devs)
     if vp.devs[1].film == C_NULL || vp.film_size != (w, h)
+        vp.pinned_fb = nothing                              # (hk_film_destroy unregisters)
         for d in vp.devs
             d.film != C_NULL && ccall((:hk_film_destroy, LIB), Int32, (Ptr{Cvoid},), d.film)
             r = Ref{Ptr{Cvoid}}()
@@ -581,6 +583,10 @@ function render_samples!(vp::MI355XVolPath, scene, film::Hikari.Film, camera, n:
     fb = film.framebuffer                               # Matrix{RGB{Float32}}[h, w]: exactly hk_film_read_rgb's layout
     if display === :every
         vp.read_pending = false
+        if vp.pinned_fb !== fb          # the viewer's one framebuffer: the frame is copied straight into it (a refusal only costs the memcpy)
+            ok = GC.@preserve fb ccall((:hk_film_pin_host, LIB), Int32, (Ptr{Cvoid}, Ptr{Float32}), root.film, Ptr{Float32}(pointer(fb)))
+            vp.pinned_fb = ok == 0 ? fb : nothing
+        end
         GC.@preserve fb check(ccall((:hk_film_read_rgb, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float32}), root.ctx, root.film, Ptr{Float32}(pointer(fb))), "hk_film_read_rgb")
     elseif display === :pipelined
         # this call's samples go to the GPU now; the frame of the PREVIOUS call is collected while they render; then this call's copy is enqueued
@@ -630,6 +636,8 @@ end
 
 function Base.close(vp::MI355XVolPath)
     vp.read_pending = false
+    vp.devs[1].film != C_NULL && vp.pinned_fb !== nothing && ccall((:hk_film_unpin_host, LIB), Int32, (Ptr{Cvoid},), vp.devs[1].film)
+    vp.pinned_fb = nothing
     vp.comm != C_NULL && ccall((:hk_comm_destroy, LIB), Int32, (Ptr{Cvoid},), vp.comm)
     vp.comm = C_NULL
     for d in vp.devs

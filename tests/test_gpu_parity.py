@@ -511,7 +511,9 @@ def test_readback_every_call_and_pipelined(hk, knobs):
 
     ref, acc_ref = loop("fresh")
     assert np.isfinite(ref[-1]).all() and ref[-1].max() > 0 and not np.array_equal(ref[0], ref[-1])
-    for mode, pin in (("view", None), ("view", "0"), (True, None)):
+    # "view" names its one buffer with hk_film_pin_host (the copy lands there directly); HK_READBACK_PIN=1 is round 5's automatic
+    # registration of a destination that comes twice in a row; without either the frame goes through the film's staging buffers
+    for mode, pin in (("view", None), ("view", "1"), (True, "1"), (True, None)):
         got, acc = loop(mode, pin)
         assert np.array_equal(acc.view(np.uint32), acc_ref.view(np.uint32)), (mode, pin)
         for i in range(n):
@@ -861,6 +863,40 @@ def test_small_pass_in_one_launch(hk, knobs):
     assert int(run(s, cam, film, {}, [1, 1], depth=5)[1].fused_passes) == 0
     for k in ("HK_SMALL_PASS_FUSED", "HK_WAVES_PER_CU", "HK_SMALL_PASS_WAVES", "HK_SMALL_PASS_MERGED", "HK_BATCH_PATHS_M"):
         knobs.delenv(k, raising=False)
-    knobs.setenv("HK_WAVES_PER_CU", "0")                   # (sticky in the context: back to the default)
+    # HK_WAVES_PER_CU is not sticky any more (the envs after {"HK_WAVES_PER_CU": "3"} above used to run at 3 segments per CU):
+    # with the knob unset the default policy applies again
     s, film, cam = scenes.cornell_box(w, h, light="area")
-    run(s, cam, film, {"HK_WAVES_PER_CU": "0"}, [1])
+    assert int(run(s, cam, film, {}, [1])[1].fused_passes) == 1
+
+
+@pytest.mark.parametrize("eltype", ["Float32", "Float64"])
+def test_film_kernels_agree(hk, knobs, eltype):
+    """K12 in its two forms (round 6): k_film_lanes — one lane per pixel streams through that pixel's samples, colour-matching functions in
+    LDS — against k_film (HK_FILM_LANES=0: four lanes add a pixel's samples from LDS).  Both add a pixel's samples in sample order onto the
+    stored accumulators, so the films must agree bit for bit: pass sizes that are and are not multiples of 8 (the eight-at-a-time loop and
+    its one-by-one tail), a film whose size is no multiple of the 8 x 8 tiles (padding lanes), several passes on top of each other."""
+    from hikari_jl_amd import scenes
+    w, h = 43, 29
+    s, film, cam = scenes.cornell_box(w, h, light="area", objects="two_spheres")
+    knobs.setenv("HK_BATCH_PATHS_M", "0")              # every call is a pass of its own
+
+    def run(lanes, plan):
+        knobs.setenv("HK_FILM_LANES", lanes)
+        vp = hk.VolPath(max_depth=5, samples=256, accumulation_eltype=eltype)
+        vp._ensure(film)
+        vp.clear()
+        first = 1
+        for k in plan:
+            vp.render_samples(s, film, cam, k, first=first, readback=False)
+            first += k
+        acc = vp.read_accumulators(film).copy()
+        vp.close()
+        return acc
+
+    bits = np.uint32 if eltype == "Float32" else np.uint64
+    for plan in ([8], [64], [24, 40], [3], [13, 8, 1], [100], [256]):
+        a, b = run("0", plan), run("1", plan)
+        assert np.isfinite(a).all() and a[:3 * w * h].max() > 0
+        assert np.array_equal(a.view(bits), b.view(bits)), (plan, float(np.abs(a - b).max()))
+    knobs.delenv("HK_FILM_LANES")
+    knobs.delenv("HK_BATCH_PATHS_M")

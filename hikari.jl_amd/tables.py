@@ -31,6 +31,8 @@ def load():
     cie = np.fromfile(os.path.join(DATA_DIR, "cie_xyz.bin"), dtype=np.float32)
     assert sobol.size == 1024 * 52 and cie.size == 3 * 471
     p = os.path.join(DATA_DIR, "srgb_spectrum_table.dat")
+    if os.environ.get("HK_RGB2SPEC_TABLE"):      # another table in the reference's own file layout (rgb2spec.jl:403-421): the one a Julia box dumped beside its fixtures
+        p = os.environ["HK_RGB2SPEC_TABLE"]      # (tests/test_reference_fixtures.py: both sides must look colours up in the SAME table)
     _ensure_rgb2spec(p)
     raw = np.fromfile(p, dtype=np.uint8)
     res = int(raw[:4].view(np.int32)[0])

@@ -62,6 +62,9 @@ def inputs():
     d[:, 16:, 8:] = 0.0
     a["nvdb_density"] = d                                # [nx, ny, nz] in NumPy order: Julia reads it as an Array{Float32,3} of size (nz, ny, nx) and permutes
     a["nvdb_ijk"] = np.stack([rng.integers(-3, 44, N), rng.integers(-3, 28, N), rng.integers(-3, 24, N)], axis=1).astype(i32)
+    # world points in and around the medium's bounds ((-0.5, 0, -0.3) .. (0.5, 0.6, 0.2)): sample_point's trilinear lookup (nanovdb.jl:400-483)
+    lo, hi = np.array([-0.5, 0.0, -0.3]), np.array([0.5, 0.6, 0.2])
+    a["nvdb_p"] = (lo - 0.1 * (hi - lo) + 1.2 * (hi - lo) * rng.random((N, 3))).astype(f32)
     return a
 
 

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <memory>
 #include <mutex>
 
@@ -83,7 +84,7 @@ static const char* const KNOB_NAMES[] = {
     "HK_MID_LISTS", "HK_MID_PASS_PATHS_M", "HK_NODE_CACHE", "HK_NVDB_DENSE_MB", "HK_OVERLAP", "HK_PIPELINE", "HK_PIPELINE_AFTER", "HK_PIPELINE_MAX_PATHS_M", "HK_PRESELECT",
     "HK_SELECT_MIN_IDLE", "HK_SHADOW_FEED_ROUNDS", "HK_SHADOW_TRACK_BATCH", "HK_SMALL_PASS", "HK_SMALL_PASS_WAVES", "HK_SOBOL_LO_GB", "HK_SOBOL_TABLE_ONLY",
     "HK_STATE_CACHE_GB", "HK_STATE_SLAB", "HK_TICKET_SHARE", "HK_TRACK_ADVANCE", "HK_TRACK_EXTRA_ADVANCE", "HK_TRACK_MIN_PENDING", "HK_TRACK_POOL", "HK_TRACK_REFILL_IDLE",
-    "HK_WALK_POOL", "HK_WALK_REFILL_IDLE", "HK_WALK_SPLIT", "HK_WAVES_PER_CU", "HK_READBACK_PIN", "HK_DEFER_EXTERNAL", "HK_SELECT_POOL", "HK_SMALL_PASS_FUSED", "HK_SMALL_PASS_MERGED", "HK_FILM_LANES"};
+    "HK_WALK_POOL", "HK_WALK_REFILL_IDLE", "HK_WALK_SPLIT", "HK_WAVES_PER_CU", "HK_READBACK_PIN", "HK_DEFER_EXTERNAL", "HK_SELECT_POOL", "HK_SMALL_PASS_FUSED", "HK_SMALL_PASS_MERGED", "HK_OCC_SCALE", "HK_ESCAPED_UNROLL", "HK_SHADOW_FINAL", "HK_TRI_PACK"};
 static bool known_knob(const char* name) {
     for (const char* k : KNOB_NAMES)
         if (std::strcmp(k, name) == 0) return true;
@@ -304,7 +305,7 @@ static int join_lanes(hk_ctx* c) {
 
 struct hk_scene {
     hk_ctx* ctx = nullptr;
-    DevBuf nodes, qnodes, leaf_tris, positions, normals, uvs, tangents, meta, materials, textures, spectra, mis, lights, lnodes, trails, infinite;
+    DevBuf nodes, qnodes, leaf_tris, positions, normals, uvs, tangents, meta, tri_shade, materials, textures, spectra, mis, lights, lnodes, trails, infinite;
     std::vector<DevBuf*> tex_data;
     std::vector<DevBuf*> spec_data;
     std::vector<DevBuf*> media_data;
@@ -755,6 +756,24 @@ extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene**
     if (d->tangents) HIP_TRY(s->tangents.upload(d->tangents, (size_t)T * 9 * 4));
     static_assert(sizeof(DTriMeta) == sizeof(hk_tri_meta), "meta layout");
     HIP_TRY(s->meta.upload(d->meta, (size_t)T * sizeof(hk_tri_meta)));
+    // scenes whose attribute arrays (108 B per triangle) fit in an XCD's L2 gain nothing and pay the second address path (cloud config,
+    // 24 triangles: shade + 4 %): records from 32 768 triangles up.  HK_TRI_PACK=0: never, 1: always (A/B switch and tests; films bit-identical)
+    bool tri_pack = T >= 32768;
+    if (const char* e = hk::knob("HK_TRI_PACK")) tri_pack = T > 0 && std::atoi(e) != 0;
+    if (tri_pack) {   // packed shading records (DScene::tri_shade): p[9] n[9] uv[6] meta[3] pad[5] per triangle, one 128-byte line
+        std::vector<float> rec((size_t)T * 32, 0.0f);
+        const float nan = std::numeric_limits<float>::quiet_NaN();
+        static const float default_uv[6] = {0.0f, 0.0f, 1.0f, 0.0f, 1.0f, 1.0f};   // (0,0), (1,0), (1,1): uv_at's defaults
+        for (int t = 0; t < T; ++t) {
+            float* r = rec.data() + (size_t)t * 32;
+            std::memcpy(r, d->positions + 9 * (size_t)t, 36);
+            if (d->normals) std::memcpy(r + 9, d->normals + 9 * (size_t)t, 36);
+            else for (int k = 0; k < 9; ++k) r[9 + k] = nan;
+            std::memcpy(r + 18, d->uvs ? d->uvs + 6 * (size_t)t : default_uv, 24);
+            std::memcpy(r + 24, &d->meta[t], 12);
+        }
+        HIP_TRY(s->tri_shade.upload(rec.data(), rec.size() * sizeof(float)));
+    }
     // ---- textures / spectra ----
     std::vector<DTexture> dt(d->n_textures > 0 ? d->n_textures : 1);
     for (int i = 0; i < d->n_textures; ++i) {
@@ -1199,6 +1218,7 @@ extern "C" int32_t hk_scene_create(hk_ctx* c, const hk_scene_desc* d, hk_scene**
     D.uvs = d->uvs ? s->uvs.as<float>() : nullptr;
     D.tangents = d->tangents ? s->tangents.as<float>() : nullptr;
     D.meta = s->meta.as<DTriMeta>();
+    D.tri_shade = s->tri_shade.p ? s->tri_shade.as<float>() : nullptr;
     D.materials = s->materials.as<DMaterial>();
     D.textures = s->textures.as<DTexture>();
     D.spectra = s->spectra.as<DPLSpectrum>();
@@ -1623,7 +1643,7 @@ hipError_t alloc_arr(hk_integrator* I, T*& dst, size_t n) {
 //   surfaces, open scene      static stride, 48 per CU   (sky: most paths escape after 1-2 vertices; finer segments only fragment
 //                             the per-kind queues: k_shade +7 % at 96, +15 % at 256, whichever way they are handed out)
 // HK_WAVES_PER_CU / HK_DYNAMIC_SEGMENTS override.  stats rows are indexed by PHYSICAL wave (ctx->stat_rows).
-int ensure_state(hk_integrator* I, int capacity, bool media, bool open_scene, bool small_scene, bool grey_compact, hipStream_t users = nullptr, bool fusable = false) {
+int ensure_state(hk_integrator* I, int capacity, bool media, bool open_scene, bool small_scene, bool grey_compact, hipStream_t users = nullptr, bool fusable = false, bool opaque_surfaces = false) {
     const int n_cu = I->ctx->n_cu;
     // a closed scene's pass of at most HK_MID_PASS_PATHS_M (48) million paths — a rank's share of a frame under 8-way strong scaling —
     // behaves like the open scene WHEN THE SCENE IS SMALL (BVH depth <= 16, the Cornell box): the deep bounces hold a few dozen rays per
@@ -1647,6 +1667,10 @@ int ensure_state(hk_integrator* I, int capacity, bool media, bool open_scene, bo
     I->st.dynamic_segments = (media || (!open_scene && !mid)) ? 1 : 0;
     if (const char* e = hk::knob("HK_DYNAMIC_SEGMENTS")) I->st.dynamic_segments = std::atoi(e) ? 1 : 0;
     I->st.compact = media ? (grey_compact ? 1 : 0) : 1;
+    {   // slim shadow records (HK_SHADOW_FINAL=0: the 60-byte records of rounds 3-5; A/B switch, films bit-identical)
+        const char* e = hk::knob("HK_SHADOW_FINAL");
+        I->st.sh_final = (!media && opaque_surfaces && !(e && std::atoi(e) == 0)) ? 1 : 0;   // (k_shadow's scenes: no medium, no alpha-tested surface)
+    }
     I->st.ticket_share = 1;
     if (const char* e = hk::knob("HK_TICKET_SHARE")) I->st.ticket_share = std::atoi(e) ? 1 : 0;
     {   // a SMALL pass (at most 16 chunks for each of 4 waves per CU: a one-sample call at 800^2) hands segment g to wave g of every launch
@@ -1959,7 +1983,8 @@ static int render_tile_now(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_film* f
     int st = ensure_state(I, S * fr.n_pixels_padded, sc->d.n_media > 0, sc->d.has_escape_lights != 0, sc->d.bvh_depth <= 16, sc->d.n_media > 0 && hk::grey_compact_ok(sc->d), piped ? c->lanes[lane_idx].stream : nullptr,
                           // (the predicate of launch_small_pass, as far as it is known here: a call of >= 16 samples draws from the sample-bit table
                           // and keeps the launches — those want 16 segments per CU, not k_small_pass's 8)
-                          !piped && !c->time_kernels && !c->count_nodes && n_samples < 16 && hk::small_pass_fusable(sc->d, sc->kinds_mask));
+                          !piped && !c->time_kernels && !c->count_nodes && n_samples < 16 && hk::small_pass_fusable(sc->d, sc->kinds_mask),
+                          sc->d.all_opaque != 0 && sc->d.n_media == 0);
     if (st != HK_OK) return st;
     fr.sample_stride = sample_stride;
     fr.max_depth = I->p.max_depth;

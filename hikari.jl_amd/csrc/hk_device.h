@@ -1031,6 +1031,14 @@ struct Surface {
     v2 uv;
     float area;
 };
+HKD const float* tri_record(const DScene& sc, int prim) { return sc.tri_shade + 32 * (size_t)prim; }   // (DScene::tri_shade != null)
+HKD DTriMeta tri_meta(const DScene& sc, int prim) {
+    if (sc.tri_shade) {
+        const uint32_t* m = reinterpret_cast<const uint32_t*>(tri_record(sc, prim) + 24);
+        return DTriMeta{m[0], m[1], m[2]};
+    }
+    return sc.meta[prim];
+}
 HKD void tri_vertices(const DScene& sc, int prim, v3& a, v3& b, v3& c) {
     const float* p = sc.positions + 9 * (size_t)prim;
     a = mk3(p[0], p[1], p[2]);
@@ -1056,17 +1064,29 @@ HKD Surface surface_at(const DScene& sc, int prim, float bu, float bv, v3 ro, v3
     Surface s;
     float w = 1.0f - bu - bv;
     s.pi = ro + rd * t;
+    // (only the shading and light-selection kernels read the packed record: in the traversal kernels the second address path cost
+    // k_trace_lean 1.6 ms per Cornell frame without ever being taken, and scenes whose attributes fit in L2 gain nothing — hk_api.cpp
+    // builds the records for scenes of >= 32 768 triangles)
     v3 a, b, c;
-    tri_vertices(sc, prim, a, b, c);
+    if (sc.tri_shade) {
+        const float* p = tri_record(sc, prim);
+        a = mk3(p[0], p[1], p[2]);
+        b = mk3(p[3], p[4], p[5]);
+        c = mk3(p[6], p[7], p[8]);
+        const float* q = p + 18;   // (a mesh without uvs: the record holds uv_at's defaults — the same products and sums)
+        s.uv = mk2(w * q[0] + bu * q[2] + bv * q[4], w * q[1] + bu * q[3] + bv * q[5]);
+    } else {
+        tri_vertices(sc, prim, a, b, c);
+        s.uv = uv_at(sc, prim, w, bu, bv);
+    }
     v3 cr = cross(b - a, c - a);
     v3 n = normalize(cr);
     s.area = 0.5f * norm(cr);
-    s.uv = uv_at(sc, prim, w, bu, bv);
     v3 ns = n;
-    if (sc.normals) {
+    if (sc.tri_shade || sc.normals) {   // (a packed record of a mesh without vertex normals holds NaNs)
         // the nine floats in three loads up front: read field by field behind the NaN test they become twelve per-lane loads
         typedef float hk_f4u __attribute__((ext_vector_type(4), aligned(4)));
-        const float* q = sc.normals + 9 * (size_t)prim;
+        const float* q = sc.tri_shade ? tri_record(sc, prim) + 9 : sc.normals + 9 * (size_t)prim;
         const hk_f4u q0 = *reinterpret_cast<const hk_f4u*>(q), q1 = *reinterpret_cast<const hk_f4u*>(q + 4);
         const float q8 = q[8];
         if (!(isnan(q0.x) || isnan(q0.w) || isnan(q1.z)))

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include <cstdlib>
+#include <cstdio>
 
 #include "hikari_mi355x.h"
 #include "hk_device.h"
@@ -2135,60 +2136,85 @@ __global__ void __launch_bounds__(64) k_detect_camera_medium(DPathState st, DSce
 // ---------------------------------------------------------------------------------------------------
 // K7: escaped rays (intersection.jl:622-678; lights.jl:408-467).  MIS uses 1/num_lights (Q6).
 // ---------------------------------------------------------------------------------------------------
+// one escaped path: what it adds to its L (false: nothing)
+__device__ __forceinline__ bool escaped_one(const DPathState& st, const DScene& sc, const DTables& T, const DPathGen& g, bool ones, uint32_t slot, S4& fin, uint32_t& pslot) {
+    const uint2 meta = g.meta[slot];
+    pslot = meta.y;
+    S4 lambda = ld_lambda(st, g, slot, meta.y);
+    S4 Le = s4(0.0f);
+    v3 rd = mk3(0, 0, 1);
+    bool have_dir = false;
+    for (int li = 0; li < sc.n_lights; ++li) {
+        const DLight& l = sc.lights[li];
+        if (l.kind == HK_LIGHT_AMBIENT) Le = Le + l.scale * light_spectrum(l, lambda);
+        if (l.kind == HK_LIGHT_ENVIRONMENT) {  // bilinear env(dir) * scale, illuminant uplift (lights.jl:408-419)
+            if (!have_dir) {
+                float4 D = g.ray_d[slot];
+                rd = mk3(D.x, D.y, D.z);
+                have_dir = true;
+            }
+            float4 t = env_eval(sc.envmaps[l.Le_tex], rd);
+            Le = Le + eval_illuminant(coef_illuminant(T, t.x * l.Le_rgba[0], t.y * l.Le_rgba[1], t.z * l.Le_rgba[2]), lambda);
+        }
+    }
+    S4 beta = ld_throughput(g.beta, slot, ones);
+    S4 contribution = beta * Le;
+    if (is_black(contribution)) return false;
+    uint32_t fl = meta.x;
+    int pdepth = (int)(fl & 0xff);
+    bool specular = (fl >> 8) & 1u;
+    S4 r_u = ld_ru(g, slot, ones, st.compact != 0);
+    if (pdepth == 0 || specular)
+        fin = contribution / average(r_u);
+    else {
+        float choice = sc.n_lights > 0 ? 1.0f / (float)sc.n_lights : 0.0f;
+        float light_pdf = 0.0f;  // only EnvironmentLight has a pdf (lights.jl:445-467)
+        if (sc.n_envmaps > 0)
+            for (int li = 0; li < sc.n_lights; ++li) {
+                const DLight& l = sc.lights[li];
+                light_pdf = light_pdf + (l.kind == HK_LIGHT_ENVIRONMENT ? env_pdf_li(sc.envmaps[l.Le_tex], rd) : 0.0f);
+            }
+        S4 rl = ld_rl(g, slot, ones, st.compact != 0) * choice * light_pdf;
+        float den = average(r_u + rl);
+        fin = den > 1e-10f ? contribution / den : contribution / average(r_u);
+    }
+    return true;
+}
+// UNROLL = 2 (round 6): a lane carries TWO queue entries through the chain of dependent loads (queue entry -> record -> environment texels ->
+// spectrum table -> L) at once.  The kernel spends 0.81 of its wave time parked at s_waitcnt (profiles/r05_wavestate_sky.txt) with one
+// entry per lane in flight; the two are different paths, so their additions to L do not meet and the film is the same bit for bit.
+template <int UNROLL>
 __device__ __forceinline__ void escaped_body(const DPathState& st, const DScene& sc, const DTables& T, int depth, int implicit_ones, const SegTickets& src) {
     HK_FOR_EACH_SEGMENT_FROM(gw, st, src) {
     const uint32_t* __restrict__ queue = st.escaped_q + (size_t)gw * st.wave_cap;
     const int n = *count_ptr(st, depth, Q_ESCAPED, gw);
     const DPathGen g = st.gen[depth & 1];
     const bool ones = depth == 0 && implicit_ones;
-    for (int i = lane_id(); i < n; i += 64) {
-        uint32_t slot = queue[i];
-        S4 lambda = ld_lambda(st, g, slot, g.meta[slot].y);
-        S4 Le = s4(0.0f);
-        v3 rd = mk3(0, 0, 1);
-        bool have_dir = false;
-        for (int li = 0; li < sc.n_lights; ++li) {
-            const DLight& l = sc.lights[li];
-            if (l.kind == HK_LIGHT_AMBIENT) Le = Le + l.scale * light_spectrum(l, lambda);
-            if (l.kind == HK_LIGHT_ENVIRONMENT) {  // bilinear env(dir) * scale, illuminant uplift (lights.jl:408-419)
-                if (!have_dir) {
-                    float4 D = g.ray_d[slot];
-                    rd = mk3(D.x, D.y, D.z);
-                    have_dir = true;
-                }
-                float4 t = env_eval(sc.envmaps[l.Le_tex], rd);
-                Le = Le + eval_illuminant(coef_illuminant(T, t.x * l.Le_rgba[0], t.y * l.Le_rgba[1], t.z * l.Le_rgba[2]), lambda);
-            }
+    int i = lane_id();
+    if (UNROLL == 2) {
+        for (; i + 64 < n; i += 128) {
+            const uint32_t slot0 = queue[i], slot1 = queue[i + 64];
+            S4 fin0, fin1;
+            uint32_t p0, p1;
+            const bool a0 = escaped_one(st, sc, T, g, ones, slot0, fin0, p0);
+            const bool a1 = escaped_one(st, sc, T, g, ones, slot1, fin1, p1);
+            S4 L0 = s4(0.0f), L1 = s4(0.0f);
+            if (a0) L0 = ld4(&st.L[p0]);
+            if (a1) L1 = ld4(&st.L[p1]);
+            if (a0) st4(&st.L[p0], L0 + fin0);
+            if (a1) st4(&st.L[p1], L1 + fin1);
         }
-        S4 beta = ld_throughput(g.beta, slot, ones);
-        S4 contribution = beta * Le;
-        if (is_black(contribution)) continue;
-        const uint2 meta = g.meta[slot];
-        uint32_t fl = meta.x;
-        int pdepth = (int)(fl & 0xff);
-        bool specular = (fl >> 8) & 1u;
-        S4 r_u = ld_ru(g, slot, ones, st.compact != 0);
+    }
+    for (; i < n; i += 64) {
         S4 fin;
-        if (pdepth == 0 || specular)
-            fin = contribution / average(r_u);
-        else {
-            float choice = sc.n_lights > 0 ? 1.0f / (float)sc.n_lights : 0.0f;
-            float light_pdf = 0.0f;  // only EnvironmentLight has a pdf (lights.jl:445-467)
-            if (sc.n_envmaps > 0)
-                for (int li = 0; li < sc.n_lights; ++li) {
-                    const DLight& l = sc.lights[li];
-                    light_pdf = light_pdf + (l.kind == HK_LIGHT_ENVIRONMENT ? env_pdf_li(sc.envmaps[l.Le_tex], rd) : 0.0f);
-                }
-            S4 rl = ld_rl(g, slot, ones, st.compact != 0) * choice * light_pdf;
-            float den = average(r_u + rl);
-            fin = den > 1e-10f ? contribution / den : contribution / average(r_u);
-        }
-        st4(&st.L[meta.y], ld4(&st.L[meta.y]) + fin);
+        uint32_t pslot;
+        if (escaped_one(st, sc, T, g, ones, queue[i], fin, pslot)) st4(&st.L[pslot], ld4(&st.L[pslot]) + fin);
     }
     }
 }
+template <int UNROLL>
 __global__ void __launch_bounds__(256) k_escaped(DPathState st, DScene sc, DTables T, int depth, int implicit_ones) {
-    escaped_body(st, sc, T, depth, implicit_ones, seg_open(st, ticket_ptr(st, depth, TK_ESCAPED), st.dynamic_segments != 0, depth, Q_ESCAPED));
+    escaped_body<UNROLL>(st, sc, T, depth, implicit_ones, seg_open(st, ticket_ptr(st, depth, TK_ESCAPED), st.dynamic_segments != 0, depth, Q_ESCAPED));
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2562,7 +2588,7 @@ HKD void shade_emission(const DPathState& st, const DPathGen& g, bool ones, cons
     const v3 ro = mk3(O.x, O.y, O.z), rd = mk3(D.x, D.y, D.z);
     const float t_hit = H.x;
     const int prim = __float_as_int(H.y);
-    const DTriMeta meta = sc.meta[prim];
+    const DTriMeta meta = tri_meta(sc, prim);
     if (meta.arealight <= 0) return;
     const Surface sf = surface_at(sc, prim, H.z, H.w, ro, rd, t_hit);
     const v3 wo = -rd;
@@ -2678,7 +2704,7 @@ __device__ __forceinline__ void shade_body(const DPathState& st, const DScene& s
             int prim = __float_as_int(H.y);
             sf = surface_at(sc, prim, H.z, H.w, ro, rd, t_hit);
             wo = -rd;
-            meta = sc.meta[prim];
+            meta = tri_meta(sc, prim);
             const uint2 pmeta = g.meta[slot];
             lambda = ld_lambda(st, g, slot, pmeta.y);
             if (ones)
@@ -2799,7 +2825,14 @@ __device__ __forceinline__ void shade_body(const DPathState& st, const DScene& s
         // the shadow record goes to its position in the segment's shadow queue: k_shadow streams the records
         {
             const size_t ps = seg + (size_t)wp_push(q_shadow, push_shadow);
-            if (push_shadow) {
+            if (push_shadow && st.sh_final) {   // slim record (shadow_contribute_final): the denominator beside the direction instead of two weights
+                const S4 mis = s4(shRu.x) * s4(1.0f) + s4(shRl.x) * s4(1.0f);
+                shD.w = average(mis);
+                stream_st(&st.sh_o[ps], shO);
+                stream_st(&st.sh_d[ps], shD);
+                stream_st(&st.sh_Ld[ps], shLd);
+                stream_st(&st.sh_slot[ps], pslot);
+            } else if (push_shadow) {
                 stream_st(&st.sh_o[ps], shO);
                 stream_st(&st.sh_d[ps], shD);
                 stream_st(&st.sh_Ld[ps], shLd);
@@ -2920,6 +2953,21 @@ HKD void shadow_contribute(const DPathState& st, uint32_t rec, S4 T_ray, S4 tr_u
     }
 }
 
+// SLIM SHADOW RECORDS (round 6; DPathState::sh_final, opaque scenes without media).  Without media a shadow ray's transmittance and its two
+// track weights are 1, so the denominator of what an unoccluded ray adds — average(w_u * 1 + w_l * 1) — is known when the record is
+// written: k_shade forms it (shadow_contribute's operations in its order: the same bits) and stores it in the unused fourth word of sh_d;
+// the two weights (8 B) are neither written nor read — a 56-byte record instead of 60 and one stream less in k_shadow, which still does
+// the division.  (First version: the DIVISION in k_shade too and the path slot beside the direction, 48 B — k_shadow -9 %, but the four
+// correctly rounded divisions cost k_shade<Matte> +0.8 ms per Cornell frame, as much as the bytes returned: LAB_NOTEBOOK.md round 6.)
+HKD void shadow_contribute_final(const DPathState& st, uint32_t rec, float den) {
+    if (den > 1e-10f) {
+        const S4 fin = ld4(&st.sh_Ld[rec]) * s4(1.0f) / den;
+        if (!is_black(fin)) {
+            const uint32_t pslot = st.sh_slot[rec];
+            st4(&st.L[pslot], ld4(&st.L[pslot]) + fin);
+        }
+    }
+}
 // the layout of the shadow weights is a run-time fact where grey media may or may not use the compact records (k_walk_pool)
 HKD void shadow_contribute_rt(const DPathState& st, uint32_t rec, S4 T_ray, S4 tr_u, S4 tr_l) {
     if (st.compact)
@@ -2940,15 +2988,19 @@ __device__ __forceinline__ void shadow_body(const DPathState& st, const DScene& 
     bool more = true;
     bool have = false;
     uint32_t slot = 0;
+    float rec_den = 0.0f;
     LaneRay r;
     r.cur = r.pend = DONE;
     for (;;) {
         const unsigned long long run_m = __ballot(have && r.cur != DONE);
         if (run_m == 0ull || (64 - __popcll(run_m) >= HK_TRACE_MIN_IDLE && (cursor < n || more))) {
             if (have && r.cur == DONE) {   // finished: an unoccluded shadow ray delivers its contribution
-                if (r.best.prim < 0)
-                    shadow_contribute<true>(st, slot, s4(1.0f), s4(1.0f), s4(1.0f));
-                else
+                if (r.best.prim < 0) {
+                    if (st.sh_final)
+                        shadow_contribute_final(st, slot, rec_den);
+                    else
+                        shadow_contribute<true>(st, slot, s4(1.0f), s4(1.0f), s4(1.0f));
+                } else
                     ++n_hits;
                 have = false;
             }
@@ -2968,6 +3020,7 @@ __device__ __forceinline__ void shadow_body(const DPathState& st, const DScene& 
             if (!have && rank < avail) {
                 slot = seg + (uint32_t)(cursor + rank);
                 float4 O = stream_ld(&st.sh_o[slot]), D = stream_ld(&st.sh_d[slot]);
+                rec_den = D.w;   // (slim records: the denominator travels beside the direction)
                 if (O.w >= 1e-6f) {   // a degenerate shadow ray is simply not visible
                     ++n_casts;
                     lane_ray_start<QN>(r, sc, mk3(O.x, O.y, O.z), mk3(D.x, D.y, D.z), O.w);
@@ -3030,6 +3083,7 @@ __device__ __forceinline__ void trace_shadow_body(const DPathState& st, const DS
     int cur_ray = 0, cur_sh = 0;
     int state = LR_EMPTY;
     uint32_t slot = 0;
+    float rec_den = 0.0f;
     LaneRay r;
     r.cur = r.pend = DONE;
     r.any = false;
@@ -3039,9 +3093,12 @@ __device__ __forceinline__ void trace_shadow_body(const DPathState& st, const DS
             int kind = -1;
             if (state == LR_ACTIVE && r.cur == DONE) {
                 if (r.any) {   // a shadow ray: unoccluded, it delivers its contribution
-                    if (r.best.prim < 0)
-                        shadow_contribute<true>(st, slot, s4(1.0f), s4(1.0f), s4(1.0f));
-                    else
+                    if (r.best.prim < 0) {
+                        if (st.sh_final)
+                            shadow_contribute_final(st, slot, rec_den);
+                        else
+                            shadow_contribute<true>(st, slot, s4(1.0f), s4(1.0f), s4(1.0f));
+                    } else
                         ++n_hits;
                 } else if (r.best.prim < 0)
                     kind = -2;
@@ -3084,6 +3141,7 @@ __device__ __forceinline__ void trace_shadow_body(const DPathState& st, const DS
                 if (rank < avail_sh) {
                     slot = seg + (uint32_t)(cur_sh + rank);
                     float4 O = stream_ld(&st.sh_o[slot]), D = stream_ld(&st.sh_d[slot]);
+                    rec_den = D.w;
                     if (O.w >= 1e-6f) {   // a degenerate shadow ray is simply not visible
                         ++n_sh_casts;
                         lane_ray_start(r, sc, mk3(O.x, O.y, O.z), mk3(D.x, D.y, D.z), O.w);
@@ -3169,7 +3227,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(BLOCK, BLOCK), amdgpu
             if (!GENERAL)
                 HK_STAGE_T(2, (shade_body<HK_MAT_MATTE, true, false, false>(st, sc, T, fr, sob, depth, 1, stats, seg_single(st, g), elist)));
             else {
-                if (sc.has_escape_lights) escaped_body(st, sc, T, depth, fr.implicit_ones, seg_single(st, g));
+                if (sc.has_escape_lights) escaped_body<1>(st, sc, T, depth, fr.implicit_ones, seg_single(st, g));
                 int first_kind = 1;   // the kinds in ascending order, each continuing the shadow / next-ray queues of the one before (as the launches do)
 #define HK_SMALL_KIND(K, S)                                                                                                                   \
     if (kinds_mask & (1u << K)) {                                                                                                             \
@@ -4508,94 +4566,6 @@ __global__ void __launch_bounds__(256) k_film(DPathState st, DFrame fr, DTables 
     for (int tile = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)); tile < n_tiles; tile += n_waves) film_tile<ACC>(st, fr, T, accum, mine, tile);
 }
 
-// K12 with ONE LANE PER PIXEL (round 6).  k_film above reads a tile's slots 64 at a time — the 64 samples of ONE pixel — converts them on
-// all lanes and lets the four lanes of that pixel add the 64 entries from LDS one after the other: every 64-slot step is a chain of
-// load -> convert -> LDS -> 64 dependent adds with nothing else of the wave in flight (3.1 ms for the 5.9 GB of a 164 M-path pass:
-// 1.9 TB/s).  Here lane l of a wave owns pixel l of the tile and streams through ITS S consecutive slots, eight at a time (one 128-B
-// line of L and of lambda_s, 32 B of filter weights per step and lane), converts them and adds them to its own four accumulators in
-// sample order — the same fp32 (or fp64) sums, 64 independent chains per wave instead of one.  The colour-matching functions sit in
-// LDS as one (x, y, z) record per nanometre: one LDS read per wavelength instead of three table gathers through the vector cache.
-// Films bit-identical to k_film's (HK_FILM_LANES=0: the old kernel; tests/test_gpu_parity.py::test_film_kernels_agree).
-HKD v3 spectral_to_rgb_clamped_lds(const float4* __restrict__ cie4, S4 L, S4 lambda, S4 pdf, float max_component_value) {   // spectral_to_rgb_clamped with the table in LDS
-    v3 sum = mk3(0.0f, 0.0f, 0.0f);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float p = at(pdf, i);
-        if (p != 0.0f) {
-            const float l = at(lambda, i), Li = at(L, i);
-            const int off = (int)rintf(l) - 360;
-            v3 cmf = mk3(0.0f, 0.0f, 0.0f);
-            if (off >= 0 && off < 471) {
-                const float4 c = cie4[off];
-                cmf = mk3(c.x, c.y, c.z);
-            }
-            sum = sum + (cmf * Li) / p;
-        }
-    }
-    const v3 xyz = sum * 0.25f;
-    const float X = xyz.x, Y = xyz.y, Z = xyz.z;
-    v3 rgb = mk3(3.2404542f * X - 1.5371385f * Y - 0.4985314f * Z, -0.9692660f * X + 1.8760108f * Y + 0.0415560f * Z,
-                 0.0556434f * X - 0.2040259f * Y + 1.0572252f * Z);
-    rgb = mk3(maxf(0.0f, rgb.x), maxf(0.0f, rgb.y), maxf(0.0f, rgb.z));
-    const float m = maxf(maxf(rgb.x, rgb.y), rgb.z);
-    if (m > max_component_value) rgb = rgb * (max_component_value / m);
-    return rgb;
-}
-template <typename ACC>
-__global__ void __launch_bounds__(256) k_film_lanes(DPathState st, DFrame fr, DTables T, ACC* __restrict__ accum) {
-    __shared__ float4 cie4[471];
-    for (int i = (int)threadIdx.x; i < 471; i += 256) cie4[i] = make_float4(T.cie[i], T.cie[471 + i], T.cie[942 + i], 0.0f);
-    __syncthreads();
-    const int lane = lane_id();
-    const int S = fr.samples_in_pass;
-    const size_t N = (size_t)fr.width * fr.height;
-    const int n_tiles = fr.n_pixels_padded >> 6;
-    const int n_waves = (int)(gridDim.x * (blockDim.x >> 6));
-    for (int tile = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)); tile < n_tiles; tile += n_waves) {
-        int px, py;
-        bool inside;
-        slot_to_pixel(fr, tile * 64 + lane, px, py, inside);
-        if (!inside) continue;   // (film padding: its slots were never written)
-        const size_t p = (size_t)py * fr.width + px;
-        ACC r = accum[3 * p], g = accum[3 * p + 1], b = accum[3 * p + 2], w = accum[3 * N + p];
-        const size_t base = ((size_t)tile * 64 + (size_t)lane) * (size_t)S;
-        int k = 0;
-        if ((S & 7) == 0) {
-            for (; k < S; k += 8) {
-                float4 Lv[8], lv[8];
-                float fwv[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) Lv[j] = stream_ld(&st.L[base + k + j]);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) lv[j] = stream_ld(&st.lambda_s[base + k + j]);
-                {
-                    const float4 f0 = stream_ld(reinterpret_cast<const float4*>(st.filter_w + base + k)), f1 = stream_ld(reinterpret_cast<const float4*>(st.filter_w + base + k) + 1);
-                    fwv[0] = f0.x, fwv[1] = f0.y, fwv[2] = f0.z, fwv[3] = f0.w, fwv[4] = f1.x, fwv[5] = f1.y, fwv[6] = f1.z, fwv[7] = f1.w;
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const S4 lam_ = s4(lv[j].x, lv[j].y, lv[j].z, lv[j].w);
-                    const v3 rgb = spectral_to_rgb_clamped_lds(cie4, s4(Lv[j].x, Lv[j].y, Lv[j].z, Lv[j].w), lam_, pdf_of(lam_), fr.max_component_value);
-                    const float fw = fwv[j];
-                    const float cr = fw * rgb.x, cg = fw * rgb.y, cb = fw * rgb.z;
-                    r += (ACC)cr, g += (ACC)cg, b += (ACC)cb, w += (ACC)fw;
-                }
-            }
-        }
-        for (; k < S; ++k) {
-            const S4 lam_ = ld4(&st.lambda_s[base + k]);
-            const v3 rgb = spectral_to_rgb_clamped_lds(cie4, ld4(&st.L[base + k]), lam_, pdf_of(lam_), fr.max_component_value);
-            const float fw = st.filter_w[base + k];
-            const float cr = fw * rgb.x, cg = fw * rgb.y, cb = fw * rgb.z;
-            r += (ACC)cr, g += (ACC)cg, b += (ACC)cb, w += (ACC)fw;
-        }
-        accum[3 * p] = r;
-        accum[3 * p + 1] = g;
-        accum[3 * p + 2] = b;
-        accum[3 * N + p] = w;
-    }
-}
-
 // K13 (volpath.jl:384-417): out = Julia Matrix{RGB{Float32}}[height,width] column-major
 template <typename ACC>
 __global__ void k_finalize(const ACC* __restrict__ accum, float* __restrict__ out, int width, int height) {
@@ -4951,6 +4921,9 @@ __global__ void __launch_bounds__(256) k_denoise_atrous(hk_denoise_params P, int
 // ---------------------------------------------------------------------------------------------------
 namespace hk {
 
+#ifndef HK_OCC_SCALE_DEFAULT
+#define HK_OCC_SCALE_DEFAULT 1.0f
+#endif
 static inline int grid_for(int n, int block, int cap) {
     long g = ((long)n + block - 1) / block;
     if (g < 1) g = 1;
@@ -4961,11 +4934,19 @@ static inline int grid_for(int n, int block, int cap) {
 // blocks per CU that are actually resident for a kernel (occupancy API, capped): the wave-segment loop makes any
 // grid size correct, so the grid is sized to residency instead of oversubscribing and paying a tail round.
 template <class K>
-static int resident_blocks(K kernel, int block, int n_cu, int cap_per_cu) {
+static int resident_blocks(K kernel, int block) {   // blocks per CU as the occupancy API reports them (uncapped)
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, 0) != hipSuccess || per_cu < 1) per_cu = 1;
-    if (per_cu > cap_per_cu) per_cu = cap_per_cu;
-    return per_cu * n_cu;
+    return per_cu;
+}
+// HK_OCC_SCALE (round 6): the occupancy API of this ROCm answers HALF of what the register file admits for the 256-thread kernels here
+// (k_camera, 52 VGPRs: 4 blocks per CU where 512 / 56 registers give 8 waves per SIMD = 8 blocks; MI355X_MICROARCH.md "Register files").
+// Grids are sized by `answer x scale`, capped at the caller's cap (8 blocks = 32 waves per CU, the hardware's own limit) — a block the
+// CU cannot hold simply starts later, and the ticketed / strided segment loops make any grid size correct.
+static float occ_scale() {
+    const char* e = hk::knob("HK_OCC_SCALE");
+    const float v = e ? (float)std::atof(e) : HK_OCC_SCALE_DEFAULT;
+    return v >= 0.25f && v <= 8.0f ? v : 1.0f;
 }
 // Residency is a property of (kernel, device): cached per kernel instantiation AND per device, so one process can drive several
 // GPUs (the in-library multi-device path) without one device's answer leaking to another.
@@ -4973,10 +4954,20 @@ static int resident_blocks(K kernel, int block, int n_cu, int cap_per_cu) {
 template <auto Kernel>
 static int cached_blocks(int block, int n_cu, int cap_per_cu) {
     static int cache[HK_MAX_DEVICES];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= HK_MAX_DEVICES) return resident_blocks(Kernel, block, n_cu, cap_per_cu);
-    if (cache[dev] == 0) cache[dev] = resident_blocks(Kernel, block, n_cu, cap_per_cu);
-    return cache[dev];
+    int dev = 0, per_cu;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= HK_MAX_DEVICES)
+        per_cu = resident_blocks(Kernel, block);
+    else {
+        if (cache[dev] == 0) {
+            cache[dev] = resident_blocks(Kernel, block);
+            if (hk::knob("HK_DEBUG_ALLOC")) std::fprintf(stderr, "HK_DEBUG_ALLOC occupancy API: %d blocks of %d per CU for %s\n", cache[dev], block, __PRETTY_FUNCTION__);
+        }
+        per_cu = cache[dev];
+    }
+    per_cu = (int)((float)per_cu * occ_scale() + 0.5f);
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > cap_per_cu) per_cu = cap_per_cu;
+    return per_cu * n_cu;
 }
 // Segments are walked with a static stride, so the number of physical waves must DIVIDE W or the last round runs with a
 // fraction of the waves (shade at W = 16/CU with 12 resident: 12 % slower than at W = 24): the largest divisor of the
@@ -5225,8 +5216,14 @@ void launch_detect_camera_medium(hipStream_t s, const DPathState& st, const DSce
     hipLaunchKernelGGL(k_detect_camera_medium, dim3(1), dim3(64), 0, s, st, sc, x, y, z, stats);
 }
 void launch_escaped(hipStream_t s, int n_cu, const DPathState& st, const DScene& sc, const DTables& T, const DFrame& fr, int depth) {
-    const int blocks = cached_blocks<k_escaped>(256, n_cu, 8);
-    hipLaunchKernelGGL(k_escaped, dim3(clamp_blocks(blocks, st)), dim3(256), 0, s, st, sc, T, depth, fr.implicit_ones);   // (one wave per segment instead of the resident stride: +-0, sky)
+    const char* e = hk::knob("HK_ESCAPED_UNROLL");   // 2: two queue entries per lane and iteration (A/B switch; films bit-identical).  Measured, sky: 8.9 ->
+    if (!(e && std::atoi(e) == 2)) {                  // 10.4 ms per frame — its registers cost the kernel a block per CU (3 instead of 4); off
+        const int blocks = cached_blocks<k_escaped<1>>(256, n_cu, 8);
+        hipLaunchKernelGGL(k_escaped<1>, dim3(clamp_blocks(blocks, st)), dim3(256), 0, s, st, sc, T, depth, fr.implicit_ones);   // (one wave per segment instead of the resident stride: +-0, sky)
+    } else {
+        const int blocks = cached_blocks<k_escaped<2>>(256, n_cu, 8);
+        hipLaunchKernelGGL(k_escaped<2>, dim3(clamp_blocks(blocks, st)), dim3(256), 0, s, st, sc, T, depth, fr.implicit_ones);
+    }
 }
 static bool sobol_tables_cover(const DSobol& sob, int depth) {
     const char* ft_env = hk::knob("HK_SOBOL_TABLE_ONLY");   // looked up per launch in the context's knob table (A/B switch)
@@ -5380,14 +5377,6 @@ bool launch_small_pass(hipStream_t s, int n_cu, const DPathState& st, const DSce
 }
 void launch_film(hipStream_t s, const DPathState& st, const DFrame& fr, const DTables& T, void* accum, bool f64) {
     int g = grid_for(fr.n_pixels_padded >> 6, 4, 4096);   // one wave per 8x8 tile
-    const char* fl = hk::knob("HK_FILM_LANES");           // 0: k_film (a pixel's samples added by four lanes from LDS; A/B switch, films bit-identical)
-    if (!(fl && std::atoi(fl) == 0)) {
-        if (f64)
-            hipLaunchKernelGGL(k_film_lanes<double>, dim3(g), dim3(256), 0, s, st, fr, T, (double*)accum);
-        else
-            hipLaunchKernelGGL(k_film_lanes<float>, dim3(g), dim3(256), 0, s, st, fr, T, (float*)accum);
-        return;
-    }
     if (f64)
         hipLaunchKernelGGL(k_film<double>, dim3(g), dim3(256), 0, s, st, fr, T, (double*)accum);
     else

@@ -194,6 +194,12 @@ struct DScene {
     int all_grey;               // every medium is a Grid / NanoVDB medium whose sigma_a and sigma_s are flat spectra (the GREY tracking kernels)
     int grey_pool;              // all_grey, ONE medium, majorant grid <= 1024 cells per axis (k_track_pool packs the cell index in one word)
     int grey_bricks;            // all_grey and the one medium is a NanoVDB grid with dense halo bricks (DMedium::nv_bricks): tracking kernels without the tree walk
+    // PACKED SHADING RECORDS (round 6): what a shading vertex reads of its triangle — positions 36 B, vertex normals 36 B (NaN: none), uvs 24 B
+    // (the defaults when the mesh has none), meta 12 B — as ONE 128-byte, 128-byte-aligned record per triangle (32 floats: p[9] n[9] uv[6]
+    // meta[3] pad[5]) instead of four arrays with strides of 36 / 36 / 24 / 12 B: a hit on a random triangle of the 10^6-triangle scene touches
+    // one line instead of five to six 64-byte sectors in four places (profiles/pmc_traffic_manylight.json: k_shade moved 2.4 x its algorithmic
+    // bytes).  Same values, same arithmetic.  Null (HK_TRI_PACK=0): the separate arrays.
+    const float* tri_shade;
 };
 
 struct DTables {
@@ -309,13 +315,14 @@ struct DPathState {
     // only media rescale them per wavelength) — r_u is not stored, r_l is one float per record (the float4 array's memory, read as
     // float), and a shadow record carries its two MIS weights as one float2 in sh_ru.  Same arithmetic on the broadcast values.
     int compact;
+    int sh_final;          // 1 (opaque scenes without media): slim shadow records — sh_d.w holds the denominator average(w_u + w_l) of the contribution, the two weights are not stored (hk_kernels.hip: shadow_contribute_final)
 };
 
 struct DStats {
     unsigned long long rays_closest, rays_shadow, nodes, tris, hits, vertices, collisions, light_nodes, sh_nodes, sh_tris;
     unsigned long long nvdb_collisions, sh_nvdb_collisions;   // the part of collisions / sh_collisions counted while a scene with a NanoVDB medium was rendered
     unsigned long long sh_collisions, dda_steps, sh_dda_steps, scatter_vertices, sc_light_nodes;   // ratio-tracking collisions of the shadow walk; majorant cells entered (delta / ratio tracking); K5+K6 vertices
-#ifdef HK_DEBUG_UTIL   // lane-utilisation bookkeeping of the media state machines (debug builds only: scratch/util_debug.sh)
+#ifdef HK_DEBUG_UTIL   // lane-utilisation bookkeeping of the media state machines (debug builds only: tools/build_variant.sh dbg -DHK_DEBUG_UTIL)
     unsigned long long dbg[32];
 #endif
 };

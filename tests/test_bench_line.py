@@ -74,3 +74,17 @@ def test_emit_prints_one_line_the_driver_can_parse(tmp_path):
     assert parsed["metric"] == "Mrays/s" and parsed["detail"] == "bench_detail.json"
     full = json.loads(detail.read_text())
     assert full["rooflines"] == d["rooflines"] and len(full["configs"]) == 4
+
+
+def test_compact_line_carries_the_frame_check():
+    """round 6: bench.py looks at the film it timed (finite, mean ratio and same-sample parity against the oracle image of its CPU leg); the
+    verdict travels in the driver-visible line, and a failing configuration is marked there too."""
+    bench = _bench()
+    d = _round4_record()
+    d["frame_check"] = {"finite": True, "mean_weight_per_pixel": 378.9, "mean_rgb_sum": 398.03, "ok": True, "oracle_spp": 14, "rel_mse_vs_oracle_14spp": 0.066,
+                        "mean_ratio": 0.99976, "same_samples_rel_mse": 1.24e-09, "same_samples_frac_pixels_within_1e-2": 1.0, "tolerance": "x" * 300}
+    d["configs"][1]["frame_check"] = {"finite": False, "mean_rgb_sum": 0.0, "ok": False}
+    line = bench.compact_line(d)
+    assert len(json.dumps(line)) <= 3500
+    assert line["frame_check"]["ok"] is True and line["frame_check"]["mean_ratio"] == 0.99976 and "tolerance" not in line["frame_check"]
+    assert line["configs"][1]["frame_ok"] is False and "frame_ok" not in line["configs"][0]

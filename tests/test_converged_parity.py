@@ -34,12 +34,22 @@ def oracle_batches(hk, oracle, s, cam, w, h, kw, n_oracle=N_ORACLE, batches=BATC
     return frames
 
 
-def converged_pair(hk, oracle, s, cam, w, h, n_oracle=N_ORACLE, n_gpu=N_GPU, batches=BATCHES, key=None, **kw):
+def converged_pair(hk, oracle, s, cam, w, h, n_oracle=N_ORACLE, n_gpu=N_GPU, batches=BATCHES, key=None, gpu_batches=0, **kw):
+    """-> (oracle batch frames, device frame); with gpu_batches > 0 the device renders its n_gpu samples in that many batches too and the
+    second value is the stack of ITS batch frames (check_converged_two_sample)"""
     kw = dict(kw, samples=n_oracle + n_gpu)          # one ZSobol index width for both sides
     frames = oracle_batches(hk, oracle, s, cam, w, h, kw, n_oracle, batches, key)
     film = hk.Film((w, h))
     vp = hk.VolPath(**kw)
     vp._ensure(film)
+    if gpu_batches:
+        per, out = n_gpu // gpu_batches, []
+        for b in range(gpu_batches):
+            vp.clear()
+            vp.render_samples(s, film, cam, per, first=n_oracle + 1 + b * per)
+            out.append(film.framebuffer.copy())
+        vp.close()
+        return frames, np.stack(out)
     vp.clear()
     vp.render_samples(s, film, cam, n_gpu, first=n_oracle + 1)
     G = film.framebuffer.copy()
@@ -47,7 +57,43 @@ def converged_pair(hk, oracle, s, cam, w, h, n_oracle=N_ORACLE, n_gpu=N_GPU, bat
     return frames, G
 
 
-def check_converged(name, frames, G, n_oracle=N_ORACLE, n_gpu=N_GPU, mean_tol=0.005, robust=False):
+def two_sample_stats(FA, FB):
+    """(median z^2, fraction |z| > 6, lit pixels) over the lit pixel channels, z = (mean B - mean A) / sqrt(se_A^2 + se_B^2 + floor^2) with BOTH
+    standard errors from the batch scatter of their own side (tools/fuzz_null.py prints the same numbers for the oracle against itself)"""
+    A, B = FA.mean(axis=0), FB.mean(axis=0)
+    seA = FA.std(axis=0, ddof=1) / np.sqrt(FA.shape[0])
+    seB = FB.std(axis=0, ddof=1) / np.sqrt(FB.shape[0])
+    z = (B - A) / np.sqrt(seA ** 2 + seB ** 2 + (1e-4 * (A + 1e-3)) ** 2)
+    lit = (A.sum(axis=2) > 0) | (B.sum(axis=2) > 0)
+    if lit.sum() < 16:
+        return 0.0, 0.0, int(lit.sum())
+    return float(np.median((z ** 2)[lit])), float(np.mean(np.abs(z[lit]) > 6.0)), int(lit.sum())
+
+
+# Bounds of the two-sample comparison, set from the NULL (the oracle against itself, tools/fuzz_null.py, 48 random scenes of the three
+# statistical classes incl. `wild_scatter 10000`, the scene on which the one-sample bar of rounds 3-5 scored 16.2 % oracle-vs-oracle):
+# median z^2 0.26 .. 0.61 and ONCE 1.00 (that scene; a normal z gives 0.455), |z| > 6 on 0 .. 0.18 % of the lit channels (0 in 47 of 48).
+# A Welch z with >= 7 degrees of freedom exceeds 6 with probability 5e-4: more than 1 % of ~600 channels doing so has probability
+# << 1e-3 per scene even with the three channels of a pixel moving together; a device biased by two standard errors everywhere
+# scores a median near 4.
+TWO_SAMPLE_MEDIAN_Z2, TWO_SAMPLE_TAIL = 1.5, 0.01
+
+
+def check_converged_two_sample(name, FA, FG, mean_tol=0.01):
+    """Random scenes (point / spot lights through glass and mirrors, scattering media): both sides in batches, so a pixel's rare bright
+    paths widen ITS OWN side's standard error instead of showing up as a 6-sigma event against the other side's eight quiet batches."""
+    G, A = FG.mean(axis=0), FA.mean(axis=0)
+    assert np.isfinite(FG).all() and (FG >= 0).all()
+    for c in range(3):
+        se = np.sqrt(FA[..., c].mean(axis=(1, 2)).var(ddof=1) / FA.shape[0] + FG[..., c].mean(axis=(1, 2)).var(ddof=1) / FG.shape[0])
+        a, g = A[..., c].mean(), G[..., c].mean()
+        assert abs(g - a) <= mean_tol * a + 4.0 * se + 1e-6, (name, c, g, a, se)
+    med, tail, n_lit = two_sample_stats(FA, FG)
+    assert med <= TWO_SAMPLE_MEDIAN_Z2, (name, med, n_lit)
+    assert tail <= TWO_SAMPLE_TAIL, (name, tail, n_lit)
+
+
+def check_converged(name, frames, G, n_oracle=N_ORACLE, n_gpu=N_GPU, mean_tol=0.005):
     assert np.isfinite(G).all() and (G >= 0).all()
     batches = frames.shape[0]
     A = frames.mean(axis=0)
@@ -60,17 +106,6 @@ def check_converged(name, frames, G, n_oracle=N_ORACLE, n_gpu=N_GPU, mean_tol=0.
         assert abs(g - a) <= mean_tol * a + 4.0 * se_mean + 1e-6, (name, c, g, a, se_mean)
     z = (G - A) / np.sqrt(seA ** 2 * widen + (1e-4 * (A + 1e-3)) ** 2)
     # the variance estimate from B batches is itself noisy: E z^2 = (B - 1) / (B - 3) (15/13 at 16 batches, 7/5 at 8); bound = 1.56 x that
-    if robust:
-        # random scenes (point / spot lights through glass and mirrors): a pixel's batches may all miss a rare bright path that the other
-        # side's four-times-larger sample catches — the MEAN of z^2 is then one firefly.  The median of z^2 (0.51 for 8 batches, t_7^2)
-        # does not see fireflies and still moves to ~1.3 when every pixel is shifted by one standard error; tails: |z| > 6 on <= 15 %
-        # (measured: up to 9 % — forty small emitters seen through glass and a mirror, 64-sample batches — where the median and the
-        # channel means hold; a variance estimated from 8 batches that all missed the bright paths is simply too small there)
-        lit = A.sum(axis=2) > 0
-        if lit.sum() >= 16:
-            assert float(np.median((z ** 2)[lit])) <= 1.0, (name, float(np.median((z ** 2)[lit])))
-            assert float(np.mean(np.abs(z[lit]) > 6.0)) <= 0.15, (name, float(np.mean(np.abs(z[lit]) > 6.0)))
-        return
     z2_bound = 1.56 * (batches - 1.0) / (batches - 3.0)
     assert float(np.mean(z ** 2)) <= z2_bound, (name, float(np.mean(z ** 2)), z2_bound)
     assert float(np.mean(np.abs(z) > 6.0)) <= 0.005 * 16.0 / batches, (name, float(np.mean(np.abs(z) > 6.0)))

@@ -77,15 +77,17 @@ def test_fuzz_strict(hk, oracle, klass, seed, size):
 @pytest.mark.gpu
 @pytest.mark.parametrize("klass,seed", STATISTICAL)
 def test_fuzz_converged(hk, oracle, klass, seed):
-    """The statistical classes at the bar of tests/test_converged_parity.py, at reduced size: a 16 x 16 film, the oracle's 512 spp in 8
-    batches against 2 048 OTHER spp on the device — channel means within 1 % + 4 standard errors, per-pixel z-scores with the median
-    square of 8-batch variance estimates (fireflies make the mean useless here) and |z| > 6 on at most 15 % of the lit pixel channels.
-    (The 64-spp A / B-distance comparison that stood beside this one until round 4 could only ever be weaker on the same seeds: removed.)"""
-    from test_converged_parity import check_converged, converged_pair
+    """The statistical classes at a converged bar, at reduced size: a 16 x 16 film, the oracle's 512 spp in 8 batches against 2 048 OTHER
+    spp on the device, ALSO in 8 batches — channel means within 1 % + 4 standard errors, and per-pixel two-sample z-scores (each side's
+    standard error from its own batch scatter): median z^2 <= 1.5 and |z| > 6 on at most 1 % of the lit pixel channels.  Both bounds are
+    set from the null — the oracle against itself on 48 such scenes, tools/fuzz_null.py (test_converged_parity.TWO_SAMPLE_*) — where the
+    one-sample bar of rounds 3-5 (the variance of the oracle's eight batches alone, 15 % of the channels allowed beyond 6) failed the
+    oracle against itself on unseen seeds."""
+    from test_converged_parity import check_converged_two_sample, converged_pair
     s, film, cam, kw, desc = random_scene(hk, seed, klass, (16, 16))
     kw = {k: v for k, v in kw.items() if k != "samples"}
-    frames, G = converged_pair(hk, oracle, s, cam, 16, 16, n_oracle=512, n_gpu=2048, batches=8, **kw)
-    check_converged(desc, frames, G, n_oracle=512, n_gpu=2048, mean_tol=0.01, robust=True)
+    FA, FG = converged_pair(hk, oracle, s, cam, 16, 16, n_oracle=512, n_gpu=2048, batches=8, gpu_batches=8, **kw)
+    check_converged_two_sample(desc, FA, FG, mean_tol=0.01)
 
 
 def _material_palette(hk, seed, n_each):

@@ -869,34 +869,39 @@ def test_small_pass_in_one_launch(hk, knobs):
     assert int(run(s, cam, film, {}, [1])[1].fused_passes) == 1
 
 
-@pytest.mark.parametrize("eltype", ["Float32", "Float64"])
-def test_film_kernels_agree(hk, knobs, eltype):
-    """K12 in its two forms (round 6): k_film_lanes — one lane per pixel streams through that pixel's samples, colour-matching functions in
-    LDS — against k_film (HK_FILM_LANES=0: four lanes add a pixel's samples from LDS).  Both add a pixel's samples in sample order onto the
-    stored accumulators, so the films must agree bit for bit: pass sizes that are and are not multiples of 8 (the eight-at-a-time loop and
-    its one-by-one tail), a film whose size is no multiple of the 8 x 8 tiles (padding lanes), several passes on top of each other."""
+@pytest.mark.parametrize("which", ["cornell", "textured", "sky", "manylight", "mix"])
+def test_packed_triangle_records_are_result_neutral(hk, knobs, which):
+    """Round 6: the shade kernels read a triangle's positions / vertex normals / uvs / meta from ONE 128-byte record (DScene::tri_shade)
+    instead of four arrays.  Same values, same arithmetic: films bit-identical to HK_TRI_PACK=0 (the knob is read when the scene is
+    created, so each side builds its own scene) — meshes with and without vertex normals and uvs, textures (uv-dependent), the
+    many-light barrel (light selection reads the surface too), a Mix material (resolved from uv in the trace flush)."""
     from hikari_jl_amd import scenes
-    w, h = 43, 29
-    s, film, cam = scenes.cornell_box(w, h, light="area", objects="two_spheres")
-    knobs.setenv("HK_BATCH_PATHS_M", "0")              # every call is a pass of its own
+    w, h = 40, 32
 
-    def run(lanes, plan):
-        knobs.setenv("HK_FILM_LANES", lanes)
-        vp = hk.VolPath(max_depth=5, samples=256, accumulation_eltype=eltype)
-        vp._ensure(film)
-        vp.clear()
-        first = 1
-        for k in plan:
-            vp.render_samples(s, film, cam, k, first=first, readback=False)
-            first += k
+    def build():
+        if which == "cornell":
+            return scenes.cornell_box(w, h, light="all", objects="two_spheres") + (dict(max_depth=6, samples=16),)
+        if which == "textured":
+            return scenes.textured_scene(w, h) + (dict(max_depth=5, samples=16),)
+        if which == "sky":
+            return scenes.sky_scene(w, h, env_res=32) + (dict(max_depth=8, samples=16),)
+        if which == "manylight":
+            return scenes.many_light_scene(w, h, n_boxes=500, emissive_frac=0.25, box_scale=8.0) + (dict(max_depth=5, samples=16),)
+        from test_parity_holes import _mix_scene
+        return _mix_scene(hk, frame=True, w=w, h=h) + (dict(max_depth=6, samples=16),)
+
+    def run(pack):
+        knobs.setenv("HK_TRI_PACK", pack)            # (the default builds the records from 32 768 triangles up: these scenes are smaller)
+        s, film, cam, kw = build()
+        vp = hk.VolPath(**kw)
+        vp(s, film, cam)
         acc = vp.read_accumulators(film).copy()
+        st = vp.stats()
         vp.close()
-        return acc
+        return acc, (int(st.rays_closest), int(st.rays_shadow), int(st.path_vertices))
 
-    bits = np.uint32 if eltype == "Float32" else np.uint64
-    for plan in ([8], [64], [24, 40], [3], [13, 8, 1], [100], [256]):
-        a, b = run("0", plan), run("1", plan)
-        assert np.isfinite(a).all() and a[:3 * w * h].max() > 0
-        assert np.array_equal(a.view(bits), b.view(bits)), (plan, float(np.abs(a - b).max()))
-    knobs.delenv("HK_FILM_LANES")
-    knobs.delenv("HK_BATCH_PATHS_M")
+    a, ca = run("0")
+    b, cb = run("1")
+    assert np.isfinite(a).all() and a.max() > 0 and ca == cb, (ca, cb)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), float(np.abs(a - b).max())
+    knobs.delenv("HK_TRI_PACK")

@@ -84,7 +84,7 @@ static const char* const KNOB_NAMES[] = {
     "HK_MID_LISTS", "HK_MID_PASS_PATHS_M", "HK_NODE_CACHE", "HK_NVDB_DENSE_MB", "HK_OVERLAP", "HK_PIPELINE", "HK_PIPELINE_AFTER", "HK_PIPELINE_MAX_PATHS_M", "HK_PRESELECT",
     "HK_SELECT_MIN_IDLE", "HK_SHADOW_FEED_ROUNDS", "HK_SHADOW_TRACK_BATCH", "HK_SMALL_PASS", "HK_SMALL_PASS_WAVES", "HK_SOBOL_LO_GB", "HK_SOBOL_TABLE_ONLY",
     "HK_STATE_CACHE_GB", "HK_STATE_SLAB", "HK_TICKET_SHARE", "HK_TRACK_ADVANCE", "HK_TRACK_EXTRA_ADVANCE", "HK_TRACK_MIN_PENDING", "HK_TRACK_POOL", "HK_TRACK_REFILL_IDLE",
-    "HK_WALK_POOL", "HK_WALK_REFILL_IDLE", "HK_WALK_SPLIT", "HK_WAVES_PER_CU", "HK_READBACK_PIN", "HK_DEFER_EXTERNAL", "HK_SELECT_POOL", "HK_SMALL_PASS_FUSED", "HK_SMALL_PASS_MERGED", "HK_OCC_SCALE", "HK_ESCAPED_UNROLL", "HK_SHADOW_FINAL", "HK_TRI_PACK"};
+    "HK_WALK_POOL", "HK_WALK_REFILL_IDLE", "HK_WALK_SPLIT", "HK_WAVES_PER_CU", "HK_READBACK_PIN", "HK_DEFER_EXTERNAL", "HK_SELECT_POOL", "HK_SMALL_PASS_FUSED", "HK_SMALL_PASS_MERGED", "HK_OCC_SCALE", "HK_ESCAPED_UNROLL", "HK_SHADOW_FINAL", "HK_TRI_PACK", "HK_LEAN_RECORDS"};
 static bool known_knob(const char* name) {
     for (const char* k : KNOB_NAMES)
         if (std::strcmp(k, name) == 0) return true;
@@ -1670,6 +1670,10 @@ int ensure_state(hk_integrator* I, int capacity, bool media, bool open_scene, bo
     {   // slim shadow records (HK_SHADOW_FINAL=0: the 60-byte records of rounds 3-5; A/B switch, films bit-identical)
         const char* e = hk::knob("HK_SHADOW_FINAL");
         I->st.sh_final = (!media && opaque_surfaces && !(e && std::atoi(e) == 0)) ? 1 : 0;   // (k_shadow's scenes: no medium, no alpha-tested surface)
+        // lean generation records of the same scenes (HK_LEAN_RECORDS=0: 8-byte meta words, depth-0 origins stored; A/B switch, films bit-identical)
+        const char* l = hk::knob("HK_LEAN_RECORDS");
+        I->st.meta32 = (!media && opaque_surfaces && !(l && std::atoi(l) == 0)) ? 1 : 0;
+        I->st.const_origin = 0;   // (per call: render_tile_now knows the camera)
     }
     I->st.ticket_share = 1;
     if (const char* e = hk::knob("HK_TICKET_SHARE")) I->st.ticket_share = std::atoi(e) ? 1 : 0;
@@ -1986,6 +1990,7 @@ static int render_tile_now(hk_ctx* c, hk_scene* sc, hk_integrator* I, hk_film* f
                           !piped && !c->time_kernels && !c->count_nodes && n_samples < 16 && hk::small_pass_fusable(sc->d, sc->kinds_mask),
                           sc->d.all_opaque != 0 && sc->d.n_media == 0);
     if (st != HK_OK) return st;
+    I->st.const_origin = (I->st.meta32 && !(cam->lens_radius > 0)) ? 1 : 0;   // a pinhole camera: generate_ray gives every path the same origin (hk_device.h), stored once per segment
     fr.sample_stride = sample_stride;
     fr.max_depth = I->p.max_depth;
     fr.regularize = I->p.regularize;

@@ -207,23 +207,24 @@ __device__ __forceinline__ void wq_push(WaveQ& q, uint32_t value, bool active) {
 __device__ __forceinline__ S4 ld_throughput(const float4* arr, size_t p, bool ones) { return ones ? s4(1.0f) : ld4(&arr[p]); }
 // r_u / r_l of generation entry p and the MIS weights of a shadow record, in either representation (DPathState::compact)
 __device__ __forceinline__ S4 ld_ru(const DPathGen& g, size_t p, bool ones, bool compact) { return (ones || compact) ? s4(1.0f) : ld4(&g.r_u[p]); }
+// (compact: r_l is one float and lives in the fourth word of the record's ray_d — the reference's ray.time, which this path never reads)
 __device__ __forceinline__ S4 ld_rl(const DPathGen& g, size_t p, bool ones, bool compact) {
     if (ones) return s4(1.0f);
-    if (compact) return s4(reinterpret_cast<const float*>(g.r_l)[p]);
+    if (compact) return s4(reinterpret_cast<const float*>(g.ray_d)[4 * p + 3]);
     return ld4(&g.r_l[p]);
 }
+// r_u / r_l of a record whose ray_d has ALREADY been stored with r_l.x in its fourth word when `compact` (the writers do that themselves)
 __device__ __forceinline__ void st_ru_rl(const DPathGen& g, size_t p, S4 r_u, S4 r_l, bool compact) {
-    if (compact)
-        reinterpret_cast<float*>(g.r_l)[p] = r_l.x;
-    else {
+    if (!compact) {
         st4(&g.r_u[p], r_u);
         st4(&g.r_l[p], r_l);
     }
 }
 __device__ __forceinline__ void mul_rl(const DPathGen& g, size_t p, bool ones, float f, bool compact) {   // r_l[p] *= f
-    if (compact)
-        reinterpret_cast<float*>(g.r_l)[p] = (ones ? 1.0f : reinterpret_cast<const float*>(g.r_l)[p]) * f;
-    else
+    if (compact) {
+        float* w = reinterpret_cast<float*>(g.ray_d) + 4 * p + 3;
+        *w = (ones ? 1.0f : *w) * f;
+    } else
         st4(&g.r_l[p], ld_throughput(g.r_l, p, ones) * f);
 }
 __device__ __forceinline__ void st_shadow_weights(const DPathState& st, size_t rec, S4 ru, S4 rl) {
@@ -307,6 +308,25 @@ __device__ __forceinline__ void st_lambda(const DPathGen& g, size_t p, S4 lambda
 #if !HK_LAMBDA_BY_SLOT
     stream_st(&g.lambda[p], lambda);
 #endif
+}
+// lean generation records (DPathState::meta32 / const_origin): the record's meta word(s) and origin through one pair of accessors
+__device__ __forceinline__ uint2 ld_meta(const DPathState& st, const DPathGen& g, size_t p, int depth) {
+    if (st.meta32) {
+        const uint32_t w = reinterpret_cast<const uint32_t*>(g.meta)[p];
+        return make_uint2((uint32_t)depth | (((w >> 30) & 1u) << 8) | ((w >> 31) << 9), w & 0x3fffffffu);
+    }
+    return g.meta[p];
+}
+__device__ __forceinline__ void st_meta(const DPathState& st, const DPathGen& g, size_t p, uint32_t flags, uint32_t slot) {
+    if (st.meta32)
+        stream_st(reinterpret_cast<uint32_t*>(g.meta) + p, slot | (((flags >> 8) & 1u) << 30) | (((flags >> 9) & 1u) << 31));
+    else
+        stream_st(&g.meta[p], make_uint2(flags, slot));
+}
+// const_origin: generation 0 keeps ONE origin per segment, at the segment's first entry `seg` (k_camera's lane with position 0 writes it),
+// and every depth-0 reader of that segment loads that entry — one hot line instead of 16 B per path; no branch, no arithmetic repeated
+__device__ __forceinline__ float4 ld_ray_o(const DPathState& st, const DPathGen& g, size_t p, int depth, size_t seg) {
+    return stream_ld(&g.ray_o[(depth == 0 && st.const_origin) ? seg : p]);
 }
 // dense append of a whole record: the position the pushing lanes get inside the segment (count + rank among the pushing lanes)
 struct WavePos {
@@ -504,16 +524,17 @@ __device__ __forceinline__ void camera_body(const DPathState& st, const DFrame& 
             v3 ro, rd;
             float time;
             generate_ray(cam, pfilm, lens, time_u, ro, rd, time);
-            stream_st(&g0.ray_o[p], make_float4(ro.x, ro.y, ro.z, INF_F));
-            stream_st(&g0.ray_d[p], make_float4(rd.x, rd.y, rd.z, 0.0f));
-            st_lambda(g0, p, lambda);
+            if (!st.const_origin || p == seg) stream_st(&g0.ray_o[p], make_float4(ro.x, ro.y, ro.z, INF_F));   // (a pinhole camera's rays all start at one point: ld_ray_o)
             // beta = r_u = r_l = 1 at depth 0 (volpath.jl:190-197): in scenes without media nothing changes them before the first
-            // shading event, so they are not stored and the depth-0 readers substitute the constant (ld_throughput)
+            // shading event, so they are not stored and the depth-0 readers substitute the constant (ld_throughput); the compact
+            // records of a grey medium keep r_l = 1 beside the direction
+            stream_st(&g0.ray_d[p], make_float4(rd.x, rd.y, rd.z, (st.compact && !fr.implicit_ones) ? 1.0f : 0.0f));
+            st_lambda(g0, p, lambda);
             if (!fr.implicit_ones) {
                 st4(&g0.beta[p], s4(1.0f));
                 st_ru_rl(g0, p, s4(1.0f), s4(1.0f), st.compact != 0);
             }
-            stream_st(&g0.meta[p], make_uint2((uint32_t)(*st.initial_medium + 1) << 16, (uint32_t)slot));
+            st_meta(st, g0, p, (uint32_t)(*st.initial_medium + 1) << 16, (uint32_t)slot);
             stream_st(&st.lambda_s[slot], lambda);
             stream_st(&st.L[slot], s4(0.0f));
             stream_st(&st.filter_w[slot], fw);
@@ -972,7 +993,7 @@ __device__ __forceinline__ void trace_lean_body(const DPathState& st, const DSce
             const int rank = __popcll(want & lt_mask);
             if (state == LR_EMPTY && rank < avail) {
                 slot = seg + (uint32_t)(cursor + rank);
-                float4 O = stream_ld(&g.ray_o[slot]), D = stream_ld(&g.ray_d[slot]);
+                float4 O = ld_ray_o(st, g, slot, depth, seg), D = stream_ld(&g.ray_d[slot]);
                 ++n_casts;
                 lane_ray_start<QN>(r, sc, mk3(O.x, O.y, O.z), mk3(D.x, D.y, D.z), O.w);
                 state = LR_ACTIVE;
@@ -2090,6 +2111,7 @@ __global__ void __launch_bounds__(256) k_scatter(DPathState st, DScene sc, DTabl
             const size_t pn = seg + (size_t)wp_push(q_next, push_ray);
             if (push_ray) {   // the continuing path's record, whole, at its position in the next generation
                 gn.ray_o[pn] = O;
+                if (st.compact) nD.w = n_rl.x;
                 gn.ray_d[pn] = nD;
                 st4(&gn.beta[pn], beta);
                 st_ru_rl(gn, pn, r_u, n_rl, st.compact != 0);
@@ -2137,8 +2159,8 @@ __global__ void __launch_bounds__(64) k_detect_camera_medium(DPathState st, DSce
 // K7: escaped rays (intersection.jl:622-678; lights.jl:408-467).  MIS uses 1/num_lights (Q6).
 // ---------------------------------------------------------------------------------------------------
 // one escaped path: what it adds to its L (false: nothing)
-__device__ __forceinline__ bool escaped_one(const DPathState& st, const DScene& sc, const DTables& T, const DPathGen& g, bool ones, uint32_t slot, S4& fin, uint32_t& pslot) {
-    const uint2 meta = g.meta[slot];
+__device__ __forceinline__ bool escaped_one(const DPathState& st, const DScene& sc, const DTables& T, const DPathGen& g, bool ones, uint32_t slot, S4& fin, uint32_t& pslot, int depth) {
+    const uint2 meta = ld_meta(st, g, slot, depth);
     pslot = meta.y;
     S4 lambda = ld_lambda(st, g, slot, meta.y);
     S4 Le = s4(0.0f);
@@ -2196,8 +2218,8 @@ __device__ __forceinline__ void escaped_body(const DPathState& st, const DScene&
             const uint32_t slot0 = queue[i], slot1 = queue[i + 64];
             S4 fin0, fin1;
             uint32_t p0, p1;
-            const bool a0 = escaped_one(st, sc, T, g, ones, slot0, fin0, p0);
-            const bool a1 = escaped_one(st, sc, T, g, ones, slot1, fin1, p1);
+            const bool a0 = escaped_one(st, sc, T, g, ones, slot0, fin0, p0, depth);
+            const bool a1 = escaped_one(st, sc, T, g, ones, slot1, fin1, p1, depth);
             S4 L0 = s4(0.0f), L1 = s4(0.0f);
             if (a0) L0 = ld4(&st.L[p0]);
             if (a1) L1 = ld4(&st.L[p1]);
@@ -2208,7 +2230,7 @@ __device__ __forceinline__ void escaped_body(const DPathState& st, const DScene&
     for (; i < n; i += 64) {
         S4 fin;
         uint32_t pslot;
-        if (escaped_one(st, sc, T, g, ones, queue[i], fin, pslot)) st4(&st.L[pslot], ld4(&st.L[pslot]) + fin);
+        if (escaped_one(st, sc, T, g, ones, queue[i], fin, pslot, depth)) st4(&st.L[pslot], ld4(&st.L[pslot]) + fin);
     }
     }
 }
@@ -2280,12 +2302,12 @@ __global__ void __launch_bounds__(256) k_light_select(DPathState st, DScene sc, 
                 const int rank = __popcll(want & lt_mask);
                 if (!busy && rank < avail) {
                     slot = queue[cursor + rank];
-                    const float4 H = st.hit[slot], O = g.ray_o[slot], D = g.ray_d[slot];
+                    const float4 H = st.hit[slot], O = ld_ray_o(st, g, slot, depth, (size_t)gw * st.wave_cap), D = g.ray_d[slot];
                     const Surface sf = surface_at(sc, __float_as_int(H.y), H.z, H.w, mk3(O.x, O.y, O.z), mk3(D.x, D.y, D.z), H.x);
                     p = sf.pi;
                     nn = sf.ns;
                     int pix, k;
-                    split_slot(fr, g.meta[slot].y, pix, k);
+                    split_slot(fr, ld_meta(st, g, slot, depth).y, pix, k);
                     const SobolCtx sctx = sobol_ctx_slot(sob, T.sobol, fr.x0, fr.y0, fr.tiles_x, pix, k, fr.first_sample + k * fr.sample_stride);
                     const float u = sobol_1d<FT>(sctx, base_dim + 1);
                     // bvh_sample_light's prologue: the infinite lights, then the root
@@ -2464,12 +2486,12 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(BLOCK, BLOCK), amdgpu
                     v3 sp = mk3(0, 0, 0), sn = mk3(0, 0, 1);
                     if (lane < take) {
                         e = queue[cursor + lane];
-                        const float4 H = st.hit[e], O = g.ray_o[e], D = g.ray_d[e];
+                        const float4 H = st.hit[e], O = ld_ray_o(st, g, e, depth, (size_t)gw * st.wave_cap), D = g.ray_d[e];
                         const Surface sf = surface_at(sc, __float_as_int(H.y), H.z, H.w, mk3(O.x, O.y, O.z), mk3(D.x, D.y, D.z), H.x);
                         sp = sf.pi;
                         sn = sf.ns;
                         int pix, k;
-                        split_slot(fr, g.meta[e].y, pix, k);
+                        split_slot(fr, ld_meta(st, g, e, depth).y, pix, k);
                         const SobolCtx sctx = sobol_ctx_slot(sob, T.sobol, fr.x0, fr.y0, fr.tiles_x, pix, k, fr.first_sample + k * fr.sample_stride);
                         const float u = sobol_1d<FT>(sctx, base_dim + 1);
                         // bvh_sample_light's prologue: the infinite lights, then the root
@@ -2582,9 +2604,9 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(BLOCK, BLOCK), amdgpu
 #endif
 // K8 for one flagged vertex (surface-eval.jl:147-220): L += beta * Le / MIS denominator.
 template <bool TWO_PLANES, bool SIMPLE>
-HKD void shade_emission(const DPathState& st, const DPathGen& g, bool ones, const DScene& sc, const DTables& T, uint32_t slot, unsigned& n_lnodes) {
+HKD void shade_emission(const DPathState& st, const DPathGen& g, bool ones, const DScene& sc, const DTables& T, uint32_t slot, unsigned& n_lnodes, int depth, size_t seg) {
     const float4 H = st.hit[slot];
-    const float4 O = g.ray_o[slot], D = g.ray_d[slot];
+    const float4 O = ld_ray_o(st, g, slot, depth, seg), D = g.ray_d[slot];
     const v3 ro = mk3(O.x, O.y, O.z), rd = mk3(D.x, D.y, D.z);
     const float t_hit = H.x;
     const int prim = __float_as_int(H.y);
@@ -2592,7 +2614,7 @@ HKD void shade_emission(const DPathState& st, const DPathGen& g, bool ones, cons
     if (meta.arealight <= 0) return;
     const Surface sf = surface_at(sc, prim, H.z, H.w, ro, rd, t_hit);
     const v3 wo = -rd;
-    const uint2 pmeta = g.meta[slot];
+    const uint2 pmeta = ld_meta(st, g, slot, depth);
     const S4 lambda = ld_lambda(st, g, slot, pmeta.y);
     const DLight& light = sc.lights[meta.arealight - 1];
     S4 Le = arealight_Le<TWO_PLANES, SIMPLE>(sc, T, light, wo, sf.n, sf.uv, lambda);
@@ -2667,7 +2689,7 @@ __device__ __forceinline__ void shade_body(const DPathState& st, const DScene& s
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             const int take = n_emit < 64 ? n_emit : 64;
-            if (lane < take) shade_emission<KIND == HK_MAT_MATTE, SIMPLE>(st, g, ones, sc, T, elist[lane], n_lnodes);
+            if (lane < take) shade_emission<KIND == HK_MAT_MATTE, SIMPLE>(st, g, ones, sc, T, elist[lane], n_lnodes, depth, seg);
             const int rest = n_emit - take;
             const uint32_t moved = lane < rest ? elist[64 + lane] : 0u;
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -2698,14 +2720,14 @@ __device__ __forceinline__ void shade_body(const DPathState& st, const DScene& s
         if (active) {
             ++n_vertices;
             H = stream_ld(&st.hit[slot]);
-            float4 O = stream_ld(&g.ray_o[slot]), D = stream_ld(&g.ray_d[slot]);
+            float4 O = ld_ray_o(st, g, slot, depth, seg), D = stream_ld(&g.ray_d[slot]);
             v3 ro = mk3(O.x, O.y, O.z), rd = mk3(D.x, D.y, D.z);
             float t_hit = H.x;
             int prim = __float_as_int(H.y);
             sf = surface_at(sc, prim, H.z, H.w, ro, rd, t_hit);
             wo = -rd;
             meta = tri_meta(sc, prim);
-            const uint2 pmeta = g.meta[slot];
+            const uint2 pmeta = ld_meta(st, g, slot, depth);
             lambda = ld_lambda(st, g, slot, pmeta.y);
             if (ones)
                 beta = s4(1.0f);
@@ -2892,14 +2914,12 @@ __device__ __forceinline__ void shade_body(const DPathState& st, const DScene& s
             const size_t pn = seg + (size_t)wp_push(q_next, push_ray);
             if (push_ray) {
                 stream_st(&gn.ray_o[pn], nO);
+                if (st.compact) nD.w = nrl.x;   // (compact: r_l travels beside the direction)
                 stream_st(&gn.ray_d[pn], nD);
                 stream_st(&gn.beta[pn], nb);
-                if (st.compact)
-                    stream_st(reinterpret_cast<float*>(gn.r_l) + pn, nrl.x);
-                else
-                    st_ru_rl(gn, pn, r_u, nrl, false);
+                st_ru_rl(gn, pn, r_u, nrl, st.compact != 0);
                 st_lambda(gn, pn, lambda);
-                stream_st(&gn.meta[pn], make_uint2(nflags, pslot));
+                st_meta(st, gn, pn, nflags, pslot);
             }
         }
     }

@@ -267,7 +267,7 @@ struct DPathGen {
     float4* r_u;
     float4* r_l;
     float4* lambda;
-    uint2* meta;           // x = flags: depth(8) | specular(1)<<8 | any_non_specular(1)<<9 | (medium+1)<<16;  y = path slot
+    uint2* meta;           // x = flags: depth(8) | specular(1)<<8 | any_non_specular(1)<<9 | (medium+1)<<16;  y = path slot   (DPathState::meta32: one uint32 per record, see there)
 };
 
 struct DPathState {
@@ -315,6 +315,13 @@ struct DPathState {
     // only media rescale them per wavelength) — r_u is not stored, r_l is one float per record (the float4 array's memory, read as
     // float), and a shadow record carries its two MIS weights as one float2 in sh_ru.  Same arithmetic on the broadcast values.
     int compact;
+    // LEAN GENERATION RECORDS (round 6; opaque scenes without media, HK_LEAN_RECORDS=0: off).  meta32: a record's meta word is ONE uint32 — the path
+    // slot (< 2^30) with the specular / any-non-specular flags in its two top bits; the depth is the kernel's own `depth` and there is no
+    // medium (4 B instead of 8 per record written and read).  const_origin (pinhole camera): every camera ray starts at the same point, so
+    // generation 0 stores ONE ray_o per segment (its first entry) that every depth-0 reader of the segment loads (16 B less per path written by
+    // k_camera and fetched by the depth-0 traversal and shading).  Independently of both, the COMPACT layouts keep r_l — one float — in the
+    // unused fourth word of ray_d instead of an array of its own.
+    int meta32, const_origin;
     int sh_final;          // 1 (opaque scenes without media): slim shadow records — sh_d.w holds the denominator average(w_u + w_l) of the contribution, the two weights are not stored (hk_kernels.hip: shadow_contribute_final)
 };
 

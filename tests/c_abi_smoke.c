@@ -38,6 +38,8 @@ typedef int32_t (*hk_ctx_get_option_t)(hk_ctx*, const char*, char*, int32_t);
 typedef int32_t (*hk_flush_t)(hk_ctx*);
 typedef int32_t (*hk_film_read_rgb_async_t)(hk_ctx*, hk_film*);
 typedef int32_t (*hk_film_read_wait_t)(hk_ctx*, hk_film*, float*, const float**);
+typedef int32_t (*hk_film_pin_host_t)(hk_film*, float*);
+typedef int32_t (*hk_film_unpin_host_t)(hk_film*);
 
 static void* slurp(const char* dir, const char* name, size_t want_bytes) {
     char path[1024];
@@ -82,6 +84,7 @@ int main(int argc, char** argv) {
     LOAD(hk_integrator_create) LOAD(hk_integrator_destroy) LOAD(hk_film_create) LOAD(hk_film_destroy) LOAD(hk_film_clear) LOAD(hk_render)
     LOAD(hk_film_read_rgb) LOAD(hk_film_read_accum) LOAD(hk_stats_get)
     LOAD(hk_ctx_set_option) LOAD(hk_ctx_get_option) LOAD(hk_flush) LOAD(hk_film_read_rgb_async) LOAD(hk_film_read_wait)
+    LOAD(hk_film_pin_host) LOAD(hk_film_unpin_host)
 
     hk_ctx* ctx = NULL;
     if (hk_ctx_create_p(0, NULL, &ctx) != HK_OK) {
@@ -187,7 +190,8 @@ int main(int argc, char** argv) {
     {
         char buf[16];
         if (hk_ctx_set_option_p(ctx, "HK_BATCH_PATHS_M", "0") != HK_OK || hk_ctx_get_option_p(ctx, "HK_BATCH_PATHS_M", buf, 16) != 1 || buf[0] != '0') return 1;
-        if (hk_ctx_set_option_p(ctx, "HK_BATCH_PATHS_M", NULL) != HK_OK || hk_ctx_get_option_p(ctx, "HK_BATCH_PATHS_M", buf, 16) != -1) return 1;
+        if (hk_ctx_set_option_p(ctx, "HK_BATCH_PATHS_M", NULL) != HK_OK || hk_ctx_get_option_p(ctx, "HK_BATCH_PATHS_M", buf, 16) != HK_UNSET || buf[0] != 0) return 1;   /* no value: HK_UNSET, not an error code */
+        if (hk_ctx_get_option_p(ctx, "HK_NOT_A_KNOB", buf, 16) != HK_ERR_INVALID) return 1;
         if (hk_ctx_set_option_p(ctx, "HK_NOT_A_KNOB", "1") != HK_ERR_INVALID) return 1;
     }
     /* the interactive loop of a viewer: one more sample per call, the frame of call i - 1 collected while call i renders; the last frame
@@ -204,6 +208,17 @@ int main(int argc, char** argv) {
         if (hk_film_read_rgb_p(ctx, film, rgb2) != HK_OK || memcmp(frame, rgb2, (size_t)W * H * 3 * 4) != 0) {
             fprintf(stderr, "asynchronous and synchronous frame differ\n");
             return 1;
+        }
+        /* a viewer's ONE frame buffer, named to the library: the frame is copied straight into it (no staging memcpy); a malloc / free per
+           frame WITHOUT naming the buffer must be just as safe — the library registers nothing on its own */
+        float* pinned = (float*)malloc((size_t)W * H * 3 * 4);
+        if (hk_film_pin_host_p(film, pinned) != HK_OK || hk_film_read_rgb_p(ctx, film, pinned) != HK_OK || memcmp(pinned, rgb2, (size_t)W * H * 3 * 4) != 0) return 1;
+        if (hk_film_read_rgb_p(ctx, film, pinned) != HK_OK || hk_film_unpin_host_p(film) != HK_OK) return 1;
+        free(pinned);
+        for (int i = 0; i < 3; ++i) {
+            float* tmp = (float*)malloc((size_t)W * H * 3 * 4);
+            if (hk_film_read_rgb_p(ctx, film, tmp) != HK_OK || memcmp(tmp, rgb2, (size_t)W * H * 3 * 4) != 0) return 1;
+            free(tmp);
         }
         free(rgb2);
     }

@@ -536,7 +536,7 @@ class SceneNP:
         self.mi = np.array([desc.meta[i].medium_interface_idx for i in range(T)], np.int64)
         self.arealight = np.array([desc.meta[i].arealight_flat_idx_1based for i in range(T)], np.int64)
         mats = [desc.materials[i] for i in range(desc.n_materials)]
-        assert all(m.kind in (0, 1, 2, 3, 5, 6, 8) for m in mats), "Matte, Mirror, Glass, Conductor, ThinDielectric, DiffuseTransmission, CoatedConductor only"
+        assert all(m.kind in (0, 1, 2, 3, 4, 5, 6, 7, 8) for m in mats), "Matte, Mirror, Glass, Conductor, CoatedDiffuse, ThinDielectric, DiffuseTransmission, CoatedDiffuseTransmission, CoatedConductor only"
         # parameters that may be TEXTURES (eval_tex, textures/texture-ref.jl:40-80, 222-243): Matte Kd and sigma, Mirror Kr, Glass Kr / Kt,
         # Conductor roughness — an image (bilinear at the hit's uv) or a VertexColorTexture (the face's three colours by the hit's barycentrics);
         # everything else must be constant
@@ -609,6 +609,20 @@ class SceneNP:
             self.cc[i] = dict(use_eta_k=bool(m.flags & 2), eta=[f32(m.rgb[0].c[k]) for k in range(3)], k=[f32(m.rgb[1].c[k]) for k in range(3)],
                               refl=[f32(m.rgb[2].c[k]) for k in range(3)], albedo=[f32(m.rgb[3].c[k]) for k in range(3)],
                               iax=al(m.f[0].v), iay=al(m.f[1].v), ieta=f32(m.f[2].v), cax=al(m.f[3].v), cay=al(m.f[4].v), thickness=f32(m.f[5].v))
+        # CoatedDiffuse (kind 4) and CoatedDiffuseTransmission (kind 7): LayeredBxDF random walks (spectral-eval.jl:1232-1940, 2341-2840) — stochastic,
+        # their PCG32 seeded from the float bits of wo / wi / the samples, so per pixel they agree with another implementation only while those
+        # bits agree; constant parameters; evaluated per hit by ref_layered_np (round 6: the walks INSIDE the wavefront loop)
+        self.cd = {}
+        for i, m in enumerate(mats):
+            if m.kind not in (4, 7):
+                continue
+            n_rgb = 2 if m.kind == 4 else 3
+            assert all(m.rgb[k].tex < 0 for k in range(n_rgb)) and all(m.f[k].tex < 0 for k in range(5))
+            remap = bool(m.flags & 1)
+            al = (lambda r: f32(np.sqrt(f32(r)))) if remap else (lambda r: f32(r))
+            rgb = lambda k: [f32(m.rgb[k].c[j]) for j in range(3)]
+            self.cd[i] = dict(kind=int(m.kind), refl=rgb(0), trans=rgb(1) if m.kind == 7 else None, albedo=rgb(1) if m.kind == 4 else rgb(2),
+                              ax=al(m.f[0].v), ay=al(m.f[1].v), thickness=f32(m.f[2].v), eta=f32(m.f[3].v), g=f32(m.f[4].v), max_depth=int(m.i[0]), n_samples=int(m.i[1]))
         self._rest(desc, tables)
 
     def coated_conductor(self, mat, lam):
@@ -625,6 +639,21 @@ class SceneNP:
             ck = (f32(2) * np.sqrt(r) / np.sqrt(np.maximum(f32(1) - r, f32(0)) + f32(1e-6))).astype(f32)
         alb = c["albedo"]
         return LN.CoatedCond(c["ieta"], c["iax"], c["iay"], c["cax"], c["cay"], ce, ck, c["thickness"], up(alb), any(x != 0 for x in alb))
+
+    def coated_diffuse(self, mat, lam):
+        """the ref_layered_np.Coated parameters of material `mat` (CoatedDiffuse / CoatedDiffuseTransmission) at the wavelengths lam [4]"""
+        import ref_layered_np as LN
+        c = self.cd[int(mat)]
+        up = lambda rgb: eval_poly(F(self.tables.rgb_to_poly([float(x) for x in rgb]))[None], F(lam)[None])[0]
+        alb = c["albedo"]
+        has_medium = any(x != 0 for x in alb)
+        if c["kind"] == 7:      # reflectance / transmittance clamped to [0, 1]; the base's lobe chosen by their largest components (spectral-eval.jl:2341-2390)
+            rr = [min(max(x, f32(0)), f32(1)) for x in c["refl"]]
+            tt = [min(max(x, f32(0)), f32(1)) for x in c["trans"]]
+            refl, trans = up(rr), up(tt)
+            return LN.Coated(refl, up(alb), has_medium, c["ax"], c["ay"], c["eta"], c["thickness"], c["g"], c["max_depth"], c["n_samples"],
+                             bottom=LN.DiffuseTransmissionBottom(refl, trans, max(rr), max(tt)))
+        return LN.Coated(up(c["refl"]), up(alb), has_medium, c["ax"], c["ay"], c["eta"], c["thickness"], c["g"], c["max_depth"], c["n_samples"])
 
     def tex_bilinear(self, ti, uv):
         """_sample_texture_bilinear (textures/texture-ref.jl:151-186) of image ti at uv [N, 2] -> [N, channels]: the (1 - v, u) flip, pixel
@@ -1901,8 +1930,10 @@ def sample_light_np(sc, li, pi, lm, d_u0, d_u1):
 
 
 def render(desc, cam_rec, tables_dict, width, height, n_samples, max_depth, max_component_value=10.0, filter_radius=(0.5, 0.5), first=1, sobol_spp=None,
-           regularize=True, scene=None):
-    """-> framebuffer [height, width, 3] (row py - 1, column px - 1), the weighted sums and the weights"""
+           regularize=True, scene=None, hits32=False):
+    """-> framebuffer [height, width, 3] (row py - 1, column px - 1), the weighted sums and the weights.
+    hits32: closest hits in binary32, operation for operation as DESIGN.md section 3 defines them (SceneNP.intersect32) instead of float64 — for scenes
+    in which a later decision HASHES bits that descend from the hit (the layered walks seed their PCG32 from wo in the shading frame)."""
     tb = Tables(tables_dict)
     sc = scene if scene is not None else SceneNP(desc, tb)
     zs = ZSobol(tb.sobol, width, height, max(sobol_spp or n_samples, 4096), 0)
@@ -1947,7 +1978,7 @@ def render(desc, cam_rec, tables_dict, width, height, n_samples, max_depth, max_
             i_u0, i_u1 = zs.d2(apx, apy, sidx, base + 6)
             i_rr = zs.d1(apx, apy, sidx, base + 7)
             o, dd = ro[A], rd[A]
-            hit, prim, t, bu, bv = sc.intersect(o, dd, np.full(len(A), np.inf))
+            hit, prim, t, bu, bv = (sc.intersect32 if hits32 else sc.intersect)(o, dd, np.full(len(A), np.inf))
             esc, surf = ~hit, hit
             pending = []                                             # shadow rays of this depth's SCATTERING vertices (traced with the surfaces' below)
             if has_media and (med[A] >= 0).any():
@@ -2073,6 +2104,14 @@ def render(desc, cam_rec, tables_dict, width, height, n_samples, max_depth, max_
                 for j in np.nonzero(is_cc)[0]:
                     cc_par[j] = sc.coated_conductor(mat[j], lm[j])
                     f_j, p_j = LN.cc_eval(cc_par[j], wo[j], wi[j], ns[j])
+                    f[j], bs_pdf[j] = f_j, p_j
+            is_cd = (kind == 4) | (kind == 7)
+            cd_par = {}
+            if is_cd.any():                                                      # CoatedDiffuse / CoatedDiffuseTransmission: the stochastic evaluate of ref_layered_np per hit
+                import ref_layered_np as LN
+                for j in np.nonzero(is_cd)[0]:
+                    cd_par[j] = sc.coated_diffuse(mat[j], lm[j])
+                    f_j, p_j = LN.coated_eval(cd_par[j], wo[j], wi[j], ns[j])
                     f[j], bs_pdf[j] = f_j, p_j
             is_cond = kind == 3
             if is_cond.any():                                                    # a Conductor: the rough lobe evaluates, the smooth one is zero (spectral-eval.jl:415-486)
@@ -2201,6 +2240,14 @@ def render(desc, cam_rec, tables_dict, width, height, n_samples, max_depth, max_
             if is_cc.any():
                 for j in np.nonzero(is_cc)[0]:
                     got = LN.cc_sample(cc_par[j], wo[j], ns[j], (i_u0[j], i_u1[j]), i_uc[j], bool(anyns[A][j]) and bool(regularize))
+                    if got is None:
+                        valid[j], pdf2[j] = False, f32(0)
+                        continue
+                    wi2[j], f2[j], pdf2[j], is_spec[j] = got[0], got[1], got[2], got[3]
+                    valid[j] = True
+            if is_cd.any():
+                for j in np.nonzero(is_cd)[0]:
+                    got = LN.coated_sample(cd_par[j], wo[j], ns[j], (i_u0[j], i_u1[j]), i_uc[j], bool(anyns[A][j]) and bool(regularize))
                     if got is None:
                         valid[j], pdf2[j] = False, f32(0)
                         continue

@@ -54,7 +54,7 @@ def test_cornell_bench_pass_equals_split_passes(hk):
     split, c_split = _frame(hk, s, film, cam, 8, 256, per_pass=64)
     assert c_one == c_split, (c_one, c_split)
     assert np.array_equal(one, split), float(np.abs(one - split).max())
-    for opt in (dict(HK_OVERLAP=0, HK_TICKET_SHARE=0), dict(HK_OVERLAP=1)):
+    for opt in (dict(HK_OVERLAP=0, HK_TICKET_SHARE=0), dict(HK_OVERLAP=1), dict(HK_LEAN_RECORDS=0, HK_SHADOW_FINAL=0)):      # (the last: the record layouts of rounds 3-5)
         again, c_again = _frame(hk, s, film, cam, 8, 256, options=opt)
         assert c_again == c_one, (opt, c_one, c_again)
         assert np.array_equal(one, again), (opt, float(np.abs(one - again).max()))

@@ -813,7 +813,7 @@ def test_scheduling_is_result_neutral(hk, knobs, which):
         s, film, cam = scenes.slab_scene(w, h, hk.HomogeneousMedium(sigma_a=hk.RGBSpectrum(0.2), sigma_s=hk.RGBSpectrum(0.8, 0.7, 0.6), g=0.3))
         kw = dict(max_depth=6, samples=64)
     names = ("HK_OVERLAP", "HK_DYNAMIC_SEGMENTS", "HK_WAVES_PER_CU", "HK_NODE_CACHE", "HK_WALK_SPLIT", "HK_GREY", "HK_DELTA_ADVANCE", "HK_TRACK_ADVANCE",
-             "HK_SHADOW_TRACK_BATCH", "HK_SHADOW_FEED_ROUNDS", "HK_TRACK_REFILL_IDLE", "HK_WALK_REFILL_IDLE", "HK_GREY_FLAT", "HK_TRACK_POOL", "HK_WALK_POOL", "HK_SMALL_PASS", "HK_SMALL_PASS_WAVES", "HK_TICKET_SHARE", "HK_GREY_COMPACT", "HK_SMALL_PASS_FUSED", "HK_SHADOW_FINAL", "HK_ESCAPED_UNROLL")
+             "HK_SHADOW_TRACK_BATCH", "HK_SHADOW_FEED_ROUNDS", "HK_TRACK_REFILL_IDLE", "HK_WALK_REFILL_IDLE", "HK_GREY_FLAT", "HK_TRACK_POOL", "HK_WALK_POOL", "HK_SMALL_PASS", "HK_SMALL_PASS_WAVES", "HK_TICKET_SHARE", "HK_GREY_COMPACT", "HK_SMALL_PASS_FUSED", "HK_SHADOW_FINAL", "HK_ESCAPED_UNROLL", "HK_LEAN_RECORDS")
 
     def run(env):
         for k in names:
@@ -836,6 +836,7 @@ def test_scheduling_is_result_neutral(hk, knobs, which):
                 {"HK_SMALL_PASS_FUSED": "0"}, {"HK_SMALL_PASS_FUSED": "0", "HK_SMALL_PASS_WAVES": "8"},      # (the Cornell film's default is k_small_pass: the whole pass in one launch)
                 {"HK_SHADOW_FINAL": "0"}, {"HK_SHADOW_FINAL": "0", "HK_SMALL_PASS_FUSED": "0", "HK_DYNAMIC_SEGMENTS": "1"},      # (round 6: the 60-byte shadow records — weights and path slot stored, the division in k_shadow — against the slim ones)
                 {"HK_ESCAPED_UNROLL": "2"}, {"HK_ESCAPED_UNROLL": "2", "HK_SMALL_PASS_FUSED": "0"},      # (two escaped paths per lane and iteration)
+                {"HK_LEAN_RECORDS": "0"}, {"HK_LEAN_RECORDS": "0", "HK_SMALL_PASS_FUSED": "0", "HK_DYNAMIC_SEGMENTS": "1"}, {"HK_LEAN_RECORDS": "0", "HK_SHADOW_FINAL": "0"},      # (round 6: 8-byte meta words and stored depth-0 origins against the lean records)
                 {"HK_DYNAMIC_SEGMENTS": "1", "HK_TICKET_SHARE": "1"}, {"HK_DYNAMIC_SEGMENTS": "1", "HK_TICKET_SHARE": "0", "HK_WAVES_PER_CU": "3"}):     # (small passes: one segment per wave, no work lists / tickets — the default of a film this size)
         got = run(env)
         assert np.array_equal(ref.view(np.uint32), got.view(np.uint32)), env

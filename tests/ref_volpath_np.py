@@ -146,8 +146,11 @@ def cross(a, b):
 
 
 def normalize(v):
+    """StaticArrays' normalize — `inv(norm(a)) * a` (the reciprocal once, then three products), which is what Vec3f / Point3f dispatch to; round 6:
+    this file divided by the norm until the hashed decisions (Mix, the layered walks) showed the last-bit difference on a tenth of the camera rays"""
     with np.errstate(invalid="ignore", divide="ignore"):
-        return v / np.sqrt(dot(v, v))[..., None]
+        inv = (f32(1) / np.sqrt(dot(v, v))).astype(f32) if np.asarray(v).dtype == np.float32 else 1.0 / np.sqrt(dot(v, v))
+        return v * inv[..., None]
 
 
 def average(s):
@@ -536,7 +539,11 @@ class SceneNP:
         self.mi = np.array([desc.meta[i].medium_interface_idx for i in range(T)], np.int64)
         self.arealight = np.array([desc.meta[i].arealight_flat_idx_1based for i in range(T)], np.int64)
         mats = [desc.materials[i] for i in range(desc.n_materials)]
-        assert all(m.kind in (0, 1, 2, 3, 4, 5, 6, 7, 8) for m in mats), "Matte, Mirror, Glass, Conductor, CoatedDiffuse, ThinDielectric, DiffuseTransmission, CoatedDiffuseTransmission, CoatedConductor only"
+        assert all(m.kind in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9) for m in mats), "Matte, Mirror, Glass, Conductor, CoatedDiffuse, ThinDielectric, DiffuseTransmission, CoatedDiffuseTransmission, CoatedConductor, Mix only"
+        # MixMaterial (kind 9; mix-material.jl:116-238): resolved at the hit — before anything else looks at the material — by a HASH of the
+        # bits of the hit point, of wo and of the two children's keys against a constant amount (textured amounts: point-wise only, test_hash_pins.py)
+        self.mix = {i: dict(amount=f32(m.f[0].v), children=(int(m.i[0]), int(m.i[1])), key=tuple(int(k) for k in m.mix_key)) for i, m in enumerate(mats) if m.kind == 9}
+        assert all(mats[i].f[0].tex < 0 for i in self.mix), "a textured Mix amount"
         # parameters that may be TEXTURES (eval_tex, textures/texture-ref.jl:40-80, 222-243): Matte Kd and sigma, Mirror Kr, Glass Kr / Kt,
         # Conductor roughness — an image (bilinear at the hit's uv) or a VertexColorTexture (the face's three colours by the hit's barycentrics);
         # everything else must be constant
@@ -654,6 +661,27 @@ class SceneNP:
             return LN.Coated(refl, up(alb), has_medium, c["ax"], c["ay"], c["eta"], c["thickness"], c["g"], c["max_depth"], c["n_samples"],
                              bottom=LN.DiffuseTransmissionBottom(refl, trans, max(rr), max(tt)))
         return LN.Coated(up(c["refl"]), up(alb), has_medium, c["ax"], c["ay"], c["eta"], c["thickness"], c["g"], c["max_depth"], c["n_samples"])
+
+    def resolve_mix(self, mat, p, wo):
+        """resolve_mix_material (mix-material.jl:222-238) for the hits (mat [N], p [N, 3], wo [N, 3]) -> material indices without Mix: amount <= 0
+        -> the first child, >= 1 -> the second, else `amount < mix_hash_float(p, wo, keys) ? first : second`; nested mixes resolve on (<= 8 levels)"""
+        from test_hash_pins import mix_hash_float
+        out = np.array(mat, np.int64).copy()
+        for j in np.nonzero(self.kind[out] == 9)[0]:
+            cur = int(out[j])
+            for _ in range(8):
+                if self.kind[cur] != 9:
+                    break
+                m = self.mix[cur]
+                a = m["amount"]
+                if a <= 0:
+                    cur = m["children"][0]
+                elif a >= 1:
+                    cur = m["children"][1]
+                else:
+                    cur = m["children"][0] if a < mix_hash_float(p[j], wo[j], m["key"]) else m["children"][1]
+            out[j] = cur
+        return out
 
     def tex_bilinear(self, ti, uv):
         """_sample_texture_bilinear (textures/texture-ref.jl:151-186) of image ti at uv [N, 2] -> [N, channels]: the (1 - v, u) flip, pixel
@@ -1728,7 +1756,9 @@ def apply_point(m, p):
     z = m[2, 0] * p[..., 0] + m[2, 1] * p[..., 1] + m[2, 2] * p[..., 2] + m[2, 3]
     w = m[3, 0] * p[..., 0] + m[3, 1] * p[..., 1] + m[3, 2] * p[..., 2] + m[3, 3]
     out = np.stack([x, y, z], -1)
-    return np.where((w == 1)[..., None], out, out / w[..., None]).astype(f32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        inv = (f32(1) / w).astype(f32)                     # (the homogeneous divide as one reciprocal and three products: Raycore's Transformation applied to a Point)
+    return np.where((w == 1)[..., None], out, out * inv[..., None]).astype(f32)
 
 
 def apply_vector(m, v):
@@ -2070,6 +2100,8 @@ def render(desc, cam_rec, tables_dict, width, height, n_samples, max_depth, max_
                 fin = np.where(is_black(Le)[:, None], f32(0), fin).astype(f32)
                 L[A[E]] += fin
             mat = sc.mat_of_mi[sc.mi[prim]]
+            if sc.mix:
+                mat = sc.resolve_mix(mat, pi, wo)                     # (K3's flush resolves a MixMaterial from the hit point and wo: intersection.jl:235-250)
             kind = sc.kind[mat]
             kd_p, kt_p, f0 = sc.hit_params(mat, prim, bw, bu, bv)
             kd = eval_poly(kd_p, lm)                                 # Kd of a matte surface, Kr of a mirror / glass — constants or textures at the hit

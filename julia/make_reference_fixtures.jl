@@ -20,7 +20,7 @@
 #   uplift    a22  uplift_rgb / uplift_rgb_unbounded / uplift_rgb_illuminant
 #   bsdf      a17 a18 a19  sample_bsdf_spectral / evaluate_bsdf_spectral of nine material kinds (+ Matte sigma, smooth conductor, measured gold)
 #   lightbvh  a25 a26  BVHLightSampler + bvh_sample_light / bvh_pmf + the node array
-#   light     a24  sample_light_spectral per light kind
+#   light     a24  sample_light_spectral per light kind (envlight: an EnvironmentLight over a 16 x 16 map, with its Distribution2D's cdfs)
 #   nanovdb   a28 a29  build_nanovdb_from_dense + nanovdb_get_value + sample_point (trilinear) + the majorant grid
 #   frame     a2   the 64 x 64 scene of test/volpath_integration.jl through Hikari.VolPath (surfaces only: per pixel; with fog: means)
 using Hikari
@@ -231,6 +231,25 @@ function stage_lights()
     put!("light_sample", ls); put!("light_index", which)
 end
 
+# ---- EnvironmentLight: Distribution2D sampling, equal-area mapping, nearest-texel radiance (environment_map.jl, sampling.jl:179-361) ------------
+function stage_envlight()
+    e = IN["env_rgb"]                                        # NumPy [v, u, rgb] -> Julia (3, u, v)
+    h, w = size(e, 3), size(e, 2)
+    data = [R(e[1, u, v], e[2, u, v], e[3, u, v]) for v in 1:h, u in 1:w]      # data[v, u]
+    env = Hikari.EnvironmentMap(data)                                                                      # ref: Hikari.EnvironmentMap textures/environment_map.jl:9
+    light = Hikari.EnvironmentLight(env, R(0.8, 1.0, 1.2))                                                 # ref: Hikari.EnvironmentLight lights/environment.jl:5
+    p, lam, u2 = IN["light_p"], IN["light_lambda"], IN["light_u2"]
+    out = Matrix{Float32}(undef, 12, N)                      # wi3, pdf, Li4, p_light3, is_delta
+    for i in 1:N
+        s = Hikari.sample_light_spectral(TABLE, (), light, p3(p, i), wl(lam, i), p2(u2, i))                # ref: Hikari.sample_light_spectral physical-wavefront/lights.jl:158
+        out[:, i] .= (s.wi..., s.pdf, spec4(s.Li)..., s.p_light..., s.is_delta ? 1f0 : 0f0)
+    end
+    put!("envlight_sample", out)
+    D = env.distribution
+    put!("envlight_marginal_cdf", Vector{Float32}(Array(D.marginal_cdf)))
+    put!("envlight_conditional_cdf", Vector{Float32}(vec(Array(D.conditional_cdf))))
+end
+
 # ---- NanoVDB -------------------------------------------------------------------------------------------------------------
 function stage_nanovdb()
     d = permutedims(IN["nvdb_density"], (3, 2, 1))           # the input is [nx, ny, nz] in NumPy order
@@ -292,7 +311,7 @@ function stage_frame()
 end
 
 # ---- run -------------------------------------------------------------------------------------------------------------------------
-stages = isempty(ARGS) ? ["sobol", "camera", "uplift", "bsdf", "lights", "nanovdb", "frame"] : ARGS
+stages = isempty(ARGS) ? ["sobol", "camera", "uplift", "bsdf", "lights", "envlight", "nanovdb", "frame"] : ARGS
 for s in stages
     @info "reference fixtures: $s"
     getfield(@__MODULE__, Symbol("stage_" * s))()

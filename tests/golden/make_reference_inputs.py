@@ -65,6 +65,11 @@ def inputs():
     # world points in and around the medium's bounds ((-0.5, 0, -0.3) .. (0.5, 0.6, 0.2)): sample_point's trilinear lookup (nanovdb.jl:400-483)
     lo, hi = np.array([-0.5, 0.0, -0.3]), np.array([0.5, 0.6, 0.2])
     a["nvdb_p"] = (lo - 0.1 * (hi - lo) + 1.2 * (hi - lo) * rng.random((N, 3))).astype(f32)
+    # a 16 x 16 equal-area environment map [v, u, rgb]: smooth sky, dark ground, one hot texel (the Distribution2D's binary searches see a spike)
+    env = (0.2 + 0.8 * rng.random((16, 16, 3))).astype(f32)
+    env[8:, :, :] *= f32(0.1)
+    env[3, 11, :] = (40.0, 36.0, 30.0)
+    a["env_rgb"] = env
     return a
 
 

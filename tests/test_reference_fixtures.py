@@ -254,6 +254,28 @@ def compute(side, IN, stages=None):
                    lightbvh_nodes=np.ascontiguousarray(nodes, f32), lightbvh_bit_trails=np.ascontiguousarray(trails, np.uint32),
                    lightbvh_counts=np.array([int(s.desc.n_lights) - 3, 3, int(s.desc.n_lights)], np.int32))     # (infinite: ambient, directional, sun)
 
+    if want("envlight"):
+        from hikari_jl_amd import geometry as G
+        env = hk.EnvironmentMap(np.ascontiguousarray(IN["env_rgb"]))
+        s = hk.Scene()
+        s.push(hk.EnvironmentLight(env, hk.RGBSpectrum(0.8, 1.0, 1.2)))
+        s.push(G.rect3f((-1, 0, -1), (2, 0.01, 2)), hk.MatteMaterial(Kd=hk.RGBSpectrum(0.73, 0.73, 0.73)))
+        s.sync()
+        p, lam, u2 = (np.ascontiguousarray(IN[k]) for k in ("light_p", "light_lambda", "light_u2"))
+        x = np.zeros((len(p), 3), f32)
+        x[:, :2] = u2
+        if dev:
+            o = np.zeros((len(p), 12), f32)
+            hk._lib.check(L.hk_test_light(ctx.h, hk.scene_handle(ctx, s), 0, 1, len(p), pf(p), pf(x), pf(lam), pf(o)), "hk_test_light")
+        else:
+            osc = O.OracleScene(s)
+            o = osc.light(0, 1, p, x, lam)
+            osc.close()
+        out["envlight_sample"] = o
+        D = env.distribution                                   # (the host-side builder, hikari.jl_amd/envmap.py restating sampler/sampling.jl:179-262 — the same on both sides)
+        out["envlight_marginal_cdf"] = np.ascontiguousarray(D.marginal_cdf, f32).reshape(-1)
+        out["envlight_conditional_cdf"] = np.ascontiguousarray(D.conditional_cdf, f32).reshape(-1)
+
     if want("nanovdb"):
         s, med = reference_nanovdb_scene(hk, np.ascontiguousarray(IN["nvdb_density"]))
         pw, lam = np.ascontiguousarray(IN["nvdb_p"]), np.ascontiguousarray(IN["light_lambda"])
@@ -361,6 +383,14 @@ def compare(got, ref):
             bad.append(("light_sample", "accept / reject decisions differ"))
         elif not np.allclose(g, r, rtol=2e-5, atol=1e-6):
             bad.append(("light_sample", "max rel %.3g" % float(np.max(np.abs(g - r) / (np.abs(r) + 1e-6)))))
+    for name in ("envlight_marginal_cdf", "envlight_conditional_cdf"):
+        if need(name) and ulp_diff(got[name], ref[name]).max() > 2:
+            bad.append((name, "%d ulp" % ulp_diff(got[name], ref[name]).max()))
+    if need("envlight_sample"):
+        g, r = got["envlight_sample"], ref["envlight_sample"]
+        same = np.isclose(g, r, rtol=2e-5, atol=1e-6).all(axis=1).mean()
+        if same < 0.999:      # (a sample within an ulp of a cdf entry may land in the neighbouring texel)
+            bad.append(("envlight_sample", "%.5f of the rows agree" % same))
     if need("nvdb_sample_point") and not np.array_equal(got["nvdb_sample_point"], ref["nvdb_sample_point"]):
         bad.append(("nvdb_sample_point", "max abs %.3g" % float(np.abs(got["nvdb_sample_point"] - ref["nvdb_sample_point"]).max())))
     name = "frame_surfaces_64_spp4_depth5"
@@ -438,7 +468,7 @@ def test_julia_generator_static():
     assert len(re.findall(r"^    Hikari\.\w+Material\(|^    Hikari\.Gold\(", src, re.M)) == N_MATERIALS
     for f in FILTER_NAMES:
         assert '("%s", Hikari.' % f in src
-    consumed = set(re.findall(r'"((?:sobol|nvdb|lightbvh|light|uplift|frame)_\w+)"', open(os.path.abspath(__file__)).read()))
+    consumed = set(re.findall(r'"((?:sobol|nvdb|lightbvh|light|envlight|uplift|frame)_\w+)"', open(os.path.abspath(__file__)).read()))
     consumed |= {n for n in written if n.startswith(("bsdf_", "camera_"))}
     assert written <= consumed, written - consumed
     for s in re.search(r'stages = isempty\(ARGS\) \? \[([^\]]+)\]', src).group(1).replace('"', "").split(","):
@@ -449,7 +479,7 @@ def test_julia_generator_static():
     cited = {r[0] for r in refs}
     stage_fns = {"zsobol_sample_1d", "zsobol_sample_2d", "compute_pixel_sample", "filter_sample", "sample_wavelengths_visible", "generate_ray", "uplift_rgb",
                  "uplift_rgb_unbounded", "uplift_rgb_illuminant", "sample_bsdf_spectral", "evaluate_bsdf_spectral", "bvh_sample_light", "bvh_pmf",
-                 "sample_light_spectral", "nanovdb_get_value", "sample_point", "BVHLightSampler", "NanoVDBMedium", "VolPath"}
+                 "sample_light_spectral", "nanovdb_get_value", "sample_point", "BVHLightSampler", "NanoVDBMedium", "VolPath", "EnvironmentMap", "EnvironmentLight"}
     assert stage_fns <= called and stage_fns <= cited, (stage_fns - called, stage_fns - cited)
     if not os.path.isdir(REFERENCE_TREE):
         pytest.skip("the reference tree is not on this box: citations were checked where it is")
@@ -466,10 +496,10 @@ def test_pipeline_runs_end_to_end_on_a_stand_in(tmp_path):
     import oracle as O
     O.build()
     stand_in = str(tmp_path / "stand_in")
-    stages = ["sobol", "camera", "uplift", "bsdf", "lights", "nanovdb", "frame"]
+    stages = ["sobol", "camera", "uplift", "bsdf", "lights", "envlight", "nanovdb", "frame"]
     ref = run_side("oracle", stand_in, stand_in, stages)
     assert {"sobol_1d", "camera_gaussian", "uplift_bounded", "bsdf_sample_7_reg1", "bsdf_eval_13", "lightbvh_choice", "light_sample", "nvdb_values",
-            "nvdb_sample_point", "nvdb_buffer"} <= set(ref)
+            "nvdb_sample_point", "nvdb_buffer", "envlight_sample", "envlight_conditional_cdf"} <= set(ref)
     assert int(ref["lightbvh_counts"][2]) == 5 + 24 * 12 and (ref["lightbvh_pmf"] > 0).mean() > 0.9 and (ref["nvdb_values"] > 0).mean() > 0.1
     got = run_side("oracle", stand_in, str(tmp_path / "again"), stages)
     assert compare(got, ref) == []

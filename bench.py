@@ -177,11 +177,12 @@ def build_workload(config, scenes):
     return scene, film, cam, W, H, depth, spp, workload
 
 
-VALU_CYCLES = 2.0              # data sheet: a wave64 VALU instruction holds a SIMD's issue port for 2 cycles.  ONE rule for every kernel: the
-                               # issue-bound classes report valu_issue (instructions x 2 cycles over the SIMD-cycles of the launch), lane_util (active lanes per
-                               # issued instruction) and their product — the share of the chip's lane-slots that did useful work — as `frac`.  Rounds 2-5 priced
-                               # these kernels at a per-kernel 4.2 / 2.6 cycles per instruction (tools/valu_rate.hip: what this mix costs on a busy SIMD): a ceiling
-                               # chosen so that the fraction stayed below 1 — gone.
+VALU_CYCLES = 2.0              # data sheet: a wave64 VALU instruction holds a SIMD's issue port for at least 2 cycles -> `valu_issue` (instructions x 2 cycles over the
+                               # SIMD-cycles of the launch), a LOWER bound of the pipe's occupancy.  What the hardware itself counts is `valu_busy` = rocprof's VALUBusy
+                               # (SQ_ACTIVE_INST_VALU x 4 / SIMDs / GRBM_GUI_ACTIVE: the share of the SIMD cycles in which the vector ALU was executing; ~4.1 cycles per
+                               # instruction in every kernel here, what tools/valu_rate.hip measures for this opcode mix).  ONE rule for every kernel:
+                               # the issue-bound classes report valu_busy (measured), lane_util (active lanes per issued instruction) and their product — the share of
+                               # the chip's VALU lane-slots that did useful work — as `frac`; valu_issue (the 2-cycle rule) stays beside it.  No per-kernel constant.
 N_SIMD = 1024                  # 256 CUs x 4 SIMDs
 KERNEL_OF_CLASS = {"trace": "k_trace", "shadow": "k_shadow", "shade": "k_shade", "media": "k_track+k_scatter", "select": "k_light_select"}
 CLASSES = ("trace", "shadow", "shade", "media", "select")
@@ -232,11 +233,14 @@ def class_rooflines(config, timed, launches, sc, default_frame):
         e = {"kernel": kernel}
         # instruction issue, re-priced on this run's launch time: the committed pass gives the wave-level VALU instruction count per launch
         # (a property of the workload), the clock (its own cycles / its own duration) and the lane utilisation
-        issue = None
+        issue = busy = None
         if u.get("valu_inst_per_launch") and u.get("valu_issue_frac") and u.get("avg_launch_us"):
             clock_hz = u["valu_inst_per_launch"] * VALU_CYCLES / (u["valu_issue_frac"] * N_SIMD) / (u["avg_launch_us"] * 1e-6)
             issue = u["valu_inst_per_launch"] * VALU_CYCLES / (avg_s * clock_hz * N_SIMD)
-        useful = issue * u["lane_util"] if (issue is not None and u.get("lane_util")) else None
+        if u.get("valu_busy") and u.get("avg_launch_us"):
+            busy = min(u["valu_busy"] * (u["avg_launch_us"] * 1e-6) / avg_s, 1.0)     # the same busy cycles per launch over THIS run's launch time
+        useful = (busy if busy is not None else issue)
+        useful = useful * u["lane_util"] if (useful is not None and u.get("lane_util")) else None
         # the light selection walks a tree whose nodes come from LDS / L2 like the traversal kernels' (the 60 B per node of SURVEY 8d are an
         # upper bound of its HBM need): priced against instruction issue, as they are
         traversal = cls == "select" or (cls in ("trace", "shadow") and not (cls == "shadow" and walk))
@@ -246,13 +250,14 @@ def class_rooflines(config, timed, launches, sc, default_frame):
                       "algorithmic_bytes_per_launch": int(alg[cls] / n_launch), "algorithmic_gbs": round(bytes_rate, 2)})
         elif traversal:
             e.update({"bound": "valu_issue", "achieved": round(useful, 4), "peak": 1.0, "unit": "share of the chip's VALU lane-slots doing useful work", "frac": round(useful, 4),
-                      "valu_issue_in_run": round(issue, 4), "cycles_per_valu_instruction": VALU_CYCLES, "valu_instructions_per_launch": u["valu_inst_per_launch"],
+                      "valu_busy_in_run": round(busy, 4) if busy is not None else None, "valu_issue_in_run": round(issue, 4) if issue is not None else None,
+                      "valu_instructions_per_launch": u["valu_inst_per_launch"],
                       "algorithmic_bytes_per_launch": int(alg[cls] / n_launch), "algorithmic_gbs": round(bytes_rate, 2)})
         else:
             e.update({"bound": "hbm", "achieved": round(bytes_rate, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(bytes_rate / HBM_PEAK_GBS, 5),
                       "algorithmic_bytes_per_launch": int(alg[cls] / n_launch)})
             if useful is not None:
-                e["useful_lane_issue"] = round(useful, 4)
+                e["useful_lane_issue"] = round(useful, 4)     # valu_busy (in run) x lane_util
         e.update({"avg_launch_ms": round(avg_s * 1e3, 4), "launches": n_launch, "seconds": round(timed[cls], 4)})
         if all("hbm_bytes_per_launch" in t for t in tr):
             # the PMC launches average over the same depths as the bench's (whole passes): traffic per launch is comparable
@@ -263,18 +268,23 @@ def class_rooflines(config, timed, launches, sc, default_frame):
             e["traffic"] = None
         if "l2_hit_rate" in tr[0]:
             e["l2_hit_rate"] = tr[0]["l2_hit_rate"]
-        for k in ("valu_issue_frac", "lane_util", "wait_frac"):
+        for k in ("valu_busy", "valu_issue_frac", "lane_util", "wait_frac", "waves_per_simd"):
             if k in u:
                 e[k] = u[k]
         if u.get("salu_per_launch") and u.get("valu_inst_per_launch"):
             e["salu_over_valu"] = round(u["salu_per_launch"] / u["valu_inst_per_launch"], 3)
         e["counters_from"] = [f for f in (pmc_file if e["traffic"] is not None else None, util_file if u else None) if f]
         e["measured_in_run"] = ["avg_launch_ms", "seconds", "launches", "algorithmic_bytes_per_launch"]
-        hb, vi = e.get("hbm_frac_by_traffic"), e.get("valu_issue_frac")
+        hb, vi, vb = e.get("hbm_frac_by_traffic"), e.get("valu_issue_frac"), e.get("valu_busy")
         if hb is None or vi is None:
             e["binding"] = "unprofiled on this workload"
-        elif hb >= 0.5:
-            e["binding"] = "HBM traffic (%.0f %% of the 8 TB/s peak, %.0f %% of the device-copy rate); VALU issue %.0f %% of the SIMD cycles" % (100 * hb, 100 * hb * HBM_PEAK_GBS / 5200.0, 100 * vi)
+        elif hb >= 0.5 and (vb is None or hb >= vb):
+            e["binding"] = "HBM traffic (%.0f %% of the 8 TB/s peak, %.0f %% of the device-copy rate); VALU pipes busy %.0f %% of the SIMD cycles" % (
+                100 * hb, 100 * hb * HBM_PEAK_GBS / 5200.0, 100 * (vb if vb is not None else vi))
+        elif vb is not None:
+            e["binding"] = ("the vector ALU: busy %.0f %% of the SIMD cycles (SQ_ACTIVE_INST_VALU; %.0f %% by the 2-cycles-per-instruction rule) with %.0f %% of the lanes active "
+                            "= %.0f %% useful lane-slots, at %.1f resident waves per SIMD; HBM traffic %.0f %% of peak" % (
+                                100 * vb, 100 * vi, 100 * e.get("lane_util", 0), 100 * vb * e.get("lane_util", 0), e.get("waves_per_simd", 0), 100 * hb))
         else:
             e["binding"] = "instruction issue and latency: VALU issue %.0f %% of the SIMD cycles (2 cycles per instruction) with %.0f %% of the lanes active = %.0f %% useful lane-slots; HBM traffic %.0f %% of peak" % (
                 100 * vi, 100 * e.get("lane_util", 0), 100 * vi * e.get("lane_util", 0), 100 * hb)
@@ -319,7 +329,7 @@ def compact_line(result, limit=LINE_LIMIT, detail_file="bench_detail.json"):
     r = result.get("roofline") or {}
     line["roofline"] = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
     line["roofline"].update(_pick(r, ("kernel", "avg_launch_ms", "launches", "algorithmic_bytes_per_launch", "hbm_frac_by_traffic",
-                                      "traffic_over_algorithmic", "traffic_frac_of_measured_copy", "lane_util", "measured_copy_gbs", "kernel_seconds")))
+                                      "traffic_over_algorithmic", "traffic_frac_of_measured_copy", "valu_busy", "lane_util", "measured_copy_gbs", "kernel_seconds")))
     cpu = result.get("cpu_baseline")
     line["cpu_baseline"] = None if cpu is None else dict(_pick(cpu, ("value", "unit", "cores", "kind", "seconds_per_frame_extrapolated")),
                                                            sample=_clip(cpu.get("sample", ""), 110))
@@ -334,7 +344,7 @@ def compact_line(result, limit=LINE_LIMIT, detail_file="bench_detail.json"):
             if "workload" in c:
                 e["workload"] = _clip(c["workload"], 120)
             if isinstance(c.get("roofline"), dict):
-                e["roofline"] = _pick(c["roofline"], ("kernel", "bound", "frac", "hbm_frac_by_traffic", "lane_util", "avg_launch_ms"))
+                e["roofline"] = _pick(c["roofline"], ("kernel", "bound", "frac", "hbm_frac_by_traffic", "valu_busy", "lane_util", "avg_launch_ms"))
             if isinstance(c.get("kernel_seconds"), dict):
                 e["kernel_seconds"] = c["kernel_seconds"]
             if isinstance(c.get("progressive"), dict):

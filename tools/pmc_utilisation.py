@@ -7,6 +7,12 @@ Per kernel family (k_trace*, k_shade*, k_shadow*, k_track*, k_scatter, k_camera,
     valu_issue_frac        SQ_INSTS_VALU * 2 cycles / (GRBM_GUI_ACTIVE * 1024 SIMDs): a wave64 VALU instruction occupies a SIMD-32 for 2
                            cycles (MI355X_MICROARCH.md); quarter-rate instructions (v_rcp / v_sqrt / v_exp, 32-bit integer
                            multiplies) are counted at the same 2 cycles, so this is a LOWER bound of the issue-port occupancy
+    valu_busy              SQ_ACTIVE_INST_VALU * 4 / (GRBM_GUI_ACTIVE * 1024 SIMDs): rocprof's own derived metric VALUBusy — the share of the SIMD
+                           cycles in which the vector ALU was executing (the SQ counts in units of 4 cycles; SQ_WAVE_CYCLES * 4 over the
+                           same denominator = resident waves per SIMD comes out at 3.8 for the kernels compiled for 4: the unit is right).
+                           The MEASURED pipe occupancy: ~4.1 cycles per issued wave64 instruction in every kernel here (tools/valu_rate.hip: 4.3 -
+                           4.5 for most opcodes, 2.3 - 2.9 for v_fma / v_mul / v_mov, 8.2 for the transcendentals)
+    waves_per_simd         SQ_WAVE_CYCLES * 4 / (GRBM_GUI_ACTIVE * 1024 SIMDs): resident waves per SIMD, averaged over the launch
     lane_util              SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU): active lanes per issued VALU instruction
     wait_frac              SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES: share of resident wave time spent waiting for any instruction's operands
     vmem_rd_per_launch     SQ_INSTS_VMEM_RD, lds_per_launch SQ_INSTS_LDS
@@ -75,6 +81,10 @@ def main(d, rnd, cfg):
             e["valu_inst_per_launch"] = int(iv / n)
         if iv is not None and gui:
             e["valu_issue_frac"] = round(iv * 2.0 / (gui / 8.0 * 1024.0), 4)     # GRBM_GUI_ACTIVE is reported once per XCD (8): /8 = kernel cycles
+        if ai is not None and gui:
+            e["valu_busy"] = round(ai * 4.0 / (gui / 8.0 * 1024.0), 4)
+        if wc and gui:
+            e["waves_per_simd"] = round(wc * 4.0 / (gui / 8.0 * 1024.0), 3)
         if tc is not None and ai:
             e["lane_util"] = round(tc / (64.0 * ai), 4)
         if wc and wi is not None:

@@ -3,7 +3,7 @@
 # (FETCH_SIZE / WRITE_SIZE / L2 hit-miss in SEPARATE passes, as /opt/skills/guides/MI355X_MICROARCH.md prescribes) and the SQ / TA
 # utilisation counters behind DESIGN.md's "what bounds the kernels".  Everything lands in gpurun_out/<round>/; the summaries
 # (text / json, no databases) are then copied into profiles/ by hand.
-#   tools/profile_round.sh r03 [quick|full] ["cornell sky cloud manylight"]     (third argument: only these configs)
+#   tools/profile_round.sh r03 [quick|full|bench] ["cornell sky cloud manylight"]     (third argument: only these configs; bench: the bench records only)
 R=${1:-r03}; MODE=$2; CFGS=${3:-cornell sky cloud manylight}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/$R; mkdir -p $O
@@ -14,6 +14,7 @@ if [ "$MODE" != "quick" ]; then
     timeout 900 python bench.py --config $c --detail-file $O/bench_${R}_${c}_detail.json > $O/bench_${R}_$c.json 2> $O/bench_$c.err
   done
 fi
+if [ "$MODE" = "bench" ]; then exit 0; fi
 # the profiled runs keep every kernel on one stream (HK_OVERLAP=0): a kernel trace of overlapping kernels charges each of them the
 # time it shared, and the per-kernel averages would no longer be comparable with the bench line's serial HIP-event replay
 export HK_OVERLAP=0

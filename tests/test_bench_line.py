@@ -88,3 +88,36 @@ def test_compact_line_carries_the_frame_check():
     assert len(json.dumps(line)) <= 3500
     assert line["frame_check"]["ok"] is True and line["frame_check"]["mean_ratio"] == 0.99976 and "tolerance" not in line["frame_check"]
     assert line["configs"][1]["frame_ok"] is False and "frame_ok" not in line["configs"][0]
+
+
+def test_frame_check_verdict_rules():
+    """The rule that ends a bench run with exit code 4: surfaces are held to SURVEY 8(d)'s frame tolerance on the same sample indices, media
+    scenes (paths decorrelate at the first ulp) to the means and to most pixels agreeing sample for sample.  The measured records of round 6
+    pass, planted failures do not."""
+    v = _bench().frame_check_verdict
+    cornell = {"finite": True, "mean_ratio": 0.99979, "same_samples_mean_ratio": 1.0, "same_samples_rel_mse": 1.15e-09, "same_samples_frac_pixels_within_1e-2": 1.0}
+    cloud = {"finite": True, "mean_ratio": 0.99989, "same_samples_mean_ratio": 1.00001, "same_samples_rel_mse": 0.203, "same_samples_frac_pixels_within_1e-2": 0.93634}
+    assert v(cornell, False) and v(cloud, True)
+    assert not v(cloud, False)                                               # a surface scene with the cloud's scatter would be a bug
+    assert not v(dict(cornell, finite=False), False)
+    assert not v(dict(cornell, mean_ratio=1.03), False) and not v(dict(cloud, mean_ratio=0.97), True)
+    assert not v(dict(cornell, same_samples_rel_mse=2e-3), False)
+    assert not v(dict(cornell, **{"same_samples_frac_pixels_within_1e-2": 0.98}), False)
+    assert not v(dict(cloud, **{"same_samples_frac_pixels_within_1e-2": 0.627}), True)     # what the build without correctly rounded division measured
+    assert not v(dict(cloud, same_samples_mean_ratio=1.05), True)
+    assert not v({}, False) and not v({}, True)
+
+
+def test_utilisation_digests_carry_the_measured_valu_occupancy():
+    """profiles/utilisation_<config>.json (tools/pmc_utilisation.py): every kernel family of every bench config carries rocprof's VALUBusy
+    (`valu_busy`), never above 1, never below the 2-cycles-per-instruction lower bound (`valu_issue_frac`), and the resident waves per SIMD
+    that pin the counters' unit (<= 8)."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for cfg in ("cornell", "sky", "cloud", "manylight", "cornell_sphere_box"):
+        d = json.load(open(os.path.join(root, "profiles", "utilisation_%s.json" % cfg)))
+        fams = {k: e for k, e in d.items() if isinstance(e, dict)}
+        assert fams, cfg
+        for k, e in fams.items():
+            assert 0.0 < e["valu_issue_frac"] <= e["valu_busy"] <= 1.0, (cfg, k, e)
+            assert 0.0 < e["lane_util"] <= 1.0 and 0.5 < e["waves_per_simd"] <= 8.0, (cfg, k, e)

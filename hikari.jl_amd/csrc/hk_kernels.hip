@@ -729,6 +729,12 @@ __global__ void __launch_bounds__(HK_TRACE_BLOCK) k_trace(DPathState st, DScene 
 #ifndef HK_TRACE_MIN_IDLE
 #define HK_TRACE_MIN_IDLE 24
 #endif
+// the closest-hit KERNEL of scenes whose tree sits in the 16-wave block's LDS cache (Cornell, sky: BVHs <= 16 deep) refills at 32 idle lanes —
+// round 6, A B | B A on one box: k_trace_lean 34.45 -> 33.6 ms per Cornell frame (40: 34.15, 48: 35.4), sky 19.95 -> 19.65; the deep-tree
+// instantiation of the 10^6-triangle scene keeps 24 (32: +1.2 %, 40: +2.6 %), and so do the any-hit kernel (32: +-0) and the small pass
+#ifndef HK_CLOSEST_MIN_IDLE_LDS
+#define HK_CLOSEST_MIN_IDLE_LDS 32
+#endif
 // leaf phases wait until this many lanes hold a leaf (0: never wait), as long as the kernel can still refill its idle lanes
 #ifndef HK_ANYHIT_LEAF_MIN
 #define HK_ANYHIT_LEAF_MIN 16
@@ -927,7 +933,7 @@ enum { LR_EMPTY = 0, LR_ACTIVE = 1 };
 
 // STACK: LDS stack entries per lane.  The stack holds at most one entry per inner level, so a BVH of depth <= 16 (every scene
 // but the 10^6-triangle one) runs with half the LDS: 16 KB per block instead of 32, and LDS stops limiting residency.
-template <bool COUNT, int NC, bool QN = false>
+template <bool COUNT, int NC, bool QN = false, int MIN_IDLE = HK_TRACE_MIN_IDLE>
 __device__ __forceinline__ void trace_lean_body(const DPathState& st, const DScene& sc, int depth, DStats* stats, const SegTickets& src, int* __restrict__ stack, const NodeCache& cache) {
     const int lane = lane_id();
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -949,7 +955,7 @@ __device__ __forceinline__ void trace_lean_body(const DPathState& st, const DSce
     r.cur = r.pend = DONE;
     for (;;) {
         const unsigned long long run_m = __ballot(state == LR_ACTIVE && r.cur != DONE);
-        if (run_m == 0ull || (64 - __popcll(run_m) >= HK_TRACE_MIN_IDLE && cursor < n)) {
+        if (run_m == 0ull || (64 - __popcll(run_m) >= MIN_IDLE && cursor < n)) {
             // ---- flush: classify the finished rays, push them to the escaped / material-kind queues ----
             HK_DBG(8, state == LR_ACTIVE && r.cur == DONE);   // flushes: lanes that deliver a finished ray
             int kind = -1;
@@ -1032,7 +1038,7 @@ __global__ void __launch_bounds__(BLOCK) k_trace_lean(DPathState st, DScene sc, 
     __shared__ int2 lds_child[NC > 0 ? NC : 1];
     int* stack = lds_stack + (threadIdx.x >> 6) * (STACK * 64);
     const NodeCache cache = node_cache_fill<NC, BLOCK, QN>(sc, lds_box, lds_child);
-    trace_lean_body<COUNT, NC, QN>(st, sc, depth, stats, seg_open(st, ticket_ptr(st, depth, TK_TRACE), st.dynamic_segments != 0, depth, Q_RAY), stack, cache);
+    trace_lean_body<COUNT, NC, QN, (NC >= 1024 ? HK_CLOSEST_MIN_IDLE_LDS : HK_TRACE_MIN_IDLE)>(st, sc, depth, stats, seg_open(st, ticket_ptr(st, depth, TK_TRACE), st.dynamic_segments != 0, depth, Q_RAY), stack, cache);
 }
 
 // ---------------------------------------------------------------------------------------------------

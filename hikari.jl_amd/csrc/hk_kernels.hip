@@ -5037,9 +5037,11 @@ void launch_trace(hipStream_t s, int n_cu, const DPathState& st, const DScene& s
 // Measured (HK_NODE_CACHE=0 switches it off): trace -11 % in the Cornell box and the sky scene; with the 32-entry stacks of the
 // 10^6-triangle scene 512 nodes are a small part of the visits (+-1 %: no cache there).
 // The any-hit kernel lives on residency (7 waves per SIMD on 16 KB of stacks; the big cache cost it three of them: +3 %), so it
-// gets the cache that FITS beside them: HK_SHADOW_NC16 nodes per 4-wave block.
+// gets the cache that FITS beside them: HK_SHADOW_NC16 nodes per 4-wave block.  176 nodes = 26 KB per block, six blocks per CU (round 6, two-spheres
+// Cornell box, A B | B A three times: k_shadow 17.55 -> 17.0 ms per frame against the 112 nodes / seven blocks of rounds 3-5; 64: 17.7, 192 — a
+// fifth block lost —: 18.5, 240: 18.3, 320: 20.3; sky +-0)
 #ifndef HK_SHADOW_NC16
-#define HK_SHADOW_NC16 112
+#define HK_SHADOW_NC16 176
 #endif
 #ifndef HK_SHADOW_NC32
 #define HK_SHADOW_NC32 0

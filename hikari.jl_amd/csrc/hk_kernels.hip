@@ -5037,11 +5037,17 @@ void launch_trace(hipStream_t s, int n_cu, const DPathState& st, const DScene& s
 // Measured (HK_NODE_CACHE=0 switches it off): trace -11 % in the Cornell box and the sky scene; with the 32-entry stacks of the
 // 10^6-triangle scene 512 nodes are a small part of the visits (+-1 %: no cache there).
 // The any-hit kernel lives on residency (7 waves per SIMD on 16 KB of stacks; the big cache cost it three of them: +3 %), so it
-// gets the cache that FITS beside them: HK_SHADOW_NC16 nodes per 4-wave block.  176 nodes = 26 KB per block, six blocks per CU (round 6, two-spheres
-// Cornell box, A B | B A three times: k_shadow 17.55 -> 17.0 ms per frame against the 112 nodes / seven blocks of rounds 3-5; 64: 17.7, 192 — a
-// fifth block lost —: 18.5, 240: 18.3, 320: 20.3; sky +-0)
+// gets the cache that FITS beside them.  Round 6 (two-spheres Cornell box, A B | B A): what counts is nodes per WAVE-SLOT — a cache is shared by the
+// waves of its block, so bigger blocks buy more of the tree for the same LDS.  12-wave blocks with the top 560 nodes (48 KB of stacks + 31 KB of
+// nodes, two blocks per CU = 6 waves per SIMD): k_shadow 17.55 -> 16.4 ms per Cornell frame, sky 2.6 -> 2.5.  On the way: 4-wave blocks with
+// 112 nodes (rounds 3-5, seven blocks per CU) 17.55, 176 nodes (six blocks) 17.0, 192 / 240 / 320 nodes (five, five, four blocks) 18.5 / 18.3 /
+// 20.3; 8-wave blocks with 384 nodes 20.2 and 14-wave blocks with 432 nodes 22.5 (one block short of the plan each); 16-wave blocks with the
+// whole tree (four waves per SIMD) 17.0.
 #ifndef HK_SHADOW_NC16
-#define HK_SHADOW_NC16 176
+#define HK_SHADOW_NC16 560
+#endif
+#ifndef HK_SHADOW_BLOCK16   // threads per block of the any-hit kernel over trees <= 16 deep
+#define HK_SHADOW_BLOCK16 768
 #endif
 #ifndef HK_SHADOW_NC32
 #define HK_SHADOW_NC32 0
@@ -5130,7 +5136,7 @@ bool grey_compact_ok(const DScene& sc) {
 }
 void launch_shadow(hipStream_t s, int n_cu, const DPathState& st, const DScene& sc, const DTables& T, const DFrame& fr, int depth, DStats* stats) {
     if (sc.all_opaque && sc.n_media == 0) {
-        HK_LEAN_DISPATCH(k_shadow, HK_TRACE_BLOCK, HK_SHADOW_NC16, HK_SHADOW_NC32)
+        HK_LEAN_DISPATCH(k_shadow, HK_SHADOW_BLOCK16, HK_SHADOW_NC16, HK_SHADOW_NC32)
         return;
     }
     if (sc.all_grey && grey_mode() && walk_split_mode() && sc.bvh_depth <= 16 && st.wq_a != nullptr) {

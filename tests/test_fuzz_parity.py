@@ -68,9 +68,11 @@ def test_fuzz_strict(hk, oracle, klass, seed, size):
         ok = (num / den) <= 1e-2
         assert float(np.mean(((g - ref) ** 2 / (ref ** 2 + 1e-3))[ok])) <= 1e-3, (desc, rel_mse, bad)
     assert abs(int(st.rays_closest) - int(ost.rays_closest)) <= 0.005 * ost.rays_closest + 8, (desc, st.rays_closest, ost.rays_closest)
-    if "medium:" not in desc:
+    if "medium:" not in desc and " alpha " not in " %s " % desc:
         assert abs(int(st.rays_shadow) - int(ost.rays_shadow)) <= 0.005 * ost.rays_shadow + 8, (desc, st.rays_shadow, ost.rays_shadow)
-    else:       # a shadow ray through media counts one cast per segment; the device stops at the first opaque one (it can only save casts)
+    else:       # a shadow ray through media or alpha-tested surfaces counts one cast per segment; the device's walk ends at the first OPAQUE triangle of
+                # a segment, the reference's closest hit may first find a passable surface in front of it: the device can only save casts (round 6, seed
+                # 22035 of tools/gpu_fuzz_more.sh: 5 184 against 5 237 shadow casts on a frame that agrees to relMSE 5e-13)
         assert 0.7 * ost.rays_shadow - 8 <= int(st.rays_shadow) <= 1.005 * ost.rays_shadow + 8, (desc, st.rays_shadow, ost.rays_shadow)
 
 
